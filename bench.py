@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py — offline-render throughput of the MI355X hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--workload welsh-1m]
+
+A "step" is one pass of the hot path over one 256-frame block of the whole project: every
+Welsh voice ticks 256 frames (welsh_render_kernel) and the mix bus sums the voice blocks
+(Orchestrator::gather_audio).  `value` = stereo bus frames rendered per second, whole job,
+with all inputs (patch parameters, voice state) resident in HBM before the timed region.
+
+Workloads:
+    welsh-1m      1,000,000 Welsh voices (config-#2 voice rule) — north-star target, default
+    welsh-256     config #2   (256 voices; 4 wavefronts: a latency config)
+    chain-4096    config #3   (4,096 voices + BiQuad→Chorus→Delay→Reverb per voice)
+    sampler-16384 config #4   (16,384 one-shot sampler voices over a shared bank)
+    mixed-131072  config #5   (50 % Welsh / 25 % FM / 25 % sampler)
+
+Multi-GPU: strong scaling — the project's voices are cut into contiguous index ranges, one
+range per rank (one process per GPU), and the per-rank buses are summed with ONE RCCL reduce
+over the whole timed region's frames (K*256 frames * 8 B), inside the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from groove_amd import entities as E, patches as P, types as T  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FRAMES = T.BLOCK_FRAMES
+SR = T.DEFAULT_SAMPLE_RATE
+
+WORKLOADS = {
+    "welsh-1m": dict(voices=1_000_000, kind="welsh", bytes_per_vf=18.0, dominant_bytes=10.0),
+    "welsh-256": dict(voices=256, kind="welsh", bytes_per_vf=18.0, dominant_bytes=10.0),
+    "chain-4096": dict(voices=4096, kind="chain", bytes_per_vf=218.0, dominant_bytes=10.0),
+    "sampler-16384": dict(voices=16384, kind="sampler", bytes_per_vf=20.25, dominant_bytes=12.25),
+    "mixed-131072": dict(voices=131072, kind="mixed", bytes_per_vf=18.2, dominant_bytes=10.0),
+}
+
+
+class Project:
+    """The synthetic many-voice project shard owned by one rank."""
+
+    def __init__(self, ctx, workload, first_voice, n_voices, fused):
+        self.ctx, self.n, self.fused = ctx, n_voices, fused
+        kind = WORKLOADS[workload]["kind"]
+        self.banks = []   # (instrument, block, [effects])
+        self.render_events = []
+        if kind in ("welsh", "chain"):
+            synth = E.WelshSynth(ctx, P.welsh_voices(n_voices, first_voice))
+            synth.handle_midi_events(P.note_on_all(n_voices, first_voice))
+            fx = []
+            if kind == "chain":
+                fx = [E.Effect(ctx, k, p) for k, p in P.chain_fx_params(n_voices)]
+            self.banks.append((synth, ctx.block(n_voices, FRAMES), fx))
+        elif kind == "sampler":
+            pcm, descs, _ = P.drum_bank()
+            s = E.Sampler(ctx, pcm, descs, P.sampler_voices(n_voices))
+            s.handle_midi_events(T.note_events_np(np.arange(n_voices, dtype=np.uint32), P.sampler_keys(n_voices), True))
+            self.banks.append((s, ctx.block(n_voices, FRAMES), []))
+        elif kind == "mixed":
+            nw, nf = n_voices // 2, n_voices // 4
+            ns = n_voices - nw - nf
+            w = E.WelshSynth(ctx, P.welsh_voices(nw, first_voice))
+            w.handle_midi_events(P.note_on_all(nw, first_voice))
+            f = E.FmSynth(ctx, P.fm_voices(nf, first_voice))
+            f.handle_midi_events(P.note_on_all(nf, first_voice))
+            pcm, descs, _ = P.drum_bank()
+            s = E.Sampler(ctx, pcm, descs, P.sampler_voices(ns))
+            s.handle_midi_events(T.note_events_np(np.arange(ns, dtype=np.uint32), P.sampler_keys(ns), True))
+            for inst, n in ((w, nw), (f, nf), (s, ns)):
+                self.banks.append((inst, ctx.block(n, FRAMES), []))
+        self.dominant = self.banks[0][0]
+
+    def step(self, bus, frame0, ev_pair=None):
+        """One block: every instrument renders, its effect chain runs, the mix bus sums."""
+        ctx = self.ctx
+        first = True
+        for inst, block, fx in self.banks:
+            if self.fused and not fx:
+                if ev_pair is not None and inst is self.dominant:
+                    ctx.record(ev_pair[0])
+                inst.render_mix(bus, FRAMES, accumulate=not first, at_frame=frame0)
+                if ev_pair is not None and inst is self.dominant:
+                    ctx.record(ev_pair[1])
+            else:
+                if ev_pair is not None and inst is self.dominant:
+                    ctx.record(ev_pair[0])
+                inst.generate_batch_values(block, FRAMES)
+                if ev_pair is not None and inst is self.dominant:
+                    ctx.record(ev_pair[1])
+                for e in fx:
+                    e.transform_audio(block, FRAMES)
+                ctx.mix([block], FRAMES, E._Slice(bus, frame0), accumulate=not first)
+            first = False
+
+
+def cpu_baseline(workload, seconds_target=15.0):
+    """The f64 scalar oracle ("port"; the reference Rust path cannot be built here) timed on
+    this host, rank 0 only, on a bounded sample of the same workload, single thread (mode A)."""
+    from oracle import oracle as O
+    L = O.lib()
+    kind = WORKLOADS[workload]["kind"]
+    V = WORKLOADS[workload]["voices"]
+    if kind not in ("welsh", "chain", "mixed"):
+        kind = "sampler"
+    sample_voices = min(V, 1024)
+    blocks = 8
+    if kind == "sampler":
+        pcm, descs, _ = P.drum_bank()
+        bank = O.Bank.sampler(pcm, descs, P.sampler_voices(sample_voices))
+        bank.note_events(T.note_events_np(np.arange(sample_voices, dtype=np.uint32), P.sampler_keys(sample_voices), True))
+    else:
+        bank = O.Bank.welsh(P.welsh_voices(sample_voices))
+        bank.note_events(P.note_on_all(sample_voices))
+    # calibrate, then run ~seconds_target of CPU work
+    t0 = time.perf_counter()
+    bank.render_bus(FRAMES)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    blocks = int(max(4, min(4096, seconds_target / dt)))
+    t0 = time.perf_counter()
+    for _ in range(blocks):
+        bank.render_bus(FRAMES)
+    el = time.perf_counter() - t0
+    vf_per_s = sample_voices * FRAMES * blocks / el
+    out = {
+        "value": vf_per_s / V, "unit": "stereo frames/s", "cores": 1, "kind": "port",
+        "sample": f"{sample_voices} of {V} voices x {blocks} blocks of {FRAMES} frames, f64 scalar oracle -O2, "
+                  f"1 thread; frames/s scaled by {sample_voices}/{V} (measured {vf_per_s:.3e} voice-frames/s)",
+    }
+    # mode B: all host cores
+    cores = int(L.oracle_hardware_concurrency()) or 1
+    mt_blocks = max(4, blocks // 2)
+    t0 = time.perf_counter()
+    for _ in range(mt_blocks):
+        bank.render_bus(FRAMES, threads=cores)
+    el = time.perf_counter() - t0
+    out["all_cores"] = {"value": sample_voices * FRAMES * mt_blocks / el / V, "cores": cores}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--workload", default="welsh-1m", choices=sorted(WORKLOADS))
+    ap.add_argument("--voices", type=int, default=0, help="override the workload's total voice count")
+    ap.add_argument("--fused", action="store_true", help="render and mix in one kernel (no materialised voice blocks)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    wl = dict(WORKLOADS[args.workload])
+    V = args.voices or wl["voices"]
+    lo = V * rank // world
+    hi = V * (rank + 1) // world
+    ctx = E.Context(local_rank if world > 1 else 0)
+    if world > 1:
+        uid = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(uid[0], rank, world)
+
+    fused = args.fused
+    proj = Project(ctx, args.workload, lo, hi - lo, fused)
+    K, W = args.steps, args.warmup
+    bus = ctx.bus((K + W) * FRAMES)
+
+    def sync_all():
+        ctx.synchronize()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            ctx.synchronize()
+
+    for s in range(W):
+        proj.step(bus, s * FRAMES)
+    sync_all()
+    pairs = [(ctx.event(), ctx.event()) for _ in range(K)]
+    t0 = time.perf_counter()
+    for s in range(K):
+        proj.step(bus, (W + s) * FRAMES, pairs[s])
+    if world > 1:
+        ctx.bus_reduce(E._Slice(bus, W * FRAMES), K * FRAMES, 0)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kern_ms = float(np.mean([ctx.elapsed_ms(a, b) for a, b in pairs]))
+    if rank == 0:
+        out_bus = bus.download()[W * FRAMES:]
+        finite = bool(np.isfinite(out_bus).all())
+        peak = float(np.abs(out_bus).max() / V)
+        frames_total = K * FRAMES
+        value = frames_total / elapsed
+        n_local = hi - lo
+        dom_bytes = (wl["bytes_per_vf"] if (fused and wl["kind"] in ("welsh", "sampler")) else wl["dominant_bytes"])
+        achieved = dom_bytes * n_local * FRAMES / (kern_ms * 1e-3) / 1e9
+        line = {
+            "metric": "stereo frames/sec rendered (offline)", "value": value, "unit": "stereo frames/s",
+            "x_realtime_44k1": value / SR, "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32 (f64 IIR state, u64 phase)", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {V} voices total, {FRAMES}-frame blocks, {SR} Hz, "
+                                   f"{'fused render+mix' if fused else 'materialised blocks + mix kernels'}",
+                       "voices_total": V, "voices_per_gpu": n_local, "parallelism": f"voices sharded x{world}, 1 RCCL bus reduce"},
+            "voice_frames_per_s": value * V,
+            "path_effective_GBs": wl["bytes_per_vf"] * value * V / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "welsh_render_mix_kernel" if fused and wl["kind"] == "welsh" else "render kernel of the first bank",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_voice_frame": dom_bytes, "kernel_ms": kern_ms, "traffic": None},
+            "output_check": {"finite": finite, "peak_abs_bus_over_V": peak},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

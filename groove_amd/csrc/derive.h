@@ -1,0 +1,174 @@
+// derive.h — host-side (f64) derivation of the packed per-lane device parameters from
+// the public `*Params` structs, i.e. what `Foo::new_with(&FooParams)` +
+// `Configurable::update_sample_rate` do in the reference
+// (/root/reference/settings/src/instruments.rs:71-92, orchestrator.rs:125-127).
+// Host only; shared by the C ABI implementation and the tests/emul numerics harness.
+#pragma once
+#include "dsp_core.h"
+
+namespace groove {
+
+inline uint32_t frames_f64(double len) {
+  if (!(len > 0.0)) return 0u;
+  double c = ceil(len);
+  return c > 4.0e9 ? 4000000000u : (uint32_t)c;
+}
+inline double clamp01_h(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
+
+inline EnvParams derive_env(const groove_envelope_params& e, double sr) {
+  EnvParams o;
+  const double sustain = clamp01_h(e.sustain);
+  const double al = e.attack * sr * (1.0 - 0.0); // same expression as the oracle's enter(ATTACK, 0)
+  const double dl = e.decay * sr * (1.0 - sustain);
+  o.attack_len = (float)al; o.attack_N = frames_f64(al);
+  o.decay_len = (float)dl; o.decay_N = frames_f64(dl);
+  o.sustain = (float)sustain;
+  o.release_len = (float)(e.release * sr);
+  return o;
+}
+inline uint64_t duty_to_u64(double duty) {
+  return (uint64_t)(clamp01_h(duty) * 18446744073709549568.0); // (2^64 - 2048): no overflow at 1.0
+}
+inline void pan_gains(double gain, double pan, float& gl, float& gr) {
+  gl = (float)(gain * (1.0 - 0.25 * (pan + 1.0) * (pan + 1.0)));
+  gr = (float)(gain * (1.0 - (0.5 * pan - 0.5) * (0.5 * pan - 0.5)));
+}
+inline Lp24Consts derive_lp24_consts(double ripple) {
+  double sg = sinh(ripple), cg = cosh(ripple);
+  cg *= cg;
+  const double c0 = 1.0 / (cg - 0.85355339059327376220);
+  const double c2 = 1.0 / (cg - 0.14644660940672623780);
+  Lp24Consts c;
+  c.c0 = (float)c0; c.d1 = (float)(c0 * sg * 1.84775906502257351226);
+  c.c2 = (float)c2; c.d3 = (float)(c2 * sg * 0.76536686473017954346);
+  return c;
+}
+
+// Cold per-voice values only the note-event kernel needs.
+struct WelshCold { double tune1, tune2, fixed1, fixed2; };
+
+inline WelshParams derive_welsh(const groove_welsh_params& p, double sr, WelshCold& cold) {
+  WelshParams o{};
+  const uint32_t w1 = p.oscillator_1.waveform & 15u, w2 = p.oscillator_2.waveform & 15u;
+  o.flags = (w1 << WF_O1_WAVE_SHIFT) | (w2 << WF_O2_WAVE_SHIFT) |
+            ((p.lfo_waveform & 15u) << WF_LFO_WAVE_SHIFT) | ((p.lfo_routing & 15u) << WF_ROUTING_SHIFT);
+  if (p.oscillator_2_sync) o.flags |= WF_SYNC;
+  if (p.filter_cutoff_end != 0.0f) o.flags |= WF_RETUNE_ENV;
+  if (p.oscillator_2.fixed_hz > 0.0) o.flags |= WF_O2_FIXED;
+  o.mix = p.oscillator_mix;
+  o.o1_duty = (w1 == GROOVE_WAVE_PULSE_WIDTH) ? p.oscillator_1.duty : 0.5f;
+  o.o2_duty = (w2 == GROOVE_WAVE_PULSE_WIDTH) ? p.oscillator_2.duty : 0.5f;
+  o.o1_duty64 = duty_to_u64((double)o.o1_duty);
+  o.o2_duty64 = duty_to_u64((double)o.o2_duty);
+  o.lfo_inc = turns_to_inc(p.lfo_frequency / sr);
+  o.lfo_depth = p.lfo_depth;
+  o.amp = derive_env(p.amp_envelope, sr);
+  o.fil = derive_env(p.filter_envelope, sr);
+  o.fc = derive_lp24_consts((double)p.filter_passband_ripple);
+  o.cutoff_hz = p.filter_cutoff_hz;
+  o.cutoff_start = p.filter_cutoff_start;
+  o.cutoff_end = p.filter_cutoff_end;
+  pan_gains(p.dca_gain, p.dca_pan, o.gl, o.gr);
+  cold.tune1 = p.oscillator_1.tune; cold.tune2 = p.oscillator_2.tune;
+  cold.fixed1 = p.oscillator_1.fixed_hz; cold.fixed2 = p.oscillator_2.fixed_hz;
+  return o;
+}
+inline WelshState initial_welsh_state() {
+  WelshState s{};
+  osc_reset(s.o1); osc_reset(s.o2); osc_reset(s.lfo);
+  return s;
+}
+
+inline FmParams derive_fm(const groove_fm_params& p, double sr) {
+  FmParams o{};
+  o.depth_beta = (double)p.depth * (double)p.beta;
+  o.cenv = derive_env(p.carrier_envelope, sr);
+  o.menv = derive_env(p.modulator_envelope, sr);
+  pan_gains(p.dca_gain, p.dca_pan, o.gl, o.gr);
+  return o;
+}
+inline FmState initial_fm_state() {
+  FmState s{};
+  osc_reset(s.carrier); osc_reset(s.modulator);
+  return s;
+}
+
+// note_to_frequency(key): 12-TET, A4 = 440 Hz (settings/src/patches.rs:8,96).
+GROOVE_HD double note_to_frequency(uint32_t key) { return 440.0 * exp2(((double)key - 69.0) / 12.0); }
+
+// PlaysNotes::note_on / note_off bodies, shared by the device event kernels.
+GROOVE_HD void welsh_note(const WelshParams& p, WelshState& s, double tune1, double tune2,
+                          double fixed1, double fixed2, double sr, uint32_t key, bool on) {
+  if (on) {
+    const double f = note_to_frequency(key);
+    s.o1_inc = turns_to_inc((fixed1 > 0.0 ? fixed1 : f * tune1) / sr);
+    s.o2_inc = turns_to_inc((fixed2 > 0.0 ? fixed2 : f * tune2) / sr);
+    env_trigger_attack(s.amp, p.amp);
+    env_trigger_attack(s.fil, p.fil);
+  } else {
+    env_trigger_release(s.amp, p.amp);
+    env_trigger_release(s.fil, p.fil);
+  }
+}
+GROOVE_HD void fm_note(const FmParams& p, FmState& s, double ratio, double sr, uint32_t key, bool on) {
+  if (on) {
+    const double f = note_to_frequency(key);
+    s.c_inc = turns_to_inc(f / sr);
+    s.m_inc = turns_to_inc(f * ratio / sr);
+    env_trigger_attack(s.cenv, p.cenv);
+    env_trigger_attack(s.menv, p.menv);
+  } else {
+    env_trigger_release(s.cenv, p.cenv);
+    env_trigger_release(s.menv, p.menv);
+  }
+}
+GROOVE_HD void sampler_note(const SamplerParams& p, SamplerState& s, uint32_t key, bool on) {
+  if (on) {
+    s.playing = 1; s.idx = 0;
+    const double step = p.root_hz > 0.0 ? note_to_frequency(key) / p.root_hz : 1.0;
+    s.step = (uint64_t)(step * 17592186044416.0); // 2^44
+  } else if (!p.one_shot) {
+    s.playing = 0;
+  }
+}
+
+// f64 coefficient sets for the effect kernels (host; identical to the oracle's math).
+inline void rbj_lowpass_h(double f0, double q, double fs, double* c5) {
+  const double w0 = 2.0 * 3.14159265358979323846 * f0 / fs, cw = cos(w0), sw = sin(w0);
+  const double alpha = sw / (2.0 * q), a0 = 1.0 + alpha;
+  c5[0] = (1.0 - cw) / 2.0 / a0; c5[1] = (1.0 - cw) / a0; c5[2] = (1.0 - cw) / 2.0 / a0;
+  c5[3] = -2.0 * cw / a0; c5[4] = (1.0 - alpha) / a0;
+}
+inline void rbj_highpass_h(double f0, double q, double fs, double* c5) {
+  const double w0 = 2.0 * 3.14159265358979323846 * f0 / fs, cw = cos(w0), sw = sin(w0);
+  const double alpha = sw / (2.0 * q), a0 = 1.0 + alpha;
+  c5[0] = (1.0 + cw) / 2.0 / a0; c5[1] = -(1.0 + cw) / a0; c5[2] = (1.0 + cw) / 2.0 / a0;
+  c5[3] = -2.0 * cw / a0; c5[4] = (1.0 - alpha) / a0;
+}
+// out6 = b0,a1,a2 (section 1), b0,a1,a2 (section 2); y = b0 x + 2 b0 x1 + b0 x2 + a1 y1 + a2 y2
+inline void lp24_coeffs_h(double fc, double ripple, double fs, double* out6) {
+  if (fc > 0.49 * fs) fc = 0.49 * fs;
+  if (fc < 1.0) fc = 1.0;
+  const double k = tan(3.14159265358979323846 * fc / fs);
+  double sg = sinh(ripple), cg = cosh(ripple);
+  cg *= cg;
+  const double c0 = 1.0 / (cg - 0.85355339059327376220), c1 = k * c0 * sg * 1.84775906502257351226;
+  const double c2 = 1.0 / (cg - 0.14644660940672623780), c3 = k * c2 * sg * 0.76536686473017954346;
+  const double K = k * k;
+  const double a0 = 1.0 / (c1 + K + c0), a3 = 1.0 / (c3 + K + c2);
+  out6[0] = a0 * K; out6[1] = 2.0 * (c0 - K) * a0; out6[2] = (c1 - K - c0) * a0;
+  out6[3] = a3 * K; out6[4] = 2.0 * (c2 - K) * a3; out6[5] = (c3 - K - c2) * a3;
+}
+inline uint32_t delay_frames_h(double seconds, double sr) {
+  const double n = floor(seconds * sr + 0.5);
+  return n < 1.0 ? 1u : (uint32_t)n;
+}
+inline double decay_gain_h(double delay_s, double decay_s) {
+  return decay_s > 0.0 ? pow(0.001, delay_s / decay_s) : 0.0;
+}
+static const double kCombDelaysH[4] = {0.0297, 0.0371, 0.0411, 0.0437};
+static const double kAllpassDelaysH[2] = {0.005, 0.0017};
+static const double kAllpassDecaysH[2] = {0.09683, 0.03292};
+inline double percent_to_frequency_h(double p) { return 25.0 * pow(800.0, p); }
+
+} // namespace groove

@@ -1,0 +1,474 @@
+// dsp_core.h — per-lane DSP arithmetic of the MI355X render path.
+//
+// One voice (or one effect channel) lives in one lane of a 64-wide wavefront; the
+// functions here are the per-frame bodies the HIP kernels in kernels.hip loop over
+// with all state in registers.  They are plain inline functions so the same text can
+// also be compiled by g++ into the host-side numerics harness under tests/emul/ (a
+// DEVELOPMENT CHECK of the fp32/f64 arithmetic choices against the f64 oracle; it is
+// not a product path and libgroove_hip.so never contains it).
+//
+// Arithmetic policy:
+//   * phases are 64-bit fixed-point turn counters (exact wrap, carry = hard-sync flag);
+//   * feed-forward math (waveforms, envelopes, coefficient formulas, pan) is fp32;
+//   * IIR recurrences (24 dB low-pass sections, biquads, recirculating combs) are f64:
+//     CDNA4 runs v_fma_f64 at half the fp32 rate, which is cheaper than compensating
+//     an fp32 recurrence whose poles sit 1e-5 from the unit circle;
+//   * anything that moves a waveform EDGE (pitch / pulse-width LFO routing, FM index)
+//     is f64, because an edge landing on a different frame is a full-scale error.
+//
+// Reference items implemented: a1 Oscillator, a2 Envelope, a3/a4
+// BiQuad + 24 dB low-pass, a5 WelshVoice, a6 FmVoice, a7 SamplerVoice, a8-a12 effects,
+// a13 Dca.  Citations: see include/groove_types.h and oracle/oracle_dsp.hpp.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+#include "../../include/groove_types.h"
+
+#if defined(__HIPCC__)
+#define GROOVE_HD __host__ __device__ __forceinline__
+#else
+#define GROOVE_HD inline
+#endif
+
+namespace groove {
+
+// ------------------------------------------------------------------ small math
+GROOVE_HD float fast_exp2(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_exp2f(x); // v_exp_f32
+#else
+  return exp2f(x);
+#endif
+}
+GROOVE_HD float fast_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // v_rcp_f32 (1 ulp) + one Newton step → correctly rounded to within 0.5-1 ulp
+  float r = __builtin_amdgcn_rcpf(x);
+  return fmaf(fmaf(-x, r, 1.0f), r, r);
+#else
+  return 1.0f / x;
+#endif
+}
+
+// sin(2*pi*x) for x in [-0.25, 0.25] (turns); odd polynomial in y = 2*pi*x.
+GROOVE_HD float sin_turns_folded(float x) {
+  const float y = x * 6.283185307179586f;
+  const float y2 = y * y;
+  float p = 2.5992782e-06f;            // least-squares fit on Chebyshev nodes, |y| <= pi/2:
+  p = fmaf(p, y2, -1.9806202e-04f);    // max abs error 1.0e-7 in fp32 (tests/test_emul.py)
+  p = fmaf(p, y2, 8.3330103e-03f);
+  p = fmaf(p, y2, -1.6666657e-01f);
+  return fmaf(p * y2, y, y);
+}
+GROOVE_HD double sin_turns_folded_f64(double x) {
+  const double y = x * 6.28318530717958647692;
+  const double y2 = y * y;
+  double p = -8.22063524662432971696e-18; // -1/19!
+  p = fma(p, y2, 2.81145725434552076320e-15);
+  p = fma(p, y2, -7.64716373181981647590e-13);
+  p = fma(p, y2, 1.60590438368216145994e-10);
+  p = fma(p, y2, -2.50521083854417187751e-08);
+  p = fma(p, y2, 2.75573192239858906526e-06);
+  p = fma(p, y2, -1.98412698412698412698e-04);
+  p = fma(p, y2, 8.33333333333333333333e-03);
+  p = fma(p, y2, -1.66666666666666666667e-01);
+  return fma(p * y2, y, y);
+}
+// Fold a signed 32-bit phase (turns * 2^32, [-0.5, 0.5)) into [-0.25, 0.25] so that
+// sin(2 pi p) is unchanged: p -> 0.5 - p (or -0.5 - p) when |p| > 0.25.
+GROOVE_HD int32_t fold_quarter(int32_t q) {
+  // top two bits differ <=> |p| >= 0.25
+  if ((q ^ (q << 1)) < 0) q = (int32_t)(0x80000000u - (uint32_t)q);
+  return q;
+}
+GROOVE_HD int64_t fold_quarter64(int64_t q) {
+  if ((q ^ (q << 1)) < 0) q = (int64_t)(0x8000000000000000ull - (uint64_t)q);
+  return q;
+}
+// 2^x for |x| <= 1 in f64 (Taylor in x ln2, 1e-14 relative).
+GROOVE_HD double exp2_small_f64(double x) {
+  const double t = x * 0.693147180559945309417;
+  double p = 1.14707455977297247139e-11; // 1/14!
+  p = fma(p, t, 1.60590438368216145994e-10);
+  p = fma(p, t, 2.08767569878680989792e-09);
+  p = fma(p, t, 2.50521083854417187751e-08);
+  p = fma(p, t, 2.75573192239858906526e-07);
+  p = fma(p, t, 2.75573192239858906526e-06);
+  p = fma(p, t, 2.48015873015873015873e-05);
+  p = fma(p, t, 1.98412698412698412698e-04);
+  p = fma(p, t, 1.38888888888888888889e-03);
+  p = fma(p, t, 8.33333333333333333333e-03);
+  p = fma(p, t, 4.16666666666666666667e-02);
+  p = fma(p, t, 1.66666666666666666667e-01);
+  p = fma(p, t, 0.5);
+  p = fma(p, t, 1.0);
+  return fma(p, t, 1.0);
+}
+// tan(x) for x in (0, pi/2): sin/cos polynomials on [0, pi/4], reflected above.
+GROOVE_HD float tan_pos(float x) {
+  const bool hi = x > 0.78539816339744831f;
+  const float z = hi ? (1.57079632679489662f - x) : x;
+  const float z2 = z * z;
+  float s = 2.7557319e-06f;            // sin(z)/z
+  s = fmaf(s, z2, -1.9841270e-04f);
+  s = fmaf(s, z2, 8.3333333e-03f);
+  s = fmaf(s, z2, -1.6666667e-01f);
+  s = fmaf(s * z2, z, z);
+  float c = 2.4801587e-05f;            // cos(z)
+  c = fmaf(c, z2, -1.3888889e-03f);
+  c = fmaf(c, z2, 4.1666667e-02f);
+  c = fmaf(c, z2, -0.5f);
+  c = fmaf(c, z2, 1.0f);
+  const float num = hi ? c : s, den = hi ? s : c;
+  return num * fast_rcp(den);
+}
+GROOVE_HD float clamp01f(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+GROOVE_HD double clamp01d(double x) { return fmin(fmax(x, 0.0), 1.0); }
+
+// f64 -> u64 for 0 <= x < 2^64
+GROOVE_HD uint64_t f64_to_u64(double x) { return (uint64_t)x; }
+// turns (f64, any sign, |x| < 2^31) -> wrapped 64-bit phase increment
+GROOVE_HD uint64_t turns_to_phase(double turns) {
+  double fl = floor(turns);
+  double frac = turns - fl; // [0,1)
+  return (uint64_t)(frac * 18446744073709551616.0);
+}
+// signed increment: turns may be negative (FM through zero); two's complement add.
+GROOVE_HD uint64_t turns_to_inc(double turns) {
+  if (turns >= 0.0) return (uint64_t)(turns * 18446744073709551616.0);
+  return (uint64_t)0 - (uint64_t)(-turns * 18446744073709551616.0);
+}
+
+// ------------------------------------------------------------------ Oscillator (a1)
+struct OscState {
+  uint64_t phase; // turns * 2^64
+  uint32_t x1, x2; // noise generator
+  uint32_t flags;  // bit0: first tick pending, bit1: sync pending
+};
+enum : uint32_t { OSC_FIRST = 1u, OSC_SYNC = 2u };
+GROOVE_HD void osc_reset(OscState& s) {
+  s.phase = 0; s.x1 = 0x70f4f854u; s.x2 = 0xe1e9f0a7u; s.flags = OSC_FIRST;
+}
+// Advance one frame by `inc` (two's complement).  Returns the wrap flag (should_sync):
+// for inc >= 0 that is the carry out of the 64-bit add.
+GROOVE_HD bool osc_advance(OscState& s, uint64_t inc) {
+  bool wrapped = false;
+  if (s.flags & OSC_SYNC) { s.phase = 0; }
+  else if (s.flags & OSC_FIRST) { /* first tick emits position 0 */ }
+  else {
+    const uint64_t np = s.phase + inc;
+    const bool neg = (int64_t)inc < 0;
+    wrapped = neg ? (np > s.phase) : (np < s.phase);
+    s.phase = np;
+  }
+  s.flags = 0;
+  return wrapped;
+}
+// Waveform value at the current phase (fp32).  duty64 = duty * 2^64.
+GROOVE_HD float osc_value(uint32_t waveform, const OscState& s, uint64_t duty64, float noise_value) {
+  const int32_t q = (int32_t)(uint32_t)(s.phase >> 32); // signed turns * 2^32
+  switch (waveform) {
+    case GROOVE_WAVE_SINE:
+      return sin_turns_folded((float)fold_quarter(q) * 2.3283064365386963e-10f);
+    case GROOVE_WAVE_SQUARE:
+    case GROOVE_WAVE_PULSE_WIDTH: return s.phase < duty64 ? 1.0f : -1.0f;
+    case GROOVE_WAVE_TRIANGLE: return fmaf(fabsf((float)q * 2.3283064365386963e-10f), 4.0f, -1.0f);
+    case GROOVE_WAVE_SAWTOOTH: return (float)q * 4.6566128730773926e-10f;
+    case GROOVE_WAVE_TRIANGLE_SINE: {
+      const int32_t r = (int32_t)((uint32_t)q + 0x40000000u);
+      return fmaf(fabsf((float)r * 2.3283064365386963e-10f), 4.0f, -1.0f);
+    }
+    case GROOVE_WAVE_NOISE: return noise_value;
+    case GROOVE_WAVE_DEBUG_MAX: return 1.0f;
+    case GROOVE_WAVE_DEBUG_MIN: return -1.0f;
+    default: return 0.0f;
+  }
+}
+// Same in f64 from the full 64-bit phase (LFO on edge-moving routings).
+GROOVE_HD double osc_value_f64(uint32_t waveform, const OscState& s, uint64_t duty64, float noise_value) {
+  const int64_t q = (int64_t)s.phase;
+  const double k = 5.42101086242752217004e-20; // 2^-64
+  switch (waveform) {
+    case GROOVE_WAVE_SINE: return sin_turns_folded_f64((double)fold_quarter64(q) * k);
+    case GROOVE_WAVE_SQUARE:
+    case GROOVE_WAVE_PULSE_WIDTH: return s.phase < duty64 ? 1.0 : -1.0;
+    case GROOVE_WAVE_TRIANGLE: return fma(fabs((double)q * k), 4.0, -1.0);
+    case GROOVE_WAVE_SAWTOOTH: return (double)q * (2.0 * k);
+    case GROOVE_WAVE_TRIANGLE_SINE: {
+      const int64_t r = (int64_t)((uint64_t)q + 0x4000000000000000ull);
+      return fma(fabs((double)r * k), 4.0, -1.0);
+    }
+    case GROOVE_WAVE_NOISE: return (double)noise_value;
+    case GROOVE_WAVE_DEBUG_MAX: return 1.0;
+    case GROOVE_WAVE_DEBUG_MIN: return -1.0;
+    default: return 0.0;
+  }
+}
+// musicdsp "fast white noise": integer generator, bit-exact on every platform.
+GROOVE_HD float noise_tick(OscState& s) {
+  s.x1 ^= s.x2;
+  const float v = (float)(int32_t)s.x2 * 4.6566128730773926e-10f; // 2^-31
+  s.x2 += s.x1;
+  return v;
+}
+
+// ------------------------------------------------------------------ Envelope (a2)
+enum : uint32_t { ENV_IDLE = 0, ENV_ATTACK = 1, ENV_DECAY = 2, ENV_SUSTAIN = 3, ENV_RELEASE = 4 };
+struct EnvParams {
+  float attack_len;   // attack_s * SR           (frames for a 0 -> 1 rise)
+  uint32_t attack_N;  // ceil(attack_len), computed in f64 on the host
+  float decay_len;    // decay_s * SR * (1 - sustain)
+  uint32_t decay_N;
+  float sustain;
+  float release_len;  // release_s * SR          (frames for a 1 -> 0 fall)
+};
+struct EnvState {
+  uint32_t state, n, N;
+  float A, B, inv_len, value;
+};
+GROOVE_HD uint32_t env_frames(float len) {
+  if (!(len > 0.0f)) return 0u;
+  const float c = ceilf(len);
+  return c > 4.0e9f ? 4000000000u : (uint32_t)c;
+}
+GROOVE_HD void env_enter_len(EnvState& s, uint32_t st, float from, float to, float len, uint32_t N) {
+  s.state = st; s.n = 0; s.A = from; s.B = to; s.N = N;
+  s.inv_len = len > 0.0f ? 1.0f / len : 0.0f;
+}
+GROOVE_HD void env_trigger_attack(EnvState& s, const EnvParams& p) {
+  const float from = s.value;
+  if (from == 0.0f) env_enter_len(s, ENV_ATTACK, 0.0f, 1.0f, p.attack_len, p.attack_N);
+  else { const float len = p.attack_len * (1.0f - from); env_enter_len(s, ENV_ATTACK, from, 1.0f, len, env_frames(len)); }
+}
+GROOVE_HD void env_trigger_release(EnvState& s, const EnvParams& p) {
+  if (s.state == ENV_IDLE) return;
+  const float from = s.value;
+  const float len = p.release_len * from;
+  env_enter_len(s, ENV_RELEASE, from, 0.0f, len, env_frames(len));
+}
+GROOVE_HD void env_tick(EnvState& s, const EnvParams& p) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const bool ramp = (s.state == ENV_ATTACK) | (s.state == ENV_DECAY) | (s.state == ENV_RELEASE);
+    if (ramp && s.n >= s.N) {
+      if (s.state == ENV_ATTACK) env_enter_len(s, ENV_DECAY, 1.0f, p.sustain, p.decay_len, p.decay_N);
+      else if (s.state == ENV_DECAY) s.state = ENV_SUSTAIN;
+      else s.state = ENV_IDLE;
+    }
+  }
+  if (s.state == ENV_IDLE) s.value = 0.0f;
+  else if (s.state == ENV_SUSTAIN) s.value = p.sustain;
+  else {
+    const float t = (float)s.n * s.inv_len;
+    s.value = fmaf(s.B - s.A, fmaf(-t, t, 2.0f * t), s.A);
+    s.n += 1;
+  }
+}
+
+// ------------------------------------------------------------------ 24 dB low-pass (a4)
+// Per-voice constants: c0 = 1/(cosh^2 r - 0.8535..), d1 = c0 sinh r 1.8477..,
+// c2 = 1/(cosh^2 r - 0.1464..), d3 = c2 sinh r 0.7653..  (host, f64 -> f32).
+struct Lp24Consts { float c0, d1, c2, d3; };
+// Coefficients in "small quantity" form: a1 = 2 - e1, a2 = e2 - 1, so that fp32
+// carries full relative precision of the distance from the unit circle.
+struct Lp24Coef { float b0a, e1a, e2a, b0b, e1b, e2b; };
+GROOVE_HD Lp24Coef lp24_coef_from_k(const Lp24Consts& c, float k) {
+  const float K = k * k;
+  const float c1 = k * c.d1, c3 = k * c.d3;
+  const float ia = fast_rcp(c1 + K + c.c0);
+  const float ib = fast_rcp(c3 + K + c.c2);
+  Lp24Coef o;
+  o.b0a = K * ia; o.e1a = 2.0f * (c1 + 2.0f * K) * ia; o.e2a = 2.0f * c1 * ia;
+  o.b0b = K * ib; o.e1b = 2.0f * (c3 + 2.0f * K) * ib; o.e2b = 2.0f * c3 * ib;
+  return o;
+}
+// k = tan(pi * fc / SR); pi_over_sr = pi / SR; fc clamped to [1, 0.49 SR].
+GROOVE_HD float lp24_k(float fc, float pi_over_sr, float fc_max) {
+  fc = fminf(fmaxf(fc, 1.0f), fc_max);
+  return tan_pos(fc * pi_over_sr);
+}
+struct Lp24StateD { double s0, s1, s2, s3; };
+GROOVE_HD double lp24_step(Lp24StateD& s, const Lp24Coef& c, double x) {
+  const double b0a = (double)c.b0a, a1a = 2.0 - (double)c.e1a, a2a = (double)c.e2a - 1.0;
+  const double b0b = (double)c.b0b, a1b = 2.0 - (double)c.e1b, a2b = (double)c.e2b - 1.0;
+  const double bx = b0a * x;
+  const double y1 = bx + s.s0;
+  s.s0 = fma(a1a, y1, 2.0 * bx + s.s1);
+  s.s1 = fma(a2a, y1, bx);
+  const double by = b0b * y1;
+  const double y2 = by + s.s2;
+  s.s2 = fma(a1b, y2, 2.0 * by + s.s3);
+  s.s3 = fma(a2b, y2, by);
+  return y2;
+}
+
+// ------------------------------------------------------------------ WelshVoice (a5)
+// Packed per-voice flags word.
+enum : uint32_t {
+  WF_O1_WAVE_SHIFT = 0, WF_O2_WAVE_SHIFT = 4, WF_LFO_WAVE_SHIFT = 8, WF_ROUTING_SHIFT = 12,
+  WF_SYNC = 1u << 16, WF_RETUNE_ENV = 1u << 17, WF_O2_FIXED = 1u << 18
+};
+struct WelshParams {
+  uint32_t flags;
+  float mix;
+  uint64_t o1_duty64, o2_duty64;
+  float o1_duty, o2_duty;
+  uint64_t lfo_inc;
+  float lfo_depth;
+  EnvParams amp, fil;
+  Lp24Consts fc;   // filter constants
+  float cutoff_hz; // static cutoff
+  float cutoff_start, cutoff_end;
+  float gl, gr;    // dca gain * pan law, per channel
+};
+struct WelshState {
+  OscState o1, o2, lfo;
+  uint64_t o1_inc, o2_inc; // base increments (set by note_on)
+  EnvState amp, fil;
+  Lp24StateD filt;
+  float nz1, nz2, nzl; // last noise values
+};
+struct RenderConsts {
+  float pi_over_sr; // pi / SR
+  float fc_max;     // 0.49 * SR
+};
+
+GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc,
+                           const Lp24Coef& static_coef, float& L, float& R) {
+  env_tick(s.amp, p.amp);
+  env_tick(s.fil, p.fil);
+  if (s.amp.state == ENV_IDLE) { L = 0.0f; R = 0.0f; return; }
+  const uint32_t w1 = (p.flags >> WF_O1_WAVE_SHIFT) & 15u, w2 = (p.flags >> WF_O2_WAVE_SHIFT) & 15u;
+  const uint32_t wl = (p.flags >> WF_LFO_WAVE_SHIFT) & 15u, routing = (p.flags >> WF_ROUTING_SHIFT) & 15u;
+
+  // LFO
+  osc_advance(s.lfo, p.lfo_inc);
+  if (wl == GROOVE_WAVE_NOISE) s.nzl = noise_tick(s.lfo);
+  const uint64_t half = 0x8000000000000000ull;
+  uint64_t inc1 = s.o1_inc, inc2 = s.o2_inc;
+  uint64_t d1 = p.o1_duty64, d2 = p.o2_duty64;
+  float lfo = 0.0f;
+  if (routing == GROOVE_LFO_PITCH || routing == GROOVE_LFO_PULSE_WIDTH) {
+    const double l = osc_value_f64(wl, s.lfo, half, s.nzl);
+    const double ld = l * (double)p.lfo_depth;
+    if (routing == GROOVE_LFO_PITCH) {
+      const double m = exp2_small_f64(ld);
+      inc1 = f64_to_u64((double)inc1 * m);
+      inc2 = f64_to_u64((double)inc2 * m); // fm applies to a fixed-frequency osc too
+    } else {
+      d1 = f64_to_u64(clamp01d((double)p.o1_duty * (1.0 + ld)) * 18446744073709549568.0);
+      d2 = f64_to_u64(clamp01d((double)p.o2_duty * (1.0 + ld)) * 18446744073709549568.0);
+    }
+    lfo = (float)l;
+  } else if (routing != GROOVE_LFO_NONE) {
+    lfo = osc_value(wl, s.lfo, half, s.nzl);
+  }
+
+  // oscillators (+ hard sync)
+  const bool wrapped = osc_advance(s.o1, inc1);
+  if (w1 == GROOVE_WAVE_NOISE) s.nz1 = noise_tick(s.o1);
+  if ((p.flags & WF_SYNC) && wrapped) s.o2.flags |= OSC_SYNC;
+  osc_advance(s.o2, inc2);
+  if (w2 == GROOVE_WAVE_NOISE) s.nz2 = noise_tick(s.o2);
+  const float v1 = osc_value(w1, s.o1, d1, s.nz1);
+  const float v2 = osc_value(w2, s.o2, d2, s.nz2);
+  const float sum = fmaf(v1, p.mix, v2 * (1.0f - p.mix));
+
+  // filter cutoff
+  Lp24Coef coef = static_coef;
+  bool retune = false;
+  float pct = 0.0f;
+  if (p.flags & WF_RETUNE_ENV) {
+    pct = fmaf((1.0f - p.cutoff_start) * p.cutoff_end, s.fil.value, p.cutoff_start);
+    retune = true;
+  } else if (routing == GROOVE_LFO_FILTER_CUTOFF) {
+    pct = p.cutoff_start * fmaf(lfo, p.lfo_depth, 1.0f);
+    retune = true;
+  }
+  if (retune) {
+    const float fc = 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f); // 25 * 800^pct
+    coef = lp24_coef_from_k(p.fc, lp24_k(fc, rc.pi_over_sr, rc.fc_max));
+  }
+  const float y = (float)lp24_step(s.filt, coef, (double)sum);
+  float a = s.amp.value;
+  if (routing == GROOVE_LFO_AMPLITUDE) a *= fmaf(lfo, p.lfo_depth, 1.0f);
+  const float m = y * a;
+  L = m * p.gl;
+  R = m * p.gr;
+}
+
+// ------------------------------------------------------------------ FmVoice (a6)
+struct FmParams {
+  double depth_beta; // depth * beta
+  EnvParams cenv, menv;
+  float gl, gr;
+};
+struct FmState {
+  OscState carrier, modulator;
+  uint64_t c_inc, m_inc;
+  EnvState cenv, menv;
+};
+GROOVE_HD void fm_frame(const FmParams& p, FmState& s, float& L, float& R) {
+  env_tick(s.cenv, p.cenv);
+  env_tick(s.menv, p.menv);
+  if (s.cenv.state == ENV_IDLE) { L = 0.0f; R = 0.0f; return; }
+  osc_advance(s.modulator, s.m_inc);
+  const double mv = osc_value_f64(GROOVE_WAVE_SINE, s.modulator, 0, 0.0f);
+  const double lfm = mv * (double)s.menv.value * p.depth_beta;
+  // carrier delta = base * (2^0 + lfm); may go negative (through-zero FM)
+  const double turns = (double)s.c_inc * 5.42101086242752217004e-20 * (1.0 + lfm);
+  osc_advance(s.carrier, turns_to_inc(turns));
+  const float cv = osc_value(GROOVE_WAVE_SINE, s.carrier, 0, 0.0f);
+  const float m = cv * s.cenv.value;
+  L = m * p.gl;
+  R = m * p.gr;
+}
+
+// ------------------------------------------------------------------ SamplerVoice (a7)
+// idx / step are Q20.44 fixed point (buffers up to 2^20 frames, 2^-44 step resolution).
+struct SamplerParams {
+  uint32_t offset, length; // frames into the shared bank
+  double root_hz;          // <= 0: drumkit (step 1)
+  float gain;
+  uint32_t one_shot;
+};
+struct SamplerState {
+  uint64_t idx, step;
+  uint32_t playing;
+};
+GROOVE_HD float sampler_frame(const SamplerParams& p, SamplerState& s, const float* bank) {
+  if (!s.playing) return 0.0f;
+  const uint32_t i = (uint32_t)(s.idx >> 44);
+  if (i >= p.length) { s.playing = 0; return 0.0f; }
+  const float v = bank[(size_t)p.offset + i] * p.gain;
+  s.idx += s.step;
+  return v;
+}
+
+// ------------------------------------------------------------------ effects (a8, a9)
+GROOVE_HD float bitcrush(float x, uint32_t bits) {
+  float ax = fabsf(x) * 32767.0f;
+  if (!(ax < 2147483648.0f)) ax = 2147483520.0f;
+  uint32_t q = (uint32_t)ax;
+  q = (q >> bits) << bits;
+  const float y = (float)q * (1.0f / 32767.0f);
+  return copysignf(y, x);
+}
+GROOVE_HD float limiter(float x, float mn, float mx) {
+  return copysignf(fminf(fmaxf(fabsf(x), mn), mx), x);
+}
+GROOVE_HD float compressor(float x, float threshold, float ratio) {
+  float a = fabsf(x);
+  if (a > threshold) a = fmaf(a - threshold, ratio, threshold);
+  return copysignf(a, x);
+}
+// Biquad Direct Form 1 (doc/Audio-EQ-Cookbook.txt Eq 4), f64 state and coefficients.
+struct BiquadCoefD { double b0, b1, b2, a1, a2; };
+struct BiquadStateD { double x1, x2, y1, y2; };
+GROOVE_HD double biquad_step(BiquadStateD& s, const BiquadCoefD& c, double x) {
+  const double y = c.b0 * x + c.b1 * s.x1 + c.b2 * s.x2 - c.a1 * s.y1 - c.a2 * s.y2;
+  s.x2 = s.x1; s.x1 = x; s.y2 = s.y1; s.y1 = y;
+  return y;
+}
+
+} // namespace groove

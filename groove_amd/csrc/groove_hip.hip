@@ -1,0 +1,892 @@
+// groove_hip.hip — implementation of the C ABI in include/groove_hip.h.
+//
+// Host side of the MI355X render path: owns device memory, derives packed per-lane
+// parameters (derive.h), queues block-granular note events, launches the kernels in
+// kernels.h on the ctx stream.  Nothing here falls back to a CPU path: every entry point
+// either launches HIP work or returns an error.
+#include "../../include/groove_hip.h"
+#include "kernels.h"
+#include <dlfcn.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include <cstring>
+#include <cstdio>
+#include <new>
+
+using namespace groove;
+
+namespace {
+thread_local std::string g_last_error;
+}
+
+struct groove_block {
+  groove_ctx* ctx;
+  uint32_t n, cap;
+  float* d;
+};
+
+enum BankKind { BANK_WELSH = 0, BANK_FM = 1, BANK_SAMPLER = 2 };
+
+struct groove_bank {
+  groove_ctx* ctx;
+  BankKind kind;
+  uint32_t n;
+  uint32_t pw, sw; // param / state words per lane
+  uint32_t* d_params = nullptr;
+  uint32_t* d_state = nullptr;
+  double* d_cold = nullptr; // welsh: [4][n]; fm: ratio [n]
+  float* d_pcm = nullptr;   // sampler bank
+  groove_note_event* d_ev = nullptr;
+  size_t ev_cap = 0;
+  groove_block* scratch = nullptr; // for render_mix
+  std::vector<groove_note_event> pending;
+  std::vector<groove_welsh_params> welsh;
+  std::vector<groove_fm_params> fm;
+  std::vector<groove_sampler_params> sampler;
+  std::vector<groove_sample_desc> descs;
+};
+
+struct groove_fx {
+  groove_ctx* ctx;
+  uint32_t kind, n;
+  std::vector<groove_fx_params> p;
+  float* d_fa = nullptr;   // per-lane float param A (ceiling / limit_min / attenuation)
+  float* d_fb = nullptr;   // per-lane float param B (limit_max / ratio)
+  uint32_t* d_ua = nullptr; // per-lane uint param (bits)
+  float* d_wet = nullptr;
+  double* d_coef = nullptr; // [5|6][n]
+  double* d_st = nullptr;   // [4][2n]
+  float* d_ring = nullptr;  // rows of 2n floats
+  size_t ring_rows = 0;
+  // uniform geometry
+  uint32_t N = 0, w = 0, voices = 1, spacing = 0;
+  ReverbGeom geo{};
+};
+
+struct groove_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = true;
+  uint32_t sr = GROOVE_DEFAULT_SAMPLE_RATE;
+  std::string err;
+  std::vector<groove_bank*> banks;
+  std::vector<groove_fx*> fxs;
+  float* d_partial = nullptr;
+  size_t partial_cap = 0;
+  int16_t* d_i16 = nullptr;
+  size_t i16_cap = 0;
+  // RCCL (dlopen'ed lazily)
+  void* rccl = nullptr;
+  void* comm = nullptr;
+  int rank = 0, world = 1;
+};
+
+namespace {
+
+int fail(groove_ctx* ctx, const std::string& msg) {
+  g_last_error = msg;
+  if (ctx) ctx->err = msg;
+  return 1;
+}
+#define GHIP(ctx, expr)                                                                    \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail(ctx, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+  } while (0)
+
+template <class T>
+std::vector<uint32_t> to_soa(const std::vector<T>& aos) {
+  const size_t n = aos.size(), W = sizeof(T) / 4;
+  std::vector<uint32_t> soa(W * n);
+  for (size_t v = 0; v < n; ++v) {
+    uint32_t w[sizeof(T) / 4];
+    std::memcpy(w, &aos[v], sizeof(T));
+    for (size_t i = 0; i < W; ++i) soa[i * n + v] = w[i];
+  }
+  return soa;
+}
+template <class T>
+int upload_soa(groove_ctx* ctx, uint32_t* dst, const std::vector<T>& aos) {
+  std::vector<uint32_t> soa = to_soa(aos);
+  GHIP(ctx, hipMemcpyAsync(dst, soa.data(), soa.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+inline uint32_t blocks_for(size_t items) { return (uint32_t)((items + kThreads - 1) / kThreads); }
+
+int bank_derive_and_upload(groove_bank* b) {
+  groove_ctx* ctx = b->ctx;
+  const double sr = ctx->sr;
+  const uint32_t n = b->n;
+  GHIP(ctx, hipSetDevice(ctx->device));
+  if (b->kind == BANK_WELSH) {
+    std::vector<WelshParams> P(n);
+    std::vector<WelshState> S(n, initial_welsh_state());
+    std::vector<double> cold((size_t)4 * n);
+    for (uint32_t v = 0; v < n; ++v) {
+      WelshCold c;
+      P[v] = derive_welsh(b->welsh[v], sr, c);
+      cold[v] = c.tune1; cold[(size_t)n + v] = c.tune2; cold[(size_t)2 * n + v] = c.fixed1; cold[(size_t)3 * n + v] = c.fixed2;
+    }
+    if (upload_soa(ctx, b->d_params, P)) return 1;
+    if (upload_soa(ctx, b->d_state, S)) return 1;
+    GHIP(ctx, hipMemcpy(b->d_cold, cold.data(), cold.size() * 8, hipMemcpyHostToDevice));
+  } else if (b->kind == BANK_FM) {
+    std::vector<FmParams> P(n);
+    std::vector<FmState> S(n, initial_fm_state());
+    std::vector<double> ratio(n);
+    for (uint32_t v = 0; v < n; ++v) { P[v] = derive_fm(b->fm[v], sr); ratio[v] = b->fm[v].ratio; }
+    if (upload_soa(ctx, b->d_params, P)) return 1;
+    if (upload_soa(ctx, b->d_state, S)) return 1;
+    GHIP(ctx, hipMemcpy(b->d_cold, ratio.data(), ratio.size() * 8, hipMemcpyHostToDevice));
+  } else {
+    std::vector<SamplerParams> P(n);
+    std::vector<SamplerState> S(n, SamplerState{0, 0, 0});
+    for (uint32_t v = 0; v < n; ++v) {
+      const groove_sampler_params& sp = b->sampler[v];
+      const groove_sample_desc& d = b->descs[sp.sample_index < b->descs.size() ? sp.sample_index : 0];
+      P[v] = SamplerParams{(uint32_t)d.offset, d.length, (double)d.root_hz, sp.gain, sp.one_shot};
+    }
+    if (upload_soa(ctx, b->d_params, P)) return 1;
+    if (upload_soa(ctx, b->d_state, S)) return 1;
+  }
+  b->pending.clear();
+  return 0;
+}
+
+int bank_alloc(groove_bank* b) {
+  groove_ctx* ctx = b->ctx;
+  GHIP(ctx, hipSetDevice(ctx->device));
+  GHIP(ctx, hipMalloc(&b->d_params, (size_t)b->pw * b->n * 4));
+  GHIP(ctx, hipMalloc(&b->d_state, (size_t)b->sw * b->n * 4));
+  return 0;
+}
+
+// Launch one note-event round resident at ev[0..count) on the device.
+int launch_events(groove_bank* b, const groove_note_event* ev, uint32_t count, int all_event) {
+  groove_ctx* ctx = b->ctx;
+  const uint32_t items = all_event >= 0 ? b->n : count;
+  const dim3 grid(blocks_for(items)), blk(kThreads);
+  if (b->kind == BANK_WELSH)
+    hipLaunchKernelGGL(welsh_events_kernel, grid, blk, 0, ctx->stream, ev, count, all_event, b->d_params,
+                       b->d_state, b->d_cold, b->n, (double)ctx->sr);
+  else if (b->kind == BANK_FM)
+    hipLaunchKernelGGL(fm_events_kernel, grid, blk, 0, ctx->stream, ev, count, all_event, b->d_params,
+                       b->d_state, b->d_cold, b->n, (double)ctx->sr);
+  else
+    hipLaunchKernelGGL(sampler_events_kernel, grid, blk, 0, ctx->stream, ev, count, all_event, b->d_params,
+                       b->d_state, b->n);
+  GHIP(ctx, hipGetLastError());
+  return 0;
+}
+
+// Apply queued events in order.  Events are cut into rounds in which every voice appears
+// at most once, so one thread per event is race-free and order is preserved across rounds.
+int flush_events(groove_bank* b) {
+  if (b->pending.empty()) return 0;
+  groove_ctx* ctx = b->ctx;
+  std::vector<groove_note_event>& ev = b->pending;
+  if (b->ev_cap < ev.size()) {
+    if (b->d_ev) GHIP(ctx, hipFree(b->d_ev));
+    b->ev_cap = std::max<size_t>(ev.size(), 1024);
+    GHIP(ctx, hipMalloc(&b->d_ev, b->ev_cap * sizeof(groove_note_event)));
+  }
+  GHIP(ctx, hipMemcpyAsync(b->d_ev, ev.data(), ev.size() * sizeof(groove_note_event), hipMemcpyHostToDevice, ctx->stream));
+  // fast path: strictly increasing voices, no ALL events → one round
+  bool sorted = true;
+  for (size_t i = 0; i < ev.size(); ++i) {
+    if (ev[i].voice == GROOVE_ALL_VOICES || (i && ev[i].voice <= ev[i - 1].voice)) { sorted = false; break; }
+  }
+  if (sorted) {
+    if (launch_events(b, b->d_ev, (uint32_t)ev.size(), -1)) return 1;
+  } else {
+    // general path: contiguous runs; a run ends at an ALL event or at a repeated voice
+    std::vector<uint32_t> seen_round(b->n, 0);
+    uint32_t round = 1;
+    size_t start = 0;
+    auto launch_run = [&](size_t lo, size_t hi) -> int {
+      if (hi <= lo) return 0;
+      return launch_events(b, b->d_ev + lo, (uint32_t)(hi - lo), -1);
+    };
+    for (size_t i = 0; i < ev.size(); ++i) {
+      if (ev[i].voice == GROOVE_ALL_VOICES) {
+        if (launch_run(start, i)) return 1;
+        if (launch_events(b, b->d_ev, (uint32_t)ev.size(), (int)i)) return 1;
+        start = i + 1; ++round;
+      } else if (ev[i].voice < b->n) {
+        if (seen_round[ev[i].voice] == round) {
+          if (launch_run(start, i)) return 1;
+          start = i; ++round;
+        }
+        seen_round[ev[i].voice] = round;
+      }
+    }
+    if (launch_run(start, ev.size())) return 1;
+  }
+  GHIP(ctx, hipStreamSynchronize(ctx->stream)); // host vector is about to be cleared
+  ev.clear();
+  return 0;
+}
+
+int ensure_partial(groove_ctx* ctx, size_t floats) {
+  if (ctx->partial_cap >= floats) return 0;
+  if (ctx->d_partial) GHIP(ctx, hipFree(ctx->d_partial));
+  GHIP(ctx, hipMalloc(&ctx->d_partial, floats * 4));
+  ctx->partial_cap = floats;
+  return 0;
+}
+
+constexpr uint32_t kMixSeg = 16384; // floats of one row summed by one workgroup
+
+int mix_one(groove_ctx* ctx, const groove_block* b, uint32_t frames, float* bus, int accumulate) {
+  const uint32_t n_seg = (b->n + kMixSeg - 1) / kMixSeg;
+  const uint32_t rows = 2 * frames;
+  if (ensure_partial(ctx, (size_t)rows * n_seg)) return 1;
+  hipLaunchKernelGGL(mix_partial_kernel, dim3(n_seg, rows), dim3(kThreads), 0, ctx->stream, b->d, b->n, frames,
+                     (size_t)b->cap * b->n, kMixSeg, ctx->d_partial, n_seg);
+  hipLaunchKernelGGL(mix_final_kernel, dim3(blocks_for(rows)), dim3(kThreads), 0, ctx->stream, ctx->d_partial,
+                     frames, n_seg, bus, accumulate);
+  GHIP(ctx, hipGetLastError());
+  return 0;
+}
+
+// ---- effects -------------------------------------------------------------------------
+int fx_upload_params(groove_fx* fx) {
+  groove_ctx* ctx = fx->ctx;
+  const uint32_t n = fx->n;
+  const double sr = ctx->sr;
+  std::vector<float> fa(n), fb(n), wet(n);
+  std::vector<uint32_t> ua(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    const groove_fx_params& p = fx->p[i];
+    wet[i] = p.wet;
+    ua[i] = p.bits > 31 ? 31 : p.bits;
+    switch (fx->kind) {
+      case GROOVE_FX_GAIN: fa[i] = p.ceiling; break;
+      case GROOVE_FX_LIMITER:
+      case GROOVE_FX_COMPRESSOR: fa[i] = p.limit_min; fb[i] = p.limit_max; break;
+      case GROOVE_FX_REVERB: fa[i] = p.attenuation; break;
+      default: break;
+    }
+  }
+  GHIP(ctx, hipMemcpy(fx->d_fa, fa.data(), n * 4, hipMemcpyHostToDevice));
+  GHIP(ctx, hipMemcpy(fx->d_fb, fb.data(), n * 4, hipMemcpyHostToDevice));
+  GHIP(ctx, hipMemcpy(fx->d_ua, ua.data(), n * 4, hipMemcpyHostToDevice));
+  GHIP(ctx, hipMemcpy(fx->d_wet, wet.data(), n * 4, hipMemcpyHostToDevice));
+  if (fx->kind == GROOVE_FX_BIQUAD_LP12 || fx->kind == GROOVE_FX_BIQUAD_HP12) {
+    std::vector<double> c((size_t)5 * n);
+    for (uint32_t i = 0; i < n; ++i) {
+      double c5[5];
+      if (fx->kind == GROOVE_FX_BIQUAD_LP12) rbj_lowpass_h(fx->p[i].cutoff_hz, fx->p[i].q, sr, c5);
+      else rbj_highpass_h(fx->p[i].cutoff_hz, fx->p[i].q, sr, c5);
+      for (int k = 0; k < 5; ++k) c[(size_t)k * n + i] = c5[k];
+    }
+    GHIP(ctx, hipMemcpy(fx->d_coef, c.data(), c.size() * 8, hipMemcpyHostToDevice));
+  } else if (fx->kind == GROOVE_FX_BIQUAD_LP24) {
+    std::vector<double> c((size_t)6 * n);
+    for (uint32_t i = 0; i < n; ++i) {
+      double c6[6];
+      lp24_coeffs_h(fx->p[i].cutoff_hz, fx->p[i].passband_ripple, sr, c6);
+      for (int k = 0; k < 6; ++k) c[(size_t)k * n + i] = c6[k];
+    }
+    GHIP(ctx, hipMemcpy(fx->d_coef, c.data(), c.size() * 8, hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+int fx_setup_state(groove_fx* fx) { // (re)allocate and zero state for the current sample rate
+  groove_ctx* ctx = fx->ctx;
+  const uint32_t n = fx->n;
+  const double sr = ctx->sr;
+  const size_t ln = 2 * (size_t)n;
+  if (fx->d_st) { GHIP(ctx, hipFree(fx->d_st)); fx->d_st = nullptr; }
+  if (fx->d_ring) { GHIP(ctx, hipFree(fx->d_ring)); fx->d_ring = nullptr; }
+  fx->ring_rows = 0; fx->w = 0;
+  const groove_fx_params& p0 = fx->p[0];
+  switch (fx->kind) {
+    case GROOVE_FX_BIQUAD_LP12:
+    case GROOVE_FX_BIQUAD_HP12:
+    case GROOVE_FX_BIQUAD_LP24:
+      GHIP(ctx, hipMalloc(&fx->d_st, 4 * ln * 8));
+      GHIP(ctx, hipMemset(fx->d_st, 0, 4 * ln * 8));
+      break;
+    case GROOVE_FX_DELAY:
+      fx->N = delay_frames_h(p0.delay_seconds, sr);
+      fx->ring_rows = fx->N;
+      break;
+    case GROOVE_FX_CHORUS:
+      fx->N = delay_frames_h(p0.delay_seconds, sr);
+      fx->voices = p0.voices < 1 ? 1 : p0.voices;
+      fx->spacing = fx->N / fx->voices;
+      fx->ring_rows = fx->N;
+      break;
+    case GROOVE_FX_REVERB: {
+      uint64_t base = 0;
+      for (int i = 0; i < 6; ++i) {
+        const double d = i < 4 ? kCombDelaysH[i] : kAllpassDelaysH[i - 4];
+        fx->geo.N[i] = delay_frames_h(d, sr);
+        fx->geo.w[i] = 0;
+        fx->geo.base[i] = base;
+        fx->geo.g[i] = (float)(i < 4 ? decay_gain_h(d, p0.reverb_seconds) : decay_gain_h(d, kAllpassDecaysH[i - 4]));
+        base += fx->geo.N[i];
+      }
+      fx->ring_rows = base;
+      break;
+    }
+    default: break;
+  }
+  if (fx->ring_rows) {
+    GHIP(ctx, hipMalloc(&fx->d_ring, fx->ring_rows * ln * 4));
+    GHIP(ctx, hipMemset(fx->d_ring, 0, fx->ring_rows * ln * 4));
+  }
+  return 0;
+}
+
+int fx_check_uniform(groove_fx* fx) {
+  const groove_fx_params& a = fx->p[0];
+  for (uint32_t i = 1; i < fx->n; ++i) {
+    const groove_fx_params& b = fx->p[i];
+    if ((fx->kind == GROOVE_FX_CHORUS && (a.voices != b.voices || a.delay_seconds != b.delay_seconds)) ||
+        (fx->kind == GROOVE_FX_DELAY && a.delay_seconds != b.delay_seconds) ||
+        (fx->kind == GROOVE_FX_REVERB && a.reverb_seconds != b.reverb_seconds))
+      return fail(fx->ctx, "groove_fx: delay-line geometry (voices / delay_seconds / reverb_seconds) must be uniform across the lanes of one effect bank");
+  }
+  return 0;
+}
+
+// ---- RCCL via dlopen -----------------------------------------------------------------
+typedef int (*nccl_get_uid_t)(void*);
+struct UidBlob { char b[128]; };
+typedef int (*nccl_init_rank_fn)(void**, int, UidBlob, int);
+typedef int (*nccl_reduce_fn)(const void*, void*, size_t, int, int, int, void*, hipStream_t);
+typedef int (*nccl_destroy_fn)(void*);
+typedef const char* (*nccl_errstr_fn)(int);
+
+int rccl_open(groove_ctx* ctx) {
+  if (ctx->rccl) return 0;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* nm : names) {
+    ctx->rccl = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (ctx->rccl) return 0;
+  }
+  return fail(ctx, std::string("dlopen(librccl) failed: ") + dlerror());
+}
+
+} // namespace
+
+extern "C" {
+
+// ============================================================================ context
+int groove_init(int device_ordinal, groove_ctx** out) {
+  if (!out) return fail(nullptr, "groove_init: out is NULL");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(nullptr, std::string("groove_init: no HIP device available (") + hipGetErrorString(e) +
+                             "); this library has no CPU path");
+  if (device_ordinal < 0 || device_ordinal >= count) return fail(nullptr, "groove_init: bad device ordinal");
+  groove_ctx* ctx = new (std::nothrow) groove_ctx();
+  if (!ctx) return fail(nullptr, "groove_init: out of memory");
+  ctx->device = device_ordinal;
+  if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return fail(nullptr, "groove_init: hipSetDevice/hipStreamCreate failed");
+  }
+  *out = ctx;
+  return 0;
+}
+void groove_shutdown(groove_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  while (!ctx->banks.empty()) groove_bank_destroy(ctx->banks.back());
+  while (!ctx->fxs.empty()) groove_fx_destroy(ctx->fxs.back());
+  groove_comm_destroy(ctx);
+  if (ctx->d_partial) hipFree(ctx->d_partial);
+  if (ctx->d_i16) hipFree(ctx->d_i16);
+  if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+const char* groove_last_error(groove_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+int groove_set_stream(groove_ctx* ctx, void* hip_stream) {
+  if (!ctx) return fail(nullptr, "groove_set_stream: ctx is NULL");
+  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->own_stream && ctx->stream) GHIP(ctx, hipStreamDestroy(ctx->stream));
+  ctx->stream = (hipStream_t)hip_stream;
+  ctx->own_stream = false;
+  return 0;
+}
+int groove_synchronize(groove_ctx* ctx) {
+  if (!ctx) return fail(nullptr, "groove_synchronize: ctx is NULL");
+  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+uint32_t groove_sample_rate(groove_ctx* ctx) { return ctx ? ctx->sr : 0; }
+int groove_update_sample_rate(groove_ctx* ctx, uint32_t hz) {
+  if (!ctx) return fail(nullptr, "groove_update_sample_rate: ctx is NULL");
+  if (hz < 1000 || hz > 768000) return fail(ctx, "groove_update_sample_rate: unsupported rate");
+  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->sr = hz;
+  for (groove_bank* b : ctx->banks)
+    if (bank_derive_and_upload(b)) return 1;
+  for (groove_fx* fx : ctx->fxs) {
+    if (fx_setup_state(fx)) return 1;
+    if (fx_upload_params(fx)) return 1;
+  }
+  return 0;
+}
+int groove_event_create(groove_ctx* ctx, void** out_event) {
+  if (!ctx || !out_event) return fail(ctx, "groove_event_create: NULL argument");
+  hipEvent_t ev;
+  GHIP(ctx, hipEventCreate(&ev));
+  *out_event = (void*)ev;
+  return 0;
+}
+int groove_event_destroy(groove_ctx* ctx, void* event) {
+  if (!ctx || !event) return fail(ctx, "groove_event_destroy: NULL argument");
+  GHIP(ctx, hipEventDestroy((hipEvent_t)event));
+  return 0;
+}
+int groove_event_record(groove_ctx* ctx, void* event) {
+  if (!ctx || !event) return fail(ctx, "groove_event_record: NULL argument");
+  GHIP(ctx, hipEventRecord((hipEvent_t)event, ctx->stream));
+  return 0;
+}
+int groove_event_elapsed_ms(groove_ctx* ctx, void* start, void* stop, float* out_ms) {
+  if (!ctx || !start || !stop || !out_ms) return fail(ctx, "groove_event_elapsed_ms: NULL argument");
+  GHIP(ctx, hipEventSynchronize((hipEvent_t)stop));
+  GHIP(ctx, hipEventElapsedTime(out_ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return 0;
+}
+
+// ============================================================================ blocks
+int groove_block_create(groove_ctx* ctx, uint32_t n, uint32_t frames_cap, groove_block** out) {
+  if (!ctx || !out) return fail(ctx, "groove_block_create: NULL argument");
+  if (n == 0 || frames_cap == 0) return fail(ctx, "groove_block_create: empty block");
+  GHIP(ctx, hipSetDevice(ctx->device));
+  groove_block* b = new groove_block{ctx, n, frames_cap, nullptr};
+  const size_t bytes = (size_t)2 * frames_cap * n * 4;
+  hipError_t e = hipMalloc(&b->d, bytes);
+  if (e != hipSuccess) { delete b; return fail(ctx, std::string("groove_block_create: hipMalloc: ") + hipGetErrorString(e)); }
+  hipMemsetAsync(b->d, 0, bytes, ctx->stream);
+  *out = b;
+  return 0;
+}
+int groove_block_destroy(groove_block* b) {
+  if (!b) return 0;
+  hipStreamSynchronize(b->ctx->stream);
+  hipFree(b->d);
+  delete b;
+  return 0;
+}
+float* groove_block_device_ptr(groove_block* b) { return b ? b->d : nullptr; }
+uint32_t groove_block_lanes(groove_block* b) { return b ? b->n : 0; }
+uint32_t groove_block_frames_cap(groove_block* b) { return b ? b->cap : 0; }
+int groove_block_upload(groove_block* b, const float* host, uint32_t frames) {
+  if (!b || !host) return fail(nullptr, "groove_block_upload: NULL argument");
+  groove_ctx* ctx = b->ctx;
+  if (frames > b->cap) return fail(ctx, "groove_block_upload: frames > capacity");
+  const size_t per = (size_t)frames * b->n;
+  for (int ch = 0; ch < 2; ++ch)
+    GHIP(ctx, hipMemcpyAsync(b->d + (size_t)ch * b->cap * b->n, host + ch * per, per * 4, hipMemcpyHostToDevice, ctx->stream));
+  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+int groove_block_download(groove_block* b, float* host, uint32_t frames) {
+  if (!b || !host) return fail(nullptr, "groove_block_download: NULL argument");
+  groove_ctx* ctx = b->ctx;
+  if (frames > b->cap) return fail(ctx, "groove_block_download: frames > capacity");
+  const size_t per = (size_t)frames * b->n;
+  for (int ch = 0; ch < 2; ++ch)
+    GHIP(ctx, hipMemcpyAsync(host + ch * per, b->d + (size_t)ch * b->cap * b->n, per * 4, hipMemcpyDeviceToHost, ctx->stream));
+  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// ============================================================================ instruments
+static int bank_finish_create(groove_bank* b, groove_bank** out) {
+  if (bank_alloc(b) || bank_derive_and_upload(b)) { groove_bank_destroy(b); return 1; }
+  b->ctx->banks.push_back(b);
+  *out = b;
+  return 0;
+}
+int groove_welsh_create(groove_ctx* ctx, const groove_welsh_params* p, uint32_t n, groove_bank** out) {
+  if (!ctx || !p || !out) return fail(ctx, "groove_welsh_create: NULL argument");
+  if (n == 0) return fail(ctx, "groove_welsh_create: n == 0");
+  groove_bank* b = new groove_bank();
+  b->ctx = ctx; b->kind = BANK_WELSH; b->n = n;
+  b->pw = sizeof(WelshParams) / 4; b->sw = sizeof(WelshState) / 4;
+  b->welsh.assign(p, p + n);
+  if (hipMalloc(&b->d_cold, (size_t)4 * n * 8) != hipSuccess) { delete b; return fail(ctx, "groove_welsh_create: hipMalloc failed"); }
+  return bank_finish_create(b, out);
+}
+int groove_fm_create(groove_ctx* ctx, const groove_fm_params* p, uint32_t n, groove_bank** out) {
+  if (!ctx || !p || !out) return fail(ctx, "groove_fm_create: NULL argument");
+  if (n == 0) return fail(ctx, "groove_fm_create: n == 0");
+  groove_bank* b = new groove_bank();
+  b->ctx = ctx; b->kind = BANK_FM; b->n = n;
+  b->pw = sizeof(FmParams) / 4; b->sw = sizeof(FmState) / 4;
+  b->fm.assign(p, p + n);
+  if (hipMalloc(&b->d_cold, (size_t)n * 8) != hipSuccess) { delete b; return fail(ctx, "groove_fm_create: hipMalloc failed"); }
+  return bank_finish_create(b, out);
+}
+int groove_sampler_create(groove_ctx* ctx, const float* bank_pcm, uint64_t bank_frames,
+                          const groove_sample_desc* descs, uint32_t n_samples,
+                          const groove_sampler_params* p, uint32_t n, groove_bank** out) {
+  if (!ctx || !bank_pcm || !descs || !p || !out) return fail(ctx, "groove_sampler_create: NULL argument");
+  if (n == 0 || n_samples == 0 || bank_frames == 0) return fail(ctx, "groove_sampler_create: empty bank");
+  if (bank_frames >= (1ull << 32)) return fail(ctx, "groove_sampler_create: bank too large");
+  for (uint32_t i = 0; i < n_samples; ++i) {
+    if (descs[i].offset + descs[i].length > bank_frames) return fail(ctx, "groove_sampler_create: sample descriptor exceeds bank");
+    if (descs[i].length >= (1u << 20)) return fail(ctx, "groove_sampler_create: sample longer than 2^20 frames");
+  }
+  for (uint32_t i = 0; i < n; ++i)
+    if (p[i].sample_index >= n_samples) return fail(ctx, "groove_sampler_create: sample_index out of range");
+  groove_bank* b = new groove_bank();
+  b->ctx = ctx; b->kind = BANK_SAMPLER; b->n = n;
+  b->pw = sizeof(SamplerParams) / 4; b->sw = sizeof(SamplerState) / 4;
+  b->sampler.assign(p, p + n);
+  b->descs.assign(descs, descs + n_samples);
+  if (hipMalloc(&b->d_pcm, bank_frames * 4) != hipSuccess) { delete b; return fail(ctx, "groove_sampler_create: hipMalloc failed"); }
+  if (hipMemcpy(b->d_pcm, bank_pcm, bank_frames * 4, hipMemcpyHostToDevice) != hipSuccess) { hipFree(b->d_pcm); delete b; return fail(ctx, "groove_sampler_create: upload failed"); }
+  return bank_finish_create(b, out);
+}
+int groove_bank_destroy(groove_bank* b) {
+  if (!b) return 0;
+  groove_ctx* ctx = b->ctx;
+  hipStreamSynchronize(ctx->stream);
+  auto it = std::find(ctx->banks.begin(), ctx->banks.end(), b);
+  if (it != ctx->banks.end()) ctx->banks.erase(it);
+  if (b->scratch) groove_block_destroy(b->scratch);
+  hipFree(b->d_params); hipFree(b->d_state); hipFree(b->d_cold); hipFree(b->d_pcm); hipFree(b->d_ev);
+  delete b;
+  return 0;
+}
+uint32_t groove_bank_voices(groove_bank* b) { return b ? b->n : 0; }
+int groove_bank_note_events(groove_bank* b, const groove_note_event* ev, uint32_t n_ev) {
+  if (!b) return fail(nullptr, "groove_bank_note_events: bank is NULL");
+  if (n_ev && !ev) return fail(b->ctx, "groove_bank_note_events: ev is NULL");
+  for (uint32_t i = 0; i < n_ev; ++i)
+    if (ev[i].voice != GROOVE_ALL_VOICES && ev[i].voice >= b->n)
+      return fail(b->ctx, "groove_bank_note_events: voice index out of range");
+  b->pending.insert(b->pending.end(), ev, ev + n_ev);
+  return 0;
+}
+int groove_bank_set_param(groove_bank* b, uint32_t voice, uint32_t control_index, double value01) {
+  if (!b) return fail(nullptr, "groove_bank_set_param: bank is NULL");
+  groove_ctx* ctx = b->ctx;
+  if (voice != GROOVE_ALL_VOICES && voice >= b->n) return fail(ctx, "groove_bank_set_param: voice out of range");
+  if (b->kind != BANK_WELSH) return fail(ctx, "groove_bank_set_param: only Welsh banks expose controls");
+  const double v01 = value01 < 0.0 ? 0.0 : (value01 > 1.0 ? 1.0 : value01);
+  const uint32_t lo = voice == GROOVE_ALL_VOICES ? 0 : voice, hi = voice == GROOVE_ALL_VOICES ? b->n : voice + 1;
+  auto set_word = [&](size_t byte_off, float val) -> int {
+    uint32_t bits; std::memcpy(&bits, &val, 4);
+    hipLaunchKernelGGL(set_word_kernel, dim3(voice == GROOVE_ALL_VOICES ? blocks_for(b->n) : 1), dim3(kThreads), 0,
+                       ctx->stream, b->d_params, b->n, (uint32_t)(byte_off / 4), voice, bits);
+    GHIP(ctx, hipGetLastError());
+    return 0;
+  };
+  switch (control_index) {
+    case GROOVE_CTL_WELSH_DCA_GAIN:
+    case GROOVE_CTL_WELSH_DCA_PAN: {
+      // per-voice pan differs, so recompute per voice unless a single voice / uniform pan
+      for (uint32_t v = lo; v < hi; ++v) {
+        if (control_index == GROOVE_CTL_WELSH_DCA_GAIN) b->welsh[v].dca_gain = (float)v01;
+        else b->welsh[v].dca_pan = (float)(v01 * 2.0 - 1.0); // ControlValue 0..1 → BipolarNormal
+      }
+      if (voice == GROOVE_ALL_VOICES) {
+        std::vector<float> gl(b->n), gr(b->n);
+        for (uint32_t v = 0; v < b->n; ++v) pan_gains(b->welsh[v].dca_gain, b->welsh[v].dca_pan, gl[v], gr[v]);
+        GHIP(ctx, hipStreamSynchronize(ctx->stream));
+        GHIP(ctx, hipMemcpy(b->d_params + (offsetof(WelshParams, gl) / 4) * (size_t)b->n, gl.data(), b->n * 4, hipMemcpyHostToDevice));
+        GHIP(ctx, hipMemcpy(b->d_params + (offsetof(WelshParams, gr) / 4) * (size_t)b->n, gr.data(), b->n * 4, hipMemcpyHostToDevice));
+      } else {
+        float gl, gr;
+        pan_gains(b->welsh[voice].dca_gain, b->welsh[voice].dca_pan, gl, gr);
+        if (set_word(offsetof(WelshParams, gl), gl) || set_word(offsetof(WelshParams, gr), gr)) return 1;
+      }
+      return 0;
+    }
+    case GROOVE_CTL_WELSH_CUTOFF: {
+      const float hz = (float)percent_to_frequency_h(v01);
+      for (uint32_t v = lo; v < hi; ++v) b->welsh[v].filter_cutoff_hz = hz;
+      return set_word(offsetof(WelshParams, cutoff_hz), hz);
+    }
+    default: return fail(ctx, "groove_bank_set_param: unknown control index");
+  }
+}
+int groove_bank_render(groove_bank* b, uint32_t frames, groove_block* out) {
+  if (!b || !out) return fail(nullptr, "groove_bank_render: NULL argument");
+  groove_ctx* ctx = b->ctx;
+  if (out->n != b->n) return fail(ctx, "groove_bank_render: block lanes != bank voices");
+  if (frames > out->cap) return fail(ctx, "groove_bank_render: frames > block capacity");
+  if (frames == 0) return 0;
+  GHIP(ctx, hipSetDevice(ctx->device));
+  if (flush_events(b)) return 1;
+  const dim3 grid(blocks_for(b->n)), blk(kThreads);
+  const size_t chs = (size_t)out->cap * out->n;
+  if (b->kind == BANK_WELSH) {
+    RenderConsts rc{(float)(3.14159265358979323846 / ctx->sr), (float)(0.49 * ctx->sr)};
+    hipLaunchKernelGGL(welsh_render_kernel, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out->d, rc);
+  } else if (b->kind == BANK_FM) {
+    hipLaunchKernelGGL(fm_render_kernel, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out->d);
+  } else {
+    hipLaunchKernelGGL(sampler_render_kernel, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out->d, b->d_pcm);
+  }
+  GHIP(ctx, hipGetLastError());
+  return 0;
+}
+int groove_bank_render_mix(groove_bank* b, uint32_t frames, float* bus_dev, int accumulate) {
+  if (!b || !bus_dev) return fail(nullptr, "groove_bank_render_mix: NULL argument");
+  groove_ctx* ctx = b->ctx;
+  if (frames > GROOVE_BLOCK_FRAMES) return fail(ctx, "groove_bank_render_mix: frames > 256");
+  if (!b->scratch && groove_block_create(ctx, b->n, GROOVE_BLOCK_FRAMES, &b->scratch)) return 1;
+  if (groove_bank_render(b, frames, b->scratch)) return 1;
+  return mix_one(ctx, b->scratch, frames, bus_dev, accumulate);
+}
+uint32_t groove_bank_state_words(groove_bank* b) { return b ? b->sw : 0; }
+int groove_bank_download_state(groove_bank* b, uint32_t* host_words) {
+  if (!b || !host_words) return fail(nullptr, "groove_bank_download_state: NULL argument");
+  groove_ctx* ctx = b->ctx;
+  if (flush_events(b)) return 1;
+  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  GHIP(ctx, hipMemcpy(host_words, b->d_state, (size_t)b->sw * b->n * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ============================================================================ effects
+int groove_fx_create(groove_ctx* ctx, uint32_t kind, const groove_fx_params* p, uint32_t n, groove_fx** out) {
+  if (!ctx || !p || !out) return fail(ctx, "groove_fx_create: NULL argument");
+  if (n == 0) return fail(ctx, "groove_fx_create: n == 0");
+  if (kind > GROOVE_FX_COMPRESSOR) return fail(ctx, "groove_fx_create: unknown effect kind");
+  GHIP(ctx, hipSetDevice(ctx->device));
+  groove_fx* fx = new groove_fx();
+  fx->ctx = ctx; fx->kind = kind; fx->n = n;
+  fx->p.assign(p, p + n);
+  if (fx_check_uniform(fx)) { delete fx; return 1; }
+  if (hipMalloc(&fx->d_fa, n * 4) != hipSuccess || hipMalloc(&fx->d_fb, n * 4) != hipSuccess ||
+      hipMalloc(&fx->d_ua, n * 4) != hipSuccess || hipMalloc(&fx->d_wet, n * 4) != hipSuccess ||
+      hipMalloc(&fx->d_coef, (size_t)6 * n * 8) != hipSuccess) {
+    groove_fx_destroy(fx);
+    return fail(ctx, "groove_fx_create: hipMalloc failed");
+  }
+  if (fx_setup_state(fx) || fx_upload_params(fx)) { groove_fx_destroy(fx); return 1; }
+  ctx->fxs.push_back(fx);
+  *out = fx;
+  return 0;
+}
+int groove_fx_destroy(groove_fx* fx) {
+  if (!fx) return 0;
+  groove_ctx* ctx = fx->ctx;
+  hipStreamSynchronize(ctx->stream);
+  auto it = std::find(ctx->fxs.begin(), ctx->fxs.end(), fx);
+  if (it != ctx->fxs.end()) ctx->fxs.erase(it);
+  hipFree(fx->d_fa); hipFree(fx->d_fb); hipFree(fx->d_ua); hipFree(fx->d_wet);
+  hipFree(fx->d_coef); hipFree(fx->d_st); hipFree(fx->d_ring);
+  delete fx;
+  return 0;
+}
+int groove_fx_process(groove_fx* fx, groove_block* io, uint32_t frames) {
+  if (!fx || !io) return fail(nullptr, "groove_fx_process: NULL argument");
+  groove_ctx* ctx = fx->ctx;
+  if (io->n != fx->n) return fail(ctx, "groove_fx_process: block lanes != effect lanes");
+  if (frames > io->cap) return fail(ctx, "groove_fx_process: frames > block capacity");
+  if (frames == 0) return 0;
+  GHIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t n = fx->n;
+  const size_t chs = (size_t)io->cap * n;
+  const dim3 blk(kThreads), lanes_grid(blocks_for(2 * (size_t)n));
+  switch (fx->kind) {
+    case GROOVE_FX_MIXER: return 0; // identity
+    case GROOVE_FX_GAIN:
+    case GROOVE_FX_BITCRUSHER:
+    case GROOVE_FX_LIMITER:
+    case GROOVE_FX_COMPRESSOR: {
+      const size_t total = (size_t)2 * frames * n;
+      const uint32_t g = (uint32_t)std::min<size_t>(blocks_for(total), 256 * 16);
+      hipLaunchKernelGGL(fx_elementwise_kernel, dim3(g), blk, 0, ctx->stream, fx->kind, io->d, n, frames, chs,
+                         fx->d_fa, fx->d_fb, fx->d_ua, fx->d_wet);
+      break;
+    }
+    case GROOVE_FX_BIQUAD_LP12:
+    case GROOVE_FX_BIQUAD_HP12:
+      hipLaunchKernelGGL(fx_biquad_kernel, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+      break;
+    case GROOVE_FX_BIQUAD_LP24:
+      hipLaunchKernelGGL(fx_lp24_kernel, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+      break;
+    case GROOVE_FX_DELAY:
+      hipLaunchKernelGGL(fx_delay_kernel, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->N, fx->w, fx->d_wet);
+      fx->w = (uint32_t)(((uint64_t)fx->w + frames) % fx->N);
+      break;
+    case GROOVE_FX_CHORUS:
+      hipLaunchKernelGGL(fx_chorus_kernel, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->N, fx->w,
+                         fx->voices, fx->spacing, fx->d_wet);
+      fx->w = (uint32_t)(((uint64_t)fx->w + frames) % fx->N);
+      break;
+    case GROOVE_FX_REVERB:
+      hipLaunchKernelGGL(fx_reverb_kernel, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->geo, fx->d_fa, fx->d_wet);
+      for (int i = 0; i < 6; ++i) fx->geo.w[i] = (uint32_t)(((uint64_t)fx->geo.w[i] + frames) % fx->geo.N[i]);
+      break;
+    default: return fail(ctx, "groove_fx_process: unknown kind");
+  }
+  GHIP(ctx, hipGetLastError());
+  return 0;
+}
+int groove_fx_set_params(groove_fx* fx, const groove_fx_params* p, uint32_t n) {
+  if (!fx || !p) return fail(nullptr, "groove_fx_set_params: NULL argument");
+  groove_ctx* ctx = fx->ctx;
+  if (n != fx->n) return fail(ctx, "groove_fx_set_params: n != lanes");
+  std::vector<groove_fx_params> old = fx->p;
+  fx->p.assign(p, p + n);
+  const groove_fx_params &a = old[0], &b = fx->p[0];
+  if (fx_check_uniform(fx) ||
+      ((fx->kind == GROOVE_FX_CHORUS || fx->kind == GROOVE_FX_DELAY) && (a.delay_seconds != b.delay_seconds || (fx->kind == GROOVE_FX_CHORUS && a.voices != b.voices))) ||
+      (fx->kind == GROOVE_FX_REVERB && a.reverb_seconds != b.reverb_seconds)) {
+    fx->p = old;
+    return fail(ctx, "groove_fx_set_params: delay-line geometry cannot change after creation");
+  }
+  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  return fx_upload_params(fx);
+}
+int groove_fx_set_param(groove_fx* fx, uint32_t lane, uint32_t control_index, double value01) {
+  if (!fx) return fail(nullptr, "groove_fx_set_param: fx is NULL");
+  groove_ctx* ctx = fx->ctx;
+  if (lane != GROOVE_ALL_VOICES && lane >= fx->n) return fail(ctx, "groove_fx_set_param: lane out of range");
+  const double v = value01 < 0.0 ? 0.0 : (value01 > 1.0 ? 1.0 : value01);
+  const uint32_t lo = lane == GROOVE_ALL_VOICES ? 0 : lane, hi = lane == GROOVE_ALL_VOICES ? fx->n : lane + 1;
+  for (uint32_t i = lo; i < hi; ++i) {
+    groove_fx_params& p = fx->p[i];
+    switch (control_index) {
+      case GROOVE_CTL_FX_CEILING: p.ceiling = (float)v; break;
+      case GROOVE_CTL_FX_BITS: p.bits = (uint32_t)(v * 16.0); break;
+      case GROOVE_CTL_FX_CUTOFF: p.cutoff_hz = (float)percent_to_frequency_h(v); break;
+      case GROOVE_CTL_FX_Q: p.q = (float)(v * v * 10.0 + 0.707); break; /* denormalize_q */
+      case GROOVE_CTL_FX_PASSBAND_RIPPLE: p.passband_ripple = (float)(v * v * 10.0 + 0.707); break;
+      case GROOVE_CTL_FX_ATTENUATION: p.attenuation = (float)v; break;
+      case GROOVE_CTL_FX_WET: p.wet = (float)v; break;
+      default: return fail(ctx, "groove_fx_set_param: unknown control index");
+    }
+  }
+  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  return fx_upload_params(fx);
+}
+
+// ============================================================================ mix bus
+int groove_mix(groove_ctx* ctx, groove_block* const* blocks, uint32_t n_blocks, uint32_t frames,
+               float* bus_dev, int accumulate) {
+  if (!ctx || !bus_dev) return fail(ctx, "groove_mix: NULL argument");
+  if (n_blocks && !blocks) return fail(ctx, "groove_mix: blocks is NULL");
+  if (frames == 0) return 0;
+  GHIP(ctx, hipSetDevice(ctx->device));
+  if (n_blocks == 0) { // nothing patched: silence (orchestrator.rs:1452-1455)
+    if (!accumulate) GHIP(ctx, hipMemsetAsync(bus_dev, 0, (size_t)frames * 8, ctx->stream));
+    return 0;
+  }
+  for (uint32_t i = 0; i < n_blocks; ++i) {
+    if (!blocks[i]) return fail(ctx, "groove_mix: NULL block");
+    if (frames > blocks[i]->cap) return fail(ctx, "groove_mix: frames > block capacity");
+    if (mix_one(ctx, blocks[i], frames, bus_dev, accumulate || i > 0)) return 1;
+  }
+  return 0;
+}
+int groove_bus_create(groove_ctx* ctx, size_t frames, float** out_dev) {
+  if (!ctx || !out_dev) return fail(ctx, "groove_bus_create: NULL argument");
+  GHIP(ctx, hipSetDevice(ctx->device));
+  GHIP(ctx, hipMalloc(out_dev, std::max<size_t>(frames, 1) * 8));
+  GHIP(ctx, hipMemset(*out_dev, 0, std::max<size_t>(frames, 1) * 8));
+  return 0;
+}
+int groove_bus_destroy(groove_ctx* ctx, float* bus_dev) {
+  if (!ctx) return fail(nullptr, "groove_bus_destroy: ctx is NULL");
+  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  GHIP(ctx, hipFree(bus_dev));
+  return 0;
+}
+int groove_bus_zero(groove_ctx* ctx, float* bus_dev, size_t frames) {
+  if (!ctx || !bus_dev) return fail(ctx, "groove_bus_zero: NULL argument");
+  GHIP(ctx, hipMemsetAsync(bus_dev, 0, frames * 8, ctx->stream));
+  return 0;
+}
+int groove_download(groove_ctx* ctx, const float* dev, float* host, size_t n_floats) {
+  if (!ctx || !dev || !host) return fail(ctx, "groove_download: NULL argument");
+  GHIP(ctx, hipMemcpyAsync(host, dev, n_floats * 4, hipMemcpyDeviceToHost, ctx->stream));
+  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+int groove_upload(groove_ctx* ctx, float* dev, const float* host, size_t n_floats) {
+  if (!ctx || !dev || !host) return fail(ctx, "groove_upload: NULL argument");
+  GHIP(ctx, hipMemcpyAsync(dev, host, n_floats * 4, hipMemcpyHostToDevice, ctx->stream));
+  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+int groove_bus_to_i16(groove_ctx* ctx, const float* bus_dev, size_t frames, int16_t* host_out) {
+  if (!ctx || !bus_dev || !host_out) return fail(ctx, "groove_bus_to_i16: NULL argument");
+  const size_t count = frames * 2;
+  if (count == 0) return 0;
+  if (ctx->i16_cap < count) {
+    if (ctx->d_i16) GHIP(ctx, hipFree(ctx->d_i16));
+    GHIP(ctx, hipMalloc(&ctx->d_i16, count * 2));
+    ctx->i16_cap = count;
+  }
+  hipLaunchKernelGGL(bus_to_i16_kernel, dim3(blocks_for(count)), dim3(kThreads), 0, ctx->stream, bus_dev, count, ctx->d_i16);
+  GHIP(ctx, hipGetLastError());
+  GHIP(ctx, hipMemcpyAsync(host_out, ctx->d_i16, count * 2, hipMemcpyDeviceToHost, ctx->stream));
+  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// ============================================================================ multi-GPU
+int groove_comm_unique_id(groove_ctx* ctx, uint8_t id_out[128]) {
+  if (!ctx || !id_out) return fail(ctx, "groove_comm_unique_id: NULL argument");
+  if (rccl_open(ctx)) return 1;
+  auto f = (nccl_get_uid_t)dlsym(ctx->rccl, "ncclGetUniqueId");
+  if (!f) return fail(ctx, "ncclGetUniqueId not found");
+  const int rc = f(id_out);
+  if (rc != 0) return fail(ctx, "ncclGetUniqueId failed");
+  return 0;
+}
+int groove_comm_init(groove_ctx* ctx, const uint8_t id[128], int rank, int world_size) {
+  if (!ctx || !id) return fail(ctx, "groove_comm_init: NULL argument");
+  if (world_size < 1 || rank < 0 || rank >= world_size) return fail(ctx, "groove_comm_init: bad rank/world");
+  if (rccl_open(ctx)) return 1;
+  GHIP(ctx, hipSetDevice(ctx->device));
+  auto f = (nccl_init_rank_fn)dlsym(ctx->rccl, "ncclCommInitRank");
+  if (!f) return fail(ctx, "ncclCommInitRank not found");
+  UidBlob blob;
+  std::memcpy(blob.b, id, 128);
+  void* comm = nullptr;
+  const int rc = f(&comm, world_size, blob, rank);
+  if (rc != 0) {
+    auto es = (nccl_errstr_fn)dlsym(ctx->rccl, "ncclGetErrorString");
+    return fail(ctx, std::string("ncclCommInitRank failed: ") + (es ? es(rc) : "?"));
+  }
+  ctx->comm = comm; ctx->rank = rank; ctx->world = world_size;
+  return 0;
+}
+int groove_comm_destroy(groove_ctx* ctx) {
+  if (!ctx || !ctx->comm) return 0;
+  auto f = (nccl_destroy_fn)dlsym(ctx->rccl, "ncclCommDestroy");
+  if (f) f(ctx->comm);
+  ctx->comm = nullptr;
+  return 0;
+}
+int groove_bus_reduce(groove_ctx* ctx, float* bus_dev, size_t frames_total, int root) {
+  if (!ctx || !bus_dev) return fail(ctx, "groove_bus_reduce: NULL argument");
+  if (ctx->world == 1 && !ctx->comm) return 0; // single GPU: the bus is already complete
+  if (!ctx->comm) return fail(ctx, "groove_bus_reduce: communicator not initialised");
+  auto f = (nccl_reduce_fn)dlsym(ctx->rccl, "ncclReduce");
+  if (!f) return fail(ctx, "ncclReduce not found");
+  // ncclFloat32 = 7, ncclSum = 0; in-place on root
+  const int rc = f(bus_dev, bus_dev, frames_total * 2, 7, 0, root, ctx->comm, ctx->stream);
+  if (rc != 0) {
+    auto es = (nccl_errstr_fn)dlsym(ctx->rccl, "ncclGetErrorString");
+    return fail(ctx, std::string("ncclReduce failed: ") + (es ? es(rc) : "?"));
+  }
+  return 0;
+}
+
+} // extern "C"

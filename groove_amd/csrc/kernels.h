@@ -1,0 +1,381 @@
+// kernels.h — HIP kernels of the render path (gfx950 / CDNA4, wave64).
+//
+// Mapping: one voice (instrument kernels) or one effect channel (IIR /
+// delay-line kernels) per lane; the frame axis of a block is walked sequentially inside
+// the lane with all state in registers, because the oscillator phase, envelope and IIR
+// recurrences serialise time.  Every per-frame global access is `base + f*n + lane`, so a
+// wavefront touches 64 consecutive floats (256 B) per instruction.  Per-lane parameters and
+// state live in "word-major SoA" buffers: word w of lane v at buf[w*n + v], loaded once
+// per block into registers and (state only) written back once.
+//
+// No MFMA: nothing here is a contraction.  The instrument kernels are VALU-bound (see
+// DESIGN.md §5 for the op budget), the effect and mix kernels HBM-bound.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dsp_core.h"
+#include "derive.h"
+
+namespace groove {
+
+template <class T> struct WordsOf { uint32_t w[sizeof(T) / 4]; };
+
+template <class T>
+__device__ __forceinline__ T soa_load(const uint32_t* __restrict__ buf, uint32_t n, uint32_t v) {
+  static_assert(sizeof(T) % 4 == 0, "word-major SoA needs 4-byte multiples");
+  WordsOf<T> t;
+#pragma unroll
+  for (uint32_t i = 0; i < sizeof(T) / 4; ++i) t.w[i] = buf[(size_t)i * n + v];
+  return __builtin_bit_cast(T, t);
+}
+template <class T>
+__device__ __forceinline__ void soa_store(uint32_t* __restrict__ buf, uint32_t n, uint32_t v, const T& x) {
+  const WordsOf<T> t = __builtin_bit_cast(WordsOf<T>, x);
+#pragma unroll
+  for (uint32_t i = 0; i < sizeof(T) / 4; ++i) buf[(size_t)i * n + v] = t.w[i];
+}
+
+constexpr int kThreads = 256;
+
+// ------------------------------------------------------------------ instruments
+// a5 WelshVoice: Ticks::tick(frames) + Generates::generate_batch_values.
+__global__ __launch_bounds__(kThreads) void welsh_render_kernel(
+    const uint32_t* __restrict__ params, uint32_t* __restrict__ state, uint32_t n, uint32_t frames,
+    size_t ch_stride, float* __restrict__ out, RenderConsts rc) {
+  const uint32_t v = blockIdx.x * kThreads + threadIdx.x;
+  if (v >= n) return;
+  const WelshParams p = soa_load<WelshParams>(params, n, v);
+  WelshState s = soa_load<WelshState>(state, n, v);
+  const Lp24Coef sc = lp24_coef_from_k(p.fc, lp24_k(p.cutoff_hz, rc.pi_over_sr, rc.fc_max));
+  float* __restrict__ oL = out + v;
+  float* __restrict__ oR = out + ch_stride + v;
+  for (uint32_t f = 0; f < frames; ++f) {
+    float L, R;
+    welsh_frame(p, s, rc, sc, L, R);
+    oL[(size_t)f * n] = L;
+    oR[(size_t)f * n] = R;
+  }
+  soa_store(state, n, v, s);
+}
+
+__global__ __launch_bounds__(kThreads) void fm_render_kernel(
+    const uint32_t* __restrict__ params, uint32_t* __restrict__ state, uint32_t n, uint32_t frames,
+    size_t ch_stride, float* __restrict__ out) {
+  const uint32_t v = blockIdx.x * kThreads + threadIdx.x;
+  if (v >= n) return;
+  const FmParams p = soa_load<FmParams>(params, n, v);
+  FmState s = soa_load<FmState>(state, n, v);
+  float* __restrict__ oL = out + v;
+  float* __restrict__ oR = out + ch_stride + v;
+  for (uint32_t f = 0; f < frames; ++f) {
+    float L, R;
+    fm_frame(p, s, L, R);
+    oL[(size_t)f * n] = L;
+    oR[(size_t)f * n] = R;
+  }
+  soa_store(state, n, v, s);
+}
+
+// a7 SamplerVoice: pointer stepping; the shared bank is a gather served from L2 / MALL.
+__global__ __launch_bounds__(kThreads) void sampler_render_kernel(
+    const uint32_t* __restrict__ params, uint32_t* __restrict__ state, uint32_t n, uint32_t frames,
+    size_t ch_stride, float* __restrict__ out, const float* __restrict__ bank) {
+  const uint32_t v = blockIdx.x * kThreads + threadIdx.x;
+  if (v >= n) return;
+  const SamplerParams p = soa_load<SamplerParams>(params, n, v);
+  SamplerState s = soa_load<SamplerState>(state, n, v);
+  float* __restrict__ oL = out + v;
+  float* __restrict__ oR = out + ch_stride + v;
+  for (uint32_t f = 0; f < frames; ++f) {
+    const float x = sampler_frame(p, s, bank);
+    oL[(size_t)f * n] = x; // mono duplicated to both channels
+    oR[(size_t)f * n] = x;
+  }
+  soa_store(state, n, v, s);
+}
+
+// HandlesMidi: one thread per event (voice != ALL) or one thread per voice (voice == ALL).
+struct NoteCtx { double sr; };
+__global__ void welsh_events_kernel(const groove_note_event* __restrict__ ev, uint32_t n_ev, int all_event,
+                                    const uint32_t* __restrict__ params, uint32_t* __restrict__ state,
+                                    const double* __restrict__ cold /*[4][n]*/, uint32_t n, double sr) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  groove_note_event e;
+  uint32_t v;
+  if (all_event >= 0) { if (i >= n) return; e = ev[all_event]; v = i; }
+  else { if (i >= n_ev) return; e = ev[i]; v = e.voice; if (v >= n) return; }
+  const WelshParams p = soa_load<WelshParams>(params, n, v);
+  WelshState s = soa_load<WelshState>(state, n, v);
+  welsh_note(p, s, cold[v], cold[(size_t)n + v], cold[(size_t)2 * n + v], cold[(size_t)3 * n + v], sr, e.key, e.on != 0);
+  soa_store(state, n, v, s);
+}
+__global__ void fm_events_kernel(const groove_note_event* __restrict__ ev, uint32_t n_ev, int all_event,
+                                 const uint32_t* __restrict__ params, uint32_t* __restrict__ state,
+                                 const double* __restrict__ ratio, uint32_t n, double sr) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  groove_note_event e;
+  uint32_t v;
+  if (all_event >= 0) { if (i >= n) return; e = ev[all_event]; v = i; }
+  else { if (i >= n_ev) return; e = ev[i]; v = e.voice; if (v >= n) return; }
+  const FmParams p = soa_load<FmParams>(params, n, v);
+  FmState s = soa_load<FmState>(state, n, v);
+  fm_note(p, s, ratio[v], sr, e.key, e.on != 0);
+  soa_store(state, n, v, s);
+}
+__global__ void sampler_events_kernel(const groove_note_event* __restrict__ ev, uint32_t n_ev, int all_event,
+                                      const uint32_t* __restrict__ params, uint32_t* __restrict__ state, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  groove_note_event e;
+  uint32_t v;
+  if (all_event >= 0) { if (i >= n) return; e = ev[all_event]; v = i; }
+  else { if (i >= n_ev) return; e = ev[i]; v = e.voice; if (v >= n) return; }
+  const SamplerParams p = soa_load<SamplerParams>(params, n, v);
+  SamplerState s = soa_load<SamplerState>(state, n, v);
+  sampler_note(p, s, e.key, e.on != 0);
+  soa_store(state, n, v, s);
+}
+// Controllable: set one 32-bit word of the SoA for one lane or all lanes.
+__global__ void set_word_kernel(uint32_t* __restrict__ buf, uint32_t n, uint32_t word, uint32_t lane, uint32_t value) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lane == GROOVE_ALL_VOICES) { if (i < n) buf[(size_t)word * n + i] = value; }
+  else if (i == 0 && lane < n) buf[(size_t)word * n + lane] = value;
+}
+
+// ------------------------------------------------------------------ mix bus (a15)
+// Stage 1: grid (segments, rows) with rows = 2*frames; each workgroup sums one segment of
+// one row of the block (row = one channel of one frame across all lanes) → partial[row][seg].
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+  return x;
+}
+__global__ __launch_bounds__(kThreads) void mix_partial_kernel(
+    const float* __restrict__ block, uint32_t n, uint32_t frames, size_t ch_stride, uint32_t seg_len,
+    float* __restrict__ partial, uint32_t n_seg) {
+  const uint32_t row = blockIdx.y; // ch*frames + f
+  const uint32_t seg = blockIdx.x;
+  const uint32_t ch = row / frames, f = row % frames;
+  const float* __restrict__ src = block + ch * ch_stride + (size_t)f * n;
+  const uint32_t lo = seg * seg_len;
+  const uint32_t hi = min(n, lo + seg_len);
+  float acc = 0.0f;
+  if ((n & 3u) == 0 && (seg_len & 3u) == 0) {
+    const float4* __restrict__ s4 = reinterpret_cast<const float4*>(src);
+    for (uint32_t i = lo / 4 + threadIdx.x; i < hi / 4; i += kThreads) {
+      const float4 q = s4[i];
+      acc += (q.x + q.y) + (q.z + q.w);
+    }
+  } else {
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += kThreads) acc += src[i];
+  }
+  acc = wave_sum(acc);
+  __shared__ float red[kThreads / 64];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kThreads / 64; ++i) t += red[i];
+    partial[(size_t)row * n_seg + seg] = t;
+  }
+}
+// Stage 2: bus[f][ch] (+)= sum_seg partial[row][seg]; one thread per row.
+__global__ void mix_final_kernel(const float* __restrict__ partial, uint32_t frames, uint32_t n_seg,
+                                 float* __restrict__ bus, int accumulate) {
+  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= 2 * frames) return;
+  float t = 0.0f;
+  for (uint32_t s = 0; s < n_seg; ++s) t += partial[(size_t)row * n_seg + s];
+  const uint32_t ch = row / frames, f = row % frames;
+  if (accumulate) bus[2 * f + ch] += t; else bus[2 * f + ch] = t;
+}
+// WAV sink quantisation (helpers.rs:79-91): (x * 32767) as i16, truncating, saturating.
+__global__ void bus_to_i16_kernel(const float* __restrict__ bus, size_t count, int16_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float v = bus[i] * 32767.0f;
+  int q;
+  if (v != v) q = 0;
+  else if (v >= 32767.0f) q = 32767;
+  else if (v <= -32768.0f) q = -32768;
+  else q = (int)v;
+  out[i] = (int16_t)q;
+}
+
+// ------------------------------------------------------------------ effects
+// Element-wise kinds (a8 Gain, a9 Bitcrusher, Limiter, Compressor, Mixer): grid-stride over
+// the block; per-lane parameters indexed by lane = i % n.
+__global__ __launch_bounds__(kThreads) void fx_elementwise_kernel(
+    uint32_t kind, float* __restrict__ data, uint32_t n, uint32_t frames, size_t ch_stride,
+    const float* __restrict__ fa, const float* __restrict__ fb, const uint32_t* __restrict__ ua,
+    const float* __restrict__ wet) {
+  const size_t per_ch = (size_t)frames * n;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < 2 * per_ch; i += (size_t)gridDim.x * kThreads) {
+    const size_t ch = i / per_ch, r = i % per_ch;
+    const uint32_t lane = (uint32_t)(r % n);
+    float* ptr = data + ch * ch_stride + r;
+    const float x = *ptr;
+    float y;
+    switch (kind) {
+      case GROOVE_FX_GAIN: y = x * fa[lane]; break;
+      case GROOVE_FX_BITCRUSHER: y = bitcrush(x, ua[lane]); break;
+      case GROOVE_FX_LIMITER: y = limiter(x, fa[lane], fb[lane]); break;
+      case GROOVE_FX_COMPRESSOR: y = compressor(x, fa[lane], fb[lane]); break;
+      default: y = x; break;
+    }
+    const float w = wet[lane];
+    if (w < 1.0f) y = fmaf(y, w, x * (1.0f - w));
+    *ptr = y;
+  }
+}
+
+// IIR kinds (a3 BiQuad 12 dB, a4 24 dB low-pass): one (channel, lane) pair per thread,
+// f64 coefficients and state.  coef: [5 or 6][n] f64; st: [4][2n] f64.
+__global__ __launch_bounds__(kThreads) void fx_biquad_kernel(
+    float* __restrict__ data, uint32_t n, uint32_t frames, size_t ch_stride,
+    const double* __restrict__ coef, double* __restrict__ st, const float* __restrict__ wet) {
+  const uint32_t t = blockIdx.x * kThreads + threadIdx.x;
+  if (t >= 2 * n) return;
+  const uint32_t ch = t / n, lane = t % n;
+  const size_t ln = 2 * (size_t)n;
+  BiquadCoefD c{coef[lane], coef[(size_t)n + lane], coef[(size_t)2 * n + lane], coef[(size_t)3 * n + lane], coef[(size_t)4 * n + lane]};
+  BiquadStateD s{st[t], st[ln + t], st[2 * ln + t], st[3 * ln + t]};
+  const float w = wet[lane];
+  float* __restrict__ ptr = data + ch * ch_stride + lane;
+  for (uint32_t f = 0; f < frames; ++f) {
+    const float x = ptr[(size_t)f * n];
+    float y = (float)biquad_step(s, c, (double)x);
+    if (w < 1.0f) y = fmaf(y, w, x * (1.0f - w));
+    ptr[(size_t)f * n] = y;
+  }
+  st[t] = s.x1; st[ln + t] = s.x2; st[2 * ln + t] = s.y1; st[3 * ln + t] = s.y2;
+}
+__global__ __launch_bounds__(kThreads) void fx_lp24_kernel(
+    float* __restrict__ data, uint32_t n, uint32_t frames, size_t ch_stride,
+    const double* __restrict__ coef, double* __restrict__ st, const float* __restrict__ wet) {
+  const uint32_t t = blockIdx.x * kThreads + threadIdx.x;
+  if (t >= 2 * n) return;
+  const uint32_t ch = t / n, lane = t % n;
+  const size_t ln = 2 * (size_t)n;
+  const double b0a = coef[lane], a1a = coef[(size_t)n + lane], a2a = coef[(size_t)2 * n + lane];
+  const double b0b = coef[(size_t)3 * n + lane], a1b = coef[(size_t)4 * n + lane], a2b = coef[(size_t)5 * n + lane];
+  double s0 = st[t], s1 = st[ln + t], s2 = st[2 * ln + t], s3 = st[3 * ln + t];
+  const float w = wet[lane];
+  float* __restrict__ ptr = data + ch * ch_stride + lane;
+  for (uint32_t f = 0; f < frames; ++f) {
+    const float xf = ptr[(size_t)f * n];
+    const double x = (double)xf;
+    const double bx = b0a * x;
+    const double y1 = bx + s0;
+    s0 = fma(a1a, y1, 2.0 * bx + s1);
+    s1 = fma(a2a, y1, bx);
+    const double by = b0b * y1;
+    const double y2 = by + s2;
+    s2 = fma(a1b, y2, 2.0 * by + s3);
+    s3 = fma(a2b, y2, by);
+    float y = (float)y2;
+    if (w < 1.0f) y = fmaf(y, w, xf * (1.0f - w));
+    ptr[(size_t)f * n] = y;
+  }
+  st[t] = s0; st[ln + t] = s1; st[2 * ln + t] = s2; st[3 * ln + t] = s3;
+}
+
+// Delay-line kinds.  Ring rows are [pos][2n] fp32 (channel-major inside a row), so the ring
+// index is wave-uniform and every access is a coalesced row segment.  `w` is the write
+// index at the start of the block (host-tracked, uniform for the whole effect bank).
+// a11 Delay{seconds}
+__global__ __launch_bounds__(kThreads) void fx_delay_kernel(
+    float* __restrict__ data, uint32_t n, uint32_t frames, size_t ch_stride,
+    float* __restrict__ ring, uint32_t N, uint32_t w, const float* __restrict__ wet) {
+  const uint32_t t = blockIdx.x * kThreads + threadIdx.x;
+  if (t >= 2 * n) return;
+  const uint32_t ch = t / n, lane = t % n;
+  const size_t ln = 2 * (size_t)n;
+  const float wm = wet[lane];
+  float* __restrict__ ptr = data + ch * ch_stride + lane;
+  uint32_t pos = w;
+  for (uint32_t f = 0; f < frames; ++f) {
+    const float x = ptr[(size_t)f * n];
+    float* r = ring + (size_t)pos * ln + t;
+    float y = *r;
+    *r = x;
+    if (wm < 1.0f) y = fmaf(y, wm, x * (1.0f - wm));
+    ptr[(size_t)f * n] = y;
+    pos = pos + 1 == N ? 0 : pos + 1;
+  }
+}
+// a10 Chorus{voices, delay_seconds}: taps at (pos + k*spacing) mod N, k = 0..voices-1.
+__global__ __launch_bounds__(kThreads) void fx_chorus_kernel(
+    float* __restrict__ data, uint32_t n, uint32_t frames, size_t ch_stride,
+    float* __restrict__ ring, uint32_t N, uint32_t w, uint32_t voices, uint32_t spacing,
+    const float* __restrict__ wet) {
+  const uint32_t t = blockIdx.x * kThreads + threadIdx.x;
+  if (t >= 2 * n) return;
+  const uint32_t ch = t / n, lane = t % n;
+  const size_t ln = 2 * (size_t)n;
+  const float wm = wet[lane];
+  float* __restrict__ ptr = data + ch * ch_stride + lane;
+  uint32_t pos = w;
+  for (uint32_t f = 0; f < frames; ++f) {
+    const float x = ptr[(size_t)f * n];
+    float sum = 0.0f;
+    uint32_t tp = pos;
+    for (uint32_t k = 0; k < voices; ++k) {
+      sum += ring[(size_t)tp * ln + t];
+      tp += spacing;
+      if (tp >= N) tp -= N;
+    }
+    ring[(size_t)pos * ln + t] = x;
+    float y = sum;
+    if (wm < 1.0f) y = fmaf(y, wm, x * (1.0f - wm));
+    ptr[(size_t)f * n] = y;
+    pos = pos + 1 == N ? 0 : pos + 1;
+  }
+}
+// a12 Reverb{attenuation, seconds}: 4 recirculating combs in parallel, 2 Schroeder all-passes
+// in series.  Six rings back to back in `ring`; geometry in ReverbGeom (uniform).
+struct ReverbGeom {
+  uint32_t N[6];      // ring lengths (frames)
+  uint32_t w[6];      // write indices at block start
+  uint64_t base[6];   // row offset of each ring inside the ring buffer (rows of 2n floats)
+  float g[6];         // feedback gains
+};
+__global__ __launch_bounds__(kThreads) void fx_reverb_kernel(
+    float* __restrict__ data, uint32_t n, uint32_t frames, size_t ch_stride,
+    float* __restrict__ ring, ReverbGeom geo, const float* __restrict__ atten, const float* __restrict__ wet) {
+  const uint32_t t = blockIdx.x * kThreads + threadIdx.x;
+  if (t >= 2 * n) return;
+  const uint32_t ch = t / n, lane = t % n;
+  const size_t ln = 2 * (size_t)n;
+  const float wm = wet[lane], att = atten[lane];
+  float* __restrict__ ptr = data + ch * ch_stride + lane;
+  uint32_t pos[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) pos[i] = geo.w[i];
+  for (uint32_t f = 0; f < frames; ++f) {
+    const float x = ptr[(size_t)f * n];
+    const float in = x * att;
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float* r = ring + (geo.base[i] + pos[i]) * ln + t;
+      const float out = geo.g[i] * *r;
+      *r = in + out;
+      sum += out;
+    }
+#pragma unroll
+    for (int i = 4; i < 6; ++i) {
+      float* r = ring + (geo.base[i] + pos[i]) * ln + t;
+      const float d = *r;
+      const float v = fmaf(geo.g[i], d, sum);
+      *r = v;
+      sum = fmaf(-geo.g[i], v, d);
+    }
+    float y = sum;
+    if (wm < 1.0f) y = fmaf(y, wm, x * (1.0f - wm));
+    ptr[(size_t)f * n] = y;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pos[i] = pos[i] + 1 == geo.N[i] ? 0 : pos[i] + 1;
+  }
+}
+
+} // namespace groove

@@ -1,0 +1,135 @@
+/* groove_hip.h — C ABI of libgroove_hip.so, the MI355X (gfx950) render path that
+ * drops in behind the reference's instrument/effect trait surface.
+ *
+ * The reference has no FFI of its own: its "plugin" boundary is the
+ * set of Rust traits an entity implements (`ensnare_core::traits`, glued by
+ * /root/reference/proc-macros/src/entity.rs:29-139).  Each entry point below names the
+ * trait method(s) it replaces and the call site in the reference that drives it.  All
+ * citations are relative to /root/reference.  INTEGRATION.md shows the Rust `extern "C"`
+ * block and the `entities`-crate wrappers a maintainer would add.
+ *
+ * Conventions
+ *   - every call returns 0 on success, non-zero on failure; groove_last_error() gives the
+ *     message (audio-path trait methods are infallible in the reference; graph edits
+ *     return anyhow::Result, orchestrator.rs:263-304 — the library never aborts);
+ *   - the caller owns host memory; the library owns device memory behind opaque handles;
+ *   - handles are not thread-safe: one HIP stream per ctx, matching the reference's
+ *     single-threaded audio path (orchestrator.rs:367-470);
+ *   - device blocks are planar, frame-major fp32:  block[ch][frame][voice], ch 0 = left,
+ *     so one wavefront's store is 64 consecutive floats; the bus is bus[frame][2];
+ *   - note events and parameter changes take effect at the next block start, exactly the
+ *     granularity of Orchestrator::tick (orchestrator.rs:856-859: handle_work once per
+ *     tick, then gather_audio over the whole buffer).
+ */
+#ifndef GROOVE_HIP_H
+#define GROOVE_HIP_H
+
+#include "groove_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct groove_ctx groove_ctx;     /* one device + one stream                       */
+typedef struct groove_bank groove_bank;   /* an instrument: N homogeneous voices, one lane each */
+typedef struct groove_fx groove_fx;       /* an effect applied per lane to an N-lane block  */
+typedef struct groove_block groove_block; /* device stereo block [2][frames_cap][n] fp32    */
+
+/* ---- context ------------------------------------------------------------------------ */
+/* Orchestrator::new_with + device selection (orchestrator.rs:522-568). */
+int groove_init(int device_ordinal, groove_ctx** out);
+void groove_shutdown(groove_ctx* ctx);
+/* ctx may be NULL: returns the last error of the calling thread. */
+const char* groove_last_error(groove_ctx* ctx);
+/* Use the caller's hipStream_t (e.g. a torch stream) instead of the ctx's own. */
+int groove_set_stream(groove_ctx* ctx, void* hip_stream);
+int groove_synchronize(groove_ctx* ctx);
+/* Configurable::update_sample_rate fan-out (orchestrator.rs:125-127, 1019-1022, 1389-1394).
+ * Re-derives every bank/effect created on this ctx and resets their state. */
+int groove_update_sample_rate(groove_ctx* ctx, uint32_t hz);
+uint32_t groove_sample_rate(groove_ctx* ctx);
+/* HIP events on the ctx stream, for measurement (bench.py): create / record / elapsed. */
+int groove_event_create(groove_ctx* ctx, void** out_event);
+int groove_event_destroy(groove_ctx* ctx, void* event);
+int groove_event_record(groove_ctx* ctx, void* event);
+int groove_event_elapsed_ms(groove_ctx* ctx, void* start, void* stop, float* out_ms);
+
+/* ---- blocks --------------------------------------------------------------------------- */
+/* The buffer a `generate_batch_values(&mut [StereoSample])` call fills
+ * (entities/src/instruments/metronome.rs:23-35), for n lanes at once. */
+int groove_block_create(groove_ctx* ctx, uint32_t n, uint32_t frames_cap, groove_block** out);
+int groove_block_destroy(groove_block* b);
+float* groove_block_device_ptr(groove_block* b);
+uint32_t groove_block_lanes(groove_block* b);
+uint32_t groove_block_frames_cap(groove_block* b);
+/* host [2][frames][n] fp32 <-> device */
+int groove_block_upload(groove_block* b, const float* host, uint32_t frames);
+int groove_block_download(groove_block* b, float* host, uint32_t frames);
+
+/* ---- instruments (Ticks + Generates<StereoSample> + HandlesMidi + Controllable) --------- */
+/* WelshSynth::new_with(&WelshSynthParams) (settings/src/instruments.rs:71-76) for n voices. */
+int groove_welsh_create(groove_ctx* ctx, const groove_welsh_params* p, uint32_t n, groove_bank** out);
+/* FmSynth::new_with(&FmSynthParams) (settings/src/instruments.rs:89-92). */
+int groove_fm_create(groove_ctx* ctx, const groove_fm_params* p, uint32_t n, groove_bank** out);
+/* Sampler::new_with / Drumkit::new_with (settings/src/instruments.rs:81-88); the shared
+ * mono sample bank is uploaded once and stays resident. */
+int groove_sampler_create(groove_ctx* ctx, const float* bank_pcm, uint64_t bank_frames,
+                          const groove_sample_desc* descs, uint32_t n_samples,
+                          const groove_sampler_params* p, uint32_t n, groove_bank** out);
+int groove_bank_destroy(groove_bank* bank);
+uint32_t groove_bank_voices(groove_bank* bank);
+/* HandlesMidi::handle_midi_message → PlaysNotes::note_on/note_off (orchestrator.rs:737-739;
+ * settings/src/patches.rs:928, 821).  Applied in order, at the start of the next render. */
+int groove_bank_note_events(groove_bank* bank, const groove_note_event* ev, uint32_t n_ev);
+/* Controllable::control_set_param_by_index (proc-macros/src/control.rs:211-226); value01 is a
+ * ControlValue in 0..1 (orchestration/src/lib.rs:43-47).  voice = GROOVE_ALL_VOICES for all. */
+int groove_bank_set_param(groove_bank* bank, uint32_t voice, uint32_t control_index, double value01);
+/* Ticks::tick(frames) + Generates::generate_batch_values: fills out[2][frames][n]. */
+int groove_bank_render(groove_bank* bank, uint32_t frames, groove_block* out);
+/* Fused form of "tick every leaf and add its value to the running sum"
+ * (orchestrator.rs:397-410) for instruments patched straight into the main mixer: renders
+ * and accumulates into bus_dev[frames][2] (device) without materialising the block.
+ * accumulate = 0 overwrites the bus, 1 adds to it. */
+int groove_bank_render_mix(groove_bank* bank, uint32_t frames, float* bus_dev, int accumulate);
+/* Raw state snapshot (checkpoint / debugging): words = groove_bank_state_words(). */
+uint32_t groove_bank_state_words(groove_bank* bank);
+int groove_bank_download_state(groove_bank* bank, uint32_t* host_words /* [words][n] */);
+
+/* ---- effects (TransformsAudio) ---------------------------------------------------------- */
+/* `Foo::new_with(&FooParams)` for n lanes (settings/src/effects.rs:59-117).  p has n entries. */
+int groove_fx_create(groove_ctx* ctx, uint32_t kind, const groove_fx_params* p, uint32_t n, groove_fx** out);
+int groove_fx_destroy(groove_fx* fx);
+/* TransformsAudio::transform_audio over a block, in place (orchestrator.rs:438-457). */
+int groove_fx_process(groove_fx* fx, groove_block* inout, uint32_t frames);
+/* Controllable for effects; lane = GROOVE_ALL_VOICES for all lanes. */
+int groove_fx_set_param(groove_fx* fx, uint32_t lane, uint32_t control_index, double value01);
+/* Replace all per-lane parameters (non-UNIFORM fields only may change). */
+int groove_fx_set_params(groove_fx* fx, const groove_fx_params* p, uint32_t n);
+
+/* ---- mix bus (Orchestrator::gather_audio, orchestrator.rs:367-470) ------------------------ */
+/* bus_dev[f][ch] (+)= sum over blocks and lanes of block[ch][f][lane]. */
+int groove_mix(groove_ctx* ctx, groove_block* const* blocks, uint32_t n_blocks, uint32_t frames,
+               float* bus_dev, int accumulate);
+/* Device scratch the caller can use as a bus: frames*2 floats, zeroed. */
+int groove_bus_create(groove_ctx* ctx, size_t frames, float** out_dev);
+int groove_bus_destroy(groove_ctx* ctx, float* bus_dev);
+int groove_bus_zero(groove_ctx* ctx, float* bus_dev, size_t frames);
+int groove_download(groove_ctx* ctx, const float* dev, float* host, size_t n_floats);
+int groove_upload(groove_ctx* ctx, float* dev, const float* host, size_t n_floats);
+/* WAV sink quantisation (orchestration/src/helpers.rs:79-91): interleaved i16 = (x*32767) as i16
+ * (truncate toward zero, saturating), computed on the device from bus_dev[frames][2]. */
+int groove_bus_to_i16(groove_ctx* ctx, const float* bus_dev, size_t frames, int16_t* host_out);
+
+/* ---- multi-GPU (no reference counterpart) ----------------------------------- */
+/* One process per GPU.  Rank 0 calls groove_comm_unique_id, the launcher broadcasts the 128
+ * bytes, every rank calls groove_comm_init; groove_bus_reduce sums bus_dev[frames_total][2]
+ * (fp32) onto `root` with one RCCL reduce over xGMI. */
+int groove_comm_unique_id(groove_ctx* ctx, uint8_t id_out[128]);
+int groove_comm_init(groove_ctx* ctx, const uint8_t id[128], int rank, int world_size);
+int groove_comm_destroy(groove_ctx* ctx);
+int groove_bus_reduce(groove_ctx* ctx, float* bus_dev, size_t frames_total, int root);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GROOVE_HIP_H */

@@ -1,0 +1,74 @@
+// emul.cpp — host build (g++) of the SAME per-lane DSP text the HIP kernels run
+// (groove_amd/csrc/dsp_core.h + derive.h), looped over voices on the CPU.
+//
+// DEVELOPMENT / TEST HARNESS ONLY.  It exists so the fp32/f64 arithmetic choices of the
+// device code can be checked against the f64 oracle in the GPU-less CI tier.  It is not
+// shipped, not linked into libgroove_hip.so, and the product never calls it.
+#include "../../groove_amd/csrc/derive.h"
+#include <vector>
+#include <cstring>
+using namespace groove;
+
+struct EmulBank {
+  int kind; uint32_t n; double sr;
+  std::vector<WelshParams> wp; std::vector<WelshState> ws; std::vector<WelshCold> wc;
+  std::vector<FmParams> fp; std::vector<FmState> fs; std::vector<double> ratio;
+  std::vector<SamplerParams> sp; std::vector<SamplerState> ss; std::vector<float> pcm;
+};
+
+extern "C" {
+void* emul_welsh_create(const groove_welsh_params* p, uint32_t n, uint32_t sr) {
+  EmulBank* b = new EmulBank(); b->kind = 0; b->n = n; b->sr = sr;
+  b->wp.resize(n); b->ws.assign(n, initial_welsh_state()); b->wc.resize(n);
+  for (uint32_t v = 0; v < n; ++v) b->wp[v] = derive_welsh(p[v], sr, b->wc[v]);
+  return b;
+}
+void* emul_fm_create(const groove_fm_params* p, uint32_t n, uint32_t sr) {
+  EmulBank* b = new EmulBank(); b->kind = 1; b->n = n; b->sr = sr;
+  b->fp.resize(n); b->fs.assign(n, initial_fm_state()); b->ratio.resize(n);
+  for (uint32_t v = 0; v < n; ++v) { b->fp[v] = derive_fm(p[v], sr); b->ratio[v] = p[v].ratio; }
+  return b;
+}
+void* emul_sampler_create(const float* pcm, uint64_t frames, const groove_sample_desc* d, uint32_t nd,
+                          const groove_sampler_params* p, uint32_t n, uint32_t sr) {
+  EmulBank* b = new EmulBank(); b->kind = 2; b->n = n; b->sr = sr;
+  b->pcm.assign(pcm, pcm + frames); b->sp.resize(n); b->ss.assign(n, SamplerState{0, 0, 0});
+  for (uint32_t v = 0; v < n; ++v) {
+    const groove_sample_desc& sd = d[p[v].sample_index < nd ? p[v].sample_index : 0];
+    b->sp[v] = SamplerParams{(uint32_t)sd.offset, sd.length, (double)sd.root_hz, p[v].gain, p[v].one_shot};
+  }
+  return b;
+}
+void emul_bank_destroy(void* h) { delete (EmulBank*)h; }
+void emul_bank_note_events(void* h, const groove_note_event* ev, uint32_t n_ev) {
+  EmulBank* b = (EmulBank*)h;
+  for (uint32_t i = 0; i < n_ev; ++i) {
+    uint32_t lo = ev[i].voice, hi = ev[i].voice + 1;
+    if (ev[i].voice == GROOVE_ALL_VOICES) { lo = 0; hi = b->n; }
+    for (uint32_t v = lo; v < hi && v < b->n; ++v) {
+      if (b->kind == 0) welsh_note(b->wp[v], b->ws[v], b->wc[v].tune1, b->wc[v].tune2, b->wc[v].fixed1, b->wc[v].fixed2, b->sr, ev[i].key, ev[i].on != 0);
+      else if (b->kind == 1) fm_note(b->fp[v], b->fs[v], b->ratio[v], b->sr, ev[i].key, ev[i].on != 0);
+      else sampler_note(b->sp[v], b->ss[v], ev[i].key, ev[i].on != 0);
+    }
+  }
+}
+// out[2][frames][n] fp32
+void emul_bank_render(void* h, uint32_t frames, float* out) {
+  EmulBank* b = (EmulBank*)h;
+  const uint32_t n = b->n;
+  RenderConsts rc{(float)(3.14159265358979323846 / b->sr), (float)(0.49 * b->sr)};
+  for (uint32_t v = 0; v < n; ++v) {
+    Lp24Coef sc{};
+    if (b->kind == 0) sc = lp24_coef_from_k(b->wp[v].fc, lp24_k(b->wp[v].cutoff_hz, rc.pi_over_sr, rc.fc_max));
+    for (uint32_t f = 0; f < frames; ++f) {
+      float L, R;
+      if (b->kind == 0) welsh_frame(b->wp[v], b->ws[v], rc, sc, L, R);
+      else if (b->kind == 1) fm_frame(b->fp[v], b->fs[v], L, R);
+      else { L = R = sampler_frame(b->sp[v], b->ss[v], b->pcm.data()); }
+      out[(size_t)f * n + v] = L;
+      out[((size_t)frames + f) * n + v] = R;
+    }
+  }
+}
+float emul_bitcrush(float x, uint32_t bits) { return bitcrush(x, bits); }
+}

@@ -1,0 +1,70 @@
+"""ctypes binding of tests/emul/libemul.so (host build of the device DSP text; test harness only)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+from groove_amd import types as T
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_fp = C.POINTER(C.c_float)
+
+
+def build():
+    src = os.path.join(HERE, "emul.cpp")
+    out = os.path.join(HERE, "libemul.so")
+    deps = [src] + [os.path.join(HERE, "..", "..", "groove_amd", "csrc", f) for f in ("dsp_core.h", "derive.h")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        # -ffp-contract=off: fmaf() calls stay fused, plain a*b+c stays unfused, like hipcc's default for explicit code
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", out, src], check=True)
+    return out
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        vp, u32 = C.c_void_p, C.c_uint32
+        L.emul_welsh_create.restype = vp; L.emul_welsh_create.argtypes = [C.POINTER(T.WelshParams), u32, u32]
+        L.emul_fm_create.restype = vp; L.emul_fm_create.argtypes = [C.POINTER(T.FmParams), u32, u32]
+        L.emul_sampler_create.restype = vp
+        L.emul_sampler_create.argtypes = [_fp, C.c_uint64, C.POINTER(T.SampleDesc), u32, C.POINTER(T.SamplerParams), u32, u32]
+        L.emul_bank_destroy.argtypes = [vp]
+        L.emul_bank_note_events.argtypes = [vp, C.POINTER(T.NoteEvent), u32]
+        L.emul_bank_render.argtypes = [vp, u32, _fp]
+        L.emul_bitcrush.restype = C.c_float; L.emul_bitcrush.argtypes = [C.c_float, u32]
+        _LIB = L
+    return _LIB
+
+
+class Bank:
+    def __init__(self, h, n):
+        self.h, self.n = h, n
+
+    @classmethod
+    def welsh(cls, params, sr=T.DEFAULT_SAMPLE_RATE):
+        return cls(lib().emul_welsh_create(params, len(params), sr), len(params))
+
+    @classmethod
+    def fm(cls, params, sr=T.DEFAULT_SAMPLE_RATE):
+        return cls(lib().emul_fm_create(params, len(params), sr), len(params))
+
+    @classmethod
+    def sampler(cls, pcm, descs, params, sr=T.DEFAULT_SAMPLE_RATE):
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        return cls(lib().emul_sampler_create(pcm.ctypes.data_as(_fp), pcm.size, descs, len(descs), params, len(params), sr), len(params))
+
+    def note_events(self, ev):
+        lib().emul_bank_note_events(self.h, ev, len(ev))
+
+    def render(self, frames):
+        out = np.zeros((2, frames, self.n), dtype=np.float32)
+        lib().emul_bank_render(self.h, frames, out.ctypes.data_as(_fp))
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().emul_bank_destroy(self.h)
+            self.h = None
