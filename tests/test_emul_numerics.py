@@ -1,0 +1,60 @@
+"""CPU tier: the device DSP text (groove_amd/csrc/dsp_core.h), compiled for the host by
+tests/emul, against the f64 oracle.  This checks the fp32 / f64 / u64 arithmetic choices of the
+kernels in the GPU-less tier; the GPU tier (tests/test_gpu_*.py) checks the kernels themselves.
+Tolerance: per-voice RMS <= 1e-5, bus/V RMS <= 1e-6."""
+import numpy as np
+
+from groove_amd import patches as P, types as T
+from tests.emul import emul as E
+
+
+def _render(bank_o, bank_e, on, off, blocks, off_block, frames=256):
+    o, e = [], []
+    for b in range(blocks):
+        if b == 0:
+            bank_o.note_events(on); bank_e.note_events(on)
+        if b == off_block:
+            bank_o.note_events(off); bank_e.note_events(off)
+        o.append(bank_o.render(frames)); e.append(bank_e.render(frames))
+    return np.concatenate(o, axis=1), np.concatenate(e, axis=1).astype(np.float64)
+
+
+def test_welsh_arithmetic_all_patches(oracle):
+    n = 32
+    params = P.welsh_voices(n)
+    o, e = _render(oracle.Bank.welsh(params), E.Bank.welsh(params), P.note_on_all(n), P.note_off_all(n), 172, 86)
+    err = e - o
+    per_voice = np.sqrt(np.mean(err ** 2, axis=(0, 1)))
+    assert per_voice.max() <= 1e-5, per_voice
+    bus = np.sqrt(np.mean((err.sum(axis=2) / n) ** 2))
+    assert bus <= 1e-6
+
+
+def test_fm_arithmetic(oracle):
+    n = 16
+    params = P.fm_voices(n)
+    o, e = _render(oracle.Bank.fm(params), E.Bank.fm(params), P.note_on_all(n), P.note_off_all(n), 60, 30)
+    assert np.sqrt(np.mean((e - o) ** 2, axis=(0, 1))).max() <= 1e-5
+
+
+def test_sampler_fetch_is_exact(oracle):
+    n = 120
+    pcm, descs, _ = P.drum_bank(scale=0.02)
+    params = P.sampler_voices(n)
+    bo, be = oracle.Bank.sampler(pcm, descs, params), E.Bank.sampler(pcm, descs, params)
+    ev = T.note_events_np(np.arange(n, dtype=np.uint32), P.sampler_keys(n), True)
+    bo.note_events(ev); be.note_events(ev)
+    for _ in range(8):
+        assert np.array_equal(be.render(256), bo.render(256).astype(np.float32))
+
+
+def test_bitcrusher_same_integer_quantise(oracle):
+    L, Le = oracle.lib(), E.lib()
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.uniform(-1.2, 1.2, 2000), [0.0, -0.0, 1.0, -1.0, 3e-5]]).astype(np.float32)
+    for bits in (0, 3, 8, 13, 15):
+        for x in xs:
+            a, b = L.oracle_bitcrush_f32(float(x), bits), Le.emul_bitcrush(float(x), bits)
+            assert np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32)
+    # worked value: 0.5 at 8 bits → floor(16383.5 / 256) * 256 / 32767
+    assert abs(L.oracle_bitcrush_f32(0.5, 8) - (16383 >> 8 << 8) / 32767.0) < 1e-7

@@ -1,0 +1,157 @@
+"""GPU parity for the effect kernels (a3, a4, a8-a12) vs the f64 oracle.
+
+Inputs are deterministic pseudo-audio blocks; the same fp32 data feeds both sides.
+Tolerances: Bitcrusher bit-exact; Gain exact (one fp32 multiply); IIR / delay-line effects
+max abs error <= 2e-6 relative to a unit-scale input (fp32 rings, f64 recurrences).
+"""
+import numpy as np
+import pytest
+
+from groove_amd import patches as P, types as T
+
+pytestmark = pytest.mark.gpu
+
+
+def _audio(n, frames_total, seed=1):
+    rng = np.random.default_rng(seed)
+    t = np.arange(frames_total)[None, :, None]
+    f = (110.0 * 2.0 ** (np.arange(n) % 37 / 12.0))[None, None, :]
+    x = 0.5 * np.sin(2 * np.pi * f * t / 44100.0 + np.arange(2)[:, None, None]) + 0.1 * rng.standard_normal((2, frames_total, n))
+    x[:, frames_total // 2:, :] *= 0.0  # let tails ring out
+    return x.astype(np.float32)
+
+
+def _params(n, **kw):
+    arr = (T.FxParams * n)()
+    for i in range(n):
+        arr[i] = T.fx_params(**{k: (v[i] if isinstance(v, (list, np.ndarray)) else v) for k, v in kw.items()})
+    return arr
+
+
+def _run(gpu_ctx, oracle, kind, params, x, frames=256, block_sizes=None):
+    from groove_amd import entities as E
+    n = x.shape[2]
+    fx = E.Effect(gpu_ctx, kind, params)
+    ofx = oracle.Fx(kind, params)
+    block = gpu_ctx.block(n, frames)
+    got, want = [], []
+    pos = 0
+    sizes = block_sizes or [frames] * (x.shape[1] // frames)
+    for fr in sizes:
+        chunk = np.ascontiguousarray(x[:, pos:pos + fr, :])
+        block.upload(chunk)
+        fx.transform_audio(block, fr)
+        got.append(block.download(fr))
+        want.append(ofx.process(chunk.astype(np.float64)))
+        pos += fr
+    fx.destroy(); block.destroy()
+    return np.concatenate(got, axis=1), np.concatenate(want, axis=1)
+
+
+def test_gain_exact(gpu_ctx, oracle):
+    n = 100
+    x = _audio(n, 512)
+    ceil = np.linspace(0.0, 1.0, n).astype(np.float32)
+    got, want = _run(gpu_ctx, oracle, T.FX_GAIN, _params(n, ceiling=list(ceil)), x)
+    assert np.array_equal(got, (x * ceil[None, None, :]).astype(np.float32))
+    assert np.max(np.abs(got - want)) <= 1e-7
+
+
+@pytest.mark.parametrize("bits", [0, 1, 4, 8, 13, 15])
+def test_bitcrusher_bit_exact(gpu_ctx, oracle, bits):
+    """Integer quantise on the 16-bit scale: GPU == oracle for every sample, bit for bit."""
+    n = 70
+    x = _audio(n, 512, seed=bits)
+    x[0, :8, 0] = [0.0, -0.0, 1.0, -1.0, 3.0e-5, -3.0e-5, 0.999985, 2.5]
+    got, want = _run(gpu_ctx, oracle, T.FX_BITCRUSHER, _params(n, bits=bits), x)
+    assert np.array_equal(got.view(np.uint32), want.astype(np.float32).view(np.uint32))
+
+
+def test_biquad_lp12_and_hp12(gpu_ctx, oracle):
+    n = 128
+    x = _audio(n, 2048)
+    cut = [40.0 + 150.0 * i for i in range(n)]
+    for kind in (T.FX_BIQUAD_LP12, T.FX_BIQUAD_HP12):
+        got, want = _run(gpu_ctx, oracle, kind, _params(n, cutoff_hz=cut, q=0.707), x)
+        assert np.max(np.abs(got - want)) <= 2e-6
+
+
+def test_lp24_effect(gpu_ctx, oracle):
+    n = 96
+    x = _audio(n, 2048)
+    cut = [40.0 * 500.0 ** (i / (n - 1)) for i in range(n)]
+    rip = [0.707 + 0.03 * i for i in range(n)]
+    got, want = _run(gpu_ctx, oracle, T.FX_BIQUAD_LP24, _params(n, cutoff_hz=cut, passband_ripple=rip), x)
+    assert np.max(np.abs(got - want)) <= 2e-6
+
+
+def test_delay_chorus_reverb(gpu_ctx, oracle):
+    n = 72
+    x = _audio(n, 256 * 40)
+    got, want = _run(gpu_ctx, oracle, T.FX_DELAY, _params(n, delay_seconds=0.1), x)
+    assert np.array_equal(got, want.astype(np.float32))  # a pure delay is exact
+    assert np.array_equal(got[:, 4410:4410 + 256, :], x[:, :256, :])
+    got, want = _run(gpu_ctx, oracle, T.FX_CHORUS, _params(n, voices=4, delay_seconds=0.25), x[:, :256 * 60 // 2, :])
+    assert np.max(np.abs(got - want)) <= 2e-6
+    got, want = _run(gpu_ctx, oracle, T.FX_REVERB, _params(n, attenuation=0.95, reverb_seconds=1.25), x)
+    assert np.max(np.abs(want)) > 0.1
+    assert np.max(np.abs(got - want)) <= 4e-6
+
+
+def test_short_delay_and_ragged_blocks(gpu_ctx, oracle):
+    """Delay shorter than a block (intra-block feedback path), odd block lengths, wet/dry mix."""
+    n = 10
+    x = _audio(n, 1500)
+    sizes = [1, 63, 256, 100, 256, 256, 256, 256, 56]
+    got, want = _run(gpu_ctx, oracle, T.FX_DELAY, _params(n, delay_seconds=0.001, wet=0.5), x, block_sizes=sizes)
+    assert np.max(np.abs(got - want)) <= 1e-6
+    got, want = _run(gpu_ctx, oracle, T.FX_REVERB, _params(n, attenuation=0.8, reverb_seconds=0.4, wet=0.3), x, block_sizes=sizes)
+    assert np.max(np.abs(got - want)) <= 4e-6
+    got, want = _run(gpu_ctx, oracle, T.FX_CHORUS, _params(n, voices=3, delay_seconds=0.002), x, block_sizes=sizes)
+    assert np.max(np.abs(got - want)) <= 2e-6
+
+
+def test_limiter_compressor_mixer(gpu_ctx, oracle):
+    n = 33
+    x = _audio(n, 512)
+    got, want = _run(gpu_ctx, oracle, T.FX_LIMITER, _params(n, limit_min=0.1, limit_max=0.4), x)
+    assert np.max(np.abs(got - want)) <= 1e-7
+    got, want = _run(gpu_ctx, oracle, T.FX_COMPRESSOR, _params(n, limit_min=0.2, limit_max=0.25), x)
+    assert np.max(np.abs(got - want)) <= 1e-7
+    got, want = _run(gpu_ctx, oracle, T.FX_MIXER, _params(n), x)
+    assert np.array_equal(got, x)
+
+
+def test_config3_chain_bus_parity(gpu_ctx, oracle):
+    """Config #3 shape at a size the oracle finishes in seconds: 64 Welsh voices, each through
+    BiQuad LP12 → Chorus → Delay → Reverb, summed on the bus; 40 blocks.  Bus/V RMS <= 1e-5."""
+    from groove_amd import entities as E
+    n, frames, blocks = 64, 256, 40
+    params = P.welsh_voices(n)
+    synth = E.WelshSynth(gpu_ctx, params)
+    chain = P.chain_fx_params(n)
+    fx = [E.Effect(gpu_ctx, k, p) for k, p in chain]
+    ofx = [oracle.Fx(k, p) for k, p in chain]
+    ob = oracle.Bank.welsh(params)
+    on, off = P.note_on_all(n), P.note_off_all(n)
+    block = gpu_ctx.block(n, frames)
+    bus = gpu_ctx.bus(blocks * frames)
+    want = []
+    for b in range(blocks):
+        if b == 0:
+            synth.handle_midi_events(on); ob.note_events(on)
+        if b == 20:
+            synth.handle_midi_events(off); ob.note_events(off)
+        synth.generate_batch_values(block, frames)
+        for e in fx:
+            e.transform_audio(block, frames)
+        gpu_ctx.mix([block], frames, E._Slice(bus, b * frames))
+        ref = ob.render(frames)
+        for e in ofx:
+            e.process(ref)
+        want.append(oracle.mix(ref))
+    got = bus.download().astype(np.float64) / n
+    want = np.concatenate(want, axis=0) / n
+    rms = np.sqrt(np.mean((got - want) ** 2))
+    assert np.sqrt(np.mean(want ** 2)) > 1e-3
+    assert rms <= 1e-5, f"chain bus rms {rms:.3e}"

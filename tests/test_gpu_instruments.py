@@ -1,0 +1,144 @@
+"""GPU parity: FM voices (a6), sampler / drumkit voices (a7), mix bus (a15), WAV sink (a18)."""
+import numpy as np
+import pytest
+
+from groove_amd import patches as P, types as T
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fm_per_voice_parity(gpu_ctx, oracle):
+    """16 FM patches (beta 0.1 .. 15, through-zero FM), 60 blocks, note-off at block 30.
+    Tolerance: per-voice RMS <= 1e-5 vs the f64 oracle."""
+    from groove_amd import entities as E
+    n, frames, blocks = 48, 256, 60
+    params = P.fm_voices(n)
+    synth = E.FmSynth(gpu_ctx, params)
+    block = gpu_ctx.block(n, frames)
+    ob = oracle.Bank.fm(params)
+    on, off = P.note_on_all(n), P.note_off_all(n)
+    got, want = [], []
+    for b in range(blocks):
+        if b == 0:
+            synth.handle_midi_events(on); ob.note_events(on)
+        if b == 30:
+            synth.handle_midi_events(off); ob.note_events(off)
+        synth.generate_batch_values(block, frames)
+        got.append(block.download(frames)); want.append(ob.render(frames))
+    got = np.concatenate(got, axis=1).astype(np.float64); want = np.concatenate(want, axis=1)
+    for v in range(n):
+        rms = np.sqrt(np.mean((got[:, :, v] - want[:, :, v]) ** 2))
+        assert np.sqrt(np.mean(want[:, :, v] ** 2)) > 1e-3
+        assert rms <= 1e-5, f"fm voice {v}: rms {rms:.3e}"
+    synth.destroy(); block.destroy()
+
+
+def test_sampler_is_exact_fetch(gpu_ctx, oracle):
+    """Pointer stepping without interpolation is a pure fetch: the fp32 output must equal the
+    oracle's value bit for bit (drumkit step 1 and pitched steps, staggered note-ons, one-shot
+    end-of-buffer stop)."""
+    from groove_amd import entities as E
+    n, frames = 240, 256
+    pcm, descs, lengths = P.drum_bank(scale=0.05)
+    params = P.sampler_voices(n)
+    s = E.Sampler(gpu_ctx, pcm, descs, params)
+    ob = oracle.Bank.sampler(pcm, descs, params)
+    block = gpu_ctx.block(n, frames)
+    keys = P.sampler_keys(n)
+    start = P.sampler_start_block(n) % 6
+    for b in range(24):
+        idx = np.nonzero(start == b)[0].astype(np.uint32)
+        if idx.size:
+            ev = T.note_events_np(idx, keys[idx], True)
+            s.handle_midi_events(ev); ob.note_events(ev)
+        s.generate_batch_values(block, frames)
+        got = block.download(frames)
+        want = ob.render(frames).astype(np.float32)
+        assert np.array_equal(got, want), f"block {b}: sampler fetch differs"
+    assert True
+    s.destroy(); block.destroy()
+
+
+def test_mix_bus_known_answers(gpu_ctx):
+    """Restates gather_audio_basic / gather_audio / gather_audio_2 / _with_branches
+    (orchestrator.rs:1444-1668) on constant-level blocks: sums of sources, Gain ceilings in
+    chains, fan-in to an effect."""
+    from groove_amd import entities as E
+    frames = 64
+
+    def const_block(levels):
+        n = len(levels)
+        b = gpu_ctx.block(n, frames)
+        host = np.empty((2, frames, n), dtype=np.float32)
+        host[:] = np.asarray(levels, dtype=np.float32)[None, None, :]
+        b.upload(host)
+        return b
+
+    bus = gpu_ctx.bus(frames)
+    # nothing patched → silence
+    gpu_ctx.mix([], frames, bus)
+    assert not bus.download().any()
+    # single source, then two sources: 0.1, 0.2, 0.1 + 0.2
+    b1, b2 = const_block([0.1]), const_block([0.2])
+    gpu_ctx.mix([b1], frames, bus); assert np.allclose(bus.download(), 0.1, atol=1e-7)
+    gpu_ctx.mix([b2], frames, bus); assert np.allclose(bus.download(), 0.2, atol=1e-7)
+    gpu_ctx.mix([b1, b2], frames, bus); assert np.allclose(bus.download(), np.float32(0.1) + np.float32(0.2), atol=1e-7)
+    # Gain{ceiling 0.5} on 0.1, siblings 0.2 0.3 0.4 → 0.1*0.5 + 0.2 + 0.3 + 0.4
+    g = E.Effect(gpu_ctx, T.FX_GAIN, (T.FxParams * 1)(T.fx_params(ceiling=0.5)))
+    c = const_block([0.1]); g.transform_audio(c, frames)
+    sib = const_block([0.2, 0.3, 0.4])
+    gpu_ctx.mix([c, sib], frames, bus)
+    assert np.allclose(bus.download(), 0.1 * 0.5 + 0.2 + 0.3 + 0.4, atol=2e-7)
+    # chains: 0.1*0.2*0.4, 0.3*0.6, 0.5*0.8 as three lanes, two gain stages
+    lanes = const_block([0.1, 0.3, 0.5])
+    g1 = E.Effect(gpu_ctx, T.FX_GAIN, (T.FxParams * 3)(T.fx_params(ceiling=0.2), T.fx_params(ceiling=0.6), T.fx_params(ceiling=0.8)))
+    g2 = E.Effect(gpu_ctx, T.FX_GAIN, (T.FxParams * 3)(T.fx_params(ceiling=0.4), T.fx_params(ceiling=1.0), T.fx_params(ceiling=1.0)))
+    g1.transform_audio(lanes, frames); g2.transform_audio(lanes, frames)
+    out = lanes.download(frames)
+    f32 = np.float32
+    assert out[0, 0, 0] == f32(f32(0.1) * f32(0.2)) * f32(0.4)
+    assert out[0, 0, 1] == f32(0.3) * f32(0.6) and out[0, 0, 2] == f32(0.5) * f32(0.8)
+    # fan-in: 0.1 + 0.5 * (0.3 + 0.5): the effect sums its sources, then transforms once
+    srcs = const_block([0.3, 0.5])
+    tmp_bus = gpu_ctx.bus(frames)
+    gpu_ctx.mix([srcs], frames, tmp_bus)               # sum of the effect's sources
+    summed = gpu_ctx.block(1, frames)
+    host = tmp_bus.download().T.reshape(2, frames, 1).copy()
+    summed.upload(host)
+    g.transform_audio(summed, frames)                  # Gain 0.5 applied once to the sum
+    gpu_ctx.mix([const_block([0.1]), summed], frames, bus)
+    assert np.allclose(bus.download(), 0.1 + 0.5 * (0.3 + 0.5), atol=2e-7)
+
+
+def test_mix_large_rows_and_accumulate(gpu_ctx):
+    """Row sums over many lanes (float4 and scalar paths, ragged n) against a float64 sum."""
+    rng = np.random.default_rng(7)
+    for n in (1, 3, 64, 1000, 16384 + 4, 100003):
+        frames = 16
+        host = rng.standard_normal((2, frames, n)).astype(np.float32)
+        b = gpu_ctx.block(n, frames)
+        b.upload(host)
+        bus = gpu_ctx.bus(frames)
+        gpu_ctx.mix([b], frames, bus)
+        want = host.astype(np.float64).sum(axis=2).T
+        got = bus.download().astype(np.float64)
+        assert np.max(np.abs(got - want)) <= 2e-7 * np.sqrt(n) * 4 + 1e-6
+        gpu_ctx.mix([b], frames, bus, accumulate=True)
+        assert np.max(np.abs(bus.download() - 2 * want)) <= 1e-5 * max(1.0, np.abs(want).max())
+        b.destroy(); bus.destroy()
+
+
+def test_wav_sink_quantisation(gpu_ctx, oracle):
+    """(x * 32767) as i16: truncation toward zero, saturation (helpers.rs:79-91)."""
+    vals = np.array([0.0, 1.0, -1.0, 0.5, -0.5, 1.5, -1.5, 3.05e-5, -3.05e-5, 0.99999, -0.99999, 2.9e-5,
+                     np.nan, 1e9], dtype=np.float32)
+    frames = vals.size // 2
+    bus = gpu_ctx.bus(frames)
+    import ctypes as C
+    from groove_amd import lib
+    lib.check(gpu_ctx.L.groove_upload(gpu_ctx.h, bus.ptr, vals.ctypes.data_as(C.POINTER(C.c_float)), vals.size), gpu_ctx.h)
+    got = bus.to_i16(frames).reshape(-1)
+    L = oracle.lib()
+    want = np.array([L.oracle_wav_quantise(float(v)) for v in vals], dtype=np.int16)
+    assert np.array_equal(got, want)
+    assert list(got[:7]) == [0, 32767, -32767, 16383, -16383, 32767, -32768]
