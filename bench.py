@@ -48,14 +48,19 @@ WORKLOADS = {
 class Project:
     """The synthetic many-voice project shard owned by one rank."""
 
-    def __init__(self, ctx, workload, first_voice, n_voices, fused):
+    def __init__(self, ctx, workload, first_voice, n_voices, fused, grouped=True):
         self.ctx, self.n, self.fused = ctx, n_voices, fused
         kind = WORKLOADS[workload]["kind"]
         self.banks = []   # (instrument, block, [effects])
         self.render_events = []
         if kind in ("welsh", "chain"):
-            synth = E.WelshSynth(ctx, P.welsh_voices(n_voices, first_voice))
-            synth.handle_midi_events(P.note_on_all(n_voices, first_voice))
+            if grouped and kind == "welsh":
+                params, idx = P.welsh_voices_grouped(n_voices, first_voice)
+                synth = E.WelshSynth(ctx, params)
+                synth.handle_midi_events(P.grouped_note_events(idx, True))
+            else:
+                synth = E.WelshSynth(ctx, P.welsh_voices(n_voices, first_voice))
+                synth.handle_midi_events(P.note_on_all(n_voices, first_voice))
             fx = []
             if kind == "chain":
                 fx = [E.Effect(ctx, k, p) for k, p in P.chain_fx_params(n_voices)]
@@ -154,6 +159,7 @@ def main():
     ap.add_argument("--workload", default="welsh-1m", choices=sorted(WORKLOADS))
     ap.add_argument("--voices", type=int, default=0, help="override the workload's total voice count")
     ap.add_argument("--fused", action="store_true", help="render and mix in one kernel (no materialised voice blocks)")
+    ap.add_argument("--interleaved", action="store_true", help="voice i uses patch i mod 32 inside every wavefront (generic per-lane kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -182,7 +188,7 @@ def main():
         ctx.comm_init(uid[0], rank, world)
 
     fused = args.fused
-    proj = Project(ctx, args.workload, lo, hi - lo, fused)
+    proj = Project(ctx, args.workload, lo, hi - lo, fused, grouped=not args.interleaved)
     K, W = args.steps, args.warmup
     bus = ctx.bus((K + W) * FRAMES)
 

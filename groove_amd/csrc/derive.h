@@ -76,6 +76,8 @@ inline WelshParams derive_welsh(const groove_welsh_params& p, double sr, WelshCo
 inline WelshState initial_welsh_state() {
   WelshState s{};
   osc_reset(s.o1); osc_reset(s.o2); osc_reset(s.lfo);
+  env_init(s.amp); env_init(s.fil);
+  s.vflags = VF_FIRST;
   return s;
 }
 
@@ -90,6 +92,8 @@ inline FmParams derive_fm(const groove_fm_params& p, double sr) {
 inline FmState initial_fm_state() {
   FmState s{};
   osc_reset(s.carrier); osc_reset(s.modulator);
+  env_init(s.cenv); env_init(s.menv);
+  s.vflags = VF_FIRST;
   return s;
 }
 

@@ -141,37 +141,23 @@ GROOVE_HD uint64_t turns_to_inc(double turns) {
 
 // ------------------------------------------------------------------ Oscillator (a1)
 struct OscState {
-  uint64_t phase; // turns * 2^64
+  uint64_t phase;  // turns * 2^64
   uint32_t x1, x2; // noise generator
-  uint32_t flags;  // bit0: first tick pending, bit1: sync pending
 };
-enum : uint32_t { OSC_FIRST = 1u, OSC_SYNC = 2u };
-GROOVE_HD void osc_reset(OscState& s) {
-  s.phase = 0; s.x1 = 0x70f4f854u; s.x2 = 0xe1e9f0a7u; s.flags = OSC_FIRST;
-}
-// Advance one frame by `inc` (two's complement).  Returns the wrap flag (should_sync):
-// for inc >= 0 that is the carry out of the 64-bit add.
-GROOVE_HD bool osc_advance(OscState& s, uint64_t inc) {
-  bool wrapped = false;
-  if (s.flags & OSC_SYNC) { s.phase = 0; }
-  else if (s.flags & OSC_FIRST) { /* first tick emits position 0 */ }
-  else {
-    const uint64_t np = s.phase + inc;
-    const bool neg = (int64_t)inc < 0;
-    wrapped = neg ? (np > s.phase) : (np < s.phase);
-    s.phase = np;
-  }
-  s.flags = 0;
-  return wrapped;
-}
-// Waveform value at the current phase (fp32).  duty64 = duty * 2^64.
-GROOVE_HD float osc_value(uint32_t waveform, const OscState& s, uint64_t duty64, float noise_value) {
-  const int32_t q = (int32_t)(uint32_t)(s.phase >> 32); // signed turns * 2^32
+GROOVE_HD void osc_reset(OscState& s) { s.phase = 0; s.x1 = 0x70f4f854u; s.x2 = 0xe1e9f0a7u; }
+// Voice-level flag word (all oscillators of a voice tick together, so "first tick after
+// reset emits position 0" is one bit per voice; note events land at block starts, so the
+// bit can only be set on frame 0 of a render call — the kernels peel that frame).
+enum : uint32_t { VF_FIRST = 1u };
+
+// Waveform value at `phase` (fp32).  duty64 = duty * 2^64.
+GROOVE_HD float osc_value(uint32_t waveform, uint64_t phase, uint64_t duty64, float noise_value) {
+  const int32_t q = (int32_t)(uint32_t)(phase >> 32); // signed turns * 2^32
   switch (waveform) {
     case GROOVE_WAVE_SINE:
       return sin_turns_folded((float)fold_quarter(q) * 2.3283064365386963e-10f);
     case GROOVE_WAVE_SQUARE:
-    case GROOVE_WAVE_PULSE_WIDTH: return s.phase < duty64 ? 1.0f : -1.0f;
+    case GROOVE_WAVE_PULSE_WIDTH: return phase < duty64 ? 1.0f : -1.0f;
     case GROOVE_WAVE_TRIANGLE: return fmaf(fabsf((float)q * 2.3283064365386963e-10f), 4.0f, -1.0f);
     case GROOVE_WAVE_SAWTOOTH: return (float)q * 4.6566128730773926e-10f;
     case GROOVE_WAVE_TRIANGLE_SINE: {
@@ -185,13 +171,13 @@ GROOVE_HD float osc_value(uint32_t waveform, const OscState& s, uint64_t duty64,
   }
 }
 // Same in f64 from the full 64-bit phase (LFO on edge-moving routings).
-GROOVE_HD double osc_value_f64(uint32_t waveform, const OscState& s, uint64_t duty64, float noise_value) {
-  const int64_t q = (int64_t)s.phase;
+GROOVE_HD double osc_value_f64(uint32_t waveform, uint64_t phase, uint64_t duty64, float noise_value) {
+  const int64_t q = (int64_t)phase;
   const double k = 5.42101086242752217004e-20; // 2^-64
   switch (waveform) {
     case GROOVE_WAVE_SINE: return sin_turns_folded_f64((double)fold_quarter64(q) * k);
     case GROOVE_WAVE_SQUARE:
-    case GROOVE_WAVE_PULSE_WIDTH: return s.phase < duty64 ? 1.0 : -1.0;
+    case GROOVE_WAVE_PULSE_WIDTH: return phase < duty64 ? 1.0 : -1.0;
     case GROOVE_WAVE_TRIANGLE: return fma(fabs((double)q * k), 4.0, -1.0);
     case GROOVE_WAVE_SAWTOOTH: return (double)q * (2.0 * k);
     case GROOVE_WAVE_TRIANGLE_SINE: {
@@ -222,9 +208,11 @@ struct EnvParams {
   float sustain;
   float release_len;  // release_s * SR          (frames for a 1 -> 0 fall)
 };
+// value = A + D * (2t - t^2), t = n * inv_len.  Plateaus (IDLE, SUSTAIN) are ramps with
+// D = 0 and N = UINT32_MAX, so the per-frame body is branch-free except the stage boundary.
 struct EnvState {
   uint32_t state, n, N;
-  float A, B, inv_len, value;
+  float A, D, inv_len, value;
 };
 GROOVE_HD uint32_t env_frames(float len) {
   if (!(len > 0.0f)) return 0u;
@@ -232,9 +220,13 @@ GROOVE_HD uint32_t env_frames(float len) {
   return c > 4.0e9f ? 4000000000u : (uint32_t)c;
 }
 GROOVE_HD void env_enter_len(EnvState& s, uint32_t st, float from, float to, float len, uint32_t N) {
-  s.state = st; s.n = 0; s.A = from; s.B = to; s.N = N;
+  s.state = st; s.n = 0; s.A = from; s.D = to - from; s.N = N;
   s.inv_len = len > 0.0f ? 1.0f / len : 0.0f;
 }
+GROOVE_HD void env_plateau(EnvState& s, uint32_t st, float level) {
+  s.state = st; s.n = 0; s.N = 0xFFFFFFFFu; s.A = level; s.D = 0.0f; s.inv_len = 0.0f;
+}
+GROOVE_HD void env_init(EnvState& s) { env_plateau(s, ENV_IDLE, 0.0f); s.value = 0.0f; }
 GROOVE_HD void env_trigger_attack(EnvState& s, const EnvParams& p) {
   const float from = s.value;
   if (from == 0.0f) env_enter_len(s, ENV_ATTACK, 0.0f, 1.0f, p.attack_len, p.attack_N);
@@ -247,22 +239,20 @@ GROOVE_HD void env_trigger_release(EnvState& s, const EnvParams& p) {
   env_enter_len(s, ENV_RELEASE, from, 0.0f, len, env_frames(len));
 }
 GROOVE_HD void env_tick(EnvState& s, const EnvParams& p) {
+  if (s.n >= s.N) { // stage boundary (rare): up to two chained transitions in one frame
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const bool ramp = (s.state == ENV_ATTACK) | (s.state == ENV_DECAY) | (s.state == ENV_RELEASE);
-    if (ramp && s.n >= s.N) {
-      if (s.state == ENV_ATTACK) env_enter_len(s, ENV_DECAY, 1.0f, p.sustain, p.decay_len, p.decay_N);
-      else if (s.state == ENV_DECAY) s.state = ENV_SUSTAIN;
-      else s.state = ENV_IDLE;
+    for (int i = 0; i < 2; ++i) {
+      if (s.n >= s.N) {
+        if (s.state == ENV_ATTACK) env_enter_len(s, ENV_DECAY, 1.0f, p.sustain, p.decay_len, p.decay_N);
+        else if (s.state == ENV_DECAY) env_plateau(s, ENV_SUSTAIN, p.sustain);
+        else if (s.state == ENV_RELEASE) env_plateau(s, ENV_IDLE, 0.0f);
+        else s.n = 0; // plateau counter wrapped after 2^32 frames
+      }
     }
   }
-  if (s.state == ENV_IDLE) s.value = 0.0f;
-  else if (s.state == ENV_SUSTAIN) s.value = p.sustain;
-  else {
-    const float t = (float)s.n * s.inv_len;
-    s.value = fmaf(s.B - s.A, fmaf(-t, t, 2.0f * t), s.A);
-    s.n += 1;
-  }
+  const float t = (float)s.n * s.inv_len;
+  s.value = fmaf(s.D, fmaf(-t, t, 2.0f * t), s.A);
+  s.n += 1;
 }
 
 // ------------------------------------------------------------------ 24 dB low-pass (a4)
@@ -288,17 +278,23 @@ GROOVE_HD float lp24_k(float fc, float pi_over_sr, float fc_max) {
   return tan_pos(fc * pi_over_sr);
 }
 struct Lp24StateD { double s0, s1, s2, s3; };
-GROOVE_HD double lp24_step(Lp24StateD& s, const Lp24Coef& c, double x) {
-  const double b0a = (double)c.b0a, a1a = 2.0 - (double)c.e1a, a2a = (double)c.e2a - 1.0;
-  const double b0b = (double)c.b0b, a1b = 2.0 - (double)c.e1b, a2b = (double)c.e2b - 1.0;
-  const double bx = b0a * x;
+// f64 coefficient set derived from the fp32 small-quantity form (exact conversions).
+struct Lp24CoefD { double b0a, a1a, a2a, b0b, a1b, a2b; };
+GROOVE_HD Lp24CoefD lp24_widen(const Lp24Coef& c) {
+  Lp24CoefD d;
+  d.b0a = (double)c.b0a; d.a1a = 2.0 - (double)c.e1a; d.a2a = (double)c.e2a - 1.0;
+  d.b0b = (double)c.b0b; d.a1b = 2.0 - (double)c.e1b; d.a2b = (double)c.e2b - 1.0;
+  return d;
+}
+GROOVE_HD double lp24_step(Lp24StateD& s, const Lp24CoefD& c, double x) {
+  const double bx = c.b0a * x;
   const double y1 = bx + s.s0;
-  s.s0 = fma(a1a, y1, 2.0 * bx + s.s1);
-  s.s1 = fma(a2a, y1, bx);
-  const double by = b0b * y1;
+  s.s0 = fma(c.a1a, y1, 2.0 * bx + s.s1);
+  s.s1 = fma(c.a2a, y1, bx);
+  const double by = c.b0b * y1;
   const double y2 = by + s.s2;
-  s.s2 = fma(a1b, y2, 2.0 * by + s.s3);
-  s.s3 = fma(a2b, y2, by);
+  s.s2 = fma(c.a1b, y2, 2.0 * by + s.s3);
+  s.s3 = fma(c.a2b, y2, by);
   return y2;
 }
 
@@ -315,9 +311,9 @@ struct WelshParams {
   float o1_duty, o2_duty;
   uint64_t lfo_inc;
   float lfo_depth;
+  float cutoff_hz; // static cutoff
   EnvParams amp, fil;
   Lp24Consts fc;   // filter constants
-  float cutoff_hz; // static cutoff
   float cutoff_start, cutoff_end;
   float gl, gr;    // dca gain * pan law, per channel
 };
@@ -326,30 +322,49 @@ struct WelshState {
   uint64_t o1_inc, o2_inc; // base increments (set by note_on)
   EnvState amp, fil;
   Lp24StateD filt;
-  float nz1, nz2, nzl; // last noise values
+  uint32_t vflags; // VF_FIRST
+  uint32_t pad_;
 };
 struct RenderConsts {
   float pi_over_sr; // pi / SR
   float fc_max;     // 0.49 * SR
 };
+// Per-block scratch that lives in registers across frames but is not persisted.
+struct WelshScratch {
+  Lp24CoefD coef;  // current filter coefficients
+  float prev_pct;  // cutoff percent the coefficients were computed for (NaN = none)
+};
+GROOVE_HD Lp24Coef welsh_static_coef(const WelshParams& p, const RenderConsts& rc) {
+  return lp24_coef_from_k(p.fc, lp24_k(p.cutoff_hz, rc.pi_over_sr, rc.fc_max));
+}
+GROOVE_HD bool welsh_retunes(const WelshParams& p) {
+  return (p.flags & WF_RETUNE_ENV) || (((p.flags >> WF_ROUTING_SHIFT) & 15u) == GROOVE_LFO_FILTER_CUTOFF);
+}
 
+// One frame of one voice.  FIRST: this is frame 0 of a render call (the only frame on which
+// VF_FIRST can be set).  RETUNE: false promises !welsh_retunes(p) for every lane, so the
+// coefficients in `sc` are loop-invariant.
+template <bool FIRST, bool RETUNE>
 GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc,
-                           const Lp24Coef& static_coef, float& L, float& R) {
+                           WelshScratch& sc, float& L, float& R) {
   env_tick(s.amp, p.amp);
   env_tick(s.fil, p.fil);
   if (s.amp.state == ENV_IDLE) { L = 0.0f; R = 0.0f; return; }
   const uint32_t w1 = (p.flags >> WF_O1_WAVE_SHIFT) & 15u, w2 = (p.flags >> WF_O2_WAVE_SHIFT) & 15u;
   const uint32_t wl = (p.flags >> WF_LFO_WAVE_SHIFT) & 15u, routing = (p.flags >> WF_ROUTING_SHIFT) & 15u;
+  const bool first = FIRST && (s.vflags & VF_FIRST);
+  if (FIRST) s.vflags = 0;
 
   // LFO
-  osc_advance(s.lfo, p.lfo_inc);
-  if (wl == GROOVE_WAVE_NOISE) s.nzl = noise_tick(s.lfo);
+  if (!first) s.lfo.phase += p.lfo_inc;
+  float nzl = 0.0f;
+  if (wl == GROOVE_WAVE_NOISE) nzl = noise_tick(s.lfo);
   const uint64_t half = 0x8000000000000000ull;
   uint64_t inc1 = s.o1_inc, inc2 = s.o2_inc;
   uint64_t d1 = p.o1_duty64, d2 = p.o2_duty64;
   float lfo = 0.0f;
   if (routing == GROOVE_LFO_PITCH || routing == GROOVE_LFO_PULSE_WIDTH) {
-    const double l = osc_value_f64(wl, s.lfo, half, s.nzl);
+    const double l = osc_value_f64(wl, s.lfo.phase, half, nzl);
     const double ld = l * (double)p.lfo_depth;
     if (routing == GROOVE_LFO_PITCH) {
       const double m = exp2_small_f64(ld);
@@ -361,40 +376,54 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
     }
     lfo = (float)l;
   } else if (routing != GROOVE_LFO_NONE) {
-    lfo = osc_value(wl, s.lfo, half, s.nzl);
+    lfo = osc_value(wl, s.lfo.phase, half, nzl);
   }
 
-  // oscillators (+ hard sync)
-  const bool wrapped = osc_advance(s.o1, inc1);
-  if (w1 == GROOVE_WAVE_NOISE) s.nz1 = noise_tick(s.o1);
-  if ((p.flags & WF_SYNC) && wrapped) s.o2.flags |= OSC_SYNC;
-  osc_advance(s.o2, inc2);
-  if (w2 == GROOVE_WAVE_NOISE) s.nz2 = noise_tick(s.o2);
-  const float v1 = osc_value(w1, s.o1, d1, s.nz1);
-  const float v2 = osc_value(w2, s.o2, d2, s.nz2);
+  // oscillators (+ hard sync): carry out of the 64-bit add = osc 1 wrapped
+  bool wrapped = false;
+  if (!first) {
+    const uint64_t np = s.o1.phase + inc1;
+    wrapped = np < s.o1.phase;
+    s.o1.phase = np;
+  }
+  float nz1 = 0.0f, nz2 = 0.0f;
+  if (w1 == GROOVE_WAVE_NOISE) nz1 = noise_tick(s.o1);
+  if ((p.flags & WF_SYNC) && wrapped) s.o2.phase = 0;
+  else if (!first) s.o2.phase += inc2;
+  if (w2 == GROOVE_WAVE_NOISE) nz2 = noise_tick(s.o2);
+  const float v1 = osc_value(w1, s.o1.phase, d1, nz1);
+  const float v2 = osc_value(w2, s.o2.phase, d2, nz2);
   const float sum = fmaf(v1, p.mix, v2 * (1.0f - p.mix));
 
   // filter cutoff
-  Lp24Coef coef = static_coef;
-  bool retune = false;
-  float pct = 0.0f;
-  if (p.flags & WF_RETUNE_ENV) {
-    pct = fmaf((1.0f - p.cutoff_start) * p.cutoff_end, s.fil.value, p.cutoff_start);
-    retune = true;
-  } else if (routing == GROOVE_LFO_FILTER_CUTOFF) {
-    pct = p.cutoff_start * fmaf(lfo, p.lfo_depth, 1.0f);
-    retune = true;
+  if (RETUNE) {
+    bool retune = false;
+    float pct = 0.0f;
+    if (p.flags & WF_RETUNE_ENV) {
+      pct = fmaf((1.0f - p.cutoff_start) * p.cutoff_end, s.fil.value, p.cutoff_start);
+      retune = true;
+    } else if (routing == GROOVE_LFO_FILTER_CUTOFF) {
+      pct = p.cutoff_start * fmaf(lfo, p.lfo_depth, 1.0f);
+      retune = true;
+    }
+    if (retune && pct != sc.prev_pct) { // unchanged percent (e.g. envelope plateau): coefficients stand
+      const float fc = 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f); // 25 * 800^pct
+      sc.coef = lp24_widen(lp24_coef_from_k(p.fc, lp24_k(fc, rc.pi_over_sr, rc.fc_max)));
+      sc.prev_pct = pct;
+    }
   }
-  if (retune) {
-    const float fc = 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f); // 25 * 800^pct
-    coef = lp24_coef_from_k(p.fc, lp24_k(fc, rc.pi_over_sr, rc.fc_max));
-  }
-  const float y = (float)lp24_step(s.filt, coef, (double)sum);
+  const float y = (float)lp24_step(s.filt, sc.coef, (double)sum);
   float a = s.amp.value;
   if (routing == GROOVE_LFO_AMPLITUDE) a *= fmaf(lfo, p.lfo_depth, 1.0f);
   const float m = y * a;
   L = m * p.gl;
   R = m * p.gr;
+}
+GROOVE_HD WelshScratch welsh_scratch_init(const WelshParams& p, const RenderConsts& rc) {
+  WelshScratch sc;
+  sc.coef = lp24_widen(welsh_static_coef(p, rc));
+  sc.prev_pct = __builtin_nanf("");
+  return sc;
 }
 
 // ------------------------------------------------------------------ FmVoice (a6)
@@ -407,18 +436,22 @@ struct FmState {
   OscState carrier, modulator;
   uint64_t c_inc, m_inc;
   EnvState cenv, menv;
+  uint32_t vflags, pad_;
 };
+template <bool FIRST>
 GROOVE_HD void fm_frame(const FmParams& p, FmState& s, float& L, float& R) {
   env_tick(s.cenv, p.cenv);
   env_tick(s.menv, p.menv);
   if (s.cenv.state == ENV_IDLE) { L = 0.0f; R = 0.0f; return; }
-  osc_advance(s.modulator, s.m_inc);
-  const double mv = osc_value_f64(GROOVE_WAVE_SINE, s.modulator, 0, 0.0f);
+  const bool first = FIRST && (s.vflags & VF_FIRST);
+  if (FIRST) s.vflags = 0;
+  if (!first) s.modulator.phase += s.m_inc;
+  const double mv = osc_value_f64(GROOVE_WAVE_SINE, s.modulator.phase, 0, 0.0f);
   const double lfm = mv * (double)s.menv.value * p.depth_beta;
   // carrier delta = base * (2^0 + lfm); may go negative (through-zero FM)
   const double turns = (double)s.c_inc * 5.42101086242752217004e-20 * (1.0 + lfm);
-  osc_advance(s.carrier, turns_to_inc(turns));
-  const float cv = osc_value(GROOVE_WAVE_SINE, s.carrier, 0, 0.0f);
+  if (!first) s.carrier.phase += turns_to_inc(turns);
+  const float cv = osc_value(GROOVE_WAVE_SINE, s.carrier.phase, 0, 0.0f);
   const float m = cv * s.cenv.value;
   L = m * p.gl;
   R = m * p.gr;
@@ -435,6 +468,7 @@ struct SamplerParams {
 struct SamplerState {
   uint64_t idx, step;
   uint32_t playing;
+  uint32_t pad_;
 };
 GROOVE_HD float sampler_frame(const SamplerParams& p, SamplerState& s, const float* bank) {
   if (!s.playing) return 0.0f;

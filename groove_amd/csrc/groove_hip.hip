@@ -36,6 +36,9 @@ struct groove_bank {
   uint32_t* d_params = nullptr;
   uint32_t* d_state = nullptr;
   double* d_cold = nullptr; // welsh: [4][n]; fm: ratio [n]
+  WelshParams* d_wave_params = nullptr; // welsh: one entry per 64-lane wave (uniform fast path)
+  uint8_t* d_wg_kind = nullptr;         // welsh: 1 = every wave of the workgroup is patch-uniform
+  uint32_t uniform_wgs = 0, generic_wgs = 0;
   float* d_pcm = nullptr;   // sampler bank
   groove_note_event* d_ev = nullptr;
   size_t ev_cap = 0;
@@ -74,6 +77,10 @@ struct groove_ctx {
   std::vector<groove_fx*> fxs;
   float* d_partial = nullptr;
   size_t partial_cap = 0;
+  float* d_fpart = nullptr;  // fused path: partial[workgroup][2][frames]
+  size_t fpart_cap = 0;
+  float* d_fseg = nullptr;   // fused path: seg[segments][2*frames]
+  size_t fseg_cap = 0;
   int16_t* d_i16 = nullptr;
   size_t i16_cap = 0;
   // RCCL (dlopen'ed lazily)
@@ -116,23 +123,50 @@ int upload_soa(groove_ctx* ctx, uint32_t* dst, const std::vector<T>& aos) {
 }
 inline uint32_t blocks_for(size_t items) { return (uint32_t)((items + kThreads - 1) / kThreads); }
 
+// Welsh: derive + upload parameters only (SoA, cold values, per-wave table, workgroup kinds).
+int welsh_upload_params(groove_bank* b) {
+  groove_ctx* ctx = b->ctx;
+  const double sr = ctx->sr;
+  const uint32_t n = b->n;
+  std::vector<WelshParams> P(n);
+  std::vector<double> cold((size_t)4 * n);
+  for (uint32_t v = 0; v < n; ++v) {
+    WelshCold c;
+    P[v] = derive_welsh(b->welsh[v], sr, c);
+    cold[v] = c.tune1; cold[(size_t)n + v] = c.tune2; cold[(size_t)2 * n + v] = c.fixed1; cold[(size_t)3 * n + v] = c.fixed2;
+  }
+  if (upload_soa(ctx, b->d_params, P)) return 1;
+  GHIP(ctx, hipMemcpy(b->d_cold, cold.data(), cold.size() * 8, hipMemcpyHostToDevice));
+  // wave-uniform fast path: one parameter record per 64-lane group; a workgroup takes the
+  // fast kernel when each of its wavefronts carries a single patch
+  const uint32_t waves = (n + 63) / 64, wgs = blocks_for(n);
+  std::vector<WelshParams> W(waves);
+  std::vector<uint8_t> kind(wgs, 1);
+  for (uint32_t w = 0; w < waves; ++w) {
+    W[w] = P[(size_t)w * 64];
+    const uint32_t hi = std::min<uint32_t>(n, (w + 1) * 64);
+    for (uint32_t v = w * 64 + 1; v < hi; ++v)
+      if (std::memcmp(&P[v], &W[w], sizeof(WelshParams)) != 0) { kind[w / kWaves] = 0; break; }
+  }
+  b->uniform_wgs = 0;
+  for (uint8_t k : kind) b->uniform_wgs += k;
+  b->generic_wgs = wgs - b->uniform_wgs;
+  if (!b->d_wave_params) GHIP(ctx, hipMalloc(&b->d_wave_params, (size_t)waves * sizeof(WelshParams)));
+  if (!b->d_wg_kind) GHIP(ctx, hipMalloc(&b->d_wg_kind, wgs));
+  GHIP(ctx, hipMemcpy(b->d_wave_params, W.data(), (size_t)waves * sizeof(WelshParams), hipMemcpyHostToDevice));
+  GHIP(ctx, hipMemcpy(b->d_wg_kind, kind.data(), wgs, hipMemcpyHostToDevice));
+  return 0;
+}
+
 int bank_derive_and_upload(groove_bank* b) {
   groove_ctx* ctx = b->ctx;
   const double sr = ctx->sr;
   const uint32_t n = b->n;
   GHIP(ctx, hipSetDevice(ctx->device));
   if (b->kind == BANK_WELSH) {
-    std::vector<WelshParams> P(n);
     std::vector<WelshState> S(n, initial_welsh_state());
-    std::vector<double> cold((size_t)4 * n);
-    for (uint32_t v = 0; v < n; ++v) {
-      WelshCold c;
-      P[v] = derive_welsh(b->welsh[v], sr, c);
-      cold[v] = c.tune1; cold[(size_t)n + v] = c.tune2; cold[(size_t)2 * n + v] = c.fixed1; cold[(size_t)3 * n + v] = c.fixed2;
-    }
-    if (upload_soa(ctx, b->d_params, P)) return 1;
+    if (welsh_upload_params(b)) return 1;
     if (upload_soa(ctx, b->d_state, S)) return 1;
-    GHIP(ctx, hipMemcpy(b->d_cold, cold.data(), cold.size() * 8, hipMemcpyHostToDevice));
   } else if (b->kind == BANK_FM) {
     std::vector<FmParams> P(n);
     std::vector<FmState> S(n, initial_fm_state());
@@ -143,7 +177,7 @@ int bank_derive_and_upload(groove_bank* b) {
     GHIP(ctx, hipMemcpy(b->d_cold, ratio.data(), ratio.size() * 8, hipMemcpyHostToDevice));
   } else {
     std::vector<SamplerParams> P(n);
-    std::vector<SamplerState> S(n, SamplerState{0, 0, 0});
+    std::vector<SamplerState> S(n, SamplerState{0, 0, 0, 0});
     for (uint32_t v = 0; v < n; ++v) {
       const groove_sampler_params& sp = b->sampler[v];
       const groove_sample_desc& d = b->descs[sp.sample_index < b->descs.size() ? sp.sample_index : 0];
@@ -406,6 +440,8 @@ void groove_shutdown(groove_ctx* ctx) {
   while (!ctx->fxs.empty()) groove_fx_destroy(ctx->fxs.back());
   groove_comm_destroy(ctx);
   if (ctx->d_partial) hipFree(ctx->d_partial);
+  if (ctx->d_fpart) hipFree(ctx->d_fpart);
+  if (ctx->d_fseg) hipFree(ctx->d_fseg);
   if (ctx->d_i16) hipFree(ctx->d_i16);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -561,7 +597,7 @@ int groove_bank_destroy(groove_bank* b) {
   auto it = std::find(ctx->banks.begin(), ctx->banks.end(), b);
   if (it != ctx->banks.end()) ctx->banks.erase(it);
   if (b->scratch) groove_block_destroy(b->scratch);
-  hipFree(b->d_params); hipFree(b->d_state); hipFree(b->d_cold); hipFree(b->d_pcm); hipFree(b->d_ev);
+  hipFree(b->d_params); hipFree(b->d_state); hipFree(b->d_cold); hipFree(b->d_pcm); hipFree(b->d_ev); hipFree(b->d_wave_params); hipFree(b->d_wg_kind);
   delete b;
   return 0;
 }
@@ -582,41 +618,41 @@ int groove_bank_set_param(groove_bank* b, uint32_t voice, uint32_t control_index
   if (b->kind != BANK_WELSH) return fail(ctx, "groove_bank_set_param: only Welsh banks expose controls");
   const double v01 = value01 < 0.0 ? 0.0 : (value01 > 1.0 ? 1.0 : value01);
   const uint32_t lo = voice == GROOVE_ALL_VOICES ? 0 : voice, hi = voice == GROOVE_ALL_VOICES ? b->n : voice + 1;
-  auto set_word = [&](size_t byte_off, float val) -> int {
-    uint32_t bits; std::memcpy(&bits, &val, 4);
-    hipLaunchKernelGGL(set_word_kernel, dim3(voice == GROOVE_ALL_VOICES ? blocks_for(b->n) : 1), dim3(kThreads), 0,
-                       ctx->stream, b->d_params, b->n, (uint32_t)(byte_off / 4), voice, bits);
-    GHIP(ctx, hipGetLastError());
-    return 0;
-  };
-  switch (control_index) {
-    case GROOVE_CTL_WELSH_DCA_GAIN:
-    case GROOVE_CTL_WELSH_DCA_PAN: {
-      // per-voice pan differs, so recompute per voice unless a single voice / uniform pan
-      for (uint32_t v = lo; v < hi; ++v) {
-        if (control_index == GROOVE_CTL_WELSH_DCA_GAIN) b->welsh[v].dca_gain = (float)v01;
-        else b->welsh[v].dca_pan = (float)(v01 * 2.0 - 1.0); // ControlValue 0..1 → BipolarNormal
-      }
-      if (voice == GROOVE_ALL_VOICES) {
-        std::vector<float> gl(b->n), gr(b->n);
-        for (uint32_t v = 0; v < b->n; ++v) pan_gains(b->welsh[v].dca_gain, b->welsh[v].dca_pan, gl[v], gr[v]);
-        GHIP(ctx, hipStreamSynchronize(ctx->stream));
-        GHIP(ctx, hipMemcpy(b->d_params + (offsetof(WelshParams, gl) / 4) * (size_t)b->n, gl.data(), b->n * 4, hipMemcpyHostToDevice));
-        GHIP(ctx, hipMemcpy(b->d_params + (offsetof(WelshParams, gr) / 4) * (size_t)b->n, gr.data(), b->n * 4, hipMemcpyHostToDevice));
-      } else {
-        float gl, gr;
-        pan_gains(b->welsh[voice].dca_gain, b->welsh[voice].dca_pan, gl, gr);
-        if (set_word(offsetof(WelshParams, gl), gl) || set_word(offsetof(WelshParams, gr), gr)) return 1;
-      }
-      return 0;
+  for (uint32_t v = lo; v < hi; ++v) {
+    groove_welsh_params& p = b->welsh[v];
+    switch (control_index) {
+      case GROOVE_CTL_WELSH_DCA_GAIN: p.dca_gain = (float)v01; break;
+      case GROOVE_CTL_WELSH_DCA_PAN: p.dca_pan = (float)(v01 * 2.0 - 1.0); break; // ControlValue 0..1 → BipolarNormal
+      case GROOVE_CTL_WELSH_CUTOFF: p.filter_cutoff_hz = (float)percent_to_frequency_h(v01); break;
+      default: return fail(ctx, "groove_bank_set_param: unknown control index");
     }
-    case GROOVE_CTL_WELSH_CUTOFF: {
-      const float hz = (float)percent_to_frequency_h(v01);
-      for (uint32_t v = lo; v < hi; ++v) b->welsh[v].filter_cutoff_hz = hz;
-      return set_word(offsetof(WelshParams, cutoff_hz), hz);
-    }
-    default: return fail(ctx, "groove_bank_set_param: unknown control index");
   }
+  // control-plane path: re-derive and re-upload the parameter tables (state is untouched)
+  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  return welsh_upload_params(b);
+}
+static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs, float* out) {
+  groove_ctx* ctx = b->ctx;
+  const dim3 grid(blocks_for(b->n)), blk(kThreads);
+  if (b->kind == BANK_WELSH) {
+    RenderConsts rc{(float)(3.14159265358979323846 / ctx->sr), (float)(0.49 * ctx->sr)};
+    if (b->uniform_wgs) {
+      if (fused) hipLaunchKernelGGL(welsh_render_uniform_kernel<true>, grid, blk, 0, ctx->stream, b->d_wave_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
+      else hipLaunchKernelGGL(welsh_render_uniform_kernel<false>, grid, blk, 0, ctx->stream, b->d_wave_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
+    }
+    if (b->generic_wgs) {
+      if (fused) hipLaunchKernelGGL(welsh_render_kernel<true>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
+      else hipLaunchKernelGGL(welsh_render_kernel<false>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
+    }
+  } else if (b->kind == BANK_FM) {
+    if (fused) hipLaunchKernelGGL(fm_render_kernel<true>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out);
+    else hipLaunchKernelGGL(fm_render_kernel<false>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out);
+  } else {
+    if (fused) hipLaunchKernelGGL(sampler_render_kernel<true>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, b->d_pcm);
+    else hipLaunchKernelGGL(sampler_render_kernel<false>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, b->d_pcm);
+  }
+  GHIP(ctx, hipGetLastError());
+  return 0;
 }
 int groove_bank_render(groove_bank* b, uint32_t frames, groove_block* out) {
   if (!b || !out) return fail(nullptr, "groove_bank_render: NULL argument");
@@ -626,26 +662,35 @@ int groove_bank_render(groove_bank* b, uint32_t frames, groove_block* out) {
   if (frames == 0) return 0;
   GHIP(ctx, hipSetDevice(ctx->device));
   if (flush_events(b)) return 1;
-  const dim3 grid(blocks_for(b->n)), blk(kThreads);
-  const size_t chs = (size_t)out->cap * out->n;
-  if (b->kind == BANK_WELSH) {
-    RenderConsts rc{(float)(3.14159265358979323846 / ctx->sr), (float)(0.49 * ctx->sr)};
-    hipLaunchKernelGGL(welsh_render_kernel, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out->d, rc);
-  } else if (b->kind == BANK_FM) {
-    hipLaunchKernelGGL(fm_render_kernel, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out->d);
-  } else {
-    hipLaunchKernelGGL(sampler_render_kernel, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out->d, b->d_pcm);
-  }
-  GHIP(ctx, hipGetLastError());
-  return 0;
+  return launch_render(b, frames, false, (size_t)out->cap * out->n, out->d);
 }
 int groove_bank_render_mix(groove_bank* b, uint32_t frames, float* bus_dev, int accumulate) {
   if (!b || !bus_dev) return fail(nullptr, "groove_bank_render_mix: NULL argument");
   groove_ctx* ctx = b->ctx;
-  if (frames > GROOVE_BLOCK_FRAMES) return fail(ctx, "groove_bank_render_mix: frames > 256");
-  if (!b->scratch && groove_block_create(ctx, b->n, GROOVE_BLOCK_FRAMES, &b->scratch)) return 1;
-  if (groove_bank_render(b, frames, b->scratch)) return 1;
-  return mix_one(ctx, b->scratch, frames, bus_dev, accumulate);
+  if (frames == 0) return 0;
+  if (frames > 4096) return fail(ctx, "groove_bank_render_mix: frames > 4096");
+  GHIP(ctx, hipSetDevice(ctx->device));
+  if (flush_events(b)) return 1;
+  const uint32_t rows = blocks_for(b->n), cols = 2 * frames;
+  const uint32_t rows_per_seg = 32;
+  const uint32_t segs = (rows + rows_per_seg - 1) / rows_per_seg;
+  if (ctx->fpart_cap < (size_t)rows * cols) {
+    if (ctx->d_fpart) GHIP(ctx, hipFree(ctx->d_fpart));
+    GHIP(ctx, hipMalloc(&ctx->d_fpart, (size_t)rows * cols * 4));
+    ctx->fpart_cap = (size_t)rows * cols;
+  }
+  if (ctx->fseg_cap < (size_t)segs * cols) {
+    if (ctx->d_fseg) GHIP(ctx, hipFree(ctx->d_fseg));
+    GHIP(ctx, hipMalloc(&ctx->d_fseg, (size_t)segs * cols * 4));
+    ctx->fseg_cap = (size_t)segs * cols;
+  }
+  if (launch_render(b, frames, true, 0, ctx->d_fpart)) return 1;
+  hipLaunchKernelGGL(partial_rows_kernel, dim3(blocks_for(cols), segs), dim3(kThreads), 0, ctx->stream, ctx->d_fpart, rows, cols,
+                     rows_per_seg, ctx->d_fseg);
+  hipLaunchKernelGGL(partial_final_kernel, dim3(blocks_for(cols)), dim3(kThreads), 0, ctx->stream, ctx->d_fseg, segs, frames,
+                     bus_dev, accumulate);
+  GHIP(ctx, hipGetLastError());
+  return 0;
 }
 uint32_t groove_bank_state_words(groove_bank* b) { return b ? b->sw : 0; }
 int groove_bank_download_state(groove_bank* b, uint32_t* host_words) {

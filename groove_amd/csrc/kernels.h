@@ -35,62 +35,219 @@ __device__ __forceinline__ void soa_store(uint32_t* __restrict__ buf, uint32_t n
 }
 
 constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+
+// ------------------------------------------------------------------ wave-uniform parameters
+// Voices of one synth share a patch (the reference's WelshSynth is one patch + a voice
+// store), so in a well-grouped project every lane of a wavefront carries identical
+// parameter words.  Then the whole parameter struct is moved to SGPRs with
+// v_readfirstlane: ~35 VGPRs freed, and every `switch (waveform)` / routing test below
+// becomes a scalar branch instead of an exec-mask region.
+template <class T>
+__device__ __forceinline__ bool wave_uniform(const T& x) {
+  const WordsOf<T> w = __builtin_bit_cast(WordsOf<T>, x);
+  bool ok = true;
+#pragma unroll
+  for (uint32_t i = 0; i < sizeof(T) / 4; ++i) ok &= (w.w[i] == (uint32_t)__builtin_amdgcn_readfirstlane((int)w.w[i]));
+  return __all(ok);
+}
+template <class T>
+__device__ __forceinline__ T make_scalar(const T& x) {
+  WordsOf<T> w = __builtin_bit_cast(WordsOf<T>, x);
+#pragma unroll
+  for (uint32_t i = 0; i < sizeof(T) / 4; ++i) w.w[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.w[i]);
+  return __builtin_bit_cast(T, w);
+}
+
+// ------------------------------------------------------------------ fused mix-bus epilogue
+// Orchestrator::gather_audio's "sum += entity.value()" (orchestrator.rs:397-410) without
+// materialising the voice block: per frame the 64 lanes of a wave are summed with DPP
+// (no LDS, no memory), the wave total is parked in lane (frame mod 64) of an accumulator
+// register (one compare + two selects), and every 64 frames the four waves of the workgroup are summed
+// through LDS and one coalesced 256-byte row per channel is written:
+//     partial[workgroup][ch][frame]
+// A second, tiny kernel pair sums the partial rows over workgroups (deterministic order).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float x) {
+  // x + (x moved by the DPP pattern); lanes of rows outside ROW_MASK receive 0
+  return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xf, false));
+}
+// Sum over the 64 lanes; the total is valid in lane 63.
+__device__ __forceinline__ float wave_sum_lane63(float x) {
+  x = dpp_add<0xb1, 0xf>(x);   // quad_perm [1,0,3,2]
+  x = dpp_add<0x4e, 0xf>(x);   // quad_perm [2,3,0,1]
+  x = dpp_add<0x124, 0xf>(x);  // row_ror:4
+  x = dpp_add<0x128, 0xf>(x);  // row_ror:8   → every lane of a 16-lane row holds the row sum
+  x = dpp_add<0x142, 0xa>(x);  // row_bcast:15 into rows 1 and 3
+  x = dpp_add<0x143, 0xc>(x);  // row_bcast:31 into rows 2 and 3
+  return x;
+}
+struct FusedAcc {
+  float accL = 0.0f, accR = 0.0f;
+  __device__ __forceinline__ void add(float L, float R, uint32_t f) {
+    const float tl = wave_sum_lane63(L), tr = wave_sum_lane63(R);
+    const int sl = __builtin_amdgcn_readlane(__builtin_bit_cast(int, tl), 63);
+    const int sr = __builtin_amdgcn_readlane(__builtin_bit_cast(int, tr), 63);
+    const bool mine = (threadIdx.x & 63u) == (f & 63u); // park the totals in lane (f mod 64)
+    accL = mine ? __builtin_bit_cast(float, sl) : accL;
+    accR = mine ? __builtin_bit_cast(float, sr) : accR;
+  }
+  // After frames [f0, f0+count) (count <= 64) have been added: reduce the workgroup's waves
+  // and store partial[wg][ch][f0 + lane].  Must be reached by every thread of the workgroup.
+  __device__ __forceinline__ void flush(float* __restrict__ partial, uint32_t frames, uint32_t f0, uint32_t count) {
+    __shared__ float red[kWaves][2][64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    red[wave][0][lane] = accL;
+    red[wave][1][lane] = accR;
+    __syncthreads();
+    if (wave < 2 && lane < count) { // wave 0 → left, wave 1 → right
+      float t = 0.0f;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) t += red[w][wave][lane];
+      partial[((size_t)blockIdx.x * 2 + wave) * frames + f0 + lane] = t;
+    }
+    __syncthreads();
+    accL = 0.0f; accR = 0.0f;
+  }
+};
+
+// Shared frame loop of the instrument kernels: `frame(f, L, R)` computes one frame of this
+// lane's voice; the epilogue either stores the planar block or feeds the fused bus sum.
+template <bool FUSED, class FrameFn>
+__device__ __forceinline__ void run_frames(uint32_t frames, uint32_t n, uint32_t v, bool active, size_t ch_stride,
+                                           float* __restrict__ out, FrameFn&& frame) {
+  if (FUSED) {
+    FusedAcc acc;
+    for (uint32_t f = 0; f < frames; ++f) {
+      float L, R;
+      frame(f, L, R);
+      acc.add(active ? L : 0.0f, active ? R : 0.0f, f);
+      if ((f & 63u) == 63u) acc.flush(out, frames, f - 63u, 64u);
+    }
+    if (frames & 63u) acc.flush(out, frames, frames & ~63u, frames & 63u);
+  } else {
+    float* __restrict__ oL = out + v;
+    float* __restrict__ oR = out + ch_stride + v;
+    for (uint32_t f = 0; f < frames; ++f) {
+      float L, R;
+      frame(f, L, R);
+      if (active) {
+        oL[(size_t)f * n] = L;
+        oR[(size_t)f * n] = R;
+      }
+    }
+  }
+}
 
 // ------------------------------------------------------------------ instruments
 // a5 WelshVoice: Ticks::tick(frames) + Generates::generate_batch_values.
+// Frame 0 is peeled (first-tick flag); RETUNE=false variants keep the filter coefficients
+// loop-invariant so their f64 widening is hoisted out of the frame loop.
+template <bool FUSED, bool RETUNE>
+__device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s, const RenderConsts& rc,
+                                            uint32_t frames, uint32_t n, uint32_t v, bool active,
+                                            size_t ch_stride, float* __restrict__ out) {
+  WelshScratch sc = welsh_scratch_init(p, rc);
+  run_frames<FUSED>(frames, n, v, active, ch_stride, out, [&](uint32_t f, float& L, float& R) {
+    if (f == 0) welsh_frame<true, RETUNE>(p, s, rc, sc, L, R);
+    else welsh_frame<false, RETUNE>(p, s, rc, sc, L, R);
+  });
+}
+// Generic form: per-lane parameters (any mix of patches inside a wave; exec-masked branches).
+// wg_kind[workgroup] = 1 when every wavefront of the workgroup is patch-uniform: those
+// workgroups belong to welsh_render_uniform_kernel, the others to this kernel (both kernels
+// are launched over the whole grid and a workgroup exits at once if it is not its kind).
+template <bool FUSED>
 __global__ __launch_bounds__(kThreads) void welsh_render_kernel(
     const uint32_t* __restrict__ params, uint32_t* __restrict__ state, uint32_t n, uint32_t frames,
-    size_t ch_stride, float* __restrict__ out, RenderConsts rc) {
-  const uint32_t v = blockIdx.x * kThreads + threadIdx.x;
-  if (v >= n) return;
+    size_t ch_stride, float* __restrict__ out, RenderConsts rc, const uint8_t* __restrict__ wg_kind) {
+  if (wg_kind && wg_kind[blockIdx.x] != 0) return;
+  const uint32_t v0 = blockIdx.x * kThreads + threadIdx.x;
+  const bool active = v0 < n;
+  const uint32_t v = active ? v0 : n - 1; // tail lanes shadow the last voice and store nothing
   const WelshParams p = soa_load<WelshParams>(params, n, v);
   WelshState s = soa_load<WelshState>(state, n, v);
-  const Lp24Coef sc = lp24_coef_from_k(p.fc, lp24_k(p.cutoff_hz, rc.pi_over_sr, rc.fc_max));
-  float* __restrict__ oL = out + v;
-  float* __restrict__ oR = out + ch_stride + v;
-  for (uint32_t f = 0; f < frames; ++f) {
-    float L, R;
-    welsh_frame(p, s, rc, sc, L, R);
-    oL[(size_t)f * n] = L;
-    oR[(size_t)f * n] = R;
-  }
-  soa_store(state, n, v, s);
+  welsh_block<FUSED, true>(p, s, rc, frames, n, v, active, ch_stride, out);
+  if (active) soa_store(state, n, v, s);
+}
+// Wave-uniform form: every 64-lane group shares one patch (the host checks this when the
+// bank is derived), so the parameters are fetched with scalar loads from a per-wave table
+// and live in SGPRs; waveform / routing dispatch is scalar branching.
+template <bool FUSED>
+__global__ __launch_bounds__(kThreads) void welsh_render_uniform_kernel(
+    const WelshParams* __restrict__ wave_params, uint32_t* __restrict__ state, uint32_t n, uint32_t frames,
+    size_t ch_stride, float* __restrict__ out, RenderConsts rc, const uint8_t* __restrict__ wg_kind) {
+  if (wg_kind[blockIdx.x] == 0) return;
+  const uint32_t v0 = blockIdx.x * kThreads + threadIdx.x;
+  const bool active = v0 < n;
+  const uint32_t v = active ? v0 : n - 1;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(v0 >> 6));
+  const WelshParams p = make_scalar(wave_params[wave]);
+  WelshState s = soa_load<WelshState>(state, n, v);
+  if (welsh_retunes(p)) welsh_block<FUSED, true>(p, s, rc, frames, n, v, active, ch_stride, out);
+  else welsh_block<FUSED, false>(p, s, rc, frames, n, v, active, ch_stride, out);
+  if (active) soa_store(state, n, v, s);
 }
 
+template <bool FUSED>
 __global__ __launch_bounds__(kThreads) void fm_render_kernel(
     const uint32_t* __restrict__ params, uint32_t* __restrict__ state, uint32_t n, uint32_t frames,
     size_t ch_stride, float* __restrict__ out) {
-  const uint32_t v = blockIdx.x * kThreads + threadIdx.x;
-  if (v >= n) return;
+  const uint32_t v0 = blockIdx.x * kThreads + threadIdx.x;
+  const bool active = v0 < n;
+  const uint32_t v = active ? v0 : n - 1;
   const FmParams p = soa_load<FmParams>(params, n, v);
   FmState s = soa_load<FmState>(state, n, v);
-  float* __restrict__ oL = out + v;
-  float* __restrict__ oR = out + ch_stride + v;
-  for (uint32_t f = 0; f < frames; ++f) {
-    float L, R;
-    fm_frame(p, s, L, R);
-    oL[(size_t)f * n] = L;
-    oR[(size_t)f * n] = R;
-  }
-  soa_store(state, n, v, s);
+  run_frames<FUSED>(frames, n, v, active, ch_stride, out, [&](uint32_t f, float& L, float& R) {
+    if (f == 0) fm_frame<true>(p, s, L, R);
+    else fm_frame<false>(p, s, L, R);
+  });
+  if (active) soa_store(state, n, v, s);
 }
 
 // a7 SamplerVoice: pointer stepping; the shared bank is a gather served from L2 / MALL.
+template <bool FUSED>
 __global__ __launch_bounds__(kThreads) void sampler_render_kernel(
     const uint32_t* __restrict__ params, uint32_t* __restrict__ state, uint32_t n, uint32_t frames,
     size_t ch_stride, float* __restrict__ out, const float* __restrict__ bank) {
-  const uint32_t v = blockIdx.x * kThreads + threadIdx.x;
-  if (v >= n) return;
+  const uint32_t v0 = blockIdx.x * kThreads + threadIdx.x;
+  const bool active = v0 < n;
+  const uint32_t v = active ? v0 : n - 1;
   const SamplerParams p = soa_load<SamplerParams>(params, n, v);
   SamplerState s = soa_load<SamplerState>(state, n, v);
-  float* __restrict__ oL = out + v;
-  float* __restrict__ oR = out + ch_stride + v;
-  for (uint32_t f = 0; f < frames; ++f) {
-    const float x = sampler_frame(p, s, bank);
-    oL[(size_t)f * n] = x; // mono duplicated to both channels
-    oR[(size_t)f * n] = x;
+  run_frames<FUSED>(frames, n, v, active, ch_stride, out, [&](uint32_t, float& L, float& R) {
+    L = R = sampler_frame(p, s, bank); // mono duplicated to both channels
+  });
+  if (active) soa_store(state, n, v, s);
+}
+
+// Fused path, stage 2: column sums of partial[rows][cols] (cols = 2*frames) over row segments.
+__global__ __launch_bounds__(kThreads) void partial_rows_kernel(
+    const float* __restrict__ partial, uint32_t rows, uint32_t cols, uint32_t rows_per_seg,
+    float* __restrict__ seg_out /*[segs][cols]*/) {
+  const uint32_t c = blockIdx.x * kThreads + threadIdx.x;
+  if (c >= cols) return;
+  const uint32_t r0 = blockIdx.y * rows_per_seg, r1 = min(rows, r0 + rows_per_seg);
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+  uint32_t r = r0;
+  for (; r + 4 <= r1; r += 4) {
+    a0 += partial[(size_t)r * cols + c];
+    a1 += partial[(size_t)(r + 1) * cols + c];
+    a2 += partial[(size_t)(r + 2) * cols + c];
+    a3 += partial[(size_t)(r + 3) * cols + c];
   }
-  soa_store(state, n, v, s);
+  for (; r < r1; ++r) a0 += partial[(size_t)r * cols + c];
+  seg_out[(size_t)blockIdx.y * cols + c] = (a0 + a1) + (a2 + a3);
+}
+// Stage 3: bus[f][ch] (+)= sum_seg seg[seg][ch*frames + f].
+__global__ void partial_final_kernel(const float* __restrict__ seg, uint32_t segs, uint32_t frames,
+                                     float* __restrict__ bus, int accumulate) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 2 * frames) return;
+  float t = 0.0f;
+  for (uint32_t s = 0; s < segs; ++s) t += seg[(size_t)s * 2 * frames + c];
+  const uint32_t ch = c / frames, f = c % frames;
+  if (accumulate) bus[2 * f + ch] += t; else bus[2 * f + ch] = t;
 }
 
 // HandlesMidi: one thread per event (voice != ALL) or one thread per voice (voice == ALL).

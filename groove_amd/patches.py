@@ -116,6 +116,32 @@ def welsh_voices(n, first_voice=0):
     return _tile(table, n, T.WelshParams)
 
 
+def grouped_order(n, first_voice=0):
+    """Project voice indices re-ordered synth-major: all voices of patch 0, then patch 1, ...
+    (stable).  The reference's WelshSynth is ONE patch plus a voice store, so a many-voice
+    project is a set of synths; laying the bank out synth by synth keeps every 64-lane
+    wavefront on one patch.  Returns the original voice index of each lane."""
+    i = np.arange(first_voice, first_voice + n, dtype=np.int64)
+    order = np.argsort(i % N_PATCHES, kind="stable")
+    return i[order]
+
+
+def welsh_voices_grouped(n, first_voice=0):
+    """Same multiset of voices as welsh_voices(n, first_voice), laid out synth-major."""
+    idx = grouped_order(n, first_voice)
+    table = (T.WelshParams * N_PATCHES)(*[welsh_patch(j) for j in range(N_PATCHES)])
+    size = C.sizeof(T.WelshParams)
+    raw = np.frombuffer(bytes(bytearray(table)), dtype=np.uint8).reshape(N_PATCHES, size)
+    out = np.ascontiguousarray(raw[idx % N_PATCHES])
+    return (T.WelshParams * n).from_buffer_copy(out.tobytes()), idx
+
+
+def grouped_note_events(idx, on=True):
+    """Note events for a grouped bank: lane L plays the key of original voice idx[L]."""
+    keys = (36 + (7 * idx) % 49).astype(np.uint8)
+    return T.note_events_np(np.arange(len(idx), dtype=np.uint32), keys, on)
+
+
 def voice_keys(n, first_voice=0):
     """key = 36 + (7 i mod 49)."""
     i = np.arange(first_voice, first_voice + n, dtype=np.int64)

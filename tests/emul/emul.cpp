@@ -32,7 +32,7 @@ void* emul_fm_create(const groove_fm_params* p, uint32_t n, uint32_t sr) {
 void* emul_sampler_create(const float* pcm, uint64_t frames, const groove_sample_desc* d, uint32_t nd,
                           const groove_sampler_params* p, uint32_t n, uint32_t sr) {
   EmulBank* b = new EmulBank(); b->kind = 2; b->n = n; b->sr = sr;
-  b->pcm.assign(pcm, pcm + frames); b->sp.resize(n); b->ss.assign(n, SamplerState{0, 0, 0});
+  b->pcm.assign(pcm, pcm + frames); b->sp.resize(n); b->ss.assign(n, SamplerState{0, 0, 0, 0});
   for (uint32_t v = 0; v < n; ++v) {
     const groove_sample_desc& sd = d[p[v].sample_index < nd ? p[v].sample_index : 0];
     b->sp[v] = SamplerParams{(uint32_t)sd.offset, sd.length, (double)sd.root_hz, p[v].gain, p[v].one_shot};
@@ -58,13 +58,17 @@ void emul_bank_render(void* h, uint32_t frames, float* out) {
   const uint32_t n = b->n;
   RenderConsts rc{(float)(3.14159265358979323846 / b->sr), (float)(0.49 * b->sr)};
   for (uint32_t v = 0; v < n; ++v) {
-    Lp24Coef sc{};
-    if (b->kind == 0) sc = lp24_coef_from_k(b->wp[v].fc, lp24_k(b->wp[v].cutoff_hz, rc.pi_over_sr, rc.fc_max));
+    WelshScratch sc{};
+    bool retunes = false;
+    if (b->kind == 0) { sc = welsh_scratch_init(b->wp[v], rc); retunes = welsh_retunes(b->wp[v]); }
     for (uint32_t f = 0; f < frames; ++f) {
       float L, R;
-      if (b->kind == 0) welsh_frame(b->wp[v], b->ws[v], rc, sc, L, R);
-      else if (b->kind == 1) fm_frame(b->fp[v], b->fs[v], L, R);
-      else { L = R = sampler_frame(b->sp[v], b->ss[v], b->pcm.data()); }
+      if (b->kind == 0) { // mirrors the kernel: frame 0 peeled, RETUNE chosen per lane
+        if (f == 0) { if (retunes) welsh_frame<true, true>(b->wp[v], b->ws[v], rc, sc, L, R); else welsh_frame<true, false>(b->wp[v], b->ws[v], rc, sc, L, R); }
+        else { if (retunes) welsh_frame<false, true>(b->wp[v], b->ws[v], rc, sc, L, R); else welsh_frame<false, false>(b->wp[v], b->ws[v], rc, sc, L, R); }
+      } else if (b->kind == 1) {
+        if (f == 0) fm_frame<true>(b->fp[v], b->fs[v], L, R); else fm_frame<false>(b->fp[v], b->fs[v], L, R);
+      } else { L = R = sampler_frame(b->sp[v], b->ss[v], b->pcm.data()); }
       out[(size_t)f * n + v] = L;
       out[((size_t)frames + f) * n + v] = R;
     }
