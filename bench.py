@@ -158,7 +158,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="welsh-1m", choices=sorted(WORKLOADS))
     ap.add_argument("--voices", type=int, default=0, help="override the workload's total voice count")
-    ap.add_argument("--fused", action="store_true", help="render and mix in one kernel (no materialised voice blocks)")
+    ap.add_argument("--materialise", action="store_true",
+                    help="entity-boundary form: write every voice block to HBM, then run the separate mix kernels "
+                         "(default: fused render+mix, no materialised voice blocks)")
     ap.add_argument("--interleaved", action="store_true", help="voice i uses patch i mod 32 inside every wavefront (generic per-lane kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -187,7 +189,7 @@ def main():
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(uid[0], rank, world)
 
-    fused = args.fused
+    fused = not args.materialise
     proj = Project(ctx, args.workload, lo, hi - lo, fused, grouped=not args.interleaved)
     K, W = args.steps, args.warmup
     bus = ctx.bus((K + W) * FRAMES)

@@ -104,9 +104,11 @@ GROOVE_HD double exp2_small_f64(double x) {
   p = fma(p, t, 1.0);
   return fma(p, t, 1.0);
 }
-// tan(x) for x in (0, pi/2): sin/cos polynomials on [0, pi/4], reflected above.
-GROOVE_HD float tan_pos(float x) {
-  const bool hi = x > 0.78539816339744831f;
+// tan of the angle x in (0, pi/2) REDUCED to [0, pi/4]: returns t = tan(min(x, pi/2 - x)) <= 1 and
+// hi = (x > pi/4), i.e. tan(x) = hi ? 1/t : t.  The caller keeps working with t (never forms
+// 1/t), which is what keeps the filter coefficients accurate next to Nyquist.
+GROOVE_HD float tan_reduced(float x, bool& hi) {
+  hi = x > 0.78539816339744831f;
   const float z = hi ? (1.57079632679489662f - x) : x;
   const float z2 = z * z;
   float s = 2.7557319e-06f;            // sin(z)/z
@@ -119,8 +121,7 @@ GROOVE_HD float tan_pos(float x) {
   c = fmaf(c, z2, 4.1666667e-02f);
   c = fmaf(c, z2, -0.5f);
   c = fmaf(c, z2, 1.0f);
-  const float num = hi ? c : s, den = hi ? s : c;
-  return num * fast_rcp(den);
+  return s * fast_rcp(c);
 }
 GROOVE_HD float clamp01f(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 GROOVE_HD double clamp01d(double x) { return fmin(fmax(x, 0.0), 1.0); }
@@ -259,31 +260,43 @@ GROOVE_HD void env_tick(EnvState& s, const EnvParams& p) {
 // Per-voice constants: c0 = 1/(cosh^2 r - 0.8535..), d1 = c0 sinh r 1.8477..,
 // c2 = 1/(cosh^2 r - 0.1464..), d3 = c2 sinh r 0.7653..  (host, f64 -> f32).
 struct Lp24Consts { float c0, d1, c2, d3; };
-// Coefficients in "small quantity" form: a1 = 2 - e1, a2 = e2 - 1, so that fp32
-// carries full relative precision of the distance from the unit circle.
-struct Lp24Coef { float b0a, e1a, e2a, b0b, e1b, e2b; };
-GROOVE_HD Lp24Coef lp24_coef_from_k(const Lp24Consts& c, float k) {
-  const float K = k * k;
-  const float c1 = k * c.d1, c3 = k * c.d3;
-  const float ia = fast_rcp(c1 + K + c.c0);
-  const float ib = fast_rcp(c3 + K + c.c2);
+// Coefficients in "small quantity" form.  With k = tan(pi fc / SR) each section is
+//   a1 = 2 (c - k^2) / D,  a2 = (d k - k^2 - c) / D,  b0 = k^2 / D,  D = c + d k + k^2.
+// Below SR/4 (k <= 1, poles towards z = +1) fp32 keeps the distance from the unit circle if
+// we carry q1 = 2 - a1, q2 = 1 + a2; above SR/4 (k > 1, poles towards z = -1) the same is true
+// of q1 = 2 + a1, q2 = 1 + a2 written in t = 1/k.  Both cases are one formula in
+// t = min(k, 1/k):   D' = Q + d t + P,  b0 = N / D',  q1 = 2 (d t + 2 P) / D',  q2 = 2 d t / D'
+// with (P, Q, N) = (t^2, c, t^2) below and (c t^2, 1, 1) above; a1 = sgn (2 - q1), a2 = q2 - 1.
+struct Lp24Coef { float b0a, q1a, q2a, b0b, q1b, q2b, sgn; };
+GROOVE_HD Lp24Coef lp24_coef_from_t(const Lp24Consts& c, float t, bool hi) {
+  const float T2 = t * t;
+  const float Pa = hi ? c.c0 * T2 : T2, Qa = hi ? 1.0f : c.c0;
+  const float Pb = hi ? c.c2 * T2 : T2, Qb = hi ? 1.0f : c.c2;
+  const float N = hi ? 1.0f : T2;
+  const float dta = c.d1 * t, dtb = c.d3 * t;
+  const float ia = fast_rcp(Qa + dta + Pa);
+  const float ib = fast_rcp(Qb + dtb + Pb);
   Lp24Coef o;
-  o.b0a = K * ia; o.e1a = 2.0f * (c1 + 2.0f * K) * ia; o.e2a = 2.0f * c1 * ia;
-  o.b0b = K * ib; o.e1b = 2.0f * (c3 + 2.0f * K) * ib; o.e2b = 2.0f * c3 * ib;
+  o.b0a = N * ia; o.q1a = 2.0f * (dta + 2.0f * Pa) * ia; o.q2a = 2.0f * dta * ia;
+  o.b0b = N * ib; o.q1b = 2.0f * (dtb + 2.0f * Pb) * ib; o.q2b = 2.0f * dtb * ib;
+  o.sgn = hi ? -1.0f : 1.0f;
   return o;
 }
-// k = tan(pi * fc / SR); pi_over_sr = pi / SR; fc clamped to [1, 0.49 SR].
-GROOVE_HD float lp24_k(float fc, float pi_over_sr, float fc_max) {
+// Coefficients for cutoff fc (Hz); pi_over_sr = pi / SR; fc clamped to [1, 0.49 SR].
+GROOVE_HD Lp24Coef lp24_coef_from_fc(const Lp24Consts& c, float fc, float pi_over_sr, float fc_max) {
   fc = fminf(fmaxf(fc, 1.0f), fc_max);
-  return tan_pos(fc * pi_over_sr);
+  bool hi;
+  const float t = tan_reduced(fc * pi_over_sr, hi);
+  return lp24_coef_from_t(c, t, hi);
 }
 struct Lp24StateD { double s0, s1, s2, s3; };
 // f64 coefficient set derived from the fp32 small-quantity form (exact conversions).
 struct Lp24CoefD { double b0a, a1a, a2a, b0b, a1b, a2b; };
 GROOVE_HD Lp24CoefD lp24_widen(const Lp24Coef& c) {
   Lp24CoefD d;
-  d.b0a = (double)c.b0a; d.a1a = 2.0 - (double)c.e1a; d.a2a = (double)c.e2a - 1.0;
-  d.b0b = (double)c.b0b; d.a1b = 2.0 - (double)c.e1b; d.a2b = (double)c.e2b - 1.0;
+  const double sg = (double)c.sgn;
+  d.b0a = (double)c.b0a; d.a1a = sg * (2.0 - (double)c.q1a); d.a2a = (double)c.q2a - 1.0;
+  d.b0b = (double)c.b0b; d.a1b = sg * (2.0 - (double)c.q1b); d.a2b = (double)c.q2b - 1.0;
   return d;
 }
 GROOVE_HD double lp24_step(Lp24StateD& s, const Lp24CoefD& c, double x) {
@@ -335,7 +348,7 @@ struct WelshScratch {
   float prev_pct;  // cutoff percent the coefficients were computed for (NaN = none)
 };
 GROOVE_HD Lp24Coef welsh_static_coef(const WelshParams& p, const RenderConsts& rc) {
-  return lp24_coef_from_k(p.fc, lp24_k(p.cutoff_hz, rc.pi_over_sr, rc.fc_max));
+  return lp24_coef_from_fc(p.fc, p.cutoff_hz, rc.pi_over_sr, rc.fc_max);
 }
 GROOVE_HD bool welsh_retunes(const WelshParams& p) {
   return (p.flags & WF_RETUNE_ENV) || (((p.flags >> WF_ROUTING_SHIFT) & 15u) == GROOVE_LFO_FILTER_CUTOFF);
@@ -408,7 +421,7 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
     }
     if (retune && pct != sc.prev_pct) { // unchanged percent (e.g. envelope plateau): coefficients stand
       const float fc = 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f); // 25 * 800^pct
-      sc.coef = lp24_widen(lp24_coef_from_k(p.fc, lp24_k(fc, rc.pi_over_sr, rc.fc_max)));
+      sc.coef = lp24_widen(lp24_coef_from_fc(p.fc, fc, rc.pi_over_sr, rc.fc_max));
       sc.prev_pct = pct;
     }
   }

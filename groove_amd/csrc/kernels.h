@@ -19,19 +19,30 @@ namespace groove {
 
 template <class T> struct WordsOf { uint32_t w[sizeof(T) / 4]; };
 
+// Word-major SoA access through a buffer resource: the descriptor sits in 4 SGPRs, the row
+// offset (w * n * 4) is the scalar soffset and the lane offset (v * 4) one shared 32-bit VGPR,
+// so loading or storing a 40-word record costs no address registers at all (with flat
+// `global_load` the compiler keeps one 64-bit VGPR address per word alive from the load to
+// the matching store at the end of the kernel: +80 VGPRs, one occupancy step).
+// Limit: words * n * 4 bytes < 4 GiB (checked on the host when a bank is created).
 template <class T>
 __device__ __forceinline__ T soa_load(const uint32_t* __restrict__ buf, uint32_t n, uint32_t v) {
   static_assert(sizeof(T) % 4 == 0, "word-major SoA needs 4-byte multiples");
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(buf), 0, (int)(sizeof(T) / 4 * n * 4u), 0x00020000);
   WordsOf<T> t;
 #pragma unroll
-  for (uint32_t i = 0; i < sizeof(T) / 4; ++i) t.w[i] = buf[(size_t)i * n + v];
+  for (uint32_t i = 0; i < sizeof(T) / 4; ++i)
+    t.w[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(v * 4u), (int)(i * n * 4u), 0);
   return __builtin_bit_cast(T, t);
 }
 template <class T>
 __device__ __forceinline__ void soa_store(uint32_t* __restrict__ buf, uint32_t n, uint32_t v, const T& x) {
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(buf, 0, (int)(sizeof(T) / 4 * n * 4u), 0x00020000);
   const WordsOf<T> t = __builtin_bit_cast(WordsOf<T>, x);
 #pragma unroll
-  for (uint32_t i = 0; i < sizeof(T) / 4; ++i) buf[(size_t)i * n + v] = t.w[i];
+  for (uint32_t i = 0; i < sizeof(T) / 4; ++i)
+    __builtin_amdgcn_raw_buffer_store_b32((int)t.w[i], rsrc, (int)(v * 4u), (int)(i * n * 4u), 0);
 }
 
 constexpr int kThreads = 256;
@@ -126,14 +137,14 @@ __device__ __forceinline__ void run_frames(uint32_t frames, uint32_t n, uint32_t
     }
     if (frames & 63u) acc.flush(out, frames, frames & ~63u, frames & 63u);
   } else {
-    float* __restrict__ oL = out + v;
-    float* __restrict__ oR = out + ch_stride + v;
     for (uint32_t f = 0; f < frames; ++f) {
       float L, R;
       frame(f, L, R);
-      if (active) {
-        oL[(size_t)f * n] = L;
-        oR[(size_t)f * n] = R;
+      if (active) { // uniform row base + 32-bit lane offset
+        float* __restrict__ rowL = out + (size_t)f * n;
+        float* __restrict__ rowR = out + ch_stride + (size_t)f * n;
+        rowL[v] = L;
+        rowR[v] = R;
       }
     }
   }
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(kThreads) void welsh_render_kernel(
 // bank is derived), so the parameters are fetched with scalar loads from a per-wave table
 // and live in SGPRs; waveform / routing dispatch is scalar branching.
 template <bool FUSED>
-__global__ __launch_bounds__(kThreads) void welsh_render_uniform_kernel(
+__global__ __launch_bounds__(kThreads, 3) void welsh_render_uniform_kernel(
     const WelshParams* __restrict__ wave_params, uint32_t* __restrict__ state, uint32_t n, uint32_t frames,
     size_t ch_stride, float* __restrict__ out, RenderConsts rc, const uint8_t* __restrict__ wg_kind) {
   if (wg_kind[blockIdx.x] == 0) return;

