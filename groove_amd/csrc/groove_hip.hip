@@ -274,14 +274,14 @@ int ensure_partial(groove_ctx* ctx, size_t floats) {
 
 constexpr uint32_t kMixSeg = 16384; // floats of one row summed by one workgroup
 
-int mix_one(groove_ctx* ctx, const groove_block* b, uint32_t frames, float* bus, int accumulate) {
+int mix_one(groove_ctx* ctx, const groove_block* b, uint32_t frames, float* bus, int accumulate, size_t planar_stride = 0) {
   const uint32_t n_seg = (b->n + kMixSeg - 1) / kMixSeg;
   const uint32_t rows = 2 * frames;
   if (ensure_partial(ctx, (size_t)rows * n_seg)) return 1;
   hipLaunchKernelGGL(mix_partial_kernel, dim3(n_seg, rows), dim3(kThreads), 0, ctx->stream, b->d, b->n, frames,
                      (size_t)b->cap * b->n, kMixSeg, ctx->d_partial, n_seg);
   hipLaunchKernelGGL(mix_final_kernel, dim3(blocks_for(rows)), dim3(kThreads), 0, ctx->stream, ctx->d_partial,
-                     frames, n_seg, bus, accumulate);
+                     frames, n_seg, bus, accumulate, planar_stride);
   GHIP(ctx, hipGetLastError());
   return 0;
 }
@@ -836,6 +836,28 @@ int groove_mix(groove_ctx* ctx, groove_block* const* blocks, uint32_t n_blocks, 
     if (frames > blocks[i]->cap) return fail(ctx, "groove_mix: frames > block capacity");
     if (mix_one(ctx, blocks[i], frames, bus_dev, accumulate || i > 0)) return 1;
   }
+  return 0;
+}
+int groove_block_accumulate(groove_block* dst, groove_block* src, uint32_t frames, int accumulate) {
+  if (!dst || !src) return fail(nullptr, "groove_block_accumulate: NULL argument");
+  groove_ctx* ctx = dst->ctx;
+  if (frames > dst->cap || frames > src->cap) return fail(ctx, "groove_block_accumulate: frames > block capacity");
+  if (frames == 0) return 0;
+  GHIP(ctx, hipSetDevice(ctx->device));
+  if (src->n == dst->n) {
+    const size_t total = (size_t)2 * frames * src->n;
+    const uint32_t g = (uint32_t)std::min<size_t>(blocks_for(total), 256 * 16);
+    hipLaunchKernelGGL(block_add_kernel, dim3(g), dim3(kThreads), 0, ctx->stream, dst->d, (size_t)dst->cap * dst->n,
+                       src->d, (size_t)src->cap * src->n, src->n, frames, accumulate);
+    GHIP(ctx, hipGetLastError());
+    return 0;
+  }
+  if (dst->n == 1) return mix_one(ctx, src, frames, dst->d, accumulate, (size_t)dst->cap);
+  return fail(ctx, "groove_block_accumulate: lane counts differ and the destination is not a 1-lane block");
+}
+int groove_block_zero(groove_block* b) {
+  if (!b) return fail(nullptr, "groove_block_zero: NULL argument");
+  GHIP(b->ctx, hipMemsetAsync(b->d, 0, (size_t)2 * b->cap * b->n * 4, b->ctx->stream));
   return 0;
 }
 int groove_bus_create(groove_ctx* ctx, size_t frames, float** out_dev) {

@@ -346,15 +346,29 @@ __global__ __launch_bounds__(kThreads) void mix_partial_kernel(
     partial[(size_t)row * n_seg + seg] = t;
   }
 }
-// Stage 2: bus[f][ch] (+)= sum_seg partial[row][seg]; one thread per row.
+// Stage 2: bus[f][ch] (+)= sum_seg partial[row][seg]; one thread per row.  planar_stride = 0
+// writes the interleaved bus; otherwise a one-lane block dst[ch * planar_stride + f].
 __global__ void mix_final_kernel(const float* __restrict__ partial, uint32_t frames, uint32_t n_seg,
-                                 float* __restrict__ bus, int accumulate) {
+                                 float* __restrict__ bus, int accumulate, size_t planar_stride) {
   const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= 2 * frames) return;
   float t = 0.0f;
   for (uint32_t s = 0; s < n_seg; ++s) t += partial[(size_t)row * n_seg + s];
   const uint32_t ch = row / frames, f = row % frames;
-  if (accumulate) bus[2 * f + ch] += t; else bus[2 * f + ch] = t;
+  float* dst = planar_stride ? bus + ch * planar_stride + f : bus + 2 * f + ch;
+  if (accumulate) *dst += t; else *dst = t;
+}
+// dst (+)= src, element-wise over [2][frames][n] blocks with their own channel strides.
+__global__ __launch_bounds__(kThreads) void block_add_kernel(
+    float* __restrict__ dst, size_t dst_chs, const float* __restrict__ src, size_t src_chs,
+    uint32_t n, uint32_t frames, int accumulate) {
+  const size_t per_ch = (size_t)frames * n;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < 2 * per_ch; i += (size_t)gridDim.x * kThreads) {
+    const size_t ch = i / per_ch, r = i % per_ch;
+    const float x = src[ch * src_chs + r];
+    float* d = dst + ch * dst_chs + r;
+    *d = accumulate ? *d + x : x;
+  }
 }
 // WAV sink quantisation (helpers.rs:79-91): (x * 32767) as i16, truncating, saturating.
 __global__ void bus_to_i16_kernel(const float* __restrict__ bus, size_t count, int16_t* __restrict__ out) {

@@ -1,0 +1,481 @@
+// groove_host.cpp — see groove_host.hpp.  Every audio operation goes through the C ABI of
+// libgroove_hip.so; there is no CPU audio path here.
+#include "groove_host.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace groove_host {
+
+// ------------------------------------------------------------------ VoiceBankInstrument
+VoiceBankInstrument::VoiceBankInstrument(groove_ctx* ctx, groove_bank* bank, uint32_t voices, bool sum_voices,
+                                         double release_seconds, bool one_voice_per_key)
+    : ctx_(ctx), bank_(bank), voices_(voices), sum_voices_(sum_voices), release_seconds_(release_seconds),
+      per_key_(one_voice_per_key), key_of_voice_(voices, -1), busy_until_(voices, 0), started_(voices, 0) {
+  groove_block_create(ctx_, voices_, GROOVE_BLOCK_FRAMES, &block_);
+  if (sum_voices_) groove_block_create(ctx_, 1, GROOVE_BLOCK_FRAMES, &summed_);
+}
+VoiceBankInstrument::~VoiceBankInstrument() {
+  if (summed_) groove_block_destroy(summed_);
+  if (block_) groove_block_destroy(block_);
+  if (bank_) groove_bank_destroy(bank_);
+}
+int VoiceBankInstrument::tick(uint32_t frames) {
+  if (groove_bank_render(bank_, frames, block_)) return 1;
+  if (sum_voices_) return groove_block_accumulate(summed_, block_, frames, 0); // Synthesizer: sum of voices
+  return 0;
+}
+void VoiceBankInstrument::note_on(uint8_t key, uint8_t velocity, uint64_t now) {
+  // VoiceStore: first idle voice (Appendix A.6); Drumkit: VoicePerNoteStore (A.10).  "Idle" is
+  // tracked on the host: a voice is busy from note-on until note-off + the patch's release time.
+  uint32_t v = voices_;
+  if (per_key_) {
+    for (uint32_t i = 0; i < voices_; ++i) if (key_of_voice_[i] == (int)key) { v = i; break; }
+  }
+  if (v == voices_)
+    for (uint32_t i = 0; i < voices_; ++i)
+      if (key_of_voice_[i] < 0 && busy_until_[i] <= now) { v = i; break; }
+  if (v == voices_) { // all busy: steal the voice that started first
+    v = 0;
+    for (uint32_t i = 1; i < voices_; ++i) if (started_[i] < started_[v]) v = i;
+  }
+  key_of_voice_[v] = key;
+  started_[v] = now;
+  busy_until_[v] = UINT64_MAX;
+  last_voice_ = v;
+  groove_note_event e{v, key, velocity, 1, 0};
+  groove_bank_note_events(bank_, &e, 1);
+}
+void VoiceBankInstrument::note_off(uint8_t key, uint8_t velocity, uint64_t now) {
+  for (uint32_t i = 0; i < voices_; ++i) {
+    if (key_of_voice_[i] == (int)key) {
+      groove_note_event e{i, key, velocity, 0, 0};
+      groove_bank_note_events(bank_, &e, 1);
+      if (!per_key_) key_of_voice_[i] = -1;
+      busy_until_[i] = now + (uint64_t)std::ceil(release_seconds_ * groove_sample_rate(ctx_)) + 1;
+      if (per_key_) busy_until_[i] = now;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ ToyAudioSource
+ToyAudioSource::ToyAudioSource(groove_ctx* ctx, double level) : ctx_(ctx), level_((float)level) {
+  groove_block_create(ctx_, 1, GROOVE_BLOCK_FRAMES, &block_);
+  host_.assign(2 * GROOVE_BLOCK_FRAMES, level_);
+  groove_block_upload(block_, host_.data(), GROOVE_BLOCK_FRAMES);
+}
+ToyAudioSource::~ToyAudioSource() { if (block_) groove_block_destroy(block_); }
+int ToyAudioSource::tick(uint32_t) { return 0; } // the block already holds `level` everywhere
+
+// ------------------------------------------------------------------ FxEffect
+FxEffect::FxEffect(groove_ctx* ctx, uint32_t kind, const groove_fx_params* p, uint32_t lanes) : ctx_(ctx), lanes_(lanes) {
+  groove_fx_create(ctx_, kind, p, lanes, &fx_);
+}
+FxEffect::~FxEffect() { if (fx_) groove_fx_destroy(fx_); }
+int FxEffect::transform_audio(groove_block* inout, uint32_t frames) {
+  if (!fx_) return 1;
+  return groove_fx_process(fx_, inout, frames);
+}
+int FxEffect::control_set_param(uint32_t index, double value01) {
+  if (!fx_) return 1;
+  return groove_fx_set_param(fx_, GROOVE_ALL_VOICES, index, value01);
+}
+int FxEffect::control_index_for_name(const std::string& name) const {
+  // #[derive(Control)] kebab-case names (proc-macros/src/control.rs:127-131, 165)
+  static const std::pair<const char*, int> table[] = {
+      {"ceiling", GROOVE_CTL_FX_CEILING}, {"bits", GROOVE_CTL_FX_BITS}, {"bits-to-crush", GROOVE_CTL_FX_BITS},
+      {"cutoff", GROOVE_CTL_FX_CUTOFF}, {"q", GROOVE_CTL_FX_Q}, {"passband-ripple", GROOVE_CTL_FX_PASSBAND_RIPPLE},
+      {"attenuation", GROOVE_CTL_FX_ATTENUATION}, {"wet-dry-mix", GROOVE_CTL_FX_WET}};
+  for (auto& t : table) if (name == t.first) return t.second;
+  return -1;
+}
+
+// ------------------------------------------------------------------ Sequencer / ControlTrip
+void Sequencer::insert(uint8_t channel, uint8_t key, double start_beat, double duration_beats) {
+  const uint64_t a = MusicalTime::from_beats(start_beat).units;
+  const uint64_t b = MusicalTime::from_beats(start_beat + duration_beats).units;
+  events_.push_back({a, channel, key, true});
+  events_.push_back({b, channel, key, false});
+  std::stable_sort(events_.begin(), events_.end(), [](const Ev& x, const Ev& y) { return x.at < y.at; });
+  if (!explicit_end_) end_ = std::max(end_, b);
+}
+void Sequencer::work(uint64_t start_units, uint64_t end_units, std::vector<MidiEvent>& out, Orchestrator&) {
+  for (const Ev& e : events_)
+    if (e.at >= start_units && e.at < end_units) out.push_back({e.channel, e.key, 127, e.on});
+}
+double ControlTrip::value_at(const ControlStep& s, double t) {
+  t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+  switch (s.kind) {
+    case ControlStep::FLAT: return s.start;
+    case ControlStep::SLOPE: return s.start + (s.end - s.start) * t;
+    // logarithmic / exponential shapes: the MMA convex / concave transforms of the linear ramp
+    // (orchestration/src/util.rs:4-21)
+    case ControlStep::LOGARITHMIC: {
+      const double c = t < std::pow(10.0, -12.0 / 5.0) ? 0.0 : 1.0 + (5.0 / 12.0) * std::log10(t);
+      return s.start + (s.end - s.start) * c;
+    }
+    case ControlStep::EXPONENTIAL: {
+      const double c = t > 1.0 - std::pow(10.0, -12.0 / 5.0) ? 1.0 : -(5.0 / 12.0) * std::log10(1.0 - t);
+      return s.start + (s.end - s.start) * c;
+    }
+    default: return s.start;
+  }
+}
+uint64_t ControlTrip::end_units_() const {
+  double b = start_;
+  for (auto& s : steps_) b += s.beats;
+  return MusicalTime::from_beats(b).units;
+}
+void ControlTrip::work(uint64_t start_units, uint64_t end_units, std::vector<MidiEvent>&, Orchestrator& o) {
+  (void)end_units;
+  const double now = (double)start_units / MusicalTime::UNITS_IN_BEAT; // block-granular: value at block start
+  double b = start_;
+  for (auto& s : steps_) {
+    if (now >= b && now < b + s.beats) {
+      const double v = value_at(s, (now - b) / s.beats);
+      if (v != last_sent_) {
+        last_sent_ = v;
+        if (Entity* e = o.get(target_))
+          if (e->is_effect()) static_cast<Effect*>(e)->control_set_param(index_, v);
+      }
+      return;
+    }
+    b += s.beats;
+  }
+}
+
+// ------------------------------------------------------------------ Orchestrator
+namespace {
+// The main mixer is an effect whose transform_audio is the identity (orchestrator.rs:543-546).
+class MainMixer : public Effect {
+ public:
+  uint32_t lanes() const override { return 1; }
+  int transform_audio(groove_block*, uint32_t) override { return 0; }
+};
+} // namespace
+
+Orchestrator::Orchestrator(int device, uint32_t sample_rate, double bpm) : sr_(sample_rate), bpm_(bpm) {
+  if (groove_init(device, &ctx_)) { err_ = groove_last_error(nullptr); ctx_ = nullptr; return; }
+  if (sample_rate != GROOVE_DEFAULT_SAMPLE_RATE) groove_update_sample_rate(ctx_, sample_rate);
+  nodes_.emplace_back();
+  nodes_[0].entity.reset(new MainMixer());
+  nodes_[0].entity->uid = 0;
+  nodes_[0].entity->name = "main-mixer";
+  bus_frames_ = GROOVE_BLOCK_FRAMES;
+  groove_bus_create(ctx_, bus_frames_, &bus_);
+}
+Orchestrator::~Orchestrator() {
+  if (!ctx_) return;
+  for (auto& n : nodes_) if (n.accum) groove_block_destroy(n.accum);
+  nodes_.clear(); // entities free their banks / effects before the context goes away
+  if (bus_) groove_bus_destroy(ctx_, bus_);
+  groove_shutdown(ctx_);
+}
+int Orchestrator::update_sample_rate(uint32_t hz) {
+  if (groove_update_sample_rate(ctx_, hz)) return fail(groove_last_error(ctx_));
+  sr_ = hz;
+  return 0;
+}
+Uid Orchestrator::add(std::unique_ptr<Entity> e) {
+  nodes_.emplace_back();
+  const Uid uid = nodes_.size() - 1;
+  e->uid = uid;
+  nodes_.back().entity = std::move(e);
+  return uid;
+}
+Entity* Orchestrator::get(Uid uid) { return uid < nodes_.size() ? nodes_[uid].entity.get() : nullptr; }
+int Orchestrator::patch(Uid source, Uid sink) {
+  Entity* in = get(sink);
+  if (!in) return fail("Couldn't find input_uid");
+  if (!in->is_effect()) return fail("Input device doesn't transform audio and can't be patched from output device");
+  Entity* out = get(source);
+  if (!out) return fail("Couldn't find output_uid");
+  if (!(out->is_instrument() || out->is_effect())) return fail("Output device doesn't output audio and can't be patched into input device");
+  if (source == sink) return fail("can't patch a device into itself");
+  nodes_[sink].sources.push_back(source);
+  return 0;
+}
+int Orchestrator::patch_chain_to_main_mixer(const std::vector<Uid>& uids) {
+  for (size_t i = 0; i + 1 < uids.size(); ++i) if (patch(uids[i], uids[i + 1])) return 1;
+  if (!uids.empty()) return patch(uids.back(), kMainMixerUid);
+  return 0;
+}
+void Orchestrator::unpatch_all() { for (auto& n : nodes_) n.sources.clear(); }
+int Orchestrator::connect_midi_downstream(Uid receiver, uint8_t channel) {
+  Entity* e = get(receiver);
+  if (!e || !e->is_instrument()) return fail("MIDI receiver is not an instrument");
+  midi_receivers_.insert({channel, receiver});
+  return 0;
+}
+int Orchestrator::ensure_accum(Node& n, uint32_t lanes) {
+  if (n.accum && n.accum_lanes == lanes) return 0;
+  if (n.accum) groove_block_destroy(n.accum);
+  n.accum = nullptr;
+  if (groove_block_create(ctx_, lanes, GROOVE_BLOCK_FRAMES, &n.accum)) return fail(groove_last_error(ctx_));
+  n.accum_lanes = lanes;
+  return 0;
+}
+// Post-order evaluation of one node for one block (the per-frame DFS of gather_audio, run per block).
+int Orchestrator::eval(Uid uid, uint32_t frames, groove_block** out_block, uint32_t* out_lanes) {
+  Node& n = nodes_[uid];
+  Entity* e = n.entity.get();
+  if (e->is_instrument()) {
+    Instrument* ins = static_cast<Instrument*>(e);
+    if (ins->tick(frames)) return fail(groove_last_error(ctx_));
+    *out_block = ins->output();
+    *out_lanes = ins->lanes();
+    return 0;
+  }
+  if (!e->is_effect()) { *out_block = nullptr; *out_lanes = 0; return 0; }
+  Effect* fx = static_cast<Effect*>(e);
+  const uint32_t lanes = fx->lanes();
+  if (ensure_accum(n, lanes)) return 1;
+  bool first = true;
+  for (Uid s : n.sources) {
+    groove_block* sb = nullptr;
+    uint32_t sl = 0;
+    if (eval(s, frames, &sb, &sl)) return 1;
+    if (!sb) continue;
+    if (sl != lanes && lanes != 1) return fail("patch: source and sink lane counts differ");
+    if (groove_block_accumulate(n.accum, sb, frames, first ? 0 : 1)) return fail(groove_last_error(ctx_));
+    first = false;
+  }
+  if (first) { // an effect at the end of a chain with no input: silence in, so silence out
+    if (groove_block_zero(n.accum)) return fail(groove_last_error(ctx_));
+  }
+  if (fx->transform_audio(n.accum, frames)) return fail(groove_last_error(ctx_));
+  *out_block = n.accum;
+  *out_lanes = lanes;
+  return 0;
+}
+int Orchestrator::gather_audio(uint32_t frames) {
+  if (frames > bus_frames_) return fail("gather_audio: frames > block size");
+  groove_block* b = nullptr;
+  uint32_t lanes = 0;
+  if (eval(kMainMixerUid, frames, &b, &lanes)) return 1;
+  groove_block* arr[1] = {b};
+  if (groove_mix(ctx_, arr, 1, frames, bus_, 0)) return fail(groove_last_error(ctx_));
+  return 0;
+}
+uint64_t Orchestrator::performance_frames() const {
+  uint64_t end = 0;
+  for (auto& n : nodes_)
+    if (n.entity && n.entity->is_controller())
+      end = std::max(end, static_cast<Controller*>(n.entity.get())->end_units());
+  const double beats = (double)end / MusicalTime::UNITS_IN_BEAT;
+  return (uint64_t)std::ceil(beats * 60.0 / bpm_ * (double)sr_);
+}
+void Orchestrator::skip_to_start() { frames_ = 0; performing_ = true; }
+int Orchestrator::tick(StereoSample* out, uint32_t frames, uint32_t* ticks_completed) {
+  // handle_work (orchestrator.rs:631-708): controllers see the block's musical-time range
+  const uint64_t total = performance_frames();
+  uint32_t done = frames;
+  if (performing_) {
+    if (frames_ >= total) done = 0;
+    else if (frames_ + frames > total) done = (uint32_t)(total - frames_);
+  }
+  if (done > 0) {
+    const uint64_t t0 = MusicalTime::frames_to_units(bpm_, sr_, frames_);
+    uint64_t t1 = MusicalTime::frames_to_units(bpm_, sr_, frames_ + done);
+    if (t1 == t0) t1 = t0 + 1;
+    std::vector<MidiEvent> midi;
+    for (auto& n : nodes_)
+      if (n.entity && n.entity->is_controller()) static_cast<Controller*>(n.entity.get())->work(t0, t1, midi, *this);
+    // broadcast_midi_messages (orchestrator.rs:710-754): every receiver on the channel
+    for (const MidiEvent& m : midi) {
+      auto range = midi_receivers_.equal_range(m.channel);
+      for (auto it = range.first; it != range.second; ++it) {
+        Instrument* ins = static_cast<Instrument*>(get(it->second));
+        if (m.on) ins->note_on(m.key, m.velocity, frames_); else ins->note_off(m.key, m.velocity, frames_);
+      }
+    }
+    if (gather_audio(done)) return 1;
+    if (out && groove_download(ctx_, bus_, &out[0].l, (size_t)done * 2)) return fail(groove_last_error(ctx_));
+    if (performing_) frames_ += done; // clock.tick_batch(ticks_completed)
+  }
+  if (done < frames) performing_ = false;
+  *ticks_completed = done;
+  return 0;
+}
+int Orchestrator::run(uint32_t buffer_frames, std::vector<StereoSample>& out) {
+  if (buffer_frames > GROOVE_BLOCK_FRAMES) return fail("run: buffer larger than the block size");
+  skip_to_start();
+  std::vector<StereoSample> buf(buffer_frames);
+  for (;;) {
+    uint32_t done = 0;
+    if (tick(buf.data(), buffer_frames, &done)) return 1;
+    out.insert(out.end(), buf.begin(), buf.begin() + done);
+    if (done < buffer_frames) break;
+  }
+  return 0;
+}
+int Orchestrator::run_performance(uint32_t buffer_frames, Performance& perf) {
+  if (buffer_frames > GROOVE_BLOCK_FRAMES) return fail("run_performance: buffer larger than the block size");
+  perf.sample_rate = sr_;
+  skip_to_start();
+  std::vector<StereoSample> buf(buffer_frames);
+  for (;;) {
+    uint32_t done = 0;
+    if (tick(buf.data(), buffer_frames, &done)) return 1;
+    if (done < buffer_frames) break; // the final partial block is dropped (orchestrator.rs:827-836)
+    perf.worker.insert(perf.worker.end(), buf.begin(), buf.end());
+  }
+  return 0;
+}
+int Orchestrator::send_performance_to_file(const Performance& perf, const std::string& path) {
+  // hound::WavSpec{channels 2, sample_rate, 16-bit Int}; sample = (x * 32767) as i16 (helpers.rs:79-91)
+  const size_t frames = perf.worker.size();
+  std::vector<int16_t> pcm(frames * 2);
+  float* dev = nullptr;
+  if (frames) {
+    if (groove_bus_create(ctx_, frames, &dev)) return fail(groove_last_error(ctx_));
+    if (groove_upload(ctx_, dev, &perf.worker[0].l, frames * 2) || groove_bus_to_i16(ctx_, dev, frames, pcm.data())) {
+      groove_bus_destroy(ctx_, dev);
+      return fail(groove_last_error(ctx_));
+    }
+    groove_bus_destroy(ctx_, dev);
+  }
+  FILE* f = std::fopen(path.c_str(), "wb");
+  if (!f) return fail("Couldn't create path from " + path);
+  const uint32_t data_bytes = (uint32_t)(pcm.size() * 2), sr = perf.sample_rate;
+  const uint32_t riff = 36 + data_bytes, fmt_len = 16, byte_rate = sr * 4;
+  const uint16_t pcm_fmt = 1, ch = 2, align = 4, bits = 16;
+  std::fwrite("RIFF", 1, 4, f); std::fwrite(&riff, 4, 1, f); std::fwrite("WAVEfmt ", 1, 8, f);
+  std::fwrite(&fmt_len, 4, 1, f); std::fwrite(&pcm_fmt, 2, 1, f); std::fwrite(&ch, 2, 1, f);
+  std::fwrite(&sr, 4, 1, f); std::fwrite(&byte_rate, 4, 1, f); std::fwrite(&align, 2, 1, f); std::fwrite(&bits, 2, 1, f);
+  std::fwrite("data", 1, 4, f); std::fwrite(&data_bytes, 4, 1, f);
+  if (!pcm.empty()) std::fwrite(pcm.data(), 2, pcm.size(), f);
+  std::fclose(f);
+  return 0;
+}
+
+} // namespace groove_host
+
+// ====================================================================== C surface for tests / tools
+using namespace groove_host;
+extern "C" {
+void* gh_orchestrator_new(int device, uint32_t sample_rate, double bpm) {
+  Orchestrator* o = new Orchestrator(device, sample_rate, bpm);
+  if (!o->ctx()) { std::fprintf(stderr, "gh_orchestrator_new: %s\n", o->last_error().c_str()); delete o; return nullptr; }
+  return o;
+}
+void gh_orchestrator_free(void* h) { delete (Orchestrator*)h; }
+const char* gh_last_error(void* h) { return ((Orchestrator*)h)->last_error().c_str(); }
+int gh_add_toy_source(void* h, double level) {
+  Orchestrator* o = (Orchestrator*)h;
+  return (int)o->add(std::unique_ptr<Entity>(new ToyAudioSource(o->ctx(), level)));
+}
+// One synth = one patch + `voices` voices (polyphony), summed to one lane.
+int gh_add_welsh(void* h, const groove_welsh_params* patch, uint32_t voices) {
+  Orchestrator* o = (Orchestrator*)h;
+  std::vector<groove_welsh_params> p(voices, *patch);
+  groove_bank* b = nullptr;
+  if (groove_welsh_create(o->ctx(), p.data(), voices, &b)) { o->fail(groove_last_error(o->ctx())); return -1; }
+  return (int)o->add(std::unique_ptr<Entity>(new VoiceBankInstrument(o->ctx(), b, voices, true, patch->amp_envelope.release, false)));
+}
+int gh_add_fm(void* h, const groove_fm_params* patch, uint32_t voices) {
+  Orchestrator* o = (Orchestrator*)h;
+  std::vector<groove_fm_params> p(voices, *patch);
+  groove_bank* b = nullptr;
+  if (groove_fm_create(o->ctx(), p.data(), voices, &b)) { o->fail(groove_last_error(o->ctx())); return -1; }
+  return (int)o->add(std::unique_ptr<Entity>(new VoiceBankInstrument(o->ctx(), b, voices, true, patch->carrier_envelope.release, false)));
+}
+// Drumkit: one one-shot voice per sample buffer; MIDI key k plays buffer key_to_sample[k] (-1: none).
+int gh_add_drumkit(void* h, const float* pcm, uint64_t frames, const groove_sample_desc* descs, uint32_t n_desc,
+                   const int* key_to_sample /*[128]*/) {
+  Orchestrator* o = (Orchestrator*)h;
+  // voice v plays the sample mapped from key v, so that note_on(key) drives voice `key`
+  std::vector<groove_sampler_params> p(128);
+  std::vector<groove_sample_desc> d(descs, descs + n_desc);
+  for (int k = 0; k < 128; ++k) {
+    const int s = key_to_sample[k];
+    p[k].sample_index = s >= 0 && (uint32_t)s < n_desc ? (uint32_t)s : 0;
+    p[k].one_shot = 1;
+    p[k].gain = s >= 0 ? 1.0f : 0.0f;
+  }
+  for (auto& x : d) x.root_hz = 0.0f; // drumkit: step 1 regardless of key
+  groove_bank* b = nullptr;
+  if (groove_sampler_create(o->ctx(), pcm, frames, d.data(), n_desc, p.data(), 128, &b)) { o->fail(groove_last_error(o->ctx())); return -1; }
+  struct Drumkit : VoiceBankInstrument {
+    using VoiceBankInstrument::VoiceBankInstrument;
+    void note_on(uint8_t key, uint8_t vel, uint64_t) override { groove_note_event e{key, key, vel, 1, 0}; groove_bank_note_events(bank(), &e, 1); }
+    void note_off(uint8_t, uint8_t, uint64_t) override {}
+  };
+  return (int)o->add(std::unique_ptr<Entity>(new Drumkit(o->ctx(), b, 128, true, 0.0, true)));
+}
+int gh_add_effect(void* h, uint32_t kind, const groove_fx_params* p) {
+  Orchestrator* o = (Orchestrator*)h;
+  return (int)o->add(std::unique_ptr<Entity>(new FxEffect(o->ctx(), kind, p, 1)));
+}
+int gh_patch(void* h, int source, int sink) { return ((Orchestrator*)h)->patch((Uid)source, (Uid)sink); }
+int gh_patch_chain_to_main_mixer(void* h, const int* uids, uint32_t n) {
+  std::vector<Uid> v(uids, uids + n);
+  return ((Orchestrator*)h)->patch_chain_to_main_mixer(v);
+}
+void gh_unpatch_all(void* h) { ((Orchestrator*)h)->unpatch_all(); }
+int gh_connect_midi_downstream(void* h, int uid, int channel) { return ((Orchestrator*)h)->connect_midi_downstream((Uid)uid, (uint8_t)channel); }
+int gh_add_timer(void* h, double beats) { return (int)((Orchestrator*)h)->add(std::unique_ptr<Entity>(new Timer(beats))); }
+int gh_add_sequencer(void* h) { return (int)((Orchestrator*)h)->add(std::unique_ptr<Entity>(new Sequencer())); }
+int gh_sequencer_insert(void* h, int uid, int channel, int key, double start_beat, double duration_beats) {
+  Entity* e = ((Orchestrator*)h)->get((Uid)uid);
+  if (!e || !e->is_controller()) return 1;
+  static_cast<Sequencer*>(e)->insert((uint8_t)channel, (uint8_t)key, start_beat, duration_beats);
+  return 0;
+}
+int gh_sequencer_set_end(void* h, int uid, double beats) {
+  Entity* e = ((Orchestrator*)h)->get((Uid)uid);
+  if (!e || !e->is_controller()) return 1;
+  static_cast<Sequencer*>(e)->set_end_beats(beats);
+  return 0;
+}
+int gh_add_control_trip(void* h, int target_uid, const char* param_name, double start_beat) {
+  Orchestrator* o = (Orchestrator*)h;
+  Entity* e = o->get((Uid)target_uid);
+  if (!e || !e->is_effect()) { o->fail("control trip target is not an effect"); return -1; }
+  const int idx = static_cast<Effect*>(e)->control_index_for_name(param_name);
+  if (idx < 0) { o->fail(std::string("unknown control name ") + param_name); return -1; }
+  return (int)o->add(std::unique_ptr<Entity>(new ControlTrip((Uid)target_uid, (uint32_t)idx, start_beat)));
+}
+int gh_control_trip_add_step(void* h, int uid, int kind, double start, double end, double beats) {
+  Entity* e = ((Orchestrator*)h)->get((Uid)uid);
+  if (!e || !e->is_controller()) return 1;
+  ControlStep s; s.kind = (ControlStep::Kind)kind; s.start = start; s.end = end; s.beats = beats;
+  static_cast<ControlTrip*>(e)->add_step(s);
+  return 0;
+}
+double gh_control_step_value(int kind, double start, double end, double t01) {
+  ControlStep s; s.kind = (ControlStep::Kind)kind; s.start = start; s.end = end;
+  return ControlTrip::value_at(s, t01);
+}
+int gh_last_allocated_voice(void* h, int uid) {
+  Entity* e = ((Orchestrator*)h)->get((Uid)uid);
+  if (!e || !e->is_instrument()) return -1;
+  return (int)static_cast<VoiceBankInstrument*>(e)->last_allocated_voice();
+}
+int gh_gather_audio(void* h, uint32_t frames, float* out_interleaved) {
+  Orchestrator* o = (Orchestrator*)h;
+  uint32_t done = 0;
+  return o->tick((StereoSample*)out_interleaved, frames, &done);
+}
+uint64_t gh_performance_frames(void* h) { return ((Orchestrator*)h)->performance_frames(); }
+// Runs the whole performance; returns the number of frames written (<= cap), or -1.
+int64_t gh_run(void* h, uint32_t buffer_frames, float* out_interleaved, uint64_t cap_frames, int performance_mode) {
+  Orchestrator* o = (Orchestrator*)h;
+  std::vector<StereoSample> out;
+  if (performance_mode) {
+    Performance p;
+    if (o->run_performance(buffer_frames, p)) return -1;
+    out.swap(p.worker);
+  } else if (o->run(buffer_frames, out)) return -1;
+  const uint64_t n = std::min<uint64_t>(cap_frames, out.size());
+  if (n) std::memcpy(out_interleaved, out.data(), n * sizeof(StereoSample));
+  return (int64_t)out.size();
+}
+int gh_render_to_wav(void* h, uint32_t buffer_frames, const char* path) {
+  Orchestrator* o = (Orchestrator*)h;
+  Performance p;
+  if (o->run_performance(buffer_frames, p)) return 1;
+  return o->send_performance_to_file(p, path);
+}
+}

@@ -1,0 +1,278 @@
+// groove_host.hpp — compiled host layer above the C ABI (include/groove_hip.h).
+//
+// The reference's host code is Rust; no Rust toolchain exists in the build image, so the
+// host side that sits above the FFI is written in C++ and mirrors the reference's
+// operator surface for this path, name for name:
+//
+//   Orchestrator::{add, patch, patch_chain_to_main_mixer, unpatch_all,
+//                  connect_midi_downstream, tick, gather_audio, run, run_performance,
+//                  update_sample_rate}      /root/reference/orchestration/src/orchestrator.rs
+//                                           :136-142, 263-325, 472-490, 367-470, 788-877
+//   Performance{sample_rate, worker}        orchestrator.rs:32-46
+//   IsInstrument / IsEffect / IsController  proc-macros/src/entity.rs:29-139
+//   IOHelper::send_performance_to_file      orchestration/src/helpers.rs:74-97
+//
+// Block semantics.  The reference evaluates the patch graph once per FRAME
+// (gather_audio, orchestrator.rs:367-470); here the same post-order traversal runs once
+// per BLOCK on device blocks, which is equivalent because entities never reference each
+// other and events are block-granular already (tick(): handle_work once, then gather).
+// A node's output is a device block with `lanes` lanes.  A WelshSynth with 8 voices is
+// one entity whose voices are summed to ONE lane (the reference's Synthesizer sums its
+// voice store); "batched" instruments (`sum_voices = false`) keep one lane per voice so
+// that per-voice effect chains (BASELINE config #3) run as wide effect banks.  An effect
+// sums ALL its sources, then transforms the sum once (orchestrator.rs:438-457, pinned by
+// the fan-in test :1642-1668); sources with more lanes than the sink are lane-summed.
+#pragma once
+#include "../../include/groove_hip.h"
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+#include <map>
+
+namespace groove_host {
+
+using Uid = size_t;
+constexpr Uid kMainMixerUid = 0; // MAIN_MIXER_UVID, orchestrator.rs:104, 543-546
+
+struct StereoSample { float l, r; };
+
+// Performance, orchestrator.rs:32-46 (the FIFO worker is a plain vector here).
+struct Performance {
+  uint32_t sample_rate = GROOVE_DEFAULT_SAMPLE_RATE;
+  std::vector<StereoSample> worker;
+};
+
+// MusicalTime: 65,536 units per beat (src/mini/transport.rs:157-176, doc/designs/time.md:94-98).
+struct MusicalTime {
+  static constexpr uint64_t UNITS_IN_BEAT = 65536;
+  uint64_t units = 0;
+  static MusicalTime from_beats(double beats) { return {(uint64_t)(beats * UNITS_IN_BEAT + 0.5)}; }
+  static uint64_t frames_to_units(double bpm, uint32_t sr, uint64_t frames) {
+    return (uint64_t)((double)frames * bpm / 60.0 / (double)sr * (double)UNITS_IN_BEAT);
+  }
+  double beats() const { return (double)units / UNITS_IN_BEAT; }
+};
+
+class Orchestrator;
+
+class Entity {
+ public:
+  virtual ~Entity() = default;
+  Uid uid = 0;
+  std::string name;
+  virtual bool is_instrument() const { return false; }
+  virtual bool is_effect() const { return false; }
+  virtual bool is_controller() const { return false; }
+};
+
+// IsInstrument: Generates<StereoSample> + Ticks + HandlesMidi.
+class Instrument : public Entity {
+ public:
+  bool is_instrument() const override { return true; }
+  virtual uint32_t lanes() const = 0;          // lanes of the block it outputs
+  virtual groove_block* output() = 0;
+  virtual int tick(uint32_t frames) = 0;       // render `frames` into output()
+  // HandlesMidi::handle_midi_message (note on/off only on this path)
+  virtual void note_on(uint8_t key, uint8_t velocity, uint64_t now_frame) = 0;
+  virtual void note_off(uint8_t key, uint8_t velocity, uint64_t now_frame) = 0;
+};
+
+// IsEffect: TransformsAudio.
+class Effect : public Entity {
+ public:
+  bool is_effect() const override { return true; }
+  virtual uint32_t lanes() const = 0;
+  virtual int transform_audio(groove_block* inout, uint32_t frames) = 0;
+  virtual int control_set_param(uint32_t index, double value01) { (void)index; (void)value01; return 1; }
+  virtual int control_index_for_name(const std::string&) const { return -1; }
+};
+
+// IsController: Controls (update_time / work / is_finished), src/mini/transport.rs:116-151.
+struct MidiEvent { uint8_t channel, key, velocity; bool on; };
+class Controller : public Entity {
+ public:
+  bool is_controller() const override { return true; }
+  // events that fall inside [start, end) musical-time units, appended to `out`
+  virtual void work(uint64_t start_units, uint64_t end_units, std::vector<MidiEvent>& out,
+                    Orchestrator& o) = 0;
+  virtual bool is_finished(uint64_t end_units) const = 0;
+  virtual uint64_t end_units() const = 0;
+  virtual void skip_to_start() {}
+};
+
+// ---- concrete entities -------------------------------------------------------------------
+// A synth = ONE patch + a voice store (first-idle allocation, A.6); voices summed to 1 lane.
+class VoiceBankInstrument : public Instrument {
+ public:
+  VoiceBankInstrument(groove_ctx* ctx, groove_bank* bank, uint32_t voices, bool sum_voices,
+                      double release_seconds, bool one_voice_per_key);
+  ~VoiceBankInstrument() override;
+  uint32_t lanes() const override { return sum_voices_ ? 1 : voices_; }
+  groove_block* output() override { return sum_voices_ ? summed_ : block_; }
+  int tick(uint32_t frames) override;
+  void note_on(uint8_t key, uint8_t velocity, uint64_t now_frame) override;
+  void note_off(uint8_t key, uint8_t velocity, uint64_t now_frame) override;
+  groove_bank* bank() { return bank_; }
+  uint32_t last_allocated_voice() const { return last_voice_; }
+ private:
+  groove_ctx* ctx_;
+  groove_bank* bank_;
+  uint32_t voices_;
+  bool sum_voices_;
+  double release_seconds_;
+  bool per_key_; // Drumkit: one voice per note (A.10)
+  groove_block* block_ = nullptr;
+  groove_block* summed_ = nullptr;
+  std::vector<int> key_of_voice_;        // -1 = free
+  std::vector<uint64_t> busy_until_;     // frame until which the voice may still sound
+  std::vector<uint64_t> started_;
+  uint32_t last_voice_ = 0;
+};
+
+// ToyAudioSource{level}: constant-level instrument used by the reference's mix-bus tests.
+class ToyAudioSource : public Instrument {
+ public:
+  ToyAudioSource(groove_ctx* ctx, double level);
+  ~ToyAudioSource() override;
+  uint32_t lanes() const override { return 1; }
+  groove_block* output() override { return block_; }
+  int tick(uint32_t frames) override;
+  void note_on(uint8_t, uint8_t, uint64_t) override {}
+  void note_off(uint8_t, uint8_t, uint64_t) override {}
+ private:
+  groove_ctx* ctx_;
+  float level_;
+  groove_block* block_ = nullptr;
+  std::vector<float> host_;
+};
+
+class FxEffect : public Effect {
+ public:
+  FxEffect(groove_ctx* ctx, uint32_t kind, const groove_fx_params* p, uint32_t lanes);
+  ~FxEffect() override;
+  uint32_t lanes() const override { return lanes_; }
+  int transform_audio(groove_block* inout, uint32_t frames) override;
+  int control_set_param(uint32_t index, double value01) override;
+  int control_index_for_name(const std::string& name) const override;
+ private:
+  groove_ctx* ctx_;
+  groove_fx* fx_ = nullptr;
+  uint32_t lanes_;
+};
+
+// Timer: finishes after N beats (groove-toys Timer, orchestrator.rs:1408-1415).
+class Timer : public Controller {
+ public:
+  explicit Timer(double beats) : end_(MusicalTime::from_beats(beats).units) {}
+  void work(uint64_t, uint64_t, std::vector<MidiEvent>&, Orchestrator&) override {}
+  bool is_finished(uint64_t end_units) const override { return end_units >= end_; }
+  uint64_t end_units() const override { return end_; }
+ private:
+  uint64_t end_;
+};
+
+// Sequencer: notes at musical-time positions on a MIDI channel (settings/src/songs.rs:210-249
+// inserts pattern notes; the beat sequencer finishes at the end of its last full measure).
+class Sequencer : public Controller {
+ public:
+  void insert(uint8_t channel, uint8_t key, double start_beat, double duration_beats);
+  void set_end_beats(double beats) { end_ = MusicalTime::from_beats(beats).units; explicit_end_ = true; }
+  void work(uint64_t start_units, uint64_t end_units, std::vector<MidiEvent>& out, Orchestrator&) override;
+  bool is_finished(uint64_t end_units) const override { return end_units >= end_; }
+  uint64_t end_units() const override { return end_; }
+ private:
+  struct Ev { uint64_t at; uint8_t channel, key; bool on; };
+  std::vector<Ev> events_;
+  uint64_t end_ = 0;
+  bool explicit_end_ = false;
+};
+
+// ControlTrip: automation of one Controllable parameter along a path of steps
+// (entities/src/controllers/control_trip.rs:7-26, 99-142, 257-264).
+struct ControlStep {
+  enum Kind { FLAT, SLOPE, LOGARITHMIC, EXPONENTIAL, TRIGGERED } kind = FLAT;
+  double start = 0.0, end = 0.0; // FLAT uses start as its value
+  double beats = 1.0;            // duration of this step
+};
+class ControlTrip : public Controller {
+ public:
+  ControlTrip(Uid target, uint32_t control_index, double start_beat) : target_(target), index_(control_index), start_(start_beat) {}
+  void add_step(const ControlStep& s) { steps_.push_back(s); }
+  void work(uint64_t start_units, uint64_t end_units, std::vector<MidiEvent>& out, Orchestrator& o) override;
+  bool is_finished(uint64_t end_units) const override { return end_units >= end_units_(); }
+  uint64_t end_units() const override { return end_units_(); }
+  static double value_at(const ControlStep& s, double t01);
+ private:
+  uint64_t end_units_() const;
+  Uid target_;
+  uint32_t index_;
+  double start_;
+  std::vector<ControlStep> steps_;
+  double last_sent_ = -1.0;
+};
+
+// ---- the orchestrator ----------------------------------------------------------------------
+class Orchestrator {
+ public:
+  Orchestrator(int device, uint32_t sample_rate, double bpm);
+  ~Orchestrator();
+  Orchestrator(const Orchestrator&) = delete;
+
+  groove_ctx* ctx() { return ctx_; }
+  const std::string& last_error() const { return err_; }
+  uint32_t sample_rate() const { return sr_; }
+  double bpm() const { return bpm_; }
+  int update_sample_rate(uint32_t hz);
+
+  // Orchestrator::add (orchestrator.rs:136-142): takes ownership, returns the Uid.
+  Uid add(std::unique_ptr<Entity> e);
+  Entity* get(Uid uid);
+  // Orchestrator::patch (orchestrator.rs:263-304): source output → sink input.  0 on success.
+  int patch(Uid source, Uid sink);
+  int patch_chain_to_main_mixer(const std::vector<Uid>& uids);
+  void unpatch_all();
+  // Orchestrator::connect_midi_downstream (orchestrator.rs:472-490)
+  int connect_midi_downstream(Uid receiver, uint8_t channel);
+
+  // Orchestrator::tick (orchestrator.rs:856-877): events for this block, gather_audio, clock
+  // advance.  Writes frames into `out` and returns ticks_completed (< frames ends the run).
+  int tick(StereoSample* out, uint32_t frames, uint32_t* ticks_completed);
+  // Orchestrator::gather_audio (orchestrator.rs:367-470) for one block into the device bus.
+  int gather_audio(uint32_t frames);
+  // Orchestrator::run / run_performance (orchestrator.rs:788-846).  `run` keeps the final
+  // partial block, `run_performance` drops it (quirk, :827-836).
+  int run(uint32_t buffer_frames, std::vector<StereoSample>& out);
+  int run_performance(uint32_t buffer_frames, Performance& perf);
+  void skip_to_start();
+  uint64_t clock_frames() const { return frames_; }
+  uint64_t performance_frames() const; // ceil(end of the last controller)
+
+  // IOHelper::send_performance_to_file (helpers.rs:74-97): 16-bit stereo PCM WAV, quantised on the device.
+  int send_performance_to_file(const Performance& perf, const std::string& path);
+
+  int fail(const std::string& msg) { err_ = msg; return 1; }
+
+ private:
+  struct Node {
+    std::unique_ptr<Entity> entity;
+    std::vector<Uid> sources;          // audio_sink_uid_to_source_uids
+    groove_block* accum = nullptr;     // effect input sum / output block
+    uint32_t accum_lanes = 0;
+  };
+  int eval(Uid uid, uint32_t frames, groove_block** out_block, uint32_t* out_lanes);
+  int ensure_accum(Node& n, uint32_t lanes);
+
+  groove_ctx* ctx_ = nullptr;
+  uint32_t sr_;
+  double bpm_;
+  std::string err_;
+  std::vector<Node> nodes_;
+  std::multimap<uint8_t, Uid> midi_receivers_;
+  float* bus_ = nullptr; // device [block][2]
+  uint32_t bus_frames_ = 0;
+  uint64_t frames_ = 0;
+  bool performing_ = false;
+};
+
+} // namespace groove_host

@@ -35,6 +35,8 @@ SYMBOLS = {
     "groove_block_frames_cap": (_u32, [_vp]),
     "groove_block_upload": (_i, [_vp, _fp, _u32]),
     "groove_block_download": (_i, [_vp, _fp, _u32]),
+    "groove_block_accumulate": (_i, [_vp, _vp, _u32, _i]),
+    "groove_block_zero": (_i, [_vp]),
     "groove_welsh_create": (_i, [_vp, C.POINTER(T.WelshParams), _u32, _vpp]),
     "groove_fm_create": (_i, [_vp, C.POINTER(T.FmParams), _u32, _vpp]),
     "groove_sampler_create": (_i, [_vp, _fp, C.c_uint64, C.POINTER(T.SampleDesc), _u32, C.POINTER(T.SamplerParams), _u32, _vpp]),

@@ -66,6 +66,11 @@ uint32_t groove_block_frames_cap(groove_block* b);
 int groove_block_upload(groove_block* b, const float* host, uint32_t frames);
 int groove_block_download(groove_block* b, float* host, uint32_t frames);
 
+/* dst (+)= src.  Equal lane counts: element-wise.  dst with ONE lane: the lanes of src are summed
+ * (a Synthesizer summing its voice store; an effect summing its sources, orchestrator.rs:438-457). */
+int groove_block_accumulate(groove_block* dst, groove_block* src, uint32_t frames, int accumulate);
+int groove_block_zero(groove_block* b);
+
 /* ---- instruments (Ticks + Generates<StereoSample> + HandlesMidi + Controllable) --------- */
 /* WelshSynth::new_with(&WelshSynthParams) (settings/src/instruments.rs:71-76) for n voices. */
 int groove_welsh_create(groove_ctx* ctx, const groove_welsh_params* p, uint32_t n, groove_bank** out);

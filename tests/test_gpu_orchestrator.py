@@ -1,0 +1,185 @@
+"""GPU tier: the compiled host layer (C++ Orchestrator over the C ABI) against the reference's own
+orchestrator tests (restated) and against the oracle's per-frame gather (rows a15, a16, a18)."""
+import math
+import struct
+
+import numpy as np
+import pytest
+
+from groove_amd import patches as P, types as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def orch():
+    from groove_amd.host_binding import Orchestrator
+    o = Orchestrator(0, 44100, 128.0)
+    yield o
+    o.close()
+
+
+def test_gather_audio_basic(orch):  # orchestrator.rs:1444-1473
+    l1, l2 = orch.add_toy_source(0.1), orch.add_toy_source(0.2)
+    assert not orch.gather_audio(1).any()
+    assert orch.patch(l1, orch.MAIN_MIXER) == 0
+    assert np.allclose(orch.gather_audio(1), 0.1, atol=1e-7)
+    orch.unpatch_all(); orch.patch(l2, orch.MAIN_MIXER)
+    assert np.allclose(orch.gather_audio(1), 0.2, atol=1e-7)
+    orch.unpatch_all(); orch.patch(l1, orch.MAIN_MIXER); orch.patch(l2, orch.MAIN_MIXER)
+    assert np.allclose(orch.gather_audio(64), 0.1 + 0.2, atol=1e-7)
+
+
+def test_gather_audio_gain_chains_and_branches(orch):  # orchestrator.rs:1475-1668
+    l1 = orch.add_toy_source(0.1)
+    gain = orch.add_effect(T.FX_GAIN, T.fx_params(ceiling=0.5))
+    sib = [orch.add_toy_source(v) for v in (0.2, 0.3, 0.4)]
+    assert orch.patch_chain_to_main_mixer([l1, gain]) == 0
+    assert np.allclose(orch.gather_audio(4), 0.1 * 0.5, atol=1e-7)
+    for s in sib:
+        orch.patch(s, orch.MAIN_MIXER)
+    assert np.allclose(orch.gather_audio(4), 0.1 * 0.5 + 0.2 + 0.3 + 0.4, atol=2e-7)
+    # instruments have no inputs; unknown uids are errors
+    assert orch.patch(gain, l1) != 0 and orch.patch(99, gain) != 0
+    # chains 0.1*0.2*0.4 + 0.3*0.6 + 0.5*0.8
+    orch.unpatch_all()
+    def chain(level, *c):
+        return [orch.add_toy_source(level)] + [orch.add_effect(T.FX_GAIN, T.fx_params(ceiling=x)) for x in c]
+    for ch in (chain(0.1, 0.2, 0.4), chain(0.3, 0.6), chain(0.5, 0.8)):
+        assert orch.patch_chain_to_main_mixer(ch) == 0
+    assert np.allclose(orch.gather_audio(4), 0.1 * 0.2 * 0.4 + 0.3 * 0.6 + 0.5 * 0.8, atol=2e-7)
+    # fan-in: 0.1 + 0.5 * (0.3 + 0.5)
+    orch.unpatch_all()
+    a, b, c = orch.add_toy_source(0.1), orch.add_toy_source(0.3), orch.add_toy_source(0.5)
+    g = orch.add_effect(T.FX_GAIN, T.fx_params(ceiling=0.5))
+    orch.patch(a, orch.MAIN_MIXER); orch.patch(b, g); orch.patch(c, g); orch.patch(g, orch.MAIN_MIXER)
+    assert np.allclose(orch.gather_audio(4), 0.1 + 0.5 * (0.3 + 0.5), atol=2e-7)
+    # a lone effect with no input → silence
+    orch.unpatch_all(); orch.patch(g, orch.MAIN_MIXER)
+    assert not orch.gather_audio(4).any()
+
+
+def test_sample_counts():  # orchestrator.rs:1689-1737, 1822-1827
+    from groove_amd.host_binding import Orchestrator
+    o = Orchestrator(0, 44100, 128.0)
+    o.add_timer(0.0)
+    assert len(o.run(64)) == 0
+    o.close()
+    o = Orchestrator(0, 24000, 240.0)
+    o.add_timer(4.0)
+    assert len(o.run(64)) == 24000
+    o.close()
+    o = Orchestrator(0, 44100, 128.0)
+    o.add_timer(4.0)
+    assert o.performance_frames() == math.ceil(4 * 60 / 128 * 44100) == 82688
+    assert len(o.run(64)) == 82688
+    assert len(o.run(100)) == 82688                      # run keeps the final partial block
+    assert len(o.run(100, performance=True)) == 82688 - 82688 % 100   # run_performance drops it
+    o.close()
+
+
+def test_sequenced_welsh_through_filter_matches_oracle(orch, oracle):
+    """A sequenced polyphonic Welsh synth (first-idle voice allocation) through a 24 dB low-pass
+    into the main mixer, block 64 like the reference's tests, against the oracle's per-frame DFS."""
+    patch = P.welsh_patch(9)
+    synth = orch.add_welsh(patch, voices=4)
+    lp = orch.add_effect(T.FX_BIQUAD_LP24, T.fx_params(cutoff_hz=1000.0, passband_ripple=0.8))
+    assert orch.patch_chain_to_main_mixer([synth, lp]) == 0
+    orch.connect_midi_downstream(synth, 0)
+    seq = orch.add_sequencer()
+    notes = [(60, 0.0, 1.0), (64, 0.5, 1.0), (67, 1.0, 0.5), (72, 2.0, 0.25)]  # (key, start beat, beats)
+    for k, s, dur in notes:
+        orch.sequencer_insert(seq, 0, k, s, dur)
+    orch.sequencer_set_end(seq, 3.0)
+    got = orch.run(64).astype(np.float64)
+    total = math.ceil(3.0 * 60 / 128 * 44100)
+    assert len(got) == total
+    # oracle: same graph, same block-granular events, voices allocated first-idle in event order
+    g = oracle.Graph()
+    params = (T.WelshParams * 4)(*[patch] * 4)
+    bank = g.add_instrument(oracle.Bank.welsh(params))
+    f = g.add_effect(T.FX_BIQUAD_LP24, T.fx_params(cutoff_hz=1000.0, passband_ripple=0.8))
+    g.patch_chain_to_main_mixer([bank, f])
+    upb = 65536
+    evs = sorted([(int(s * upb + 0.5), 1, k) for k, s, d in notes] + [(int((s + d) * upb + 0.5), 0, k) for k, s, d in notes],
+                 key=lambda e: e[0])
+    voice_of, busy_until, started = {}, [0] * 4, [0] * 4
+    key_of_voice = [-1] * 4
+    rel = math.ceil(patch.amp_envelope.release * 44100) + 1
+    want, pos = [], 0
+    while pos < total:
+        fr = min(64, total - pos)
+        t0 = int(pos * 128.0 / 60.0 / 44100 * upb); t1 = int((pos + fr) * 128.0 / 60.0 / 44100 * upb)
+        for at, on, k in evs:
+            if t0 <= at < t1:
+                if on:
+                    v = next((i for i in range(4) if key_of_voice[i] < 0 and busy_until[i] <= pos), None)
+                    if v is None:
+                        v = min(range(4), key=lambda i: started[i])
+                    key_of_voice[v] = k; started[v] = pos; busy_until[v] = 1 << 62
+                    g.note_events(bank, T.note_events([(v, k, True)]))
+                else:
+                    for i in range(4):
+                        if key_of_voice[i] == k:
+                            g.note_events(bank, T.note_events([(i, k, False)]))
+                            key_of_voice[i] = -1; busy_until[i] = pos + rel
+        want.append(g.gather(fr)); pos += fr
+    want = np.concatenate(want, axis=0)
+    assert np.sqrt(np.mean(want ** 2)) > 1e-3
+    assert np.sqrt(np.mean((got - want) ** 2)) <= 1e-5
+
+
+def test_control_trip_steps_and_filter_sweep(orch):
+    """ControlStep shapes (control_trip.rs:7-26) and a block-granular cutoff sweep (config #1's trip)."""
+    from groove_amd import host_binding as H
+    L = orch.L
+    assert L.gh_control_step_value(H.STEP_FLAT, 0.3, 0.9, 0.5) == 0.3
+    assert abs(L.gh_control_step_value(H.STEP_SLOPE, 0.0, 1.0, 0.25) - 0.25) < 1e-12
+    e = [L.gh_control_step_value(H.STEP_EXPONENTIAL, 0.0, 1.0, t) for t in np.linspace(0, 1, 11)]
+    l = [L.gh_control_step_value(H.STEP_LOGARITHMIC, 0.0, 1.0, t) for t in np.linspace(0, 1, 11)]
+    assert e[0] == 0.0 and e[-1] == 1.0 and l[0] == 0.0 and l[-1] == 1.0
+    assert all(a <= b for a, b in zip(e, e[1:])) and all(a <= b for a, b in zip(l, l[1:]))
+    assert all(x <= t + 1e-12 for x, t in zip(e, np.linspace(0, 1, 11)))   # exponential lies under the ramp
+    assert all(x >= t - 1e-12 for x, t in zip(l, np.linspace(0, 1, 11)))   # logarithmic above it
+    src = orch.add_toy_source(0.5)
+    lp = orch.add_effect(T.FX_BIQUAD_LP24, T.fx_params(cutoff_hz=1000.0, passband_ripple=0.8))
+    orch.patch_chain_to_main_mixer([src, lp])
+    trip = orch.add_control_trip(lp, "cutoff", 0.0)
+    orch.control_trip_add_step(trip, H.STEP_EXPONENTIAL, 0.0, 1.0, 2.0)
+    out = orch.run(256)
+    assert len(out) == math.ceil(2.0 * 60 / 128 * 44100)
+    assert np.isfinite(out).all() and abs(out[-1, 0] - 0.5) < 1e-3   # DC passes the low-pass (gain 1)
+    with pytest.raises(RuntimeError):
+        orch.add_control_trip(lp, "no-such-param")
+
+
+def test_drumkit_render_to_wav(orch, tmp_path, oracle):
+    """Config #1 shape on the GPU path: drumkit on MIDI channel 10 → 24 dB low-pass → main mixer,
+    two measures of four-on-the-floor at 128 bpm, written as 16-bit stereo WAV."""
+    pcm, descs, lengths = P.drum_bank(scale=0.25)
+    key_to_sample = [-1] * 128
+    for k, s in ((35, 0), (38, 2), (42, 4), (44, 6)):
+        key_to_sample[k] = s
+    kit = orch.add_drumkit(pcm, descs, key_to_sample)
+    lp = orch.add_effect(T.FX_BIQUAD_LP24, T.fx_params(cutoff_hz=1000.0, passband_ripple=0.8))
+    assert orch.patch_chain_to_main_mixer([kit, lp]) == 0
+    orch.connect_midi_downstream(kit, 10)
+    seq = orch.add_sequencer()
+    rows = [[42, 44] * 8, [0, 0, 0, 0, 38, 0, 0, 0, 0, 0, 0, 0, 38, 0, 0, 0], [35, 0, 0, 0] * 4]
+    for measure in range(2):
+        for row in rows:
+            for i, k in enumerate(row):
+                if k:
+                    orch.sequencer_insert(seq, 10, k, measure * 4 + i * 0.25, 0.25)
+    orch.sequencer_set_end(seq, 8.0)
+    assert orch.performance_frames() == 165375
+    path = tmp_path / "drums.wav"
+    orch.render_to_wav(str(path), 256)
+    raw = path.read_bytes()
+    assert raw[:4] == b"RIFF" and raw[8:16] == b"WAVEfmt "
+    fmt, ch, sr, _, _, bits = struct.unpack("<HHIIHH", raw[20:36])
+    assert (fmt, ch, sr, bits) == (1, 2, 44100, 16)
+    n_bytes = struct.unpack("<I", raw[40:44])[0]
+    assert n_bytes == (165375 - 165375 % 256) * 4        # run_performance drops the partial block
+    pcm16 = np.frombuffer(raw[44:], dtype="<i2").reshape(-1, 2)
+    assert np.abs(pcm16).max() > 1000 and (pcm16[:, 0] == pcm16[:, 1]).all()   # mono kit duplicated L = R
