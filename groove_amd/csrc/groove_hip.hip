@@ -71,6 +71,8 @@ struct groove_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = true;
+  hipStream_t side_stream = nullptr; // runs the few non-uniform workgroups beside the main kernel
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   uint32_t sr = GROOVE_DEFAULT_SAMPLE_RATE;
   std::string err;
   std::vector<groove_bank*> banks;
@@ -425,7 +427,10 @@ int groove_init(int device_ordinal, groove_ctx** out) {
   groove_ctx* ctx = new (std::nothrow) groove_ctx();
   if (!ctx) return fail(nullptr, "groove_init: out of memory");
   ctx->device = device_ordinal;
-  if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
     delete ctx;
     return fail(nullptr, "groove_init: hipSetDevice/hipStreamCreate failed");
   }
@@ -444,6 +449,9 @@ void groove_shutdown(groove_ctx* ctx) {
   if (ctx->d_fseg) hipFree(ctx->d_fseg);
   if (ctx->d_i16) hipFree(ctx->d_i16);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+  if (ctx->side_stream) { hipStreamSynchronize(ctx->side_stream); hipStreamDestroy(ctx->side_stream); }
+  if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
   delete ctx;
 }
 const char* groove_last_error(groove_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
@@ -636,14 +644,25 @@ static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs
   const dim3 grid(blocks_for(b->n)), blk(kThreads);
   if (b->kind == BANK_WELSH) {
     RenderConsts rc{(float)(3.14159265358979323846 / ctx->sr), (float)(0.49 * ctx->sr)};
+    // Workgroups whose wavefronts are not patch-uniform (typically the handful that straddle two
+    // patches) run the per-lane kernel on a side stream, forked from and joined to the main
+    // stream with events, so their long single-workgroup latency hides under the main kernel.
+    const bool both = b->uniform_wgs && b->generic_wgs;
+    hipStream_t gs = both ? ctx->side_stream : ctx->stream;
+    if (both) {
+      GHIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+      GHIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+    }
+    if (b->generic_wgs) {
+      if (fused) hipLaunchKernelGGL(welsh_render_kernel<true>, grid, blk, 0, gs, b->d_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
+      else hipLaunchKernelGGL(welsh_render_kernel<false>, grid, blk, 0, gs, b->d_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
+    }
+    if (both) GHIP(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
     if (b->uniform_wgs) {
       if (fused) hipLaunchKernelGGL(welsh_render_uniform_kernel<true>, grid, blk, 0, ctx->stream, b->d_wave_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
       else hipLaunchKernelGGL(welsh_render_uniform_kernel<false>, grid, blk, 0, ctx->stream, b->d_wave_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
     }
-    if (b->generic_wgs) {
-      if (fused) hipLaunchKernelGGL(welsh_render_kernel<true>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
-      else hipLaunchKernelGGL(welsh_render_kernel<false>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
-    }
+    if (both) GHIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   } else if (b->kind == BANK_FM) {
     if (fused) hipLaunchKernelGGL(fm_render_kernel<true>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out);
     else hipLaunchKernelGGL(fm_render_kernel<false>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out);

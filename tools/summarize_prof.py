@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Reduce the rocprofv3 CSVs of tools/profile_round.sh to profiles/<round>_*.{csv,json}."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+out, rnd = sys.argv[1], sys.argv[2]
+os.makedirs("profiles", exist_ok=True)
+summary = {"round": rnd, "command": "python3 bench.py --steps 20 --warmup 4 --no-cpu-baseline"}
+
+ks = glob.glob(f"{out}/kt/*/*_kernel_stats.csv")
+if ks:
+    shutil.copy(ks[0], f"profiles/{rnd}_kernel_stats.csv")
+    rows = list(csv.DictReader(open(ks[0])))
+    summary["kernel_stats"] = [{"name": r["Name"][:90], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                                "pct": float(r["Percentage"])} for r in rows[:8]]
+for log in glob.glob(f"{out}/bench_kt.log"):
+    for line in open(log):
+        if line.startswith("{"):
+            summary["bench_line_under_profiler"] = json.loads(line)
+
+
+def counters(sub):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    meta = {}
+    for f in glob.glob(f"{out}/{sub}/*/*_counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0][-70:]
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta[k] = {"vgpr": r.get("VGPR_Count"), "sgpr": r.get("SGPR_Count"), "lds": r.get("LDS_Block_Size"),
+                       "scratch": r.get("Scratch_Size"), "grid": r.get("Grid_Size"), "wg": r.get("Workgroup_Size")}
+    return {k: {"mean_per_dispatch": {c: sum(v) / len(v) for c, v in cs.items()}, "dispatches": max(len(v) for v in cs.values()),
+                **meta[k]} for k, cs in agg.items() if "rocclr" not in k}
+
+
+for sub in ("fetch", "write", "sq", "grbm"):
+    summary[sub] = counters(sub)
+
+# HBM traffic of the dominant kernel per launch (MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB;
+# FETCH_SIZE reads 1/2 of the bytes of a wide coalesced streaming read on gfx950 — our reads are 4 B/lane
+# state loads, an uncalibrated width, so both the raw and the doubled figure are kept).
+dom = None
+for k in summary.get("write", {}):
+    if "welsh_render" in k and (dom is None or summary["write"][k]["mean_per_dispatch"]["WRITE_SIZE"] > summary["write"][dom]["mean_per_dispatch"]["WRITE_SIZE"]):
+        dom = k
+if dom:
+    w = summary["write"][dom]["mean_per_dispatch"]["WRITE_SIZE"] * 1024
+    f = summary.get("fetch", {}).get(dom, {}).get("mean_per_dispatch", {}).get("FETCH_SIZE", 0.0) * 1024
+    summary["dominant_kernel"] = dom
+    summary["hbm_traffic_bytes_per_launch"] = {"write": w, "fetch_raw": f, "fetch_x2_gfx950": 2 * f,
+                                               "total_raw": w + f, "total_corrected": w + 2 * f}
+json.dump(summary, open(f"profiles/{rnd}_summary.json", "w"), indent=1)
+print(json.dumps({k: summary[k] for k in ("dominant_kernel", "hbm_traffic_bytes_per_launch") if k in summary}, indent=1))
+for r in summary.get("kernel_stats", []):
+    print(f"{r['pct']:6.2f}%  {r['avg_ns'] / 1e3:10.1f} us x {r['calls']:4d}  {r['name']}")
