@@ -350,14 +350,19 @@ struct WelshScratch {
 GROOVE_HD Lp24Coef welsh_static_coef(const WelshParams& p, const RenderConsts& rc) {
   return lp24_coef_from_fc(p.fc, p.cutoff_hz, rc.pi_over_sr, rc.fc_max);
 }
+GROOVE_HD bool welsh_f64_lfo(const WelshParams& p) {
+  const uint32_t r = (p.flags >> WF_ROUTING_SHIFT) & 15u;
+  return r == GROOVE_LFO_PITCH || r == GROOVE_LFO_PULSE_WIDTH;
+}
 GROOVE_HD bool welsh_retunes(const WelshParams& p) {
   return (p.flags & WF_RETUNE_ENV) || (((p.flags >> WF_ROUTING_SHIFT) & 15u) == GROOVE_LFO_FILTER_CUTOFF);
 }
 
 // One frame of one voice.  FIRST: this is frame 0 of a render call (the only frame on which
 // VF_FIRST can be set).  RETUNE: false promises !welsh_retunes(p) for every lane, so the
-// coefficients in `sc` are loop-invariant.
-template <bool FIRST, bool RETUNE>
+// coefficients in `sc` are loop-invariant.  F64LFO: false promises that no lane routes the LFO
+// to Pitch or PulseWidth, which removes the f64 LFO / 2^x / u64<->f64 path (and ~50 VGPRs).
+template <bool FIRST, bool RETUNE, bool F64LFO = true>
 GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc,
                            WelshScratch& sc, float& L, float& R) {
   env_tick(s.amp, p.amp);
@@ -376,7 +381,7 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
   uint64_t inc1 = s.o1_inc, inc2 = s.o2_inc;
   uint64_t d1 = p.o1_duty64, d2 = p.o2_duty64;
   float lfo = 0.0f;
-  if (routing == GROOVE_LFO_PITCH || routing == GROOVE_LFO_PULSE_WIDTH) {
+  if (F64LFO && (routing == GROOVE_LFO_PITCH || routing == GROOVE_LFO_PULSE_WIDTH)) {
     const double l = osc_value_f64(wl, s.lfo.phase, half, nzl);
     const double ld = l * (double)p.lfo_depth;
     if (routing == GROOVE_LFO_PITCH) {

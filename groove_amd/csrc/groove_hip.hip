@@ -38,7 +38,7 @@ struct groove_bank {
   double* d_cold = nullptr; // welsh: [4][n]; fm: ratio [n]
   WelshParams* d_wave_params = nullptr; // welsh: one entry per 64-lane wave (uniform fast path)
   uint8_t* d_wg_kind = nullptr;         // welsh: 1 = every wave of the workgroup is patch-uniform
-  uint32_t uniform_wgs = 0, generic_wgs = 0;
+  uint32_t wgs_of_kind[3] = {0, 0, 0};
   float* d_pcm = nullptr;   // sampler bank
   groove_note_event* d_ev = nullptr;
   size_t ev_cap = 0;
@@ -71,8 +71,8 @@ struct groove_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = true;
-  hipStream_t side_stream = nullptr; // runs the few non-uniform workgroups beside the main kernel
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t side_stream[2] = {nullptr, nullptr}; // kernels of the other workgroup kinds run beside the main one
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   uint32_t sr = GROOVE_DEFAULT_SAMPLE_RATE;
   std::string err;
   std::vector<groove_bank*> banks;
@@ -143,16 +143,17 @@ int welsh_upload_params(groove_bank* b) {
   // fast kernel when each of its wavefronts carries a single patch
   const uint32_t waves = (n + 63) / 64, wgs = blocks_for(n);
   std::vector<WelshParams> W(waves);
-  std::vector<uint8_t> kind(wgs, 1);
+  std::vector<uint8_t> kind(wgs, WG_UNIFORM);
   for (uint32_t w = 0; w < waves; ++w) {
     W[w] = P[(size_t)w * 64];
+    uint8_t& k = kind[w / kWaves];
+    if (k != WG_GENERIC && welsh_f64_lfo(W[w])) k = WG_UNIFORM_F64;
     const uint32_t hi = std::min<uint32_t>(n, (w + 1) * 64);
     for (uint32_t v = w * 64 + 1; v < hi; ++v)
-      if (std::memcmp(&P[v], &W[w], sizeof(WelshParams)) != 0) { kind[w / kWaves] = 0; break; }
+      if (std::memcmp(&P[v], &W[w], sizeof(WelshParams)) != 0) { k = WG_GENERIC; break; }
   }
-  b->uniform_wgs = 0;
-  for (uint8_t k : kind) b->uniform_wgs += k;
-  b->generic_wgs = wgs - b->uniform_wgs;
+  b->wgs_of_kind[0] = b->wgs_of_kind[1] = b->wgs_of_kind[2] = 0;
+  for (uint8_t k : kind) b->wgs_of_kind[k] += 1;
   if (!b->d_wave_params) GHIP(ctx, hipMalloc(&b->d_wave_params, (size_t)waves * sizeof(WelshParams)));
   if (!b->d_wg_kind) GHIP(ctx, hipMalloc(&b->d_wg_kind, wgs));
   GHIP(ctx, hipMemcpy(b->d_wave_params, W.data(), (size_t)waves * sizeof(WelshParams), hipMemcpyHostToDevice));
@@ -428,9 +429,11 @@ int groove_init(int device_ordinal, groove_ctx** out) {
   if (!ctx) return fail(nullptr, "groove_init: out of memory");
   ctx->device = device_ordinal;
   if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->side_stream[0], hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->side_stream[1], hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&ctx->ev_join[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_join[1], hipEventDisableTiming) != hipSuccess) {
     delete ctx;
     return fail(nullptr, "groove_init: hipSetDevice/hipStreamCreate failed");
   }
@@ -449,9 +452,11 @@ void groove_shutdown(groove_ctx* ctx) {
   if (ctx->d_fseg) hipFree(ctx->d_fseg);
   if (ctx->d_i16) hipFree(ctx->d_i16);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
-  if (ctx->side_stream) { hipStreamSynchronize(ctx->side_stream); hipStreamDestroy(ctx->side_stream); }
+  for (int i = 0; i < 2; ++i) {
+    if (ctx->side_stream[i]) { hipStreamSynchronize(ctx->side_stream[i]); hipStreamDestroy(ctx->side_stream[i]); }
+    if (ctx->ev_join[i]) hipEventDestroy(ctx->ev_join[i]);
+  }
   if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
-  if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
   delete ctx;
 }
 const char* groove_last_error(groove_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
@@ -644,25 +649,35 @@ static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs
   const dim3 grid(blocks_for(b->n)), blk(kThreads);
   if (b->kind == BANK_WELSH) {
     RenderConsts rc{(float)(3.14159265358979323846 / ctx->sr), (float)(0.49 * ctx->sr)};
-    // Workgroups whose wavefronts are not patch-uniform (typically the handful that straddle two
-    // patches) run the per-lane kernel on a side stream, forked from and joined to the main
-    // stream with events, so their long single-workgroup latency hides under the main kernel.
-    const bool both = b->uniform_wgs && b->generic_wgs;
-    hipStream_t gs = both ? ctx->side_stream : ctx->stream;
-    if (both) {
-      GHIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-      GHIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+    // One kernel per workgroup kind.  The kind with the most workgroups runs on the ctx stream,
+    // the others on side streams forked from / joined to it with events, so the short ones (e.g.
+    // the handful of workgroups that straddle two patches) hide under the main kernel.
+    int order[3] = {0, 1, 2};
+    std::sort(order, order + 3, [&](int a, int c) { return b->wgs_of_kind[a] > b->wgs_of_kind[c]; });
+    bool forked = false;
+    int side = 0, used_side[2] = {0, 0};
+    for (int oi = 2; oi >= 0; --oi) { // smallest first, so the main kernel is launched last
+      const int k = order[oi];
+      if (!b->wgs_of_kind[k]) continue;
+      hipStream_t st = ctx->stream;
+      if (oi != 0) {
+        if (!forked) { GHIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream)); forked = true; }
+        st = ctx->side_stream[side];
+        GHIP(ctx, hipStreamWaitEvent(st, ctx->ev_fork, 0));
+      }
+      if (k == WG_GENERIC) {
+        if (fused) hipLaunchKernelGGL(welsh_render_kernel<true>, grid, blk, 0, st, b->d_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
+        else hipLaunchKernelGGL(welsh_render_kernel<false>, grid, blk, 0, st, b->d_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
+      } else if (k == WG_UNIFORM) {
+        if (fused) hipLaunchKernelGGL((welsh_render_uniform_kernel<true, false>), grid, blk, 0, st, b->d_wave_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
+        else hipLaunchKernelGGL((welsh_render_uniform_kernel<false, false>), grid, blk, 0, st, b->d_wave_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
+      } else {
+        if (fused) hipLaunchKernelGGL((welsh_render_uniform_kernel<true, true>), grid, blk, 0, st, b->d_wave_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
+        else hipLaunchKernelGGL((welsh_render_uniform_kernel<false, true>), grid, blk, 0, st, b->d_wave_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
+      }
+      if (oi != 0) { GHIP(ctx, hipEventRecord(ctx->ev_join[side], st)); used_side[side] = 1; ++side; }
     }
-    if (b->generic_wgs) {
-      if (fused) hipLaunchKernelGGL(welsh_render_kernel<true>, grid, blk, 0, gs, b->d_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
-      else hipLaunchKernelGGL(welsh_render_kernel<false>, grid, blk, 0, gs, b->d_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
-    }
-    if (both) GHIP(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
-    if (b->uniform_wgs) {
-      if (fused) hipLaunchKernelGGL(welsh_render_uniform_kernel<true>, grid, blk, 0, ctx->stream, b->d_wave_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
-      else hipLaunchKernelGGL(welsh_render_uniform_kernel<false>, grid, blk, 0, ctx->stream, b->d_wave_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
-    }
-    if (both) GHIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    for (int i = 0; i < 2; ++i) if (used_side[i]) GHIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0));
   } else if (b->kind == BANK_FM) {
     if (fused) hipLaunchKernelGGL(fm_render_kernel<true>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out);
     else hipLaunchKernelGGL(fm_render_kernel<false>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out);

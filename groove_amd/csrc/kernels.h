@@ -154,25 +154,27 @@ __device__ __forceinline__ void run_frames(uint32_t frames, uint32_t n, uint32_t
 // a5 WelshVoice: Ticks::tick(frames) + Generates::generate_batch_values.
 // Frame 0 is peeled (first-tick flag); RETUNE=false variants keep the filter coefficients
 // loop-invariant so their f64 widening is hoisted out of the frame loop.
-template <bool FUSED, bool RETUNE>
+template <bool FUSED, bool RETUNE, bool F64LFO = true>
 __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s, const RenderConsts& rc,
                                             uint32_t frames, uint32_t n, uint32_t v, bool active,
                                             size_t ch_stride, float* __restrict__ out) {
   WelshScratch sc = welsh_scratch_init(p, rc);
   run_frames<FUSED>(frames, n, v, active, ch_stride, out, [&](uint32_t f, float& L, float& R) {
-    if (f == 0) welsh_frame<true, RETUNE>(p, s, rc, sc, L, R);
-    else welsh_frame<false, RETUNE>(p, s, rc, sc, L, R);
+    if (f == 0) welsh_frame<true, RETUNE, F64LFO>(p, s, rc, sc, L, R);
+    else welsh_frame<false, RETUNE, F64LFO>(p, s, rc, sc, L, R);
   });
 }
 // Generic form: per-lane parameters (any mix of patches inside a wave; exec-masked branches).
-// wg_kind[workgroup] = 1 when every wavefront of the workgroup is patch-uniform: those
-// workgroups belong to welsh_render_uniform_kernel, the others to this kernel (both kernels
-// are launched over the whole grid and a workgroup exits at once if it is not its kind).
+// wg_kind[workgroup]: 0 = some wavefront mixes patches → per-lane kernel; 1 = every wavefront is
+// patch-uniform and none routes the LFO to pitch / pulse width; 2 = patch-uniform with such a
+// routing (needs the f64 LFO path).  The three kernels are launched over the whole grid on
+// forked streams; a workgroup exits at once if it is not the kernel's kind.
+enum : uint8_t { WG_GENERIC = 0, WG_UNIFORM = 1, WG_UNIFORM_F64 = 2 };
 template <bool FUSED>
 __global__ __launch_bounds__(kThreads) void welsh_render_kernel(
     const uint32_t* __restrict__ params, uint32_t* __restrict__ state, uint32_t n, uint32_t frames,
     size_t ch_stride, float* __restrict__ out, RenderConsts rc, const uint8_t* __restrict__ wg_kind) {
-  if (wg_kind && wg_kind[blockIdx.x] != 0) return;
+  if (wg_kind && wg_kind[blockIdx.x] != WG_GENERIC) return;
   const uint32_t v0 = blockIdx.x * kThreads + threadIdx.x;
   const bool active = v0 < n;
   const uint32_t v = active ? v0 : n - 1; // tail lanes shadow the last voice and store nothing
@@ -184,19 +186,19 @@ __global__ __launch_bounds__(kThreads) void welsh_render_kernel(
 // Wave-uniform form: every 64-lane group shares one patch (the host checks this when the
 // bank is derived), so the parameters are fetched with scalar loads from a per-wave table
 // and live in SGPRs; waveform / routing dispatch is scalar branching.
-template <bool FUSED>
-__global__ __launch_bounds__(kThreads, 3) void welsh_render_uniform_kernel(
+template <bool FUSED, bool F64LFO>
+__global__ __launch_bounds__(kThreads, F64LFO ? 3 : 4) void welsh_render_uniform_kernel(
     const WelshParams* __restrict__ wave_params, uint32_t* __restrict__ state, uint32_t n, uint32_t frames,
     size_t ch_stride, float* __restrict__ out, RenderConsts rc, const uint8_t* __restrict__ wg_kind) {
-  if (wg_kind[blockIdx.x] == 0) return;
+  if (wg_kind[blockIdx.x] != (F64LFO ? WG_UNIFORM_F64 : WG_UNIFORM)) return;
   const uint32_t v0 = blockIdx.x * kThreads + threadIdx.x;
   const bool active = v0 < n;
   const uint32_t v = active ? v0 : n - 1;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(v0 >> 6));
   const WelshParams p = make_scalar(wave_params[wave]);
   WelshState s = soa_load<WelshState>(state, n, v);
-  if (welsh_retunes(p)) welsh_block<FUSED, true>(p, s, rc, frames, n, v, active, ch_stride, out);
-  else welsh_block<FUSED, false>(p, s, rc, frames, n, v, active, ch_stride, out);
+  if (welsh_retunes(p)) welsh_block<FUSED, true, F64LFO>(p, s, rc, frames, n, v, active, ch_stride, out);
+  else welsh_block<FUSED, false, F64LFO>(p, s, rc, frames, n, v, active, ch_stride, out);
   if (active) soa_store(state, n, v, s);
 }
 
