@@ -649,19 +649,21 @@ static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs
   const dim3 grid(blocks_for(b->n)), blk(kThreads);
   if (b->kind == BANK_WELSH) {
     RenderConsts rc{(float)(3.14159265358979323846 / ctx->sr), (float)(0.49 * ctx->sr)};
-    // One kernel per workgroup kind.  The kind with the most workgroups runs on the ctx stream,
-    // the others on side streams forked from / joined to it with events, so the short ones (e.g.
-    // the handful of workgroups that straddle two patches) hide under the main kernel.
-    int order[3] = {0, 1, 2};
-    std::sort(order, order + 3, [&](int a, int c) { return b->wgs_of_kind[a] > b->wgs_of_kind[c]; });
-    bool forked = false;
+    // One kernel per workgroup kind, each with its own register budget, running concurrently.
+    // Heaviest work per workgroup first (longest-task-first list scheduling): the f64-LFO kind
+    // goes out on the ctx stream at once, the per-lane stragglers and the short uniform kind on
+    // side streams forked from it, and the ctx stream joins them before the bus reduction.
+    const int order[3] = {WG_UNIFORM_F64, WG_GENERIC, WG_UNIFORM};
+    int first = -1;
+    for (int oi = 0; oi < 3; ++oi) if (b->wgs_of_kind[order[oi]]) { first = oi; break; }
+    const int kinds_present = (b->wgs_of_kind[0] != 0) + (b->wgs_of_kind[1] != 0) + (b->wgs_of_kind[2] != 0);
+    if (kinds_present > 1) GHIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream)); // fork point: before ANY of the kernels
     int side = 0, used_side[2] = {0, 0};
-    for (int oi = 2; oi >= 0; --oi) { // smallest first, so the main kernel is launched last
+    for (int oi = 0; oi < 3; ++oi) {
       const int k = order[oi];
       if (!b->wgs_of_kind[k]) continue;
       hipStream_t st = ctx->stream;
-      if (oi != 0) {
-        if (!forked) { GHIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream)); forked = true; }
+      if (oi != first) {
         st = ctx->side_stream[side];
         GHIP(ctx, hipStreamWaitEvent(st, ctx->ev_fork, 0));
       }
@@ -675,7 +677,7 @@ static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs
         if (fused) hipLaunchKernelGGL((welsh_render_uniform_kernel<true, true>), grid, blk, 0, st, b->d_wave_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
         else hipLaunchKernelGGL((welsh_render_uniform_kernel<false, true>), grid, blk, 0, st, b->d_wave_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
       }
-      if (oi != 0) { GHIP(ctx, hipEventRecord(ctx->ev_join[side], st)); used_side[side] = 1; ++side; }
+      if (oi != first) { GHIP(ctx, hipEventRecord(ctx->ev_join[side], st)); used_side[side] = 1; ++side; }
     }
     for (int i = 0; i < 2; ++i) if (used_side[i]) GHIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0));
   } else if (b->kind == BANK_FM) {

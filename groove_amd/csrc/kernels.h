@@ -45,6 +45,12 @@ __device__ __forceinline__ void soa_store(uint32_t* __restrict__ buf, uint32_t n
     __builtin_amdgcn_raw_buffer_store_b32((int)t.w[i], rsrc, (int)(v * 4u), (int)(i * n * 4u), 0);
 }
 
+#ifndef GROOVE_WAVES_SIMPLE
+#define GROOVE_WAVES_SIMPLE 5 /* waves per SIMD the uniform kernel is register-budgeted for */
+#endif
+#ifndef GROOVE_WAVES_F64
+#define GROOVE_WAVES_F64 3
+#endif
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 
@@ -175,6 +181,7 @@ __global__ __launch_bounds__(kThreads) void welsh_render_kernel(
     const uint32_t* __restrict__ params, uint32_t* __restrict__ state, uint32_t n, uint32_t frames,
     size_t ch_stride, float* __restrict__ out, RenderConsts rc, const uint8_t* __restrict__ wg_kind) {
   if (wg_kind && wg_kind[blockIdx.x] != WG_GENERIC) return;
+  __builtin_amdgcn_s_setprio(3); // long-latency stragglers: win issue arbitration against the short kind
   const uint32_t v0 = blockIdx.x * kThreads + threadIdx.x;
   const bool active = v0 < n;
   const uint32_t v = active ? v0 : n - 1; // tail lanes shadow the last voice and store nothing
@@ -187,10 +194,13 @@ __global__ __launch_bounds__(kThreads) void welsh_render_kernel(
 // bank is derived), so the parameters are fetched with scalar loads from a per-wave table
 // and live in SGPRs; waveform / routing dispatch is scalar branching.
 template <bool FUSED, bool F64LFO>
-__global__ __launch_bounds__(kThreads, F64LFO ? 3 : 4) void welsh_render_uniform_kernel(
+__global__ __launch_bounds__(kThreads, F64LFO ? GROOVE_WAVES_F64 : GROOVE_WAVES_SIMPLE) void welsh_render_uniform_kernel(
     const WelshParams* __restrict__ wave_params, uint32_t* __restrict__ state, uint32_t n, uint32_t frames,
     size_t ch_stride, float* __restrict__ out, RenderConsts rc, const uint8_t* __restrict__ wg_kind) {
   if (wg_kind[blockIdx.x] != (F64LFO ? WG_UNIFORM_F64 : WG_UNIFORM)) return;
+  // The f64-LFO kind is ~2x the work per voice and the critical path of a block: its waves get
+  // issue priority over co-resident waves of the short kind (list scheduling, longest first).
+  if (F64LFO) __builtin_amdgcn_s_setprio(2);
   const uint32_t v0 = blockIdx.x * kThreads + threadIdx.x;
   const bool active = v0 < n;
   const uint32_t v = active ? v0 : n - 1;
