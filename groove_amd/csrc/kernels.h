@@ -99,7 +99,8 @@ __device__ __forceinline__ float wave_sum_lane63(float x) {
   x = dpp_add<0x143, 0xc>(x);  // row_bcast:31 into rows 2 and 3
   return x;
 }
-struct FusedAcc {
+// (kept for reference / A-B: the all-DPP form, 17 VALU per frame)
+struct FusedAccDpp {
   float accL = 0.0f, accR = 0.0f;
   __device__ __forceinline__ void add(float L, float R, uint32_t f) {
     const float tl = wave_sum_lane63(L), tr = wave_sum_lane63(R);
@@ -109,8 +110,6 @@ struct FusedAcc {
     accL = mine ? __builtin_bit_cast(float, sl) : accL;
     accR = mine ? __builtin_bit_cast(float, sr) : accR;
   }
-  // After frames [f0, f0+count) (count <= 64) have been added: reduce the workgroup's waves
-  // and store partial[wg][ch][f0 + lane].  Must be reached by every thread of the workgroup.
   __device__ __forceinline__ void flush(float* __restrict__ partial, uint32_t frames, uint32_t f0, uint32_t count) {
     __shared__ float red[kWaves][2][64];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -126,7 +125,48 @@ struct FusedAcc {
     __syncthreads();
     accL = 0.0f; accR = 0.0f;
   }
+  static constexpr uint32_t kChunk = 64;
 };
+
+// LDS-transposed form (default).  Every frame each lane drops its (L, R) pair into a
+// [8 frames][256 lanes] float2 tile with one ds_write_b64; every 8 frames the workgroup turns
+// the tile: 32 lanes per frame row, each sums 8 pairs (conflict-free 256-byte row segments),
+// then 5 DPP steps finish the 32-lane sum and two lanes per wave store the row totals.
+// ≈ 5 VALU + 1 LDS write per frame instead of 17 VALU; 16 KiB of LDS per workgroup.
+struct FusedAccLds {
+  static constexpr uint32_t kChunk = 8;
+  __device__ __forceinline__ float2* tile() {
+    __shared__ float2 t[kChunk][kThreads];
+    return &t[0][0];
+  }
+  __device__ __forceinline__ void add(float L, float R, uint32_t f) {
+    tile()[(f & (kChunk - 1)) * kThreads + threadIdx.x] = make_float2(L, R);
+  }
+  __device__ __forceinline__ void flush(float* __restrict__ partial, uint32_t frames, uint32_t f0, uint32_t count) {
+    __syncthreads();
+    const uint32_t row = threadIdx.x >> 5, col = threadIdx.x & 31u; // 32 lanes per frame row
+    const float2* __restrict__ src = tile() + row * kThreads + col;
+    float l = 0.0f, r = 0.0f;
+#pragma unroll
+    for (uint32_t j = 0; j < kThreads / 32; ++j) { const float2 v = src[j * 32]; l += v.x; r += v.y; }
+    // 32-lane sums: quad, quad, ror4, ror8 (16-lane row sums), then row_bcast:15 into rows 1 and 3
+    l = dpp_add<0xb1, 0xf>(l); r = dpp_add<0xb1, 0xf>(r);
+    l = dpp_add<0x4e, 0xf>(l); r = dpp_add<0x4e, 0xf>(r);
+    l = dpp_add<0x124, 0xf>(l); r = dpp_add<0x124, 0xf>(r);
+    l = dpp_add<0x128, 0xf>(l); r = dpp_add<0x128, 0xf>(r);
+    l = dpp_add<0x142, 0xa>(l); r = dpp_add<0x142, 0xa>(r);
+    if (col == 31 && row < count) { // lanes 31 and 63 of each wave hold the totals of their rows
+      partial[((size_t)blockIdx.x * 2 + 0) * frames + f0 + row] = l;
+      partial[((size_t)blockIdx.x * 2 + 1) * frames + f0 + row] = r;
+    }
+    __syncthreads();
+  }
+};
+#ifdef GROOVE_FUSED_DPP
+using FusedAcc = FusedAccDpp;
+#else
+using FusedAcc = FusedAccLds;
+#endif
 
 // Shared frame loop of the instrument kernels: `frame(f, L, R)` computes one frame of this
 // lane's voice; the epilogue either stores the planar block or feeds the fused bus sum.
@@ -139,9 +179,10 @@ __device__ __forceinline__ void run_frames(uint32_t frames, uint32_t n, uint32_t
       float L, R;
       frame(f, L, R);
       acc.add(active ? L : 0.0f, active ? R : 0.0f, f);
-      if ((f & 63u) == 63u) acc.flush(out, frames, f - 63u, 64u);
+      constexpr uint32_t C = FusedAcc::kChunk;
+      if ((f & (C - 1)) == C - 1) acc.flush(out, frames, f - (C - 1), C);
     }
-    if (frames & 63u) acc.flush(out, frames, frames & ~63u, frames & 63u);
+    if (frames & (FusedAcc::kChunk - 1)) acc.flush(out, frames, frames & ~(FusedAcc::kChunk - 1), frames & (FusedAcc::kChunk - 1));
   } else {
     for (uint32_t f = 0; f < frames; ++f) {
       float L, R;
