@@ -52,18 +52,22 @@ class Project:
         self.ctx, self.n, self.fused = ctx, n_voices, fused
         kind = WORKLOADS[workload]["kind"]
         self.banks = []   # (instrument, block, [effects])
-        self.render_events = []
+        self.timeline = []  # Welsh banks that follow the config-#2 note timeline
+        self.on_ev = self.off_ev = None
+        self.block_index = 0
         if kind in ("welsh", "chain"):
-            if grouped and kind == "welsh":
+            if grouped:
                 params, idx = P.welsh_voices_grouped(n_voices, first_voice)
                 synth = E.WelshSynth(ctx, params)
-                synth.handle_midi_events(P.grouped_note_events(idx, True))
+                self.on_ev, self.off_ev = P.grouped_note_events(idx, True), P.grouped_note_events(idx, False)
             else:
+                idx = np.arange(first_voice, first_voice + n_voices)
                 synth = E.WelshSynth(ctx, P.welsh_voices(n_voices, first_voice))
-                synth.handle_midi_events(P.note_on_all(n_voices, first_voice))
+                self.on_ev, self.off_ev = P.note_on_all(n_voices, first_voice), P.note_off_all(n_voices, first_voice)
+            self.timeline.append(synth)
             fx = []
-            if kind == "chain":
-                fx = [E.Effect(ctx, k, p) for k, p in P.chain_fx_params(n_voices)]
+            if kind == "chain":  # per-voice chain parameters follow the voice into its lane
+                fx = [E.Effect(ctx, k, p) for k, p in P.chain_fx_params(n_voices, idx)]
             self.banks.append((synth, ctx.block(n_voices, FRAMES), fx))
         elif kind == "sampler":
             pcm, descs, _ = P.drum_bank()
@@ -73,8 +77,10 @@ class Project:
         elif kind == "mixed":
             nw, nf = n_voices // 2, n_voices // 4
             ns = n_voices - nw - nf
-            w = E.WelshSynth(ctx, P.welsh_voices(nw, first_voice))
-            w.handle_midi_events(P.note_on_all(nw, first_voice))
+            wp, widx = P.welsh_voices_grouped(nw, first_voice)
+            w = E.WelshSynth(ctx, wp)
+            self.on_ev, self.off_ev = P.grouped_note_events(widx, True), P.grouped_note_events(widx, False)
+            self.timeline.append(w)
             f = E.FmSynth(ctx, P.fm_voices(nf, first_voice))
             f.handle_midi_events(P.note_on_all(nf, first_voice))
             pcm, descs, _ = P.drum_bank()
@@ -87,6 +93,14 @@ class Project:
     def step(self, bus, frame0, ev_pair=None):
         """One block: every instrument renders, its effect chain runs, the mix bus sums."""
         ctx = self.ctx
+        # config-#2 timeline, looped: note-on at block 0, note-off at block 86 of every 172 blocks
+        b = self.block_index % P.RENDER_BLOCKS
+        for synth in self.timeline:
+            if b == 0:
+                synth.handle_midi_events(self.on_ev)
+            elif b == P.NOTE_OFF_FRAME // FRAMES:
+                synth.handle_midi_events(self.off_ev)
+        self.block_index += 1
         first = True
         for inst, block, fx in self.banks:
             if self.fused and not fx:
@@ -154,7 +168,7 @@ def cpu_baseline(workload, seconds_target=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=172, help="default: one full 172-block project (44,032 frames)")
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="welsh-1m", choices=sorted(WORKLOADS))
     ap.add_argument("--voices", type=int, default=0, help="override the workload's total voice count")

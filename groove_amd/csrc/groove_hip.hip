@@ -64,6 +64,7 @@ struct groove_fx {
   size_t ring_rows = 0;
   // uniform geometry
   uint32_t N = 0, w = 0, voices = 1, spacing = 0;
+  bool all_wet = true; // every lane has wet == 1 (enables the split reverb path)
   ReverbGeom geo{};
 };
 
@@ -296,9 +297,11 @@ int fx_upload_params(groove_fx* fx) {
   const double sr = ctx->sr;
   std::vector<float> fa(n), fb(n), wet(n);
   std::vector<uint32_t> ua(n);
+  fx->all_wet = true;
   for (uint32_t i = 0; i < n; ++i) {
     const groove_fx_params& p = fx->p[i];
     wet[i] = p.wet;
+    if (p.wet < 1.0f) fx->all_wet = false;
     ua[i] = p.bits > 31 ? 31 : p.bits;
     switch (fx->kind) {
       case GROOVE_FX_GAIN: fa[i] = p.ceiling; break;
@@ -794,24 +797,43 @@ int groove_fx_process(groove_fx* fx, groove_block* io, uint32_t frames) {
     }
     case GROOVE_FX_BIQUAD_LP12:
     case GROOVE_FX_BIQUAD_HP12:
-      hipLaunchKernelGGL(fx_biquad_kernel, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+      hipLaunchKernelGGL(fx_biquad_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       break;
     case GROOVE_FX_BIQUAD_LP24:
-      hipLaunchKernelGGL(fx_lp24_kernel, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+      hipLaunchKernelGGL(fx_lp24_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       break;
     case GROOVE_FX_DELAY:
-      hipLaunchKernelGGL(fx_delay_kernel, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->N, fx->w, fx->d_wet);
+      if (fx->N >= frames) // no feedback inside the block: fully parallel over (frame, lane)
+        hipLaunchKernelGGL(fx_delay_par_kernel, dim3(lanes_grid.x, frames), blk, 0, ctx->stream, io->d, n, chs, fx->d_ring, fx->N, fx->w, fx->d_wet);
+      else if (fx->N >= 16) // chunked loads need every read of a chunk to precede its writes: N >= chunk
+        hipLaunchKernelGGL(fx_delay_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->N, fx->w, fx->d_wet);
+      else hipLaunchKernelGGL(fx_delay_kernel<1>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->N, fx->w, fx->d_wet);
       fx->w = (uint32_t)(((uint64_t)fx->w + frames) % fx->N);
       break;
-    case GROOVE_FX_CHORUS:
-      hipLaunchKernelGGL(fx_chorus_kernel, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->N, fx->w,
-                         fx->voices, fx->spacing, fx->d_wet);
+    case GROOVE_FX_CHORUS: {
+      const uint32_t nearest = fx->N - (fx->voices - 1) * fx->spacing; // newest tap: pushed this many frames ago
+      if (nearest >= frames && (fx->voices == 1 || fx->spacing >= frames))
+        hipLaunchKernelGGL(fx_chorus_par_kernel, dim3(lanes_grid.x, frames), blk, 0, ctx->stream, io->d, n, chs, fx->d_ring, fx->N, fx->w, fx->voices, fx->spacing, fx->d_wet);
+      else if (nearest >= 16 && (fx->voices == 1 || fx->spacing >= 16))
+        hipLaunchKernelGGL(fx_chorus_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->N, fx->w, fx->voices, fx->spacing, fx->d_wet);
+      else hipLaunchKernelGGL(fx_chorus_kernel<1>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->N, fx->w, fx->voices, fx->spacing, fx->d_wet);
       fx->w = (uint32_t)(((uint64_t)fx->w + frames) % fx->N);
       break;
-    case GROOVE_FX_REVERB:
-      hipLaunchKernelGGL(fx_reverb_kernel, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->geo, fx->d_fa, fx->d_wet);
+    }
+    case GROOVE_FX_REVERB: {
+      uint32_t shortest = fx->geo.N[0], shortest_comb = fx->geo.N[0];
+      for (int i = 1; i < 6; ++i) shortest = std::min(shortest, fx->geo.N[i]);
+      for (int i = 1; i < 4; ++i) shortest_comb = std::min(shortest_comb, fx->geo.N[i]);
+      const uint32_t shortest_ap = std::min(fx->geo.N[4], fx->geo.N[5]);
+      if (fx->all_wet && shortest_comb >= frames && shortest_ap >= 32) {
+        // combs: parallel over (frame, lane); all-passes: sequential per lane, 32-frame chunks
+        hipLaunchKernelGGL(fx_reverb_combs_par_kernel, dim3(lanes_grid.x, frames), blk, 0, ctx->stream, io->d, n, chs, fx->d_ring, fx->geo, fx->d_fa);
+        hipLaunchKernelGGL(fx_reverb_allpass_kernel<32>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->geo);
+      } else if (shortest >= 8) hipLaunchKernelGGL(fx_reverb_kernel<8>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->geo, fx->d_fa, fx->d_wet);
+      else hipLaunchKernelGGL(fx_reverb_kernel<1>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->geo, fx->d_fa, fx->d_wet);
       for (int i = 0; i < 6; ++i) fx->geo.w[i] = (uint32_t)(((uint64_t)fx->geo.w[i] + frames) % fx->geo.N[i]);
       break;
+    }
     default: return fail(ctx, "groove_fx_process: unknown kind");
   }
   GHIP(ctx, hipGetLastError());

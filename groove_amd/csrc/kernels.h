@@ -463,8 +463,17 @@ __global__ __launch_bounds__(kThreads) void fx_elementwise_kernel(
   }
 }
 
-// IIR kinds (a3 BiQuad 12 dB, a4 24 dB low-pass): one (channel, lane) pair per thread,
-// f64 coefficients and state.  coef: [5 or 6][n] f64; st: [4][2n] f64.
+// The IIR and delay-line effect kernels keep one (channel, lane) pair per thread and walk the
+// block sequentially (feedback), but in CHUNKS of C frames: all the loads of a chunk (inputs and
+// delay-line reads) are issued back to back before any arithmetic, so a chunk costs one memory
+// round trip instead of C.  Delay-line reads of a chunk may not alias its writes, which holds
+// when every line is at least C frames long (the host picks C = 1 otherwise).  With only
+// 2 * lanes threads (config #3: 8,192 = 128 waves on 1,024 SIMDs) these kernels are latency
+// bound, and the chunking is what sets their speed.
+
+// IIR kinds (a3 BiQuad 12 dB, a4 24 dB low-pass): f64 coefficients and state.
+// coef: [5 or 6][n] f64; st: [4][2n] f64.
+template <int C>
 __global__ __launch_bounds__(kThreads) void fx_biquad_kernel(
     float* __restrict__ data, uint32_t n, uint32_t frames, size_t ch_stride,
     const double* __restrict__ coef, double* __restrict__ st, const float* __restrict__ wet) {
@@ -476,14 +485,23 @@ __global__ __launch_bounds__(kThreads) void fx_biquad_kernel(
   BiquadStateD s{st[t], st[ln + t], st[2 * ln + t], st[3 * ln + t]};
   const float w = wet[lane];
   float* __restrict__ ptr = data + ch * ch_stride + lane;
-  for (uint32_t f = 0; f < frames; ++f) {
-    const float x = ptr[(size_t)f * n];
-    float y = (float)biquad_step(s, c, (double)x);
-    if (w < 1.0f) y = fmaf(y, w, x * (1.0f - w));
-    ptr[(size_t)f * n] = y;
+  for (uint32_t f0 = 0; f0 < frames; f0 += C) {
+    const uint32_t c_n = min((uint32_t)C, frames - f0);
+    float x[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) x[j] = (uint32_t)j < c_n ? ptr[(size_t)(f0 + j) * n] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      if ((uint32_t)j < c_n) {
+        float y = (float)biquad_step(s, c, (double)x[j]);
+        if (w < 1.0f) y = fmaf(y, w, x[j] * (1.0f - w));
+        ptr[(size_t)(f0 + j) * n] = y;
+      }
+    }
   }
   st[t] = s.x1; st[ln + t] = s.x2; st[2 * ln + t] = s.y1; st[3 * ln + t] = s.y2;
 }
+template <int C>
 __global__ __launch_bounds__(kThreads) void fx_lp24_kernel(
     float* __restrict__ data, uint32_t n, uint32_t frames, size_t ch_stride,
     const double* __restrict__ coef, double* __restrict__ st, const float* __restrict__ wet) {
@@ -491,57 +509,71 @@ __global__ __launch_bounds__(kThreads) void fx_lp24_kernel(
   if (t >= 2 * n) return;
   const uint32_t ch = t / n, lane = t % n;
   const size_t ln = 2 * (size_t)n;
-  const double b0a = coef[lane], a1a = coef[(size_t)n + lane], a2a = coef[(size_t)2 * n + lane];
-  const double b0b = coef[(size_t)3 * n + lane], a1b = coef[(size_t)4 * n + lane], a2b = coef[(size_t)5 * n + lane];
-  double s0 = st[t], s1 = st[ln + t], s2 = st[2 * ln + t], s3 = st[3 * ln + t];
+  const Lp24CoefD c{coef[lane], coef[(size_t)n + lane], coef[(size_t)2 * n + lane],
+                    coef[(size_t)3 * n + lane], coef[(size_t)4 * n + lane], coef[(size_t)5 * n + lane]};
+  Lp24StateD s{st[t], st[ln + t], st[2 * ln + t], st[3 * ln + t]};
   const float w = wet[lane];
   float* __restrict__ ptr = data + ch * ch_stride + lane;
-  for (uint32_t f = 0; f < frames; ++f) {
-    const float xf = ptr[(size_t)f * n];
-    const double x = (double)xf;
-    const double bx = b0a * x;
-    const double y1 = bx + s0;
-    s0 = fma(a1a, y1, 2.0 * bx + s1);
-    s1 = fma(a2a, y1, bx);
-    const double by = b0b * y1;
-    const double y2 = by + s2;
-    s2 = fma(a1b, y2, 2.0 * by + s3);
-    s3 = fma(a2b, y2, by);
-    float y = (float)y2;
-    if (w < 1.0f) y = fmaf(y, w, xf * (1.0f - w));
-    ptr[(size_t)f * n] = y;
+  for (uint32_t f0 = 0; f0 < frames; f0 += C) {
+    const uint32_t c_n = min((uint32_t)C, frames - f0);
+    float x[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) x[j] = (uint32_t)j < c_n ? ptr[(size_t)(f0 + j) * n] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      if ((uint32_t)j < c_n) {
+        float y = (float)lp24_step(s, c, (double)x[j]);
+        if (w < 1.0f) y = fmaf(y, w, x[j] * (1.0f - w));
+        ptr[(size_t)(f0 + j) * n] = y;
+      }
+    }
   }
-  st[t] = s0; st[ln + t] = s1; st[2 * ln + t] = s2; st[3 * ln + t] = s3;
+  st[t] = s.s0; st[ln + t] = s.s1; st[2 * ln + t] = s.s2; st[3 * ln + t] = s.s3;
 }
 
 // Delay-line kinds.  Ring rows are [pos][2n] fp32 (channel-major inside a row), so the ring
-// index is wave-uniform and every access is a coalesced row segment.  `w` is the write
+// index is wave-uniform and every access is a coalesced row segment.  `w0` is the write
 // index at the start of the block (host-tracked, uniform for the whole effect bank).
 // a11 Delay{seconds}
+template <int C>
 __global__ __launch_bounds__(kThreads) void fx_delay_kernel(
     float* __restrict__ data, uint32_t n, uint32_t frames, size_t ch_stride,
-    float* __restrict__ ring, uint32_t N, uint32_t w, const float* __restrict__ wet) {
+    float* __restrict__ ring, uint32_t N, uint32_t w0, const float* __restrict__ wet) {
   const uint32_t t = blockIdx.x * kThreads + threadIdx.x;
   if (t >= 2 * n) return;
   const uint32_t ch = t / n, lane = t % n;
   const size_t ln = 2 * (size_t)n;
   const float wm = wet[lane];
   float* __restrict__ ptr = data + ch * ch_stride + lane;
-  uint32_t pos = w;
-  for (uint32_t f = 0; f < frames; ++f) {
-    const float x = ptr[(size_t)f * n];
-    float* r = ring + (size_t)pos * ln + t;
-    float y = *r;
-    *r = x;
-    if (wm < 1.0f) y = fmaf(y, wm, x * (1.0f - wm));
-    ptr[(size_t)f * n] = y;
-    pos = pos + 1 == N ? 0 : pos + 1;
+  float* __restrict__ rg = ring + t;
+  uint32_t pos = w0;
+  for (uint32_t f0 = 0; f0 < frames; f0 += C) {
+    const uint32_t c_n = min((uint32_t)C, frames - f0);
+    float x[C], y[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      uint32_t p = pos + j; if (p >= N) p -= N;
+      x[j] = (uint32_t)j < c_n ? ptr[(size_t)(f0 + j) * n] : 0.0f;
+      y[j] = (uint32_t)j < c_n ? rg[(size_t)p * ln] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      if ((uint32_t)j < c_n) {
+        uint32_t p = pos + j; if (p >= N) p -= N;
+        rg[(size_t)p * ln] = x[j];
+        float o = y[j];
+        if (wm < 1.0f) o = fmaf(o, wm, x[j] * (1.0f - wm));
+        ptr[(size_t)(f0 + j) * n] = o;
+      }
+    }
+    pos += c_n; if (pos >= N) pos -= N;
   }
 }
 // a10 Chorus{voices, delay_seconds}: taps at (pos + k*spacing) mod N, k = 0..voices-1.
+template <int C>
 __global__ __launch_bounds__(kThreads) void fx_chorus_kernel(
     float* __restrict__ data, uint32_t n, uint32_t frames, size_t ch_stride,
-    float* __restrict__ ring, uint32_t N, uint32_t w, uint32_t voices, uint32_t spacing,
+    float* __restrict__ ring, uint32_t N, uint32_t w0, uint32_t voices, uint32_t spacing,
     const float* __restrict__ wet) {
   const uint32_t t = blockIdx.x * kThreads + threadIdx.x;
   if (t >= 2 * n) return;
@@ -549,21 +581,35 @@ __global__ __launch_bounds__(kThreads) void fx_chorus_kernel(
   const size_t ln = 2 * (size_t)n;
   const float wm = wet[lane];
   float* __restrict__ ptr = data + ch * ch_stride + lane;
-  uint32_t pos = w;
-  for (uint32_t f = 0; f < frames; ++f) {
-    const float x = ptr[(size_t)f * n];
-    float sum = 0.0f;
-    uint32_t tp = pos;
-    for (uint32_t k = 0; k < voices; ++k) {
-      sum += ring[(size_t)tp * ln + t];
-      tp += spacing;
-      if (tp >= N) tp -= N;
+  float* __restrict__ rg = ring + t;
+  uint32_t pos = w0;
+  for (uint32_t f0 = 0; f0 < frames; f0 += C) {
+    const uint32_t c_n = min((uint32_t)C, frames - f0);
+    float x[C], sum[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      x[j] = (uint32_t)j < c_n ? ptr[(size_t)(f0 + j) * n] : 0.0f;
+      sum[j] = 0.0f;
     }
-    ring[(size_t)pos * ln + t] = x;
-    float y = sum;
-    if (wm < 1.0f) y = fmaf(y, wm, x * (1.0f - wm));
-    ptr[(size_t)f * n] = y;
-    pos = pos + 1 == N ? 0 : pos + 1;
+    for (uint32_t k = 0; k < voices; ++k) { // tap k of every frame of the chunk, loads back to back
+      uint32_t base = pos + k * spacing; if (base >= N) base -= N;
+#pragma unroll
+      for (int j = 0; j < C; ++j) {
+        uint32_t p = base + j; if (p >= N) p -= N;
+        if ((uint32_t)j < c_n) sum[j] += rg[(size_t)p * ln];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      if ((uint32_t)j < c_n) {
+        uint32_t p = pos + j; if (p >= N) p -= N;
+        rg[(size_t)p * ln] = x[j];
+        float o = sum[j];
+        if (wm < 1.0f) o = fmaf(o, wm, x[j] * (1.0f - wm));
+        ptr[(size_t)(f0 + j) * n] = o;
+      }
+    }
+    pos += c_n; if (pos >= N) pos -= N;
   }
 }
 // a12 Reverb{attenuation, seconds}: 4 recirculating combs in parallel, 2 Schroeder all-passes
@@ -574,6 +620,7 @@ struct ReverbGeom {
   uint64_t base[6];   // row offset of each ring inside the ring buffer (rows of 2n floats)
   float g[6];         // feedback gains
 };
+template <int C>
 __global__ __launch_bounds__(kThreads) void fx_reverb_kernel(
     float* __restrict__ data, uint32_t n, uint32_t frames, size_t ch_stride,
     float* __restrict__ ring, ReverbGeom geo, const float* __restrict__ atten, const float* __restrict__ wet) {
@@ -583,33 +630,155 @@ __global__ __launch_bounds__(kThreads) void fx_reverb_kernel(
   const size_t ln = 2 * (size_t)n;
   const float wm = wet[lane], att = atten[lane];
   float* __restrict__ ptr = data + ch * ch_stride + lane;
+  float* __restrict__ rg = ring + t;
   uint32_t pos[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) pos[i] = geo.w[i];
-  for (uint32_t f = 0; f < frames; ++f) {
-    const float x = ptr[(size_t)f * n];
-    const float in = x * att;
-    float sum = 0.0f;
+  for (uint32_t f0 = 0; f0 < frames; f0 += C) {
+    const uint32_t c_n = min((uint32_t)C, frames - f0);
+    float x[C], d[6][C];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float* r = ring + (geo.base[i] + pos[i]) * ln + t;
-      const float out = geo.g[i] * *r;
-      *r = in + out;
-      sum += out;
+    for (int j = 0; j < C; ++j) x[j] = (uint32_t)j < c_n ? ptr[(size_t)(f0 + j) * n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < C; ++j) {
+        uint32_t p = pos[i] + j; if (p >= geo.N[i]) p -= geo.N[i];
+        d[i][j] = (uint32_t)j < c_n ? rg[(geo.base[i] + p) * ln] : 0.0f;
+      }
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      if ((uint32_t)j < c_n) {
+        const float in = x[j] * att;
+        float sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          uint32_t p = pos[i] + j; if (p >= geo.N[i]) p -= geo.N[i];
+          const float out = geo.g[i] * d[i][j];
+          rg[(geo.base[i] + p) * ln] = in + out;
+          sum += out;
+        }
+#pragma unroll
+        for (int i = 4; i < 6; ++i) {
+          uint32_t p = pos[i] + j; if (p >= geo.N[i]) p -= geo.N[i];
+          const float v = fmaf(geo.g[i], d[i][j], sum);
+          rg[(geo.base[i] + p) * ln] = v;
+          sum = fmaf(-geo.g[i], v, d[i][j]);
+        }
+        float o = sum;
+        if (wm < 1.0f) o = fmaf(o, wm, x[j] * (1.0f - wm));
+        ptr[(size_t)(f0 + j) * n] = o;
+      }
     }
 #pragma unroll
-    for (int i = 4; i < 6; ++i) {
-      float* r = ring + (geo.base[i] + pos[i]) * ln + t;
-      const float d = *r;
-      const float v = fmaf(geo.g[i], d, sum);
-      *r = v;
-      sum = fmaf(-geo.g[i], v, d);
-    }
-    float y = sum;
-    if (wm < 1.0f) y = fmaf(y, wm, x * (1.0f - wm));
-    ptr[(size_t)f * n] = y;
+    for (int i = 0; i < 6; ++i) { pos[i] += c_n; if (pos[i] >= geo.N[i]) pos[i] -= geo.N[i]; }
+  }
+}
+
+// ---- time-parallel forms ---------------------------------------------------------------
+// A delay line that is at least one block long has no feedback INSIDE a block: every frame of
+// the block reads a ring slot written in an earlier block and writes a slot nobody else in the
+// block touches.  Then the effect is a pure gather/scatter over (frame, lane) and runs as one
+// fully parallel, HBM-bound launch: grid = (ceil(2n / 256), frames).
+__global__ __launch_bounds__(kThreads) void fx_delay_par_kernel(
+    float* __restrict__ data, uint32_t n, size_t ch_stride, float* __restrict__ ring, uint32_t N, uint32_t w0,
+    const float* __restrict__ wet) {
+  const uint32_t t = blockIdx.x * kThreads + threadIdx.x, f = blockIdx.y;
+  if (t >= 2 * n) return;
+  const uint32_t ch = t / n, lane = t % n;
+  uint32_t p = w0 + f; if (p >= N) p -= N;
+  float* px = data + ch * ch_stride + (size_t)f * n + lane;
+  float* pr = ring + (size_t)p * (2 * (size_t)n) + t;
+  const float x = *px;
+  float y = *pr;
+  *pr = x;
+  const float wm = wet[lane];
+  if (wm < 1.0f) y = fmaf(y, wm, x * (1.0f - wm));
+  *px = y;
+}
+__global__ __launch_bounds__(kThreads) void fx_chorus_par_kernel(
+    float* __restrict__ data, uint32_t n, size_t ch_stride, float* __restrict__ ring, uint32_t N, uint32_t w0,
+    uint32_t voices, uint32_t spacing, const float* __restrict__ wet) {
+  const uint32_t t = blockIdx.x * kThreads + threadIdx.x, f = blockIdx.y;
+  if (t >= 2 * n) return;
+  const uint32_t ch = t / n, lane = t % n;
+  const size_t ln = 2 * (size_t)n;
+  uint32_t p = w0 + f; if (p >= N) p -= N;
+  float* px = data + ch * ch_stride + (size_t)f * n + lane;
+  const float x = *px;
+  float sum = 0.0f;
+  uint32_t tp = p;
+  for (uint32_t k = 0; k < voices; ++k) {
+    sum += ring[(size_t)tp * ln + t];
+    tp += spacing; if (tp >= N) tp -= N;
+  }
+  ring[(size_t)p * ln + t] = x;
+  const float wm = wet[lane];
+  if (wm < 1.0f) sum = fmaf(sum, wm, x * (1.0f - wm));
+  *px = sum;
+}
+// Reverb, stage 1: the four recirculating combs (all at least one block long) in parallel over
+// (frame, lane); the comb sum replaces the block contents (only used when every lane is fully wet).
+__global__ __launch_bounds__(kThreads) void fx_reverb_combs_par_kernel(
+    float* __restrict__ data, uint32_t n, size_t ch_stride, float* __restrict__ ring, ReverbGeom geo,
+    const float* __restrict__ atten) {
+  const uint32_t t = blockIdx.x * kThreads + threadIdx.x, f = blockIdx.y;
+  if (t >= 2 * n) return;
+  const uint32_t ch = t / n, lane = t % n;
+  const size_t ln = 2 * (size_t)n;
+  float* px = data + ch * ch_stride + (size_t)f * n + lane;
+  const float in = *px * atten[lane];
+  float sum = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) pos[i] = pos[i] + 1 == geo.N[i] ? 0 : pos[i] + 1;
+  for (int i = 0; i < 4; ++i) {
+    uint32_t p = geo.w[i] + f; if (p >= geo.N[i]) p -= geo.N[i];
+    float* r = ring + (geo.base[i] + p) * ln + t;
+    const float out = geo.g[i] * *r;
+    *r = in + out;
+    sum += out;
+  }
+  *px = sum;
+}
+// Reverb, stage 2: the two short Schroeder all-passes (5 ms, 1.7 ms: shorter than a block, so
+// sequential per lane), chunked like the other delay-line kernels.
+template <int C>
+__global__ __launch_bounds__(kThreads) void fx_reverb_allpass_kernel(
+    float* __restrict__ data, uint32_t n, uint32_t frames, size_t ch_stride, float* __restrict__ ring, ReverbGeom geo) {
+  const uint32_t t = blockIdx.x * kThreads + threadIdx.x;
+  if (t >= 2 * n) return;
+  const uint32_t ch = t / n, lane = t % n;
+  const size_t ln = 2 * (size_t)n;
+  float* __restrict__ ptr = data + ch * ch_stride + lane;
+  float* __restrict__ rg = ring + t;
+  uint32_t pos[2] = {geo.w[4], geo.w[5]};
+  for (uint32_t f0 = 0; f0 < frames; f0 += C) {
+    const uint32_t c_n = min((uint32_t)C, frames - f0);
+    float x[C], d[2][C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) x[j] = (uint32_t)j < c_n ? ptr[(size_t)(f0 + j) * n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < C; ++j) {
+        uint32_t p = pos[i] + j; if (p >= geo.N[4 + i]) p -= geo.N[4 + i];
+        d[i][j] = (uint32_t)j < c_n ? rg[(geo.base[4 + i] + p) * ln] : 0.0f;
+      }
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      if ((uint32_t)j < c_n) {
+        float sum = x[j];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          uint32_t p = pos[i] + j; if (p >= geo.N[4 + i]) p -= geo.N[4 + i];
+          const float v = fmaf(geo.g[4 + i], d[i][j], sum);
+          rg[(geo.base[4 + i] + p) * ln] = v;
+          sum = fmaf(-geo.g[4 + i], v, d[i][j]);
+        }
+        ptr[(size_t)(f0 + j) * n] = sum;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { pos[i] += c_n; if (pos[i] >= geo.N[4 + i]) pos[i] -= geo.N[4 + i]; }
   }
 }
 

@@ -235,9 +235,10 @@ def sampler_start_block(n):
     return (h % np.uint64(172)).astype(np.int64)
 
 
-def chain_fx_params(n):
+def chain_fx_params(n, voice_index=None):
     """Config #3 per-voice chain: BiQuad LP12 (cutoff 1000 + 50 (i mod 64) Hz, q 0.707) → Chorus
-    (4 voices, 0.25 s) → Delay (0.1 s) → Reverb (0.95, 1.25 s)."""
+    (4 voices, 0.25 s) → Delay (0.1 s) → Reverb (0.95, 1.25 s).  voice_index[lane] is the project
+    voice index i of each lane (identity when None)."""
     def arr(**kw):
         a = (T.FxParams * n)()
         base = T.fx_params(**kw)
@@ -246,6 +247,6 @@ def chain_fx_params(n):
         return a
     lp = arr(q=0.707)
     for i in range(n):
-        lp[i].cutoff_hz = 1000.0 + 50.0 * (i % 64)
+        lp[i].cutoff_hz = 1000.0 + 50.0 * (int(i if voice_index is None else voice_index[i]) % 64)
     return [(T.FX_BIQUAD_LP12, lp), (T.FX_CHORUS, arr(voices=4, delay_seconds=0.25)),
             (T.FX_DELAY, arr(delay_seconds=0.1)), (T.FX_REVERB, arr(attenuation=0.95, reverb_seconds=1.25))]
