@@ -121,6 +121,22 @@ class Project:
             first = False
 
 
+def committed_traffic(workload, world):
+    """HBM bytes per step from the committed PMC passes (profiles/*_summary.json, FETCH_SIZE doubled per
+    MI355X_MICROARCH.md §HBM); only meaningful for the default single-GPU workload it was collected on."""
+    if workload != "welsh-1m" or world != 1:
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_summary.json")))
+    if not files:
+        return None
+    try:
+        t = json.load(open(files[-1])).get("hbm_traffic_bytes_per_step", {})
+        return {"bytes_per_step": t.get("total_corrected"), "source": os.path.basename(files[-1])}
+    except Exception:
+        return None
+
+
 def cpu_baseline(workload, seconds_target=15.0):
     """The f64 scalar oracle ("port"; the reference Rust path cannot be built here) timed on
     this host, rank 0 only, on a bounded sample of the same workload, single thread (mode A)."""
@@ -154,14 +170,19 @@ def cpu_baseline(workload, seconds_target=15.0):
         "sample": f"{sample_voices} of {V} voices x {blocks} blocks of {FRAMES} frames, f64 scalar oracle -O2, "
                   f"1 thread; frames/s scaled by {sample_voices}/{V} (measured {vf_per_s:.3e} voice-frames/s)",
     }
-    # mode B: all host cores
+    # mode B: all host cores, on a sample large enough to keep every thread busy
     cores = int(L.oracle_hardware_concurrency()) or 1
-    mt_blocks = max(4, blocks // 2)
-    t0 = time.perf_counter()
-    for _ in range(mt_blocks):
-        bank.render_bus(FRAMES, threads=cores)
-    el = time.perf_counter() - t0
-    out["all_cores"] = {"value": sample_voices * FRAMES * mt_blocks / el / V, "cores": cores}
+    if kind != "sampler":
+        mt_voices = min(V, 64 * cores)
+        mbank = O.Bank.welsh(P.welsh_voices(mt_voices))
+        mbank.note_events(P.note_on_all(mt_voices))
+        mt_blocks = int(max(2, min(512, 0.3 * seconds_target * vf_per_s * min(cores, 16) / (mt_voices * FRAMES))))
+        t0 = time.perf_counter()
+        for _ in range(mt_blocks):
+            mbank.render_bus(FRAMES, threads=cores)
+        el = time.perf_counter() - t0
+        out["all_cores"] = {"value": mt_voices * FRAMES * mt_blocks / el / V, "cores": cores,
+                            "sample": f"{mt_voices} voices x {mt_blocks} blocks, {cores} threads"}
     return out
 
 
@@ -185,7 +206,8 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("GROOVE_BENCH_FORCE_DIST") == "1"  # the latter: exercise the N>1 code path on one GPU
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import torch
@@ -197,8 +219,8 @@ def main():
     V = args.voices or wl["voices"]
     lo = V * rank // world
     hi = V * (rank + 1) // world
-    ctx = E.Context(local_rank if world > 1 else 0)
-    if world > 1:
+    ctx = E.Context(local_rank if use_dist else 0)
+    if use_dist:
         uid = [ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(uid[0], rank, world)
@@ -223,7 +245,7 @@ def main():
     t0 = time.perf_counter()
     for s in range(K):
         proj.step(bus, (W + s) * FRAMES, pairs[s])
-    if world > 1:
+    if use_dist:
         ctx.bus_reduce(E._Slice(bus, W * FRAMES), K * FRAMES, 0)
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -253,9 +275,13 @@ def main():
                        "voices_total": V, "voices_per_gpu": n_local, "parallelism": f"voices sharded x{world}, 1 RCCL bus reduce"},
             "voice_frames_per_s": value * V,
             "path_effective_GBs": wl["bytes_per_vf"] * value * V / 1e9,
-            "roofline": {"bound": "hbm", "kernel": "welsh_render_mix_kernel" if fused and wl["kind"] == "welsh" else "render kernel of the first bank",
+            "roofline": {"bound": "hbm",
+                         "kernel": ("welsh_render_uniform_kernel<fused> (uniform, f64-LFO and per-lane workgroup kinds run "
+                                    "concurrently) + partial_rows/final" if fused and wl["kind"] == "welsh"
+                                    else "render kernel of the first bank"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_voice_frame": dom_bytes, "kernel_ms": kern_ms, "traffic": None},
+                         "algorithmic_bytes_per_voice_frame": dom_bytes, "kernel_ms": kern_ms,
+                         "traffic": committed_traffic(args.workload, world)},
             "output_check": {"finite": finite, "peak_abs_bus_over_V": peak},
         }
         if not args.no_cpu_baseline and world == 1:

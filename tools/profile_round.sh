@@ -13,7 +13,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$ROUND
 mkdir -p $OUT profiles
-BENCH="python3 bench.py --steps 20 --warmup 4 --no-cpu-baseline"
+BENCH="python3 bench.py --no-cpu-baseline"   # the default bench command (172 steps, 4 warm-up)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/bench_kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH > $OUT/bench_write.log 2>&1

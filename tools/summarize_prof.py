@@ -10,7 +10,7 @@ import sys
 
 out, rnd = sys.argv[1], sys.argv[2]
 os.makedirs("profiles", exist_ok=True)
-summary = {"round": rnd, "command": "python3 bench.py --steps 20 --warmup 4 --no-cpu-baseline"}
+summary = {"round": rnd, "command": "python3 bench.py --no-cpu-baseline   (defaults: --gpus 1 --steps 172 --warmup 4, workload welsh-1m)"}
 
 ks = glob.glob(f"{out}/kt/*/*_kernel_stats.csv")
 if ks:
@@ -40,20 +40,24 @@ def counters(sub):
 for sub in ("fetch", "write", "sq", "grbm"):
     summary[sub] = counters(sub)
 
-# HBM traffic of the dominant kernel per launch (MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB;
-# FETCH_SIZE reads 1/2 of the bytes of a wide coalesced streaming read on gfx950 — our reads are 4 B/lane
-# state loads, an uncalibrated width, so both the raw and the doubled figure are kept).
-dom = None
-for k in summary.get("write", {}):
-    if "welsh_render" in k and (dom is None or summary["write"][k]["mean_per_dispatch"]["WRITE_SIZE"] > summary["write"][dom]["mean_per_dispatch"]["WRITE_SIZE"]):
-        dom = k
-if dom:
-    w = summary["write"][dom]["mean_per_dispatch"]["WRITE_SIZE"] * 1024
-    f = summary.get("fetch", {}).get(dom, {}).get("mean_per_dispatch", {}).get("FETCH_SIZE", 0.0) * 1024
-    summary["dominant_kernel"] = dom
-    summary["hbm_traffic_bytes_per_launch"] = {"write": w, "fetch_raw": f, "fetch_x2_gfx950": 2 * f,
-                                               "total_raw": w + f, "total_corrected": w + 2 * f}
+# HBM traffic per STEP (one 256-frame block of the whole project): the Welsh render runs as up to
+# three concurrent kernels (one per workgroup kind) plus the two partial-row reductions, so the
+# per-kernel means are summed.  MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB;
+# FETCH_SIZE reads 1/2 of the bytes of a wide coalesced streaming read on gfx950 — the state loads
+# here are 4 B/lane buffer loads (an uncalibrated width), so the raw and the doubled figure are kept.
+def per_step(sub, counter):
+    tot = 0.0
+    for k, v in summary.get(sub, {}).items():
+        if "welsh_render" in k or "partial_" in k or "mix_" in k:
+            tot += v["mean_per_dispatch"].get(counter, 0.0)
+    return tot * 1024.0
+
+
+w, f = per_step("write", "WRITE_SIZE"), per_step("fetch", "FETCH_SIZE")
+summary["dominant_kernel"] = "welsh_render_uniform_kernel<fused> (+ f64-LFO and per-lane kinds, concurrent) + partial_rows/final"
+summary["hbm_traffic_bytes_per_step"] = {"write": w, "fetch_raw": f, "fetch_x2_gfx950": 2 * f,
+                                         "total_raw": w + f, "total_corrected": w + 2 * f}
 json.dump(summary, open(f"profiles/{rnd}_summary.json", "w"), indent=1)
-print(json.dumps({k: summary[k] for k in ("dominant_kernel", "hbm_traffic_bytes_per_launch") if k in summary}, indent=1))
+print(json.dumps({k: summary[k] for k in ("dominant_kernel", "hbm_traffic_bytes_per_step") if k in summary}, indent=1))
 for r in summary.get("kernel_stats", []):
     print(f"{r['pct']:6.2f}%  {r['avg_ns'] / 1e3:10.1f} us x {r['calls']:4d}  {r['name']}")
