@@ -36,8 +36,11 @@ struct groove_bank {
   uint32_t* d_params = nullptr;
   uint32_t* d_state = nullptr;
   double* d_cold = nullptr; // welsh: [4][n]; fm: ratio [n]
-  WelshParams* d_wave_params = nullptr; // welsh: one entry per 64-lane wave (uniform fast path)
-  uint8_t* d_wg_kind = nullptr;         // welsh: 1 = every wave of the workgroup is patch-uniform
+  WaveDesc* d_waves = nullptr;   // welsh: virtual waves (runs of <= 64 voices sharing a patch)
+  uint32_t n_vwaves = 0;         // 0: the bank runs on the per-lane kernel
+  size_t vwaves_cap = 0;
+  uint8_t* d_wg_kind = nullptr;  // welsh: register budget each workgroup of virtual waves needs
+  size_t wg_kind_cap = 0;
   uint32_t wgs_of_kind[3] = {0, 0, 0};
   float* d_pcm = nullptr;   // sampler bank
   groove_note_event* d_ev = nullptr;
@@ -140,24 +143,40 @@ int welsh_upload_params(groove_bank* b) {
   }
   if (upload_soa(ctx, b->d_params, P)) return 1;
   GHIP(ctx, hipMemcpy(b->d_cold, cold.data(), cold.size() * 8, hipMemcpyHostToDevice));
-  // wave-uniform fast path: one parameter record per 64-lane group; a workgroup takes the
-  // fast kernel when each of its wavefronts carries a single patch
-  const uint32_t waves = (n + 63) / 64, wgs = blocks_for(n);
-  std::vector<WelshParams> W(waves);
-  std::vector<uint8_t> kind(wgs, WG_UNIFORM);
-  for (uint32_t w = 0; w < waves; ++w) {
-    W[w] = P[(size_t)w * 64];
-    uint8_t& k = kind[w / kWaves];
-    if (k != WG_GENERIC && welsh_f64_lfo(W[w])) k = WG_UNIFORM_F64;
-    const uint32_t hi = std::min<uint32_t>(n, (w + 1) * 64);
-    for (uint32_t v = w * 64 + 1; v < hi; ++v)
-      if (std::memcmp(&P[v], &W[w], sizeof(WelshParams)) != 0) { k = WG_GENERIC; break; }
+  // Virtual waves: maximal runs of consecutive voices with identical parameter words, cut at 64.
+  std::vector<WaveDesc> W;
+  W.reserve((size_t)n / 64 + 64);
+  for (uint32_t v = 0; v < n;) {
+    uint32_t e = v + 1;
+    while (e < n && e - v < 64 && std::memcmp(&P[e], &P[v], sizeof(WelshParams)) == 0) ++e;
+    WaveDesc d;
+    d.p = P[v]; d.vbase = v; d.count = e - v;
+    W.push_back(d);
+    v = e;
   }
+  const uint32_t phys_waves = (n + 63) / 64;
   b->wgs_of_kind[0] = b->wgs_of_kind[1] = b->wgs_of_kind[2] = 0;
+  if (W.size() > (size_t)phys_waves + phys_waves / 2 + 8) {
+    b->n_vwaves = 0; // patches interleaved lane by lane: the per-lane kernel serves the whole bank
+    return 0;
+  }
+  b->n_vwaves = (uint32_t)W.size();
+  const uint32_t wgs = (b->n_vwaves + kWaves - 1) / kWaves;
+  std::vector<uint8_t> kind(wgs, WG_UNIFORM);
+  for (uint32_t w = 0; w < b->n_vwaves; ++w)
+    if (welsh_f64_lfo(W[w].p)) kind[w / kWaves] = WG_UNIFORM_F64;
   for (uint8_t k : kind) b->wgs_of_kind[k] += 1;
-  if (!b->d_wave_params) GHIP(ctx, hipMalloc(&b->d_wave_params, (size_t)waves * sizeof(WelshParams)));
-  if (!b->d_wg_kind) GHIP(ctx, hipMalloc(&b->d_wg_kind, wgs));
-  GHIP(ctx, hipMemcpy(b->d_wave_params, W.data(), (size_t)waves * sizeof(WelshParams), hipMemcpyHostToDevice));
+  if (b->vwaves_cap < W.size()) {
+    if (b->d_waves) GHIP(ctx, hipFree(b->d_waves));
+    b->vwaves_cap = W.size() + W.size() / 8 + 16;
+    GHIP(ctx, hipMalloc(&b->d_waves, b->vwaves_cap * sizeof(WaveDesc)));
+  }
+  if (b->wg_kind_cap < wgs) {
+    if (b->d_wg_kind) GHIP(ctx, hipFree(b->d_wg_kind));
+    b->wg_kind_cap = wgs + wgs / 8 + 16;
+    GHIP(ctx, hipMalloc(&b->d_wg_kind, b->wg_kind_cap));
+  }
+  GHIP(ctx, hipMemcpy(b->d_waves, W.data(), W.size() * sizeof(WaveDesc), hipMemcpyHostToDevice));
   GHIP(ctx, hipMemcpy(b->d_wg_kind, kind.data(), wgs, hipMemcpyHostToDevice));
   return 0;
 }
@@ -613,7 +632,7 @@ int groove_bank_destroy(groove_bank* b) {
   auto it = std::find(ctx->banks.begin(), ctx->banks.end(), b);
   if (it != ctx->banks.end()) ctx->banks.erase(it);
   if (b->scratch) groove_block_destroy(b->scratch);
-  hipFree(b->d_params); hipFree(b->d_state); hipFree(b->d_cold); hipFree(b->d_pcm); hipFree(b->d_ev); hipFree(b->d_wave_params); hipFree(b->d_wg_kind);
+  hipFree(b->d_params); hipFree(b->d_state); hipFree(b->d_cold); hipFree(b->d_pcm); hipFree(b->d_ev); hipFree(b->d_waves); hipFree(b->d_wg_kind);
   delete b;
   return 0;
 }
@@ -652,37 +671,33 @@ static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs
   const dim3 grid(blocks_for(b->n)), blk(kThreads);
   if (b->kind == BANK_WELSH) {
     RenderConsts rc{(float)(3.14159265358979323846 / ctx->sr), (float)(0.49 * ctx->sr)};
-    // One kernel per workgroup kind, each with its own register budget, running concurrently.
-    // Heaviest work per workgroup first (longest-task-first list scheduling): the f64-LFO kind
-    // goes out on the ctx stream at once, the per-lane stragglers and the short uniform kind on
-    // side streams forked from it, and the ctx stream joins them before the bus reduction.
-    const int order[3] = {WG_UNIFORM_F64, WG_GENERIC, WG_UNIFORM};
-    int first = -1;
-    for (int oi = 0; oi < 3; ++oi) if (b->wgs_of_kind[order[oi]]) { first = oi; break; }
-    const int kinds_present = (b->wgs_of_kind[0] != 0) + (b->wgs_of_kind[1] != 0) + (b->wgs_of_kind[2] != 0);
-    if (kinds_present > 1) GHIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream)); // fork point: before ANY of the kernels
-    int side = 0, used_side[2] = {0, 0};
-    for (int oi = 0; oi < 3; ++oi) {
-      const int k = order[oi];
-      if (!b->wgs_of_kind[k]) continue;
-      hipStream_t st = ctx->stream;
-      if (oi != first) {
-        st = ctx->side_stream[side];
-        GHIP(ctx, hipStreamWaitEvent(st, ctx->ev_fork, 0));
+    if (b->n_vwaves == 0) { // interleaved bank: per-lane kernel over the physical lanes
+      if (fused) hipLaunchKernelGGL(welsh_render_kernel<true>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, rc);
+      else hipLaunchKernelGGL(welsh_render_kernel<false>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, rc);
+    } else {
+      // Two kernels, one per register budget, running concurrently: the f64-LFO kind (more work
+      // per voice: the critical path) goes out on the ctx stream, the plain kind on a side stream
+      // forked from it, and the ctx stream joins it before the bus reduction.
+      const dim3 vgrid((b->n_vwaves + kWaves - 1) / kWaves);
+      const bool both = b->wgs_of_kind[WG_UNIFORM] && b->wgs_of_kind[WG_UNIFORM_F64];
+      if (both) {
+        GHIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        GHIP(ctx, hipStreamWaitEvent(ctx->side_stream[0], ctx->ev_fork, 0));
       }
-      if (k == WG_GENERIC) {
-        if (fused) hipLaunchKernelGGL(welsh_render_kernel<true>, grid, blk, 0, st, b->d_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
-        else hipLaunchKernelGGL(welsh_render_kernel<false>, grid, blk, 0, st, b->d_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
-      } else if (k == WG_UNIFORM) {
-        if (fused) hipLaunchKernelGGL((welsh_render_uniform_kernel<true, false>), grid, blk, 0, st, b->d_wave_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
-        else hipLaunchKernelGGL((welsh_render_uniform_kernel<false, false>), grid, blk, 0, st, b->d_wave_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
-      } else {
-        if (fused) hipLaunchKernelGGL((welsh_render_uniform_kernel<true, true>), grid, blk, 0, st, b->d_wave_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
-        else hipLaunchKernelGGL((welsh_render_uniform_kernel<false, true>), grid, blk, 0, st, b->d_wave_params, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
+      if (b->wgs_of_kind[WG_UNIFORM_F64]) {
+        if (fused) hipLaunchKernelGGL((welsh_render_uniform_kernel<true, true>), vgrid, blk, 0, ctx->stream, b->d_waves, b->n_vwaves, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
+        else hipLaunchKernelGGL((welsh_render_uniform_kernel<false, true>), vgrid, blk, 0, ctx->stream, b->d_waves, b->n_vwaves, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
       }
-      if (oi != first) { GHIP(ctx, hipEventRecord(ctx->ev_join[side], st)); used_side[side] = 1; ++side; }
+      if (b->wgs_of_kind[WG_UNIFORM]) {
+        hipStream_t st = both ? ctx->side_stream[0] : ctx->stream;
+        if (fused) hipLaunchKernelGGL((welsh_render_uniform_kernel<true, false>), vgrid, blk, 0, st, b->d_waves, b->n_vwaves, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
+        else hipLaunchKernelGGL((welsh_render_uniform_kernel<false, false>), vgrid, blk, 0, st, b->d_waves, b->n_vwaves, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
+      }
+      if (both) {
+        GHIP(ctx, hipEventRecord(ctx->ev_join[0], ctx->side_stream[0]));
+        GHIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[0], 0));
+      }
     }
-    for (int i = 0; i < 2; ++i) if (used_side[i]) GHIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0));
   } else if (b->kind == BANK_FM) {
     if (fused) hipLaunchKernelGGL(fm_render_kernel<true>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out);
     else hipLaunchKernelGGL(fm_render_kernel<false>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out);
@@ -710,7 +725,8 @@ int groove_bank_render_mix(groove_bank* b, uint32_t frames, float* bus_dev, int 
   if (frames > 4096) return fail(ctx, "groove_bank_render_mix: frames > 4096");
   GHIP(ctx, hipSetDevice(ctx->device));
   if (flush_events(b)) return 1;
-  const uint32_t rows = blocks_for(b->n), cols = 2 * frames;
+  const uint32_t rows = (b->kind == BANK_WELSH && b->n_vwaves) ? (b->n_vwaves + kWaves - 1) / kWaves : blocks_for(b->n);
+  const uint32_t cols = 2 * frames;
   const uint32_t rows_per_seg = 32;
   const uint32_t segs = (rows + rows_per_seg - 1) / rows_per_seg;
   if (ctx->fpart_cap < (size_t)rows * cols) {

@@ -212,17 +212,12 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
   });
 }
 // Generic form: per-lane parameters (any mix of patches inside a wave; exec-masked branches).
-// wg_kind[workgroup]: 0 = some wavefront mixes patches → per-lane kernel; 1 = every wavefront is
-// patch-uniform and none routes the LFO to pitch / pulse width; 2 = patch-uniform with such a
-// routing (needs the f64 LFO path).  The three kernels are launched over the whole grid on
-// forked streams; a workgroup exits at once if it is not the kernel's kind.
-enum : uint8_t { WG_GENERIC = 0, WG_UNIFORM = 1, WG_UNIFORM_F64 = 2 };
+// Per-lane form: any mix of patches inside a wave (exec-masked branches).  Used for banks
+// whose patches are interleaved lane by lane.
 template <bool FUSED>
 __global__ __launch_bounds__(kThreads) void welsh_render_kernel(
     const uint32_t* __restrict__ params, uint32_t* __restrict__ state, uint32_t n, uint32_t frames,
-    size_t ch_stride, float* __restrict__ out, RenderConsts rc, const uint8_t* __restrict__ wg_kind) {
-  if (wg_kind && wg_kind[blockIdx.x] != WG_GENERIC) return;
-  __builtin_amdgcn_s_setprio(3); // long-latency stragglers: win issue arbitration against the short kind
+    size_t ch_stride, float* __restrict__ out, RenderConsts rc) {
   const uint32_t v0 = blockIdx.x * kThreads + threadIdx.x;
   const bool active = v0 < n;
   const uint32_t v = active ? v0 : n - 1; // tail lanes shadow the last voice and store nothing
@@ -231,25 +226,36 @@ __global__ __launch_bounds__(kThreads) void welsh_render_kernel(
   welsh_block<FUSED, true>(p, s, rc, frames, n, v, active, ch_stride, out);
   if (active) soa_store(state, n, v, s);
 }
-// Wave-uniform form: every 64-lane group shares one patch (the host checks this when the
-// bank is derived), so the parameters are fetched with scalar loads from a per-wave table
-// and live in SGPRs; waveform / routing dispatch is scalar branching.
+// Wave-uniform form.  The host cuts the bank into VIRTUAL WAVES: maximal runs of consecutive
+// voices that share one patch, at most 64 long (a 64-lane group that straddles two patches
+// becomes two partly filled waves).  Each wavefront of the launch takes one descriptor with
+// scalar loads — patch parameters land in SGPRs, waveform / routing dispatch is scalar
+// branching — and works on voices [vbase, vbase + count).  wg_kind[workgroup] tells which of
+// the two register budgets the workgroup needs: WG_UNIFORM, or WG_UNIFORM_F64 when one of its
+// waves routes the LFO to pitch / pulse width (f64 LFO path); both kernels are launched over
+// the whole grid on forked streams and a workgroup exits at once if it is the other's kind.
+struct WaveDesc {
+  WelshParams p;
+  uint32_t vbase, count;
+};
+enum : uint8_t { WG_UNIFORM = 1, WG_UNIFORM_F64 = 2 };
 template <bool FUSED, bool F64LFO>
 __global__ __launch_bounds__(kThreads, F64LFO ? GROOVE_WAVES_F64 : GROOVE_WAVES_SIMPLE) void welsh_render_uniform_kernel(
-    const WelshParams* __restrict__ wave_params, uint32_t* __restrict__ state, uint32_t n, uint32_t frames,
+    const WaveDesc* __restrict__ waves, uint32_t n_waves, uint32_t* __restrict__ state, uint32_t n, uint32_t frames,
     size_t ch_stride, float* __restrict__ out, RenderConsts rc, const uint8_t* __restrict__ wg_kind) {
   if (wg_kind[blockIdx.x] != (F64LFO ? WG_UNIFORM_F64 : WG_UNIFORM)) return;
   // The f64-LFO kind is ~2x the work per voice and the critical path of a block: its waves get
   // issue priority over co-resident waves of the short kind (list scheduling, longest first).
   if (F64LFO) __builtin_amdgcn_s_setprio(2);
-  const uint32_t v0 = blockIdx.x * kThreads + threadIdx.x;
-  const bool active = v0 < n;
-  const uint32_t v = active ? v0 : n - 1;
-  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(v0 >> 6));
-  const WelshParams p = make_scalar(wave_params[wave]);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t w0 = blockIdx.x * kWaves + (threadIdx.x >> 6);
+  const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(w0, n_waves - 1));
+  const WaveDesc d = make_scalar(waves[w]);
+  const bool active = (w0 < n_waves) && (lane < d.count);
+  const uint32_t v = active ? d.vbase + lane : d.vbase; // idle lanes shadow the run's first voice
   WelshState s = soa_load<WelshState>(state, n, v);
-  if (welsh_retunes(p)) welsh_block<FUSED, true, F64LFO>(p, s, rc, frames, n, v, active, ch_stride, out);
-  else welsh_block<FUSED, false, F64LFO>(p, s, rc, frames, n, v, active, ch_stride, out);
+  if (welsh_retunes(d.p)) welsh_block<FUSED, true, F64LFO>(d.p, s, rc, frames, n, v, active, ch_stride, out);
+  else welsh_block<FUSED, false, F64LFO>(d.p, s, rc, frames, n, v, active, ch_stride, out);
   if (active) soa_store(state, n, v, s);
 }
 
