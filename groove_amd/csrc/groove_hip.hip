@@ -727,7 +727,7 @@ int groove_bank_render_mix(groove_bank* b, uint32_t frames, float* bus_dev, int 
   if (flush_events(b)) return 1;
   const uint32_t rows = (b->kind == BANK_WELSH && b->n_vwaves) ? (b->n_vwaves + kWaves - 1) / kWaves : blocks_for(b->n);
   const uint32_t cols = 2 * frames;
-  const uint32_t rows_per_seg = 32;
+  const uint32_t rows_per_seg = 64;
   const uint32_t segs = (rows + rows_per_seg - 1) / rows_per_seg;
   if (ctx->fpart_cap < (size_t)rows * cols) {
     if (ctx->d_fpart) GHIP(ctx, hipFree(ctx->d_fpart));
