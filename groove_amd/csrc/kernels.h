@@ -46,10 +46,10 @@ __device__ __forceinline__ void soa_store(uint32_t* __restrict__ buf, uint32_t n
 }
 
 #ifndef GROOVE_WAVES_SIMPLE
-#define GROOVE_WAVES_SIMPLE 5 /* waves per SIMD the uniform kernel is register-budgeted for */
+#define GROOVE_WAVES_SIMPLE 6 /* waves per SIMD the uniform kernel is register-budgeted for */
 #endif
 #ifndef GROOVE_WAVES_F64
-#define GROOVE_WAVES_F64 3
+#define GROOVE_WAVES_F64 2
 #endif
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
