@@ -155,14 +155,27 @@ def cpu_baseline(workload, seconds_target=15.0):
     else:
         bank = O.Bank.welsh(P.welsh_voices(sample_voices))
         bank.note_events(P.note_on_all(sample_voices))
+    chain = []
+    if WORKLOADS[workload]["kind"] == "chain":  # config #3: the per-voice effect chain is part of the path
+        chain = [O.Fx(k, p) for k, p in P.chain_fx_params(sample_voices)]
+
+    def one_block():
+        if chain:
+            blk = bank.render(FRAMES)
+            for fx in chain:
+                fx.process(blk)
+            O.mix(blk)
+        else:
+            bank.render_bus(FRAMES)
+
     # calibrate, then run ~seconds_target of CPU work
     t0 = time.perf_counter()
-    bank.render_bus(FRAMES)
+    one_block()
     dt = max(time.perf_counter() - t0, 1e-6)
     blocks = int(max(4, min(4096, seconds_target / dt)))
     t0 = time.perf_counter()
     for _ in range(blocks):
-        bank.render_bus(FRAMES)
+        one_block()
     el = time.perf_counter() - t0
     vf_per_s = sample_voices * FRAMES * blocks / el
     out = {
@@ -172,7 +185,7 @@ def cpu_baseline(workload, seconds_target=15.0):
     }
     # mode B: all host cores, on a sample large enough to keep every thread busy
     cores = int(L.oracle_hardware_concurrency()) or 1
-    if kind != "sampler":
+    if kind != "sampler" and not chain:
         mt_voices = min(V, 64 * cores)
         mbank = O.Bank.welsh(P.welsh_voices(mt_voices))
         mbank.note_events(P.note_on_all(mt_voices))
