@@ -223,6 +223,7 @@ class Orchestrator {
   const std::string& last_error() const { return err_; }
   uint32_t sample_rate() const { return sr_; }
   double bpm() const { return bpm_; }
+  void set_bpm(double bpm) { bpm_ = bpm; } // Clock::set_bpm (orchestrator.rs:888-890)
   int update_sample_rate(uint32_t hz);
 
   // Orchestrator::add (orchestrator.rs:136-142): takes ownership, returns the Uid.

@@ -183,3 +183,35 @@ def test_drumkit_render_to_wav(orch, tmp_path, oracle):
     assert n_bytes == (165375 - 165375 % 256) * 4        # run_performance drops the partial block
     pcm16 = np.frombuffer(raw[44:], dtype="<i2").reshape(-1, 2)
     assert np.abs(pcm16).max() > 1000 and (pcm16[:, 0] == pcm16[:, 1]).all()   # mono kit duplicated L = R
+
+
+def test_cli_renders_synthetic_config1_project(tmp_path):
+    """groove-cli-hip --wav on the committed synthetic config-#1 project (drumkit → 24 dB low-pass
+    with an exponential cutoff trip), synthetic sample bank: 16-bit stereo WAV of the expected length,
+    non-silent, and the rising cutoff lets progressively more high-frequency energy through."""
+    import os
+    import shutil
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(repo, "groove_amd", "host", "groove-cli-hip")
+    proj = tmp_path / "drums.json5"
+    shutil.copy(os.path.join(repo, "tests", "data", "drums-filtered-synthetic.json5"), proj)
+    r = subprocess.run([cli, "--wav", "--synthetic-kit", "--perf", str(proj)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "x real time" in r.stdout
+    raw = (tmp_path / "drums.wav").read_bytes()
+    fmt, ch, sr, _, _, bits = struct.unpack("<HHIIHH", raw[20:36])
+    assert (fmt, ch, sr, bits) == (1, 2, 44100, 16)
+    pcm = np.frombuffer(raw[44:], dtype="<i2").reshape(-1, 2).astype(np.float64)
+    assert len(pcm) == 165375 - 165375 % 256
+    assert np.abs(pcm).max() > 500
+    # high-band (> 4 kHz) share of the energy in the first vs the last quarter of the render
+    def hi_share(x):
+        spec = np.abs(np.fft.rfft(x[:, 0])) ** 2
+        k = int(4000 / 44100 * len(x))
+        return spec[k:].sum() / max(spec.sum(), 1e-30)
+    q = len(pcm) // 4
+    assert hi_share(pcm[-q:]) > 5 * hi_share(pcm[:q])
+    # unknown input → non-zero exit and a message, never an abort
+    r = subprocess.run([cli, str(tmp_path / "missing.json5")], capture_output=True, text=True)
+    assert r.returncode != 0 and "couldn't read" in r.stderr
