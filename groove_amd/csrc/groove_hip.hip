@@ -156,8 +156,12 @@ int welsh_upload_params(groove_bank* b) {
   }
   const uint32_t phys_waves = (n + 63) / 64;
   b->wgs_of_kind[0] = b->wgs_of_kind[1] = b->wgs_of_kind[2] = 0;
-  if (W.size() > (size_t)phys_waves + phys_waves / 2 + 8) {
-    b->n_vwaves = 0; // patches interleaved lane by lane: the per-lane kernel serves the whole bank
+  // Use the scalar-parameter kernels when the runs are long (at most 1.5x as many virtual waves as
+  // physical ones), or when the bank is so small that even one short run per wave leaves the machine
+  // (1,024 SIMDs) under-filled: there a partly filled fast wave beats a full slow one.  Otherwise the
+  // patches are interleaved lane by lane and the per-lane kernel serves the whole bank.
+  if (W.size() > (size_t)phys_waves + phys_waves / 2 + 8 && W.size() > 2048) {
+    b->n_vwaves = 0;
     return 0;
   }
   b->n_vwaves = (uint32_t)W.size();
