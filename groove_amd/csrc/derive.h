@@ -149,6 +149,53 @@ inline void rbj_highpass_h(double f0, double q, double fs, double* c5) {
   c5[0] = (1.0 + cw) / 2.0 / a0; c5[1] = -(1.0 + cw) / a0; c5[2] = (1.0 + cw) / 2.0 / a0;
   c5[3] = -2.0 * cw / a0; c5[4] = (1.0 - alpha) / a0;
 }
+// The remaining cookbook modes (doc/Audio-EQ-Cookbook.txt:113-198); parameter conventions: DSP_SPEC §4.
+inline double bw_octaves_h(double f0, double bw_hz) {
+  const double lo = f0 - 0.5 * bw_hz, hi = f0 + 0.5 * bw_hz;
+  if (!(lo > 0.0) || hi / lo > 256.0) return 8.0;
+  return log2(hi / lo);
+}
+inline void rbj_norm_h(double b0, double b1, double b2, double a0, double a1, double a2, double* c5) {
+  c5[0] = b0 / a0; c5[1] = b1 / a0; c5[2] = b2 / a0; c5[3] = a1 / a0; c5[4] = a2 / a0;
+}
+// Coefficients of any BiQuad 12 dB effect kind; false when `kind` is not one.
+inline bool rbj_for_kind_h(uint32_t kind, const groove_fx_params& p, double fs, double* c5) {
+  const double pi = 3.14159265358979323846;
+  const double f0 = p.cutoff_hz, w0 = 2.0 * pi * f0 / fs, cw = cos(w0), sw = sin(w0);
+  switch (kind) {
+    case GROOVE_FX_BIQUAD_LP12: rbj_lowpass_h(f0, p.q, fs, c5); return true;
+    case GROOVE_FX_BIQUAD_HP12: rbj_highpass_h(f0, p.q, fs, c5); return true;
+    case GROOVE_FX_BIQUAD_BP12: {
+      const double al = sw * sinh(log(2.0) / 2.0 * bw_octaves_h(f0, p.bandwidth_hz) * w0 / sw);
+      rbj_norm_h(al, 0.0, -al, 1.0 + al, -2.0 * cw, 1.0 - al, c5); return true;
+    }
+    case GROOVE_FX_BIQUAD_BS12: {
+      const double al = sw * sinh(log(2.0) / 2.0 * bw_octaves_h(f0, p.bandwidth_hz) * w0 / sw);
+      rbj_norm_h(1.0, -2.0 * cw, 1.0, 1.0 + al, -2.0 * cw, 1.0 - al, c5); return true;
+    }
+    case GROOVE_FX_BIQUAD_AP12: {
+      const double al = sw / (2.0 * p.q);
+      rbj_norm_h(1.0 - al, -2.0 * cw, 1.0 + al, 1.0 + al, -2.0 * cw, 1.0 - al, c5); return true;
+    }
+    case GROOVE_FX_BIQUAD_PEAK12: {
+      const double A = pow(10.0, p.db_gain / 40.0), al = sw / (2.0 * 0.70710678118654752440);
+      rbj_norm_h(1.0 + al * A, -2.0 * cw, 1.0 - al * A, 1.0 + al / A, -2.0 * cw, 1.0 - al / A, c5); return true;
+    }
+    case GROOVE_FX_BIQUAD_LSHELF12: {
+      const double A = pow(10.0, p.db_gain / 40.0), t = 2.0 * sqrt(A) * (sw / 2.0 * sqrt(2.0));
+      rbj_norm_h(A * ((A + 1) - (A - 1) * cw + t), 2 * A * ((A - 1) - (A + 1) * cw), A * ((A + 1) - (A - 1) * cw - t),
+                 (A + 1) + (A - 1) * cw + t, -2 * ((A - 1) + (A + 1) * cw), (A + 1) + (A - 1) * cw - t, c5);
+      return true;
+    }
+    case GROOVE_FX_BIQUAD_HSHELF12: {
+      const double A = pow(10.0, p.db_gain / 40.0), t = 2.0 * sqrt(A) * (sw / 2.0 * sqrt(2.0));
+      rbj_norm_h(A * ((A + 1) + (A - 1) * cw + t), -2 * A * ((A - 1) + (A + 1) * cw), A * ((A + 1) + (A - 1) * cw - t),
+                 (A + 1) - (A - 1) * cw + t, 2 * ((A - 1) - (A + 1) * cw), (A + 1) - (A - 1) * cw - t, c5);
+      return true;
+    }
+    default: return false;
+  }
+}
 // out6 = b0,a1,a2 (section 1), b0,a1,a2 (section 2); y = b0 x + 2 b0 x1 + b0 x2 + a1 y1 + a2 y2
 inline void lp24_coeffs_h(double fc, double ripple, double fs, double* out6) {
   if (fc > 0.49 * fs) fc = 0.49 * fs;

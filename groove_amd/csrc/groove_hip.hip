@@ -338,12 +338,12 @@ int fx_upload_params(groove_fx* fx) {
   GHIP(ctx, hipMemcpy(fx->d_fb, fb.data(), n * 4, hipMemcpyHostToDevice));
   GHIP(ctx, hipMemcpy(fx->d_ua, ua.data(), n * 4, hipMemcpyHostToDevice));
   GHIP(ctx, hipMemcpy(fx->d_wet, wet.data(), n * 4, hipMemcpyHostToDevice));
-  if (fx->kind == GROOVE_FX_BIQUAD_LP12 || fx->kind == GROOVE_FX_BIQUAD_HP12) {
+  double probe[5];
+  if (rbj_for_kind_h(fx->kind, fx->p[0], sr, probe)) { // any BiQuad 12 dB mode
     std::vector<double> c((size_t)5 * n);
     for (uint32_t i = 0; i < n; ++i) {
       double c5[5];
-      if (fx->kind == GROOVE_FX_BIQUAD_LP12) rbj_lowpass_h(fx->p[i].cutoff_hz, fx->p[i].q, sr, c5);
-      else rbj_highpass_h(fx->p[i].cutoff_hz, fx->p[i].q, sr, c5);
+      rbj_for_kind_h(fx->kind, fx->p[i], sr, c5);
       for (int k = 0; k < 5; ++k) c[(size_t)k * n + i] = c5[k];
     }
     GHIP(ctx, hipMemcpy(fx->d_coef, c.data(), c.size() * 8, hipMemcpyHostToDevice));
@@ -371,6 +371,12 @@ int fx_setup_state(groove_fx* fx) { // (re)allocate and zero state for the curre
   switch (fx->kind) {
     case GROOVE_FX_BIQUAD_LP12:
     case GROOVE_FX_BIQUAD_HP12:
+    case GROOVE_FX_BIQUAD_BP12:
+    case GROOVE_FX_BIQUAD_BS12:
+    case GROOVE_FX_BIQUAD_AP12:
+    case GROOVE_FX_BIQUAD_PEAK12:
+    case GROOVE_FX_BIQUAD_LSHELF12:
+    case GROOVE_FX_BIQUAD_HSHELF12:
     case GROOVE_FX_BIQUAD_LP24:
       GHIP(ctx, hipMalloc(&fx->d_st, 4 * ln * 8));
       GHIP(ctx, hipMemset(fx->d_st, 0, 4 * ln * 8));
@@ -765,7 +771,7 @@ int groove_bank_download_state(groove_bank* b, uint32_t* host_words) {
 int groove_fx_create(groove_ctx* ctx, uint32_t kind, const groove_fx_params* p, uint32_t n, groove_fx** out) {
   if (!ctx || !p || !out) return fail(ctx, "groove_fx_create: NULL argument");
   if (n == 0) return fail(ctx, "groove_fx_create: n == 0");
-  if (kind > GROOVE_FX_COMPRESSOR) return fail(ctx, "groove_fx_create: unknown effect kind");
+  if (kind >= GROOVE_FX_KIND_COUNT) return fail(ctx, "groove_fx_create: unknown effect kind");
   GHIP(ctx, hipSetDevice(ctx->device));
   groove_fx* fx = new groove_fx();
   fx->ctx = ctx; fx->kind = kind; fx->n = n;
@@ -817,6 +823,12 @@ int groove_fx_process(groove_fx* fx, groove_block* io, uint32_t frames) {
     }
     case GROOVE_FX_BIQUAD_LP12:
     case GROOVE_FX_BIQUAD_HP12:
+    case GROOVE_FX_BIQUAD_BP12:
+    case GROOVE_FX_BIQUAD_BS12:
+    case GROOVE_FX_BIQUAD_AP12:
+    case GROOVE_FX_BIQUAD_PEAK12:
+    case GROOVE_FX_BIQUAD_LSHELF12:
+    case GROOVE_FX_BIQUAD_HSHELF12:
       hipLaunchKernelGGL(fx_biquad_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       break;
     case GROOVE_FX_BIQUAD_LP24:

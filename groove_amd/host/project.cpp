@@ -159,6 +159,7 @@ void parse_effect(const std::string& kind, const json5::Value& v, ProjectDesc::D
   groove_fx_params& f = d.fx;
   f.ceiling = 1.0f; f.bits = 8; f.cutoff_hz = 1000.0f; f.q = 0.707f; f.passband_ripple = 0.707f; f.voices = 4;
   f.delay_seconds = 0.25f; f.attenuation = 0.5f; f.reverb_seconds = 1.0f; f.wet = 1.0f; f.limit_min = 0.0f; f.limit_max = 1.0f;
+  f.bandwidth_hz = 500.0f; f.db_gain = 0.0f;
   d.is_effect = true;
   if (kind == "gain") { d.fx_kind = GROOVE_FX_GAIN; f.ceiling = (float)v.number_or("ceiling", 1.0); }
   else if (kind == "mixer") d.fx_kind = GROOVE_FX_MIXER;
@@ -173,6 +174,12 @@ void parse_effect(const std::string& kind, const json5::Value& v, ProjectDesc::D
   else if (kind == "reverb") { d.fx_kind = GROOVE_FX_REVERB; f.attenuation = (float)v.number_or("attenuation", 0.5); f.reverb_seconds = (float)v.number_or("seconds", 1.0); }
   else if (kind == "filter-low-pass-12db") { d.fx_kind = GROOVE_FX_BIQUAD_LP12; f.cutoff_hz = (float)v.number_or("cutoff", 1000); f.q = (float)v.number_or("q", 0.707); }
   else if (kind == "filter-high-pass-12db") { d.fx_kind = GROOVE_FX_BIQUAD_HP12; f.cutoff_hz = (float)v.number_or("cutoff", 1000); f.q = (float)v.number_or("q", 0.707); }
+  else if (kind == "filter-band-pass-12db") { d.fx_kind = GROOVE_FX_BIQUAD_BP12; f.cutoff_hz = (float)v.number_or("cutoff", 1000); f.bandwidth_hz = (float)v.number_or("bandwidth", 500); }
+  else if (kind == "filter-band-stop-12db") { d.fx_kind = GROOVE_FX_BIQUAD_BS12; f.cutoff_hz = (float)v.number_or("cutoff", 1000); f.bandwidth_hz = (float)v.number_or("bandwidth", 500); }
+  else if (kind == "filter-all-pass-12db") { d.fx_kind = GROOVE_FX_BIQUAD_AP12; f.cutoff_hz = (float)v.number_or("cutoff", 1000); f.q = (float)v.number_or("q", 0.707); }
+  else if (kind == "filter-peaking-eq-12db") { d.fx_kind = GROOVE_FX_BIQUAD_PEAK12; f.cutoff_hz = (float)v.number_or("cutoff", 1000); f.db_gain = (float)v.number_or("db-gain", 0); }
+  else if (kind == "filter-low-shelf-12db") { d.fx_kind = GROOVE_FX_BIQUAD_LSHELF12; f.cutoff_hz = (float)v.number_or("cutoff", 1000); f.db_gain = (float)v.number_or("db-gain", 0); }
+  else if (kind == "filter-high-shelf-12db") { d.fx_kind = GROOVE_FX_BIQUAD_HSHELF12; f.cutoff_hz = (float)v.number_or("cutoff", 1000); f.db_gain = (float)v.number_or("db-gain", 0); }
   else if (kind == "filter-low-pass-24db") { d.fx_kind = GROOVE_FX_BIQUAD_LP24; f.cutoff_hz = (float)v.number_or("cutoff", 1000); f.passband_ripple = (float)v.number_or("passband-ripple", 0.707); }
   else {
     d.fx_kind = GROOVE_FX_MIXER;

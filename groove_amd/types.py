@@ -16,7 +16,8 @@ WAVE_NONE, WAVE_SINE, WAVE_SQUARE, WAVE_PULSE_WIDTH, WAVE_TRIANGLE, WAVE_SAWTOOT
 LFO_NONE, LFO_AMPLITUDE, LFO_PITCH, LFO_PULSE_WIDTH, LFO_FILTER_CUTOFF = range(5)
 # groove_fx_kind
 FX_GAIN, FX_BITCRUSHER, FX_BIQUAD_LP12, FX_BIQUAD_LP24, FX_CHORUS, FX_DELAY, FX_REVERB, FX_MIXER, \
-    FX_BIQUAD_HP12, FX_LIMITER, FX_COMPRESSOR = range(11)
+    FX_BIQUAD_HP12, FX_LIMITER, FX_COMPRESSOR, FX_BIQUAD_BP12, FX_BIQUAD_BS12, FX_BIQUAD_AP12, FX_BIQUAD_PEAK12, \
+    FX_BIQUAD_LSHELF12, FX_BIQUAD_HSHELF12 = range(17)
 # groove_control_index
 CTL_FX_CEILING, CTL_FX_BITS, CTL_FX_CUTOFF, CTL_FX_Q, CTL_FX_PASSBAND_RIPPLE, CTL_FX_ATTENUATION, CTL_FX_WET = range(7)
 CTL_WELSH_DCA_GAIN, CTL_WELSH_DCA_PAN, CTL_WELSH_CUTOFF = 32, 33, 34
@@ -68,14 +69,15 @@ class FxParams(C.Structure):
         ("ceiling", C.c_float), ("bits", C.c_uint32), ("cutoff_hz", C.c_float), ("q", C.c_float),
         ("passband_ripple", C.c_float), ("voices", C.c_uint32), ("delay_seconds", C.c_float),
         ("attenuation", C.c_float), ("reverb_seconds", C.c_float), ("wet", C.c_float),
-        ("limit_min", C.c_float), ("limit_max", C.c_float),
+        ("limit_min", C.c_float), ("limit_max", C.c_float), ("bandwidth_hz", C.c_float), ("db_gain", C.c_float),
     ]
 
 
 def fx_params(**kw):
     """FxParams with the reference defaults (wet-dry-mix fully wet, gain ceiling 1)."""
     p = FxParams(ceiling=1.0, bits=8, cutoff_hz=1000.0, q=0.707, passband_ripple=0.707, voices=4,
-                 delay_seconds=0.25, attenuation=0.95, reverb_seconds=1.25, wet=1.0, limit_min=0.0, limit_max=1.0)
+                 delay_seconds=0.25, attenuation=0.95, reverb_seconds=1.25, wet=1.0, limit_min=0.0, limit_max=1.0,
+                 bandwidth_hz=500.0, db_gain=6.0)
     for k, v in kw.items():
         setattr(p, k, v)
     return p

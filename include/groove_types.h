@@ -132,8 +132,15 @@ typedef enum {
   GROOVE_FX_MIXER = 7,       /* Mixer (identity; orchestrator.rs:543-546)       */
   GROOVE_FX_BIQUAD_HP12 = 8, /* filter-high-pass-12db{cutoff, q}                */
   GROOVE_FX_LIMITER = 9,     /* Limiter{min, max}                               */
-  GROOVE_FX_COMPRESSOR = 10  /* Compressor{threshold, ratio}                    */
+  GROOVE_FX_COMPRESSOR = 10, /* Compressor{threshold, ratio}                    */
+  GROOVE_FX_BIQUAD_BP12 = 11,     /* filter-band-pass-12db{cutoff, bandwidth}    */
+  GROOVE_FX_BIQUAD_BS12 = 12,     /* filter-band-stop-12db{cutoff, bandwidth}    */
+  GROOVE_FX_BIQUAD_AP12 = 13,     /* filter-all-pass-12db{cutoff, q}             */
+  GROOVE_FX_BIQUAD_PEAK12 = 14,   /* filter-peaking-eq-12db{cutoff, db-gain}     */
+  GROOVE_FX_BIQUAD_LSHELF12 = 15, /* filter-low-shelf-12db{cutoff, db-gain}      */
+  GROOVE_FX_BIQUAD_HSHELF12 = 16  /* filter-high-shelf-12db{cutoff, db-gain}     */
 } groove_fx_kind;
+#define GROOVE_FX_KIND_COUNT 17
 
 /* Per-lane effect parameters.  One struct for every kind keeps the ABI flat;
  * unused fields are ignored.  Structural fields (marked UNIFORM) must be equal
@@ -152,6 +159,8 @@ typedef struct {
   float wet;             /* wet-dry-mix, 1.0 = fully wet (reference default) */
   float limit_min;       /* Limiter / Compressor threshold                   */
   float limit_max;       /* Limiter max / Compressor ratio                   */
+  float bandwidth_hz;    /* BiQuad band-pass / band-stop: -3 dB bandwidth in Hz */
+  float db_gain;         /* BiQuad peaking / shelves: gain in dB              */
 } groove_fx_params;
 
 /* Controllable indices for groove_bank_set_param / groove_fx_set_param

@@ -45,6 +45,7 @@ def _bind(lib):
         "oracle_wav_quantise": (i, [d]), "oracle_bitcrush_f32": (C.c_float, [C.c_float, u32]),
         "oracle_dca": (None, [d, d, d, _dp]),
         "oracle_rbj_lowpass": (None, [d, d, d, _dp]), "oracle_rbj_highpass": (None, [d, d, d, _dp]),
+        "oracle_rbj_for_kind": (i, [u32, C.POINTER(T.FxParams), d, _dp]),
         "oracle_lp24_coeffs": (None, [d, d, d, _dp]), "oracle_lp24_run": (None, [d, d, d, _dp, _dp, u32]),
         "oracle_biquad_df1_run": (None, [_dp, _dp, _dp, u32]),
         "oracle_oscillator_run": (None, [C.POINTER(T.OscillatorParams), d, d, _dp, _dp, u32, C.POINTER(u32)]),

@@ -82,6 +82,13 @@ void oracle_rbj_highpass(double f0, double q, double fs, double* out) {
   BiquadCoeffs c = rbj_highpass(f0, q, fs);
   out[0] = c.b0; out[1] = c.b1; out[2] = c.b2; out[3] = c.a1; out[4] = c.a2;
 }
+// any BiQuad 12 dB kind: out[5] = b0,b1,b2,a1,a2; returns 0 when `kind` is not a biquad
+int oracle_rbj_for_kind(uint32_t kind, const groove_fx_params* p, double fs, double* out) {
+  BiquadCoeffs c;
+  if (!rbj_for_kind(kind, *p, fs, c)) return 0;
+  out[0] = c.b0; out[1] = c.b1; out[2] = c.b2; out[3] = c.a1; out[4] = c.a2;
+  return 1;
+}
 // out[6] = b0,a1,a2 of section 1 then section 2
 void oracle_lp24_coeffs(double fc, double ripple, double fs, double* out) {
   Lp24Coeffs c = lp24_coeffs(fc, ripple, fs);

@@ -218,6 +218,64 @@ inline BiquadCoeffs rbj_highpass(double f0, double q, double fs) {
   return {(1.0 + cw) / 2.0 / a0, -(1.0 + cw) / a0, (1.0 + cw) / 2.0 / a0, -2.0 * cw / a0,
           (1.0 - alpha) / a0};
 }
+// The remaining cookbook modes (doc/Audio-EQ-Cookbook.txt:113-198).  Parameter conventions of the
+// project files (projects/demos/effects/filter-*-12db_*.json): band-pass / band-stop carry a
+// `bandwidth` in Hz, converted to the cookbook's BW in octaves between the -3 dB frequencies,
+// BW = log2((f0 + bw/2) / (f0 - bw/2)) (capped at 8 octaves when bw >= 2 f0); peaking and shelves
+// carry `db-gain`; peaking uses Q = 1/sqrt(2), shelves use slope S = 1.  [conventions unpinned,
+// coefficient formulas pinned]
+inline double bw_octaves(double f0, double bw_hz) {
+  const double lo = f0 - 0.5 * bw_hz, hi = f0 + 0.5 * bw_hz;
+  if (!(lo > 0.0) || hi / lo > 256.0) return 8.0;
+  return std::log2(hi / lo);
+}
+inline BiquadCoeffs rbj_normalise(double b0, double b1, double b2, double a0, double a1, double a2) {
+  return {b0 / a0, b1 / a0, b2 / a0, a1 / a0, a2 / a0};
+}
+inline BiquadCoeffs rbj_bandpass(double f0, double bw_hz, double fs) { // constant 0 dB peak gain
+  double w0 = 2.0 * kPi * f0 / fs, cw = std::cos(w0), sw = std::sin(w0);
+  double alpha = sw * std::sinh(std::log(2.0) / 2.0 * bw_octaves(f0, bw_hz) * w0 / sw);
+  return rbj_normalise(alpha, 0.0, -alpha, 1.0 + alpha, -2.0 * cw, 1.0 - alpha);
+}
+inline BiquadCoeffs rbj_bandstop(double f0, double bw_hz, double fs) {
+  double w0 = 2.0 * kPi * f0 / fs, cw = std::cos(w0), sw = std::sin(w0);
+  double alpha = sw * std::sinh(std::log(2.0) / 2.0 * bw_octaves(f0, bw_hz) * w0 / sw);
+  return rbj_normalise(1.0, -2.0 * cw, 1.0, 1.0 + alpha, -2.0 * cw, 1.0 - alpha);
+}
+inline BiquadCoeffs rbj_allpass(double f0, double q, double fs) {
+  double w0 = 2.0 * kPi * f0 / fs, cw = std::cos(w0), sw = std::sin(w0), alpha = sw / (2.0 * q);
+  return rbj_normalise(1.0 - alpha, -2.0 * cw, 1.0 + alpha, 1.0 + alpha, -2.0 * cw, 1.0 - alpha);
+}
+inline BiquadCoeffs rbj_peaking(double f0, double db_gain, double fs) {
+  double A = std::pow(10.0, db_gain / 40.0), w0 = 2.0 * kPi * f0 / fs, cw = std::cos(w0), sw = std::sin(w0);
+  double alpha = sw / (2.0 * 0.70710678118654752440);
+  return rbj_normalise(1.0 + alpha * A, -2.0 * cw, 1.0 - alpha * A, 1.0 + alpha / A, -2.0 * cw, 1.0 - alpha / A);
+}
+inline BiquadCoeffs rbj_lowshelf(double f0, double db_gain, double fs) {
+  double A = std::pow(10.0, db_gain / 40.0), w0 = 2.0 * kPi * f0 / fs, cw = std::cos(w0), sw = std::sin(w0);
+  double alpha = sw / 2.0 * std::sqrt(2.0), t = 2.0 * std::sqrt(A) * alpha; // S = 1
+  return rbj_normalise(A * ((A + 1) - (A - 1) * cw + t), 2 * A * ((A - 1) - (A + 1) * cw), A * ((A + 1) - (A - 1) * cw - t),
+                       (A + 1) + (A - 1) * cw + t, -2 * ((A - 1) + (A + 1) * cw), (A + 1) + (A - 1) * cw - t);
+}
+inline BiquadCoeffs rbj_highshelf(double f0, double db_gain, double fs) {
+  double A = std::pow(10.0, db_gain / 40.0), w0 = 2.0 * kPi * f0 / fs, cw = std::cos(w0), sw = std::sin(w0);
+  double alpha = sw / 2.0 * std::sqrt(2.0), t = 2.0 * std::sqrt(A) * alpha;
+  return rbj_normalise(A * ((A + 1) + (A - 1) * cw + t), -2 * A * ((A - 1) + (A + 1) * cw), A * ((A + 1) + (A - 1) * cw - t),
+                       (A + 1) - (A - 1) * cw + t, 2 * ((A - 1) - (A + 1) * cw), (A + 1) - (A - 1) * cw - t);
+}
+inline bool rbj_for_kind(uint32_t kind, const groove_fx_params& p, double sr, BiquadCoeffs& out) {
+  switch (kind) {
+    case GROOVE_FX_BIQUAD_LP12: out = rbj_lowpass(p.cutoff_hz, p.q, sr); return true;
+    case GROOVE_FX_BIQUAD_HP12: out = rbj_highpass(p.cutoff_hz, p.q, sr); return true;
+    case GROOVE_FX_BIQUAD_BP12: out = rbj_bandpass(p.cutoff_hz, p.bandwidth_hz, sr); return true;
+    case GROOVE_FX_BIQUAD_BS12: out = rbj_bandstop(p.cutoff_hz, p.bandwidth_hz, sr); return true;
+    case GROOVE_FX_BIQUAD_AP12: out = rbj_allpass(p.cutoff_hz, p.q, sr); return true;
+    case GROOVE_FX_BIQUAD_PEAK12: out = rbj_peaking(p.cutoff_hz, p.db_gain, sr); return true;
+    case GROOVE_FX_BIQUAD_LSHELF12: out = rbj_lowshelf(p.cutoff_hz, p.db_gain, sr); return true;
+    case GROOVE_FX_BIQUAD_HSHELF12: out = rbj_highshelf(p.cutoff_hz, p.db_gain, sr); return true;
+    default: return false;
+  }
+}
 struct BiquadDF1 { // one channel
   double x1 = 0, x2 = 0, y1 = 0, y2 = 0;
   double step(const BiquadCoeffs& c, double x) {
@@ -527,8 +585,7 @@ struct Effect {
     }
   }
   void retune() {
-    if (kind == GROOVE_FX_BIQUAD_LP12) bq = rbj_lowpass(p.cutoff_hz, p.q, sr);
-    if (kind == GROOVE_FX_BIQUAD_HP12) bq = rbj_highpass(p.cutoff_hz, p.q, sr);
+    rbj_for_kind(kind, p, sr, bq);
     if (kind == GROOVE_FX_BIQUAD_LP24) l24 = lp24_coeffs(p.cutoff_hz, p.passband_ripple, sr);
     for (int c = 0; c < 2; ++c) reverb[c].attenuation = p.attenuation;
   }
@@ -537,7 +594,13 @@ struct Effect {
       case GROOVE_FX_GAIN: return gain_fx(x, p.ceiling);
       case GROOVE_FX_BITCRUSHER: return (double)bitcrush_f32((float)x, p.bits);
       case GROOVE_FX_BIQUAD_LP12:
-      case GROOVE_FX_BIQUAD_HP12: return df1[ch].step(bq, x);
+      case GROOVE_FX_BIQUAD_HP12:
+      case GROOVE_FX_BIQUAD_BP12:
+      case GROOVE_FX_BIQUAD_BS12:
+      case GROOVE_FX_BIQUAD_AP12:
+      case GROOVE_FX_BIQUAD_PEAK12:
+      case GROOVE_FX_BIQUAD_LSHELF12:
+      case GROOVE_FX_BIQUAD_HSHELF12: return df1[ch].step(bq, x);
       case GROOVE_FX_BIQUAD_LP24: return l24s[ch].step(l24, x);
       case GROOVE_FX_CHORUS: return chorus[ch].step(x);
       case GROOVE_FX_DELAY: return delay[ch].step(x);

@@ -76,6 +76,24 @@ def test_biquad_lp12_and_hp12(gpu_ctx, oracle):
         assert np.max(np.abs(got - want)) <= 2e-6
 
 
+def test_biquad_other_modes(gpu_ctx, oracle):
+    """Band-pass, band-stop, all-pass, peaking, low / high shelf (cookbook :113-198) — same kernel,
+    host-side f64 coefficients."""
+    n = 64
+    x = _audio(n, 2048)
+    cut = [200.0 + 120.0 * i for i in range(n)]
+    cases = [(T.FX_BIQUAD_BP12, dict(bandwidth_hz=[30.0 + 10 * i for i in range(n)])),
+             (T.FX_BIQUAD_BS12, dict(bandwidth_hz=[30.0 + 10 * i for i in range(n)])),
+             (T.FX_BIQUAD_AP12, dict(q=[0.707 + 0.3 * i for i in range(n)])),
+             (T.FX_BIQUAD_PEAK12, dict(db_gain=[-12.0 + 0.5 * i for i in range(n)])),
+             (T.FX_BIQUAD_LSHELF12, dict(db_gain=[-12.0 + 0.5 * i for i in range(n)])),
+             (T.FX_BIQUAD_HSHELF12, dict(db_gain=[-12.0 + 0.5 * i for i in range(n)]))]
+    for kind, kw in cases:
+        got, want = _run(gpu_ctx, oracle, kind, _params(n, cutoff_hz=cut, **kw), x)
+        assert np.max(np.abs(want)) > 0.05
+        assert np.max(np.abs(got - want)) <= 4e-6 * max(1.0, np.max(np.abs(want))), kind
+
+
 def test_lp24_effect(gpu_ctx, oracle):
     n = 96
     x = _audio(n, 2048)

@@ -185,3 +185,61 @@ def test_frames_per_beat(oracle):
     L = oracle.lib()
     for sr in (2000, 8000, 22050, 24000, 44100, 48000, 88200, 96000, 192000):
         assert L.oracle_performance_total_frames(1.0, 60.0, float(sr)) == sr
+
+
+# ---- doc/Audio-EQ-Cookbook.txt:113-198: the remaining biquad modes ------------------------------
+def _H(c, f, fs=44100.0):
+    b0, b1, b2, a1, a2 = c
+    z = np.exp(1j * 2 * np.pi * f / fs)
+    return (b0 + b1 / z + b2 / z ** 2) / (1 + a1 / z + a2 / z ** 2)
+
+
+def test_rbj_cookbook_other_modes(oracle):
+    import ctypes as C
+    L = oracle.lib()
+    out = (C.c_double * 5)()
+    fs, f0 = 44100.0, 1000.0
+    w0 = 2 * math.pi * f0 / fs
+    cw, sw = math.cos(w0), math.sin(w0)
+
+    def coef(kind, **kw):
+        p = T.fx_params(cutoff_hz=f0, **kw)
+        assert L.oracle_rbj_for_kind(kind, C.byref(p), fs, out) == 1
+        return list(out)
+
+    # band-pass (constant 0 dB peak gain), bandwidth given in Hz → octaves between the -3 dB points
+    bw_oct = math.log2((f0 + 150) / (f0 - 150))
+    alpha = sw * math.sinh(math.log(2) / 2 * bw_oct * w0 / sw)
+    c = coef(T.FX_BIQUAD_BP12, bandwidth_hz=300.0)
+    assert np.allclose(c, [alpha / (1 + alpha), 0.0, -alpha / (1 + alpha), -2 * cw / (1 + alpha), (1 - alpha) / (1 + alpha)], rtol=1e-12, atol=1e-15)
+    assert abs(abs(_H(c, f0)) - 1.0) < 1e-9 and abs(_H(c, 0.0)) < 1e-9
+    # band-stop (notch): zero at f0, unity at DC and Nyquist
+    c = coef(T.FX_BIQUAD_BS12, bandwidth_hz=300.0)
+    assert np.allclose(c, [1 / (1 + alpha), -2 * cw / (1 + alpha), 1 / (1 + alpha), -2 * cw / (1 + alpha), (1 - alpha) / (1 + alpha)], rtol=1e-12)
+    assert abs(_H(c, f0)) < 1e-9 and abs(abs(_H(c, 0.0)) - 1) < 1e-9 and abs(abs(_H(c, fs / 2)) - 1) < 1e-9
+    # all-pass: |H| = 1 everywhere
+    c = coef(T.FX_BIQUAD_AP12, q=0.707)
+    a = sw / (2 * 0.707)
+    a = sw / (2 * float(np.float32(0.707)))
+    assert np.allclose(c, [(1 - a) / (1 + a), -2 * cw / (1 + a), 1.0, -2 * cw / (1 + a), (1 - a) / (1 + a)], rtol=1e-12)
+    for f in (50.0, 1000.0, 9000.0):
+        assert abs(abs(_H(c, f)) - 1.0) < 1e-9
+    # peaking EQ: gain dBgain at f0, unity far away
+    c = coef(T.FX_BIQUAD_PEAK12, db_gain=6.0)
+    A = 10 ** (6.0 / 40)
+    a = sw / (2 * math.sqrt(0.5))
+    assert np.allclose(c, [(1 + a * A) / (1 + a / A), -2 * cw / (1 + a / A), (1 - a * A) / (1 + a / A), -2 * cw / (1 + a / A), (1 - a / A) / (1 + a / A)], rtol=1e-12)
+    assert abs(20 * math.log10(abs(_H(c, f0))) - 6.0) < 1e-9 and abs(abs(_H(c, 0.0)) - 1) < 1e-9
+    # shelves (S = 1): low shelf has gain A^2 at DC and 1 at Nyquist; high shelf the reverse
+    c = coef(T.FX_BIQUAD_LSHELF12, db_gain=6.0)
+    assert abs(20 * math.log10(abs(_H(c, 0.0))) - 6.0) < 1e-9 and abs(abs(_H(c, fs / 2)) - 1) < 1e-9
+    t = 2 * math.sqrt(A) * (sw / 2 * math.sqrt(2))
+    a0 = (A + 1) + (A - 1) * cw + t
+    assert abs(c[0] - A * ((A + 1) - (A - 1) * cw + t) / a0) < 1e-14 and abs(c[3] - (-2 * ((A - 1) + (A + 1) * cw)) / a0) < 1e-14
+    c = coef(T.FX_BIQUAD_HSHELF12, db_gain=6.0)
+    assert abs(20 * math.log10(abs(_H(c, fs / 2))) - 6.0) < 1e-9 and abs(abs(_H(c, 0.0)) - 1) < 1e-9
+    # a bandwidth wider than 2 f0 is capped (8 octaves) instead of producing NaN
+    c = coef(T.FX_BIQUAD_BP12, bandwidth_hz=2000.0)
+    assert np.isfinite(c).all()
+    p = T.fx_params()
+    assert L.oracle_rbj_for_kind(T.FX_GAIN, C.byref(p), fs, out) == 0

@@ -91,8 +91,10 @@ def test_json5_syntax_and_errors(host):
     with pytest.raises(RuntimeError, match="note-value"):
         describe(host, text='{"patterns":[{"id":"p","note-value":"seventh","notes":[[60]]}]}')
     # a one-ID patch cable is ignored with a warning (songs.rs:136-139); unknown effects pass through
-    d = describe(host, text='{"devices":[{"effect":["e",{"filter-band-pass-12db":{"cutoff":500,"bandwidth":1}}]}],"patch-cables":[["e"]]}')
+    d = describe(host, text='{"devices":[{"effect":["e",{"toy":{"my-value":0.5}}]}],"patch-cables":[["e"]]}')
     assert d["warnings"] == 2 and d["devices"][0]["fx_kind"] == T.FX_MIXER
+    d = describe(host, text='{"devices":[{"effect":["e",{"filter-band-pass-12db":{"cutoff":500,"bandwidth":30}}]}]}')
+    assert d["warnings"] == 0 and d["devices"][0]["fx_kind"] == T.FX_BIQUAD_BP12
     # patterns: default note value is a quarter; a 5-note row takes two 4/4 measures
     d = describe(host, text='{"patterns":[{"id":"p","notes":[[60,0,62,64,65]]}],"tracks":[{"id":"t","midi-channel":3,"patterns":["p","p"]}]}')
     assert d["n_notes"] == 8 and d["end_beats"] == 16.0
