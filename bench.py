@@ -30,7 +30,7 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-from groove_amd import entities as E, patches as P, types as T  # noqa: E402
+from groove_amd import entities as E, patches as P, abi_types as T  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FRAMES = T.BLOCK_FRAMES

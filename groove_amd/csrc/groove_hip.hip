@@ -474,21 +474,21 @@ int groove_init(int device_ordinal, groove_ctx** out) {
 }
 void groove_shutdown(groove_ctx* ctx) {
   if (!ctx) return;
-  hipSetDevice(ctx->device);
-  hipStreamSynchronize(ctx->stream);
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
   while (!ctx->banks.empty()) groove_bank_destroy(ctx->banks.back());
   while (!ctx->fxs.empty()) groove_fx_destroy(ctx->fxs.back());
   groove_comm_destroy(ctx);
-  if (ctx->d_partial) hipFree(ctx->d_partial);
-  if (ctx->d_fpart) hipFree(ctx->d_fpart);
-  if (ctx->d_fseg) hipFree(ctx->d_fseg);
-  if (ctx->d_i16) hipFree(ctx->d_i16);
-  if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+  if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+  if (ctx->d_fpart) (void)hipFree(ctx->d_fpart);
+  if (ctx->d_fseg) (void)hipFree(ctx->d_fseg);
+  if (ctx->d_i16) (void)hipFree(ctx->d_i16);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   for (int i = 0; i < 2; ++i) {
-    if (ctx->side_stream[i]) { hipStreamSynchronize(ctx->side_stream[i]); hipStreamDestroy(ctx->side_stream[i]); }
-    if (ctx->ev_join[i]) hipEventDestroy(ctx->ev_join[i]);
+    if (ctx->side_stream[i]) { (void)hipStreamSynchronize(ctx->side_stream[i]); (void)hipStreamDestroy(ctx->side_stream[i]); }
+    if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
   }
-  if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   delete ctx;
 }
 const char* groove_last_error(groove_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
@@ -552,14 +552,14 @@ int groove_block_create(groove_ctx* ctx, uint32_t n, uint32_t frames_cap, groove
   const size_t bytes = (size_t)2 * frames_cap * n * 4;
   hipError_t e = hipMalloc(&b->d, bytes);
   if (e != hipSuccess) { delete b; return fail(ctx, std::string("groove_block_create: hipMalloc: ") + hipGetErrorString(e)); }
-  hipMemsetAsync(b->d, 0, bytes, ctx->stream);
+  (void)hipMemsetAsync(b->d, 0, bytes, ctx->stream);
   *out = b;
   return 0;
 }
 int groove_block_destroy(groove_block* b) {
   if (!b) return 0;
-  hipStreamSynchronize(b->ctx->stream);
-  hipFree(b->d);
+  (void)hipStreamSynchronize(b->ctx->stream);
+  (void)hipFree(b->d);
   delete b;
   return 0;
 }
@@ -632,17 +632,17 @@ int groove_sampler_create(groove_ctx* ctx, const float* bank_pcm, uint64_t bank_
   b->sampler.assign(p, p + n);
   b->descs.assign(descs, descs + n_samples);
   if (hipMalloc(&b->d_pcm, bank_frames * 4) != hipSuccess) { delete b; return fail(ctx, "groove_sampler_create: hipMalloc failed"); }
-  if (hipMemcpy(b->d_pcm, bank_pcm, bank_frames * 4, hipMemcpyHostToDevice) != hipSuccess) { hipFree(b->d_pcm); delete b; return fail(ctx, "groove_sampler_create: upload failed"); }
+  if (hipMemcpy(b->d_pcm, bank_pcm, bank_frames * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(b->d_pcm); delete b; return fail(ctx, "groove_sampler_create: upload failed"); }
   return bank_finish_create(b, out);
 }
 int groove_bank_destroy(groove_bank* b) {
   if (!b) return 0;
   groove_ctx* ctx = b->ctx;
-  hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream);
   auto it = std::find(ctx->banks.begin(), ctx->banks.end(), b);
   if (it != ctx->banks.end()) ctx->banks.erase(it);
   if (b->scratch) groove_block_destroy(b->scratch);
-  hipFree(b->d_params); hipFree(b->d_state); hipFree(b->d_cold); hipFree(b->d_pcm); hipFree(b->d_ev); hipFree(b->d_waves); hipFree(b->d_wg_kind);
+  (void)hipFree(b->d_params); (void)hipFree(b->d_state); (void)hipFree(b->d_cold); (void)hipFree(b->d_pcm); (void)hipFree(b->d_ev); (void)hipFree(b->d_waves); (void)hipFree(b->d_wg_kind);
   delete b;
   return 0;
 }
@@ -791,11 +791,11 @@ int groove_fx_create(groove_ctx* ctx, uint32_t kind, const groove_fx_params* p, 
 int groove_fx_destroy(groove_fx* fx) {
   if (!fx) return 0;
   groove_ctx* ctx = fx->ctx;
-  hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream);
   auto it = std::find(ctx->fxs.begin(), ctx->fxs.end(), fx);
   if (it != ctx->fxs.end()) ctx->fxs.erase(it);
-  hipFree(fx->d_fa); hipFree(fx->d_fb); hipFree(fx->d_ua); hipFree(fx->d_wet);
-  hipFree(fx->d_coef); hipFree(fx->d_st); hipFree(fx->d_ring);
+  (void)hipFree(fx->d_fa); (void)hipFree(fx->d_fb); (void)hipFree(fx->d_ua); (void)hipFree(fx->d_wet);
+  (void)hipFree(fx->d_coef); (void)hipFree(fx->d_st); (void)hipFree(fx->d_ring);
   delete fx;
   return 0;
 }

@@ -368,13 +368,6 @@ __global__ void sampler_events_kernel(const groove_note_event* __restrict__ ev, 
   sampler_note(p, s, e.key, e.on != 0);
   soa_store(state, n, v, s);
 }
-// Controllable: set one 32-bit word of the SoA for one lane or all lanes.
-__global__ void set_word_kernel(uint32_t* __restrict__ buf, uint32_t n, uint32_t word, uint32_t lane, uint32_t value) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (lane == GROOVE_ALL_VOICES) { if (i < n) buf[(size_t)word * n + i] = value; }
-  else if (i == 0 && lane < n) buf[(size_t)word * n + lane] = value;
-}
-
 // ------------------------------------------------------------------ mix bus (a15)
 // Stage 1: grid (segments, rows) with rows = 2*frames; each workgroup sums one segment of
 // one row of the block (row = one channel of one frame across all lanes) → partial[row][seg].

@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 from . import lib as _lib
-from . import types as T
+from . import abi_types as T
 
 _fp = C.POINTER(C.c_float)
 

@@ -5,7 +5,7 @@ import os
 
 import numpy as np
 
-from . import types as T
+from . import abi_types as T
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_LIB = os.path.join(HERE, "host", "libgroove_host.so")

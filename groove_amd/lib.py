@@ -7,7 +7,7 @@ no fallback: if the shared object is missing, or the machine has no HIP device, 
 import ctypes as C
 import os
 
-from . import types as T
+from . import abi_types as T
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libgroove_hip.so")

@@ -11,7 +11,7 @@ import math
 
 import numpy as np
 
-from . import types as T
+from . import abi_types as T
 
 N_PATCHES = 32
 

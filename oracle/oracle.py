@@ -17,7 +17,7 @@ REPO = os.path.dirname(HERE)
 import sys
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
-from groove_amd import types as T  # noqa: E402  (shared POD layouts only; no product code paths)
+from groove_amd import abi_types as T  # noqa: E402  (shared POD layouts only; no product code paths)
 
 
 def build(native=False, ref=True):

@@ -3,7 +3,7 @@ import ctypes as C
 import os
 import subprocess
 import numpy as np
-from groove_amd import types as T
+from groove_amd import abi_types as T
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 _fp = C.POINTER(C.c_float)

@@ -15,7 +15,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-from groove_amd import patches as P, types as T  # noqa: E402
+from groove_amd import patches as P, abi_types as T  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 FRAMES, BLOCK = 1024, 256

@@ -44,7 +44,7 @@ def test_no_cpu_fallback_without_a_device():
 
 def test_param_struct_sizes_match_the_c_headers(tmp_path):
     """ctypes mirrors vs the C compiler's view of include/groove_types.h."""
-    from groove_amd import types as T
+    from groove_amd import abi_types as T
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "groove_types.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(groove_envelope_params),sizeof(groove_oscillator_params),sizeof(groove_welsh_params),'

@@ -4,7 +4,7 @@ kernels in the GPU-less tier; the GPU tier (tests/test_gpu_*.py) checks the kern
 Tolerance: per-voice RMS <= 1e-5, bus/V RMS <= 1e-6."""
 import numpy as np
 
-from groove_amd import patches as P, types as T
+from groove_amd import patches as P, abi_types as T
 from tests.emul import emul as E
 
 

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from groove_amd import patches as P, types as T
+from groove_amd import patches as P, abi_types as T
 from tests.golden import make_golden as G
 
 GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(G.__file__)), "golden_r01.npz"))

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from groove_amd import patches as P, types as T
+from groove_amd import patches as P, abi_types as T
 
 pytestmark = pytest.mark.gpu
 V = 1_000_000

@@ -7,7 +7,7 @@ max abs error <= 2e-6 relative to a unit-scale input (fp32 rings, f64 recurrence
 import numpy as np
 import pytest
 
-from groove_amd import patches as P, types as T
+from groove_amd import patches as P, abi_types as T
 
 pytestmark = pytest.mark.gpu
 

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from groove_amd import patches as P, types as T
+from groove_amd import patches as P, abi_types as T
 
 pytestmark = pytest.mark.gpu
 

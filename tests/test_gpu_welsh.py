@@ -8,7 +8,7 @@ Tolerances (fp32 device output vs f64 oracle):
 import numpy as np
 import pytest
 
-from groove_amd import patches as P, types as T
+from groove_amd import patches as P, abi_types as T
 
 pytestmark = pytest.mark.gpu
 

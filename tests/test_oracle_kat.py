@@ -5,7 +5,7 @@ import math
 import numpy as np
 import pytest
 
-from groove_amd import types as T
+from groove_amd import abi_types as T
 
 
 # ---- settings/src/patches.rs:754-796 oscillator_tuning_helpers --------------------------

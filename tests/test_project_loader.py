@@ -10,7 +10,7 @@ import os
 
 import pytest
 
-from groove_amd import types as T
+from groove_amd import abi_types as T
 from groove_amd.host_binding import HOST_LIB
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
