@@ -1,0 +1,92 @@
+"""GPU tier: error behaviour of the C ABI.  The reference's audio-path trait methods are infallible and
+its graph edits return anyhow::Result (orchestrator.rs:263-304); the library returns a non-zero status
+plus groove_last_error() and never aborts or falls back."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from groove_amd import abi_types as T, lib, patches as P
+
+pytestmark = pytest.mark.gpu
+
+
+def test_argument_validation(gpu_ctx):
+    from groove_amd import entities as E
+    L = gpu_ctx.L
+    params = P.welsh_voices(8)
+    s = E.WelshSynth(gpu_ctx, params)
+    small, big = gpu_ctx.block(4, 256), gpu_ctx.block(8, 64)
+    with pytest.raises(lib.GrooveError, match="lanes"):
+        s.generate_batch_values(small, 16)
+    with pytest.raises(lib.GrooveError, match="capacity"):
+        s.generate_batch_values(big, 65)
+    with pytest.raises(lib.GrooveError, match="out of range"):
+        s.handle_midi_events(T.note_events([(8, 60, True)]))
+    with pytest.raises(lib.GrooveError, match="unknown control"):
+        s.control_set_param_by_index(999, 0.5)
+    with pytest.raises(lib.GrooveError, match="voice out of range"):
+        s.control_set_param_by_index(T.CTL_WELSH_DCA_GAIN, 0.5, voice=99)
+    # zero voices / zero-size blocks are errors, not crashes
+    h = C.c_void_p()
+    assert L.groove_welsh_create(gpu_ctx.h, params, 0, C.byref(h)) != 0
+    assert L.groove_block_create(gpu_ctx.h, 0, 256, C.byref(h)) != 0
+    assert L.groove_fx_create(gpu_ctx.h, 99, (T.FxParams * 1)(T.fx_params()), 1, C.byref(h)) != 0
+    assert b"unknown effect kind" in L.groove_last_error(gpu_ctx.h)
+    # rendering zero frames is a no-op
+    s.generate_batch_values(big, 0)
+    # delay-line geometry must be uniform across the lanes of one effect bank, and cannot change later
+    two = (T.FxParams * 2)(T.fx_params(delay_seconds=0.1), T.fx_params(delay_seconds=0.2))
+    with pytest.raises(lib.GrooveError, match="uniform"):
+        E.Effect(gpu_ctx, T.FX_DELAY, two)
+    d = E.Effect(gpu_ctx, T.FX_DELAY, (T.FxParams * 2)(T.fx_params(delay_seconds=0.1), T.fx_params(delay_seconds=0.1)))
+    with pytest.raises(lib.GrooveError, match="geometry cannot change"):
+        d.set_params((T.FxParams * 2)(T.fx_params(delay_seconds=0.3), T.fx_params(delay_seconds=0.3)))
+    with pytest.raises(lib.GrooveError, match="lanes"):
+        d.transform_audio(small, 16)
+    # sampler descriptors are checked against the bank
+    pcm = np.zeros(100, dtype=np.float32)
+    descs = (T.SampleDesc * 1)()
+    descs[0].offset, descs[0].length = 50, 100
+    sp = (T.SamplerParams * 1)()
+    with pytest.raises(lib.GrooveError, match="exceeds bank"):
+        E.Sampler(gpu_ctx, pcm, descs, sp)
+    descs[0].offset, descs[0].length = 0, 100
+    sp[0].sample_index = 3
+    with pytest.raises(lib.GrooveError, match="sample_index"):
+        E.Sampler(gpu_ctx, pcm, descs, sp)
+    # a failed call leaves the context usable
+    s.handle_midi_events(T.note_events([(0, 60, True)]))
+    s.generate_batch_values(big, 64)
+    assert big.download(64)[:, :, 0].any()
+    # mixing blocks of different lane counts into one bus is fine; block sums need matching lanes or a 1-lane sink
+    bus = gpu_ctx.bus(64)
+    gpu_ctx.mix([big, small], 64, bus)
+    assert L.groove_block_accumulate(small.h, big.h, 16, 0) != 0
+    one = gpu_ctx.block(1, 64)
+    assert L.groove_block_accumulate(one.h, big.h, 64, 0) == 0
+    assert np.allclose(one.download(64)[:, :, 0], big.download(64).sum(axis=2), atol=1e-6)
+    for x in (s, d, small, big, one, bus):
+        x.destroy()
+
+
+def test_sample_rate_change_rebuilds_effects(oracle):
+    """Configurable::update_sample_rate reaches effects: ring lengths and filter coefficients follow the new rate."""
+    from groove_amd import entities as E
+    ctx = E.Context(0)
+    fx = E.Effect(ctx, T.FX_DELAY, (T.FxParams * 4)(*[T.fx_params(delay_seconds=0.01)] * 4))
+    lp = E.Effect(ctx, T.FX_BIQUAD_LP12, (T.FxParams * 4)(*[T.fx_params(cutoff_hz=2000.0, q=0.9)] * 4))
+    ctx.update_sample_rate(48000)
+    x = np.zeros((2, 1024, 4), dtype=np.float32)
+    x[:, 0, :] = 1.0
+    b = ctx.block(4, 256)
+    outs, lps = [], []
+    b2 = ctx.block(4, 256)
+    for i in range(4):
+        b.upload(x[:, i * 256:(i + 1) * 256]); fx.transform_audio(b, 256); outs.append(b.download(256))
+        b2.upload(x[:, i * 256:(i + 1) * 256]); lp.transform_audio(b2, 256); lps.append(b2.download(256))
+    y = np.concatenate(outs, axis=1)
+    assert y[0, 480, 0] == 1.0 and np.count_nonzero(y) == 8        # 0.01 s * 48,000 = 480 frames, both channels, 4 lanes
+    want = oracle.Fx(T.FX_BIQUAD_LP12, (T.FxParams * 4)(*[T.fx_params(cutoff_hz=2000.0, q=0.9)] * 4), sr=48000).process(x.astype(np.float64))
+    assert np.max(np.abs(np.concatenate(lps, axis=1) - want)) <= 2e-6
+    ctx.close()
