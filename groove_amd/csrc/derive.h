@@ -62,6 +62,20 @@ inline WelshParams derive_welsh(const groove_welsh_params& p, double sr, WelshCo
   o.o2_duty64 = duty_to_u64((double)o.o2_duty);
   o.lfo_inc = turns_to_inc(p.lfo_frequency / sr);
   o.lfo_depth = p.lfo_depth;
+  { // LFO recurrence constants and the WF_LFO_SMOOTH promise (dsp_core.h, welsh_frame)
+    const double D = 6.28318530717958647692 * ((double)(int64_t)o.lfo_inc * 5.42101086242752217004e-20);
+    const double h = sin(0.5 * D);
+    o.lfo_rk = 2.0 * h * h;
+    o.lfo_rs = sin(D);
+    o.lfo_a = (double)p.lfo_depth * 0.693147180559945309417;
+    const uint32_t wl = p.lfo_waveform & 15u, r = p.lfo_routing & 15u;
+    const bool tri = wl == GROOVE_WAVE_TRIANGLE || wl == GROOVE_WAVE_TRIANGLE_SINE;
+    // largest per-frame change of the LFO value: |D| for a sine, 4 |inc| (in turns) for a triangle
+    const double dl = wl == GROOVE_WAVE_SINE ? fabs(D) : 4.0 * fabs((double)(int64_t)o.lfo_inc * 5.42101086242752217004e-20);
+    if ((wl == GROOVE_WAVE_SINE || tri) &&
+        (r == GROOVE_LFO_PULSE_WIDTH || (r == GROOVE_LFO_PITCH && fabs(o.lfo_a) * dl <= 1.5e-3)))
+      o.flags |= WF_LFO_SMOOTH;
+  }
   o.amp = derive_env(p.amp_envelope, sr);
   o.fil = derive_env(p.filter_envelope, sr);
   o.fc = derive_lp24_consts((double)p.filter_passband_ripple);

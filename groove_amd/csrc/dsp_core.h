@@ -104,6 +104,14 @@ GROOVE_HD double exp2_small_f64(double x) {
   p = fma(p, t, 1.0);
   return fma(p, t, 1.0);
 }
+// e^x for |x| <= 1.5e-3 (x^5/120 < 1e-16): the per-frame growth factor of a slowly moving exponent.
+GROOVE_HD double exp_tiny_f64(double x) {
+  double p = 4.16666666666666666667e-02;
+  p = fma(p, x, 1.66666666666666666667e-01);
+  p = fma(p, x, 0.5);
+  p = fma(p, x, 1.0);
+  return fma(p, x, 1.0);
+}
 // tan of the angle x in (0, pi/2) REDUCED to [0, pi/4]: returns t = tan(min(x, pi/2 - x)) <= 1 and
 // hi = (x > pi/4), i.e. tan(x) = hi ? 1/t : t.  The caller keeps working with t (never forms
 // 1/t), which is what keeps the filter coefficients accurate next to Nyquist.
@@ -126,8 +134,18 @@ GROOVE_HD float tan_reduced(float x, bool& hi) {
 GROOVE_HD float clamp01f(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 GROOVE_HD double clamp01d(double x) { return fmin(fmax(x, 0.0), 1.0); }
 
-// f64 -> u64 for 0 <= x < 2^64
-GROOVE_HD uint64_t f64_to_u64(double x) { return (uint64_t)x; }
+// f64 -> u64 (truncating) for 0 <= x < 2^64
+GROOVE_HD uint64_t f64_to_u64(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // two v_cvt_u32_f64 (truncating) around one exact fma: hi = floor(x / 2^32), lo = x - hi * 2^32
+  // (exact: both are multiples of ulp(x) below 2^32) -- 5 instructions instead of the generic 7.
+  const uint32_t hi = (uint32_t)(x * 2.3283064365386963e-10);
+  const uint32_t lo = (uint32_t)fma((double)hi, -4294967296.0, x);
+  return ((uint64_t)hi << 32) | (uint64_t)lo;
+#else
+  return (uint64_t)x;
+#endif
+}
 // turns (f64, any sign, |x| < 2^31) -> wrapped 64-bit phase increment
 GROOVE_HD uint64_t turns_to_phase(double turns) {
   double fl = floor(turns);
@@ -315,7 +333,8 @@ GROOVE_HD double lp24_step(Lp24StateD& s, const Lp24CoefD& c, double x) {
 // Packed per-voice flags word.
 enum : uint32_t {
   WF_O1_WAVE_SHIFT = 0, WF_O2_WAVE_SHIFT = 4, WF_LFO_WAVE_SHIFT = 8, WF_ROUTING_SHIFT = 12,
-  WF_SYNC = 1u << 16, WF_RETUNE_ENV = 1u << 17, WF_O2_FIXED = 1u << 18
+  WF_SYNC = 1u << 16, WF_RETUNE_ENV = 1u << 17, WF_O2_FIXED = 1u << 18,
+  WF_LFO_SMOOTH = 1u << 19 // host promise: the f64 LFO may be advanced by recurrences (see welsh_frame)
 };
 struct WelshParams {
   uint32_t flags;
@@ -329,6 +348,10 @@ struct WelshParams {
   Lp24Consts fc;   // filter constants
   float cutoff_start, cutoff_end;
   float gl, gr;    // dca gain * pan law, per channel
+  // LFO recurrence constants (host, f64): with D = 2 pi lfo_inc / 2^64 the per-frame rotation is
+  // sin' = sin + (rs cos - rk sin), cos' = cos - (rs sin + rk cos), rk = 1 - cos D = 2 sin^2(D/2), rs = sin D;
+  // lfo_a = lfo_depth * ln 2 (pitch routing: 2^(l depth) = e^(l lfo_a)).
+  double lfo_rk, lfo_rs, lfo_a;
 };
 struct WelshState {
   OscState o1, o2, lfo;
@@ -346,6 +369,8 @@ struct RenderConsts {
 struct WelshScratch {
   Lp24CoefD coef;  // current filter coefficients
   float prev_pct;  // cutoff percent the coefficients were computed for (NaN = none)
+  double ls, lc;   // LFO_F64_SMOOTH: LFO value of the previous frame (sine: sin), and cos of the sine LFO's angle
+  double lm;       // LFO_F64_SMOOTH, pitch routing: 2^(ls * depth)
 };
 GROOVE_HD Lp24Coef welsh_static_coef(const WelshParams& p, const RenderConsts& rc) {
   return lp24_coef_from_fc(p.fc, p.cutoff_hz, rc.pi_over_sr, rc.fc_max);
@@ -358,11 +383,26 @@ GROOVE_HD bool welsh_retunes(const WelshParams& p) {
   return (p.flags & WF_RETUNE_ENV) || (((p.flags >> WF_ROUTING_SHIFT) & 15u) == GROOVE_LFO_FILTER_CUTOFF);
 }
 
+// How the LFO is evaluated.  LFO_F32: promise that no lane routes the LFO to Pitch or PulseWidth,
+// which removes the f64 LFO / 2^x / u64<->f64 path (and ~80 VGPRs).  LFO_F64: exact per-frame
+// evaluation from the 64-bit phase (any waveform).  LFO_F64_SMOOTH: promise that every lane that
+// routes to Pitch / PulseWidth carries WF_LFO_SMOOTH (sine or triangle LFO, |lfo_a dl| <= 1.5e-3 per
+// frame): frame 0 of a render call evaluates exactly and seeds (ls, lc, lm); later frames advance
+// the sine by one rotation (6 f64 ops instead of a 10-term polynomial + conversions) and the
+// pitch factor by lm *= e^(lfo_a (l - ls)) with a 4-term series (instead of a 15-term one).  The
+// recurrences are re-seeded every block, so their error stays a random walk of <= 255 steps of
+// ~1e-16 (tests/test_emul_numerics.py checks the result against the oracle).
+enum : int { LFO_F32 = 0, LFO_F64 = 1, LFO_F64_SMOOTH = 2 };
+GROOVE_HD int welsh_lfo_mode(const WelshParams& p) {
+  const uint32_t r = (p.flags >> WF_ROUTING_SHIFT) & 15u;
+  if (r != GROOVE_LFO_PITCH && r != GROOVE_LFO_PULSE_WIDTH) return LFO_F32;
+  return (p.flags & WF_LFO_SMOOTH) ? LFO_F64_SMOOTH : LFO_F64;
+}
+
 // One frame of one voice.  FIRST: this is frame 0 of a render call (the only frame on which
 // VF_FIRST can be set).  RETUNE: false promises !welsh_retunes(p) for every lane, so the
-// coefficients in `sc` are loop-invariant.  F64LFO: false promises that no lane routes the LFO
-// to Pitch or PulseWidth, which removes the f64 LFO / 2^x / u64<->f64 path (and ~50 VGPRs).
-template <bool FIRST, bool RETUNE, bool F64LFO = true>
+// coefficients in `sc` are loop-invariant.  LFO_MODE: see above.
+template <bool FIRST, bool RETUNE, int LFO_MODE = LFO_F64>
 GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc,
                            WelshScratch& sc, float& L, float& R) {
   env_tick(s.amp, p.amp);
@@ -381,17 +421,30 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
   uint64_t inc1 = s.o1_inc, inc2 = s.o2_inc;
   uint64_t d1 = p.o1_duty64, d2 = p.o2_duty64;
   float lfo = 0.0f;
-  if (F64LFO && (routing == GROOVE_LFO_PITCH || routing == GROOVE_LFO_PULSE_WIDTH)) {
-    const double l = osc_value_f64(wl, s.lfo.phase, half, nzl);
-    const double ld = l * (double)p.lfo_depth;
+  if (LFO_MODE != LFO_F32 && (routing == GROOVE_LFO_PITCH || routing == GROOVE_LFO_PULSE_WIDTH)) {
+    constexpr bool SMOOTH = LFO_MODE == LFO_F64_SMOOTH;
+    double l;
+    if (SMOOTH && !FIRST && wl == GROOVE_WAVE_SINE) { // one rotation step (an idle voice never gets here: see above)
+      l = sc.ls + fma(p.lfo_rs, sc.lc, -(p.lfo_rk * sc.ls));
+      sc.lc = sc.lc - fma(p.lfo_rs, sc.ls, p.lfo_rk * sc.lc);
+    } else {
+      l = osc_value_f64(wl, s.lfo.phase, half, nzl);
+      if (SMOOTH && FIRST && wl == GROOVE_WAVE_SINE) // cos(2 pi x) = sin(2 pi (x + 1/4))
+        sc.lc = sin_turns_folded_f64((double)fold_quarter64((int64_t)(s.lfo.phase + 0x4000000000000000ull)) * 5.42101086242752217004e-20);
+    }
     if (routing == GROOVE_LFO_PITCH) {
-      const double m = exp2_small_f64(ld);
+      double m;
+      if (SMOOTH && !FIRST) m = sc.lm * exp_tiny_f64((l - sc.ls) * p.lfo_a);
+      else m = exp2_small_f64(l * (double)p.lfo_depth);
+      if (SMOOTH) sc.lm = m;
       inc1 = f64_to_u64((double)inc1 * m);
       inc2 = f64_to_u64((double)inc2 * m); // fm applies to a fixed-frequency osc too
     } else {
+      const double ld = l * (double)p.lfo_depth;
       d1 = f64_to_u64(clamp01d((double)p.o1_duty * (1.0 + ld)) * 18446744073709549568.0);
       d2 = f64_to_u64(clamp01d((double)p.o2_duty * (1.0 + ld)) * 18446744073709549568.0);
     }
+    if (SMOOTH) sc.ls = l;
     lfo = (float)l;
   } else if (routing != GROOVE_LFO_NONE) {
     lfo = osc_value(wl, s.lfo.phase, half, nzl);
@@ -441,6 +494,7 @@ GROOVE_HD WelshScratch welsh_scratch_init(const WelshParams& p, const RenderCons
   WelshScratch sc;
   sc.coef = lp24_widen(welsh_static_coef(p, rc));
   sc.prev_pct = __builtin_nanf("");
+  sc.ls = 0.0; sc.lc = 1.0; sc.lm = 1.0;
   return sc;
 }
 

@@ -39,9 +39,9 @@ struct groove_bank {
   WaveDesc* d_waves = nullptr;   // welsh: virtual waves (runs of <= 64 voices sharing a patch)
   uint32_t n_vwaves = 0;         // 0: the bank runs on the per-lane kernel
   size_t vwaves_cap = 0;
-  uint8_t* d_wg_kind = nullptr;  // welsh: register budget each workgroup of virtual waves needs
-  size_t wg_kind_cap = 0;
-  uint32_t wgs_of_kind[3] = {0, 0, 0};
+  uint32_t* d_wg_list = nullptr; // welsh: workgroup ids (groups of 4 virtual waves) sorted by kind (kernels.h)
+  size_t wg_list_cap = 0;
+  uint32_t wgs_of_kind[kWgKinds] = {};  // slice lengths of d_wg_list, in kind order
   float* d_pcm = nullptr;   // sampler bank
   groove_note_event* d_ev = nullptr;
   size_t ev_cap = 0;
@@ -75,8 +75,8 @@ struct groove_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = true;
-  hipStream_t side_stream[2] = {nullptr, nullptr}; // kernels of the other workgroup kinds run beside the main one
-  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  hipStream_t side_stream[kWgKinds - 1] = {}; // kernels of the other workgroup kinds run beside the main one
+  hipEvent_t ev_fork = nullptr, ev_join[kWgKinds - 1] = {};
   uint32_t sr = GROOVE_DEFAULT_SAMPLE_RATE;
   std::string err;
   std::vector<groove_bank*> banks;
@@ -155,7 +155,7 @@ int welsh_upload_params(groove_bank* b) {
     v = e;
   }
   const uint32_t phys_waves = (n + 63) / 64;
-  b->wgs_of_kind[0] = b->wgs_of_kind[1] = b->wgs_of_kind[2] = 0;
+  for (uint32_t& c : b->wgs_of_kind) c = 0;
   // Use the scalar-parameter kernels when the runs are long (at most 1.5x as many virtual waves as
   // physical ones), or when the bank is so small that even one short run per wave leaves the machine
   // (1,024 SIMDs) under-filled: there a partly filled fast wave beats a full slow one.  Otherwise the
@@ -166,22 +166,33 @@ int welsh_upload_params(groove_bank* b) {
   }
   b->n_vwaves = (uint32_t)W.size();
   const uint32_t wgs = (b->n_vwaves + kWaves - 1) / kWaves;
-  std::vector<uint8_t> kind(wgs, WG_UNIFORM);
-  for (uint32_t w = 0; w < b->n_vwaves; ++w)
-    if (welsh_f64_lfo(W[w].p)) kind[w / kWaves] = WG_UNIFORM_F64;
-  for (uint8_t k : kind) b->wgs_of_kind[k] += 1;
+  // a workgroup runs in the instantiation its most demanding wave needs (kernels.h, "Workgroup KINDS")
+  std::vector<uint8_t> kind(wgs, 0);
+  for (uint32_t w = 0; w < b->n_vwaves; ++w) {
+    const int mode = welsh_lfo_mode(W[w].p);
+    const int rank = mode == LFO_F32 ? 0 : (mode == LFO_F64_SMOOTH ? 1 : 2);
+    uint8_t& k = kind[w / kWaves]; // kept as (rank << 1) | retune while merging
+    k = (uint8_t)((std::max<int>(k >> 1, rank) << 1) | ((k & 1) | (welsh_retunes(W[w].p) ? 1 : 0)));
+  }
+  std::vector<uint32_t> wg_list(wgs);
+  {
+    uint32_t at[kWgKinds + 1] = {};
+    for (uint8_t k : kind) b->wgs_of_kind[k] += 1; // (rank << 1) | retune is exactly wg_kind_of()'s numbering
+    for (int k = 0; k < kWgKinds; ++k) at[k + 1] = at[k] + b->wgs_of_kind[k];
+    for (uint32_t g = 0; g < wgs; ++g) wg_list[at[kind[g]]++] = g;
+  }
   if (b->vwaves_cap < W.size()) {
     if (b->d_waves) GHIP(ctx, hipFree(b->d_waves));
     b->vwaves_cap = W.size() + W.size() / 8 + 16;
     GHIP(ctx, hipMalloc(&b->d_waves, b->vwaves_cap * sizeof(WaveDesc)));
   }
-  if (b->wg_kind_cap < wgs) {
-    if (b->d_wg_kind) GHIP(ctx, hipFree(b->d_wg_kind));
-    b->wg_kind_cap = wgs + wgs / 8 + 16;
-    GHIP(ctx, hipMalloc(&b->d_wg_kind, b->wg_kind_cap));
+  if (b->wg_list_cap < wgs) {
+    if (b->d_wg_list) GHIP(ctx, hipFree(b->d_wg_list));
+    b->wg_list_cap = wgs + wgs / 8 + 16;
+    GHIP(ctx, hipMalloc(&b->d_wg_list, b->wg_list_cap * sizeof(uint32_t)));
   }
   GHIP(ctx, hipMemcpy(b->d_waves, W.data(), W.size() * sizeof(WaveDesc), hipMemcpyHostToDevice));
-  GHIP(ctx, hipMemcpy(b->d_wg_kind, kind.data(), wgs, hipMemcpyHostToDevice));
+  GHIP(ctx, hipMemcpy(b->d_wg_list, wg_list.data(), (size_t)wgs * sizeof(uint32_t), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -460,13 +471,13 @@ int groove_init(int device_ordinal, groove_ctx** out) {
   groove_ctx* ctx = new (std::nothrow) groove_ctx();
   if (!ctx) return fail(nullptr, "groove_init: out of memory");
   ctx->device = device_ordinal;
-  if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&ctx->side_stream[0], hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&ctx->side_stream[1], hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_join[0], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_join[1], hipEventDisableTiming) != hipSuccess) {
-    delete ctx;
+  bool ok = hipSetDevice(device_ordinal) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; ok && i < kWgKinds - 1; ++i)
+    ok = hipStreamCreateWithFlags(&ctx->side_stream[i], hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    groove_shutdown(ctx);
     return fail(nullptr, "groove_init: hipSetDevice/hipStreamCreate failed");
   }
   *out = ctx;
@@ -484,7 +495,7 @@ void groove_shutdown(groove_ctx* ctx) {
   if (ctx->d_fseg) (void)hipFree(ctx->d_fseg);
   if (ctx->d_i16) (void)hipFree(ctx->d_i16);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < kWgKinds - 1; ++i) {
     if (ctx->side_stream[i]) { (void)hipStreamSynchronize(ctx->side_stream[i]); (void)hipStreamDestroy(ctx->side_stream[i]); }
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
   }
@@ -642,7 +653,7 @@ int groove_bank_destroy(groove_bank* b) {
   auto it = std::find(ctx->banks.begin(), ctx->banks.end(), b);
   if (it != ctx->banks.end()) ctx->banks.erase(it);
   if (b->scratch) groove_block_destroy(b->scratch);
-  (void)hipFree(b->d_params); (void)hipFree(b->d_state); (void)hipFree(b->d_cold); (void)hipFree(b->d_pcm); (void)hipFree(b->d_ev); (void)hipFree(b->d_waves); (void)hipFree(b->d_wg_kind);
+  (void)hipFree(b->d_params); (void)hipFree(b->d_state); (void)hipFree(b->d_cold); (void)hipFree(b->d_pcm); (void)hipFree(b->d_ev); (void)hipFree(b->d_waves); (void)hipFree(b->d_wg_list);
   delete b;
   return 0;
 }
@@ -685,27 +696,47 @@ static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs
       if (fused) hipLaunchKernelGGL(welsh_render_kernel<true>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, rc);
       else hipLaunchKernelGGL(welsh_render_kernel<false>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, rc);
     } else {
-      // Two kernels, one per register budget, running concurrently: the f64-LFO kind (more work
-      // per voice: the critical path) goes out on the ctx stream, the plain kind on a side stream
-      // forked from it, and the ctx stream joins it before the bus reduction.
-      const dim3 vgrid((b->n_vwaves + kWaves - 1) / kWaves);
-      const bool both = b->wgs_of_kind[WG_UNIFORM] && b->wgs_of_kind[WG_UNIFORM_F64];
-      if (both) {
-        GHIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-        GHIP(ctx, hipStreamWaitEvent(ctx->side_stream[0], ctx->ev_fork, 0));
-      }
-      if (b->wgs_of_kind[WG_UNIFORM_F64]) {
-        if (fused) hipLaunchKernelGGL((welsh_render_uniform_kernel<true, true>), vgrid, blk, 0, ctx->stream, b->d_waves, b->n_vwaves, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
-        else hipLaunchKernelGGL((welsh_render_uniform_kernel<false, true>), vgrid, blk, 0, ctx->stream, b->d_waves, b->n_vwaves, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
-      }
-      if (b->wgs_of_kind[WG_UNIFORM]) {
-        hipStream_t st = both ? ctx->side_stream[0] : ctx->stream;
-        if (fused) hipLaunchKernelGGL((welsh_render_uniform_kernel<true, false>), vgrid, blk, 0, st, b->d_waves, b->n_vwaves, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
-        else hipLaunchKernelGGL((welsh_render_uniform_kernel<false, false>), vgrid, blk, 0, st, b->d_waves, b->n_vwaves, b->d_state, b->n, frames, chs, out, rc, b->d_wg_kind);
-      }
-      if (both) {
-        GHIP(ctx, hipEventRecord(ctx->ev_join[0], ctx->side_stream[0]));
-        GHIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[0], 0));
+      // One kernel per workgroup kind present, all running concurrently: the most expensive kind
+      // goes out first on the ctx stream (list scheduling, longest first), the others on side
+      // streams forked from it, and the ctx stream joins them before the bus reduction.
+      int present = 0;
+      for (uint32_t c : b->wgs_of_kind) present += c ? 1 : 0;
+      if (present > 1) GHIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+      uint32_t offset[kWgKinds];
+      for (uint32_t k = 0, at = 0; k < (uint32_t)kWgKinds; ++k) { offset[k] = at; at += b->wgs_of_kind[k]; }
+      int side = 0;
+      bool first_kind = true;
+      for (int k = kWgKinds - 1; k >= 0; --k) {
+        if (!b->wgs_of_kind[k]) continue;
+        hipStream_t st = ctx->stream;
+        if (!first_kind) {
+          st = ctx->side_stream[side];
+          GHIP(ctx, hipStreamWaitEvent(st, ctx->ev_fork, 0));
+        }
+        const dim3 kgrid(b->wgs_of_kind[k]);
+        const uint32_t* list = b->d_wg_list + offset[k];
+#define GROOVE_LAUNCH_UNIFORM(MODE, RETUNE)                                                                                    \
+  do {                                                                                                                         \
+    if (fused) hipLaunchKernelGGL((welsh_render_uniform_kernel<true, MODE, RETUNE>), kgrid, blk, 0, st, b->d_waves,             \
+                                  b->n_vwaves, b->d_state, b->n, frames, chs, out, rc, list);                                  \
+    else hipLaunchKernelGGL((welsh_render_uniform_kernel<false, MODE, RETUNE>), kgrid, blk, 0, st, b->d_waves, b->n_vwaves,     \
+                            b->d_state, b->n, frames, chs, out, rc, list);                                                     \
+  } while (0)
+        switch (k) {
+          case wg_kind_of(LFO_F32, false): GROOVE_LAUNCH_UNIFORM(LFO_F32, false); break;
+          case wg_kind_of(LFO_F32, true): GROOVE_LAUNCH_UNIFORM(LFO_F32, true); break;
+          case wg_kind_of(LFO_F64_SMOOTH, false): GROOVE_LAUNCH_UNIFORM(LFO_F64_SMOOTH, false); break;
+          case wg_kind_of(LFO_F64_SMOOTH, true): GROOVE_LAUNCH_UNIFORM(LFO_F64_SMOOTH, true); break;
+          case wg_kind_of(LFO_F64, false): GROOVE_LAUNCH_UNIFORM(LFO_F64, false); break;
+          default: GROOVE_LAUNCH_UNIFORM(LFO_F64, true); break;
+        }
+#undef GROOVE_LAUNCH_UNIFORM
+        if (!first_kind) {
+          GHIP(ctx, hipEventRecord(ctx->ev_join[side], st));
+          GHIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[side], 0));
+          ++side;
+        }
+        first_kind = false;
       }
     }
   } else if (b->kind == BANK_FM) {

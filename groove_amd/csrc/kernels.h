@@ -45,8 +45,18 @@ __device__ __forceinline__ void soa_store(uint32_t* __restrict__ buf, uint32_t n
     __builtin_amdgcn_raw_buffer_store_b32((int)t.w[i], rsrc, (int)(v * 4u), (int)(i * n * 4u), 0);
 }
 
-#ifndef GROOVE_WAVES_SIMPLE
-#define GROOVE_WAVES_SIMPLE 6 /* waves per SIMD the uniform kernel is register-budgeted for */
+// Waves per SIMD each uniform-kernel kind is register-budgeted for (512 VGPRs / waves, in steps of 8).
+#ifndef GROOVE_WAVES_F32_STATIC
+#define GROOVE_WAVES_F32_STATIC 6
+#endif
+#ifndef GROOVE_WAVES_F32_RETUNE
+#define GROOVE_WAVES_F32_RETUNE 6
+#endif
+#ifndef GROOVE_WAVES_SMOOTH_STATIC
+#define GROOVE_WAVES_SMOOTH_STATIC 4
+#endif
+#ifndef GROOVE_WAVES_SMOOTH_RETUNE
+#define GROOVE_WAVES_SMOOTH_RETUNE 4
 #endif
 #ifndef GROOVE_WAVES_F64
 #define GROOVE_WAVES_F64 2
@@ -101,7 +111,9 @@ __device__ __forceinline__ float wave_sum_lane63(float x) {
 }
 // (kept for reference / A-B: the all-DPP form, 17 VALU per frame)
 struct FusedAccDpp {
+  uint32_t prow;   // this workgroup's row pair in partial[]
   float accL = 0.0f, accR = 0.0f;
+  __device__ __forceinline__ explicit FusedAccDpp(uint32_t row) : prow(row) {}
   __device__ __forceinline__ void add(float L, float R, uint32_t f) {
     const float tl = wave_sum_lane63(L), tr = wave_sum_lane63(R);
     const int sl = __builtin_amdgcn_readlane(__builtin_bit_cast(int, tl), 63);
@@ -120,7 +132,7 @@ struct FusedAccDpp {
       float t = 0.0f;
 #pragma unroll
       for (int w = 0; w < kWaves; ++w) t += red[w][wave][lane];
-      partial[((size_t)blockIdx.x * 2 + wave) * frames + f0 + lane] = t;
+      partial[((size_t)prow * 2 + wave) * frames + f0 + lane] = t;
     }
     __syncthreads();
     accL = 0.0f; accR = 0.0f;
@@ -135,6 +147,8 @@ struct FusedAccDpp {
 // ≈ 5 VALU + 1 LDS write per frame instead of 17 VALU; 16 KiB of LDS per workgroup.
 struct FusedAccLds {
   static constexpr uint32_t kChunk = 8;
+  uint32_t prow;   // this workgroup's row pair in partial[]
+  __device__ __forceinline__ explicit FusedAccLds(uint32_t row) : prow(row) {}
   __device__ __forceinline__ float2* tile() {
     __shared__ float2 t[kChunk][kThreads];
     return &t[0][0];
@@ -156,8 +170,8 @@ struct FusedAccLds {
     l = dpp_add<0x128, 0xf>(l); r = dpp_add<0x128, 0xf>(r);
     l = dpp_add<0x142, 0xa>(l); r = dpp_add<0x142, 0xa>(r);
     if (col == 31 && row < count) { // lanes 31 and 63 of each wave hold the totals of their rows
-      partial[((size_t)blockIdx.x * 2 + 0) * frames + f0 + row] = l;
-      partial[((size_t)blockIdx.x * 2 + 1) * frames + f0 + row] = r;
+      partial[((size_t)prow * 2 + 0) * frames + f0 + row] = l;
+      partial[((size_t)prow * 2 + 1) * frames + f0 + row] = r;
     }
     __syncthreads();
   }
@@ -172,9 +186,9 @@ using FusedAcc = FusedAccLds;
 // lane's voice; the epilogue either stores the planar block or feeds the fused bus sum.
 template <bool FUSED, class FrameFn>
 __device__ __forceinline__ void run_frames(uint32_t frames, uint32_t n, uint32_t v, bool active, size_t ch_stride,
-                                           float* __restrict__ out, FrameFn&& frame) {
+                                           float* __restrict__ out, uint32_t prow, FrameFn&& frame) {
   if (FUSED) {
-    FusedAcc acc;
+    FusedAcc acc(prow);
     for (uint32_t f = 0; f < frames; ++f) {
       float L, R;
       frame(f, L, R);
@@ -196,20 +210,71 @@ __device__ __forceinline__ void run_frames(uint32_t frames, uint32_t n, uint32_t
     }
   }
 }
+// The same loop with frame 0 peeled by hand: `first(L, R)` computes frame 0 (first-tick flag, block
+// seeds of the LFO recurrences), `rest(f, L, R)` frames 1...  Used where the frame-0 body is so much
+// larger than the steady-state body that the compiler's own peeling of `if (f == 0)` gives up and
+// leaves both bodies (and the seed polynomials' constants) inside the loop.
+template <bool FUSED, class FirstFn, class RestFn>
+__device__ __forceinline__ void run_frames_peeled(uint32_t frames, uint32_t n, uint32_t v, bool active, size_t ch_stride,
+                                                  float* __restrict__ out, uint32_t prow, FirstFn&& first, RestFn&& rest) {
+  if (frames == 0) return;
+  if (FUSED) {
+    FusedAcc acc(prow);
+    constexpr uint32_t C = FusedAcc::kChunk;
+    static_assert(C > 1, "frame 0 never completes a chunk");
+    {
+      float L, R;
+      first(L, R);
+      acc.add(active ? L : 0.0f, active ? R : 0.0f, 0);
+    }
+    for (uint32_t f = 1; f < frames; ++f) {
+      float L, R;
+      rest(f, L, R);
+      acc.add(active ? L : 0.0f, active ? R : 0.0f, f);
+      if ((f & (C - 1)) == C - 1) acc.flush(out, frames, f - (C - 1), C);
+    }
+    if (frames & (C - 1)) acc.flush(out, frames, frames & ~(C - 1), frames & (C - 1));
+  } else {
+    {
+      float L, R;
+      first(L, R);
+      if (active) { out[v] = L; out[ch_stride + v] = R; }
+    }
+    for (uint32_t f = 1; f < frames; ++f) {
+      float L, R;
+      rest(f, L, R);
+      if (active) {
+        float* __restrict__ rowL = out + (size_t)f * n;
+        float* __restrict__ rowR = out + ch_stride + (size_t)f * n;
+        rowL[v] = L;
+        rowR[v] = R;
+      }
+    }
+  }
+}
 
 // ------------------------------------------------------------------ instruments
 // a5 WelshVoice: Ticks::tick(frames) + Generates::generate_batch_values.
 // Frame 0 is peeled (first-tick flag); RETUNE=false variants keep the filter coefficients
 // loop-invariant so their f64 widening is hoisted out of the frame loop.
-template <bool FUSED, bool RETUNE, bool F64LFO = true>
+template <bool FUSED, bool RETUNE, int LFO_MODE = LFO_F64, bool UNIFORM = false>
 __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s, const RenderConsts& rc,
                                             uint32_t frames, uint32_t n, uint32_t v, bool active,
-                                            size_t ch_stride, float* __restrict__ out) {
+                                            size_t ch_stride, float* __restrict__ out, uint32_t prow) {
   WelshScratch sc = welsh_scratch_init(p, rc);
-  run_frames<FUSED>(frames, n, v, active, ch_stride, out, [&](uint32_t f, float& L, float& R) {
-    if (f == 0) welsh_frame<true, RETUNE, F64LFO>(p, s, rc, sc, L, R);
-    else welsh_frame<false, RETUNE, F64LFO>(p, s, rc, sc, L, R);
-  });
+  // Static cutoff + wave-uniform patch: the six f64 coefficients are the same in every lane and
+  // never change, so they ride in SGPRs (12 VGPRs back; f64 FMAs take one scalar operand).
+  if (UNIFORM && !RETUNE) sc.coef = make_scalar(sc.coef);
+  if constexpr (UNIFORM && LFO_MODE != LFO_F32) {
+    run_frames_peeled<FUSED>(frames, n, v, active, ch_stride, out, prow,
+                             [&](float& L, float& R) { welsh_frame<true, RETUNE, LFO_MODE>(p, s, rc, sc, L, R); },
+                             [&](uint32_t, float& L, float& R) { welsh_frame<false, RETUNE, LFO_MODE>(p, s, rc, sc, L, R); });
+  } else {
+    run_frames<FUSED>(frames, n, v, active, ch_stride, out, prow, [&](uint32_t f, float& L, float& R) {
+      if (f == 0) welsh_frame<true, RETUNE, LFO_MODE>(p, s, rc, sc, L, R);
+      else welsh_frame<false, RETUNE, LFO_MODE>(p, s, rc, sc, L, R);
+    });
+  }
 }
 // Generic form: per-lane parameters (any mix of patches inside a wave; exec-masked branches).
 // Per-lane form: any mix of patches inside a wave (exec-masked branches).  Used for banks
@@ -223,39 +288,56 @@ __global__ __launch_bounds__(kThreads) void welsh_render_kernel(
   const uint32_t v = active ? v0 : n - 1; // tail lanes shadow the last voice and store nothing
   const WelshParams p = soa_load<WelshParams>(params, n, v);
   WelshState s = soa_load<WelshState>(state, n, v);
-  welsh_block<FUSED, true>(p, s, rc, frames, n, v, active, ch_stride, out);
+  welsh_block<FUSED, true>(p, s, rc, frames, n, v, active, ch_stride, out, blockIdx.x);
   if (active) soa_store(state, n, v, s);
 }
 // Wave-uniform form.  The host cuts the bank into VIRTUAL WAVES: maximal runs of consecutive
 // voices that share one patch, at most 64 long (a 64-lane group that straddles two patches
 // becomes two partly filled waves).  Each wavefront of the launch takes one descriptor with
 // scalar loads — patch parameters land in SGPRs, waveform / routing dispatch is scalar
-// branching — and works on voices [vbase, vbase + count).  wg_kind[workgroup] tells which of
-// the two register budgets the workgroup needs: WG_UNIFORM, or WG_UNIFORM_F64 when one of its
-// waves routes the LFO to pitch / pulse width (f64 LFO path); both kernels are launched over
-// the whole grid on forked streams and a workgroup exits at once if it is the other's kind.
+// branching — and works on voices [vbase, vbase + count).
+//
+// Workgroup KINDS.  What a patch needs decides which instantiation (code + register budget) its
+// workgroup runs in: the LFO mode (dsp_core.h: none in f64 / smooth recurrences / exact f64) times
+// whether the filter is retuned per frame (envelope- or LFO-driven cutoff: per-lane f64
+// coefficients, the tan / reciprocal path) or static (coefficients in SGPRs).  A workgroup takes
+// the most demanding kind among its four waves.  The host sorts workgroup ids by kind into
+// wg_list; every kind present is launched over its own slice of the list, all concurrently on
+// forked streams.  Separate kernels (rather than one kernel with scalar branches) because
+// register allocation is per kernel: the cheapest kind fits 64 VGPRs (8 waves / SIMD), the most
+// expensive needs 170 (2 waves), and inside one kernel everybody paid for the maximum.
 struct WaveDesc {
   WelshParams p;
   uint32_t vbase, count;
 };
-enum : uint8_t { WG_UNIFORM = 1, WG_UNIFORM_F64 = 2 };
-template <bool FUSED, bool F64LFO>
-__global__ __launch_bounds__(kThreads, F64LFO ? GROOVE_WAVES_F64 : GROOVE_WAVES_SIMPLE) void welsh_render_uniform_kernel(
+constexpr int kWgKinds = 6;
+__host__ __device__ constexpr int wg_kind_of(int lfo_mode, bool retune) {
+  // cost order (cheap to expensive): F32 static, F32 retune, SMOOTH static, SMOOTH retune, F64 static, F64 retune
+  return (lfo_mode == LFO_F32 ? 0 : (lfo_mode == LFO_F64_SMOOTH ? 2 : 4)) + (retune ? 1 : 0);
+}
+template <int LFO_MODE, bool RETUNE> struct WavesBudget;
+template <> struct WavesBudget<LFO_F32, false> { static constexpr int value = GROOVE_WAVES_F32_STATIC; };
+template <> struct WavesBudget<LFO_F32, true> { static constexpr int value = GROOVE_WAVES_F32_RETUNE; };
+template <> struct WavesBudget<LFO_F64_SMOOTH, false> { static constexpr int value = GROOVE_WAVES_SMOOTH_STATIC; };
+template <> struct WavesBudget<LFO_F64_SMOOTH, true> { static constexpr int value = GROOVE_WAVES_SMOOTH_RETUNE; };
+template <> struct WavesBudget<LFO_F64, false> { static constexpr int value = GROOVE_WAVES_F64; };
+template <> struct WavesBudget<LFO_F64, true> { static constexpr int value = GROOVE_WAVES_F64; };
+template <bool FUSED, int LFO_MODE, bool RETUNE>
+__global__ __launch_bounds__(kThreads, (WavesBudget<LFO_MODE, RETUNE>::value)) void welsh_render_uniform_kernel(
     const WaveDesc* __restrict__ waves, uint32_t n_waves, uint32_t* __restrict__ state, uint32_t n, uint32_t frames,
-    size_t ch_stride, float* __restrict__ out, RenderConsts rc, const uint8_t* __restrict__ wg_kind) {
-  if (wg_kind[blockIdx.x] != (F64LFO ? WG_UNIFORM_F64 : WG_UNIFORM)) return;
-  // The f64-LFO kind is ~2x the work per voice and the critical path of a block: its waves get
-  // issue priority over co-resident waves of the short kind (list scheduling, longest first).
-  if (F64LFO) __builtin_amdgcn_s_setprio(2);
+    size_t ch_stride, float* __restrict__ out, RenderConsts rc, const uint32_t* __restrict__ wg_list) {
+  // The f64-LFO kinds are 2-3x the work per voice and the critical path of a block: their waves get
+  // issue priority over co-resident waves of the short kinds (list scheduling, longest first).
+  if (LFO_MODE != LFO_F32) __builtin_amdgcn_s_setprio(2);
+  const uint32_t wg = wg_list[blockIdx.x]; // scalar load: the workgroup of virtual waves this block renders
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t w0 = blockIdx.x * kWaves + (threadIdx.x >> 6);
+  const uint32_t w0 = wg * kWaves + (threadIdx.x >> 6);
   const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(w0, n_waves - 1));
   const WaveDesc d = make_scalar(waves[w]);
   const bool active = (w0 < n_waves) && (lane < d.count);
   const uint32_t v = active ? d.vbase + lane : d.vbase; // idle lanes shadow the run's first voice
   WelshState s = soa_load<WelshState>(state, n, v);
-  if (welsh_retunes(d.p)) welsh_block<FUSED, true, F64LFO>(d.p, s, rc, frames, n, v, active, ch_stride, out);
-  else welsh_block<FUSED, false, F64LFO>(d.p, s, rc, frames, n, v, active, ch_stride, out);
+  welsh_block<FUSED, RETUNE, LFO_MODE, true>(d.p, s, rc, frames, n, v, active, ch_stride, out, wg);
   if (active) soa_store(state, n, v, s);
 }
 
@@ -268,7 +350,7 @@ __global__ __launch_bounds__(kThreads) void fm_render_kernel(
   const uint32_t v = active ? v0 : n - 1;
   const FmParams p = soa_load<FmParams>(params, n, v);
   FmState s = soa_load<FmState>(state, n, v);
-  run_frames<FUSED>(frames, n, v, active, ch_stride, out, [&](uint32_t f, float& L, float& R) {
+  run_frames<FUSED>(frames, n, v, active, ch_stride, out, blockIdx.x, [&](uint32_t f, float& L, float& R) {
     if (f == 0) fm_frame<true>(p, s, L, R);
     else fm_frame<false>(p, s, L, R);
   });
@@ -285,7 +367,7 @@ __global__ __launch_bounds__(kThreads) void sampler_render_kernel(
   const uint32_t v = active ? v0 : n - 1;
   const SamplerParams p = soa_load<SamplerParams>(params, n, v);
   SamplerState s = soa_load<SamplerState>(state, n, v);
-  run_frames<FUSED>(frames, n, v, active, ch_stride, out, [&](uint32_t, float& L, float& R) {
+  run_frames<FUSED>(frames, n, v, active, ch_stride, out, blockIdx.x, [&](uint32_t, float& L, float& R) {
     L = R = sampler_frame(p, s, bank); // mono duplicated to both channels
   });
   if (active) soa_store(state, n, v, s);

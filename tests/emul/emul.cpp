@@ -10,13 +10,27 @@
 using namespace groove;
 
 struct EmulBank {
-  int kind; uint32_t n; double sr;
+  int kind; uint32_t n; double sr; int generic_lfo = 0;
   std::vector<WelshParams> wp; std::vector<WelshState> ws; std::vector<WelshCold> wc;
   std::vector<FmParams> fp; std::vector<FmState> fs; std::vector<double> ratio;
   std::vector<SamplerParams> sp; std::vector<SamplerState> ss; std::vector<float> pcm;
 };
 
+template <bool FIRST, bool RETUNE>
+static void welsh_emul_frame2(const WelshParams& p, WelshState& s, const RenderConsts& rc, WelshScratch& sc, int mode, float& L, float& R) {
+  if (mode == LFO_F32) welsh_frame<FIRST, RETUNE, LFO_F32>(p, s, rc, sc, L, R);
+  else if (mode == LFO_F64) welsh_frame<FIRST, RETUNE, LFO_F64>(p, s, rc, sc, L, R);
+  else welsh_frame<FIRST, RETUNE, LFO_F64_SMOOTH>(p, s, rc, sc, L, R);
+}
+static void welsh_emul_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc, WelshScratch& sc, bool first, bool retune,
+                             int mode, float& L, float& R) {
+  if (first) { if (retune) welsh_emul_frame2<true, true>(p, s, rc, sc, mode, L, R); else welsh_emul_frame2<true, false>(p, s, rc, sc, mode, L, R); }
+  else { if (retune) welsh_emul_frame2<false, true>(p, s, rc, sc, mode, L, R); else welsh_emul_frame2<false, false>(p, s, rc, sc, mode, L, R); }
+}
+
 extern "C" {
+// generic_lfo != 0: evaluate the f64 LFO exactly on every frame (the per-lane kernel's choice) instead of the recurrences
+void emul_set_generic_lfo(void* h, int on);
 void* emul_welsh_create(const groove_welsh_params* p, uint32_t n, uint32_t sr) {
   EmulBank* b = new EmulBank(); b->kind = 0; b->n = n; b->sr = sr;
   b->wp.resize(n); b->ws.assign(n, initial_welsh_state()); b->wc.resize(n);
@@ -40,6 +54,7 @@ void* emul_sampler_create(const float* pcm, uint64_t frames, const groove_sample
   return b;
 }
 void emul_bank_destroy(void* h) { delete (EmulBank*)h; }
+void emul_set_generic_lfo(void* h, int on) { ((EmulBank*)h)->generic_lfo = on; }
 void emul_bank_note_events(void* h, const groove_note_event* ev, uint32_t n_ev) {
   EmulBank* b = (EmulBank*)h;
   for (uint32_t i = 0; i < n_ev; ++i) {
@@ -60,12 +75,15 @@ void emul_bank_render(void* h, uint32_t frames, float* out) {
   for (uint32_t v = 0; v < n; ++v) {
     WelshScratch sc{};
     bool retunes = false;
-    if (b->kind == 0) { sc = welsh_scratch_init(b->wp[v], rc); retunes = welsh_retunes(b->wp[v]); }
+    int mode = LFO_F64;
+    if (b->kind == 0) {
+      sc = welsh_scratch_init(b->wp[v], rc); retunes = welsh_retunes(b->wp[v]);
+      mode = b->generic_lfo ? (welsh_lfo_mode(b->wp[v]) == LFO_F32 ? LFO_F32 : LFO_F64) : welsh_lfo_mode(b->wp[v]);
+    }
     for (uint32_t f = 0; f < frames; ++f) {
       float L, R;
-      if (b->kind == 0) { // mirrors the kernel: frame 0 peeled, RETUNE chosen per lane
-        if (f == 0) { if (retunes) welsh_frame<true, true>(b->wp[v], b->ws[v], rc, sc, L, R); else welsh_frame<true, false>(b->wp[v], b->ws[v], rc, sc, L, R); }
-        else { if (retunes) welsh_frame<false, true>(b->wp[v], b->ws[v], rc, sc, L, R); else welsh_frame<false, false>(b->wp[v], b->ws[v], rc, sc, L, R); }
+      if (b->kind == 0) { // mirrors the uniform kernel: frame 0 peeled, RETUNE and the LFO mode chosen per voice
+        welsh_emul_frame(b->wp[v], b->ws[v], rc, sc, f == 0, retunes, mode, L, R);
       } else if (b->kind == 1) {
         if (f == 0) fm_frame<true>(b->fp[v], b->fs[v], L, R); else fm_frame<false>(b->fp[v], b->fs[v], L, R);
       } else { L = R = sampler_frame(b->sp[v], b->ss[v], b->pcm.data()); }
