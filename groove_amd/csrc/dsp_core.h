@@ -399,16 +399,41 @@ GROOVE_HD int welsh_lfo_mode(const WelshParams& p) {
   return (p.flags & WF_LFO_SMOOTH) ? LFO_F64_SMOOTH : LFO_F64;
 }
 
+// Oscillator CLASSES: what the code of an audio oscillator can be specialised on at compile time.
+// With wave-uniform patches "which waveform" is a scalar switch taken on every frame, and on gfx950
+// the scalar pipe (one instruction per ~1.9 ns per SIMD, docs/VALU_COSTS.md) then carries as much
+// work as the vector pipe: fixing the two audio oscillators' waveforms took 34 % off a frame.  The
+// uniform kernels therefore dispatch ONCE per block on (class of oscillator 1, class of
+// oscillator 2) to a copy of the frame loop compiled for that pair.  OSC_ANY keeps the run-time
+// switch (noise, none, debug constants, triangle-sine; and every per-lane / unspecialised use).
+enum : int { OSC_ANY = 0, OSC_PULSE = 1, OSC_SAW = 2, OSC_TRIANGLE = 3, OSC_SINE = 4, OSC_CLASSES = 5 };
+GROOVE_HD int osc_class_of(uint32_t waveform) {
+  switch (waveform) {
+    case GROOVE_WAVE_SQUARE:
+    case GROOVE_WAVE_PULSE_WIDTH: return OSC_PULSE; // same code; a square is duty 0.5
+    case GROOVE_WAVE_SAWTOOTH: return OSC_SAW;
+    case GROOVE_WAVE_TRIANGLE: return OSC_TRIANGLE;
+    case GROOVE_WAVE_SINE: return OSC_SINE;
+    default: return OSC_ANY;
+  }
+}
+template <int CLS>
+GROOVE_HD uint32_t osc_class_wave(uint32_t runtime_waveform) {
+  return CLS == OSC_PULSE ? (uint32_t)GROOVE_WAVE_PULSE_WIDTH : CLS == OSC_SAW ? (uint32_t)GROOVE_WAVE_SAWTOOTH
+       : CLS == OSC_TRIANGLE ? (uint32_t)GROOVE_WAVE_TRIANGLE : CLS == OSC_SINE ? (uint32_t)GROOVE_WAVE_SINE : runtime_waveform;
+}
+
 // One frame of one voice.  FIRST: this is frame 0 of a render call (the only frame on which
 // VF_FIRST can be set).  RETUNE: false promises !welsh_retunes(p) for every lane, so the
-// coefficients in `sc` are loop-invariant.  LFO_MODE: see above.
-template <bool FIRST, bool RETUNE, int LFO_MODE = LFO_F64>
+// coefficients in `sc` are loop-invariant.  LFO_MODE: see above.  C1, C2: promise that every lane's
+// oscillator 1 / 2 waveform is of that class (OSC_ANY promises nothing).
+template <bool FIRST, bool RETUNE, int LFO_MODE = LFO_F64, int C1 = OSC_ANY, int C2 = OSC_ANY>
 GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc,
                            WelshScratch& sc, float& L, float& R) {
   env_tick(s.amp, p.amp);
   env_tick(s.fil, p.fil);
   if (s.amp.state == ENV_IDLE) { L = 0.0f; R = 0.0f; return; }
-  const uint32_t w1 = (p.flags >> WF_O1_WAVE_SHIFT) & 15u, w2 = (p.flags >> WF_O2_WAVE_SHIFT) & 15u;
+  const uint32_t w1 = osc_class_wave<C1>((p.flags >> WF_O1_WAVE_SHIFT) & 15u), w2 = osc_class_wave<C2>((p.flags >> WF_O2_WAVE_SHIFT) & 15u);
   const uint32_t wl = (p.flags >> WF_LFO_WAVE_SHIFT) & 15u, routing = (p.flags >> WF_ROUTING_SHIFT) & 15u;
   const bool first = FIRST && (s.vflags & VF_FIRST);
   if (FIRST) s.vflags = 0;

@@ -39,6 +39,7 @@ struct groove_bank {
   WaveDesc* d_waves = nullptr;   // welsh: virtual waves (runs of <= 64 voices sharing a patch)
   uint32_t n_vwaves = 0;         // 0: the bank runs on the per-lane kernel
   size_t vwaves_cap = 0;
+  uint8_t* d_wg_cls = nullptr;   // welsh: oscillator class pair of each entry of d_wg_list
   uint32_t* d_wg_list = nullptr; // welsh: workgroup ids (groups of 4 virtual waves) sorted by kind (kernels.h)
   size_t wg_list_cap = 0;
   uint32_t wgs_of_kind[kWgKinds] = {};  // slice lengths of d_wg_list, in kind order
@@ -71,12 +72,13 @@ struct groove_fx {
   ReverbGeom geo{};
 };
 
+constexpr int kSideStreams = kBaseKinds - 1; // + the ctx stream: one per base kind
 struct groove_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = true;
-  hipStream_t side_stream[kWgKinds - 1] = {}; // kernels of the other workgroup kinds run beside the main one
-  hipEvent_t ev_fork = nullptr, ev_join[kWgKinds - 1] = {};
+  hipStream_t side_stream[kSideStreams] = {}; // kernels of the other workgroup kinds run beside the main one
+  hipEvent_t ev_fork = nullptr, ev_join[kSideStreams] = {};
   uint32_t sr = GROOVE_DEFAULT_SAMPLE_RATE;
   std::string err;
   std::vector<groove_bank*> banks;
@@ -167,19 +169,35 @@ int welsh_upload_params(groove_bank* b) {
   b->n_vwaves = (uint32_t)W.size();
   const uint32_t wgs = (b->n_vwaves + kWaves - 1) / kWaves;
   // a workgroup runs in the instantiation its most demanding wave needs (kernels.h, "Workgroup KINDS")
-  std::vector<uint8_t> kind(wgs, 0);
+  struct Need { int rank = 0; bool retune = false; int c1 = -1, c2 = -1; };
+  std::vector<Need> need(wgs);
   for (uint32_t w = 0; w < b->n_vwaves; ++w) {
-    const int mode = welsh_lfo_mode(W[w].p);
-    const int rank = mode == LFO_F32 ? 0 : (mode == LFO_F64_SMOOTH ? 1 : 2);
-    uint8_t& k = kind[w / kWaves]; // kept as (rank << 1) | retune while merging
-    k = (uint8_t)((std::max<int>(k >> 1, rank) << 1) | ((k & 1) | (welsh_retunes(W[w].p) ? 1 : 0)));
+    const WelshParams& p = W[w].p;
+    const int mode = welsh_lfo_mode(p);
+    Need& k = need[w / kWaves];
+    k.rank = std::max(k.rank, mode == LFO_F32 ? 0 : (mode == LFO_F64_SMOOTH ? 1 : 2));
+    k.retune = k.retune || welsh_retunes(p);
+    const int c1 = osc_class_of((p.flags >> WF_O1_WAVE_SHIFT) & 15u), c2 = osc_class_of((p.flags >> WF_O2_WAVE_SHIFT) & 15u);
+    k.c1 = k.c1 < 0 ? c1 : (k.c1 == c1 ? c1 : (int)OSC_ANY); // waves that disagree fall back to the run-time switch
+    k.c2 = k.c2 < 0 ? c2 : (k.c2 == c2 ? c2 : (int)OSC_ANY);
+  }
+  std::vector<uint16_t> kind(wgs);
+  for (uint32_t g = 0; g < wgs; ++g) {
+    const int base = need[g].rank * 2 + (need[g].retune ? 1 : 0); // == wg_base_kind_of()
+    const bool spec = wg_base_kind_specialised(base);
+    kind[g] = (uint16_t)wg_kind_of(base, spec ? std::max(need[g].c1, 0) : (int)OSC_ANY, spec ? std::max(need[g].c2, 0) : (int)OSC_ANY);
   }
   std::vector<uint32_t> wg_list(wgs);
+  std::vector<uint8_t> wg_cls(wgs);
   {
-    uint32_t at[kWgKinds + 1] = {};
-    for (uint8_t k : kind) b->wgs_of_kind[k] += 1; // (rank << 1) | retune is exactly wg_kind_of()'s numbering
+    std::vector<uint32_t> at(kWgKinds + 1, 0);
+    for (uint16_t k : kind) b->wgs_of_kind[k] += 1;
     for (int k = 0; k < kWgKinds; ++k) at[k + 1] = at[k] + b->wgs_of_kind[k];
-    for (uint32_t g = 0; g < wgs; ++g) wg_list[at[kind[g]]++] = g;
+    for (uint32_t g = 0; g < wgs; ++g) {
+      const uint32_t slot = at[kind[g]]++;
+      wg_list[slot] = g;
+      wg_cls[slot] = (uint8_t)(kind[g] % (OSC_CLASSES * OSC_CLASSES));
+    }
   }
   if (b->vwaves_cap < W.size()) {
     if (b->d_waves) GHIP(ctx, hipFree(b->d_waves));
@@ -190,9 +208,12 @@ int welsh_upload_params(groove_bank* b) {
     if (b->d_wg_list) GHIP(ctx, hipFree(b->d_wg_list));
     b->wg_list_cap = wgs + wgs / 8 + 16;
     GHIP(ctx, hipMalloc(&b->d_wg_list, b->wg_list_cap * sizeof(uint32_t)));
+    if (b->d_wg_cls) GHIP(ctx, hipFree(b->d_wg_cls));
+    GHIP(ctx, hipMalloc(&b->d_wg_cls, b->wg_list_cap));
   }
   GHIP(ctx, hipMemcpy(b->d_waves, W.data(), W.size() * sizeof(WaveDesc), hipMemcpyHostToDevice));
   GHIP(ctx, hipMemcpy(b->d_wg_list, wg_list.data(), (size_t)wgs * sizeof(uint32_t), hipMemcpyHostToDevice));
+  GHIP(ctx, hipMemcpy(b->d_wg_cls, wg_cls.data(), wgs, hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -473,7 +494,7 @@ int groove_init(int device_ordinal, groove_ctx** out) {
   ctx->device = device_ordinal;
   bool ok = hipSetDevice(device_ordinal) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
-  for (int i = 0; ok && i < kWgKinds - 1; ++i)
+  for (int i = 0; ok && i < kSideStreams; ++i)
     ok = hipStreamCreateWithFlags(&ctx->side_stream[i], hipStreamNonBlocking) == hipSuccess &&
          hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
   if (!ok) {
@@ -495,7 +516,7 @@ void groove_shutdown(groove_ctx* ctx) {
   if (ctx->d_fseg) (void)hipFree(ctx->d_fseg);
   if (ctx->d_i16) (void)hipFree(ctx->d_i16);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
-  for (int i = 0; i < kWgKinds - 1; ++i) {
+  for (int i = 0; i < kSideStreams; ++i) {
     if (ctx->side_stream[i]) { (void)hipStreamSynchronize(ctx->side_stream[i]); (void)hipStreamDestroy(ctx->side_stream[i]); }
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
   }
@@ -653,7 +674,7 @@ int groove_bank_destroy(groove_bank* b) {
   auto it = std::find(ctx->banks.begin(), ctx->banks.end(), b);
   if (it != ctx->banks.end()) ctx->banks.erase(it);
   if (b->scratch) groove_block_destroy(b->scratch);
-  (void)hipFree(b->d_params); (void)hipFree(b->d_state); (void)hipFree(b->d_cold); (void)hipFree(b->d_pcm); (void)hipFree(b->d_ev); (void)hipFree(b->d_waves); (void)hipFree(b->d_wg_list);
+  (void)hipFree(b->d_params); (void)hipFree(b->d_state); (void)hipFree(b->d_cold); (void)hipFree(b->d_pcm); (void)hipFree(b->d_ev); (void)hipFree(b->d_waves); (void)hipFree(b->d_wg_list); (void)hipFree(b->d_wg_cls);
   delete b;
   return 0;
 }
@@ -696,41 +717,55 @@ static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs
       if (fused) hipLaunchKernelGGL(welsh_render_kernel<true>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, rc);
       else hipLaunchKernelGGL(welsh_render_kernel<false>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, rc);
     } else {
-      // One kernel per workgroup kind present, all running concurrently: the most expensive kind
-      // goes out first on the ctx stream (list scheduling, longest first), the others on side
-      // streams forked from it, and the ctx stream joins them before the bus reduction.
+      // One kernel per base kind present, all running concurrently: the most expensive kind goes
+      // out first on the ctx stream (list scheduling, longest first), the others on side streams
+      // forked from it, and the ctx stream joins them before the bus reduction.
+      uint32_t count[kBaseKinds] = {}, offset[kBaseKinds] = {};
+      {
+        uint32_t at = 0;
+        for (int base = 0; base < kBaseKinds; ++base) {
+          offset[base] = at;
+          for (int c = 0; c < OSC_CLASSES * OSC_CLASSES; ++c) count[base] += b->wgs_of_kind[base * OSC_CLASSES * OSC_CLASSES + c];
+          at += count[base];
+        }
+      }
       int present = 0;
-      for (uint32_t c : b->wgs_of_kind) present += c ? 1 : 0;
+      for (uint32_t c : count) present += c ? 1 : 0;
       if (present > 1) GHIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-      uint32_t offset[kWgKinds];
-      for (uint32_t k = 0, at = 0; k < (uint32_t)kWgKinds; ++k) { offset[k] = at; at += b->wgs_of_kind[k]; }
       int side = 0;
       bool first_kind = true;
-      for (int k = kWgKinds - 1; k >= 0; --k) {
-        if (!b->wgs_of_kind[k]) continue;
+      for (int k = kBaseKinds - 1; k >= 0; --k) {
+        if (!count[k]) continue;
         hipStream_t st = ctx->stream;
         if (!first_kind) {
           st = ctx->side_stream[side];
           GHIP(ctx, hipStreamWaitEvent(st, ctx->ev_fork, 0));
         }
-        const dim3 kgrid(b->wgs_of_kind[k]);
-        const uint32_t* list = b->d_wg_list + offset[k];
-#define GROOVE_LAUNCH_UNIFORM(MODE, RETUNE)                                                                                    \
-  do {                                                                                                                         \
-    if (fused) hipLaunchKernelGGL((welsh_render_uniform_kernel<true, MODE, RETUNE>), kgrid, blk, 0, st, b->d_waves,             \
-                                  b->n_vwaves, b->d_state, b->n, frames, chs, out, rc, list);                                  \
-    else hipLaunchKernelGGL((welsh_render_uniform_kernel<false, MODE, RETUNE>), kgrid, blk, 0, st, b->d_waves, b->n_vwaves,     \
-                            b->d_state, b->n, frames, chs, out, rc, list);                                                     \
+        UniformArgs a{b->d_waves, b->d_state, out, b->d_wg_list + offset[k], b->d_wg_cls + offset[k], chs, rc, b->n_vwaves, b->n, frames, count[k]};
+        const dim3 kgrid(count[k]);
+        if (fused && wg_base_kind_specialised(k)) {
+          switch (k) {
+            case 0: launch_welsh_uniform_specialised_0(a, st); break;
+            case 1: launch_welsh_uniform_specialised_1(a, st); break;
+            case 2: launch_welsh_uniform_specialised_2(a, st); break;
+            default: launch_welsh_uniform_specialised_3(a, st); break;
+          }
+        } else {
+#define GROOVE_LAUNCH_UNIFORM(MODE, RETUNE)                                                                              \
+  do {                                                                                                                   \
+    if (fused) hipLaunchKernelGGL((welsh_render_uniform_kernel<true, MODE, RETUNE, false>), kgrid, blk, 0, st, a);        \
+    else hipLaunchKernelGGL((welsh_render_uniform_kernel<false, MODE, RETUNE, false>), kgrid, blk, 0, st, a);             \
   } while (0)
-        switch (k) {
-          case wg_kind_of(LFO_F32, false): GROOVE_LAUNCH_UNIFORM(LFO_F32, false); break;
-          case wg_kind_of(LFO_F32, true): GROOVE_LAUNCH_UNIFORM(LFO_F32, true); break;
-          case wg_kind_of(LFO_F64_SMOOTH, false): GROOVE_LAUNCH_UNIFORM(LFO_F64_SMOOTH, false); break;
-          case wg_kind_of(LFO_F64_SMOOTH, true): GROOVE_LAUNCH_UNIFORM(LFO_F64_SMOOTH, true); break;
-          case wg_kind_of(LFO_F64, false): GROOVE_LAUNCH_UNIFORM(LFO_F64, false); break;
-          default: GROOVE_LAUNCH_UNIFORM(LFO_F64, true); break;
-        }
+          switch (k) {
+            case wg_base_kind_of(LFO_F32, false): GROOVE_LAUNCH_UNIFORM(LFO_F32, false); break;
+            case wg_base_kind_of(LFO_F32, true): GROOVE_LAUNCH_UNIFORM(LFO_F32, true); break;
+            case wg_base_kind_of(LFO_F64_SMOOTH, false): GROOVE_LAUNCH_UNIFORM(LFO_F64_SMOOTH, false); break;
+            case wg_base_kind_of(LFO_F64_SMOOTH, true): GROOVE_LAUNCH_UNIFORM(LFO_F64_SMOOTH, true); break;
+            case wg_base_kind_of(LFO_F64, false): GROOVE_LAUNCH_UNIFORM(LFO_F64, false); break;
+            default: GROOVE_LAUNCH_UNIFORM(LFO_F64, true); break;
+          }
 #undef GROOVE_LAUNCH_UNIFORM
+        }
         if (!first_kind) {
           GHIP(ctx, hipEventRecord(ctx->ev_join[side], st));
           GHIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[side], 0));

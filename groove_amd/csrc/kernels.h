@@ -257,7 +257,7 @@ __device__ __forceinline__ void run_frames_peeled(uint32_t frames, uint32_t n, u
 // a5 WelshVoice: Ticks::tick(frames) + Generates::generate_batch_values.
 // Frame 0 is peeled (first-tick flag); RETUNE=false variants keep the filter coefficients
 // loop-invariant so their f64 widening is hoisted out of the frame loop.
-template <bool FUSED, bool RETUNE, int LFO_MODE = LFO_F64, bool UNIFORM = false>
+template <bool FUSED, bool RETUNE, int LFO_MODE = LFO_F64, bool UNIFORM = false, int C1 = OSC_ANY, int C2 = OSC_ANY>
 __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s, const RenderConsts& rc,
                                             uint32_t frames, uint32_t n, uint32_t v, bool active,
                                             size_t ch_stride, float* __restrict__ out, uint32_t prow) {
@@ -267,12 +267,12 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
   if (UNIFORM && !RETUNE) sc.coef = make_scalar(sc.coef);
   if constexpr (UNIFORM && LFO_MODE != LFO_F32) {
     run_frames_peeled<FUSED>(frames, n, v, active, ch_stride, out, prow,
-                             [&](float& L, float& R) { welsh_frame<true, RETUNE, LFO_MODE>(p, s, rc, sc, L, R); },
-                             [&](uint32_t, float& L, float& R) { welsh_frame<false, RETUNE, LFO_MODE>(p, s, rc, sc, L, R); });
+                             [&](float& L, float& R) { welsh_frame<true, RETUNE, LFO_MODE, C1, C2>(p, s, rc, sc, L, R); },
+                             [&](uint32_t, float& L, float& R) { welsh_frame<false, RETUNE, LFO_MODE, C1, C2>(p, s, rc, sc, L, R); });
   } else {
     run_frames<FUSED>(frames, n, v, active, ch_stride, out, prow, [&](uint32_t f, float& L, float& R) {
-      if (f == 0) welsh_frame<true, RETUNE, LFO_MODE>(p, s, rc, sc, L, R);
-      else welsh_frame<false, RETUNE, LFO_MODE>(p, s, rc, sc, L, R);
+      if (f == 0) welsh_frame<true, RETUNE, LFO_MODE, C1, C2>(p, s, rc, sc, L, R);
+      else welsh_frame<false, RETUNE, LFO_MODE, C1, C2>(p, s, rc, sc, L, R);
     });
   }
 }
@@ -298,23 +298,36 @@ __global__ __launch_bounds__(kThreads) void welsh_render_kernel(
 // branching — and works on voices [vbase, vbase + count).
 //
 // Workgroup KINDS.  What a patch needs decides which instantiation (code + register budget) its
-// workgroup runs in: the LFO mode (dsp_core.h: none in f64 / smooth recurrences / exact f64) times
-// whether the filter is retuned per frame (envelope- or LFO-driven cutoff: per-lane f64
-// coefficients, the tan / reciprocal path) or static (coefficients in SGPRs).  A workgroup takes
-// the most demanding kind among its four waves.  The host sorts workgroup ids by kind into
-// wg_list; every kind present is launched over its own slice of the list, all concurrently on
-// forked streams.  Separate kernels (rather than one kernel with scalar branches) because
-// register allocation is per kernel: the cheapest kind fits 64 VGPRs (8 waves / SIMD), the most
-// expensive needs 170 (2 waves), and inside one kernel everybody paid for the maximum.
+// workgroup runs in:
+//   - the LFO mode (dsp_core.h: none in f64 / smooth recurrences / exact f64) and whether the
+//     filter is retuned per frame (envelope- or LFO-driven cutoff: per-lane f64 coefficients, the
+//     tan / reciprocal path) or static (coefficients in SGPRs): six BASE KINDS, one kernel each,
+//     launched concurrently on forked streams over their slices of a kind-sorted workgroup list.
+//     Separate kernels because register allocation is per kernel: the cheapest base kind fits 72
+//     VGPRs (7 waves / SIMD), the most expensive needs 133 (3 waves); inside one kernel everybody
+//     paid for the maximum.
+//   - the CLASSES of the two audio oscillators (dsp_core.h, "Oscillator CLASSES"): inside the fused
+//     kernels of the first four base kinds, one scalar switch per workgroup calls the copy of the
+//     whole block body compiled for its class pair (5 x 5 copies).  The copies are NOT inlined:
+//     each is a function with its own register allocation (inlined, their hoisted loop invariants
+//     all became live across the switch and every copy spilled in its hot loop), and all copies of
+//     a base kind need about the same registers, so the kernel's budget fits them all.  (One kernel
+//     per class pair was tried too: 32 small launches per block do not run concurrently - the
+//     hardware queues are few - and the block took 1.5x as long.)
+// A workgroup takes the most demanding base kind among its four waves, and OSC_ANY where they
+// disagree on a class.
 struct WaveDesc {
   WelshParams p;
   uint32_t vbase, count;
 };
-constexpr int kWgKinds = 6;
-__host__ __device__ constexpr int wg_kind_of(int lfo_mode, bool retune) {
+constexpr int kBaseKinds = 6;                                     // LFO mode x retune
+constexpr int kWgKinds = kBaseKinds * OSC_CLASSES * OSC_CLASSES;  // x class pair (sort key of the workgroup list)
+__host__ __device__ constexpr int wg_base_kind_of(int lfo_mode, bool retune) {
   // cost order (cheap to expensive): F32 static, F32 retune, SMOOTH static, SMOOTH retune, F64 static, F64 retune
   return (lfo_mode == LFO_F32 ? 0 : (lfo_mode == LFO_F64_SMOOTH ? 2 : 4)) + (retune ? 1 : 0);
 }
+__host__ __device__ constexpr int wg_kind_of(int base_kind, int c1, int c2) { return (base_kind * OSC_CLASSES + c1) * OSC_CLASSES + c2; }
+__host__ __device__ constexpr bool wg_base_kind_specialised(int base_kind) { return base_kind < 4; } // exact-f64 kinds keep OSC_ANY
 template <int LFO_MODE, bool RETUNE> struct WavesBudget;
 template <> struct WavesBudget<LFO_F32, false> { static constexpr int value = GROOVE_WAVES_F32_STATIC; };
 template <> struct WavesBudget<LFO_F32, true> { static constexpr int value = GROOVE_WAVES_F32_RETUNE; };
@@ -322,24 +335,66 @@ template <> struct WavesBudget<LFO_F64_SMOOTH, false> { static constexpr int val
 template <> struct WavesBudget<LFO_F64_SMOOTH, true> { static constexpr int value = GROOVE_WAVES_SMOOTH_RETUNE; };
 template <> struct WavesBudget<LFO_F64, false> { static constexpr int value = GROOVE_WAVES_F64; };
 template <> struct WavesBudget<LFO_F64, true> { static constexpr int value = GROOVE_WAVES_F64; };
-template <bool FUSED, int LFO_MODE, bool RETUNE>
-__global__ __launch_bounds__(kThreads, (WavesBudget<LFO_MODE, RETUNE>::value)) void welsh_render_uniform_kernel(
-    const WaveDesc* __restrict__ waves, uint32_t n_waves, uint32_t* __restrict__ state, uint32_t n, uint32_t frames,
-    size_t ch_stride, float* __restrict__ out, RenderConsts rc, const uint32_t* __restrict__ wg_list) {
-  // The f64-LFO kinds are 2-3x the work per voice and the critical path of a block: their waves get
-  // issue priority over co-resident waves of the short kinds (list scheduling, longest first).
-  if (LFO_MODE != LFO_F32) __builtin_amdgcn_s_setprio(2);
-  const uint32_t wg = wg_list[blockIdx.x]; // scalar load: the workgroup of virtual waves this block renders
+// The one kernel argument (so that the non-inlined bodies can read it from the kernarg segment
+// with scalar loads instead of taking a dozen uniform values through VGPR arguments).
+struct UniformArgs {
+  const WaveDesc* waves; uint32_t* state; float* out; const uint32_t* wg_list; const uint8_t* wg_cls;
+  size_t ch_stride; RenderConsts rc; uint32_t n_waves, n, frames, n_wgs;
+};
+typedef const __attribute__((address_space(4))) UniformArgs* UniformArgsPtr; // kernarg segment: scalar loads
+__device__ __forceinline__ UniformArgsPtr uniform_args_scalar(UniformArgsPtr a) { // arguments of a call travel in VGPRs
+  const uint64_t bits = (uint64_t)a;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bits);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bits >> 32));
+  return (UniformArgsPtr)(((uint64_t)hi << 32) | lo);
+}
+template <bool FUSED, int LFO_MODE, bool RETUNE, int C1, int C2>
+__device__ __forceinline__ void welsh_uniform_body_impl(UniformArgsPtr a) {
+  const uint32_t wg = a->wg_list[blockIdx.x]; // scalar load: the workgroup of virtual waves this block renders
+  const uint32_t n_waves = a->n_waves, n = a->n;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t w0 = wg * kWaves + (threadIdx.x >> 6);
   const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(w0, n_waves - 1));
-  const WaveDesc d = make_scalar(waves[w]);
+  const WaveDesc d = make_scalar(a->waves[w]);
   const bool active = (w0 < n_waves) && (lane < d.count);
   const uint32_t v = active ? d.vbase + lane : d.vbase; // idle lanes shadow the run's first voice
-  WelshState s = soa_load<WelshState>(state, n, v);
-  welsh_block<FUSED, RETUNE, LFO_MODE, true>(d.p, s, rc, frames, n, v, active, ch_stride, out, wg);
-  if (active) soa_store(state, n, v, s);
+  WelshState s = soa_load<WelshState>(a->state, n, v);
+  const RenderConsts rc{a->rc.pi_over_sr, a->rc.fc_max};
+  welsh_block<FUSED, RETUNE, LFO_MODE, true, C1, C2>(d.p, s, rc, a->frames, n, v, active, a->ch_stride, a->out, wg);
+  if (active) soa_store(a->state, n, v, s);
 }
+template <bool FUSED, int LFO_MODE, bool RETUNE, int C1, int C2>
+__device__ __attribute__((noinline)) void welsh_uniform_body(UniformArgsPtr a) {
+  welsh_uniform_body_impl<FUSED, LFO_MODE, RETUNE, C1, C2>(uniform_args_scalar(a));
+}
+// SPECIALISED = false: the whole launch runs the OSC_ANY x OSC_ANY body (wg_cls is not read).
+template <bool FUSED, int LFO_MODE, bool RETUNE, bool SPECIALISED>
+__global__ __launch_bounds__(kThreads, (WavesBudget<LFO_MODE, RETUNE>::value)) void welsh_render_uniform_kernel(UniformArgs a) {
+  // The f64-LFO kinds are 2-3x the work per voice and the critical path of a block: their waves get
+  // issue priority over co-resident waves of the short kinds (list scheduling, longest first).
+  if (LFO_MODE != LFO_F32) __builtin_amdgcn_s_setprio(2);
+  const UniformArgsPtr ka = (UniformArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(); // == &a, in the constant address space
+  if constexpr (!SPECIALISED) {
+    welsh_uniform_body_impl<FUSED, LFO_MODE, RETUNE, OSC_ANY, OSC_ANY>(ka);
+  } else {
+    const uint32_t cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[blockIdx.x]); // c1 * OSC_CLASSES + c2
+#define GROOVE_CLS_CASE(C1, C2) case (C1) * OSC_CLASSES + (C2): welsh_uniform_body<FUSED, LFO_MODE, RETUNE, C1, C2>(ka); break;
+#define GROOVE_CLS_ROW(C1) GROOVE_CLS_CASE(C1, 0) GROOVE_CLS_CASE(C1, 1) GROOVE_CLS_CASE(C1, 2) GROOVE_CLS_CASE(C1, 3) GROOVE_CLS_CASE(C1, 4)
+    switch (cls) {
+      GROOVE_CLS_ROW(0) GROOVE_CLS_ROW(1) GROOVE_CLS_ROW(2) GROOVE_CLS_ROW(3) GROOVE_CLS_ROW(4)
+      default: break;
+    }
+#undef GROOVE_CLS_ROW
+#undef GROOVE_CLS_CASE
+  }
+}
+static_assert(OSC_CLASSES == 5, "the class switch above lists 5 x 5 pairs");
+// Launchers of the four class-specialised fused kernels, one translation unit each
+// (csrc/welsh_class.hip, -DGROOVE_BASE_KIND=0..3) so that they compile in parallel.
+void launch_welsh_uniform_specialised_0(const UniformArgs& a, hipStream_t st);
+void launch_welsh_uniform_specialised_1(const UniformArgs& a, hipStream_t st);
+void launch_welsh_uniform_specialised_2(const UniformArgs& a, hipStream_t st);
+void launch_welsh_uniform_specialised_3(const UniformArgs& a, hipStream_t st);
 
 template <bool FUSED>
 __global__ __launch_bounds__(kThreads) void fm_render_kernel(
@@ -373,6 +428,7 @@ __global__ __launch_bounds__(kThreads) void sampler_render_kernel(
   if (active) soa_store(state, n, v, s);
 }
 
+#ifndef GROOVE_WELSH_CLASS_TU // everything below is defined once, in groove_hip.hip
 // Fused path, stage 2: column sums of partial[rows][cols] (cols = 2*frames) over row segments.
 __global__ __launch_bounds__(kThreads) void partial_rows_kernel(
     const float* __restrict__ partial, uint32_t rows, uint32_t cols, uint32_t rows_per_seg,
@@ -870,5 +926,7 @@ __global__ __launch_bounds__(kThreads) void fx_reverb_allpass_kernel(
     for (int i = 0; i < 2; ++i) { pos[i] += c_n; if (pos[i] >= geo.N[4 + i]) pos[i] -= geo.N[4 + i]; }
   }
 }
+
+#endif // GROOVE_WELSH_CLASS_TU
 
 } // namespace groove

@@ -1,0 +1,31 @@
+// welsh_class.hip — the fused, class-specialised uniform Welsh kernel of ONE base kind (compiled
+// four times, -DGROOVE_BASE_KIND=0..3, so the 4 x 25 block bodies build in parallel).  See
+// kernels.h, "Workgroup KINDS".
+#define GROOVE_WELSH_CLASS_TU 1
+#include "kernels.h"
+#ifndef GROOVE_BASE_KIND
+#error "compile with -DGROOVE_BASE_KIND=<0..3>"
+#endif
+namespace groove {
+#if GROOVE_BASE_KIND == 0
+void launch_welsh_uniform_specialised_0(const UniformArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL((welsh_render_uniform_kernel<true, LFO_F32, false, true>), dim3(a.n_wgs), dim3(kThreads), 0, st, a);
+}
+#elif GROOVE_BASE_KIND == 1
+void launch_welsh_uniform_specialised_1(const UniformArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL((welsh_render_uniform_kernel<true, LFO_F32, true, true>), dim3(a.n_wgs), dim3(kThreads), 0, st, a);
+}
+#elif GROOVE_BASE_KIND == 2
+void launch_welsh_uniform_specialised_2(const UniformArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL((welsh_render_uniform_kernel<true, LFO_F64_SMOOTH, false, true>), dim3(a.n_wgs), dim3(kThreads), 0, st, a);
+}
+#elif GROOVE_BASE_KIND == 3
+void launch_welsh_uniform_specialised_3(const UniformArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL((welsh_render_uniform_kernel<true, LFO_F64_SMOOTH, true, true>), dim3(a.n_wgs), dim3(kThreads), 0, st, a);
+}
+#else
+#error "GROOVE_BASE_KIND out of range"
+#endif
+static_assert(wg_base_kind_of(LFO_F32, false) == 0 && wg_base_kind_of(LFO_F32, true) == 1 &&
+              wg_base_kind_of(LFO_F64_SMOOTH, false) == 2 && wg_base_kind_of(LFO_F64_SMOOTH, true) == 3, "base kind numbering");
+} // namespace groove
