@@ -407,6 +407,9 @@ GROOVE_HD int welsh_lfo_mode(const WelshParams& p) {
 // oscillator 2) to a copy of the frame loop compiled for that pair.  OSC_ANY keeps the run-time
 // switch (noise, none, debug constants, triangle-sine; and every per-lane / unspecialised use).
 enum : int { OSC_ANY = 0, OSC_PULSE = 1, OSC_SAW = 2, OSC_TRIANGLE = 3, OSC_SINE = 4, OSC_CLASSES = 5 };
+// The LFO has the same classes (its waveform, when its value is used) plus LFO_UNUSED: routed nowhere
+// and not a noise LFO, so only its phase advances.
+enum : int { LFO_UNUSED = OSC_CLASSES, LFO_CLASSES = OSC_CLASSES + 1 };
 GROOVE_HD int osc_class_of(uint32_t waveform) {
   switch (waveform) {
     case GROOVE_WAVE_SQUARE:
@@ -417,6 +420,10 @@ GROOVE_HD int osc_class_of(uint32_t waveform) {
     default: return OSC_ANY;
   }
 }
+GROOVE_HD int lfo_class_of(uint32_t waveform, uint32_t routing) {
+  if (routing == GROOVE_LFO_NONE) return waveform == GROOVE_WAVE_NOISE ? (int)OSC_ANY : (int)LFO_UNUSED;
+  return osc_class_of(waveform);
+}
 template <int CLS>
 GROOVE_HD uint32_t osc_class_wave(uint32_t runtime_waveform) {
   return CLS == OSC_PULSE ? (uint32_t)GROOVE_WAVE_PULSE_WIDTH : CLS == OSC_SAW ? (uint32_t)GROOVE_WAVE_SAWTOOTH
@@ -425,16 +432,21 @@ GROOVE_HD uint32_t osc_class_wave(uint32_t runtime_waveform) {
 
 // One frame of one voice.  FIRST: this is frame 0 of a render call (the only frame on which
 // VF_FIRST can be set).  RETUNE: false promises !welsh_retunes(p) for every lane, so the
-// coefficients in `sc` are loop-invariant.  LFO_MODE: see above.  C1, C2: promise that every lane's
-// oscillator 1 / 2 waveform is of that class (OSC_ANY promises nothing).
-template <bool FIRST, bool RETUNE, int LFO_MODE = LFO_F64, int C1 = OSC_ANY, int C2 = OSC_ANY>
+// coefficients in `sc` are loop-invariant.  LFO_MODE: see above.  C1, C2, CL: promise that every
+// lane's oscillator 1 / oscillator 2 / LFO is of that class (OSC_ANY promises nothing).
+template <bool FIRST, bool RETUNE, int LFO_MODE = LFO_F64, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY>
 GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc,
                            WelshScratch& sc, float& L, float& R) {
   env_tick(s.amp, p.amp);
   env_tick(s.fil, p.fil);
   if (s.amp.state == ENV_IDLE) { L = 0.0f; R = 0.0f; return; }
   const uint32_t w1 = osc_class_wave<C1>((p.flags >> WF_O1_WAVE_SHIFT) & 15u), w2 = osc_class_wave<C2>((p.flags >> WF_O2_WAVE_SHIFT) & 15u);
-  const uint32_t wl = (p.flags >> WF_LFO_WAVE_SHIFT) & 15u, routing = (p.flags >> WF_ROUTING_SHIFT) & 15u;
+  // LFO class: an unused LFO has no routing; a classed LFO in a static-filter f32 kind can only be
+  // routed to the amplitude (cutoff routing retunes, pitch / pulse width are other LFO modes)
+  const uint32_t wl = CL == LFO_UNUSED ? (uint32_t)GROOVE_WAVE_NONE : osc_class_wave<CL>((p.flags >> WF_LFO_WAVE_SHIFT) & 15u);
+  const uint32_t routing = CL == LFO_UNUSED ? (uint32_t)GROOVE_LFO_NONE
+                         : (CL != OSC_ANY && LFO_MODE == LFO_F32 && !RETUNE) ? (uint32_t)GROOVE_LFO_AMPLITUDE
+                         : (p.flags >> WF_ROUTING_SHIFT) & 15u;
   const bool first = FIRST && (s.vflags & VF_FIRST);
   if (FIRST) s.vflags = 0;
 

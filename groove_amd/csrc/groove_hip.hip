@@ -169,7 +169,7 @@ int welsh_upload_params(groove_bank* b) {
   b->n_vwaves = (uint32_t)W.size();
   const uint32_t wgs = (b->n_vwaves + kWaves - 1) / kWaves;
   // a workgroup runs in the instantiation its most demanding wave needs (kernels.h, "Workgroup KINDS")
-  struct Need { int rank = 0; bool retune = false; int c1 = -1, c2 = -1; };
+  struct Need { int rank = 0; bool retune = false; int c1 = -1, c2 = -1, cl = -1; };
   std::vector<Need> need(wgs);
   for (uint32_t w = 0; w < b->n_vwaves; ++w) {
     const WelshParams& p = W[w].p;
@@ -180,12 +180,17 @@ int welsh_upload_params(groove_bank* b) {
     const int c1 = osc_class_of((p.flags >> WF_O1_WAVE_SHIFT) & 15u), c2 = osc_class_of((p.flags >> WF_O2_WAVE_SHIFT) & 15u);
     k.c1 = k.c1 < 0 ? c1 : (k.c1 == c1 ? c1 : (int)OSC_ANY); // waves that disagree fall back to the run-time switch
     k.c2 = k.c2 < 0 ? c2 : (k.c2 == c2 ? c2 : (int)OSC_ANY);
+    const int cl = lfo_class_of((p.flags >> WF_LFO_WAVE_SHIFT) & 15u, (p.flags >> WF_ROUTING_SHIFT) & 15u);
+    k.cl = k.cl < 0 ? cl : (k.cl == cl ? cl : (int)OSC_ANY);
   }
   std::vector<uint16_t> kind(wgs);
   for (uint32_t g = 0; g < wgs; ++g) {
     const int base = need[g].rank * 2 + (need[g].retune ? 1 : 0); // == wg_base_kind_of()
     const bool spec = wg_base_kind_specialised(base);
-    kind[g] = (uint16_t)wg_kind_of(base, spec ? std::max(need[g].c1, 0) : (int)OSC_ANY, spec ? std::max(need[g].c2, 0) : (int)OSC_ANY);
+    int cl = spec ? std::max(need[g].cl, 0) : (int)OSC_ANY;
+    // the smooth-f64 kernels carry the sine / triangle / any LFO copies only (a mixed workgroup could ask for more)
+    if (base >= 2 && cl != OSC_SINE && cl != OSC_TRIANGLE) cl = OSC_ANY;
+    kind[g] = (uint16_t)wg_kind_of(base, cl, spec ? std::max(need[g].c1, 0) : (int)OSC_ANY, spec ? std::max(need[g].c2, 0) : (int)OSC_ANY);
   }
   std::vector<uint32_t> wg_list(wgs);
   std::vector<uint8_t> wg_cls(wgs);
@@ -196,7 +201,7 @@ int welsh_upload_params(groove_bank* b) {
     for (uint32_t g = 0; g < wgs; ++g) {
       const uint32_t slot = at[kind[g]]++;
       wg_list[slot] = g;
-      wg_cls[slot] = (uint8_t)(kind[g] % (OSC_CLASSES * OSC_CLASSES));
+      wg_cls[slot] = (uint8_t)(kind[g] % kClassCombos);
     }
   }
   if (b->vwaves_cap < W.size()) {
@@ -725,7 +730,7 @@ static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs
         uint32_t at = 0;
         for (int base = 0; base < kBaseKinds; ++base) {
           offset[base] = at;
-          for (int c = 0; c < OSC_CLASSES * OSC_CLASSES; ++c) count[base] += b->wgs_of_kind[base * OSC_CLASSES * OSC_CLASSES + c];
+          for (int c = 0; c < kClassCombos; ++c) count[base] += b->wgs_of_kind[base * kClassCombos + c];
           at += count[base];
         }
       }

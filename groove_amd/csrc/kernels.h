@@ -257,7 +257,7 @@ __device__ __forceinline__ void run_frames_peeled(uint32_t frames, uint32_t n, u
 // a5 WelshVoice: Ticks::tick(frames) + Generates::generate_batch_values.
 // Frame 0 is peeled (first-tick flag); RETUNE=false variants keep the filter coefficients
 // loop-invariant so their f64 widening is hoisted out of the frame loop.
-template <bool FUSED, bool RETUNE, int LFO_MODE = LFO_F64, bool UNIFORM = false, int C1 = OSC_ANY, int C2 = OSC_ANY>
+template <bool FUSED, bool RETUNE, int LFO_MODE = LFO_F64, bool UNIFORM = false, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY>
 __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s, const RenderConsts& rc,
                                             uint32_t frames, uint32_t n, uint32_t v, bool active,
                                             size_t ch_stride, float* __restrict__ out, uint32_t prow) {
@@ -267,12 +267,12 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
   if (UNIFORM && !RETUNE) sc.coef = make_scalar(sc.coef);
   if constexpr (UNIFORM && LFO_MODE != LFO_F32) {
     run_frames_peeled<FUSED>(frames, n, v, active, ch_stride, out, prow,
-                             [&](float& L, float& R) { welsh_frame<true, RETUNE, LFO_MODE, C1, C2>(p, s, rc, sc, L, R); },
-                             [&](uint32_t, float& L, float& R) { welsh_frame<false, RETUNE, LFO_MODE, C1, C2>(p, s, rc, sc, L, R); });
+                             [&](float& L, float& R) { welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL>(p, s, rc, sc, L, R); },
+                             [&](uint32_t, float& L, float& R) { welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL>(p, s, rc, sc, L, R); });
   } else {
     run_frames<FUSED>(frames, n, v, active, ch_stride, out, prow, [&](uint32_t f, float& L, float& R) {
-      if (f == 0) welsh_frame<true, RETUNE, LFO_MODE, C1, C2>(p, s, rc, sc, L, R);
-      else welsh_frame<false, RETUNE, LFO_MODE, C1, C2>(p, s, rc, sc, L, R);
+      if (f == 0) welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL>(p, s, rc, sc, L, R);
+      else welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL>(p, s, rc, sc, L, R);
     });
   }
 }
@@ -321,12 +321,14 @@ struct WaveDesc {
   uint32_t vbase, count;
 };
 constexpr int kBaseKinds = 6;                                     // LFO mode x retune
-constexpr int kWgKinds = kBaseKinds * OSC_CLASSES * OSC_CLASSES;  // x class pair (sort key of the workgroup list)
+constexpr int kClassCombos = LFO_CLASSES * OSC_CLASSES * OSC_CLASSES;  // (LFO class, oscillator 1 class, oscillator 2 class)
+constexpr int kWgKinds = kBaseKinds * kClassCombos;                    // sort key of the workgroup list
 __host__ __device__ constexpr int wg_base_kind_of(int lfo_mode, bool retune) {
   // cost order (cheap to expensive): F32 static, F32 retune, SMOOTH static, SMOOTH retune, F64 static, F64 retune
   return (lfo_mode == LFO_F32 ? 0 : (lfo_mode == LFO_F64_SMOOTH ? 2 : 4)) + (retune ? 1 : 0);
 }
-__host__ __device__ constexpr int wg_kind_of(int base_kind, int c1, int c2) { return (base_kind * OSC_CLASSES + c1) * OSC_CLASSES + c2; }
+__host__ __device__ constexpr int wg_class_combo(int cl, int c1, int c2) { return (cl * OSC_CLASSES + c1) * OSC_CLASSES + c2; }
+__host__ __device__ constexpr int wg_kind_of(int base_kind, int cl, int c1, int c2) { return base_kind * kClassCombos + wg_class_combo(cl, c1, c2); }
 __host__ __device__ constexpr bool wg_base_kind_specialised(int base_kind) { return base_kind < 4; } // exact-f64 kinds keep OSC_ANY
 template <int LFO_MODE, bool RETUNE> struct WavesBudget;
 template <> struct WavesBudget<LFO_F32, false> { static constexpr int value = GROOVE_WAVES_F32_STATIC; };
@@ -348,7 +350,7 @@ __device__ __forceinline__ UniformArgsPtr uniform_args_scalar(UniformArgsPtr a) 
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bits >> 32));
   return (UniformArgsPtr)(((uint64_t)hi << 32) | lo);
 }
-template <bool FUSED, int LFO_MODE, bool RETUNE, int C1, int C2>
+template <bool FUSED, int LFO_MODE, bool RETUNE, int C1, int C2, int CL>
 __device__ __forceinline__ void welsh_uniform_body_impl(UniformArgsPtr a) {
   const uint32_t wg = a->wg_list[blockIdx.x]; // scalar load: the workgroup of virtual waves this block renders
   const uint32_t n_waves = a->n_waves, n = a->n;
@@ -360,12 +362,12 @@ __device__ __forceinline__ void welsh_uniform_body_impl(UniformArgsPtr a) {
   const uint32_t v = active ? d.vbase + lane : d.vbase; // idle lanes shadow the run's first voice
   WelshState s = soa_load<WelshState>(a->state, n, v);
   const RenderConsts rc{a->rc.pi_over_sr, a->rc.fc_max};
-  welsh_block<FUSED, RETUNE, LFO_MODE, true, C1, C2>(d.p, s, rc, a->frames, n, v, active, a->ch_stride, a->out, wg);
+  welsh_block<FUSED, RETUNE, LFO_MODE, true, C1, C2, CL>(d.p, s, rc, a->frames, n, v, active, a->ch_stride, a->out, wg);
   if (active) soa_store(a->state, n, v, s);
 }
-template <bool FUSED, int LFO_MODE, bool RETUNE, int C1, int C2>
+template <bool FUSED, int LFO_MODE, bool RETUNE, int C1, int C2, int CL>
 __device__ __attribute__((noinline)) void welsh_uniform_body(UniformArgsPtr a) {
-  welsh_uniform_body_impl<FUSED, LFO_MODE, RETUNE, C1, C2>(uniform_args_scalar(a));
+  welsh_uniform_body_impl<FUSED, LFO_MODE, RETUNE, C1, C2, CL>(uniform_args_scalar(a));
 }
 // SPECIALISED = false: the whole launch runs the OSC_ANY x OSC_ANY body (wg_cls is not read).
 template <bool FUSED, int LFO_MODE, bool RETUNE, bool SPECIALISED>
@@ -375,20 +377,29 @@ __global__ __launch_bounds__(kThreads, (WavesBudget<LFO_MODE, RETUNE>::value)) v
   if (LFO_MODE != LFO_F32) __builtin_amdgcn_s_setprio(2);
   const UniformArgsPtr ka = (UniformArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(); // == &a, in the constant address space
   if constexpr (!SPECIALISED) {
-    welsh_uniform_body_impl<FUSED, LFO_MODE, RETUNE, OSC_ANY, OSC_ANY>(ka);
+    welsh_uniform_body_impl<FUSED, LFO_MODE, RETUNE, OSC_ANY, OSC_ANY, OSC_ANY>(ka);
   } else {
-    const uint32_t cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[blockIdx.x]); // c1 * OSC_CLASSES + c2
-#define GROOVE_CLS_CASE(C1, C2) case (C1) * OSC_CLASSES + (C2): welsh_uniform_body<FUSED, LFO_MODE, RETUNE, C1, C2>(ka); break;
-#define GROOVE_CLS_ROW(C1) GROOVE_CLS_CASE(C1, 0) GROOVE_CLS_CASE(C1, 1) GROOVE_CLS_CASE(C1, 2) GROOVE_CLS_CASE(C1, 3) GROOVE_CLS_CASE(C1, 4)
+    const uint32_t cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[blockIdx.x]); // wg_class_combo(cl, c1, c2)
+#define GROOVE_CLS_CASE(CL, C1, C2) case wg_class_combo(CL, C1, C2): welsh_uniform_body<FUSED, LFO_MODE, RETUNE, C1, C2, CL>(ka); break;
+#define GROOVE_CLS_ROW(CL, C1) GROOVE_CLS_CASE(CL, C1, 0) GROOVE_CLS_CASE(CL, C1, 1) GROOVE_CLS_CASE(CL, C1, 2) GROOVE_CLS_CASE(CL, C1, 3) GROOVE_CLS_CASE(CL, C1, 4)
+#define GROOVE_CLS_PLANE(CL) GROOVE_CLS_ROW(CL, 0) GROOVE_CLS_ROW(CL, 1) GROOVE_CLS_ROW(CL, 2) GROOVE_CLS_ROW(CL, 3) GROOVE_CLS_ROW(CL, 4)
     switch (cls) {
-      GROOVE_CLS_ROW(0) GROOVE_CLS_ROW(1) GROOVE_CLS_ROW(2) GROOVE_CLS_ROW(3) GROOVE_CLS_ROW(4)
-      default: break;
+      GROOVE_CLS_PLANE(OSC_ANY) GROOVE_CLS_PLANE(OSC_TRIANGLE) GROOVE_CLS_PLANE(OSC_SINE)
+      default:
+        if constexpr (LFO_MODE == LFO_F32) { // a smooth f64 LFO is a sine or a triangle (or OSC_ANY: triangle-sine)
+          switch (cls) {
+            GROOVE_CLS_PLANE(OSC_PULSE) GROOVE_CLS_PLANE(OSC_SAW) GROOVE_CLS_PLANE(LFO_UNUSED)
+            default: break;
+          }
+        }
+        break;
     }
+#undef GROOVE_CLS_PLANE
 #undef GROOVE_CLS_ROW
 #undef GROOVE_CLS_CASE
   }
 }
-static_assert(OSC_CLASSES == 5, "the class switch above lists 5 x 5 pairs");
+static_assert(OSC_CLASSES == 5 && LFO_CLASSES == 6 && kClassCombos <= 256, "the class switch above lists 6 x 5 x 5 combinations, one byte each");
 // Launchers of the four class-specialised fused kernels, one translation unit each
 // (csrc/welsh_class.hip, -DGROOVE_BASE_KIND=0..3) so that they compile in parallel.
 void launch_welsh_uniform_specialised_0(const UniformArgs& a, hipStream_t st);
