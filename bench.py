@@ -289,8 +289,8 @@ def main():
             "voice_frames_per_s": value * V,
             "path_effective_GBs": wl["bytes_per_vf"] * value * V / 1e9,
             "roofline": {"bound": "hbm",
-                         "kernel": ("welsh_render_uniform_kernel<fused> (uniform, f64-LFO and per-lane workgroup kinds run "
-                                    "concurrently) + partial_rows/final" if fused and wl["kind"] == "welsh"
+                         "kernel": ("welsh_render_uniform_kernel<fused, LFO mode, retune> (one kernel per base kind, run "
+                                    "concurrently; class-specialised block bodies) + partial_rows/final" if fused and wl["kind"] == "welsh"
                                     else "render kernel of the first bank"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_voice_frame": dom_bytes, "kernel_ms": kern_ms,
