@@ -248,3 +248,44 @@ def test_rccl_single_rank_bus_reduce(gpu_ctx):
     gpu_ctx.bus_reduce(bus, 512, 0)
     gpu_ctx.synchronize()
     assert np.array_equal(bus.download().reshape(-1), vals)
+
+
+def test_pipelined_blocks_with_events_controls_and_state_reads(oracle, monkeypatch):
+    """The block pipeline of the fused path (render_mix_pipelined: every base kind on its own stream,
+    block b+1's kernels not waiting for block b's bus reduction) forced onto a small grouped bank
+    (GROOVE_PIPELINE_MIN_WAVES=1), with everything that has to join the pipeline in between: note
+    events mid-render, a control change, a state download, a materialised render.  Bus vs the oracle."""
+    from groove_amd import entities as E
+    monkeypatch.setenv("GROOVE_PIPELINE_MIN_WAVES", "1")
+    ctx = E.Context(0)
+    n, frames, blocks = 2048, 256, 24
+    params, vidx = P.welsh_voices_grouped(n)
+    on, off = P.grouped_note_events(vidx, True), P.grouped_note_events(vidx, False)
+    synth = E.WelshSynth(ctx, params)
+    ob = oracle.Bank.welsh(params)
+    bus = ctx.bus(blocks * frames)
+    block = ctx.block(n, frames)
+    want = []
+    for b in range(blocks):
+        if b == 0:
+            synth.handle_midi_events(on); ob.note_events(on)
+        if b == 9:
+            synth.handle_midi_events(off); ob.note_events(off)
+        if b == 13:  # re-trigger half of the voices while the others release
+            half = T.note_events_np(np.arange(0, n, 2, dtype=np.uint32), (36 + (7 * vidx[::2]) % 49).astype(np.uint8), True)
+            synth.handle_midi_events(half); ob.note_events(half)
+        if b == 5:
+            state = synth.download_state()  # joins the pipeline, reads consistent state
+            assert state.shape[1] == n
+        if b == 17:  # a materialised block in the middle of the fused ones
+            synth.generate_batch_values(block, frames)
+            ctx.mix([block], frames, E._Slice(bus, b * frames))
+        else:
+            synth.render_mix(bus, frames, at_frame=b * frames)
+        want.append(ob.render_bus(frames))
+    got = bus.download().astype(np.float64)
+    want = np.concatenate(want, axis=0)
+    assert np.isfinite(got).all()
+    rms = np.sqrt(np.mean(((got - want) / n) ** 2))
+    assert rms <= 1e-6, rms
+    synth.destroy(); bus.destroy(); block.destroy(); ctx.close()
