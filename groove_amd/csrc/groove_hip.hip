@@ -55,6 +55,11 @@ struct groove_bank {
   hipEvent_t ev_reduce_done[2] = {nullptr, nullptr};
   bool reduce_recorded[2] = {false, false};
   int pipe_slot = 0;
+  // welsh: lane permutation.  A bank whose patches are interleaved voice by voice is kept patch-major inside
+  // the library (params, state, cold values in INTERNAL lane order) so that it runs on the wave-uniform kernels;
+  // perm[internal lane] = caller's voice index, inv = its inverse.  Empty = identity.
+  std::vector<uint32_t> perm, inv;
+  uint32_t* d_inv = nullptr;      // device copy of inv (materialised renders are handed out in the caller's lane order)
   uint8_t* d_wg_cls = nullptr;   // welsh: oscillator class pair of each entry of d_wg_list
   uint32_t* d_wg_list = nullptr; // welsh: workgroup ids (groups of 4 virtual waves) sorted by kind (kernels.h)
   size_t wg_list_cap = 0;
@@ -166,16 +171,67 @@ int upload_soa(groove_ctx* ctx, uint32_t* dst, const std::vector<T>& aos) {
 inline uint32_t blocks_for(size_t items) { return (uint32_t)((items + kThreads - 1) / kThreads); }
 
 // Welsh: derive + upload parameters only (SoA, cold values, per-wave table, workgroup kinds).
-int welsh_upload_params(groove_bank* b) {
+// Number of virtual waves (runs of <= 64 equal parameter records) the lane order `at(i)` gives.
+template <class At>
+size_t count_virtual_waves(const std::vector<WelshParams>& P, uint32_t n, At&& at) {
+  size_t waves = 0;
+  for (uint32_t i = 0; i < n;) {
+    uint32_t e = i + 1;
+    while (e < n && e - i < 64 && std::memcmp(&P[at(e)], &P[at(i)], sizeof(WelshParams)) == 0) ++e;
+    ++waves;
+    i = e;
+  }
+  return waves;
+}
+inline bool runs_are_long(size_t virtual_waves, uint32_t n) {
+  // Use the scalar-parameter kernels when the runs are long (at most 1.5x as many virtual waves as
+  // physical ones), or when the bank is so small that even one short run per wave leaves the machine
+  // (1,024 SIMDs) under-filled: there a partly filled fast wave beats a full slow one.
+  const uint32_t phys_waves = (n + 63) / 64;
+  return !(virtual_waves > (size_t)phys_waves + phys_waves / 2 + 8 && virtual_waves > 2048);
+}
+// `regroup`: the state is (being) reset, so the lane order may be chosen afresh.
+int welsh_upload_params(groove_bank* b, bool regroup) {
   groove_ctx* ctx = b->ctx;
   const double sr = ctx->sr;
   const uint32_t n = b->n;
+  std::vector<WelshParams> Pext(n);
+  std::vector<WelshCold> Cext(n);
+  for (uint32_t v = 0; v < n; ++v) Pext[v] = derive_welsh(b->welsh[v], sr, Cext[v]);
+  if (regroup) {
+    b->perm.clear(); b->inv.clear();
+    if (!runs_are_long(count_virtual_waves(Pext, n, [](uint32_t i) { return i; }), n)) {
+      // patches interleaved voice by voice: try the patch-major order (stable sort by a hash of the record)
+      std::vector<uint64_t> h(n);
+      for (uint32_t v = 0; v < n; ++v) {
+        uint64_t x = 1469598103934665603ull;
+        const unsigned char* bytes = reinterpret_cast<const unsigned char*>(&Pext[v]);
+        for (size_t k = 0; k < sizeof(WelshParams); ++k) { x ^= bytes[k]; x *= 1099511628211ull; }
+        h[v] = x;
+      }
+      std::vector<uint32_t> order(n);
+      for (uint32_t v = 0; v < n; ++v) order[v] = v;
+      std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) { return h[a] < h[c]; });
+      if (runs_are_long(count_virtual_waves(Pext, n, [&](uint32_t i) { return order[i]; }), n)) {
+        b->perm = std::move(order);
+        b->inv.resize(n);
+        for (uint32_t i = 0; i < n; ++i) b->inv[b->perm[i]] = i;
+      }
+    }
+    if (b->d_inv) { GHIP(ctx, hipFree(b->d_inv)); b->d_inv = nullptr; }
+    if (!b->perm.empty()) {
+      GHIP(ctx, hipMalloc(&b->d_inv, (size_t)n * sizeof(uint32_t)));
+      GHIP(ctx, hipMemcpy(b->d_inv, b->inv.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+  }
+  // everything below is in INTERNAL lane order
   std::vector<WelshParams> P(n);
   std::vector<double> cold((size_t)4 * n);
-  for (uint32_t v = 0; v < n; ++v) {
-    WelshCold c;
-    P[v] = derive_welsh(b->welsh[v], sr, c);
-    cold[v] = c.tune1; cold[(size_t)n + v] = c.tune2; cold[(size_t)2 * n + v] = c.fixed1; cold[(size_t)3 * n + v] = c.fixed2;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t v = b->perm.empty() ? i : b->perm[i];
+    P[i] = Pext[v];
+    const WelshCold& c = Cext[v];
+    cold[i] = c.tune1; cold[(size_t)n + i] = c.tune2; cold[(size_t)2 * n + i] = c.fixed1; cold[(size_t)3 * n + i] = c.fixed2;
   }
   if (upload_soa(ctx, b->d_params, P)) return 1;
   GHIP(ctx, hipMemcpy(b->d_cold, cold.data(), cold.size() * 8, hipMemcpyHostToDevice));
@@ -190,13 +246,9 @@ int welsh_upload_params(groove_bank* b) {
     W.push_back(d);
     v = e;
   }
-  const uint32_t phys_waves = (n + 63) / 64;
   for (uint32_t& c : b->wgs_of_kind) c = 0;
-  // Use the scalar-parameter kernels when the runs are long (at most 1.5x as many virtual waves as
-  // physical ones), or when the bank is so small that even one short run per wave leaves the machine
-  // (1,024 SIMDs) under-filled: there a partly filled fast wave beats a full slow one.  Otherwise the
-  // patches are interleaved lane by lane and the per-lane kernel serves the whole bank.
-  if (W.size() > (size_t)phys_waves + phys_waves / 2 + 8 && W.size() > 2048) {
+  // Otherwise (every voice its own patch, even patch-major) the per-lane kernel serves the whole bank.
+  if (!runs_are_long(W.size(), n)) {
     b->n_vwaves = 0;
     return 0;
   }
@@ -262,8 +314,8 @@ int bank_derive_and_upload(groove_bank* b) {
   const uint32_t n = b->n;
   GHIP(ctx, hipSetDevice(ctx->device));
   if (b->kind == BANK_WELSH) {
-    std::vector<WelshState> S(n, initial_welsh_state());
-    if (welsh_upload_params(b)) return 1;
+    std::vector<WelshState> S(n, initial_welsh_state()); // every voice starts from the same state: any lane order will do
+    if (welsh_upload_params(b, true)) return 1;
     if (upload_soa(ctx, b->d_state, S)) return 1;
   } else if (b->kind == BANK_FM) {
     std::vector<FmParams> P(n);
@@ -320,6 +372,9 @@ int flush_events(groove_bank* b) {
   if (b->pending.empty()) return 0;
   groove_ctx* ctx = b->ctx;
   if (ctx_join(ctx)) return 1;
+  if (!b->inv.empty()) // caller's voice index -> internal lane
+    for (groove_note_event& e : b->pending)
+      if (e.voice != GROOVE_ALL_VOICES) e.voice = b->inv[e.voice];
   std::vector<groove_note_event>& ev = b->pending;
   if (b->ev_cap < ev.size()) {
     if (b->d_ev) GHIP(ctx, hipFree(b->d_ev));
@@ -725,7 +780,7 @@ int groove_bank_destroy(groove_bank* b) {
   auto it = std::find(ctx->banks.begin(), ctx->banks.end(), b);
   if (it != ctx->banks.end()) ctx->banks.erase(it);
   if (b->scratch) groove_block_destroy(b->scratch);
-  (void)hipFree(b->d_params); (void)hipFree(b->d_state); (void)hipFree(b->d_cold); (void)hipFree(b->d_pcm); (void)hipFree(b->d_ev); (void)hipFree(b->d_waves); (void)hipFree(b->d_wg_list); (void)hipFree(b->d_wg_cls);
+  (void)hipFree(b->d_params); (void)hipFree(b->d_state); (void)hipFree(b->d_cold); (void)hipFree(b->d_pcm); (void)hipFree(b->d_ev); (void)hipFree(b->d_waves); (void)hipFree(b->d_wg_list); (void)hipFree(b->d_wg_cls); (void)hipFree(b->d_inv);
   delete b;
   return 0;
 }
@@ -758,7 +813,7 @@ int groove_bank_set_param(groove_bank* b, uint32_t voice, uint32_t control_index
   // control-plane path: re-derive and re-upload the parameter tables (state is untouched)
   if (ctx_join(ctx)) return 1;
   GHIP(ctx, hipStreamSynchronize(ctx->stream));
-  return welsh_upload_params(b);
+  return welsh_upload_params(b, false); // the state stays where it is: keep the lane order
 }
 static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs, float* out) {
   groove_ctx* ctx = b->ctx;
@@ -846,7 +901,17 @@ int groove_bank_render(groove_bank* b, uint32_t frames, groove_block* out) {
   GHIP(ctx, hipSetDevice(ctx->device));
   if (flush_events(b)) return 1;
   if (ctx_join(ctx)) return 1; // the bank's state may still be in flight on the side streams (pipelined fused renders)
-  return launch_render(b, frames, false, (size_t)out->cap * out->n, out->d);
+  if (b->perm.empty()) return launch_render(b, frames, false, (size_t)out->cap * out->n, out->d);
+  // regrouped bank: render in the internal lane order (coalesced rows), then hand the caller's order out
+  if (!b->scratch || b->scratch->cap < frames) {
+    if (b->scratch) { GHIP(ctx, hipStreamSynchronize(ctx->stream)); groove_block_destroy(b->scratch); b->scratch = nullptr; }
+    if (groove_block_create(ctx, b->n, std::max<uint32_t>(frames, GROOVE_BLOCK_FRAMES), &b->scratch)) return 1;
+  }
+  if (launch_render(b, frames, false, (size_t)b->scratch->cap * b->n, b->scratch->d)) return 1;
+  hipLaunchKernelGGL(block_gather_kernel, dim3(blocks_for(b->n), std::min<uint32_t>(frames, 64)), dim3(kThreads), 0, ctx->stream, out->d,
+                     (size_t)out->cap * out->n, b->scratch->d, (size_t)b->scratch->cap * b->n, b->d_inv, b->n, frames);
+  GHIP(ctx, hipGetLastError());
+  return 0;
 }
 // Fused render + mix of a wave-uniform Welsh bank, pipelined over blocks.  Every base kind has its
 // own stream that carries that kind's kernels block after block (a workgroup's state only depends
@@ -956,7 +1021,14 @@ int groove_bank_download_state(groove_bank* b, uint32_t* host_words) {
   if (flush_events(b)) return 1;
   if (ctx_join(ctx)) return 1;
   GHIP(ctx, hipStreamSynchronize(ctx->stream));
-  GHIP(ctx, hipMemcpy(host_words, b->d_state, (size_t)b->sw * b->n * 4, hipMemcpyDeviceToHost));
+  if (b->perm.empty()) {
+    GHIP(ctx, hipMemcpy(host_words, b->d_state, (size_t)b->sw * b->n * 4, hipMemcpyDeviceToHost));
+  } else { // internal lane order -> caller's voice order
+    std::vector<uint32_t> tmp((size_t)b->sw * b->n);
+    GHIP(ctx, hipMemcpy(tmp.data(), b->d_state, tmp.size() * 4, hipMemcpyDeviceToHost));
+    for (uint32_t w = 0; w < b->sw; ++w)
+      for (uint32_t i = 0; i < b->n; ++i) host_words[(size_t)w * b->n + b->perm[i]] = tmp[(size_t)w * b->n + i];
+  }
   return 0;
 }
 

@@ -567,6 +567,22 @@ __global__ void mix_final_kernel(const float* __restrict__ partial, uint32_t fra
   float* dst = planar_stride ? bus + ch * planar_stride + f : bus + 2 * f + ch;
   if (accumulate) *dst += t; else *dst = t;
 }
+// Lane permutation of a planar block: dst[ch][f][e] = src[ch][f][src_lane[e]].  Used when a bank keeps
+// its voices in another lane order than the caller (patch-major regrouping): the render writes its
+// own order with coalesced rows and this pass hands the caller's order out, again with coalesced
+// writes (the gathered reads of neighbouring workgroups share cache lines).
+__global__ __launch_bounds__(kThreads) void block_gather_kernel(float* __restrict__ dst, size_t dst_ch_stride, const float* __restrict__ src,
+                                                               size_t src_ch_stride, const uint32_t* __restrict__ src_lane, uint32_t n,
+                                                               uint32_t frames) {
+  const uint32_t e = blockIdx.x * kThreads + threadIdx.x;
+  if (e >= n) return;
+  const uint32_t i = src_lane[e];
+  for (uint32_t f = blockIdx.y; f < frames; f += gridDim.y) {
+    dst[(size_t)f * n + e] = src[(size_t)f * n + i];
+    dst[dst_ch_stride + (size_t)f * n + e] = src[src_ch_stride + (size_t)f * n + i];
+  }
+}
+
 // dst (+)= src, element-wise over [2][frames][n] blocks with their own channel strides.
 __global__ __launch_bounds__(kThreads) void block_add_kernel(
     float* __restrict__ dst, size_t dst_chs, const float* __restrict__ src, size_t src_chs,

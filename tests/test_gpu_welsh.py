@@ -289,3 +289,42 @@ def test_pipelined_blocks_with_events_controls_and_state_reads(oracle, monkeypat
     rms = np.sqrt(np.mean(((got - want) / n) ** 2))
     assert rms <= 1e-6, rms
     synth.destroy(); bus.destroy(); block.destroy(); ctx.close()
+
+
+def test_interleaved_bank_is_regrouped_transparently(gpu_ctx, oracle):
+    """Voice i uses patch i mod 32 (config #2's literal rule) in a bank large enough that the library
+    regroups it patch-major internally (lane permutation): note events, state download and the
+    materialised block must keep the caller's voice order; fused bus and sampled voices vs the oracle."""
+    from groove_amd import entities as E
+    n, frames, blocks = 8192, 256, 4   # 8192 runs of one voice: too short for the uniform kernels unless regrouped
+    params = P.welsh_voices(n)
+    synth = E.WelshSynth(gpu_ctx, params)
+    on = P.note_on_all(n)
+    # only the even voices play, so a wrong event mapping is audible
+    ev_on = T.note_events_np(np.arange(0, n, 2, dtype=np.uint32), P.voice_keys(n)[::2], True)
+    synth.handle_midi_events(ev_on)
+    sample = np.arange(0, n, 37)
+    ob = oracle.Bank.welsh((T.WelshParams * len(sample))(*[params[int(i)] for i in sample]))
+    ob.note_events(T.note_events_np(np.flatnonzero(sample % 2 == 0).astype(np.uint32), P.voice_keys(n)[sample[sample % 2 == 0]], True))
+    block = gpu_ctx.block(n, frames)
+    for b in range(blocks):
+        synth.generate_batch_values(block, frames)
+        got = block.download(frames)[:, :, sample].astype(np.float64)
+        want = ob.render(frames)
+        assert np.abs(got[:, :, sample % 2 == 1]).max() == 0.0, "an odd voice sounds: note events landed on the wrong lanes"
+        rms = np.sqrt(np.mean((got - want) ** 2, axis=(0, 1)))
+        assert rms.max() <= TOL_RMS, rms.max()
+    st = synth.download_state()
+    idle_word = st[:, 1::2]
+    assert (idle_word == idle_word[:, :1]).all(), "odd (never triggered) voices must all hold the initial state"
+    assert not (st[:, 0::2] == st[:, 1:2]).all(), "even voices played: their state moved"
+    # fused form of the same bank against a fresh grouped bank of the same voices
+    a = E.WelshSynth(gpu_ctx, params); a.handle_midi_events(on)
+    pg, vidx = P.welsh_voices_grouped(n)
+    g = E.WelshSynth(gpu_ctx, pg); g.handle_midi_events(P.grouped_note_events(vidx, True))
+    ba, bg = gpu_ctx.bus(frames), gpu_ctx.bus(frames)
+    for b in range(blocks):
+        a.render_mix(ba, frames); g.render_mix(bg, frames)
+        assert np.max(np.abs(ba.download() - bg.download())) / n <= 1e-6
+    for x in (synth, a, g, block, ba, bg):
+        x.destroy()
