@@ -355,6 +355,28 @@ int Orchestrator::send_performance_to_file(const Performance& perf, const std::s
 // ====================================================================== C surface for tests / tools
 using namespace groove_host;
 extern "C" {
+// BusStation C surface (tests restate the reference's unit test through it)
+void* gh_bus_station_new() { return new groove_host::BusStation(); }
+void gh_bus_station_free(void* h) { delete (groove_host::BusStation*)h; }
+void gh_bus_station_add_send_route(void* h, uint32_t track, uint32_t aux, double amount) {
+  ((groove_host::BusStation*)h)->add_send_route(track, groove_host::BusRoute{aux, amount});
+}
+void gh_bus_station_remove_send_route(void* h, uint32_t track, uint32_t aux) { ((groove_host::BusStation*)h)->remove_send_route(track, aux); }
+void gh_bus_station_remove_track_sends(void* h, uint32_t track) { ((groove_host::BusStation*)h)->remove_track_sends(track); }
+uint32_t gh_bus_station_tracks(void* h) { return (uint32_t)((groove_host::BusStation*)h)->tracks(); }
+// number of sends of `track` (-1: the track has no list); the i-th route through aux_out / amount_out
+int gh_bus_station_sends_for(void* h, uint32_t track) {
+  const auto* r = ((groove_host::BusStation*)h)->sends_for(track);
+  return r ? (int)r->size() : -1;
+}
+int gh_bus_station_send(void* h, uint32_t track, uint32_t i, uint32_t* aux_out, double* amount_out) {
+  const auto* r = ((groove_host::BusStation*)h)->sends_for(track);
+  if (!r || i >= r->size()) return 1;
+  *aux_out = (*r)[i].aux_track_uid; *amount_out = (*r)[i].amount;
+  return 0;
+}
+}
+extern "C" {
 void* gh_orchestrator_new(int device, uint32_t sample_rate, double bpm) {
   Orchestrator* o = new Orchestrator(device, sample_rate, bpm);
   if (!o->ctx()) { std::fprintf(stderr, "gh_orchestrator_new: %s\n", o->last_error().c_str()); delete o; return nullptr; }

@@ -276,4 +276,33 @@ class Orchestrator {
   bool performing_ = false;
 };
 
+// BusStation (src/mini/bus_station.rs:7-52): which track sends how much of its signal to which aux
+// track.  At the reference commit it is a routing table only (nothing renders through it yet), so
+// this is the table, with the behaviour of its code and unit test (:55-140): adding a route appends
+// (the test's "should replace the prior one" only counts tracks; the code pushes, so does this),
+// removing a route drops every route to that aux and leaves the track's (possibly empty) list in
+// place, removing a track's sends leaves an empty list for it.
+struct BusRoute { uint32_t aux_track_uid; double amount; };
+class BusStation {
+ public:
+  void add_send_route(uint32_t track_uid, const BusRoute& route) {
+    send_routes_[track_uid].push_back(route);
+  }
+  void remove_send_route(uint32_t track_uid, uint32_t aux_track_uid) {
+    auto it = send_routes_.find(track_uid);
+    if (it == send_routes_.end()) return;
+    std::vector<BusRoute>& routes = it->second;
+    for (size_t i = 0; i < routes.size();)
+      if (routes[i].aux_track_uid == aux_track_uid) routes.erase(routes.begin() + (long)i); else ++i;
+  }
+  void remove_track_sends(uint32_t track_uid) { send_routes_[track_uid].clear(); }
+  const std::vector<BusRoute>* sends_for(uint32_t track_uid) const {
+    auto it = send_routes_.find(track_uid);
+    return it == send_routes_.end() ? nullptr : &it->second;
+  }
+  size_t tracks() const { return send_routes_.size(); }
+ private:
+  std::map<uint32_t, std::vector<BusRoute>> send_routes_;
+};
+
 } // namespace groove_host

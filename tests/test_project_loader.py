@@ -160,3 +160,37 @@ def test_all_reference_welsh_patches_derive(host):
         assert 0.0 <= p.oscillator_mix <= 1.0 and 0.0 <= p.filter_cutoff_start <= 1.0
         assert p.lfo_routing in range(5)
     assert n_ok >= 100
+
+
+def test_bus_station_routing_table(host):
+    """BusStation: restates the reference's unit test (src/mini/bus_station.rs:55-140) through the
+    compiled host layer's C surface."""
+    L = host
+    L.gh_bus_station_new.restype = C.c_void_p
+    for f in ("gh_bus_station_free", "gh_bus_station_add_send_route", "gh_bus_station_remove_send_route", "gh_bus_station_remove_track_sends"):
+        getattr(L, f).restype = None
+    L.gh_bus_station_free.argtypes = [C.c_void_p]
+    L.gh_bus_station_add_send_route.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_double]
+    L.gh_bus_station_remove_send_route.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    L.gh_bus_station_remove_track_sends.argtypes = [C.c_void_p, C.c_uint32]
+    L.gh_bus_station_tracks.argtypes = [C.c_void_p]; L.gh_bus_station_tracks.restype = C.c_uint32
+    L.gh_bus_station_sends_for.argtypes = [C.c_void_p, C.c_uint32]
+    L.gh_bus_station_send.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+    bs = L.gh_bus_station_new()
+    assert L.gh_bus_station_tracks(bs) == 0
+    L.gh_bus_station_add_send_route(bs, 7, 13, 0.8)
+    assert L.gh_bus_station_tracks(bs) == 1
+    L.gh_bus_station_add_send_route(bs, 7, 13, 0.7)
+    assert L.gh_bus_station_tracks(bs) == 1, "a second route of the same track adds no track"
+    aux, amount = C.c_uint32(), C.c_double()
+    assert L.gh_bus_station_send(bs, 7, 1, C.byref(aux), C.byref(amount)) == 0 and aux.value == 13 and amount.value == 0.7
+    L.gh_bus_station_remove_send_route(bs, 7, 13)
+    assert L.gh_bus_station_tracks(bs) == 1 and L.gh_bus_station_sends_for(bs, 7) == 0, "the (empty) list stays"
+    L.gh_bus_station_remove_send_route(bs, 7, 13)  # removing a nonexistent route is a no-op
+    L.gh_bus_station_add_send_route(bs, 7, 13, 0.8)
+    L.gh_bus_station_add_send_route(bs, 7, 14, 0.8)
+    assert L.gh_bus_station_tracks(bs) == 1 and L.gh_bus_station_sends_for(bs, 7) == 2
+    L.gh_bus_station_remove_track_sends(bs, 7)
+    assert L.gh_bus_station_sends_for(bs, 7) == 0, "removing a track's sends leaves an empty list for it"
+    assert L.gh_bus_station_sends_for(bs, 99) == -1
+    L.gh_bus_station_free(bs)
