@@ -18,6 +18,17 @@ if ks:
     rows = list(csv.DictReader(open(ks[0])))
     summary["kernel_stats"] = [{"name": r["Name"][:90], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
                                 "pct": float(r["Percentage"])} for r in rows[:8]]
+# The fused step is several kernels running concurrently (and, pipelined, overlapping the next
+# step's), so no single kernel's average duration is "the step": the step period is read off the
+# trace as the spacing of the per-step bus reductions (partial_final_kernel ends once per step).
+kt = glob.glob(f"{out}/kt/*/*_kernel_trace.csv")
+if kt:
+    ends = sorted(int(r["End_Timestamp"]) for r in csv.DictReader(open(kt[0])) if "partial_final_kernel" in r["Kernel_Name"])
+    if len(ends) > 20:
+        steady = ends[4:]  # skip the warm-up steps
+        summary["step_period_from_trace"] = {
+            "mean_us": (steady[-1] - steady[0]) / (len(steady) - 1) / 1e3, "steps": len(steady) - 1,
+            "note": "spacing of partial_final_kernel completions over the timed steps; compare with roofline.kernel_ms of the bench line"}
 for log in glob.glob(f"{out}/bench_kt.log"):
     for line in open(log):
         if line.startswith("{"):
@@ -54,10 +65,10 @@ def per_step(sub, counter):
 
 
 w, f = per_step("write", "WRITE_SIZE"), per_step("fetch", "FETCH_SIZE")
-summary["dominant_kernel"] = "welsh_render_uniform_kernel<fused> (+ f64-LFO and per-lane kinds, concurrent) + partial_rows/final"
+summary["dominant_kernel"] = "welsh_render_uniform_kernel<fused, LFO mode, retune> (one per base kind, concurrent, blocks pipelined) + partial_rows/final"
 summary["hbm_traffic_bytes_per_step"] = {"write": w, "fetch_raw": f, "fetch_x2_gfx950": 2 * f,
                                          "total_raw": w + f, "total_corrected": w + 2 * f}
 json.dump(summary, open(f"profiles/{rnd}_summary.json", "w"), indent=1)
-print(json.dumps({k: summary[k] for k in ("dominant_kernel", "hbm_traffic_bytes_per_step") if k in summary}, indent=1))
+print(json.dumps({k: summary[k] for k in ("dominant_kernel", "hbm_traffic_bytes_per_step", "step_period_from_trace") if k in summary}, indent=1))
 for r in summary.get("kernel_stats", []):
     print(f"{r['pct']:6.2f}%  {r['avg_ns'] / 1e3:10.1f} us x {r['calls']:4d}  {r['name']}")
