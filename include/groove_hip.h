@@ -94,7 +94,15 @@ int groove_bank_render(groove_bank* bank, uint32_t frames, groove_block* out);
 /* Fused form of "tick every leaf and add its value to the running sum"
  * (orchestrator.rs:397-410) for instruments patched straight into the main mixer: renders
  * and accumulates into bus_dev[frames][2] (device) without materialising the block.
- * accumulate = 0 overwrites the bus, 1 adds to it. */
+ * accumulate = 0 overwrites the bus, 1 adds to it.
+ * Asynchronous like every call here: the bus is complete for anything ordered after this call on the
+ * ctx stream (groove_download, groove_bus_to_i16, groove_bus_reduce, groove_synchronize ...).  Large
+ * Welsh banks pipeline consecutive calls (block b+1's voice kernels, on the library's own per-kind
+ * streams, do not wait for block b's bus sum); calls that touch the bank in between (note events,
+ * groove_bank_set_param, groove_bank_render, groove_bank_download_state) join that pipeline first, so
+ * the order of effects is the order of calls.  The voices' lane order inside the library is its own
+ * business (a bank whose patches are interleaved voice by voice is kept patch-major): every index in
+ * this API is the caller's voice index. */
 int groove_bank_render_mix(groove_bank* bank, uint32_t frames, float* bus_dev, int accumulate);
 /* Raw state snapshot (checkpoint / debugging): words = groove_bank_state_words(). */
 uint32_t groove_bank_state_words(groove_bank* bank);
