@@ -375,10 +375,6 @@ struct WelshScratch {
 GROOVE_HD Lp24Coef welsh_static_coef(const WelshParams& p, const RenderConsts& rc) {
   return lp24_coef_from_fc(p.fc, p.cutoff_hz, rc.pi_over_sr, rc.fc_max);
 }
-GROOVE_HD bool welsh_f64_lfo(const WelshParams& p) {
-  const uint32_t r = (p.flags >> WF_ROUTING_SHIFT) & 15u;
-  return r == GROOVE_LFO_PITCH || r == GROOVE_LFO_PULSE_WIDTH;
-}
 GROOVE_HD bool welsh_retunes(const WelshParams& p) {
   return (p.flags & WF_RETUNE_ENV) || (((p.flags >> WF_ROUTING_SHIFT) & 15u) == GROOVE_LFO_FILTER_CUTOFF);
 }

@@ -71,14 +71,6 @@ constexpr int kWaves = kThreads / 64;
 // v_readfirstlane: ~35 VGPRs freed, and every `switch (waveform)` / routing test below
 // becomes a scalar branch instead of an exec-mask region.
 template <class T>
-__device__ __forceinline__ bool wave_uniform(const T& x) {
-  const WordsOf<T> w = __builtin_bit_cast(WordsOf<T>, x);
-  bool ok = true;
-#pragma unroll
-  for (uint32_t i = 0; i < sizeof(T) / 4; ++i) ok &= (w.w[i] == (uint32_t)__builtin_amdgcn_readfirstlane((int)w.w[i]));
-  return __all(ok);
-}
-template <class T>
 __device__ __forceinline__ T make_scalar(const T& x) {
   WordsOf<T> w = __builtin_bit_cast(WordsOf<T>, x);
 #pragma unroll
