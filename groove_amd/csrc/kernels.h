@@ -368,6 +368,33 @@ __global__ __launch_bounds__(kThreads, (WavesBudget<LFO_MODE, RETUNE>::value)) v
   // issue priority over co-resident waves of the short kinds (list scheduling, longest first).
   if (LFO_MODE != LFO_F32) __builtin_amdgcn_s_setprio(2);
   const UniformArgsPtr ka = (UniformArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(); // == &a, in the constant address space
+  if constexpr (FUSED) {
+    // A workgroup whose voices are all silent with both envelopes idle (unused polyphony, voices past
+    // their release) contributes zeros and changes nothing but idle-plateau counters: it writes its
+    // zero rows and leaves.  Two state words per lane, one vote; nothing else is loaded.
+    const uint32_t wg = a.wg_list[blockIdx.x];
+    const uint32_t w0 = wg * kWaves + (threadIdx.x >> 6);
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(w0, a.n_waves - 1));
+    const uint32_t vbase = a.waves[w].vbase, count = a.waves[w].count;
+    const bool active = (w0 < a.n_waves) && ((threadIdx.x & 63u) < count);
+    const uint32_t v = active ? vbase + (threadIdx.x & 63u) : vbase;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(a.state, 0, (int)(sizeof(WelshState) / 4 * a.n * 4u), 0x00020000);
+    constexpr uint32_t kAmpWord = offsetof(WelshState, amp) / 4 + offsetof(EnvState, state) / 4;
+    constexpr uint32_t kFilWord = offsetof(WelshState, fil) / 4 + offsetof(EnvState, state) / 4;
+    const uint32_t sa = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(v * 4u), (int)(kAmpWord * a.n * 4u), 0);
+    const uint32_t sf = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(v * 4u), (int)(kFilWord * a.n * 4u), 0);
+    __shared__ int busy_waves;
+    if (threadIdx.x == 0) busy_waves = 0;
+    __syncthreads();
+    if (!__all(!active || (sa == ENV_IDLE && sf == ENV_IDLE)) && (threadIdx.x & 63u) == 0) atomicAdd(&busy_waves, 1);
+    __syncthreads();
+    if (busy_waves == 0) {
+      float* __restrict__ rows = a.out + (size_t)wg * 2 * a.frames; // partial[wg][ch][frame]
+      for (uint32_t t = threadIdx.x; t < 2 * a.frames; t += kThreads) rows[t] = 0.0f;
+      return;
+    }
+  }
   if constexpr (!SPECIALISED) {
     welsh_uniform_body_impl<FUSED, LFO_MODE, RETUNE, OSC_ANY, OSC_ANY, OSC_ANY>(ka);
   } else {
