@@ -317,6 +317,31 @@ GROOVE_HD Lp24CoefD lp24_widen(const Lp24Coef& c) {
   d.b0b = (double)c.b0b; d.a1b = sg * (2.0 - (double)c.q1b); d.a2b = (double)c.q2b - 1.0;
   return d;
 }
+// The two steps above in one, branching on the side of SR/4 instead of selecting per term (on the
+// device the upper side is an exec-mask region that a wave with no lane above SR/4 skips), and with
+// the sign folded into the f64 subtraction (q - 2 == -(2 - q) exactly).  Same operations on the
+// same values in either case, so the result is bit-identical to lp24_widen(lp24_coef_from_fc(...)).
+GROOVE_HD Lp24CoefD lp24_coefd_from_fc(const Lp24Consts& c, float fc, float pi_over_sr, float fc_max) {
+  fc = fminf(fmaxf(fc, 1.0f), fc_max);
+  bool hi;
+  const float t = tan_reduced(fc * pi_over_sr, hi);
+  const float T2 = t * t;
+  const float dta = c.d1 * t, dtb = c.d3 * t;
+  Lp24CoefD d;
+  if (!hi) {
+    const float ia = fast_rcp(c.c0 + dta + T2);
+    const float ib = fast_rcp(c.c2 + dtb + T2);
+    d.b0a = (double)(T2 * ia); d.a1a = 2.0 - (double)(2.0f * (dta + 2.0f * T2) * ia); d.a2a = (double)(2.0f * dta * ia) - 1.0;
+    d.b0b = (double)(T2 * ib); d.a1b = 2.0 - (double)(2.0f * (dtb + 2.0f * T2) * ib); d.a2b = (double)(2.0f * dtb * ib) - 1.0;
+  } else {
+    const float Pa = c.c0 * T2, Pb = c.c2 * T2;
+    const float ia = fast_rcp(1.0f + dta + Pa);
+    const float ib = fast_rcp(1.0f + dtb + Pb);
+    d.b0a = (double)(1.0f * ia); d.a1a = (double)(2.0f * (dta + 2.0f * Pa) * ia) - 2.0; d.a2a = (double)(2.0f * dta * ia) - 1.0;
+    d.b0b = (double)(1.0f * ib); d.a1b = (double)(2.0f * (dtb + 2.0f * Pb) * ib) - 2.0; d.a2b = (double)(2.0f * dtb * ib) - 1.0;
+  }
+  return d;
+}
 GROOVE_HD double lp24_step(Lp24StateD& s, const Lp24CoefD& c, double x) {
   const double bx = c.b0a * x;
   const double y1 = bx + s.s0;
@@ -372,9 +397,6 @@ struct WelshScratch {
   double ls, lc;   // LFO_F64_SMOOTH: LFO value of the previous frame (sine: sin), and cos of the sine LFO's angle
   double lm;       // LFO_F64_SMOOTH, pitch routing: 2^(ls * depth)
 };
-GROOVE_HD Lp24Coef welsh_static_coef(const WelshParams& p, const RenderConsts& rc) {
-  return lp24_coef_from_fc(p.fc, p.cutoff_hz, rc.pi_over_sr, rc.fc_max);
-}
 GROOVE_HD bool welsh_retunes(const WelshParams& p) {
   return (p.flags & WF_RETUNE_ENV) || (((p.flags >> WF_ROUTING_SHIFT) & 15u) == GROOVE_LFO_FILTER_CUTOFF);
 }
@@ -512,7 +534,7 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
     }
     if (retune && pct != sc.prev_pct) { // unchanged percent (e.g. envelope plateau): coefficients stand
       const float fc = 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f); // 25 * 800^pct
-      sc.coef = lp24_widen(lp24_coef_from_fc(p.fc, fc, rc.pi_over_sr, rc.fc_max));
+      sc.coef = lp24_coefd_from_fc(p.fc, fc, rc.pi_over_sr, rc.fc_max);
       sc.prev_pct = pct;
     }
   }
@@ -525,7 +547,7 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
 }
 GROOVE_HD WelshScratch welsh_scratch_init(const WelshParams& p, const RenderConsts& rc) {
   WelshScratch sc;
-  sc.coef = lp24_widen(welsh_static_coef(p, rc));
+  sc.coef = lp24_coefd_from_fc(p.fc, p.cutoff_hz, rc.pi_over_sr, rc.fc_max);
   sc.prev_pct = __builtin_nanf("");
   sc.ls = 0.0; sc.lc = 1.0; sc.lm = 1.0;
   return sc;
