@@ -93,4 +93,12 @@ void emul_bank_render(void* h, uint32_t frames, float* out) {
   }
 }
 float emul_bitcrush(float x, uint32_t bits) { return bitcrush(x, bits); }
+// both forms of the 24 dB coefficient computation (dsp_core.h): out[0..5] two-step, out[6..11] fused
+void emul_lp24_coef_both(double ripple, float fc, float sr, double* out) {
+  const Lp24Consts c = derive_lp24_consts(ripple);
+  const Lp24CoefD a = lp24_widen(lp24_coef_from_fc(c, fc, 3.14159265358979323846f / sr, 0.49f * sr));
+  const Lp24CoefD b = lp24_coefd_from_fc(c, fc, 3.14159265358979323846f / sr, 0.49f * sr);
+  std::memcpy(out, &a, sizeof a);
+  std::memcpy(out + 6, &b, sizeof b);
+}
 }

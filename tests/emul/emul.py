@@ -36,6 +36,7 @@ def lib():
         L.emul_bank_note_events.argtypes = [vp, C.POINTER(T.NoteEvent), u32]
         L.emul_bank_render.argtypes = [vp, u32, _fp]
         L.emul_bitcrush.restype = C.c_float; L.emul_bitcrush.argtypes = [C.c_float, u32]
+        L.emul_lp24_coef_both.argtypes = [C.c_double, C.c_float, C.c_float, C.POINTER(C.c_double)]
         _LIB = L
     return _LIB
 

@@ -58,3 +58,19 @@ def test_bitcrusher_same_integer_quantise(oracle):
             assert np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32)
     # worked value: 0.5 at 8 bits → floor(16383.5 / 256) * 256 / 32767
     assert abs(L.oracle_bitcrush_f32(0.5, 8) - (16383 >> 8 << 8) / 32767.0) < 1e-7
+
+
+def test_fused_filter_coefficients_are_bit_identical_to_the_two_step_form():
+    """lp24_coefd_from_fc (branch on the side of SR/4, sign folded into the f64 subtraction) against
+    lp24_widen(lp24_coef_from_fc(...)) (per-term selects): same bits, both sides of SR/4, two rates."""
+    import ctypes as C
+    L = E.lib()
+    rng = np.random.default_rng(7)
+    out = (C.c_double * 12)()
+    for _ in range(20000):
+        ripple = 0.1 + 1.3 * rng.random()
+        fc = float(20.0 * 1100.0 ** rng.random())
+        sr = float(rng.choice([22050.0, 44100.0, 96000.0]))
+        L.emul_lp24_coef_both(ripple, fc, sr, out)
+        a = np.frombuffer(out, dtype=np.uint64)
+        assert (a[:6] == a[6:]).all(), (ripple, fc, sr)
