@@ -51,10 +51,11 @@ struct groove_bank {
   float* d_pipe_part[2] = {nullptr, nullptr};
   float* d_pipe_seg[2] = {nullptr, nullptr};
   size_t pipe_part_cap[2] = {0, 0}, pipe_seg_cap[2] = {0, 0};
-  hipEvent_t ev_render_done[kBaseKinds][2] = {};
+  hipEvent_t ev_render_done[kBaseKinds + 4][2] = {};
   hipEvent_t ev_reduce_done[2] = {nullptr, nullptr};
   bool reduce_recorded[2] = {false, false};
   int pipe_slot = 0;
+  int stream_slot = 0; // side stream of a single-kernel bank (FM, sampler, per-lane Welsh) in the asynchronous fused path
   // welsh: lane permutation.  A bank whose patches are interleaved voice by voice is kept patch-major inside
   // the library (params, state, cold values in INTERNAL lane order) so that it runs on the wave-uniform kernels;
   // perm[internal lane] = caller's voice index, inv = its inverse.  Empty = identity.
@@ -93,7 +94,8 @@ struct groove_fx {
   ReverbGeom geo{};
 };
 
-constexpr int kSideStreams = kBaseKinds; // one per base kind; the ctx stream carries events, reductions and everything else
+constexpr int kBankStreams = 4;                         // shared round-robin by single-kernel banks (FM, sampler, per-lane Welsh)
+constexpr int kSideStreams = kBaseKinds + kBankStreams; // + one per Welsh base kind; the ctx stream carries events, reductions and the rest
 struct groove_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -104,6 +106,7 @@ struct groove_ctx {
   bool fork_pending[kSideStreams] = {}; // the side stream has not yet waited for ev_fork
   bool need_fork = true;                // ctx-stream work since the last fork that side streams must wait for
   uint32_t pipeline_min_waves = 3072;   // banks at least this long (~200,000 voices) pipeline their fused blocks
+  int next_stream_slot = 0;             // round-robin side-stream assignment of single-kernel banks
   uint32_t sr = GROOVE_DEFAULT_SAMPLE_RATE;
   std::string err;
   std::vector<groove_bank*> banks;
@@ -721,6 +724,7 @@ int groove_block_download(groove_block* b, float* host, uint32_t frames) {
 
 // ============================================================================ instruments
 static int bank_finish_create(groove_bank* b, groove_bank** out) {
+  b->stream_slot = kBaseKinds + b->ctx->next_stream_slot++ % kBankStreams;
   if (bank_alloc(b) || bank_derive_and_upload(b)) { groove_bank_destroy(b); return 1; }
   b->ctx->banks.push_back(b);
   *out = b;
@@ -775,7 +779,7 @@ int groove_bank_destroy(groove_bank* b) {
   for (int slot = 0; slot < 2; ++slot) {
     (void)hipFree(b->d_pipe_part[slot]); (void)hipFree(b->d_pipe_seg[slot]);
     if (b->ev_reduce_done[slot]) (void)hipEventDestroy(b->ev_reduce_done[slot]);
-    for (int k = 0; k < kBaseKinds; ++k) if (b->ev_render_done[k][slot]) (void)hipEventDestroy(b->ev_render_done[k][slot]);
+    for (int k = 0; k < kBaseKinds + 4; ++k) if (b->ev_render_done[k][slot]) (void)hipEventDestroy(b->ev_render_done[k][slot]);
   }
   auto it = std::find(ctx->banks.begin(), ctx->banks.end(), b);
   if (it != ctx->banks.end()) ctx->banks.erase(it);
@@ -922,7 +926,8 @@ int groove_bank_render(groove_bank* b, uint32_t frames, groove_block* out) {
 // render of block b+2 waits for the reduction of block b.
 static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev, int accumulate) {
   groove_ctx* ctx = b->ctx;
-  const uint32_t rows = (b->n_vwaves + kWaves - 1) / kWaves;
+  const bool uniform = b->kind == BANK_WELSH && b->n_vwaves;
+  const uint32_t rows = uniform ? (b->n_vwaves + kWaves - 1) / kWaves : blocks_for(b->n);
   const uint32_t cols = 2 * frames, rows_per_seg = 64, segs = (rows + rows_per_seg - 1) / rows_per_seg;
   const int slot = b->pipe_slot;
   b->pipe_slot ^= 1;
@@ -939,13 +944,17 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
   }
   if (!b->ev_reduce_done[slot]) {
     GHIP(ctx, hipEventCreateWithFlags(&b->ev_reduce_done[slot], hipEventDisableTiming));
-    for (int k = 0; k < kBaseKinds; ++k) GHIP(ctx, hipEventCreateWithFlags(&b->ev_render_done[k][slot], hipEventDisableTiming));
+    for (int k = 0; k < kSideStreams; ++k) GHIP(ctx, hipEventCreateWithFlags(&b->ev_render_done[k][slot], hipEventDisableTiming));
   }
-  uint32_t count[kBaseKinds] = {}, offset[kBaseKinds] = {};
-  for (uint32_t base = 0, at = 0; base < (uint32_t)kBaseKinds; ++base) {
-    offset[base] = at;
-    for (int c = 0; c < kClassCombos; ++c) count[base] += b->wgs_of_kind[base * kClassCombos + c];
-    at += count[base];
+  uint32_t count[kSideStreams] = {}, offset[kSideStreams] = {}; // per stream: Welsh base kinds first, then the bank streams
+  if (uniform) {
+    for (uint32_t base = 0, at = 0; base < (uint32_t)kBaseKinds; ++base) {
+      offset[base] = at;
+      for (int c = 0; c < kClassCombos; ++c) count[base] += b->wgs_of_kind[base * kClassCombos + c];
+      at += count[base];
+    }
+  } else {
+    count[b->stream_slot] = rows; // one kernel, on this bank's side stream (the loop below runs once)
   }
   if (ctx->need_fork) { // side streams must see what the ctx stream did since the last join (note events, uploads)
     GHIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -954,19 +963,27 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
   }
   const RenderConsts rc{(float)(3.14159265358979323846 / ctx->sr), (float)(0.49 * ctx->sr)};
   const dim3 blk(kThreads);
-  for (int k = kBaseKinds - 1; k >= 0; --k) { // most expensive kind first
+  for (int k = kSideStreams - 1; k >= 0; --k) { // most expensive Welsh kind first
     if (!count[k]) continue;
     hipStream_t st = ctx->side_stream[k];
     if (ctx->fork_pending[k]) { GHIP(ctx, hipStreamWaitEvent(st, ctx->ev_fork, 0)); ctx->fork_pending[k] = false; }
     if (b->reduce_recorded[slot]) GHIP(ctx, hipStreamWaitEvent(st, b->ev_reduce_done[slot], 0));
-    UniformArgs a{b->d_waves, b->d_state, b->d_pipe_part[slot], b->d_wg_list + offset[k], b->d_wg_cls + offset[k], 0, rc, b->n_vwaves, b->n, frames, count[k]};
-    switch (k) {
-      case 0: launch_welsh_uniform_specialised_0(a, st); break;
-      case 1: launch_welsh_uniform_specialised_1(a, st); break;
-      case 2: launch_welsh_uniform_specialised_2(a, st); break;
-      case 3: launch_welsh_uniform_specialised_3(a, st); break;
-      case 4: hipLaunchKernelGGL((welsh_render_uniform_kernel<true, LFO_F64, false, false>), dim3(count[k]), blk, 0, st, a); break;
-      default: hipLaunchKernelGGL((welsh_render_uniform_kernel<true, LFO_F64, true, false>), dim3(count[k]), blk, 0, st, a); break;
+    if (uniform) {
+      UniformArgs a{b->d_waves, b->d_state, b->d_pipe_part[slot], b->d_wg_list + offset[k], b->d_wg_cls + offset[k], 0, rc, b->n_vwaves, b->n, frames, count[k]};
+      switch (k) {
+        case 0: launch_welsh_uniform_specialised_0(a, st); break;
+        case 1: launch_welsh_uniform_specialised_1(a, st); break;
+        case 2: launch_welsh_uniform_specialised_2(a, st); break;
+        case 3: launch_welsh_uniform_specialised_3(a, st); break;
+        case 4: hipLaunchKernelGGL((welsh_render_uniform_kernel<true, LFO_F64, false, false>), dim3(count[k]), blk, 0, st, a); break;
+        default: hipLaunchKernelGGL((welsh_render_uniform_kernel<true, LFO_F64, true, false>), dim3(count[k]), blk, 0, st, a); break;
+      }
+    } else if (b->kind == BANK_WELSH) {
+      hipLaunchKernelGGL(welsh_render_kernel<true>, dim3(rows), blk, 0, st, b->d_params, b->d_state, b->n, frames, (size_t)0, b->d_pipe_part[slot], rc);
+    } else if (b->kind == BANK_FM) {
+      hipLaunchKernelGGL(fm_render_kernel<true>, dim3(rows), blk, 0, st, b->d_params, b->d_state, b->n, frames, (size_t)0, b->d_pipe_part[slot]);
+    } else {
+      hipLaunchKernelGGL(sampler_render_kernel<true>, dim3(rows), blk, 0, st, b->d_params, b->d_state, b->n, frames, (size_t)0, b->d_pipe_part[slot], b->d_pcm);
     }
     GHIP(ctx, hipEventRecord(b->ev_render_done[k][slot], st));
     GHIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_render_done[k][slot], 0));
@@ -988,9 +1005,14 @@ int groove_bank_render_mix(groove_bank* b, uint32_t frames, float* bus_dev, int 
   if (frames > 4096) return fail(ctx, "groove_bank_render_mix: frames > 4096");
   GHIP(ctx, hipSetDevice(ctx->device));
   if (flush_events(b)) return 1;
-  // pipeline over blocks when a block is long enough to pay for the extra stream bookkeeping
-  // (measured: +15 % at 1,000,000 voices, +21 % at 500,000, +4 % at 250,000, -17 % at 125,000)
-  if (b->kind == BANK_WELSH && b->n_vwaves >= ctx->pipeline_min_waves && !kNoPipeline) return render_mix_pipelined(b, frames, bus_dev, accumulate);
+  // Asynchronous form (kernels on side streams, only the bus reductions on the ctx stream):
+  //  - a large Welsh bank pipelines its own blocks when a block is long enough to pay for the extra stream
+  //    bookkeeping (measured: +15 % at 1,000,000 voices, +21 % at 500,000, +4 % at 250,000, -17 % at 125,000);
+  //  - in a project of several banks (synths, samplers) every bank takes it, so that the banks of one block
+  //    run beside each other instead of one after the other (mixed-131072: 0.46 -> 0.2x ms per block).
+  const bool force = ctx->pipeline_min_waves <= 1;
+  const bool big = b->kind == BANK_WELSH && b->n_vwaves >= ctx->pipeline_min_waves;
+  if (!kNoPipeline && (big || force || ctx->banks.size() > 1)) return render_mix_pipelined(b, frames, bus_dev, accumulate);
   if (ctx_join(ctx)) return 1; // earlier pipelined blocks of this bank may still be running on the side streams
   const uint32_t rows = (b->kind == BANK_WELSH && b->n_vwaves) ? (b->n_vwaves + kWaves - 1) / kWaves : blocks_for(b->n);
   const uint32_t cols = 2 * frames;
