@@ -314,6 +314,21 @@ def test_interleaved_bank_is_regrouped_transparently(gpu_ctx, oracle):
         assert np.abs(got[:, :, sample % 2 == 1]).max() == 0.0, "an odd voice sounds: note events landed on the wrong lanes"
         rms = np.sqrt(np.mean((got - want) ** 2, axis=(0, 1)))
         assert rms.max() <= TOL_RMS, rms.max()
+    # a control change on ONE voice of the regrouped bank (its run of equal patches splits around it)
+    v_ctl = int(sample[2])
+    assert v_ctl % 2 == 0
+    synth.control_set_param_by_index(T.CTL_WELSH_DCA_PAN, 0.9, voice=v_ctl)
+    pm = T.WelshParams.from_buffer_copy(params[v_ctl])  # a copy: params[...] is a view into the table
+    pm.dca_pan = 0.9 * 2.0 - 1.0
+    oc = oracle.Bank.welsh((T.WelshParams * 1)(pm))
+    oc.note_events(T.note_events_np(np.array([0], dtype=np.uint32), P.voice_keys(n)[v_ctl:v_ctl + 1], True))
+    for _ in range(blocks):
+        oc.render(frames)  # catch up with the blocks already rendered (pan is memoryless: only gains change)
+    synth.generate_batch_values(block, frames)
+    got = block.download(frames)[:, :, v_ctl].astype(np.float64)
+    want = oc.render(frames)[:, :, 0]
+    assert np.sqrt(np.mean((got - want) ** 2)) <= TOL_RMS
+    ob.render(frames)  # keep the sampled oracle in step
     st = synth.download_state()
     idle_word = st[:, 1::2]
     assert (idle_word == idle_word[:, :1]).all(), "odd (never triggered) voices must all hold the initial state"
