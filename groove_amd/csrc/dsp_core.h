@@ -257,7 +257,9 @@ GROOVE_HD void env_trigger_release(EnvState& s, const EnvParams& p) {
   const float len = p.release_len * from;
   env_enter_len(s, ENV_RELEASE, from, 0.0f, len, env_frames(len));
 }
-GROOVE_HD void env_tick(EnvState& s, const EnvParams& p) {
+// A tick = the stage-boundary check, then the value at the stage's frame counter.  The two halves are
+// also used apart: between two boundaries (of any lane of a wave) a run of frames needs no checks.
+GROOVE_HD void env_boundary(EnvState& s, const EnvParams& p) {
   if (s.n >= s.N) { // stage boundary (rare): up to two chained transitions in one frame
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -269,10 +271,18 @@ GROOVE_HD void env_tick(EnvState& s, const EnvParams& p) {
       }
     }
   }
+}
+GROOVE_HD void env_advance(EnvState& s) {
   const float t = (float)s.n * s.inv_len;
   s.value = fmaf(s.D, fmaf(-t, t, 2.0f * t), s.A);
   s.n += 1;
 }
+GROOVE_HD void env_tick(EnvState& s, const EnvParams& p) {
+  env_boundary(s, p);
+  env_advance(s);
+}
+// frames this envelope can advance before its next boundary check must run (>= 1 right after env_boundary)
+GROOVE_HD uint32_t env_frames_to_boundary(const EnvState& s) { return s.N - s.n; }
 
 // ------------------------------------------------------------------ 24 dB low-pass (a4)
 // Per-voice constants: c0 = 1/(cosh^2 r - 0.8535..), d1 = c0 sinh r 1.8477..,
@@ -452,12 +462,19 @@ GROOVE_HD uint32_t osc_class_wave(uint32_t runtime_waveform) {
 // VF_FIRST can be set).  RETUNE: false promises !welsh_retunes(p) for every lane, so the
 // coefficients in `sc` are loop-invariant.  LFO_MODE: see above.  C1, C2, CL: promise that every
 // lane's oscillator 1 / oscillator 2 / LFO is of that class (OSC_ANY promises nothing).
-template <bool FIRST, bool RETUNE, int LFO_MODE = LFO_F64, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY>
+// SEGMENT: the caller runs this frame inside a boundary-free segment (welsh_segment_begin) of a voice
+// that is not idle, so neither the envelopes' boundary checks nor the idle test are needed here.
+template <bool FIRST, bool RETUNE, int LFO_MODE = LFO_F64, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool SEGMENT = false>
 GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc,
                            WelshScratch& sc, float& L, float& R) {
-  env_tick(s.amp, p.amp);
-  env_tick(s.fil, p.fil);
-  if (s.amp.state == ENV_IDLE) { L = 0.0f; R = 0.0f; return; }
+  if (SEGMENT) {
+    env_advance(s.amp);
+    env_advance(s.fil);
+  } else {
+    env_tick(s.amp, p.amp);
+    env_tick(s.fil, p.fil);
+    if (s.amp.state == ENV_IDLE) { L = 0.0f; R = 0.0f; return; }
+  }
   const uint32_t w1 = osc_class_wave<C1>((p.flags >> WF_O1_WAVE_SHIFT) & 15u), w2 = osc_class_wave<C2>((p.flags >> WF_O2_WAVE_SHIFT) & 15u);
   // LFO class: an unused LFO has no routing; a classed LFO in a static-filter f32 kind can only be
   // routed to the amplitude (cutoff routing retunes, pitch / pulse width are other LFO modes)
@@ -544,6 +561,24 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
   const float m = y * a;
   L = m * p.gl;
   R = m * p.gr;
+}
+// Segments.  Between two envelope stage boundaries nothing about a voice's control flow changes: the
+// boundary checks of both envelopes and the idle test can be made once, and the frames up to the next
+// boundary run without them.  welsh_segment_begin handles any boundary due now and returns how many
+// frames THIS voice can run unchecked (>= 1); a wave takes the minimum over its lanes.  `live` = the
+// voice sounds in this segment (its frames go through welsh_frame<..., SEGMENT = true>); an idle
+// voice only advances its envelope counters (welsh_segment_idle_frame).  Frame for frame the
+// operations on every piece of state are those of the checked form.
+GROOVE_HD uint32_t welsh_segment_begin(const WelshParams& p, WelshState& s, bool& live) {
+  env_boundary(s.amp, p.amp);
+  env_boundary(s.fil, p.fil);
+  live = s.amp.state != ENV_IDLE;
+  const uint32_t a = env_frames_to_boundary(s.amp), f = env_frames_to_boundary(s.fil);
+  return a < f ? a : f;
+}
+GROOVE_HD void welsh_segment_idle_frame(WelshState& s) {
+  env_advance(s.amp);
+  env_advance(s.fil);
 }
 GROOVE_HD WelshScratch welsh_scratch_init(const WelshParams& p, const RenderConsts& rc) {
   WelshScratch sc;

@@ -202,47 +202,58 @@ __device__ __forceinline__ void run_frames(uint32_t frames, uint32_t n, uint32_t
     }
   }
 }
-// The same loop with frame 0 peeled by hand: `first(L, R)` computes frame 0 (first-tick flag, block
-// seeds of the LFO recurrences), `rest(f, L, R)` frames 1...  Used where the frame-0 body is so much
-// larger than the steady-state body that the compiler's own peeling of `if (f == 0)` gives up and
-// leaves both bodies (and the seed polynomials' constants) inside the loop.
-template <bool FUSED, class FirstFn, class RestFn>
-__device__ __forceinline__ void run_frames_peeled(uint32_t frames, uint32_t n, uint32_t v, bool active, size_t ch_stride,
-                                                  float* __restrict__ out, uint32_t prow, FirstFn&& first, RestFn&& rest) {
+template <int V> struct IntTag { static constexpr int value = V; };
+// Minimum of x over the 64 lanes (wave-uniform result).
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
+  auto step = [](uint32_t v, auto ctrl) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, decltype(ctrl)::value, 0xf, 0xf, false);
+    return o < v ? o : v;
+  };
+  x = step(x, IntTag<0xb1>{});   // quad_perm [1,0,3,2]
+  x = step(x, IntTag<0x4e>{});   // quad_perm [2,3,0,1]
+  x = step(x, IntTag<0x124>{});  // row_ror:4
+  x = step(x, IntTag<0x128>{});  // row_ror:8   -> every lane of a 16-lane row holds the row minimum
+  const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)x, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)x, 16);
+  const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)x, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)x, 48);
+  return min(min(r0, r1), min(r2, r3));
+}
+// Frame 0 by `first` (checked form); then boundary-free SEGMENTS (dsp_core.h): `begin(live)` handles the
+// envelope boundaries due now and returns the frames this lane can run unchecked, the wave takes the
+// minimum, and `live_frame` / `idle_frame` run that many frames without boundary or idle tests.
+template <bool FUSED, class FirstFn, class BeginFn, class LiveFn, class IdleFn>
+__device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n, uint32_t v, bool active, size_t ch_stride,
+                                                     float* __restrict__ out, uint32_t prow, FirstFn&& first, BeginFn&& begin,
+                                                     LiveFn&& live_frame, IdleFn&& idle_frame) {
   if (frames == 0) return;
-  if (FUSED) {
-    FusedAcc acc(prow);
-    constexpr uint32_t C = FusedAcc::kChunk;
-    static_assert(C > 1, "frame 0 never completes a chunk");
-    {
-      float L, R;
-      first(L, R);
-      acc.add(active ? L : 0.0f, active ? R : 0.0f, 0);
-    }
-    for (uint32_t f = 1; f < frames; ++f) {
-      float L, R;
-      rest(f, L, R);
+  constexpr uint32_t C = FusedAcc::kChunk;
+  static_assert(C > 1, "frame 0 never completes a chunk");
+  FusedAcc acc(prow);
+  auto put = [&](uint32_t f, float L, float R) {
+    if (FUSED) {
       acc.add(active ? L : 0.0f, active ? R : 0.0f, f);
       if ((f & (C - 1)) == C - 1) acc.flush(out, frames, f - (C - 1), C);
+    } else if (active) {
+      out[(size_t)f * n + v] = L;
+      out[ch_stride + (size_t)f * n + v] = R;
     }
-    if (frames & (C - 1)) acc.flush(out, frames, frames & ~(C - 1), frames & (C - 1));
-  } else {
-    {
-      float L, R;
-      first(L, R);
-      if (active) { out[v] = L; out[ch_stride + v] = R; }
-    }
-    for (uint32_t f = 1; f < frames; ++f) {
-      float L, R;
-      rest(f, L, R);
-      if (active) {
-        float* __restrict__ rowL = out + (size_t)f * n;
-        float* __restrict__ rowR = out + ch_stride + (size_t)f * n;
-        rowL[v] = L;
-        rowR[v] = R;
-      }
+  };
+  {
+    float L, R;
+    first(L, R);
+    put(0, L, R);
+  }
+  uint32_t f = 1;
+  while (f < frames) {
+    bool live;
+    const uint32_t mine = begin(live);
+    const uint32_t seg = min(wave_min_u32(mine), frames - f);
+    for (uint32_t k = 0; k < seg; ++k, ++f) {
+      float L = 0.0f, R = 0.0f;
+      if (live) live_frame(L, R); else idle_frame();
+      put(f, L, R);
     }
   }
+  if (FUSED && (frames & (C - 1))) acc.flush(out, frames, frames & ~(C - 1), frames & (C - 1));
 }
 
 // ------------------------------------------------------------------ instruments
@@ -257,10 +268,13 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
   // Static cutoff + wave-uniform patch: the six f64 coefficients are the same in every lane and
   // never change, so they ride in SGPRs (12 VGPRs back; f64 FMAs take one scalar operand).
   if (UNIFORM && !RETUNE) sc.coef = make_scalar(sc.coef);
-  if constexpr (UNIFORM && LFO_MODE != LFO_F32) {
-    run_frames_peeled<FUSED>(frames, n, v, active, ch_stride, out, prow,
-                             [&](float& L, float& R) { welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL>(p, s, rc, sc, L, R); },
-                             [&](uint32_t, float& L, float& R) { welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL>(p, s, rc, sc, L, R); });
+  if constexpr (UNIFORM) {
+    run_frames_segmented<FUSED>(
+        frames, n, v, active, ch_stride, out, prow,
+        [&](float& L, float& R) { welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL>(p, s, rc, sc, L, R); },
+        [&](bool& live) { return welsh_segment_begin(p, s, live); },
+        [&](float& L, float& R) { welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true>(p, s, rc, sc, L, R); },
+        [&]() { welsh_segment_idle_frame(s); });
   } else {
     run_frames<FUSED>(frames, n, v, active, ch_stride, out, prow, [&](uint32_t f, float& L, float& R) {
       if (f == 0) welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL>(p, s, rc, sc, L, R);

@@ -10,7 +10,7 @@
 using namespace groove;
 
 struct EmulBank {
-  int kind; uint32_t n; double sr; int generic_lfo = 0;
+  int kind; uint32_t n; double sr; int generic_lfo = 0; int segmented = 1;
   std::vector<WelshParams> wp; std::vector<WelshState> ws; std::vector<WelshCold> wc;
   std::vector<FmParams> fp; std::vector<FmState> fs; std::vector<double> ratio;
   std::vector<SamplerParams> sp; std::vector<SamplerState> ss; std::vector<float> pcm;
@@ -28,7 +28,20 @@ static void welsh_emul_frame(const WelshParams& p, WelshState& s, const RenderCo
   else { if (retune) welsh_emul_frame2<false, true>(p, s, rc, sc, mode, L, R); else welsh_emul_frame2<false, false>(p, s, rc, sc, mode, L, R); }
 }
 
+template <bool RETUNE>
+static void welsh_emul_segment_frame2(const WelshParams& p, WelshState& s, const RenderConsts& rc, WelshScratch& sc, int mode, float& L, float& R) {
+  if (mode == LFO_F32) welsh_frame<false, RETUNE, LFO_F32, OSC_ANY, OSC_ANY, OSC_ANY, true>(p, s, rc, sc, L, R);
+  else if (mode == LFO_F64) welsh_frame<false, RETUNE, LFO_F64, OSC_ANY, OSC_ANY, OSC_ANY, true>(p, s, rc, sc, L, R);
+  else welsh_frame<false, RETUNE, LFO_F64_SMOOTH, OSC_ANY, OSC_ANY, OSC_ANY, true>(p, s, rc, sc, L, R);
+}
+static void welsh_emul_segment_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc, WelshScratch& sc, bool retune, int mode,
+                                     float& L, float& R) {
+  if (retune) welsh_emul_segment_frame2<true>(p, s, rc, sc, mode, L, R); else welsh_emul_segment_frame2<false>(p, s, rc, sc, mode, L, R);
+}
+
 extern "C" {
+// segmented != 0 (default): frames after the first run in boundary-free segments, as in the uniform kernels
+void emul_set_segmented(void* h, int on);
 // generic_lfo != 0: evaluate the f64 LFO exactly on every frame (the per-lane kernel's choice) instead of the recurrences
 void emul_set_generic_lfo(void* h, int on);
 void* emul_welsh_create(const groove_welsh_params* p, uint32_t n, uint32_t sr) {
@@ -55,6 +68,7 @@ void* emul_sampler_create(const float* pcm, uint64_t frames, const groove_sample
 }
 void emul_bank_destroy(void* h) { delete (EmulBank*)h; }
 void emul_set_generic_lfo(void* h, int on) { ((EmulBank*)h)->generic_lfo = on; }
+void emul_set_segmented(void* h, int on) { ((EmulBank*)h)->segmented = on; }
 void emul_bank_note_events(void* h, const groove_note_event* ev, uint32_t n_ev) {
   EmulBank* b = (EmulBank*)h;
   for (uint32_t i = 0; i < n_ev; ++i) {
@@ -80,9 +94,17 @@ void emul_bank_render(void* h, uint32_t frames, float* out) {
       sc = welsh_scratch_init(b->wp[v], rc); retunes = welsh_retunes(b->wp[v]);
       mode = b->generic_lfo ? (welsh_lfo_mode(b->wp[v]) == LFO_F32 ? LFO_F32 : LFO_F64) : welsh_lfo_mode(b->wp[v]);
     }
+    uint32_t seg_left = 0; // segmented form (uniform kernels): frames left before the next boundary check
+    bool seg_live = false;
     for (uint32_t f = 0; f < frames; ++f) {
       float L, R;
-      if (b->kind == 0) { // mirrors the uniform kernel: frame 0 peeled, RETUNE and the LFO mode chosen per voice
+      if (b->kind == 0 && b->segmented && f > 0) { // mirrors run_frames_segmented with a one-lane wave
+        if (seg_left == 0) seg_left = welsh_segment_begin(b->wp[v], b->ws[v], seg_live);
+        L = R = 0.0f;
+        if (seg_live) welsh_emul_segment_frame(b->wp[v], b->ws[v], rc, sc, retunes, mode, L, R);
+        else welsh_segment_idle_frame(b->ws[v]);
+        --seg_left;
+      } else if (b->kind == 0) { // mirrors the kernels' checked form: frame 0 peeled, RETUNE and the LFO mode chosen per voice
         welsh_emul_frame(b->wp[v], b->ws[v], rc, sc, f == 0, retunes, mode, L, R);
       } else if (b->kind == 1) {
         if (f == 0) fm_frame<true>(b->fp[v], b->fs[v], L, R); else fm_frame<false>(b->fp[v], b->fs[v], L, R);

@@ -33,6 +33,7 @@ def lib():
         L.emul_sampler_create.argtypes = [_fp, C.c_uint64, C.POINTER(T.SampleDesc), u32, C.POINTER(T.SamplerParams), u32, u32]
         L.emul_bank_destroy.argtypes = [vp]
         L.emul_set_generic_lfo.argtypes = [vp, C.c_int]
+        L.emul_set_segmented.argtypes = [vp, C.c_int]
         L.emul_bank_note_events.argtypes = [vp, C.POINTER(T.NoteEvent), u32]
         L.emul_bank_render.argtypes = [vp, u32, _fp]
         L.emul_bitcrush.restype = C.c_float; L.emul_bitcrush.argtypes = [C.c_float, u32]
@@ -60,6 +61,10 @@ class Bank:
 
     def note_events(self, ev):
         lib().emul_bank_note_events(self.h, ev, len(ev))
+
+    def set_segmented(self, on):
+        """True (default): boundary-free segments as in the uniform kernels; False: every frame checked (per-lane kernel)."""
+        lib().emul_set_segmented(self.h, 1 if on else 0)
 
     def set_generic_lfo(self, on):
         """True: exact per-frame f64 LFO (per-lane kernel); False: block-seeded recurrences where promised."""

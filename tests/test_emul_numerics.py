@@ -74,3 +74,21 @@ def test_fused_filter_coefficients_are_bit_identical_to_the_two_step_form():
         L.emul_lp24_coef_both(ripple, fc, sr, out)
         a = np.frombuffer(out, dtype=np.uint64)
         assert (a[:6] == a[6:]).all(), (ripple, fc, sr)
+
+
+def test_segmented_and_checked_forms_are_bit_identical():
+    """Boundary-free segments (uniform kernels) against per-frame envelope checks (per-lane kernel):
+    the same operations on the same state, so the same bits — over note-on, release, idle and re-trigger."""
+    n = 32
+    params = P.welsh_voices(n)
+    a, b = E.Bank.welsh(params), E.Bank.welsh(params)
+    a.set_segmented(True); b.set_segmented(False)
+    on, off = P.note_on_all(n), P.note_off_all(n)
+    for blk in range(60):
+        if blk in (0, 40):
+            a.note_events(on); b.note_events(on)
+        if blk == 12:
+            a.note_events(off); b.note_events(off)
+        frames = [256, 100, 7, 1][blk % 4]
+        x, y = a.render(frames), b.render(frames)
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), blk
