@@ -542,7 +542,8 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
   if (RETUNE) {
     bool retune = false;
     float pct = 0.0f;
-    if (p.flags & WF_RETUNE_ENV) {
+    // (an unused LFO cannot drive the cutoff: in a retuned kind the envelope must)
+    if (CL == LFO_UNUSED || (p.flags & WF_RETUNE_ENV)) {
       pct = fmaf((1.0f - p.cutoff_start) * p.cutoff_end, s.fil.value, p.cutoff_start);
       retune = true;
     } else if (routing == GROOVE_LFO_FILTER_CUTOFF) {
