@@ -53,10 +53,10 @@ __device__ __forceinline__ void soa_store(uint32_t* __restrict__ buf, uint32_t n
 #define GROOVE_WAVES_F32_RETUNE 6
 #endif
 #ifndef GROOVE_WAVES_SMOOTH_STATIC
-#define GROOVE_WAVES_SMOOTH_STATIC 5
+#define GROOVE_WAVES_SMOOTH_STATIC 4
 #endif
 #ifndef GROOVE_WAVES_SMOOTH_RETUNE
-#define GROOVE_WAVES_SMOOTH_RETUNE 5
+#define GROOVE_WAVES_SMOOTH_RETUNE 4
 #endif
 #ifndef GROOVE_WAVES_F64
 #define GROOVE_WAVES_F64 2
