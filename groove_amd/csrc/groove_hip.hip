@@ -62,6 +62,7 @@ struct groove_bank {
   std::vector<uint32_t> perm, inv;
   uint32_t* d_inv = nullptr;      // device copy of inv (materialised renders are handed out in the caller's lane order)
   uint8_t* d_wg_cls = nullptr;   // welsh: oscillator class pair of each entry of d_wg_list
+  uint8_t* d_wg_base = nullptr;  // welsh: base kind of each entry of d_wg_list (the all-kinds kernel of small banks)
   uint32_t* d_wg_list = nullptr; // welsh: workgroup ids (groups of 4 virtual waves) sorted by kind (kernels.h)
   size_t wg_list_cap = 0;
   uint32_t wgs_of_kind[kWgKinds] = {};  // slice lengths of d_wg_list, in kind order
@@ -105,7 +106,7 @@ struct groove_ctx {
   bool side_busy[kSideStreams] = {};    // work enqueued on the side stream since the last join
   bool fork_pending[kSideStreams] = {}; // the side stream has not yet waited for ev_fork
   bool need_fork = true;                // ctx-stream work since the last fork that side streams must wait for
-  uint32_t pipeline_min_waves = 3072;   // banks at least this long (~200,000 voices) pipeline their fused blocks
+  uint32_t pipeline_min_waves = 4700;   // banks at least this long (~300,000 voices) run one kernel per base kind and pipeline their fused blocks; smaller ones take the all-kinds kernel
   int next_stream_slot = 0;             // round-robin side-stream assignment of single-kernel banks
   uint32_t sr = GROOVE_DEFAULT_SAMPLE_RATE;
   std::string err;
@@ -282,7 +283,7 @@ int welsh_upload_params(groove_bank* b, bool regroup) {
     kind[g] = (uint16_t)wg_kind_of(base, cl, spec ? std::max(need[g].c1, 0) : (int)OSC_ANY, spec ? std::max(need[g].c2, 0) : (int)OSC_ANY);
   }
   std::vector<uint32_t> wg_list(wgs);
-  std::vector<uint8_t> wg_cls(wgs);
+  std::vector<uint8_t> wg_cls(wgs), wg_base(wgs);
   {
     std::vector<uint32_t> at(kWgKinds + 1, 0);
     for (uint16_t k : kind) b->wgs_of_kind[k] += 1;
@@ -291,6 +292,7 @@ int welsh_upload_params(groove_bank* b, bool regroup) {
       const uint32_t slot = at[kind[g]]++;
       wg_list[slot] = g;
       wg_cls[slot] = (uint8_t)(kind[g] % kClassCombos);
+      wg_base[slot] = (uint8_t)(kind[g] / kClassCombos);
     }
   }
   if (b->vwaves_cap < W.size()) {
@@ -304,10 +306,13 @@ int welsh_upload_params(groove_bank* b, bool regroup) {
     GHIP(ctx, hipMalloc(&b->d_wg_list, b->wg_list_cap * sizeof(uint32_t)));
     if (b->d_wg_cls) GHIP(ctx, hipFree(b->d_wg_cls));
     GHIP(ctx, hipMalloc(&b->d_wg_cls, b->wg_list_cap));
+    if (b->d_wg_base) GHIP(ctx, hipFree(b->d_wg_base));
+    GHIP(ctx, hipMalloc(&b->d_wg_base, b->wg_list_cap));
   }
   GHIP(ctx, hipMemcpy(b->d_waves, W.data(), W.size() * sizeof(WaveDesc), hipMemcpyHostToDevice));
   GHIP(ctx, hipMemcpy(b->d_wg_list, wg_list.data(), (size_t)wgs * sizeof(uint32_t), hipMemcpyHostToDevice));
   GHIP(ctx, hipMemcpy(b->d_wg_cls, wg_cls.data(), wgs, hipMemcpyHostToDevice));
+  GHIP(ctx, hipMemcpy(b->d_wg_base, wg_base.data(), wgs, hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -784,7 +789,7 @@ int groove_bank_destroy(groove_bank* b) {
   auto it = std::find(ctx->banks.begin(), ctx->banks.end(), b);
   if (it != ctx->banks.end()) ctx->banks.erase(it);
   if (b->scratch) groove_block_destroy(b->scratch);
-  (void)hipFree(b->d_params); (void)hipFree(b->d_state); (void)hipFree(b->d_cold); (void)hipFree(b->d_pcm); (void)hipFree(b->d_ev); (void)hipFree(b->d_waves); (void)hipFree(b->d_wg_list); (void)hipFree(b->d_wg_cls); (void)hipFree(b->d_inv);
+  (void)hipFree(b->d_params); (void)hipFree(b->d_state); (void)hipFree(b->d_cold); (void)hipFree(b->d_pcm); (void)hipFree(b->d_ev); (void)hipFree(b->d_waves); (void)hipFree(b->d_wg_list); (void)hipFree(b->d_wg_cls); (void)hipFree(b->d_wg_base); (void)hipFree(b->d_inv);
   delete b;
   return 0;
 }
@@ -831,6 +836,13 @@ static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs
       // One kernel per base kind present, all running concurrently: the most expensive kind goes
       // out first on the ctx stream (list scheduling, longest first), the others on side streams
       // forked from it, and the ctx stream joins them before the bus reduction.
+      if (fused && b->n_vwaves < ctx->pipeline_min_waves) { // small bank: all base kinds in one launch (kernels.h)
+        const uint32_t wgs = (b->n_vwaves + kWaves - 1) / kWaves;
+        UniformArgs a{b->d_waves, b->d_state, out, b->d_wg_list, b->d_wg_cls, chs, rc, b->n_vwaves, b->n, frames, wgs};
+        launch_welsh_uniform_any(a, b->d_wg_base, ctx->stream);
+        GHIP(ctx, hipGetLastError());
+        return 0;
+      }
       uint32_t count[kBaseKinds] = {}, offset[kBaseKinds] = {};
       {
         uint32_t at = 0;
@@ -926,8 +938,9 @@ int groove_bank_render(groove_bank* b, uint32_t frames, groove_block* out) {
 // render of block b+2 waits for the reduction of block b.
 static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev, int accumulate) {
   groove_ctx* ctx = b->ctx;
-  const bool uniform = b->kind == BANK_WELSH && b->n_vwaves;
-  const uint32_t rows = uniform ? (b->n_vwaves + kWaves - 1) / kWaves : blocks_for(b->n);
+  const bool small_uniform = b->kind == BANK_WELSH && b->n_vwaves && b->n_vwaves < ctx->pipeline_min_waves && ctx->pipeline_min_waves > 1;
+  const bool uniform = b->kind == BANK_WELSH && b->n_vwaves && !small_uniform; // one kernel per base kind
+  const uint32_t rows = (b->kind == BANK_WELSH && b->n_vwaves) ? (b->n_vwaves + kWaves - 1) / kWaves : blocks_for(b->n);
   const uint32_t cols = 2 * frames, rows_per_seg = 64, segs = (rows + rows_per_seg - 1) / rows_per_seg;
   const int slot = b->pipe_slot;
   b->pipe_slot ^= 1;
@@ -978,6 +991,9 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
         case 4: hipLaunchKernelGGL((welsh_render_uniform_kernel<true, LFO_F64, false, false>), dim3(count[k]), blk, 0, st, a); break;
         default: hipLaunchKernelGGL((welsh_render_uniform_kernel<true, LFO_F64, true, false>), dim3(count[k]), blk, 0, st, a); break;
       }
+    } else if (small_uniform) { // all base kinds in one launch on this bank's stream
+      UniformArgs a{b->d_waves, b->d_state, b->d_pipe_part[slot], b->d_wg_list, b->d_wg_cls, 0, rc, b->n_vwaves, b->n, frames, rows};
+      launch_welsh_uniform_any(a, b->d_wg_base, st);
     } else if (b->kind == BANK_WELSH) {
       hipLaunchKernelGGL(welsh_render_kernel<true>, dim3(rows), blk, 0, st, b->d_params, b->d_state, b->n, frames, (size_t)0, b->d_pipe_part[slot], rc);
     } else if (b->kind == BANK_FM) {
@@ -1006,8 +1022,9 @@ int groove_bank_render_mix(groove_bank* b, uint32_t frames, float* bus_dev, int 
   GHIP(ctx, hipSetDevice(ctx->device));
   if (flush_events(b)) return 1;
   // Asynchronous form (kernels on side streams, only the bus reductions on the ctx stream):
-  //  - a large Welsh bank pipelines its own blocks when a block is long enough to pay for the extra stream
-  //    bookkeeping (measured: +15 % at 1,000,000 voices, +21 % at 500,000, +4 % at 250,000, -17 % at 125,000);
+  //  - a large Welsh bank (>= ~300,000 voices) runs one kernel per base kind and pipelines its own blocks
+  //    (+15 % at 1,000,000 voices, +21 % at 500,000); below that a block is latency-bound and the
+  //    all-kinds kernel wins (250,000 voices: 0.265 ms against 0.306; 125,000: 0.233 against 0.276);
   //  - in a project of several banks (synths, samplers) every bank takes it, so that the banks of one block
   //    run beside each other instead of one after the other (mixed-131072: 0.46 -> 0.2x ms per block).
   const bool force = ctx->pipeline_min_waves <= 1;

@@ -61,6 +61,9 @@ __device__ __forceinline__ void soa_store(uint32_t* __restrict__ buf, uint32_t n
 #ifndef GROOVE_WAVES_F64
 #define GROOVE_WAVES_F64 2
 #endif
+#ifndef GROOVE_WAVES_ANY
+#define GROOVE_WAVES_ANY 3 /* the all-kinds kernel of small banks: room for the exact-f64 bodies */
+#endif
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 
@@ -375,6 +378,54 @@ template <bool FUSED, int LFO_MODE, bool RETUNE, int C1, int C2, int CL>
 __device__ __attribute__((noinline)) void welsh_uniform_body(UniformArgsPtr a) {
   welsh_uniform_body_impl<FUSED, LFO_MODE, RETUNE, C1, C2, CL>(uniform_args_scalar(a));
 }
+// A workgroup whose voices are all silent with both envelopes idle (unused polyphony, voices past
+// their release) contributes zeros and changes nothing but idle-plateau counters: it writes its zero
+// rows and leaves.  Two state words per lane, one vote; nothing else is loaded.  Returns true if
+// the workgroup is done.
+__device__ __forceinline__ bool welsh_idle_workgroup(const UniformArgs& a) {
+  const uint32_t wg = a.wg_list[blockIdx.x];
+  const uint32_t w0 = wg * kWaves + (threadIdx.x >> 6);
+  const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(w0, a.n_waves - 1));
+  const uint32_t vbase = a.waves[w].vbase, count = a.waves[w].count;
+  const bool active = (w0 < a.n_waves) && ((threadIdx.x & 63u) < count);
+  const uint32_t v = active ? vbase + (threadIdx.x & 63u) : vbase;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(a.state, 0, (int)(sizeof(WelshState) / 4 * a.n * 4u), 0x00020000);
+  constexpr uint32_t kAmpWord = offsetof(WelshState, amp) / 4 + offsetof(EnvState, state) / 4;
+  constexpr uint32_t kFilWord = offsetof(WelshState, fil) / 4 + offsetof(EnvState, state) / 4;
+  const uint32_t sa = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(v * 4u), (int)(kAmpWord * a.n * 4u), 0);
+  const uint32_t sf = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(v * 4u), (int)(kFilWord * a.n * 4u), 0);
+  __shared__ int busy_waves;
+  if (threadIdx.x == 0) busy_waves = 0;
+  __syncthreads();
+  if (!__all(!active || (sa == ENV_IDLE && sf == ENV_IDLE)) && (threadIdx.x & 63u) == 0) atomicAdd(&busy_waves, 1);
+  __syncthreads();
+  if (busy_waves != 0) return false;
+  float* __restrict__ rows = a.out + (size_t)wg * 2 * a.frames; // partial[wg][ch][frame]
+  for (uint32_t t = threadIdx.x; t < 2 * a.frames; t += kThreads) rows[t] = 0.0f;
+  return true;
+}
+// One scalar switch on the workgroup's class combination, to the block body compiled for it.
+template <bool FUSED, int LFO_MODE, bool RETUNE>
+__device__ __forceinline__ void welsh_dispatch_class(uint32_t cls, UniformArgsPtr ka) {
+#define GROOVE_CLS_CASE(CL, C1, C2) case wg_class_combo(CL, C1, C2): welsh_uniform_body<FUSED, LFO_MODE, RETUNE, C1, C2, CL>(ka); break;
+#define GROOVE_CLS_ROW(CL, C1) GROOVE_CLS_CASE(CL, C1, 0) GROOVE_CLS_CASE(CL, C1, 1) GROOVE_CLS_CASE(CL, C1, 2) GROOVE_CLS_CASE(CL, C1, 3) GROOVE_CLS_CASE(CL, C1, 4)
+#define GROOVE_CLS_PLANE(CL) GROOVE_CLS_ROW(CL, 0) GROOVE_CLS_ROW(CL, 1) GROOVE_CLS_ROW(CL, 2) GROOVE_CLS_ROW(CL, 3) GROOVE_CLS_ROW(CL, 4)
+  switch (cls) {
+    GROOVE_CLS_PLANE(OSC_ANY) GROOVE_CLS_PLANE(OSC_TRIANGLE) GROOVE_CLS_PLANE(OSC_SINE)
+    default:
+      if constexpr (LFO_MODE == LFO_F32) { // a smooth f64 LFO is a sine or a triangle (or OSC_ANY: triangle-sine)
+        switch (cls) {
+          GROOVE_CLS_PLANE(OSC_PULSE) GROOVE_CLS_PLANE(OSC_SAW) GROOVE_CLS_PLANE(LFO_UNUSED)
+          default: break;
+        }
+      }
+      break;
+  }
+#undef GROOVE_CLS_PLANE
+#undef GROOVE_CLS_ROW
+#undef GROOVE_CLS_CASE
+}
 // SPECIALISED = false: the whole launch runs the OSC_ANY x OSC_ANY body (wg_cls is not read).
 template <bool FUSED, int LFO_MODE, bool RETUNE, bool SPECIALISED>
 __global__ __launch_bounds__(kThreads, (WavesBudget<LFO_MODE, RETUNE>::value)) void welsh_render_uniform_kernel(UniformArgs a) {
@@ -382,56 +433,33 @@ __global__ __launch_bounds__(kThreads, (WavesBudget<LFO_MODE, RETUNE>::value)) v
   // issue priority over co-resident waves of the short kinds (list scheduling, longest first).
   if (LFO_MODE != LFO_F32) __builtin_amdgcn_s_setprio(2);
   const UniformArgsPtr ka = (UniformArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(); // == &a, in the constant address space
-  if constexpr (FUSED) {
-    // A workgroup whose voices are all silent with both envelopes idle (unused polyphony, voices past
-    // their release) contributes zeros and changes nothing but idle-plateau counters: it writes its
-    // zero rows and leaves.  Two state words per lane, one vote; nothing else is loaded.
-    const uint32_t wg = a.wg_list[blockIdx.x];
-    const uint32_t w0 = wg * kWaves + (threadIdx.x >> 6);
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(w0, a.n_waves - 1));
-    const uint32_t vbase = a.waves[w].vbase, count = a.waves[w].count;
-    const bool active = (w0 < a.n_waves) && ((threadIdx.x & 63u) < count);
-    const uint32_t v = active ? vbase + (threadIdx.x & 63u) : vbase;
-    const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(a.state, 0, (int)(sizeof(WelshState) / 4 * a.n * 4u), 0x00020000);
-    constexpr uint32_t kAmpWord = offsetof(WelshState, amp) / 4 + offsetof(EnvState, state) / 4;
-    constexpr uint32_t kFilWord = offsetof(WelshState, fil) / 4 + offsetof(EnvState, state) / 4;
-    const uint32_t sa = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(v * 4u), (int)(kAmpWord * a.n * 4u), 0);
-    const uint32_t sf = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(v * 4u), (int)(kFilWord * a.n * 4u), 0);
-    __shared__ int busy_waves;
-    if (threadIdx.x == 0) busy_waves = 0;
-    __syncthreads();
-    if (!__all(!active || (sa == ENV_IDLE && sf == ENV_IDLE)) && (threadIdx.x & 63u) == 0) atomicAdd(&busy_waves, 1);
-    __syncthreads();
-    if (busy_waves == 0) {
-      float* __restrict__ rows = a.out + (size_t)wg * 2 * a.frames; // partial[wg][ch][frame]
-      for (uint32_t t = threadIdx.x; t < 2 * a.frames; t += kThreads) rows[t] = 0.0f;
-      return;
-    }
-  }
+  if constexpr (FUSED) { if (welsh_idle_workgroup(a)) return; }
   if constexpr (!SPECIALISED) {
     welsh_uniform_body_impl<FUSED, LFO_MODE, RETUNE, OSC_ANY, OSC_ANY, OSC_ANY>(ka);
   } else {
-    const uint32_t cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[blockIdx.x]); // wg_class_combo(cl, c1, c2)
-#define GROOVE_CLS_CASE(CL, C1, C2) case wg_class_combo(CL, C1, C2): welsh_uniform_body<FUSED, LFO_MODE, RETUNE, C1, C2, CL>(ka); break;
-#define GROOVE_CLS_ROW(CL, C1) GROOVE_CLS_CASE(CL, C1, 0) GROOVE_CLS_CASE(CL, C1, 1) GROOVE_CLS_CASE(CL, C1, 2) GROOVE_CLS_CASE(CL, C1, 3) GROOVE_CLS_CASE(CL, C1, 4)
-#define GROOVE_CLS_PLANE(CL) GROOVE_CLS_ROW(CL, 0) GROOVE_CLS_ROW(CL, 1) GROOVE_CLS_ROW(CL, 2) GROOVE_CLS_ROW(CL, 3) GROOVE_CLS_ROW(CL, 4)
-    switch (cls) {
-      GROOVE_CLS_PLANE(OSC_ANY) GROOVE_CLS_PLANE(OSC_TRIANGLE) GROOVE_CLS_PLANE(OSC_SINE)
-      default:
-        if constexpr (LFO_MODE == LFO_F32) { // a smooth f64 LFO is a sine or a triangle (or OSC_ANY: triangle-sine)
-          switch (cls) {
-            GROOVE_CLS_PLANE(OSC_PULSE) GROOVE_CLS_PLANE(OSC_SAW) GROOVE_CLS_PLANE(LFO_UNUSED)
-            default: break;
-          }
-        }
-        break;
-    }
-#undef GROOVE_CLS_PLANE
-#undef GROOVE_CLS_ROW
-#undef GROOVE_CLS_CASE
+    welsh_dispatch_class<FUSED, LFO_MODE, RETUNE>((uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[blockIdx.x]), ka);
   }
 }
+// All base kinds in ONE launch (fused form), for banks too small to fill the machine: there a block is
+// bound by one wavefront's serial walk of its frames, register budgets do not matter (the kernel takes
+// the largest), and what counts is that every workgroup starts at once instead of queueing behind
+// the few hardware queues that several per-kind launches share.  wg_base[] = base kind per workgroup.
+#ifdef GROOVE_WELSH_ANY_TU // defined (once) by the translation unit that owns this kernel
+__global__ __launch_bounds__(kThreads, GROOVE_WAVES_ANY) void welsh_render_uniform_any_kernel(UniformArgs a, const uint8_t* __restrict__ wg_base) {
+  const UniformArgsPtr ka = (UniformArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  if (welsh_idle_workgroup(a)) return;
+  const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wg_base[blockIdx.x]);
+  const uint32_t cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[blockIdx.x]);
+  switch (base) {
+    case wg_base_kind_of(LFO_F32, false): welsh_dispatch_class<true, LFO_F32, false>(cls, ka); break;
+    case wg_base_kind_of(LFO_F32, true): welsh_dispatch_class<true, LFO_F32, true>(cls, ka); break;
+    case wg_base_kind_of(LFO_F64_SMOOTH, false): welsh_dispatch_class<true, LFO_F64_SMOOTH, false>(cls, ka); break;
+    case wg_base_kind_of(LFO_F64_SMOOTH, true): welsh_dispatch_class<true, LFO_F64_SMOOTH, true>(cls, ka); break;
+    case wg_base_kind_of(LFO_F64, false): welsh_uniform_body<true, LFO_F64, false, OSC_ANY, OSC_ANY, OSC_ANY>(ka); break;
+    default: welsh_uniform_body<true, LFO_F64, true, OSC_ANY, OSC_ANY, OSC_ANY>(ka); break;
+  }
+}
+#endif // GROOVE_WELSH_ANY_TU
 static_assert(OSC_CLASSES == 5 && LFO_CLASSES == 6 && kClassCombos <= 256, "the class switch above lists 6 x 5 x 5 combinations, one byte each");
 // Launchers of the four class-specialised fused kernels, one translation unit each
 // (csrc/welsh_class.hip, -DGROOVE_BASE_KIND=0..3) so that they compile in parallel.
@@ -439,6 +467,7 @@ void launch_welsh_uniform_specialised_0(const UniformArgs& a, hipStream_t st);
 void launch_welsh_uniform_specialised_1(const UniformArgs& a, hipStream_t st);
 void launch_welsh_uniform_specialised_2(const UniformArgs& a, hipStream_t st);
 void launch_welsh_uniform_specialised_3(const UniformArgs& a, hipStream_t st);
+void launch_welsh_uniform_any(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st); // csrc/welsh_class.hip, -DGROOVE_BASE_KIND=9
 
 template <bool FUSED>
 __global__ __launch_bounds__(kThreads) void fm_render_kernel(

@@ -1,7 +1,11 @@
 // welsh_class.hip — the fused, class-specialised uniform Welsh kernel of ONE base kind (compiled
-// four times, -DGROOVE_BASE_KIND=0..3, so the 4 x 25 block bodies build in parallel).  See
+// with -DGROOVE_BASE_KIND=0..3, so the block bodies build in parallel), or (-DGROOVE_BASE_KIND=9)
+// the all-kinds kernel of small banks.  See
 // kernels.h, "Workgroup KINDS".
 #define GROOVE_WELSH_CLASS_TU 1
+#if defined(GROOVE_BASE_KIND) && GROOVE_BASE_KIND == 9
+#define GROOVE_WELSH_ANY_TU 1
+#endif
 #include "kernels.h"
 #ifndef GROOVE_BASE_KIND
 #error "compile with -DGROOVE_BASE_KIND=<0..3>"
@@ -22,6 +26,10 @@ void launch_welsh_uniform_specialised_2(const UniformArgs& a, hipStream_t st) {
 #elif GROOVE_BASE_KIND == 3
 void launch_welsh_uniform_specialised_3(const UniformArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((welsh_render_uniform_kernel<true, LFO_F64_SMOOTH, true, true>), dim3(a.n_wgs), dim3(kThreads), 0, st, a);
+}
+#elif GROOVE_BASE_KIND == 9
+void launch_welsh_uniform_any(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st) {
+  hipLaunchKernelGGL(welsh_render_uniform_any_kernel, dim3(a.n_wgs), dim3(kThreads), 0, st, a, wg_base);
 }
 #else
 #error "GROOVE_BASE_KIND out of range"
