@@ -84,3 +84,26 @@ def test_full_size_properties_and_sampled_parity(gpu_ctx, oracle):
     mbus = bus2.download().astype(np.float64)
     assert np.max(np.abs(mbus - whole)) / V <= 1e-6, "fused and materialised buses differ"
     mat.destroy(); block.destroy()
+
+
+def test_repeated_renders_are_bit_identical(gpu_ctx):
+    """The fused bus is a fixed-order reduction (partial rows, then segments), whichever streams the voice
+    kernels ran on and however the blocks overlapped: two renders of the same project give the same bits.
+    One size per launch form: all-kinds kernel (small bank), per-kind kernels with the block pipeline."""
+    from groove_amd import entities as E
+    for n in (40_000, 400_000):
+        params, vidx = P.welsh_voices_grouped(n)
+        on, off = P.grouped_note_events(vidx, True), P.grouped_note_events(vidx, False)
+        runs = []
+        for _ in range(2):
+            synth = E.WelshSynth(gpu_ctx, params)
+            bus = gpu_ctx.bus(12 * 256)
+            for b in range(12):
+                if b == 0:
+                    synth.handle_midi_events(on)
+                if b == 7:
+                    synth.handle_midi_events(off)
+                synth.render_mix(bus, 256, at_frame=b * 256)
+            runs.append(bus.download())
+            synth.destroy(); bus.destroy()
+        assert np.array_equal(runs[0].view(np.uint32), runs[1].view(np.uint32)), n
