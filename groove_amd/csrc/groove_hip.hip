@@ -2,7 +2,8 @@
 //
 // Host side of the MI355X render path: owns device memory, derives packed per-lane
 // parameters (derive.h), queues block-granular note events, launches the kernels in
-// kernels.h on the ctx stream.  Nothing here falls back to a CPU path: every entry point
+// kernels.h (voice kernels on per-kind / per-bank side streams, everything else on the ctx stream).
+// Nothing here falls back to a CPU path: every entry point
 // either launches HIP work or returns an error.
 #include "../../include/groove_hip.h"
 #include "kernels.h"

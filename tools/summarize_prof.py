@@ -52,7 +52,7 @@ for sub in ("fetch", "write", "sq", "grbm"):
     summary[sub] = counters(sub)
 
 # HBM traffic per STEP (one 256-frame block of the whole project): the Welsh render runs as up to
-# three concurrent kernels (one per workgroup kind) plus the two partial-row reductions, so the
+# six concurrent kernels (one per base kind) plus the two partial-row reductions, so the
 # per-kernel means are summed.  MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB;
 # FETCH_SIZE reads 1/2 of the bytes of a wide coalesced streaming read on gfx950 — the state loads
 # here are 4 B/lane buffer loads (an uncalibrated width), so the raw and the doubled figure are kept.
