@@ -352,7 +352,46 @@ GROOVE_HD Lp24CoefD lp24_coefd_from_fc(const Lp24Consts& c, float fc, float pi_o
   }
   return d;
 }
+// SCALAR_COEF: the coefficients are wave-uniform values the caller keeps in SGPRs (device only).
+template <bool SCALAR_COEF = false>
 GROOVE_HD double lp24_step(Lp24StateD& s, const Lp24CoefD& c, double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // The ten operations below, written out: left to itself the compiler picks the two-operand
+  // v_fmac_f64 for the state updates and then copies all four loop-carried state pairs (and two
+  // temporaries) back with v_mov_b64 every frame — 6 of 16 instructions.  Three-operand v_fma_f64
+  // updates each state pair in place.  Same operations, same order, same roundings as the C below.
+  double bx, y1, t, by, y2, u;
+  if constexpr (SCALAR_COEF) {
+    asm("v_mul_f64 %[bx], %[b0a], %[x]\n\t"
+        "v_add_f64 %[y1], %[bx], %[s0]\n\t"
+        "v_fma_f64 %[t], %[bx], 2.0, %[s1]\n\t"
+        "v_fma_f64 %[s0], %[a1a], %[y1], %[t]\n\t"
+        "v_fma_f64 %[s1], %[a2a], %[y1], %[bx]\n\t"
+        "v_mul_f64 %[by], %[b0b], %[y1]\n\t"
+        "v_add_f64 %[y2], %[by], %[s2]\n\t"
+        "v_fma_f64 %[u], %[by], 2.0, %[s3]\n\t"
+        "v_fma_f64 %[s2], %[a1b], %[y2], %[u]\n\t"
+        "v_fma_f64 %[s3], %[a2b], %[y2], %[by]"
+        : [s0] "+v"(s.s0), [s1] "+v"(s.s1), [s2] "+v"(s.s2), [s3] "+v"(s.s3), [bx] "=&v"(bx), [y1] "=&v"(y1), [t] "=&v"(t),
+          [by] "=&v"(by), [y2] "=&v"(y2), [u] "=&v"(u)
+        : [x] "v"(x), [b0a] "s"(c.b0a), [a1a] "s"(c.a1a), [a2a] "s"(c.a2a), [b0b] "s"(c.b0b), [a1b] "s"(c.a1b), [a2b] "s"(c.a2b));
+  } else {
+    asm("v_mul_f64 %[bx], %[b0a], %[x]\n\t"
+        "v_add_f64 %[y1], %[bx], %[s0]\n\t"
+        "v_fma_f64 %[t], %[bx], 2.0, %[s1]\n\t"
+        "v_fma_f64 %[s0], %[a1a], %[y1], %[t]\n\t"
+        "v_fma_f64 %[s1], %[a2a], %[y1], %[bx]\n\t"
+        "v_mul_f64 %[by], %[b0b], %[y1]\n\t"
+        "v_add_f64 %[y2], %[by], %[s2]\n\t"
+        "v_fma_f64 %[u], %[by], 2.0, %[s3]\n\t"
+        "v_fma_f64 %[s2], %[a1b], %[y2], %[u]\n\t"
+        "v_fma_f64 %[s3], %[a2b], %[y2], %[by]"
+        : [s0] "+v"(s.s0), [s1] "+v"(s.s1), [s2] "+v"(s.s2), [s3] "+v"(s.s3), [bx] "=&v"(bx), [y1] "=&v"(y1), [t] "=&v"(t),
+          [by] "=&v"(by), [y2] "=&v"(y2), [u] "=&v"(u)
+        : [x] "v"(x), [b0a] "v"(c.b0a), [a1a] "v"(c.a1a), [a2a] "v"(c.a2a), [b0b] "v"(c.b0b), [a1b] "v"(c.a1b), [a2b] "v"(c.a2b));
+  }
+  return y2;
+#else
   const double bx = c.b0a * x;
   const double y1 = bx + s.s0;
   s.s0 = fma(c.a1a, y1, 2.0 * bx + s.s1);
@@ -362,6 +401,7 @@ GROOVE_HD double lp24_step(Lp24StateD& s, const Lp24CoefD& c, double x) {
   s.s2 = fma(c.a1b, y2, 2.0 * by + s.s3);
   s.s3 = fma(c.a2b, y2, by);
   return y2;
+#endif
 }
 
 // ------------------------------------------------------------------ WelshVoice (a5)
@@ -556,7 +596,7 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
       sc.prev_pct = pct;
     }
   }
-  const float y = (float)lp24_step(s.filt, sc.coef, (double)sum);
+  const float y = (float)lp24_step<SEGMENT && !RETUNE>(s.filt, sc.coef, (double)sum); // uniform static kinds: coefficients in SGPRs
   float a = s.amp.value;
   if (routing == GROOVE_LFO_AMPLITUDE) a *= fmaf(lfo, p.lfo_depth, 1.0f);
   const float m = y * a;
