@@ -867,12 +867,12 @@ static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs
         }
         UniformArgs a{b->d_waves, b->d_state, out, b->d_wg_list + offset[k], b->d_wg_cls + offset[k], chs, rc, b->n_vwaves, b->n, frames, count[k]};
         const dim3 kgrid(count[k]);
-        if (fused && wg_base_kind_specialised(k)) {
+        if (wg_base_kind_specialised(k)) {
           switch (k) {
-            case 0: launch_welsh_uniform_specialised_0(a, st); break;
-            case 1: launch_welsh_uniform_specialised_1(a, st); break;
-            case 2: launch_welsh_uniform_specialised_2(a, st); break;
-            default: launch_welsh_uniform_specialised_3(a, st); break;
+            case 0: launch_welsh_uniform_specialised_0(a, st, fused); break;
+            case 1: launch_welsh_uniform_specialised_1(a, st, fused); break;
+            case 2: launch_welsh_uniform_specialised_2(a, st, fused); break;
+            default: launch_welsh_uniform_specialised_3(a, st, fused); break;
           }
         } else {
 #define GROOVE_LAUNCH_UNIFORM(MODE, RETUNE)                                                                              \
@@ -985,10 +985,10 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
     if (uniform) {
       UniformArgs a{b->d_waves, b->d_state, b->d_pipe_part[slot], b->d_wg_list + offset[k], b->d_wg_cls + offset[k], 0, rc, b->n_vwaves, b->n, frames, count[k]};
       switch (k) {
-        case 0: launch_welsh_uniform_specialised_0(a, st); break;
-        case 1: launch_welsh_uniform_specialised_1(a, st); break;
-        case 2: launch_welsh_uniform_specialised_2(a, st); break;
-        case 3: launch_welsh_uniform_specialised_3(a, st); break;
+        case 0: launch_welsh_uniform_specialised_0(a, st, true); break;
+        case 1: launch_welsh_uniform_specialised_1(a, st, true); break;
+        case 2: launch_welsh_uniform_specialised_2(a, st, true); break;
+        case 3: launch_welsh_uniform_specialised_3(a, st, true); break;
         case 4: hipLaunchKernelGGL((welsh_render_uniform_kernel<true, LFO_F64, false, false>), dim3(count[k]), blk, 0, st, a); break;
         default: hipLaunchKernelGGL((welsh_render_uniform_kernel<true, LFO_F64, true, false>), dim3(count[k]), blk, 0, st, a); break;
       }

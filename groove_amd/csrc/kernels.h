@@ -463,10 +463,10 @@ __global__ __launch_bounds__(kThreads, GROOVE_WAVES_ANY) void welsh_render_unifo
 static_assert(OSC_CLASSES == 5 && LFO_CLASSES == 6 && kClassCombos <= 256, "the class switch above lists 6 x 5 x 5 combinations, one byte each");
 // Launchers of the four class-specialised fused kernels, one translation unit each
 // (csrc/welsh_class.hip, -DGROOVE_BASE_KIND=0..3) so that they compile in parallel.
-void launch_welsh_uniform_specialised_0(const UniformArgs& a, hipStream_t st);
-void launch_welsh_uniform_specialised_1(const UniformArgs& a, hipStream_t st);
-void launch_welsh_uniform_specialised_2(const UniformArgs& a, hipStream_t st);
-void launch_welsh_uniform_specialised_3(const UniformArgs& a, hipStream_t st);
+void launch_welsh_uniform_specialised_0(const UniformArgs& a, hipStream_t st, bool fused);
+void launch_welsh_uniform_specialised_1(const UniformArgs& a, hipStream_t st, bool fused);
+void launch_welsh_uniform_specialised_2(const UniformArgs& a, hipStream_t st, bool fused);
+void launch_welsh_uniform_specialised_3(const UniformArgs& a, hipStream_t st, bool fused);
 void launch_welsh_uniform_any(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st); // csrc/welsh_class.hip, -DGROOVE_BASE_KIND=9
 
 template <bool FUSED>
