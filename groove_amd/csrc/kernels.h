@@ -315,9 +315,10 @@ __global__ __launch_bounds__(kThreads) void welsh_render_kernel(
 //     Separate kernels because register allocation is per kernel: the cheapest base kind fits 72
 //     VGPRs (7 waves / SIMD), the most expensive needs 133 (3 waves); inside one kernel everybody
 //     paid for the maximum.
-//   - the CLASSES of the two audio oscillators (dsp_core.h, "Oscillator CLASSES"): inside the fused
-//     kernels of the first four base kinds, one scalar switch per workgroup calls the copy of the
-//     whole block body compiled for its class pair (5 x 5 copies).  The copies are NOT inlined:
+//   - the CLASSES of the LFO and the two audio oscillators (dsp_core.h, "Oscillator CLASSES"): inside
+//     the kernels of the first four base kinds (fused and materialised form), one scalar switch per
+//     workgroup calls the copy of the whole block body compiled for its class triple (6 x 5 x 5
+//     copies; 3 x 5 x 5 for the smooth-LFO kinds).  The copies are NOT inlined:
 //     each is a function with its own register allocation (inlined, their hoisted loop invariants
 //     all became live across the switch and every copy spilled in its hot loop), and all copies of
 //     a base kind need about the same registers, so the kernel's budget fits them all.  (One kernel
