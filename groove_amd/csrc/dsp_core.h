@@ -682,6 +682,28 @@ GROOVE_HD float sampler_frame(const SamplerParams& p, SamplerState& s, const flo
   return v;
 }
 
+// C consecutive frames at once (count <= C of them wanted), same results as `count` calls of
+// sampler_frame.  The index only moves forward, so "still inside the sample" is monotone over the
+// chunk: all C fetches are issued from clamped addresses before any is used (the per-frame form
+// pays one cache round trip per frame: the fetch is the only long-latency operation of a voice).
+template <int C>
+GROOVE_HD void sampler_chunk(const SamplerParams& p, SamplerState& s, const float* bank, uint32_t count, float (&v)[C]) {
+  uint32_t valid = 0; // frames of the chunk that play
+  float raw[C];
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    const uint32_t i = (uint32_t)((s.idx + (uint64_t)k * s.step) >> 44);
+    const bool ok = s.playing && (uint32_t)k < count && i < p.length;
+    raw[k] = bank[(size_t)p.offset + (i < p.length ? i : p.length - 1)];
+    valid += ok ? 1u : 0u;
+    v[k] = ok ? 1.0f : 0.0f;
+  }
+#pragma unroll
+  for (int k = 0; k < C; ++k) v[k] = v[k] != 0.0f ? raw[k] * p.gain : 0.0f;
+  s.idx += (uint64_t)valid * s.step;
+  if (s.playing && valid < count) s.playing = 0; // ran off the end inside the chunk
+}
+
 // ------------------------------------------------------------------ effects (a8, a9)
 GROOVE_HD float bitcrush(float x, uint32_t bits) {
   float ax = fabsf(x) * 32767.0f;

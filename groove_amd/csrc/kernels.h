@@ -496,9 +496,23 @@ __global__ __launch_bounds__(kThreads) void sampler_render_kernel(
   const uint32_t v = active ? v0 : n - 1;
   const SamplerParams p = soa_load<SamplerParams>(params, n, v);
   SamplerState s = soa_load<SamplerState>(state, n, v);
-  run_frames<FUSED>(frames, n, v, active, ch_stride, out, blockIdx.x, [&](uint32_t, float& L, float& R) {
-    L = R = sampler_frame(p, s, bank); // mono duplicated to both channels
-  });
+  // chunks of 16 frames: sixteen fetches in flight instead of one (sampler_chunk); mono duplicated to both channels
+  constexpr uint32_t C = 16, K = FusedAcc::kChunk;
+  static_assert(C % K == 0, "whole flush periods of the fused epilogue per chunk");
+  FusedAcc acc(blockIdx.x);
+  for (uint32_t f0 = 0; f0 < frames; f0 += C) {
+    const uint32_t count = min(C, frames - f0);
+    float x[C];
+    sampler_chunk<C>(p, s, bank, count, x);
+#pragma unroll
+    for (uint32_t k = 0; k < C; ++k) {
+      if (k < count) {
+        if (FUSED) acc.add(active ? x[k] : 0.0f, active ? x[k] : 0.0f, f0 + k);
+        else if (active) { out[(size_t)(f0 + k) * n + v] = x[k]; out[ch_stride + (size_t)(f0 + k) * n + v] = x[k]; }
+      }
+      if (FUSED && (k & (K - 1)) == K - 1 && k - (K - 1) < count) acc.flush(out, frames, f0 + k - (K - 1), min(K, count - (k - (K - 1))));
+    }
+  }
   if (active) soa_store(state, n, v, s);
 }
 

@@ -94,6 +94,7 @@ void emul_bank_render(void* h, uint32_t frames, float* out) {
       sc = welsh_scratch_init(b->wp[v], rc); retunes = welsh_retunes(b->wp[v]);
       mode = b->generic_lfo ? (welsh_lfo_mode(b->wp[v]) == LFO_F32 ? LFO_F32 : LFO_F64) : welsh_lfo_mode(b->wp[v]);
     }
+    float sampler_buf[16] = {};
     uint32_t seg_left = 0; // segmented form (uniform kernels): frames left before the next boundary check
     bool seg_live = false;
     for (uint32_t f = 0; f < frames; ++f) {
@@ -108,7 +109,10 @@ void emul_bank_render(void* h, uint32_t frames, float* out) {
         welsh_emul_frame(b->wp[v], b->ws[v], rc, sc, f == 0, retunes, mode, L, R);
       } else if (b->kind == 1) {
         if (f == 0) fm_frame<true>(b->fp[v], b->fs[v], L, R); else fm_frame<false>(b->fp[v], b->fs[v], L, R);
-      } else { L = R = sampler_frame(b->sp[v], b->ss[v], b->pcm.data()); }
+      } else { // mirrors the kernel: chunks of 16 frames (sampler_chunk)
+        if ((f & 15u) == 0) sampler_chunk<16>(b->sp[v], b->ss[v], b->pcm.data(), frames - f < 16 ? frames - f : 16, sampler_buf);
+        L = R = sampler_buf[f & 15u];
+      }
       out[(size_t)f * n + v] = L;
       out[((size_t)frames + f) * n + v] = R;
     }
