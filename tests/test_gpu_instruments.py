@@ -55,8 +55,36 @@ def test_sampler_is_exact_fetch(gpu_ctx, oracle):
         got = block.download(frames)
         want = ob.render(frames).astype(np.float32)
         assert np.array_equal(got, want), f"block {b}: sampler fetch differs"
-    assert True
     s.destroy(); block.destroy()
+
+
+def test_sampler_ragged_blocks_materialised_and_fused(gpu_ctx, oracle):
+    """Block lengths that are not multiples of the sampler's 16-frame fetch chunk or of the fused epilogue's
+    8-frame flush (including 1 and 0): the materialised block stays bit-exact, the fused bus matches the
+    oracle's sum; samples run off their ends inside chunks (scaled-down bank)."""
+    from groove_amd import entities as E
+    n = 240
+    pcm, descs, lengths = P.drum_bank(scale=0.02)
+    params = P.sampler_voices(n)
+    keys = P.sampler_keys(n)
+    on = T.note_events_np(np.arange(n, dtype=np.uint32), keys, True)
+    a, f = E.Sampler(gpu_ctx, pcm, descs, params), E.Sampler(gpu_ctx, pcm, descs, params)
+    oa, of = oracle.Bank.sampler(pcm, descs, params), oracle.Bank.sampler(pcm, descs, params)
+    for x in (a, f, oa, of):
+        (x.handle_midi_events if hasattr(x, "handle_midi_events") else x.note_events)(on)
+    block = gpu_ctx.block(n, 256)
+    bus = gpu_ctx.bus(256)
+    for frames in (100, 7, 1, 16, 17, 0, 255, 33, 8, 256, 9):
+        a.generate_batch_values(block, frames)
+        want = oa.render(frames).astype(np.float32)
+        if frames:
+            assert np.array_equal(block.download(frames), want), frames
+        f.render_mix(bus, frames)
+        wb = of.render_bus(frames)
+        if frames:
+            assert np.max(np.abs(bus.download(frames).astype(np.float64) - wb)) <= 1e-4, frames
+    for x in (a, f, block, bus):
+        x.destroy()
 
 
 def test_mix_bus_known_answers(gpu_ctx):
