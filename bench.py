@@ -48,8 +48,10 @@ WORKLOADS = {
 class Project:
     """The synthetic many-voice project shard owned by one rank."""
 
-    def __init__(self, ctx, workload, first_voice, n_voices, fused, grouped=True):
+    def __init__(self, ctx, workload, first_voice, n_voices, fused, grouped=True, render_ahead=True):
         self.ctx, self.n, self.fused = ctx, n_voices, fused
+        self.render_ahead = render_ahead  # instruments with an effect chain: render block b+1 beside the effects of block b
+        self.ahead = {}                   # instrument -> [current block, next block] once primed
         kind = WORKLOADS[workload]["kind"]
         self.banks = []   # (instrument, block, [effects])
         self.timeline = []  # Welsh banks that follow the config-#2 note timeline
@@ -90,16 +92,49 @@ class Project:
                 self.banks.append((inst, ctx.block(n, FRAMES), []))
         self.dominant = self.banks[0][0]
 
-    def step(self, bus, frame0, ev_pair=None):
-        """One block: every instrument renders, its effect chain runs, the mix bus sums."""
-        ctx = self.ctx
+    def _timeline_events(self, block_index):
         # config-#2 timeline, looped: note-on at block 0, note-off at block 86 of every 172 blocks
-        b = self.block_index % P.RENDER_BLOCKS
+        b = block_index % P.RENDER_BLOCKS
         for synth in self.timeline:
             if b == 0:
                 synth.handle_midi_events(self.on_ev)
             elif b == P.NOTE_OFF_FRAME // FRAMES:
                 synth.handle_midi_events(self.off_ev)
+
+    def _step_render_ahead(self, bus, frame0, ev_pair):
+        """The same block walk, software-pipelined: the instruments' render of block b+1 goes to the
+        library's side streams (groove_bank_render_async) before the effect chains of block b are
+        submitted, two blocks per instrument alternating.  Every step still submits one render, one
+        pass of every effect and one mix per instrument; the first call also renders block b itself."""
+        ctx = self.ctx
+        if ev_pair is not None:
+            ctx.record(ev_pair[0])
+        if not self.ahead:
+            self._timeline_events(self.block_index)
+            for inst, block, fx in self.banks:
+                self.ahead[inst] = [block, ctx.block(inst.n, FRAMES)]
+                inst.generate_batch_values_async(block, FRAMES)
+        self._timeline_events(self.block_index + 1)
+        self.block_index += 1
+        for inst, _, fx in self.banks:
+            inst.generate_batch_values_async(self.ahead[inst][1], FRAMES)
+        first = True
+        for inst, _, fx in self.banks:
+            cur = self.ahead[inst][0]
+            for e in fx:
+                e.transform_audio(cur, FRAMES)
+            ctx.mix([cur], FRAMES, E._Slice(bus, frame0), accumulate=not first)
+            self.ahead[inst].reverse()
+            first = False
+        if ev_pair is not None:
+            ctx.record(ev_pair[1])
+
+    def step(self, bus, frame0, ev_pair=None):
+        """One block: every instrument renders, its effect chain runs, the mix bus sums."""
+        ctx = self.ctx
+        if self.render_ahead and any(fx for _, _, fx in self.banks):
+            return self._step_render_ahead(bus, frame0, ev_pair)
+        self._timeline_events(self.block_index)
         self.block_index += 1
         first = True
         for inst, block, fx in self.banks:
@@ -211,6 +246,9 @@ def main():
                          "(default: fused render+mix, no materialised voice blocks)")
     ap.add_argument("--interleaved", action="store_true", help="voice i uses patch i mod 32 inside every wavefront (generic per-lane kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-render-ahead", action="store_true",
+                    help="workloads with effect chains: render block b, then its effects (default: the render of block b+1 "
+                         "is submitted to the side streams before the effects of block b)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -239,7 +277,7 @@ def main():
         ctx.comm_init(uid[0], rank, world)
 
     fused = not args.materialise
-    proj = Project(ctx, args.workload, lo, hi - lo, fused, grouped=not args.interleaved)
+    proj = Project(ctx, args.workload, lo, hi - lo, fused, grouped=not args.interleaved, render_ahead=not args.no_render_ahead)
     K, W = args.steps, args.warmup
     bus = ctx.bus((K + W) * FRAMES)
 
@@ -276,7 +314,8 @@ def main():
         frames_total = K * FRAMES
         value = frames_total / elapsed
         n_local = hi - lo
-        dom_bytes = (wl["bytes_per_vf"] if (fused and wl["kind"] in ("welsh", "sampler")) else wl["dominant_bytes"])
+        whole_step = wl["kind"] == "chain" and not args.no_render_ahead  # the events bracket the step, not one kernel
+        dom_bytes = (wl["bytes_per_vf"] if ((fused and wl["kind"] in ("welsh", "sampler")) or whole_step) else wl["dominant_bytes"])
         achieved = dom_bytes * n_local * FRAMES / (kern_ms * 1e-3) / 1e9
         line = {
             "metric": "stereo frames/sec rendered (offline)", "value": value, "unit": "stereo frames/s",
@@ -291,6 +330,7 @@ def main():
             "roofline": {"bound": "hbm",
                          "kernel": ("welsh_render_uniform_kernel<fused, LFO mode, retune> (one kernel per base kind, run "
                                     "concurrently; class-specialised block bodies) + partial_rows/final" if fused and wl["kind"] == "welsh"
+                                    else "whole step: render of block b+1 (side streams) beside the effect chain + mix of block b" if whole_step
                                     else "render kernel of the first bank"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_voice_frame": dom_bytes, "kernel_ms": kern_ms,

@@ -26,6 +26,10 @@ struct groove_block {
   groove_ctx* ctx;
   uint32_t n, cap;
   float* d;
+  // groove_bank_render_async: the producer kernels run on side streams; ev_ready[k] is recorded on
+  // side stream k behind them, ready_mask says which are outstanding (block_acquire clears it).
+  hipEvent_t ev_free = nullptr, ev_ready[16] = {};
+  uint32_t ready_mask = 0;
 };
 
 enum BankKind { BANK_WELSH = 0, BANK_FM = 1, BANK_SAMPLER = 2 };
@@ -57,6 +61,9 @@ struct groove_bank {
   bool reduce_recorded[2] = {false, false};
   int pipe_slot = 0;
   int stream_slot = 0; // side stream of a single-kernel bank (FM, sampler, per-lane Welsh) in the asynchronous fused path
+  int side_mode = 0;    // which side streams carried this bank's last asynchronous work: 0 none, 1 one per base kind, 2 stream_slot
+  hipEvent_t ev_gather = nullptr; // groove_bank_render_async of a regrouped bank: the scratch block has been gathered
+  bool gather_recorded = false;
   // welsh: lane permutation.  A bank whose patches are interleaved voice by voice is kept patch-major inside
   // the library (params, state, cold values in INTERNAL lane order) so that it runs on the wave-uniform kernels;
   // perm[internal lane] = caller's voice index, inv = its inverse.  Empty = identity.
@@ -98,6 +105,7 @@ struct groove_fx {
 
 constexpr int kBankStreams = 4;                         // shared round-robin by single-kernel banks (FM, sampler, per-lane Welsh)
 constexpr int kSideStreams = kBaseKinds + kBankStreams; // + one per Welsh base kind; the ctx stream carries events, reductions and the rest
+static_assert(kSideStreams <= 16, "groove_block::ev_ready holds one event per side stream");
 struct groove_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -152,6 +160,23 @@ int ctx_join(groove_ctx* ctx) {
     ctx->side_busy[k] = false;
   }
   ctx->need_fork = true;
+  return 0;
+}
+
+// Order the ctx stream after the asynchronous render that produced `blk` (groove_bank_render_async).
+// Every ctx-stream operation that reads or writes a block calls this first.
+int block_acquire(groove_block* blk) {
+  if (!blk->ready_mask) return 0;
+  groove_ctx* ctx = blk->ctx;
+  for (int k = 0; k < kSideStreams; ++k)
+    if (blk->ready_mask & (1u << k)) GHIP(ctx, hipStreamWaitEvent(ctx->stream, blk->ev_ready[k], 0));
+  blk->ready_mask = 0;
+  return 0;
+}
+// A bank's state is touched by one set of side streams at a time; changing the set joins first.
+int bank_side_mode(groove_bank* b, int mode) {
+  if (b->side_mode && b->side_mode != mode && ctx_join(b->ctx)) return 1;
+  b->side_mode = mode;
   return 0;
 }
 
@@ -699,8 +724,11 @@ int groove_block_create(groove_ctx* ctx, uint32_t n, uint32_t frames_cap, groove
 }
 int groove_block_destroy(groove_block* b) {
   if (!b) return 0;
+  if (b->ready_mask) (void)ctx_join(b->ctx);
   (void)hipStreamSynchronize(b->ctx->stream);
   (void)hipFree(b->d);
+  if (b->ev_free) (void)hipEventDestroy(b->ev_free);
+  for (hipEvent_t e : b->ev_ready) if (e) (void)hipEventDestroy(e);
   delete b;
   return 0;
 }
@@ -711,6 +739,7 @@ int groove_block_upload(groove_block* b, const float* host, uint32_t frames) {
   if (!b || !host) return fail(nullptr, "groove_block_upload: NULL argument");
   groove_ctx* ctx = b->ctx;
   if (frames > b->cap) return fail(ctx, "groove_block_upload: frames > capacity");
+  if (block_acquire(b)) return 1;
   const size_t per = (size_t)frames * b->n;
   for (int ch = 0; ch < 2; ++ch)
     GHIP(ctx, hipMemcpyAsync(b->d + (size_t)ch * b->cap * b->n, host + ch * per, per * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -721,6 +750,7 @@ int groove_block_download(groove_block* b, float* host, uint32_t frames) {
   if (!b || !host) return fail(nullptr, "groove_block_download: NULL argument");
   groove_ctx* ctx = b->ctx;
   if (frames > b->cap) return fail(ctx, "groove_block_download: frames > capacity");
+  if (block_acquire(b)) return 1;
   const size_t per = (size_t)frames * b->n;
   for (int ch = 0; ch < 2; ++ch)
     GHIP(ctx, hipMemcpyAsync(host + ch * per, b->d + (size_t)ch * b->cap * b->n, per * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -790,6 +820,7 @@ int groove_bank_destroy(groove_bank* b) {
   auto it = std::find(ctx->banks.begin(), ctx->banks.end(), b);
   if (it != ctx->banks.end()) ctx->banks.erase(it);
   if (b->scratch) groove_block_destroy(b->scratch);
+  if (b->ev_gather) (void)hipEventDestroy(b->ev_gather);
   (void)hipFree(b->d_params); (void)hipFree(b->d_state); (void)hipFree(b->d_cold); (void)hipFree(b->d_pcm); (void)hipFree(b->d_ev); (void)hipFree(b->d_waves); (void)hipFree(b->d_wg_list); (void)hipFree(b->d_wg_cls); (void)hipFree(b->d_wg_base); (void)hipFree(b->d_inv);
   delete b;
   return 0;
@@ -824,6 +855,33 @@ int groove_bank_set_param(groove_bank* b, uint32_t voice, uint32_t control_index
   if (ctx_join(ctx)) return 1;
   GHIP(ctx, hipStreamSynchronize(ctx->stream));
   return welsh_upload_params(b, false); // the state stays where it is: keep the lane order
+}
+// One base kind's uniform Welsh kernel (kernels.h, "Workgroup KINDS") on stream `st`.
+static void launch_welsh_kind(int k, const UniformArgs& a, hipStream_t st, bool fused) {
+  const dim3 kgrid(a.n_wgs), blk(kThreads);
+  if (wg_base_kind_specialised(k)) {
+    switch (k) {
+      case 0: launch_welsh_uniform_specialised_0(a, st, fused); break;
+      case 1: launch_welsh_uniform_specialised_1(a, st, fused); break;
+      case 2: launch_welsh_uniform_specialised_2(a, st, fused); break;
+      default: launch_welsh_uniform_specialised_3(a, st, fused); break;
+    }
+    return;
+  }
+#define GROOVE_LAUNCH_UNIFORM(MODE, RETUNE)                                                                              \
+  do {                                                                                                                   \
+    if (fused) hipLaunchKernelGGL((welsh_render_uniform_kernel<true, MODE, RETUNE, false>), kgrid, blk, 0, st, a);        \
+    else hipLaunchKernelGGL((welsh_render_uniform_kernel<false, MODE, RETUNE, false>), kgrid, blk, 0, st, a);             \
+  } while (0)
+  switch (k) {
+    case wg_base_kind_of(LFO_F32, false): GROOVE_LAUNCH_UNIFORM(LFO_F32, false); break;
+    case wg_base_kind_of(LFO_F32, true): GROOVE_LAUNCH_UNIFORM(LFO_F32, true); break;
+    case wg_base_kind_of(LFO_F64_SMOOTH, false): GROOVE_LAUNCH_UNIFORM(LFO_F64_SMOOTH, false); break;
+    case wg_base_kind_of(LFO_F64_SMOOTH, true): GROOVE_LAUNCH_UNIFORM(LFO_F64_SMOOTH, true); break;
+    case wg_base_kind_of(LFO_F64, false): GROOVE_LAUNCH_UNIFORM(LFO_F64, false); break;
+    default: GROOVE_LAUNCH_UNIFORM(LFO_F64, true); break;
+  }
+#undef GROOVE_LAUNCH_UNIFORM
 }
 static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs, float* out) {
   groove_ctx* ctx = b->ctx;
@@ -866,30 +924,7 @@ static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs
           GHIP(ctx, hipStreamWaitEvent(st, ctx->ev_fork, 0));
         }
         UniformArgs a{b->d_waves, b->d_state, out, b->d_wg_list + offset[k], b->d_wg_cls + offset[k], chs, rc, b->n_vwaves, b->n, frames, count[k]};
-        const dim3 kgrid(count[k]);
-        if (wg_base_kind_specialised(k)) {
-          switch (k) {
-            case 0: launch_welsh_uniform_specialised_0(a, st, fused); break;
-            case 1: launch_welsh_uniform_specialised_1(a, st, fused); break;
-            case 2: launch_welsh_uniform_specialised_2(a, st, fused); break;
-            default: launch_welsh_uniform_specialised_3(a, st, fused); break;
-          }
-        } else {
-#define GROOVE_LAUNCH_UNIFORM(MODE, RETUNE)                                                                              \
-  do {                                                                                                                   \
-    if (fused) hipLaunchKernelGGL((welsh_render_uniform_kernel<true, MODE, RETUNE, false>), kgrid, blk, 0, st, a);        \
-    else hipLaunchKernelGGL((welsh_render_uniform_kernel<false, MODE, RETUNE, false>), kgrid, blk, 0, st, a);             \
-  } while (0)
-          switch (k) {
-            case wg_base_kind_of(LFO_F32, false): GROOVE_LAUNCH_UNIFORM(LFO_F32, false); break;
-            case wg_base_kind_of(LFO_F32, true): GROOVE_LAUNCH_UNIFORM(LFO_F32, true); break;
-            case wg_base_kind_of(LFO_F64_SMOOTH, false): GROOVE_LAUNCH_UNIFORM(LFO_F64_SMOOTH, false); break;
-            case wg_base_kind_of(LFO_F64_SMOOTH, true): GROOVE_LAUNCH_UNIFORM(LFO_F64_SMOOTH, true); break;
-            case wg_base_kind_of(LFO_F64, false): GROOVE_LAUNCH_UNIFORM(LFO_F64, false); break;
-            default: GROOVE_LAUNCH_UNIFORM(LFO_F64, true); break;
-          }
-#undef GROOVE_LAUNCH_UNIFORM
-        }
+        launch_welsh_kind(k, a, st, fused);
         if (!first_kind) {
           GHIP(ctx, hipEventRecord(ctx->ev_join[side], st));
           GHIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[side], 0));
@@ -918,6 +953,8 @@ int groove_bank_render(groove_bank* b, uint32_t frames, groove_block* out) {
   GHIP(ctx, hipSetDevice(ctx->device));
   if (flush_events(b)) return 1;
   if (ctx_join(ctx)) return 1; // the bank's state may still be in flight on the side streams (pipelined fused renders)
+  b->side_mode = 0;
+  out->ready_mask = 0; // joined above
   if (b->perm.empty()) return launch_render(b, frames, false, (size_t)out->cap * out->n, out->d);
   // regrouped bank: render in the internal lane order (coalesced rows), then hand the caller's order out
   if (!b->scratch || b->scratch->cap < frames) {
@@ -929,6 +966,108 @@ int groove_bank_render(groove_bank* b, uint32_t frames, groove_block* out) {
                      (size_t)out->cap * out->n, b->scratch->d, (size_t)b->scratch->cap * b->n, b->d_inv, b->n, frames);
   GHIP(ctx, hipGetLastError());
   return 0;
+}
+// groove_bank_render on the side streams: the render kernels start once everything submitted to the
+// ctx stream so far has finished (that covers the previous users of `out` and of the bank), and run
+// beside whatever the ctx stream is given next; the ctx-stream operations that take `out` wait for
+// them (block_acquire).  A host that keeps two blocks per instrument and submits the render of block
+// b+1 before the effect chain of block b overlaps the two (bench.py, workload chain-4096: the Welsh
+// render of a 4,096-voice bank is one wavefront's serial walk, 0.2 ms whatever else runs).
+int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out) {
+  if (!b || !out) return fail(nullptr, "groove_bank_render_async: NULL argument");
+  groove_ctx* ctx = b->ctx;
+  if (out->n != b->n) return fail(ctx, "groove_bank_render_async: block lanes != bank voices");
+  if (frames > out->cap) return fail(ctx, "groove_bank_render_async: frames > block capacity");
+  if (frames == 0) return 0;
+  GHIP(ctx, hipSetDevice(ctx->device));
+  if (flush_events(b)) return 1;
+  if (block_acquire(out)) return 1; // an earlier asynchronous render into the same block comes first
+  const bool uniform = b->kind == BANK_WELSH && b->n_vwaves;
+  if (bank_side_mode(b, uniform ? 1 : 2)) return 1;
+  if (!out->ev_free) {
+    GHIP(ctx, hipEventCreateWithFlags(&out->ev_free, hipEventDisableTiming));
+    for (int k = 0; k < kSideStreams; ++k) GHIP(ctx, hipEventCreateWithFlags(&out->ev_ready[k], hipEventDisableTiming));
+  }
+  float* dst = out->d;
+  size_t chs = (size_t)out->cap * out->n;
+  const bool regrouped = !b->perm.empty();
+  if (regrouped) { // render in the internal lane order, gather into the caller's order afterwards
+    if (!b->scratch || b->scratch->cap < frames) {
+      if (ctx_join(ctx)) return 1;
+      GHIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (b->scratch) { groove_block_destroy(b->scratch); b->scratch = nullptr; }
+      if (groove_block_create(ctx, b->n, std::max<uint32_t>(frames, GROOVE_BLOCK_FRAMES), &b->scratch)) return 1;
+      b->gather_recorded = false;
+    }
+    if (!b->ev_gather) GHIP(ctx, hipEventCreateWithFlags(&b->ev_gather, hipEventDisableTiming));
+    dst = b->scratch->d;
+    chs = (size_t)b->scratch->cap * b->n;
+  }
+  GHIP(ctx, hipEventRecord(out->ev_free, ctx->stream));
+  const dim3 blk(kThreads);
+  uint32_t used = 0;
+  auto begin = [&](int k) -> hipStream_t {
+    hipStream_t st = ctx->side_stream[k];
+    (void)hipStreamWaitEvent(st, out->ev_free, 0);
+    if (regrouped && b->gather_recorded) (void)hipStreamWaitEvent(st, b->ev_gather, 0); // the scratch block is free again
+    ctx->fork_pending[k] = false; // ev_free is later than any ev_fork recorded so far
+    return st;
+  };
+  auto end = [&](int k) {
+    (void)hipEventRecord(out->ev_ready[k], ctx->side_stream[k]);
+    used |= 1u << k;
+    ctx->side_busy[k] = true;
+  };
+  if (uniform) {
+    const RenderConsts rc{(float)(3.14159265358979323846 / ctx->sr), (float)(0.49 * ctx->sr)};
+    uint32_t at = 0;
+    uint32_t count[kBaseKinds] = {}, offset[kBaseKinds] = {};
+    for (int base = 0; base < kBaseKinds; ++base) {
+      offset[base] = at;
+      for (int c = 0; c < kClassCombos; ++c) count[base] += b->wgs_of_kind[base * kClassCombos + c];
+      at += count[base];
+    }
+    for (int k = kBaseKinds - 1; k >= 0; --k) { // most expensive kind first
+      if (!count[k]) continue;
+      hipStream_t st = begin(k);
+      UniformArgs a{b->d_waves, b->d_state, dst, b->d_wg_list + offset[k], b->d_wg_cls + offset[k], chs, rc, b->n_vwaves, b->n, frames, count[k]};
+      launch_welsh_kind(k, a, st, false);
+      end(k);
+    }
+  } else {
+    const int k = b->stream_slot;
+    hipStream_t st = begin(k);
+    const dim3 grid(blocks_for(b->n));
+    if (b->kind == BANK_WELSH) {
+      const RenderConsts rc{(float)(3.14159265358979323846 / ctx->sr), (float)(0.49 * ctx->sr)};
+      hipLaunchKernelGGL(welsh_render_kernel<false>, grid, blk, 0, st, b->d_params, b->d_state, b->n, frames, chs, dst, rc);
+    } else if (b->kind == BANK_FM) {
+      hipLaunchKernelGGL(fm_render_kernel<false>, grid, blk, 0, st, b->d_params, b->d_state, b->n, frames, chs, dst);
+    } else {
+      hipLaunchKernelGGL(sampler_render_kernel<false>, grid, blk, 0, st, b->d_params, b->d_state, b->n, frames, chs, dst, b->d_pcm);
+    }
+    end(k);
+  }
+  if (regrouped) {
+    const int g = b->stream_slot;
+    hipStream_t st = ctx->side_stream[g];
+    for (int k = 0; k < kSideStreams; ++k)
+      if ((used & (1u << k)) && k != g) GHIP(ctx, hipStreamWaitEvent(st, out->ev_ready[k], 0));
+    hipLaunchKernelGGL(block_gather_kernel, dim3(blocks_for(b->n), std::min<uint32_t>(frames, 64)), blk, 0, st, out->d,
+                       (size_t)out->cap * out->n, b->scratch->d, (size_t)b->scratch->cap * b->n, b->d_inv, b->n, frames);
+    GHIP(ctx, hipEventRecord(b->ev_gather, st));
+    b->gather_recorded = true;
+    GHIP(ctx, hipEventRecord(out->ev_ready[g], st));
+    ctx->side_busy[g] = true;
+    used = 1u << g;
+  }
+  out->ready_mask = used;
+  GHIP(ctx, hipGetLastError());
+  return 0;
+}
+int groove_block_acquire(groove_block* b) {
+  if (!b) return fail(nullptr, "groove_block_acquire: block is NULL");
+  return block_acquire(b);
 }
 // Fused render + mix of a wave-uniform Welsh bank, pipelined over blocks.  Every base kind has its
 // own stream that carries that kind's kernels block after block (a workgroup's state only depends
@@ -943,6 +1082,7 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
   const bool uniform = b->kind == BANK_WELSH && b->n_vwaves && !small_uniform; // one kernel per base kind
   const uint32_t rows = (b->kind == BANK_WELSH && b->n_vwaves) ? (b->n_vwaves + kWaves - 1) / kWaves : blocks_for(b->n);
   const uint32_t cols = 2 * frames, rows_per_seg = 64, segs = (rows + rows_per_seg - 1) / rows_per_seg;
+  if (bank_side_mode(b, uniform ? 1 : 2)) return 1;
   const int slot = b->pipe_slot;
   b->pipe_slot ^= 1;
   if (b->pipe_part_cap[slot] < (size_t)rows * cols || b->pipe_seg_cap[slot] < (size_t)segs * cols) {
@@ -1111,6 +1251,7 @@ int groove_fx_process(groove_fx* fx, groove_block* io, uint32_t frames) {
   if (frames > io->cap) return fail(ctx, "groove_fx_process: frames > block capacity");
   if (frames == 0) return 0;
   GHIP(ctx, hipSetDevice(ctx->device));
+  if (block_acquire(io)) return 1;
   const uint32_t n = fx->n;
   const size_t chs = (size_t)io->cap * n;
   const dim3 blk(kThreads), lanes_grid(blocks_for(2 * (size_t)n));
@@ -1229,6 +1370,7 @@ int groove_mix(groove_ctx* ctx, groove_block* const* blocks, uint32_t n_blocks, 
   for (uint32_t i = 0; i < n_blocks; ++i) {
     if (!blocks[i]) return fail(ctx, "groove_mix: NULL block");
     if (frames > blocks[i]->cap) return fail(ctx, "groove_mix: frames > block capacity");
+    if (block_acquire(blocks[i])) return 1;
     if (mix_one(ctx, blocks[i], frames, bus_dev, accumulate || i > 0)) return 1;
   }
   return 0;
@@ -1239,6 +1381,7 @@ int groove_block_accumulate(groove_block* dst, groove_block* src, uint32_t frame
   if (frames > dst->cap || frames > src->cap) return fail(ctx, "groove_block_accumulate: frames > block capacity");
   if (frames == 0) return 0;
   GHIP(ctx, hipSetDevice(ctx->device));
+  if (block_acquire(dst) || block_acquire(src)) return 1;
   if (src->n == dst->n) {
     const size_t total = (size_t)2 * frames * src->n;
     const uint32_t g = (uint32_t)std::min<size_t>(blocks_for(total), 256 * 16);
@@ -1252,6 +1395,7 @@ int groove_block_accumulate(groove_block* dst, groove_block* src, uint32_t frame
 }
 int groove_block_zero(groove_block* b) {
   if (!b) return fail(nullptr, "groove_block_zero: NULL argument");
+  if (block_acquire(b)) return 1;
   GHIP(b->ctx, hipMemsetAsync(b->d, 0, (size_t)2 * b->cap * b->n * 4, b->ctx->stream));
   return 0;
 }

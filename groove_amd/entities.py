@@ -179,6 +179,11 @@ class Instrument:
 
     tick = generate_batch_values
 
+    def generate_batch_values_async(self, block, frames=None):
+        """groove_bank_render_async: the render runs beside what the ctx stream is given next."""
+        frames = block.cap if frames is None else frames
+        _lib.check(self.ctx.L.groove_bank_render_async(self.h, frames, block.h), self.ctx.h)
+
     def render_mix(self, bus, frames, accumulate=False, at_frame=0):
         ptr = bus.at(at_frame) if at_frame else bus.ptr
         _lib.check(self.ctx.L.groove_bank_render_mix(self.h, frames, ptr, 1 if accumulate else 0), self.ctx.h)

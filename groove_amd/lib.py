@@ -45,6 +45,8 @@ SYMBOLS = {
     "groove_bank_note_events": (_i, [_vp, C.POINTER(T.NoteEvent), _u32]),
     "groove_bank_set_param": (_i, [_vp, _u32, _u32, _d]),
     "groove_bank_render": (_i, [_vp, _u32, _vp]),
+    "groove_bank_render_async": (_i, [_vp, _u32, _vp]),
+    "groove_block_acquire": (_i, [_vp]),
     "groove_bank_render_mix": (_i, [_vp, _u32, _vp, _i]),
     "groove_bank_state_words": (_u32, [_vp]),
     "groove_bank_download_state": (_i, [_vp, C.POINTER(C.c_uint32)]),

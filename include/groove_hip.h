@@ -91,6 +91,19 @@ int groove_bank_note_events(groove_bank* bank, const groove_note_event* ev, uint
 int groove_bank_set_param(groove_bank* bank, uint32_t voice, uint32_t control_index, double value01);
 /* Ticks::tick(frames) + Generates::generate_batch_values: fills out[2][frames][n]. */
 int groove_bank_render(groove_bank* bank, uint32_t frames, groove_block* out);
+/* The same render submitted to the library's own side streams: it starts once everything submitted
+ * to the ctx stream so far has finished (the previous users of `out` and of the bank), and runs BESIDE
+ * what the ctx stream is given next.  Operations that take `out` (groove_fx_process, groove_mix,
+ * groove_block_accumulate / download / upload / zero, another render into it) wait for it by
+ * themselves; a caller that hands groove_block_device_ptr(out) to its own kernels on the ctx stream
+ * calls groove_block_acquire(out) first.  Purpose: the per-entity walk of Orchestrator::run
+ * (orchestrator.rs:397-457) has the instruments of block b+1 depend on nothing the effect chains of
+ * block b produce, so a host that keeps two blocks per instrument submits render(b+1) before the
+ * effects of block b and the two overlap (bench.py --workload chain-4096).  Results are identical to
+ * groove_bank_render's. */
+int groove_bank_render_async(groove_bank* bank, uint32_t frames, groove_block* out);
+/* Orders the ctx stream after the asynchronous render that last filled `b` (no-op otherwise). */
+int groove_block_acquire(groove_block* b);
 /* Fused form of "tick every leaf and add its value to the running sum"
  * (orchestrator.rs:397-410) for instruments patched straight into the main mixer: renders
  * and accumulates into bus_dev[frames][2] (device) without materialising the block.

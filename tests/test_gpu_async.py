@@ -1,0 +1,149 @@
+"""GPU: groove_bank_render_async (render-ahead on the library's side streams) produces exactly what
+groove_bank_render does, whatever the host interleaves with it on the ctx stream."""
+import numpy as np
+import pytest
+
+from groove_amd import patches as P, abi_types as T
+
+pytestmark = pytest.mark.gpu
+
+FRAMES = 256
+
+
+def _twin(make):
+    return make(), make()
+
+
+def _render_ahead(gpu_ctx, sync_inst, async_inst, n, blocks, events, fx_sync=(), fx_async=(), frames_of=lambda b: FRAMES):
+    """Walk `blocks` blocks twice: instrument A the plain way (render, effects, mix into bus A);
+    instrument B software-pipelined (render of block b+1 submitted before the effects of block b,
+    two blocks alternating).  events(b) -> note events applied before block b.  Returns both buses
+    and the per-block downloads of the effect outputs."""
+    blk_s = gpu_ctx.block(n, FRAMES)
+    blk_a = [gpu_ctx.block(n, FRAMES), gpu_ctx.block(n, FRAMES)]
+    bus_s, bus_a = gpu_ctx.bus(blocks * FRAMES), gpu_ctx.bus(blocks * FRAMES)
+    from groove_amd import entities as E
+    outs_s, outs_a = [], []
+    at = 0
+    # plain walk
+    for b in range(blocks):
+        f = frames_of(b)
+        ev = events(b)
+        if ev is not None:
+            sync_inst.handle_midi_events(ev)
+        sync_inst.generate_batch_values(blk_s, f)
+        for e in fx_sync:
+            e.transform_audio(blk_s, f)
+        gpu_ctx.mix([blk_s], f, E._Slice(bus_s, at), accumulate=False)
+        outs_s.append(blk_s.download(f))
+        at += f
+    # render-ahead walk
+    at = 0
+    ev = events(0)
+    if ev is not None:
+        async_inst.handle_midi_events(ev)
+    async_inst.generate_batch_values_async(blk_a[0], frames_of(0))
+    for b in range(blocks):
+        cur, nxt = blk_a[b & 1], blk_a[(b + 1) & 1]
+        f = frames_of(b)
+        if b + 1 < blocks:
+            ev = events(b + 1)
+            if ev is not None:
+                async_inst.handle_midi_events(ev)
+            async_inst.generate_batch_values_async(nxt, frames_of(b + 1))
+        for e in fx_async:
+            e.transform_audio(cur, f)
+        gpu_ctx.mix([cur], f, E._Slice(bus_a, at), accumulate=False)
+        if b % 3 == 0:  # downloads synchronise the ctx stream: do it on some blocks only, so others stay overlapped
+            outs_a.append((b, cur.download(f)))
+        at += f
+    gpu_ctx.synchronize()
+    got_s, got_a = bus_s.download(), bus_a.download()
+    for b, o in outs_a:
+        assert np.array_equal(o, outs_s[b]), f"block {b}: render-ahead block differs from the plain walk"
+    assert np.array_equal(got_s, got_a), "bus of the render-ahead walk differs from the plain walk"
+    assert np.abs(got_s).max() > 1e-3
+    for x in (blk_s, *blk_a, bus_s, bus_a):
+        x.destroy()
+    return got_s
+
+
+def _short_chain(n):
+    """The config-#3 chain with delay times short enough that sound comes out within a few blocks."""
+    import ctypes as C
+
+    def arr(**kw):
+        a = (T.FxParams * n)()
+        raw = np.frombuffer(bytes(bytearray(T.fx_params(**kw))), dtype=np.uint8)
+        C.memmove(a, np.tile(raw, n).tobytes(), n * C.sizeof(T.FxParams))
+        return a
+    lp = arr(q=0.707)
+    for i in range(n):
+        lp[i].cutoff_hz = 1000.0 + 50.0 * (i % 64)
+    return [(T.FX_BIQUAD_LP12, lp), (T.FX_CHORUS, arr(voices=4, delay_seconds=0.02)),
+            (T.FX_DELAY, arr(delay_seconds=0.004)), (T.FX_REVERB, arr(attenuation=0.95, reverb_seconds=0.3))]
+
+
+def test_welsh_chain_render_ahead_is_identical(gpu_ctx):
+    """Config #3 shape: grouped Welsh bank + BiQuad -> Chorus -> Delay -> Reverb per voice."""
+    from groove_amd import entities as E
+    n, blocks = 1024, 14
+    params, idx = P.welsh_voices_grouped(n, 0)
+    on, off = P.grouped_note_events(idx, True), P.grouped_note_events(idx, False)
+    a, b = _twin(lambda: E.WelshSynth(gpu_ctx, params))
+    fx_a = [E.Effect(gpu_ctx, k, p) for k, p in _short_chain(n)]
+    fx_b = [E.Effect(gpu_ctx, k, p) for k, p in _short_chain(n)]
+    _render_ahead(gpu_ctx, a, b, n, blocks, lambda k: on if k == 0 else (off if k == 8 else None), fx_a, fx_b)
+    for x in (a, b, *fx_a, *fx_b):
+        x.destroy()
+
+
+def test_regrouped_welsh_render_ahead_is_identical(gpu_ctx):
+    """Interleaved patches: the bank is regrouped inside the library, so the asynchronous render goes
+    through the scratch block and the gather kernel; ragged block lengths."""
+    from groove_amd import entities as E
+    n, blocks = 8192, 9
+    params = P.welsh_voices(n)
+    on, off = P.note_on_all(n), P.note_off_all(n)
+    a, b = _twin(lambda: E.WelshSynth(gpu_ctx, params))
+    lens = [256, 100, 7, 256, 1, 255, 64, 256, 33]
+    _render_ahead(gpu_ctx, a, b, n, blocks, lambda k: on if k == 0 else (off if k == 5 else None), frames_of=lambda k: lens[k])
+    a.destroy(); b.destroy()
+
+
+def test_fm_and_sampler_render_ahead_is_identical(gpu_ctx):
+    from groove_amd import entities as E
+    n = 512
+    fm = P.fm_voices(n)
+    a, b = _twin(lambda: E.FmSynth(gpu_ctx, fm))
+    _render_ahead(gpu_ctx, a, b, n, 8, lambda k: P.note_on_all(n) if k == 0 else (P.note_off_all(n) if k == 4 else None))
+    a.destroy(); b.destroy()
+    pcm, descs, _ = P.drum_bank(scale=0.05)
+    sp = P.sampler_voices(n)
+    keys = P.sampler_keys(n)
+    a, b = _twin(lambda: E.Sampler(gpu_ctx, pcm, descs, sp))
+    ev = T.note_events_np(np.arange(n, dtype=np.uint32), keys, True)
+    _render_ahead(gpu_ctx, a, b, n, 6, lambda k: ev if k in (0, 3) else None)
+    a.destroy(); b.destroy()
+
+
+def test_async_render_then_fused_mix_and_state(gpu_ctx):
+    """Switching between the asynchronous render, the fused render+mix and the state download on the
+    same bank keeps the order of calls (different side streams are joined when the bank changes sets)."""
+    from groove_amd import entities as E
+    n = 2048
+    params, idx = P.welsh_voices_grouped(n, 0)
+    on = P.grouped_note_events(idx, True)
+    a, b = _twin(lambda: E.WelshSynth(gpu_ctx, params))
+    blk_a, blk_b = gpu_ctx.block(n, FRAMES), gpu_ctx.block(n, FRAMES)
+    bus_a, bus_b = gpu_ctx.bus(FRAMES), gpu_ctx.bus(FRAMES)
+    a.handle_midi_events(on); b.handle_midi_events(on)
+    for step in range(6):
+        a.generate_batch_values(blk_a, FRAMES)
+        b.generate_batch_values_async(blk_b, FRAMES)
+        a.render_mix(bus_a, FRAMES); b.render_mix(bus_b, FRAMES)
+        assert np.array_equal(blk_a.download(FRAMES), blk_b.download(FRAMES)), f"step {step}: blocks differ"
+        assert np.array_equal(bus_a.download(), bus_b.download()), f"step {step}: fused buses differ"
+    assert np.array_equal(a.download_state(), b.download_state())
+    for x in (a, b, blk_a, blk_b, bus_a, bus_b):
+        x.destroy()
