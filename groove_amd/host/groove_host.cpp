@@ -18,12 +18,23 @@ VoiceBankInstrument::VoiceBankInstrument(groove_ctx* ctx, groove_bank* bank, uin
 }
 VoiceBankInstrument::~VoiceBankInstrument() {
   if (summed_) groove_block_destroy(summed_);
+  if (block_next_) groove_block_destroy(block_next_);
   if (block_) groove_block_destroy(block_);
   if (bank_) groove_bank_destroy(bank_);
 }
 int VoiceBankInstrument::tick(uint32_t frames) {
   if (groove_bank_render(bank_, frames, block_)) return 1;
   if (sum_voices_) return groove_block_accumulate(summed_, block_, frames, 0); // Synthesizer: sum of voices
+  return 0;
+}
+int VoiceBankInstrument::render_ahead(uint32_t frames) {
+  if (!block_next_ && groove_block_create(ctx_, voices_, GROOVE_BLOCK_FRAMES, &block_next_)) return 1;
+  return groove_bank_render_async(bank_, frames, block_next_); // side streams; consumers of the block wait for it
+}
+int VoiceBankInstrument::finish(uint32_t frames) {
+  if (!block_next_) return tick(frames); // nothing was rendered ahead
+  std::swap(block_, block_next_);
+  if (sum_voices_) return groove_block_accumulate(summed_, block_, frames, 0);
   return 0;
 }
 void VoiceBankInstrument::note_on(uint8_t key, uint8_t velocity, uint64_t now) {
@@ -136,8 +147,7 @@ void ControlTrip::work(uint64_t start_units, uint64_t end_units, std::vector<Mid
       const double v = value_at(s, (now - b) / s.beats);
       if (v != last_sent_) {
         last_sent_ = v;
-        if (Entity* e = o.get(target_))
-          if (e->is_effect()) static_cast<Effect*>(e)->control_set_param(index_, v);
+        o.control_effect(target_, index_, v);
       }
       return;
     }
@@ -222,7 +232,7 @@ int Orchestrator::eval(Uid uid, uint32_t frames, groove_block** out_block, uint3
   Entity* e = n.entity.get();
   if (e->is_instrument()) {
     Instrument* ins = static_cast<Instrument*>(e);
-    if (ins->tick(frames)) return fail(groove_last_error(ctx_));
+    if (!ahead_eval_ && ins->tick(frames)) return fail(groove_last_error(ctx_));
     *out_block = ins->output();
     *out_lanes = ins->lanes();
     return 0;
@@ -266,9 +276,92 @@ uint64_t Orchestrator::performance_frames() const {
   const double beats = (double)end / MusicalTime::UNITS_IN_BEAT;
   return (uint64_t)std::ceil(beats * 60.0 / bpm_ * (double)sr_);
 }
-void Orchestrator::skip_to_start() { frames_ = 0; performing_ = true; }
-int Orchestrator::tick(StereoSample* out, uint32_t frames, uint32_t* ticks_completed) {
+void Orchestrator::skip_to_start() { frames_ = 0; performing_ = true; ahead_primed_ = false; deferred_.clear(); }
+int Orchestrator::control_effect(Uid target, uint32_t index, double value01) {
+  if (deferring_) { deferred_.push_back({target, index, value01}); return 0; }
+  Entity* e = get(target);
+  if (e && e->is_effect()) return static_cast<Effect*>(e)->control_set_param(index, value01);
+  return 0;
+}
+void Orchestrator::sequence_block(uint64_t at_frame, uint32_t frames) {
   // handle_work (orchestrator.rs:631-708): controllers see the block's musical-time range
+  const uint64_t t0 = MusicalTime::frames_to_units(bpm_, sr_, at_frame);
+  uint64_t t1 = MusicalTime::frames_to_units(bpm_, sr_, at_frame + frames);
+  if (t1 == t0) t1 = t0 + 1;
+  std::vector<MidiEvent> midi;
+  for (auto& n : nodes_)
+    if (n.entity && n.entity->is_controller()) static_cast<Controller*>(n.entity.get())->work(t0, t1, midi, *this);
+  // broadcast_midi_messages (orchestrator.rs:710-754): every receiver on the channel
+  for (const MidiEvent& m : midi) {
+    auto range = midi_receivers_.equal_range(m.channel);
+    for (auto it = range.first; it != range.second; ++it) {
+      Instrument* ins = static_cast<Instrument*>(get(it->second));
+      if (m.on) ins->note_on(m.key, m.velocity, at_frame); else ins->note_off(m.key, m.velocity, at_frame);
+    }
+  }
+}
+bool Orchestrator::ahead_instruments(std::vector<Instrument*>& out) {
+  out.clear();
+  std::vector<uint32_t> seen(nodes_.size(), 0);
+  std::vector<Uid> stack{kMainMixerUid};
+  while (!stack.empty()) {
+    const Uid u = stack.back();
+    stack.pop_back();
+    if (++seen[u] > 1) return false; // heard through two paths: the block-by-block walk renders it twice; keep that
+    Entity* e = nodes_[u].entity.get();
+    if (!e) continue;
+    if (e->is_instrument()) {
+      Instrument* ins = static_cast<Instrument*>(e);
+      if (!ins->supports_render_ahead()) return false;
+      out.push_back(ins);
+    }
+    for (Uid s : nodes_[u].sources) stack.push_back(s);
+  }
+  return true;
+}
+// One block of an offline run with the instruments one block ahead of the effects: the instruments'
+// block b was rendered by the previous call (or by the priming below); this call sequences block b+1,
+// starts its render on the side streams, and only then walks the effect graph of block b.  Effect
+// automation computed while sequencing b+1 is held back until the effects have been given block b.
+int Orchestrator::tick_ahead(StereoSample* out, uint32_t frames, uint32_t* ticks_completed, const std::vector<Instrument*>& instruments) {
+  const uint64_t total = performance_frames();
+  auto len_at = [&](uint64_t at) -> uint32_t { return at >= total ? 0u : (uint32_t)std::min<uint64_t>(frames, total - at); };
+  const uint32_t done = len_at(frames_);
+  if (done > 0) {
+    if (!ahead_primed_) {
+      sequence_block(frames_, done);
+      for (Instrument* ins : instruments) if (ins->render_ahead(done)) return fail(groove_last_error(ctx_));
+      ahead_primed_ = true;
+    }
+    for (Instrument* ins : instruments) if (ins->finish(done)) return fail(groove_last_error(ctx_));
+    const uint32_t next = done == frames ? len_at(frames_ + done) : 0;
+    if (next > 0) {
+      deferring_ = true;
+      sequence_block(frames_ + done, next);
+      deferring_ = false;
+      for (Instrument* ins : instruments) if (ins->render_ahead(next)) return fail(groove_last_error(ctx_));
+    } else {
+      ahead_primed_ = false;
+    }
+    ahead_eval_ = true;
+    const int rc = gather_audio(done);
+    ahead_eval_ = false;
+    if (rc) return 1;
+    if (out && groove_download(ctx_, bus_, &out[0].l, (size_t)done * 2)) return fail(groove_last_error(ctx_));
+    for (const Deferred& d : deferred_) control_effect(d.target, d.index, d.value);
+    deferred_.clear();
+    frames_ += done; // clock.tick_batch(ticks_completed)
+  }
+  if (done < frames) performing_ = false;
+  *ticks_completed = done;
+  return 0;
+}
+int Orchestrator::tick_offline(StereoSample* out, uint32_t frames, uint32_t* ticks_completed) {
+  std::vector<Instrument*> instruments;
+  if (render_ahead_ && performing_ && ahead_instruments(instruments)) return tick_ahead(out, frames, ticks_completed, instruments);
+  return tick(out, frames, ticks_completed);
+}
+int Orchestrator::tick(StereoSample* out, uint32_t frames, uint32_t* ticks_completed) {
   const uint64_t total = performance_frames();
   uint32_t done = frames;
   if (performing_) {
@@ -276,20 +369,7 @@ int Orchestrator::tick(StereoSample* out, uint32_t frames, uint32_t* ticks_compl
     else if (frames_ + frames > total) done = (uint32_t)(total - frames_);
   }
   if (done > 0) {
-    const uint64_t t0 = MusicalTime::frames_to_units(bpm_, sr_, frames_);
-    uint64_t t1 = MusicalTime::frames_to_units(bpm_, sr_, frames_ + done);
-    if (t1 == t0) t1 = t0 + 1;
-    std::vector<MidiEvent> midi;
-    for (auto& n : nodes_)
-      if (n.entity && n.entity->is_controller()) static_cast<Controller*>(n.entity.get())->work(t0, t1, midi, *this);
-    // broadcast_midi_messages (orchestrator.rs:710-754): every receiver on the channel
-    for (const MidiEvent& m : midi) {
-      auto range = midi_receivers_.equal_range(m.channel);
-      for (auto it = range.first; it != range.second; ++it) {
-        Instrument* ins = static_cast<Instrument*>(get(it->second));
-        if (m.on) ins->note_on(m.key, m.velocity, frames_); else ins->note_off(m.key, m.velocity, frames_);
-      }
-    }
+    sequence_block(frames_, done);
     if (gather_audio(done)) return 1;
     if (out && groove_download(ctx_, bus_, &out[0].l, (size_t)done * 2)) return fail(groove_last_error(ctx_));
     if (performing_) frames_ += done; // clock.tick_batch(ticks_completed)
@@ -304,7 +384,7 @@ int Orchestrator::run(uint32_t buffer_frames, std::vector<StereoSample>& out) {
   std::vector<StereoSample> buf(buffer_frames);
   for (;;) {
     uint32_t done = 0;
-    if (tick(buf.data(), buffer_frames, &done)) return 1;
+    if (tick_offline(buf.data(), buffer_frames, &done)) return 1;
     out.insert(out.end(), buf.begin(), buf.begin() + done);
     if (done < buffer_frames) break;
   }
@@ -317,7 +397,7 @@ int Orchestrator::run_performance(uint32_t buffer_frames, Performance& perf) {
   std::vector<StereoSample> buf(buffer_frames);
   for (;;) {
     uint32_t done = 0;
-    if (tick(buf.data(), buffer_frames, &done)) return 1;
+    if (tick_offline(buf.data(), buffer_frames, &done)) return 1;
     if (done < buffer_frames) break; // the final partial block is dropped (orchestrator.rs:827-836)
     perf.worker.insert(perf.worker.end(), buf.begin(), buf.end());
   }
@@ -436,6 +516,7 @@ int gh_patch_chain_to_main_mixer(void* h, const int* uids, uint32_t n) {
   return ((Orchestrator*)h)->patch_chain_to_main_mixer(v);
 }
 void gh_unpatch_all(void* h) { ((Orchestrator*)h)->unpatch_all(); }
+void gh_set_render_ahead(void* h, int on) { ((Orchestrator*)h)->set_render_ahead(on != 0); }
 int gh_connect_midi_downstream(void* h, int uid, int channel) { return ((Orchestrator*)h)->connect_midi_downstream((Uid)uid, (uint8_t)channel); }
 int gh_add_timer(void* h, double beats) { return (int)((Orchestrator*)h)->add(std::unique_ptr<Entity>(new Timer(beats))); }
 int gh_add_sequencer(void* h) { return (int)((Orchestrator*)h)->add(std::unique_ptr<Entity>(new Sequencer())); }

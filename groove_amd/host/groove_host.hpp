@@ -76,6 +76,12 @@ class Instrument : public Entity {
   // HandlesMidi::handle_midi_message (note on/off only on this path)
   virtual void note_on(uint8_t key, uint8_t velocity, uint64_t now_frame) = 0;
   virtual void note_off(uint8_t key, uint8_t velocity, uint64_t now_frame) = 0;
+  // Render-ahead protocol of the offline runs (Orchestrator::run / run_performance): render_ahead()
+  // starts the NEXT block's render beside whatever the ctx stream does (groove_bank_render_async)
+  // without disturbing output(); finish() makes that block the current output().
+  virtual bool supports_render_ahead() const { return false; }
+  virtual int render_ahead(uint32_t frames) { (void)frames; return 0; }
+  virtual int finish(uint32_t frames) { return tick(frames); }
 };
 
 // IsEffect: TransformsAudio.
@@ -111,6 +117,9 @@ class VoiceBankInstrument : public Instrument {
   uint32_t lanes() const override { return sum_voices_ ? 1 : voices_; }
   groove_block* output() override { return sum_voices_ ? summed_ : block_; }
   int tick(uint32_t frames) override;
+  bool supports_render_ahead() const override { return true; }
+  int render_ahead(uint32_t frames) override;
+  int finish(uint32_t frames) override;
   void note_on(uint8_t key, uint8_t velocity, uint64_t now_frame) override;
   void note_off(uint8_t key, uint8_t velocity, uint64_t now_frame) override;
   groove_bank* bank() { return bank_; }
@@ -123,6 +132,7 @@ class VoiceBankInstrument : public Instrument {
   double release_seconds_;
   bool per_key_; // Drumkit: one voice per note (A.10)
   groove_block* block_ = nullptr;
+  groove_block* block_next_ = nullptr; // render-ahead: the block being rendered while block_ is consumed
   groove_block* summed_ = nullptr;
   std::vector<int> key_of_voice_;        // -1 = free
   std::vector<uint64_t> busy_until_;     // frame until which the voice may still sound
@@ -138,6 +148,7 @@ class ToyAudioSource : public Instrument {
   uint32_t lanes() const override { return 1; }
   groove_block* output() override { return block_; }
   int tick(uint32_t frames) override;
+  bool supports_render_ahead() const override { return true; } // constant block: nothing to render
   void note_on(uint8_t, uint8_t, uint64_t) override {}
   void note_off(uint8_t, uint8_t, uint64_t) override {}
  private:
@@ -246,6 +257,12 @@ class Orchestrator {
   int run(uint32_t buffer_frames, std::vector<StereoSample>& out);
   int run_performance(uint32_t buffer_frames, Performance& perf);
   void skip_to_start();
+  // Offline runs render the instruments of block b+1 on the library's side streams while the effect
+  // graph of block b runs (same samples; DESIGN.md "Render-ahead").  On by default; off = block by block.
+  void set_render_ahead(bool on) { render_ahead_ = on; }
+  // ControlTrip -> effect parameter.  While the controllers are run one block ahead of the effects
+  // the update is held back until the effects have processed the current block.
+  int control_effect(Uid target, uint32_t index, double value01);
   uint64_t clock_frames() const { return frames_; }
   uint64_t performance_frames() const; // ceil(end of the last controller)
 
@@ -263,6 +280,12 @@ class Orchestrator {
   };
   int eval(Uid uid, uint32_t frames, groove_block** out_block, uint32_t* out_lanes);
   int ensure_accum(Node& n, uint32_t lanes);
+  // handle_work + broadcast_midi_messages for the block [at_frame, at_frame + frames)
+  void sequence_block(uint64_t at_frame, uint32_t frames);
+  // the instruments the main mixer hears, if every one of them is heard exactly once and can render ahead
+  bool ahead_instruments(std::vector<Instrument*>& out);
+  int tick_ahead(StereoSample* out, uint32_t frames, uint32_t* ticks_completed, const std::vector<Instrument*>& instruments);
+  int tick_offline(StereoSample* out, uint32_t frames, uint32_t* ticks_completed);
 
   groove_ctx* ctx_ = nullptr;
   uint32_t sr_;
@@ -274,6 +297,12 @@ class Orchestrator {
   uint32_t bus_frames_ = 0;
   uint64_t frames_ = 0;
   bool performing_ = false;
+  bool render_ahead_ = true;
+  bool ahead_primed_ = false;   // the current block's instruments were rendered by the previous tick_ahead
+  bool ahead_eval_ = false;     // eval(): instruments already hold their block
+  bool deferring_ = false;      // controllers are being run for the NEXT block
+  struct Deferred { Uid target; uint32_t index; double value; };
+  std::vector<Deferred> deferred_;
 };
 
 // BusStation (src/mini/bus_station.rs:7-52): which track sends how much of its signal to which aux

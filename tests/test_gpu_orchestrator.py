@@ -215,3 +215,43 @@ def test_cli_renders_synthetic_config1_project(tmp_path):
     # unknown input → non-zero exit and a message, never an abort
     r = subprocess.run([cli, str(tmp_path / "missing.json5")], capture_output=True, text=True)
     assert r.returncode != 0 and "couldn't read" in r.stderr
+
+
+def _sequenced_project(o, with_trip=True):
+    """Two sequenced synths (Welsh through a swept low-pass + delay; FM straight) into the main mixer."""
+    from groove_amd import host_binding as H
+    w = o.add_welsh(P.welsh_patch(3), voices=6)
+    lp = o.add_effect(T.FX_BIQUAD_LP24, T.fx_params(cutoff_hz=800.0, passband_ripple=0.8))
+    dl = o.add_effect(T.FX_DELAY, T.fx_params(delay_seconds=0.003))
+    assert o.patch_chain_to_main_mixer([w, lp, dl]) == 0
+    f = o.add_fm(P.fm_patch(2), voices=4)
+    assert o.patch(f, o.MAIN_MIXER) == 0
+    o.connect_midi_downstream(w, 0)
+    o.connect_midi_downstream(f, 1)
+    seq = o.add_sequencer()
+    for i, (k, s, d) in enumerate([(60, 0.0, 0.75), (64, 0.25, 0.5), (67, 0.5, 1.0), (72, 1.25, 0.25), (48, 1.5, 0.4)]):
+        o.sequencer_insert(seq, 0, k, s, d)
+        o.sequencer_insert(seq, 1, k + 12, s + 0.1, d * 0.5)
+    o.sequencer_set_end(seq, 2.0)
+    if with_trip:
+        trip = o.add_control_trip(lp, "cutoff", 0.0)
+        o.control_trip_add_step(trip, H.STEP_SLOPE, 0.1, 0.9, 1.0)
+        o.control_trip_add_step(trip, H.STEP_EXPONENTIAL, 0.9, 0.2, 1.0)
+
+
+@pytest.mark.parametrize("buffer_frames,performance", [(64, False), (256, False), (256, True), (100, False)])
+def test_render_ahead_run_is_identical_to_block_by_block(buffer_frames, performance):
+    """Offline runs keep the instruments one block ahead of the effects (groove_bank_render_async;
+    automation for the effects is held back a block).  Same samples as the block-by-block walk,
+    including the final partial block (`run`) and its omission (`run_performance`)."""
+    from groove_amd.host_binding import Orchestrator
+    outs = []
+    for ahead in (False, True):
+        o = Orchestrator(0, 44100, 128.0)
+        o.set_render_ahead(ahead)
+        _sequenced_project(o)
+        outs.append(o.run(buffer_frames, performance=performance))
+        o.close()
+    assert len(outs[0]) == len(outs[1]) > 0
+    assert np.sqrt(np.mean(outs[0].astype(np.float64) ** 2)) > 1e-3
+    assert np.array_equal(outs[0], outs[1])
