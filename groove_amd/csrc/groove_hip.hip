@@ -117,6 +117,7 @@ struct groove_ctx {
   bool need_fork = true;                // ctx-stream work since the last fork that side streams must wait for
   uint32_t pipeline_min_waves = 4700;   // banks at least this long (~300,000 voices) run one kernel per base kind and pipeline their fused blocks; smaller ones take the all-kinds kernel
   int next_stream_slot = 0;             // round-robin side-stream assignment of single-kernel banks
+  bool seq_allpass = false;             // GROOVE_FX_SEQ_ALLPASS=1: the sequential all-pass kernel (A/B and bit-identity tests)
   uint32_t sr = GROOVE_DEFAULT_SAMPLE_RATE;
   std::string err;
   std::vector<groove_bank*> banks;
@@ -621,6 +622,7 @@ int groove_init(int device_ordinal, groove_ctx** out) {
   groove_ctx* ctx = new (std::nothrow) groove_ctx();
   if (!ctx) return fail(nullptr, "groove_init: out of memory");
   ctx->device = device_ordinal;
+  if (const char* e = std::getenv("GROOVE_FX_SEQ_ALLPASS")) ctx->seq_allpass = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_PIPELINE_MIN_WAVES")) ctx->pipeline_min_waves = (uint32_t)std::strtoul(e, nullptr, 10); // tests force the pipeline on small banks
   bool ok = hipSetDevice(device_ordinal) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
@@ -1304,9 +1306,15 @@ int groove_fx_process(groove_fx* fx, groove_block* io, uint32_t frames) {
       for (int i = 1; i < 4; ++i) shortest_comb = std::min(shortest_comb, fx->geo.N[i]);
       const uint32_t shortest_ap = std::min(fx->geo.N[4], fx->geo.N[5]);
       if (fx->all_wet && shortest_comb >= frames && shortest_ap >= 32) {
-        // combs: parallel over (frame, lane); all-passes: sequential per lane, 32-frame chunks
+        // combs: parallel over (frame, lane); all-passes: parallel inside chunks of one line length
         hipLaunchKernelGGL(fx_reverb_combs_par_kernel, dim3(lanes_grid.x, frames), blk, 0, ctx->stream, io->d, n, chs, fx->d_ring, fx->geo, fx->d_fa);
-        hipLaunchKernelGGL(fx_reverb_allpass_kernel<32>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->geo);
+        if (ctx->seq_allpass) {
+          hipLaunchKernelGGL(fx_reverb_allpass_kernel<32>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->geo);
+        } else { // chunks of one line length, parallel inside (kernels.h)
+          const uint32_t T = std::max<uint32_t>(1, std::min<uint32_t>(64, 2 * n / 512));
+          hipLaunchKernelGGL(fx_reverb_allpass_chunked_kernel, dim3((2 * n + T - 1) / T), dim3(kAllpassThreads), 0, ctx->stream, io->d, n, frames, chs,
+                             fx->d_ring, fx->geo, T);
+        }
       } else if (shortest >= 8) hipLaunchKernelGGL(fx_reverb_kernel<8>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->geo, fx->d_fa, fx->d_wet);
       else hipLaunchKernelGGL(fx_reverb_kernel<1>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->geo, fx->d_fa, fx->d_wet);
       for (int i = 0; i < 6; ++i) fx->geo.w[i] = (uint32_t)(((uint64_t)fx->geo.w[i] + frames) % fx->geo.N[i]);

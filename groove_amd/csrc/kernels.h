@@ -1031,6 +1031,57 @@ __global__ __launch_bounds__(kThreads) void fx_reverb_allpass_kernel(
   }
 }
 
+// The same two all-passes, time-parallel inside chunks: an all-pass whose line is N frames long has
+// no feedback within N frames, so a chunk of N frames is a pure gather/scatter over (frame, lane) and
+// only chunk k+1 depends on chunk k (through the ring).  A workgroup owns T adjacent lane-channels
+// (T chosen by the host so that the launch has ~500 workgroups, and a thread issues the loads of four
+// items together: the dependent chain is then 2 + 4 chunks of one memory round trip each instead of
+// 256 frames / 32 per round trip), walks the
+// chunks of stage 1 and then of stage 2 with a barrier between chunks; the arithmetic per frame is
+// the sequential kernel's, so are the bits.  (All waves of a workgroup share one L1, so the barrier
+// makes the ring and block writes of a chunk visible to the next.)
+constexpr uint32_t kAllpassThreads = 1024, kAllpassUnroll = 4;
+__global__ __launch_bounds__(kAllpassThreads) void fx_reverb_allpass_chunked_kernel(
+    float* __restrict__ data, uint32_t n, uint32_t frames, size_t ch_stride, float* __restrict__ ring, ReverbGeom geo, uint32_t T) {
+  const uint32_t ln = 2 * n;
+  const uint32_t t0 = blockIdx.x * T;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const uint32_t N = geo.N[4 + i], w = geo.w[4 + i];
+    const float g = geo.g[4 + i];
+    float* __restrict__ rg = ring + geo.base[4 + i] * ln;
+    for (uint32_t f0 = 0; f0 < frames; f0 += N) {
+      const uint32_t items = min(N, frames - f0) * T;
+      for (uint32_t k0 = threadIdx.x; k0 < items; k0 += kAllpassThreads * kAllpassUnroll) {
+        float* px[kAllpassUnroll];
+        float* pr[kAllpassUnroll];
+        float x[kAllpassUnroll], d[kAllpassUnroll];
+        bool live[kAllpassUnroll];
+#pragma unroll
+        for (uint32_t u = 0; u < kAllpassUnroll; ++u) { // all the loads of this pass first: one round trip
+          const uint32_t k = k0 + u * kAllpassThreads;
+          const uint32_t f = f0 + k / T, tt = t0 + k % T;
+          live[u] = k < items && tt < ln;
+          const uint32_t ch = tt >= n ? 1u : 0u, lane = tt - ch * n;
+          px[u] = data + ch * ch_stride + (size_t)f * n + lane;
+          pr[u] = rg + (size_t)((w + f) % N) * ln + tt;
+          x[u] = live[u] ? *px[u] : 0.0f;
+          d[u] = live[u] ? *pr[u] : 0.0f;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kAllpassUnroll; ++u) {
+          if (live[u]) {
+            const float v = fmaf(g, d[u], x[u]);
+            *pr[u] = v;
+            *px[u] = fmaf(-g, v, d[u]);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 #endif // GROOVE_WELSH_CLASS_TU
 
 } // namespace groove

@@ -173,3 +173,34 @@ def test_config3_chain_bus_parity(gpu_ctx, oracle):
     rms = np.sqrt(np.mean((got - want) ** 2))
     assert np.sqrt(np.mean(want ** 2)) > 1e-3
     assert rms <= 1e-5, f"chain bus rms {rms:.3e}"
+
+
+@pytest.mark.parametrize("n", [1, 72, 1500])
+def test_reverb_allpass_chunks_ragged_blocks(gpu_ctx, oracle, n):
+    """All-wet reverb: the all-passes run time-parallel inside chunks of one line length (220 and 74
+    frames at 44.1 kHz).  Block lengths around those lengths and around multiples of them; lane counts
+    that give one and two lane-channels per workgroup.  Same tolerance as the sequential form, and
+    bit-identical to it (second context with GROOVE_FX_SEQ_ALLPASS=1)."""
+    import os
+    from groove_amd import entities as E
+    sizes = [256, 1, 73, 74, 75, 148, 149, 219, 220, 221, 256, 255, 33, 256, 256]
+    x = _audio(n, sum(sizes), seed=3)
+    params = _params(n, attenuation=0.9, reverb_seconds=0.8)
+    got, want = _run(gpu_ctx, oracle, T.FX_REVERB, params, x, block_sizes=sizes)
+    assert np.max(np.abs(want)) > 0.1
+    assert np.max(np.abs(got - want)) <= 4e-6
+    os.environ["GROOVE_FX_SEQ_ALLPASS"] = "1"
+    try:
+        ctx2 = E.Context(0)
+    finally:
+        del os.environ["GROOVE_FX_SEQ_ALLPASS"]
+    fx = E.Effect(ctx2, T.FX_REVERB, params)
+    block = ctx2.block(n, 256)
+    seq, pos = [], 0
+    for fr in sizes:
+        block.upload(np.ascontiguousarray(x[:, pos:pos + fr, :]))
+        fx.transform_audio(block, fr)
+        seq.append(block.download(fr))
+        pos += fr
+    fx.destroy(); block.destroy(); ctx2.close()
+    assert np.array_equal(got, np.concatenate(seq, axis=1))
