@@ -734,11 +734,18 @@ __global__ __launch_bounds__(kThreads) void fx_biquad_kernel(
   BiquadStateD s{st[t], st[ln + t], st[2 * ln + t], st[3 * ln + t]};
   const float w = wet[lane];
   float* __restrict__ ptr = data + ch * ch_stride + lane;
+  // the next chunk's inputs are requested before this chunk's recurrence runs, so the memory round
+  // trip of chunk k+1 hides behind the arithmetic of chunk k
+  float xn[C];
+#pragma unroll
+  for (int j = 0; j < C; ++j) xn[j] = (uint32_t)j < frames ? ptr[(size_t)j * n] : 0.0f;
   for (uint32_t f0 = 0; f0 < frames; f0 += C) {
     const uint32_t c_n = min((uint32_t)C, frames - f0);
     float x[C];
 #pragma unroll
-    for (int j = 0; j < C; ++j) x[j] = (uint32_t)j < c_n ? ptr[(size_t)(f0 + j) * n] : 0.0f;
+    for (int j = 0; j < C; ++j) x[j] = xn[j];
+#pragma unroll
+    for (int j = 0; j < C; ++j) xn[j] = f0 + C + j < frames ? ptr[(size_t)(f0 + C + j) * n] : 0.0f;
 #pragma unroll
     for (int j = 0; j < C; ++j) {
       if ((uint32_t)j < c_n) {
@@ -763,11 +770,18 @@ __global__ __launch_bounds__(kThreads) void fx_lp24_kernel(
   Lp24StateD s{st[t], st[ln + t], st[2 * ln + t], st[3 * ln + t]};
   const float w = wet[lane];
   float* __restrict__ ptr = data + ch * ch_stride + lane;
+  // the next chunk's inputs are requested before this chunk's recurrence runs, so the memory round
+  // trip of chunk k+1 hides behind the arithmetic of chunk k
+  float xn[C];
+#pragma unroll
+  for (int j = 0; j < C; ++j) xn[j] = (uint32_t)j < frames ? ptr[(size_t)j * n] : 0.0f;
   for (uint32_t f0 = 0; f0 < frames; f0 += C) {
     const uint32_t c_n = min((uint32_t)C, frames - f0);
     float x[C];
 #pragma unroll
-    for (int j = 0; j < C; ++j) x[j] = (uint32_t)j < c_n ? ptr[(size_t)(f0 + j) * n] : 0.0f;
+    for (int j = 0; j < C; ++j) x[j] = xn[j];
+#pragma unroll
+    for (int j = 0; j < C; ++j) xn[j] = f0 + C + j < frames ? ptr[(size_t)(f0 + C + j) * n] : 0.0f;
 #pragma unroll
     for (int j = 0; j < C; ++j) {
       if ((uint32_t)j < c_n) {
