@@ -15,9 +15,16 @@ Workloads:
     sampler-16384 config #4   (16,384 one-shot sampler voices over a shared bank)
     mixed-131072  config #5   (50 % Welsh / 25 % FM / 25 % sampler)
 
-Multi-GPU: strong scaling — the project's voices are cut into contiguous index ranges, one
-range per rank (one process per GPU), and the per-rank buses are summed with ONE RCCL reduce
+Multi-GPU: the project's voices are cut into contiguous index ranges, one range per rank (one
+process per GPU, no data-path collective), and the per-rank buses are summed with ONE RCCL reduce
 over the whole timed region's frames (K*256 frames * 8 B), inside the timed region.
+  default (weak scaling): every rank holds the workload's voice count, so the project grows with
+      N (N x 1,000,000 voices); `value` = stereo frames rendered by all ranks per second (each
+      rank renders the K*256 bus frames of its shard), `project_frames_per_s` = the merged
+      project's frames per second (flat when scaling is ideal), `voice_frames_per_s` the rate in
+      the unit that does not depend on how the voices are grouped.
+  --strong: the workload's voice count is fixed and split N ways; `value` = project frames/s.
+      (1,000,000 voices are small for eight MI355X: DESIGN.md §6 has the latency ceiling.)
 """
 import argparse
 import json
@@ -245,6 +252,9 @@ def main():
                     help="entity-boundary form: write every voice block to HBM, then run the separate mix kernels "
                          "(default: fused render+mix, no materialised voice blocks)")
     ap.add_argument("--interleaved", action="store_true", help="voice i uses patch i mod 32 inside every wavefront (generic per-lane kernel)")
+    ap.add_argument("--strong", action="store_true",
+                    help="multi-GPU: split the workload's voices over the ranks (default: weak scaling, every rank "
+                         "holds the workload's voice count and the project grows with --gpus)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-render-ahead", action="store_true",
                     help="workloads with effect chains: render block b, then its effects (default: the render of block b+1 "
@@ -268,8 +278,10 @@ def main():
 
     wl = dict(WORKLOADS[args.workload])
     V = args.voices or wl["voices"]
-    lo = V * rank // world
-    hi = V * (rank + 1) // world
+    weak = not args.strong
+    V_total = V * world if weak else V   # voices of the whole project
+    lo = V_total * rank // world
+    hi = V_total * (rank + 1) // world
     ctx = E.Context(local_rank if use_dist else 0)
     if use_dist:
         uid = [ctx.comm_unique_id() if rank == 0 else None]
@@ -310,23 +322,27 @@ def main():
     if rank == 0:
         out_bus = bus.download()[W * FRAMES:]
         finite = bool(np.isfinite(out_bus).all())
-        peak = float(np.abs(out_bus).max() / V)
+        peak = float(np.abs(out_bus).max() / V_total)
         frames_total = K * FRAMES
-        value = frames_total / elapsed
+        project_fps = frames_total / elapsed                    # frames of the merged project per second
+        value = project_fps * (world if weak else 1)            # weak: every rank rendered frames_total bus frames of its shard
         n_local = hi - lo
         whole_step = wl["kind"] == "chain" and not args.no_render_ahead  # the events bracket the step, not one kernel
         dom_bytes = (wl["bytes_per_vf"] if ((fused and wl["kind"] in ("welsh", "sampler")) or whole_step) else wl["dominant_bytes"])
         achieved = dom_bytes * n_local * FRAMES / (kern_ms * 1e-3) / 1e9
         line = {
             "metric": "stereo frames/sec rendered (offline)", "value": value, "unit": "stereo frames/s",
-            "x_realtime_44k1": value / SR, "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong",
+            "x_realtime_44k1": project_fps / SR, "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak" if weak else "strong",
             "vs_baseline": None, "dtype": "f32 (f64 IIR state, u64 phase)", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {V} voices total, {FRAMES}-frame blocks, {SR} Hz, "
+            "config": {"workload": f"{args.workload}: {V_total} voices total, {FRAMES}-frame blocks, {SR} Hz, "
                                    f"{'fused render+mix' if fused else 'materialised blocks + mix kernels'}",
-                       "voices_total": V, "voices_per_gpu": n_local, "parallelism": f"voices sharded x{world}, 1 RCCL bus reduce"},
-            "voice_frames_per_s": value * V,
-            "path_effective_GBs": wl["bytes_per_vf"] * value * V / 1e9,
+                       "voices_total": V_total, "voices_per_gpu": n_local,
+                       "parallelism": (f"voices sharded x{world} ({'weak: ' + str(V) + ' voices per GPU, project grows with N' if weak else 'strong: fixed project split N ways'}), "
+                                       "no data-path collective, 1 RCCL bus reduce per render")},
+            "project_frames_per_s": project_fps,
+            "voice_frames_per_s": project_fps * V_total,
+            "path_effective_GBs": wl["bytes_per_vf"] * project_fps * V_total / 1e9,
             "roofline": {"bound": "hbm",
                          "kernel": ("welsh_render_uniform_kernel<fused, LFO mode, retune> (one kernel per base kind, run "
                                     "concurrently; class-specialised block bodies) + partial_rows/final" if fused and wl["kind"] == "welsh"
