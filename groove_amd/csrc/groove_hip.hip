@@ -104,7 +104,8 @@ struct groove_fx {
 };
 
 constexpr int kBankStreams = 4;                         // shared round-robin by single-kernel banks (FM, sampler, per-lane Welsh)
-constexpr int kSideStreams = kBaseKinds + kBankStreams; // + one per Welsh base kind; the ctx stream carries events, reductions and the rest
+constexpr int kSideStreams = kBaseKinds + kBankStreams;
+static_assert(kBaseKinds == 6 && kBankStreams == 4, "groove_init lists the side streams in creation order"); // + one per Welsh base kind; the ctx stream carries events, reductions and the rest
 static_assert(kSideStreams <= 16, "groove_block::ev_ready holds one event per side stream");
 struct groove_ctx {
   int device = 0;
@@ -150,13 +151,21 @@ int fail(groove_ctx* ctx, const std::string& msg) {
       return fail(ctx, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
   } while (0)
 
+hipStream_t side_stream_of(groove_ctx* ctx, int k) {
+  if (!ctx->side_stream[k] && hipStreamCreateWithFlags(&ctx->side_stream[k], hipStreamNonBlocking) != hipSuccess) {
+    ctx->side_stream[k] = nullptr;
+    fail(ctx, "side stream: hipStreamCreate failed");
+    return ctx->stream; // degrade to the ctx stream: still ordered, just not concurrent
+  }
+  return ctx->side_stream[k];
+}
 // Order the ctx stream after everything enqueued on the side streams, and make later side-stream work
 // wait for whatever the ctx stream does next.  Called by every operation that touches bank state or
 // parameters outside the pipelined fused render (note events, controls, state download, destroy...).
 int ctx_join(groove_ctx* ctx) {
   for (int k = 0; k < kSideStreams; ++k) {
     if (!ctx->side_busy[k]) continue;
-    GHIP(ctx, hipEventRecord(ctx->ev_join[k], ctx->side_stream[k]));
+    GHIP(ctx, hipEventRecord(ctx->ev_join[k], side_stream_of(ctx, k)));
     GHIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[k], 0));
     ctx->side_busy[k] = false;
   }
@@ -283,32 +292,47 @@ int welsh_upload_params(groove_bank* b, bool regroup) {
     b->n_vwaves = 0;
     return 0;
   }
-  b->n_vwaves = (uint32_t)W.size();
-  const uint32_t wgs = (b->n_vwaves + kWaves - 1) / kWaves;
-  // a workgroup runs in the instantiation its most demanding wave needs (kernels.h, "Workgroup KINDS")
-  struct Need { int rank = 0; bool retune = false; int c1 = -1, c2 = -1, cl = -1; };
-  std::vector<Need> need(wgs);
-  for (uint32_t w = 0; w < b->n_vwaves; ++w) {
-    const WelshParams& p = W[w].p;
+  // A workgroup runs in ONE instantiation (kernels.h, "Workgroup KINDS"), so it is built from waves that
+  // ask for the same one: the waves are ordered by the kind they need and every kind's last workgroup is
+  // filled up with empty waves (count 0).  (Cutting the run order into fours made every workgroup of a
+  // small many-patch bank a mixture, which runs in the most demanding base kind with the run-time
+  // waveform switches: config #2's 32 waves took 0.21 ms per block where their slowest patch needs 0.16.)
+  auto kind_of_wave = [](const WelshParams& p) -> uint16_t {
     const int mode = welsh_lfo_mode(p);
-    Need& k = need[w / kWaves];
-    k.rank = std::max(k.rank, mode == LFO_F32 ? 0 : (mode == LFO_F64_SMOOTH ? 1 : 2));
-    k.retune = k.retune || welsh_retunes(p);
-    const int c1 = osc_class_of((p.flags >> WF_O1_WAVE_SHIFT) & 15u), c2 = osc_class_of((p.flags >> WF_O2_WAVE_SHIFT) & 15u);
-    k.c1 = k.c1 < 0 ? c1 : (k.c1 == c1 ? c1 : (int)OSC_ANY); // waves that disagree fall back to the run-time switch
-    k.c2 = k.c2 < 0 ? c2 : (k.c2 == c2 ? c2 : (int)OSC_ANY);
-    const int cl = lfo_class_of((p.flags >> WF_LFO_WAVE_SHIFT) & 15u, (p.flags >> WF_ROUTING_SHIFT) & 15u);
-    k.cl = k.cl < 0 ? cl : (k.cl == cl ? cl : (int)OSC_ANY);
-  }
-  std::vector<uint16_t> kind(wgs);
-  for (uint32_t g = 0; g < wgs; ++g) {
-    const int base = need[g].rank * 2 + (need[g].retune ? 1 : 0); // == wg_base_kind_of()
+    const int base = (mode == LFO_F32 ? 0 : (mode == LFO_F64_SMOOTH ? 1 : 2)) * 2 + (welsh_retunes(p) ? 1 : 0); // == wg_base_kind_of()
     const bool spec = wg_base_kind_specialised(base);
-    int cl = spec ? std::max(need[g].cl, 0) : (int)OSC_ANY;
-    // the smooth-f64 kernels carry the sine / triangle / any LFO copies only (a mixed workgroup could ask for more)
+    const int c1 = osc_class_of((p.flags >> WF_O1_WAVE_SHIFT) & 15u), c2 = osc_class_of((p.flags >> WF_O2_WAVE_SHIFT) & 15u);
+    int cl = spec ? lfo_class_of((p.flags >> WF_LFO_WAVE_SHIFT) & 15u, (p.flags >> WF_ROUTING_SHIFT) & 15u) : (int)OSC_ANY;
+    // the smooth-f64 kernels carry the sine / triangle / any LFO copies only
     if (base >= 2 && cl != OSC_SINE && cl != OSC_TRIANGLE) cl = OSC_ANY;
-    kind[g] = (uint16_t)wg_kind_of(base, cl, spec ? std::max(need[g].c1, 0) : (int)OSC_ANY, spec ? std::max(need[g].c2, 0) : (int)OSC_ANY);
+    return (uint16_t)wg_kind_of(base, cl, spec ? c1 : (int)OSC_ANY, spec ? c2 : (int)OSC_ANY);
+  };
+  std::vector<uint16_t> kind; // per workgroup
+  {
+    std::vector<uint16_t> wave_kind(W.size());
+    std::vector<uint32_t> order(W.size());
+    for (uint32_t w = 0; w < W.size(); ++w) { wave_kind[w] = kind_of_wave(W[w].p); order[w] = w; }
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) { return wave_kind[a] < wave_kind[c]; });
+    std::vector<WaveDesc> packed;
+    packed.reserve(W.size() + (size_t)kWaves * 64);
+    for (size_t i = 0; i < order.size();) {
+      size_t e = i;
+      while (e < order.size() && wave_kind[order[e]] == wave_kind[order[i]]) ++e;
+      for (size_t j = i; j < e; ++j) {
+        if ((j - i) % kWaves == 0) kind.push_back(wave_kind[order[i]]);
+        packed.push_back(W[order[j]]);
+      }
+      while (packed.size() % kWaves) { // empty waves: no lane active, the first wave's voice as the shadow address
+        WaveDesc pad = W[order[i]];
+        pad.count = 0;
+        packed.push_back(pad);
+      }
+      i = e;
+    }
+    W.swap(packed);
   }
+  b->n_vwaves = (uint32_t)W.size();
+  const uint32_t wgs = b->n_vwaves / kWaves;
   std::vector<uint32_t> wg_list(wgs);
   std::vector<uint8_t> wg_cls(wgs), wg_base(wgs);
   {
@@ -624,11 +648,26 @@ int groove_init(int device_ordinal, groove_ctx** out) {
   ctx->device = device_ordinal;
   if (const char* e = std::getenv("GROOVE_FX_SEQ_ALLPASS")) ctx->seq_allpass = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_PIPELINE_MIN_WAVES")) ctx->pipeline_min_waves = (uint32_t)std::strtoul(e, nullptr, 10); // tests force the pipeline on small banks
-  bool ok = hipSetDevice(device_ordinal) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
+  // The runtime spreads the streams of one priority over a handful of hardware queues, and streams that
+  // share a queue run one after the other.  The ctx stream is created at the highest priority: that
+  // gives it a hardware queue of its own, so that a bank's side stream can never land behind it (as a
+  // normal-priority stream it shared a queue with the first bank stream and the render-ahead overlap of
+  // config #3 was gone: 0.25 ms per block against 0.14), and its short bus reductions, which every
+  // pipelined block waits for, are dispatched ahead of the long render kernels.
+  int prio_least = 0, prio_greatest = 0;
+  bool ok = hipSetDevice(device_ordinal) == hipSuccess && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess &&
+            hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
             hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
-  for (int i = 0; ok && i < kSideStreams; ++i)
-    ok = hipStreamCreateWithFlags(&ctx->side_stream[i], hipStreamNonBlocking) == hipSuccess &&
-         hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
+  // Four normal-priority streams for the four class-specialised Welsh kinds (side by side in every block
+  // of a big bank; the two exact-f64-LFO kinds, rare, share the first two), and four LOW-priority streams
+  // for the single-kernel banks (side by side in a mixed project): never more streams of one priority
+  // than hardware queues, so no two of them are serialised behind each other by the runtime.
+  for (int i = 0; ok && i < kSideStreams; ++i) {
+    if (i == 4 || i == 5) ctx->side_stream[i] = ctx->side_stream[i - 4];
+    else if (i < kBaseKinds) ok = hipStreamCreateWithFlags(&ctx->side_stream[i], hipStreamNonBlocking) == hipSuccess;
+    else ok = hipStreamCreateWithPriority(&ctx->side_stream[i], hipStreamNonBlocking, prio_least) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
+  }
   if (!ok) {
     groove_shutdown(ctx);
     return fail(nullptr, "groove_init: hipSetDevice/hipStreamCreate failed");
@@ -650,7 +689,7 @@ void groove_shutdown(groove_ctx* ctx) {
   if (ctx->d_i16) (void)hipFree(ctx->d_i16);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   for (int i = 0; i < kSideStreams; ++i) {
-    if (ctx->side_stream[i]) { (void)hipStreamSynchronize(ctx->side_stream[i]); (void)hipStreamDestroy(ctx->side_stream[i]); }
+    if (ctx->side_stream[i] && i != 4 && i != 5) { (void)hipStreamSynchronize(ctx->side_stream[i]); (void)hipStreamDestroy(ctx->side_stream[i]); }
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -897,10 +936,11 @@ static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs
       // One kernel per base kind present, all running concurrently: the most expensive kind goes
       // out first on the ctx stream (list scheduling, longest first), the others on side streams
       // forked from it, and the ctx stream joins them before the bus reduction.
-      if (fused && b->n_vwaves < ctx->pipeline_min_waves) { // small bank: all base kinds in one launch (kernels.h)
+      if (b->n_vwaves < ctx->pipeline_min_waves) { // small bank: all base kinds in one launch (kernels.h)
         const uint32_t wgs = (b->n_vwaves + kWaves - 1) / kWaves;
         UniformArgs a{b->d_waves, b->d_state, out, b->d_wg_list, b->d_wg_cls, chs, rc, b->n_vwaves, b->n, frames, wgs};
-        launch_welsh_uniform_any(a, b->d_wg_base, ctx->stream);
+        if (fused) launch_welsh_uniform_any(a, b->d_wg_base, ctx->stream);
+        else launch_welsh_uniform_any_unfused(a, b->d_wg_base, ctx->stream);
         GHIP(ctx, hipGetLastError());
         return 0;
       }
@@ -922,7 +962,7 @@ static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs
         if (!count[k]) continue;
         hipStream_t st = ctx->stream;
         if (!first_kind) {
-          st = ctx->side_stream[side];
+          st = side_stream_of(ctx, side);
           GHIP(ctx, hipStreamWaitEvent(st, ctx->ev_fork, 0));
         }
         UniformArgs a{b->d_waves, b->d_state, out, b->d_wg_list + offset[k], b->d_wg_cls + offset[k], chs, rc, b->n_vwaves, b->n, frames, count[k]};
@@ -984,7 +1024,8 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
   GHIP(ctx, hipSetDevice(ctx->device));
   if (flush_events(b)) return 1;
   if (block_acquire(out)) return 1; // an earlier asynchronous render into the same block comes first
-  const bool uniform = b->kind == BANK_WELSH && b->n_vwaves;
+  const bool small_uniform = b->kind == BANK_WELSH && b->n_vwaves && b->n_vwaves < ctx->pipeline_min_waves;
+  const bool uniform = b->kind == BANK_WELSH && b->n_vwaves && !small_uniform; // one kernel per base kind
   if (bank_side_mode(b, uniform ? 1 : 2)) return 1;
   if (!out->ev_free) {
     GHIP(ctx, hipEventCreateWithFlags(&out->ev_free, hipEventDisableTiming));
@@ -1009,14 +1050,14 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
   const dim3 blk(kThreads);
   uint32_t used = 0;
   auto begin = [&](int k) -> hipStream_t {
-    hipStream_t st = ctx->side_stream[k];
+    hipStream_t st = side_stream_of(ctx, k);
     (void)hipStreamWaitEvent(st, out->ev_free, 0);
     if (regrouped && b->gather_recorded) (void)hipStreamWaitEvent(st, b->ev_gather, 0); // the scratch block is free again
     ctx->fork_pending[k] = false; // ev_free is later than any ev_fork recorded so far
     return st;
   };
   auto end = [&](int k) {
-    (void)hipEventRecord(out->ev_ready[k], ctx->side_stream[k]);
+    (void)hipEventRecord(out->ev_ready[k], side_stream_of(ctx, k));
     used |= 1u << k;
     ctx->side_busy[k] = true;
   };
@@ -1040,7 +1081,11 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
     const int k = b->stream_slot;
     hipStream_t st = begin(k);
     const dim3 grid(blocks_for(b->n));
-    if (b->kind == BANK_WELSH) {
+    if (small_uniform) { // all base kinds in one launch
+      const RenderConsts rc{(float)(3.14159265358979323846 / ctx->sr), (float)(0.49 * ctx->sr)};
+      UniformArgs a{b->d_waves, b->d_state, dst, b->d_wg_list, b->d_wg_cls, chs, rc, b->n_vwaves, b->n, frames, b->n_vwaves / kWaves};
+      launch_welsh_uniform_any_unfused(a, b->d_wg_base, st);
+    } else if (b->kind == BANK_WELSH) {
       const RenderConsts rc{(float)(3.14159265358979323846 / ctx->sr), (float)(0.49 * ctx->sr)};
       hipLaunchKernelGGL(welsh_render_kernel<false>, grid, blk, 0, st, b->d_params, b->d_state, b->n, frames, chs, dst, rc);
     } else if (b->kind == BANK_FM) {
@@ -1052,7 +1097,7 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
   }
   if (regrouped) {
     const int g = b->stream_slot;
-    hipStream_t st = ctx->side_stream[g];
+    hipStream_t st = side_stream_of(ctx, g);
     for (int k = 0; k < kSideStreams; ++k)
       if ((used & (1u << k)) && k != g) GHIP(ctx, hipStreamWaitEvent(st, out->ev_ready[k], 0));
     hipLaunchKernelGGL(block_gather_kernel, dim3(blocks_for(b->n), std::min<uint32_t>(frames, 64)), blk, 0, st, out->d,
@@ -1121,7 +1166,7 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
   const dim3 blk(kThreads);
   for (int k = kSideStreams - 1; k >= 0; --k) { // most expensive Welsh kind first
     if (!count[k]) continue;
-    hipStream_t st = ctx->side_stream[k];
+    hipStream_t st = side_stream_of(ctx, k);
     if (ctx->fork_pending[k]) { GHIP(ctx, hipStreamWaitEvent(st, ctx->ev_fork, 0)); ctx->fork_pending[k] = false; }
     if (b->reduce_recorded[slot]) GHIP(ctx, hipStreamWaitEvent(st, b->ev_reduce_done[slot], 0));
     if (uniform) {

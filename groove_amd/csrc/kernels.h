@@ -441,23 +441,24 @@ __global__ __launch_bounds__(kThreads, (WavesBudget<LFO_MODE, RETUNE>::value)) v
     welsh_dispatch_class<FUSED, LFO_MODE, RETUNE>((uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[blockIdx.x]), ka);
   }
 }
-// All base kinds in ONE launch (fused form), for banks too small to fill the machine: there a block is
+// All base kinds in ONE launch, for banks too small to fill the machine: there a block is
 // bound by one wavefront's serial walk of its frames, register budgets do not matter (the kernel takes
 // the largest), and what counts is that every workgroup starts at once instead of queueing behind
 // the few hardware queues that several per-kind launches share.  wg_base[] = base kind per workgroup.
-#ifdef GROOVE_WELSH_ANY_TU // defined (once) by the translation unit that owns this kernel
+#ifdef GROOVE_WELSH_ANY_TU // defined by the two translation units that own this kernel (fused form, block-writing form)
+template <bool FUSED>
 __global__ __launch_bounds__(kThreads, GROOVE_WAVES_ANY) void welsh_render_uniform_any_kernel(UniformArgs a, const uint8_t* __restrict__ wg_base) {
   const UniformArgsPtr ka = (UniformArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-  if (welsh_idle_workgroup(a)) return;
+  if constexpr (FUSED) { if (welsh_idle_workgroup(a)) return; }
   const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wg_base[blockIdx.x]);
   const uint32_t cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[blockIdx.x]);
   switch (base) {
-    case wg_base_kind_of(LFO_F32, false): welsh_dispatch_class<true, LFO_F32, false>(cls, ka); break;
-    case wg_base_kind_of(LFO_F32, true): welsh_dispatch_class<true, LFO_F32, true>(cls, ka); break;
-    case wg_base_kind_of(LFO_F64_SMOOTH, false): welsh_dispatch_class<true, LFO_F64_SMOOTH, false>(cls, ka); break;
-    case wg_base_kind_of(LFO_F64_SMOOTH, true): welsh_dispatch_class<true, LFO_F64_SMOOTH, true>(cls, ka); break;
-    case wg_base_kind_of(LFO_F64, false): welsh_uniform_body<true, LFO_F64, false, OSC_ANY, OSC_ANY, OSC_ANY>(ka); break;
-    default: welsh_uniform_body<true, LFO_F64, true, OSC_ANY, OSC_ANY, OSC_ANY>(ka); break;
+    case wg_base_kind_of(LFO_F32, false): welsh_dispatch_class<FUSED, LFO_F32, false>(cls, ka); break;
+    case wg_base_kind_of(LFO_F32, true): welsh_dispatch_class<FUSED, LFO_F32, true>(cls, ka); break;
+    case wg_base_kind_of(LFO_F64_SMOOTH, false): welsh_dispatch_class<FUSED, LFO_F64_SMOOTH, false>(cls, ka); break;
+    case wg_base_kind_of(LFO_F64_SMOOTH, true): welsh_dispatch_class<FUSED, LFO_F64_SMOOTH, true>(cls, ka); break;
+    case wg_base_kind_of(LFO_F64, false): welsh_uniform_body<FUSED, LFO_F64, false, OSC_ANY, OSC_ANY, OSC_ANY>(ka); break;
+    default: welsh_uniform_body<FUSED, LFO_F64, true, OSC_ANY, OSC_ANY, OSC_ANY>(ka); break;
   }
 }
 #endif // GROOVE_WELSH_ANY_TU
@@ -468,7 +469,8 @@ void launch_welsh_uniform_specialised_0(const UniformArgs& a, hipStream_t st, bo
 void launch_welsh_uniform_specialised_1(const UniformArgs& a, hipStream_t st, bool fused);
 void launch_welsh_uniform_specialised_2(const UniformArgs& a, hipStream_t st, bool fused);
 void launch_welsh_uniform_specialised_3(const UniformArgs& a, hipStream_t st, bool fused);
-void launch_welsh_uniform_any(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st); // csrc/welsh_class.hip, -DGROOVE_BASE_KIND=9
+void launch_welsh_uniform_any(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st);         // fused: csrc/welsh_class.hip, -DGROOVE_BASE_KIND=9
+void launch_welsh_uniform_any_unfused(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st); // writes the voice block: -DGROOVE_BASE_KIND=8
 
 template <bool FUSED>
 __global__ __launch_bounds__(kThreads) void fm_render_kernel(

@@ -1,14 +1,14 @@
 // welsh_class.hip — the fused, class-specialised uniform Welsh kernel of ONE base kind (compiled
 // with -DGROOVE_BASE_KIND=0..3, so the block bodies build in parallel), or (-DGROOVE_BASE_KIND=9)
-// the all-kinds kernel of small banks.  See
+// the all-kinds kernel of small banks (=8: its block-writing form).  See
 // kernels.h, "Workgroup KINDS".
 #define GROOVE_WELSH_CLASS_TU 1
-#if defined(GROOVE_BASE_KIND) && GROOVE_BASE_KIND == 9
+#if defined(GROOVE_BASE_KIND) && (GROOVE_BASE_KIND == 9 || GROOVE_BASE_KIND == 8)
 #define GROOVE_WELSH_ANY_TU 1
 #endif
 #include "kernels.h"
 #ifndef GROOVE_BASE_KIND
-#error "compile with -DGROOVE_BASE_KIND=<0..3>"
+#error "compile with -DGROOVE_BASE_KIND=<0..3, 8, 9>"
 #endif
 namespace groove {
 #if GROOVE_BASE_KIND == 0
@@ -33,7 +33,11 @@ void launch_welsh_uniform_specialised_3(const UniformArgs& a, hipStream_t st, bo
 }
 #elif GROOVE_BASE_KIND == 9
 void launch_welsh_uniform_any(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st) {
-  hipLaunchKernelGGL(welsh_render_uniform_any_kernel, dim3(a.n_wgs), dim3(kThreads), 0, st, a, wg_base);
+  hipLaunchKernelGGL(welsh_render_uniform_any_kernel<true>, dim3(a.n_wgs), dim3(kThreads), 0, st, a, wg_base);
+}
+#elif GROOVE_BASE_KIND == 8
+void launch_welsh_uniform_any_unfused(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st) {
+  hipLaunchKernelGGL(welsh_render_uniform_any_kernel<false>, dim3(a.n_wgs), dim3(kThreads), 0, st, a, wg_base);
 }
 #else
 #error "GROOVE_BASE_KIND out of range"
