@@ -324,8 +324,9 @@ __global__ __launch_bounds__(kThreads) void welsh_render_kernel(
 //     a base kind need about the same registers, so the kernel's budget fits them all.  (One kernel
 //     per class pair was tried too: 32 small launches per block do not run concurrently - the
 //     hardware queues are few - and the block took 1.5x as long.)
-// A workgroup takes the most demanding base kind among its four waves, and OSC_ANY where they
-// disagree on a class.
+// The host builds every workgroup from waves that need the SAME kind (welsh_upload_params: the wave
+// descriptors are ordered by kind, a kind's last workgroup is filled up with empty waves), so no
+// wave runs in a more demanding instantiation than its patch asks for.
 struct WaveDesc {
   WelshParams p;
   uint32_t vbase, count;
