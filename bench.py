@@ -319,6 +319,10 @@ def main():
         elapsed = float(t.item())
 
     kern_ms = float(np.mean([ctx.elapsed_ms(a, b) for a, b in pairs]))
+    # Where the event pair brackets the whole (pipelined) step, consecutive pairs tile the timed region and
+    # the average step is the events' span over it divided by the steps (robust against where in the
+    # gap between two steps the runtime stamps an event).
+    span_ms = ctx.elapsed_ms(pairs[0][0], pairs[-1][1]) / K
     if rank == 0:
         out_bus = bus.download()[W * FRAMES:]
         finite = bool(np.isfinite(out_bus).all())
@@ -328,6 +332,8 @@ def main():
         value = project_fps * (world if weak else 1)            # weak: every rank rendered frames_total bus frames of its shard
         n_local = hi - lo
         whole_step = wl["kind"] == "chain" and not args.no_render_ahead  # the events bracket the step, not one kernel
+        if whole_step or (fused and wl["kind"] == "welsh"):
+            kern_ms = span_ms
         dom_bytes = (wl["bytes_per_vf"] if ((fused and wl["kind"] in ("welsh", "sampler")) or whole_step) else wl["dominant_bytes"])
         achieved = dom_bytes * n_local * FRAMES / (kern_ms * 1e-3) / 1e9
         line = {
