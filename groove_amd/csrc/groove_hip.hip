@@ -834,7 +834,9 @@ int groove_sampler_create(groove_ctx* ctx, const float* bank_pcm, uint64_t bank_
   if (n == 0 || n_samples == 0 || bank_frames == 0) return fail(ctx, "groove_sampler_create: empty bank");
   if (bank_frames >= (1ull << 32)) return fail(ctx, "groove_sampler_create: bank too large");
   for (uint32_t i = 0; i < n_samples; ++i) {
-    if (descs[i].offset + descs[i].length > bank_frames) return fail(ctx, "groove_sampler_create: sample descriptor exceeds bank");
+    if (descs[i].offset > bank_frames || descs[i].length > bank_frames - descs[i].offset)
+      return fail(ctx, "groove_sampler_create: sample descriptor exceeds bank");
+    if (descs[i].length == 0) return fail(ctx, "groove_sampler_create: empty sample"); // the fetch clamps to length - 1
     if (descs[i].length >= (1u << 20)) return fail(ctx, "groove_sampler_create: sample longer than 2^20 frames");
   }
   for (uint32_t i = 0; i < n; ++i)

@@ -106,9 +106,13 @@ int FxEffect::control_index_for_name(const std::string& name) const {
 void Sequencer::insert(uint8_t channel, uint8_t key, double start_beat, double duration_beats) {
   const uint64_t a = MusicalTime::from_beats(start_beat).units;
   const uint64_t b = MusicalTime::from_beats(start_beat + duration_beats).units;
-  events_.push_back({a, channel, key, true});
-  events_.push_back({b, channel, key, false});
-  std::stable_sort(events_.begin(), events_.end(), [](const Ev& x, const Ev& y) { return x.at < y.at; });
+  // kept ordered by time, equal times in insertion order (what a stable sort after every insert gave,
+  // without sorting a large project's whole list once per note)
+  auto put = [&](const Ev& e) {
+    events_.insert(std::upper_bound(events_.begin(), events_.end(), e, [](const Ev& x, const Ev& y) { return x.at < y.at; }), e);
+  };
+  put({a, channel, key, true});
+  put({b, channel, key, false});
   if (!explicit_end_) end_ = std::max(end_, b);
 }
 void Sequencer::work(uint64_t start_units, uint64_t end_units, std::vector<MidiEvent>& out, Orchestrator&) {

@@ -51,6 +51,15 @@ struct Value {
   }
 };
 
+// double -> integer for numbers that come from a file: NaN gives `dflt`, everything else is clamped
+// (a double outside the integer's range is undefined behaviour to cast).
+inline long long to_int(double x, long long lo, long long hi, long long dflt = 0) {
+  if (!(x == x)) return dflt;
+  if (x <= (double)lo) return lo;
+  if (x >= (double)hi) return hi;
+  return (long long)x;
+}
+
 class Parser {
  public:
   explicit Parser(const std::string& text) : s_(text) {}
@@ -112,9 +121,16 @@ class Parser {
     ++i_;
     return out;
   }
+  struct DepthGuard {
+    size_t& d;
+    explicit DepthGuard(size_t& depth) : d(depth) { ++d; }
+    ~DepthGuard() { --d; }
+  };
   ValuePtr value() {
     ws();
     if (i_ >= s_.size()) fail("unexpected end of input");
+    DepthGuard guard(depth_);
+    if (depth_ > kMaxDepth) fail("nesting deeper than 256 levels"); // value() recurses: bound the stack for hostile input
     auto v = std::make_shared<Value>();
     const char c = s_[i_];
     if (c == '{') {
@@ -177,6 +193,8 @@ class Parser {
   }
   const std::string& s_;
   size_t i_ = 0;
+  size_t depth_ = 0;
+  static constexpr size_t kMaxDepth = 256;
 };
 
 inline ValuePtr parse(const std::string& text) { return Parser(text).parse(); }

@@ -61,8 +61,8 @@ int parse_tune(const json5::Value* v, double& ratio) {
   const std::string& k = v->obj[0].first;
   const json5::Value& x = *v->obj[0].second;
   if (k == "float") ratio = x.num;
-  else if (k == "note") return (int)x.num;
-  else if (k == "osc") ratio = semis_and_cents((int)x.number_or("octave", 0) * 12 + (int)x.number_or("semi", 0), x.number_or("cent", 0));
+  else if (k == "note") return (int)json5::to_int(x.num, -1, 127, -1);
+  else if (k == "osc") ratio = semis_and_cents((int)json5::to_int(x.number_or("octave", 0), -16, 16) * 12 + (int)json5::to_int(x.number_or("semi", 0), -1200, 1200), x.number_or("cent", 0));
   return -1;
 }
 groove_envelope_params parse_envelope(const json5::Value* v) {
@@ -165,9 +165,9 @@ void parse_effect(const std::string& kind, const json5::Value& v, ProjectDesc::D
   else if (kind == "mixer") d.fx_kind = GROOVE_FX_MIXER;
   else if (kind == "limiter") { d.fx_kind = GROOVE_FX_LIMITER; f.limit_min = (float)v.number_or("min", 0.0); f.limit_max = (float)v.number_or("max", 1.0); }
   else if (kind == "compressor") { d.fx_kind = GROOVE_FX_COMPRESSOR; f.limit_min = (float)v.number_or("threshold", 1.0); f.limit_max = (float)v.number_or("ratio", 1.0); }
-  else if (kind == "bitcrusher") { d.fx_kind = GROOVE_FX_BITCRUSHER; f.bits = (uint32_t)v.number_or("bits", v.number_or("bits-to-crush", 8)); }
+  else if (kind == "bitcrusher") { d.fx_kind = GROOVE_FX_BITCRUSHER; f.bits = (uint32_t)json5::to_int(v.number_or("bits", v.number_or("bits-to-crush", 8)), 0, 16, 8); }
   else if (kind == "chorus") {
-    d.fx_kind = GROOVE_FX_CHORUS; f.voices = (uint32_t)v.number_or("voices", 4);
+    d.fx_kind = GROOVE_FX_CHORUS; f.voices = (uint32_t)json5::to_int(v.number_or("voices", 4), 1, 64, 4);
     f.delay_seconds = (float)v.number_or("delay-seconds", v.number_or("delay-factor", 0.25));
   }
   else if (kind == "delay") { d.fx_kind = GROOVE_FX_DELAY; f.delay_seconds = (float)v.number_or("seconds", v.number_or("delay", 0.1)); }
@@ -197,8 +197,8 @@ ProjectDesc parse_project(const std::string& text, const std::string& assets_roo
   if (const json5::Value* clock = root->get("clock")) {
     p.bpm = clock->number_or("bpm", 128.0);
     if (const json5::Value* ts = clock->get("time-signature")) {
-      if (ts->is_array() && ts->arr.size() == 2) { p.ts_top = (int)ts->arr[0]->num; p.ts_bottom = (int)ts->arr[1]->num; }
-      else if (ts->is_object()) { p.ts_top = (int)ts->number_or("top", 4); p.ts_bottom = (int)ts->number_or("bottom", 4); }
+      if (ts->is_array() && ts->arr.size() == 2) { p.ts_top = (int)json5::to_int(ts->arr[0]->num, 1, 64, 4); p.ts_bottom = (int)json5::to_int(ts->arr[1]->num, 1, 64, 4); }
+      else if (ts->is_object()) { p.ts_top = (int)json5::to_int(ts->number_or("top", 4), 1, 64, 4); p.ts_bottom = (int)json5::to_int(ts->number_or("bottom", 4), 1, 64, 4); }
     }
   }
   // devices: [{"instrument": [id, {kind: [midi, params]}]}, {"effect": [id, {kind: params}]}, {"controller": …}]
@@ -217,7 +217,7 @@ ProjectDesc parse_project(const std::string& text, const std::string& assets_roo
       const json5::Value& body = *pair.arr[1]->obj[0].second;
       if (cls == "instrument") {
         if (!body.is_array() || body.arr.size() != 2) { p.warnings.push_back("malformed instrument " + d.id); continue; }
-        d.midi_in = (int)body.arr[0]->number_or("midi-in", 0);
+        d.midi_in = (int)json5::to_int(body.arr[0]->number_or("midi-in", 0), 0, 255, 0);
         const json5::Value& params = *body.arr[1];
         if (d.kind == "welsh") {
           d.name = params.string_or("name", "");
@@ -267,7 +267,7 @@ ProjectDesc parse_project(const std::string& text, const std::string& assets_roo
       if (const json5::Value* notes = pv->get("notes"))
         for (auto& row : notes->arr) {
           std::vector<int> r;
-          for (auto& n : row->arr) r.push_back((int)n->num);
+          for (auto& n : row->arr) r.push_back((int)json5::to_int(n->num, 0, 127, 0)); // 0 = rest
           pat.rows.push_back(r);
         }
       const std::string id = pv->string_or("id", "");
@@ -277,7 +277,7 @@ ProjectDesc parse_project(const std::string& text, const std::string& assets_roo
   const double beats_per_measure = p.ts_top * 4.0 / p.ts_bottom;
   if (const json5::Value* tracks = root->get("tracks"))
     for (auto& tv : tracks->arr) {
-      const int channel = (int)tv->number_or("midi-channel", 0);
+      const int channel = (int)json5::to_int(tv->number_or("midi-channel", 0), 0, 255, 0);
       double cursor = 0.0;
       if (const json5::Value* ids = tv->get("patterns"))
         for (auto& idv : ids->arr) {
@@ -379,11 +379,15 @@ bool read_wav_mono(const std::string& path, std::vector<float>& out, uint32_t* s
     const std::string id = data.substr(pos, 4);
     const size_t len = rd32(pos + 4);
     if (id == "fmt " && pos + 8 + 16 <= data.size()) { fmt = rd16(pos + 8); channels = rd16(pos + 10); rate = rd32(pos + 12); bits = rd16(pos + 22);
-      if (fmt == 0xFFFE && len >= 26) fmt = rd16(pos + 8 + 24); }
+      if (fmt == 0xFFFE && len >= 26 && pos + 8 + 26 <= data.size()) fmt = rd16(pos + 8 + 24); }
     else if (id == "data") { dpos = pos + 8; dlen = std::min(len, data.size() - dpos); }
     pos += 8 + len + (len & 1);
   }
   if (!dpos || !channels || !bits) { if (err) *err = "WAV without fmt/data chunk: " + path; return false; }
+  if ((bits != 8 && bits != 16 && bits != 24 && bits != 32) || channels > 64) {
+    if (err) *err = "unsupported WAV format (" + std::to_string(bits) + " bits, " + std::to_string(channels) + " channels): " + path;
+    return false;
+  }
   const size_t bytes = bits / 8, frames = dlen / (bytes * channels);
   out.resize(frames);
   for (size_t f = 0; f < frames; ++f) {
@@ -496,6 +500,19 @@ int instantiate(Orchestrator& o, const ProjectDesc& p, const std::string& assets
 // ---- C surface ------------------------------------------------------------------------------
 using namespace groove_host;
 extern "C" {
+// read_wav_mono for the tests: frames written (<= cap) or -1 with a message.
+int64_t gh_read_wav_mono(const char* path, float* out, uint64_t cap, uint32_t* sample_rate, char* err, size_t err_cap) {
+  std::vector<float> v;
+  std::string e;
+  if (!groove_host::read_wav_mono(path, v, sample_rate, &e)) {
+    if (err && err_cap) { std::snprintf(err, err_cap, "%s", e.c_str()); }
+    return -1;
+  }
+  const uint64_t n = std::min<uint64_t>(cap, v.size());
+  if (n && out) std::memcpy(out, v.data(), n * sizeof(float));
+  return (int64_t)v.size();
+}
+
 // Parse only (no GPU): returns a malloc'ed JSON summary, or NULL and the message in err[0..err_len).
 char* gh_project_describe(const char* path, const char* assets_root, char* err, size_t err_len) {
   try {

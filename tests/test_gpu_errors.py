@@ -90,3 +90,35 @@ def test_sample_rate_change_rebuilds_effects(oracle):
     want = oracle.Fx(T.FX_BIQUAD_LP12, (T.FxParams * 4)(*[T.fx_params(cutoff_hz=2000.0, q=0.9)] * 4), sr=48000).process(x.astype(np.float64))
     assert np.max(np.abs(np.concatenate(lps, axis=1) - want)) <= 2e-6
     ctx.close()
+
+
+def test_sampler_descriptors_that_would_index_outside_the_bank(gpu_ctx):
+    """An empty sample (the fetch clamps to length - 1) and an offset whose sum with the length wraps
+    around 2^64 are refused at creation; the asynchronous render checks its arguments like the plain one."""
+    from groove_amd import entities as E
+    L, h = gpu_ctx.L, gpu_ctx.h
+    pcm = np.linspace(-1, 1, 1000, dtype=np.float32)
+    sp = (T.SamplerParams * 2)()
+    out = C.c_void_p()
+
+    def create(offset, length, frames=1000):
+        d = (T.SampleDesc * 1)()
+        d[0].offset, d[0].length, d[0].root_hz = offset, length, 0.0
+        return L.groove_sampler_create(h, pcm.ctypes.data_as(C.POINTER(C.c_float)), frames, d, 1, sp, 2, C.byref(out))
+
+    assert create(0, 0) != 0 and b"empty sample" in L.groove_last_error(h)
+    assert create(2 ** 64 - 50, 100) != 0 and b"exceeds" in L.groove_last_error(h)
+    assert create(1001, 0) != 0
+    assert create(0, 100, frames=0) != 0
+    assert create(0, 1000) == 0
+    L.groove_bank_destroy(out)
+    s = E.WelshSynth(gpu_ctx, P.welsh_voices(8))
+    small, big = gpu_ctx.block(4, 256), gpu_ctx.block(8, 64)
+    assert L.groove_bank_render_async(s.h, 16, small.h) != 0 and b"lanes" in L.groove_last_error(h)
+    assert L.groove_bank_render_async(s.h, 65, big.h) != 0 and b"capacity" in L.groove_last_error(h)
+    assert L.groove_bank_render_async(None, 16, big.h) != 0
+    assert L.groove_block_acquire(None) != 0
+    s.generate_batch_values_async(big, 64)
+    assert np.isfinite(big.download(64)).all()
+    for x in (s, small, big):
+        x.destroy()

@@ -194,3 +194,71 @@ def test_bus_station_routing_table(host):
     assert L.gh_bus_station_sends_for(bs, 7) == 0, "removing a track's sends leaves an empty list for it"
     assert L.gh_bus_station_sends_for(bs, 99) == -1
     L.gh_bus_station_free(bs)
+
+
+def test_hostile_project_text_is_rejected_not_crashed(host):
+    """The loaders read user files: nesting is bounded (the parser recurses), numbers far outside
+    an integer field's range are clamped, truncated text gives an error string.  (The same inputs,
+    plus a few thousand random mutations, were run under ASan + UBSan with float-cast-overflow.)"""
+    with pytest.raises(RuntimeError, match="nesting"):
+        describe(host, text="[" * 100000)
+    with pytest.raises(RuntimeError, match="nesting"):
+        describe(host, text='{"a":' * 5000 + "1" + "}" * 5000)
+    base = open(os.path.join(REPO, "tests", "data", "drums-filtered-synthetic.json5")).read()
+    for cut in (1, len(base) // 3, len(base) - 2):
+        with pytest.raises(RuntimeError):
+            describe(host, text=base[:cut])
+    d = describe(host, text='{"clock": {"bpm": 1e308, "time-signature": [1e99, -1e99]}, "devices": [], '
+                            '"patterns": [{"id": "p", "notes": [[1e300, -1e300, NaN, 60]]}], '
+                            '"tracks": [{"midi-channel": 1e100, "patterns": ["p"]}]}')
+    assert d["time_signature"] == [64, 1]
+    wp = T.WelshParams()
+    err = C.create_string_buffer(256)
+    rc = host.gh_welsh_params_from_patch_json(
+        b'{"name": "x", "oscillator-1": {"waveform": "sine", "tune": {"osc": {"octave": 1e300, "semi": -1e300, "cent": 0}}}}',
+        C.byref(wp), err, 256)
+    assert rc in (0, 1)  # accepted with clamped tuning or rejected with a message: either way no crash
+
+
+def _wav(bits=16, channels=2, fmt=1, frames=10, rate=44100, data_len=None, truncate=None):
+    import struct
+    bps = max(bits // 8, 0)
+    payload = bytes((i * 37) & 0xFF for i in range(frames * channels * max(bps, 1)))
+    hdr = struct.pack("<HHIIHH", fmt, channels, rate, rate * channels * bps, channels * bps, bits)
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(hdr)) + hdr + b"data" + struct.pack("<I", len(payload) if data_len is None else data_len) + payload
+    blob = b"RIFF" + struct.pack("<I", len(body)) + body
+    return blob if truncate is None else blob[:truncate]
+
+
+def test_wav_reader_formats_and_malformed_files(host, tmp_path):
+    """Sample files are user data too: 8/16/24/32-bit PCM and float decode, anything else is refused
+    with a message (a 4-bit header used to divide by zero), lying chunk lengths are clamped."""
+    import numpy as np
+    host.gh_read_wav_mono.restype = C.c_int64
+    host.gh_read_wav_mono.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_uint64, C.POINTER(C.c_uint32), C.c_char_p, C.c_size_t]
+
+    def read(blob):
+        path = tmp_path / "x.wav"
+        path.write_bytes(blob)
+        out = np.zeros(64, dtype=np.float32)
+        sr = C.c_uint32(0)
+        err = C.create_string_buffer(256)
+        n = host.gh_read_wav_mono(str(path).encode(), out.ctypes.data_as(C.POINTER(C.c_float)), 64, C.byref(sr), err, 256)
+        return n, out, sr.value, err.value.decode()
+
+    for bits in (8, 16, 24, 32):
+        n, out, sr, _ = read(_wav(bits=bits))
+        assert n == 10 and sr == 44100 and np.isfinite(out).all() and np.abs(out).max() <= 1.0
+    n, out, _, _ = read(_wav(bits=16, channels=1, frames=4))
+    want = np.frombuffer(bytes((i * 37) & 0xFF for i in range(8)), dtype="<i2") / 32768.0
+    assert n == 4 and np.allclose(out[:4], want)
+    for bits in (0, 4, 12, 64):
+        n, _, _, err = read(_wav(bits=bits))
+        assert n == -1 and err
+    assert read(_wav(channels=0))[0] == -1
+    assert read(_wav(channels=1000))[0] == -1
+    assert read(_wav(data_len=0xFFFFFFF0))[0] == 10          # the data chunk claims 4 GiB: clamped to the file
+    for cut in (0, 11, 20, 30, 44, 50):
+        n = read(_wav(truncate=cut))[0]
+        assert n == -1 or 0 <= n <= 10
+    assert read(b"RIFF\x00\x00\x00\x00WAVEjunk")[0] == -1
