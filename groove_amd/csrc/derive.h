@@ -226,7 +226,8 @@ inline void lp24_coeffs_h(double fc, double ripple, double fs, double* out6) {
 }
 inline uint32_t delay_frames_h(double seconds, double sr) {
   const double n = floor(seconds * sr + 0.5);
-  return n < 1.0 ? 1u : (uint32_t)n;
+  if (!(n >= 1.0)) return 1u;                    // zero, negative, NaN
+  return n > 1073741824.0 ? 1073741824u : (uint32_t)n; // the ring allocation fails long before this
 }
 inline double decay_gain_h(double delay_s, double decay_s) {
   return decay_s > 0.0 ? pow(0.001, delay_s / decay_s) : 0.0;

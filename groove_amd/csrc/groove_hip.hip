@@ -573,6 +573,7 @@ int fx_setup_state(groove_fx* fx) { // (re)allocate and zero state for the curre
       break;
     case GROOVE_FX_CHORUS:
       fx->N = delay_frames_h(p0.delay_seconds, sr);
+      if (p0.voices > 64) return fail(ctx, "groove_fx: chorus voices > 64"); // the taps are a per-frame loop on the device
       fx->voices = p0.voices < 1 ? 1 : p0.voices;
       fx->spacing = fx->N / fx->voices;
       fx->ring_rows = fx->N;
@@ -592,6 +593,7 @@ int fx_setup_state(groove_fx* fx) { // (re)allocate and zero state for the curre
     }
     default: break;
   }
+  if (fx->ring_rows > (1ull << 26)) return fail(ctx, "groove_fx: delay line longer than 2^26 frames");
   if (fx->ring_rows) {
     GHIP(ctx, hipMalloc(&fx->d_ring, fx->ring_rows * ln * 4));
     GHIP(ctx, hipMemset(fx->d_ring, 0, fx->ring_rows * ln * 4));

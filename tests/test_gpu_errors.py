@@ -122,3 +122,28 @@ def test_sampler_descriptors_that_would_index_outside_the_bank(gpu_ctx):
     assert np.isfinite(big.download(64)).all()
     for x in (s, small, big):
         x.destroy()
+
+
+def test_delay_line_geometry_from_hostile_parameters(gpu_ctx):
+    """NaN / negative / absurd delay times and tap counts: a one-frame line, a refused effect, or an
+    allocation error — never a zero-length ring (the kernels take indices modulo the length) or an
+    unbounded tap loop on the device."""
+    from groove_amd import entities as E
+    L, h = gpu_ctx.L, gpu_ctx.h
+    out = C.c_void_p()
+    with pytest.raises(lib.GrooveError):  # NaN is not equal to itself: refused by the uniformity check
+        E.Effect(gpu_ctx, T.FX_DELAY, (T.FxParams * 2)(*[T.fx_params(delay_seconds=float("nan"))] * 2))
+    nan1 = E.Effect(gpu_ctx, T.FX_DELAY, (T.FxParams * 1)(T.fx_params(delay_seconds=float("nan"))))  # one lane: a one-frame line
+    nan1.destroy()
+    for secs in (-1.0, 0.0):
+        fx = E.Effect(gpu_ctx, T.FX_DELAY, (T.FxParams * 2)(*[T.fx_params(delay_seconds=secs)] * 2))
+        blk = gpu_ctx.block(2, 64)
+        x = np.random.default_rng(0).standard_normal((2, 64, 2)).astype(np.float32)
+        blk.upload(x)
+        fx.transform_audio(blk, 64)
+        y = blk.download(64)
+        assert np.array_equal(y[:, 1:, :], x[:, :-1, :])   # one frame of delay
+        fx.destroy(); blk.destroy()
+    assert L.groove_fx_create(h, T.FX_DELAY, (T.FxParams * 2)(*[T.fx_params(delay_seconds=1e30)] * 2), 2, C.byref(out)) != 0
+    assert L.groove_fx_create(h, T.FX_CHORUS, (T.FxParams * 2)(*[T.fx_params(voices=4_000_000_000, delay_seconds=0.01)] * 2), 2, C.byref(out)) != 0
+    assert b"voices" in L.groove_last_error(h)
