@@ -336,6 +336,7 @@ def main():
             kern_ms = span_ms
         dom_bytes = (wl["bytes_per_vf"] if ((fused and wl["kind"] in ("welsh", "sampler")) or whole_step) else wl["dominant_bytes"])
         achieved = dom_bytes * n_local * FRAMES / (kern_ms * 1e-3) / 1e9
+        traffic = committed_traffic(args.workload, world)
         line = {
             "metric": "stereo frames/sec rendered (offline)", "value": value, "unit": "stereo frames/s",
             "x_realtime_44k1": project_fps / SR, "n_gpus": world, "steps": K, "warmup": W,
@@ -355,8 +356,10 @@ def main():
                                     else "whole step: render of block b+1 (side streams) beside the effect chain + mix of block b" if whole_step
                                     else "render kernel of the first bank"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_voice_frame": dom_bytes, "kernel_ms": kern_ms,
-                         "traffic": committed_traffic(args.workload, world)},
+                         "algorithmic_bytes_per_voice_frame": dom_bytes, "algorithmic_bytes_per_step": dom_bytes * n_local * FRAMES,
+                         "kernel_ms": kern_ms,
+                         "traffic": (traffic or {}).get("bytes_per_step"), "traffic_unit": "bytes per step (PMC, committed pass)",
+                         "traffic_source": (traffic or {}).get("source")},
             "output_check": {"finite": finite, "peak_abs_bus_over_V": peak},
         }
         if not args.no_cpu_baseline and world == 1:
