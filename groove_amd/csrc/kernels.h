@@ -263,7 +263,7 @@ __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n
 // a5 WelshVoice: Ticks::tick(frames) + Generates::generate_batch_values.
 // Frame 0 is peeled (first-tick flag); RETUNE=false variants keep the filter coefficients
 // loop-invariant so their f64 widening is hoisted out of the frame loop.
-template <bool FUSED, bool RETUNE, int LFO_MODE = LFO_F64, bool UNIFORM = false, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY>
+template <bool FUSED, bool RETUNE, int LFO_MODE = LFO_F64, bool UNIFORM = false, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool REST = false>
 __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s, const RenderConsts& rc,
                                             uint32_t frames, uint32_t n, uint32_t v, bool active,
                                             size_t ch_stride, float* __restrict__ out, uint32_t prow) {
@@ -274,9 +274,9 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
   if constexpr (UNIFORM) {
     run_frames_segmented<FUSED>(
         frames, n, v, active, ch_stride, out, prow,
-        [&](float& L, float& R) { welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL>(p, s, rc, sc, L, R); },
+        [&](float& L, float& R) { welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL, false, REST>(p, s, rc, sc, L, R); },
         [&](bool& live) { return welsh_segment_begin(p, s, live); },
-        [&](float& L, float& R) { welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true>(p, s, rc, sc, L, R); },
+        [&](float& L, float& R) { welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST>(p, s, rc, sc, L, R); },
         [&]() { welsh_segment_idle_frame(s); });
   } else {
     run_frames<FUSED>(frames, n, v, active, ch_stride, out, prow, [&](uint32_t f, float& L, float& R) {
@@ -361,7 +361,7 @@ __device__ __forceinline__ UniformArgsPtr uniform_args_scalar(UniformArgsPtr a) 
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bits >> 32));
   return (UniformArgsPtr)(((uint64_t)hi << 32) | lo);
 }
-template <bool FUSED, int LFO_MODE, bool RETUNE, int C1, int C2, int CL>
+template <bool FUSED, int LFO_MODE, bool RETUNE, int C1, int C2, int CL, bool REST = false>
 __device__ __forceinline__ void welsh_uniform_body_impl(UniformArgsPtr a) {
   const uint32_t wg = a->wg_list[blockIdx.x]; // scalar load: the workgroup of virtual waves this block renders
   const uint32_t n_waves = a->n_waves, n = a->n;
@@ -373,12 +373,13 @@ __device__ __forceinline__ void welsh_uniform_body_impl(UniformArgsPtr a) {
   const uint32_t v = active ? d.vbase + lane : d.vbase; // idle lanes shadow the run's first voice
   WelshState s = soa_load<WelshState>(a->state, n, v);
   const RenderConsts rc{a->rc.pi_over_sr, a->rc.fc_max};
-  welsh_block<FUSED, RETUNE, LFO_MODE, true, C1, C2, CL>(d.p, s, rc, a->frames, n, v, active, a->ch_stride, a->out, wg);
+  welsh_block<FUSED, RETUNE, LFO_MODE, true, C1, C2, CL, REST>(d.p, s, rc, a->frames, n, v, active, a->ch_stride, a->out, wg);
   if (active) soa_store(a->state, n, v, s);
 }
 template <bool FUSED, int LFO_MODE, bool RETUNE, int C1, int C2, int CL>
 __device__ __attribute__((noinline)) void welsh_uniform_body(UniformArgsPtr a) {
-  welsh_uniform_body_impl<FUSED, LFO_MODE, RETUNE, C1, C2, CL>(uniform_args_scalar(a));
+  // the class bodies of the class-specialised kinds only ever see waves of their own classes (dsp_core.h, REST)
+  welsh_uniform_body_impl<FUSED, LFO_MODE, RETUNE, C1, C2, CL, LFO_MODE != LFO_F64>(uniform_args_scalar(a));
 }
 // A workgroup whose voices are all silent with both envelopes idle (unused polyphony, voices past
 // their release) contributes zeros and changes nothing but idle-plateau counters: it writes its zero
