@@ -539,6 +539,9 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
   const uint32_t routing = CL == LFO_UNUSED ? (uint32_t)GROOVE_LFO_NONE
                          : (CL != OSC_ANY && LFO_MODE == LFO_F32 && !RETUNE) ? (uint32_t)GROOVE_LFO_AMPLITUDE
                          : (p.flags >> WF_ROUTING_SHIFT) & 15u;
+  // LFO_F64_SMOOTH is only ever chosen for an LFO routed to pitch or pulse width (welsh_lfo_mode): the
+  // other routings' tests below are compile-time false there (each is a scalar branch per frame otherwise)
+  constexpr bool EDGE_ONLY = LFO_MODE == LFO_F64_SMOOTH;
   const bool first = FIRST && (s.vflags & VF_FIRST);
   if (FIRST) s.vflags = 0;
 
@@ -550,7 +553,7 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
   uint64_t inc1 = s.o1_inc, inc2 = s.o2_inc;
   uint64_t d1 = p.o1_duty64, d2 = p.o2_duty64;
   float lfo = 0.0f;
-  if (LFO_MODE != LFO_F32 && (routing == GROOVE_LFO_PITCH || routing == GROOVE_LFO_PULSE_WIDTH)) {
+  if (EDGE_ONLY || (LFO_MODE != LFO_F32 && (routing == GROOVE_LFO_PITCH || routing == GROOVE_LFO_PULSE_WIDTH))) {
     constexpr bool SMOOTH = LFO_MODE == LFO_F64_SMOOTH;
     double l;
     if (SMOOTH && !FIRST && wl == GROOVE_WAVE_SINE) { // one rotation step (an idle voice never gets here: see above)
@@ -603,7 +606,7 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
     if (CL == LFO_UNUSED || (p.flags & WF_RETUNE_ENV)) {
       pct = fmaf((1.0f - p.cutoff_start) * p.cutoff_end, s.fil.value, p.cutoff_start);
       retune = true;
-    } else if (routing == GROOVE_LFO_FILTER_CUTOFF) {
+    } else if (!EDGE_ONLY && routing == GROOVE_LFO_FILTER_CUTOFF) {
       pct = p.cutoff_start * fmaf(lfo, p.lfo_depth, 1.0f);
       retune = true;
     }
@@ -615,7 +618,7 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
   }
   const float y = (float)lp24_step<SEGMENT && !RETUNE>(s.filt, sc.coef, (double)sum); // uniform static kinds: coefficients in SGPRs
   float a = s.amp.value;
-  if (routing == GROOVE_LFO_AMPLITUDE) a *= fmaf(lfo, p.lfo_depth, 1.0f);
+  if (!EDGE_ONLY && routing == GROOVE_LFO_AMPLITUDE) a *= fmaf(lfo, p.lfo_depth, 1.0f);
   const float m = y * a;
   L = m * p.gl;
   R = m * p.gr;
