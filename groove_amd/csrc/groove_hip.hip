@@ -103,6 +103,10 @@ struct groove_fx {
   ReverbGeom geo{};
 };
 
+// Events that only order the library's own streams on one device: no timing, and no system-scope fence
+// (cache writeback + invalidate) when they are recorded — the host reads results through
+// hipMemcpy / hipStreamSynchronize, which fence by themselves.
+constexpr unsigned kSyncEventFlags = hipEventDisableTiming | hipEventDisableSystemFence;
 constexpr int kBankStreams = 4;                         // shared round-robin by single-kernel banks (FM, sampler, per-lane Welsh)
 constexpr int kSideStreams = kBaseKinds + kBankStreams;
 static_assert(kBaseKinds == 6 && kBankStreams == 4, "groove_init lists the side streams in creation order"); // + one per Welsh base kind; the ctx stream carries events, reductions and the rest
@@ -659,7 +663,7 @@ int groove_init(int device_ordinal, groove_ctx** out) {
   int prio_least = 0, prio_greatest = 0;
   bool ok = hipSetDevice(device_ordinal) == hipSuccess && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess &&
             hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
-            hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
+            hipEventCreateWithFlags(&ctx->ev_fork, kSyncEventFlags) == hipSuccess;
   // Four normal-priority streams for the four class-specialised Welsh kinds (side by side in every block
   // of a big bank; the two exact-f64-LFO kinds, rare, share the first two), and four LOW-priority streams
   // for the single-kernel banks (side by side in a mixed project): never more streams of one priority
@@ -668,7 +672,7 @@ int groove_init(int device_ordinal, groove_ctx** out) {
     if (i == 4 || i == 5) ctx->side_stream[i] = ctx->side_stream[i - 4];
     else if (i < kBaseKinds) ok = hipStreamCreateWithFlags(&ctx->side_stream[i], hipStreamNonBlocking) == hipSuccess;
     else ok = hipStreamCreateWithPriority(&ctx->side_stream[i], hipStreamNonBlocking, prio_least) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ctx->ev_join[i], kSyncEventFlags) == hipSuccess;
   }
   if (!ok) {
     groove_shutdown(ctx);
@@ -1032,8 +1036,8 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
   const bool uniform = b->kind == BANK_WELSH && b->n_vwaves && !small_uniform; // one kernel per base kind
   if (bank_side_mode(b, uniform ? 1 : 2)) return 1;
   if (!out->ev_free) {
-    GHIP(ctx, hipEventCreateWithFlags(&out->ev_free, hipEventDisableTiming));
-    for (int k = 0; k < kSideStreams; ++k) GHIP(ctx, hipEventCreateWithFlags(&out->ev_ready[k], hipEventDisableTiming));
+    GHIP(ctx, hipEventCreateWithFlags(&out->ev_free, kSyncEventFlags));
+    for (int k = 0; k < kSideStreams; ++k) GHIP(ctx, hipEventCreateWithFlags(&out->ev_ready[k], kSyncEventFlags));
   }
   float* dst = out->d;
   size_t chs = (size_t)out->cap * out->n;
@@ -1046,7 +1050,7 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
       if (groove_block_create(ctx, b->n, std::max<uint32_t>(frames, GROOVE_BLOCK_FRAMES), &b->scratch)) return 1;
       b->gather_recorded = false;
     }
-    if (!b->ev_gather) GHIP(ctx, hipEventCreateWithFlags(&b->ev_gather, hipEventDisableTiming));
+    if (!b->ev_gather) GHIP(ctx, hipEventCreateWithFlags(&b->ev_gather, kSyncEventFlags));
     dst = b->scratch->d;
     chs = (size_t)b->scratch->cap * b->n;
   }
@@ -1148,8 +1152,8 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
     b->reduce_recorded[slot] = false;
   }
   if (!b->ev_reduce_done[slot]) {
-    GHIP(ctx, hipEventCreateWithFlags(&b->ev_reduce_done[slot], hipEventDisableTiming));
-    for (int k = 0; k < kSideStreams; ++k) GHIP(ctx, hipEventCreateWithFlags(&b->ev_render_done[k][slot], hipEventDisableTiming));
+    GHIP(ctx, hipEventCreateWithFlags(&b->ev_reduce_done[slot], kSyncEventFlags));
+    for (int k = 0; k < kSideStreams; ++k) GHIP(ctx, hipEventCreateWithFlags(&b->ev_render_done[k][slot], kSyncEventFlags));
   }
   uint32_t count[kSideStreams] = {}, offset[kSideStreams] = {}; // per stream: Welsh base kinds first, then the bank streams
   if (uniform) {
