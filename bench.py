@@ -114,16 +114,17 @@ class Project:
         submitted, two blocks per instrument alternating.  Every step still submits one render, one
         pass of every effect and one mix per instrument; the first call also renders block b itself."""
         ctx = self.ctx
-        if ev_pair is not None:
+        if ev_pair is not None and ev_pair[0] is not None:
             ctx.record(ev_pair[0])
-        if not self.ahead:
+        if not self.ahead:  # three blocks per instrument in rotation: [current, next, spare]
             self._timeline_events(self.block_index)
             for inst, block, fx in self.banks:
-                self.ahead[inst] = [block, ctx.block(inst.n, FRAMES)]
+                self.ahead[inst] = [block, ctx.block(inst.n, FRAMES), ctx.block(inst.n, FRAMES)]
                 inst.generate_batch_values_async(block, FRAMES)
         self._timeline_events(self.block_index + 1)
         self.block_index += 1
         for inst, _, fx in self.banks:
+            # the block this render fills was released a whole step ago: no cross-queue wait (groove_block_release)
             inst.generate_batch_values_async(self.ahead[inst][1], FRAMES)
         first = True
         for inst, _, fx in self.banks:
@@ -131,9 +132,10 @@ class Project:
             for e in fx:
                 e.transform_audio(cur, FRAMES)
             ctx.mix([cur], FRAMES, E._Slice(bus, frame0), accumulate=not first)
-            self.ahead[inst].reverse()
+            cur.release()
+            self.ahead[inst] = self.ahead[inst][1:] + [cur]
             first = False
-        if ev_pair is not None:
+        if ev_pair is not None and ev_pair[1] is not None:
             ctx.record(ev_pair[1])
 
     def step(self, bus, frame0, ev_pair=None):
@@ -146,16 +148,16 @@ class Project:
         first = True
         for inst, block, fx in self.banks:
             if self.fused and not fx:
-                if ev_pair is not None and inst is self.dominant:
+                if ev_pair is not None and ev_pair[0] is not None and inst is self.dominant:
                     ctx.record(ev_pair[0])
                 inst.render_mix(bus, FRAMES, accumulate=not first, at_frame=frame0)
-                if ev_pair is not None and inst is self.dominant:
-                    ctx.record(ev_pair[1])
+                if ev_pair is not None and ev_pair[1] is not None and inst is self.banks[-1][0]:
+                    ctx.record(ev_pair[1])  # fused steps are bracketed whole: after the last bank's bus sum
             else:
-                if ev_pair is not None and inst is self.dominant:
+                if ev_pair is not None and ev_pair[0] is not None and inst is self.dominant:
                     ctx.record(ev_pair[0])
                 inst.generate_batch_values(block, FRAMES)
-                if ev_pair is not None and inst is self.dominant:
+                if ev_pair is not None and ev_pair[1] is not None and inst is self.dominant:
                     ctx.record(ev_pair[1])
                 for e in fx:
                     e.transform_audio(block, FRAMES)
@@ -304,7 +306,15 @@ def main():
     for s in range(W):
         proj.step(bus, s * FRAMES)
     sync_all()
-    pairs = [(ctx.event(), ctx.event()) for _ in range(K)]
+    # Where the event pair brackets the whole (pipelined) step, consecutive pairs would tile the timed
+    # region: only its two ends are recorded (every record is a packet on the ctx stream, ~5 us of its
+    # timeline each) and the average step is their span divided by the steps.
+    span_mode = (fused and wl["kind"] != "chain") or (wl["kind"] == "chain" and not args.no_render_ahead)
+    if span_mode:
+        first_ev, last_ev = ctx.event(), ctx.event()
+        pairs = [(first_ev if s == 0 else None, last_ev if s == K - 1 else None) for s in range(K)]
+    else:
+        pairs = [(ctx.event(), ctx.event()) for _ in range(K)]
     t0 = time.perf_counter()
     for s in range(K):
         proj.step(bus, (W + s) * FRAMES, pairs[s])
@@ -318,11 +328,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kern_ms = float(np.mean([ctx.elapsed_ms(a, b) for a, b in pairs]))
-    # Where the event pair brackets the whole (pipelined) step, consecutive pairs tile the timed region and
-    # the average step is the events' span over it divided by the steps (robust against where in the
-    # gap between two steps the runtime stamps an event).
-    span_ms = ctx.elapsed_ms(pairs[0][0], pairs[-1][1]) / K
+    if span_mode:
+        kern_ms = ctx.elapsed_ms(pairs[0][0], pairs[-1][1]) / K
+    else:
+        kern_ms = float(np.mean([ctx.elapsed_ms(a, b) for a, b in pairs]))
     if rank == 0:
         out_bus = bus.download()[W * FRAMES:]
         finite = bool(np.isfinite(out_bus).all())
@@ -331,10 +340,8 @@ def main():
         project_fps = frames_total / elapsed                    # frames of the merged project per second
         value = project_fps * (world if weak else 1)            # weak: every rank rendered frames_total bus frames of its shard
         n_local = hi - lo
-        whole_step = wl["kind"] == "chain" and not args.no_render_ahead  # the events bracket the step, not one kernel
-        if whole_step or (fused and wl["kind"] == "welsh"):
-            kern_ms = span_ms
-        dom_bytes = (wl["bytes_per_vf"] if ((fused and wl["kind"] in ("welsh", "sampler")) or whole_step) else wl["dominant_bytes"])
+        whole_step = span_mode and wl["kind"] in ("chain", "mixed")  # the events bracket the step, not one kernel
+        dom_bytes = wl["bytes_per_vf"] if span_mode else wl["dominant_bytes"]
         achieved = dom_bytes * n_local * FRAMES / (kern_ms * 1e-3) / 1e9
         traffic = committed_traffic(args.workload, world)
         line = {
@@ -353,7 +360,8 @@ def main():
             "roofline": {"bound": "hbm",
                          "kernel": ("welsh_render_uniform_kernel<fused, LFO mode, retune> (one kernel per base kind, run "
                                     "concurrently; class-specialised block bodies) + partial_rows/final" if fused and wl["kind"] == "welsh"
-                                    else "whole step: render of block b+1 (side streams) beside the effect chain + mix of block b" if whole_step
+                                    else "whole step: render of block b+1 (side streams) beside the effect chain + mix of block b" if whole_step and wl["kind"] == "chain"
+                                    else "whole step: the banks' fused render kernels side by side + their bus reductions" if whole_step
                                     else "render kernel of the first bank"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_voice_frame": dom_bytes, "algorithmic_bytes_per_step": dom_bytes * n_local * FRAMES,

@@ -30,6 +30,7 @@ struct groove_block {
   // side stream k behind them, ready_mask says which are outstanding (block_acquire clears it).
   hipEvent_t ev_free = nullptr, ev_ready[16] = {};
   uint32_t ready_mask = 0;
+  bool released = false; // groove_block_release: ev_free marks the end of the block's consumers so far
 };
 
 enum BankKind { BANK_WELSH = 0, BANK_FM = 1, BANK_SAMPLER = 2 };
@@ -61,6 +62,7 @@ struct groove_bank {
   bool reduce_recorded[2] = {false, false};
   int pipe_slot = 0;
   int stream_slot = 0; // side stream of a single-kernel bank (FM, sampler, per-lane Welsh) in the asynchronous fused path
+  bool ctx_touched = true; // the ctx stream has worked on this bank's state since its last asynchronous render waited for it
   int side_mode = 0;    // which side streams carried this bank's last asynchronous work: 0 none, 1 one per base kind, 2 stream_slot
   hipEvent_t ev_gather = nullptr; // groove_bank_render_async of a regrouped bank: the scratch block has been gathered
   bool gather_recorded = false;
@@ -180,6 +182,7 @@ int ctx_join(groove_ctx* ctx) {
 // Order the ctx stream after the asynchronous render that produced `blk` (groove_bank_render_async).
 // Every ctx-stream operation that reads or writes a block calls this first.
 int block_acquire(groove_block* blk) {
+  blk->released = false; // the ctx stream is about to use the block again
   if (!blk->ready_mask) return 0;
   groove_ctx* ctx = blk->ctx;
   for (int k = 0; k < kSideStreams; ++k)
@@ -434,6 +437,7 @@ int launch_events(groove_bank* b, const groove_note_event* ev, uint32_t count, i
 int flush_events(groove_bank* b) {
   if (b->pending.empty()) return 0;
   groove_ctx* ctx = b->ctx;
+  b->ctx_touched = true;
   if (ctx_join(ctx)) return 1;
   if (!b->inv.empty()) // caller's voice index -> internal lane
     for (groove_note_event& e : b->pending)
@@ -934,6 +938,7 @@ static void launch_welsh_kind(int k, const UniformArgs& a, hipStream_t st, bool 
 }
 static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs, float* out) {
   groove_ctx* ctx = b->ctx;
+  b->ctx_touched = true;
   const dim3 grid(blocks_for(b->n)), blk(kThreads);
   if (b->kind == BANK_WELSH) {
     RenderConsts rc{(float)(3.14159265358979323846 / ctx->sr), (float)(0.49 * ctx->sr)};
@@ -1031,6 +1036,7 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
   if (frames == 0) return 0;
   GHIP(ctx, hipSetDevice(ctx->device));
   if (flush_events(b)) return 1;
+  const bool was_released = out->released;
   if (block_acquire(out)) return 1; // an earlier asynchronous render into the same block comes first
   const bool small_uniform = b->kind == BANK_WELSH && b->n_vwaves && b->n_vwaves < ctx->pipeline_min_waves;
   const bool uniform = b->kind == BANK_WELSH && b->n_vwaves && !small_uniform; // one kernel per base kind
@@ -1054,7 +1060,12 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
     dst = b->scratch->d;
     chs = (size_t)b->scratch->cap * b->n;
   }
-  GHIP(ctx, hipEventRecord(out->ev_free, ctx->stream));
+  // What the render has to wait for on the ctx stream: the block's consumers, and the bank's state if
+  // the ctx stream has worked on it.  A block the host has released (groove_block_release) carries the
+  // event of that moment, typically long past, so the render follows the previous one on its stream
+  // without a cross-queue wait; otherwise everything submitted so far is waited for.
+  if (!(was_released && !b->ctx_touched)) GHIP(ctx, hipEventRecord(out->ev_free, ctx->stream));
+  b->ctx_touched = false;
   const dim3 blk(kThreads);
   uint32_t used = 0;
   auto begin = [&](int k) -> hipStream_t {
@@ -1118,6 +1129,18 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
   }
   out->ready_mask = used;
   GHIP(ctx, hipGetLastError());
+  return 0;
+}
+int groove_block_release(groove_block* b) {
+  if (!b) return fail(nullptr, "groove_block_release: block is NULL");
+  groove_ctx* ctx = b->ctx;
+  if (block_acquire(b)) return 1;
+  if (!b->ev_free) {
+    GHIP(ctx, hipEventCreateWithFlags(&b->ev_free, kSyncEventFlags));
+    for (int k = 0; k < kSideStreams; ++k) GHIP(ctx, hipEventCreateWithFlags(&b->ev_ready[k], kSyncEventFlags));
+  }
+  GHIP(ctx, hipEventRecord(b->ev_free, ctx->stream));
+  b->released = true;
   return 0;
 }
 int groove_block_acquire(groove_block* b) {

@@ -105,6 +105,10 @@ class Block:
         _lib.check(self.ctx.L.groove_block_download(self.h, out.ctypes.data_as(_fp), frames), self.ctx.h)
         return out
 
+    def release(self):
+        """groove_block_release: the block's consumers so far are all that the next asynchronous render into it waits for."""
+        _lib.check(self.ctx.L.groove_block_release(self.h), self.ctx.h)
+
     def destroy(self):
         if self.h:
             self.ctx.L.groove_block_destroy(self.h)

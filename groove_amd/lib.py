@@ -47,6 +47,7 @@ SYMBOLS = {
     "groove_bank_render": (_i, [_vp, _u32, _vp]),
     "groove_bank_render_async": (_i, [_vp, _u32, _vp]),
     "groove_block_acquire": (_i, [_vp]),
+    "groove_block_release": (_i, [_vp]),
     "groove_bank_render_mix": (_i, [_vp, _u32, _vp, _i]),
     "groove_bank_state_words": (_u32, [_vp]),
     "groove_bank_download_state": (_i, [_vp, C.POINTER(C.c_uint32)]),

@@ -104,6 +104,12 @@ int groove_bank_render(groove_bank* bank, uint32_t frames, groove_block* out);
 int groove_bank_render_async(groove_bank* bank, uint32_t frames, groove_block* out);
 /* Orders the ctx stream after the asynchronous render that last filled `b` (no-op otherwise). */
 int groove_block_acquire(groove_block* b);
+/* Marks the end of the block's consumers so far (one event on the ctx stream).  The next
+ * groove_bank_render_async into `b` then waits for this point only — not for everything submitted to
+ * the ctx stream by the time of that call — provided nothing uses the block on the ctx stream in
+ * between.  With three blocks per instrument in rotation the released block's consumers are a whole
+ * step in the past, the render needs no cross-queue wait and follows the previous one directly. */
+int groove_block_release(groove_block* b);
 /* Fused form of "tick every leaf and add its value to the running sum"
  * (orchestrator.rs:397-410) for instruments patched straight into the main mixer: renders
  * and accumulates into bus_dev[frames][2] (device) without materialising the block.

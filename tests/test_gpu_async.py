@@ -14,13 +14,13 @@ def _twin(make):
     return make(), make()
 
 
-def _render_ahead(gpu_ctx, sync_inst, async_inst, n, blocks, events, fx_sync=(), fx_async=(), frames_of=lambda b: FRAMES):
+def _render_ahead(gpu_ctx, sync_inst, async_inst, n, blocks, events, fx_sync=(), fx_async=(), frames_of=lambda b: FRAMES, rotation=2):
     """Walk `blocks` blocks twice: instrument A the plain way (render, effects, mix into bus A);
     instrument B software-pipelined (render of block b+1 submitted before the effects of block b,
     two blocks alternating).  events(b) -> note events applied before block b.  Returns both buses
     and the per-block downloads of the effect outputs."""
     blk_s = gpu_ctx.block(n, FRAMES)
-    blk_a = [gpu_ctx.block(n, FRAMES), gpu_ctx.block(n, FRAMES)]
+    blk_a = [gpu_ctx.block(n, FRAMES) for _ in range(rotation)]  # rotation 3: blocks are released after their mix (groove_block_release)
     bus_s, bus_a = gpu_ctx.bus(blocks * FRAMES), gpu_ctx.bus(blocks * FRAMES)
     from groove_amd import entities as E
     outs_s, outs_a = [], []
@@ -44,7 +44,7 @@ def _render_ahead(gpu_ctx, sync_inst, async_inst, n, blocks, events, fx_sync=(),
         async_inst.handle_midi_events(ev)
     async_inst.generate_batch_values_async(blk_a[0], frames_of(0))
     for b in range(blocks):
-        cur, nxt = blk_a[b & 1], blk_a[(b + 1) & 1]
+        cur, nxt = blk_a[b % rotation], blk_a[(b + 1) % rotation]
         f = frames_of(b)
         if b + 1 < blocks:
             ev = events(b + 1)
@@ -54,6 +54,8 @@ def _render_ahead(gpu_ctx, sync_inst, async_inst, n, blocks, events, fx_sync=(),
         for e in fx_async:
             e.transform_audio(cur, f)
         gpu_ctx.mix([cur], f, E._Slice(bus_a, at), accumulate=False)
+        if rotation > 2:
+            cur.release()
         if b % 3 == 0:  # downloads synchronise the ctx stream: do it on some blocks only, so others stay overlapped
             outs_a.append((b, cur.download(f)))
         at += f
@@ -94,6 +96,28 @@ def test_welsh_chain_render_ahead_is_identical(gpu_ctx):
     fx_a = [E.Effect(gpu_ctx, k, p) for k, p in _short_chain(n)]
     fx_b = [E.Effect(gpu_ctx, k, p) for k, p in _short_chain(n)]
     _render_ahead(gpu_ctx, a, b, n, blocks, lambda k: on if k == 0 else (off if k == 8 else None), fx_a, fx_b)
+    for x in (a, b, *fx_a, *fx_b):
+        x.destroy()
+
+
+@pytest.mark.parametrize("n", [1024, 8192])
+def test_three_block_rotation_with_release_is_identical(gpu_ctx, n):
+    """Blocks released after their mix (groove_block_release) and reused two steps later: the render
+    into a released block waits for that release only.  Grouped bank and (8192 interleaved voices) a
+    regrouped one; a download right after a release, and a note-off in the middle, take the block
+    back to the conservative path."""
+    from groove_amd import entities as E
+    blocks = 15
+    if n == 1024:
+        params, idx = P.welsh_voices_grouped(n, 0)
+        on, off = P.grouped_note_events(idx, True), P.grouped_note_events(idx, False)
+    else:
+        params = P.welsh_voices(n)
+        on, off = P.note_on_all(n), P.note_off_all(n)
+    a, b = _twin(lambda: E.WelshSynth(gpu_ctx, params))
+    fx_a = [E.Effect(gpu_ctx, k, p) for k, p in _short_chain(n)]
+    fx_b = [E.Effect(gpu_ctx, k, p) for k, p in _short_chain(n)]
+    _render_ahead(gpu_ctx, a, b, n, blocks, lambda k: on if k == 0 else (off if k == 9 else None), fx_a, fx_b, rotation=3)
     for x in (a, b, *fx_a, *fx_b):
         x.destroy()
 
