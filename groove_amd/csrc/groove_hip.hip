@@ -499,8 +499,14 @@ int mix_one(groove_ctx* ctx, const groove_block* b, uint32_t frames, float* bus,
   const uint32_t n_seg = (b->n + kMixSeg - 1) / kMixSeg;
   const uint32_t rows = 2 * frames;
   if (ensure_partial(ctx, (size_t)rows * n_seg)) return 1;
+  if (n_seg == 1) { // one segment per row: the partial sums are the totals
+    hipLaunchKernelGGL(mix_partial_kernel, dim3(1, rows), dim3(kThreads), 0, ctx->stream, b->d, b->n, frames,
+                       (size_t)b->cap * b->n, kMixSeg, ctx->d_partial, 1u, bus, accumulate, planar_stride);
+    GHIP(ctx, hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(mix_partial_kernel, dim3(n_seg, rows), dim3(kThreads), 0, ctx->stream, b->d, b->n, frames,
-                     (size_t)b->cap * b->n, kMixSeg, ctx->d_partial, n_seg);
+                     (size_t)b->cap * b->n, kMixSeg, ctx->d_partial, n_seg, (float*)nullptr, 0, (size_t)0);
   hipLaunchKernelGGL(mix_final_kernel, dim3(blocks_for(rows)), dim3(kThreads), 0, ctx->stream, ctx->d_partial,
                      frames, n_seg, bus, accumulate, planar_stride);
   GHIP(ctx, hipGetLastError());
@@ -573,7 +579,7 @@ int fx_setup_state(groove_fx* fx) { // (re)allocate and zero state for the curre
     case GROOVE_FX_BIQUAD_HSHELF12:
     case GROOVE_FX_BIQUAD_LP24:
       GHIP(ctx, hipMalloc(&fx->d_st, 4 * ln * 8));
-      GHIP(ctx, hipMemset(fx->d_st, 0, 4 * ln * 8));
+      GHIP(ctx, hipMemsetAsync(fx->d_st, 0, 4 * ln * 8, ctx->stream)); // on the ctx stream: a null-stream memset is not ordered with it
       break;
     case GROOVE_FX_DELAY:
       fx->N = delay_frames_h(p0.delay_seconds, sr);
@@ -604,7 +610,7 @@ int fx_setup_state(groove_fx* fx) { // (re)allocate and zero state for the curre
   if (fx->ring_rows > (1ull << 26)) return fail(ctx, "groove_fx: delay line longer than 2^26 frames");
   if (fx->ring_rows) {
     GHIP(ctx, hipMalloc(&fx->d_ring, fx->ring_rows * ln * 4));
-    GHIP(ctx, hipMemset(fx->d_ring, 0, fx->ring_rows * ln * 4));
+    GHIP(ctx, hipMemsetAsync(fx->d_ring, 0, fx->ring_rows * ln * 4, ctx->stream));
   }
   return 0;
 }
@@ -1224,10 +1230,15 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
     GHIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_render_done[k][slot], 0));
     ctx->side_busy[k] = true;
   }
-  hipLaunchKernelGGL(partial_rows_kernel, dim3(blocks_for(cols), segs), blk, 0, ctx->stream, b->d_pipe_part[slot], rows, cols,
-                     rows_per_seg, b->d_pipe_seg[slot]);
-  hipLaunchKernelGGL(partial_final_kernel, dim3(blocks_for(cols)), blk, 0, ctx->stream, b->d_pipe_seg[slot], segs, frames,
-                     bus_dev, accumulate);
+  if (segs == 1) { // small bank: the one segment's column sums are the bus frames
+    hipLaunchKernelGGL(partial_rows_kernel, dim3(blocks_for(cols), 1), blk, 0, ctx->stream, b->d_pipe_part[slot], rows, cols,
+                       rows_per_seg, b->d_pipe_seg[slot], bus_dev, accumulate);
+  } else {
+    hipLaunchKernelGGL(partial_rows_kernel, dim3(blocks_for(cols), segs), blk, 0, ctx->stream, b->d_pipe_part[slot], rows, cols,
+                       rows_per_seg, b->d_pipe_seg[slot], (float*)nullptr, 0);
+    hipLaunchKernelGGL(partial_final_kernel, dim3(blocks_for(cols)), blk, 0, ctx->stream, b->d_pipe_seg[slot], segs, frames,
+                       bus_dev, accumulate);
+  }
   GHIP(ctx, hipEventRecord(b->ev_reduce_done[slot], ctx->stream));
   b->reduce_recorded[slot] = true;
   GHIP(ctx, hipGetLastError());
@@ -1265,10 +1276,15 @@ int groove_bank_render_mix(groove_bank* b, uint32_t frames, float* bus_dev, int 
     ctx->fseg_cap = (size_t)segs * cols;
   }
   if (launch_render(b, frames, true, 0, ctx->d_fpart)) return 1;
-  hipLaunchKernelGGL(partial_rows_kernel, dim3(blocks_for(cols), segs), dim3(kThreads), 0, ctx->stream, ctx->d_fpart, rows, cols,
-                     rows_per_seg, ctx->d_fseg);
-  hipLaunchKernelGGL(partial_final_kernel, dim3(blocks_for(cols)), dim3(kThreads), 0, ctx->stream, ctx->d_fseg, segs, frames,
-                     bus_dev, accumulate);
+  if (segs == 1) {
+    hipLaunchKernelGGL(partial_rows_kernel, dim3(blocks_for(cols), 1), dim3(kThreads), 0, ctx->stream, ctx->d_fpart, rows, cols,
+                       rows_per_seg, ctx->d_fseg, bus_dev, accumulate);
+  } else {
+    hipLaunchKernelGGL(partial_rows_kernel, dim3(blocks_for(cols), segs), dim3(kThreads), 0, ctx->stream, ctx->d_fpart, rows, cols,
+                       rows_per_seg, ctx->d_fseg, (float*)nullptr, 0);
+    hipLaunchKernelGGL(partial_final_kernel, dim3(blocks_for(cols)), dim3(kThreads), 0, ctx->stream, ctx->d_fseg, segs, frames,
+                       bus_dev, accumulate);
+  }
   GHIP(ctx, hipGetLastError());
   return 0;
 }
@@ -1487,7 +1503,9 @@ int groove_bus_create(groove_ctx* ctx, size_t frames, float** out_dev) {
   if (!ctx || !out_dev) return fail(ctx, "groove_bus_create: NULL argument");
   GHIP(ctx, hipSetDevice(ctx->device));
   GHIP(ctx, hipMalloc(out_dev, std::max<size_t>(frames, 1) * 8));
-  GHIP(ctx, hipMemset(*out_dev, 0, std::max<size_t>(frames, 1) * 8));
+  // zeroed ON THE CTX STREAM: hipMemset runs on the null stream, which the (non-blocking) ctx stream does
+  // not wait for, and may land after the first kernels that write the bus
+  GHIP(ctx, hipMemsetAsync(*out_dev, 0, std::max<size_t>(frames, 1) * 8, ctx->stream));
   return 0;
 }
 int groove_bus_destroy(groove_ctx* ctx, float* bus_dev) {

@@ -524,7 +524,7 @@ __global__ __launch_bounds__(kThreads) void sampler_render_kernel(
 // Fused path, stage 2: column sums of partial[rows][cols] (cols = 2*frames) over row segments.
 __global__ __launch_bounds__(kThreads) void partial_rows_kernel(
     const float* __restrict__ partial, uint32_t rows, uint32_t cols, uint32_t rows_per_seg,
-    float* __restrict__ seg_out /*[segs][cols]*/) {
+    float* __restrict__ seg_out /*[segs][cols]*/, float* __restrict__ bus = nullptr, int accumulate = 0) {
   const uint32_t c = blockIdx.x * kThreads + threadIdx.x;
   if (c >= cols) return;
   const uint32_t r0 = blockIdx.y * rows_per_seg, r1 = min(rows, r0 + rows_per_seg);
@@ -537,7 +537,13 @@ __global__ __launch_bounds__(kThreads) void partial_rows_kernel(
     a3 += partial[(size_t)(r + 3) * cols + c];
   }
   for (; r < r1; ++r) a0 += partial[(size_t)r * cols + c];
-  seg_out[(size_t)blockIdx.y * cols + c] = (a0 + a1) + (a2 + a3);
+  const float t = (a0 + a1) + (a2 + a3);
+  if (bus) { // a single segment: this IS the column total (what partial_final_kernel would add up and write)
+    const uint32_t frames = cols / 2, ch = c / frames, f = c % frames;
+    if (accumulate) bus[2 * f + ch] += t; else bus[2 * f + ch] = t;
+  } else {
+    seg_out[(size_t)blockIdx.y * cols + c] = t;
+  }
 }
 // Stage 3: bus[f][ch] (+)= sum_seg seg[seg][ch*frames + f].  Eight independent accumulators keep
 // eight L2 round trips in flight (a single dependent chain made this 29 us for 123 segments).
@@ -606,9 +612,11 @@ __device__ __forceinline__ float wave_sum(float x) {
   for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
   return x;
 }
+// direct != nullptr (only with n_seg == 1): the row total goes straight to the bus / one-lane block
+// that mix_final_kernel would have copied it to (one launch less on a latency-bound path).
 __global__ __launch_bounds__(kThreads) void mix_partial_kernel(
     const float* __restrict__ block, uint32_t n, uint32_t frames, size_t ch_stride, uint32_t seg_len,
-    float* __restrict__ partial, uint32_t n_seg) {
+    float* __restrict__ partial, uint32_t n_seg, float* __restrict__ direct = nullptr, int accumulate = 0, size_t planar_stride = 0) {
   const uint32_t row = blockIdx.y; // ch*frames + f
   const uint32_t seg = blockIdx.x;
   const uint32_t ch = row / frames, f = row % frames;
@@ -633,7 +641,12 @@ __global__ __launch_bounds__(kThreads) void mix_partial_kernel(
     float t = 0.0f;
 #pragma unroll
     for (int i = 0; i < kThreads / 64; ++i) t += red[i];
-    partial[(size_t)row * n_seg + seg] = t;
+    if (direct) {
+      float* dst = planar_stride ? direct + ch * planar_stride + f : direct + 2 * f + ch;
+      if (accumulate) *dst += t; else *dst = t;
+    } else {
+      partial[(size_t)row * n_seg + seg] = t;
+    }
   }
 }
 // Stage 2: bus[f][ch] (+)= sum_seg partial[row][seg]; one thread per row.  planar_stride = 0
