@@ -372,11 +372,19 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.workload)
-        print(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    if rank == 0:
+        # The JSON line goes out last: RCCL prints a version banner through C stdio, which would otherwise
+        # be flushed at exit, after this line.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
