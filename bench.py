@@ -286,9 +286,33 @@ def main():
     hi = V_total * (rank + 1) // world
     ctx = E.Context(local_rank if use_dist else 0)
     if use_dist:
-        uid = [ctx.comm_unique_id() if rank == 0 else None]
+        # The library's own communicator (RCCL, dlopen'ed): one ncclReduce of the bus per render.  If it cannot
+        # be set up on this node the reduce falls back to the launcher's process group (same RCCL collective
+        # through torch, plus two staging copies of the bus, once per render) and the line says so.
+        reduce_via = "groove_bus_reduce (RCCL ncclReduce on the ctx stream)"
+        try:
+            uid = [ctx.comm_unique_id() if rank == 0 else None]
+        except Exception as e:  # noqa: BLE001
+            uid = [None]
+            reduce_via = f"torch.distributed.reduce (library communicator unavailable: {e})"
         dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(uid[0], rank, world)
+        ok = [1]
+        if uid[0] is not None:
+            try:
+                if os.environ.get("GROOVE_BENCH_BREAK_COMM") == "1":  # exercise the fallback below
+                    raise RuntimeError("GROOVE_BENCH_BREAK_COMM=1")
+                ctx.comm_init(uid[0], rank, world)
+            except Exception as e:  # noqa: BLE001
+                ok = [0]
+                reduce_via = f"torch.distributed.reduce (groove_comm_init failed: {e})"
+        else:
+            ok = [0]
+        import torch
+        flag = torch.tensor(ok, dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # every rank takes the same path
+        own_comm = bool(int(flag.item()))
+        if not own_comm and reduce_via.startswith("groove_bus_reduce"):
+            reduce_via = "torch.distributed.reduce (another rank could not set up the library communicator)"
 
     fused = not args.materialise
     proj = Project(ctx, args.workload, lo, hi - lo, fused, grouped=not args.interleaved, render_ahead=not args.no_render_ahead)
@@ -319,7 +343,16 @@ def main():
     for s in range(K):
         proj.step(bus, (W + s) * FRAMES, pairs[s])
     if use_dist:
-        ctx.bus_reduce(E._Slice(bus, W * FRAMES), K * FRAMES, 0)
+        if own_comm:
+            ctx.bus_reduce(E._Slice(bus, W * FRAMES), K * FRAMES, 0)
+        else:
+            import torch
+            host = bus.download()
+            t = torch.from_numpy(host[W * FRAMES:(W + K) * FRAMES].copy()).cuda()
+            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                host[W * FRAMES:(W + K) * FRAMES] = t.cpu().numpy()
+                bus.upload(host)
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -352,6 +385,7 @@ def main():
             "config": {"workload": f"{args.workload}: {V_total} voices total, {FRAMES}-frame blocks, {SR} Hz, "
                                    f"{'fused render+mix' if fused else 'materialised blocks + mix kernels'}",
                        "voices_total": V_total, "voices_per_gpu": n_local,
+                       "bus_reduce": (reduce_via if use_dist else "none (one rank)"),
                        "parallelism": (f"voices sharded x{world} ({'weak: ' + str(V) + ' voices per GPU, project grows with N' if weak else 'strong: fixed project split N ways'}), "
                                        "no data-path collective, 1 RCCL bus reduce per render")},
             "project_frames_per_s": project_fps,

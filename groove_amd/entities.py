@@ -137,6 +137,11 @@ class Bus:
         _lib.check(self.ctx.L.groove_download(self.ctx.h, self.ptr, out.ctypes.data_as(_fp), frames * 2), self.ctx.h)
         return out
 
+    def upload(self, host):
+        host = np.ascontiguousarray(host, dtype=np.float32)
+        assert host.ndim == 2 and host.shape[1] == 2 and host.shape[0] <= self.frames
+        _lib.check(self.ctx.L.groove_upload(self.ctx.h, self.ptr, host.ctypes.data_as(_fp), host.size), self.ctx.h)
+
     def to_i16(self, frames=None):
         frames = self.frames if frames is None else frames
         out = np.empty((frames, 2), dtype=np.int16)
