@@ -432,9 +432,9 @@ __device__ __forceinline__ void welsh_dispatch_class(uint32_t cls, UniformArgsPt
 // SPECIALISED = false: the whole launch runs the OSC_ANY x OSC_ANY body (wg_cls is not read).
 template <bool FUSED, int LFO_MODE, bool RETUNE, bool SPECIALISED>
 __global__ __launch_bounds__(kThreads, (WavesBudget<LFO_MODE, RETUNE>::value)) void welsh_render_uniform_kernel(UniformArgs a) {
-  // The f64-LFO kinds are 2-3x the work per voice and the critical path of a block: their waves get
-  // issue priority over co-resident waves of the short kinds (list scheduling, longest first).
-  if (LFO_MODE != LFO_F32) __builtin_amdgcn_s_setprio(2);
+  // (No s_setprio: raising the f64-LFO kinds' wave priority paid when a block's kernels were forked and
+  // joined; with the blocks pipelined the longest kernel is the most numerous kind, and any priority
+  // costs 5 % — measured: none 0.460 ms, f64-LFO kinds raised 0.484, F32-retune raised 0.513.)
   const UniformArgsPtr ka = (UniformArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(); // == &a, in the constant address space
   if constexpr (FUSED) { if (welsh_idle_workgroup(a)) return; }
   if constexpr (!SPECIALISED) {
