@@ -3,32 +3,39 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload welsh-1m]
 
-A "step" is one pass of the hot path over one 256-frame block of the whole project: every
-Welsh voice ticks 256 frames (welsh_render_kernel) and the mix bus sums the voice blocks
-(Orchestrator::gather_audio).  `value` = stereo bus frames rendered per second, whole job,
-with all inputs (patch parameters, voice state) resident in HBM before the timed region.
+A "step" is one pass of the hot path over one 256-frame block of the whole project: every voice
+ticks 256 frames (render kernels), its effect chain runs, and the mix bus sums the voice blocks
+(Orchestrator::gather_audio).  `value` = stereo bus frames of the project rendered per second,
+with all inputs (patch parameters, voice state, sample bank) resident in HBM before the timed
+region.  The timed region is repeated (--repeats, default 3) from a reset state — W warm-up steps,
+then exactly K timed steps, i.e. blocks W .. W+K-1 of the project's timeline each time — and
+`value` is the median repeat; every repeat is on the line.
 
-Workloads:
+Workloads (groove_amd/projects.py):
     welsh-1m      1,000,000 Welsh voices (config-#2 voice rule) — north-star target, default
     welsh-256     config #2   (256 voices; 4 wavefronts: a latency config)
     chain-4096    config #3   (4,096 voices + BiQuad→Chorus→Delay→Reverb per voice)
-    sampler-16384 config #4   (16,384 one-shot sampler voices over a shared bank)
+    sampler-16384 config #4   (16,384 one-shot sampler voices over a shared bank, staggered starts)
     mixed-131072  config #5   (50 % Welsh / 25 % FM / 25 % sampler)
+With the default workload on one GPU the line also carries `configs`: the other four workloads,
+each timed over its WHOLE project timeline (172 blocks; 344 for the sampler), with the bus RMS error
+of a voice sample against the CPU oracle (computed outside the timed region).
 
-Multi-GPU: the project's voices are cut into contiguous index ranges, one range per rank (one
-process per GPU, no data-path collective), and the per-rank buses are summed with ONE RCCL reduce
-over the whole timed region's frames (K*256 frames * 8 B), inside the timed region.
-  default (weak scaling): every rank holds the workload's voice count, so the project grows with
-      N (N x 1,000,000 voices); `value` = stereo frames rendered by all ranks per second (each
-      rank renders the K*256 bus frames of its shard), `project_frames_per_s` = the merged
-      project's frames per second (flat when scaling is ideal), `voice_frames_per_s` the rate in
-      the unit that does not depend on how the voices are grouped.
-  --strong: the workload's voice count is fixed and split N ways; `value` = project frames/s.
-      (1,000,000 voices are small for eight MI355X: DESIGN.md §6 has the latency ceiling.)
+Multi-GPU (`--gpus N`): one process per GPU.  Started without WORLD_SIZE in the environment this
+script launches the N rank processes itself (before anything touches a GPU); started under
+`torch.distributed.run` it is one of the ranks.  The project's voices are cut into contiguous index
+ranges, one per rank, no data-path collective, and the per-rank buses are summed with ONE RCCL
+reduce over the timed region's frames, inside the timed region.
+  default (strong scaling): the workload's voices are split N ways; `value` = project frames/s.
+  --weak: every rank holds the workload's voice count, the project grows with N; `value` is still
+      the merged project's frames per second (flat when scaling is ideal) and
+      `voice_frames_per_s` is the unit that scales.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,264 +44,191 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-from groove_amd import entities as E, patches as P, abi_types as T  # noqa: E402
+from groove_amd import entities as E, abi_types as T, projects as PJ  # noqa: E402  (no GPU call at import)
+from groove_amd.parallel import voice_range  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_ISSUE_PER_S = 1024 * 2.4e9 / 2.0  # 1,024 SIMD-32s, one wave64 VALU instruction per 2 cycles at 2.4 GHz (same guide)
 FRAMES = T.BLOCK_FRAMES
 SR = T.DEFAULT_SAMPLE_RATE
-
-WORKLOADS = {
-    "welsh-1m": dict(voices=1_000_000, kind="welsh", bytes_per_vf=18.0, dominant_bytes=10.0),
-    "welsh-256": dict(voices=256, kind="welsh", bytes_per_vf=18.0, dominant_bytes=10.0),
-    "chain-4096": dict(voices=4096, kind="chain", bytes_per_vf=218.0, dominant_bytes=10.0),
-    "sampler-16384": dict(voices=16384, kind="sampler", bytes_per_vf=20.25, dominant_bytes=12.25),
-    "mixed-131072": dict(voices=131072, kind="mixed", bytes_per_vf=18.2, dominant_bytes=10.0),
-}
+WORKLOADS = PJ.WORKLOADS
 
 
-class Project:
-    """The synthetic many-voice project shard owned by one rank."""
-
-    def __init__(self, ctx, workload, first_voice, n_voices, fused, grouped=True, render_ahead=True):
-        self.ctx, self.n, self.fused = ctx, n_voices, fused
-        self.render_ahead = render_ahead  # instruments with an effect chain: render block b+1 beside the effects of block b
-        self.ahead = {}                   # instrument -> [current block, next block] once primed
-        kind = WORKLOADS[workload]["kind"]
-        self.banks = []   # (instrument, block, [effects])
-        self.timeline = []  # Welsh banks that follow the config-#2 note timeline
-        self.on_ev = self.off_ev = None
-        self.block_index = 0
-        if kind in ("welsh", "chain"):
-            if grouped:
-                params, idx = P.welsh_voices_grouped(n_voices, first_voice)
-                synth = E.WelshSynth(ctx, params)
-                self.on_ev, self.off_ev = P.grouped_note_events(idx, True), P.grouped_note_events(idx, False)
-            else:
-                idx = np.arange(first_voice, first_voice + n_voices)
-                synth = E.WelshSynth(ctx, P.welsh_voices(n_voices, first_voice))
-                self.on_ev, self.off_ev = P.note_on_all(n_voices, first_voice), P.note_off_all(n_voices, first_voice)
-            self.timeline.append(synth)
-            fx = []
-            if kind == "chain":  # per-voice chain parameters follow the voice into its lane
-                fx = [E.Effect(ctx, k, p) for k, p in P.chain_fx_params(n_voices, idx)]
-            self.banks.append((synth, ctx.block(n_voices, FRAMES), fx))
-        elif kind == "sampler":
-            pcm, descs, _ = P.drum_bank()
-            s = E.Sampler(ctx, pcm, descs, P.sampler_voices(n_voices))
-            s.handle_midi_events(T.note_events_np(np.arange(n_voices, dtype=np.uint32), P.sampler_keys(n_voices), True))
-            self.banks.append((s, ctx.block(n_voices, FRAMES), []))
-        elif kind == "mixed":
-            nw, nf = n_voices // 2, n_voices // 4
-            ns = n_voices - nw - nf
-            wp, widx = P.welsh_voices_grouped(nw, first_voice)
-            w = E.WelshSynth(ctx, wp)
-            self.on_ev, self.off_ev = P.grouped_note_events(widx, True), P.grouped_note_events(widx, False)
-            self.timeline.append(w)
-            f = E.FmSynth(ctx, P.fm_voices(nf, first_voice))
-            f.handle_midi_events(P.note_on_all(nf, first_voice))
-            pcm, descs, _ = P.drum_bank()
-            s = E.Sampler(ctx, pcm, descs, P.sampler_voices(ns))
-            s.handle_midi_events(T.note_events_np(np.arange(ns, dtype=np.uint32), P.sampler_keys(ns), True))
-            for inst, n in ((w, nw), (f, nf), (s, ns)):
-                self.banks.append((inst, ctx.block(n, FRAMES), []))
-        self.dominant = self.banks[0][0]
-
-    def _timeline_events(self, block_index):
-        # config-#2 timeline, looped: note-on at block 0, note-off at block 86 of every 172 blocks
-        b = block_index % P.RENDER_BLOCKS
-        for synth in self.timeline:
-            if b == 0:
-                synth.handle_midi_events(self.on_ev)
-            elif b == P.NOTE_OFF_FRAME // FRAMES:
-                synth.handle_midi_events(self.off_ev)
-
-    def _step_render_ahead(self, bus, frame0, ev_pair):
-        """The same block walk, software-pipelined: the instruments' render of block b+1 goes to the
-        library's side streams (groove_bank_render_async) before the effect chains of block b are
-        submitted, two blocks per instrument alternating.  Every step still submits one render, one
-        pass of every effect and one mix per instrument; the first call also renders block b itself."""
-        ctx = self.ctx
-        if ev_pair is not None and ev_pair[0] is not None:
-            ctx.record(ev_pair[0])
-        if not self.ahead:  # three blocks per instrument in rotation: [current, next, spare]
-            self._timeline_events(self.block_index)
-            for inst, block, fx in self.banks:
-                self.ahead[inst] = [block, ctx.block(inst.n, FRAMES), ctx.block(inst.n, FRAMES)]
-                inst.generate_batch_values_async(block, FRAMES)
-        self._timeline_events(self.block_index + 1)
-        self.block_index += 1
-        for inst, _, fx in self.banks:
-            # the block this render fills was released a whole step ago: no cross-queue wait (groove_block_release)
-            inst.generate_batch_values_async(self.ahead[inst][1], FRAMES)
-        first = True
-        for inst, _, fx in self.banks:
-            cur = self.ahead[inst][0]
-            for e in fx:
-                e.transform_audio(cur, FRAMES)
-            ctx.mix([cur], FRAMES, E._Slice(bus, frame0), accumulate=not first)
-            cur.release()
-            self.ahead[inst] = self.ahead[inst][1:] + [cur]
-            first = False
-        if ev_pair is not None and ev_pair[1] is not None:
-            ctx.record(ev_pair[1])
-
-    def step(self, bus, frame0, ev_pair=None):
-        """One block: every instrument renders, its effect chain runs, the mix bus sums."""
-        ctx = self.ctx
-        if self.render_ahead and any(fx for _, _, fx in self.banks):
-            return self._step_render_ahead(bus, frame0, ev_pair)
-        self._timeline_events(self.block_index)
-        self.block_index += 1
-        first = True
-        for inst, block, fx in self.banks:
-            if self.fused and not fx:
-                if ev_pair is not None and ev_pair[0] is not None and inst is self.dominant:
-                    ctx.record(ev_pair[0])
-                inst.render_mix(bus, FRAMES, accumulate=not first, at_frame=frame0)
-                if ev_pair is not None and ev_pair[1] is not None and inst is self.banks[-1][0]:
-                    ctx.record(ev_pair[1])  # fused steps are bracketed whole: after the last bank's bus sum
-            else:
-                if ev_pair is not None and ev_pair[0] is not None and inst is self.dominant:
-                    ctx.record(ev_pair[0])
-                inst.generate_batch_values(block, FRAMES)
-                if ev_pair is not None and ev_pair[1] is not None and inst is self.dominant:
-                    ctx.record(ev_pair[1])
-                for e in fx:
-                    e.transform_audio(block, FRAMES)
-                ctx.mix([block], FRAMES, E._Slice(bus, frame0), accumulate=not first)
-            first = False
+# ------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
-def committed_traffic(workload, world):
-    """HBM bytes per step from the committed PMC passes (profiles/*_summary.json, FETCH_SIZE doubled per
-    MI355X_MICROARCH.md §HBM); only meaningful for the default single-GPU workload it was collected on."""
-    if workload != "welsh-1m" or world != 1:
-        return None
+def launch_ranks(n, argv):
+    """Start n rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), pass rank 0's
+    output through and return non-zero unless every rank exits cleanly.  Nothing here touches a GPU."""
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        out = subprocess.PIPE if r == 0 else sys.stderr  # only rank 0 prints the JSON line
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
+    failed = None
+    out0 = b""
+    pending = set(range(n))
+    while pending and failed is None:
+        for r in sorted(pending):
+            p = procs[r]
+            try:
+                if r == 0:
+                    o, _ = p.communicate(timeout=0.2)
+                    out0 += o or b""
+                else:
+                    p.wait(timeout=0.2)
+            except subprocess.TimeoutExpired:
+                continue
+            pending.discard(r)
+            if p.returncode != 0:
+                failed = (r, p.returncode)
+                break
+    if failed is not None:
+        for r in pending:  # exactly the processes started above
+            procs[r].terminate()
+        for r in pending:
+            try:
+                procs[r].wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        sys.stderr.write(f"bench.py: rank {failed[0]} exited with code {failed[1]}; {n} ranks were asked for\n")
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    return 0 if failed is None else 1
+
+
+def dry_launch(world, rank):
+    """--dry-launch: the rendezvous of the N>1 path without a GPU (gloo); rank 0 prints how many ranks joined."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    t = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(t)
+    lo, hi = voice_range(WORKLOADS["welsh-1m"]["voices"], rank, world)
+    spans = [None] * world
+    dist.all_gather_object(spans, (lo, hi))
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "ranks": int(t.item()), "world": world, "voice_ranges": spans}), flush=True)
+    return 0 if int(t.item()) == world else 1
+
+
+# ------------------------------------------------------------------------------------------ evidence
+def committed_profile(workload):
+    """The committed rocprofv3 summary of a workload (profiles/rNN_<workload>_summary.json, or the round's
+    default-command summary for welsh-1m): HBM traffic per step (FETCH_SIZE doubled per MI355X_MICROARCH.md
+    §HBM) and the VALU / SALU wave-instruction counts per step of the PMC pass."""
     import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_summary.json")))
+    pats = [f"r*_{workload}_summary.json"] + (["r*_summary.json"] if workload == "welsh-1m" else [])
+    files = []
+    for pat in pats:
+        files += [f for f in glob.glob(os.path.join(REPO, "profiles", pat))]
+    files = sorted(set(files), key=lambda f: (os.path.basename(f)[:3], len(os.path.basename(f))))
     if not files:
         return None
     try:
-        t = json.load(open(files[-1])).get("hbm_traffic_bytes_per_step", {})
-        return {"bytes_per_step": t.get("total_corrected"), "source": os.path.basename(files[-1])}
+        d = json.load(open(files[-1]))
     except Exception:
         return None
+    out = {"source": os.path.basename(files[-1]),
+           "traffic": (d.get("hbm_traffic_bytes_per_step") or {}).get("total_corrected")}
+    valu = salu = 0.0
+    for k, v in (d.get("sq") or {}).items():
+        if "render" in k or "partial_" in k or "mix_" in k or "fx_" in k:
+            m = v.get("mean_per_dispatch", {})
+            valu += m.get("SQ_INSTS_VALU", 0.0)
+            salu += m.get("SQ_INSTS_SALU", 0.0)
+    out["valu_per_step"], out["salu_per_step"] = (valu or None), (salu or None)
+    out["cost_model_frac"] = (d.get("valu_cost_model") or {}).get("frac")
+    return out
+
+
+def sampled_parity(ctx, workload, v_total, blocks, sample=64, fused=True, grouped=True):
+    """Bus RMS error (normalised by the sample size) of `sample` voices of the project, spread over its
+    whole index range, rendered by the product path and by the CPU oracle over the first `blocks`
+    blocks of the timeline.  Outside every timed region."""
+    from oracle.projects import OracleProject
+    sample = min(sample, v_total)
+    sel = np.unique((np.arange(sample, dtype=np.int64) * (v_total // sample)) + (v_total // sample) // 2)
+    proj = PJ.Project(ctx, workload, sel, fused=fused, grouped=grouped)
+    bus = ctx.bus(blocks * FRAMES)
+    for b in range(blocks):
+        proj.step(bus, b * FRAMES)
+    got = bus.download().astype(np.float64) / len(sel)
+    proj.destroy()
+    bus.destroy()
+    want = OracleProject(workload, sel, grouped=grouped).render(blocks) / len(sel)
+    return {"voices_sampled": int(len(sel)), "blocks": blocks,
+            "bus_rms_err": float(np.sqrt(np.mean((got - want) ** 2))), "signal_rms": float(np.sqrt(np.mean(want ** 2))),
+            "max_abs_err": float(np.max(np.abs(got - want)))}
 
 
 def cpu_baseline(workload, seconds_target=15.0):
-    """The f64 scalar oracle ("port"; the reference Rust path cannot be built here) timed on
-    this host, rank 0 only, on a bounded sample of the same workload, single thread (mode A)."""
+    """The f64 scalar oracle ("port"; the reference Rust path cannot be built here) timed on this host,
+    rank 0 only, on a bounded sample of the same workload: mode A single thread, mode B all host cores."""
     from oracle import oracle as O
-    L = O.lib()
-    kind = WORKLOADS[workload]["kind"]
+    from oracle.projects import OracleProject
     V = WORKLOADS[workload]["voices"]
-    if kind not in ("welsh", "chain", "mixed"):
-        kind = "sampler"
     sample_voices = min(V, 1024)
-    blocks = 8
-    if kind == "sampler":
-        pcm, descs, _ = P.drum_bank()
-        bank = O.Bank.sampler(pcm, descs, P.sampler_voices(sample_voices))
-        bank.note_events(T.note_events_np(np.arange(sample_voices, dtype=np.uint32), P.sampler_keys(sample_voices), True))
-    else:
-        bank = O.Bank.welsh(P.welsh_voices(sample_voices))
-        bank.note_events(P.note_on_all(sample_voices))
-    chain = []
-    if WORKLOADS[workload]["kind"] == "chain":  # config #3: the per-voice effect chain is part of the path
-        chain = [O.Fx(k, p) for k, p in P.chain_fx_params(sample_voices)]
-
-    def one_block():
-        if chain:
-            blk = bank.render(FRAMES)
-            for fx in chain:
-                fx.process(blk)
-            O.mix(blk)
-        else:
-            bank.render_bus(FRAMES)
-
-    # calibrate, then run ~seconds_target of CPU work
+    sel = np.arange(sample_voices, dtype=np.int64) * (V // sample_voices)
+    op = OracleProject(workload, sel)
     t0 = time.perf_counter()
-    one_block()
+    op.step()
     dt = max(time.perf_counter() - t0, 1e-6)
     blocks = int(max(4, min(4096, seconds_target / dt)))
     t0 = time.perf_counter()
     for _ in range(blocks):
-        one_block()
+        op.step()
     el = time.perf_counter() - t0
     vf_per_s = sample_voices * FRAMES * blocks / el
     out = {
         "value": vf_per_s / V, "unit": "stereo frames/s", "cores": 1, "kind": "port",
-        "sample": f"{sample_voices} of {V} voices x {blocks} blocks of {FRAMES} frames, f64 scalar oracle -O2, "
-                  f"1 thread; frames/s scaled by {sample_voices}/{V} (measured {vf_per_s:.3e} voice-frames/s)",
+        "sample": f"{sample_voices} of {V} voices (every {V // sample_voices}th) x {blocks} blocks of {FRAMES} frames from block 1 of the "
+                  f"timeline, f64 scalar oracle -O2, 1 thread; frames/s scaled by {sample_voices}/{V} "
+                  f"(measured {vf_per_s:.3e} voice-frames/s)",
     }
-    # mode B: all host cores (BASELINE.md §2), on a sample large enough to keep every thread busy
-    cores = int(L.oracle_hardware_concurrency()) or 1
-    if kind != "sampler" and not chain:
+    cores = int(O.lib().oracle_hardware_concurrency()) or 1
+    if WORKLOADS[workload]["kind"] in ("welsh", "mixed", "sampler"):  # mode B (BASELINE.md §2): voices sharded over all host cores
         mt_voices = min(V, 64 * cores)
-        mbank = O.Bank.welsh(P.welsh_voices(mt_voices))
-        mbank.note_events(P.note_on_all(mt_voices))
+        mp_ = OracleProject(workload, np.arange(mt_voices, dtype=np.int64) * (V // mt_voices))
+        mp_.step(threads=cores)
         mt_blocks = int(max(2, min(512, 0.3 * seconds_target * vf_per_s * min(cores, 16) / (mt_voices * FRAMES))))
         t0 = time.perf_counter()
         for _ in range(mt_blocks):
-            mbank.render_bus(FRAMES, threads=cores)
+            mp_.step(threads=cores)
         el = time.perf_counter() - t0
         out["all_cores"] = {"value": mt_voices * FRAMES * mt_blocks / el / V, "cores": cores,
                             "sample": f"{mt_voices} voices x {mt_blocks} blocks, {cores} threads"}
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=172, help="default: one full 172-block project (44,032 frames)")
-    ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--workload", default="welsh-1m", choices=sorted(WORKLOADS))
-    ap.add_argument("--voices", type=int, default=0, help="override the workload's total voice count")
-    ap.add_argument("--materialise", action="store_true",
-                    help="entity-boundary form: write every voice block to HBM, then run the separate mix kernels "
-                         "(default: fused render+mix, no materialised voice blocks)")
-    ap.add_argument("--interleaved", action="store_true", help="voice i uses patch i mod 32 inside every wavefront (generic per-lane kernel)")
-    ap.add_argument("--strong", action="store_true",
-                    help="multi-GPU: split the workload's voices over the ranks (default: weak scaling, every rank "
-                         "holds the workload's voice count and the project grows with --gpus)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-render-ahead", action="store_true",
-                    help="workloads with effect chains: render block b, then its effects (default: the render of block b+1 "
-                         "is submitted to the side streams before the effects of block b)")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------ timing
+class Dist:
+    """The launcher's process group (torch.distributed over RCCL) and the library's own communicator."""
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dist = None
-    use_dist = world > 1 or os.environ.get("GROOVE_BENCH_FORCE_DIST") == "1"  # the latter: exercise the N>1 code path on one GPU
-    if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    def __init__(self, ctx, rank, world, local_rank):
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
-    wl = dict(WORKLOADS[args.workload])
-    V = args.voices or wl["voices"]
-    weak = not args.strong
-    V_total = V * world if weak else V   # voices of the whole project
-    lo = V_total * rank // world
-    hi = V_total * (rank + 1) // world
-    ctx = E.Context(local_rank if use_dist else 0)
-    if use_dist:
+        self.torch, self.dist, self.ctx, self.rank, self.world = torch, dist, ctx, rank, world
         # The library's own communicator (RCCL, dlopen'ed): one ncclReduce of the bus per render.  If it cannot
         # be set up on this node the reduce falls back to the launcher's process group (same RCCL collective
         # through torch, plus two staging copies of the bus, once per render) and the line says so.
-        reduce_via = "groove_bus_reduce (RCCL ncclReduce on the ctx stream)"
+        self.reduce_via = "groove_bus_reduce (RCCL ncclReduce on the ctx stream)"
         try:
             uid = [ctx.comm_unique_id() if rank == 0 else None]
         except Exception as e:  # noqa: BLE001
             uid = [None]
-            reduce_via = f"torch.distributed.reduce (library communicator unavailable: {e})"
+            self.reduce_via = f"torch.distributed.reduce (library communicator unavailable: {e})"
         dist.broadcast_object_list(uid, src=0)
         ok = [1]
         if uid[0] is not None:
@@ -304,111 +238,261 @@ def main():
                 ctx.comm_init(uid[0], rank, world)
             except Exception as e:  # noqa: BLE001
                 ok = [0]
-                reduce_via = f"torch.distributed.reduce (groove_comm_init failed: {e})"
+                self.reduce_via = f"torch.distributed.reduce (groove_comm_init failed: {e})"
         else:
             ok = [0]
-        import torch
         flag = torch.tensor(ok, dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # every rank takes the same path
-        own_comm = bool(int(flag.item()))
-        if not own_comm and reduce_via.startswith("groove_bus_reduce"):
-            reduce_via = "torch.distributed.reduce (another rank could not set up the library communicator)"
+        self.own_comm = bool(int(flag.item()))
+        if not self.own_comm and self.reduce_via.startswith("groove_bus_reduce"):
+            self.reduce_via = "torch.distributed.reduce (another rank could not set up the library communicator)"
+        self.rccl_ranks = ctx.comm_ranks() if self.own_comm else dist.get_world_size()
+
+    def sync(self):
+        self.ctx.synchronize()
+        self.torch.cuda.synchronize()
+        self.dist.barrier()
+        self.ctx.synchronize()
+
+    def reduce_bus(self, bus, frame0, frames):
+        if self.own_comm:
+            self.ctx.bus_reduce(E._Slice(bus, frame0), frames, 0)
+            return
+        host = bus.download()
+        t = self.torch.from_numpy(host[frame0:frame0 + frames].copy()).cuda()
+        self.dist.reduce(t, dst=0, op=self.dist.ReduceOp.SUM)
+        if self.rank == 0:
+            host[frame0:frame0 + frames] = t.cpu().numpy()
+            bus.upload(host)
+
+    def max_over_ranks(self, x):
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def time_project(ctx, proj, bus, K, W, repeats, span_mode, dist=None):
+    """`repeats` x (reset, W warm-up steps, K timed steps bracketed by a synchronisation — and a barrier
+    across ranks — on both sides).  Returns per-repeat wall seconds (max over ranks) and HIP-event ms per step."""
+    walls, kerns = [], []
+    for _ in range(repeats):
+        proj.reset()
+        for s in range(W):
+            proj.step(bus, s * FRAMES)
+        dist.sync() if dist else ctx.synchronize()
+        # Where the event pair brackets the whole (pipelined) step, consecutive pairs would tile the timed
+        # region: only its two ends are recorded (every record is a packet on the ctx stream, ~5 us of its
+        # timeline each) and the average step is their span divided by the steps.
+        if span_mode:
+            first_ev, last_ev = ctx.event(), ctx.event()
+            pairs = [(first_ev if s == 0 else None, last_ev if s == K - 1 else None) for s in range(K)]
+        else:
+            pairs = [(ctx.event(), ctx.event()) for _ in range(K)]
+        t0 = time.perf_counter()
+        for s in range(K):
+            proj.step(bus, (W + s) * FRAMES, pairs[s])
+        if dist:
+            dist.reduce_bus(bus, W * FRAMES, K * FRAMES)
+            dist.sync()
+        else:
+            ctx.synchronize()
+        el = time.perf_counter() - t0
+        walls.append(dist.max_over_ranks(el) if dist else el)
+        if span_mode:
+            kerns.append(ctx.elapsed_ms(pairs[0][0], pairs[-1][1]) / K)
+        else:
+            kerns.append(float(np.mean([ctx.elapsed_ms(a, b) for a, b in pairs])))
+        for a, b in pairs:
+            for e in (a, b):
+                if e is not None:
+                    ctx.L.groove_event_destroy(ctx.h, e)
+    return walls, kerns
+
+
+def roofline_block(workload, n_local, kern_ms, span_mode, fused):
+    wl = WORKLOADS[workload]
+    whole = span_mode
+    dom_bytes = wl["bytes_per_vf"] if whole else wl["dominant_bytes"]
+    achieved = dom_bytes * n_local * FRAMES / (kern_ms * 1e-3) / 1e9
+    prof = committed_profile(workload) or {}
+    welsh_like = wl["kind"] in ("welsh", "mixed", "chain")
+    kernel = ("welsh_render_uniform_kernel<fused, LFO mode, retune> (one kernel per base kind, run concurrently; "
+              "class-specialised block bodies) + partial_rows/final" if fused and wl["kind"] == "welsh"
+              else "whole step: render of block b+1 (side streams) beside the effect chain + mix of block b" if whole and wl["kind"] == "chain"
+              else "whole step: the banks' fused render kernels side by side + their bus reductions" if whole
+              else "render kernel of the first bank")
+    r = {"bound": "valu-issue" if welsh_like else "hbm",
+         "kernel": kernel,
+         # SURVEY §8d's entity-boundary bytes ÷ time: an EFFECTIVE rate (the fused kernels never move these
+         # bytes; it can exceed the HBM peak).  `traffic` is what the PMC pass saw actually move.
+         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "effective": {"note": "algorithmic (entity-boundary) bytes / time, SURVEY §8d; not a physical bandwidth",
+                       "GBs": achieved, "frac_of_hbm_peak": achieved / HBM_PEAK_GBS},
+         "algorithmic_bytes_per_voice_frame": dom_bytes, "algorithmic_bytes_per_step": dom_bytes * n_local * FRAMES,
+         "kernel_ms": kern_ms,
+         "traffic": prof.get("traffic"), "traffic_unit": "HBM bytes per step (PMC FETCH_SIZE x2 + WRITE_SIZE, committed pass)",
+         "traffic_source": prof.get("source")}
+    if prof.get("traffic"):
+        r["hbm_physical_frac"] = prof["traffic"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if prof.get("valu_per_step"):
+        # the committed PMC pass counted the instructions of the workload's full-size step; scale to this shard
+        scale = n_local / WORKLOADS[workload]["voices"]
+        wi = prof["valu_per_step"] * scale
+        r["valu"] = {"wave_insts_per_step": wi, "salu_wave_insts_per_step": (prof.get("salu_per_step") or 0.0) * scale,
+                     "valu_per_voice_frame": wi * 64.0 / (n_local * FRAMES) if n_local else None,
+                     "spec_issue_rate": VALU_ISSUE_PER_S, "spec_issue_rate_unit": "wave64 VALU instructions/s (1,024 SIMD-32 x 2.4 GHz / 2 clk)",
+                     "achieved_frac": wi / (kern_ms * 1e-3) / VALU_ISSUE_PER_S,
+                     "cost_model_frac": prof.get("cost_model_frac"),
+                     "source": prof.get("source")}
+    return r
+
+
+def bench_workload(ctx, workload, sel, K, W, repeats, fused=True, grouped=True, render_ahead=True, dist=None):
+    """Build the shard `sel` of a workload, time it, return the measurements (no parity, no JSON)."""
+    wl = WORKLOADS[workload]
+    proj = PJ.Project(ctx, workload, sel, fused=fused, grouped=grouped, render_ahead=render_ahead)
+    bus = ctx.bus((K + W) * FRAMES)
+    span_mode = (fused and wl["kind"] != "chain") or (wl["kind"] == "chain" and render_ahead)
+    walls, kerns = time_project(ctx, proj, bus, K, W, repeats, span_mode, dist)
+    out_bus = bus.download()[W * FRAMES:] if (dist is None or dist.rank == 0) else None
+    proj.destroy()
+    bus.destroy()
+    order = np.argsort(walls)
+    med = int(order[len(order) // 2])
+    return {"walls": walls, "kerns": kerns, "median": med, "span_mode": span_mode, "bus": out_bus}
+
+
+def config_entry(ctx, workload, repeats, parity_voices=64):
+    """One sub-entry of `configs`: the workload's whole project timeline timed on this GPU + sampled parity."""
+    wl = WORKLOADS[workload]
+    V, K = wl["voices"], wl["blocks"]
+    m = bench_workload(ctx, workload, np.arange(V, dtype=np.int64), K, 0, repeats)
+    ms = [w / K * 1e3 for w in m["walls"]]
+    i = m["median"]
+    fps = K * FRAMES / m["walls"][i]
+    roof = roofline_block(workload, V, m["kerns"][i], m["span_mode"], True)
+    par = sampled_parity(ctx, workload, V, min(K, 172), sample=parity_voices)
+    return {"workload": workload, "voices": V, "blocks_timed": f"0..{K - 1} (the whole project, {K * FRAMES} frames)",
+            "ms_per_step": ms[i], "ms_per_step_min": min(ms), "ms_per_step_repeats": ms,
+            "value": fps, "unit": "stereo frames/s", "x_realtime_44k1": fps / SR,
+            "kernel_ms": m["kerns"][i], "frac": roof["frac"], "bound": roof["bound"],
+            "algorithmic_bytes_per_voice_frame": roof["algorithmic_bytes_per_voice_frame"],
+            "traffic": roof.get("traffic"), "traffic_source": roof.get("traffic_source"), "valu": roof.get("valu"),
+            "parity_vs_oracle": par}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=172, help="default: one full 172-block project (44,032 frames)")
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions, each from a reset state (value = the median)")
+    ap.add_argument("--workload", default="welsh-1m", choices=sorted(WORKLOADS))
+    ap.add_argument("--voices", type=int, default=0, help="override the workload's total voice count")
+    ap.add_argument("--materialise", action="store_true",
+                    help="entity-boundary form: write every voice block to HBM, then run the separate mix kernels "
+                         "(default: fused render+mix, no materialised voice blocks)")
+    ap.add_argument("--interleaved", action="store_true", help="voice i uses patch i mod 32 inside every wavefront (the library regroups or runs the per-lane kernel)")
+    ap.add_argument("--weak", action="store_true",
+                    help="multi-GPU: every rank holds the workload's voice count and the project grows with --gpus "
+                         "(default: strong scaling, the workload's voices are split over the ranks)")
+    ap.add_argument("--strong", action="store_true", help="(the default; kept for explicit command lines)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` entries (the other four workloads)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the sampled oracle comparison")
+    ap.add_argument("--no-render-ahead", action="store_true",
+                    help="workloads with effect chains: render block b, then its effects (default: the render of block b+1 "
+                         "is submitted to the side streams before the effects of block b)")
+    ap.add_argument("--dry-launch", action="store_true", help="rendezvous of the ranks over gloo only (no GPU): launcher test")
+    args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Not under a launcher: start the N ranks ourselves, before anything initialises a GPU in this process.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: fewer (or more) ranks than GPUs asked for")
+    if args.dry_launch:
+        sys.exit(dry_launch(world, rank))
+
+    use_dist = world > 1 or os.environ.get("GROOVE_BENCH_FORCE_DIST") == "1"  # the latter: exercise the N>1 code path on one GPU
+    if use_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        import torch
+        import torch.distributed as tdist
+        torch.cuda.set_device(local_rank)
+        tdist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    wl = dict(WORKLOADS[args.workload])
+    V = args.voices or wl["voices"]
+    weak = args.weak and not args.strong
+    V_total = V * world if weak else V   # voices of the whole project
+    lo, hi = voice_range(V_total, rank, world)
+    ctx = E.Context(local_rank if use_dist else 0)
+    dist = Dist(ctx, rank, world, local_rank) if use_dist else None
+    if dist is not None and dist.rccl_ranks != world:
+        sys.stderr.write(f"bench.py: the communicator has {dist.rccl_ranks} ranks, {world} GPUs were asked for\n")
+        ctx.close()
+        sys.exit(3)
 
     fused = not args.materialise
-    proj = Project(ctx, args.workload, lo, hi - lo, fused, grouped=not args.interleaved, render_ahead=not args.no_render_ahead)
-    K, W = args.steps, args.warmup
-    bus = ctx.bus((K + W) * FRAMES)
-
-    def sync_all():
-        ctx.synchronize()
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-            ctx.synchronize()
-
-    for s in range(W):
-        proj.step(bus, s * FRAMES)
-    sync_all()
-    # Where the event pair brackets the whole (pipelined) step, consecutive pairs would tile the timed
-    # region: only its two ends are recorded (every record is a packet on the ctx stream, ~5 us of its
-    # timeline each) and the average step is their span divided by the steps.
-    span_mode = (fused and wl["kind"] != "chain") or (wl["kind"] == "chain" and not args.no_render_ahead)
-    if span_mode:
-        first_ev, last_ev = ctx.event(), ctx.event()
-        pairs = [(first_ev if s == 0 else None, last_ev if s == K - 1 else None) for s in range(K)]
-    else:
-        pairs = [(ctx.event(), ctx.event()) for _ in range(K)]
-    t0 = time.perf_counter()
-    for s in range(K):
-        proj.step(bus, (W + s) * FRAMES, pairs[s])
-    if use_dist:
-        if own_comm:
-            ctx.bus_reduce(E._Slice(bus, W * FRAMES), K * FRAMES, 0)
-        else:
-            import torch
-            host = bus.download()
-            t = torch.from_numpy(host[W * FRAMES:(W + K) * FRAMES].copy()).cuda()
-            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
-            if rank == 0:
-                host[W * FRAMES:(W + K) * FRAMES] = t.cpu().numpy()
-                bus.upload(host)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    if span_mode:
-        kern_ms = ctx.elapsed_ms(pairs[0][0], pairs[-1][1]) / K
-    else:
-        kern_ms = float(np.mean([ctx.elapsed_ms(a, b) for a, b in pairs]))
+    K, W, R = args.steps, args.warmup, max(1, args.repeats)
+    sel = np.arange(lo, hi, dtype=np.int64)
+    m = bench_workload(ctx, args.workload, sel, K, W, R, fused=fused, grouped=not args.interleaved,
+                       render_ahead=not args.no_render_ahead, dist=dist)
+    line = None
     if rank == 0:
-        out_bus = bus.download()[W * FRAMES:]
-        finite = bool(np.isfinite(out_bus).all())
-        peak = float(np.abs(out_bus).max() / V_total)
+        i = m["median"]
+        elapsed, kern_ms = m["walls"][i], m["kerns"][i]
+        out_bus = m["bus"]
         frames_total = K * FRAMES
-        project_fps = frames_total / elapsed                    # frames of the merged project per second
-        value = project_fps * (world if weak else 1)            # weak: every rank rendered frames_total bus frames of its shard
+        project_fps = frames_total / elapsed   # frames of the (merged) project per second: the metric, under either scaling
         n_local = hi - lo
-        whole_step = span_mode and wl["kind"] in ("chain", "mixed")  # the events bracket the step, not one kernel
-        dom_bytes = wl["bytes_per_vf"] if span_mode else wl["dominant_bytes"]
-        achieved = dom_bytes * n_local * FRAMES / (kern_ms * 1e-3) / 1e9
-        traffic = committed_traffic(args.workload, world)
+        period = wl["blocks"]
         line = {
-            "metric": "stereo frames/sec rendered (offline)", "value": value, "unit": "stereo frames/s",
+            "metric": "stereo frames/sec rendered (offline)", "value": project_fps, "unit": "stereo frames/s",
             "x_realtime_44k1": project_fps / SR, "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak" if weak else "strong",
             "vs_baseline": None, "dtype": "f32 (f64 IIR state, u64 phase)", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {V_total} voices total, {FRAMES}-frame blocks, {SR} Hz, "
                                    f"{'fused render+mix' if fused else 'materialised blocks + mix kernels'}",
                        "voices_total": V_total, "voices_per_gpu": n_local,
-                       "bus_reduce": (reduce_via if use_dist else "none (one rank)"),
-                       "parallelism": (f"voices sharded x{world} ({'weak: ' + str(V) + ' voices per GPU, project grows with N' if weak else 'strong: fixed project split N ways'}), "
-                                       "no data-path collective, 1 RCCL bus reduce per render")},
+                       "bus_reduce": (dist.reduce_via if dist else "none (one rank)"),
+                       "parallelism": (f"voices sharded x{world} ("
+                                       + (f"weak: {V} voices per GPU, the project grows with N; value = the merged project's frames/s, voice_frames_per_s scales"
+                                          if weak else "strong: the fixed project split N ways")
+                                       + "), no data-path collective, 1 RCCL bus reduce per render")},
+            "timed_region": {"repeats": R, "statistic": "median repeat (by wall time)",
+                             "ms_per_step_repeats": [w / K * 1e3 for w in m["walls"]],
+                             "ms_per_step_min": min(m["walls"]) / K * 1e3,
+                             "kernel_ms_repeats": m["kerns"],
+                             "timeline_blocks": f"{W}..{W + K - 1} of the {period}-block project timeline (looped), each repeat from a reset state "
+                                                f"(note-on at block 0, note-off at block {PJ.NOTE_OFF_BLOCK})"},
             "project_frames_per_s": project_fps,
             "voice_frames_per_s": project_fps * V_total,
             "path_effective_GBs": wl["bytes_per_vf"] * project_fps * V_total / 1e9,
-            "roofline": {"bound": "hbm",
-                         "kernel": ("welsh_render_uniform_kernel<fused, LFO mode, retune> (one kernel per base kind, run "
-                                    "concurrently; class-specialised block bodies) + partial_rows/final" if fused and wl["kind"] == "welsh"
-                                    else "whole step: render of block b+1 (side streams) beside the effect chain + mix of block b" if whole_step and wl["kind"] == "chain"
-                                    else "whole step: the banks' fused render kernels side by side + their bus reductions" if whole_step
-                                    else "render kernel of the first bank"),
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_voice_frame": dom_bytes, "algorithmic_bytes_per_step": dom_bytes * n_local * FRAMES,
-                         "kernel_ms": kern_ms,
-                         "traffic": (traffic or {}).get("bytes_per_step"), "traffic_unit": "bytes per step (PMC, committed pass)",
-                         "traffic_source": (traffic or {}).get("source")},
-            "output_check": {"finite": finite, "peak_abs_bus_over_V": peak},
+            "roofline": roofline_block(args.workload, n_local, kern_ms, m["span_mode"], fused),
+            "output_check": {"finite": bool(np.isfinite(out_bus).all()), "peak_abs_bus_over_V": float(np.abs(out_bus).max() / V_total)},
         }
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.workload)
+        if dist is not None:
+            line["rccl_ranks"] = dist.rccl_ranks
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        dist.dist.barrier()
+        dist.dist.destroy_process_group()
+    if rank == 0 and world == 1:
+        if not args.no_parity:
+            line["parity_vs_oracle"] = sampled_parity(ctx, args.workload, V_total, min(K + W, 48), sample=128, fused=fused,
+                                                      grouped=not args.interleaved)
+        if args.workload == "welsh-1m" and not args.no_configs and not args.voices and fused and not args.interleaved:
+            line["configs"] = [config_entry(ctx, w, R) for w in ("welsh-256", "chain-4096", "sampler-16384", "mixed-131072")]
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload)
     ctx.close()
     if rank == 0:
         # The JSON line goes out last: RCCL prints a version banner through C stdio, which would otherwise

@@ -8,6 +8,7 @@
 #include "../../include/groove_hip.h"
 #include "kernels.h"
 #include <dlfcn.h>
+#include <rccl/rccl.h> // types, enumerators and prototypes only: the library itself is dlopen'ed (rccl_open)
 #include <string>
 #include <vector>
 #include <algorithm>
@@ -79,6 +80,14 @@ struct groove_bank {
   float* d_pcm = nullptr;   // sampler bank
   groove_note_event* d_ev = nullptr;
   size_t ev_cap = 0;
+  // pinned staging of queued note events, two slots in rotation: flush_events hands the events to the ctx
+  // stream and returns without a host synchronisation (a project with note events in every block would
+  // otherwise serialise host and GPU once per block)
+  groove_note_event* h_ev[2] = {nullptr, nullptr};
+  size_t h_ev_cap[2] = {0, 0};
+  hipEvent_t ev_staged[2] = {nullptr, nullptr};
+  bool staged[2] = {false, false};
+  int ev_slot = 0;
   groove_block* scratch = nullptr; // for render_mix
   std::vector<groove_note_event> pending;
   std::vector<groove_welsh_params> welsh;
@@ -409,6 +418,10 @@ int bank_derive_and_upload(groove_bank* b) {
 int bank_alloc(groove_bank* b) {
   groove_ctx* ctx = b->ctx;
   GHIP(ctx, hipSetDevice(ctx->device));
+  // soa_load / soa_store (kernels.h) address a record through ONE buffer resource: its byte size and the
+  // row offsets are 32-bit, so words * n * 4 must stay below 4 GiB (26.8 M Welsh voices per bank).
+  if ((uint64_t)std::max(b->pw, b->sw) * b->n * 4ull >= (1ull << 32))
+    return fail(ctx, "bank too large: parameter/state record x voices must stay below 4 GiB per bank (split the voices over several banks)");
   GHIP(ctx, hipMalloc(&b->d_params, (size_t)b->pw * b->n * 4));
   GHIP(ctx, hipMalloc(&b->d_state, (size_t)b->sw * b->n * 4));
   return 0;
@@ -439,16 +452,31 @@ int flush_events(groove_bank* b) {
   groove_ctx* ctx = b->ctx;
   b->ctx_touched = true;
   if (ctx_join(ctx)) return 1;
-  if (!b->inv.empty()) // caller's voice index -> internal lane
-    for (groove_note_event& e : b->pending)
+  // caller's voice index -> internal lane, into a copy: a failure below leaves `pending` as it was queued,
+  // so the next flush maps it exactly once
+  std::vector<groove_note_event> ev = b->pending;
+  if (!b->inv.empty())
+    for (groove_note_event& e : ev)
       if (e.voice != GROOVE_ALL_VOICES) e.voice = b->inv[e.voice];
-  std::vector<groove_note_event>& ev = b->pending;
   if (b->ev_cap < ev.size()) {
+    GHIP(ctx, hipStreamSynchronize(ctx->stream)); // earlier event kernels may still read the old buffer
     if (b->d_ev) GHIP(ctx, hipFree(b->d_ev));
-    b->ev_cap = std::max<size_t>(ev.size(), 1024);
+    b->ev_cap = std::max<size_t>(ev.size() * 2, 1024);
     GHIP(ctx, hipMalloc(&b->d_ev, b->ev_cap * sizeof(groove_note_event)));
   }
-  GHIP(ctx, hipMemcpyAsync(b->d_ev, ev.data(), ev.size() * sizeof(groove_note_event), hipMemcpyHostToDevice, ctx->stream));
+  const int hs = b->ev_slot;
+  b->ev_slot ^= 1;
+  if (b->staged[hs]) GHIP(ctx, hipEventSynchronize(b->ev_staged[hs])); // two flushes ago: long done
+  if (b->h_ev_cap[hs] < ev.size()) {
+    if (b->h_ev[hs]) GHIP(ctx, hipHostFree(b->h_ev[hs]));
+    b->h_ev_cap[hs] = std::max<size_t>(ev.size() * 2, 1024);
+    GHIP(ctx, hipHostMalloc(&b->h_ev[hs], b->h_ev_cap[hs] * sizeof(groove_note_event), hipHostMallocDefault));
+  }
+  if (!b->ev_staged[hs]) GHIP(ctx, hipEventCreateWithFlags(&b->ev_staged[hs], hipEventDisableTiming));
+  std::memcpy(b->h_ev[hs], ev.data(), ev.size() * sizeof(groove_note_event));
+  GHIP(ctx, hipMemcpyAsync(b->d_ev, b->h_ev[hs], ev.size() * sizeof(groove_note_event), hipMemcpyHostToDevice, ctx->stream));
+  GHIP(ctx, hipEventRecord(b->ev_staged[hs], ctx->stream));
+  b->staged[hs] = true;
   // fast path: strictly increasing voices, no ALL events → one round
   bool sorted = true;
   for (size_t i = 0; i < ev.size(); ++i) {
@@ -480,8 +508,7 @@ int flush_events(groove_bank* b) {
     }
     if (launch_run(start, ev.size())) return 1;
   }
-  GHIP(ctx, hipStreamSynchronize(ctx->stream)); // host vector is about to be cleared
-  ev.clear();
+  b->pending.clear(); // (the device reads the pinned copy, not this vector)
   return 0;
 }
 
@@ -628,12 +655,15 @@ int fx_check_uniform(groove_fx* fx) {
 }
 
 // ---- RCCL via dlopen -----------------------------------------------------------------
-typedef int (*nccl_get_uid_t)(void*);
-struct UidBlob { char b[128]; };
-typedef int (*nccl_init_rank_fn)(void**, int, UidBlob, int);
-typedef int (*nccl_reduce_fn)(const void*, void*, size_t, int, int, int, void*, hipStream_t);
-typedef int (*nccl_destroy_fn)(void*);
-typedef const char* (*nccl_errstr_fn)(int);
+// Function-pointer types are taken from the prototypes in <rccl/rccl.h>, so a change of the ABI is a
+// compile error here instead of a silently wrong call.
+using nccl_get_uid_fn = decltype(&ncclGetUniqueId);
+using nccl_init_rank_fn = decltype(&ncclCommInitRank);
+using nccl_reduce_fn = decltype(&ncclReduce);
+using nccl_destroy_fn = decltype(&ncclCommDestroy);
+using nccl_count_fn = decltype(&ncclCommCount);
+using nccl_errstr_fn = decltype(&ncclGetErrorString);
+static_assert(sizeof(ncclUniqueId) == 128, "groove_comm_unique_id hands out a 128-byte id");
 
 int rccl_open(groove_ctx* ctx) {
   if (ctx->rccl) return 0;
@@ -880,6 +910,7 @@ int groove_bank_destroy(groove_bank* b) {
   if (it != ctx->banks.end()) ctx->banks.erase(it);
   if (b->scratch) groove_block_destroy(b->scratch);
   if (b->ev_gather) (void)hipEventDestroy(b->ev_gather);
+  for (int k = 0; k < 2; ++k) { if (b->h_ev[k]) (void)hipHostFree(b->h_ev[k]); if (b->ev_staged[k]) (void)hipEventDestroy(b->ev_staged[k]); }
   (void)hipFree(b->d_params); (void)hipFree(b->d_state); (void)hipFree(b->d_cold); (void)hipFree(b->d_pcm); (void)hipFree(b->d_ev); (void)hipFree(b->d_waves); (void)hipFree(b->d_wg_list); (void)hipFree(b->d_wg_cls); (void)hipFree(b->d_wg_base); (void)hipFree(b->d_inv);
   delete b;
   return 0;
@@ -1070,7 +1101,8 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
   // the ctx stream has worked on it.  A block the host has released (groove_block_release) carries the
   // event of that moment, typically long past, so the render follows the previous one on its stream
   // without a cross-queue wait; otherwise everything submitted so far is waited for.
-  if (!(was_released && !b->ctx_touched)) GHIP(ctx, hipEventRecord(out->ev_free, ctx->stream));
+  const bool free_recorded_now = !(was_released && !b->ctx_touched);
+  if (free_recorded_now) GHIP(ctx, hipEventRecord(out->ev_free, ctx->stream));
   b->ctx_touched = false;
   const dim3 blk(kThreads);
   uint32_t used = 0;
@@ -1078,7 +1110,10 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
     hipStream_t st = side_stream_of(ctx, k);
     (void)hipStreamWaitEvent(st, out->ev_free, 0);
     if (regrouped && b->gather_recorded) (void)hipStreamWaitEvent(st, b->ev_gather, 0); // the scratch block is free again
-    ctx->fork_pending[k] = false; // ev_free is later than any ev_fork recorded so far
+    // An ev_free recorded in this call is later than any ev_fork; the event of an earlier release may
+    // predate one, and then this (shared) side stream still owes the wait for the fork.
+    if (ctx->fork_pending[k] && !free_recorded_now) (void)hipStreamWaitEvent(st, ctx->ev_fork, 0);
+    ctx->fork_pending[k] = false;
     return st;
   };
   auto end = [&](int k) {
@@ -1288,6 +1323,22 @@ int groove_bank_render_mix(groove_bank* b, uint32_t frames, float* bus_dev, int 
   GHIP(ctx, hipGetLastError());
   return 0;
 }
+int groove_bank_reset(groove_bank* b) {
+  if (!b) return fail(nullptr, "groove_bank_reset: bank is NULL");
+  groove_ctx* ctx = b->ctx;
+  GHIP(ctx, hipSetDevice(ctx->device));
+  if (ctx_join(ctx)) return 1;
+  b->side_mode = 0;
+  b->ctx_touched = true;
+  b->pending.clear();
+  StateWords w{};
+  if (b->kind == BANK_WELSH) { const WelshState s = initial_welsh_state(); std::memcpy(w.w, &s, sizeof(s)); }
+  else if (b->kind == BANK_FM) { const FmState s = initial_fm_state(); std::memcpy(w.w, &s, sizeof(s)); }
+  else { const SamplerState s{0, 0, 0, 0}; std::memcpy(w.w, &s, sizeof(s)); }
+  hipLaunchKernelGGL(state_fill_kernel, dim3(blocks_for(b->n)), dim3(kThreads), 0, ctx->stream, b->d_state, b->n, b->sw, w);
+  GHIP(ctx, hipGetLastError());
+  return 0;
+}
 uint32_t groove_bank_state_words(groove_bank* b) { return b ? b->sw : 0; }
 int groove_bank_download_state(groove_bank* b, uint32_t* host_words) {
   if (!b || !host_words) return fail(nullptr, "groove_bank_download_state: NULL argument");
@@ -1336,6 +1387,17 @@ int groove_fx_destroy(groove_fx* fx) {
   (void)hipFree(fx->d_fa); (void)hipFree(fx->d_fb); (void)hipFree(fx->d_ua); (void)hipFree(fx->d_wet);
   (void)hipFree(fx->d_coef); (void)hipFree(fx->d_st); (void)hipFree(fx->d_ring);
   delete fx;
+  return 0;
+}
+int groove_fx_reset(groove_fx* fx) {
+  if (!fx) return fail(nullptr, "groove_fx_reset: fx is NULL");
+  groove_ctx* ctx = fx->ctx;
+  GHIP(ctx, hipSetDevice(ctx->device));
+  const size_t ln = 2 * (size_t)fx->n;
+  if (fx->d_st) GHIP(ctx, hipMemsetAsync(fx->d_st, 0, 4 * ln * 8, ctx->stream));
+  if (fx->d_ring) GHIP(ctx, hipMemsetAsync(fx->d_ring, 0, fx->ring_rows * ln * 4, ctx->stream));
+  fx->w = 0;
+  for (uint32_t& w : fx->geo.w) w = 0;
   return 0;
 }
 int groove_fx_process(groove_fx* fx, groove_block* io, uint32_t frames) {
@@ -1551,10 +1613,12 @@ int groove_bus_to_i16(groove_ctx* ctx, const float* bus_dev, size_t frames, int1
 int groove_comm_unique_id(groove_ctx* ctx, uint8_t id_out[128]) {
   if (!ctx || !id_out) return fail(ctx, "groove_comm_unique_id: NULL argument");
   if (rccl_open(ctx)) return 1;
-  auto f = (nccl_get_uid_t)dlsym(ctx->rccl, "ncclGetUniqueId");
+  auto f = (nccl_get_uid_fn)dlsym(ctx->rccl, "ncclGetUniqueId");
   if (!f) return fail(ctx, "ncclGetUniqueId not found");
-  const int rc = f(id_out);
-  if (rc != 0) return fail(ctx, "ncclGetUniqueId failed");
+  ncclUniqueId id;
+  const ncclResult_t rc = f(&id);
+  if (rc != ncclSuccess) return fail(ctx, "ncclGetUniqueId failed");
+  std::memcpy(id_out, &id, sizeof(id));
   return 0;
 }
 int groove_comm_init(groove_ctx* ctx, const uint8_t id[128], int rank, int world_size) {
@@ -1564,21 +1628,33 @@ int groove_comm_init(groove_ctx* ctx, const uint8_t id[128], int rank, int world
   GHIP(ctx, hipSetDevice(ctx->device));
   auto f = (nccl_init_rank_fn)dlsym(ctx->rccl, "ncclCommInitRank");
   if (!f) return fail(ctx, "ncclCommInitRank not found");
-  UidBlob blob;
-  std::memcpy(blob.b, id, 128);
-  void* comm = nullptr;
-  const int rc = f(&comm, world_size, blob, rank);
-  if (rc != 0) {
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, sizeof(uid));
+  ncclComm_t comm = nullptr;
+  const ncclResult_t rc = f(&comm, world_size, uid, rank);
+  if (rc != ncclSuccess) {
     auto es = (nccl_errstr_fn)dlsym(ctx->rccl, "ncclGetErrorString");
     return fail(ctx, std::string("ncclCommInitRank failed: ") + (es ? es(rc) : "?"));
   }
   ctx->comm = comm; ctx->rank = rank; ctx->world = world_size;
   return 0;
 }
+int groove_comm_ranks(groove_ctx* ctx, int* out_ranks) {
+  if (!ctx || !out_ranks) return fail(ctx, "groove_comm_ranks: NULL argument");
+  *out_ranks = 1;
+  if (!ctx->comm) return 0; // no communicator: one rank
+  auto f = (nccl_count_fn)dlsym(ctx->rccl, "ncclCommCount");
+  if (!f) return fail(ctx, "ncclCommCount not found");
+  int count = 0;
+  const ncclResult_t rc = f((ncclComm_t)ctx->comm, &count);
+  if (rc != ncclSuccess) return fail(ctx, "ncclCommCount failed");
+  *out_ranks = count;
+  return 0;
+}
 int groove_comm_destroy(groove_ctx* ctx) {
   if (!ctx || !ctx->comm) return 0;
   auto f = (nccl_destroy_fn)dlsym(ctx->rccl, "ncclCommDestroy");
-  if (f) f(ctx->comm);
+  if (f) f((ncclComm_t)ctx->comm);
   ctx->comm = nullptr;
   return 0;
 }
@@ -1588,9 +1664,9 @@ int groove_bus_reduce(groove_ctx* ctx, float* bus_dev, size_t frames_total, int 
   if (!ctx->comm) return fail(ctx, "groove_bus_reduce: communicator not initialised");
   auto f = (nccl_reduce_fn)dlsym(ctx->rccl, "ncclReduce");
   if (!f) return fail(ctx, "ncclReduce not found");
-  // ncclFloat32 = 7, ncclSum = 0; in-place on root
-  const int rc = f(bus_dev, bus_dev, frames_total * 2, 7, 0, root, ctx->comm, ctx->stream);
-  if (rc != 0) {
+  // in place on the root
+  const ncclResult_t rc = f(bus_dev, bus_dev, frames_total * 2, ncclFloat32, ncclSum, root, (ncclComm_t)ctx->comm, ctx->stream);
+  if (rc != ncclSuccess) {
     auto es = (nccl_errstr_fn)dlsym(ctx->rccl, "ncclGetErrorString");
     return fail(ctx, std::string("ncclReduce failed: ") + (es ? es(rc) : "?"));
   }

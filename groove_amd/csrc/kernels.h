@@ -564,6 +564,16 @@ __global__ void partial_final_kernel(const float* __restrict__ seg, uint32_t seg
   if (accumulate) bus[2 * f + ch] += t; else bus[2 * f + ch] = t;
 }
 
+// Every voice back to the state a freshly created bank has (groove_bank_reset): the initial state is
+// the same record for every lane, passed by value.
+struct StateWords { uint32_t w[64]; };
+static_assert(sizeof(WelshState) <= sizeof(StateWords) && sizeof(FmState) <= sizeof(StateWords) && sizeof(SamplerState) <= sizeof(StateWords), "state record fits the reset argument");
+__global__ __launch_bounds__(kThreads) void state_fill_kernel(uint32_t* __restrict__ state, uint32_t n, uint32_t words, StateWords init) {
+  const uint32_t v = blockIdx.x * kThreads + threadIdx.x;
+  if (v >= n) return;
+  for (uint32_t i = 0; i < words; ++i) state[(size_t)i * n + v] = init.w[i];
+}
+
 // HandlesMidi: one thread per event (voice != ALL) or one thread per voice (voice == ALL).
 struct NoteCtx { double sr; };
 __global__ void welsh_events_kernel(const groove_note_event* __restrict__ ev, uint32_t n_ev, int all_event,

@@ -76,6 +76,11 @@ class Context:
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)
         _lib.check(self.L.groove_comm_init(self.h, buf, rank, world), self.h)
 
+    def comm_ranks(self):
+        n = C.c_int()
+        _lib.check(self.L.groove_comm_ranks(self.h, C.byref(n)), self.h)
+        return n.value
+
     def bus_reduce(self, bus, frames_total, root=0):
         _lib.check(self.L.groove_bus_reduce(self.h, bus.ptr, frames_total, root), self.h)
 
@@ -197,6 +202,10 @@ class Instrument:
         ptr = bus.at(at_frame) if at_frame else bus.ptr
         _lib.check(self.ctx.L.groove_bank_render_mix(self.h, frames, ptr, 1 if accumulate else 0), self.ctx.h)
 
+    def reset(self):
+        """groove_bank_reset: every voice back to its freshly created state."""
+        _lib.check(self.ctx.L.groove_bank_reset(self.h), self.ctx.h)
+
     def download_state(self):
         w = self.ctx.L.groove_bank_state_words(self.h)
         out = np.empty((w, self.n), dtype=np.uint32)
@@ -254,6 +263,9 @@ class Effect:
 
     def set_params(self, params):
         _lib.check(self.ctx.L.groove_fx_set_params(self.h, params, len(params)), self.ctx.h)
+
+    def reset(self):
+        _lib.check(self.ctx.L.groove_fx_reset(self.h), self.ctx.h)
 
     def destroy(self):
         if self.h:

@@ -49,10 +49,12 @@ SYMBOLS = {
     "groove_block_acquire": (_i, [_vp]),
     "groove_block_release": (_i, [_vp]),
     "groove_bank_render_mix": (_i, [_vp, _u32, _vp, _i]),
+    "groove_bank_reset": (_i, [_vp]),
     "groove_bank_state_words": (_u32, [_vp]),
     "groove_bank_download_state": (_i, [_vp, C.POINTER(C.c_uint32)]),
     "groove_fx_create": (_i, [_vp, _u32, C.POINTER(T.FxParams), _u32, _vpp]),
     "groove_fx_destroy": (_i, [_vp]),
+    "groove_fx_reset": (_i, [_vp]),
     "groove_fx_process": (_i, [_vp, _vp, _u32]),
     "groove_fx_set_param": (_i, [_vp, _u32, _u32, _d]),
     "groove_fx_set_params": (_i, [_vp, C.POINTER(T.FxParams), _u32]),
@@ -65,6 +67,7 @@ SYMBOLS = {
     "groove_bus_to_i16": (_i, [_vp, _vp, C.c_size_t, C.POINTER(C.c_int16)]),
     "groove_comm_unique_id": (_i, [_vp, C.POINTER(C.c_uint8)]),
     "groove_comm_init": (_i, [_vp, C.POINTER(C.c_uint8), _i, _i]),
+    "groove_comm_ranks": (_i, [_vp, C.POINTER(C.c_int)]),
     "groove_comm_destroy": (_i, [_vp]),
     "groove_bus_reduce": (_i, [_vp, _vp, C.c_size_t, _i]),
 }

@@ -1,0 +1,229 @@
+"""The synthetic many-voice projects of SURVEY.md §8d, as functions of the PROJECT VOICE INDEX.
+
+A project is a set of voices 0 .. V-1; what voice i is (instrument kind, patch, key, when it
+starts) depends on i alone, so any subset of voices — a rank's contiguous shard
+(`groove_amd.parallel.voice_range`), or a sample picked for a parity check — renders exactly the
+frames those voices contribute to the whole project's bus.  `plan()` turns a workload name and an
+index set into plain data (parameter arrays, block-granular note events, effect-chain parameters);
+`Project` instantiates a plan on the GPU through the entity surface (`groove_amd.entities`), and
+the test-side `oracle/projects.py` instantiates the same plan on the CPU oracle.
+
+Workloads (BASELINE.json `configs`):
+    welsh-1m       1,000,000 Welsh voices, config-#2 voice rule            172 blocks of 256 frames
+    welsh-256      config #2                                               172 blocks
+    chain-4096     config #3: + BiQuad LP12 → Chorus → Delay → Reverb      172 blocks
+    sampler-16384  config #4: one-shots over the shared bank, staggered    344 blocks
+    mixed-131072   config #5: 50 % Welsh / 25 % FM / 25 % sampler          172 blocks
+Voice rules:
+    Welsh voice w: patch w mod 32, key 36 + (7 w mod 49), note-on at block 0, note-off at block 86;
+    FM voice f: patch f mod 16, same keys and timeline;
+    sampler voice s: buffer s mod 60, key 69 + (s mod 25) - 12, note-on at block h(s) mod 172,
+        h(s) = s * 2654435761 mod 2^32 (one-shot: never released);
+    mixed project voice i: i mod 4 in {0, 1} -> Welsh voice 2 (i div 4) + (i mod 4); 2 -> FM voice
+        i div 4; 3 -> sampler voice i div 4 (every contiguous range keeps the 50 / 25 / 25 mix).
+The timeline loops with the project's length.
+"""
+import numpy as np
+
+from . import abi_types as T
+from . import entities as E
+from . import patches as P
+
+FRAMES = T.BLOCK_FRAMES
+
+WORKLOADS = {
+    "welsh-1m": dict(voices=1_000_000, kind="welsh", bytes_per_vf=18.0, dominant_bytes=10.0, blocks=172),
+    "welsh-256": dict(voices=256, kind="welsh", bytes_per_vf=18.0, dominant_bytes=10.0, blocks=172),
+    "chain-4096": dict(voices=4096, kind="chain", bytes_per_vf=218.0, dominant_bytes=10.0, blocks=172),
+    "sampler-16384": dict(voices=16384, kind="sampler", bytes_per_vf=20.25, dominant_bytes=12.25, blocks=344),
+    "mixed-131072": dict(voices=131072, kind="mixed", bytes_per_vf=18.2, dominant_bytes=10.0, blocks=172),
+}
+NOTE_OFF_BLOCK = P.NOTE_OFF_FRAME // FRAMES  # 86
+
+
+def _take(table, ctype, idx):
+    """table[idx] as a ctypes array (vectorised)."""
+    import ctypes as C
+    size = C.sizeof(ctype)
+    raw = np.frombuffer(bytes(bytearray(table)), dtype=np.uint8).reshape(len(table), size)
+    out = np.ascontiguousarray(raw[np.asarray(idx, dtype=np.int64)])
+    return (ctype * len(idx)).from_buffer_copy(out.tobytes())
+
+
+def _keys(v):
+    return (36 + (7 * np.asarray(v, dtype=np.int64)) % 49).astype(np.uint8)
+
+
+def _lanes(n):
+    return np.arange(n, dtype=np.uint32)
+
+
+def split_kinds(workload, sel):
+    """Project voice indices `sel` -> {kind: within-kind voice numbers} (ascending)."""
+    sel = np.asarray(sel, dtype=np.int64)
+    kind = WORKLOADS[workload]["kind"]
+    if kind in ("welsh", "chain"):
+        return {"welsh": sel}
+    if kind == "sampler":
+        return {"sampler": sel}
+    r, q = sel % 4, sel // 4
+    return {"welsh": 2 * q[r < 2] + r[r < 2], "fm": q[r == 2], "sampler": q[r == 3]}
+
+
+def plan(workload, sel, grouped=True, bank_scale=1.0):
+    """The banks a shard of the project consists of, as plain data.  Returns a list of dicts:
+    kind, n, params (ctypes array in LANE order), voice (within-kind voice number of each lane),
+    events {block -> ctypes NoteEvent array}, fx [(kind, params)], and for samplers pcm / descs."""
+    wl = WORKLOADS[workload]
+    kinds = split_kinds(workload, sel)
+    out = []
+    w = kinds.get("welsh")
+    if w is not None and len(w):
+        if grouped:  # synth-major lane order: all voices of patch 0, then patch 1, ... (stable)
+            w = w[np.argsort(w % P.N_PATCHES, kind="stable")]
+        table = (T.WelshParams * P.N_PATCHES)(*[P.welsh_patch(j) for j in range(P.N_PATCHES)])
+        n = len(w)
+        bank = dict(kind="welsh", n=n, params=_take(table, T.WelshParams, w % P.N_PATCHES), voice=w, fx=[],
+                    events={0: T.note_events_np(_lanes(n), _keys(w), True),
+                            NOTE_OFF_BLOCK: T.note_events_np(_lanes(n), _keys(w), False)})
+        if wl["kind"] == "chain":
+            bank["fx"] = P.chain_fx_params(n, w)
+        out.append(bank)
+    f = kinds.get("fm")
+    if f is not None and len(f):
+        table = (T.FmParams * 16)(*[P.fm_patch(j) for j in range(16)])
+        n = len(f)
+        out.append(dict(kind="fm", n=n, params=_take(table, T.FmParams, f % 16), voice=f, fx=[],
+                        events={0: T.note_events_np(_lanes(n), _keys(f), True),
+                                NOTE_OFF_BLOCK: T.note_events_np(_lanes(n), _keys(f), False)}))
+    s = kinds.get("sampler")
+    if s is not None and len(s):
+        n = len(s)
+        pcm, descs, _ = P.drum_bank(scale=bank_scale)
+        raw = np.zeros(n, dtype=np.dtype([("sample_index", "<u4"), ("one_shot", "<u4"), ("gain", "<f4")]))
+        raw["sample_index"] = s % P.BANK_BUFFERS
+        raw["one_shot"] = 1
+        raw["gain"] = 1.0
+        params = (T.SamplerParams * n).from_buffer_copy(raw.tobytes())
+        keys = (69 + (s % 25) - 12).astype(np.uint8)
+        h = (s.astype(np.uint64) * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)
+        start = (h % np.uint64(172)).astype(np.int64)
+        events = {}
+        for b in np.unique(start):
+            lanes = np.nonzero(start == b)[0].astype(np.uint32)
+            events[int(b)] = T.note_events_np(lanes, keys[lanes], True)
+        out.append(dict(kind="sampler", n=n, params=params, voice=s, fx=[], events=events, pcm=pcm, descs=descs))
+    return out
+
+
+class Project:
+    """One shard of a synthetic project on one GPU: banks, blocks, effect chains and the block loop
+    (instruments render, their chains run, the mix bus sums: Orchestrator::tick / gather_audio,
+    /root/reference/orchestration/src/orchestrator.rs:856-877, 367-470)."""
+
+    def __init__(self, ctx, workload, sel, fused=True, grouped=True, render_ahead=True, bank_scale=1.0):
+        self.ctx, self.fused, self.workload = ctx, fused, workload
+        self.period = WORKLOADS[workload]["blocks"]
+        self.render_ahead = render_ahead  # instruments with an effect chain: render block b+1 beside the effects of block b
+        self.ahead = {}                   # instrument -> [current block, next block, spare] once primed
+        self.block_index = 0
+        self.n = int(len(sel))
+        self.banks = []  # (instrument, block, [effects], events)
+        for spec in plan(workload, sel, grouped, bank_scale):
+            if spec["kind"] == "welsh":
+                inst = E.WelshSynth(ctx, spec["params"])
+            elif spec["kind"] == "fm":
+                inst = E.FmSynth(ctx, spec["params"])
+            else:
+                inst = E.Sampler(ctx, spec["pcm"], spec["descs"], spec["params"])
+            fx = [E.Effect(ctx, k, p) for k, p in spec["fx"]]
+            block = ctx.block(spec["n"], FRAMES) if (fx or not fused) else None
+            self.banks.append((inst, block, fx, spec["events"]))
+        self.dominant = self.banks[0][0] if self.banks else None
+        self.has_chain = any(fx for _, _, fx, _ in self.banks)
+
+    def reset(self):
+        """Back to block 0 of the timeline with every voice and effect in its initial state."""
+        for inst, _, fx, _ in self.banks:
+            inst.reset()
+            for e in fx:
+                e.reset()
+        for blocks in self.ahead.values():
+            for b in blocks[1:]:
+                b.destroy()
+        self.ahead = {}
+        self.block_index = 0
+
+    def _events(self, block_index):
+        b = block_index % self.period
+        for inst, _, _, events in self.banks:
+            ev = events.get(b)
+            if ev is not None:
+                inst.handle_midi_events(ev)
+
+    def _step_render_ahead(self, bus, frame0, ev_pair):
+        """The same block walk, software-pipelined: the instruments' render of block b+1 goes to the
+        library's side streams (groove_bank_render_async) before the effect chains of block b are
+        submitted, three blocks per instrument in rotation.  Every step still submits one render, one
+        pass of every effect and one mix per instrument; the first call also renders block b itself."""
+        ctx = self.ctx
+        if ev_pair is not None and ev_pair[0] is not None:
+            ctx.record(ev_pair[0])
+        if not self.ahead:
+            self._events(self.block_index)
+            for inst, block, fx, _ in self.banks:
+                self.ahead[inst] = [block, ctx.block(inst.n, FRAMES), ctx.block(inst.n, FRAMES)]
+                inst.generate_batch_values_async(block, FRAMES)
+        self._events(self.block_index + 1)
+        self.block_index += 1
+        for inst, _, fx, _ in self.banks:
+            # the block this render fills was released a whole step ago: no cross-queue wait (groove_block_release)
+            inst.generate_batch_values_async(self.ahead[inst][1], FRAMES)
+        first = True
+        for inst, _, fx, _ in self.banks:
+            cur = self.ahead[inst][0]
+            for e in fx:
+                e.transform_audio(cur, FRAMES)
+            ctx.mix([cur], FRAMES, E._Slice(bus, frame0), accumulate=not first)
+            cur.release()
+            self.ahead[inst] = self.ahead[inst][1:] + [cur]
+            first = False
+        if ev_pair is not None and ev_pair[1] is not None:
+            ctx.record(ev_pair[1])
+
+    def step(self, bus, frame0, ev_pair=None):
+        """One block: every instrument renders, its effect chain runs, the mix bus sums."""
+        ctx = self.ctx
+        if self.render_ahead and self.has_chain:
+            return self._step_render_ahead(bus, frame0, ev_pair)
+        self._events(self.block_index)
+        self.block_index += 1
+        first = True
+        for inst, block, fx, _ in self.banks:
+            if ev_pair is not None and ev_pair[0] is not None and inst is self.dominant:
+                ctx.record(ev_pair[0])
+            if self.fused and not fx:
+                inst.render_mix(bus, FRAMES, accumulate=not first, at_frame=frame0)
+                if ev_pair is not None and ev_pair[1] is not None and inst is self.banks[-1][0]:
+                    ctx.record(ev_pair[1])  # fused steps are bracketed whole: after the last bank's bus sum
+            else:
+                inst.generate_batch_values(block, FRAMES)
+                if ev_pair is not None and ev_pair[1] is not None and inst is self.dominant:
+                    ctx.record(ev_pair[1])
+                for e in fx:
+                    e.transform_audio(block, FRAMES)
+                ctx.mix([block], FRAMES, E._Slice(bus, frame0), accumulate=not first)
+            first = False
+
+    def destroy(self):
+        for blocks in self.ahead.values():
+            for b in blocks[1:]:
+                b.destroy()
+        self.ahead = {}
+        for inst, block, fx, _ in self.banks:
+            for e in fx:
+                e.destroy()
+            inst.destroy()
+            if block is not None:
+                block.destroy()
+        self.banks = []

@@ -123,6 +123,12 @@ int groove_block_release(groove_block* b);
  * business (a bank whose patches are interleaved voice by voice is kept patch-major): every index in
  * this API is the caller's voice index. */
 int groove_bank_render_mix(groove_bank* bank, uint32_t frames, float* bus_dev, int accumulate);
+/* Every voice back to its freshly created state (oscillator phases, envelopes idle, filter memory,
+ * sampler cursors); parameters stay; queued note events are dropped.  What the reference gets by
+ * re-running a project from the top: Orchestrator::skip_to_start (orchestrator.rs:971-983) followed by
+ * the Configurable::update_sample_rate fan-out that resets every entity (orchestrator.rs:125-127) —
+ * without re-deriving or re-uploading the parameter tables. */
+int groove_bank_reset(groove_bank* bank);
 /* Raw state snapshot (checkpoint / debugging): words = groove_bank_state_words(). */
 uint32_t groove_bank_state_words(groove_bank* bank);
 int groove_bank_download_state(groove_bank* bank, uint32_t* host_words /* [words][n] */);
@@ -131,6 +137,8 @@ int groove_bank_download_state(groove_bank* bank, uint32_t* host_words /* [words
 /* `Foo::new_with(&FooParams)` for n lanes (settings/src/effects.rs:59-117).  p has n entries. */
 int groove_fx_create(groove_ctx* ctx, uint32_t kind, const groove_fx_params* p, uint32_t n, groove_fx** out);
 int groove_fx_destroy(groove_fx* fx);
+/* Clears the effect's memory (IIR state, delay lines, ring positions); parameters stay. */
+int groove_fx_reset(groove_fx* fx);
 /* TransformsAudio::transform_audio over a block, in place (orchestrator.rs:438-457). */
 int groove_fx_process(groove_fx* fx, groove_block* inout, uint32_t frames);
 /* Controllable for effects; lane = GROOVE_ALL_VOICES for all lanes. */
@@ -158,6 +166,9 @@ int groove_bus_to_i16(groove_ctx* ctx, const float* bus_dev, size_t frames, int1
  * (fp32) onto `root` with one RCCL reduce over xGMI. */
 int groove_comm_unique_id(groove_ctx* ctx, uint8_t id_out[128]);
 int groove_comm_init(groove_ctx* ctx, const uint8_t id[128], int rank, int world_size);
+/* Ranks that joined the communicator (ncclCommCount); 1 when no communicator has been set up.  The
+ * launcher checks it against the number of GPUs it asked for (bench.py: `rccl_ranks`). */
+int groove_comm_ranks(groove_ctx* ctx, int* out_ranks);
 int groove_comm_destroy(groove_ctx* ctx);
 int groove_bus_reduce(groove_ctx* ctx, float* bus_dev, size_t frames_total, int root);
 

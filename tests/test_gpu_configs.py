@@ -1,0 +1,142 @@
+"""GPU tier: BASELINE.json configs #3, #4 and #5 at their FULL sizes, through the C ABI.
+
+  config #5  mixed-131072   the three banks into one bus exactly as bench.py builds them (groove_amd.projects):
+                            the whole project on one GPU == the sum of the eight 16,384-voice shards
+                            voice_range(131072, r, 8) (the multi-GPU partition), and a voice sample of every
+                            kind against the oracle over the whole 172-block timeline;
+  config #3  chain-4096     4,096 lanes with the real per-voice chain parameters, 100 blocks (the 11,025-frame
+                            chorus line and the 4,410-frame delay line both wrap), 64 sampled lanes against
+                            the oracle, and the render-ahead walk of bench.py against the plain walk;
+  config #4  sampler-16384  the full-size bank, starts staggered by the hash rule, 344 blocks: sampled lanes
+                            bit-exact, fused bus against the oracle's sum of all 16,384 voices.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from groove_amd import abi_types as T, projects as PJ
+from groove_amd.parallel import voice_range
+
+pytestmark = pytest.mark.gpu
+FR = 256
+
+
+def _render(ctx, workload, sel, blocks, **kw):
+    proj = PJ.Project(ctx, workload, sel, **kw)
+    bus = ctx.bus(blocks * FR)
+    for b in range(blocks):
+        proj.step(bus, b * FR)
+    out = bus.download().astype(np.float64)
+    proj.destroy()
+    bus.destroy()
+    return out
+
+
+def test_config5_mixed_131072_shards_and_sampled_parity(gpu_ctx, oracle):
+    from oracle.projects import OracleProject
+    V, blocks = 131072, 172
+    whole = _render(gpu_ctx, "mixed-131072", np.arange(V), blocks)
+    assert np.isfinite(whole).all() and np.abs(whole).max() / V > 1e-3
+    acc = np.zeros_like(whole)
+    for r in range(8):
+        lo, hi = voice_range(V, r, 8)
+        assert hi - lo == 16384
+        acc += _render(gpu_ctx, "mixed-131072", np.arange(lo, hi), blocks)
+    assert np.max(np.abs(acc - whole)) / V <= 1e-6, "sum of the eight shards differs from the single-GPU project"
+    # a sample spread over the whole index range, every kind in it (stride 1021 is odd: i mod 4 cycles)
+    sel = np.arange(0, V, 1021)[:128]
+    kinds = PJ.split_kinds("mixed-131072", sel)
+    assert min(len(kinds["welsh"]), len(kinds["fm"]), len(kinds["sampler"])) >= 24
+    got = _render(gpu_ctx, "mixed-131072", sel, blocks) / len(sel)
+    want = OracleProject("mixed-131072", sel).render(blocks) / len(sel)
+    rms = np.sqrt(np.mean((got - want) ** 2))
+    assert np.sqrt(np.mean(want ** 2)) > 1e-3 and rms <= 1e-5, rms
+    # and per kind (a kind's error must not hide behind the others' signal)
+    for kind_sel in (sel[sel % 4 < 2], sel[sel % 4 == 2], sel[sel % 4 == 3]):
+        g = _render(gpu_ctx, "mixed-131072", kind_sel, 60) / len(kind_sel)
+        w = OracleProject("mixed-131072", kind_sel).render(60) / len(kind_sel)
+        assert np.sqrt(np.mean((g - w) ** 2)) <= 1e-5
+
+
+def test_config3_chain_4096_full_size(gpu_ctx, oracle):
+    from groove_amd import entities as E
+    V, blocks = 4096, 100   # 25,600 frames: the chorus line (11,025) and the delay line (4,410) wrap
+    spec = PJ.plan("chain-4096", np.arange(V))[0]
+    synth = E.WelshSynth(gpu_ctx, spec["params"])
+    fx = [E.Effect(gpu_ctx, k, p) for k, p in spec["fx"]]
+    block = gpu_ctx.block(V, FR)
+    bus = gpu_ctx.bus(blocks * FR)
+    lanes = np.arange(64) * 64 + 17   # 64 sampled lanes across the patch-major lane order
+    sub = (T.WelshParams * 64)(*[spec["params"][int(i)] for i in lanes])
+    ob = oracle.Bank.welsh(sub)
+    ofx = []
+    for k, p in spec["fx"]:
+        ofx.append(oracle.Fx(k, (T.FxParams * 64)(*[p[int(i)] for i in lanes])))
+    keys = np.array([e.key for e in spec["events"][0]], dtype=np.uint8)
+    worst = 0.0
+    for b in range(blocks):
+        for blk, on in ((0, True), (PJ.NOTE_OFF_BLOCK, False)):
+            if b == blk:
+                synth.handle_midi_events(spec["events"][blk])
+                ob.note_events(T.note_events_np(np.arange(64, dtype=np.uint32), keys[lanes], on))
+        synth.generate_batch_values(block, FR)
+        for e in fx:
+            e.transform_audio(block, FR)
+        gpu_ctx.mix([block], FR, E._Slice(bus, b * FR))
+        want = ob.render(FR)
+        for e in ofx:
+            e.process(want)
+        got = block.download(FR)[:, :, lanes].astype(np.float64)
+        err = np.sqrt(np.mean((got - want) ** 2, axis=(0, 1)))   # per-lane RMS over the block
+        worst = max(worst, float(err.max()))
+        # the bus is the lane sum of the block (fixed-order fp32 reduction)
+        if b in (0, 43, 44, 99):
+            full = block.download(FR).astype(np.float64)
+            assert np.max(np.abs(bus.download()[b * FR:(b + 1) * FR].astype(np.float64) - full.sum(axis=2).T)) / V <= 1e-6
+    assert worst <= 1e-5, worst
+    plain = bus.download().astype(np.float64)
+    assert np.abs(plain[12000:]).max() > np.abs(plain[:256]).max() * 0.01  # the delayed taps do sound
+    for e in fx:
+        e.destroy()
+    synth.destroy(); block.destroy(); bus.destroy()
+    # bench.py's software-pipelined walk (render of block b+1 beside the effects of block b) gives the same bus
+    ahead = _render(gpu_ctx, "chain-4096", np.arange(V), blocks)
+    assert np.array_equal(ahead.astype(np.float32).view(np.uint32), plain.astype(np.float32).view(np.uint32))
+
+
+def test_config4_sampler_16384_full_size(gpu_ctx, oracle):
+    from groove_amd import entities as E
+    from oracle.projects import OracleProject
+    V, blocks = 16384, 344
+    spec = PJ.plan("sampler-16384", np.arange(V))[0]
+    assert sum(d.length for d in spec["descs"]) > 2_700_000   # the real bank's size class
+    assert len(spec["events"]) == 172
+    # fused form (what bench.py times) against the oracle's sum of ALL voices
+    fused = _render(gpu_ctx, "sampler-16384", np.arange(V), blocks)
+    op = OracleProject("sampler-16384", np.arange(V))
+    want = np.concatenate([op.step(threads=8) for _ in range(blocks)], axis=0)
+    assert np.abs(want).max() > 10.0
+    assert np.max(np.abs(fused - want)) / V <= 1e-6 and np.sqrt(np.mean((fused - want) ** 2)) / V <= 1e-7
+    # materialised form: sampled lanes bit-exact (the fetch is exact, the gain is 1)
+    s = E.Sampler(gpu_ctx, spec["pcm"], spec["descs"], spec["params"])
+    block = gpu_ctx.block(V, FR)
+    lanes = (np.arange(96) * 167 + 5) % V
+    ob = oracle.Bank.sampler(spec["pcm"], spec["descs"], (T.SamplerParams * 96)(*[spec["params"][int(i)] for i in lanes]))
+    pos = {int(l): k for k, l in enumerate(lanes)}
+    checked = 0
+    for b in range(blocks):
+        ev = spec["events"].get(b % 172) if b < 172 else None
+        if ev is not None:
+            s.handle_midi_events(ev)
+            mine = [(pos[int(e.voice)], int(e.key), True) for e in ev if int(e.voice) in pos]
+            if mine:
+                ob.note_events(T.note_events(mine))
+        s.generate_batch_values(block, FR)
+        ref = ob.render(FR)
+        if b % 7 == 0 or b < 8:
+            got = block.download(FR)[:, :, lanes]
+            assert np.array_equal(got, ref.astype(np.float32)), b
+            checked += 1
+    assert checked > 50
+    s.destroy(); block.destroy()

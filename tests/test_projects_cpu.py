@@ -1,0 +1,103 @@
+"""CPU tier: the synthetic projects as data (groove_amd/projects.py `plan`) and bench.py's launcher.
+
+  * every project voice index lands in exactly one bank lane, whatever the shard cut;
+  * a shard's plan is the restriction of the whole project's plan (same patch / key / start block per voice);
+  * the oracle instantiation of two shards sums to the oracle render of the whole (what the N > 1 path relies on);
+  * `bench.py --gpus 2 --dry-launch` starts two ranks that rendezvous (gloo) without touching a GPU.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from groove_amd import projects as PJ, patches as P, abi_types as T
+from groove_amd.parallel import voice_range
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_workload_table_matches_baseline_configs():
+    assert PJ.WORKLOADS["welsh-256"]["voices"] == 256
+    assert PJ.WORKLOADS["chain-4096"]["voices"] == 4096
+    assert PJ.WORKLOADS["sampler-16384"]["voices"] == 16384 and PJ.WORKLOADS["sampler-16384"]["blocks"] == 344
+    assert PJ.WORKLOADS["mixed-131072"]["voices"] == 131072
+    assert PJ.WORKLOADS["welsh-1m"]["voices"] == 1_000_000
+
+
+def test_mixed_split_keeps_the_mix_in_every_contiguous_range():
+    V = 131072
+    for r in range(8):
+        lo, hi = voice_range(V, r, 8)
+        k = PJ.split_kinds("mixed-131072", np.arange(lo, hi))
+        assert (len(k["welsh"]), len(k["fm"]), len(k["sampler"])) == (8192, 4096, 4096)
+    whole = PJ.split_kinds("mixed-131072", np.arange(V))
+    parts = [PJ.split_kinds("mixed-131072", np.arange(*voice_range(V, r, 8))) for r in range(8)]
+    for kind in ("welsh", "fm", "sampler"):
+        assert np.array_equal(np.sort(np.concatenate([p[kind] for p in parts])), whole[kind])
+        assert np.array_equal(whole[kind], np.arange(len(whole[kind])))  # within-kind voice numbers are dense
+
+
+def _voice_table(spec):
+    """{within-kind voice number: (parameter bytes, events as (block, key, on))}"""
+    import ctypes as C
+    size = C.sizeof(spec["params"]._type_)
+    raw = bytes(memoryview(spec["params"]))
+    ev = {}
+    for b, arr in spec["events"].items():
+        for e in arr:
+            ev.setdefault(int(e.voice), []).append((b, int(e.key), int(e.on)))
+    return {int(v): (raw[i * size:(i + 1) * size], tuple(sorted(ev.get(i, [])))) for i, v in enumerate(spec["voice"])}
+
+
+@pytest.mark.parametrize("workload,V", [("welsh-256", 256), ("sampler-16384", 2048), ("mixed-131072", 4096)])
+def test_shard_plans_are_restrictions_of_the_whole(workload, V):
+    whole = {s["kind"]: _voice_table(s) for s in PJ.plan(workload, np.arange(V), bank_scale=0.01)}
+    seen = {k: {} for k in whole}
+    for r in range(3):
+        lo, hi = voice_range(V, r, 3)
+        for s in PJ.plan(workload, np.arange(lo, hi), bank_scale=0.01):
+            t = _voice_table(s)
+            assert not (set(t) & set(seen[s["kind"]]))
+            seen[s["kind"]].update(t)
+    assert seen == whole
+
+
+def test_sampler_start_blocks_follow_the_hash_rule():
+    spec = PJ.plan("sampler-16384", np.arange(512), bank_scale=0.01)[0]
+    start = P.sampler_start_block(512)
+    for b, arr in spec["events"].items():
+        lanes = sorted(int(e.voice) for e in arr)
+        assert lanes == sorted(np.nonzero(start == b)[0].tolist())
+        assert all(e.on == 1 and e.key == 69 + (int(e.voice) % 25) - 12 for e in arr)
+    assert sum(len(a) for a in spec["events"].values()) == 512
+
+
+def test_oracle_shards_sum_to_the_whole_project(oracle):
+    from oracle.projects import OracleProject
+    V, blocks = 96, 3
+    whole = OracleProject("mixed-131072", np.arange(V), bank_scale=0.02).render(blocks)
+    acc = np.zeros_like(whole)
+    for r in range(2):
+        acc += OracleProject("mixed-131072", np.arange(*voice_range(V, r, 2)), bank_scale=0.02).render(blocks)
+    assert np.abs(whole).max() > 0.1
+    assert np.max(np.abs(acc - whole)) <= 1e-9
+
+
+def test_bench_dry_launch_starts_two_ranks():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-launch"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["dry_launch"] is True and line["ranks"] == 2 and line["world"] == 2
+    assert line["voice_ranges"] == [[0, 500000], [500000, 1000000]]
+
+
+def test_bench_refuses_a_world_size_that_is_not_the_gpu_count():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--dry-launch"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in (p.stderr + p.stdout)

@@ -10,7 +10,8 @@ import time
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
-import bench  # noqa: E402
+import numpy as np  # noqa: E402
+from groove_amd import projects as PJ  # noqa: E402
 from groove_amd import entities as E  # noqa: E402
 
 
@@ -21,15 +22,15 @@ def main():
     ap.add_argument("--no-render-ahead", action="store_true")
     a = ap.parse_args()
     ctx = E.Context(0)
-    V = bench.WORKLOADS[a.workload]["voices"]
-    proj = bench.Project(ctx, a.workload, 0, V, True, render_ahead=not a.no_render_ahead)
-    bus = ctx.bus((a.steps + 8) * bench.FRAMES)
+    V = PJ.WORKLOADS[a.workload]["voices"]
+    proj = PJ.Project(ctx, a.workload, np.arange(V, dtype=np.int64), True, render_ahead=not a.no_render_ahead)
+    bus = ctx.bus((a.steps + 8) * PJ.FRAMES)
     for s in range(8):
-        proj.step(bus, s * bench.FRAMES)
+        proj.step(bus, s * PJ.FRAMES)
     ctx.synchronize()
     t0 = time.perf_counter()
     for s in range(a.steps):
-        proj.step(bus, (8 + s) * bench.FRAMES)
+        proj.step(bus, (8 + s) * PJ.FRAMES)
     t1 = time.perf_counter()
     ctx.synchronize()
     t2 = time.perf_counter()
