@@ -153,13 +153,21 @@ def committed_profile(workload):
     return out
 
 
+def spread_sample(v_total, count):
+    """`count` project voice indices spread over [0, v_total) with an ODD stride, so that the sample meets every
+    residue of the voice rules' moduli (32 patches, 16 FM patches, 4 kinds, 60 buffers ...)."""
+    count = min(count, v_total)
+    stride = max(1, v_total // count)
+    stride -= 1 - (stride & 1) if stride > 1 else 0
+    return np.unique((np.arange(count, dtype=np.int64) * stride + stride // 2) % v_total)
+
+
 def sampled_parity(ctx, workload, v_total, blocks, sample=64, fused=True, grouped=True):
     """Bus RMS error (normalised by the sample size) of `sample` voices of the project, spread over its
     whole index range, rendered by the product path and by the CPU oracle over the first `blocks`
     blocks of the timeline.  Outside every timed region."""
     from oracle.projects import OracleProject
-    sample = min(sample, v_total)
-    sel = np.unique((np.arange(sample, dtype=np.int64) * (v_total // sample)) + (v_total // sample) // 2)
+    sel = spread_sample(v_total, sample)
     proj = PJ.Project(ctx, workload, sel, fused=fused, grouped=grouped)
     bus = ctx.bus(blocks * FRAMES)
     for b in range(blocks):
@@ -168,8 +176,12 @@ def sampled_parity(ctx, workload, v_total, blocks, sample=64, fused=True, groupe
     proj.destroy()
     bus.destroy()
     want = OracleProject(workload, sel, grouped=grouped).render(blocks) / len(sel)
-    return {"voices_sampled": int(len(sel)), "blocks": blocks,
-            "bus_rms_err": float(np.sqrt(np.mean((got - want) ** 2))), "signal_rms": float(np.sqrt(np.mean(want ** 2))),
+    rms = float(np.sqrt(np.mean((got - want) ** 2)))
+    peak = float(np.abs(want).max())
+    return {"voices_sampled": int(len(sel)), "blocks": blocks, "normalisation": "bus / voices sampled",
+            "bus_rms_err": rms, "signal_rms": float(np.sqrt(np.mean(want ** 2))), "signal_peak": peak,
+            # an effect chain with gain (config #3: chorus taps + recirculating combs) lifts signal and error alike
+            "bus_rms_err_rel_full_scale": rms / max(1.0, peak),
             "max_abs_err": float(np.max(np.abs(got - want)))}
 
 
@@ -180,7 +192,8 @@ def cpu_baseline(workload, seconds_target=15.0):
     from oracle.projects import OracleProject
     V = WORKLOADS[workload]["voices"]
     sample_voices = min(V, 1024)
-    sel = np.arange(sample_voices, dtype=np.int64) * (V // sample_voices)
+    sel = spread_sample(V, sample_voices)
+    sample_voices = len(sel)
     op = OracleProject(workload, sel)
     t0 = time.perf_counter()
     op.step()
@@ -193,14 +206,14 @@ def cpu_baseline(workload, seconds_target=15.0):
     vf_per_s = sample_voices * FRAMES * blocks / el
     out = {
         "value": vf_per_s / V, "unit": "stereo frames/s", "cores": 1, "kind": "port",
-        "sample": f"{sample_voices} of {V} voices (every {V // sample_voices}th) x {blocks} blocks of {FRAMES} frames from block 1 of the "
+        "sample": f"{sample_voices} of {V} voices (spread over the project, odd stride) x {blocks} blocks of {FRAMES} frames from block 1 of the "
                   f"timeline, f64 scalar oracle -O2, 1 thread; frames/s scaled by {sample_voices}/{V} "
                   f"(measured {vf_per_s:.3e} voice-frames/s)",
     }
     cores = int(O.lib().oracle_hardware_concurrency()) or 1
     if WORKLOADS[workload]["kind"] in ("welsh", "mixed", "sampler"):  # mode B: voices sharded over all host cores
         mt_voices = min(V, 64 * cores)
-        mp_ = OracleProject(workload, np.arange(mt_voices, dtype=np.int64) * (V // mt_voices))
+        mp_ = OracleProject(workload, spread_sample(V, mt_voices))
         mp_.step(threads=cores)
         mt_blocks = int(max(2, min(512, 0.3 * seconds_target * vf_per_s * min(cores, 16) / (mt_voices * FRAMES))))
         t0 = time.perf_counter()

@@ -13,7 +13,8 @@ ALL_VOICES = 0xFFFFFFFF
 WAVE_NONE, WAVE_SINE, WAVE_SQUARE, WAVE_PULSE_WIDTH, WAVE_TRIANGLE, WAVE_SAWTOOTH, WAVE_NOISE, \
     WAVE_DEBUG_ZERO, WAVE_DEBUG_MAX, WAVE_DEBUG_MIN, WAVE_TRIANGLE_SINE = range(11)
 # groove_lfo_routing
-LFO_NONE, LFO_AMPLITUDE, LFO_PITCH, LFO_PULSE_WIDTH, LFO_FILTER_CUTOFF = range(5)
+LFO_NONE, LFO_AMPLITUDE, LFO_PITCH, LFO_PULSE_WIDTH, LFO_FILTER_CUTOFF, LFO_PITCH_OSC2, LFO_PW_OSC1, LFO_PW_OSC2, \
+    LFO_RESONANCE, LFO_CUTOFF_AMP = range(10)
 # groove_fx_kind
 FX_GAIN, FX_BITCRUSHER, FX_BIQUAD_LP12, FX_BIQUAD_LP24, FX_CHORUS, FX_DELAY, FX_REVERB, FX_MIXER, \
     FX_BIQUAD_HP12, FX_LIMITER, FX_COMPRESSOR, FX_BIQUAD_BP12, FX_BIQUAD_BS12, FX_BIQUAD_AP12, FX_BIQUAD_PEAK12, \

@@ -52,6 +52,7 @@ inline WelshParams derive_welsh(const groove_welsh_params& p, double sr, WelshCo
   const uint32_t w1 = p.oscillator_1.waveform & 15u, w2 = p.oscillator_2.waveform & 15u;
   o.flags = (w1 << WF_O1_WAVE_SHIFT) | (w2 << WF_O2_WAVE_SHIFT) |
             ((p.lfo_waveform & 15u) << WF_LFO_WAVE_SHIFT) | ((p.lfo_routing & 15u) << WF_ROUTING_SHIFT);
+  o.flags |= lfo_routing_bits(p.lfo_routing & 15u);
   if (p.oscillator_2_sync) o.flags |= WF_SYNC;
   if (p.filter_cutoff_end != 0.0f) o.flags |= WF_RETUNE_ENV;
   if (p.oscillator_2.fixed_hz > 0.0) o.flags |= WF_O2_FIXED;
@@ -72,13 +73,15 @@ inline WelshParams derive_welsh(const groove_welsh_params& p, double sr, WelshCo
     const bool tri = wl == GROOVE_WAVE_TRIANGLE || wl == GROOVE_WAVE_TRIANGLE_SINE;
     // largest per-frame change of the LFO value: |D| for a sine, 4 |inc| (in turns) for a triangle
     const double dl = wl == GROOVE_WAVE_SINE ? fabs(D) : 4.0 * fabs((double)(int64_t)o.lfo_inc * 5.42101086242752217004e-20);
+    const uint32_t rb = lfo_routing_bits(r);
     if ((wl == GROOVE_WAVE_SINE || tri) &&
-        (r == GROOVE_LFO_PULSE_WIDTH || (r == GROOVE_LFO_PITCH && fabs(o.lfo_a) * dl <= 1.5e-3)))
+        ((rb & WF_LFO_PW) || ((rb & WF_LFO_PITCH) && fabs(o.lfo_a) * dl <= 1.5e-3)))
       o.flags |= WF_LFO_SMOOTH;
   }
   o.amp = derive_env(p.amp_envelope, sr);
   o.fil = derive_env(p.filter_envelope, sr);
   o.fc = derive_lp24_consts((double)p.filter_passband_ripple);
+  o.ripple = p.filter_passband_ripple;
   o.cutoff_hz = p.filter_cutoff_hz;
   o.cutoff_start = p.filter_cutoff_start;
   o.cutoff_end = p.filter_cutoff_end;

@@ -409,8 +409,27 @@ GROOVE_HD double lp24_step(Lp24StateD& s, const Lp24CoefD& c, double x) {
 enum : uint32_t {
   WF_O1_WAVE_SHIFT = 0, WF_O2_WAVE_SHIFT = 4, WF_LFO_WAVE_SHIFT = 8, WF_ROUTING_SHIFT = 12,
   WF_SYNC = 1u << 16, WF_RETUNE_ENV = 1u << 17, WF_O2_FIXED = 1u << 18,
-  WF_LFO_SMOOTH = 1u << 19 // host promise: the f64 LFO may be advanced by recurrences (see welsh_frame)
+  WF_LFO_SMOOTH = 1u << 19, // host promise: the f64 LFO may be advanced by recurrences (see welsh_frame)
+  // What the LFO drives, decoded from the routing once on the host (derive_welsh) so that every per-frame
+  // test is one bit: pitch- or pulse-width-like (the edge-moving routings) and which oscillators they
+  // reach, amplitude, cutoff percent, passband ripple.
+  WF_LFO_PITCH = 1u << 20, WF_LFO_PW = 1u << 21, WF_LFO_O1 = 1u << 22, WF_LFO_O2 = 1u << 23,
+  WF_LFO_AMP = 1u << 24, WF_LFO_CUTOFF = 1u << 25, WF_LFO_RESO = 1u << 26
 };
+GROOVE_HD uint32_t lfo_routing_bits(uint32_t routing) {
+  switch (routing) {
+    case GROOVE_LFO_AMPLITUDE: return WF_LFO_AMP;
+    case GROOVE_LFO_PITCH: return WF_LFO_PITCH | WF_LFO_O1 | WF_LFO_O2;
+    case GROOVE_LFO_PITCH_OSC2: return WF_LFO_PITCH | WF_LFO_O2;
+    case GROOVE_LFO_PULSE_WIDTH: return WF_LFO_PW | WF_LFO_O1 | WF_LFO_O2;
+    case GROOVE_LFO_PW_OSC1: return WF_LFO_PW | WF_LFO_O1;
+    case GROOVE_LFO_PW_OSC2: return WF_LFO_PW | WF_LFO_O2;
+    case GROOVE_LFO_FILTER_CUTOFF: return WF_LFO_CUTOFF;
+    case GROOVE_LFO_CUTOFF_AMP: return WF_LFO_CUTOFF | WF_LFO_AMP;
+    case GROOVE_LFO_RESONANCE: return WF_LFO_RESO;
+    default: return 0u;
+  }
+}
 struct WelshParams {
   uint32_t flags;
   float mix;
@@ -421,6 +440,7 @@ struct WelshParams {
   float cutoff_hz; // static cutoff
   EnvParams amp, fil;
   Lp24Consts fc;   // filter constants
+  float ripple;    // passband ripple r itself (resonance routing: the constants are recomputed from r (1 + l depth))
   float cutoff_start, cutoff_end;
   float gl, gr;    // dca gain * pan law, per channel
   // LFO recurrence constants (host, f64): with D = 2 pi lfo_inc / 2^64 the per-frame rotation is
@@ -448,7 +468,17 @@ struct WelshScratch {
   double lm;       // LFO_F64_SMOOTH, pitch routing: 2^(ls * depth)
 };
 GROOVE_HD bool welsh_retunes(const WelshParams& p) {
-  return (p.flags & WF_RETUNE_ENV) || (((p.flags >> WF_ROUTING_SHIFT) & 15u) == GROOVE_LFO_FILTER_CUTOFF);
+  return (p.flags & (WF_RETUNE_ENV | WF_LFO_CUTOFF | WF_LFO_RESO)) != 0;
+}
+// Filter constants from the passband ripple r on the device (fp32): the resonance routing moves r every
+// frame.  sinh / cosh from one exp; r stays below ~22 (denormalize_q(1) (1 + depth)), far from overflow.
+GROOVE_HD Lp24Consts lp24_consts_from_ripple(float r) {
+  const float e = fast_exp2(r * 1.4426950408889634f), ie = fast_rcp(e);
+  const float sg = 0.5f * (e - ie), ch = 0.5f * (e + ie), cg = ch * ch;
+  Lp24Consts c;
+  c.c0 = fast_rcp(cg - 0.85355339059327376220f); c.d1 = c.c0 * sg * 1.84775906502257351226f;
+  c.c2 = fast_rcp(cg - 0.14644660940672623780f); c.d3 = c.c2 * sg * 0.76536686473017954346f;
+  return c;
 }
 
 // How the LFO is evaluated.  LFO_F32: promise that no lane routes the LFO to Pitch or PulseWidth,
@@ -462,8 +492,10 @@ GROOVE_HD bool welsh_retunes(const WelshParams& p) {
 // ~1e-16 (tests/test_emul_numerics.py checks the result against the oracle).
 enum : int { LFO_F32 = 0, LFO_F64 = 1, LFO_F64_SMOOTH = 2 };
 GROOVE_HD int welsh_lfo_mode(const WelshParams& p) {
-  const uint32_t r = (p.flags >> WF_ROUTING_SHIFT) & 15u;
-  if (r != GROOVE_LFO_PITCH && r != GROOVE_LFO_PULSE_WIDTH) return LFO_F32;
+  // the resonance routing (per-frame sinh / cosh) is only compiled into the exact-f64 retuned kind: rare, and
+  // it keeps the other five kinds free of its code and registers
+  if (p.flags & WF_LFO_RESO) return LFO_F64;
+  if (!(p.flags & (WF_LFO_PITCH | WF_LFO_PW))) return LFO_F32;
   return (p.flags & WF_LFO_SMOOTH) ? LFO_F64_SMOOTH : LFO_F64;
 }
 
@@ -489,7 +521,7 @@ GROOVE_HD int osc_class_of(uint32_t waveform) {
   }
 }
 GROOVE_HD int lfo_class_of(uint32_t waveform, uint32_t routing) {
-  if (routing == GROOVE_LFO_NONE) return waveform == GROOVE_WAVE_NOISE ? (int)OSC_ANY : (int)LFO_UNUSED;
+  if (lfo_routing_bits(routing) == 0u) return waveform == GROOVE_WAVE_NOISE ? (int)OSC_ANY : (int)LFO_UNUSED;
   return osc_class_of(waveform);
 }
 template <int CLS>
@@ -536,12 +568,20 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
   // LFO class: an unused LFO has no routing; a classed LFO in a static-filter f32 kind can only be
   // routed to the amplitude (cutoff routing retunes, pitch / pulse width are other LFO modes)
   const uint32_t wl = CL == LFO_UNUSED ? (uint32_t)GROOVE_WAVE_NONE : osc_class_wave<CL>((p.flags >> WF_LFO_WAVE_SHIFT) & 15u);
-  const uint32_t routing = CL == LFO_UNUSED ? (uint32_t)GROOVE_LFO_NONE
-                         : (CL != OSC_ANY && LFO_MODE == LFO_F32 && !RETUNE) ? (uint32_t)GROOVE_LFO_AMPLITUDE
-                         : (p.flags >> WF_ROUTING_SHIFT) & 15u;
-  // LFO_F64_SMOOTH is only ever chosen for an LFO routed to pitch or pulse width (welsh_lfo_mode): the
-  // other routings' tests below are compile-time false there (each is a scalar branch per frame otherwise)
+  // What the LFO drives (WF_LFO_* bits).  Three promises turn the bit tests into constants: an unused LFO
+  // drives nothing; a classed LFO in a static-filter f32 kind can only be routed to the amplitude (cutoff and
+  // resonance routings retune, pitch / pulse width are other LFO modes); LFO_F64_SMOOTH is only ever chosen
+  // for an LFO routed to pitch or pulse width (welsh_lfo_mode).  The resonance routing exists in the exact-f64
+  // retuned kind only.
+  constexpr bool NO_LFO = CL == LFO_UNUSED;
+  constexpr bool AMP_ONLY = !NO_LFO && CL != OSC_ANY && LFO_MODE == LFO_F32 && !RETUNE;
   constexpr bool EDGE_ONLY = LFO_MODE == LFO_F64_SMOOTH;
+  constexpr bool RESO = LFO_MODE == LFO_F64 && RETUNE;
+  const uint32_t fl = p.flags;
+  const bool r_edge = NO_LFO || AMP_ONLY || LFO_MODE == LFO_F32 ? false : (EDGE_ONLY ? true : (fl & (WF_LFO_PITCH | WF_LFO_PW)) != 0);
+  const bool r_amp = NO_LFO || EDGE_ONLY ? false : (AMP_ONLY ? true : (fl & WF_LFO_AMP) != 0);
+  const bool r_cut = NO_LFO || EDGE_ONLY || AMP_ONLY || !RETUNE ? false : (fl & WF_LFO_CUTOFF) != 0;
+  const bool r_res = RESO && !NO_LFO ? (fl & WF_LFO_RESO) != 0 : false;
   const bool first = FIRST && (s.vflags & VF_FIRST);
   if (FIRST) s.vflags = 0;
 
@@ -553,7 +593,7 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
   uint64_t inc1 = s.o1_inc, inc2 = s.o2_inc;
   uint64_t d1 = p.o1_duty64, d2 = p.o2_duty64;
   float lfo = 0.0f;
-  if (EDGE_ONLY || (LFO_MODE != LFO_F32 && (routing == GROOVE_LFO_PITCH || routing == GROOVE_LFO_PULSE_WIDTH))) {
+  if (r_edge) {
     constexpr bool SMOOTH = LFO_MODE == LFO_F64_SMOOTH;
     double l;
     if (SMOOTH && !FIRST && wl == GROOVE_WAVE_SINE) { // one rotation step (an idle voice never gets here: see above)
@@ -564,21 +604,21 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
       if (SMOOTH && FIRST && wl == GROOVE_WAVE_SINE) // cos(2 pi x) = sin(2 pi (x + 1/4))
         sc.lc = sin_turns_folded_f64((double)fold_quarter64((int64_t)(s.lfo.phase + 0x4000000000000000ull)) * 5.42101086242752217004e-20);
     }
-    if (routing == GROOVE_LFO_PITCH) {
+    if (fl & WF_LFO_PITCH) {
       double m;
       if (SMOOTH && !FIRST) m = sc.lm * exp_tiny_f64((l - sc.ls) * p.lfo_a);
       else m = exp2_small_f64(l * (double)p.lfo_depth);
       if (SMOOTH) sc.lm = m;
-      inc1 = f64_to_u64((double)inc1 * m);
-      inc2 = f64_to_u64((double)inc2 * m); // fm applies to a fixed-frequency osc too
+      if (fl & WF_LFO_O1) inc1 = f64_to_u64((double)inc1 * m);
+      if (fl & WF_LFO_O2) inc2 = f64_to_u64((double)inc2 * m); // fm applies to a fixed-frequency osc too
     } else {
       const double ld = l * (double)p.lfo_depth;
-      d1 = f64_to_u64(clamp01d((double)p.o1_duty * (1.0 + ld)) * 18446744073709549568.0);
-      d2 = f64_to_u64(clamp01d((double)p.o2_duty * (1.0 + ld)) * 18446744073709549568.0);
+      if (fl & WF_LFO_O1) d1 = f64_to_u64(clamp01d((double)p.o1_duty * (1.0 + ld)) * 18446744073709549568.0);
+      if (fl & WF_LFO_O2) d2 = f64_to_u64(clamp01d((double)p.o2_duty * (1.0 + ld)) * 18446744073709549568.0);
     }
     if (SMOOTH) sc.ls = l;
     lfo = (float)l;
-  } else if (routing != GROOVE_LFO_NONE) {
+  } else if (r_amp || r_cut || r_res) {
     lfo = osc_value(wl, s.lfo.phase, half, nzl);
   }
 
@@ -606,11 +646,15 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
     if (CL == LFO_UNUSED || (p.flags & WF_RETUNE_ENV)) {
       pct = fmaf((1.0f - p.cutoff_start) * p.cutoff_end, s.fil.value, p.cutoff_start);
       retune = true;
-    } else if (!EDGE_ONLY && routing == GROOVE_LFO_FILTER_CUTOFF) {
+    } else if (r_cut) {
       pct = p.cutoff_start * fmaf(lfo, p.lfo_depth, 1.0f);
       retune = true;
     }
-    if (retune && pct != sc.prev_pct) { // unchanged percent (e.g. envelope plateau): coefficients stand
+    if (RESO && r_res) { // the ripple moves every frame: constants and coefficients are recomputed
+      const Lp24Consts c = lp24_consts_from_ripple(p.ripple * fmaf(lfo, p.lfo_depth, 1.0f));
+      const float fc = retune ? 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f) : p.cutoff_hz;
+      sc.coef = lp24_coefd_from_fc(c, fc, rc.pi_over_sr, rc.fc_max);
+    } else if (retune && pct != sc.prev_pct) { // unchanged percent (e.g. envelope plateau): coefficients stand
       const float fc = 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f); // 25 * 800^pct
       sc.coef = lp24_coefd_from_fc(p.fc, fc, rc.pi_over_sr, rc.fc_max);
       sc.prev_pct = pct;
@@ -618,7 +662,7 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
   }
   const float y = (float)lp24_step<SEGMENT && !RETUNE>(s.filt, sc.coef, (double)sum); // uniform static kinds: coefficients in SGPRs
   float a = s.amp.value;
-  if (!EDGE_ONLY && routing == GROOVE_LFO_AMPLITUDE) a *= fmaf(lfo, p.lfo_depth, 1.0f);
+  if (r_amp) a *= fmaf(lfo, p.lfo_depth, 1.0f);
   const float m = y * a;
   L = m * p.gl;
   R = m * p.gr;

@@ -78,8 +78,7 @@ struct groove_bank {
   size_t wg_list_cap = 0;
   uint32_t wgs_of_kind[kWgKinds] = {};  // slice lengths of d_wg_list, in kind order
   float* d_pcm = nullptr;   // sampler bank
-  groove_note_event* d_ev = nullptr;
-  size_t ev_cap = 0;
+  groove_note_event* d_ev[2] = {nullptr, nullptr};
   // pinned staging of queued note events, two slots in rotation: flush_events hands the events to the ctx
   // stream and returns without a host synchronisation (a project with note events in every block would
   // otherwise serialise host and GPU once per block)
@@ -428,18 +427,18 @@ int bank_alloc(groove_bank* b) {
 }
 
 // Launch one note-event round resident at ev[0..count) on the device.
-int launch_events(groove_bank* b, const groove_note_event* ev, uint32_t count, int all_event) {
+int launch_events(groove_bank* b, const groove_note_event* ev, uint32_t count, int all_event, hipStream_t st) {
   groove_ctx* ctx = b->ctx;
   const uint32_t items = all_event >= 0 ? b->n : count;
   const dim3 grid(blocks_for(items)), blk(kThreads);
   if (b->kind == BANK_WELSH)
-    hipLaunchKernelGGL(welsh_events_kernel, grid, blk, 0, ctx->stream, ev, count, all_event, b->d_params,
+    hipLaunchKernelGGL(welsh_events_kernel, grid, blk, 0, st, ev, count, all_event, b->d_params,
                        b->d_state, b->d_cold, b->n, (double)ctx->sr);
   else if (b->kind == BANK_FM)
-    hipLaunchKernelGGL(fm_events_kernel, grid, blk, 0, ctx->stream, ev, count, all_event, b->d_params,
+    hipLaunchKernelGGL(fm_events_kernel, grid, blk, 0, st, ev, count, all_event, b->d_params,
                        b->d_state, b->d_cold, b->n, (double)ctx->sr);
   else
-    hipLaunchKernelGGL(sampler_events_kernel, grid, blk, 0, ctx->stream, ev, count, all_event, b->d_params,
+    hipLaunchKernelGGL(sampler_events_kernel, grid, blk, 0, st, ev, count, all_event, b->d_params,
                        b->d_state, b->n);
   GHIP(ctx, hipGetLastError());
   return 0;
@@ -450,40 +449,50 @@ int launch_events(groove_bank* b, const groove_note_event* ev, uint32_t count, i
 int flush_events(groove_bank* b) {
   if (b->pending.empty()) return 0;
   groove_ctx* ctx = b->ctx;
-  b->ctx_touched = true;
-  if (ctx_join(ctx)) return 1;
+  // Which stream applies the events.  A bank whose renders all run on ONE side stream (side_mode 2: FM,
+  // sampler, small or per-lane Welsh banks in the asynchronous forms) and whose state the ctx stream has not
+  // touched since gets its events on that same stream: they are ordered with its renders, nothing else reads
+  // its state, and the other banks' streams never notice (a project with note events in every block —
+  // config #4's staggered starts inside config #5 — would otherwise join and re-fork every stream once per
+  // block: mixed-131072 0.229 -> 0.13 ms per block).  Otherwise: the ctx stream, after joining the side streams.
+  hipStream_t st = ctx->stream;
+  const bool own_stream = b->side_mode == 2 && !b->ctx_touched;
+  if (own_stream) {
+    st = side_stream_of(ctx, b->stream_slot);
+    ctx->side_busy[b->stream_slot] = true;
+  } else {
+    b->ctx_touched = true;
+    if (ctx_join(ctx)) return 1;
+  }
   // caller's voice index -> internal lane, into a copy: a failure below leaves `pending` as it was queued,
   // so the next flush maps it exactly once
   std::vector<groove_note_event> ev = b->pending;
   if (!b->inv.empty())
     for (groove_note_event& e : ev)
       if (e.voice != GROOVE_ALL_VOICES) e.voice = b->inv[e.voice];
-  if (b->ev_cap < ev.size()) {
-    GHIP(ctx, hipStreamSynchronize(ctx->stream)); // earlier event kernels may still read the old buffer
-    if (b->d_ev) GHIP(ctx, hipFree(b->d_ev));
-    b->ev_cap = std::max<size_t>(ev.size() * 2, 1024);
-    GHIP(ctx, hipMalloc(&b->d_ev, b->ev_cap * sizeof(groove_note_event)));
-  }
+  // Device and pinned host staging, two slots each in rotation: the events of this flush are handed to the
+  // stream and the call returns without a host synchronisation.
   const int hs = b->ev_slot;
   b->ev_slot ^= 1;
   if (b->staged[hs]) GHIP(ctx, hipEventSynchronize(b->ev_staged[hs])); // two flushes ago: long done
   if (b->h_ev_cap[hs] < ev.size()) {
     if (b->h_ev[hs]) GHIP(ctx, hipHostFree(b->h_ev[hs]));
+    if (b->d_ev[hs]) GHIP(ctx, hipFree(b->d_ev[hs]));
     b->h_ev_cap[hs] = std::max<size_t>(ev.size() * 2, 1024);
     GHIP(ctx, hipHostMalloc(&b->h_ev[hs], b->h_ev_cap[hs] * sizeof(groove_note_event), hipHostMallocDefault));
+    GHIP(ctx, hipMalloc(&b->d_ev[hs], b->h_ev_cap[hs] * sizeof(groove_note_event)));
   }
   if (!b->ev_staged[hs]) GHIP(ctx, hipEventCreateWithFlags(&b->ev_staged[hs], hipEventDisableTiming));
   std::memcpy(b->h_ev[hs], ev.data(), ev.size() * sizeof(groove_note_event));
-  GHIP(ctx, hipMemcpyAsync(b->d_ev, b->h_ev[hs], ev.size() * sizeof(groove_note_event), hipMemcpyHostToDevice, ctx->stream));
-  GHIP(ctx, hipEventRecord(b->ev_staged[hs], ctx->stream));
-  b->staged[hs] = true;
+  groove_note_event* d_ev = b->d_ev[hs];
+  GHIP(ctx, hipMemcpyAsync(d_ev, b->h_ev[hs], ev.size() * sizeof(groove_note_event), hipMemcpyHostToDevice, st));
   // fast path: strictly increasing voices, no ALL events → one round
   bool sorted = true;
   for (size_t i = 0; i < ev.size(); ++i) {
     if (ev[i].voice == GROOVE_ALL_VOICES || (i && ev[i].voice <= ev[i - 1].voice)) { sorted = false; break; }
   }
   if (sorted) {
-    if (launch_events(b, b->d_ev, (uint32_t)ev.size(), -1)) return 1;
+    if (launch_events(b, d_ev, (uint32_t)ev.size(), -1, st)) return 1;
   } else {
     // general path: contiguous runs; a run ends at an ALL event or at a repeated voice
     std::vector<uint32_t> seen_round(b->n, 0);
@@ -491,12 +500,12 @@ int flush_events(groove_bank* b) {
     size_t start = 0;
     auto launch_run = [&](size_t lo, size_t hi) -> int {
       if (hi <= lo) return 0;
-      return launch_events(b, b->d_ev + lo, (uint32_t)(hi - lo), -1);
+      return launch_events(b, d_ev + lo, (uint32_t)(hi - lo), -1, st);
     };
     for (size_t i = 0; i < ev.size(); ++i) {
       if (ev[i].voice == GROOVE_ALL_VOICES) {
         if (launch_run(start, i)) return 1;
-        if (launch_events(b, b->d_ev, (uint32_t)ev.size(), (int)i)) return 1;
+        if (launch_events(b, d_ev, (uint32_t)ev.size(), (int)i, st)) return 1;
         start = i + 1; ++round;
       } else if (ev[i].voice < b->n) {
         if (seen_round[ev[i].voice] == round) {
@@ -508,6 +517,8 @@ int flush_events(groove_bank* b) {
     }
     if (launch_run(start, ev.size())) return 1;
   }
+  GHIP(ctx, hipEventRecord(b->ev_staged[hs], st));
+  b->staged[hs] = true;
   b->pending.clear(); // (the device reads the pinned copy, not this vector)
   return 0;
 }
@@ -856,6 +867,10 @@ static int bank_finish_create(groove_bank* b, groove_bank** out) {
 int groove_welsh_create(groove_ctx* ctx, const groove_welsh_params* p, uint32_t n, groove_bank** out) {
   if (!ctx || !p || !out) return fail(ctx, "groove_welsh_create: NULL argument");
   if (n == 0) return fail(ctx, "groove_welsh_create: n == 0");
+  for (uint32_t v = 0; v < n; ++v) // every kernel form must see the same, canonical enumerators
+    if (p[v].oscillator_1.waveform >= GROOVE_WAVEFORM_COUNT || p[v].oscillator_2.waveform >= GROOVE_WAVEFORM_COUNT ||
+        p[v].lfo_waveform >= GROOVE_WAVEFORM_COUNT || p[v].lfo_routing >= GROOVE_LFO_ROUTING_COUNT)
+      return fail(ctx, "groove_welsh_create: waveform or LFO routing enumerator out of range (voice " + std::to_string(v) + ")");
   groove_bank* b = new groove_bank();
   b->ctx = ctx; b->kind = BANK_WELSH; b->n = n;
   b->pw = sizeof(WelshParams) / 4; b->sw = sizeof(WelshState) / 4;
@@ -911,7 +926,7 @@ int groove_bank_destroy(groove_bank* b) {
   if (b->scratch) groove_block_destroy(b->scratch);
   if (b->ev_gather) (void)hipEventDestroy(b->ev_gather);
   for (int k = 0; k < 2; ++k) { if (b->h_ev[k]) (void)hipHostFree(b->h_ev[k]); if (b->ev_staged[k]) (void)hipEventDestroy(b->ev_staged[k]); }
-  (void)hipFree(b->d_params); (void)hipFree(b->d_state); (void)hipFree(b->d_cold); (void)hipFree(b->d_pcm); (void)hipFree(b->d_ev); (void)hipFree(b->d_waves); (void)hipFree(b->d_wg_list); (void)hipFree(b->d_wg_cls); (void)hipFree(b->d_wg_base); (void)hipFree(b->d_inv);
+  (void)hipFree(b->d_params); (void)hipFree(b->d_state); (void)hipFree(b->d_cold); (void)hipFree(b->d_pcm); (void)hipFree(b->d_ev[0]); (void)hipFree(b->d_ev[1]); (void)hipFree(b->d_waves); (void)hipFree(b->d_wg_list); (void)hipFree(b->d_wg_cls); (void)hipFree(b->d_wg_base); (void)hipFree(b->d_inv);
   delete b;
   return 0;
 }
@@ -1265,6 +1280,7 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
     GHIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_render_done[k][slot], 0));
     ctx->side_busy[k] = true;
   }
+  b->ctx_touched = false; // the bank's stream(s) have waited for whatever the ctx stream did to its state (ev_fork above)
   if (segs == 1) { // small bank: the one segment's column sums are the bus frames
     hipLaunchKernelGGL(partial_rows_kernel, dim3(blocks_for(cols), 1), blk, 0, ctx->stream, b->d_pipe_part[slot], rows, cols,
                        rows_per_seg, b->d_pipe_seg[slot], bus_dev, accumulate);

@@ -98,7 +98,7 @@ groove_welsh_params welsh_params_from_patch_json(const json5::Value& patch, std:
   const int note2 = parse_tune(o2 ? o2->get("tune") : nullptr, p.oscillator_2.tune);
   const bool track2 = patch.bool_or("oscillator-2-track", true);
   if (p.oscillator_2.waveform != GROOVE_WAVE_NONE && !track2) {
-    if (note2 < 0) throw std::runtime_error("Patch configured without oscillator 2 tracking, but tune is not a note specification");
+    if (note2 < 0) throw std::runtime_error("patch has oscillator-2-track = false, so oscillator 2 needs a fixed pitch, but its tune is not given as a note");
     p.oscillator_2.fixed_hz = note_to_frequency(note2); // patches.rs:94-100
   }
   p.oscillator_2_sync = patch.bool_or("oscillator-2-sync", false) ? 1 : 0;
@@ -124,12 +124,15 @@ groove_welsh_params welsh_params_from_patch_json(const json5::Value& patch, std:
   else if (routing == "pitch") p.lfo_routing = GROOVE_LFO_PITCH;
   else if (routing == "pulse-width") p.lfo_routing = GROOVE_LFO_PULSE_WIDTH;
   else if (routing == "filter-cutoff") p.lfo_routing = GROOVE_LFO_FILTER_CUTOFF;
-  else { // shipped patches also carry routings LfoRoutingType does not know
-    if (routing.compare(0, 5, "pitch") == 0) p.lfo_routing = GROOVE_LFO_PITCH;
-    else if (routing.compare(0, 2, "pw") == 0) p.lfo_routing = GROOVE_LFO_PULSE_WIDTH;
-    else if (routing.compare(0, 6, "cutoff") == 0) p.lfo_routing = GROOVE_LFO_FILTER_CUTOFF;
-    else p.lfo_routing = GROOVE_LFO_NONE;
-    if (warnings) warnings->push_back("lfo routing '" + routing + "' is not in LfoRoutingType; mapped to the nearest supported routing");
+  // the shipped patches also carry routings LfoRoutingType does not know yet (docs/DSP_SPEC.md §6)
+  else if (routing == "pitch-osc2") p.lfo_routing = GROOVE_LFO_PITCH_OSC2;
+  else if (routing == "pw-osc1") p.lfo_routing = GROOVE_LFO_PW_OSC1;
+  else if (routing == "pw-osc2") p.lfo_routing = GROOVE_LFO_PW_OSC2;
+  else if (routing == "resonance") p.lfo_routing = GROOVE_LFO_RESONANCE;
+  else if (routing == "cutoff-amp") p.lfo_routing = GROOVE_LFO_CUTOFF_AMP;
+  else { // not a routing at all (one shipped file carries a spreadsheet note in this field)
+    p.lfo_routing = GROOVE_LFO_NONE;
+    if (warnings) warnings->push_back("lfo routing '" + routing + "' is not a routing; the LFO is left unrouted");
   }
   p.lfo_depth = 0.0f;
   if (lfo) {
@@ -416,6 +419,27 @@ const std::pair<int, const char*> k707[] = {
     {45, "Tom 2 R1.wav"}, {46, "Hat Open R1.wav"}, {47, "Tom 2 R1.wav"}, {48, "Tom 3 R1.wav"}, {49, "Crash R1.wav"},
     {50, "Tom 3 R1.wav"}, {51, "Ride R1.wav"}, {54, "Tambourine R1.wav"}, {56, "Cowbell R1.wav"}};
 
+// --synthetic-kit: a decaying tone + noise per drum key, deterministic; stands in for the CC0 707 samples
+// on boxes without the assets directory (the GPU box, the tests).
+void synthetic_707_kit(uint32_t sample_rate, std::vector<float>& pcm, std::vector<groove_sample_desc>& descs, int key_to_sample[128]) {
+  pcm.clear(); descs.clear();
+  for (int k = 0; k < 128; ++k) key_to_sample[k] = -1;
+  for (auto& km : k707) {
+    const uint32_t len = 12000 + 900 * (uint32_t)(km.first % 13);
+    std::vector<float> one(len);
+    uint32_t lcg = 12345u + (uint32_t)km.first;
+    for (uint32_t i = 0; i < len; ++i) {
+      lcg = lcg * 1664525u + 1013904223u;
+      const double env = std::exp(-(double)i / (0.08 * sample_rate));
+      one[i] = (float)(env * (0.7 * std::sin(2.0 * 3.14159265358979 * (50.0 + 4.0 * km.first) * i / sample_rate) +
+                              0.2 * ((double)(lcg >> 8) / 8388608.0 - 1.0)));
+    }
+    groove_sample_desc sd{(uint64_t)pcm.size(), (uint32_t)one.size(), 0.0f};
+    key_to_sample[km.first] = (int)descs.size();
+    descs.push_back(sd);
+    pcm.insert(pcm.end(), one.begin(), one.end());
+  }
+}
 extern "C" int gh_add_drumkit(void*, const float*, uint64_t, const groove_sample_desc*, uint32_t, const int*);
 extern "C" int gh_add_welsh(void*, const groove_welsh_params*, uint32_t);
 extern "C" int gh_add_fm(void*, const groove_fm_params*, uint32_t);
@@ -438,27 +462,19 @@ int instantiate(Orchestrator& o, const ProjectDesc& p, const std::string& assets
       std::vector<groove_sample_desc> descs;
       int key_to_sample[128];
       for (int& k : key_to_sample) k = -1;
-      for (auto& km : k707) {
-        std::vector<float> one;
-        if (synthetic_kit) { // decaying tone + noise, deterministic; stands in for the CC0 707 samples on boxes without assets
-          const uint32_t len = 12000 + 900 * (uint32_t)(km.first % 13);
-          one.resize(len);
-          uint32_t lcg = 12345u + (uint32_t)km.first;
-          for (uint32_t i = 0; i < len; ++i) {
-            lcg = lcg * 1664525u + 1013904223u;
-            const double env = std::exp(-(double)i / (0.08 * o.sample_rate()));
-            one[i] = (float)(env * (0.7 * std::sin(2.0 * 3.14159265358979 * (50.0 + 4.0 * km.first) * i / o.sample_rate()) +
-                                    0.2 * ((double)(lcg >> 8) / 8388608.0 - 1.0)));
-          }
-        } else {
+      if (synthetic_kit) {
+        synthetic_707_kit(o.sample_rate(), pcm, descs, key_to_sample);
+      } else {
+        for (auto& km : k707) {
+          std::vector<float> one;
           std::string err;
           uint32_t sr = 0;
           if (!read_wav_mono(assets_root + "/samples/elphnt.io/707/" + km.second, one, &sr, &err)) return o.fail(err);
+          groove_sample_desc sd{(uint64_t)pcm.size(), (uint32_t)one.size(), 0.0f};
+          key_to_sample[km.first] = (int)descs.size();
+          descs.push_back(sd);
+          pcm.insert(pcm.end(), one.begin(), one.end());
         }
-        groove_sample_desc sd{(uint64_t)pcm.size(), (uint32_t)one.size(), 0.0f};
-        key_to_sample[km.first] = (int)descs.size();
-        descs.push_back(sd);
-        pcm.insert(pcm.end(), one.begin(), one.end());
       }
       uid = gh_add_drumkit(&o, pcm.data(), pcm.size(), descs.data(), (uint32_t)descs.size(), key_to_sample);
     } else {
@@ -546,6 +562,22 @@ int gh_welsh_params_from_patch_json(const char* text, groove_welsh_params* out, 
     if (err && err_len) { std::strncpy(err, e.what(), err_len - 1); err[err_len - 1] = 0; }
     return 1;
   }
+}
+// The --synthetic-kit sample bank as data (no GPU): pcm_out may be NULL to ask for the sizes only.
+int gh_synthetic_kit(uint32_t sample_rate, float* pcm_out, uint64_t pcm_cap, groove_sample_desc* descs_out, uint32_t descs_cap,
+                     int* key_to_sample /*[128]*/, uint64_t* pcm_frames, uint32_t* n_descs) {
+  std::vector<float> pcm;
+  std::vector<groove_sample_desc> descs;
+  int k2s[128];
+  synthetic_707_kit(sample_rate, pcm, descs, k2s);
+  if (pcm_frames) *pcm_frames = pcm.size();
+  if (n_descs) *n_descs = (uint32_t)descs.size();
+  if (!pcm_out) return 0;
+  if (pcm_cap < pcm.size() || descs_cap < descs.size() || !descs_out || !key_to_sample) return 1;
+  std::memcpy(pcm_out, pcm.data(), pcm.size() * sizeof(float));
+  std::memcpy(descs_out, descs.data(), descs.size() * sizeof(groove_sample_desc));
+  std::memcpy(key_to_sample, k2s, sizeof(k2s));
+  return 0;
 }
 // Load a project into an existing orchestrator (GPU).
 int gh_load_project(void* h, const char* path, const char* assets_root, int synthetic_kit) {

@@ -33,11 +33,24 @@ def load():
         "gh_control_step_value": (d, [i, d, d, d]), "gh_last_allocated_voice": (i, [vp, i]),
         "gh_gather_audio": (i, [vp, u32, _fp]), "gh_performance_frames": (C.c_uint64, [vp]),
         "gh_run": (C.c_int64, [vp, u32, _fp, C.c_uint64, i]), "gh_render_to_wav": (i, [vp, u32, C.c_char_p]),
+        "gh_synthetic_kit": (i, [u32, _fp, C.c_uint64, C.POINTER(T.SampleDesc), u32, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(u32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
         fn.restype, fn.argtypes = res, args
     return L
+
+
+def synthetic_kit(sample_rate=T.DEFAULT_SAMPLE_RATE):
+    """The sample bank `groove-cli-hip --synthetic-kit` builds (data only, no GPU): (pcm, descs, key_to_sample)."""
+    L = load()
+    frames, nd = C.c_uint64(), C.c_uint32()
+    assert L.gh_synthetic_kit(sample_rate, None, 0, None, 0, None, C.byref(frames), C.byref(nd)) == 0
+    pcm = np.empty(frames.value, dtype=np.float32)
+    descs = (T.SampleDesc * nd.value)()
+    k2s = (C.c_int * 128)()
+    assert L.gh_synthetic_kit(sample_rate, pcm.ctypes.data_as(_fp), pcm.size, descs, nd.value, k2s, None, None) == 0
+    return pcm, descs, list(k2s)
 
 
 class Orchestrator:

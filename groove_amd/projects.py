@@ -125,7 +125,8 @@ class Project:
         self.ctx, self.fused, self.workload = ctx, fused, workload
         self.period = WORKLOADS[workload]["blocks"]
         self.render_ahead = render_ahead  # instruments with an effect chain: render block b+1 beside the effects of block b
-        self.ahead = {}                   # instrument -> [current block, next block, spare] once primed
+        self.ahead = {}                   # instrument -> [current block, next block, spare] (rotating), created on first use
+        self.primed = False               # the current block's render has been submitted
         self.block_index = 0
         self.n = int(len(sel))
         self.banks = []  # (instrument, block, [effects], events)
@@ -148,10 +149,7 @@ class Project:
             inst.reset()
             for e in fx:
                 e.reset()
-        for blocks in self.ahead.values():
-            for b in blocks[1:]:
-                b.destroy()
-        self.ahead = {}
+        self.primed = False  # (the three blocks per instrument stay)
         self.block_index = 0
 
     def _events(self, block_index):
@@ -169,11 +167,13 @@ class Project:
         ctx = self.ctx
         if ev_pair is not None and ev_pair[0] is not None:
             ctx.record(ev_pair[0])
-        if not self.ahead:
+        if not self.primed:
             self._events(self.block_index)
             for inst, block, fx, _ in self.banks:
-                self.ahead[inst] = [block, ctx.block(inst.n, FRAMES), ctx.block(inst.n, FRAMES)]
-                inst.generate_batch_values_async(block, FRAMES)
+                if inst not in self.ahead:
+                    self.ahead[inst] = [block, ctx.block(inst.n, FRAMES), ctx.block(inst.n, FRAMES)]
+                inst.generate_batch_values_async(self.ahead[inst][0], FRAMES)
+            self.primed = True
         self._events(self.block_index + 1)
         self.block_index += 1
         for inst, _, fx, _ in self.banks:
@@ -216,14 +216,12 @@ class Project:
             first = False
 
     def destroy(self):
-        for blocks in self.ahead.values():
-            for b in blocks[1:]:
-                b.destroy()
-        self.ahead = {}
         for inst, block, fx, _ in self.banks:
             for e in fx:
                 e.destroy()
             inst.destroy()
-            if block is not None:
-                block.destroy()
+            for b in self.ahead.get(inst, [block]):  # the rotation holds the bank's own block too
+                if b is not None:
+                    b.destroy()
+        self.ahead = {}
         self.banks = []

@@ -35,14 +35,23 @@ typedef enum {
   GROOVE_WAVE_TRIANGLE_SINE = 10 /* "triangle-sine"                             */
 } groove_waveform;
 
-/* LfoRoutingType, settings/src/patches.rs:269-290. */
+/* LfoRoutingType, settings/src/patches.rs:269-290 (values 0-4), plus the routings the shipped Welsh
+ * patch files carry that the enum does not know yet (the files under assets/patches/welsh, field "routing": "pitch-osc2",
+ * "pw-osc1", "pw-osc2", "resonance", "cutoff-amp").  docs/DSP_SPEC.md §6 defines them. */
 typedef enum {
   GROOVE_LFO_NONE = 0,
   GROOVE_LFO_AMPLITUDE = 1,
   GROOVE_LFO_PITCH = 2,
   GROOVE_LFO_PULSE_WIDTH = 3,
-  GROOVE_LFO_FILTER_CUTOFF = 4
+  GROOVE_LFO_FILTER_CUTOFF = 4,
+  GROOVE_LFO_PITCH_OSC2 = 5,  /* "pitch-osc2": frequency modulation of oscillator 2 only          */
+  GROOVE_LFO_PW_OSC1 = 6,     /* "pw-osc1":    pulse width of oscillator 1 only                   */
+  GROOVE_LFO_PW_OSC2 = 7,     /* "pw-osc2":    pulse width of oscillator 2 only                   */
+  GROOVE_LFO_RESONANCE = 8,   /* "resonance":  the 24 dB filter's passband ripple, every frame    */
+  GROOVE_LFO_CUTOFF_AMP = 9   /* "cutoff-amp": filter cutoff and amplitude together               */
 } groove_lfo_routing;
+#define GROOVE_LFO_ROUTING_COUNT 10
+#define GROOVE_WAVEFORM_COUNT 11
 
 /* EnvelopeParams{attack, decay, sustain, release}, settings/src/patches.rs:133-138.
  * Times are SECONDS (the unit the shipped patch JSON carries, e.g.

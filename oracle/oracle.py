@@ -74,6 +74,9 @@ def _bind(lib):
         "oracle_graph_patch": (i, [vp, i, i]), "oracle_graph_unpatch_all": (None, [vp]),
         "oracle_graph_note_events": (None, [vp, i, C.POINTER(T.NoteEvent), u32]),
         "oracle_graph_gather": (None, [vp, u32, _dp]),
+        "oracle_graph_set_bpm": (None, [vp, d]), "oracle_graph_skip_to_start": (None, [vp]),
+        "oracle_graph_add_control_trip": (i, [vp, i, u32, d]), "oracle_graph_trip_add_step": (i, [vp, i, i, d, d, d]),
+        "oracle_control_step_value": (d, [i, d, d, d]), "oracle_graph_tick": (None, [vp, u32, _dp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -237,6 +240,29 @@ class Graph:
     def gather(self, frames):
         bus = np.zeros((frames, 2), dtype=np.float64)
         self.L.oracle_graph_gather(self.h, frames, _dptr(bus))
+        return bus
+
+    # automation (ControlTrip) and the block loop (Orchestrator::tick)
+    STEP_FLAT, STEP_SLOPE, STEP_LOGARITHMIC, STEP_EXPONENTIAL = range(4)
+
+    def set_bpm(self, bpm):
+        self.L.oracle_graph_set_bpm(self.h, bpm)
+
+    def skip_to_start(self):
+        self.L.oracle_graph_skip_to_start(self.h)
+
+    def add_control_trip(self, target_uid, control_index, start_beat=0.0):
+        t = self.L.oracle_graph_add_control_trip(self.h, target_uid, control_index, start_beat)
+        assert t >= 0
+        return t
+
+    def trip_add_step(self, trip, kind, start, end, beats):
+        assert self.L.oracle_graph_trip_add_step(self.h, trip, kind, start, end, beats) == 0
+
+    def tick(self, frames):
+        """One block: trips' values at the block start → effect parameters, gather, clock += frames."""
+        bus = np.zeros((frames, 2), dtype=np.float64)
+        self.L.oracle_graph_tick(self.h, frames, _dptr(bus))
         return bus
 
     def __del__(self):

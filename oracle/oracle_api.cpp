@@ -51,10 +51,52 @@ struct Node {
   Effect fx;                      // effect
   std::vector<int> sources;       // audio_sink_uid_to_source_uids
 };
+// ControlTrip (entities/src/controllers/control_trip.rs:7-26: the step shapes; :99-142 add_path: a step
+// covers [cursor, cursor + path_multiplier) beats and interpolates start → end by its function;
+// :184-254 work: the value is sent to the target whenever it changed).  The GPU path applies automation
+// once per block (Orchestrator::tick, orchestrator.rs:856-859: handle_work once, then gather_audio over
+// the whole buffer), with the value the trip has at the block's first frame — restated here the same way.
+struct TripStep { int kind; double start, end, beats; };
+struct Trip {
+  int target; uint32_t index; double start_beat;
+  std::vector<TripStep> steps;
+  double last_sent = -1.0;
+};
 struct Graph {
   double sr;
   std::vector<Node> nodes; // uid = index; uid 0 = main mixer
+  double bpm = 128.0;
+  uint64_t clock_frames = 0;
+  std::vector<Trip> trips;
 };
+// Value of one step at t in [0, 1]: Flat, Slope (linear), Logarithmic (fast first: the MMA convex
+// transform of the ramp), Exponential (slow first: the MMA concave transform); docs/DSP_SPEC.md §7.
+double trip_step_value(int kind, double start, double end, double t) {
+  t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+  switch (kind) {
+    case 0: return start;
+    case 1: return start + (end - start) * t;
+    case 2: return start + (end - start) * mma_convex(t);
+    case 3: return start + (end - start) * mma_concave(t);
+    default: return start;
+  }
+}
+// Controllable::control_set_param_by_index for an effect: ControlValue 0..1 → the parameter's own unit
+// (include/groove_types.h groove_control_index).
+void effect_set_control(Effect& fx, uint32_t index, double v) {
+  v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+  switch (index) {
+    case GROOVE_CTL_FX_CEILING: fx.p.ceiling = (float)v; break;
+    case GROOVE_CTL_FX_BITS: fx.p.bits = (uint32_t)(v * 16.0); break;
+    case GROOVE_CTL_FX_CUTOFF: fx.p.cutoff_hz = (float)percent_to_frequency(v); break;
+    case GROOVE_CTL_FX_Q: fx.p.q = (float)denormalize_q(v); break;
+    case GROOVE_CTL_FX_PASSBAND_RIPPLE: fx.p.passband_ripple = (float)denormalize_q(v); break;
+    case GROOVE_CTL_FX_ATTENUATION: fx.p.attenuation = (float)v; break;
+    case GROOVE_CTL_FX_WET: fx.p.wet = (float)v; break;
+    default: return;
+  }
+  fx.retune();
+}
 
 } // namespace
 
@@ -325,6 +367,49 @@ void oracle_graph_note_events(void* h, int uid, const groove_note_event* ev, uin
   if (uid > 0 && uid < (int)g->nodes.size() && g->nodes[uid].bank)
     for (uint32_t i = 0; i < n_ev; ++i) g->nodes[uid].bank->note(ev[i]);
 }
+// ---- automation + the block loop (Orchestrator::tick, orchestrator.rs:856-877)
+void oracle_graph_set_bpm(void* h, double bpm) { ((Graph*)h)->bpm = bpm; }
+void oracle_graph_skip_to_start(void* h) {
+  Graph* g = (Graph*)h;
+  g->clock_frames = 0;
+  for (auto& t : g->trips) t.last_sent = -1.0;
+}
+int oracle_graph_add_control_trip(void* h, int target_uid, uint32_t control_index, double start_beat) {
+  Graph* g = (Graph*)h;
+  if (target_uid <= 0 || target_uid >= (int)g->nodes.size() || g->nodes[target_uid].type != Node::EFFECT) return -1;
+  g->trips.push_back(Trip{target_uid, control_index, start_beat, {}, -1.0});
+  return (int)g->trips.size() - 1;
+}
+int oracle_graph_trip_add_step(void* h, int trip, int kind, double start, double end, double beats) {
+  Graph* g = (Graph*)h;
+  if (trip < 0 || trip >= (int)g->trips.size() || !(beats > 0.0)) return -1;
+  g->trips[trip].steps.push_back(TripStep{kind, start, end, beats});
+  return 0;
+}
+double oracle_control_step_value(int kind, double start, double end, double t) { return trip_step_value(kind, start, end, t); }
+void oracle_graph_gather(void* h, uint32_t frames, double* bus);
+// One tick(): the trips' values at the block's first frame (MusicalTime has 65,536 units per beat,
+// src/mini/transport.rs:157-176; the clock converts frames to whole units), then gather_audio over the
+// block, then the clock advances.
+void oracle_graph_tick(void* h, uint32_t frames, double* bus) {
+  Graph* g = (Graph*)h;
+  const uint64_t units = (uint64_t)((double)g->clock_frames * g->bpm / 60.0 / g->sr * 65536.0);
+  const double now = (double)units / 65536.0;
+  for (auto& t : g->trips) {
+    double b = t.start_beat;
+    for (const TripStep& s : t.steps) {
+      if (now >= b && now < b + s.beats) {
+        const double v = trip_step_value(s.kind, s.start, s.end, (now - b) / s.beats);
+        if (v != t.last_sent) { t.last_sent = v; effect_set_control(g->nodes[t.target].fx, t.index, v); }
+        break;
+      }
+      b += s.beats;
+    }
+  }
+  oracle_graph_gather(h, frames, bus);
+  g->clock_frames += frames;
+}
+
 // gather_audio, orchestrator.rs:367-470: per frame, explicit-stack post-order DFS from
 // the main mixer; a leaf instrument is ticked once and its value added to the running
 // sum; an effect sums ALL its sources, transforms that sum once, and adds the result to

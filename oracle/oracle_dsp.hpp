@@ -374,29 +374,32 @@ struct WelshVoice {
     lfo.tick();
     const double l = lfo.value();
     const double depth = p.lfo_depth;
-    if (p.lfo_routing == GROOVE_LFO_PITCH) { o1.fm = l * depth; o2.fm = l * depth; }
-    if (p.lfo_routing == GROOVE_LFO_PULSE_WIDTH) {
-      o1.duty_eff = clamp01(o1.duty * (1.0 + l * depth));
-      o2.duty_eff = clamp01(o2.duty * (1.0 + l * depth));
-    }
+    const uint32_t r = p.lfo_routing;
+    // docs/DSP_SPEC.md §6: which oscillators an edge-moving routing reaches
+    if (r == GROOVE_LFO_PITCH) { o1.fm = l * depth; o2.fm = l * depth; }
+    if (r == GROOVE_LFO_PITCH_OSC2) o2.fm = l * depth;
+    if (r == GROOVE_LFO_PULSE_WIDTH || r == GROOVE_LFO_PW_OSC1) o1.duty_eff = clamp01(o1.duty * (1.0 + l * depth));
+    if (r == GROOVE_LFO_PULSE_WIDTH || r == GROOVE_LFO_PW_OSC2) o2.duty_eff = clamp01(o2.duty * (1.0 + l * depth));
     o1.tick();
     if (p.oscillator_2_sync && o1.should_sync()) o2.sync();
     o2.tick();
     const double mix = p.oscillator_mix;
     double s = o1.value() * mix + o2.value() * (1.0 - mix);
     bool retune = false;
-    double pct = 0.0;
+    double fc = p.filter_cutoff_hz;
     if (p.filter_cutoff_end != 0.0f) {
-      pct = p.filter_cutoff_start + (1.0 - p.filter_cutoff_start) * p.filter_cutoff_end * fil.value();
+      fc = percent_to_frequency(clamp01(p.filter_cutoff_start + (1.0 - p.filter_cutoff_start) * p.filter_cutoff_end * fil.value()));
       retune = true;
-    } else if (p.lfo_routing == GROOVE_LFO_FILTER_CUTOFF) {
-      pct = p.filter_cutoff_start * (1.0 + l * depth);
+    } else if (r == GROOVE_LFO_FILTER_CUTOFF || r == GROOVE_LFO_CUTOFF_AMP) {
+      fc = percent_to_frequency(clamp01(p.filter_cutoff_start * (1.0 + l * depth)));
       retune = true;
     }
-    if (retune) coeffs = lp24_coeffs(percent_to_frequency(clamp01(pct)), p.filter_passband_ripple, sample_rate);
+    double ripple = p.filter_passband_ripple;
+    if (r == GROOVE_LFO_RESONANCE) { ripple *= (1.0 + l * depth); retune = true; }
+    if (retune) coeffs = lp24_coeffs(fc, ripple, sample_rate);
     double y = filt.step(coeffs, s);
     double a = amp.value();
-    if (p.lfo_routing == GROOVE_LFO_AMPLITUDE) a *= (1.0 + l * depth);
+    if (r == GROOVE_LFO_AMPLITUDE || r == GROOVE_LFO_CUTOFF_AMP) a *= (1.0 + l * depth);
     dca(y * a, p.dca_gain, p.dca_pan, L, R);
   }
 };

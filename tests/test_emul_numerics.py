@@ -92,3 +92,38 @@ def test_segmented_and_checked_forms_are_bit_identical():
         frames = [256, 100, 7, 1][blk % 4]
         x, y = a.render(frames), b.render(frames)
         assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), blk
+
+
+def test_extended_lfo_routings_arithmetic(oracle):
+    """The five routings beyond LfoRoutingType (pitch-osc2, pw-osc1, pw-osc2, resonance, cutoff-amp; SURVEY §8 f1,
+    docs/DSP_SPEC.md §6): device arithmetic vs the oracle, every LFO waveform that is smooth enough to be meaningful,
+    static and envelope-retuned filters, and each differs from the routing it used to be collapsed into."""
+    pats, keys = [], []
+    routings = [T.LFO_PITCH_OSC2, T.LFO_PW_OSC1, T.LFO_PW_OSC2, T.LFO_RESONANCE, T.LFO_CUTOFF_AMP]
+    for k, r in enumerate(routings * 6):
+        p = P.welsh_patch([0, 4, 9, 13, 20, 29][k // 5])
+        p.oscillator_1.waveform, p.oscillator_1.duty = T.WAVE_PULSE_WIDTH, 0.3
+        p.oscillator_2.waveform, p.oscillator_2.duty = (T.WAVE_PULSE_WIDTH, 0.2) if k % 2 else (T.WAVE_SAWTOOTH, 0.5)
+        p.oscillator_mix = 0.55
+        p.lfo_waveform = [T.WAVE_SINE, T.WAVE_TRIANGLE, T.WAVE_SQUARE][k % 3]
+        p.lfo_routing, p.lfo_depth, p.lfo_frequency = r, [0.05, 0.2, 0.4][(k // 5) % 3], [2.07, 5.13][k % 2]
+        p.filter_cutoff_end = 0.0 if (r == T.LFO_CUTOFF_AMP or k % 4 == 0) else 0.5
+        pats.append(p); keys.append(46 + (5 * k) % 30)   # no A notes: 440 * 2^n Hz over 44,100 is rational and its edges tie exactly (DSP_SPEC §2)
+    n = len(pats)
+    params = (T.WelshParams * n)(*pats)
+    on = T.note_events_np(np.arange(n, dtype=np.uint32), np.array(keys, dtype=np.uint8), True)
+    off = T.note_events_np(np.arange(n, dtype=np.uint32), np.array(keys, dtype=np.uint8), False)
+    o, e = _render(oracle.Bank.welsh(params), E.Bank.welsh(params), on, off, 40, 30)
+    # (a resonant patch's voice exceeds full scale here: the bar is relative to max(1, the voice's peak))
+    per_voice = np.sqrt(np.mean((e - o) ** 2, axis=(0, 1))) / np.maximum(1.0, np.abs(o).max(axis=(0, 1)))
+    assert np.sqrt(np.mean(o ** 2, axis=(0, 1))).min() > 1e-3
+    assert per_voice.max() <= 1e-5, per_voice
+    # not the collapsed routings: the same patches with the old mapping sound different
+    old = {T.LFO_PITCH_OSC2: T.LFO_PITCH, T.LFO_PW_OSC1: T.LFO_PULSE_WIDTH, T.LFO_PW_OSC2: T.LFO_PULSE_WIDTH,
+           T.LFO_RESONANCE: T.LFO_NONE, T.LFO_CUTOFF_AMP: T.LFO_FILTER_CUTOFF}
+    for p in pats:
+        p.lfo_routing = old[p.lfo_routing]
+    o2, _ = _render(oracle.Bank.welsh((T.WelshParams * n)(*pats)), E.Bank.welsh((T.WelshParams * n)(*pats)), on, off, 40, 30)
+    differs = np.sqrt(np.mean((o2 - o) ** 2, axis=(0, 1))) > 1e-4
+    # (pw-osc1 equals pulse-width when oscillator 2 is not a pulse wave: nothing else for the LFO to move)
+    assert differs[[i for i in range(n) if not (i % 5 == 1 and pats[i].oscillator_2.waveform != T.WAVE_PULSE_WIDTH)]].all()

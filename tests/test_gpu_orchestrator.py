@@ -153,9 +153,54 @@ def test_control_trip_steps_and_filter_sweep(orch):
         orch.add_control_trip(lp, "no-such-param")
 
 
+CONFIG1_ROWS = [[42, 44] * 8, [0, 0, 0, 0, 38, 0, 0, 0, 0, 0, 0, 0, 38, 0, 0, 0], [35, 0, 0, 0] * 4]
+
+
+def _config1_notes(measures=2):
+    """(key, start beat) of config #1's pattern: three simultaneous rows of sixteenth notes per measure."""
+    return [(k, m * 4 + i * 0.25) for m in range(measures) for row in CONFIG1_ROWS for i, k in enumerate(row) if k]
+
+
+def _oracle_config1(oracle, pcm, descs, key_to_sample, notes, total, buffer_frames, trip_steps=None, bpm=128.0, sr=44100,
+                    cutoff=1000.0, ripple=0.8):
+    """Config #1 on the oracle: a 128-voice drumkit bank (voice = MIDI key, one-shot, step 1) → 24 dB low-pass →
+    main mixer, block-granular note events and automation; returns the f64 bus of whole blocks up to `total`."""
+    sp = (T.SamplerParams * 128)()
+    for k in range(128):
+        s_ = key_to_sample[k]
+        sp[k].sample_index, sp[k].one_shot, sp[k].gain = (s_ if s_ >= 0 else 0), 1, (1.0 if s_ >= 0 else 0.0)
+    d0 = (T.SampleDesc * len(descs))(*[T.SampleDesc(d.offset, d.length, 0.0) for d in descs])
+    g = oracle.Graph(sr)
+    g.set_bpm(bpm)
+    kit = g.add_instrument(oracle.Bank.sampler(pcm, d0, sp, sr))
+    lp = g.add_effect(T.FX_BIQUAD_LP24, T.fx_params(cutoff_hz=cutoff, passband_ripple=ripple))
+    g.patch_chain_to_main_mixer([kit, lp])
+    if trip_steps:
+        trip = g.add_control_trip(lp, T.CTL_FX_CUTOFF, 0.0)
+        for kind, a, b, beats in trip_steps:
+            g.trip_add_step(trip, kind, a, b, beats)
+    upb = 65536
+    evs = sorted((int(s * upb + 0.5), k) for k, s in notes)
+    out, pos = [], 0
+    while pos < total:
+        fr = min(buffer_frames, total - pos)
+        t0 = int(pos * bpm / 60.0 / sr * upb); t1 = int((pos + fr) * bpm / 60.0 / sr * upb)
+        on = [(k, k, True) for at, k in evs if t0 <= at < t1]
+        if on:
+            g.note_events(kit, T.note_events(on))
+        out.append(g.tick(fr)); pos += fr
+    return np.concatenate(out, axis=0)
+
+
+def _quantise(oracle, bus):
+    q = np.vectorize(oracle.lib().oracle_wav_quantise)
+    return q(bus.astype(np.float32).astype(np.float64)).astype(np.int32)
+
+
 def test_drumkit_render_to_wav(orch, tmp_path, oracle):
     """Config #1 shape on the GPU path: drumkit on MIDI channel 10 → 24 dB low-pass → main mixer,
-    two measures of four-on-the-floor at 128 bpm, written as 16-bit stereo WAV."""
+    two measures of four-on-the-floor at 128 bpm, written as 16-bit stereo WAV; the i16 stream
+    against the oracle graph's quantised render."""
     pcm, descs, lengths = P.drum_bank(scale=0.25)
     key_to_sample = [-1] * 128
     for k, s in ((35, 0), (38, 2), (42, 4), (44, 6)):
@@ -165,12 +210,8 @@ def test_drumkit_render_to_wav(orch, tmp_path, oracle):
     assert orch.patch_chain_to_main_mixer([kit, lp]) == 0
     orch.connect_midi_downstream(kit, 10)
     seq = orch.add_sequencer()
-    rows = [[42, 44] * 8, [0, 0, 0, 0, 38, 0, 0, 0, 0, 0, 0, 0, 38, 0, 0, 0], [35, 0, 0, 0] * 4]
-    for measure in range(2):
-        for row in rows:
-            for i, k in enumerate(row):
-                if k:
-                    orch.sequencer_insert(seq, 10, k, measure * 4 + i * 0.25, 0.25)
+    for k, s in _config1_notes():
+        orch.sequencer_insert(seq, 10, k, s, 0.25)
     orch.sequencer_set_end(seq, 8.0)
     assert orch.performance_frames() == 165375
     path = tmp_path / "drums.wav"
@@ -180,15 +221,92 @@ def test_drumkit_render_to_wav(orch, tmp_path, oracle):
     fmt, ch, sr, _, _, bits = struct.unpack("<HHIIHH", raw[20:36])
     assert (fmt, ch, sr, bits) == (1, 2, 44100, 16)
     n_bytes = struct.unpack("<I", raw[40:44])[0]
-    assert n_bytes == (165375 - 165375 % 256) * 4        # run_performance drops the partial block
+    whole = 165375 - 165375 % 256
+    assert n_bytes == whole * 4        # run_performance drops the partial block
     pcm16 = np.frombuffer(raw[44:], dtype="<i2").reshape(-1, 2)
     assert np.abs(pcm16).max() > 1000 and (pcm16[:, 0] == pcm16[:, 1]).all()   # mono kit duplicated L = R
+    want = _quantise(oracle, _oracle_config1(oracle, pcm, descs, key_to_sample, _config1_notes(), whole, 256))
+    assert want.shape == pcm16.shape
+    assert np.max(np.abs(pcm16.astype(np.int32) - want)) <= 1
 
 
-def test_cli_renders_synthetic_config1_project(tmp_path):
+@pytest.mark.parametrize("kind", ["exponential", "logarithmic", "slope+flat"])
+def test_control_trip_sweep_matches_oracle(kind, oracle):
+    """f3: automation parity.  A toy source and a drumkit, each through a 24 dB low-pass whose cutoff a
+    ControlTrip sweeps (control_trip.rs:7-26 shapes, block-granular, held back a block in the render-ahead
+    walk) — the bus against the oracle graph's trip, for the render-ahead and the block-by-block walk."""
+    from groove_amd import host_binding as H
+    from groove_amd.host_binding import Orchestrator
+    steps = {"exponential": [(H.STEP_EXPONENTIAL, 0.0, 1.0, 4.0)],
+             "logarithmic": [(H.STEP_LOGARITHMIC, 0.9, 0.1, 4.0)],
+             "slope+flat": [(H.STEP_SLOPE, 0.2, 0.8, 1.5), (H.STEP_FLAT, 0.35, 0.35, 1.0), (H.STEP_SLOPE, 0.8, 0.05, 1.5)]}[kind]
+    pcm, descs, k2s = H.synthetic_kit()
+    notes = _config1_notes(1)
+    total = math.ceil(4.0 * 60 / 128 * 44100)
+    for ahead in (True, False):
+        o = Orchestrator(0, 44100, 128.0)
+        o.set_render_ahead(ahead)
+        src = o.add_toy_source(0.25)
+        kit = o.add_drumkit(pcm, descs, k2s)
+        lp = o.add_effect(T.FX_BIQUAD_LP24, T.fx_params(cutoff_hz=1000.0, passband_ripple=0.8))
+        assert o.patch(src, lp) == 0 and o.patch(kit, lp) == 0 and o.patch(lp, o.MAIN_MIXER) == 0
+        o.connect_midi_downstream(kit, 10)
+        seq = o.add_sequencer()
+        for k, s in notes:
+            o.sequencer_insert(seq, 10, k, s, 0.25)
+        o.sequencer_set_end(seq, 4.0)
+        trip = o.add_control_trip(lp, "cutoff", 0.0)
+        for st in steps:
+            o.control_trip_add_step(trip, *st)
+        got = o.run(256).astype(np.float64)
+        o.close()
+        assert len(got) == total
+        # oracle: the same graph (two sources into one effect: it sums them, then transforms once)
+        sp = (T.SamplerParams * 128)()
+        for k in range(128):
+            sp[k].sample_index, sp[k].one_shot, sp[k].gain = (k2s[k] if k2s[k] >= 0 else 0), 1, (1.0 if k2s[k] >= 0 else 0.0)
+        g = oracle.Graph()
+        g.set_bpm(128.0)
+        s_uid = g.add_source(0.25)
+        k_uid = g.add_instrument(oracle.Bank.sampler(pcm, descs, sp))
+        f_uid = g.add_effect(T.FX_BIQUAD_LP24, T.fx_params(cutoff_hz=1000.0, passband_ripple=0.8))
+        assert g.patch(s_uid, f_uid) == 0 and g.patch(k_uid, f_uid) == 0 and g.patch(f_uid, g.MAIN_MIXER) == 0
+        t = g.add_control_trip(f_uid, T.CTL_FX_CUTOFF, 0.0)
+        for st in steps:
+            g.trip_add_step(t, *st)
+        evs = sorted((int(s * 65536 + 0.5), k) for k, s in notes)
+        want, pos = [], 0
+        while pos < total:
+            fr = min(256, total - pos)
+            t0 = int(pos * 128.0 / 60.0 / 44100 * 65536); t1 = int((pos + fr) * 128.0 / 60.0 / 44100 * 65536)
+            on = [(k, k, True) for at, k in evs if t0 <= at < t1]
+            if on:
+                g.note_events(k_uid, T.note_events(on))
+            want.append(g.tick(fr)); pos += fr
+        want = np.concatenate(want, axis=0)
+        assert np.sqrt(np.mean(want ** 2)) > 1e-2
+        rms = np.sqrt(np.mean((got - want) ** 2))
+        assert rms <= 1e-5, (kind, ahead, rms)
+        # and the trip does something: a fixed 1 kHz filter gives a different signal
+        assert np.sqrt(np.mean((want - want.mean()) ** 2)) > 0
+
+
+def test_control_step_shapes_match_oracle(oracle):
+    """ControlStep::{Flat, Slope, Logarithmic, Exponential} on the host against the oracle's restatement."""
+    from groove_amd import host_binding as H
+    L = H.load()
+    OL = oracle.lib()
+    for kind in range(4):
+        for a, b in ((0.0, 1.0), (0.9, 0.2), (0.3, 0.3)):
+            for t in np.linspace(-0.1, 1.1, 49):
+                assert abs(L.gh_control_step_value(kind, a, b, t) - OL.oracle_control_step_value(kind, a, b, t)) <= 1e-15
+
+
+def test_cli_renders_synthetic_config1_project(tmp_path, oracle):
     """groove-cli-hip --wav on the committed synthetic config-#1 project (drumkit → 24 dB low-pass
     with an exponential cutoff trip), synthetic sample bank: 16-bit stereo WAV of the expected length,
-    non-silent, and the rising cutoff lets progressively more high-frequency energy through."""
+    equal within ±1 LSB to the oracle graph's quantised render of the same project, and the rising
+    cutoff lets progressively more high-frequency energy through."""
     import os
     import shutil
     import subprocess
@@ -205,6 +323,13 @@ def test_cli_renders_synthetic_config1_project(tmp_path):
     pcm = np.frombuffer(raw[44:], dtype="<i2").reshape(-1, 2).astype(np.float64)
     assert len(pcm) == 165375 - 165375 % 256
     assert np.abs(pcm).max() > 500
+    # end-to-end parity: the same project on the oracle graph (loader semantics restated here: rows are
+    # simultaneous, sixteenth notes, two measures; the 'double' path is one 8-beat exponential step)
+    from groove_amd import host_binding as H
+    kpcm, kdescs, k2s = H.synthetic_kit()
+    want = _quantise(oracle, _oracle_config1(oracle, kpcm, kdescs, k2s, _config1_notes(), len(pcm), 256,
+                                             trip_steps=[(H.STEP_EXPONENTIAL, 0.0, 1.0, 8.0)]))
+    assert np.max(np.abs(pcm.astype(np.int32) - want)) <= 1
     # high-band (> 4 kHz) share of the energy in the first vs the last quarter of the render
     def hi_share(x):
         spec = np.abs(np.fft.rfft(x[:, 0])) ** 2

@@ -5,7 +5,8 @@ combination of oscillator-1 waveform x oscillator-2 waveform x (LFO waveform, LF
 
 Each patch fills one workgroup (256 identical voices), so the workgroup's class is exactly the
 patch's; a bank holds 128 patches and the check is on its bus, which the oracle reproduces from one
-voice per patch (x 256).  Tolerance: bus / V RMS <= 1e-6 (bar 1e-5).  4,050 patches in total; the 36
+voice per patch (x 256).  Tolerance: bus / V RMS <= 1e-6 (bar 1e-5).  8,100 patches in total (the five routings of LfoRoutingType and
+the five more the shipped patch files use: pitch-osc2, pw-osc1, pw-osc2, resonance, cutoff-amp); the few
 of them whose oracle output is unbounded (a noise LFO on the cutoff retunes the filter randomly every
 frame; some depth / cutoff pairs grow to 1e10, chaotically, in oracle and device alike) stay idle."""
 import itertools
@@ -20,7 +21,9 @@ pytestmark = pytest.mark.gpu
 WAVES = [T.WAVE_NONE, T.WAVE_SINE, T.WAVE_SQUARE, T.WAVE_PULSE_WIDTH, T.WAVE_TRIANGLE, T.WAVE_SAWTOOTH,
          T.WAVE_NOISE, T.WAVE_TRIANGLE_SINE, T.WAVE_DEBUG_MAX]
 LFO_WAVES = [T.WAVE_SINE, T.WAVE_TRIANGLE, T.WAVE_SQUARE, T.WAVE_SAWTOOTH, T.WAVE_NOISE]
-ROUTINGS = [T.LFO_NONE, T.LFO_AMPLITUDE, T.LFO_PITCH, T.LFO_PULSE_WIDTH, T.LFO_FILTER_CUTOFF]
+ROUTINGS = [T.LFO_NONE, T.LFO_AMPLITUDE, T.LFO_PITCH, T.LFO_PULSE_WIDTH, T.LFO_FILTER_CUTOFF,
+            T.LFO_PITCH_OSC2, T.LFO_PW_OSC1, T.LFO_PW_OSC2, T.LFO_RESONANCE, T.LFO_CUTOFF_AMP]
+CUTOFF_ROUTINGS = (T.LFO_FILTER_CUTOFF, T.LFO_CUTOFF_AMP)
 PER_PATCH = 256   # one workgroup of four 64-lane waves
 PER_BANK = 128
 
@@ -34,7 +37,7 @@ def _patch(k, w1, w2, wl, routing, retune):
     p.lfo_waveform, p.lfo_routing = wl, routing
     p.lfo_frequency = [0.53, 2.07, 5.13, 7.49][k % 4]
     p.lfo_depth = [0.05, 0.2, 0.5][k % 3]
-    p.filter_cutoff_end = 0.5 if (retune and routing != T.LFO_FILTER_CUTOFF) else 0.0
+    p.filter_cutoff_end = 0.5 if (retune and routing not in CUTOFF_ROUTINGS) else 0.0
     return p
 
 

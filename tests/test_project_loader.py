@@ -138,8 +138,17 @@ def test_welsh_patch_derivation(host):
     assert _patch(host, json.dumps(patch)).oscillator_mix == 0.0
     # untracked oscillator 2 without a note tune is the reference's panic (patches.rs:98)
     patch["oscillator-2"] = {"waveform": "square", "tune": {"float": 1}, "mix-pct": 1}; patch["oscillator-2-track"] = False
-    with pytest.raises(RuntimeError, match="tracking"):
+    with pytest.raises(RuntimeError, match="oscillator-2-track"):
         _patch(host, json.dumps(patch))
+    # the routings of the shipped patch library beyond LfoRoutingType's five
+    patch["oscillator-2-track"] = True
+    for name, want in (("none", T.LFO_NONE), ("amplitude", T.LFO_AMPLITUDE), ("pitch", T.LFO_PITCH), ("pulse-width", T.LFO_PULSE_WIDTH),
+                       ("filter-cutoff", T.LFO_FILTER_CUTOFF), ("pitch-osc2", T.LFO_PITCH_OSC2), ("pw-osc1", T.LFO_PW_OSC1),
+                       ("pw-osc2", T.LFO_PW_OSC2), ("resonance", T.LFO_RESONANCE), ("cutoff-amp", T.LFO_CUTOFF_AMP)):
+        patch["lfo"]["routing"] = name
+        assert _patch(host, json.dumps(patch)).lfo_routing == want, name
+    patch["lfo"]["routing"] = "lfo-routing-and-depth---something-else"
+    assert _patch(host, json.dumps(patch)).lfo_routing == T.LFO_NONE
 
 
 @pytest.mark.skipif(not os.path.exists(REF), reason="reference tree not present")
@@ -152,13 +161,16 @@ def test_all_reference_welsh_patches_derive(host):
         try:
             p = _patch(host, open(f).read())
         except RuntimeError as e:
-            assert "tracking" in str(e), f"{f}: {e}"   # the reference panics on these too
+            assert "oscillator-2-track" in str(e), f"{f}: {e}"   # the reference panics on these too
             continue
         n_ok += 1
         assert p.amp_envelope.release == p.amp_envelope.decay
         assert p.filter_cutoff_hz == pytest.approx(raw["filter-type-24db"].get("cutoff-hz", 0.0))
         assert 0.0 <= p.oscillator_mix <= 1.0 and 0.0 <= p.filter_cutoff_start <= 1.0
-        assert p.lfo_routing in range(5)
+        want = {"none": T.LFO_NONE, "amplitude": T.LFO_AMPLITUDE, "pitch": T.LFO_PITCH, "pulse-width": T.LFO_PULSE_WIDTH,
+                "filter-cutoff": T.LFO_FILTER_CUTOFF, "pitch-osc2": T.LFO_PITCH_OSC2, "pw-osc1": T.LFO_PW_OSC1,
+                "pw-osc2": T.LFO_PW_OSC2, "resonance": T.LFO_RESONANCE, "cutoff-amp": T.LFO_CUTOFF_AMP}
+        assert p.lfo_routing == want.get(raw["lfo"]["routing"], T.LFO_NONE), f
     assert n_ok >= 100
 
 
