@@ -7,6 +7,7 @@
 // either launches HIP work or returns an error.
 #include "../../include/groove_hip.h"
 #include "kernels.h"
+#include "welsh_tp.h"
 #include <dlfcn.h>
 #include <rccl/rccl.h> // types, enumerators and prototypes only: the library itself is dlopen'ed (rccl_open)
 #include <string>
@@ -130,6 +131,7 @@ struct groove_ctx {
   bool side_busy[kSideStreams] = {};    // work enqueued on the side stream since the last join
   bool fork_pending[kSideStreams] = {}; // the side stream has not yet waited for ev_fork
   bool need_fork = true;                // ctx-stream work since the last fork that side streams must wait for
+  uint32_t tp_max_voices = kTpMaxVoices; // Welsh banks up to this size render time-parallel (welsh_tp.h); GROOVE_TP_MAX_VOICES overrides, 0 = never
   uint32_t pipeline_min_waves = 4700;   // banks at least this long (~300,000 voices) run one kernel per base kind and pipeline their fused blocks; smaller ones take the all-kinds kernel
   int next_stream_slot = 0;             // round-robin side-stream assignment of single-kernel banks
   bool seq_allpass = false;             // GROOVE_FX_SEQ_ALLPASS=1: the sequential all-pass kernel (A/B and bit-identity tests)
@@ -704,6 +706,7 @@ int groove_init(int device_ordinal, groove_ctx** out) {
   if (!ctx) return fail(nullptr, "groove_init: out of memory");
   ctx->device = device_ordinal;
   if (const char* e = std::getenv("GROOVE_FX_SEQ_ALLPASS")) ctx->seq_allpass = e[0] == '1';
+  if (const char* e = std::getenv("GROOVE_TP_MAX_VOICES")) ctx->tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_PIPELINE_MIN_WAVES")) ctx->pipeline_min_waves = (uint32_t)std::strtoul(e, nullptr, 10); // tests force the pipeline on small banks
   // The runtime spreads the streams of one priority over a handful of hardware queues, and streams that
   // share a queue run one after the other.  The ctx stream is created at the highest priority: that
@@ -769,6 +772,14 @@ int groove_synchronize(groove_ctx* ctx) {
   return 0;
 }
 uint32_t groove_sample_rate(groove_ctx* ctx) { return ctx ? ctx->sr : 0; }
+int groove_set_time_parallel_max_voices(groove_ctx* ctx, uint32_t max_voices) {
+  if (!ctx) return fail(nullptr, "groove_set_time_parallel_max_voices: ctx is NULL");
+  if (ctx_join(ctx)) return 1; // banks change kernels (and side streams) at their next render
+  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->tp_max_voices = max_voices;
+  return 0;
+}
+uint32_t groove_time_parallel_max_voices(groove_ctx* ctx) { return ctx ? ctx->tp_max_voices : 0; }
 int groove_update_sample_rate(groove_ctx* ctx, uint32_t hz) {
   if (!ctx) return fail(nullptr, "groove_update_sample_rate: ctx is NULL");
   if (hz < 1000 || hz > 768000) return fail(ctx, "groove_update_sample_rate: unsupported rate");
@@ -961,6 +972,20 @@ int groove_bank_set_param(groove_bank* b, uint32_t voice, uint32_t control_index
   GHIP(ctx, hipStreamSynchronize(ctx->stream));
   return welsh_upload_params(b, false); // the state stays where it is: keep the lane order
 }
+// Small Welsh banks and blocks of up to 256 frames: one wavefront per voice, lanes = time (welsh_tp.h).
+static bool use_tp(const groove_bank* b, uint32_t frames) {
+  return b->kind == BANK_WELSH && frames <= kTpMaxFrames && b->n <= b->ctx->tp_max_voices;
+}
+static void launch_tp(groove_bank* b, uint32_t frames, bool fused, size_t chs, float* out, hipStream_t st) {
+  groove_ctx* ctx = b->ctx;
+  const TpArgs a{b->d_params, b->d_state, out, chs, RenderConsts{(float)(3.14159265358979323846 / ctx->sr), (float)(0.49 * ctx->sr)}, b->n, frames};
+  launch_welsh_tp(a, st, fused);
+}
+// rows of partial[][2][frames] a bank's fused render writes
+static uint32_t fused_rows(const groove_bank* b, uint32_t frames) {
+  if (use_tp(b, frames)) return welsh_tp_workgroups(b->n);
+  return (b->kind == BANK_WELSH && b->n_vwaves) ? (b->n_vwaves + kWaves - 1) / kWaves : blocks_for(b->n);
+}
 // One base kind's uniform Welsh kernel (kernels.h, "Workgroup KINDS") on stream `st`.
 static void launch_welsh_kind(int k, const UniformArgs& a, hipStream_t st, bool fused) {
   const dim3 kgrid(a.n_wgs), blk(kThreads);
@@ -992,7 +1017,9 @@ static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs
   groove_ctx* ctx = b->ctx;
   b->ctx_touched = true;
   const dim3 grid(blocks_for(b->n)), blk(kThreads);
-  if (b->kind == BANK_WELSH) {
+  if (use_tp(b, frames)) {
+    launch_tp(b, frames, fused, chs, out, ctx->stream);
+  } else if (b->kind == BANK_WELSH) {
     RenderConsts rc{(float)(3.14159265358979323846 / ctx->sr), (float)(0.49 * ctx->sr)};
     if (b->n_vwaves == 0) { // interleaved bank: per-lane kernel over the physical lanes
       if (fused) hipLaunchKernelGGL(welsh_render_kernel<true>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, rc);
@@ -1090,8 +1117,9 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
   if (flush_events(b)) return 1;
   const bool was_released = out->released;
   if (block_acquire(out)) return 1; // an earlier asynchronous render into the same block comes first
-  const bool small_uniform = b->kind == BANK_WELSH && b->n_vwaves && b->n_vwaves < ctx->pipeline_min_waves;
-  const bool uniform = b->kind == BANK_WELSH && b->n_vwaves && !small_uniform; // one kernel per base kind
+  const bool tp = use_tp(b, frames);
+  const bool small_uniform = !tp && b->kind == BANK_WELSH && b->n_vwaves && b->n_vwaves < ctx->pipeline_min_waves;
+  const bool uniform = !tp && b->kind == BANK_WELSH && b->n_vwaves && !small_uniform; // one kernel per base kind
   if (bank_side_mode(b, uniform ? 1 : 2)) return 1;
   if (!out->ev_free) {
     GHIP(ctx, hipEventCreateWithFlags(&out->ev_free, kSyncEventFlags));
@@ -1156,7 +1184,9 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
     const int k = b->stream_slot;
     hipStream_t st = begin(k);
     const dim3 grid(blocks_for(b->n));
-    if (small_uniform) { // all base kinds in one launch
+    if (tp) {
+      launch_tp(b, frames, false, chs, dst, st);
+    } else if (small_uniform) { // all base kinds in one launch
       const RenderConsts rc{(float)(3.14159265358979323846 / ctx->sr), (float)(0.49 * ctx->sr)};
       UniformArgs a{b->d_waves, b->d_state, dst, b->d_wg_list, b->d_wg_cls, chs, rc, b->n_vwaves, b->n, frames, b->n_vwaves / kWaves};
       launch_welsh_uniform_any_unfused(a, b->d_wg_base, st);
@@ -1212,9 +1242,10 @@ int groove_block_acquire(groove_block* b) {
 // render of block b+2 waits for the reduction of block b.
 static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev, int accumulate) {
   groove_ctx* ctx = b->ctx;
-  const bool small_uniform = b->kind == BANK_WELSH && b->n_vwaves && b->n_vwaves < ctx->pipeline_min_waves && ctx->pipeline_min_waves > 1;
-  const bool uniform = b->kind == BANK_WELSH && b->n_vwaves && !small_uniform; // one kernel per base kind
-  const uint32_t rows = (b->kind == BANK_WELSH && b->n_vwaves) ? (b->n_vwaves + kWaves - 1) / kWaves : blocks_for(b->n);
+  const bool tp = use_tp(b, frames);
+  const bool small_uniform = !tp && b->kind == BANK_WELSH && b->n_vwaves && b->n_vwaves < ctx->pipeline_min_waves && ctx->pipeline_min_waves > 1;
+  const bool uniform = !tp && b->kind == BANK_WELSH && b->n_vwaves && !small_uniform; // one kernel per base kind
+  const uint32_t rows = fused_rows(b, frames);
   const uint32_t cols = 2 * frames, rows_per_seg = 64, segs = (rows + rows_per_seg - 1) / rows_per_seg;
   if (bank_side_mode(b, uniform ? 1 : 2)) return 1;
   const int slot = b->pipe_slot;
@@ -1266,6 +1297,8 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
         case 4: hipLaunchKernelGGL((welsh_render_uniform_kernel<true, LFO_F64, false, false>), dim3(count[k]), blk, 0, st, a); break;
         default: hipLaunchKernelGGL((welsh_render_uniform_kernel<true, LFO_F64, true, false>), dim3(count[k]), blk, 0, st, a); break;
       }
+    } else if (tp) {
+      launch_tp(b, frames, true, 0, b->d_pipe_part[slot], st);
     } else if (small_uniform) { // all base kinds in one launch on this bank's stream
       UniformArgs a{b->d_waves, b->d_state, b->d_pipe_part[slot], b->d_wg_list, b->d_wg_cls, 0, rc, b->n_vwaves, b->n, frames, rows};
       launch_welsh_uniform_any(a, b->d_wg_base, st);
@@ -1312,7 +1345,7 @@ int groove_bank_render_mix(groove_bank* b, uint32_t frames, float* bus_dev, int 
   const bool big = b->kind == BANK_WELSH && b->n_vwaves >= ctx->pipeline_min_waves;
   if (!kNoPipeline && (big || force || ctx->banks.size() > 1)) return render_mix_pipelined(b, frames, bus_dev, accumulate);
   if (ctx_join(ctx)) return 1; // earlier pipelined blocks of this bank may still be running on the side streams
-  const uint32_t rows = (b->kind == BANK_WELSH && b->n_vwaves) ? (b->n_vwaves + kWaves - 1) / kWaves : blocks_for(b->n);
+  const uint32_t rows = fused_rows(b, frames);
   const uint32_t cols = 2 * frames;
   const uint32_t rows_per_seg = 64;
   const uint32_t segs = (rows + rows_per_seg - 1) / rows_per_seg;

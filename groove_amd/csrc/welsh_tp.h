@@ -1,0 +1,425 @@
+// welsh_tp.h — time-parallel evaluation of a Welsh voice: ONE WAVEFRONT PER VOICE, lanes = time.
+//
+// Why.  A voice's frame loop is a recurrence, so the render kernels in kernels.h give a voice to one lane
+// and walk the block's frames serially: a block costs what ONE wavefront needs for 256 dependent frames
+// (about 0.11 ms), however few voices the bank has.  Every bank below ~250,000 voices sits on that floor
+// (BASELINE configs #2, #3, #5; every synth of a real project; every shard of a strong-scaled run).
+//
+// What is actually sequential in a voice is small:
+//   * oscillator / LFO phases are sums of per-frame increments: a closed form (constant increments) or a
+//     prefix sum over frames (pitch LFO); hard sync is "phase 2 restarts at oscillator 1's last wrap": a
+//     max-scan of wrap positions plus a difference of two prefix sums;
+//   * envelopes are closed forms in a stage counter; stages change at most a handful of times per block,
+//     so the state at any frame is reached by stepping over whole stages (env_seek);
+//   * the 24 dB filter is LINEAR in its four state values: over a run of frames it is an affine map
+//     s -> Phi s + z, with Phi and z depending only on that run's coefficients and input.  Affine maps
+//     compose associatively, so the 64 lanes each build the map of their own 4 frames (five short
+//     recurrences: the forced response from zero state and the responses to the four unit states), a
+//     log-step scan over the lanes gives every lane its true start state, and a second 4-frame pass
+//     produces the outputs.  All in f64, like the serial kernels' recurrence.
+//   * only the integer noise generator has no jump-ahead (xor and add mixed): a noise oscillator's values are
+//     produced serially by one lane first (3 integer operations per tick) and handed out through LDS.
+// A block of a voice is then ~1,500 instructions deep instead of ~25,000, at ~4x the total work: the right
+// trade exactly where the serial form leaves the machine idle.  groove_hip.hip picks this kernel for Welsh
+// banks of up to kTpMaxVoices voices and blocks of up to 256 frames; results agree with the serial kernels to
+// f64 rounding of the filter (1e-13 relative) and with the oracle to the same tolerance as they do.
+//
+// The per-lane pieces are plain inline functions (host + device), so tests/emul runs the same text on the
+// CPU with a loop in place of the wavefront.
+#pragma once
+#include "dsp_core.h"
+
+namespace groove {
+
+constexpr uint32_t kTpLanes = 64, kTpChunk = 4, kTpMaxFrames = kTpLanes * kTpChunk;
+
+// ------------------------------------------------------------------ envelopes at an arbitrary frame
+// k more ticks of an envelope, stage by stage: counter and stage exactly as k calls of env_tick leave them
+// (`value` is refreshed by the next env_tick, or by env_last_value).
+GROOVE_HD void env_seek(EnvState& s, const EnvParams& p, uint32_t k) {
+  while (k > 0) {
+    env_boundary(s, p);
+    if (s.n >= s.N) { s.n += 1; k -= 1; continue; } // more than two chained zero-length stages: the tick advances anyway
+    const uint32_t room = s.N - s.n;
+    const uint32_t step = k < room ? k : room;
+    s.n += step; k -= step;
+  }
+}
+// value the most recent tick produced (the stage counter has already moved on by one)
+GROOVE_HD float env_last_value(const EnvState& s) {
+  const float t = (float)(s.n - 1u) * s.inv_len;
+  return fmaf(s.D, fmaf(-t, t, 2.0f * t), s.A);
+}
+// First frame of the next `frames` at which the amp envelope is idle after its tick (the voice is silent
+// from there on: notes land at block starts only); `frames` if it sounds throughout.
+GROOVE_HD uint32_t env_idle_at(EnvState s, const EnvParams& p, uint32_t frames) {
+  uint32_t done = 0;
+  while (done < frames) {
+    env_boundary(s, p);
+    if (s.state == ENV_IDLE) return done;
+    if (s.n >= s.N) { s.n += 1; done += 1; continue; }
+    const uint32_t room = s.N - s.n, left = frames - done;
+    const uint32_t step = left < room ? left : room;
+    s.n += step; done += step;
+  }
+  return frames;
+}
+
+// ------------------------------------------------------------------ the filter as an affine map
+// Phi's columns (the section-1 state never sees section 2, so columns 2 and 3 have only their lower halves)
+// and the forced response z.
+struct Lp24Affine { double c0[4], c1[4], c2[2], c3[2], z[4]; };
+GROOVE_HD void lp24_affine_identity(Lp24Affine& m) {
+  m.c0[0] = 1.0; m.c0[1] = 0.0; m.c0[2] = 0.0; m.c0[3] = 0.0;
+  m.c1[0] = 0.0; m.c1[1] = 1.0; m.c1[2] = 0.0; m.c1[3] = 0.0;
+  m.c2[0] = 1.0; m.c2[1] = 0.0; m.c3[0] = 0.0; m.c3[1] = 1.0;
+  m.z[0] = 0.0; m.z[1] = 0.0; m.z[2] = 0.0; m.z[3] = 0.0;
+}
+// one filter step with input x on a plain state vector (the operations of lp24_step, in its order)
+GROOVE_HD double lp24_step_v(double* s, const Lp24CoefD& c, double x) {
+  const double bx = c.b0a * x;
+  const double y1 = bx + s[0];
+  s[0] = fma(c.a1a, y1, 2.0 * bx + s[1]);
+  s[1] = fma(c.a2a, y1, bx);
+  const double by = c.b0b * y1;
+  const double y2 = by + s[2];
+  s[2] = fma(c.a1b, y2, 2.0 * by + s[3]);
+  s[3] = fma(c.a2b, y2, by);
+  return y2;
+}
+GROOVE_HD void lp24_step_h(double* s, const Lp24CoefD& c) { // homogeneous (x = 0)
+  const double y1 = s[0];
+  s[0] = fma(c.a1a, y1, s[1]);
+  s[1] = c.a2a * y1;
+  const double by = c.b0b * y1;
+  const double y2 = by + s[2];
+  s[2] = fma(c.a1b, y2, 2.0 * by + s[3]);
+  s[3] = fma(c.a2b, y2, by);
+}
+GROOVE_HD void lp24_step_h2(double* s23, const Lp24CoefD& c) { // homogeneous, section 2 alone
+  const double y2 = s23[0];
+  s23[0] = fma(c.a1b, y2, s23[1]);
+  s23[1] = c.a2b * y2;
+}
+// m <- (one more frame with coefficients c and input x) o m
+GROOVE_HD void lp24_affine_push(Lp24Affine& m, const Lp24CoefD& c, double x) {
+  lp24_step_v(m.z, c, x);
+  lp24_step_h(m.c0, c);
+  lp24_step_h(m.c1, c);
+  lp24_step_h2(m.c2, c);
+  lp24_step_h2(m.c3, c);
+}
+// Phi v + (with_z ? z : 0)
+GROOVE_HD void lp24_affine_mul(const Lp24Affine& m, const double* v, double* out, bool with_z) {
+  const double z0 = with_z ? m.z[0] : 0.0, z1 = with_z ? m.z[1] : 0.0, z2 = with_z ? m.z[2] : 0.0, z3 = with_z ? m.z[3] : 0.0;
+  out[0] = fma(m.c0[0], v[0], fma(m.c1[0], v[1], z0));
+  out[1] = fma(m.c0[1], v[0], fma(m.c1[1], v[1], z1));
+  out[2] = fma(m.c0[2], v[0], fma(m.c1[2], v[1], fma(m.c2[0], v[2], fma(m.c3[0], v[3], z2))));
+  out[3] = fma(m.c0[3], v[0], fma(m.c1[3], v[1], fma(m.c2[1], v[2], fma(m.c3[1], v[3], z3))));
+}
+// later <- later o earlier   (apply `earlier` first)
+GROOVE_HD void lp24_affine_compose(Lp24Affine& later, const Lp24Affine& earlier) {
+  Lp24Affine r;
+  lp24_affine_mul(later, earlier.c0, r.c0, false);
+  lp24_affine_mul(later, earlier.c1, r.c1, false);
+  const double e2[4] = {0.0, 0.0, earlier.c2[0], earlier.c2[1]}, e3[4] = {0.0, 0.0, earlier.c3[0], earlier.c3[1]};
+  double t[4];
+  lp24_affine_mul(later, e2, t, false); r.c2[0] = t[2]; r.c2[1] = t[3];
+  lp24_affine_mul(later, e3, t, false); r.c3[0] = t[2]; r.c3[1] = t[3];
+  lp24_affine_mul(later, earlier.z, r.z, true);
+  later = r;
+}
+
+// ------------------------------------------------------------------ one frame of feed-forward work
+// Per-frame phase increments of the two audio oscillators (pass 1 of the kinds whose phases need a scan:
+// pitch-routed LFO, hard sync).  lfo_phase is the LFO's phase AT this frame.
+GROOVE_HD void welsh_tp_incs(const WelshParams& p, const WelshState& s0, uint64_t lfo_phase, float nzl, uint64_t& inc1, uint64_t& inc2) {
+  inc1 = s0.o1_inc; inc2 = s0.o2_inc;
+  if (p.flags & WF_LFO_PITCH) {
+    const uint32_t wl = (p.flags >> WF_LFO_WAVE_SHIFT) & 15u;
+    const double l = osc_value_f64(wl, lfo_phase, 0x8000000000000000ull, nzl);
+    const double m = exp2_small_f64(l * (double)p.lfo_depth);
+    if (p.flags & WF_LFO_O1) inc1 = f64_to_u64((double)inc1 * m);
+    if (p.flags & WF_LFO_O2) inc2 = f64_to_u64((double)inc2 * m);
+  }
+}
+// Everything of a LIVE frame except the filter: the mixed oscillator sample x (the filter's input), the
+// amplitude factor a (envelope x amplitude LFO), and — retuned kinds — this frame's filter coefficients.
+// `s` is the lane's running state: both envelopes have been ticked for this frame by the caller; the LFO
+// phase and (constant-increment kinds) the oscillator phases are advanced here exactly as welsh_frame does;
+// kinds with scanned phases pass this frame's phases in (ext_phase).
+template <bool RETUNE>
+GROOVE_HD void welsh_tp_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc, bool is_first, bool ext_phase,
+                              uint64_t ph1, uint64_t ph2, float nz1, float nz2, float nzl,
+                              Lp24CoefD& coef, float& prev_pct, float& x, float& a) {
+  const uint32_t fl = p.flags;
+  const uint32_t w1 = (fl >> WF_O1_WAVE_SHIFT) & 15u, w2 = (fl >> WF_O2_WAVE_SHIFT) & 15u, wl = (fl >> WF_LFO_WAVE_SHIFT) & 15u;
+  const uint64_t half = 0x8000000000000000ull;
+  if (!is_first) s.lfo.phase += p.lfo_inc;
+  uint64_t d1 = p.o1_duty64, d2 = p.o2_duty64;
+  float lfo = 0.0f;
+  if (fl & WF_LFO_PW) {
+    const double ld = osc_value_f64(wl, s.lfo.phase, half, nzl) * (double)p.lfo_depth;
+    if (fl & WF_LFO_O1) d1 = f64_to_u64(clamp01d((double)p.o1_duty * (1.0 + ld)) * 18446744073709549568.0);
+    if (fl & WF_LFO_O2) d2 = f64_to_u64(clamp01d((double)p.o2_duty * (1.0 + ld)) * 18446744073709549568.0);
+  } else if (fl & (WF_LFO_AMP | WF_LFO_CUTOFF | WF_LFO_RESO)) {
+    lfo = osc_value(wl, s.lfo.phase, half, nzl);
+  }
+  if (ext_phase) {
+    s.o1.phase = ph1; s.o2.phase = ph2;
+  } else if (!is_first) {
+    s.o1.phase += s.o1_inc; s.o2.phase += s.o2_inc;
+  }
+  const float v1 = osc_value(w1, s.o1.phase, d1, nz1);
+  const float v2 = osc_value(w2, s.o2.phase, d2, nz2);
+  x = fmaf(v1, p.mix, v2 * (1.0f - p.mix));
+  if (RETUNE) {
+    bool retune = false;
+    float pct = 0.0f;
+    if (fl & WF_RETUNE_ENV) {
+      pct = fmaf((1.0f - p.cutoff_start) * p.cutoff_end, s.fil.value, p.cutoff_start);
+      retune = true;
+    } else if (fl & WF_LFO_CUTOFF) {
+      pct = p.cutoff_start * fmaf(lfo, p.lfo_depth, 1.0f);
+      retune = true;
+    }
+    if (fl & WF_LFO_RESO) {
+      const Lp24Consts c = lp24_consts_from_ripple(p.ripple * fmaf(lfo, p.lfo_depth, 1.0f));
+      const float fc = retune ? 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f) : p.cutoff_hz;
+      coef = lp24_coefd_from_fc(c, fc, rc.pi_over_sr, rc.fc_max);
+    } else if (retune && pct != prev_pct) {
+      const float fc = 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f);
+      coef = lp24_coefd_from_fc(p.fc, fc, rc.pi_over_sr, rc.fc_max);
+      prev_pct = pct;
+    }
+  }
+  a = s.amp.value;
+  if (fl & WF_LFO_AMP) a *= fmaf(lfo, p.lfo_depth, 1.0f);
+}
+GROOVE_HD bool welsh_tp_scans(const WelshParams& p) { return (p.flags & (WF_LFO_PITCH | WF_SYNC)) != 0; }
+GROOVE_HD bool welsh_tp_noise(const WelshParams& p, int osc /*0: osc 1, 1: osc 2, 2: LFO*/) {
+  const uint32_t sh = osc == 0 ? (uint32_t)WF_O1_WAVE_SHIFT : (osc == 1 ? (uint32_t)WF_O2_WAVE_SHIFT : (uint32_t)WF_LFO_WAVE_SHIFT);
+  return ((p.flags >> sh) & 15u) == GROOVE_WAVE_NOISE;
+}
+
+#if defined(__HIPCC__)
+// ------------------------------------------------------------------ the kernel
+constexpr int kTpWaves = 4;                 // voices per workgroup
+constexpr int kTpThreads = kTpWaves * 64;
+constexpr uint32_t kTpMaxVoices = 16384;    // measured crossover with the serial kernels ~24,000 voices (tools/tp_bench.py)
+
+template <class T> __device__ __forceinline__ T tp_shfl(T x, int src) {
+  static_assert(sizeof(T) == 8 || sizeof(T) == 4, "");
+  if constexpr (sizeof(T) == 8) {
+    const uint64_t b = __builtin_bit_cast(uint64_t, x);
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)b, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(b >> 32), src, 64);
+    return __builtin_bit_cast(T, ((uint64_t)hi << 32) | lo);
+  } else {
+    return __builtin_bit_cast(T, __shfl(__builtin_bit_cast(int, x), src, 64));
+  }
+}
+__device__ __forceinline__ void tp_shfl_affine(const Lp24Affine& m, int src, Lp24Affine& out) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { out.c0[i] = tp_shfl(m.c0[i], src); out.c1[i] = tp_shfl(m.c1[i], src); out.z[i] = tp_shfl(m.z[i], src); }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { out.c2[i] = tp_shfl(m.c2[i], src); out.c3[i] = tp_shfl(m.c3[i], src); }
+}
+struct TpArgs {
+  const uint32_t* params; uint32_t* state; float* out; size_t ch_stride; RenderConsts rc; uint32_t n, frames;
+};
+// FUSED: out = partial[workgroup][ch][frame] (the bus reduction's rows); otherwise the planar block [ch][frame][voice].
+template <bool FUSED>
+__global__ __launch_bounds__(kTpThreads, 2) void welsh_tp_kernel(TpArgs a) {
+  __shared__ float s_noise[kTpWaves][3][kTpMaxFrames];
+  __shared__ uint64_t s_sum2[kTpWaves][kTpMaxFrames];
+  __shared__ float s_tile[kTpWaves][2][kTpMaxFrames];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t v0 = blockIdx.x * kTpWaves + wave;
+  const bool voice = v0 < a.n;
+  const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(voice ? v0 : a.n - 1));
+  const uint32_t frames = a.frames, n = a.n;
+  const WelshParams p = make_scalar(soa_load<WelshParams>(a.params, n, v));
+  const WelshState s0 = soa_load<WelshState>(a.state, n, v); // the same in every lane
+  const RenderConsts rc = a.rc;
+  const bool first0 = (s0.vflags & VF_FIRST) != 0;
+  const uint32_t live_total = env_idle_at(s0.amp, p.amp, frames);
+  const bool retunes = welsh_retunes(p), scans = welsh_tp_scans(p);
+  const bool nz_any = welsh_tp_noise(p, 0) || welsh_tp_noise(p, 1) || welsh_tp_noise(p, 2);
+
+  // ---- noise oscillators: one lane each, serially, values through LDS; end states stay in those lanes
+  OscState nz_end = lane == 0 ? s0.o1 : (lane == 1 ? s0.o2 : s0.lfo);
+  if (nz_any) {
+    if (lane < 3 && welsh_tp_noise(p, (int)lane)) {
+      for (uint32_t j = 0; j < live_total; ++j) s_noise[wave][lane][j] = noise_tick(nz_end);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- this lane's frames
+  const uint32_t n0 = lane * kTpChunk;
+  const uint32_t cnt = n0 < frames ? (frames - n0 < kTpChunk ? frames - n0 : kTpChunk) : 0u;
+  WelshState s = s0;
+  env_seek(s.amp, p.amp, n0 < frames ? n0 : 0u);
+  env_seek(s.fil, p.fil, n0 < frames ? n0 : 0u);
+  const uint32_t live_before = n0 < live_total ? n0 : live_total;                   // live frames before n0
+  const uint64_t adv = (uint64_t)(live_before - ((first0 && live_before >= 1u) ? 1u : 0u)); // phase advances before n0
+  s.lfo.phase = s0.lfo.phase + adv * p.lfo_inc;
+  s.o1.phase = s0.o1.phase + adv * s0.o1_inc;
+  s.o2.phase = s0.o2.phase + adv * s0.o2_inc;
+  if (live_before >= 1u) s.vflags = 0;
+
+  // pass 1 (scanned phases): per-frame increments, prefix sums over the block, wrap positions
+  uint64_t ph1[kTpChunk] = {}, ph2[kTpChunk] = {};
+  if (scans) {
+    uint64_t inc1[kTpChunk], inc2[kTpChunk], run1 = 0, run2 = 0, loc1[kTpChunk], loc2[kTpChunk];
+    uint64_t lph = s.lfo.phase;
+#pragma unroll
+    for (uint32_t j = 0; j < kTpChunk; ++j) {
+      const uint32_t f = n0 + j;
+      const bool live = j < cnt && f < live_total, is_first = first0 && f == 0;
+      inc1[j] = 0; inc2[j] = 0;
+      if (live) {
+        if (!is_first) lph += p.lfo_inc;
+        const float nzl = welsh_tp_noise(p, 2) ? s_noise[wave][2][f] : 0.0f;
+        if (!is_first) welsh_tp_incs(p, s0, lph, nzl, inc1[j], inc2[j]);
+      }
+      run1 += inc1[j]; run2 += inc2[j];
+      loc1[j] = run1; loc2[j] = run2;
+    }
+    // exclusive prefix over the lanes of the lane totals (Hillis-Steele on the inclusive sums)
+    uint64_t t1 = run1, t2 = run2;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint64_t o1 = tp_shfl(t1, (int)lane - d), o2 = tp_shfl(t2, (int)lane - d);
+      if ((int)lane >= d) { t1 += o1; t2 += o2; }
+    }
+    const uint64_t base1 = t1 - run1, base2 = t2 - run2;
+    int wlast = -1; // last frame <= f at which oscillator 1 wrapped (hard sync), within this lane so far
+#pragma unroll
+    for (uint32_t j = 0; j < kTpChunk; ++j) {
+      ph1[j] = s0.o1.phase + base1 + loc1[j];
+      if (ph1[j] < inc1[j]) wlast = (int)(n0 + j); // carry out of the add (inc 0: never)
+      loc2[j] += base2;                              // inclusive prefix of the oscillator-2 increments at frame n0 + j
+    }
+    if (p.flags & WF_SYNC) {
+#pragma unroll
+      for (uint32_t j = 0; j < kTpChunk; ++j) if (j < cnt) s_sum2[wave][n0 + j] = loc2[j];
+      int wl_incl = wlast; // max-scan over the lanes
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl(wl_incl, (int)lane - d, 64);
+        if ((int)lane >= d && o > wl_incl) wl_incl = o;
+      }
+      int wprev = __shfl(wl_incl, (int)lane - 1, 64);
+      if (lane == 0) wprev = -1;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      int w = wprev;
+#pragma unroll
+      for (uint32_t j = 0; j < kTpChunk; ++j) {
+        if (ph1[j] < inc1[j]) w = (int)(n0 + j);
+        if (j < cnt) ph2[j] = w >= 0 ? loc2[j] - s_sum2[wave][w] : s0.o2.phase + loc2[j];
+      }
+    } else {
+#pragma unroll
+      for (uint32_t j = 0; j < kTpChunk; ++j) ph2[j] = s0.o2.phase + loc2[j];
+    }
+  }
+
+  // pass 2: the frames' feed-forward values; the filter's affine map of this chunk
+  float x[kTpChunk], amp[kTpChunk];
+  Lp24CoefD coef[kTpChunk];
+  bool lives[kTpChunk];
+  Lp24CoefD cur = lp24_coefd_from_fc(p.fc, p.cutoff_hz, rc.pi_over_sr, rc.fc_max);
+  float prev_pct = __builtin_nanf("");
+  Lp24Affine mine;
+  lp24_affine_identity(mine);
+#pragma unroll
+  for (uint32_t j = 0; j < kTpChunk; ++j) {
+    const uint32_t f = n0 + j;
+    x[j] = 0.0f; amp[j] = 0.0f; lives[j] = false;
+    if (j < cnt) {
+      env_tick(s.amp, p.amp);
+      env_tick(s.fil, p.fil);
+      if (f < live_total) {
+        lives[j] = true;
+        const bool is_first = first0 && f == 0;
+        const float nz1 = welsh_tp_noise(p, 0) ? s_noise[wave][0][f] : 0.0f;
+        const float nz2 = welsh_tp_noise(p, 1) ? s_noise[wave][1][f] : 0.0f;
+        const float nzl = welsh_tp_noise(p, 2) ? s_noise[wave][2][f] : 0.0f;
+        if (retunes) welsh_tp_frame<true>(p, s, rc, is_first, scans, ph1[j], ph2[j], nz1, nz2, nzl, cur, prev_pct, x[j], amp[j]);
+        else welsh_tp_frame<false>(p, s, rc, is_first, scans, ph1[j], ph2[j], nz1, nz2, nzl, cur, prev_pct, x[j], amp[j]);
+        s.vflags = 0;
+        lp24_affine_push(mine, cur, (double)x[j]);
+      } else if (scans) { // phases stay where the last live frame left them
+        s.o1.phase = ph1[j]; s.o2.phase = ph2[j];
+      }
+    }
+    coef[j] = cur;
+  }
+  // inclusive scan of the affine maps over the lanes, then every lane's start state
+  Lp24Affine incl = mine;
+#pragma unroll 1
+  for (int d = 1; d < 64; d <<= 1) {
+    Lp24Affine other;
+    tp_shfl_affine(incl, (int)lane - d, other);
+    if ((int)lane >= d) lp24_affine_compose(incl, other);
+  }
+  const double s_init[4] = {s0.filt.s0, s0.filt.s1, s0.filt.s2, s0.filt.s3};
+  double s_end[4];
+  lp24_affine_mul(incl, s_init, s_end, true);
+  double st[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { st[i] = tp_shfl(s_end[i], (int)lane - 1); if (lane == 0) st[i] = s_init[i]; }
+  float oL[kTpChunk], oR[kTpChunk];
+#pragma unroll
+  for (uint32_t j = 0; j < kTpChunk; ++j) {
+    float y = 0.0f;
+    if (lives[j]) y = (float)lp24_step_v(st, coef[j], (double)x[j]);
+    const float m = y * amp[j];
+    oL[j] = m * p.gl; oR[j] = m * p.gr;
+  }
+
+  // ---- outputs
+  if (FUSED) {
+#pragma unroll
+    for (uint32_t j = 0; j < kTpChunk; ++j) {
+      s_tile[wave][0][n0 + j] = (voice && j < cnt) ? oL[j] : 0.0f;
+      s_tile[wave][1][n0 + j] = (voice && j < cnt) ? oR[j] : 0.0f;
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < 2 * frames; t += kTpThreads) {
+      const uint32_t ch = t / frames, f = t % frames;
+      float acc = 0.0f;
+#pragma unroll
+      for (int w = 0; w < kTpWaves; ++w) acc += s_tile[w][ch][f];
+      a.out[((size_t)blockIdx.x * 2 + ch) * frames + f] = acc;
+    }
+  } else if (voice) {
+#pragma unroll
+    for (uint32_t j = 0; j < kTpChunk; ++j) {
+      if (j < cnt) {
+        a.out[(size_t)(n0 + j) * n + v] = oL[j];
+        a.out[a.ch_stride + (size_t)(n0 + j) * n + v] = oR[j];
+      }
+    }
+  }
+
+  // ---- state after the block: the lane that holds the last frame has every running value
+  const uint32_t last = frames ? (frames - 1) / kTpChunk : 0u;
+  OscState e1 = nz_end, e2 = nz_end, el = nz_end;
+  e1.x1 = tp_shfl(nz_end.x1, 0); e1.x2 = tp_shfl(nz_end.x2, 0);
+  e2.x1 = tp_shfl(nz_end.x1, 1); e2.x2 = tp_shfl(nz_end.x2, 1);
+  el.x1 = tp_shfl(nz_end.x1, 2); el.x2 = tp_shfl(nz_end.x2, 2);
+  if (voice && lane == last && frames) {
+    s.o1.x1 = e1.x1; s.o1.x2 = e1.x2; s.o2.x1 = e2.x1; s.o2.x2 = e2.x2; s.lfo.x1 = el.x1; s.lfo.x2 = el.x2;
+    s.filt.s0 = s_end[0]; s.filt.s1 = s_end[1]; s.filt.s2 = s_end[2]; s.filt.s3 = s_end[3];
+    soa_store(a.state, n, v, s);
+  }
+}
+void launch_welsh_tp(const TpArgs& a, hipStream_t st, bool fused);
+inline uint32_t welsh_tp_workgroups(uint32_t n) { return (n + kTpWaves - 1) / kTpWaves; }
+#endif // __HIPCC__
+
+} // namespace groove

@@ -1,0 +1,12 @@
+// welsh_tp.hip — the time-parallel Welsh kernel (welsh_tp.h: one wavefront per voice, lanes = time), its own
+// translation unit so that it builds beside the class-specialised ones.
+#define GROOVE_WELSH_CLASS_TU 1
+#include "kernels.h"
+#include "welsh_tp.h"
+namespace groove {
+void launch_welsh_tp(const TpArgs& a, hipStream_t st, bool fused) {
+  const dim3 grid(welsh_tp_workgroups(a.n)), blk(kTpThreads);
+  if (fused) hipLaunchKernelGGL(welsh_tp_kernel<true>, grid, blk, 0, st, a);
+  else hipLaunchKernelGGL(welsh_tp_kernel<false>, grid, blk, 0, st, a);
+}
+} // namespace groove

@@ -35,6 +35,14 @@ class Context:
     def sample_rate(self):
         return self.L.groove_sample_rate(self.h)
 
+    @property
+    def time_parallel_max_voices(self):
+        return self.L.groove_time_parallel_max_voices(self.h)
+
+    @time_parallel_max_voices.setter
+    def time_parallel_max_voices(self, n):
+        _lib.check(self.L.groove_set_time_parallel_max_voices(self.h, n), self.h)
+
     def set_stream(self, hip_stream):
         _lib.check(self.L.groove_set_stream(self.h, C.c_void_p(hip_stream)), self.h)
 

@@ -24,6 +24,8 @@ SYMBOLS = {
     "groove_synchronize": (_i, [_vp]),
     "groove_update_sample_rate": (_i, [_vp, _u32]),
     "groove_sample_rate": (_u32, [_vp]),
+    "groove_set_time_parallel_max_voices": (_i, [_vp, _u32]),
+    "groove_time_parallel_max_voices": (_u32, [_vp]),
     "groove_event_create": (_i, [_vp, _vpp]),
     "groove_event_destroy": (_i, [_vp, _vp]),
     "groove_event_record": (_i, [_vp, _vp]),

@@ -48,6 +48,13 @@ int groove_synchronize(groove_ctx* ctx);
  * Re-derives every bank/effect created on this ctx and resets their state. */
 int groove_update_sample_rate(groove_ctx* ctx, uint32_t hz);
 uint32_t groove_sample_rate(groove_ctx* ctx);
+/* Tuning: Welsh banks of up to this many voices render a block (of up to 256 frames) TIME-PARALLEL, one
+ * wavefront per voice with the frames spread over its lanes (csrc/welsh_tp.h), instead of one voice per
+ * lane walking the frames serially — the form that is latency-bound below ~250,000 voices.  Same results
+ * to f64 rounding of the filter.  0 = always the serial kernels.  Default 16,384 (GROOVE_TP_MAX_VOICES in
+ * the environment overrides it at groove_init).  No reference counterpart. */
+int groove_set_time_parallel_max_voices(groove_ctx* ctx, uint32_t max_voices);
+uint32_t groove_time_parallel_max_voices(groove_ctx* ctx);
 /* HIP events on the ctx stream, for measurement (bench.py): create / record / elapsed. */
 int groove_event_create(groove_ctx* ctx, void** out_event);
 int groove_event_destroy(groove_ctx* ctx, void* event);

@@ -25,3 +25,13 @@ def gpu_ctx():
     ctx = E.Context(0)  # raises loudly if libgroove_hip.so or the GPU is missing
     yield ctx
     ctx.close()
+
+
+@pytest.fixture()
+def serial_kernels(gpu_ctx):
+    """The serial (one voice per lane) Welsh kernels whatever the bank size: tests that target them
+    (class-specialised bodies, the all-kinds kernel, the per-lane kernel) switch the time-parallel form off."""
+    old = gpu_ctx.time_parallel_max_voices
+    gpu_ctx.time_parallel_max_voices = 0
+    yield gpu_ctx
+    gpu_ctx.time_parallel_max_voices = old

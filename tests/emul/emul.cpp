@@ -5,12 +5,13 @@
 // device code can be checked against the f64 oracle in the GPU-less CI tier.  It is not
 // shipped, not linked into libgroove_hip.so, and the product never calls it.
 #include "../../groove_amd/csrc/derive.h"
+#include "../../groove_amd/csrc/welsh_tp.h"
 #include <vector>
 #include <cstring>
 using namespace groove;
 
 struct EmulBank {
-  int kind; uint32_t n; double sr; int generic_lfo = 0; int segmented = 1;
+  int kind; uint32_t n; double sr; int generic_lfo = 0; int segmented = 1; int time_parallel = 0;
   std::vector<WelshParams> wp; std::vector<WelshState> ws; std::vector<WelshCold> wc;
   std::vector<FmParams> fp; std::vector<FmState> fs; std::vector<double> ratio;
   std::vector<SamplerParams> sp; std::vector<SamplerState> ss; std::vector<float> pcm;
@@ -39,7 +40,127 @@ static void welsh_emul_segment_frame(const WelshParams& p, WelshState& s, const 
   if (retune) welsh_emul_segment_frame2<true>(p, s, rc, sc, mode, L, R); else welsh_emul_segment_frame2<false>(p, s, rc, sc, mode, L, R);
 }
 
+// The time-parallel form (welsh_tp.h) with a loop over 64 "lanes" in place of the wavefront: the per-lane
+// functions are the kernel's, the cross-lane steps (prefix sums, max-scan, affine-map scan) plain loops.
+static void welsh_tp_render_voice(const WelshParams& p, WelshState& state, const RenderConsts& rc, uint32_t frames, float* outL, float* outR) {
+  const WelshState s0 = state;
+  const bool first0 = (s0.vflags & VF_FIRST) != 0;
+  const uint32_t live_total = env_idle_at(s0.amp, p.amp, frames);
+  const bool retunes = welsh_retunes(p), scans = welsh_tp_scans(p);
+  std::vector<float> nz[3];
+  OscState nz_end[3] = {s0.o1, s0.o2, s0.lfo};
+  for (int o = 0; o < 3; ++o) {
+    nz[o].assign(kTpMaxFrames, 0.0f);
+    if (welsh_tp_noise(p, o)) for (uint32_t j = 0; j < live_total; ++j) nz[o][j] = noise_tick(nz_end[o]);
+  }
+  struct Lane {
+    WelshState s; uint32_t n0, cnt; uint64_t ph1[kTpChunk], ph2[kTpChunk], inc1[kTpChunk], loc1[kTpChunk], loc2[kTpChunk], run1, run2;
+    float x[kTpChunk], amp[kTpChunk]; Lp24CoefD coef[kTpChunk]; bool lives[kTpChunk]; Lp24Affine mine, incl; double s_end[4];
+  };
+  std::vector<Lane> L(kTpLanes);
+  for (uint32_t lane = 0; lane < kTpLanes; ++lane) {
+    Lane& l = L[lane];
+    l.n0 = lane * kTpChunk;
+    l.cnt = l.n0 < frames ? (frames - l.n0 < kTpChunk ? frames - l.n0 : kTpChunk) : 0u;
+    l.s = s0;
+    env_seek(l.s.amp, p.amp, l.n0 < frames ? l.n0 : 0u);
+    env_seek(l.s.fil, p.fil, l.n0 < frames ? l.n0 : 0u);
+    const uint32_t live_before = l.n0 < live_total ? l.n0 : live_total;
+    const uint64_t adv = (uint64_t)(live_before - ((first0 && live_before >= 1u) ? 1u : 0u));
+    l.s.lfo.phase = s0.lfo.phase + adv * p.lfo_inc;
+    l.s.o1.phase = s0.o1.phase + adv * s0.o1_inc;
+    l.s.o2.phase = s0.o2.phase + adv * s0.o2_inc;
+    if (live_before >= 1u) l.s.vflags = 0;
+    l.run1 = l.run2 = 0;
+    for (uint32_t j = 0; j < kTpChunk; ++j) { l.ph1[j] = l.ph2[j] = l.inc1[j] = 0; }
+    if (scans) {
+      uint64_t lph = l.s.lfo.phase;
+      for (uint32_t j = 0; j < kTpChunk; ++j) {
+        const uint32_t f = l.n0 + j;
+        const bool live = j < l.cnt && f < live_total, is_first = first0 && f == 0;
+        uint64_t i1 = 0, i2 = 0;
+        if (live) {
+          if (!is_first) lph += p.lfo_inc;
+          if (!is_first) welsh_tp_incs(p, s0, lph, nz[2][f < kTpMaxFrames ? f : 0], i1, i2);
+        }
+        l.inc1[j] = i1; l.run1 += i1; l.run2 += i2; l.loc1[j] = l.run1; l.loc2[j] = l.run2;
+      }
+    }
+  }
+  if (scans) {
+    uint64_t base1 = 0, base2 = 0;
+    int wprev = -1;
+    std::vector<uint64_t> sum2(kTpMaxFrames, 0);
+    for (uint32_t lane = 0; lane < kTpLanes; ++lane) { // prefix sums first (the gather below reads other lanes' entries)
+      Lane& l = L[lane];
+      for (uint32_t j = 0; j < kTpChunk; ++j) { l.ph1[j] = s0.o1.phase + base1 + l.loc1[j]; l.loc2[j] += base2; if (j < l.cnt) sum2[l.n0 + j] = l.loc2[j]; }
+      base1 += l.run1; base2 += l.run2;
+    }
+    for (uint32_t lane = 0; lane < kTpLanes; ++lane) {
+      Lane& l = L[lane];
+      int w = wprev;
+      for (uint32_t j = 0; j < kTpChunk; ++j) {
+        if (l.ph1[j] < l.inc1[j]) w = (int)(l.n0 + j);
+        if (p.flags & WF_SYNC) { if (j < l.cnt) l.ph2[j] = w >= 0 ? l.loc2[j] - sum2[w] : s0.o2.phase + l.loc2[j]; }
+        else l.ph2[j] = s0.o2.phase + l.loc2[j];
+      }
+      wprev = w;
+    }
+  }
+  for (uint32_t lane = 0; lane < kTpLanes; ++lane) {
+    Lane& l = L[lane];
+    Lp24CoefD cur = lp24_coefd_from_fc(p.fc, p.cutoff_hz, rc.pi_over_sr, rc.fc_max);
+    float prev_pct = __builtin_nanf("");
+    lp24_affine_identity(l.mine);
+    for (uint32_t j = 0; j < kTpChunk; ++j) {
+      const uint32_t f = l.n0 + j;
+      l.x[j] = 0.0f; l.amp[j] = 0.0f; l.lives[j] = false;
+      if (j < l.cnt) {
+        env_tick(l.s.amp, p.amp);
+        env_tick(l.s.fil, p.fil);
+        if (f < live_total) {
+          l.lives[j] = true;
+          const bool is_first = first0 && f == 0;
+          if (retunes) welsh_tp_frame<true>(p, l.s, rc, is_first, scans, l.ph1[j], l.ph2[j], nz[0][f], nz[1][f], nz[2][f], cur, prev_pct, l.x[j], l.amp[j]);
+          else welsh_tp_frame<false>(p, l.s, rc, is_first, scans, l.ph1[j], l.ph2[j], nz[0][f], nz[1][f], nz[2][f], cur, prev_pct, l.x[j], l.amp[j]);
+          l.s.vflags = 0;
+          lp24_affine_push(l.mine, cur, (double)l.x[j]);
+        } else if (scans) { l.s.o1.phase = l.ph1[j]; l.s.o2.phase = l.ph2[j]; }
+      }
+      l.coef[j] = cur;
+    }
+    l.incl = l.mine;
+  }
+  for (int d = 1; d < (int)kTpLanes; d <<= 1) { // Hillis-Steele, as the wavefront does it
+    std::vector<Lp24Affine> prev(kTpLanes);
+    for (uint32_t lane = 0; lane < kTpLanes; ++lane) prev[lane] = L[lane].incl;
+    for (uint32_t lane = d; lane < kTpLanes; ++lane) lp24_affine_compose(L[lane].incl, prev[lane - d]);
+  }
+  const double s_init[4] = {s0.filt.s0, s0.filt.s1, s0.filt.s2, s0.filt.s3};
+  for (uint32_t lane = 0; lane < kTpLanes; ++lane) lp24_affine_mul(L[lane].incl, s_init, L[lane].s_end, true);
+  for (uint32_t lane = 0; lane < kTpLanes; ++lane) {
+    Lane& l = L[lane];
+    double st[4];
+    for (int i = 0; i < 4; ++i) st[i] = lane ? L[lane - 1].s_end[i] : s_init[i];
+    for (uint32_t j = 0; j < l.cnt; ++j) {
+      float y = 0.0f;
+      if (l.lives[j]) y = (float)lp24_step_v(st, l.coef[j], (double)l.x[j]);
+      const float m = y * l.amp[j];
+      outL[l.n0 + j] = m * p.gl; outR[l.n0 + j] = m * p.gr;
+    }
+  }
+  if (frames) {
+    Lane& l = L[(frames - 1) / kTpChunk];
+    l.s.o1.x1 = nz_end[0].x1; l.s.o1.x2 = nz_end[0].x2; l.s.o2.x1 = nz_end[1].x1; l.s.o2.x2 = nz_end[1].x2;
+    l.s.lfo.x1 = nz_end[2].x1; l.s.lfo.x2 = nz_end[2].x2;
+    l.s.filt.s0 = l.s_end[0]; l.s.filt.s1 = l.s_end[1]; l.s.filt.s2 = l.s_end[2]; l.s.filt.s3 = l.s_end[3];
+    state = l.s;
+  }
+}
+
 extern "C" {
+// time_parallel != 0: Welsh voices render through the time-parallel form (blocks of up to 256 frames)
+void emul_set_time_parallel(void* h, int on);
 // segmented != 0 (default): frames after the first run in boundary-free segments, as in the uniform kernels
 void emul_set_segmented(void* h, int on);
 // generic_lfo != 0: evaluate the f64 LFO exactly on every frame (the per-lane kernel's choice) instead of the recurrences
@@ -69,6 +190,7 @@ void* emul_sampler_create(const float* pcm, uint64_t frames, const groove_sample
 void emul_bank_destroy(void* h) { delete (EmulBank*)h; }
 void emul_set_generic_lfo(void* h, int on) { ((EmulBank*)h)->generic_lfo = on; }
 void emul_set_segmented(void* h, int on) { ((EmulBank*)h)->segmented = on; }
+void emul_set_time_parallel(void* h, int on) { ((EmulBank*)h)->time_parallel = on; }
 void emul_bank_note_events(void* h, const groove_note_event* ev, uint32_t n_ev) {
   EmulBank* b = (EmulBank*)h;
   for (uint32_t i = 0; i < n_ev; ++i) {
@@ -87,6 +209,12 @@ void emul_bank_render(void* h, uint32_t frames, float* out) {
   const uint32_t n = b->n;
   RenderConsts rc{(float)(3.14159265358979323846 / b->sr), (float)(0.49 * b->sr)};
   for (uint32_t v = 0; v < n; ++v) {
+    if (b->kind == 0 && b->time_parallel && frames <= kTpMaxFrames) {
+      std::vector<float> l(frames), r(frames);
+      welsh_tp_render_voice(b->wp[v], b->ws[v], rc, frames, l.data(), r.data());
+      for (uint32_t f = 0; f < frames; ++f) { out[(size_t)f * n + v] = l[f]; out[((size_t)frames + f) * n + v] = r[f]; }
+      continue;
+    }
     WelshScratch sc{};
     bool retunes = false;
     int mode = LFO_F64;

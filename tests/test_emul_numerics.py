@@ -127,3 +127,44 @@ def test_extended_lfo_routings_arithmetic(oracle):
     differs = np.sqrt(np.mean((o2 - o) ** 2, axis=(0, 1))) > 1e-4
     # (pw-osc1 equals pulse-width when oscillator 2 is not a pulse wave: nothing else for the LFO to move)
     assert differs[[i for i in range(n) if not (i % 5 == 1 and pats[i].oscillator_2.waveform != T.WAVE_PULSE_WIDTH)]].all()
+
+
+def test_time_parallel_form_matches_serial_and_oracle(oracle):
+    """welsh_tp.h (one wavefront per voice, lanes = time: envelope seek, phase prefix sums, hard-sync max-scan,
+    the filter as a scan of affine maps) against the serial per-lane form and the oracle: all 32 synthetic
+    patches plus the extended routings, note-on, release, idle tails, re-trigger, ragged block lengths; the
+    voice STATE after every block is compared too (it is what the next block starts from)."""
+    pats = [P.welsh_patch(j) for j in range(32)]
+    for k, r in enumerate([T.LFO_PITCH_OSC2, T.LFO_PW_OSC1, T.LFO_PW_OSC2, T.LFO_RESONANCE, T.LFO_CUTOFF_AMP]):
+        p = P.welsh_patch(4 + 5 * k)
+        p.oscillator_1.waveform, p.oscillator_1.duty = T.WAVE_PULSE_WIDTH, 0.3
+        p.lfo_routing, p.lfo_depth = r, 0.2
+        if r == T.LFO_CUTOFF_AMP:
+            p.filter_cutoff_end = 0.0
+        pats.append(p)
+    q = P.welsh_patch(1); q.oscillator_2_sync = 1; q.lfo_routing = T.LFO_PITCH; q.lfo_waveform = T.WAVE_TRIANGLE; pats.append(q)  # sync + pitch LFO
+    q = P.welsh_patch(5); q.lfo_waveform = T.WAVE_NOISE; q.lfo_routing = T.LFO_AMPLITUDE; pats.append(q)                            # noise LFO
+    n = len(pats)
+    params = (T.WelshParams * n)(*pats)
+    keys = (38 + (7 * np.arange(n)) % 40).astype(np.uint8)
+    keys[keys % 12 == 9] += 1   # no A notes (rational frequency / sample-rate pairs tie exactly, DSP_SPEC §2)
+    on = T.note_events_np(np.arange(n, dtype=np.uint32), keys, True)
+    off = T.note_events_np(np.arange(n, dtype=np.uint32), keys, False)
+    tp, ser, orc = E.Bank.welsh(params), E.Bank.welsh(params), oracle.Bank.welsh(params)
+    tp.set_time_parallel(True); ser.set_segmented(False); ser.set_generic_lfo(True)
+    worst_ser = worst_orc = 0.0
+    sig = 0.0
+    for blk in range(70):
+        if blk in (0, 45):
+            for b in (tp, ser, orc): b.note_events(on)
+        if blk == 20:
+            for b in (tp, ser, orc): b.note_events(off)
+        frames = [256, 256, 100, 7, 1, 255][blk % 6]
+        a, b_, c = tp.render(frames).astype(np.float64), ser.render(frames).astype(np.float64), orc.render(frames)
+        scale = np.maximum(1.0, np.abs(c).max(axis=(0, 1)))
+        worst_ser = max(worst_ser, float((np.abs(a - b_).max(axis=(0, 1)) / scale).max()))
+        worst_orc = max(worst_orc, float((np.sqrt(np.mean((a - c) ** 2, axis=(0, 1))) / scale).max()))
+        sig = max(sig, float(np.abs(c).max()))
+    assert sig > 0.1
+    assert worst_ser <= 2e-6, worst_ser     # same fp32 feed-forward values; the filter differs by f64 rounding only
+    assert worst_orc <= 1e-5, worst_orc

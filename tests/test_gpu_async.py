@@ -7,6 +7,15 @@ from groove_amd import patches as P, abi_types as T
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["serial", "time-parallel"])
+def kernel_form(request, gpu_ctx):
+    """Both forms of the Welsh render (kernels.h: one voice per lane; welsh_tp.h: one wavefront per voice)."""
+    old = gpu_ctx.time_parallel_max_voices
+    gpu_ctx.time_parallel_max_voices = 0 if request.param == "serial" else old
+    yield request.param
+    gpu_ctx.time_parallel_max_voices = old
+
 FRAMES = 256
 
 

@@ -12,6 +12,17 @@ from groove_amd import patches as P, abi_types as T
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["serial", "time-parallel"])
+def kernel_form(request, gpu_ctx):
+    """Every test of this module runs against both forms of the Welsh render: one voice per lane walking the
+    frames (kernels.h) and one wavefront per voice with the frames over its lanes (welsh_tp.h, the default for
+    banks this small)."""
+    old = gpu_ctx.time_parallel_max_voices
+    gpu_ctx.time_parallel_max_voices = 0 if request.param == "serial" else old
+    yield request.param
+    gpu_ctx.time_parallel_max_voices = old
+
 TOL_RMS = 1e-5
 
 
@@ -257,6 +268,7 @@ def test_pipelined_blocks_with_events_controls_and_state_reads(oracle, monkeypat
     events mid-render, a control change, a state download, a materialised render.  Bus vs the oracle."""
     from groove_amd import entities as E
     monkeypatch.setenv("GROOVE_PIPELINE_MIN_WAVES", "1")
+    monkeypatch.setenv("GROOVE_TP_MAX_VOICES", "0")   # the serial kernels' pipeline is the subject here
     ctx = E.Context(0)
     n, frames, blocks = 2048, 256, 24
     params, vidx = P.welsh_voices_grouped(n)

@@ -18,6 +18,15 @@ from groove_amd import patches as P, abi_types as T
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["serial", "time-parallel"])
+def kernel_form(request, gpu_ctx):
+    """Both forms of the Welsh render (kernels.h: one voice per lane; welsh_tp.h: one wavefront per voice)."""
+    old = gpu_ctx.time_parallel_max_voices
+    gpu_ctx.time_parallel_max_voices = 0 if request.param == "serial" else old
+    yield request.param
+    gpu_ctx.time_parallel_max_voices = old
+
 WAVES = [T.WAVE_NONE, T.WAVE_SINE, T.WAVE_SQUARE, T.WAVE_PULSE_WIDTH, T.WAVE_TRIANGLE, T.WAVE_SAWTOOTH,
          T.WAVE_NOISE, T.WAVE_TRIANGLE_SINE, T.WAVE_DEBUG_MAX]
 LFO_WAVES = [T.WAVE_SINE, T.WAVE_TRIANGLE, T.WAVE_SQUARE, T.WAVE_SAWTOOTH, T.WAVE_NOISE]
