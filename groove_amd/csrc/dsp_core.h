@@ -277,6 +277,11 @@ GROOVE_HD void env_advance(EnvState& s) {
   s.value = fmaf(s.D, fmaf(-t, t, 2.0f * t), s.A);
   s.n += 1;
 }
+// value of the most recent tick (the stage counter has already moved past it)
+GROOVE_HD float env_last_value_of(const EnvState& s) {
+  const float t = (float)(s.n - 1u) * s.inv_len;
+  return fmaf(s.D, fmaf(-t, t, 2.0f * t), s.A);
+}
 GROOVE_HD void env_tick(EnvState& s, const EnvParams& p) {
   env_boundary(s, p);
   env_advance(s);
@@ -284,6 +289,23 @@ GROOVE_HD void env_tick(EnvState& s, const EnvParams& p) {
 // frames this envelope can advance before its next boundary check must run (>= 1 right after env_boundary)
 GROOVE_HD uint32_t env_frames_to_boundary(const EnvState& s) { return s.N - s.n; }
 
+// Launch-wide constants of the render kernels (sample-rate dependent).
+struct RenderConsts {
+  float pi_over_sr; // pi / SR
+  float fc_max;     // 0.49 * SR
+  // per-frame retune: x = pi fc / SR of fc = 25 * 800^pct is ONE exp2 with the constants folded into its argument
+  float log2_x0;    // log2(25 pi / SR)
+  float x_lo, x_hi; // pi / SR (fc = 1 Hz), 0.49 pi (fc = 0.49 SR): the clamp of fc, applied to x
+};
+GROOVE_HD RenderConsts render_consts(double sr) {
+  RenderConsts rc;
+  rc.pi_over_sr = (float)(3.14159265358979323846 / sr);
+  rc.fc_max = (float)(0.49 * sr);
+  rc.log2_x0 = (float)log2(25.0 * 3.14159265358979323846 / sr);
+  rc.x_lo = (float)(3.14159265358979323846 / sr);
+  rc.x_hi = (float)(0.49 * 3.14159265358979323846);
+  return rc;
+}
 // ------------------------------------------------------------------ 24 dB low-pass (a4)
 // Per-voice constants: c0 = 1/(cosh^2 r - 0.8535..), d1 = c0 sinh r 1.8477..,
 // c2 = 1/(cosh^2 r - 0.1464..), d3 = c2 sinh r 0.7653..  (host, f64 -> f32).
@@ -349,6 +371,53 @@ GROOVE_HD Lp24CoefD lp24_coefd_from_fc(const Lp24Consts& c, float fc, float pi_o
     const float ib = fast_rcp(1.0f + dtb + Pb);
     d.b0a = (double)(1.0f * ia); d.a1a = (double)(2.0f * (dta + 2.0f * Pa) * ia) - 2.0; d.a2a = (double)(2.0f * dta * ia) - 1.0;
     d.b0b = (double)(1.0f * ib); d.a1b = (double)(2.0f * (dtb + 2.0f * Pb) * ib) - 2.0; d.a2b = (double)(2.0f * dtb * ib) - 1.0;
+  }
+  return d;
+}
+// The per-frame retune of a voice: coefficients for cutoff PERCENT pct (fc = 25 * 800^pct Hz, clamped to
+// [1 Hz, 0.49 SR]).  Same mathematics as lp24_coefd_from_fc(c, 25 * 800^pct, ...), arranged for the frame loop:
+//   * x = pi fc / SR straight from one exp2 (constants folded into the exponent), the clamp of fc applied to x;
+//   * tan's argument is min(x, pi/2 - x);
+//   * q1 = q2 + 4 b0 (lower side; q2 + 4 P / D' on the upper side), so a1 = +-(2 - q1) is one f64 fma on the widened
+//     b0 and q2 instead of five more fp32 operations and a third conversion per section.
+GROOVE_HD float med3f(float x, float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_fmed3f(x, lo, hi);
+#else
+  return fminf(fmaxf(x, lo), hi);
+#endif
+}
+GROOVE_HD Lp24CoefD lp24_coefd_from_pct(const Lp24Consts& c, float pct, const RenderConsts& rc) {
+  const float x = med3f(fast_exp2(fmaf(clamp01f(pct), 9.6438561897747244f, rc.log2_x0)), rc.x_lo, rc.x_hi);
+  const bool hi = x > 0.78539816339744831f;
+  const float z = fminf(x, 1.57079632679489662f - x);
+  const float z2 = z * z;
+  float p = 9.449327447e-03f;
+  p = fmaf(p, z2, 2.985451510e-03f);
+  p = fmaf(p, z2, 2.453938616e-02f);
+  p = fmaf(p, z2, 5.336849955e-02f);
+  p = fmaf(p, z2, 1.333961619e-01f);
+  p = fmaf(p, z2, 3.333309016e-01f);
+  p = fmaf(p, z2, 1.000000015e+00f);
+  const float t = p * z;
+  const float T2 = t * t;
+  const float dta = c.d1 * t, dtb = c.d3 * t;
+  Lp24CoefD d;
+  if (!hi) {
+    const float ia = fast_rcp(c.c0 + dta + T2);
+    const float ib = fast_rcp(c.c2 + dtb + T2);
+    const double b0a = (double)(T2 * ia), q2a = (double)((dta + dta) * ia);
+    const double b0b = (double)(T2 * ib), q2b = (double)((dtb + dtb) * ib);
+    d.b0a = b0a; d.a1a = fma(-4.0, b0a, 2.0 - q2a); d.a2a = q2a - 1.0;
+    d.b0b = b0b; d.a1b = fma(-4.0, b0b, 2.0 - q2b); d.a2b = q2b - 1.0;
+  } else {
+    const float Pa = c.c0 * T2, Pb = c.c2 * T2;
+    const float ia = fast_rcp(1.0f + dta + Pa);
+    const float ib = fast_rcp(1.0f + dtb + Pb);
+    const double q2a = (double)((dta + dta) * ia), pa = (double)(Pa * ia);
+    const double q2b = (double)((dtb + dtb) * ib), pb = (double)(Pb * ib);
+    d.b0a = (double)ia; d.a1a = fma(4.0, pa, q2a - 2.0); d.a2a = q2a - 1.0;
+    d.b0b = (double)ib; d.a1b = fma(4.0, pb, q2b - 2.0); d.a2b = q2b - 1.0;
   }
   return d;
 }
@@ -456,16 +525,13 @@ struct WelshState {
   uint32_t vflags; // VF_FIRST
   uint32_t pad_;
 };
-struct RenderConsts {
-  float pi_over_sr; // pi / SR
-  float fc_max;     // 0.49 * SR
-};
 // Per-block scratch that lives in registers across frames but is not persisted.
 struct WelshScratch {
   Lp24CoefD coef;  // current filter coefficients
   float prev_pct;  // cutoff percent the coefficients were computed for (NaN = none)
   double ls, lc;   // LFO_F64_SMOOTH: LFO value of the previous frame (sine: sin), and cos of the sine LFO's angle
   double lm;       // LFO_F64_SMOOTH, pitch routing: 2^(ls * depth)
+  float ta, tf;    // HOIST: the two envelopes' stage counters as floats, for the frames of one segment
 };
 GROOVE_HD bool welsh_retunes(const WelshParams& p) {
   return (p.flags & (WF_RETUNE_ENV | WF_LFO_CUTOFF | WF_LFO_RESO)) != 0;
@@ -553,10 +619,21 @@ GROOVE_HD float osc_value_classed(uint32_t w, uint64_t phase, uint64_t duty64, f
     return osc_value(w, phase, duty64, noise_value);
   }
 }
-template <bool FIRST, bool RETUNE, int LFO_MODE = LFO_F64, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool SEGMENT = false, bool REST = false>
+// HOIST (with SEGMENT): the caller keeps the envelopes' stage counters for the segment — as floats in sc.ta /
+// sc.tf, which this frame reads and bumps (exact below 2^24 frames per stage), the integer counters moving once,
+// after the segment (welsh_segment_end) — and an unused LFO's phase moves there too: two conversions, two integer
+// adds and a 64-bit add less on every frame.
+template <bool FIRST, bool RETUNE, int LFO_MODE = LFO_F64, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool SEGMENT = false, bool REST = false,
+          bool HOIST = false>
 GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc,
                            WelshScratch& sc, float& L, float& R) {
-  if (SEGMENT) {
+  static_assert(!HOIST || (SEGMENT && !FIRST), "hoisted counters belong to a segment");
+  if (SEGMENT && HOIST) {
+    const float ta = sc.ta * s.amp.inv_len, tf = sc.tf * s.fil.inv_len;
+    s.amp.value = fmaf(s.amp.D, fmaf(-ta, ta, 2.0f * ta), s.amp.A);
+    s.fil.value = fmaf(s.fil.D, fmaf(-tf, tf, 2.0f * tf), s.fil.A);
+    sc.ta += 1.0f; sc.tf += 1.0f;
+  } else if (SEGMENT) {
     env_advance(s.amp);
     env_advance(s.fil);
   } else {
@@ -586,7 +663,7 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
   if (FIRST) s.vflags = 0;
 
   // LFO
-  if (!first) s.lfo.phase += p.lfo_inc;
+  if (!first && !(HOIST && NO_LFO)) s.lfo.phase += p.lfo_inc;
   float nzl = 0.0f;
   if (wl == GROOVE_WAVE_NOISE) nzl = noise_tick(s.lfo);
   const uint64_t half = 0x8000000000000000ull;
@@ -631,8 +708,22 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
   }
   float nz1 = 0.0f, nz2 = 0.0f;
   if (w1 == GROOVE_WAVE_NOISE) nz1 = noise_tick(s.o1);
+#ifdef GROOVE_SEG_PLAIN /* A/B */
   if ((p.flags & WF_SYNC) && wrapped) s.o2.phase = 0;
   else if (!first) s.o2.phase += inc2;
+#else
+  {
+    uint64_t ph2 = s.o2.phase;
+    if (!first) ph2 += inc2;
+    if (fl & WF_SYNC) { // wave-uniform in the uniform kernels: a scalar branch that five patches in six never take
+      if (wrapped) ph2 = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" : "+v"(ph2)); // keeps this a branch: if-converted it is a 64-bit compare and three selects on every frame
+#endif
+    }
+    s.o2.phase = ph2;
+  }
+#endif
   if (w2 == GROOVE_WAVE_NOISE) nz2 = noise_tick(s.o2);
   const float v1 = osc_value_classed<C1, REST>(w1, s.o1.phase, d1, nz1);
   const float v2 = osc_value_classed<C2, REST>(w2, s.o2.phase, d2, nz2);
@@ -655,8 +746,11 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
       const float fc = retune ? 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f) : p.cutoff_hz;
       sc.coef = lp24_coefd_from_fc(c, fc, rc.pi_over_sr, rc.fc_max);
     } else if (retune && pct != sc.prev_pct) { // unchanged percent (e.g. envelope plateau): coefficients stand
-      const float fc = 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f); // 25 * 800^pct
-      sc.coef = lp24_coefd_from_fc(p.fc, fc, rc.pi_over_sr, rc.fc_max);
+#ifdef GROOVE_RETUNE_V1 /* A/B: the two-step form */
+      sc.coef = lp24_coefd_from_fc(p.fc, 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f), rc.pi_over_sr, rc.fc_max);
+#else
+      sc.coef = lp24_coefd_from_pct(p.fc, pct, rc);
+#endif
       sc.prev_pct = pct;
     }
   }
@@ -684,6 +778,17 @@ GROOVE_HD uint32_t welsh_segment_begin(const WelshParams& p, WelshState& s, bool
 GROOVE_HD void welsh_segment_idle_frame(WelshState& s) {
   env_advance(s.amp);
   env_advance(s.fil);
+}
+// Hoisted form (welsh_frame<..., HOIST>): what a segment of `seg` frames leaves to do once.  Live voices had
+// their envelope VALUES set by their frames; an idle voice's are what its last tick would have produced.
+GROOVE_HD void welsh_segment_start_hoisted(const WelshState& s, WelshScratch& sc) {
+  sc.ta = (float)s.amp.n; sc.tf = (float)s.fil.n;
+}
+template <bool LFO_TOO>
+GROOVE_HD void welsh_segment_end_hoisted(const WelshParams& p, WelshState& s, uint32_t seg, bool live) {
+  s.amp.n += seg; s.fil.n += seg;
+  if (!live) { s.amp.value = env_last_value_of(s.amp); s.fil.value = env_last_value_of(s.fil); }
+  else if (LFO_TOO) s.lfo.phase += (uint64_t)seg * p.lfo_inc;
 }
 GROOVE_HD WelshScratch welsh_scratch_init(const WelshParams& p, const RenderConsts& rc) {
   WelshScratch sc;

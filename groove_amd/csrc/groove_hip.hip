@@ -978,7 +978,7 @@ static bool use_tp(const groove_bank* b, uint32_t frames) {
 }
 static void launch_tp(groove_bank* b, uint32_t frames, bool fused, size_t chs, float* out, hipStream_t st) {
   groove_ctx* ctx = b->ctx;
-  const TpArgs a{b->d_params, b->d_state, out, chs, RenderConsts{(float)(3.14159265358979323846 / ctx->sr), (float)(0.49 * ctx->sr)}, b->n, frames};
+  const TpArgs a{b->d_params, b->d_state, out, chs, render_consts(ctx->sr), b->n, frames};
   launch_welsh_tp(a, st, fused);
 }
 // rows of partial[][2][frames] a bank's fused render writes
@@ -1020,7 +1020,7 @@ static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs
   if (use_tp(b, frames)) {
     launch_tp(b, frames, fused, chs, out, ctx->stream);
   } else if (b->kind == BANK_WELSH) {
-    RenderConsts rc{(float)(3.14159265358979323846 / ctx->sr), (float)(0.49 * ctx->sr)};
+    const RenderConsts rc = render_consts(ctx->sr);
     if (b->n_vwaves == 0) { // interleaved bank: per-lane kernel over the physical lanes
       if (fused) hipLaunchKernelGGL(welsh_render_kernel<true>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, rc);
       else hipLaunchKernelGGL(welsh_render_kernel<false>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, rc);
@@ -1165,7 +1165,7 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
     ctx->side_busy[k] = true;
   };
   if (uniform) {
-    const RenderConsts rc{(float)(3.14159265358979323846 / ctx->sr), (float)(0.49 * ctx->sr)};
+    const RenderConsts rc = render_consts(ctx->sr);
     uint32_t at = 0;
     uint32_t count[kBaseKinds] = {}, offset[kBaseKinds] = {};
     for (int base = 0; base < kBaseKinds; ++base) {
@@ -1187,11 +1187,11 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
     if (tp) {
       launch_tp(b, frames, false, chs, dst, st);
     } else if (small_uniform) { // all base kinds in one launch
-      const RenderConsts rc{(float)(3.14159265358979323846 / ctx->sr), (float)(0.49 * ctx->sr)};
+      const RenderConsts rc = render_consts(ctx->sr);
       UniformArgs a{b->d_waves, b->d_state, dst, b->d_wg_list, b->d_wg_cls, chs, rc, b->n_vwaves, b->n, frames, b->n_vwaves / kWaves};
       launch_welsh_uniform_any_unfused(a, b->d_wg_base, st);
     } else if (b->kind == BANK_WELSH) {
-      const RenderConsts rc{(float)(3.14159265358979323846 / ctx->sr), (float)(0.49 * ctx->sr)};
+      const RenderConsts rc = render_consts(ctx->sr);
       hipLaunchKernelGGL(welsh_render_kernel<false>, grid, blk, 0, st, b->d_params, b->d_state, b->n, frames, chs, dst, rc);
     } else if (b->kind == BANK_FM) {
       hipLaunchKernelGGL(fm_render_kernel<false>, grid, blk, 0, st, b->d_params, b->d_state, b->n, frames, chs, dst);
@@ -1280,7 +1280,7 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
     for (bool& f : ctx->fork_pending) f = true;
     ctx->need_fork = false;
   }
-  const RenderConsts rc{(float)(3.14159265358979323846 / ctx->sr), (float)(0.49 * ctx->sr)};
+  const RenderConsts rc = render_consts(ctx->sr);
   const dim3 blk(kThreads);
   for (int k = kSideStreams - 1; k >= 0; --k) { // most expensive Welsh kind first
     if (!count[k]) continue;

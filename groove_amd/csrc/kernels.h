@@ -223,17 +223,21 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
 // Frame 0 by `first` (checked form); then boundary-free SEGMENTS (dsp_core.h): `begin(live)` handles the
 // envelope boundaries due now and returns the frames this lane can run unchecked, the wave takes the
 // minimum, and `live_frame` / `idle_frame` run that many frames without boundary or idle tests.
-template <bool FUSED, class FirstFn, class BeginFn, class LiveFn, class IdleFn>
+// HOISTED: `begin` also prepares the segment (float stage counters), live frames leave the envelope counters
+// alone, and `end(seg, live)` moves them once per segment (welsh_segment_end_hoisted); lanes that are not `active`
+// are never live, so their L and R stay zero without a select per frame.
+template <bool FUSED, bool HOISTED, class FirstFn, class BeginFn, class LiveFn, class IdleFn, class EndFn>
 __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n, uint32_t v, bool active, size_t ch_stride,
                                                      float* __restrict__ out, uint32_t prow, FirstFn&& first, BeginFn&& begin,
-                                                     LiveFn&& live_frame, IdleFn&& idle_frame) {
+                                                     LiveFn&& live_frame, IdleFn&& idle_frame, EndFn&& end) {
   if (frames == 0) return;
   constexpr uint32_t C = FusedAcc::kChunk;
   static_assert(C > 1, "frame 0 never completes a chunk");
   FusedAcc acc(prow);
-  auto put = [&](uint32_t f, float L, float R) {
+  auto put = [&](uint32_t f, float L, float R, bool masked) {
     if (FUSED) {
-      acc.add(active ? L : 0.0f, active ? R : 0.0f, f);
+      if (masked) acc.add(active ? L : 0.0f, active ? R : 0.0f, f);
+      else acc.add(L, R, f);
       if ((f & (C - 1)) == C - 1) acc.flush(out, frames, f - (C - 1), C);
     } else if (active) {
       out[(size_t)f * n + v] = L;
@@ -243,18 +247,20 @@ __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n
   {
     float L, R;
     first(L, R);
-    put(0, L, R);
+    put(0, L, R, true);
   }
   uint32_t f = 1;
   while (f < frames) {
     bool live;
     const uint32_t mine = begin(live);
+    if (HOISTED) live = live && active;
     const uint32_t seg = min(wave_min_u32(mine), frames - f);
     for (uint32_t k = 0; k < seg; ++k, ++f) {
       float L = 0.0f, R = 0.0f;
-      if (live) live_frame(L, R); else idle_frame();
-      put(f, L, R);
+      if (live) live_frame(L, R); else if (!HOISTED) idle_frame();
+      put(f, L, R, !HOISTED);
     }
+    if (HOISTED) end(seg, live);
   }
   if (FUSED && (frames & (C - 1))) acc.flush(out, frames, frames & ~(C - 1), frames & (C - 1));
 }
@@ -272,12 +278,18 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
   // never change, so they ride in SGPRs (12 VGPRs back; f64 FMAs take one scalar operand).
   if (UNIFORM && !RETUNE) sc.coef = make_scalar(sc.coef);
   if constexpr (UNIFORM) {
-    run_frames_segmented<FUSED>(
+#ifdef GROOVE_SEG_PLAIN /* A/B: counters and selects on every frame */
+    constexpr bool HOIST = false;
+#else
+    constexpr bool HOIST = true;
+#endif
+    run_frames_segmented<FUSED, HOIST>(
         frames, n, v, active, ch_stride, out, prow,
         [&](float& L, float& R) { welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL, false, REST>(p, s, rc, sc, L, R); },
-        [&](bool& live) { return welsh_segment_begin(p, s, live); },
-        [&](float& L, float& R) { welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST>(p, s, rc, sc, L, R); },
-        [&]() { welsh_segment_idle_frame(s); });
+        [&](bool& live) { const uint32_t k = welsh_segment_begin(p, s, live); if (HOIST) welsh_segment_start_hoisted(s, sc); return k; },
+        [&](float& L, float& R) { welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, HOIST>(p, s, rc, sc, L, R); },
+        [&]() { welsh_segment_idle_frame(s); },
+        [&](uint32_t seg, bool live) { welsh_segment_end_hoisted<CL == LFO_UNUSED>(p, s, seg, live); });
   } else {
     run_frames<FUSED>(frames, n, v, active, ch_stride, out, prow, [&](uint32_t f, float& L, float& R) {
       if (f == 0) welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL>(p, s, rc, sc, L, R);
@@ -372,7 +384,7 @@ __device__ __forceinline__ void welsh_uniform_body_impl(UniformArgsPtr a) {
   const bool active = (w0 < n_waves) && (lane < d.count);
   const uint32_t v = active ? d.vbase + lane : d.vbase; // idle lanes shadow the run's first voice
   WelshState s = soa_load<WelshState>(a->state, n, v);
-  const RenderConsts rc{a->rc.pi_over_sr, a->rc.fc_max};
+  const RenderConsts rc{a->rc.pi_over_sr, a->rc.fc_max, a->rc.log2_x0, a->rc.x_lo, a->rc.x_hi};
   welsh_block<FUSED, RETUNE, LFO_MODE, true, C1, C2, CL, REST>(d.p, s, rc, a->frames, n, v, active, a->ch_stride, a->out, wg);
   if (active) soa_store(a->state, n, v, s);
 }

@@ -45,11 +45,6 @@ GROOVE_HD void env_seek(EnvState& s, const EnvParams& p, uint32_t k) {
     s.n += step; k -= step;
   }
 }
-// value the most recent tick produced (the stage counter has already moved on by one)
-GROOVE_HD float env_last_value(const EnvState& s) {
-  const float t = (float)(s.n - 1u) * s.inv_len;
-  return fmaf(s.D, fmaf(-t, t, 2.0f * t), s.A);
-}
 // First frame of the next `frames` at which the amp envelope is idle after its tick (the voice is silent
 // from there on: notes land at block starts only); `frames` if it sounds throughout.
 GROOVE_HD uint32_t env_idle_at(EnvState s, const EnvParams& p, uint32_t frames) {
@@ -188,8 +183,7 @@ GROOVE_HD void welsh_tp_frame(const WelshParams& p, WelshState& s, const RenderC
       const float fc = retune ? 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f) : p.cutoff_hz;
       coef = lp24_coefd_from_fc(c, fc, rc.pi_over_sr, rc.fc_max);
     } else if (retune && pct != prev_pct) {
-      const float fc = 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f);
-      coef = lp24_coefd_from_fc(p.fc, fc, rc.pi_over_sr, rc.fc_max);
+      coef = lp24_coefd_from_pct(p.fc, pct, rc);
       prev_pct = pct;
     }
   }

@@ -31,9 +31,10 @@ static void welsh_emul_frame(const WelshParams& p, WelshState& s, const RenderCo
 
 template <bool RETUNE>
 static void welsh_emul_segment_frame2(const WelshParams& p, WelshState& s, const RenderConsts& rc, WelshScratch& sc, int mode, float& L, float& R) {
-  if (mode == LFO_F32) welsh_frame<false, RETUNE, LFO_F32, OSC_ANY, OSC_ANY, OSC_ANY, true>(p, s, rc, sc, L, R);
-  else if (mode == LFO_F64) welsh_frame<false, RETUNE, LFO_F64, OSC_ANY, OSC_ANY, OSC_ANY, true>(p, s, rc, sc, L, R);
-  else welsh_frame<false, RETUNE, LFO_F64_SMOOTH, OSC_ANY, OSC_ANY, OSC_ANY, true>(p, s, rc, sc, L, R);
+  // the uniform kernels' form: boundary-free segment, envelope counters hoisted (welsh_frame<..., HOIST>)
+  if (mode == LFO_F32) welsh_frame<false, RETUNE, LFO_F32, OSC_ANY, OSC_ANY, OSC_ANY, true, false, true>(p, s, rc, sc, L, R);
+  else if (mode == LFO_F64) welsh_frame<false, RETUNE, LFO_F64, OSC_ANY, OSC_ANY, OSC_ANY, true, false, true>(p, s, rc, sc, L, R);
+  else welsh_frame<false, RETUNE, LFO_F64_SMOOTH, OSC_ANY, OSC_ANY, OSC_ANY, true, false, true>(p, s, rc, sc, L, R);
 }
 static void welsh_emul_segment_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc, WelshScratch& sc, bool retune, int mode,
                                      float& L, float& R) {
@@ -207,7 +208,7 @@ void emul_bank_note_events(void* h, const groove_note_event* ev, uint32_t n_ev) 
 void emul_bank_render(void* h, uint32_t frames, float* out) {
   EmulBank* b = (EmulBank*)h;
   const uint32_t n = b->n;
-  RenderConsts rc{(float)(3.14159265358979323846 / b->sr), (float)(0.49 * b->sr)};
+  const RenderConsts rc = render_consts(b->sr);
   for (uint32_t v = 0; v < n; ++v) {
     if (b->kind == 0 && b->time_parallel && frames <= kTpMaxFrames) {
       std::vector<float> l(frames), r(frames);
@@ -223,16 +224,20 @@ void emul_bank_render(void* h, uint32_t frames, float* out) {
       mode = b->generic_lfo ? (welsh_lfo_mode(b->wp[v]) == LFO_F32 ? LFO_F32 : LFO_F64) : welsh_lfo_mode(b->wp[v]);
     }
     float sampler_buf[16] = {};
-    uint32_t seg_left = 0; // segmented form (uniform kernels): frames left before the next boundary check
+    uint32_t seg_left = 0, seg_len = 0; // segmented form (uniform kernels): frames left before the next boundary check
     bool seg_live = false;
     for (uint32_t f = 0; f < frames; ++f) {
       float L, R;
-      if (b->kind == 0 && b->segmented && f > 0) { // mirrors run_frames_segmented with a one-lane wave
-        if (seg_left == 0) seg_left = welsh_segment_begin(b->wp[v], b->ws[v], seg_live);
+      if (b->kind == 0 && b->segmented && f > 0) { // mirrors run_frames_segmented<HOISTED> with a one-lane wave
+        if (seg_left == 0) {
+          seg_left = welsh_segment_begin(b->wp[v], b->ws[v], seg_live);
+          if (seg_left > frames - f) seg_left = frames - f;
+          seg_len = seg_left;
+          welsh_segment_start_hoisted(b->ws[v], sc);
+        }
         L = R = 0.0f;
         if (seg_live) welsh_emul_segment_frame(b->wp[v], b->ws[v], rc, sc, retunes, mode, L, R);
-        else welsh_segment_idle_frame(b->ws[v]);
-        --seg_left;
+        if (--seg_left == 0) welsh_segment_end_hoisted<false>(b->wp[v], b->ws[v], seg_len, seg_live);
       } else if (b->kind == 0) { // mirrors the kernels' checked form: frame 0 peeled, RETUNE and the LFO mode chosen per voice
         welsh_emul_frame(b->wp[v], b->ws[v], rc, sc, f == 0, retunes, mode, L, R);
       } else if (b->kind == 1) {
