@@ -391,15 +391,13 @@ GROOVE_HD Lp24CoefD lp24_coefd_from_pct(const Lp24Consts& c, float pct, const Re
   const float x = med3f(fast_exp2(fmaf(clamp01f(pct), 9.6438561897747244f, rc.log2_x0)), rc.x_lo, rc.x_hi);
   const bool hi = x > 0.78539816339744831f;
   const float z = fminf(x, 1.57079632679489662f - x);
-  const float z2 = z * z;
-  float p = 9.449327447e-03f;
-  p = fmaf(p, z2, 2.985451510e-03f);
-  p = fmaf(p, z2, 2.453938616e-02f);
-  p = fmaf(p, z2, 5.336849955e-02f);
-  p = fmaf(p, z2, 1.333961619e-01f);
-  p = fmaf(p, z2, 3.333309016e-01f);
-  p = fmaf(p, z2, 1.000000015e+00f);
-  const float t = p * z;
+  // tan(z) = z P(z^2), the polynomial of tan_reduced by Estrin's scheme (four dependent steps instead of seven)
+  const float w = z * z, w2 = w * w;
+  const float e0 = fmaf(3.333309016e-01f, w, 1.000000015e+00f), e1 = fmaf(5.336849955e-02f, w, 1.333961619e-01f);
+  const float e2 = fmaf(2.985451510e-03f, w, 2.453938616e-02f);
+  const float w4 = w2 * w2;
+  const float f0 = fmaf(e1, w2, e0), f1 = fmaf(9.449327447e-03f, w2, e2);
+  const float t = fmaf(f1, w4, f0) * z;
   const float T2 = t * t;
   const float dta = c.d1 * t, dtb = c.d3 * t;
   Lp24CoefD d;
