@@ -142,12 +142,14 @@ def committed_profile(workload):
         return None
     out = {"source": os.path.basename(files[-1]),
            "traffic": (d.get("hbm_traffic_bytes_per_step") or {}).get("total_corrected")}
-    valu = salu = 0.0
-    for k, v in (d.get("sq") or {}).items():
-        if "render" in k or "partial_" in k or "mix_" in k or "fx_" in k:
-            m = v.get("mean_per_dispatch", {})
-            valu += m.get("SQ_INSTS_VALU", 0.0)
-            salu += m.get("SQ_INSTS_SALU", 0.0)
+    ins = d.get("instructions_per_step") or {}
+    valu, salu = ins.get("valu_wave_insts") or 0.0, ins.get("salu_wave_insts") or 0.0
+    if not valu:  # round-1 layout: per-dispatch means of the (once-per-step) kernels
+        for k, v in (d.get("sq") or {}).items():
+            if "render" in k or "partial_" in k or "mix_" in k or "fx_" in k:
+                m = v.get("mean_per_dispatch", {})
+                valu += m.get("SQ_INSTS_VALU", 0.0)
+                salu += m.get("SQ_INSTS_SALU", 0.0)
     out["valu_per_step"], out["salu_per_step"] = (valu or None), (salu or None)
     out["cost_model_frac"] = (d.get("valu_cost_model") or {}).get("frac")
     return out

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Reduce the rocprofv3 CSVs of tools/profile_round.sh to profiles/<round>_*.{csv,json}."""
+"""Reduce the rocprofv3 CSVs of tools/profile_round.sh to profiles/<round>_<workload>_{kernel_stats.csv,summary.json}."""
 import collections
 import csv
 import glob
@@ -8,31 +8,40 @@ import os
 import shutil
 import sys
 
-out, rnd = sys.argv[1], sys.argv[2]
+out, rnd, workload = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "welsh-1m")
 os.makedirs("profiles", exist_ok=True)
-summary = {"round": rnd, "command": "python3 bench.py --no-cpu-baseline   (defaults: --gpus 1 --steps 172 --warmup 4, workload welsh-1m)"}
+summary = {"round": rnd, "workload": workload,
+           "command": f"python3 bench.py --workload {workload} --no-cpu-baseline --no-configs --no-parity --repeats 1   (defaults: --gpus 1 --steps 172 --warmup 4)"}
+STEP_KERNELS = ("render", "welsh_tp", "partial_", "mix_", "fx_", "block_", "_events_")   # what one step of the hot path launches
 
 ks = glob.glob(f"{out}/kt/*/*_kernel_stats.csv")
 if ks:
-    shutil.copy(ks[0], f"profiles/{rnd}_kernel_stats.csv")
+    shutil.copy(ks[0], f"profiles/{rnd}_{workload}_kernel_stats.csv")
     rows = list(csv.DictReader(open(ks[0])))
-    summary["kernel_stats"] = [{"name": r["Name"][:90], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
-                                "pct": float(r["Percentage"])} for r in rows[:8]]
-# The fused step is several kernels running concurrently (and, pipelined, overlapping the next
-# step's), so no single kernel's average duration is "the step": the step period is read off the
-# trace as the spacing of the per-step bus reductions (partial_final_kernel ends once per step).
+    summary["kernel_stats"] = [{"name": r["Name"][:110], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                                "pct": float(r["Percentage"])} for r in rows[:10]]
+# A step is several kernels, some concurrent and (pipelined) overlapping the next step's, so no single kernel's
+# average duration is "the step": the step period is read off the trace as the spacing of the kernel that ends
+# every step (the bus reduction / mix).
 kt = glob.glob(f"{out}/kt/*/*_kernel_trace.csv")
 if kt:
-    ends = sorted(int(r["End_Timestamp"]) for r in csv.DictReader(open(kt[0])) if "partial_final_kernel" in r["Kernel_Name"])
-    if len(ends) > 20:
-        steady = ends[4:]  # skip the warm-up steps
-        summary["step_period_from_trace"] = {
-            "mean_us": (steady[-1] - steady[0]) / (len(steady) - 1) / 1e3, "steps": len(steady) - 1,
-            "note": "spacing of partial_final_kernel completions over the timed steps; compare with roofline.kernel_ms of the bench line"}
+    rows = list(csv.DictReader(open(kt[0])))
+    for marker in ("partial_final_kernel", "partial_rows_kernel", "mix_final_kernel", "mix_partial_kernel"):
+        ends = sorted(int(r["End_Timestamp"]) for r in rows if marker in r["Kernel_Name"])
+        if len(ends) > 40:
+            n_steps = 176
+            per = max(1, round(len(ends) / n_steps))       # a step may end with several launches of the marker (one per bank)
+            ends = ends[per - 1::per]
+            steady = ends[4:]
+            summary["step_period_from_trace"] = {
+                "mean_us": (steady[-1] - steady[0]) / (len(steady) - 1) / 1e3, "steps": len(steady) - 1, "marker": marker,
+                "note": "spacing of the step-ending kernel's completions over the timed steps; compare with roofline.kernel_ms of the bench line"}
+            break
 for log in glob.glob(f"{out}/bench_kt.log"):
     for line in open(log):
         if line.startswith("{"):
-            summary["bench_line_under_profiler"] = json.loads(line)
+            summary["bench_line_under_profiler"] = {k: v for k, v in json.loads(line).items() if k in
+                                                    ("value", "ms_per_step", "steps", "warmup", "config", "roofline", "timed_region")}
 
 
 def counters(sub):
@@ -50,25 +59,25 @@ def counters(sub):
 
 for sub in ("fetch", "write", "sq", "grbm"):
     summary[sub] = counters(sub)
+STEPS = 176.0   # 172 timed + 4 warm-up steps per run
 
-# HBM traffic per STEP (one 256-frame block of the whole project): the Welsh render runs as up to
-# six concurrent kernels (one per base kind) plus the two partial-row reductions, so the
-# per-kernel means are summed.  MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB;
-# FETCH_SIZE reads 1/2 of the bytes of a wide coalesced streaming read on gfx950 — the state loads
-# here are 4 B/lane buffer loads (an uncalibrated width), so the raw and the doubled figure are kept.
+
+# Per STEP (one 256-frame block of the whole project): per-kernel totals over the run divided by the steps, summed over
+# the kernels a step launches.  MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE reads 1/2 of
+# the bytes of a wide coalesced streaming read on gfx950 — the raw and the doubled figure are both kept.
 def per_step(sub, counter):
     tot = 0.0
     for k, v in summary.get(sub, {}).items():
-        if "welsh_render" in k or "partial_" in k or "mix_" in k:
-            tot += v["mean_per_dispatch"].get(counter, 0.0)
-    return tot * 1024.0
+        if any(m in k for m in STEP_KERNELS):
+            tot += v["mean_per_dispatch"].get(counter, 0.0) * v["dispatches"] / STEPS
+    return tot
 
 
-w, f = per_step("write", "WRITE_SIZE"), per_step("fetch", "FETCH_SIZE")
-summary["dominant_kernel"] = "welsh_render_uniform_kernel<fused, LFO mode, retune> (one per base kind, concurrent, blocks pipelined) + partial_rows/final"
-summary["hbm_traffic_bytes_per_step"] = {"write": w, "fetch_raw": f, "fetch_x2_gfx950": 2 * f,
-                                         "total_raw": w + f, "total_corrected": w + 2 * f}
-json.dump(summary, open(f"profiles/{rnd}_summary.json", "w"), indent=1)
-print(json.dumps({k: summary[k] for k in ("dominant_kernel", "hbm_traffic_bytes_per_step", "step_period_from_trace") if k in summary}, indent=1))
-for r in summary.get("kernel_stats", []):
-    print(f"{r['pct']:6.2f}%  {r['avg_ns'] / 1e3:10.1f} us x {r['calls']:4d}  {r['name']}")
+w, f = per_step("write", "WRITE_SIZE") * 1024.0, per_step("fetch", "FETCH_SIZE") * 1024.0
+summary["hbm_traffic_bytes_per_step"] = {"write": w, "fetch_raw": f, "fetch_x2_gfx950": 2 * f, "total_raw": w + f, "total_corrected": w + 2 * f}
+summary["instructions_per_step"] = {"valu_wave_insts": per_step("sq", "SQ_INSTS_VALU"), "salu_wave_insts": per_step("sq", "SQ_INSTS_SALU"),
+                                    "note": "SQ_INSTS_VALU / SQ_INSTS_SALU summed over the step's kernels (wave-level instructions)"}
+json.dump(summary, open(f"profiles/{rnd}_{workload}_summary.json", "w"), indent=1)
+print(workload, json.dumps({k: summary[k] for k in ("hbm_traffic_bytes_per_step", "instructions_per_step", "step_period_from_trace") if k in summary}))
+for r in summary.get("kernel_stats", [])[:8]:
+    print(f"{r['pct']:6.2f}%  {r['avg_ns'] / 1e3:10.1f} us x {r['calls']:5d}  {r['name'][:90]}")
