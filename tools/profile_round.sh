@@ -5,7 +5,9 @@
 #   1. --kernel-trace --stats                     -> profiles/<round>_<workload>_kernel_stats.csv
 #   2. --pmc FETCH_SIZE / WRITE_SIZE / SQ mix / GRBM_GUI_ACTIVE, one pass each
 # and tools/summarize_prof.py reduces them to profiles/<round>_<workload>_summary.json.
-# Everything is written under gpurun_out/ (scratch); only the summaries are copied to profiles/.
+# Everything is written under gpurun_out/ (scratch, merged back by gpurun); afterwards, in the development container,
+#   for w in welsh-1m welsh-256 chain-4096 sampler-16384 mixed-131072; do python3 tools/summarize_prof.py gpurun_out/prof_r02_$w r02 $w; done
+# writes the tracked summaries under profiles/ (the GPU box's own profiles/ directory does not travel back).
 set -u
 ROUND=${1:-r02}; shift || true
 WORKLOADS=${@:-welsh-1m welsh-256 chain-4096 sampler-16384 mixed-131072}
