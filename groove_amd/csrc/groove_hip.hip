@@ -33,6 +33,13 @@ struct groove_block {
   hipEvent_t ev_free = nullptr, ev_ready[16] = {};
   uint32_t ready_mask = 0;
   bool released = false; // groove_block_release: ev_free marks the end of the block's consumers so far
+  // The lane sums of the block, as the render that filled it left them: sums[row][ch][frame], `sum_rows` rows whose
+  // column totals are the block's bus contribution (the fused path's partial rows).  groove_mix reduces these 8 MB
+  // instead of reading 2 GB of voice block back; anything else that writes the block clears sums_valid.
+  float* d_sums = nullptr;
+  size_t sums_cap = 0;
+  uint32_t sum_rows = 0, sum_frames = 0;
+  bool sums_valid = false;
 };
 
 enum BankKind { BANK_WELSH = 0, BANK_FM = 1, BANK_SAMPLER = 2 };
@@ -533,6 +540,27 @@ int ensure_partial(groove_ctx* ctx, size_t floats) {
   return 0;
 }
 
+// bus[f][ch] (+)= column sums of rows[row][ch][frame] (fixed order: segments of 64 rows, then the segments).
+int reduce_rows(groove_ctx* ctx, const float* rows_dev, uint32_t rows, uint32_t frames, float* bus_dev, int accumulate) {
+  const uint32_t cols = 2 * frames, rows_per_seg = 64, segs = (rows + rows_per_seg - 1) / rows_per_seg;
+  if (ctx->fseg_cap < (size_t)segs * cols) {
+    if (ctx->d_fseg) GHIP(ctx, hipFree(ctx->d_fseg));
+    GHIP(ctx, hipMalloc(&ctx->d_fseg, (size_t)segs * cols * 4));
+    ctx->fseg_cap = (size_t)segs * cols;
+  }
+  if (segs == 1) {
+    hipLaunchKernelGGL(partial_rows_kernel, dim3(blocks_for(cols), 1), dim3(kThreads), 0, ctx->stream, rows_dev, rows, cols,
+                       rows_per_seg, ctx->d_fseg, bus_dev, accumulate);
+  } else {
+    hipLaunchKernelGGL(partial_rows_kernel, dim3(blocks_for(cols), segs), dim3(kThreads), 0, ctx->stream, rows_dev, rows, cols,
+                       rows_per_seg, ctx->d_fseg, (float*)nullptr, 0);
+    hipLaunchKernelGGL(partial_final_kernel, dim3(blocks_for(cols)), dim3(kThreads), 0, ctx->stream, ctx->d_fseg, segs, frames,
+                       bus_dev, accumulate);
+  }
+  GHIP(ctx, hipGetLastError());
+  return 0;
+}
+
 constexpr uint32_t kMixSeg = 16384; // floats of one row summed by one workgroup
 
 int mix_one(groove_ctx* ctx, const groove_block* b, uint32_t frames, float* bus, int accumulate, size_t planar_stride = 0) {
@@ -836,6 +864,7 @@ int groove_block_destroy(groove_block* b) {
   if (b->ready_mask) (void)ctx_join(b->ctx);
   (void)hipStreamSynchronize(b->ctx->stream);
   (void)hipFree(b->d);
+  (void)hipFree(b->d_sums);
   if (b->ev_free) (void)hipEventDestroy(b->ev_free);
   for (hipEvent_t e : b->ev_ready) if (e) (void)hipEventDestroy(e);
   delete b;
@@ -849,6 +878,7 @@ int groove_block_upload(groove_block* b, const float* host, uint32_t frames) {
   groove_ctx* ctx = b->ctx;
   if (frames > b->cap) return fail(ctx, "groove_block_upload: frames > capacity");
   if (block_acquire(b)) return 1;
+  b->sums_valid = false;
   const size_t per = (size_t)frames * b->n;
   for (int ch = 0; ch < 2; ++ch)
     GHIP(ctx, hipMemcpyAsync(b->d + (size_t)ch * b->cap * b->n, host + ch * per, per * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -972,13 +1002,25 @@ int groove_bank_set_param(groove_bank* b, uint32_t voice, uint32_t control_index
   GHIP(ctx, hipStreamSynchronize(ctx->stream));
   return welsh_upload_params(b, false); // the state stays where it is: keep the lane order
 }
+// The block's row-sum buffer for a render of `rows` partial rows (reallocated when it grows).
+static float* block_sums(groove_block* blk, uint32_t rows, uint32_t frames) {
+  const size_t need = (size_t)rows * 2 * frames;
+  if (blk->sums_cap < need) {
+    if (blk->d_sums) { (void)hipStreamSynchronize(blk->ctx->stream); (void)hipFree(blk->d_sums); blk->d_sums = nullptr; blk->sums_cap = 0; }
+    const size_t cap = std::max(need, (size_t)rows * 2 * std::min<uint32_t>(blk->cap, 4096));
+    if (hipMalloc(&blk->d_sums, cap * 4) != hipSuccess) { fail(blk->ctx, "block row sums: hipMalloc failed"); return nullptr; }
+    blk->sums_cap = cap;
+  }
+  blk->sums_valid = false;
+  return blk->d_sums;
+}
 // Small Welsh banks and blocks of up to 256 frames: one wavefront per voice, lanes = time (welsh_tp.h).
 static bool use_tp(const groove_bank* b, uint32_t frames) {
   return b->kind == BANK_WELSH && frames <= kTpMaxFrames && b->n <= b->ctx->tp_max_voices;
 }
-static void launch_tp(groove_bank* b, uint32_t frames, bool fused, size_t chs, float* out, hipStream_t st) {
+static void launch_tp(groove_bank* b, uint32_t frames, bool fused, size_t chs, float* out, float* rows, hipStream_t st) {
   groove_ctx* ctx = b->ctx;
-  const TpArgs a{b->d_params, b->d_state, out, chs, render_consts(ctx->sr), b->n, frames};
+  const TpArgs a{b->d_params, b->d_state, out, rows, chs, render_consts(ctx->sr), b->n, frames};
   launch_welsh_tp(a, st, fused);
 }
 // rows of partial[][2][frames] a bank's fused render writes
@@ -1013,24 +1055,25 @@ static void launch_welsh_kind(int k, const UniformArgs& a, hipStream_t st, bool 
   }
 #undef GROOVE_LAUNCH_UNIFORM
 }
-static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs, float* out) {
+// fused: `rows` = partial rows only.  Otherwise `out` = the planar block and `rows` = its row sums (kernels.h run_frames).
+static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs, float* out, float* rows) {
   groove_ctx* ctx = b->ctx;
   b->ctx_touched = true;
   const dim3 grid(blocks_for(b->n)), blk(kThreads);
   if (use_tp(b, frames)) {
-    launch_tp(b, frames, fused, chs, out, ctx->stream);
+    launch_tp(b, frames, fused, chs, out, rows, ctx->stream);
   } else if (b->kind == BANK_WELSH) {
     const RenderConsts rc = render_consts(ctx->sr);
     if (b->n_vwaves == 0) { // interleaved bank: per-lane kernel over the physical lanes
-      if (fused) hipLaunchKernelGGL(welsh_render_kernel<true>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, rc);
-      else hipLaunchKernelGGL(welsh_render_kernel<false>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, rc);
+      if (fused) hipLaunchKernelGGL(welsh_render_kernel<true>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, rows, rc);
+      else hipLaunchKernelGGL(welsh_render_kernel<false>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, rows, rc);
     } else {
       // One kernel per base kind present, all running concurrently: the most expensive kind goes
       // out first on the ctx stream (list scheduling, longest first), the others on side streams
       // forked from it, and the ctx stream joins them before the bus reduction.
       if (b->n_vwaves < ctx->pipeline_min_waves) { // small bank: all base kinds in one launch (kernels.h)
         const uint32_t wgs = (b->n_vwaves + kWaves - 1) / kWaves;
-        UniformArgs a{b->d_waves, b->d_state, out, b->d_wg_list, b->d_wg_cls, chs, rc, b->n_vwaves, b->n, frames, wgs};
+        UniformArgs a{b->d_waves, b->d_state, out, rows, b->d_wg_list, b->d_wg_cls, chs, rc, b->n_vwaves, b->n, frames, wgs};
         if (fused) launch_welsh_uniform_any(a, b->d_wg_base, ctx->stream);
         else launch_welsh_uniform_any_unfused(a, b->d_wg_base, ctx->stream);
         GHIP(ctx, hipGetLastError());
@@ -1057,7 +1100,7 @@ static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs
           st = side_stream_of(ctx, side);
           GHIP(ctx, hipStreamWaitEvent(st, ctx->ev_fork, 0));
         }
-        UniformArgs a{b->d_waves, b->d_state, out, b->d_wg_list + offset[k], b->d_wg_cls + offset[k], chs, rc, b->n_vwaves, b->n, frames, count[k]};
+        UniformArgs a{b->d_waves, b->d_state, out, rows, b->d_wg_list + offset[k], b->d_wg_cls + offset[k], chs, rc, b->n_vwaves, b->n, frames, count[k]};
         launch_welsh_kind(k, a, st, fused);
         if (!first_kind) {
           GHIP(ctx, hipEventRecord(ctx->ev_join[side], st));
@@ -1069,11 +1112,11 @@ static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs
       }
     }
   } else if (b->kind == BANK_FM) {
-    if (fused) hipLaunchKernelGGL(fm_render_kernel<true>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out);
-    else hipLaunchKernelGGL(fm_render_kernel<false>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out);
+    if (fused) hipLaunchKernelGGL(fm_render_kernel<true>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, rows);
+    else hipLaunchKernelGGL(fm_render_kernel<false>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, rows);
   } else {
-    if (fused) hipLaunchKernelGGL(sampler_render_kernel<true>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, b->d_pcm);
-    else hipLaunchKernelGGL(sampler_render_kernel<false>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, b->d_pcm);
+    if (fused) hipLaunchKernelGGL(sampler_render_kernel<true>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, rows, b->d_pcm);
+    else hipLaunchKernelGGL(sampler_render_kernel<false>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, rows, b->d_pcm);
   }
   GHIP(ctx, hipGetLastError());
   return 0;
@@ -1089,17 +1132,21 @@ int groove_bank_render(groove_bank* b, uint32_t frames, groove_block* out) {
   if (ctx_join(ctx)) return 1; // the bank's state may still be in flight on the side streams (pipelined fused renders)
   b->side_mode = 0;
   out->ready_mask = 0; // joined above
-  if (b->perm.empty()) return launch_render(b, frames, false, (size_t)out->cap * out->n, out->d);
+  const uint32_t rows_n = fused_rows(b, frames);
+  float* rows = block_sums(out, rows_n, frames);
+  if (!rows) return 1;
+  auto rendered = [&]() { out->sum_rows = rows_n; out->sum_frames = frames; out->sums_valid = true; return 0; };
+  if (b->perm.empty()) return launch_render(b, frames, false, (size_t)out->cap * out->n, out->d, rows) || rendered();
   // regrouped bank: render in the internal lane order (coalesced rows), then hand the caller's order out
   if (!b->scratch || b->scratch->cap < frames) {
     if (b->scratch) { GHIP(ctx, hipStreamSynchronize(ctx->stream)); groove_block_destroy(b->scratch); b->scratch = nullptr; }
     if (groove_block_create(ctx, b->n, std::max<uint32_t>(frames, GROOVE_BLOCK_FRAMES), &b->scratch)) return 1;
   }
-  if (launch_render(b, frames, false, (size_t)b->scratch->cap * b->n, b->scratch->d)) return 1;
+  if (launch_render(b, frames, false, (size_t)b->scratch->cap * b->n, b->scratch->d, rows)) return 1; // (a sum has no lane order)
   hipLaunchKernelGGL(block_gather_kernel, dim3(blocks_for(b->n), std::min<uint32_t>(frames, 64)), dim3(kThreads), 0, ctx->stream, out->d,
                      (size_t)out->cap * out->n, b->scratch->d, (size_t)b->scratch->cap * b->n, b->d_inv, b->n, frames);
   GHIP(ctx, hipGetLastError());
-  return 0;
+  return rendered();
 }
 // groove_bank_render on the side streams: the render kernels start once everything submitted to the
 // ctx stream so far has finished (that covers the previous users of `out` and of the bank), and run
@@ -1127,6 +1174,9 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
   }
   float* dst = out->d;
   size_t chs = (size_t)out->cap * out->n;
+  const uint32_t rows_n = fused_rows(b, frames);
+  float* rows = block_sums(out, rows_n, frames);
+  if (!rows) return 1;
   const bool regrouped = !b->perm.empty();
   if (regrouped) { // render in the internal lane order, gather into the caller's order afterwards
     if (!b->scratch || b->scratch->cap < frames) {
@@ -1176,7 +1226,7 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
     for (int k = kBaseKinds - 1; k >= 0; --k) { // most expensive kind first
       if (!count[k]) continue;
       hipStream_t st = begin(k);
-      UniformArgs a{b->d_waves, b->d_state, dst, b->d_wg_list + offset[k], b->d_wg_cls + offset[k], chs, rc, b->n_vwaves, b->n, frames, count[k]};
+      UniformArgs a{b->d_waves, b->d_state, dst, rows, b->d_wg_list + offset[k], b->d_wg_cls + offset[k], chs, rc, b->n_vwaves, b->n, frames, count[k]};
       launch_welsh_kind(k, a, st, false);
       end(k);
     }
@@ -1185,18 +1235,18 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
     hipStream_t st = begin(k);
     const dim3 grid(blocks_for(b->n));
     if (tp) {
-      launch_tp(b, frames, false, chs, dst, st);
+      launch_tp(b, frames, false, chs, dst, rows, st);
     } else if (small_uniform) { // all base kinds in one launch
       const RenderConsts rc = render_consts(ctx->sr);
-      UniformArgs a{b->d_waves, b->d_state, dst, b->d_wg_list, b->d_wg_cls, chs, rc, b->n_vwaves, b->n, frames, b->n_vwaves / kWaves};
+      UniformArgs a{b->d_waves, b->d_state, dst, rows, b->d_wg_list, b->d_wg_cls, chs, rc, b->n_vwaves, b->n, frames, b->n_vwaves / kWaves};
       launch_welsh_uniform_any_unfused(a, b->d_wg_base, st);
     } else if (b->kind == BANK_WELSH) {
       const RenderConsts rc = render_consts(ctx->sr);
-      hipLaunchKernelGGL(welsh_render_kernel<false>, grid, blk, 0, st, b->d_params, b->d_state, b->n, frames, chs, dst, rc);
+      hipLaunchKernelGGL(welsh_render_kernel<false>, grid, blk, 0, st, b->d_params, b->d_state, b->n, frames, chs, dst, rows, rc);
     } else if (b->kind == BANK_FM) {
-      hipLaunchKernelGGL(fm_render_kernel<false>, grid, blk, 0, st, b->d_params, b->d_state, b->n, frames, chs, dst);
+      hipLaunchKernelGGL(fm_render_kernel<false>, grid, blk, 0, st, b->d_params, b->d_state, b->n, frames, chs, dst, rows);
     } else {
-      hipLaunchKernelGGL(sampler_render_kernel<false>, grid, blk, 0, st, b->d_params, b->d_state, b->n, frames, chs, dst, b->d_pcm);
+      hipLaunchKernelGGL(sampler_render_kernel<false>, grid, blk, 0, st, b->d_params, b->d_state, b->n, frames, chs, dst, rows, b->d_pcm);
     }
     end(k);
   }
@@ -1214,6 +1264,7 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
     used = 1u << g;
   }
   out->ready_mask = used;
+  out->sum_rows = rows_n; out->sum_frames = frames; out->sums_valid = true;
   GHIP(ctx, hipGetLastError());
   return 0;
 }
@@ -1288,7 +1339,7 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
     if (ctx->fork_pending[k]) { GHIP(ctx, hipStreamWaitEvent(st, ctx->ev_fork, 0)); ctx->fork_pending[k] = false; }
     if (b->reduce_recorded[slot]) GHIP(ctx, hipStreamWaitEvent(st, b->ev_reduce_done[slot], 0));
     if (uniform) {
-      UniformArgs a{b->d_waves, b->d_state, b->d_pipe_part[slot], b->d_wg_list + offset[k], b->d_wg_cls + offset[k], 0, rc, b->n_vwaves, b->n, frames, count[k]};
+      UniformArgs a{b->d_waves, b->d_state, b->d_pipe_part[slot], b->d_pipe_part[slot], b->d_wg_list + offset[k], b->d_wg_cls + offset[k], 0, rc, b->n_vwaves, b->n, frames, count[k]};
       switch (k) {
         case 0: launch_welsh_uniform_specialised_0(a, st, true); break;
         case 1: launch_welsh_uniform_specialised_1(a, st, true); break;
@@ -1298,16 +1349,16 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
         default: hipLaunchKernelGGL((welsh_render_uniform_kernel<true, LFO_F64, true, false>), dim3(count[k]), blk, 0, st, a); break;
       }
     } else if (tp) {
-      launch_tp(b, frames, true, 0, b->d_pipe_part[slot], st);
+      launch_tp(b, frames, true, 0, b->d_pipe_part[slot], b->d_pipe_part[slot], st);
     } else if (small_uniform) { // all base kinds in one launch on this bank's stream
-      UniformArgs a{b->d_waves, b->d_state, b->d_pipe_part[slot], b->d_wg_list, b->d_wg_cls, 0, rc, b->n_vwaves, b->n, frames, rows};
+      UniformArgs a{b->d_waves, b->d_state, b->d_pipe_part[slot], b->d_pipe_part[slot], b->d_wg_list, b->d_wg_cls, 0, rc, b->n_vwaves, b->n, frames, rows};
       launch_welsh_uniform_any(a, b->d_wg_base, st);
     } else if (b->kind == BANK_WELSH) {
-      hipLaunchKernelGGL(welsh_render_kernel<true>, dim3(rows), blk, 0, st, b->d_params, b->d_state, b->n, frames, (size_t)0, b->d_pipe_part[slot], rc);
+      hipLaunchKernelGGL(welsh_render_kernel<true>, dim3(rows), blk, 0, st, b->d_params, b->d_state, b->n, frames, (size_t)0, b->d_pipe_part[slot], b->d_pipe_part[slot], rc);
     } else if (b->kind == BANK_FM) {
-      hipLaunchKernelGGL(fm_render_kernel<true>, dim3(rows), blk, 0, st, b->d_params, b->d_state, b->n, frames, (size_t)0, b->d_pipe_part[slot]);
+      hipLaunchKernelGGL(fm_render_kernel<true>, dim3(rows), blk, 0, st, b->d_params, b->d_state, b->n, frames, (size_t)0, b->d_pipe_part[slot], b->d_pipe_part[slot]);
     } else {
-      hipLaunchKernelGGL(sampler_render_kernel<true>, dim3(rows), blk, 0, st, b->d_params, b->d_state, b->n, frames, (size_t)0, b->d_pipe_part[slot], b->d_pcm);
+      hipLaunchKernelGGL(sampler_render_kernel<true>, dim3(rows), blk, 0, st, b->d_params, b->d_state, b->n, frames, (size_t)0, b->d_pipe_part[slot], b->d_pipe_part[slot], b->d_pcm);
     }
     GHIP(ctx, hipEventRecord(b->ev_render_done[k][slot], st));
     GHIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_render_done[k][slot], 0));
@@ -1359,7 +1410,7 @@ int groove_bank_render_mix(groove_bank* b, uint32_t frames, float* bus_dev, int 
     GHIP(ctx, hipMalloc(&ctx->d_fseg, (size_t)segs * cols * 4));
     ctx->fseg_cap = (size_t)segs * cols;
   }
-  if (launch_render(b, frames, true, 0, ctx->d_fpart)) return 1;
+  if (launch_render(b, frames, true, 0, ctx->d_fpart, ctx->d_fpart)) return 1;
   if (segs == 1) {
     hipLaunchKernelGGL(partial_rows_kernel, dim3(blocks_for(cols), 1), dim3(kThreads), 0, ctx->stream, ctx->d_fpart, rows, cols,
                        rows_per_seg, ctx->d_fseg, bus_dev, accumulate);
@@ -1457,6 +1508,7 @@ int groove_fx_process(groove_fx* fx, groove_block* io, uint32_t frames) {
   if (frames == 0) return 0;
   GHIP(ctx, hipSetDevice(ctx->device));
   if (block_acquire(io)) return 1;
+  if (fx->kind != GROOVE_FX_MIXER) io->sums_valid = false; // the block is transformed in place
   const uint32_t n = fx->n;
   const size_t chs = (size_t)io->cap * n;
   const dim3 blk(kThreads), lanes_grid(blocks_for(2 * (size_t)n));
@@ -1582,7 +1634,10 @@ int groove_mix(groove_ctx* ctx, groove_block* const* blocks, uint32_t n_blocks, 
     if (!blocks[i]) return fail(ctx, "groove_mix: NULL block");
     if (frames > blocks[i]->cap) return fail(ctx, "groove_mix: frames > block capacity");
     if (block_acquire(blocks[i])) return 1;
-    if (mix_one(ctx, blocks[i], frames, bus_dev, accumulate || i > 0)) return 1;
+    const groove_block* blk = blocks[i];
+    if (blk->sums_valid && blk->sum_frames == frames) { // the render left the block's lane sums: reduce those rows
+      if (reduce_rows(ctx, blk->d_sums, blk->sum_rows, frames, bus_dev, accumulate || i > 0)) return 1;
+    } else if (mix_one(ctx, blocks[i], frames, bus_dev, accumulate || i > 0)) return 1;
   }
   return 0;
 }
@@ -1593,6 +1648,7 @@ int groove_block_accumulate(groove_block* dst, groove_block* src, uint32_t frame
   if (frames == 0) return 0;
   GHIP(ctx, hipSetDevice(ctx->device));
   if (block_acquire(dst) || block_acquire(src)) return 1;
+  dst->sums_valid = false;
   if (src->n == dst->n) {
     const size_t total = (size_t)2 * frames * src->n;
     const uint32_t g = (uint32_t)std::min<size_t>(blocks_for(total), 256 * 16);
@@ -1607,6 +1663,7 @@ int groove_block_accumulate(groove_block* dst, groove_block* src, uint32_t frame
 int groove_block_zero(groove_block* b) {
   if (!b) return fail(nullptr, "groove_block_zero: NULL argument");
   if (block_acquire(b)) return 1;
+  b->sums_valid = false;
   GHIP(b->ctx, hipMemsetAsync(b->d, 0, (size_t)2 * b->cap * b->n * 4, b->ctx->stream));
   return 0;
 }

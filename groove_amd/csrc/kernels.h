@@ -179,31 +179,27 @@ using FusedAcc = FusedAccLds;
 
 // Shared frame loop of the instrument kernels: `frame(f, L, R)` computes one frame of this
 // lane's voice; the epilogue either stores the planar block or feeds the fused bus sum.
+// FUSED: only the rows of the fused bus sum (partial[workgroup][ch][frame]) are produced.  Otherwise the planar block is
+// stored AND the same rows are written to `rows`: the block's own lane sums, which groove_mix then reduces instead of
+// reading the 8 bytes per voice-frame back (a block keeps them valid until something else writes it).
 template <bool FUSED, class FrameFn>
 __device__ __forceinline__ void run_frames(uint32_t frames, uint32_t n, uint32_t v, bool active, size_t ch_stride,
-                                           float* __restrict__ out, uint32_t prow, FrameFn&& frame) {
-  if (FUSED) {
-    FusedAcc acc(prow);
-    for (uint32_t f = 0; f < frames; ++f) {
-      float L, R;
-      frame(f, L, R);
-      acc.add(active ? L : 0.0f, active ? R : 0.0f, f);
-      constexpr uint32_t C = FusedAcc::kChunk;
-      if ((f & (C - 1)) == C - 1) acc.flush(out, frames, f - (C - 1), C);
-    }
-    if (frames & (FusedAcc::kChunk - 1)) acc.flush(out, frames, frames & ~(FusedAcc::kChunk - 1), frames & (FusedAcc::kChunk - 1));
-  } else {
-    for (uint32_t f = 0; f < frames; ++f) {
-      float L, R;
-      frame(f, L, R);
-      if (active) { // uniform row base + 32-bit lane offset
-        float* __restrict__ rowL = out + (size_t)f * n;
-        float* __restrict__ rowR = out + ch_stride + (size_t)f * n;
-        rowL[v] = L;
-        rowR[v] = R;
-      }
+                                           float* __restrict__ out, float* __restrict__ rows, uint32_t prow, FrameFn&& frame) {
+  FusedAcc acc(prow);
+  constexpr uint32_t C = FusedAcc::kChunk;
+  for (uint32_t f = 0; f < frames; ++f) {
+    float L, R;
+    frame(f, L, R);
+    acc.add(active ? L : 0.0f, active ? R : 0.0f, f);
+    if ((f & (C - 1)) == C - 1) acc.flush(rows, frames, f - (C - 1), C);
+    if (!FUSED && active) { // uniform row base + 32-bit lane offset
+      float* __restrict__ rowL = out + (size_t)f * n;
+      float* __restrict__ rowR = out + ch_stride + (size_t)f * n;
+      rowL[v] = L;
+      rowR[v] = R;
     }
   }
+  if (frames & (C - 1)) acc.flush(rows, frames, frames & ~(C - 1), frames & (C - 1));
 }
 template <int V> struct IntTag { static constexpr int value = V; };
 // Minimum of x over the 64 lanes (wave-uniform result).
@@ -228,18 +224,17 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
 // are never live, so their L and R stay zero without a select per frame.
 template <bool FUSED, bool HOISTED, class FirstFn, class BeginFn, class LiveFn, class IdleFn, class EndFn>
 __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n, uint32_t v, bool active, size_t ch_stride,
-                                                     float* __restrict__ out, uint32_t prow, FirstFn&& first, BeginFn&& begin,
+                                                     float* __restrict__ out, float* __restrict__ rows, uint32_t prow, FirstFn&& first, BeginFn&& begin,
                                                      LiveFn&& live_frame, IdleFn&& idle_frame, EndFn&& end) {
   if (frames == 0) return;
   constexpr uint32_t C = FusedAcc::kChunk;
   static_assert(C > 1, "frame 0 never completes a chunk");
   FusedAcc acc(prow);
   auto put = [&](uint32_t f, float L, float R, bool masked) {
-    if (FUSED) {
-      if (masked) acc.add(active ? L : 0.0f, active ? R : 0.0f, f);
-      else acc.add(L, R, f);
-      if ((f & (C - 1)) == C - 1) acc.flush(out, frames, f - (C - 1), C);
-    } else if (active) {
+    if (masked) acc.add(active ? L : 0.0f, active ? R : 0.0f, f);
+    else acc.add(L, R, f);
+    if ((f & (C - 1)) == C - 1) acc.flush(rows, frames, f - (C - 1), C);
+    if (!FUSED && active) {
       out[(size_t)f * n + v] = L;
       out[ch_stride + (size_t)f * n + v] = R;
     }
@@ -262,7 +257,7 @@ __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n
     }
     if (HOISTED) end(seg, live);
   }
-  if (FUSED && (frames & (C - 1))) acc.flush(out, frames, frames & ~(C - 1), frames & (C - 1));
+  if (frames & (C - 1)) acc.flush(rows, frames, frames & ~(C - 1), frames & (C - 1));
 }
 
 // ------------------------------------------------------------------ instruments
@@ -272,7 +267,7 @@ __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n
 template <bool FUSED, bool RETUNE, int LFO_MODE = LFO_F64, bool UNIFORM = false, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool REST = false>
 __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s, const RenderConsts& rc,
                                             uint32_t frames, uint32_t n, uint32_t v, bool active,
-                                            size_t ch_stride, float* __restrict__ out, uint32_t prow) {
+                                            size_t ch_stride, float* __restrict__ out, float* __restrict__ rows, uint32_t prow) {
   WelshScratch sc = welsh_scratch_init(p, rc);
   // Static cutoff + wave-uniform patch: the six f64 coefficients are the same in every lane and
   // never change, so they ride in SGPRs (12 VGPRs back; f64 FMAs take one scalar operand).
@@ -284,14 +279,14 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
     constexpr bool HOIST = true;
 #endif
     run_frames_segmented<FUSED, HOIST>(
-        frames, n, v, active, ch_stride, out, prow,
+        frames, n, v, active, ch_stride, out, rows, prow,
         [&](float& L, float& R) { welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL, false, REST>(p, s, rc, sc, L, R); },
         [&](bool& live) { const uint32_t k = welsh_segment_begin(p, s, live); if (HOIST) welsh_segment_start_hoisted(s, sc); return k; },
         [&](float& L, float& R) { welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, HOIST>(p, s, rc, sc, L, R); },
         [&]() { welsh_segment_idle_frame(s); },
         [&](uint32_t seg, bool live) { welsh_segment_end_hoisted<CL == LFO_UNUSED>(p, s, seg, live); });
   } else {
-    run_frames<FUSED>(frames, n, v, active, ch_stride, out, prow, [&](uint32_t f, float& L, float& R) {
+    run_frames<FUSED>(frames, n, v, active, ch_stride, out, rows, prow, [&](uint32_t f, float& L, float& R) {
       if (f == 0) welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL>(p, s, rc, sc, L, R);
       else welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL>(p, s, rc, sc, L, R);
     });
@@ -303,13 +298,13 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
 template <bool FUSED>
 __global__ __launch_bounds__(kThreads) void welsh_render_kernel(
     const uint32_t* __restrict__ params, uint32_t* __restrict__ state, uint32_t n, uint32_t frames,
-    size_t ch_stride, float* __restrict__ out, RenderConsts rc) {
+    size_t ch_stride, float* __restrict__ out, float* __restrict__ rows, RenderConsts rc) {
   const uint32_t v0 = blockIdx.x * kThreads + threadIdx.x;
   const bool active = v0 < n;
   const uint32_t v = active ? v0 : n - 1; // tail lanes shadow the last voice and store nothing
   const WelshParams p = soa_load<WelshParams>(params, n, v);
   WelshState s = soa_load<WelshState>(state, n, v);
-  welsh_block<FUSED, true>(p, s, rc, frames, n, v, active, ch_stride, out, blockIdx.x);
+  welsh_block<FUSED, true>(p, s, rc, frames, n, v, active, ch_stride, out, rows, blockIdx.x);
   if (active) soa_store(state, n, v, s);
 }
 // Wave-uniform form.  The host cuts the bank into VIRTUAL WAVES: maximal runs of consecutive
@@ -363,8 +358,8 @@ template <> struct WavesBudget<LFO_F64, true> { static constexpr int value = GRO
 // The one kernel argument (so that the non-inlined bodies can read it from the kernarg segment
 // with scalar loads instead of taking a dozen uniform values through VGPR arguments).
 struct UniformArgs {
-  const WaveDesc* waves; uint32_t* state; float* out; const uint32_t* wg_list; const uint8_t* wg_cls;
-  size_t ch_stride; RenderConsts rc; uint32_t n_waves, n, frames, n_wgs;
+  const WaveDesc* waves; uint32_t* state; float* out; float* rows; const uint32_t* wg_list; const uint8_t* wg_cls;
+  size_t ch_stride; RenderConsts rc; uint32_t n_waves, n, frames, n_wgs; // out: the planar block (block-writing form); rows: partial[workgroup][ch][frame] (both forms)
 };
 typedef const __attribute__((address_space(4))) UniformArgs* UniformArgsPtr; // kernarg segment: scalar loads
 __device__ __forceinline__ UniformArgsPtr uniform_args_scalar(UniformArgsPtr a) { // arguments of a call travel in VGPRs
@@ -385,7 +380,7 @@ __device__ __forceinline__ void welsh_uniform_body_impl(UniformArgsPtr a) {
   const uint32_t v = active ? d.vbase + lane : d.vbase; // idle lanes shadow the run's first voice
   WelshState s = soa_load<WelshState>(a->state, n, v);
   const RenderConsts rc{a->rc.pi_over_sr, a->rc.fc_max, a->rc.log2_x0, a->rc.x_lo, a->rc.x_hi};
-  welsh_block<FUSED, RETUNE, LFO_MODE, true, C1, C2, CL, REST>(d.p, s, rc, a->frames, n, v, active, a->ch_stride, a->out, wg);
+  welsh_block<FUSED, RETUNE, LFO_MODE, true, C1, C2, CL, REST>(d.p, s, rc, a->frames, n, v, active, a->ch_stride, a->out, a->rows, wg);
   if (active) soa_store(a->state, n, v, s);
 }
 template <bool FUSED, int LFO_MODE, bool RETUNE, int C1, int C2, int CL>
@@ -416,7 +411,7 @@ __device__ __forceinline__ bool welsh_idle_workgroup(const UniformArgs& a) {
   if (!__all(!active || (sa == ENV_IDLE && sf == ENV_IDLE)) && (threadIdx.x & 63u) == 0) atomicAdd(&busy_waves, 1);
   __syncthreads();
   if (busy_waves != 0) return false;
-  float* __restrict__ rows = a.out + (size_t)wg * 2 * a.frames; // partial[wg][ch][frame]
+  float* __restrict__ rows = a.rows + (size_t)wg * 2 * a.frames; // partial[wg][ch][frame]
   for (uint32_t t = threadIdx.x; t < 2 * a.frames; t += kThreads) rows[t] = 0.0f;
   return true;
 }
@@ -489,13 +484,13 @@ void launch_welsh_uniform_any_unfused(const UniformArgs& a, const uint8_t* wg_ba
 template <bool FUSED>
 __global__ __launch_bounds__(kThreads) void fm_render_kernel(
     const uint32_t* __restrict__ params, uint32_t* __restrict__ state, uint32_t n, uint32_t frames,
-    size_t ch_stride, float* __restrict__ out) {
+    size_t ch_stride, float* __restrict__ out, float* __restrict__ rows) {
   const uint32_t v0 = blockIdx.x * kThreads + threadIdx.x;
   const bool active = v0 < n;
   const uint32_t v = active ? v0 : n - 1;
   const FmParams p = soa_load<FmParams>(params, n, v);
   FmState s = soa_load<FmState>(state, n, v);
-  run_frames<FUSED>(frames, n, v, active, ch_stride, out, blockIdx.x, [&](uint32_t f, float& L, float& R) {
+  run_frames<FUSED>(frames, n, v, active, ch_stride, out, rows, blockIdx.x, [&](uint32_t f, float& L, float& R) {
     if (f == 0) fm_frame<true>(p, s, L, R);
     else fm_frame<false>(p, s, L, R);
   });
@@ -506,7 +501,7 @@ __global__ __launch_bounds__(kThreads) void fm_render_kernel(
 template <bool FUSED>
 __global__ __launch_bounds__(kThreads) void sampler_render_kernel(
     const uint32_t* __restrict__ params, uint32_t* __restrict__ state, uint32_t n, uint32_t frames,
-    size_t ch_stride, float* __restrict__ out, const float* __restrict__ bank) {
+    size_t ch_stride, float* __restrict__ out, float* __restrict__ rows, const float* __restrict__ bank) {
   const uint32_t v0 = blockIdx.x * kThreads + threadIdx.x;
   const bool active = v0 < n;
   const uint32_t v = active ? v0 : n - 1;
@@ -523,10 +518,10 @@ __global__ __launch_bounds__(kThreads) void sampler_render_kernel(
 #pragma unroll
     for (uint32_t k = 0; k < C; ++k) {
       if (k < count) {
-        if (FUSED) acc.add(active ? x[k] : 0.0f, active ? x[k] : 0.0f, f0 + k);
-        else if (active) { out[(size_t)(f0 + k) * n + v] = x[k]; out[ch_stride + (size_t)(f0 + k) * n + v] = x[k]; }
+        acc.add(active ? x[k] : 0.0f, active ? x[k] : 0.0f, f0 + k);
+        if (!FUSED && active) { out[(size_t)(f0 + k) * n + v] = x[k]; out[ch_stride + (size_t)(f0 + k) * n + v] = x[k]; }
       }
-      if (FUSED && (k & (K - 1)) == K - 1 && k - (K - 1) < count) acc.flush(out, frames, f0 + k - (K - 1), min(K, count - (k - (K - 1))));
+      if ((k & (K - 1)) == K - 1 && k - (K - 1) < count) acc.flush(rows, frames, f0 + k - (K - 1), min(K, count - (k - (K - 1))));
     }
   }
   if (active) soa_store(state, n, v, s);

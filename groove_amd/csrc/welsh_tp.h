@@ -219,9 +219,10 @@ __device__ __forceinline__ void tp_shfl_affine(const Lp24Affine& m, int src, Lp2
   for (int i = 0; i < 2; ++i) { out.c2[i] = tp_shfl(m.c2[i], src); out.c3[i] = tp_shfl(m.c3[i], src); }
 }
 struct TpArgs {
-  const uint32_t* params; uint32_t* state; float* out; size_t ch_stride; RenderConsts rc; uint32_t n, frames;
+  const uint32_t* params; uint32_t* state; float* out; float* rows; size_t ch_stride; RenderConsts rc; uint32_t n, frames;
 };
-// FUSED: out = partial[workgroup][ch][frame] (the bus reduction's rows); otherwise the planar block [ch][frame][voice].
+// rows = partial[workgroup][ch][frame] (the bus reduction's rows), written by both forms; !FUSED also stores the planar
+// block out[ch][frame][voice] (kernels.h run_frames: the rows are then the block's own lane sums for groove_mix).
 template <bool FUSED>
 __global__ __launch_bounds__(kTpThreads, 2) void welsh_tp_kernel(TpArgs a) {
   __shared__ float s_noise[kTpWaves][3][kTpMaxFrames];
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(kTpThreads, 2) void welsh_tp_kernel(TpArgs a) {
   }
 
   // ---- outputs
-  if (FUSED) {
+  {
 #pragma unroll
     for (uint32_t j = 0; j < kTpChunk; ++j) {
       s_tile[wave][0][n0 + j] = (voice && j < cnt) ? oL[j] : 0.0f;
@@ -388,9 +389,10 @@ __global__ __launch_bounds__(kTpThreads, 2) void welsh_tp_kernel(TpArgs a) {
       float acc = 0.0f;
 #pragma unroll
       for (int w = 0; w < kTpWaves; ++w) acc += s_tile[w][ch][f];
-      a.out[((size_t)blockIdx.x * 2 + ch) * frames + f] = acc;
+      a.rows[((size_t)blockIdx.x * 2 + ch) * frames + f] = acc;
     }
-  } else if (voice) {
+  }
+  if (!FUSED && voice) {
 #pragma unroll
     for (uint32_t j = 0; j < kTpChunk; ++j) {
       if (j < cnt) {
