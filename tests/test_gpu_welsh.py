@@ -355,3 +355,44 @@ def test_interleaved_bank_is_regrouped_transparently(gpu_ctx, oracle):
         assert np.max(np.abs(ba.download() - bg.download())) / n <= 1e-6
     for x in (synth, a, g, block, ba, bg):
         x.destroy()
+
+
+def test_mix_uses_the_blocks_row_sums_only_while_they_are_valid(gpu_ctx, oracle):
+    """A block-writing render leaves the block's lane sums behind and groove_mix reduces those rows instead of reading the
+    block back; whatever else writes the block (an effect in place, an upload, an accumulate into it, a zero) must make
+    the mix read the block again, and so must a mix over another frame count than was rendered."""
+    from groove_amd import entities as E
+    n = 96
+    params = P.welsh_voices(n)
+    synth = E.WelshSynth(gpu_ctx, params)
+    synth.handle_midi_events(P.note_on_all(n))
+    block, other = gpu_ctx.block(n, 256), gpu_ctx.block(n, 256)
+    bus = gpu_ctx.bus(256)
+
+    def mixed(frames=256):
+        gpu_ctx.mix([block], frames, bus)
+        return bus.download(frames).astype(np.float64)
+
+    synth.generate_batch_values(block, 256)
+    full = block.download(256).astype(np.float64)
+    assert np.abs(full).max() > 0.1
+    assert np.max(np.abs(mixed() - full.sum(axis=2).T)) <= 1e-5                      # cached rows
+    assert np.max(np.abs(mixed(100) - full[:, :100].sum(axis=2).T)) <= 1e-5          # other frame count: reads the block
+    g = E.Effect(gpu_ctx, T.FX_GAIN, (T.FxParams * n)(*[T.fx_params(ceiling=0.5)] * n))
+    g.transform_audio(block, 256)
+    assert np.max(np.abs(mixed() - 0.5 * full.sum(axis=2).T)) <= 1e-5                # effect in place
+    synth.generate_batch_values(block, 256)
+    nxt = block.download(256).astype(np.float64)
+    half = (0.25 * nxt).astype(np.float32)
+    block.upload(half)
+    assert np.max(np.abs(mixed() - half.astype(np.float64).sum(axis=2).T)) <= 1e-5   # upload
+    synth.generate_batch_values(block, 256)
+    cur = block.download(256).astype(np.float64)
+    other.upload(half)
+    assert gpu_ctx.L.groove_block_accumulate(block.h, other.h, 256, 1) == 0
+    assert np.max(np.abs(mixed() - (cur + half).sum(axis=2).T)) <= 1e-5              # accumulate into it
+    synth.generate_batch_values(block, 256)
+    assert gpu_ctx.L.groove_block_zero(block.h) == 0
+    assert not mixed().any()                                                          # zero
+    for x in (g, synth, block, other, bus):
+        x.destroy()
