@@ -229,21 +229,33 @@ def cpu_baseline(workload, seconds_target=15.0):
 
 # ------------------------------------------------------------------------------------------ timing
 class Dist:
-    """The launcher's process group (torch.distributed over RCCL) and the library's own communicator."""
+    """The ranks' rendezvous and the bus reduce.  The data-path collective is the library's own RCCL communicator (one
+    ncclReduce of the bus on the ctx stream, groove_bus_reduce); the launcher-side process group only carries the
+    128-byte unique id, the barriers and the max of the ranks' clocks, so it runs over gloo on the host and torch
+    never opens a GPU context of its own in a rank: its streams and a second RCCL instance would share the device's
+    few hardware queues with the render's per-kind streams (measured on one GPU: 0.58 -> 0.69 ms per block).  Only if
+    the library communicator cannot be set up does the reduce fall back to torch.distributed over nccl."""
 
-    def __init__(self, ctx, rank, world, local_rank):
+    def __init__(self, rank, world, local_rank):
+        # torch is imported (and the host-side group formed) BEFORE libgroove_hip.so is loaded: a process has one HIP
+        # runtime and one RCCL, whichever library asks first, and the wheel's bundled pair only works as a pair
+        # (libgroove_hip.so first, then torch: ncclCommInitRank fails with "unhandled cuda error").
         import torch
         import torch.distributed as dist
-        self.torch, self.dist, self.ctx, self.rank, self.world = torch, dist, ctx, rank, world
-        # The library's own communicator (RCCL, dlopen'ed): one ncclReduce of the bus per render.  If it cannot
-        # be set up on this node the reduce falls back to the launcher's process group (same RCCL collective
-        # through torch, plus two staging copies of the bus, once per render) and the line says so.
+        self.torch, self.dist, self.rank, self.world, self.local_rank = torch, dist, rank, world, local_rank
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        self.nccl_group = None
+        self.ctx = None
+
+    def attach(self, ctx):
+        torch, dist, rank, world, local_rank = self.torch, self.dist, self.rank, self.world, self.local_rank
+        self.ctx = ctx
         self.reduce_via = "groove_bus_reduce (RCCL ncclReduce on the ctx stream)"
         try:
             uid = [ctx.comm_unique_id() if rank == 0 else None]
         except Exception as e:  # noqa: BLE001
             uid = [None]
-            self.reduce_via = f"torch.distributed.reduce (library communicator unavailable: {e})"
+            self.reduce_via = f"torch.distributed.reduce over nccl (library communicator unavailable: {e})"
         dist.broadcast_object_list(uid, src=0)
         ok = [1]
         if uid[0] is not None:
@@ -253,19 +265,23 @@ class Dist:
                 ctx.comm_init(uid[0], rank, world)
             except Exception as e:  # noqa: BLE001
                 ok = [0]
-                self.reduce_via = f"torch.distributed.reduce (groove_comm_init failed: {e})"
+                self.reduce_via = f"torch.distributed.reduce over nccl (groove_comm_init failed: {e})"
         else:
             ok = [0]
-        flag = torch.tensor(ok, dtype=torch.int32, device="cuda")
+        flag = torch.tensor(ok, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # every rank takes the same path
         self.own_comm = bool(int(flag.item()))
-        if not self.own_comm and self.reduce_via.startswith("groove_bus_reduce"):
-            self.reduce_via = "torch.distributed.reduce (another rank could not set up the library communicator)"
-        self.rccl_ranks = ctx.comm_ranks() if self.own_comm else dist.get_world_size()
+        if not self.own_comm:
+            if self.reduce_via.startswith("groove_bus_reduce"):
+                self.reduce_via = "torch.distributed.reduce over nccl (another rank could not set up the library communicator)"
+            torch.cuda.set_device(local_rank)
+            self.nccl_group = dist.new_group(backend="nccl")
+        self.rccl_ranks = ctx.comm_ranks() if self.own_comm else dist.get_world_size(self.nccl_group)
 
     def sync(self):
-        self.ctx.synchronize()
-        self.torch.cuda.synchronize()
+        self.ctx.synchronize()      # every stream of the library on this device
+        if self.nccl_group is not None:
+            self.torch.cuda.synchronize()
         self.dist.barrier()
         self.ctx.synchronize()
 
@@ -275,13 +291,13 @@ class Dist:
             return
         host = bus.download()
         t = self.torch.from_numpy(host[frame0:frame0 + frames].copy()).cuda()
-        self.dist.reduce(t, dst=0, op=self.dist.ReduceOp.SUM)
+        self.dist.reduce(t, dst=0, op=self.dist.ReduceOp.SUM, group=self.nccl_group)
         if self.rank == 0:
             host[frame0:frame0 + frames] = t.cpu().numpy()
             bus.upload(host)
 
     def max_over_ranks(self, x):
-        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        t = self.torch.tensor([x], dtype=self.torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -439,18 +455,16 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        import torch
-        import torch.distributed as tdist
-        torch.cuda.set_device(local_rank)
-        tdist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     wl = dict(WORKLOADS[args.workload])
     V = args.voices or wl["voices"]
     weak = args.weak and not args.strong
     V_total = V * world if weak else V   # voices of the whole project
     lo, hi = voice_range(V_total, rank, world)
+    dist = Dist(rank, world, local_rank) if use_dist else None
     ctx = E.Context(local_rank if use_dist else 0)
-    dist = Dist(ctx, rank, world, local_rank) if use_dist else None
+    if dist is not None:
+        dist.attach(ctx)
     if dist is not None and dist.rccl_ranks != world:
         sys.stderr.write(f"bench.py: the communicator has {dist.rccl_ranks} ranks, {world} GPUs were asked for\n")
         ctx.close()
