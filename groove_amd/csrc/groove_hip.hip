@@ -8,6 +8,7 @@
 #include "../../include/groove_hip.h"
 #include "kernels.h"
 #include "welsh_tp.h"
+#include "fx_tp.h"
 #include <dlfcn.h>
 #include <rccl/rccl.h> // types, enumerators and prototypes only: the library itself is dlopen'ed (rccl_open)
 #include <string>
@@ -139,6 +140,7 @@ struct groove_ctx {
   bool fork_pending[kSideStreams] = {}; // the side stream has not yet waited for ev_fork
   bool need_fork = true;                // ctx-stream work since the last fork that side streams must wait for
   uint32_t tp_max_voices = kTpMaxVoices; // Welsh banks up to this size render time-parallel (welsh_tp.h); GROOVE_TP_MAX_VOICES overrides, 0 = never
+  uint32_t fx_tp_max_lanes = 65536;      // IIR effect banks of up to this many lane-channels run time-parallel (fx_tp.h); GROOVE_FX_TP_MAX_LANES
   uint32_t pipeline_min_waves = 4700;   // banks at least this long (~300,000 voices) run one kernel per base kind and pipeline their fused blocks; smaller ones take the all-kinds kernel
   int next_stream_slot = 0;             // round-robin side-stream assignment of single-kernel banks
   bool seq_allpass = false;             // GROOVE_FX_SEQ_ALLPASS=1: the sequential all-pass kernel (A/B and bit-identity tests)
@@ -735,6 +737,7 @@ int groove_init(int device_ordinal, groove_ctx** out) {
   ctx->device = device_ordinal;
   if (const char* e = std::getenv("GROOVE_FX_SEQ_ALLPASS")) ctx->seq_allpass = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_TP_MAX_VOICES")) ctx->tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
+  if (const char* e = std::getenv("GROOVE_FX_TP_MAX_LANES")) ctx->fx_tp_max_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_PIPELINE_MIN_WAVES")) ctx->pipeline_min_waves = (uint32_t)std::strtoul(e, nullptr, 10); // tests force the pipeline on small banks
   // The runtime spreads the streams of one priority over a handful of hardware queues, and streams that
   // share a queue run one after the other.  The ctx stream is created at the highest priority: that
@@ -1016,12 +1019,16 @@ static float* block_sums(groove_block* blk, uint32_t rows, uint32_t frames) {
 }
 // Small Welsh banks and blocks of up to 256 frames: one wavefront per voice, lanes = time (welsh_tp.h).
 static bool use_tp(const groove_bank* b, uint32_t frames) {
-  return b->kind == BANK_WELSH && frames <= kTpMaxFrames && b->n <= b->ctx->tp_max_voices;
+  if (frames > kTpMaxFrames || b->ctx->tp_max_voices == 0) return false;
+  if (b->kind == BANK_WELSH) return b->n <= b->ctx->tp_max_voices;
+  if (b->kind == BANK_FM) return b->n <= kFmTpMaxVoices; // no filter scan: far cheaper per voice than a Welsh voice
+  return false;
 }
 static void launch_tp(groove_bank* b, uint32_t frames, bool fused, size_t chs, float* out, float* rows, hipStream_t st) {
   groove_ctx* ctx = b->ctx;
   const TpArgs a{b->d_params, b->d_state, out, rows, chs, render_consts(ctx->sr), b->n, frames};
-  launch_welsh_tp(a, st, fused);
+  if (b->kind == BANK_FM) launch_fm_tp(a, st, fused);
+  else launch_welsh_tp(a, st, fused);
 }
 // rows of partial[][2][frames] a bank's fused render writes
 static uint32_t fused_rows(const groove_bank* b, uint32_t frames) {
@@ -1532,10 +1539,17 @@ int groove_fx_process(groove_fx* fx, groove_block* io, uint32_t frames) {
     case GROOVE_FX_BIQUAD_PEAK12:
     case GROOVE_FX_BIQUAD_LSHELF12:
     case GROOVE_FX_BIQUAD_HSHELF12:
-      hipLaunchKernelGGL(fx_biquad_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+      // few lane-channels: one wavefront each, frames over its lanes (fx_tp.h); many: one thread each, frames serial
+      if (frames <= kTpMaxFrames && 2 * (size_t)n <= ctx->fx_tp_max_lanes && ctx->tp_max_voices)
+        hipLaunchKernelGGL(fx_biquad_tp_kernel, dim3((2 * n + kFxTpWaves - 1) / kFxTpWaves), dim3(kFxTpWaves * 64), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+      else
+        hipLaunchKernelGGL(fx_biquad_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       break;
     case GROOVE_FX_BIQUAD_LP24:
-      hipLaunchKernelGGL(fx_lp24_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+      if (frames <= kTpMaxFrames && 2 * (size_t)n <= ctx->fx_tp_max_lanes && ctx->tp_max_voices)
+        hipLaunchKernelGGL(fx_lp24_tp_kernel, dim3((2 * n + kFxTpWaves - 1) / kFxTpWaves), dim3(kFxTpWaves * 64), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+      else
+        hipLaunchKernelGGL(fx_lp24_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       break;
     case GROOVE_FX_DELAY:
       if (fx->N >= frames) // no feedback inside the block: fully parallel over (frame, lane)

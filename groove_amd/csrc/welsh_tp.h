@@ -196,6 +196,16 @@ GROOVE_HD bool welsh_tp_noise(const WelshParams& p, int osc /*0: osc 1, 1: osc 2
   return ((p.flags >> sh) & 15u) == GROOVE_WAVE_NOISE;
 }
 
+// ------------------------------------------------------------------ FmVoice, time-parallel
+// An FM voice has no filter: the modulator's phase is a closed form, the carrier's a prefix sum of per-frame
+// (signed, through-zero) increments.  One frame's carrier increment, given the modulator phase AT that frame and
+// the modulator envelope's value (fm_frame's arithmetic):
+GROOVE_HD uint64_t fm_tp_carrier_inc(const FmParams& p, uint64_t c_inc, uint64_t mod_phase, float menv_value) {
+  const double mv = osc_value_f64(GROOVE_WAVE_SINE, mod_phase, 0, 0.0f);
+  const double lfm = mv * (double)menv_value * p.depth_beta;
+  return turns_to_inc((double)c_inc * 5.42101086242752217004e-20 * (1.0 + lfm));
+}
+
 #if defined(__HIPCC__)
 // ------------------------------------------------------------------ the kernel
 constexpr int kTpWaves = 4;                 // voices per workgroup
@@ -414,7 +424,100 @@ __global__ __launch_bounds__(kTpThreads, 2) void welsh_tp_kernel(TpArgs a) {
     soa_store(a.state, n, v, s);
   }
 }
+// FmVoice: one wavefront per voice, 64 lanes x 4 frames (same argument block; rows / out as above).
+constexpr uint32_t kFmTpMaxVoices = 131072; // the serial kernel's 256-frame walk costs ~0.09 ms whatever the size; above this it has the wavefronts
+template <bool FUSED>
+__global__ __launch_bounds__(kTpThreads) void fm_tp_kernel(TpArgs a) {
+  __shared__ float s_tile[kTpWaves][2][kTpMaxFrames];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t v0 = blockIdx.x * kTpWaves + wave;
+  const bool voice = v0 < a.n;
+  const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(voice ? v0 : a.n - 1));
+  const uint32_t frames = a.frames, n = a.n;
+  const FmParams p = make_scalar(soa_load<FmParams>(a.params, n, v));
+  const FmState s0 = soa_load<FmState>(a.state, n, v);
+  const bool first0 = (s0.vflags & VF_FIRST) != 0;
+  const uint32_t live_total = env_idle_at(s0.cenv, p.cenv, frames);
+  const uint32_t n0 = lane * kTpChunk;
+  const uint32_t cnt = n0 < frames ? (frames - n0 < kTpChunk ? frames - n0 : kTpChunk) : 0u;
+  FmState s = s0;
+  env_seek(s.cenv, p.cenv, n0 < frames ? n0 : 0u);
+  env_seek(s.menv, p.menv, n0 < frames ? n0 : 0u);
+  const uint32_t live_before = n0 < live_total ? n0 : live_total;
+  const uint64_t adv = (uint64_t)(live_before - ((first0 && live_before >= 1u) ? 1u : 0u));
+  uint64_t mph = s0.modulator.phase + adv * s0.m_inc;
+  if (live_before >= 1u) s.vflags = 0;
+  uint64_t loc[kTpChunk], run = 0;
+  float cval[kTpChunk];
+  bool lives[kTpChunk];
+#pragma unroll
+  for (uint32_t j = 0; j < kTpChunk; ++j) {
+    const uint32_t f = n0 + j;
+    lives[j] = false; cval[j] = 0.0f;
+    uint64_t inc = 0;
+    if (j < cnt) {
+      env_tick(s.cenv, p.cenv);
+      env_tick(s.menv, p.menv);
+      if (f < live_total) {
+        lives[j] = true;
+        const bool is_first = first0 && f == 0;
+        if (!is_first) mph += s0.m_inc;
+        const uint64_t ci = fm_tp_carrier_inc(p, s0.c_inc, mph, s.menv.value);
+        if (!is_first) inc = ci;
+        cval[j] = s.cenv.value;
+        s.vflags = 0;
+      }
+    }
+    run += inc;
+    loc[j] = run;
+  }
+  uint64_t t = run; // inclusive scan of the lane totals
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t o = tp_shfl(t, (int)lane - d);
+    if ((int)lane >= d) t += o;
+  }
+  const uint64_t base = s0.carrier.phase + (t - run);
+  float oL[kTpChunk], oR[kTpChunk];
+#pragma unroll
+  for (uint32_t j = 0; j < kTpChunk; ++j) {
+    float m = 0.0f;
+    if (lives[j]) m = osc_value(GROOVE_WAVE_SINE, base + loc[j], 0, 0.0f) * cval[j];
+    oL[j] = m * p.gl; oR[j] = m * p.gr;
+  }
+  {
+#pragma unroll
+    for (uint32_t j = 0; j < kTpChunk; ++j) {
+      s_tile[wave][0][n0 + j] = (voice && j < cnt) ? oL[j] : 0.0f;
+      s_tile[wave][1][n0 + j] = (voice && j < cnt) ? oR[j] : 0.0f;
+    }
+    __syncthreads();
+    for (uint32_t tt = threadIdx.x; tt < 2 * frames; tt += kTpThreads) {
+      const uint32_t ch = tt / frames, f = tt % frames;
+      float acc = 0.0f;
+#pragma unroll
+      for (int w = 0; w < kTpWaves; ++w) acc += s_tile[w][ch][f];
+      a.rows[((size_t)blockIdx.x * 2 + ch) * frames + f] = acc;
+    }
+  }
+  if (!FUSED && voice) {
+#pragma unroll
+    for (uint32_t j = 0; j < kTpChunk; ++j) {
+      if (j < cnt) {
+        a.out[(size_t)(n0 + j) * n + v] = oL[j];
+        a.out[a.ch_stride + (size_t)(n0 + j) * n + v] = oR[j];
+      }
+    }
+  }
+  const uint32_t last = frames ? (frames - 1) / kTpChunk : 0u;
+  if (voice && lane == last && frames) {
+    s.modulator.phase = mph;
+    s.carrier.phase = base + run;
+    soa_store(a.state, n, v, s);
+  }
+}
 void launch_welsh_tp(const TpArgs& a, hipStream_t st, bool fused);
+void launch_fm_tp(const TpArgs& a, hipStream_t st, bool fused);
 inline uint32_t welsh_tp_workgroups(uint32_t n) { return (n + kTpWaves - 1) / kTpWaves; }
 #endif // __HIPCC__
 

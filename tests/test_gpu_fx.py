@@ -12,6 +12,17 @@ from groove_amd import patches as P, abi_types as T
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["serial", "time-parallel"])
+def kernel_form(request, gpu_ctx):
+    """The IIR effects (BiQuad family, 24 dB low-pass) have two forms: one thread per lane-channel walking the frames
+    (kernels.h) and one wavefront per lane-channel with the frames over its lanes (fx_tp.h, the default for banks of up
+    to 65,536 lane-channels); every test of this module runs against both."""
+    old = gpu_ctx.time_parallel_max_voices
+    gpu_ctx.time_parallel_max_voices = 0 if request.param == "serial" else old
+    yield request.param
+    gpu_ctx.time_parallel_max_voices = old
+
+
 def _audio(n, frames_total, seed=1):
     rng = np.random.default_rng(seed)
     t = np.arange(frames_total)[None, :, None]

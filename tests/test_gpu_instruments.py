@@ -7,11 +7,23 @@ from groove_amd import patches as P, abi_types as T
 pytestmark = pytest.mark.gpu
 
 
-def test_fm_per_voice_parity(gpu_ctx, oracle):
-    """16 FM patches (beta 0.1 .. 15, through-zero FM), 60 blocks, note-off at block 30.
-    Tolerance: per-voice RMS <= 1e-5 vs the f64 oracle."""
+@pytest.mark.parametrize("form", ["serial", "time-parallel"])
+def test_fm_per_voice_parity(gpu_ctx, oracle, form):
+    """16 FM patches (beta 0.1 .. 15, through-zero FM), 60 blocks (ragged lengths), note-off at block 30, re-trigger at
+    block 45; both forms of the FM render (one voice per lane, kernels.h; one wavefront per voice with the carrier
+    phase as a prefix sum over its lanes, welsh_tp.h).  Tolerance: per-voice RMS <= 1e-5 vs the f64 oracle; the
+    voice state of the two forms agrees bit for bit apart from the last bits of the carrier phase."""
     from groove_amd import entities as E
-    n, frames, blocks = 48, 256, 60
+    old = gpu_ctx.time_parallel_max_voices
+    gpu_ctx.time_parallel_max_voices = 0 if form == "serial" else old
+    try:
+        _fm_parity(gpu_ctx, oracle, E)
+    finally:
+        gpu_ctx.time_parallel_max_voices = old
+
+
+def _fm_parity(gpu_ctx, oracle, E):
+    n, frames, blocks = 50, 256, 60
     params = P.fm_voices(n)
     synth = E.FmSynth(gpu_ctx, params)
     block = gpu_ctx.block(n, frames)
@@ -19,18 +31,49 @@ def test_fm_per_voice_parity(gpu_ctx, oracle):
     on, off = P.note_on_all(n), P.note_off_all(n)
     got, want = [], []
     for b in range(blocks):
-        if b == 0:
+        if b in (0, 45):
             synth.handle_midi_events(on); ob.note_events(on)
         if b == 30:
             synth.handle_midi_events(off); ob.note_events(off)
-        synth.generate_batch_values(block, frames)
-        got.append(block.download(frames)); want.append(ob.render(frames))
+        fr = [256, 256, 100, 7, 1, 255][b % 6]
+        synth.generate_batch_values(block, fr)
+        got.append(block.download(fr)); want.append(ob.render(fr))
     got = np.concatenate(got, axis=1).astype(np.float64); want = np.concatenate(want, axis=1)
     for v in range(n):
         rms = np.sqrt(np.mean((got[:, :, v] - want[:, :, v]) ** 2))
         assert np.sqrt(np.mean(want[:, :, v] ** 2)) > 1e-3
         assert rms <= 1e-5, f"fm voice {v}: rms {rms:.3e}"
     synth.destroy(); block.destroy()
+
+
+def test_fm_forms_leave_the_same_state(gpu_ctx):
+    from groove_amd import entities as E
+    n = 37
+    params = P.fm_voices(n)
+    on, off = P.note_on_all(n), P.note_off_all(n)
+    old = gpu_ctx.time_parallel_max_voices
+    a, b = E.FmSynth(gpu_ctx, params), E.FmSynth(gpu_ctx, params)
+    block = gpu_ctx.block(n, 256)
+    try:
+        for blk in range(40):
+            for s in (a, b):
+                if blk in (0, 30): s.handle_midi_events(on)
+                if blk == 12: s.handle_midi_events(off)
+            fr = [256, 100, 7, 1][blk % 4]
+            gpu_ctx.time_parallel_max_voices = old
+            a.generate_batch_values(block, fr); xa = block.download(fr); sa = a.download_state()
+            gpu_ctx.time_parallel_max_voices = 0
+            b.generate_batch_values(block, fr); xb = block.download(fr); sb = b.download_state()
+            assert np.max(np.abs(xa.astype(np.float64) - xb)) <= 2e-6, blk
+            # FmState words: carrier {u64 phase, x1, x2}, modulator {...}, c_inc, m_inc (u64), 2 x EnvState (7 words), vflags, pad
+            exact = list(range(2, 27))
+            assert np.array_equal(sa[exact], sb[exact]), blk
+            pa = sa[0].astype(np.uint64) | (sa[1].astype(np.uint64) << np.uint64(32))
+            pb = sb[0].astype(np.uint64) | (sb[1].astype(np.uint64) << np.uint64(32))
+            assert np.array_equal(pa, pb), blk   # same increments, integer sums: the carrier phase is exact too
+    finally:
+        gpu_ctx.time_parallel_max_voices = old
+    a.destroy(); b.destroy(); block.destroy()
 
 
 def test_sampler_is_exact_fetch(gpu_ctx, oracle):
