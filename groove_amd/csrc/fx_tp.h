@@ -31,114 +31,174 @@ __device__ __forceinline__ void bq_affine_compose(BqAffine& later, const BqAffin
   later = r;
 }
 
-constexpr int kFxTpWaves = 4; // lane-channels per workgroup
-// coef: [5][n] f64 (b0 b1 b2 a1 a2); st: [4][2n] f64 (x1 x2 y1 y2); data: the planar block, in place.
-__global__ __launch_bounds__(kFxTpWaves * 64) void fx_biquad_tp_kernel(
+// Workgroup = 8 adjacent lane-channels of one channel x the block's frames (one per wave).  The block is planar [frame][lane], so a
+// lane-channel's frames are 4 n bytes apart: read per wavefront they would cost one 128-byte line per sample.  The
+// workgroup therefore moves its [frames][32] tile through LDS with whole-line accesses (two 128-byte rows per wave
+// instruction), transposed to tile[lane-channel][frame] (+1 float per row: conflict-free both ways), and its waves take
+// the lane-channels in turn from there (one ds_read_b128 = a lane's four frames).
+constexpr uint32_t kFxTile = 8, kFxTpThreads = 512, kFxTileRow = kTpMaxFrames + 4; // rows stay 16-byte aligned
+struct FxTile { float t[kFxTile][kFxTileRow]; };
+__device__ __forceinline__ void fx_tile_load(FxTile& tile, const float* __restrict__ data, uint32_t n, uint32_t frames, uint32_t lane0, uint32_t lanes) {
+  const uint32_t c = threadIdx.x % kFxTile;
+  for (uint32_t f = threadIdx.x / kFxTile; f < frames; f += kFxTpThreads / kFxTile)
+    if (c < lanes) tile.t[c][f] = data[(size_t)f * n + lane0 + c];
+}
+__device__ __forceinline__ void fx_tile_store(const FxTile& tile, float* __restrict__ data, uint32_t n, uint32_t frames, uint32_t lane0, uint32_t lanes) {
+  const uint32_t c = threadIdx.x % kFxTile;
+  for (uint32_t f = threadIdx.x / kFxTile; f < frames; f += kFxTpThreads / kFxTile)
+    if (c < lanes) data[(size_t)f * n + lane0 + c] = tile.t[c][f];
+}
+// grid: (ceil(n / 32), 2 channels).  coef: [5][n] f64 (b0 b1 b2 a1 a2); st: [4][2n] f64 (x1 x2 y1 y2); data: the planar block, in place.
+__global__ __launch_bounds__(kFxTpThreads) void fx_biquad_tp_kernel(
     float* __restrict__ data, uint32_t n, uint32_t frames, size_t ch_stride,
     const double* __restrict__ coef, double* __restrict__ st, const float* __restrict__ wet) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kFxTpWaves + (threadIdx.x >> 6)));
-  if (t >= 2 * n) return;
-  const uint32_t ch = t / n, ln = t % n;
+  __shared__ FxTile tile;
+  __shared__ double s_coef[5][kFxTile], s_st[4][kFxTile]; // the tile's coefficients and state: one coalesced load each, not one round trip per lane-channel
+  __shared__ float s_wet[kFxTile];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, ch = blockIdx.y;
+  const uint32_t lane0 = blockIdx.x * kFxTile, lanes = min(kFxTile, n - lane0);
+  float* __restrict__ base = data + ch * ch_stride;
   const size_t tn = 2 * (size_t)n;
-  const double b0 = coef[ln], b1 = coef[(size_t)n + ln], b2 = coef[(size_t)2 * n + ln], a1 = coef[(size_t)3 * n + ln], a2 = coef[(size_t)4 * n + ln];
-  const double sx1 = st[t], sx2 = st[tn + t], sy1 = st[2 * tn + t], sy2 = st[3 * tn + t];
-  const float wm = wet[ln];
-  float* __restrict__ ptr = data + ch * ch_stride + ln;
+  if (threadIdx.x < lanes) {
+    const uint32_t c = threadIdx.x, ln = lane0 + c;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s_coef[k][c] = coef[(size_t)k * n + ln];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_st[k][c] = st[(size_t)k * tn + ch * n + ln];
+    s_wet[c] = wet[ln];
+  }
+  fx_tile_load(tile, base, n, frames, lane0, lanes);
+  __syncthreads();
   const uint32_t n0 = lane * kTpChunk;
   const uint32_t cnt = n0 < frames ? (frames - n0 < kTpChunk ? frames - n0 : kTpChunk) : 0u;
-  float xf[kTpChunk];
+  for (uint32_t c = wave; c < lanes; c += kFxTpThreads / 64) { // this wave's lane-channels, one after the other
+    const double b0 = s_coef[0][c], b1 = s_coef[1][c], b2 = s_coef[2][c], a1 = s_coef[3][c], a2 = s_coef[4][c];
+    const double sx1 = s_st[0][c], sx2 = s_st[1][c], sy1 = s_st[2][c], sy2 = s_st[3][c];
+    const float wm = s_wet[c];
+    float xf[kTpChunk];
+    {
+      const float4 q = *reinterpret_cast<const float4*>(&tile.t[c][n0]);
+      xf[0] = q.x; xf[1] = q.y; xf[2] = q.z; xf[3] = q.w;
 #pragma unroll
-  for (uint32_t j = 0; j < kTpChunk; ++j) xf[j] = j < cnt ? ptr[(size_t)(n0 + j) * n] : 0.0f;
-  // the two inputs before this lane's first frame: the previous lane's last two, or the state
-  const double last1 = (double)xf[kTpChunk - 1], last2 = (double)xf[kTpChunk - 2];
-  double px1 = tp_shfl(last1, (int)lane - 1), px2 = tp_shfl(last2, (int)lane - 1);
-  if (lane == 0) { px1 = sx1; px2 = sx2; }
-  double w[kTpChunk];
-  BqAffine mine;
-  bq_affine_identity(mine);
-  {
-    double x1 = px1, x2 = px2;
+      for (uint32_t j = 0; j < kTpChunk; ++j) if (j >= cnt) xf[j] = 0.0f;
+    }
+    // the two inputs before this lane's first frame: the previous lane's last two, or the state
+    double px1 = tp_shfl((double)xf[kTpChunk - 1], (int)lane - 1), px2 = tp_shfl((double)xf[kTpChunk - 2], (int)lane - 1);
+    if (lane == 0) { px1 = sx1; px2 = sx2; }
+    double w[kTpChunk];
+    BqAffine mine;
+    bq_affine_identity(mine);
+    {
+      double x1 = px1, x2 = px2;
+#pragma unroll
+      for (uint32_t j = 0; j < kTpChunk; ++j) {
+        const double x = (double)xf[j];
+        w[j] = b0 * x + b1 * x1 + b2 * x2;
+        if (j < cnt) bq_affine_push(mine, a1, a2, w[j]);
+        x2 = x1; x1 = x;
+      }
+    }
+    BqAffine incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      BqAffine o;
+      o.m00 = tp_shfl(incl.m00, (int)lane - d); o.m01 = tp_shfl(incl.m01, (int)lane - d);
+      o.m10 = tp_shfl(incl.m10, (int)lane - d); o.m11 = tp_shfl(incl.m11, (int)lane - d);
+      o.z0 = tp_shfl(incl.z0, (int)lane - d); o.z1 = tp_shfl(incl.z1, (int)lane - d);
+      if ((int)lane >= d) bq_affine_compose(incl, o);
+    }
+    const double e1 = incl.m00 * sy1 + incl.m01 * sy2 + incl.z0, e2 = incl.m10 * sy1 + incl.m11 * sy2 + incl.z1; // (y1, y2) after this lane
+    double y1 = tp_shfl(e1, (int)lane - 1), y2 = tp_shfl(e2, (int)lane - 1);
+    if (lane == 0) { y1 = sy1; y2 = sy2; }
+    float o[kTpChunk];
 #pragma unroll
     for (uint32_t j = 0; j < kTpChunk; ++j) {
-      const double x = (double)xf[j];
-      w[j] = b0 * x + b1 * x1 + b2 * x2;
-      if (j < cnt) bq_affine_push(mine, a1, a2, w[j]);
-      x2 = x1; x1 = x;
+      o[j] = 0.0f;
+      if (j < cnt) {
+        const double y = w[j] - a1 * y1 - a2 * y2;
+        y2 = y1; y1 = y;
+        o[j] = (float)y;
+        if (wm < 1.0f) o[j] = fmaf(o[j], wm, xf[j] * (1.0f - wm));
+      }
+    }
+    if (cnt) *reinterpret_cast<float4*>(&tile.t[c][n0]) = make_float4(o[0], o[1], o[2], o[3]); // (frames past the block: never stored)
+    if (frames && lane == (frames - 1) / kTpChunk) { // x1, x2 = the block's last two inputs; y1, y2 = its last two outputs
+      const double nx1 = (double)xf[cnt - 1], nx2 = cnt >= 2 ? (double)xf[cnt - 2] : px1;
+      s_st[0][c] = nx1; s_st[1][c] = nx2; s_st[2][c] = y1; s_st[3][c] = y2;
     }
   }
-  BqAffine incl = mine;
+  __syncthreads();
+  if (threadIdx.x < lanes && frames) {
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    BqAffine o;
-    o.m00 = tp_shfl(incl.m00, (int)lane - d); o.m01 = tp_shfl(incl.m01, (int)lane - d);
-    o.m10 = tp_shfl(incl.m10, (int)lane - d); o.m11 = tp_shfl(incl.m11, (int)lane - d);
-    o.z0 = tp_shfl(incl.z0, (int)lane - d); o.z1 = tp_shfl(incl.z1, (int)lane - d);
-    if ((int)lane >= d) bq_affine_compose(incl, o);
+    for (int k = 0; k < 4; ++k) st[(size_t)k * tn + ch * n + lane0 + threadIdx.x] = s_st[k][threadIdx.x];
   }
-  const double e1 = incl.m00 * sy1 + incl.m01 * sy2 + incl.z0, e2 = incl.m10 * sy1 + incl.m11 * sy2 + incl.z1; // (y1, y2) after this lane
-  double y1 = tp_shfl(e1, (int)lane - 1), y2 = tp_shfl(e2, (int)lane - 1);
-  if (lane == 0) { y1 = sy1; y2 = sy2; }
-#pragma unroll
-  for (uint32_t j = 0; j < kTpChunk; ++j) {
-    if (j < cnt) {
-      const double y = w[j] - a1 * y1 - a2 * y2;
-      y2 = y1; y1 = y;
-      float o = (float)y;
-      if (wm < 1.0f) o = fmaf(o, wm, xf[j] * (1.0f - wm));
-      ptr[(size_t)(n0 + j) * n] = o;
-    }
-  }
-  const uint32_t last = (frames - 1) / kTpChunk;
-  if (lane == last) { // x1, x2 = the block's last two inputs; y1, y2 = its last two outputs
-    const uint32_t c = cnt; // >= 1 in this lane
-    const double nx1 = (double)xf[c - 1], nx2 = c >= 2 ? (double)xf[c - 2] : px1;
-    st[t] = nx1; st[tn + t] = nx2; st[2 * tn + t] = y1; st[3 * tn + t] = y2;
-  }
+  fx_tile_store(tile, base, n, frames, lane0, lanes);
 }
 // coef: [6][n] f64 (b0 a1 a2 per section); st: [4][2n] f64.
-__global__ __launch_bounds__(kFxTpWaves * 64) void fx_lp24_tp_kernel(
+__global__ __launch_bounds__(kFxTpThreads) void fx_lp24_tp_kernel(
     float* __restrict__ data, uint32_t n, uint32_t frames, size_t ch_stride,
     const double* __restrict__ coef, double* __restrict__ st, const float* __restrict__ wet) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kFxTpWaves + (threadIdx.x >> 6)));
-  if (t >= 2 * n) return;
-  const uint32_t ch = t / n, ln = t % n;
+  __shared__ FxTile tile;
+  __shared__ double s_coef[6][kFxTile], s_st[4][kFxTile];
+  __shared__ float s_wet[kFxTile];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, ch = blockIdx.y;
+  const uint32_t lane0 = blockIdx.x * kFxTile, lanes = min(kFxTile, n - lane0);
+  float* __restrict__ base = data + ch * ch_stride;
   const size_t tn = 2 * (size_t)n;
-  const Lp24CoefD c{coef[ln], coef[(size_t)n + ln], coef[(size_t)2 * n + ln], coef[(size_t)3 * n + ln], coef[(size_t)4 * n + ln], coef[(size_t)5 * n + ln]};
-  const double s_init[4] = {st[t], st[tn + t], st[2 * tn + t], st[3 * tn + t]};
-  const float wm = wet[ln];
-  float* __restrict__ ptr = data + ch * ch_stride + ln;
+  if (threadIdx.x < lanes) {
+    const uint32_t c = threadIdx.x, ln = lane0 + c;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s_coef[k][c] = coef[(size_t)k * n + ln];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_st[k][c] = st[(size_t)k * tn + ch * n + ln];
+    s_wet[c] = wet[ln];
+  }
+  fx_tile_load(tile, base, n, frames, lane0, lanes);
+  __syncthreads();
   const uint32_t n0 = lane * kTpChunk;
   const uint32_t cnt = n0 < frames ? (frames - n0 < kTpChunk ? frames - n0 : kTpChunk) : 0u;
-  float xf[kTpChunk];
-  Lp24Affine mine;
-  lp24_affine_identity(mine);
-#pragma unroll
-  for (uint32_t j = 0; j < kTpChunk; ++j) {
-    xf[j] = j < cnt ? ptr[(size_t)(n0 + j) * n] : 0.0f;
-    if (j < cnt) lp24_affine_push(mine, c, (double)xf[j]);
-  }
-  Lp24Affine incl = mine;
-#pragma unroll 1
-  for (int d = 1; d < 64; d <<= 1) {
-    Lp24Affine other;
-    tp_shfl_affine(incl, (int)lane - d, other);
-    if ((int)lane >= d) lp24_affine_compose(incl, other);
-  }
-  double s_end[4], sv[4];
-  lp24_affine_mul(incl, s_init, s_end, true);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { sv[i] = tp_shfl(s_end[i], (int)lane - 1); if (lane == 0) sv[i] = s_init[i]; }
-#pragma unroll
-  for (uint32_t j = 0; j < kTpChunk; ++j) {
-    if (j < cnt) {
-      float o = (float)lp24_step_v(sv, c, (double)xf[j]);
-      if (wm < 1.0f) o = fmaf(o, wm, xf[j] * (1.0f - wm));
-      ptr[(size_t)(n0 + j) * n] = o;
+  for (uint32_t c = wave; c < lanes; c += kFxTpThreads / 64) {
+    const Lp24CoefD cf{s_coef[0][c], s_coef[1][c], s_coef[2][c], s_coef[3][c], s_coef[4][c], s_coef[5][c]};
+    const double s_init[4] = {s_st[0][c], s_st[1][c], s_st[2][c], s_st[3][c]};
+    const float wm = s_wet[c];
+    float xf[kTpChunk];
+    {
+      const float4 q = *reinterpret_cast<const float4*>(&tile.t[c][n0]);
+      xf[0] = q.x; xf[1] = q.y; xf[2] = q.z; xf[3] = q.w;
     }
+    Lp24Affine mine;
+    lp24_affine_identity(mine);
+#pragma unroll
+    for (uint32_t j = 0; j < kTpChunk; ++j) if (j < cnt) lp24_affine_push(mine, cf, (double)xf[j]);
+    Lp24Affine incl = mine;
+#pragma unroll 1
+    for (int d = 1; d < 64; d <<= 1) {
+      Lp24Affine other;
+      tp_shfl_affine(incl, (int)lane - d, other);
+      if ((int)lane >= d) lp24_affine_compose(incl, other);
+    }
+    double s_end[4], sv[4];
+    lp24_affine_mul(incl, s_init, s_end, true);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sv[i] = tp_shfl(s_end[i], (int)lane - 1); if (lane == 0) sv[i] = s_init[i]; }
+    float o[kTpChunk];
+#pragma unroll
+    for (uint32_t j = 0; j < kTpChunk; ++j) {
+      o[j] = 0.0f;
+      if (j < cnt) {
+        o[j] = (float)lp24_step_v(sv, cf, (double)xf[j]);
+        if (wm < 1.0f) o[j] = fmaf(o[j], wm, xf[j] * (1.0f - wm));
+      }
+    }
+    if (cnt) *reinterpret_cast<float4*>(&tile.t[c][n0]) = make_float4(o[0], o[1], o[2], o[3]);
+    if (frames && lane == (frames - 1) / kTpChunk) { s_st[0][c] = s_end[0]; s_st[1][c] = s_end[1]; s_st[2][c] = s_end[2]; s_st[3][c] = s_end[3]; }
   }
-  if (lane == (frames - 1) / kTpChunk) { st[t] = s_end[0]; st[tn + t] = s_end[1]; st[2 * tn + t] = s_end[2]; st[3 * tn + t] = s_end[3]; }
+  __syncthreads();
+  if (threadIdx.x < lanes && frames) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) st[(size_t)k * tn + ch * n + lane0 + threadIdx.x] = s_st[k][threadIdx.x];
+  }
+  fx_tile_store(tile, base, n, frames, lane0, lanes);
 }
 
 } // namespace groove

@@ -140,7 +140,7 @@ struct groove_ctx {
   bool fork_pending[kSideStreams] = {}; // the side stream has not yet waited for ev_fork
   bool need_fork = true;                // ctx-stream work since the last fork that side streams must wait for
   uint32_t tp_max_voices = kTpMaxVoices; // Welsh banks up to this size render time-parallel (welsh_tp.h); GROOVE_TP_MAX_VOICES overrides, 0 = never
-  uint32_t fx_tp_max_lanes = 65536;      // IIR effect banks of up to this many lane-channels run time-parallel (fx_tp.h); GROOVE_FX_TP_MAX_LANES
+  uint32_t fx_tp_max_lanes = 4096;       // IIR effect banks of up to this many lane-channels (half as many for the 24 dB low-pass) run time-parallel (fx_tp.h: measured crossovers, tools/fx_bench.py); GROOVE_FX_TP_MAX_LANES
   uint32_t pipeline_min_waves = 4700;   // banks at least this long (~300,000 voices) run one kernel per base kind and pipeline their fused blocks; smaller ones take the all-kinds kernel
   int next_stream_slot = 0;             // round-robin side-stream assignment of single-kernel banks
   bool seq_allpass = false;             // GROOVE_FX_SEQ_ALLPASS=1: the sequential all-pass kernel (A/B and bit-identity tests)
@@ -1541,13 +1541,13 @@ int groove_fx_process(groove_fx* fx, groove_block* io, uint32_t frames) {
     case GROOVE_FX_BIQUAD_HSHELF12:
       // few lane-channels: one wavefront each, frames over its lanes (fx_tp.h); many: one thread each, frames serial
       if (frames <= kTpMaxFrames && 2 * (size_t)n <= ctx->fx_tp_max_lanes && ctx->tp_max_voices)
-        hipLaunchKernelGGL(fx_biquad_tp_kernel, dim3((2 * n + kFxTpWaves - 1) / kFxTpWaves), dim3(kFxTpWaves * 64), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+        hipLaunchKernelGGL(fx_biquad_tp_kernel, dim3((n + kFxTile - 1) / kFxTile, 2), dim3(kFxTpThreads), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       else
         hipLaunchKernelGGL(fx_biquad_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       break;
     case GROOVE_FX_BIQUAD_LP24:
-      if (frames <= kTpMaxFrames && 2 * (size_t)n <= ctx->fx_tp_max_lanes && ctx->tp_max_voices)
-        hipLaunchKernelGGL(fx_lp24_tp_kernel, dim3((2 * n + kFxTpWaves - 1) / kFxTpWaves), dim3(kFxTpWaves * 64), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+      if (frames <= kTpMaxFrames && 4 * (size_t)n <= ctx->fx_tp_max_lanes && ctx->tp_max_voices)
+        hipLaunchKernelGGL(fx_lp24_tp_kernel, dim3((n + kFxTile - 1) / kFxTile, 2), dim3(kFxTpThreads), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       else
         hipLaunchKernelGGL(fx_lp24_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       break;

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 def kernel_form(request, gpu_ctx):
     """The IIR effects (BiQuad family, 24 dB low-pass) have two forms: one thread per lane-channel walking the frames
     (kernels.h) and one wavefront per lane-channel with the frames over its lanes (fx_tp.h, the default for banks of up
-    to 65,536 lane-channels); every test of this module runs against both."""
+    to 4,096 lane-channels); every test of this module runs against both."""
     old = gpu_ctx.time_parallel_max_voices
     gpu_ctx.time_parallel_max_voices = 0 if request.param == "serial" else old
     yield request.param
