@@ -15,6 +15,7 @@ VoiceBankInstrument::VoiceBankInstrument(groove_ctx* ctx, groove_bank* bank, uin
       per_key_(one_voice_per_key), key_of_voice_(voices, -1), busy_until_(voices, 0), started_(voices, 0) {
   groove_block_create(ctx_, voices_, GROOVE_BLOCK_FRAMES, &block_);
   if (sum_voices_) groove_block_create(ctx_, 1, GROOVE_BLOCK_FRAMES, &summed_);
+  short_render_ = !per_key_ && voices_ <= groove_time_parallel_max_voices(ctx_); // synth banks of this size render time-parallel
 }
 VoiceBankInstrument::~VoiceBankInstrument() {
   if (summed_) groove_block_destroy(summed_);
@@ -317,6 +318,7 @@ bool Orchestrator::ahead_instruments(std::vector<Instrument*>& out) {
     if (e->is_instrument()) {
       Instrument* ins = static_cast<Instrument*>(e);
       if (!ins->supports_render_ahead()) return false;
+      if (render_ahead_ < 2 && !ins->render_ahead_pays()) return false;
       out.push_back(ins);
     }
     for (Uid s : nodes_[u].sources) stack.push_back(s);
@@ -520,7 +522,7 @@ int gh_patch_chain_to_main_mixer(void* h, const int* uids, uint32_t n) {
   return ((Orchestrator*)h)->patch_chain_to_main_mixer(v);
 }
 void gh_unpatch_all(void* h) { ((Orchestrator*)h)->unpatch_all(); }
-void gh_set_render_ahead(void* h, int on) { ((Orchestrator*)h)->set_render_ahead(on != 0); }
+void gh_set_render_ahead(void* h, int mode) { ((Orchestrator*)h)->set_render_ahead(mode); }
 int gh_connect_midi_downstream(void* h, int uid, int channel) { return ((Orchestrator*)h)->connect_midi_downstream((Uid)uid, (uint8_t)channel); }
 int gh_add_timer(void* h, double beats) { return (int)((Orchestrator*)h)->add(std::unique_ptr<Entity>(new Timer(beats))); }
 int gh_add_sequencer(void* h) { return (int)((Orchestrator*)h)->add(std::unique_ptr<Entity>(new Sequencer())); }

@@ -80,6 +80,7 @@ class Instrument : public Entity {
   // starts the NEXT block's render beside whatever the ctx stream does (groove_bank_render_async)
   // without disturbing output(); finish() makes that block the current output().
   virtual bool supports_render_ahead() const { return false; }
+  virtual bool render_ahead_pays() const { return true; }
   virtual int render_ahead(uint32_t frames) { (void)frames; return 0; }
   virtual int finish(uint32_t frames) { return tick(frames); }
 };
@@ -118,6 +119,9 @@ class VoiceBankInstrument : public Instrument {
   groove_block* output() override { return sum_voices_ ? summed_ : block_; }
   int tick(uint32_t frames) override;
   bool supports_render_ahead() const override { return true; }
+  // A bank the library renders time-parallel (one wavefront per voice: ~20 us per block) is shorter than what the
+  // side-stream hand-over costs (event packets, a cross-queue wait): render-ahead only pays for the serial forms.
+  bool render_ahead_pays() const override { return !short_render_; }
   int render_ahead(uint32_t frames) override;
   int finish(uint32_t frames) override;
   void note_on(uint8_t key, uint8_t velocity, uint64_t now_frame) override;
@@ -131,6 +135,7 @@ class VoiceBankInstrument : public Instrument {
   bool sum_voices_;
   double release_seconds_;
   bool per_key_; // Drumkit: one voice per note (A.10)
+  bool short_render_ = false;
   groove_block* block_ = nullptr;
   groove_block* block_next_ = nullptr; // render-ahead: the block being rendered while block_ is consumed
   groove_block* summed_ = nullptr;
@@ -259,7 +264,8 @@ class Orchestrator {
   void skip_to_start();
   // Offline runs render the instruments of block b+1 on the library's side streams while the effect
   // graph of block b runs (same samples; DESIGN.md "Render-ahead").  On by default; off = block by block.
-  void set_render_ahead(bool on) { render_ahead_ = on; }
+  // 0 = block by block, 1 = where it pays (default), 2 = whenever the graph allows it (tests).
+  void set_render_ahead(int mode) { render_ahead_ = mode; }
   // ControlTrip -> effect parameter.  While the controllers are run one block ahead of the effects
   // the update is held back until the effects have processed the current block.
   int control_effect(Uid target, uint32_t index, double value01);
@@ -297,7 +303,7 @@ class Orchestrator {
   uint32_t bus_frames_ = 0;
   uint64_t frames_ = 0;
   bool performing_ = false;
-  bool render_ahead_ = true;
+  int render_ahead_ = 1;
   bool ahead_primed_ = false;   // the current block's instruments were rendered by the previous tick_ahead
   bool ahead_eval_ = false;     // eval(): instruments already hold their block
   bool deferring_ = false;      // controllers are being run for the NEXT block

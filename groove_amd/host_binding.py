@@ -83,7 +83,10 @@ class Orchestrator:
         return self.L.gh_patch_chain_to_main_mixer(self.h, arr, len(uids))
 
     def unpatch_all(self): self.L.gh_unpatch_all(self.h)
-    def set_render_ahead(self, on): self.L.gh_set_render_ahead(self.h, 1 if on else 0)  # offline runs; default on
+    def set_render_ahead(self, on):
+        """Offline runs: False = block by block, True = instruments one block ahead of the effects whenever the graph allows
+        (the default, "auto", does so only for instruments whose render is long enough to be worth the hand-over)."""
+        self.L.gh_set_render_ahead(self.h, 2 if on else 0)
     def connect_midi_downstream(self, uid, channel): self._chk(self.L.gh_connect_midi_downstream(self.h, uid, channel))
     def add_timer(self, beats): return self.L.gh_add_timer(self.h, beats)
     def add_sequencer(self): return self.L.gh_add_sequencer(self.h)
