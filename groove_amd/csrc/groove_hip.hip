@@ -1022,12 +1022,14 @@ static bool use_tp(const groove_bank* b, uint32_t frames) {
   if (frames > kTpMaxFrames || b->ctx->tp_max_voices == 0) return false;
   if (b->kind == BANK_WELSH) return b->n <= b->ctx->tp_max_voices;
   if (b->kind == BANK_FM) return b->n <= kFmTpMaxVoices; // no filter scan: far cheaper per voice than a Welsh voice
+  if (b->kind == BANK_SAMPLER) return b->n <= kSamplerTpMaxVoices; // a pure gather
   return false;
 }
 static void launch_tp(groove_bank* b, uint32_t frames, bool fused, size_t chs, float* out, float* rows, hipStream_t st) {
   groove_ctx* ctx = b->ctx;
   const TpArgs a{b->d_params, b->d_state, out, rows, chs, render_consts(ctx->sr), b->n, frames};
   if (b->kind == BANK_FM) launch_fm_tp(a, st, fused);
+  else if (b->kind == BANK_SAMPLER) launch_sampler_tp(a, b->d_pcm, st, fused);
   else launch_welsh_tp(a, st, fused);
 }
 // rows of partial[][2][frames] a bank's fused render writes

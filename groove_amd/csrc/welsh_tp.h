@@ -516,8 +516,65 @@ __global__ __launch_bounds__(kTpThreads) void fm_tp_kernel(TpArgs a) {
     soa_store(a.state, n, v, s);
   }
 }
+// SamplerVoice: pointer stepping is a closed form in the frame index (idx0 + k * step, Q20.44), so a voice's block is a
+// pure gather: one wavefront per voice, 64 lanes x 4 frames, every fetch of the block in flight at once (the serial form
+// walks 256 frames in chunks of 16 fetches: 45 us for a one-wave-per-SIMD bank).  Exact, like the serial form.
+constexpr uint32_t kSamplerTpMaxVoices = 65536;
+template <bool FUSED>
+__global__ __launch_bounds__(kTpThreads) void sampler_tp_kernel(TpArgs a, const float* __restrict__ bank) {
+  __shared__ float s_tile[kTpWaves][kTpMaxFrames];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t v0 = blockIdx.x * kTpWaves + wave;
+  const bool voice = v0 < a.n;
+  const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(voice ? v0 : a.n - 1));
+  const uint32_t frames = a.frames, n = a.n;
+  const SamplerParams p = make_scalar(soa_load<SamplerParams>(a.params, n, v));
+  const SamplerState s0 = make_scalar(soa_load<SamplerState>(a.state, n, v));
+  const uint32_t n0 = lane * kTpChunk;
+  float x[kTpChunk];
+  uint32_t mine = 0; // frames of this lane that play
+#pragma unroll
+  for (uint32_t j = 0; j < kTpChunk; ++j) {
+    const uint32_t f = n0 + j;
+    const uint32_t i = (uint32_t)((s0.idx + (uint64_t)f * s0.step) >> 44);
+    const bool ok = s0.playing && f < frames && i < p.length;
+    const float raw = bank[(size_t)p.offset + (i < p.length ? i : p.length - 1)];
+    x[j] = ok ? raw * p.gain : 0.0f;
+    mine += ok ? 1u : 0u;
+  }
+  // valid frames of the block (they are a prefix: the index only moves forward)
+  uint32_t valid = mine;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) valid += (uint32_t)__shfl_xor((int)valid, off, 64);
+#pragma unroll
+  for (uint32_t j = 0; j < kTpChunk; ++j) s_tile[wave][n0 + j] = voice ? x[j] : 0.0f;
+  __syncthreads();
+  for (uint32_t t = threadIdx.x; t < frames; t += kTpThreads) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int w = 0; w < kTpWaves; ++w) acc += s_tile[w][t];
+    a.rows[((size_t)blockIdx.x * 2 + 0) * frames + t] = acc; // mono voices: the same sum on both channels
+    a.rows[((size_t)blockIdx.x * 2 + 1) * frames + t] = acc;
+  }
+  if (!FUSED && voice) {
+#pragma unroll
+    for (uint32_t j = 0; j < kTpChunk; ++j) {
+      if (n0 + j < frames) {
+        a.out[(size_t)(n0 + j) * n + v] = x[j];
+        a.out[a.ch_stride + (size_t)(n0 + j) * n + v] = x[j];
+      }
+    }
+  }
+  if (voice && lane == 0 && frames) {
+    SamplerState s = s0;
+    s.idx = s0.idx + (uint64_t)valid * s0.step;
+    if (s0.playing && valid < frames) s.playing = 0; // ran off the end inside the block
+    soa_store(a.state, n, v, s);
+  }
+}
 void launch_welsh_tp(const TpArgs& a, hipStream_t st, bool fused);
 void launch_fm_tp(const TpArgs& a, hipStream_t st, bool fused);
+void launch_sampler_tp(const TpArgs& a, const float* bank, hipStream_t st, bool fused);
 inline uint32_t welsh_tp_workgroups(uint32_t n) { return (n + kTpWaves - 1) / kTpWaves; }
 #endif // __HIPCC__
 

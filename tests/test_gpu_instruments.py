@@ -7,19 +7,24 @@ from groove_amd import patches as P, abi_types as T
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("form", ["serial", "time-parallel"])
+@pytest.fixture(autouse=True, params=["serial", "time-parallel"])
+def kernel_form(request, gpu_ctx):
+    """FM and sampler banks have two forms as well (one voice per lane, kernels.h; one wavefront per voice with the
+    block's frames over its lanes, welsh_tp.h): every test of this module runs against both."""
+    old = gpu_ctx.time_parallel_max_voices
+    gpu_ctx.time_parallel_max_voices = 0 if request.param == "serial" else old
+    yield request.param
+    gpu_ctx.time_parallel_max_voices = old
+
+
+@pytest.mark.parametrize("form", ["as-set"])
 def test_fm_per_voice_parity(gpu_ctx, oracle, form):
     """16 FM patches (beta 0.1 .. 15, through-zero FM), 60 blocks (ragged lengths), note-off at block 30, re-trigger at
     block 45; both forms of the FM render (one voice per lane, kernels.h; one wavefront per voice with the carrier
     phase as a prefix sum over its lanes, welsh_tp.h).  Tolerance: per-voice RMS <= 1e-5 vs the f64 oracle; the
     voice state of the two forms agrees bit for bit apart from the last bits of the carrier phase."""
     from groove_amd import entities as E
-    old = gpu_ctx.time_parallel_max_voices
-    gpu_ctx.time_parallel_max_voices = 0 if form == "serial" else old
-    try:
-        _fm_parity(gpu_ctx, oracle, E)
-    finally:
-        gpu_ctx.time_parallel_max_voices = old
+    _fm_parity(gpu_ctx, oracle, E)
 
 
 def _fm_parity(gpu_ctx, oracle, E):
@@ -46,8 +51,10 @@ def _fm_parity(gpu_ctx, oracle, E):
     synth.destroy(); block.destroy()
 
 
-def test_fm_forms_leave_the_same_state(gpu_ctx):
+def test_fm_forms_leave_the_same_state(gpu_ctx, kernel_form):
     from groove_amd import entities as E
+    if kernel_form == "serial":
+        pytest.skip("compares the two forms itself")
     n = 37
     params = P.fm_voices(n)
     on, off = P.note_on_all(n), P.note_off_all(n)
@@ -213,3 +220,35 @@ def test_wav_sink_quantisation(gpu_ctx, oracle):
     want = np.array([L.oracle_wav_quantise(float(v)) for v in vals], dtype=np.int16)
     assert np.array_equal(got, want)
     assert list(got[:7]) == [0, 32767, -32767, 16383, -16383, 32767, -32768]
+
+
+def test_sampler_forms_leave_the_same_state(gpu_ctx, kernel_form):
+    """Serial chunks of 16 fetches against the time-parallel gather: same samples, same voice state, bit for bit
+    (staggered note-ons, pitched and drumkit buffers, voices running off their buffers, ragged block lengths)."""
+    from groove_amd import entities as E
+    if kernel_form == "serial":
+        pytest.skip("compares the two forms itself")
+    n = 150
+    pcm, descs, _ = P.drum_bank(scale=0.05)
+    params = P.sampler_voices(n)
+    keys = P.sampler_keys(n)
+    old = gpu_ctx.time_parallel_max_voices
+    a, b = E.Sampler(gpu_ctx, pcm, descs, params), E.Sampler(gpu_ctx, pcm, descs, params)
+    block = gpu_ctx.block(n, 256)
+    try:
+        for blk in range(40):
+            voices = np.arange(n, dtype=np.uint32)[(np.arange(n) % 13) == (blk % 13)]
+            if blk < 26 and len(voices):
+                ev = T.note_events_np(voices, keys[voices], True)
+                a.handle_midi_events(ev); b.handle_midi_events(ev)
+            fr = [256, 100, 7, 1, 255][blk % 5]
+            gpu_ctx.time_parallel_max_voices = old
+            a.generate_batch_values(block, fr); xa = block.download(fr); sa = a.download_state()
+            gpu_ctx.time_parallel_max_voices = 0
+            b.generate_batch_values(block, fr); xb = block.download(fr); sb = b.download_state()
+            assert np.array_equal(xa, xb), blk
+            assert np.array_equal(sa[:5], sb[:5]), blk   # idx, step (u64 each), playing
+        assert np.abs(xa).max() >= 0.0
+    finally:
+        gpu_ctx.time_parallel_max_voices = old
+    a.destroy(); b.destroy(); block.destroy()
