@@ -128,12 +128,13 @@ def committed_profile(workload):
     """The committed rocprofv3 summary of a workload (profiles/rNN_<workload>_summary.json, or the round's
     default-command summary for welsh-1m): HBM traffic per step (FETCH_SIZE doubled per MI355X_MICROARCH.md
     §HBM) and the VALU / SALU wave-instruction counts per step of the PMC pass."""
-    import glob
-    pats = [f"r*_{workload}_summary.json"] + (["r*_summary.json"] if workload == "welsh-1m" else [])
-    files = []
-    for pat in pats:
-        files += [f for f in glob.glob(os.path.join(REPO, "profiles", pat))]
-    files = sorted(set(files), key=lambda f: (os.path.basename(f)[:3], len(os.path.basename(f))))
+    import re
+    names = os.listdir(os.path.join(REPO, "profiles")) if os.path.isdir(os.path.join(REPO, "profiles")) else []
+    rx = [re.compile(rf"^r(\d+)_{re.escape(workload)}_summary\.json$")]
+    if workload == "welsh-1m":
+        rx.append(re.compile(r"^r(\d+)_summary\.json$"))  # round 1's layout: one summary, of the default workload
+    found = sorted((int(m.group(1)), n) for n in names for r in rx for m in [r.match(n)] if m)
+    files = [os.path.join(REPO, "profiles", n) for _, n in found]
     if not files:
         return None
     try:
@@ -151,7 +152,6 @@ def committed_profile(workload):
                 valu += m.get("SQ_INSTS_VALU", 0.0)
                 salu += m.get("SQ_INSTS_SALU", 0.0)
     out["valu_per_step"], out["salu_per_step"] = (valu or None), (salu or None)
-    out["cost_model_frac"] = (d.get("valu_cost_model") or {}).get("frac")
     return out
 
 
@@ -373,7 +373,8 @@ def roofline_block(workload, n_local, kern_ms, span_mode, fused):
                      "valu_per_voice_frame": wi * 64.0 / (n_local * FRAMES) if n_local else None,
                      "spec_issue_rate": VALU_ISSUE_PER_S, "spec_issue_rate_unit": "wave64 VALU instructions/s (1,024 SIMD-32 x 2.4 GHz / 2 clk)",
                      "achieved_frac": wi / (kern_ms * 1e-3) / VALU_ISSUE_PER_S,
-                     "cost_model_frac": prof.get("cost_model_frac"),
+                     "note": "at the spec rate every instruction is a 2-cycle fp32 one; a retuning Welsh frame's mix (16 f64, 9 conversions, "
+                             "3 transcendentals of ~86) needs ~1.35x that, DESIGN.md section 5",
                      "source": prof.get("source")}
     return r
 
