@@ -120,6 +120,11 @@ struct groove_fx {
   uint32_t N = 0, w = 0, voices = 1, spacing = 0;
   bool all_wet = true; // every lane has wet == 1 (enables the split reverb path)
   ReverbGeom geo{};
+  // reverb, direct all-pass form (kernels.h): second copies of the two all-pass rings (read one, write the other, swap)
+  // and a staging block for the comb sum, allocated at first use
+  uint64_t ap_alt[2] = {0, 0};
+  float* d_tmp = nullptr;
+  uint32_t tmp_cap = 0; // frames
 };
 
 // Events that only order the library's own streams on one device: no timing, and no system-scope fence
@@ -144,6 +149,7 @@ struct groove_ctx {
   uint32_t pipeline_min_waves = 4700;   // banks at least this long (~300,000 voices) run one kernel per base kind and pipeline their fused blocks; smaller ones take the all-kinds kernel
   int next_stream_slot = 0;             // round-robin side-stream assignment of single-kernel banks
   bool seq_allpass = false;             // GROOVE_FX_SEQ_ALLPASS=1: the sequential all-pass kernel (A/B and bit-identity tests)
+  bool chunked_allpass = false;         // GROOVE_FX_CHUNKED_ALLPASS=1: the chunk-parallel all-pass kernel instead of the direct one
   uint32_t sr = GROOVE_DEFAULT_SAMPLE_RATE;
   std::string err;
   std::vector<groove_bank*> banks;
@@ -672,6 +678,7 @@ int fx_setup_state(groove_fx* fx) { // (re)allocate and zero state for the curre
         fx->geo.g[i] = (float)(i < 4 ? decay_gain_h(d, p0.reverb_seconds) : decay_gain_h(d, kAllpassDecaysH[i - 4]));
         base += fx->geo.N[i];
       }
+      for (int i = 0; i < 2; ++i) { fx->ap_alt[i] = base; base += fx->geo.N[4 + i]; }
       fx->ring_rows = base;
       break;
     }
@@ -736,6 +743,7 @@ int groove_init(int device_ordinal, groove_ctx** out) {
   if (!ctx) return fail(nullptr, "groove_init: out of memory");
   ctx->device = device_ordinal;
   if (const char* e = std::getenv("GROOVE_FX_SEQ_ALLPASS")) ctx->seq_allpass = e[0] == '1';
+  if (const char* e = std::getenv("GROOVE_FX_CHUNKED_ALLPASS")) ctx->chunked_allpass = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_TP_MAX_VOICES")) ctx->tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_TP_MAX_LANES")) ctx->fx_tp_max_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_PIPELINE_MIN_WAVES")) ctx->pipeline_min_waves = (uint32_t)std::strtoul(e, nullptr, 10); // tests force the pipeline on small banks
@@ -1494,7 +1502,7 @@ int groove_fx_destroy(groove_fx* fx) {
   auto it = std::find(ctx->fxs.begin(), ctx->fxs.end(), fx);
   if (it != ctx->fxs.end()) ctx->fxs.erase(it);
   (void)hipFree(fx->d_fa); (void)hipFree(fx->d_fb); (void)hipFree(fx->d_ua); (void)hipFree(fx->d_wet);
-  (void)hipFree(fx->d_coef); (void)hipFree(fx->d_st); (void)hipFree(fx->d_ring);
+  (void)hipFree(fx->d_coef); (void)hipFree(fx->d_st); (void)hipFree(fx->d_ring); (void)hipFree(fx->d_tmp);
   delete fx;
   return 0;
 }
@@ -1509,30 +1517,97 @@ int groove_fx_reset(groove_fx* fx) {
   for (uint32_t& w : fx->geo.w) w = 0;
   return 0;
 }
-int groove_fx_process(groove_fx* fx, groove_block* io, uint32_t frames) {
-  if (!fx || !io) return fail(nullptr, "groove_fx_process: NULL argument");
+// ---- effect stages ---------------------------------------------------------------------
+// Can this effect, for a block of `frames`, run as a stage of a fused run (kernels.h, fx_run_kernel)?  The element-wise
+// kinds always can; a delay line can when it is at least a block long (no feedback inside the block).
+static bool fx_run_capable(const groove_fx* fx, uint32_t frames) {
+  switch (fx->kind) {
+    case GROOVE_FX_GAIN: case GROOVE_FX_BITCRUSHER: case GROOVE_FX_LIMITER: case GROOVE_FX_COMPRESSOR: return true;
+    case GROOVE_FX_DELAY: return fx->N >= frames;
+    case GROOVE_FX_CHORUS: {
+      const uint32_t nearest = fx->N - (fx->voices - 1) * fx->spacing; // newest tap: pushed this many frames ago
+      return nearest >= frames && (fx->voices == 1 || fx->spacing >= frames);
+    }
+    case GROOVE_FX_REVERB: { // combs in the run, the two all-passes behind it
+      uint32_t shortest_comb = fx->geo.N[0];
+      for (int i = 1; i < 4; ++i) shortest_comb = std::min(shortest_comb, fx->geo.N[i]);
+      return fx->all_wet && shortest_comb >= frames && std::min(fx->geo.N[4], fx->geo.N[5]) >= 32;
+    }
+    default: return false;
+  }
+}
+static void fx_advance(groove_fx* fx, uint32_t frames) { // the delay lines' write positions after a block
+  if (fx->kind == GROOVE_FX_DELAY || fx->kind == GROOVE_FX_CHORUS) fx->w = (uint32_t)(((uint64_t)fx->w + frames) % fx->N);
+  if (fx->kind == GROOVE_FX_REVERB)
+    for (int i = 0; i < 6; ++i) fx->geo.w[i] = (uint32_t)(((uint64_t)fx->geo.w[i] + frames) % fx->geo.N[i]);
+}
+// One launch for `count` (<= kRunMaxStages) run-capable stages in chain order; a reverb, if there is one, is the last,
+// and its all-passes follow.
+static int fx_launch_run(groove_ctx* ctx, groove_fx* const* run, uint32_t count, groove_block* io, uint32_t frames) {
+  const uint32_t n = io->n;
+  const size_t chs = (size_t)io->cap * n;
+  FxRunArgs a{};
+  for (uint32_t s = 0; s < count; ++s) {
+    const groove_fx* fx = run[s];
+    a.st[s] = FxRunStage{fx->kind, fx->N, fx->w, fx->voices, fx->spacing, 0, fx->d_ring, fx->d_fa, fx->d_fb, fx->d_ua, fx->d_wet};
+  }
+  a.n_stages = count; a.n = n;
+  a.src = io->d; a.src_chs = chs;
+  a.dst = io->d; a.dst_chs = chs;
+  groove_fx* rv = run[count - 1]->kind == GROOVE_FX_REVERB ? run[count - 1] : nullptr;
+  bool direct = false;
+  if (rv) {
+    a.geo = rv->geo;
+    // the direct all-pass form wants the comb sum in a staging block (it reads other frames than the one it writes)
+    const uint32_t shortest_ap = std::min(rv->geo.N[4], rv->geo.N[5]);
+    direct = !ctx->seq_allpass && !ctx->chunked_allpass && frames <= 8 * shortest_ap && (size_t)2 * io->cap * n * 4 <= ((size_t)1 << 30);
+    if (direct) {
+      if (rv->tmp_cap < io->cap) {
+        GHIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (rv->d_tmp) { GHIP(ctx, hipFree(rv->d_tmp)); rv->d_tmp = nullptr; rv->tmp_cap = 0; }
+        GHIP(ctx, hipMalloc(&rv->d_tmp, (size_t)2 * io->cap * n * 4));
+        rv->tmp_cap = io->cap;
+      }
+      a.dst = rv->d_tmp; a.dst_chs = (size_t)rv->tmp_cap * n;
+    }
+  }
+  const dim3 blk(kThreads);
+  if (n % 4 == 0) hipLaunchKernelGGL(fx_run_kernel<4>, dim3(blocks_for(2 * (size_t)n / 4), frames), blk, 0, ctx->stream, a);
+  else hipLaunchKernelGGL(fx_run_kernel<1>, dim3(blocks_for(2 * (size_t)n), frames), blk, 0, ctx->stream, a);
+  if (rv) {
+    const ReverbGeom& g = rv->geo;
+    if (direct) {
+      AllpassDirectArgs d{};
+      d.src = rv->d_tmp; d.src_chs = (size_t)rv->tmp_cap * n;
+      d.dst = io->d; d.dst_chs = chs;
+      d.ring = rv->d_ring;
+      for (int i = 0; i < 2; ++i) {
+        d.old_base[i] = g.base[4 + i]; d.new_base[i] = rv->ap_alt[i];
+        d.N[i] = g.N[4 + i]; d.w[i] = g.w[4 + i]; d.g[i] = g.g[4 + i];
+      }
+      d.n = n; d.frames = frames;
+      const uint32_t rows = std::max(frames, std::max(g.N[4], g.N[5]));
+      if (n % 4 == 0) hipLaunchKernelGGL(fx_reverb_allpass_direct_kernel<4>, dim3(blocks_for(2 * (size_t)n / 4), rows), blk, 0, ctx->stream, d);
+      else hipLaunchKernelGGL(fx_reverb_allpass_direct_kernel<1>, dim3(blocks_for(2 * (size_t)n), rows), blk, 0, ctx->stream, d);
+      for (int i = 0; i < 2; ++i) std::swap(rv->geo.base[4 + i], rv->ap_alt[i]);
+    } else if (ctx->seq_allpass) {
+      hipLaunchKernelGGL(fx_reverb_allpass_kernel<32>, dim3(blocks_for(2 * (size_t)n)), blk, 0, ctx->stream, io->d, n, frames, chs, rv->d_ring, g);
+    } else { // chunks of one line length, parallel inside (kernels.h)
+      const uint32_t T = std::max<uint32_t>(1, std::min<uint32_t>(64, 2 * n / 512));
+      hipLaunchKernelGGL(fx_reverb_allpass_chunked_kernel, dim3((2 * n + T - 1) / T), dim3(kAllpassThreads), 0, ctx->stream, io->d, n, frames, chs, rv->d_ring, g, T);
+    }
+  }
+  for (uint32_t s = 0; s < count; ++s) fx_advance(run[s], frames);
+  GHIP(ctx, hipGetLastError());
+  return 0;
+}
+// The kinds with feedback inside a block: the IIR filters, and delay lines shorter than the block.
+static int fx_launch_serial(groove_fx* fx, groove_block* io, uint32_t frames) {
   groove_ctx* ctx = fx->ctx;
-  if (io->n != fx->n) return fail(ctx, "groove_fx_process: block lanes != effect lanes");
-  if (frames > io->cap) return fail(ctx, "groove_fx_process: frames > block capacity");
-  if (frames == 0) return 0;
-  GHIP(ctx, hipSetDevice(ctx->device));
-  if (block_acquire(io)) return 1;
-  if (fx->kind != GROOVE_FX_MIXER) io->sums_valid = false; // the block is transformed in place
   const uint32_t n = fx->n;
   const size_t chs = (size_t)io->cap * n;
   const dim3 blk(kThreads), lanes_grid(blocks_for(2 * (size_t)n));
   switch (fx->kind) {
-    case GROOVE_FX_MIXER: return 0; // identity
-    case GROOVE_FX_GAIN:
-    case GROOVE_FX_BITCRUSHER:
-    case GROOVE_FX_LIMITER:
-    case GROOVE_FX_COMPRESSOR: {
-      const size_t total = (size_t)2 * frames * n;
-      const uint32_t g = (uint32_t)std::min<size_t>(blocks_for(total), 256 * 16);
-      hipLaunchKernelGGL(fx_elementwise_kernel, dim3(g), blk, 0, ctx->stream, fx->kind, io->d, n, frames, chs,
-                         fx->d_fa, fx->d_fb, fx->d_ua, fx->d_wet);
-      break;
-    }
     case GROOVE_FX_BIQUAD_LP12:
     case GROOVE_FX_BIQUAD_HP12:
     case GROOVE_FX_BIQUAD_BP12:
@@ -1554,47 +1629,69 @@ int groove_fx_process(groove_fx* fx, groove_block* io, uint32_t frames) {
         hipLaunchKernelGGL(fx_lp24_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       break;
     case GROOVE_FX_DELAY:
-      if (fx->N >= frames) // no feedback inside the block: fully parallel over (frame, lane)
-        hipLaunchKernelGGL(fx_delay_par_kernel, dim3(lanes_grid.x, frames), blk, 0, ctx->stream, io->d, n, chs, fx->d_ring, fx->N, fx->w, fx->d_wet);
-      else if (fx->N >= 16) // chunked loads need every read of a chunk to precede its writes: N >= chunk
+      if (fx->N >= 16) // chunked loads need every read of a chunk to precede its writes: N >= chunk
         hipLaunchKernelGGL(fx_delay_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->N, fx->w, fx->d_wet);
       else hipLaunchKernelGGL(fx_delay_kernel<1>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->N, fx->w, fx->d_wet);
-      fx->w = (uint32_t)(((uint64_t)fx->w + frames) % fx->N);
       break;
     case GROOVE_FX_CHORUS: {
-      const uint32_t nearest = fx->N - (fx->voices - 1) * fx->spacing; // newest tap: pushed this many frames ago
-      if (nearest >= frames && (fx->voices == 1 || fx->spacing >= frames))
-        hipLaunchKernelGGL(fx_chorus_par_kernel, dim3(lanes_grid.x, frames), blk, 0, ctx->stream, io->d, n, chs, fx->d_ring, fx->N, fx->w, fx->voices, fx->spacing, fx->d_wet);
-      else if (nearest >= 16 && (fx->voices == 1 || fx->spacing >= 16))
+      const uint32_t nearest = fx->N - (fx->voices - 1) * fx->spacing;
+      if (nearest >= 16 && (fx->voices == 1 || fx->spacing >= 16))
         hipLaunchKernelGGL(fx_chorus_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->N, fx->w, fx->voices, fx->spacing, fx->d_wet);
       else hipLaunchKernelGGL(fx_chorus_kernel<1>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->N, fx->w, fx->voices, fx->spacing, fx->d_wet);
-      fx->w = (uint32_t)(((uint64_t)fx->w + frames) % fx->N);
       break;
     }
     case GROOVE_FX_REVERB: {
-      uint32_t shortest = fx->geo.N[0], shortest_comb = fx->geo.N[0];
+      uint32_t shortest = fx->geo.N[0];
       for (int i = 1; i < 6; ++i) shortest = std::min(shortest, fx->geo.N[i]);
-      for (int i = 1; i < 4; ++i) shortest_comb = std::min(shortest_comb, fx->geo.N[i]);
-      const uint32_t shortest_ap = std::min(fx->geo.N[4], fx->geo.N[5]);
-      if (fx->all_wet && shortest_comb >= frames && shortest_ap >= 32) {
-        // combs: parallel over (frame, lane); all-passes: parallel inside chunks of one line length
-        hipLaunchKernelGGL(fx_reverb_combs_par_kernel, dim3(lanes_grid.x, frames), blk, 0, ctx->stream, io->d, n, chs, fx->d_ring, fx->geo, fx->d_fa);
-        if (ctx->seq_allpass) {
-          hipLaunchKernelGGL(fx_reverb_allpass_kernel<32>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->geo);
-        } else { // chunks of one line length, parallel inside (kernels.h)
-          const uint32_t T = std::max<uint32_t>(1, std::min<uint32_t>(64, 2 * n / 512));
-          hipLaunchKernelGGL(fx_reverb_allpass_chunked_kernel, dim3((2 * n + T - 1) / T), dim3(kAllpassThreads), 0, ctx->stream, io->d, n, frames, chs,
-                             fx->d_ring, fx->geo, T);
-        }
-      } else if (shortest >= 8) hipLaunchKernelGGL(fx_reverb_kernel<8>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->geo, fx->d_fa, fx->d_wet);
+      if (shortest >= 8) hipLaunchKernelGGL(fx_reverb_kernel<8>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->geo, fx->d_fa, fx->d_wet);
       else hipLaunchKernelGGL(fx_reverb_kernel<1>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->geo, fx->d_fa, fx->d_wet);
-      for (int i = 0; i < 6; ++i) fx->geo.w[i] = (uint32_t)(((uint64_t)fx->geo.w[i] + frames) % fx->geo.N[i]);
       break;
     }
     default: return fail(ctx, "groove_fx_process: unknown kind");
   }
+  fx_advance(fx, frames);
   GHIP(ctx, hipGetLastError());
   return 0;
+}
+int groove_fx_chain_process(groove_fx* const* chain, uint32_t n_fx, groove_block* io, uint32_t frames) {
+  if (!io || (n_fx && !chain)) return fail(nullptr, "groove_fx_chain_process: NULL argument");
+  groove_ctx* ctx = io->ctx;
+  for (uint32_t i = 0; i < n_fx; ++i) {
+    if (!chain[i]) return fail(ctx, "groove_fx_chain_process: NULL effect");
+    if (chain[i]->ctx != ctx) return fail(ctx, "groove_fx_chain_process: effect and block belong to different contexts");
+    if (chain[i]->n != io->n) return fail(ctx, "groove_fx_chain_process: block lanes != effect lanes");
+    for (uint32_t j = 0; j < i; ++j)
+      if (chain[j] == chain[i]) return fail(ctx, "groove_fx_chain_process: the same effect twice in one chain");
+  }
+  if (frames > io->cap) return fail(ctx, "groove_fx_chain_process: frames > block capacity");
+  if (frames == 0 || n_fx == 0) return 0;
+  GHIP(ctx, hipSetDevice(ctx->device));
+  if (block_acquire(io)) return 1;
+  groove_fx* run[kRunMaxStages];
+  uint32_t count = 0;
+  auto flush = [&]() -> int {
+    if (!count) return 0;
+    const int rc = fx_launch_run(ctx, run, count, io, frames);
+    count = 0;
+    return rc;
+  };
+  for (uint32_t i = 0; i < n_fx; ++i) {
+    groove_fx* fx = chain[i];
+    if (fx->kind == GROOVE_FX_MIXER) continue; // identity
+    io->sums_valid = false; // the block is transformed in place
+    if (fx_run_capable(fx, frames)) {
+      run[count++] = fx;
+      if (count == kRunMaxStages || fx->kind == GROOVE_FX_REVERB) { if (flush()) return 1; }
+    } else {
+      if (flush()) return 1;
+      if (fx_launch_serial(fx, io, frames)) return 1;
+    }
+  }
+  return flush();
+}
+int groove_fx_process(groove_fx* fx, groove_block* io, uint32_t frames) {
+  if (!fx || !io) return fail(nullptr, "groove_fx_process: NULL argument");
+  return groove_fx_chain_process(&fx, 1, io, frames);
 }
 int groove_fx_set_params(groove_fx* fx, const groove_fx_params* p, uint32_t n) {
   if (!fx || !p) return fail(nullptr, "groove_fx_set_params: NULL argument");

@@ -977,64 +977,109 @@ __global__ __launch_bounds__(kThreads) void fx_reverb_kernel(
 // the block reads a ring slot written in an earlier block and writes a slot nobody else in the
 // block touches.  Then the effect is a pure gather/scatter over (frame, lane) and runs as one
 // fully parallel, HBM-bound launch: grid = (ceil(2n / 256), frames).
-__global__ __launch_bounds__(kThreads) void fx_delay_par_kernel(
-    float* __restrict__ data, uint32_t n, size_t ch_stride, float* __restrict__ ring, uint32_t N, uint32_t w0,
-    const float* __restrict__ wet) {
-  const uint32_t t = blockIdx.x * kThreads + threadIdx.x, f = blockIdx.y;
-  if (t >= 2 * n) return;
-  const uint32_t ch = t / n, lane = t % n;
-  uint32_t p = w0 + f; if (p >= N) p -= N;
-  float* px = data + ch * ch_stride + (size_t)f * n + lane;
-  float* pr = ring + (size_t)p * (2 * (size_t)n) + t;
-  const float x = *px;
-  float y = *pr;
-  *pr = x;
-  const float wm = wet[lane];
-  if (wm < 1.0f) y = fmaf(y, wm, x * (1.0f - wm));
-  *px = y;
-}
-__global__ __launch_bounds__(kThreads) void fx_chorus_par_kernel(
-    float* __restrict__ data, uint32_t n, size_t ch_stride, float* __restrict__ ring, uint32_t N, uint32_t w0,
-    uint32_t voices, uint32_t spacing, const float* __restrict__ wet) {
-  const uint32_t t = blockIdx.x * kThreads + threadIdx.x, f = blockIdx.y;
-  if (t >= 2 * n) return;
-  const uint32_t ch = t / n, lane = t % n;
-  const size_t ln = 2 * (size_t)n;
-  uint32_t p = w0 + f; if (p >= N) p -= N;
-  float* px = data + ch * ch_stride + (size_t)f * n + lane;
-  const float x = *px;
-  float sum = 0.0f;
-  uint32_t tp = p;
-  for (uint32_t k = 0; k < voices; ++k) {
-    sum += ring[(size_t)tp * ln + t];
-    tp += spacing; if (tp >= N) tp -= N;
-  }
-  ring[(size_t)p * ln + t] = x;
-  const float wm = wet[lane];
-  if (wm < 1.0f) sum = fmaf(sum, wm, x * (1.0f - wm));
-  *px = sum;
-}
-// Reverb, stage 1: the four recirculating combs (all at least one block long) in parallel over
-// (frame, lane); the comb sum replaces the block contents (only used when every lane is fully wet).
-__global__ __launch_bounds__(kThreads) void fx_reverb_combs_par_kernel(
-    float* __restrict__ data, uint32_t n, size_t ch_stride, float* __restrict__ ring, ReverbGeom geo,
-    const float* __restrict__ atten) {
-  const uint32_t t = blockIdx.x * kThreads + threadIdx.x, f = blockIdx.y;
-  if (t >= 2 * n) return;
-  const uint32_t ch = t / n, lane = t % n;
-  const size_t ln = 2 * (size_t)n;
-  float* px = data + ch * ch_stride + (size_t)f * n + lane;
-  const float in = *px * atten[lane];
-  float sum = 0.0f;
+// A RUN of such stages — and of the element-wise kinds, which never had feedback — is one launch: the stages of a
+// chain that follow each other (config #3: chorus -> delay -> reverb combs) are applied to the element in registers,
+// one after the other, exactly as the per-stage kernels would (same operations in the same order: same bits), and the
+// block is read and written once instead of once per stage.  A thread owns V adjacent lane-channels of one frame
+// (V = 4 when the lane count allows 16-byte accesses).  A reverb ends its run: its comb sum goes to `dst` (the
+// reverb's staging block when the direct all-pass kernel follows, the block itself otherwise).
+template <int V> struct VecF { float v[V]; };
+template <int V> __device__ __forceinline__ VecF<V> vload(const float* p) {
+  VecF<V> r;
+  if constexpr (V == 4) { const float4 q = *reinterpret_cast<const float4*>(p); r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; r.v[3] = q.w; }
+  else {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    uint32_t p = geo.w[i] + f; if (p >= geo.N[i]) p -= geo.N[i];
-    float* r = ring + (geo.base[i] + p) * ln + t;
-    const float out = geo.g[i] * *r;
-    *r = in + out;
-    sum += out;
+    for (int j = 0; j < V; ++j) r.v[j] = p[j];
   }
-  *px = sum;
+  return r;
+}
+template <int V> __device__ __forceinline__ void vstore(float* p, const VecF<V>& x) {
+  if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
+  else {
+#pragma unroll
+    for (int j = 0; j < V; ++j) p[j] = x.v[j];
+  }
+}
+constexpr int kRunMaxStages = 4;
+struct FxRunStage {
+  uint32_t kind, N, w, voices, spacing, pad;
+  float* ring;
+  const float* fa;
+  const float* fb;
+  const uint32_t* ua;
+  const float* wet;
+};
+struct FxRunArgs {
+  FxRunStage st[kRunMaxStages];
+  ReverbGeom geo;       // of the reverb that ends the run, if one does
+  const float* src;
+  float* dst;
+  size_t src_chs, dst_chs;
+  uint32_t n_stages, n;
+};
+template <int V>
+__global__ __launch_bounds__(kThreads) void fx_run_kernel(FxRunArgs a) {
+  const uint32_t t = (blockIdx.x * kThreads + threadIdx.x) * V, f = blockIdx.y;
+  if (t >= 2 * a.n) return;
+  const uint32_t ch = t / a.n, lane = t % a.n;
+  const size_t ln = 2 * (size_t)a.n;
+  VecF<V> x = vload<V>(a.src + ch * a.src_chs + (size_t)f * a.n + lane);
+#pragma unroll
+  for (int s = 0; s < kRunMaxStages; ++s) {
+    if ((uint32_t)s >= a.n_stages) break;
+    const FxRunStage& st = a.st[s];
+    VecF<V> y;
+    if (st.kind == GROOVE_FX_REVERB) { // the four combs; only taken when every lane is fully wet
+      const VecF<V> att = vload<V>(st.fa + lane);
+      VecF<V> in;
+#pragma unroll
+      for (int j = 0; j < V; ++j) { in.v[j] = x.v[j] * att.v[j]; y.v[j] = 0.0f; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint32_t p = a.geo.w[i] + f; if (p >= a.geo.N[i]) p -= a.geo.N[i];
+        float* r = st.ring + (a.geo.base[i] + p) * ln + t;
+        VecF<V> d = vload<V>(r);
+#pragma unroll
+        for (int j = 0; j < V; ++j) { const float out = a.geo.g[i] * d.v[j]; d.v[j] = in.v[j] + out; y.v[j] += out; }
+        vstore<V>(r, d);
+      }
+      x = y;
+      continue;
+    }
+    if (st.kind == GROOVE_FX_DELAY) {
+      uint32_t p = st.w + f; if (p >= st.N) p -= st.N;
+      float* pr = st.ring + (size_t)p * ln + t;
+      y = vload<V>(pr);
+      vstore<V>(pr, x);
+    } else if (st.kind == GROOVE_FX_CHORUS) {
+      uint32_t p = st.w + f; if (p >= st.N) p -= st.N;
+#pragma unroll
+      for (int j = 0; j < V; ++j) y.v[j] = 0.0f;
+      uint32_t tp = p;
+      for (uint32_t k = 0; k < st.voices; ++k) {
+        const VecF<V> d = vload<V>(st.ring + (size_t)tp * ln + t);
+#pragma unroll
+        for (int j = 0; j < V; ++j) y.v[j] += d.v[j];
+        tp += st.spacing; if (tp >= st.N) tp -= st.N;
+      }
+      vstore<V>(st.ring + (size_t)p * ln + t, x);
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        switch (st.kind) {
+          case GROOVE_FX_GAIN: y.v[j] = x.v[j] * st.fa[lane + j]; break;
+          case GROOVE_FX_BITCRUSHER: y.v[j] = bitcrush(x.v[j], st.ua[lane + j]); break;
+          case GROOVE_FX_LIMITER: y.v[j] = limiter(x.v[j], st.fa[lane + j], st.fb[lane + j]); break;
+          case GROOVE_FX_COMPRESSOR: y.v[j] = compressor(x.v[j], st.fa[lane + j], st.fb[lane + j]); break;
+          default: y.v[j] = x.v[j]; break;
+        }
+      }
+    }
+    const VecF<V> wm = vload<V>(st.wet + lane);
+#pragma unroll
+    for (int j = 0; j < V; ++j) x.v[j] = wm.v[j] < 1.0f ? fmaf(y.v[j], wm.v[j], x.v[j] * (1.0f - wm.v[j])) : y.v[j];
+  }
+  vstore<V>(a.dst + ch * a.dst_chs + (size_t)f * a.n + lane, x);
 }
 // Reverb, stage 2: the two short Schroeder all-passes (5 ms, 1.7 ms: shorter than a block, so
 // sequential per lane), chunked like the other delay-line kernels.
@@ -1128,6 +1173,68 @@ __global__ __launch_bounds__(kAllpassThreads) void fx_reverb_allpass_chunked_ker
       __syncthreads();
     }
   }
+}
+
+
+// The two all-passes with no sequential step at all.  v[f] = x[f] + g v[f - N] unrolls, inside one block, into at most
+// ceil(frames / N) terms that end at a ring slot written by an EARLIER block:
+//     u <- ring_old[(w + f) mod N];  for j = hops-1 .. 0:  d <- u,  u <- fma(g, d, x[f - j N]);   v[f] = u,  out[f] = fma(-g, u, d)
+// which is the sequential kernel's chain of operations for that frame, evaluated from its oldest term: same bits.  The
+// second all-pass takes the first one's output at f, f - N2, f - 2 N2 ... and evaluates each of those the same way
+// (<= 4 x 2 input reads for 1.7 ms / 5 ms lines and 256 frames, almost all L2 hits: neighbouring frames read the same
+// rows).  Every (frame, lane-channel) is independent, so the launch is (lane-channels / V) x frames threads and one
+// memory round trip deep, against 2 + 4 dependent chunk passes.  Reads and writes must not alias: the input comes from
+// a staging block `src` (the comb sum), the result goes to the block, and the rings are double-buffered (`old_base`
+// read, `new_base` written; rows of a ring that this block does not rewrite are copied over by the rows of the grid
+// beyond `frames`).  The host swaps the bases afterwards.
+struct AllpassDirectArgs {
+  const float* src;
+  float* dst;
+  float* ring;
+  size_t src_chs, dst_chs;
+  uint64_t old_base[2], new_base[2];
+  uint32_t N[2], w[2];
+  float g[2];
+  uint32_t n, frames;
+};
+template <int V>
+__global__ __launch_bounds__(kThreads) void fx_reverb_allpass_direct_kernel(AllpassDirectArgs a) {
+  const uint32_t t = (blockIdx.x * kThreads + threadIdx.x) * V, f = blockIdx.y;
+  if (t >= 2 * a.n) return;
+  const uint32_t ch = t / a.n, lane = t % a.n;
+  const size_t ln = 2 * (size_t)a.n;
+  if (f >= a.frames) { // ring rows this block leaves as they are
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (f < a.N[i]) {
+        const uint32_t slot = (a.w[i] + f) % a.N[i];
+        vstore<V>(a.ring + (a.new_base[i] + slot) * ln + t, vload<V>(a.ring + (a.old_base[i] + slot) * ln + t));
+      }
+    return;
+  }
+  const float* __restrict__ x = a.src + ch * a.src_chs + lane;
+  const uint32_t slot1 = (a.w[1] + f) % a.N[1];
+  VecF<V> u = vload<V>(a.ring + (a.old_base[1] + slot1) * ln + t), d = u, v0;
+  for (int j = (int)(f / a.N[1]); j >= 0; --j) {
+    const uint32_t np = f - (uint32_t)j * a.N[1]; // the first all-pass, at frame np
+    VecF<V> ua = vload<V>(a.ring + (a.old_base[0] + (a.w[0] + np) % a.N[0]) * ln + t), da = ua;
+    for (int i = (int)(np / a.N[0]); i >= 0; --i) {
+      const VecF<V> xin = vload<V>(x + (size_t)(np - (uint32_t)i * a.N[0]) * a.n);
+      da = ua;
+#pragma unroll
+      for (int k = 0; k < V; ++k) ua.v[k] = fmaf(a.g[0], da.v[k], xin.v[k]);
+    }
+    if (j == 0) v0 = ua;
+    d = u;
+#pragma unroll
+    for (int k = 0; k < V; ++k) u.v[k] = fmaf(a.g[1], d.v[k], fmaf(-a.g[0], ua.v[k], da.v[k]));
+  }
+  VecF<V> out;
+#pragma unroll
+  for (int k = 0; k < V; ++k) out.v[k] = fmaf(-a.g[1], u.v[k], d.v[k]);
+  vstore<V>(a.dst + ch * a.dst_chs + (size_t)f * a.n + lane, out);
+  if (f + a.N[0] >= a.frames) vstore<V>(a.ring + (a.new_base[0] + (a.w[0] + f) % a.N[0]) * ln + t, v0);
+  if (f + a.N[1] >= a.frames) vstore<V>(a.ring + (a.new_base[1] + slot1) * ln + t, u);
 }
 
 #endif // GROOVE_WELSH_CLASS_TU

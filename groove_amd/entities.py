@@ -74,6 +74,12 @@ class Context:
         arr = (C.c_void_p * len(blocks))(*[b.h for b in blocks])
         _lib.check(self.L.groove_mix(self.h, arr, len(blocks), frames, bus.ptr, 1 if accumulate else 0), self.h)
 
+    # the effects patched behind one instrument, in patch order, over one block (same bits as one transform_audio each)
+    def transform_chain(self, effects, block, frames=None):
+        frames = block.cap if frames is None else frames
+        arr = (C.c_void_p * len(effects))(*[e.h for e in effects])
+        _lib.check(self.L.groove_fx_chain_process(arr, len(effects), block.h, frames), self.h)
+
     # multi-GPU
     def comm_unique_id(self):
         buf = (C.c_uint8 * 128)()

@@ -209,6 +209,7 @@ int Orchestrator::patch(Uid source, Uid sink) {
   if (!(out->is_instrument() || out->is_effect())) return fail("Output device doesn't output audio and can't be patched into input device");
   if (source == sink) return fail("can't patch a device into itself");
   nodes_[sink].sources.push_back(source);
+  fanout_valid_ = false;
   return 0;
 }
 int Orchestrator::patch_chain_to_main_mixer(const std::vector<Uid>& uids) {
@@ -216,7 +217,7 @@ int Orchestrator::patch_chain_to_main_mixer(const std::vector<Uid>& uids) {
   if (!uids.empty()) return patch(uids.back(), kMainMixerUid);
   return 0;
 }
-void Orchestrator::unpatch_all() { for (auto& n : nodes_) n.sources.clear(); }
+void Orchestrator::unpatch_all() { for (auto& n : nodes_) n.sources.clear(); fanout_valid_ = false; }
 int Orchestrator::connect_midi_downstream(Uid receiver, uint8_t channel) {
   Entity* e = get(receiver);
   if (!e || !e->is_instrument()) return fail("MIDI receiver is not an instrument");
@@ -233,8 +234,7 @@ int Orchestrator::ensure_accum(Node& n, uint32_t lanes) {
 }
 // Post-order evaluation of one node for one block (the per-frame DFS of gather_audio, run per block).
 int Orchestrator::eval(Uid uid, uint32_t frames, groove_block** out_block, uint32_t* out_lanes) {
-  Node& n = nodes_[uid];
-  Entity* e = n.entity.get();
+  Entity* e = nodes_[uid].entity.get();
   if (e->is_instrument()) {
     Instrument* ins = static_cast<Instrument*>(e);
     if (!ahead_eval_ && ins->tick(frames)) return fail(groove_last_error(ctx_));
@@ -245,24 +245,76 @@ int Orchestrator::eval(Uid uid, uint32_t frames, groove_block** out_block, uint3
   if (!e->is_effect()) { *out_block = nullptr; *out_lanes = 0; return 0; }
   Effect* fx = static_cast<Effect*>(e);
   const uint32_t lanes = fx->lanes();
-  if (ensure_accum(n, lanes)) return 1;
-  bool first = true;
-  for (Uid s : n.sources) {
+  // A run of library effects patched one into the next, each heard by nobody else, is what the reference's walk applies
+  // one after the other to the same signal: collect it (this node is its LAST stage) and hand it to the library as one
+  // chain (groove_fx_chain_process: same bits as stage by stage, fewer passes over the block, and no copy from one
+  // effect's block into the next one's).
+  std::vector<groove_fx*> chain;
+  Uid head = uid; // the chain's first stage: the one whose sources are summed
+  if (fx->library_fx()) {
+    chain.push_back(fx->library_fx());
+    while (nodes_[head].sources.size() == 1) {
+      const Uid s = nodes_[head].sources[0];
+      Entity* se = nodes_[s].entity.get();
+      if (!se || !se->is_effect() || fanout(s) != 1) break;
+      Effect* sfx = static_cast<Effect*>(se);
+      if (!sfx->library_fx() || sfx->lanes() != lanes) break;
+      chain.push_back(sfx->library_fx());
+      head = s;
+    }
+    std::reverse(chain.begin(), chain.end());
+  }
+  const std::vector<Uid>& sources = nodes_[head].sources;
+  groove_block* io = nullptr;
+  bool evaluated = false;
+  if (!chain.empty() && sources.size() == 1 && fanout(sources[0]) == 1) {
+    // one source that only this chain hears: lane for lane, its block is transformed where it lies
     groove_block* sb = nullptr;
     uint32_t sl = 0;
-    if (eval(s, frames, &sb, &sl)) return 1;
-    if (!sb) continue;
-    if (sl != lanes && lanes != 1) return fail("patch: source and sink lane counts differ");
-    if (groove_block_accumulate(n.accum, sb, frames, first ? 0 : 1)) return fail(groove_last_error(ctx_));
-    first = false;
+    if (eval(sources[0], frames, &sb, &sl)) return 1;
+    evaluated = true;
+    Entity* se = nodes_[sources[0]].entity.get();
+    const bool in_place = sl == lanes && !(se->is_instrument() && !static_cast<Instrument*>(se)->output_is_scratch());
+    if (sb && in_place) io = sb;
+    else if (sb) {
+      if (sl != lanes && lanes != 1) return fail("patch: source and sink lane counts differ");
+      if (ensure_accum(nodes_[uid], lanes)) return 1;
+      if (groove_block_accumulate(nodes_[uid].accum, sb, frames, 0)) return fail(groove_last_error(ctx_));
+      io = nodes_[uid].accum;
+    }
   }
-  if (first) { // an effect at the end of a chain with no input: silence in, so silence out
-    if (groove_block_zero(n.accum)) return fail(groove_last_error(ctx_));
+  if (!io) {
+    if (ensure_accum(nodes_[uid], lanes)) return 1;
+    bool first = true;
+    for (size_t i = 0; !evaluated && i < sources.size(); ++i) {
+      groove_block* sb = nullptr;
+      uint32_t sl = 0;
+      if (eval(sources[i], frames, &sb, &sl)) return 1;
+      if (!sb) continue;
+      if (sl != lanes && lanes != 1) return fail("patch: source and sink lane counts differ");
+      if (groove_block_accumulate(nodes_[uid].accum, sb, frames, first ? 0 : 1)) return fail(groove_last_error(ctx_));
+      first = false;
+    }
+    if (first) { // an effect at the end of a chain with no input: silence in, so silence out
+      if (groove_block_zero(nodes_[uid].accum)) return fail(groove_last_error(ctx_));
+    }
+    io = nodes_[uid].accum;
   }
-  if (fx->transform_audio(n.accum, frames)) return fail(groove_last_error(ctx_));
-  *out_block = n.accum;
+  if (chain.empty()) {
+    if (fx->transform_audio(io, frames)) return fail(groove_last_error(ctx_));
+  } else if (groove_fx_chain_process(chain.data(), (uint32_t)chain.size(), io, frames)) return fail(groove_last_error(ctx_));
+  *out_block = io;
   *out_lanes = lanes;
   return 0;
+}
+uint32_t Orchestrator::fanout(Uid uid) {
+  if (!fanout_valid_) {
+    fanout_.assign(nodes_.size(), 0);
+    for (const Node& n : nodes_)
+      for (Uid s : n.sources) fanout_[s]++;
+    fanout_valid_ = true;
+  }
+  return uid < fanout_.size() ? fanout_[uid] : 0;
 }
 int Orchestrator::gather_audio(uint32_t frames) {
   if (frames > bus_frames_) return fail("gather_audio: frames > block size");

@@ -73,6 +73,9 @@ class Instrument : public Entity {
   virtual uint32_t lanes() const = 0;          // lanes of the block it outputs
   virtual groove_block* output() = 0;
   virtual int tick(uint32_t frames) = 0;       // render `frames` into output()
+  // Does every tick / finish write the whole of output() anew?  Then a chain that is the block's only listener may
+  // transform it where it lies; a source that keeps a constant block (ToyAudioSource) must be copied first.
+  virtual bool output_is_scratch() const { return true; }
   // HandlesMidi::handle_midi_message (note on/off only on this path)
   virtual void note_on(uint8_t key, uint8_t velocity, uint64_t now_frame) = 0;
   virtual void note_off(uint8_t key, uint8_t velocity, uint64_t now_frame) = 0;
@@ -91,6 +94,7 @@ class Effect : public Entity {
   bool is_effect() const override { return true; }
   virtual uint32_t lanes() const = 0;
   virtual int transform_audio(groove_block* inout, uint32_t frames) = 0;
+  virtual groove_fx* library_fx() { return nullptr; } // the library effect behind it, if it is one (chains of those are fused)
   virtual int control_set_param(uint32_t index, double value01) { (void)index; (void)value01; return 1; }
   virtual int control_index_for_name(const std::string&) const { return -1; }
 };
@@ -154,6 +158,7 @@ class ToyAudioSource : public Instrument {
   groove_block* output() override { return block_; }
   int tick(uint32_t frames) override;
   bool supports_render_ahead() const override { return true; } // constant block: nothing to render
+  bool output_is_scratch() const override { return false; }
   void note_on(uint8_t, uint8_t, uint64_t) override {}
   void note_off(uint8_t, uint8_t, uint64_t) override {}
  private:
@@ -169,6 +174,7 @@ class FxEffect : public Effect {
   ~FxEffect() override;
   uint32_t lanes() const override { return lanes_; }
   int transform_audio(groove_block* inout, uint32_t frames) override;
+  groove_fx* library_fx() override { return fx_; }
   int control_set_param(uint32_t index, double value01) override;
   int control_index_for_name(const std::string& name) const override;
  private:
@@ -286,6 +292,7 @@ class Orchestrator {
   };
   int eval(Uid uid, uint32_t frames, groove_block** out_block, uint32_t* out_lanes);
   int ensure_accum(Node& n, uint32_t lanes);
+  uint32_t fanout(Uid uid); // how many sinks hear this node
   // handle_work + broadcast_midi_messages for the block [at_frame, at_frame + frames)
   void sequence_block(uint64_t at_frame, uint32_t frames);
   // the instruments the main mixer hears, if every one of them is heard exactly once and can render ahead
@@ -298,6 +305,8 @@ class Orchestrator {
   double bpm_;
   std::string err_;
   std::vector<Node> nodes_;
+  std::vector<uint32_t> fanout_; // per node, rebuilt after a patch change
+  bool fanout_valid_ = false;
   std::multimap<uint8_t, Uid> midi_receivers_;
   float* bus_ = nullptr; // device [block][2]
   uint32_t bus_frames_ = 0;

@@ -182,8 +182,7 @@ class Project:
         first = True
         for inst, _, fx, _ in self.banks:
             cur = self.ahead[inst][0]
-            for e in fx:
-                e.transform_audio(cur, FRAMES)
+            ctx.transform_chain(fx, cur, FRAMES)
             ctx.mix([cur], FRAMES, E._Slice(bus, frame0), accumulate=not first)
             cur.release()
             self.ahead[inst] = self.ahead[inst][1:] + [cur]
@@ -210,8 +209,7 @@ class Project:
                 inst.generate_batch_values(block, FRAMES)
                 if ev_pair is not None and ev_pair[1] is not None and inst is self.dominant:
                     ctx.record(ev_pair[1])
-                for e in fx:
-                    e.transform_audio(block, FRAMES)
+                ctx.transform_chain(fx, block, FRAMES)
                 ctx.mix([block], FRAMES, E._Slice(bus, frame0), accumulate=not first)
             first = False
 

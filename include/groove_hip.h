@@ -148,6 +148,12 @@ int groove_fx_destroy(groove_fx* fx);
 int groove_fx_reset(groove_fx* fx);
 /* TransformsAudio::transform_audio over a block, in place (orchestrator.rs:438-457). */
 int groove_fx_process(groove_fx* fx, groove_block* inout, uint32_t frames);
+/* The effects patched behind one instrument, in patch order, over one block: what the reference's gather walk does when
+ * it meets a chain of TransformsAudio entities above a source (orchestrator.rs:438-457: each effect transforms the sum
+ * of what is patched into it).  Same result, bit for bit, as groove_fx_process on chain[0] .. chain[n_fx-1] in turn;
+ * the library fuses the stages that have no feedback inside a block (element-wise kinds, delay lines at least a block
+ * long) into one pass over the block.  An effect may appear once. */
+int groove_fx_chain_process(groove_fx* const* chain, uint32_t n_fx, groove_block* inout, uint32_t frames);
 /* Controllable for effects; lane = GROOVE_ALL_VOICES for all lanes. */
 int groove_fx_set_param(groove_fx* fx, uint32_t lane, uint32_t control_index, double value01);
 /* Replace all per-lane parameters (non-UNIFORM fields only may change). */

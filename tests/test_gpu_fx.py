@@ -186,13 +186,24 @@ def test_config3_chain_bus_parity(gpu_ctx, oracle):
     assert rms <= 1e-5, f"chain bus rms {rms:.3e}"
 
 
-@pytest.mark.parametrize("n", [1, 72, 1500])
-def test_reverb_allpass_chunks_ragged_blocks(gpu_ctx, oracle, n):
-    """All-wet reverb: the all-passes run time-parallel inside chunks of one line length (220 and 74
-    frames at 44.1 kHz).  Block lengths around those lengths and around multiples of them; lane counts
-    that give one and two lane-channels per workgroup.  Same tolerance as the sequential form, and
-    bit-identical to it (second context with GROOVE_FX_SEQ_ALLPASS=1)."""
+def _second_context(env):
     import os
+    from groove_amd import entities as E
+    os.environ[env] = "1"
+    try:
+        return E.Context(0)
+    finally:
+        del os.environ[env]
+
+
+@pytest.mark.parametrize("n", [1, 72, 1500])
+def test_reverb_allpass_forms_ragged_blocks(gpu_ctx, oracle, n):
+    """All-wet reverb.  The default form evaluates the two all-passes with no sequential step (each frame unrolls its
+    feedback back to a ring slot of an earlier block; rings double-buffered); GROOVE_FX_CHUNKED_ALLPASS=1 selects the
+    form that is time-parallel inside chunks of one line length (220 and 74 frames at 44.1 kHz), GROOVE_FX_SEQ_ALLPASS=1
+    the sequential walk.  Block lengths around the line lengths and around multiples of them (blocks shorter than a line
+    leave ring rows untouched: the copy rows of the direct form); lane counts with and without 16-byte accesses.  Same
+    tolerance against the oracle, and the three forms bit-identical."""
     from groove_amd import entities as E
     sizes = [256, 1, 73, 74, 75, 148, 149, 219, 220, 221, 256, 255, 33, 256, 256]
     x = _audio(n, sum(sizes), seed=3)
@@ -200,18 +211,59 @@ def test_reverb_allpass_chunks_ragged_blocks(gpu_ctx, oracle, n):
     got, want = _run(gpu_ctx, oracle, T.FX_REVERB, params, x, block_sizes=sizes)
     assert np.max(np.abs(want)) > 0.1
     assert np.max(np.abs(got - want)) <= 4e-6
-    os.environ["GROOVE_FX_SEQ_ALLPASS"] = "1"
-    try:
-        ctx2 = E.Context(0)
-    finally:
-        del os.environ["GROOVE_FX_SEQ_ALLPASS"]
-    fx = E.Effect(ctx2, T.FX_REVERB, params)
-    block = ctx2.block(n, 256)
-    seq, pos = [], 0
-    for fr in sizes:
-        block.upload(np.ascontiguousarray(x[:, pos:pos + fr, :]))
-        fx.transform_audio(block, fr)
-        seq.append(block.download(fr))
-        pos += fr
-    fx.destroy(); block.destroy(); ctx2.close()
-    assert np.array_equal(got, np.concatenate(seq, axis=1))
+    for env in ("GROOVE_FX_SEQ_ALLPASS", "GROOVE_FX_CHUNKED_ALLPASS"):
+        ctx2 = _second_context(env)
+        fx = E.Effect(ctx2, T.FX_REVERB, params)
+        block = ctx2.block(n, 256)
+        other, pos = [], 0
+        for fr in sizes:
+            block.upload(np.ascontiguousarray(x[:, pos:pos + fr, :]))
+            fx.transform_audio(block, fr)
+            other.append(block.download(fr))
+            pos += fr
+        fx.destroy(); block.destroy(); ctx2.close()
+        assert np.array_equal(got, np.concatenate(other, axis=1)), env
+
+
+@pytest.mark.parametrize("n", [6, 64])
+def test_chain_process_equals_stage_by_stage(gpu_ctx, n):
+    """groove_fx_chain_process fuses the stages without feedback inside a block (gain, chorus, delay, reverb combs ...)
+    into one pass; the result is the stage-by-stage result bit for bit, block after block, including partly wet stages,
+    an IIR stage in the middle (which splits the run), a stage after the reverb, ragged blocks, and a reset."""
+    from groove_amd import entities as E
+    chain = [(T.FX_GAIN, _params(n, ceiling=[0.5 + 0.01 * i for i in range(n)])),
+             (T.FX_CHORUS, _params(n, voices=2, delay_seconds=0.03, wet=[1.0 if i % 2 else 0.6 for i in range(n)])),
+             (T.FX_BIQUAD_LP12, _params(n, cutoff_hz=[300.0 + 40 * i for i in range(n)], q=0.707)),
+             (T.FX_DELAY, _params(n, delay_seconds=0.01, wet=0.8)),
+             (T.FX_COMPRESSOR, _params(n, limit_min=0.2, limit_max=0.25)),
+             (T.FX_DELAY, _params(n, delay_seconds=0.001, wet=0.7)),  # shorter than a block: the serial kernel, splits the run
+             (T.FX_DELAY, _params(n, delay_seconds=0.02)),
+             (T.FX_BITCRUSHER, _params(n, bits=12, wet=0.5)),
+             (T.FX_CHORUS, _params(n, voices=2, delay_seconds=0.03)),
+             (T.FX_REVERB, _params(n, attenuation=0.9, reverb_seconds=0.8)),
+             (T.FX_LIMITER, _params(n, limit_min=0.0, limit_max=0.7))]
+    sizes = [256, 256, 100, 256, 1, 255, 256, 256] * 3
+    x = _audio(n, sum(sizes), seed=11)
+    a = [E.Effect(gpu_ctx, k, p) for k, p in chain]
+    b = [E.Effect(gpu_ctx, k, p) for k, p in chain]
+    ba, bb = gpu_ctx.block(n, 256), gpu_ctx.block(n, 256)
+    for rep in range(2):
+        pos, peak = 0, 0.0
+        for fr in sizes:
+            chunk = np.ascontiguousarray(x[:, pos:pos + fr, :])
+            ba.upload(chunk); bb.upload(chunk)
+            for e in a:
+                e.transform_audio(ba, fr)
+            gpu_ctx.transform_chain(b, bb, fr)
+            ga, gb = ba.download(fr), bb.download(fr)
+            assert np.array_equal(ga.view(np.uint32), gb.view(np.uint32)), (rep, pos)
+            pos += fr
+            peak = max(peak, float(np.max(np.abs(ga[:, :, 1::2]))))  # the fully wet lanes: only what went through every line
+        assert peak > 1e-2
+        for e in a + b:
+            e.reset()
+    with pytest.raises(RuntimeError, match="twice"):
+        gpu_ctx.transform_chain([b[0], b[0]], bb, 256)
+    for e in a + b:
+        e.destroy()
+    ba.destroy(); bb.destroy()
