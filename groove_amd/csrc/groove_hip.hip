@@ -98,6 +98,7 @@ struct groove_bank {
   int ev_slot = 0;
   groove_block* scratch = nullptr; // for render_mix
   std::vector<groove_note_event> pending;
+  InlineEvents inline_ev{};  // sampler: this block's events, to ride in the next time-parallel render's arguments (flush_events)
   std::vector<groove_welsh_params> welsh;
   std::vector<groove_fm_params> fm;
   std::vector<groove_sampler_params> sampler;
@@ -147,7 +148,13 @@ struct groove_ctx {
   uint32_t tp_max_voices = kTpMaxVoices; // Welsh banks up to this size render time-parallel (welsh_tp.h); GROOVE_TP_MAX_VOICES overrides, 0 = never
   uint32_t fx_tp_max_lanes = 4096;       // IIR effect banks of up to this many lane-channels (half as many for the 24 dB low-pass) run time-parallel (fx_tp.h: measured crossovers, tools/fx_bench.py); GROOVE_FX_TP_MAX_LANES
   uint32_t pipeline_min_waves = 4700;   // banks at least this long (~300,000 voices) run one kernel per base kind and pipeline their fused blocks; smaller ones take the all-kinds kernel
+  // How many of the bank streams exist and are handed out (GROOVE_BANK_STREAMS).  Three: with the ctx stream and the four
+  // kind streams that is eight streams; a ninth lands on a hardware queue that already carries one of the others, and a
+  // project with a bank on it ran three times slower (mixed-131072: 0.12 -> 0.39 ms per block whenever a bank had the
+  // fourth bank stream, whichever bank it was; tools/micro/slot_probe.py).
+  int bank_streams = 3;
   int next_stream_slot = 0;             // round-robin side-stream assignment of single-kernel banks
+  uint32_t fx_long_chunk_max_lanes = 131072; // GROOVE_FX_LONG_CHUNK_MAX_LANES (0: always 16-frame chunks)
   bool seq_allpass = false;             // GROOVE_FX_SEQ_ALLPASS=1: the sequential all-pass kernel (A/B and bit-identity tests)
   bool chunked_allpass = false;         // GROOVE_FX_CHUNKED_ALLPASS=1: the chunk-parallel all-pass kernel instead of the direct one
   uint32_t sr = GROOVE_DEFAULT_SAMPLE_RATE;
@@ -463,9 +470,26 @@ int launch_events(groove_bank* b, const groove_note_event* ev, uint32_t count, i
 
 // Apply queued events in order.  Events are cut into rounds in which every voice appears
 // at most once, so one thread per event is race-free and order is preserved across rounds.
-int flush_events(groove_bank* b) {
+// `inline_ok`: the caller is about to launch the bank's time-parallel render, which can take a short sorted list of
+// events in its arguments (welsh_tp.h, InlineEvents).
+int flush_events(groove_bank* b, bool inline_ok = false) {
+  if (b->inline_ev.n) { // handed to a render that never ran: they come first, through the ordinary path
+    b->pending.insert(b->pending.begin(), b->inline_ev.ev, b->inline_ev.ev + b->inline_ev.n);
+    b->inline_ev.n = 0;
+    inline_ok = false;
+  }
   if (b->pending.empty()) return 0;
   groove_ctx* ctx = b->ctx;
+  if (inline_ok && b->kind == BANK_SAMPLER && b->inv.empty() && b->pending.size() <= kInlineEvents) {
+    bool sorted = b->pending[0].voice != GROOVE_ALL_VOICES;
+    for (size_t i = 1; sorted && i < b->pending.size(); ++i) sorted = b->pending[i].voice != GROOVE_ALL_VOICES && b->pending[i].voice > b->pending[i - 1].voice;
+    if (sorted) {
+      b->inline_ev.n = (uint32_t)b->pending.size();
+      std::memcpy(b->inline_ev.ev, b->pending.data(), b->pending.size() * sizeof(groove_note_event));
+      b->pending.clear();
+      return 0;
+    }
+  }
   // Which stream applies the events.  A bank whose renders all run on ONE side stream (side_mode 2: FM,
   // sampler, small or per-lane Welsh banks in the asynchronous forms) and whose state the ctx stream has not
   // touched since gets its events on that same stream: they are ordered with its renders, nothing else reads
@@ -548,23 +572,31 @@ int ensure_partial(groove_ctx* ctx, size_t floats) {
   return 0;
 }
 
-// bus[f][ch] (+)= column sums of rows[row][ch][frame] (fixed order: segments of 64 rows, then the segments).
-int reduce_rows(groove_ctx* ctx, const float* rows_dev, uint32_t rows, uint32_t frames, float* bus_dev, int accumulate) {
-  const uint32_t cols = 2 * frames, rows_per_seg = 64, segs = (rows + rows_per_seg - 1) / rows_per_seg;
-  if (ctx->fseg_cap < (size_t)segs * cols) {
-    if (ctx->d_fseg) GHIP(ctx, hipFree(ctx->d_fseg));
-    GHIP(ctx, hipMalloc(&ctx->d_fseg, (size_t)segs * cols * 4));
-    ctx->fseg_cap = (size_t)segs * cols;
-  }
+// The segment buffer of a bus reduction: seg[segs][cols].
+int ensure_seg_buffer(groove_ctx* ctx, float** buf, size_t* cap, size_t seg_floats) {
+  if (*buf && *cap >= seg_floats) return 0;
+  if (*buf) { GHIP(ctx, hipFree(*buf)); *buf = nullptr; *cap = 0; }
+  GHIP(ctx, hipMalloc(buf, seg_floats * 4));
+  *cap = seg_floats;
+  return 0;
+}
+// bus[f][ch] (+)= column sums of partial[row][ch][frame] on the ctx stream (fixed order: segments of 64 rows, then the
+// segments in index order; a single segment's sums go straight to the bus).
+constexpr uint32_t kRowsPerSeg = 64;
+void launch_reduce(groove_ctx* ctx, const float* partial, uint32_t rows, uint32_t frames, float* seg_buf, float* bus_dev, int accumulate) {
+  const uint32_t cols = 2 * frames, segs = (rows + kRowsPerSeg - 1) / kRowsPerSeg;
+  const dim3 blk(kThreads);
   if (segs == 1) {
-    hipLaunchKernelGGL(partial_rows_kernel, dim3(blocks_for(cols), 1), dim3(kThreads), 0, ctx->stream, rows_dev, rows, cols,
-                       rows_per_seg, ctx->d_fseg, bus_dev, accumulate);
+    hipLaunchKernelGGL(partial_rows_kernel, dim3(blocks_for(cols), 1), blk, 0, ctx->stream, partial, rows, cols, kRowsPerSeg, seg_buf, bus_dev, accumulate);
   } else {
-    hipLaunchKernelGGL(partial_rows_kernel, dim3(blocks_for(cols), segs), dim3(kThreads), 0, ctx->stream, rows_dev, rows, cols,
-                       rows_per_seg, ctx->d_fseg, (float*)nullptr, 0);
-    hipLaunchKernelGGL(partial_final_kernel, dim3(blocks_for(cols)), dim3(kThreads), 0, ctx->stream, ctx->d_fseg, segs, frames,
-                       bus_dev, accumulate);
+    hipLaunchKernelGGL(partial_rows_kernel, dim3(blocks_for(cols), segs), blk, 0, ctx->stream, partial, rows, cols, kRowsPerSeg, seg_buf, (float*)nullptr, 0);
+    hipLaunchKernelGGL(partial_final_kernel, dim3(blocks_for(cols)), blk, 0, ctx->stream, seg_buf, segs, frames, bus_dev, accumulate);
   }
+}
+int reduce_rows(groove_ctx* ctx, const float* rows_dev, uint32_t rows, uint32_t frames, float* bus_dev, int accumulate) {
+  const uint32_t cols = 2 * frames, segs = (rows + kRowsPerSeg - 1) / kRowsPerSeg;
+  if (ensure_seg_buffer(ctx, &ctx->d_fseg, &ctx->fseg_cap, (size_t)segs * cols)) return 1;
+  launch_reduce(ctx, rows_dev, rows, frames, ctx->d_fseg, bus_dev, accumulate);
   GHIP(ctx, hipGetLastError());
   return 0;
 }
@@ -743,6 +775,8 @@ int groove_init(int device_ordinal, groove_ctx** out) {
   if (!ctx) return fail(nullptr, "groove_init: out of memory");
   ctx->device = device_ordinal;
   if (const char* e = std::getenv("GROOVE_FX_SEQ_ALLPASS")) ctx->seq_allpass = e[0] == '1';
+  if (const char* e = std::getenv("GROOVE_BANK_STREAMS")) ctx->bank_streams = std::max(1, std::min(kBankStreams, std::atoi(e)));
+  if (const char* e = std::getenv("GROOVE_FX_LONG_CHUNK_MAX_LANES")) ctx->fx_long_chunk_max_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_CHUNKED_ALLPASS")) ctx->chunked_allpass = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_TP_MAX_VOICES")) ctx->tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_TP_MAX_LANES")) ctx->fx_tp_max_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
@@ -758,10 +792,11 @@ int groove_init(int device_ordinal, groove_ctx** out) {
             hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
             hipEventCreateWithFlags(&ctx->ev_fork, kSyncEventFlags) == hipSuccess;
   // Four normal-priority streams for the four class-specialised Welsh kinds (side by side in every block
-  // of a big bank; the two exact-f64-LFO kinds, rare, share the first two), and four LOW-priority streams
-  // for the single-kernel banks (side by side in a mixed project): never more streams of one priority
-  // than hardware queues, so no two of them are serialised behind each other by the runtime.
+  // of a big bank; the two exact-f64-LFO kinds, rare, share the first two), and three LOW-priority streams
+  // for the single-kernel banks (side by side in a mixed project): never more streams than hardware queues,
+  // so no two of them are serialised behind each other by the runtime (see bank_streams).
   for (int i = 0; ok && i < kSideStreams; ++i) {
+    if (i >= kBaseKinds + ctx->bank_streams) { ok = hipEventCreateWithFlags(&ctx->ev_join[i], kSyncEventFlags) == hipSuccess; continue; }
     if (i == 4 || i == 5) ctx->side_stream[i] = ctx->side_stream[i - 4];
     else if (i < kBaseKinds) ok = hipStreamCreateWithFlags(&ctx->side_stream[i], hipStreamNonBlocking) == hipSuccess;
     else ok = hipStreamCreateWithPriority(&ctx->side_stream[i], hipStreamNonBlocking, prio_least) == hipSuccess;
@@ -910,7 +945,7 @@ int groove_block_download(groove_block* b, float* host, uint32_t frames) {
 
 // ============================================================================ instruments
 static int bank_finish_create(groove_bank* b, groove_bank** out) {
-  b->stream_slot = kBaseKinds + b->ctx->next_stream_slot++ % kBankStreams;
+  b->stream_slot = kBaseKinds + b->ctx->next_stream_slot++ % b->ctx->bank_streams;
   if (bank_alloc(b) || bank_derive_and_upload(b)) { groove_bank_destroy(b); return 1; }
   b->ctx->banks.push_back(b);
   *out = b;
@@ -1037,12 +1072,12 @@ static void launch_tp(groove_bank* b, uint32_t frames, bool fused, size_t chs, f
   groove_ctx* ctx = b->ctx;
   const TpArgs a{b->d_params, b->d_state, out, rows, chs, render_consts(ctx->sr), b->n, frames};
   if (b->kind == BANK_FM) launch_fm_tp(a, st, fused);
-  else if (b->kind == BANK_SAMPLER) launch_sampler_tp(a, b->d_pcm, st, fused);
+  else if (b->kind == BANK_SAMPLER) { launch_sampler_tp(a, b->d_pcm, b->inline_ev, st, fused); b->inline_ev.n = 0; }
   else launch_welsh_tp(a, st, fused);
 }
 // rows of partial[][2][frames] a bank's fused render writes
 static uint32_t fused_rows(const groove_bank* b, uint32_t frames) {
-  if (use_tp(b, frames)) return welsh_tp_workgroups(b->n);
+  if (use_tp(b, frames)) return b->kind == BANK_SAMPLER ? sampler_tp_workgroups(b->n) : welsh_tp_workgroups(b->n);
   return (b->kind == BANK_WELSH && b->n_vwaves) ? (b->n_vwaves + kWaves - 1) / kWaves : blocks_for(b->n);
 }
 // One base kind's uniform Welsh kernel (kernels.h, "Workgroup KINDS") on stream `st`.
@@ -1145,7 +1180,7 @@ int groove_bank_render(groove_bank* b, uint32_t frames, groove_block* out) {
   if (frames > out->cap) return fail(ctx, "groove_bank_render: frames > block capacity");
   if (frames == 0) return 0;
   GHIP(ctx, hipSetDevice(ctx->device));
-  if (flush_events(b)) return 1;
+  if (flush_events(b, use_tp(b, frames))) return 1;
   if (ctx_join(ctx)) return 1; // the bank's state may still be in flight on the side streams (pipelined fused renders)
   b->side_mode = 0;
   out->ready_mask = 0; // joined above
@@ -1178,7 +1213,7 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
   if (frames > out->cap) return fail(ctx, "groove_bank_render_async: frames > block capacity");
   if (frames == 0) return 0;
   GHIP(ctx, hipSetDevice(ctx->device));
-  if (flush_events(b)) return 1;
+  if (flush_events(b, use_tp(b, frames))) return 1;
   const bool was_released = out->released;
   if (block_acquire(out)) return 1; // an earlier asynchronous render into the same block comes first
   const bool tp = use_tp(b, frames);
@@ -1322,11 +1357,9 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
     if (ctx_join(ctx)) return 1;
     GHIP(ctx, hipStreamSynchronize(ctx->stream));
     if (b->d_pipe_part[slot]) GHIP(ctx, hipFree(b->d_pipe_part[slot]));
-    if (b->d_pipe_seg[slot]) GHIP(ctx, hipFree(b->d_pipe_seg[slot]));
     GHIP(ctx, hipMalloc(&b->d_pipe_part[slot], (size_t)rows * cols * 4));
-    GHIP(ctx, hipMalloc(&b->d_pipe_seg[slot], (size_t)segs * cols * 4));
     b->pipe_part_cap[slot] = (size_t)rows * cols;
-    b->pipe_seg_cap[slot] = (size_t)segs * cols;
+    if (ensure_seg_buffer(ctx, &b->d_pipe_seg[slot], &b->pipe_seg_cap[slot], (size_t)segs * cols)) return 1;
     b->reduce_recorded[slot] = false;
   }
   if (!b->ev_reduce_done[slot]) {
@@ -1382,15 +1415,7 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
     ctx->side_busy[k] = true;
   }
   b->ctx_touched = false; // the bank's stream(s) have waited for whatever the ctx stream did to its state (ev_fork above)
-  if (segs == 1) { // small bank: the one segment's column sums are the bus frames
-    hipLaunchKernelGGL(partial_rows_kernel, dim3(blocks_for(cols), 1), blk, 0, ctx->stream, b->d_pipe_part[slot], rows, cols,
-                       rows_per_seg, b->d_pipe_seg[slot], bus_dev, accumulate);
-  } else {
-    hipLaunchKernelGGL(partial_rows_kernel, dim3(blocks_for(cols), segs), blk, 0, ctx->stream, b->d_pipe_part[slot], rows, cols,
-                       rows_per_seg, b->d_pipe_seg[slot], (float*)nullptr, 0);
-    hipLaunchKernelGGL(partial_final_kernel, dim3(blocks_for(cols)), blk, 0, ctx->stream, b->d_pipe_seg[slot], segs, frames,
-                       bus_dev, accumulate);
-  }
+  launch_reduce(ctx, b->d_pipe_part[slot], rows, frames, b->d_pipe_seg[slot], bus_dev, accumulate);
   GHIP(ctx, hipEventRecord(b->ev_reduce_done[slot], ctx->stream));
   b->reduce_recorded[slot] = true;
   GHIP(ctx, hipGetLastError());
@@ -1402,7 +1427,7 @@ int groove_bank_render_mix(groove_bank* b, uint32_t frames, float* bus_dev, int 
   if (frames == 0) return 0;
   if (frames > 4096) return fail(ctx, "groove_bank_render_mix: frames > 4096");
   GHIP(ctx, hipSetDevice(ctx->device));
-  if (flush_events(b)) return 1;
+  if (flush_events(b, use_tp(b, frames))) return 1;
   // Asynchronous form (kernels on side streams, only the bus reductions on the ctx stream):
   //  - a large Welsh bank (>= ~300,000 voices) runs one kernel per base kind and pipelines its own blocks
   //    (+15 % at 1,000,000 voices, +21 % at 500,000); below that a block is latency-bound and the
@@ -1422,21 +1447,9 @@ int groove_bank_render_mix(groove_bank* b, uint32_t frames, float* bus_dev, int 
     GHIP(ctx, hipMalloc(&ctx->d_fpart, (size_t)rows * cols * 4));
     ctx->fpart_cap = (size_t)rows * cols;
   }
-  if (ctx->fseg_cap < (size_t)segs * cols) {
-    if (ctx->d_fseg) GHIP(ctx, hipFree(ctx->d_fseg));
-    GHIP(ctx, hipMalloc(&ctx->d_fseg, (size_t)segs * cols * 4));
-    ctx->fseg_cap = (size_t)segs * cols;
-  }
+  if (ensure_seg_buffer(ctx, &ctx->d_fseg, &ctx->fseg_cap, (size_t)segs * cols)) return 1;
   if (launch_render(b, frames, true, 0, ctx->d_fpart, ctx->d_fpart)) return 1;
-  if (segs == 1) {
-    hipLaunchKernelGGL(partial_rows_kernel, dim3(blocks_for(cols), 1), dim3(kThreads), 0, ctx->stream, ctx->d_fpart, rows, cols,
-                       rows_per_seg, ctx->d_fseg, bus_dev, accumulate);
-  } else {
-    hipLaunchKernelGGL(partial_rows_kernel, dim3(blocks_for(cols), segs), dim3(kThreads), 0, ctx->stream, ctx->d_fpart, rows, cols,
-                       rows_per_seg, ctx->d_fseg, (float*)nullptr, 0);
-    hipLaunchKernelGGL(partial_final_kernel, dim3(blocks_for(cols)), dim3(kThreads), 0, ctx->stream, ctx->d_fseg, segs, frames,
-                       bus_dev, accumulate);
-  }
+  launch_reduce(ctx, ctx->d_fpart, rows, frames, ctx->d_fseg, bus_dev, accumulate);
   GHIP(ctx, hipGetLastError());
   return 0;
 }
@@ -1448,6 +1461,7 @@ int groove_bank_reset(groove_bank* b) {
   b->side_mode = 0;
   b->ctx_touched = true;
   b->pending.clear();
+  b->inline_ev.n = 0;
   StateWords w{};
   if (b->kind == BANK_WELSH) { const WelshState s = initial_welsh_state(); std::memcpy(w.w, &s, sizeof(s)); }
   else if (b->kind == BANK_FM) { const FmState s = initial_fm_state(); std::memcpy(w.w, &s, sizeof(s)); }
@@ -1607,6 +1621,10 @@ static int fx_launch_serial(groove_fx* fx, groove_block* io, uint32_t frames) {
   const uint32_t n = fx->n;
   const size_t chs = (size_t)io->cap * n;
   const dim3 blk(kThreads), lanes_grid(blocks_for(2 * (size_t)n));
+  // The serial IIR kernels read a chunk of frames ahead of the recurrence; with a wavefront or two per SIMD (banks of up
+  // to ~100,000 lane-channels) the walk is bound by one memory round trip per chunk, so the chunks are long (64 frames:
+  // 4 round trips per block instead of 16); bigger banks hide the latency with occupancy and keep the registers.
+  const bool long_chunks = frames >= 64 && 2 * (size_t)n <= ctx->fx_long_chunk_max_lanes;
   switch (fx->kind) {
     case GROOVE_FX_BIQUAD_LP12:
     case GROOVE_FX_BIQUAD_HP12:
@@ -1619,12 +1637,16 @@ static int fx_launch_serial(groove_fx* fx, groove_block* io, uint32_t frames) {
       // few lane-channels: one wavefront each, frames over its lanes (fx_tp.h); many: one thread each, frames serial
       if (frames <= kTpMaxFrames && 2 * (size_t)n <= ctx->fx_tp_max_lanes && ctx->tp_max_voices)
         hipLaunchKernelGGL(fx_biquad_tp_kernel, dim3((n + kFxTile - 1) / kFxTile, 2), dim3(kFxTpThreads), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+      else if (long_chunks)
+        hipLaunchKernelGGL(fx_biquad_kernel<64>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       else
         hipLaunchKernelGGL(fx_biquad_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       break;
     case GROOVE_FX_BIQUAD_LP24:
       if (frames <= kTpMaxFrames && 4 * (size_t)n <= ctx->fx_tp_max_lanes && ctx->tp_max_voices)
         hipLaunchKernelGGL(fx_lp24_tp_kernel, dim3((n + kFxTile - 1) / kFxTile, 2), dim3(kFxTpThreads), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+      else if (long_chunks)
+        hipLaunchKernelGGL(fx_lp24_kernel<64>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       else
         hipLaunchKernelGGL(fx_lp24_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       break;

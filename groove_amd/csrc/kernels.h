@@ -529,6 +529,9 @@ __global__ __launch_bounds__(kThreads) void sampler_render_kernel(
 
 #ifndef GROOVE_WELSH_CLASS_TU // everything below is defined once, in groove_hip.hip
 // Fused path, stage 2: column sums of partial[rows][cols] (cols = 2*frames) over row segments.
+// (Both stages in one launch — the last workgroup of a column group to finish adds the segments up — was tried and is
+// slower: the agent-scope release every workgroup needs before it counts itself done writes the whole L2 back on this
+// multi-XCD part, 18.6 us against 6 + 5 for sampler-16384.)
 __global__ __launch_bounds__(kThreads) void partial_rows_kernel(
     const float* __restrict__ partial, uint32_t rows, uint32_t cols, uint32_t rows_per_seg,
     float* __restrict__ seg_out /*[segs][cols]*/, float* __restrict__ bus = nullptr, int accumulate = 0) {

@@ -210,6 +210,10 @@ GROOVE_HD uint64_t fm_tp_carrier_inc(const FmParams& p, uint64_t c_inc, uint64_t
 // ------------------------------------------------------------------ the kernel
 constexpr int kTpWaves = 4;                 // voices per workgroup
 constexpr int kTpThreads = kTpWaves * 64;
+// sampler voices are a gather and nothing else: sixteen to a workgroup, so that the bus reduction behind the render has
+// a quarter of the partial rows to read (sampler-16384: 4,096 rows of 2 KB -> 1,024)
+constexpr int kSamplerTpWaves = 16;
+constexpr int kSamplerTpThreads = kSamplerTpWaves * 64;
 constexpr uint32_t kTpMaxVoices = 16384;    // measured crossover with the serial kernels ~24,000 voices (tools/tp_bench.py)
 
 template <class T> __device__ __forceinline__ T tp_shfl(T x, int src) {
@@ -231,6 +235,12 @@ __device__ __forceinline__ void tp_shfl_affine(const Lp24Affine& m, int src, Lp2
 struct TpArgs {
   const uint32_t* params; uint32_t* state; float* out; float* rows; size_t ch_stride; RenderConsts rc; uint32_t n, frames;
 };
+// A block's note events, small enough to ride in the kernel's argument block (4 KB): strictly increasing voices, so a
+// wavefront finds its voice's event (there is at most one) by bisection with scalar loads and applies it to the state
+// it has just read — no separate events kernel, and no host-to-device copy ordered in front of the render.  A sampler
+// project with staggered note-ons (config #4) has a few hundred events per block, every block.
+constexpr uint32_t kInlineEvents = 440;
+struct InlineEvents { uint32_t n; groove_note_event ev[kInlineEvents]; };
 // rows = partial[workgroup][ch][frame] (the bus reduction's rows), written by both forms; !FUSED also stores the planar
 // block out[ch][frame][voice] (kernels.h run_frames: the rows are then the block's own lane sums for groove_mix).
 template <bool FUSED>
@@ -521,15 +531,23 @@ __global__ __launch_bounds__(kTpThreads) void fm_tp_kernel(TpArgs a) {
 // walks 256 frames in chunks of 16 fetches: 45 us for a one-wave-per-SIMD bank).  Exact, like the serial form.
 constexpr uint32_t kSamplerTpMaxVoices = 65536;
 template <bool FUSED>
-__global__ __launch_bounds__(kTpThreads) void sampler_tp_kernel(TpArgs a, const float* __restrict__ bank) {
-  __shared__ float s_tile[kTpWaves][kTpMaxFrames];
+__global__ __launch_bounds__(kSamplerTpThreads) void sampler_tp_kernel(TpArgs a, const float* __restrict__ bank, InlineEvents ie) {
+  __shared__ float s_tile[kSamplerTpWaves][kTpMaxFrames];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint32_t v0 = blockIdx.x * kTpWaves + wave;
+  const uint32_t v0 = blockIdx.x * kSamplerTpWaves + wave;
   const bool voice = v0 < a.n;
   const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(voice ? v0 : a.n - 1));
   const uint32_t frames = a.frames, n = a.n;
   const SamplerParams p = make_scalar(soa_load<SamplerParams>(a.params, n, v));
-  const SamplerState s0 = make_scalar(soa_load<SamplerState>(a.state, n, v));
+  SamplerState s0 = make_scalar(soa_load<SamplerState>(a.state, n, v));
+  if (ie.n) { // this block's note events: is one of them this voice's?
+    uint32_t lo = 0, hi = ie.n;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (ie.ev[mid].voice < v) lo = mid + 1; else hi = mid;
+    }
+    if (lo < ie.n && ie.ev[lo].voice == v) sampler_note(p, s0, ie.ev[lo].key, ie.ev[lo].on != 0);
+  }
   const uint32_t n0 = lane * kTpChunk;
   float x[kTpChunk];
   uint32_t mine = 0; // frames of this lane that play
@@ -549,10 +567,10 @@ __global__ __launch_bounds__(kTpThreads) void sampler_tp_kernel(TpArgs a, const 
 #pragma unroll
   for (uint32_t j = 0; j < kTpChunk; ++j) s_tile[wave][n0 + j] = voice ? x[j] : 0.0f;
   __syncthreads();
-  for (uint32_t t = threadIdx.x; t < frames; t += kTpThreads) {
+  for (uint32_t t = threadIdx.x; t < frames; t += kSamplerTpThreads) {
     float acc = 0.0f;
 #pragma unroll
-    for (int w = 0; w < kTpWaves; ++w) acc += s_tile[w][t];
+    for (int w = 0; w < kSamplerTpWaves; ++w) acc += s_tile[w][t];
     a.rows[((size_t)blockIdx.x * 2 + 0) * frames + t] = acc; // mono voices: the same sum on both channels
     a.rows[((size_t)blockIdx.x * 2 + 1) * frames + t] = acc;
   }
@@ -574,8 +592,9 @@ __global__ __launch_bounds__(kTpThreads) void sampler_tp_kernel(TpArgs a, const 
 }
 void launch_welsh_tp(const TpArgs& a, hipStream_t st, bool fused);
 void launch_fm_tp(const TpArgs& a, hipStream_t st, bool fused);
-void launch_sampler_tp(const TpArgs& a, const float* bank, hipStream_t st, bool fused);
+void launch_sampler_tp(const TpArgs& a, const float* bank, const InlineEvents& ie, hipStream_t st, bool fused);
 inline uint32_t welsh_tp_workgroups(uint32_t n) { return (n + kTpWaves - 1) / kTpWaves; }
+inline uint32_t sampler_tp_workgroups(uint32_t n) { return (n + kSamplerTpWaves - 1) / kSamplerTpWaves; }
 #endif // __HIPCC__
 
 } // namespace groove

@@ -14,9 +14,9 @@ void launch_fm_tp(const TpArgs& a, hipStream_t st, bool fused) {
   if (fused) hipLaunchKernelGGL(fm_tp_kernel<true>, grid, blk, 0, st, a);
   else hipLaunchKernelGGL(fm_tp_kernel<false>, grid, blk, 0, st, a);
 }
-void launch_sampler_tp(const TpArgs& a, const float* bank, hipStream_t st, bool fused) {
-  const dim3 grid(welsh_tp_workgroups(a.n)), blk(kTpThreads);
-  if (fused) hipLaunchKernelGGL(sampler_tp_kernel<true>, grid, blk, 0, st, a, bank);
-  else hipLaunchKernelGGL(sampler_tp_kernel<false>, grid, blk, 0, st, a, bank);
+void launch_sampler_tp(const TpArgs& a, const float* bank, const InlineEvents& ie, hipStream_t st, bool fused) {
+  const dim3 grid(sampler_tp_workgroups(a.n)), blk(kSamplerTpThreads);
+  if (fused) hipLaunchKernelGGL(sampler_tp_kernel<true>, grid, blk, 0, st, a, bank, ie);
+  else hipLaunchKernelGGL(sampler_tp_kernel<false>, grid, blk, 0, st, a, bank, ie);
 }
 } // namespace groove

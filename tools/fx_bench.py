@@ -9,7 +9,7 @@ from groove_amd import entities as E, abi_types as T
 ctx = E.Context(0)
 default = ctx.time_parallel_max_voices
 for kind, name in ((T.FX_BIQUAD_LP12, "biquad"), (T.FX_BIQUAD_LP24, "lp24")):
-    for n in (1, 64, 1024, 4096, 16384):
+    for n in (1, 64, 1024, 4096, 16384, 65536, 262144):
         params = (T.FxParams * n)(*[T.fx_params(cutoff_hz=500.0 + 10 * (i % 64)) for i in range(n)])
         blk = ctx.block(n, 256)
         blk.upload(np.random.default_rng(1).standard_normal((2, 256, n)).astype(np.float32) * 0.1)
