@@ -36,27 +36,33 @@ __device__ __forceinline__ void bq_affine_compose(BqAffine& later, const BqAffin
 // workgroup therefore moves its [frames][32] tile through LDS with whole-line accesses (two 128-byte rows per wave
 // instruction), transposed to tile[lane-channel][frame] (+1 float per row: conflict-free both ways), and its waves take
 // the lane-channels in turn from there (one ds_read_b128 = a lane's four frames).
-constexpr uint32_t kFxTile = 8, kFxTpThreads = 512, kFxTileRow = kTpMaxFrames + 4; // rows stay 16-byte aligned
-struct FxTile { float t[kFxTile][kFxTileRow]; };
-__device__ __forceinline__ void fx_tile_load(FxTile& tile, const float* __restrict__ data, uint32_t n, uint32_t frames, uint32_t lane0, uint32_t lanes) {
-  const uint32_t c = threadIdx.x % kFxTile;
-  for (uint32_t f = threadIdx.x / kFxTile; f < frames; f += kFxTpThreads / kFxTile)
+// Two tile widths: 8 lane-channels (one per wave) for small banks, where the number of workgroups is what matters, and
+// 32 (four per wave, one after the other) for banks of thousands of lanes, where a tile row is then a whole 128-byte
+// line instead of a quarter of one (the 8-wide tile moves every line of the block four times).
+constexpr uint32_t kFxTile = 8, kFxTileWide = 32, kFxTpThreads = 512, kFxTileRow = kTpMaxFrames + 4; // rows stay 16-byte aligned
+template <uint32_t TILE> struct FxTile { float t[TILE][kFxTileRow]; };
+template <uint32_t TILE>
+__device__ __forceinline__ void fx_tile_load(FxTile<TILE>& tile, const float* __restrict__ data, uint32_t n, uint32_t frames, uint32_t lane0, uint32_t lanes) {
+  const uint32_t c = threadIdx.x % TILE;
+  for (uint32_t f = threadIdx.x / TILE; f < frames; f += kFxTpThreads / TILE)
     if (c < lanes) tile.t[c][f] = data[(size_t)f * n + lane0 + c];
 }
-__device__ __forceinline__ void fx_tile_store(const FxTile& tile, float* __restrict__ data, uint32_t n, uint32_t frames, uint32_t lane0, uint32_t lanes) {
-  const uint32_t c = threadIdx.x % kFxTile;
-  for (uint32_t f = threadIdx.x / kFxTile; f < frames; f += kFxTpThreads / kFxTile)
+template <uint32_t TILE>
+__device__ __forceinline__ void fx_tile_store(const FxTile<TILE>& tile, float* __restrict__ data, uint32_t n, uint32_t frames, uint32_t lane0, uint32_t lanes) {
+  const uint32_t c = threadIdx.x % TILE;
+  for (uint32_t f = threadIdx.x / TILE; f < frames; f += kFxTpThreads / TILE)
     if (c < lanes) data[(size_t)f * n + lane0 + c] = tile.t[c][f];
 }
-// grid: (ceil(n / 32), 2 channels).  coef: [5][n] f64 (b0 b1 b2 a1 a2); st: [4][2n] f64 (x1 x2 y1 y2); data: the planar block, in place.
+// grid: (ceil(n / TILE), 2 channels).  coef: [5][n] f64 (b0 b1 b2 a1 a2); st: [4][2n] f64 (x1 x2 y1 y2); data: the planar block, in place.
+template <uint32_t TILE>
 __global__ __launch_bounds__(kFxTpThreads) void fx_biquad_tp_kernel(
     float* __restrict__ data, uint32_t n, uint32_t frames, size_t ch_stride,
     const double* __restrict__ coef, double* __restrict__ st, const float* __restrict__ wet) {
-  __shared__ FxTile tile;
-  __shared__ double s_coef[5][kFxTile], s_st[4][kFxTile]; // the tile's coefficients and state: one coalesced load each, not one round trip per lane-channel
-  __shared__ float s_wet[kFxTile];
+  __shared__ FxTile<TILE> tile;
+  __shared__ double s_coef[5][TILE], s_st[4][TILE]; // the tile's coefficients and state: one coalesced load each, not one round trip per lane-channel
+  __shared__ float s_wet[TILE];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, ch = blockIdx.y;
-  const uint32_t lane0 = blockIdx.x * kFxTile, lanes = min(kFxTile, n - lane0);
+  const uint32_t lane0 = blockIdx.x * TILE, lanes = min(TILE, n - lane0);
   float* __restrict__ base = data + ch * ch_stride;
   const size_t tn = 2 * (size_t)n;
   if (threadIdx.x < lanes) {
@@ -135,14 +141,15 @@ __global__ __launch_bounds__(kFxTpThreads) void fx_biquad_tp_kernel(
   fx_tile_store(tile, base, n, frames, lane0, lanes);
 }
 // coef: [6][n] f64 (b0 a1 a2 per section); st: [4][2n] f64.
+template <uint32_t TILE>
 __global__ __launch_bounds__(kFxTpThreads) void fx_lp24_tp_kernel(
     float* __restrict__ data, uint32_t n, uint32_t frames, size_t ch_stride,
     const double* __restrict__ coef, double* __restrict__ st, const float* __restrict__ wet) {
-  __shared__ FxTile tile;
-  __shared__ double s_coef[6][kFxTile], s_st[4][kFxTile];
-  __shared__ float s_wet[kFxTile];
+  __shared__ FxTile<TILE> tile;
+  __shared__ double s_coef[6][TILE], s_st[4][TILE];
+  __shared__ float s_wet[TILE];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, ch = blockIdx.y;
-  const uint32_t lane0 = blockIdx.x * kFxTile, lanes = min(kFxTile, n - lane0);
+  const uint32_t lane0 = blockIdx.x * TILE, lanes = min(TILE, n - lane0);
   float* __restrict__ base = data + ch * ch_stride;
   const size_t tn = 2 * (size_t)n;
   if (threadIdx.x < lanes) {

@@ -154,6 +154,7 @@ struct groove_ctx {
   // fourth bank stream, whichever bank it was; tools/micro/slot_probe.py).
   int bank_streams = 3;
   int next_stream_slot = 0;             // round-robin side-stream assignment of single-kernel banks
+  uint32_t fx_tp_wide_min_lanes = 8192;  // from this many lane-channels the time-parallel IIR kernels take 32-wide tiles (GROOVE_FX_TP_WIDE_MIN_LANES)
   uint32_t fx_long_chunk_max_lanes = 131072; // GROOVE_FX_LONG_CHUNK_MAX_LANES (0: always 16-frame chunks)
   bool seq_allpass = false;             // GROOVE_FX_SEQ_ALLPASS=1: the sequential all-pass kernel (A/B and bit-identity tests)
   bool chunked_allpass = false;         // GROOVE_FX_CHUNKED_ALLPASS=1: the chunk-parallel all-pass kernel instead of the direct one
@@ -776,6 +777,7 @@ int groove_init(int device_ordinal, groove_ctx** out) {
   ctx->device = device_ordinal;
   if (const char* e = std::getenv("GROOVE_FX_SEQ_ALLPASS")) ctx->seq_allpass = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_BANK_STREAMS")) ctx->bank_streams = std::max(1, std::min(kBankStreams, std::atoi(e)));
+  if (const char* e = std::getenv("GROOVE_FX_TP_WIDE_MIN_LANES")) ctx->fx_tp_wide_min_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_LONG_CHUNK_MAX_LANES")) ctx->fx_long_chunk_max_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_CHUNKED_ALLPASS")) ctx->chunked_allpass = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_TP_MAX_VOICES")) ctx->tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
@@ -1635,16 +1637,20 @@ static int fx_launch_serial(groove_fx* fx, groove_block* io, uint32_t frames) {
     case GROOVE_FX_BIQUAD_LSHELF12:
     case GROOVE_FX_BIQUAD_HSHELF12:
       // few lane-channels: one wavefront each, frames over its lanes (fx_tp.h); many: one thread each, frames serial
-      if (frames <= kTpMaxFrames && 2 * (size_t)n <= ctx->fx_tp_max_lanes && ctx->tp_max_voices)
-        hipLaunchKernelGGL(fx_biquad_tp_kernel, dim3((n + kFxTile - 1) / kFxTile, 2), dim3(kFxTpThreads), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+      if (frames <= kTpMaxFrames && 2 * (size_t)n <= ctx->fx_tp_max_lanes && ctx->tp_max_voices) {
+        if (2 * (size_t)n >= ctx->fx_tp_wide_min_lanes) hipLaunchKernelGGL(fx_biquad_tp_kernel<kFxTileWide>, dim3((n + kFxTileWide - 1) / kFxTileWide, 2), dim3(kFxTpThreads), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+        else hipLaunchKernelGGL(fx_biquad_tp_kernel<kFxTile>, dim3((n + kFxTile - 1) / kFxTile, 2), dim3(kFxTpThreads), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+      }
       else if (long_chunks)
         hipLaunchKernelGGL(fx_biquad_kernel<64>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       else
         hipLaunchKernelGGL(fx_biquad_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       break;
     case GROOVE_FX_BIQUAD_LP24:
-      if (frames <= kTpMaxFrames && 4 * (size_t)n <= ctx->fx_tp_max_lanes && ctx->tp_max_voices)
-        hipLaunchKernelGGL(fx_lp24_tp_kernel, dim3((n + kFxTile - 1) / kFxTile, 2), dim3(kFxTpThreads), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+      if (frames <= kTpMaxFrames && 4 * (size_t)n <= ctx->fx_tp_max_lanes && ctx->tp_max_voices) {
+        if (2 * (size_t)n >= ctx->fx_tp_wide_min_lanes) hipLaunchKernelGGL(fx_lp24_tp_kernel<kFxTileWide>, dim3((n + kFxTileWide - 1) / kFxTileWide, 2), dim3(kFxTpThreads), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+        else hipLaunchKernelGGL(fx_lp24_tp_kernel<kFxTile>, dim3((n + kFxTile - 1) / kFxTile, 2), dim3(kFxTpThreads), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+      }
       else if (long_chunks)
         hipLaunchKernelGGL(fx_lp24_kernel<64>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       else
