@@ -155,7 +155,6 @@ struct groove_ctx {
   int bank_streams = 3;
   int next_stream_slot = 0;             // round-robin side-stream assignment of single-kernel banks
   uint32_t fx_tp_wide_min_lanes = 8192;  // from this many lane-channels the time-parallel IIR kernels take 32-wide tiles (GROOVE_FX_TP_WIDE_MIN_LANES)
-  uint32_t fx_long_chunk_max_lanes = 131072; // GROOVE_FX_LONG_CHUNK_MAX_LANES (0: always 16-frame chunks)
   bool seq_allpass = false;             // GROOVE_FX_SEQ_ALLPASS=1: the sequential all-pass kernel (A/B and bit-identity tests)
   bool chunked_allpass = false;         // GROOVE_FX_CHUNKED_ALLPASS=1: the chunk-parallel all-pass kernel instead of the direct one
   uint32_t sr = GROOVE_DEFAULT_SAMPLE_RATE;
@@ -778,7 +777,6 @@ int groove_init(int device_ordinal, groove_ctx** out) {
   if (const char* e = std::getenv("GROOVE_FX_SEQ_ALLPASS")) ctx->seq_allpass = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_BANK_STREAMS")) ctx->bank_streams = std::max(1, std::min(kBankStreams, std::atoi(e)));
   if (const char* e = std::getenv("GROOVE_FX_TP_WIDE_MIN_LANES")) ctx->fx_tp_wide_min_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
-  if (const char* e = std::getenv("GROOVE_FX_LONG_CHUNK_MAX_LANES")) ctx->fx_long_chunk_max_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_CHUNKED_ALLPASS")) ctx->chunked_allpass = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_TP_MAX_VOICES")) ctx->tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_TP_MAX_LANES")) ctx->fx_tp_max_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
@@ -1623,10 +1621,8 @@ static int fx_launch_serial(groove_fx* fx, groove_block* io, uint32_t frames) {
   const uint32_t n = fx->n;
   const size_t chs = (size_t)io->cap * n;
   const dim3 blk(kThreads), lanes_grid(blocks_for(2 * (size_t)n));
-  // The serial IIR kernels read a chunk of frames ahead of the recurrence; with a wavefront or two per SIMD (banks of up
-  // to ~100,000 lane-channels) the walk is bound by one memory round trip per chunk, so the chunks are long (64 frames:
-  // 4 round trips per block instead of 16); bigger banks hide the latency with occupancy and keep the registers.
-  const bool long_chunks = frames >= 64 && 2 * (size_t)n <= ctx->fx_long_chunk_max_lanes;
+  // (64-frame chunks instead of 16 were measured for the serial IIR kernels: no change at any bank size — the walk is
+  // bound by its dependent f64 chain, not by the chunk loads.)
   switch (fx->kind) {
     case GROOVE_FX_BIQUAD_LP12:
     case GROOVE_FX_BIQUAD_HP12:
@@ -1641,8 +1637,6 @@ static int fx_launch_serial(groove_fx* fx, groove_block* io, uint32_t frames) {
         if (2 * (size_t)n >= ctx->fx_tp_wide_min_lanes) hipLaunchKernelGGL(fx_biquad_tp_kernel<kFxTileWide>, dim3((n + kFxTileWide - 1) / kFxTileWide, 2), dim3(kFxTpThreads), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
         else hipLaunchKernelGGL(fx_biquad_tp_kernel<kFxTile>, dim3((n + kFxTile - 1) / kFxTile, 2), dim3(kFxTpThreads), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       }
-      else if (long_chunks)
-        hipLaunchKernelGGL(fx_biquad_kernel<64>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       else
         hipLaunchKernelGGL(fx_biquad_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       break;
@@ -1651,8 +1645,6 @@ static int fx_launch_serial(groove_fx* fx, groove_block* io, uint32_t frames) {
         if (2 * (size_t)n >= ctx->fx_tp_wide_min_lanes) hipLaunchKernelGGL(fx_lp24_tp_kernel<kFxTileWide>, dim3((n + kFxTileWide - 1) / kFxTileWide, 2), dim3(kFxTpThreads), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
         else hipLaunchKernelGGL(fx_lp24_tp_kernel<kFxTile>, dim3((n + kFxTile - 1) / kFxTile, 2), dim3(kFxTpThreads), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       }
-      else if (long_chunks)
-        hipLaunchKernelGGL(fx_lp24_kernel<64>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       else
         hipLaunchKernelGGL(fx_lp24_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       break;
