@@ -154,6 +154,7 @@ struct groove_ctx {
   // fourth bank stream, whichever bank it was; tools/micro/slot_probe.py).
   int bank_streams = 3;
   int next_stream_slot = 0;             // round-robin side-stream assignment of single-kernel banks
+  uint32_t fm_tp_max_voices = kFmTpMaxVoices; // GROOVE_FM_TP_MAX_VOICES
   uint32_t fx_tp_wide_min_lanes = 8192;  // from this many lane-channels the time-parallel IIR kernels take 32-wide tiles (GROOVE_FX_TP_WIDE_MIN_LANES)
   bool seq_allpass = false;             // GROOVE_FX_SEQ_ALLPASS=1: the sequential all-pass kernel (A/B and bit-identity tests)
   bool chunked_allpass = false;         // GROOVE_FX_CHUNKED_ALLPASS=1: the chunk-parallel all-pass kernel instead of the direct one
@@ -776,6 +777,7 @@ int groove_init(int device_ordinal, groove_ctx** out) {
   ctx->device = device_ordinal;
   if (const char* e = std::getenv("GROOVE_FX_SEQ_ALLPASS")) ctx->seq_allpass = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_BANK_STREAMS")) ctx->bank_streams = std::max(1, std::min(kBankStreams, std::atoi(e)));
+  if (const char* e = std::getenv("GROOVE_FM_TP_MAX_VOICES")) ctx->fm_tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_TP_WIDE_MIN_LANES")) ctx->fx_tp_wide_min_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_CHUNKED_ALLPASS")) ctx->chunked_allpass = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_TP_MAX_VOICES")) ctx->tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
@@ -1064,7 +1066,7 @@ static float* block_sums(groove_block* blk, uint32_t rows, uint32_t frames) {
 static bool use_tp(const groove_bank* b, uint32_t frames) {
   if (frames > kTpMaxFrames || b->ctx->tp_max_voices == 0) return false;
   if (b->kind == BANK_WELSH) return b->n <= b->ctx->tp_max_voices;
-  if (b->kind == BANK_FM) return b->n <= kFmTpMaxVoices; // no filter scan: far cheaper per voice than a Welsh voice
+  if (b->kind == BANK_FM) return b->n <= b->ctx->fm_tp_max_voices; // no filter scan: far cheaper per voice than a Welsh voice
   if (b->kind == BANK_SAMPLER) return b->n <= kSamplerTpMaxVoices; // a pure gather
   return false;
 }

@@ -723,31 +723,8 @@ __global__ void bus_to_i16_kernel(const float* __restrict__ bus, size_t count, i
 }
 
 // ------------------------------------------------------------------ effects
-// Element-wise kinds (a8 Gain, a9 Bitcrusher, Limiter, Compressor, Mixer): grid-stride over
-// the block; per-lane parameters indexed by lane = i % n.
-__global__ __launch_bounds__(kThreads) void fx_elementwise_kernel(
-    uint32_t kind, float* __restrict__ data, uint32_t n, uint32_t frames, size_t ch_stride,
-    const float* __restrict__ fa, const float* __restrict__ fb, const uint32_t* __restrict__ ua,
-    const float* __restrict__ wet) {
-  const size_t per_ch = (size_t)frames * n;
-  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < 2 * per_ch; i += (size_t)gridDim.x * kThreads) {
-    const size_t ch = i / per_ch, r = i % per_ch;
-    const uint32_t lane = (uint32_t)(r % n);
-    float* ptr = data + ch * ch_stride + r;
-    const float x = *ptr;
-    float y;
-    switch (kind) {
-      case GROOVE_FX_GAIN: y = x * fa[lane]; break;
-      case GROOVE_FX_BITCRUSHER: y = bitcrush(x, ua[lane]); break;
-      case GROOVE_FX_LIMITER: y = limiter(x, fa[lane], fb[lane]); break;
-      case GROOVE_FX_COMPRESSOR: y = compressor(x, fa[lane], fb[lane]); break;
-      default: y = x; break;
-    }
-    const float w = wet[lane];
-    if (w < 1.0f) y = fmaf(y, w, x * (1.0f - w));
-    *ptr = y;
-  }
-}
+// Element-wise kinds (a8 Gain, a9 Bitcrusher, Limiter, Compressor; the Mixer is the identity and launches nothing): stages
+// of fx_run_kernel below, alone or fused with their neighbours in a chain.
 
 // The IIR and delay-line effect kernels keep one (channel, lane) pair per thread and walk the
 // block sequentially (feedback), but in CHUNKS of C frames: all the loads of a chunk (inputs and

@@ -14,14 +14,15 @@ WORKLOADS=${@:-welsh-1m welsh-256 chain-4096 sampler-16384 mixed-131072}
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 mkdir -p profiles
+TO="timeout ${PASS_TIMEOUT:-420}"   # one pass of one workload takes 20-60 s; a box that crawls must not eat the budget
 for W in $WORKLOADS; do
   OUT=gpurun_out/prof_${ROUND}_$W
   rm -rf $OUT; mkdir -p $OUT
   BENCH="python3 bench.py --workload $W --no-cpu-baseline --no-configs --no-parity --repeats 1"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/bench_kt.log 2>&1
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH > $OUT/bench_fetch.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH > $OUT/bench_write.log 2>&1
-  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq -- $BENCH > $OUT/bench_sq.log 2>&1
-  rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/grbm -- $BENCH > $OUT/bench_grbm.log 2>&1
+  $TO rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/bench_kt.log 2>&1
+  $TO rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH > $OUT/bench_fetch.log 2>&1
+  $TO rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH > $OUT/bench_write.log 2>&1
+  $TO rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq -- $BENCH > $OUT/bench_sq.log 2>&1
+  $TO rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/grbm -- $BENCH > $OUT/bench_grbm.log 2>&1
   python3 tools/summarize_prof.py $OUT $ROUND $W
 done

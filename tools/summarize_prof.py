@@ -59,7 +59,11 @@ def counters(sub):
 
 for sub in ("fetch", "write", "sq", "grbm"):
     summary[sub] = counters(sub)
-STEPS = 176.0   # 172 timed + 4 warm-up steps per run
+STEPS = 176.0   # 172 timed + 4 warm-up steps per run, unless the bench line of the run says otherwise
+_bl = summary.get("bench_line_under_profiler", {})
+if _bl.get("steps"):
+    STEPS = float(_bl["steps"] + _bl.get("warmup", 0))
+summary["steps_per_run"] = STEPS
 
 
 # Per STEP (one 256-frame block of the whole project): per-kernel totals over the run divided by the steps, summed over
@@ -77,6 +81,21 @@ w, f = per_step("write", "WRITE_SIZE") * 1024.0, per_step("fetch", "FETCH_SIZE")
 summary["hbm_traffic_bytes_per_step"] = {"write": w, "fetch_raw": f, "fetch_x2_gfx950": 2 * f, "total_raw": w + f, "total_corrected": w + 2 * f}
 summary["instructions_per_step"] = {"valu_wave_insts": per_step("sq", "SQ_INSTS_VALU"), "salu_wave_insts": per_step("sq", "SQ_INSTS_SALU"),
                                     "note": "SQ_INSTS_VALU / SQ_INSTS_SALU summed over the step's kernels (wave-level instructions)"}
+# The clock the chip held under each kernel (MI355X_MICROARCH.md, DVFS give-back): GRBM_GUI_ACTIVE is summed over the 8
+# XCDs, so clock = GRBM_GUI_ACTIVE / 8 / the kernel's average duration (reads high on dispatches well under 0.3 ms).
+if ks:
+    dur = {r["Name"].split("(")[0][-70:]: float(r["AverageNs"]) for r in csv.DictReader(open(ks[0]))}
+    clocks = {}
+    for k, v in summary.get("grbm", {}).items():
+        g = v["mean_per_dispatch"].get("GRBM_GUI_ACTIVE")
+        if g and dur.get(k):
+            clocks[k] = {"avg_us": dur[k] / 1e3, "clock_ghz": g / 8.0 / dur[k]}
+    summary["clock_under_load"] = {"per_kernel": clocks,
+                                   "note": "GRBM_GUI_ACTIVE / 8 XCDs / average kernel duration; kernels shorter than ~0.3 ms read high"}
+    long_ones = [c for c in clocks.values() if c["avg_us"] >= 150.0]
+    if long_ones:
+        tot = sum(c["avg_us"] for c in long_ones)
+        summary["clock_under_load"]["ghz_weighted_long_kernels"] = sum(c["clock_ghz"] * c["avg_us"] for c in long_ones) / tot
 json.dump(summary, open(f"profiles/{rnd}_{workload}_summary.json", "w"), indent=1)
 print(workload, json.dumps({k: summary[k] for k in ("hbm_traffic_bytes_per_step", "instructions_per_step", "step_period_from_trace") if k in summary}))
 for r in summary.get("kernel_stats", [])[:8]:
