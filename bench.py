@@ -152,7 +152,7 @@ def committed_profile(workload):
                 valu += m.get("SQ_INSTS_VALU", 0.0)
                 salu += m.get("SQ_INSTS_SALU", 0.0)
     out["valu_per_step"], out["salu_per_step"] = (valu or None), (salu or None)
-    out["clock_ghz"] = (d.get("clock_under_load") or {}).get("ghz_weighted_long_kernels")
+    out["clock_ghz"] = (d.get("clock_in_counter_pass") or {}).get("ghz_weighted_long_kernels")
     return out
 
 
@@ -374,11 +374,9 @@ def roofline_block(workload, n_local, kern_ms, span_mode, fused):
                      "valu_per_voice_frame": wi * 64.0 / (n_local * FRAMES) if n_local else None,
                      "spec_issue_rate": VALU_ISSUE_PER_S, "spec_issue_rate_unit": "wave64 VALU instructions/s (1,024 SIMD-32 x 2.4 GHz / 2 clk)",
                      "achieved_frac": wi / (kern_ms * 1e-3) / VALU_ISSUE_PER_S,
-                     # the clock the chip held under the render kernels in the committed PMC pass (GRBM_GUI_ACTIVE / 8 XCDs /
-                     # kernel time, MI355X_MICROARCH.md "DVFS give-back"), and the same fraction against the issue rate at THAT clock
-                     "clock_ghz_under_load": prof.get("clock_ghz"),
-                     "achieved_frac_at_that_clock": (wi / (kern_ms * 1e-3) / (VALU_ISSUE_PER_S * prof["clock_ghz"] / 2.4)
-                                                     if prof.get("clock_ghz") else None),
+                     # the clock the render kernels held in the committed GRBM counter pass, where they run one at a time
+                     # (GRBM_GUI_ACTIVE / 8 XCDs / dispatch time; MI355X_MICROARCH.md "DVFS give-back"): the spec clock holds
+                     "clock_ghz_in_counter_pass": prof.get("clock_ghz"),
                      "note": "at the spec rate every instruction is a 2-cycle fp32 one; a retuning Welsh frame's mix (16 f64, 9 conversions, "
                              "3 transcendentals of ~86) needs ~1.35x that, DESIGN.md section 5",
                      "source": prof.get("source")}

@@ -12,7 +12,7 @@ out, rnd, workload = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3
 os.makedirs("profiles", exist_ok=True)
 summary = {"round": rnd, "workload": workload,
            "command": f"python3 bench.py --workload {workload} --no-cpu-baseline --no-configs --no-parity --repeats 1   (defaults: --gpus 1 --steps 172 --warmup 4)"}
-STEP_KERNELS = ("render", "welsh_tp", "partial_", "mix_", "fx_", "block_", "_events_")   # what one step of the hot path launches
+STEP_KERNELS = ("render", "_tp_kernel", "partial_", "mix_", "fx_", "block_", "_events_")   # what one step of the hot path launches
 
 ks = glob.glob(f"{out}/kt/*/*_kernel_stats.csv")
 if ks:
@@ -51,9 +51,11 @@ def counters(sub):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0][-70:]
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if r.get("Start_Timestamp") and r.get("End_Timestamp"):
+                agg[k]["_duration_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
             meta[k] = {"vgpr": r.get("VGPR_Count"), "sgpr": r.get("SGPR_Count"), "lds": r.get("LDS_Block_Size"),
                        "scratch": r.get("Scratch_Size"), "grid": r.get("Grid_Size"), "wg": r.get("Workgroup_Size")}
-    return {k: {"mean_per_dispatch": {c: sum(v) / len(v) for c, v in cs.items()}, "dispatches": max(len(v) for v in cs.values()),
+    return {k: {"mean_per_dispatch": {c: sum(v) / len(v) for c, v in cs.items()}, "dispatches": max(len(v) for c, v in cs.items() if not c.startswith("_")),
                 **meta[k]} for k, cs in agg.items() if "rocclr" not in k}
 
 
@@ -82,20 +84,21 @@ summary["hbm_traffic_bytes_per_step"] = {"write": w, "fetch_raw": f, "fetch_x2_g
 summary["instructions_per_step"] = {"valu_wave_insts": per_step("sq", "SQ_INSTS_VALU"), "salu_wave_insts": per_step("sq", "SQ_INSTS_SALU"),
                                     "note": "SQ_INSTS_VALU / SQ_INSTS_SALU summed over the step's kernels (wave-level instructions)"}
 # The clock the chip held under each kernel (MI355X_MICROARCH.md, DVFS give-back): GRBM_GUI_ACTIVE is summed over the 8
-# XCDs, so clock = GRBM_GUI_ACTIVE / 8 / the kernel's average duration (reads high on dispatches well under 0.3 ms).
-if ks:
-    dur = {r["Name"].split("(")[0][-70:]: float(r["AverageNs"]) for r in csv.DictReader(open(ks[0]))}
-    clocks = {}
-    for k, v in summary.get("grbm", {}).items():
-        g = v["mean_per_dispatch"].get("GRBM_GUI_ACTIVE")
-        if g and dur.get(k):
-            clocks[k] = {"avg_us": dur[k] / 1e3, "clock_ghz": g / 8.0 / dur[k]}
-    summary["clock_under_load"] = {"per_kernel": clocks,
-                                   "note": "GRBM_GUI_ACTIVE / 8 XCDs / average kernel duration; kernels shorter than ~0.3 ms read high"}
-    long_ones = [c for c in clocks.values() if c["avg_us"] >= 150.0]
+# XCDs, so clock = GRBM_GUI_ACTIVE / 8 / the dispatch's duration IN THE SAME PASS (a counter pass runs the kernels one
+# at a time, so these are a kernel's own cycles and its own time — NOT the clock of the real run, where four render kernels
+# share the chip; the quotient reads high on dispatches well under 0.3 ms).
+clocks = {}
+for k, v in summary.get("grbm", {}).items():
+    g, d = v["mean_per_dispatch"].get("GRBM_GUI_ACTIVE"), v["mean_per_dispatch"].get("_duration_ns")
+    if g and d:
+        clocks[k] = {"avg_us_alone": d / 1e3, "clock_ghz": g / 8.0 / d}
+if clocks:
+    summary["clock_in_counter_pass"] = {"per_kernel": clocks,
+                                   "note": "GRBM_GUI_ACTIVE / 8 XCDs / the dispatch's duration in the counter pass (kernels run one at a time there); kernels shorter than ~0.3 ms read high"}
+    long_ones = [c for c in clocks.values() if c["avg_us_alone"] >= 100.0]
     if long_ones:
-        tot = sum(c["avg_us"] for c in long_ones)
-        summary["clock_under_load"]["ghz_weighted_long_kernels"] = sum(c["clock_ghz"] * c["avg_us"] for c in long_ones) / tot
+        tot = sum(c["avg_us_alone"] for c in long_ones)
+        summary["clock_in_counter_pass"]["ghz_weighted_long_kernels"] = sum(c["clock_ghz"] * c["avg_us_alone"] for c in long_ones) / tot
 json.dump(summary, open(f"profiles/{rnd}_{workload}_summary.json", "w"), indent=1)
 print(workload, json.dumps({k: summary[k] for k in ("hbm_traffic_bytes_per_step", "instructions_per_step", "step_period_from_trace") if k in summary}))
 for r in summary.get("kernel_stats", [])[:8]:
