@@ -267,3 +267,42 @@ def test_chain_process_equals_stage_by_stage(gpu_ctx, n):
     for e in a + b:
         e.destroy()
     ba.destroy(); bb.destroy()
+
+
+def test_reverb_long_blocks_and_sample_rate_change(oracle):
+    """The direct all-pass form unrolls at most 8 hops per frame; a block longer than 8 x the shorter line (592 frames at
+    44.1 kHz) takes the chunk-parallel form with the comb sum written in place — same result.  And a sample-rate change
+    rebuilds the delay-line geometry (both copies of the all-pass rings): the effect then matches a fresh oracle effect
+    at the new rate."""
+    from groove_amd import entities as E
+    n = 12
+    ctx = E.Context(0)
+    try:
+        params = _params(n, attenuation=0.9, reverb_seconds=0.8)
+        sizes = [1024, 256, 700, 1024, 100]
+        x = _audio(n, sum(sizes), seed=5)
+        fx, ofx = E.Effect(ctx, T.FX_REVERB, params), oracle.Fx(T.FX_REVERB, params)
+        block = ctx.block(n, 1024)
+        pos = 0
+        for fr in sizes:
+            chunk = np.ascontiguousarray(x[:, pos:pos + fr, :])
+            block.upload(chunk)
+            fx.transform_audio(block, fr)
+            want = ofx.process(chunk.astype(np.float64))
+            assert np.max(np.abs(block.download(fr) - want)) <= 4e-6, (pos, fr)
+            pos += fr
+        ctx.update_sample_rate(48000)
+        ofx = oracle.Fx(T.FX_REVERB, params, sr=48000)
+        pos, peak = 0, 0.0
+        for fr in [256, 256, 300, 256, 256, 256, 256, 256, 256]:
+            chunk = np.ascontiguousarray(x[:, pos:pos + fr, :])
+            block.upload(chunk)
+            fx.transform_audio(block, fr)
+            want = ofx.process(chunk.astype(np.float64))
+            assert np.max(np.abs(block.download(fr) - want)) <= 4e-6, ("48k", pos)
+            peak = max(peak, float(np.max(np.abs(want))))
+            pos += fr
+        assert peak > 0.05  # (the shortest comb is 1,426 frames at 48 kHz: the tail starts in the sixth block)
+        fx.destroy(); block.destroy()
+    finally:
+        ctx.close()
