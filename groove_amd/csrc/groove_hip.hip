@@ -147,7 +147,7 @@ struct groove_ctx {
   bool need_fork = true;                // ctx-stream work since the last fork that side streams must wait for
   uint32_t tp_max_voices = kTpMaxVoices; // Welsh banks up to this size render time-parallel (welsh_tp.h); GROOVE_TP_MAX_VOICES overrides, 0 = never
   uint32_t fx_tp_max_lanes = 4096;       // IIR effect banks of up to this many lane-channels (half as many for the 24 dB low-pass) run time-parallel (fx_tp.h: measured crossovers, tools/fx_bench.py); GROOVE_FX_TP_MAX_LANES
-  uint32_t pipeline_min_waves = 4700;   // banks at least this long (~300,000 voices) run one kernel per base kind and pipeline their fused blocks; smaller ones take the all-kinds kernel
+  uint32_t pipeline_min_waves = 8600;   // banks at least this long (~550,000 voices) run one kernel per base kind and pipeline their fused blocks; smaller ones take the all-kinds kernel (round 2, blocks 5-44 of the timeline: 300,000 voices 0.275 -> 0.250 ms per block, 500,000 0.357 -> 0.342; 600,000 0.372 against 0.400)
   // How many of the bank streams exist and are handed out (GROOVE_BANK_STREAMS).  Three: with the ctx stream and the four
   // kind streams that is eight streams; a ninth lands on a hardware queue that already carries one of the others, and a
   // project with a bank on it ran three times slower (mixed-131072: 0.12 -> 0.39 ms per block whenever a bank had the
@@ -1431,9 +1431,10 @@ int groove_bank_render_mix(groove_bank* b, uint32_t frames, float* bus_dev, int 
   GHIP(ctx, hipSetDevice(ctx->device));
   if (flush_events(b, use_tp(b, frames))) return 1;
   // Asynchronous form (kernels on side streams, only the bus reductions on the ctx stream):
-  //  - a large Welsh bank (>= ~300,000 voices) runs one kernel per base kind and pipelines its own blocks
-  //    (+15 % at 1,000,000 voices, +21 % at 500,000); below that a block is latency-bound and the
-  //    all-kinds kernel wins (250,000 voices: 0.265 ms against 0.306; 125,000: 0.233 against 0.276);
+  //  - a large Welsh bank (>= ~550,000 voices) runs one kernel per base kind and pipelines its own blocks
+  //    (+11 % at 1,000,000 voices, +7 % at 600,000); below that the all-kinds kernel wins, run block after block on the
+  //    ctx stream (500,000 voices: 0.342 ms against 0.357; 300,000: 0.250 against 0.275; through the block pipeline
+  //    it is no faster: 250,000 voices 0.222 against 0.215);
   //  - in a project of several banks (synths, samplers) every bank takes it, so that the banks of one block
   //    run beside each other instead of one after the other (mixed-131072: 0.46 -> 0.2x ms per block).
   const bool force = ctx->pipeline_min_waves <= 1;
