@@ -155,6 +155,7 @@ struct groove_ctx {
   int bank_streams = 3;
   int next_stream_slot = 0;             // round-robin side-stream assignment of single-kernel banks
   uint32_t fm_tp_max_voices = kFmTpMaxVoices; // GROOVE_FM_TP_MAX_VOICES
+  uint32_t fx_seg_max_lanes = 49152;     // biquad banks of up to this many lane-channels take the four-segment kernel (measured, tools/fx_bench.py: 8,192 lane-channels 17.5 -> 9.3 us, 32,768 19.4 -> 15.6, 131,072 42.9 -> 58.4; GROOVE_FX_SEG_MAX_LANES, 0 = never)
   uint32_t fx_tp_wide_min_lanes = 8192;  // from this many lane-channels the time-parallel IIR kernels take 32-wide tiles (GROOVE_FX_TP_WIDE_MIN_LANES)
   bool seq_allpass = false;             // GROOVE_FX_SEQ_ALLPASS=1: the sequential all-pass kernel (A/B and bit-identity tests)
   bool chunked_allpass = false;         // GROOVE_FX_CHUNKED_ALLPASS=1: the chunk-parallel all-pass kernel instead of the direct one
@@ -778,6 +779,7 @@ int groove_init(int device_ordinal, groove_ctx** out) {
   if (const char* e = std::getenv("GROOVE_FX_SEQ_ALLPASS")) ctx->seq_allpass = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_BANK_STREAMS")) ctx->bank_streams = std::max(1, std::min(kBankStreams, std::atoi(e)));
   if (const char* e = std::getenv("GROOVE_FM_TP_MAX_VOICES")) ctx->fm_tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
+  if (const char* e = std::getenv("GROOVE_FX_SEG_MAX_LANES")) ctx->fx_seg_max_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_TP_WIDE_MIN_LANES")) ctx->fx_tp_wide_min_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_CHUNKED_ALLPASS")) ctx->chunked_allpass = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_TP_MAX_VOICES")) ctx->tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
@@ -1640,6 +1642,8 @@ static int fx_launch_serial(groove_fx* fx, groove_block* io, uint32_t frames) {
         if (2 * (size_t)n >= ctx->fx_tp_wide_min_lanes) hipLaunchKernelGGL(fx_biquad_tp_kernel<kFxTileWide>, dim3((n + kFxTileWide - 1) / kFxTileWide, 2), dim3(kFxTpThreads), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
         else hipLaunchKernelGGL(fx_biquad_tp_kernel<kFxTile>, dim3((n + kFxTile - 1) / kFxTile, 2), dim3(kFxTpThreads), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       }
+      else if (frames <= (uint32_t)(kBqSegs * kBqSegMax) && frames >= 16 && 2 * (size_t)n <= ctx->fx_seg_max_lanes) // four time segments per lane-channel
+        hipLaunchKernelGGL(fx_biquad_seg_kernel, dim3((2 * n + 63) / 64), blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       else
         hipLaunchKernelGGL(fx_biquad_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       break;

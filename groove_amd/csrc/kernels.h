@@ -798,6 +798,89 @@ __global__ __launch_bounds__(kThreads) void fx_biquad_kernel(
   }
   st[t] = s.x1; st[ln + t] = s.x2; st[2 * ln + t] = s.y1; st[3 * ln + t] = s.y2;
 }
+// The same biquad with the block cut into FOUR time segments per lane-channel (blocks of up to 256 frames).  A bank of
+// thousands of lanes is a few hundred wavefronts walking 256 dependent frames each (two f64 operations of latency per
+// frame, ~9 us, whatever else the chip could be doing); the recurrence is linear, so a segment can be run from a ZERO
+// output state together with the two basis responses of the homogeneous part (three independent chains: they fill
+// each other's latency), the four segments' true start states follow from four 2x2 products, and a second sweep runs
+// each segment's recurrence again — biquad_step's operations in their order — from its true start state and stores.
+// A workgroup is 64 adjacent lane-channels x 4 segments (wave = segment, so every load and store is a coalesced row);
+// the hand-over goes through LDS.  The second sweep's start state agrees with the serial walk's to f64 rounding, so
+// the fp32 outputs are the serial kernel's except where a value sits within 1e-16 of a rounding boundary.
+constexpr int kBqSegs = 4, kBqSegMax = 64; // 4 x 64 = 256 frames
+struct BqSegEnds { double z1, z2, u1, u2, v1, v2; };
+// FULL: the segment holds kBqSegMax frames (straight-line code); otherwise `cnt` of them (predicated)
+template <bool FULL>
+__device__ __forceinline__ BqSegEnds bq_seg_sweep1(const BiquadCoefD& c, const float (&x)[kBqSegMax], uint32_t cnt, double x1, double x2) {
+  BqSegEnds e{0.0, 0.0, 1.0, 0.0, 0.0, 1.0};
+#pragma unroll
+  for (int j = 0; j < kBqSegMax; ++j) {
+    if (FULL || (uint32_t)j < cnt) {
+      const double xd = (double)x[j];
+      const double ff = c.b0 * xd + c.b1 * x1 + c.b2 * x2;
+      const double zn = ff - c.a1 * e.z1 - c.a2 * e.z2;
+      const double un = -c.a1 * e.u1 - c.a2 * e.u2, vn = -c.a1 * e.v1 - c.a2 * e.v2;
+      e.z2 = e.z1; e.z1 = zn; e.u2 = e.u1; e.u1 = un; e.v2 = e.v1; e.v1 = vn;
+      x2 = x1; x1 = xd;
+    }
+  }
+  return e;
+}
+template <bool FULL>
+__device__ __forceinline__ void bq_seg_sweep2(const BiquadCoefD& c, const float (&x)[kBqSegMax], uint32_t cnt, float w, bool live,
+                                              float* __restrict__ out, uint32_t n, BiquadStateD& s) {
+#pragma unroll
+  for (int j = 0; j < kBqSegMax; ++j) {
+    if (FULL || (uint32_t)j < cnt) {
+      float y = (float)biquad_step(s, c, (double)x[j]);
+      if (w < 1.0f) y = fmaf(y, w, x[j] * (1.0f - w));
+      if (live) out[(size_t)j * n] = y;
+    }
+  }
+}
+__global__ __launch_bounds__(kThreads) void fx_biquad_seg_kernel(
+    float* __restrict__ data, uint32_t n, uint32_t frames, size_t ch_stride,
+    const double* __restrict__ coef, double* __restrict__ st, const float* __restrict__ wet) {
+  __shared__ double s_end[kBqSegs][6][64]; // per segment: zero-state (y1, y2) at its end, then M = [[u1, v1], [u2, v2]]
+  const uint32_t lane = threadIdx.x & 63u, seg = threadIdx.x >> 6;
+  const uint32_t t = blockIdx.x * 64 + lane;
+  const bool live = t < 2 * n;
+  const uint32_t tt = live ? t : 2 * n - 1;
+  const uint32_t ch = tt / n, ln_ = tt % n;
+  const size_t ln = 2 * (size_t)n;
+  const uint32_t L = (frames + kBqSegs - 1) / kBqSegs;          // frames per segment (<= 64)
+  const uint32_t f_lo = min(seg * L, frames), f_hi = min(f_lo + L, frames), cnt = f_hi - f_lo;
+  const BiquadCoefD c{coef[ln_], coef[(size_t)n + ln_], coef[(size_t)2 * n + ln_], coef[(size_t)3 * n + ln_], coef[(size_t)4 * n + ln_]};
+  const float w = wet[ln_];
+  float* __restrict__ ptr = data + ch * ch_stride + ln_;
+  // Everything this thread reads of the block and of the state is read BEFORE the barrier: the other segments' threads
+  // overwrite the frames in front of this segment, and the last segment's thread the state, after it.
+  float x[kBqSegMax];
+#pragma unroll
+  for (int j = 0; j < kBqSegMax; ++j) x[j] = (uint32_t)j < cnt ? ptr[(size_t)(f_lo + j) * n] : 0.0f;
+  const double sx1 = st[tt], sx2 = st[ln + tt];
+  double y1 = st[2 * ln + tt], y2 = st[3 * ln + tt];
+  // the two inputs before the segment: the block's own frames, or the state's (x1, x2) in front of the block
+  const double px1 = (f_lo >= 1 && cnt) ? (double)ptr[(size_t)(f_lo - 1) * n] : sx1;
+  const double px2 = (f_lo >= 2 && cnt) ? (double)ptr[(size_t)(f_lo - 2) * n] : (f_lo == 1 ? sx1 : sx2);
+  // sweep 1: zero-state response and the homogeneous basis (u: start (1, 0), v: start (0, 1)), ends only
+  const BqSegEnds e = cnt == (uint32_t)kBqSegMax ? bq_seg_sweep1<true>(c, x, cnt, px1, px2) : bq_seg_sweep1<false>(c, x, cnt, px1, px2);
+  s_end[seg][0][lane] = e.z1; s_end[seg][1][lane] = e.z2;
+  s_end[seg][2][lane] = e.u1; s_end[seg][3][lane] = e.v1; s_end[seg][4][lane] = e.u2; s_end[seg][5][lane] = e.v2;
+  __syncthreads();
+  // this segment's true start state: through the earlier segments, in order
+  for (uint32_t k = 0; k < seg; ++k) {
+    const double n1 = s_end[k][0][lane] + s_end[k][2][lane] * y1 + s_end[k][3][lane] * y2;
+    const double n2 = s_end[k][1][lane] + s_end[k][4][lane] * y1 + s_end[k][5][lane] * y2;
+    y1 = n1; y2 = n2;
+  }
+  // sweep 2: the recurrence itself (biquad_step), from that state
+  BiquadStateD s{px1, px2, y1, y2};
+  if (cnt == (uint32_t)kBqSegMax) bq_seg_sweep2<true>(c, x, cnt, w, live, ptr + (size_t)f_lo * n, n, s);
+  else bq_seg_sweep2<false>(c, x, cnt, w, live, ptr + (size_t)f_lo * n, n, s);
+  // the segment that holds the block's last frame leaves the state
+  if (live && cnt && f_hi == frames) { st[tt] = s.x1; st[ln + tt] = s.x2; st[2 * ln + tt] = s.y1; st[3 * ln + tt] = s.y2; }
+}
 template <int C>
 __global__ __launch_bounds__(kThreads) void fx_lp24_kernel(
     float* __restrict__ data, uint32_t n, uint32_t frames, size_t ch_stride,
