@@ -538,16 +538,26 @@ __global__ __launch_bounds__(kThreads) void partial_rows_kernel(
   const uint32_t c = blockIdx.x * kThreads + threadIdx.x;
   if (c >= cols) return;
   const uint32_t r0 = blockIdx.y * rows_per_seg, r1 = min(rows, r0 + rows_per_seg);
-  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+  // sixteen independent accumulators: a 64-row segment is four rounds of sixteen loads in flight (with four it was
+  // sixteen dependent rounds, 6 us for a bank whose whole reduction is one segment)
+  float a[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] = 0.0f;
   uint32_t r = r0;
-  for (; r + 4 <= r1; r += 4) {
-    a0 += partial[(size_t)r * cols + c];
-    a1 += partial[(size_t)(r + 1) * cols + c];
-    a2 += partial[(size_t)(r + 2) * cols + c];
-    a3 += partial[(size_t)(r + 3) * cols + c];
+  for (; r + 16 <= r1; r += 16) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] += partial[(size_t)(r + k) * cols + c];
   }
-  for (; r < r1; ++r) a0 += partial[(size_t)r * cols + c];
-  const float t = (a0 + a1) + (a2 + a3);
+  for (; r + 4 <= r1; r += 4) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] += partial[(size_t)(r + k) * cols + c];
+  }
+  for (; r < r1; ++r) a[0] += partial[(size_t)r * cols + c];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] += a[k + 8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) a[k] += a[k + 4];
+  const float t = (a[0] + a[1]) + (a[2] + a[3]);
   if (bus) { // a single segment: this IS the column total (what partial_final_kernel would add up and write)
     const uint32_t frames = cols / 2, ch = c / frames, f = c % frames;
     if (accumulate) bus[2 * f + ch] += t; else bus[2 * f + ch] = t;
