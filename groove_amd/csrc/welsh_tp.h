@@ -527,63 +527,108 @@ __global__ __launch_bounds__(kTpThreads) void fm_tp_kernel(TpArgs a) {
   }
 }
 // SamplerVoice: pointer stepping is a closed form in the frame index (idx0 + k * step, Q20.44), so a voice's block is a
-// pure gather: one wavefront per voice, 64 lanes x 4 frames, every fetch of the block in flight at once (the serial form
-// walks 256 frames in chunks of 16 fetches: 45 us for a one-wave-per-SIMD bank).  Exact, like the serial form.
+// pure gather (the serial form walks 256 frames in chunks of 16 fetches: 45 us for a one-wave-per-SIMD bank).  Exact,
+// like the serial form.  A wavefront takes `vpw` ADJACENT voices (<= 64), one after the other, its 64 lanes x 4 frames
+// each time: the voices' parameters and state are read and written lane-parallel (lane l = the wave's l-th voice:
+// coalesced rows, one round trip), handed to the loop by v_readlane, and the voices' fetches are independent, so
+// several voices' gathers are in flight together.  Sixteen waves per workgroup and vpw = ceil(n / 1024): a bank of any
+// size up to 65,536 voices leaves at most 64 partial rows, which the bus reduction sums in ONE launch (config #4:
+// render + two reduction launches -> render + one).
 constexpr uint32_t kSamplerTpMaxVoices = 65536;
+inline uint32_t sampler_tp_vpw(uint32_t n) { return n <= 1024 ? 1u : (n + 1023) / 1024; }
+inline uint32_t sampler_tp_workgroups(uint32_t n) { const uint32_t per = kSamplerTpWaves * sampler_tp_vpw(n); return (n + per - 1) / per; }
 template <bool FUSED>
-__global__ __launch_bounds__(kSamplerTpThreads) void sampler_tp_kernel(TpArgs a, const float* __restrict__ bank, InlineEvents ie) {
+__global__ __launch_bounds__(kSamplerTpThreads) void sampler_tp_kernel(TpArgs a, const float* __restrict__ bank, InlineEvents ie, uint32_t vpw) {
   __shared__ float s_tile[kSamplerTpWaves][kTpMaxFrames];
+  __shared__ volatile uint32_t s_ev[kSamplerTpWaves][64]; // volatile: lanes read what OTHER lanes of the wave wrote, with no barrier the compiler knows of
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint32_t v0 = blockIdx.x * kSamplerTpWaves + wave;
-  const bool voice = v0 < a.n;
-  const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(voice ? v0 : a.n - 1));
   const uint32_t frames = a.frames, n = a.n;
-  const SamplerParams p = make_scalar(soa_load<SamplerParams>(a.params, n, v));
-  SamplerState s0 = make_scalar(soa_load<SamplerState>(a.state, n, v));
-  if (ie.n) { // this block's note events: is one of them this voice's?
+  const uint32_t v_begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * kSamplerTpWaves + wave) * vpw));
+  const uint32_t cnt = v_begin < n ? min(vpw, n - v_begin) : 0u; // this wave's voices (wave-uniform)
+  // lane l < cnt: voice v_begin + l
+  const bool mine = lane < cnt;
+  const uint32_t v = mine ? v_begin + lane : (n - 1);
+  const SamplerParams p = soa_load<SamplerParams>(a.params, n, v);
+  SamplerState s0 = soa_load<SamplerState>(a.state, n, v);
+  if (ie.n && cnt) { // this block's note events (strictly increasing voices): those of this wave's voice range
     uint32_t lo = 0, hi = ie.n;
-    while (lo < hi) {
+    while (lo < hi) { // first event at or after v_begin (scalar loads)
       const uint32_t mid = (lo + hi) >> 1;
-      if (ie.ev[mid].voice < v) lo = mid + 1; else hi = mid;
+      if (ie.ev[mid].voice < v_begin) lo = mid + 1; else hi = mid;
     }
-    if (lo < ie.n && ie.ev[lo].voice == v) sampler_note(p, s0, ie.ev[lo].key, ie.ev[lo].on != 0);
+    s_ev[wave][lane] = 0u;
+    if (lo + lane < ie.n) { // at most cnt <= 64 of them fall into the range: one event per lane, scattered to its voice's lane
+      const groove_note_event e = ie.ev[lo + lane];
+      if (e.voice - v_begin < cnt) s_ev[wave][e.voice - v_begin] = 0x10000u | ((uint32_t)(e.on != 0) << 8) | e.key;
+    }
+    __builtin_amdgcn_wave_barrier(); // (scheduling fence; a wave's LDS operations complete in issue order)
+    const uint32_t got = s_ev[wave][lane];
+    if (mine && (got & 0x10000u)) sampler_note(p, s0, got & 0xFFu, (got >> 8) & 1u);
+  }
+  // frames of the block this lane's voice plays: a prefix, the index only moves forward
+  uint32_t valid = 0;
+  if (mine && s0.playing && frames) {
+    const uint64_t lim = (uint64_t)p.length << 44;
+    if (s0.idx < lim) {
+      const uint64_t room = lim - s0.idx - 1; // idx + f * step <= lim - 1
+      const uint64_t fmax = s0.step ? room / s0.step : (uint64_t)frames;
+      valid = fmax >= frames ? frames : (uint32_t)fmax + 1u;
+    }
   }
   const uint32_t n0 = lane * kTpChunk;
-  float x[kTpChunk];
-  uint32_t mine = 0; // frames of this lane that play
+  float acc[kTpChunk];
 #pragma unroll
-  for (uint32_t j = 0; j < kTpChunk; ++j) {
-    const uint32_t f = n0 + j;
-    const uint32_t i = (uint32_t)((s0.idx + (uint64_t)f * s0.step) >> 44);
-    const bool ok = s0.playing && f < frames && i < p.length;
-    const float raw = bank[(size_t)p.offset + (i < p.length ? i : p.length - 1)];
-    x[j] = ok ? raw * p.gain : 0.0f;
-    mine += ok ? 1u : 0u;
-  }
-  // valid frames of the block (they are a prefix: the index only moves forward)
-  uint32_t valid = mine;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) valid += (uint32_t)__shfl_xor((int)valid, off, 64);
-#pragma unroll
-  for (uint32_t j = 0; j < kTpChunk; ++j) s_tile[wave][n0 + j] = voice ? x[j] : 0.0f;
-  __syncthreads();
-  for (uint32_t t = threadIdx.x; t < frames; t += kSamplerTpThreads) {
-    float acc = 0.0f;
-#pragma unroll
-    for (int w = 0; w < kSamplerTpWaves; ++w) acc += s_tile[w][t];
-    a.rows[((size_t)blockIdx.x * 2 + 0) * frames + t] = acc; // mono voices: the same sum on both channels
-    a.rows[((size_t)blockIdx.x * 2 + 1) * frames + t] = acc;
-  }
-  if (!FUSED && voice) {
+  for (uint32_t j = 0; j < kTpChunk; ++j) acc[j] = 0.0f;
+  const uint32_t idx_lo = (uint32_t)s0.idx, idx_hi = (uint32_t)(s0.idx >> 32), step_lo = (uint32_t)s0.step, step_hi = (uint32_t)(s0.step >> 32);
+  for (uint32_t k = 0; k < cnt; ++k) { // k is wave-uniform: v_readlane
+    const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)p.offset, (int)k), len = (uint32_t)__builtin_amdgcn_readlane((int)p.length, (int)k);
+    const float gain = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p.gain), (int)k));
+    const uint64_t idx = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)idx_hi, (int)k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)idx_lo, (int)k);
+    const uint64_t step = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)step_hi, (int)k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)step_lo, (int)k);
+    const uint32_t playing = (uint32_t)__builtin_amdgcn_readlane((int)s0.playing, (int)k);
+    if (!playing) continue; // (uniform)
+    float x[kTpChunk];
 #pragma unroll
     for (uint32_t j = 0; j < kTpChunk; ++j) {
-      if (n0 + j < frames) {
-        a.out[(size_t)(n0 + j) * n + v] = x[j];
-        a.out[a.ch_stride + (size_t)(n0 + j) * n + v] = x[j];
+      const uint32_t f = n0 + j;
+      const uint32_t i = (uint32_t)((idx + (uint64_t)f * step) >> 44);
+      const bool ok = f < frames && i < len;
+      const float raw = bank[(size_t)off + (i < len ? i : len - 1)];
+      x[j] = ok ? raw * gain : 0.0f;
+      acc[j] += x[j];
+    }
+    if (!FUSED) {
+      const uint32_t vk = v_begin + k;
+#pragma unroll
+      for (uint32_t j = 0; j < kTpChunk; ++j) {
+        if (n0 + j < frames) {
+          a.out[(size_t)(n0 + j) * n + vk] = x[j];
+          a.out[a.ch_stride + (size_t)(n0 + j) * n + vk] = x[j];
+        }
       }
     }
   }
-  if (voice && lane == 0 && frames) {
+  if (!FUSED) { // voices that do not play still own their columns of the block
+    for (uint32_t k = 0; k < cnt; ++k) {
+      if (__builtin_amdgcn_readlane((int)s0.playing, (int)k)) continue;
+      const uint32_t vk = v_begin + k;
+#pragma unroll
+      for (uint32_t j = 0; j < kTpChunk; ++j) {
+        if (n0 + j < frames) { a.out[(size_t)(n0 + j) * n + vk] = 0.0f; a.out[a.ch_stride + (size_t)(n0 + j) * n + vk] = 0.0f; }
+      }
+    }
+  }
+#pragma unroll
+  for (uint32_t j = 0; j < kTpChunk; ++j) s_tile[wave][n0 + j] = acc[j];
+  __syncthreads();
+  for (uint32_t t = threadIdx.x; t < frames; t += kSamplerTpThreads) {
+    float sum = 0.0f;
+#pragma unroll
+    for (int w = 0; w < kSamplerTpWaves; ++w) sum += s_tile[w][t];
+    a.rows[((size_t)blockIdx.x * 2 + 0) * frames + t] = sum; // mono voices: the same sum on both channels
+    a.rows[((size_t)blockIdx.x * 2 + 1) * frames + t] = sum;
+  }
+  if (mine && frames) {
     SamplerState s = s0;
     s.idx = s0.idx + (uint64_t)valid * s0.step;
     if (s0.playing && valid < frames) s.playing = 0; // ran off the end inside the block
@@ -594,7 +639,6 @@ void launch_welsh_tp(const TpArgs& a, hipStream_t st, bool fused);
 void launch_fm_tp(const TpArgs& a, hipStream_t st, bool fused);
 void launch_sampler_tp(const TpArgs& a, const float* bank, const InlineEvents& ie, hipStream_t st, bool fused);
 inline uint32_t welsh_tp_workgroups(uint32_t n) { return (n + kTpWaves - 1) / kTpWaves; }
-inline uint32_t sampler_tp_workgroups(uint32_t n) { return (n + kSamplerTpWaves - 1) / kSamplerTpWaves; }
 #endif // __HIPCC__
 
 } // namespace groove
