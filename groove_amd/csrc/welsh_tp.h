@@ -580,30 +580,50 @@ __global__ __launch_bounds__(kSamplerTpThreads) void sampler_tp_kernel(TpArgs a,
 #pragma unroll
   for (uint32_t j = 0; j < kTpChunk; ++j) acc[j] = 0.0f;
   const uint32_t idx_lo = (uint32_t)s0.idx, idx_hi = (uint32_t)(s0.idx >> 32), step_lo = (uint32_t)s0.step, step_hi = (uint32_t)(s0.step >> 32);
-  for (uint32_t k = 0; k < cnt; ++k) { // k is wave-uniform: v_readlane
-    const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)p.offset, (int)k), len = (uint32_t)__builtin_amdgcn_readlane((int)p.length, (int)k);
-    const float gain = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p.gain), (int)k));
-    const uint64_t idx = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)idx_hi, (int)k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)idx_lo, (int)k);
-    const uint64_t step = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)step_hi, (int)k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)step_lo, (int)k);
-    const uint32_t playing = (uint32_t)__builtin_amdgcn_readlane((int)s0.playing, (int)k);
-    if (!playing) continue; // (uniform)
-    float x[kTpChunk];
+  constexpr uint32_t U = 4; // voices whose fetches are issued together
+  for (uint32_t k0 = 0; k0 < cnt; k0 += U) { // k is wave-uniform: v_readlane
+    uint32_t off[U], len[U], playing[U];
+    float gain[U];
+    uint64_t idx[U], step[U];
+    uint32_t any = 0;
 #pragma unroll
-    for (uint32_t j = 0; j < kTpChunk; ++j) {
-      const uint32_t f = n0 + j;
-      const uint32_t i = (uint32_t)((idx + (uint64_t)f * step) >> 44);
-      const bool ok = f < frames && i < len;
-      const float raw = bank[(size_t)off + (i < len ? i : len - 1)];
-      x[j] = ok ? raw * gain : 0.0f;
-      acc[j] += x[j];
+    for (uint32_t u = 0; u < U; ++u) {
+      const int k = (int)min(k0 + u, cnt - 1);
+      off[u] = (uint32_t)__builtin_amdgcn_readlane((int)p.offset, k);
+      len[u] = (uint32_t)__builtin_amdgcn_readlane((int)p.length, k);
+      gain[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p.gain), k));
+      idx[u] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)idx_hi, k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)idx_lo, k);
+      step[u] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)step_hi, k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)step_lo, k);
+      playing[u] = k0 + u < cnt ? (uint32_t)__builtin_amdgcn_readlane((int)s0.playing, k) : 0u;
+      any |= playing[u];
     }
-    if (!FUSED) {
-      const uint32_t vk = v_begin + k;
+    if (!any) continue; // (uniform)
+    float raw[U][kTpChunk];
+    bool ok[U][kTpChunk];
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) {
 #pragma unroll
       for (uint32_t j = 0; j < kTpChunk; ++j) {
-        if (n0 + j < frames) {
-          a.out[(size_t)(n0 + j) * n + vk] = x[j];
-          a.out[a.ch_stride + (size_t)(n0 + j) * n + vk] = x[j];
+        const uint32_t f = n0 + j;
+        const uint32_t i = (uint32_t)((idx[u] + (uint64_t)f * step[u]) >> 44);
+        ok[u][j] = playing[u] && f < frames && i < len[u];
+        raw[u][j] = bank[(size_t)off[u] + (i < len[u] ? i : len[u] - 1)];
+      }
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) { // accumulated voice by voice, in voice order
+      if (!playing[u]) continue;
+      float x[kTpChunk];
+#pragma unroll
+      for (uint32_t j = 0; j < kTpChunk; ++j) { x[j] = ok[u][j] ? raw[u][j] * gain[u] : 0.0f; acc[j] += x[j]; }
+      if (!FUSED) {
+        const uint32_t vk = v_begin + k0 + u;
+#pragma unroll
+        for (uint32_t j = 0; j < kTpChunk; ++j) {
+          if (n0 + j < frames) {
+            a.out[(size_t)(n0 + j) * n + vk] = x[j];
+            a.out[a.ch_stride + (size_t)(n0 + j) * n + vk] = x[j];
+          }
         }
       }
     }
