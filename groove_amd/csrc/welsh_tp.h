@@ -531,11 +531,11 @@ __global__ __launch_bounds__(kTpThreads) void fm_tp_kernel(TpArgs a) {
 // like the serial form.  A wavefront takes `vpw` ADJACENT voices (<= 64), one after the other, its 64 lanes x 4 frames
 // each time: the voices' parameters and state are read and written lane-parallel (lane l = the wave's l-th voice:
 // coalesced rows, one round trip), handed to the loop by v_readlane, and the voices' fetches are independent, so
-// several voices' gathers are in flight together.  Sixteen waves per workgroup and vpw = ceil(n / 1024): a bank of any
-// size up to 65,536 voices leaves at most 64 partial rows, which the bus reduction sums in ONE launch (config #4:
-// render + two reduction launches -> render + one).
+// several voices' gathers are in flight together.  Sixteen waves per workgroup and vpw = min(ceil(n / 1024), 16): a bank
+// of up to 16,384 voices leaves at most 64 partial rows, which the bus reduction sums in ONE launch (config #4: render +
+// two reduction launches -> render + one); bigger banks keep 16 voices per wave and more workgroups.
 constexpr uint32_t kSamplerTpMaxVoices = 65536;
-inline uint32_t sampler_tp_vpw(uint32_t n) { return n <= 1024 ? 1u : (n + 1023) / 1024; }
+inline uint32_t sampler_tp_vpw(uint32_t n) { return n <= 1024 ? 1u : std::min<uint32_t>((n + 1023) / 1024, 16u); } // (32 voices per wave for 32,768 voices: 38 us against ~20 with 16)
 inline uint32_t sampler_tp_workgroups(uint32_t n) { const uint32_t per = kSamplerTpWaves * sampler_tp_vpw(n); return (n + per - 1) / per; }
 template <bool FUSED>
 __global__ __launch_bounds__(kSamplerTpThreads) void sampler_tp_kernel(TpArgs a, const float* __restrict__ bank, InlineEvents ie, uint32_t vpw) {
