@@ -45,12 +45,14 @@ __device__ __forceinline__ void soa_store(uint32_t* __restrict__ buf, uint32_t n
     __builtin_amdgcn_raw_buffer_store_b32((int)t.w[i], rsrc, (int)(v * 4u), (int)(i * n * 4u), 0);
 }
 
-// Waves per SIMD each uniform-kernel kind is register-budgeted for (512 VGPRs / waves, in steps of 8).
+// Waves per SIMD each uniform-kernel kind is register-budgeted for (512 VGPRs / waves, in steps of 8).  Re-measured on
+// the un-packed code (-fno-slp-vectorize), 1,000,000 voices, in-job: F32 kinds 5 -> +1.8 % in the all-voices window
+// (+-0 over the project), 4 the same, 8 -> -12 %; smooth kinds 6 -> -3 %, 3 -> -10 %.
 #ifndef GROOVE_WAVES_F32_STATIC
-#define GROOVE_WAVES_F32_STATIC 6
+#define GROOVE_WAVES_F32_STATIC 5
 #endif
 #ifndef GROOVE_WAVES_F32_RETUNE
-#define GROOVE_WAVES_F32_RETUNE 6
+#define GROOVE_WAVES_F32_RETUNE 5
 #endif
 #ifndef GROOVE_WAVES_SMOOTH_STATIC
 #define GROOVE_WAVES_SMOOTH_STATIC 4
