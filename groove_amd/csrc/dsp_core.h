@@ -296,6 +296,9 @@ struct RenderConsts {
   // per-frame retune: x = pi fc / SR of fc = 25 * 800^pct is ONE exp2 with the constants folded into its argument
   float log2_x0;    // log2(25 pi / SR)
   float x_lo, x_hi; // pi / SR (fc = 1 Hz), 0.49 pi (fc = 0.49 SR): the clamp of fc, applied to x
+  // two addends of the retune's tangent polynomial: carried here so that a kernel can pin them in registers for the
+  // whole block (as literals the compiler re-materialises them with a v_mov on every frame)
+  float tan_k1 = 1.333961619e-01f, tan_k2 = 2.453938616e-02f;
 };
 GROOVE_HD RenderConsts render_consts(double sr) {
   RenderConsts rc;
@@ -393,8 +396,8 @@ GROOVE_HD Lp24CoefD lp24_coefd_from_pct(const Lp24Consts& c, float pct, const Re
   const float z = fminf(x, 1.57079632679489662f - x);
   // tan(z) = z P(z^2), the polynomial of tan_reduced by Estrin's scheme (four dependent steps instead of seven)
   const float w = z * z, w2 = w * w;
-  const float e0 = fmaf(3.333309016e-01f, w, 1.000000015e+00f), e1 = fmaf(5.336849955e-02f, w, 1.333961619e-01f);
-  const float e2 = fmaf(2.985451510e-03f, w, 2.453938616e-02f);
+  const float e0 = fmaf(3.333309016e-01f, w, 1.000000015e+00f), e1 = fmaf(5.336849955e-02f, w, rc.tan_k1);
+  const float e2 = fmaf(2.985451510e-03f, w, rc.tan_k2);
   const float w4 = w2 * w2;
   const float f0 = fmaf(e1, w2, e0), f1 = fmaf(9.449327447e-03f, w2, e2);
   const float t = fmaf(f1, w4, f0) * z;

@@ -381,7 +381,10 @@ __device__ __forceinline__ void welsh_uniform_body_impl(UniformArgsPtr a) {
   const bool active = (w0 < n_waves) && (lane < d.count);
   const uint32_t v = active ? d.vbase + lane : d.vbase; // idle lanes shadow the run's first voice
   WelshState s = soa_load<WelshState>(a->state, n, v);
-  const RenderConsts rc{a->rc.pi_over_sr, a->rc.fc_max, a->rc.log2_x0, a->rc.x_lo, a->rc.x_hi};
+  RenderConsts rc{a->rc.pi_over_sr, a->rc.fc_max, a->rc.log2_x0, a->rc.x_lo, a->rc.x_hi};
+  // pinned in VGPRs for the block: as literals / SGPRs each costs a v_mov on every retuning frame (the instructions
+  // that use them take one constant-bus operand): +2.5 % in the all-voices window of the million-voice project
+  if constexpr (RETUNE) asm volatile("" : "+v"(rc.tan_k1), "+v"(rc.tan_k2), "+v"(rc.log2_x0), "+v"(rc.x_hi));
   welsh_block<FUSED, RETUNE, LFO_MODE, true, C1, C2, CL, REST>(d.p, s, rc, a->frames, n, v, active, a->ch_stride, a->out, a->rows, wg);
   if (active) soa_store(a->state, n, v, s);
 }
