@@ -191,6 +191,14 @@ int fail(groove_ctx* ctx, const std::string& msg) {
       return fail(ctx, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
   } while (0)
 
+// Synchronous copies go through the CTX stream, never the null stream: the null stream is one more normal-priority
+// stream for the runtime to map, and with the four kind streams it made five on four hardware queues — the fourth kind
+// stream shared its queue with it (rocprofv3 trace, round 2).
+hipError_t ctx_memcpy(groove_ctx* ctx, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, ctx->stream);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(ctx->stream);
+}
 hipStream_t side_stream_of(groove_ctx* ctx, int k) {
   if (!ctx->side_stream[k] && hipStreamCreateWithFlags(&ctx->side_stream[k], hipStreamNonBlocking) != hipSuccess) {
     ctx->side_stream[k] = nullptr;
@@ -302,7 +310,7 @@ int welsh_upload_params(groove_bank* b, bool regroup) {
     if (b->d_inv) { GHIP(ctx, hipFree(b->d_inv)); b->d_inv = nullptr; }
     if (!b->perm.empty()) {
       GHIP(ctx, hipMalloc(&b->d_inv, (size_t)n * sizeof(uint32_t)));
-      GHIP(ctx, hipMemcpy(b->d_inv, b->inv.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+      GHIP(ctx, ctx_memcpy(ctx, b->d_inv, b->inv.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
   }
   // everything below is in INTERNAL lane order
@@ -315,7 +323,7 @@ int welsh_upload_params(groove_bank* b, bool regroup) {
     cold[i] = c.tune1; cold[(size_t)n + i] = c.tune2; cold[(size_t)2 * n + i] = c.fixed1; cold[(size_t)3 * n + i] = c.fixed2;
   }
   if (upload_soa(ctx, b->d_params, P)) return 1;
-  GHIP(ctx, hipMemcpy(b->d_cold, cold.data(), cold.size() * 8, hipMemcpyHostToDevice));
+  GHIP(ctx, ctx_memcpy(ctx, b->d_cold, cold.data(), cold.size() * 8, hipMemcpyHostToDevice));
   // Virtual waves: maximal runs of consecutive voices with identical parameter words, cut at 64.
   std::vector<WaveDesc> W;
   W.reserve((size_t)n / 64 + 64);
@@ -401,10 +409,10 @@ int welsh_upload_params(groove_bank* b, bool regroup) {
     if (b->d_wg_base) GHIP(ctx, hipFree(b->d_wg_base));
     GHIP(ctx, hipMalloc(&b->d_wg_base, b->wg_list_cap));
   }
-  GHIP(ctx, hipMemcpy(b->d_waves, W.data(), W.size() * sizeof(WaveDesc), hipMemcpyHostToDevice));
-  GHIP(ctx, hipMemcpy(b->d_wg_list, wg_list.data(), (size_t)wgs * sizeof(uint32_t), hipMemcpyHostToDevice));
-  GHIP(ctx, hipMemcpy(b->d_wg_cls, wg_cls.data(), wgs, hipMemcpyHostToDevice));
-  GHIP(ctx, hipMemcpy(b->d_wg_base, wg_base.data(), wgs, hipMemcpyHostToDevice));
+  GHIP(ctx, ctx_memcpy(ctx, b->d_waves, W.data(), W.size() * sizeof(WaveDesc), hipMemcpyHostToDevice));
+  GHIP(ctx, ctx_memcpy(ctx, b->d_wg_list, wg_list.data(), (size_t)wgs * sizeof(uint32_t), hipMemcpyHostToDevice));
+  GHIP(ctx, ctx_memcpy(ctx, b->d_wg_cls, wg_cls.data(), wgs, hipMemcpyHostToDevice));
+  GHIP(ctx, ctx_memcpy(ctx, b->d_wg_base, wg_base.data(), wgs, hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -424,7 +432,7 @@ int bank_derive_and_upload(groove_bank* b) {
     for (uint32_t v = 0; v < n; ++v) { P[v] = derive_fm(b->fm[v], sr); ratio[v] = b->fm[v].ratio; }
     if (upload_soa(ctx, b->d_params, P)) return 1;
     if (upload_soa(ctx, b->d_state, S)) return 1;
-    GHIP(ctx, hipMemcpy(b->d_cold, ratio.data(), ratio.size() * 8, hipMemcpyHostToDevice));
+    GHIP(ctx, ctx_memcpy(ctx, b->d_cold, ratio.data(), ratio.size() * 8, hipMemcpyHostToDevice));
   } else {
     std::vector<SamplerParams> P(n);
     std::vector<SamplerState> S(n, SamplerState{0, 0, 0, 0});
@@ -644,10 +652,10 @@ int fx_upload_params(groove_fx* fx) {
       default: break;
     }
   }
-  GHIP(ctx, hipMemcpy(fx->d_fa, fa.data(), n * 4, hipMemcpyHostToDevice));
-  GHIP(ctx, hipMemcpy(fx->d_fb, fb.data(), n * 4, hipMemcpyHostToDevice));
-  GHIP(ctx, hipMemcpy(fx->d_ua, ua.data(), n * 4, hipMemcpyHostToDevice));
-  GHIP(ctx, hipMemcpy(fx->d_wet, wet.data(), n * 4, hipMemcpyHostToDevice));
+  GHIP(ctx, ctx_memcpy(ctx, fx->d_fa, fa.data(), n * 4, hipMemcpyHostToDevice));
+  GHIP(ctx, ctx_memcpy(ctx, fx->d_fb, fb.data(), n * 4, hipMemcpyHostToDevice));
+  GHIP(ctx, ctx_memcpy(ctx, fx->d_ua, ua.data(), n * 4, hipMemcpyHostToDevice));
+  GHIP(ctx, ctx_memcpy(ctx, fx->d_wet, wet.data(), n * 4, hipMemcpyHostToDevice));
   double probe[5];
   if (rbj_for_kind_h(fx->kind, fx->p[0], sr, probe)) { // any BiQuad 12 dB mode
     std::vector<double> c((size_t)5 * n);
@@ -656,7 +664,7 @@ int fx_upload_params(groove_fx* fx) {
       rbj_for_kind_h(fx->kind, fx->p[i], sr, c5);
       for (int k = 0; k < 5; ++k) c[(size_t)k * n + i] = c5[k];
     }
-    GHIP(ctx, hipMemcpy(fx->d_coef, c.data(), c.size() * 8, hipMemcpyHostToDevice));
+    GHIP(ctx, ctx_memcpy(ctx, fx->d_coef, c.data(), c.size() * 8, hipMemcpyHostToDevice));
   } else if (fx->kind == GROOVE_FX_BIQUAD_LP24) {
     std::vector<double> c((size_t)6 * n);
     for (uint32_t i = 0; i < n; ++i) {
@@ -664,7 +672,7 @@ int fx_upload_params(groove_fx* fx) {
       lp24_coeffs_h(fx->p[i].cutoff_hz, fx->p[i].passband_ripple, sr, c6);
       for (int k = 0; k < 6; ++k) c[(size_t)k * n + i] = c6[k];
     }
-    GHIP(ctx, hipMemcpy(fx->d_coef, c.data(), c.size() * 8, hipMemcpyHostToDevice));
+    GHIP(ctx, ctx_memcpy(ctx, fx->d_coef, c.data(), c.size() * 8, hipMemcpyHostToDevice));
   }
   return 0;
 }
@@ -999,7 +1007,7 @@ int groove_sampler_create(groove_ctx* ctx, const float* bank_pcm, uint64_t bank_
   b->sampler.assign(p, p + n);
   b->descs.assign(descs, descs + n_samples);
   if (hipMalloc(&b->d_pcm, bank_frames * 4) != hipSuccess) { delete b; return fail(ctx, "groove_sampler_create: hipMalloc failed"); }
-  if (hipMemcpy(b->d_pcm, bank_pcm, bank_frames * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(b->d_pcm); delete b; return fail(ctx, "groove_sampler_create: upload failed"); }
+  if (ctx_memcpy(ctx, b->d_pcm, bank_pcm, bank_frames * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(b->d_pcm); delete b; return fail(ctx, "groove_sampler_create: upload failed"); }
   return bank_finish_create(b, out);
 }
 int groove_bank_destroy(groove_bank* b) {
@@ -1483,10 +1491,10 @@ int groove_bank_download_state(groove_bank* b, uint32_t* host_words) {
   if (ctx_join(ctx)) return 1;
   GHIP(ctx, hipStreamSynchronize(ctx->stream));
   if (b->perm.empty()) {
-    GHIP(ctx, hipMemcpy(host_words, b->d_state, (size_t)b->sw * b->n * 4, hipMemcpyDeviceToHost));
+    GHIP(ctx, ctx_memcpy(ctx, host_words, b->d_state, (size_t)b->sw * b->n * 4, hipMemcpyDeviceToHost));
   } else { // internal lane order -> caller's voice order
     std::vector<uint32_t> tmp((size_t)b->sw * b->n);
-    GHIP(ctx, hipMemcpy(tmp.data(), b->d_state, tmp.size() * 4, hipMemcpyDeviceToHost));
+    GHIP(ctx, ctx_memcpy(ctx, tmp.data(), b->d_state, tmp.size() * 4, hipMemcpyDeviceToHost));
     for (uint32_t w = 0; w < b->sw; ++w)
       for (uint32_t i = 0; i < b->n; ++i) host_words[(size_t)w * b->n + b->perm[i]] = tmp[(size_t)w * b->n + i];
   }
