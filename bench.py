@@ -440,6 +440,7 @@ def main():
                     help="workloads with effect chains: render block b, then its effects (default: the render of block b+1 "
                          "is submitted to the side streams before the effects of block b)")
     ap.add_argument("--dry-launch", action="store_true", help="rendezvous of the ranks over gloo only (no GPU): launcher test")
+    ap.add_argument("--no-canary", action="store_true", help="do not run the first-process canary (groove_amd/canary.py)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -453,6 +454,12 @@ def main():
     if args.dry_launch:
         sys.exit(dry_launch(world, rank))
 
+    # A freshly leased box's FIRST GPU process sometimes crawls on the multi-stream path (groove_amd/canary.py): let a
+    # child process be that first process, before this one touches the GPU.
+    canary = "skipped"
+    if not args.no_canary:
+        from groove_amd import canary as _canary
+        canary = _canary.run(device=local_rank)
     use_dist = world > 1 or os.environ.get("GROOVE_BENCH_FORCE_DIST") == "1"  # the latter: exercise the N>1 code path on one GPU
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -502,6 +509,7 @@ def main():
                                        + (f"weak: {V} voices per GPU, the project grows with N; value = the merged project's frames/s, voice_frames_per_s scales"
                                           if weak else "strong: the fixed project split N ways")
                                        + "), no data-path collective, 1 RCCL bus reduce per render")},
+            "first_process_canary": canary,
             "timed_region": {"repeats": R, "statistic": "median repeat (by wall time)",
                              "ms_per_step_repeats": [w / K * 1e3 for w in m["walls"]],
                              "ms_per_step_min": min(m["walls"]) / K * 1e3,

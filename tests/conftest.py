@@ -12,6 +12,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_finish(session):
+    """GPU tier only: a freshly leased box's first GPU process sometimes crawls on the multi-stream path
+    (groove_amd/canary.py); a child process takes that role before the first test touches the GPU."""
+    if any(item.get_closest_marker("gpu") for item in session.items):
+        from groove_amd import canary
+        outcome = canary.run()
+        print(f"\n[groove] first-process canary: {outcome}")
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as O
