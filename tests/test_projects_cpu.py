@@ -101,3 +101,19 @@ def test_bench_refuses_a_world_size_that_is_not_the_gpu_count():
     p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--dry-launch"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=2" in (p.stderr + p.stdout)
+
+
+def test_first_process_canary_outcomes(monkeypatch):
+    """groove_amd/canary.py on a box without a GPU: switched off it says so; switched on, its child fails at once
+    (no HIP device: the library has no CPU path) and the parent reports 'failed' — not 'killed', and not an exception."""
+    import time
+    from groove_amd import canary
+    monkeypatch.setenv("GROOVE_NO_CANARY", "1")
+    assert canary.run() == "skipped"
+    monkeypatch.delenv("GROOVE_NO_CANARY")
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the child would run the real path")
+    t0 = time.time()
+    assert canary.run(timeout_s=60.0) == "failed"
+    assert time.time() - t0 < 60.0
