@@ -1,18 +1,19 @@
-"""First-process canary for a fresh GPU box.
+"""Canary process for the GPU test session and smoke().
 
-Observed on this pool (round 2, three times in ~25 jobs, each time in the FIRST GPU process a freshly leased MI355X box
-ran, never in a later process on the same box, never in 30 back-to-back processes on a warm box): the million-voice
-path — five streams at three priorities, one render kernel per Welsh base kind side by side — crawls.  The rocprofv3
-trace of one such run (profiles/ has none of it: it never finished) shows ONE of the four render kernels, always the
-one on the fourth normal-priority queue, starting tens of seconds after its siblings or running for 10-50 s instead of
-0.36 ms, block after block, with the rest of the chip idle; every kernel of every other queue is normal.  A 176-block
-run then takes 40 minutes.  Nothing in the library's own ordering explains it (no cross-queue wait is outstanding
-while that kernel runs), and it cannot be provoked on demand.
+Observed on this pool (round 2, four times in ~60 processes that ran the million-voice path on recently leased MI355X
+boxes; never in 30 back-to-back processes on a warm box): the path — five streams at three priorities, one render
+kernel per Welsh base kind side by side — crawls for the life of the process.  The rocprofv3 trace of one such run
+shows ONE of the four render kernels, always the one on the fourth normal-priority queue, starting tens of seconds
+after its siblings or running for 10-50 s instead of 0.36 ms, block after block, with the rest of the chip idle and
+every kernel of every other queue normal.  A 176-block run then takes 40 minutes.  The next process on the same box is
+fine.  Three of the four were the first GPU process of their box, one the second.  Nothing in the library's own
+ordering explains it (no cross-queue wait is outstanding while that kernel runs) and it cannot be provoked on demand.
 
-What the measurement and test entry points do about it: before they touch the GPU themselves they run THIS module in a
-child process — the same path for a few blocks — with a timeout.  If the child is the unlucky first process it is
-killed when the timeout expires (its exact PID), and the parent, a later process on the box, runs normally.  It costs
-about ten seconds; `GROOVE_NO_CANARY=1` skips it.
+`bench.py` protects its measurement with a watchdog (the measurement runs in a child process that is killed and
+restarted if it does not finish in time).  A test session cannot restart itself, so it does the next best thing:
+before it touches the GPU it runs THIS module — the same path for eight blocks — in a child process with a timeout,
+which takes the most exposed position (a box's first GPU process) and is killed (its exact PID) if it crawls.
+About ten seconds; `GROOVE_NO_CANARY=1` skips it.
 """
 import os
 import subprocess

@@ -13,8 +13,9 @@ def pytest_configure(config):
 
 
 def pytest_collection_finish(session):
-    """GPU tier only: a freshly leased box's first GPU process sometimes crawls on the multi-stream path
-    (groove_amd/canary.py); a child process takes that role before the first test touches the GPU."""
+    """GPU tier only: on this pool a process now and then crawls on the multi-stream million-voice path, mostly a box's
+    first GPU process (groove_amd/canary.py); a child process takes that position before the first
+    test touches the GPU."""
     if any(item.get_closest_marker("gpu") for item in session.items):
         from groove_amd import canary
         outcome = canary.run()

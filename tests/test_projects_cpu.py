@@ -117,3 +117,17 @@ def test_first_process_canary_outcomes(monkeypatch):
     t0 = time.time()
     assert canary.run(timeout_s=60.0) == "failed"
     assert time.time() - t0 < 60.0
+
+
+def test_bench_watchdog_kills_a_stalled_child_and_retries(tmp_path):
+    """bench.py on one GPU runs its measurement in a child process; a child that does not finish in time is killed and
+    the run starts again.  Here the child is a stand-in that hangs the first time and answers the second (no GPU)."""
+    marker = tmp_path / "stalled_once"
+    env = dict(os.environ, GROOVE_BENCH_FAKE_STALL_ONCE=str(marker))
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--watchdog-seconds", "3"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["metric"] == "fake" and d["watchdog"] == {"attempts": 2, "killed": 1, "seconds_allowed": 3.0}
+    assert "killed" in r.stderr

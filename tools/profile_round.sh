@@ -18,7 +18,7 @@ TO="timeout ${PASS_TIMEOUT:-420}"   # one pass of one workload takes 20-60 s; a 
 for W in $WORKLOADS; do
   OUT=gpurun_out/prof_${ROUND}_$W
   rm -rf $OUT; mkdir -p $OUT
-  BENCH="python3 bench.py --workload $W --no-cpu-baseline --no-configs --no-parity --repeats 1"
+  BENCH="python3 bench.py --workload $W --no-cpu-baseline --no-configs --no-parity --repeats 1 --no-watchdog"   # (the watchdog would start a child from under the profiler)
   $TO rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/bench_kt.log 2>&1
   $TO rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH > $OUT/bench_fetch.log 2>&1
   $TO rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH > $OUT/bench_write.log 2>&1

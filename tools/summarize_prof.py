@@ -11,7 +11,7 @@ import sys
 out, rnd, workload = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "welsh-1m")
 os.makedirs("profiles", exist_ok=True)
 summary = {"round": rnd, "workload": workload,
-           "command": f"python3 bench.py --workload {workload} --no-cpu-baseline --no-configs --no-parity --repeats 1   (defaults: --gpus 1 --steps 172 --warmup 4)"}
+           "command": f"python3 bench.py --workload {workload} --no-cpu-baseline --no-configs --no-parity --repeats 1 --no-watchdog   (defaults: --gpus 1 --steps 172 --warmup 4)"}
 STEP_KERNELS = ("render", "_tp_kernel", "partial_", "mix_", "fx_", "block_", "_events_")   # what one step of the hot path launches
 
 ks = glob.glob(f"{out}/kt/*/*_kernel_stats.csv")
