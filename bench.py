@@ -21,6 +21,10 @@ With the default workload on one GPU the line also carries `configs`: the other 
 each timed over its WHOLE project timeline (172 blocks; 344 for the sampler), with the bus RMS error
 of a voice sample against the CPU oracle (computed outside the timed region).
 
+On one GPU (and not under a launcher) the measurement runs in a CHILD process under a watchdog: a child that has not
+printed its line in time is killed and the measurement starts again (DESIGN.md section 7 says why); the line carries
+`watchdog: {attempts, killed, seconds_allowed}`.  `--no-watchdog` runs in this process.
+
 Multi-GPU (`--gpus N`): one process per GPU.  Started without WORLD_SIZE in the environment this
 script launches the N rank processes itself (before anything touches a GPU); started under
 `torch.distributed.run` it is one of the ranks.  The project's voices are cut into contiguous index
