@@ -424,7 +424,7 @@ def config_entry(ctx, workload, repeats, parity_voices=64):
 def run_under_watchdog(argv, args, attempts=3):
     """Run this script's measurement in a child process; kill and restart a child that exceeds its time.  The parent never
     touches the GPU.  Prints the child's JSON line with `watchdog` added; returns the exit code."""
-    limit = args.watchdog_seconds or (240.0 if args.steps <= 50 else 900.0)
+    limit = args.watchdog_seconds or (150.0 if args.steps <= 50 else 300.0)  # a healthy run takes 25-45 s / 75-100 s
     env = dict(os.environ, GROOVE_BENCH_CHILD="1")
     killed = 0
     for attempt in range(1, attempts + 1):
@@ -478,7 +478,7 @@ def main():
     ap.add_argument("--dry-launch", action="store_true", help="rendezvous of the ranks over gloo only (no GPU): launcher test")
     ap.add_argument("--no-canary", action="store_true", help="(kept for old command lines; the watchdog replaced the canary)")
     ap.add_argument("--no-watchdog", action="store_true", help="run the measurement in this process (default on one GPU: in a child process that is killed and restarted if it crawls)")
-    ap.add_argument("--watchdog-seconds", type=float, default=0.0, help="time allowed per attempt (default: 240 s for up to 50 steps, 900 s otherwise)")
+    ap.add_argument("--watchdog-seconds", type=float, default=0.0, help="time allowed per attempt (default: 150 s for up to 50 steps, 300 s otherwise)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

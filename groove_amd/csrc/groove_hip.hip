@@ -800,8 +800,10 @@ int groove_init(int device_ordinal, groove_ctx** out) {
   // config #3 was gone: 0.25 ms per block against 0.14), and its short bus reductions, which every
   // pipelined block waits for, are dispatched ahead of the long render kernels.
   int prio_least = 0, prio_greatest = 0;
-  bool ok = hipSetDevice(device_ordinal) == hipSuccess && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess &&
-            hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
+  const char* flat = std::getenv("GROOVE_STREAM_PRIORITIES"); // "0": every stream at the normal priority (A/B)
+  bool ok = hipSetDevice(device_ordinal) == hipSuccess && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess;
+  if (ok && flat && flat[0] == '0') prio_least = prio_greatest = 0;
+  ok = ok && hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
             hipEventCreateWithFlags(&ctx->ev_fork, kSyncEventFlags) == hipSuccess;
   // Four normal-priority streams for the four class-specialised Welsh kinds (side by side in every block
   // of a big bank; the two exact-f64-LFO kinds, rare, share the first two), and three LOW-priority streams
