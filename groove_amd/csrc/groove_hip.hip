@@ -141,6 +141,7 @@ struct groove_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = true;
   hipStream_t side_stream[kSideStreams] = {}; // kernels of the other workgroup kinds run beside the main one
+  hipStream_t placeholder_stream = nullptr;   // created, never used (groove_init)
   hipEvent_t ev_fork = nullptr, ev_join[kSideStreams] = {};
   bool side_busy[kSideStreams] = {};    // work enqueued on the side stream since the last join
   bool fork_pending[kSideStreams] = {}; // the side stream has not yet waited for ev_fork
@@ -153,6 +154,12 @@ struct groove_ctx {
   // project with a bank on it ran three times slower (mixed-131072: 0.12 -> 0.39 ms per block whenever a bank had the
   // fourth bank stream, whichever bank it was; tools/micro/slot_probe.py).
   int bank_streams = 3;
+  // Normal-priority streams for the class-specialised Welsh kinds.  Three: the fourth kind shares the first kind's stream
+  // (1,000,000 voices: 0.511 against 0.515 ms per block with four).  docs/STREAMS.md item 10: the k-th stream a process
+  // creates lands on hardware queue (k - 1) mod 4, so the fifth (and the ninth) shares the ctx stream's queue; the fifth
+  // used to be the fourth kind stream — the one whose kernel crawled in the incidents of DESIGN.md section 7 — and is now
+  // a placeholder nobody uses.  GROOVE_KIND_STREAMS=4 brings the old layout back.
+  int kind_streams = 3;
   int next_stream_slot = 0;             // round-robin side-stream assignment of single-kernel banks
   uint32_t fm_tp_max_voices = kFmTpMaxVoices; // GROOVE_FM_TP_MAX_VOICES
   uint32_t fx_seg_max_lanes = 49152;     // biquad banks of up to this many lane-channels take the four-segment kernel (measured, tools/fx_bench.py: 8,192 lane-channels 17.5 -> 9.3 us, 32,768 19.4 -> 15.6, 131,072 42.9 -> 58.4; GROOVE_FX_SEG_MAX_LANES, 0 = never)
@@ -785,6 +792,7 @@ int groove_init(int device_ordinal, groove_ctx** out) {
   if (!ctx) return fail(nullptr, "groove_init: out of memory");
   ctx->device = device_ordinal;
   if (const char* e = std::getenv("GROOVE_FX_SEQ_ALLPASS")) ctx->seq_allpass = e[0] == '1';
+  if (const char* e = std::getenv("GROOVE_KIND_STREAMS")) ctx->kind_streams = std::atoi(e) == 4 ? 4 : 3;
   if (const char* e = std::getenv("GROOVE_BANK_STREAMS")) ctx->bank_streams = std::max(1, std::min(kBankStreams, std::atoi(e)));
   if (const char* e = std::getenv("GROOVE_FM_TP_MAX_VOICES")) ctx->fm_tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_SEG_MAX_LANES")) ctx->fx_seg_max_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
@@ -812,6 +820,11 @@ int groove_init(int device_ordinal, groove_ctx** out) {
   for (int i = 0; ok && i < kSideStreams; ++i) {
     if (i >= kBaseKinds + ctx->bank_streams) { ok = hipEventCreateWithFlags(&ctx->ev_join[i], kSyncEventFlags) == hipSuccess; continue; }
     if (i == 4 || i == 5) ctx->side_stream[i] = ctx->side_stream[i - 4];
+    else if (i == 3 && ctx->kind_streams == 3) { // three normal-priority streams (see kind_streams); the fifth stream the
+      // process creates lands on the ctx stream's hardware queue (so does the ninth): that place is taken by a stream nobody uses
+      ok = hipStreamCreateWithFlags(&ctx->placeholder_stream, hipStreamNonBlocking) == hipSuccess;
+      ctx->side_stream[3] = ctx->side_stream[0];
+    }
     else if (i < kBaseKinds) ok = hipStreamCreateWithFlags(&ctx->side_stream[i], hipStreamNonBlocking) == hipSuccess;
     else ok = hipStreamCreateWithPriority(&ctx->side_stream[i], hipStreamNonBlocking, prio_least) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&ctx->ev_join[i], kSyncEventFlags) == hipSuccess;
@@ -837,9 +850,10 @@ void groove_shutdown(groove_ctx* ctx) {
   if (ctx->d_i16) (void)hipFree(ctx->d_i16);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   for (int i = 0; i < kSideStreams; ++i) {
-    if (ctx->side_stream[i] && i != 4 && i != 5) { (void)hipStreamSynchronize(ctx->side_stream[i]); (void)hipStreamDestroy(ctx->side_stream[i]); }
+    if (ctx->side_stream[i] && i != 4 && i != 5 && !(i == 3 && ctx->kind_streams == 3)) { (void)hipStreamSynchronize(ctx->side_stream[i]); (void)hipStreamDestroy(ctx->side_stream[i]); }
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
   }
+  if (ctx->placeholder_stream) (void)hipStreamDestroy(ctx->placeholder_stream);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   delete ctx;
 }
