@@ -67,46 +67,168 @@ def _free_port():
     return p
 
 
-def launch_ranks(n, argv):
-    """Start n rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), pass rank 0's
-    output through and return non-zero unless every rank exits cleanly.  Nothing here touches a GPU."""
-    port = os.environ.get("MASTER_PORT") or str(_free_port())
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
-        out = subprocess.PIPE if r == 0 else sys.stderr  # only rank 0 prints the JSON line
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
-    failed = None
-    out0 = b""
-    pending = set(range(n))
-    while pending and failed is None:
-        for r in sorted(pending):
-            p = procs[r]
-            try:
-                if r == 0:
-                    o, _ = p.communicate(timeout=0.2)
-                    out0 += o or b""
-                else:
-                    p.wait(timeout=0.2)
-            except subprocess.TimeoutExpired:
-                continue
-            pending.discard(r)
-            if p.returncode != 0:
-                failed = (r, p.returncode)
-                break
-    if failed is not None:
-        for r in pending:  # exactly the processes started above
-            procs[r].terminate()
-        for r in pending:
-            try:
-                procs[r].wait(timeout=10)
-            except subprocess.TimeoutExpired:
-                procs[r].kill()
+RANK_STALL_EXIT = 75   # EX_TEMPFAIL: a rank whose library reported a stalled stream (groove_synchronize's deadline) — worth a fresh attempt
+
+
+def _stop(procs):
+    """Terminate exactly the processes in `procs` (started by this script), then kill what is left."""
+    for p in procs:
+        if p.poll() is None:
+            p.terminate()
+    for p in procs:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+
+
+def launch_ranks(n, argv, deadline_s=None, attempts=3):
+    """Start n rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), pass rank 0's output through and
+    return non-zero unless every rank exits cleanly.  Nothing here touches a GPU.  Every attempt has a deadline for the
+    whole group: when it passes (or a rank reports a stalled stream, exit code 75), exactly the rank processes started
+    here are killed and n FRESH ones are started, up to `attempts` times; rank 0's JSON line gets a `watchdog` entry."""
+    deadline_s = deadline_s or float(os.environ.get("GROOVE_BENCH_RANKS_DEADLINE_S", "420"))
+    killed = 0
+    for attempt in range(1, attempts + 1):
+        port = str(_free_port())  # a fresh rendezvous per attempt
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0", GROOVE_BENCH_CHILD="1",
+                       GROOVE_BENCH_ATTEMPT=str(attempt))
+            out = subprocess.PIPE if r == 0 else sys.stderr  # only rank 0 prints the JSON line
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=out))
+        failed = None
+        out0 = b""
+        pending = set(range(n))
+        t0 = time.monotonic()
+        timed_out = False
+        while pending and failed is None and not timed_out:
+            for r in sorted(pending):
+                p = procs[r]
+                try:
+                    if r == 0:
+                        o, _ = p.communicate(timeout=0.2)
+                        out0 += o or b""
+                    else:
+                        p.wait(timeout=0.2)
+                except subprocess.TimeoutExpired:
+                    continue
+                pending.discard(r)
+                if p.returncode != 0:
+                    failed = (r, p.returncode)
+                    break
+            timed_out = bool(pending) and time.monotonic() - t0 > deadline_s
+        if failed is None and not timed_out:
+            text = out0.decode(errors="replace")
+            lines = text.splitlines()
+            for i in range(len(lines) - 1, -1, -1):
+                if lines[i].startswith("{"):
+                    try:
+                        d = json.loads(lines[i])
+                        d["watchdog"] = {"attempts": attempt, "killed": killed, "seconds_allowed": deadline_s, "ranks": n}
+                        lines[i] = json.dumps(d)
+                    except Exception:
+                        pass
+                    break
+            sys.stdout.write("\n".join(lines) + ("\n" if lines else ""))
+            sys.stdout.flush()
+            return 0
+        still = sorted(pending)
+        _stop([procs[r] for r in still])
+        if timed_out:
+            killed += 1
+            sys.stderr.write(f"bench.py: attempt {attempt}: ranks {still} had not finished after {deadline_s:.0f} s; killed, "
+                             f"{'starting fresh ranks' if attempt < attempts else 'giving up'}\n")
+            continue
+        if failed[1] == RANK_STALL_EXIT:
+            killed += 1
+            sys.stderr.write(f"bench.py: attempt {attempt}: rank {failed[0]} reported a stalled stream; "
+                             f"{'starting fresh ranks' if attempt < attempts else 'giving up'}\n")
+            continue
         sys.stderr.write(f"bench.py: rank {failed[0]} exited with code {failed[1]}; {n} ranks were asked for\n")
-    sys.stdout.write(out0.decode(errors="replace"))
-    sys.stdout.flush()
-    return 0 if failed is None else 1
+        sys.stdout.write(out0.decode(errors="replace"))
+        sys.stdout.flush()
+        return 1
+    print(json.dumps({"error": f"bench: {attempts} attempts of {n} ranks did not finish", "watchdog": {"attempts": attempts, "killed": killed, "ranks": n}}), flush=True)
+    return 3
+
+
+def supervise_rank(argv, rank, world, deadline_s=None, attempts=3):
+    """Under an external launcher (torch.distributed.run: RANK / WORLD_SIZE already set) this process IS a rank.  It then
+    only SUPERVISES: the measurement of the rank runs in a child process (this one never touches a GPU), the supervisors
+    talk to each other over gloo on the launcher's rendezvous, and when a child stalls or the group's deadline passes
+    every supervisor kills its own child (exactly that PID) and all start fresh children on a fresh port — what
+    launch_ranks does when this script starts the ranks itself.  Rank 0 prints its child's line with `watchdog` added."""
+    import torch
+    import torch.distributed as dist
+    deadline_s = deadline_s or float(os.environ.get("GROOVE_BENCH_RANKS_DEADLINE_S", "420"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    killed = 0
+    rc_final = 3
+    for attempt in range(1, attempts + 1):
+        port = [_free_port() if rank == 0 else None]
+        dist.broadcast_object_list(port, src=0)
+        env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}  # the children host their own store
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port[0]), GROOVE_BENCH_CHILD="1", GROOVE_BENCH_ATTEMPT=str(attempt),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                 stdout=subprocess.PIPE if rank == 0 else sys.stderr)
+        out0 = []
+        if rank == 0:  # drain the pipe while waiting
+            import threading
+            th = threading.Thread(target=lambda: out0.append(child.stdout.read()), daemon=True)
+            th.start()
+        t0 = time.monotonic()
+        RUNNING, OK, STALL, FAIL = 0, 1, 2, 3
+        while True:
+            rc = child.poll()
+            mine = RUNNING if rc is None else OK if rc == 0 else STALL if rc == RANK_STALL_EXIT else FAIL
+            if mine == RUNNING and time.monotonic() - t0 > deadline_s:
+                mine = STALL
+            t = torch.tensor([mine, -mine], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            worst, best = int(t[0]), -int(t[1])
+            if worst >= STALL or best == OK:
+                break
+            time.sleep(0.5)
+        if worst < STALL:  # every child finished cleanly
+            if rank == 0:
+                th.join(timeout=10)
+                text = (out0[0] if out0 else b"").decode(errors="replace")
+                lines = text.splitlines()
+                for i in range(len(lines) - 1, -1, -1):
+                    if lines[i].startswith("{"):
+                        try:
+                            d = json.loads(lines[i])
+                            d["watchdog"] = {"attempts": attempt, "killed": killed, "seconds_allowed": deadline_s, "ranks": world,
+                                             "supervised_under_launcher": True}
+                            lines[i] = json.dumps(d)
+                        except Exception:
+                            pass
+                        break
+                sys.stdout.write("\n".join(lines) + ("\n" if lines else ""))
+                sys.stdout.flush()
+            rc_final = 0
+            break
+        _stop([child])
+        killed += 1
+        if worst == FAIL:
+            if rank == 0:
+                sys.stderr.write(f"bench.py: attempt {attempt}: a rank failed (not a stall); giving up\n")
+            rc_final = 1
+            break
+        if rank == 0:
+            sys.stderr.write(f"bench.py: attempt {attempt}: a rank stalled or the {deadline_s:.0f} s deadline passed; every rank's child was "
+                             f"killed, {'starting fresh ones' if attempt < attempts else 'giving up'}\n")
+    if rc_final == 3 and rank == 0:
+        print(json.dumps({"error": f"bench: {attempts} attempts of {world} supervised ranks did not finish",
+                          "watchdog": {"attempts": attempts, "killed": killed, "ranks": world}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return rc_final
 
 
 def dry_launch(world, rank):
@@ -128,24 +250,38 @@ def dry_launch(world, rank):
 
 
 # ------------------------------------------------------------------------------------------ evidence
-def committed_profile(workload):
-    """The committed rocprofv3 summary of a workload (profiles/rNN_<workload>_summary.json, or the round's
-    default-command summary for welsh-1m): HBM traffic per step (FETCH_SIZE doubled per MI355X_MICROARCH.md
-    §HBM) and the VALU / SALU wave-instruction counts per step of the PMC pass."""
+def committed_profile(workload, window=None):
+    """The committed rocprofv3 summary of a workload (profiles/rNN_<workload>_summary.json, or round 1's single
+    summary for welsh-1m): HBM traffic per step (FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM) and the VALU / SALU
+    wave-instruction counts per step of the PMC passes.  `window` = (steps, warmup): a summary collected with exactly
+    that command (profiles/rNN_<workload>-window_summary.json, e.g. the driver's --steps 20 --warmup 5) is preferred when
+    the run being described times the same blocks; otherwise the whole-timeline summary is used and the line says so."""
     import re
-    names = os.listdir(os.path.join(REPO, "profiles")) if os.path.isdir(os.path.join(REPO, "profiles")) else []
-    rx = [re.compile(rf"^r(\d+)_{re.escape(workload)}_summary\.json$")]
-    if workload == "welsh-1m":
-        rx.append(re.compile(r"^r(\d+)_summary\.json$"))  # round 1's layout: one summary, of the default workload
-    found = sorted((int(m.group(1)), n) for n in names for r in rx for m in [r.match(n)] if m)
-    files = [os.path.join(REPO, "profiles", n) for _, n in found]
-    if not files:
+    pdir = os.path.join(REPO, "profiles")
+    names = os.listdir(pdir) if os.path.isdir(pdir) else []
+
+    def newest(pattern):
+        found = sorted((int(m.group(1)), n) for n in names for m in [re.match(pattern, n)] if m)
+        for _, n in reversed(found):
+            try:
+                return n, json.load(open(os.path.join(pdir, n)))
+            except Exception:
+                continue
+        return None, None
+
+    name, d = None, None
+    if window is not None:
+        name, d = newest(rf"^r(\d+)_{re.escape(workload)}-window_summary\.json$")
+        if d is not None and [d.get("steps"), d.get("warmup")] != list(window):
+            name, d = None, None
+    if d is None:
+        name, d = newest(rf"^r(\d+)_{re.escape(workload)}_summary\.json$")
+    if d is None and workload == "welsh-1m":
+        name, d = newest(r"^r(\d+)_summary\.json$")  # round 1's layout: one summary, of the default workload
+    if d is None:
         return None
-    try:
-        d = json.load(open(files[-1]))
-    except Exception:
-        return None
-    out = {"source": os.path.basename(files[-1]),
+    out = {"source": name, "window_steps_warmup": [d.get("steps"), d.get("warmup")],
+           "same_window_as_this_run": window is not None and [d.get("steps"), d.get("warmup")] == list(window),
            "traffic": (d.get("hbm_traffic_bytes_per_step") or {}).get("total_corrected")}
     ins = d.get("instructions_per_step") or {}
     valu, salu = ins.get("valu_wave_insts") or 0.0, ins.get("salu_wave_insts") or 0.0
@@ -156,6 +292,8 @@ def committed_profile(workload):
                 valu += m.get("SQ_INSTS_VALU", 0.0)
                 salu += m.get("SQ_INSTS_SALU", 0.0)
     out["valu_per_step"], out["salu_per_step"] = (valu or None), (salu or None)
+    out["valu_mix_per_step"] = d.get("valu_mix_per_step")   # measured classes (f64 / conversions / transcendental / ...), if the pass was run
+    out["valu_cycles_per_step"] = (d.get("valu_mix_per_step") or {}).get("cost_weighted_cycles")
     out["clock_ghz"] = (d.get("clock_in_counter_pass") or {}).get("ghz_weighted_long_kernels")
     return out
 
@@ -169,24 +307,61 @@ def spread_sample(v_total, count):
     return np.unique((np.arange(count, dtype=np.int64) * stride + stride // 2) % v_total)
 
 
+def under_profiler():
+    """rocprofv3 preloads its tool library into the program after `--`: nothing may start a child process from here then
+    (the child would be profiled instead, and a re-launch from under --pmc is the forbidden exec of DESIGN.md section 7)."""
+    pre = os.environ.get("LD_PRELOAD", "")
+    return "rocprof" in pre or any(k.startswith(("ROCPROFILER_", "ROCP_", "ROCPROF_")) for k in os.environ)
+
+
+class timed_kernel_form:
+    """Make a SMALL sample project run the kernels the full-size workload's timed region runs: welsh-1m (and any Welsh
+    bank above ~550,000 voices) takes one welsh_render_uniform_kernel per base kind with pipelined blocks, but a bank of
+    a few hundred voices would take the time-parallel kernel — so the time-parallel form is switched off and the per-kind
+    pipeline forced for the duration (groove_set_time_parallel_max_voices 0, groove_set_pipeline_min_waves 1)."""
+
+    def __init__(self, ctx, workload, v_total):
+        self.ctx = ctx
+        wl = WORKLOADS[workload]
+        self.force = wl["kind"] == "welsh" and v_total >= 550_000
+
+    def __enter__(self):
+        if self.force:
+            self.old = (self.ctx.time_parallel_max_voices, self.ctx.pipeline_min_waves)
+            self.ctx.time_parallel_max_voices = 0
+            self.ctx.pipeline_min_waves = 1
+        return self
+
+    def __exit__(self, *exc):
+        if self.force:
+            self.ctx.time_parallel_max_voices, self.ctx.pipeline_min_waves = self.old
+
+
 def sampled_parity(ctx, workload, v_total, blocks, sample=64, fused=True, grouped=True):
     """Bus RMS error (normalised by the sample size) of `sample` voices of the project, spread over its
-    whole index range, rendered by the product path and by the CPU oracle over the first `blocks`
-    blocks of the timeline.  Outside every timed region."""
+    whole index range, rendered by the product path — by the SAME kernel form the timed region ran — and by the CPU
+    oracle over the first `blocks` blocks of the timeline.  Outside every timed region."""
     from oracle.projects import OracleProject
     sel = spread_sample(v_total, sample)
-    proj = PJ.Project(ctx, workload, sel, fused=fused, grouped=grouped)
-    bus = ctx.bus(blocks * FRAMES)
-    for b in range(blocks):
-        proj.step(bus, b * FRAMES)
-    got = bus.download().astype(np.float64) / len(sel)
-    proj.destroy()
-    bus.destroy()
+    with timed_kernel_form(ctx, workload, v_total) as forced:
+        proj = PJ.Project(ctx, workload, sel, fused=fused, grouped=grouped)
+        forms = sorted({inst.kernel_form(FRAMES, fused and not fx) for inst, _, fx, _ in proj.banks})
+        bus = ctx.bus(blocks * FRAMES)
+        for b in range(blocks):
+            proj.step(bus, b * FRAMES)
+        got = bus.download().astype(np.float64) / len(sel)
+        proj.destroy()
+        bus.destroy()
     want = OracleProject(workload, sel, grouped=grouped).render(blocks) / len(sel)
     rms = float(np.sqrt(np.mean((got - want) ** 2)))
     peak = float(np.abs(want).max())
-    return {"voices_sampled": int(len(sel)), "blocks": blocks, "normalisation": "bus / voices sampled",
-            "bus_rms_err": rms, "signal_rms": float(np.sqrt(np.mean(want ** 2))), "signal_peak": peak,
+    # the worst single block, so that a window (e.g. the release after the note-off) cannot hide in the average
+    per_block = np.sqrt(np.mean((got - want).reshape(blocks, -1) ** 2, axis=1))
+    return {"voices_sampled": int(len(sel)), "blocks": blocks, "timeline_blocks": f"0..{blocks - 1}",
+            "normalisation": "bus / voices sampled",
+            "kernel_form": forms, "kernel_form_forced_to_match_timed_region": bool(forced.force),
+            "bus_rms_err": rms, "bus_rms_err_worst_block": float(per_block.max()), "worst_block": int(per_block.argmax()),
+            "signal_rms": float(np.sqrt(np.mean(want ** 2))), "signal_peak": peak,
             # an effect chain with gain (config #3: chorus taps + recirculating combs) lifts signal and error alike
             "bus_rms_err_rel_full_scale": rms / max(1.0, peak),
             "max_abs_err": float(np.max(np.abs(got - want)))}
@@ -217,6 +392,24 @@ def cpu_baseline(workload, seconds_target=15.0):
                   f"timeline, f64 scalar oracle -O2, 1 thread; frames/s scaled by {sample_voices}/{V} "
                   f"(measured {vf_per_s:.3e} voice-frames/s)",
     }
+    # second figure: the same scalar port compiled -O3 -march=native ON THIS HOST (the .so is
+    # rebuilt here: one built in another container may use instructions this CPU lacks), same sample, single thread
+    try:
+        import subprocess as sp
+        odir = os.path.join(REPO, "oracle")
+        sp.run(["make", "-s", "-B", "-C", odir, "native"], check=True, timeout=120)
+        Ln = O.lib(native=True)
+        opn = OracleProject(workload, sel, lib_=Ln)
+        opn.step()
+        nb = max(4, blocks // 3)
+        t0 = time.perf_counter()
+        for _ in range(nb):
+            opn.step()
+        eln = time.perf_counter() - t0
+        out["native"] = {"value": sample_voices * FRAMES * nb / eln / V, "cores": 1, "flags": "-O3 -march=native (built on this host)",
+                         "sample": f"{sample_voices} voices x {nb} blocks"}
+    except Exception as e:  # noqa: BLE001
+        out["native"] = {"error": str(e)[:200]}
     cores = int(O.lib().oracle_hardware_concurrency()) or 1
     if WORKLOADS[workload]["kind"] in ("welsh", "mixed", "sampler"):  # mode B: voices sharded over all host cores
         mt_voices = min(V, 64 * cores)
@@ -252,27 +445,32 @@ class Dist:
         self.nccl_group = None
         self.ctx = None
 
-    def attach(self, ctx):
+    def make_context(self):
+        """The rank's library context with its RCCL communicator created BEFORE the library's streams (groove_init_comm:
+        RCCL's own streams then do not land between them)."""
         torch, dist, rank, world, local_rank = self.torch, self.dist, self.rank, self.world, self.local_rank
-        self.ctx = ctx
-        self.reduce_via = "groove_bus_reduce (RCCL ncclReduce on the ctx stream)"
+        self.reduce_via = "groove_bus_reduce (RCCL ncclReduce on the ctx stream; communicator created before the library's streams)"
         try:
-            uid = [ctx.comm_unique_id() if rank == 0 else None]
+            uid = [E.Context.new_comm_unique_id() if rank == 0 else None]
         except Exception as e:  # noqa: BLE001
             uid = [None]
             self.reduce_via = f"torch.distributed.reduce over nccl (library communicator unavailable: {e})"
         dist.broadcast_object_list(uid, src=0)
         ok = [1]
+        ctx = None
         if uid[0] is not None:
             try:
                 if os.environ.get("GROOVE_BENCH_BREAK_COMM") == "1":  # exercise the fallback below
                     raise RuntimeError("GROOVE_BENCH_BREAK_COMM=1")
-                ctx.comm_init(uid[0], rank, world)
+                ctx = E.Context(local_rank, comm=(uid[0], rank, world))
             except Exception as e:  # noqa: BLE001
                 ok = [0]
-                self.reduce_via = f"torch.distributed.reduce over nccl (groove_comm_init failed: {e})"
+                self.reduce_via = f"torch.distributed.reduce over nccl (groove_init_comm failed: {e})"
         else:
             ok = [0]
+        if ctx is None:
+            ctx = E.Context(local_rank)
+        self.ctx = ctx
         flag = torch.tensor(ok, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # every rank takes the same path
         self.own_comm = bool(int(flag.item()))
@@ -282,6 +480,7 @@ class Dist:
             torch.cuda.set_device(local_rank)
             self.nccl_group = dist.new_group(backend="nccl")
         self.rccl_ranks = ctx.comm_ranks() if self.own_comm else dist.get_world_size(self.nccl_group)
+        return ctx
 
     def sync(self):
         self.ctx.synchronize()      # every stream of the library on this device
@@ -345,52 +544,75 @@ def time_project(ctx, proj, bus, K, W, repeats, span_mode, dist=None):
     return walls, kerns
 
 
-def roofline_block(workload, n_local, kern_ms, span_mode, fused):
+def roofline_block(workload, n_local, kern_ms, span_mode, fused, window=None):
+    """Two views of one step.  EFFECTIVE (`achieved` / `frac`): the entity-boundary algorithmic bytes of
+    the step divided by its duration — what an implementation that materialised every voice block would have to move;
+    a fused kernel does not move them and the figure can exceed 1.  PHYSICAL: what the PMC passes of the committed
+    profile counted for the same command — HBM bytes (`traffic`, `hbm_physical_frac`) and VALU wave-instructions
+    (`valu.achieved_frac` of the spec issue rate, and of the cost-weighted issue cycles when the instruction-class pass
+    was collected).  `bound` names the larger of the two physical fractions, or "latency" when both are under 0.25 (a
+    step of a few short, dependent launches)."""
     wl = WORKLOADS[workload]
     whole = span_mode
     dom_bytes = wl["bytes_per_vf"] if whole else wl["dominant_bytes"]
     achieved = dom_bytes * n_local * FRAMES / (kern_ms * 1e-3) / 1e9
-    prof = committed_profile(workload) or {}
-    welsh_like = wl["kind"] in ("welsh", "mixed", "chain")
+    prof = committed_profile(workload, window) or {}
     kernel = ("welsh_render_uniform_kernel<fused, LFO mode, retune> (one kernel per base kind, run concurrently; "
               "class-specialised block bodies) + partial_rows/final" if fused and wl["kind"] == "welsh"
-              else "whole step: render of block b+1 (side streams) beside the effect chain + mix of block b" if whole and wl["kind"] == "chain"
+              else "whole step: render of block b+1 + the chain's IIR head (side stream) beside the rest of the effect chain + mix of block b" if whole and wl["kind"] == "chain"
               else "whole step: the banks' fused render kernels side by side + their bus reductions" if whole
               else "render kernel of the first bank")
-    r = {"bound": "valu-issue" if welsh_like else "hbm",
+    r = {"bound": None,
          "kernel": kernel,
          # SURVEY §8d's entity-boundary bytes ÷ time: an EFFECTIVE rate (the fused kernels never move these
          # bytes; it can exceed the HBM peak).  `traffic` is what the PMC pass saw actually move.
          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "frac_is": "effective (algorithmic entity-boundary bytes / time, SURVEY §8d); the physical fractions are hbm_physical_frac and valu.achieved_frac",
          "effective": {"note": "algorithmic (entity-boundary) bytes / time, SURVEY §8d; not a physical bandwidth",
                        "GBs": achieved, "frac_of_hbm_peak": achieved / HBM_PEAK_GBS},
          "algorithmic_bytes_per_voice_frame": dom_bytes, "algorithmic_bytes_per_step": dom_bytes * n_local * FRAMES,
          "kernel_ms": kern_ms,
-         "traffic": prof.get("traffic"), "traffic_unit": "HBM bytes per step (PMC FETCH_SIZE x2 + WRITE_SIZE, committed pass)",
-         "traffic_source": prof.get("source")}
+         "traffic": None, "traffic_unit": "HBM bytes per step (PMC FETCH_SIZE x2 + WRITE_SIZE, committed pass)",
+         "traffic_source": prof.get("source"), "traffic_same_window": prof.get("same_window_as_this_run"),
+         "profile_window_steps_warmup": prof.get("window_steps_warmup")}
+    scale = n_local / WORKLOADS[workload]["voices"]   # the committed pass counted the workload's full-size step
+    hbm_frac = valu_frac = None
     if prof.get("traffic"):
-        r["hbm_physical_frac"] = prof["traffic"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        r["traffic"] = prof["traffic"] * scale
+        hbm_frac = r["traffic"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        r["hbm_physical_frac"] = hbm_frac
+        r["traffic_over_algorithmic"] = r["traffic"] / r["algorithmic_bytes_per_step"] if r["algorithmic_bytes_per_step"] else None
     if prof.get("valu_per_step"):
-        # the committed PMC pass counted the instructions of the workload's full-size step; scale to this shard
-        scale = n_local / WORKLOADS[workload]["voices"]
         wi = prof["valu_per_step"] * scale
+        valu_frac = wi / (kern_ms * 1e-3) / VALU_ISSUE_PER_S
         r["valu"] = {"wave_insts_per_step": wi, "salu_wave_insts_per_step": (prof.get("salu_per_step") or 0.0) * scale,
                      "valu_per_voice_frame": wi * 64.0 / (n_local * FRAMES) if n_local else None,
                      "spec_issue_rate": VALU_ISSUE_PER_S, "spec_issue_rate_unit": "wave64 VALU instructions/s (1,024 SIMD-32 x 2.4 GHz / 2 clk)",
-                     "achieved_frac": wi / (kern_ms * 1e-3) / VALU_ISSUE_PER_S,
+                     "achieved_frac": valu_frac,
                      # the clock the render kernels held in the committed GRBM counter pass, where they run one at a time
                      # (GRBM_GUI_ACTIVE / 8 XCDs / dispatch time; MI355X_MICROARCH.md "DVFS give-back"): the spec clock holds
                      "clock_ghz_in_counter_pass": prof.get("clock_ghz"),
-                     "note": "at the spec rate every instruction is a 2-cycle fp32 one; a retuning Welsh frame's mix (16 f64, 9 conversions, "
-                             "3 transcendentals of ~86) needs ~1.35x that, DESIGN.md section 5",
-                     "source": prof.get("source")}
+                     "source": prof.get("source"), "same_window": prof.get("same_window_as_this_run")}
+        if prof.get("valu_cycles_per_step"):
+            # measured instruction classes: cycles = 2 x plain + 4 x f64 + 4 x conversions + 8 x transcendental (tools/summarize_prof.py)
+            cyc = prof["valu_cycles_per_step"] * scale
+            r["valu"]["cost_weighted_issue_cycles_per_step"] = cyc
+            r["valu"]["cost_weighted_frac"] = cyc / (kern_ms * 1e-3) / (1024 * 2.4e9)
+            r["valu"]["mix_per_step"] = {k: (v * scale if isinstance(v, (int, float)) else v) for k, v in (prof.get("valu_mix_per_step") or {}).items()}
+            valu_frac = max(valu_frac, r["valu"]["cost_weighted_frac"])
+    fr = {"hbm": hbm_frac or 0.0, "valu-issue": valu_frac or 0.0}
+    top = max(fr, key=fr.get)
+    r["bound"] = (top if fr[top] >= 0.25 else "latency (few short dependent launches: neither HBM nor VALU issue is a quarter busy)") if (hbm_frac is not None or valu_frac is not None) \
+        else ("valu-issue" if wl["kind"] in ("welsh", "mixed") else "hbm")
+    r["physical"] = {"hbm_frac": hbm_frac, "valu_frac": valu_frac}
     return r
 
 
-def bench_workload(ctx, workload, sel, K, W, repeats, fused=True, grouped=True, render_ahead=True, dist=None):
+def bench_workload(ctx, workload, sel, K, W, repeats, fused=True, grouped=True, render_ahead=True, dist=None, head_ahead=True):
     """Build the shard `sel` of a workload, time it, return the measurements (no parity, no JSON)."""
     wl = WORKLOADS[workload]
-    proj = PJ.Project(ctx, workload, sel, fused=fused, grouped=grouped, render_ahead=render_ahead)
+    proj = PJ.Project(ctx, workload, sel, fused=fused, grouped=grouped, render_ahead=render_ahead, head_ahead=head_ahead)
+    forms = sorted({inst.kernel_form(FRAMES, fused and not fx) for inst, _, fx, _ in proj.banks})
     bus = ctx.bus((K + W) * FRAMES)
     span_mode = (fused and wl["kind"] != "chain") or (wl["kind"] == "chain" and render_ahead)
     walls, kerns = time_project(ctx, proj, bus, K, W, repeats, span_mode, dist)
@@ -399,7 +621,7 @@ def bench_workload(ctx, workload, sel, K, W, repeats, fused=True, grouped=True, 
     bus.destroy()
     order = np.argsort(walls)
     med = int(order[len(order) // 2])
-    return {"walls": walls, "kerns": kerns, "median": med, "span_mode": span_mode, "bus": out_bus}
+    return {"walls": walls, "kerns": kerns, "median": med, "span_mode": span_mode, "bus": out_bus, "kernel_form": forms}
 
 
 def config_entry(ctx, workload, repeats, parity_voices=64):
@@ -415,16 +637,56 @@ def config_entry(ctx, workload, repeats, parity_voices=64):
     return {"workload": workload, "voices": V, "blocks_timed": f"0..{K - 1} (the whole project, {K * FRAMES} frames)",
             "ms_per_step": ms[i], "ms_per_step_min": min(ms), "ms_per_step_repeats": ms,
             "value": fps, "unit": "stereo frames/s", "x_realtime_44k1": fps / SR,
-            "kernel_ms": m["kerns"][i], "frac": roof["frac"], "bound": roof["bound"],
+            "kernel_ms": m["kerns"][i], "kernel_form": m["kernel_form"],
+            "frac": roof["frac"], "frac_is": "effective (SURVEY §8d algorithmic bytes / time)", "bound": roof["bound"],
+            "hbm_physical_frac": roof.get("hbm_physical_frac"), "valu_achieved_frac": (roof.get("valu") or {}).get("achieved_frac"),
             "algorithmic_bytes_per_voice_frame": roof["algorithmic_bytes_per_voice_frame"],
             "traffic": roof.get("traffic"), "traffic_source": roof.get("traffic_source"), "valu": roof.get("valu"),
             "parity_vs_oracle": par}
 
 
+def form_entry(ctx, label, K, W, fused, grouped, note):
+    """welsh-1m in one of the entity-boundary forms (voice blocks written to HBM, then mixed), timed over the same
+    window as the headline: what a host that calls Generates::generate_batch_values and then gather_audio gets
+    (/root/reference/entities/src/instruments/metronome.rs:23-35, orchestration/src/orchestrator.rs:397-410)."""
+    V = WORKLOADS["welsh-1m"]["voices"]
+    m = bench_workload(ctx, "welsh-1m", np.arange(V, dtype=np.int64), K, W, 1, fused=fused, grouped=grouped)
+    ms = m["walls"][0] / K * 1e3
+    byts = WORKLOADS["welsh-1m"]["bytes_per_vf"] * V * FRAMES
+    fps = K * FRAMES / m["walls"][0]
+    return {"workload": label, "voices": V, "blocks_timed": f"{W}..{W + K - 1}", "note": note, "kernel_form": m["kernel_form"],
+            "ms_per_step": ms, "value": fps, "unit": "stereo frames/s", "x_realtime_44k1": fps / SR,
+            "frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "frac_is": "algorithmic 18 B per voice-frame / time; in this form 16 of the 18 bytes are really moved (block written, state in and out; the mix reads the render's row sums)"}
+
+
+def shard_curve(ctx, K, W, ms_full):
+    """What strong scaling can reach, measured on this one GPU: the per-GPU shard of welsh-1m on 1 / 2 / 4 / 8 GPUs (V, V/2,
+    V/4, V/8 voices: the first rank's contiguous range) over the same window, and the 16,384-voice shard of
+    mixed-131072 (config #5's per-GPU share) over its whole timeline.  efficiency = t(V) / (N x t(V / N)): the bus reduce
+    (352 KB once per render) is not in it."""
+    V = WORKLOADS["welsh-1m"]["voices"]
+    rows = [{"gpus": 1, "voices_per_gpu": V, "ms_per_step": ms_full, "implied_speedup": 1.0, "implied_efficiency": 1.0}]
+    for n in (2, 4, 8):
+        lo, hi = voice_range(V, 0, n)
+        m = bench_workload(ctx, "welsh-1m", np.arange(lo, hi, dtype=np.int64), K, W, 1)
+        ms = m["walls"][0] / K * 1e3
+        rows.append({"gpus": n, "voices_per_gpu": hi - lo, "ms_per_step": ms, "kernel_form": m["kernel_form"],
+                     "implied_speedup": ms_full / ms, "implied_efficiency": ms_full / ms / n})
+    out = {"welsh-1m": rows, "window_blocks": f"{W}..{W + K - 1}", "repeats": 1}
+    Vm, Km = WORKLOADS["mixed-131072"]["voices"], WORKLOADS["mixed-131072"]["blocks"]
+    lo, hi = voice_range(Vm, 0, 8)
+    m = bench_workload(ctx, "mixed-131072", np.arange(lo, hi, dtype=np.int64), Km, 0, 1)
+    out["mixed-131072_shard_of_8"] = {"voices_per_gpu": hi - lo, "ms_per_step": m["walls"][0] / Km * 1e3, "kernel_form": m["kernel_form"],
+                                      "blocks_timed": f"0..{Km - 1}", "note": "compare with configs[mixed-131072].ms_per_step (the whole project on one GPU)"}
+    return out
+
+
 def run_under_watchdog(argv, args, attempts=3):
-    """Run this script's measurement in a child process; kill and restart a child that exceeds its time.  The parent never
-    touches the GPU.  Prints the child's JSON line with `watchdog` added; returns the exit code."""
-    limit = args.watchdog_seconds or (150.0 if args.steps <= 50 else 300.0)  # a healthy run takes 25-45 s / 75-100 s
+    """Run this script's measurement in a child process; kill and restart a child that exceeds its time or whose library
+    reported a stalled stream (exit code 75).  The parent never touches the GPU.  Prints the child's JSON line with
+    `watchdog` added; returns the exit code."""
+    limit = args.watchdog_seconds or (240.0 if args.steps <= 50 else 420.0)  # a healthy run takes 40-70 s / 100-140 s
     env = dict(os.environ, GROOVE_BENCH_CHILD="1")
     killed = 0
     for attempt in range(1, attempts + 1):
@@ -438,11 +700,18 @@ def run_under_watchdog(argv, args, attempts=3):
             print(f"[bench] attempt {attempt}: no result after {limit:.0f} s, child {p.pid} killed", file=sys.stderr, flush=True)
             time.sleep(2.0)
             continue
+        if p.returncode == RANK_STALL_EXIT:
+            killed += 1
+            print(f"[bench] attempt {attempt}: the library reported a stalled stream (child {p.pid} exited {RANK_STALL_EXIT}); starting again", file=sys.stderr, flush=True)
+            time.sleep(2.0)
+            continue
         lines = [ln for ln in out.splitlines() if ln.startswith("{")]
         if p.returncode == 0 and lines:
             try:
                 d = json.loads(lines[-1])
-                d["watchdog"] = {"attempts": attempt, "killed": killed, "seconds_allowed": limit}
+                d["watchdog"] = {"attempts": attempt, "killed": killed, "seconds_allowed": limit,
+                                 "tainted": killed > 0,  # a restarted run: quote it as such
+                                 }
                 print(json.dumps(d), flush=True)
             except Exception:
                 print(lines[-1], flush=True)
@@ -470,17 +739,21 @@ def main():
                          "(default: strong scaling, the workload's voices are split over the ranks)")
     ap.add_argument("--strong", action="store_true", help="(the default; kept for explicit command lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` entries (the other four workloads)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` entries (the other four workloads and the entity-boundary forms)")
+    ap.add_argument("--no-shard-curve", action="store_true", help="skip `shard_curve` (the per-GPU shards of 2 / 4 / 8 GPUs timed on this one)")
     ap.add_argument("--no-parity", action="store_true", help="skip the sampled oracle comparison")
     ap.add_argument("--no-render-ahead", action="store_true",
                     help="workloads with effect chains: render block b, then its effects (default: the render of block b+1 "
                          "is submitted to the side streams before the effects of block b)")
+    ap.add_argument("--no-head-ahead", action="store_true", help="render-ahead walk: keep the chain's leading IIR stage on the ctx stream (A/B)")
     ap.add_argument("--dry-launch", action="store_true", help="rendezvous of the ranks over gloo only (no GPU): launcher test")
     ap.add_argument("--no-canary", action="store_true", help="(kept for old command lines; the watchdog replaced the canary)")
     ap.add_argument("--no-watchdog", action="store_true", help="run the measurement in this process (default on one GPU: in a child process that is killed and restarted if it crawls)")
-    ap.add_argument("--watchdog-seconds", type=float, default=0.0, help="time allowed per attempt (default: 150 s for up to 50 steps, 300 s otherwise)")
+    ap.add_argument("--watchdog-seconds", type=float, default=0.0, help="time allowed per attempt (default: 240 s for up to 50 steps, 420 s otherwise)")
     args = ap.parse_args()
 
+    is_child = os.environ.get("GROOVE_BENCH_CHILD") == "1"
+    supervise = not args.no_watchdog and not under_profiler()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # Not under a launcher: start the N ranks ourselves, before anything initialises a GPU in this process.
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
@@ -489,22 +762,42 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: fewer (or more) ranks than GPUs asked for")
-    if args.dry_launch:
-        sys.exit(dry_launch(world, rank))
-
-    # Watchdog (one GPU, not under a launcher): about one process in twenty on this pool crawls on the multi-stream path
-    # (DESIGN.md section 7: one render kernel of the million-voice step takes seconds, block after block, for as long as
-    # the process lives; the next process is fine).  The measurement therefore runs in a child process; a child that
-    # has not finished in time is killed (its exact PID) and the run starts again, and the line says how often.
-    fake = os.environ.get("GROOVE_BENCH_FAKE_STALL_ONCE")  # test hook of the watchdog (tests/test_projects_cpu.py): no GPU involved
-    if fake and os.environ.get("GROOVE_BENCH_CHILD") == "1":
+    # test hooks of the watchdogs (tests/test_projects_cpu.py): no GPU involved
+    fake = os.environ.get("GROOVE_BENCH_FAKE_STALL_ONCE")
+    if fake and is_child and (world == 1 or rank == world - 1):
         if not os.path.exists(fake):
             open(fake, "w").close()
+            if os.environ.get("GROOVE_BENCH_FAKE_STALL_EXIT") == "1":
+                sys.exit(RANK_STALL_EXIT)
             time.sleep(3600)
+    if world > 1 and not is_child and supervise:
+        # Under an external launcher (torch.distributed.run): this process supervises, a child of it is the rank.
+        sys.exit(supervise_rank(sys.argv[1:], rank, world))
+    if args.dry_launch:
+        sys.exit(dry_launch(world, rank))
+    if fake and is_child and world == 1:
         print(json.dumps({"metric": "fake", "value": 1.0}), flush=True)
         sys.exit(0)
-    if world == 1 and "WORLD_SIZE" not in os.environ and not args.no_watchdog and os.environ.get("GROOVE_BENCH_CHILD") != "1":
+
+    # Watchdog (one GPU, not under a launcher): about one process in fifteen on this pool crawls on the multi-stream path
+    # (DESIGN.md section 7: one render kernel of the million-voice step takes seconds, block after block, for as long as
+    # the process lives; the next process is fine).  The measurement therefore runs in a child process; a child that
+    # has not finished in time — or whose library reported the stalled stream itself — is killed (its exact PID) and the
+    # run starts again, and the line says how often.  Never from under a profiler.
+    if world == 1 and "WORLD_SIZE" not in os.environ and supervise and not is_child:
         sys.exit(run_under_watchdog(sys.argv[1:], args))
+    from groove_amd.lib import GrooveError
+    try:
+        measure(args, world, rank, local_rank)
+    except GrooveError as e:
+        if "not complete after" in str(e):   # groove_synchronize's deadline: a stalled stream.  The ctx cannot be torn down
+            sys.stderr.write(f"bench.py rank {rank}: {e}\n")  # (hipFree would wait for the stalled kernel): leave at once
+            sys.stderr.flush()
+            os._exit(RANK_STALL_EXIT)
+        raise
+
+
+def measure(args, world, rank, local_rank):
     use_dist = world > 1 or os.environ.get("GROOVE_BENCH_FORCE_DIST") == "1"  # the latter: exercise the N>1 code path on one GPU
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -512,6 +805,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+    # a stalled stream comes back as an error after this long (the library's default is 60 s; a healthy sync here takes < 1 s)
+    os.environ.setdefault("GROOVE_SYNC_TIMEOUT_MS", "30000" if not under_profiler() else "0")
 
     wl = dict(WORKLOADS[args.workload])
     V = args.voices or wl["voices"]
@@ -519,9 +814,7 @@ def main():
     V_total = V * world if weak else V   # voices of the whole project
     lo, hi = voice_range(V_total, rank, world)
     dist = Dist(rank, world, local_rank) if use_dist else None
-    ctx = E.Context(local_rank if use_dist else 0)
-    if dist is not None:
-        dist.attach(ctx)
+    ctx = dist.make_context() if dist is not None else E.Context(0)
     if dist is not None and dist.rccl_ranks != world:
         sys.stderr.write(f"bench.py: the communicator has {dist.rccl_ranks} ranks, {world} GPUs were asked for\n")
         ctx.close()
@@ -531,7 +824,7 @@ def main():
     K, W, R = args.steps, args.warmup, max(1, args.repeats)
     sel = np.arange(lo, hi, dtype=np.int64)
     m = bench_workload(ctx, args.workload, sel, K, W, R, fused=fused, grouped=not args.interleaved,
-                       render_ahead=not args.no_render_ahead, dist=dist)
+                       render_ahead=not args.no_render_ahead, dist=dist, head_ahead=not args.no_head_ahead)
     line = None
     if rank == 0:
         i = m["median"]
@@ -549,6 +842,7 @@ def main():
             "config": {"workload": f"{args.workload}: {V_total} voices total, {FRAMES}-frame blocks, {SR} Hz, "
                                    f"{'fused render+mix' if fused else 'materialised blocks + mix kernels'}",
                        "voices_total": V_total, "voices_per_gpu": n_local,
+                       "kernel_form": m["kernel_form"],
                        "bus_reduce": (dist.reduce_via if dist else "none (one rank)"),
                        "parallelism": (f"voices sharded x{world} ("
                                        + (f"weak: {V} voices per GPU, the project grows with N; value = the merged project's frames/s, voice_frames_per_s scales"
@@ -563,8 +857,9 @@ def main():
             "project_frames_per_s": project_fps,
             "voice_frames_per_s": project_fps * V_total,
             "path_effective_GBs": wl["bytes_per_vf"] * project_fps * V_total / 1e9,
-            "roofline": roofline_block(args.workload, n_local, kern_ms, m["span_mode"], fused),
+            "roofline": roofline_block(args.workload, n_local, kern_ms, m["span_mode"], fused, window=(K, W)),
             "output_check": {"finite": bool(np.isfinite(out_bus).all()), "peak_abs_bus_over_V": float(np.abs(out_bus).max() / V_total)},
+            "streams": ctx.debug_info(),
         }
         if dist is not None:
             line["rccl_ranks"] = dist.rccl_ranks
@@ -572,11 +867,20 @@ def main():
         dist.dist.barrier()
         dist.dist.destroy_process_group()
     if rank == 0 and world == 1:
+        default_line = args.workload == "welsh-1m" and not args.voices and fused and not args.interleaved
         if not args.no_parity:
-            line["parity_vs_oracle"] = sampled_parity(ctx, args.workload, V_total, min(K + W, 48), sample=128, fused=fused,
+            line["parity_vs_oracle"] = sampled_parity(ctx, args.workload, V_total, min(K + W, 48), sample=256 if default_line else 128, fused=fused,
                                                       grouped=not args.interleaved)
-        if args.workload == "welsh-1m" and not args.no_configs and not args.voices and fused and not args.interleaved:
+        if default_line and not args.no_configs:
             line["configs"] = [config_entry(ctx, w, R) for w in ("welsh-256", "chain-4096", "sampler-16384", "mixed-131072")]
+            Kf, Wf = min(K, 20), min(W, 5)
+            line["configs"].append(form_entry(ctx, "welsh-1m-materialised", Kf, Wf, False, True,
+                                              "entity-boundary form: every voice block written to HBM (2 GB per block), mixed from the render's row sums"))
+            line["configs"].append(form_entry(ctx, "welsh-1m-interleaved-materialised", Kf, Wf, False, False,
+                                              "the same with patch i mod 32 on voice i (no two neighbouring voices share a patch): regrouped inside the library"))
+        if default_line and not args.no_shard_curve:
+            line["shard_curve"] = shard_curve(ctx, min(K, 20), min(W, 5), line["ms_per_step"] if (K, W) == (min(K, 20), min(W, 5)) else
+                                              bench_workload(ctx, "welsh-1m", sel, min(K, 20), min(W, 5), 1)["walls"][0] / min(K, 20) * 1e3)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload)
     ctx.close()

@@ -17,6 +17,8 @@
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
+#include <thread>
 #include <new>
 
 using namespace groove;
@@ -126,6 +128,8 @@ struct groove_fx {
   uint64_t ap_alt[2] = {0, 0};
   float* d_tmp = nullptr;
   uint32_t tmp_cap = 0; // frames
+  int last_side = -1;           // side stream whose kernels touched this effect last (-1: the ctx stream); fx_acquire_ctx
+  hipEvent_t ev_done = nullptr; // end of that use
 };
 
 // Events that only order the library's own streams on one device: no timing, and no system-scope fence
@@ -167,6 +171,13 @@ struct groove_ctx {
   bool seq_allpass = false;             // GROOVE_FX_SEQ_ALLPASS=1: the sequential all-pass kernel (A/B and bit-identity tests)
   bool chunked_allpass = false;         // GROOVE_FX_CHUNKED_ALLPASS=1: the chunk-parallel all-pass kernel instead of the direct one
   uint32_t sr = GROOVE_DEFAULT_SAMPLE_RATE;
+  // Blocking waits (groove_synchronize and every call that hands data to the host) poll the stream with a deadline
+  // instead of sleeping inside hipStreamSynchronize: a kernel that does not complete then comes
+  // back as an ERROR that names the streams still busy, not as a hang.  0 = wait for ever.  GROOVE_SYNC_TIMEOUT_MS.
+  uint32_t sync_timeout_ms = 60000;
+  bool safe_streams = false;            // GROOVE_SAFE_STREAMS=1: one priority, four streams in all (ctx + three that kinds and banks share)
+  bool comm_before_streams = false;     // groove_init_comm: the RCCL communicator (and its streams) existed before the library's own
+  int streams_created = 0;              // hipStreamCreate* calls of this ctx, in order: ctx, kind streams, placeholder, bank streams
   std::string err;
   std::vector<groove_bank*> banks;
   std::vector<groove_fx*> fxs;
@@ -194,6 +205,7 @@ int fail(groove_ctx* ctx, const std::string& msg) {
 #define GHIP(ctx, expr)                                                                    \
   do {                                                                                     \
     hipError_t e_ = (expr);                                                                \
+    if (e_ == hipErrorNotReady) return 2; /* a deadline passed: wait_deadline wrote the message */ \
     if (e_ != hipSuccess)                                                                  \
       return fail(ctx, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
   } while (0)
@@ -201,10 +213,50 @@ int fail(groove_ctx* ctx, const std::string& msg) {
 // Synchronous copies go through the CTX stream, never the null stream: the null stream is one more normal-priority
 // stream for the runtime to map, and with the four kind streams it made five on four hardware queues — the fourth kind
 // stream shared its queue with it (rocprofv3 trace, round 2).
+const char* side_stream_name(int k) {
+  static const char* names[] = {"kind stream 0 (Welsh F32 static; also kinds 3 and 4)", "kind stream 1 (Welsh F32 retune; also kind 5)",
+                                "kind stream 2 (Welsh smooth-LFO static)", "kind stream 3 (Welsh smooth-LFO retune)",
+                                "kind stream 4", "kind stream 5", "bank stream 0", "bank stream 1", "bank stream 2", "bank stream 3"};
+  return k >= 0 && k < 10 ? names[k] : "side stream";
+}
+// Wait for `st` (or, if `ev` is given, for that event) with the ctx's deadline.  hipSuccess when it completed;
+// hipErrorNotReady when the deadline passed — ctx->err then names every library stream that still has work.  Nothing is
+// cancelled: the work stays queued and a later wait may still see it complete.
+hipError_t wait_deadline(groove_ctx* ctx, hipStream_t st, hipEvent_t ev, const char* what) {
+  if (ctx->sync_timeout_ms == 0) return ev ? hipEventSynchronize(ev) : hipStreamSynchronize(st);
+  const auto t0 = std::chrono::steady_clock::now();
+  const auto limit = std::chrono::milliseconds(ctx->sync_timeout_ms);
+  for (uint32_t spins = 0;; ++spins) {
+    const hipError_t q = ev ? hipEventQuery(ev) : hipStreamQuery(st);
+    if (q != hipErrorNotReady) return q;
+    const auto waited = std::chrono::steady_clock::now() - t0;
+    if (waited > limit) break;
+    // the first ~100 us busy-poll (most waits of this path are that short), then yield, then sleep in growing steps
+    if (spins < 64) continue;
+    if (waited < std::chrono::milliseconds(2)) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(waited < std::chrono::milliseconds(50) ? 50 : 500));
+  }
+  std::string busy;
+  if (hipStreamQuery(ctx->stream) == hipErrorNotReady) busy += "ctx stream";
+  for (int k = 0; k < kSideStreams; ++k) {
+    hipStream_t s = ctx->side_stream[k];
+    if (!s) continue;
+    bool dup = false;
+    for (int j = 0; j < k; ++j) dup = dup || ctx->side_stream[j] == s;
+    if (dup) continue;
+    if (hipStreamQuery(s) == hipErrorNotReady) { if (!busy.empty()) busy += ", "; busy += side_stream_name(k); }
+  }
+  (void)hipGetLastError(); // hipErrorNotReady is sticky in the runtime's last-error slot
+  fail(ctx, std::string(what) + ": not complete after " + std::to_string(ctx->sync_timeout_ms) + " ms (GROOVE_SYNC_TIMEOUT_MS / groove_set_sync_timeout_ms); still busy: " +
+                (busy.empty() ? "nothing (the wait itself raced the completion)" : busy) +
+                ".  The work stays queued; a kernel that crawls like this does so for the life of the process (DESIGN.md section 7): tear the process down and start again.");
+  return hipErrorNotReady;
+}
+hipError_t ctx_wait(groove_ctx* ctx, const char* what = "wait for the ctx stream") { return wait_deadline(ctx, ctx->stream, nullptr, what); }
 hipError_t ctx_memcpy(groove_ctx* ctx, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
   hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, ctx->stream);
   if (e != hipSuccess) return e;
-  return hipStreamSynchronize(ctx->stream);
+  return ctx_wait(ctx, "copy on the ctx stream");
 }
 hipStream_t side_stream_of(groove_ctx* ctx, int k) {
   if (!ctx->side_stream[k] && hipStreamCreateWithFlags(&ctx->side_stream[k], hipStreamNonBlocking) != hipSuccess) {
@@ -239,6 +291,15 @@ int block_acquire(groove_block* blk) {
   blk->ready_mask = 0;
   return 0;
 }
+// An effect's memory (IIR state, rings, parameter arrays) is touched by one stream at a time: the ctx stream, or — for the
+// stages groove_fx_chain_process_async runs behind a block's asynchronous render — that render's side stream.  ev_done
+// marks the end of its last side-stream use; the ctx stream waits for it before it touches the effect again.
+int fx_acquire_ctx(groove_fx* fx) {
+  if (fx->last_side < 0) return 0;
+  GHIP(fx->ctx, hipStreamWaitEvent(fx->ctx->stream, fx->ev_done, 0));
+  fx->last_side = -1;
+  return 0;
+}
 // A bank's state is touched by one set of side streams at a time; changing the set joins first.
 int bank_side_mode(groove_bank* b, int mode) {
   if (b->side_mode && b->side_mode != mode && ctx_join(b->ctx)) return 1;
@@ -261,7 +322,7 @@ template <class T>
 int upload_soa(groove_ctx* ctx, uint32_t* dst, const std::vector<T>& aos) {
   std::vector<uint32_t> soa = to_soa(aos);
   GHIP(ctx, hipMemcpyAsync(dst, soa.data(), soa.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  GHIP(ctx, ctx_wait(ctx));
   return 0;
 }
 inline uint32_t blocks_for(size_t items) { return (uint32_t)((items + kThreads - 1) / kThreads); }
@@ -532,7 +593,7 @@ int flush_events(groove_bank* b, bool inline_ok = false) {
   // stream and the call returns without a host synchronisation.
   const int hs = b->ev_slot;
   b->ev_slot ^= 1;
-  if (b->staged[hs]) GHIP(ctx, hipEventSynchronize(b->ev_staged[hs])); // two flushes ago: long done
+  if (b->staged[hs]) GHIP(ctx, wait_deadline(ctx, nullptr, b->ev_staged[hs], "note-event staging slot")); // two flushes ago: long done
   if (b->h_ev_cap[hs] < ev.size()) {
     if (b->h_ev[hs]) GHIP(ctx, hipHostFree(b->h_ev[hs]));
     if (b->d_ev[hs]) GHIP(ctx, hipFree(b->d_ev[hs]));
@@ -764,14 +825,24 @@ using nccl_count_fn = decltype(&ncclCommCount);
 using nccl_errstr_fn = decltype(&ncclGetErrorString);
 static_assert(sizeof(ncclUniqueId) == 128, "groove_comm_unique_id hands out a 128-byte id");
 
+void* g_rccl = nullptr; // one RCCL per process, whichever ctx asks first
 int rccl_open(groove_ctx* ctx) {
-  if (ctx->rccl) return 0;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* nm : names) {
-    ctx->rccl = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-    if (ctx->rccl) return 0;
+  if (!g_rccl) {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names) {
+      g_rccl = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+      if (g_rccl) break;
+    }
   }
-  return fail(ctx, std::string("dlopen(librccl) failed: ") + dlerror());
+  if (!g_rccl) return fail(ctx, std::string("dlopen(librccl) failed: ") + dlerror());
+  if (ctx) ctx->rccl = g_rccl;
+  return 0;
+}
+
+// Test hook (groove_debug_spin): one wave that sleeps until `ticks` of the constant-rate wall clock have passed.
+__global__ void debug_spin_kernel(uint64_t ticks) {
+  const uint64_t t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
 }
 
 } // namespace
@@ -779,7 +850,53 @@ int rccl_open(groove_ctx* ctx) {
 extern "C" {
 
 // ============================================================================ context
-int groove_init(int device_ordinal, groove_ctx** out) {
+// The library's streams, in the order the design of DESIGN.md section 7 wants them created: ctx (highest priority),
+// three normal-priority kind streams, the placeholder in fifth place, then the low-priority bank streams.
+static bool create_streams(groove_ctx* ctx) {
+  // The runtime spreads the streams of one priority over a handful of hardware queues, and streams that
+  // share a queue run one after the other.  The ctx stream is created at the highest priority: that
+  // gives it a hardware queue of its own, so that a bank's side stream can never land behind it (as a
+  // normal-priority stream it shared a queue with the first bank stream and the render-ahead overlap of
+  // config #3 was gone: 0.25 ms per block against 0.14), and its short bus reductions, which every
+  // pipelined block waits for, are dispatched ahead of the long render kernels.
+  int prio_least = 0, prio_greatest = 0;
+  const char* flat = std::getenv("GROOVE_STREAM_PRIORITIES"); // "0": every stream at the normal priority (A/B)
+  bool ok = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess;
+  if (ok && ((flat && flat[0] == '0') || ctx->safe_streams)) prio_least = prio_greatest = 0;
+  auto make = [&](hipStream_t* st, int prio) {
+    const bool made = hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio) == hipSuccess;
+    if (made) ctx->streams_created += 1;
+    return made;
+  };
+  ok = ok && make(&ctx->stream, prio_greatest) && hipEventCreateWithFlags(&ctx->ev_fork, kSyncEventFlags) == hipSuccess;
+  // Normal-priority streams for the four class-specialised Welsh kinds (side by side in every block
+  // of a big bank; the two exact-f64-LFO kinds, rare, share the first two), and three LOW-priority streams
+  // for the single-kernel banks (side by side in a mixed project): never more streams than hardware queues,
+  // so no two of them are serialised behind each other by the runtime (see bank_streams).
+  // SAFE layout (GROOVE_SAFE_STREAMS=1): one priority and four streams in all — the ctx stream and three side streams
+  // that kinds and banks share — so that no two streams of this library ever share a hardware queue and nothing rests
+  // on the order in which the process created its streams.  Measured cost: about 8 % at 1,000,000 voices.
+  for (int i = 0; ok && i < kSideStreams; ++i) {
+    if (i >= kBaseKinds + ctx->bank_streams) { ok = hipEventCreateWithFlags(&ctx->ev_join[i], kSyncEventFlags) == hipSuccess; continue; }
+    if (i == 4 || i == 5) ctx->side_stream[i] = ctx->side_stream[i - 4];
+    else if (i == 3 && ctx->kind_streams == 3) { // three normal-priority streams (see kind_streams); the fifth stream the
+      // process creates lands on the ctx stream's hardware queue (so does the ninth): that place is taken by a stream nobody uses
+      if (!ctx->safe_streams) ok = make(&ctx->placeholder_stream, 0);
+      ctx->side_stream[3] = ctx->side_stream[0];
+    }
+    else if (i < kBaseKinds) ok = make(&ctx->side_stream[i], 0);
+    else if (ctx->safe_streams) ctx->side_stream[i] = ctx->side_stream[(i - kBaseKinds) % 3];
+    else ok = make(&ctx->side_stream[i], prio_least);
+    ok = ok && hipEventCreateWithFlags(&ctx->ev_join[i], kSyncEventFlags) == hipSuccess;
+  }
+  return ok;
+}
+static bool side_stream_owned(const groove_ctx* ctx, int i) {
+  if (!ctx->side_stream[i] || i == 4 || i == 5 || (i == 3 && ctx->kind_streams == 3)) return false;
+  return !(ctx->safe_streams && i >= kBaseKinds);
+}
+static int comm_init_rank(groove_ctx* ctx, const uint8_t id[128], int rank, int world_size);
+static int init_impl(int device_ordinal, const uint8_t* comm_id, int rank, int world_size, groove_ctx** out) {
   if (!out) return fail(nullptr, "groove_init: out is NULL");
   *out = nullptr;
   int count = 0;
@@ -792,7 +909,10 @@ int groove_init(int device_ordinal, groove_ctx** out) {
   if (!ctx) return fail(nullptr, "groove_init: out of memory");
   ctx->device = device_ordinal;
   if (const char* e = std::getenv("GROOVE_FX_SEQ_ALLPASS")) ctx->seq_allpass = e[0] == '1';
+  if (const char* e = std::getenv("GROOVE_SAFE_STREAMS")) ctx->safe_streams = e[0] == '1';
+  if (const char* e = std::getenv("GROOVE_SYNC_TIMEOUT_MS")) ctx->sync_timeout_ms = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_KIND_STREAMS")) ctx->kind_streams = std::atoi(e) == 4 ? 4 : 3;
+  if (ctx->safe_streams) ctx->kind_streams = 3;
   if (const char* e = std::getenv("GROOVE_BANK_STREAMS")) ctx->bank_streams = std::max(1, std::min(kBankStreams, std::atoi(e)));
   if (const char* e = std::getenv("GROOVE_FM_TP_MAX_VOICES")) ctx->fm_tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_SEG_MAX_LANES")) ctx->fx_seg_max_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
@@ -801,40 +921,26 @@ int groove_init(int device_ordinal, groove_ctx** out) {
   if (const char* e = std::getenv("GROOVE_TP_MAX_VOICES")) ctx->tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_TP_MAX_LANES")) ctx->fx_tp_max_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_PIPELINE_MIN_WAVES")) ctx->pipeline_min_waves = (uint32_t)std::strtoul(e, nullptr, 10); // tests force the pipeline on small banks
-  // The runtime spreads the streams of one priority over a handful of hardware queues, and streams that
-  // share a queue run one after the other.  The ctx stream is created at the highest priority: that
-  // gives it a hardware queue of its own, so that a bank's side stream can never land behind it (as a
-  // normal-priority stream it shared a queue with the first bank stream and the render-ahead overlap of
-  // config #3 was gone: 0.25 ms per block against 0.14), and its short bus reductions, which every
-  // pipelined block waits for, are dispatched ahead of the long render kernels.
-  int prio_least = 0, prio_greatest = 0;
-  const char* flat = std::getenv("GROOVE_STREAM_PRIORITIES"); // "0": every stream at the normal priority (A/B)
-  bool ok = hipSetDevice(device_ordinal) == hipSuccess && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess;
-  if (ok && flat && flat[0] == '0') prio_least = prio_greatest = 0;
-  ok = ok && hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
-            hipEventCreateWithFlags(&ctx->ev_fork, kSyncEventFlags) == hipSuccess;
-  // Four normal-priority streams for the four class-specialised Welsh kinds (side by side in every block
-  // of a big bank; the two exact-f64-LFO kinds, rare, share the first two), and three LOW-priority streams
-  // for the single-kernel banks (side by side in a mixed project): never more streams than hardware queues,
-  // so no two of them are serialised behind each other by the runtime (see bank_streams).
-  for (int i = 0; ok && i < kSideStreams; ++i) {
-    if (i >= kBaseKinds + ctx->bank_streams) { ok = hipEventCreateWithFlags(&ctx->ev_join[i], kSyncEventFlags) == hipSuccess; continue; }
-    if (i == 4 || i == 5) ctx->side_stream[i] = ctx->side_stream[i - 4];
-    else if (i == 3 && ctx->kind_streams == 3) { // three normal-priority streams (see kind_streams); the fifth stream the
-      // process creates lands on the ctx stream's hardware queue (so does the ninth): that place is taken by a stream nobody uses
-      ok = hipStreamCreateWithFlags(&ctx->placeholder_stream, hipStreamNonBlocking) == hipSuccess;
-      ctx->side_stream[3] = ctx->side_stream[0];
-    }
-    else if (i < kBaseKinds) ok = hipStreamCreateWithFlags(&ctx->side_stream[i], hipStreamNonBlocking) == hipSuccess;
-    else ok = hipStreamCreateWithPriority(&ctx->side_stream[i], hipStreamNonBlocking, prio_least) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&ctx->ev_join[i], kSyncEventFlags) == hipSuccess;
+  bool ok = hipSetDevice(device_ordinal) == hipSuccess;
+  // groove_init_comm: the rank's RCCL communicator first, so that whatever streams RCCL creates for itself exist BEFORE
+  // the library's five, which then follow each other in the process's creation order as section 7's layout assumes
+  // (with groove_comm_init after groove_init, RCCL's streams became the ctx stream's queue-mates in every rank).
+  if (ok && comm_id) {
+    if (comm_init_rank(ctx, comm_id, rank, world_size)) { const std::string m = ctx->err; delete ctx; return fail(nullptr, m); }
+    ctx->comm_before_streams = true;
   }
+  ok = ok && create_streams(ctx);
   if (!ok) {
     groove_shutdown(ctx);
     return fail(nullptr, "groove_init: hipSetDevice/hipStreamCreate failed");
   }
   *out = ctx;
   return 0;
+}
+int groove_init(int device_ordinal, groove_ctx** out) { return init_impl(device_ordinal, nullptr, 0, 1, out); }
+int groove_init_comm(int device_ordinal, const uint8_t id[128], int rank, int world_size, groove_ctx** out) {
+  if (!id) return fail(nullptr, "groove_init_comm: id is NULL");
+  return init_impl(device_ordinal, id, rank, world_size, out);
 }
 void groove_shutdown(groove_ctx* ctx) {
   if (!ctx) return;
@@ -850,7 +956,7 @@ void groove_shutdown(groove_ctx* ctx) {
   if (ctx->d_i16) (void)hipFree(ctx->d_i16);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   for (int i = 0; i < kSideStreams; ++i) {
-    if (ctx->side_stream[i] && i != 4 && i != 5 && !(i == 3 && ctx->kind_streams == 3)) { (void)hipStreamSynchronize(ctx->side_stream[i]); (void)hipStreamDestroy(ctx->side_stream[i]); }
+    if (side_stream_owned(ctx, i)) { (void)hipStreamSynchronize(ctx->side_stream[i]); (void)hipStreamDestroy(ctx->side_stream[i]); }
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
   }
   if (ctx->placeholder_stream) (void)hipStreamDestroy(ctx->placeholder_stream);
@@ -861,7 +967,7 @@ const char* groove_last_error(groove_ctx* ctx) { return ctx ? ctx->err.c_str() :
 int groove_set_stream(groove_ctx* ctx, void* hip_stream) {
   if (!ctx) return fail(nullptr, "groove_set_stream: ctx is NULL");
   if (ctx_join(ctx)) return 1;
-  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  GHIP(ctx, ctx_wait(ctx));
   if (ctx->own_stream && ctx->stream) GHIP(ctx, hipStreamDestroy(ctx->stream));
   ctx->stream = (hipStream_t)hip_stream;
   ctx->own_stream = false;
@@ -870,27 +976,70 @@ int groove_set_stream(groove_ctx* ctx, void* hip_stream) {
 int groove_synchronize(groove_ctx* ctx) {
   if (!ctx) return fail(nullptr, "groove_synchronize: ctx is NULL");
   if (ctx_join(ctx)) return 1;
-  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  GHIP(ctx, ctx_wait(ctx, "groove_synchronize"));
+  return 0;
+}
+int groove_set_sync_timeout_ms(groove_ctx* ctx, uint32_t ms) {
+  if (!ctx) return fail(nullptr, "groove_set_sync_timeout_ms: ctx is NULL");
+  ctx->sync_timeout_ms = ms;
+  return 0;
+}
+uint32_t groove_sync_timeout_ms(groove_ctx* ctx) { return ctx ? ctx->sync_timeout_ms : 0; }
+int groove_debug_spin(groove_ctx* ctx, int side_stream, uint32_t ms) {
+  if (!ctx) return fail(nullptr, "groove_debug_spin: ctx is NULL");
+  if (side_stream >= kSideStreams) return fail(ctx, "groove_debug_spin: no such side stream");
+  int khz = 0;
+  GHIP(ctx, hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device));
+  if (khz <= 0) khz = 100000; // 100 MHz
+  hipStream_t st = side_stream < 0 ? ctx->stream : side_stream_of(ctx, side_stream);
+  hipLaunchKernelGGL(debug_spin_kernel, dim3(1), dim3(64), 0, st, (uint64_t)ms * (uint64_t)khz);
+  GHIP(ctx, hipGetLastError());
+  if (side_stream >= 0) ctx->side_busy[side_stream] = true;
+  return 0;
+}
+int groove_debug_info(groove_ctx* ctx, char* out, size_t cap) {
+  if (!ctx || !out || cap == 0) return fail(ctx, "groove_debug_info: NULL argument");
+  int distinct = 0;
+  for (int k = 0; k < kSideStreams; ++k) {
+    bool dup = !ctx->side_stream[k];
+    for (int j = 0; j < k && !dup; ++j) dup = ctx->side_stream[j] == ctx->side_stream[k];
+    distinct += dup ? 0 : 1;
+  }
+  std::snprintf(out, cap,
+                "{\"layout\": \"%s\", \"streams_created\": %d, \"distinct_side_streams\": %d, \"kind_streams\": %d, \"bank_streams\": %d, "
+                "\"placeholder_fifth\": %s, \"comm_before_streams\": %s, \"own_ctx_stream\": %s, \"sync_timeout_ms\": %u}",
+                ctx->safe_streams ? "safe (one priority, ctx + 3 shared side streams)" : "default (ctx high, 3 kind streams normal, placeholder, bank streams low)",
+                ctx->streams_created, distinct, ctx->kind_streams, ctx->safe_streams ? 0 : ctx->bank_streams, ctx->placeholder_stream ? "true" : "false",
+                ctx->comm_before_streams ? "true" : "false", ctx->own_stream ? "true" : "false", ctx->sync_timeout_ms);
   return 0;
 }
 uint32_t groove_sample_rate(groove_ctx* ctx) { return ctx ? ctx->sr : 0; }
 int groove_set_time_parallel_max_voices(groove_ctx* ctx, uint32_t max_voices) {
   if (!ctx) return fail(nullptr, "groove_set_time_parallel_max_voices: ctx is NULL");
   if (ctx_join(ctx)) return 1; // banks change kernels (and side streams) at their next render
-  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  GHIP(ctx, ctx_wait(ctx));
   ctx->tp_max_voices = max_voices;
   return 0;
 }
 uint32_t groove_time_parallel_max_voices(groove_ctx* ctx) { return ctx ? ctx->tp_max_voices : 0; }
+int groove_set_pipeline_min_waves(groove_ctx* ctx, uint32_t waves) {
+  if (!ctx) return fail(nullptr, "groove_set_pipeline_min_waves: ctx is NULL");
+  if (ctx_join(ctx)) return 1; // banks change kernels (and side streams) at their next render
+  GHIP(ctx, ctx_wait(ctx));
+  ctx->pipeline_min_waves = waves;
+  return 0;
+}
+uint32_t groove_pipeline_min_waves(groove_ctx* ctx) { return ctx ? ctx->pipeline_min_waves : 0; }
 int groove_update_sample_rate(groove_ctx* ctx, uint32_t hz) {
   if (!ctx) return fail(nullptr, "groove_update_sample_rate: ctx is NULL");
   if (hz < 1000 || hz > 768000) return fail(ctx, "groove_update_sample_rate: unsupported rate");
   if (ctx_join(ctx)) return 1;
-  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  GHIP(ctx, ctx_wait(ctx));
   ctx->sr = hz;
   for (groove_bank* b : ctx->banks)
     if (bank_derive_and_upload(b)) return 1;
   for (groove_fx* fx : ctx->fxs) {
+    fx->last_side = -1; // joined above
     if (fx_setup_state(fx)) return 1;
     if (fx_upload_params(fx)) return 1;
   }
@@ -915,7 +1064,7 @@ int groove_event_record(groove_ctx* ctx, void* event) {
 }
 int groove_event_elapsed_ms(groove_ctx* ctx, void* start, void* stop, float* out_ms) {
   if (!ctx || !start || !stop || !out_ms) return fail(ctx, "groove_event_elapsed_ms: NULL argument");
-  GHIP(ctx, hipEventSynchronize((hipEvent_t)stop));
+  GHIP(ctx, wait_deadline(ctx, nullptr, (hipEvent_t)stop, "groove_event_elapsed_ms"));
   GHIP(ctx, hipEventElapsedTime(out_ms, (hipEvent_t)start, (hipEvent_t)stop));
   return 0;
 }
@@ -944,7 +1093,17 @@ int groove_block_destroy(groove_block* b) {
   delete b;
   return 0;
 }
-float* groove_block_device_ptr(groove_block* b) { return b ? b->d : nullptr; }
+float* groove_block_device_ptr(groove_block* b) {
+  // The pointer escapes: whatever the caller's own kernels do to the block, the row sums the last render left no
+  // longer describe it (groove_mix would put the pre-modification audio on the bus).
+  if (b) b->sums_valid = false;
+  return b ? b->d : nullptr;
+}
+int groove_block_mark_dirty(groove_block* b) {
+  if (!b) return fail(nullptr, "groove_block_mark_dirty: block is NULL");
+  b->sums_valid = false;
+  return 0;
+}
 uint32_t groove_block_lanes(groove_block* b) { return b ? b->n : 0; }
 uint32_t groove_block_frames_cap(groove_block* b) { return b ? b->cap : 0; }
 int groove_block_upload(groove_block* b, const float* host, uint32_t frames) {
@@ -956,7 +1115,7 @@ int groove_block_upload(groove_block* b, const float* host, uint32_t frames) {
   const size_t per = (size_t)frames * b->n;
   for (int ch = 0; ch < 2; ++ch)
     GHIP(ctx, hipMemcpyAsync(b->d + (size_t)ch * b->cap * b->n, host + ch * per, per * 4, hipMemcpyHostToDevice, ctx->stream));
-  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  GHIP(ctx, ctx_wait(ctx));
   return 0;
 }
 int groove_block_download(groove_block* b, float* host, uint32_t frames) {
@@ -967,7 +1126,7 @@ int groove_block_download(groove_block* b, float* host, uint32_t frames) {
   const size_t per = (size_t)frames * b->n;
   for (int ch = 0; ch < 2; ++ch)
     GHIP(ctx, hipMemcpyAsync(host + ch * per, b->d + (size_t)ch * b->cap * b->n, per * 4, hipMemcpyDeviceToHost, ctx->stream));
-  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  GHIP(ctx, ctx_wait(ctx));
   return 0;
 }
 
@@ -1073,7 +1232,7 @@ int groove_bank_set_param(groove_bank* b, uint32_t voice, uint32_t control_index
   }
   // control-plane path: re-derive and re-upload the parameter tables (state is untouched)
   if (ctx_join(ctx)) return 1;
-  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  GHIP(ctx, ctx_wait(ctx));
   return welsh_upload_params(b, false); // the state stays where it is: keep the lane order
 }
 // The block's row-sum buffer for a render of `rows` partial rows (reallocated when it grows).
@@ -1219,7 +1378,7 @@ int groove_bank_render(groove_bank* b, uint32_t frames, groove_block* out) {
   if (b->perm.empty()) return launch_render(b, frames, false, (size_t)out->cap * out->n, out->d, rows) || rendered();
   // regrouped bank: render in the internal lane order (coalesced rows), then hand the caller's order out
   if (!b->scratch || b->scratch->cap < frames) {
-    if (b->scratch) { GHIP(ctx, hipStreamSynchronize(ctx->stream)); groove_block_destroy(b->scratch); b->scratch = nullptr; }
+    if (b->scratch) { GHIP(ctx, ctx_wait(ctx)); groove_block_destroy(b->scratch); b->scratch = nullptr; }
     if (groove_block_create(ctx, b->n, std::max<uint32_t>(frames, GROOVE_BLOCK_FRAMES), &b->scratch)) return 1;
   }
   if (launch_render(b, frames, false, (size_t)b->scratch->cap * b->n, b->scratch->d, rows)) return 1; // (a sum has no lane order)
@@ -1261,7 +1420,7 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
   if (regrouped) { // render in the internal lane order, gather into the caller's order afterwards
     if (!b->scratch || b->scratch->cap < frames) {
       if (ctx_join(ctx)) return 1;
-      GHIP(ctx, hipStreamSynchronize(ctx->stream));
+      GHIP(ctx, ctx_wait(ctx));
       if (b->scratch) { groove_block_destroy(b->scratch); b->scratch = nullptr; }
       if (groove_block_create(ctx, b->n, std::max<uint32_t>(frames, GROOVE_BLOCK_FRAMES), &b->scratch)) return 1;
       b->gather_recorded = false;
@@ -1362,6 +1521,7 @@ int groove_block_release(groove_block* b) {
 }
 int groove_block_acquire(groove_block* b) {
   if (!b) return fail(nullptr, "groove_block_acquire: block is NULL");
+  b->sums_valid = false; // the caller is about to run its own kernels on the block (include/groove_hip.h)
   return block_acquire(b);
 }
 // Fused render + mix of a wave-uniform Welsh bank, pipelined over blocks.  Every base kind has its
@@ -1383,7 +1543,7 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
   b->pipe_slot ^= 1;
   if (b->pipe_part_cap[slot] < (size_t)rows * cols || b->pipe_seg_cap[slot] < (size_t)segs * cols) {
     if (ctx_join(ctx)) return 1;
-    GHIP(ctx, hipStreamSynchronize(ctx->stream));
+    GHIP(ctx, ctx_wait(ctx));
     if (b->d_pipe_part[slot]) GHIP(ctx, hipFree(b->d_pipe_part[slot]));
     GHIP(ctx, hipMalloc(&b->d_pipe_part[slot], (size_t)rows * cols * 4));
     b->pipe_part_cap[slot] = (size_t)rows * cols;
@@ -1482,6 +1642,19 @@ int groove_bank_render_mix(groove_bank* b, uint32_t frames, float* bus_dev, int 
   GHIP(ctx, hipGetLastError());
   return 0;
 }
+const char* groove_bank_kernel_form(groove_bank* b, uint32_t frames, int fused) {
+  if (!b) return "";
+  groove_ctx* ctx = b->ctx;
+  if (use_tp(b, frames)) return b->kind == BANK_WELSH ? "welsh_tp_kernel (time-parallel, one wavefront per voice)" : b->kind == BANK_FM ? "fm_tp_kernel (time-parallel)" : "sampler_tp_kernel (time-parallel)";
+  if (b->kind == BANK_FM) return "fm_render_kernel (serial, one voice per lane)";
+  if (b->kind == BANK_SAMPLER) return "sampler_render_kernel (serial, one voice per lane)";
+  if (!b->n_vwaves) return "welsh_render_kernel (per-lane parameters)";
+  const bool pipelined = fused && (b->n_vwaves >= ctx->pipeline_min_waves || ctx->pipeline_min_waves <= 1);
+  if (b->n_vwaves >= ctx->pipeline_min_waves || (fused && ctx->pipeline_min_waves <= 1))
+    return pipelined ? "welsh_render_uniform_kernel (one launch per base kind, class-specialised bodies, blocks pipelined)"
+                     : "welsh_render_uniform_kernel (one launch per base kind, class-specialised bodies)";
+  return "welsh_render_uniform_any_kernel (all base kinds in one launch, class-specialised bodies)";
+}
 int groove_bank_reset(groove_bank* b) {
   if (!b) return fail(nullptr, "groove_bank_reset: bank is NULL");
   groove_ctx* ctx = b->ctx;
@@ -1505,7 +1678,7 @@ int groove_bank_download_state(groove_bank* b, uint32_t* host_words) {
   groove_ctx* ctx = b->ctx;
   if (flush_events(b)) return 1;
   if (ctx_join(ctx)) return 1;
-  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  GHIP(ctx, ctx_wait(ctx));
   if (b->perm.empty()) {
     GHIP(ctx, ctx_memcpy(ctx, host_words, b->d_state, (size_t)b->sw * b->n * 4, hipMemcpyDeviceToHost));
   } else { // internal lane order -> caller's voice order
@@ -1541,7 +1714,9 @@ int groove_fx_create(groove_ctx* ctx, uint32_t kind, const groove_fx_params* p, 
 int groove_fx_destroy(groove_fx* fx) {
   if (!fx) return 0;
   groove_ctx* ctx = fx->ctx;
+  (void)fx_acquire_ctx(fx);
   (void)hipStreamSynchronize(ctx->stream);
+  if (fx->ev_done) (void)hipEventDestroy(fx->ev_done);
   auto it = std::find(ctx->fxs.begin(), ctx->fxs.end(), fx);
   if (it != ctx->fxs.end()) ctx->fxs.erase(it);
   (void)hipFree(fx->d_fa); (void)hipFree(fx->d_fb); (void)hipFree(fx->d_ua); (void)hipFree(fx->d_wet);
@@ -1553,6 +1728,7 @@ int groove_fx_reset(groove_fx* fx) {
   if (!fx) return fail(nullptr, "groove_fx_reset: fx is NULL");
   groove_ctx* ctx = fx->ctx;
   GHIP(ctx, hipSetDevice(ctx->device));
+  if (fx_acquire_ctx(fx)) return 1;
   const size_t ln = 2 * (size_t)fx->n;
   if (fx->d_st) GHIP(ctx, hipMemsetAsync(fx->d_st, 0, 4 * ln * 8, ctx->stream));
   if (fx->d_ring) GHIP(ctx, hipMemsetAsync(fx->d_ring, 0, fx->ring_rows * ln * 4, ctx->stream));
@@ -1586,7 +1762,7 @@ static void fx_advance(groove_fx* fx, uint32_t frames) { // the delay lines' wri
 }
 // One launch for `count` (<= kRunMaxStages) run-capable stages in chain order; a reverb, if there is one, is the last,
 // and its all-passes follow.
-static int fx_launch_run(groove_ctx* ctx, groove_fx* const* run, uint32_t count, groove_block* io, uint32_t frames) {
+static int fx_launch_run(groove_ctx* ctx, groove_fx* const* run, uint32_t count, groove_block* io, uint32_t frames, hipStream_t st, bool last) {
   const uint32_t n = io->n;
   const size_t chs = (size_t)io->cap * n;
   FxRunArgs a{};
@@ -1606,7 +1782,7 @@ static int fx_launch_run(groove_ctx* ctx, groove_fx* const* run, uint32_t count,
     direct = !ctx->seq_allpass && !ctx->chunked_allpass && frames <= 8 * shortest_ap && (size_t)2 * io->cap * n * 4 <= ((size_t)1 << 30);
     if (direct) {
       if (rv->tmp_cap < io->cap) {
-        GHIP(ctx, hipStreamSynchronize(ctx->stream));
+        GHIP(ctx, wait_deadline(ctx, st, nullptr, "effect staging block"));
         if (rv->d_tmp) { GHIP(ctx, hipFree(rv->d_tmp)); rv->d_tmp = nullptr; rv->tmp_cap = 0; }
         GHIP(ctx, hipMalloc(&rv->d_tmp, (size_t)2 * io->cap * n * 4));
         rv->tmp_cap = io->cap;
@@ -1615,8 +1791,15 @@ static int fx_launch_run(groove_ctx* ctx, groove_fx* const* run, uint32_t count,
     }
   }
   const dim3 blk(kThreads);
-  if (n % 4 == 0) hipLaunchKernelGGL(fx_run_kernel<4>, dim3(blocks_for(2 * (size_t)n / 4), frames), blk, 0, ctx->stream, a);
-  else hipLaunchKernelGGL(fx_run_kernel<1>, dim3(blocks_for(2 * (size_t)n), frames), blk, 0, ctx->stream, a);
+  const uint32_t V = n % 4 == 0 ? 4 : 1, wg_per_ch = fx_wg_per_ch(n, V);
+  // the chain's last launch leaves the block's lane sums for groove_mix (kernels.h, fx_row_sum)
+  float* rows = last ? block_sums(io, wg_per_ch, frames) : nullptr;
+  if (last && !rows) return 1;
+  a.frames = frames; a.wg_per_ch = wg_per_ch;
+  a.rows = (rv && direct) ? nullptr : rows;
+  if (rv && !direct) rows = nullptr; // the sequential / chunked all-pass kernels run last and leave none
+  if (V == 4) hipLaunchKernelGGL(fx_run_kernel<4>, dim3(2 * wg_per_ch, frames), blk, 0, st, a);
+  else hipLaunchKernelGGL(fx_run_kernel<1>, dim3(2 * wg_per_ch, frames), blk, 0, st, a);
   if (rv) {
     const ReverbGeom& g = rv->geo;
     if (direct) {
@@ -1629,23 +1812,25 @@ static int fx_launch_run(groove_ctx* ctx, groove_fx* const* run, uint32_t count,
         d.N[i] = g.N[4 + i]; d.w[i] = g.w[4 + i]; d.g[i] = g.g[4 + i];
       }
       d.n = n; d.frames = frames;
-      const uint32_t rows = std::max(frames, std::max(g.N[4], g.N[5]));
-      if (n % 4 == 0) hipLaunchKernelGGL(fx_reverb_allpass_direct_kernel<4>, dim3(blocks_for(2 * (size_t)n / 4), rows), blk, 0, ctx->stream, d);
-      else hipLaunchKernelGGL(fx_reverb_allpass_direct_kernel<1>, dim3(blocks_for(2 * (size_t)n), rows), blk, 0, ctx->stream, d);
+      d.rows = rows; d.wg_per_ch = wg_per_ch;
+      const uint32_t grid_rows = std::max(frames, std::max(g.N[4], g.N[5]));
+      if (V == 4) hipLaunchKernelGGL(fx_reverb_allpass_direct_kernel<4>, dim3(2 * wg_per_ch, grid_rows), blk, 0, st, d);
+      else hipLaunchKernelGGL(fx_reverb_allpass_direct_kernel<1>, dim3(2 * wg_per_ch, grid_rows), blk, 0, st, d);
       for (int i = 0; i < 2; ++i) std::swap(rv->geo.base[4 + i], rv->ap_alt[i]);
     } else if (ctx->seq_allpass) {
-      hipLaunchKernelGGL(fx_reverb_allpass_kernel<32>, dim3(blocks_for(2 * (size_t)n)), blk, 0, ctx->stream, io->d, n, frames, chs, rv->d_ring, g);
+      hipLaunchKernelGGL(fx_reverb_allpass_kernel<32>, dim3(blocks_for(2 * (size_t)n)), blk, 0, st, io->d, n, frames, chs, rv->d_ring, g);
     } else { // chunks of one line length, parallel inside (kernels.h)
       const uint32_t T = std::max<uint32_t>(1, std::min<uint32_t>(64, 2 * n / 512));
-      hipLaunchKernelGGL(fx_reverb_allpass_chunked_kernel, dim3((2 * n + T - 1) / T), dim3(kAllpassThreads), 0, ctx->stream, io->d, n, frames, chs, rv->d_ring, g, T);
+      hipLaunchKernelGGL(fx_reverb_allpass_chunked_kernel, dim3((2 * n + T - 1) / T), dim3(kAllpassThreads), 0, st, io->d, n, frames, chs, rv->d_ring, g, T);
     }
   }
   for (uint32_t s = 0; s < count; ++s) fx_advance(run[s], frames);
   GHIP(ctx, hipGetLastError());
+  if (rows) { io->sum_rows = wg_per_ch; io->sum_frames = frames; io->sums_valid = true; }
   return 0;
 }
 // The kinds with feedback inside a block: the IIR filters, and delay lines shorter than the block.
-static int fx_launch_serial(groove_fx* fx, groove_block* io, uint32_t frames) {
+static int fx_launch_serial(groove_fx* fx, groove_block* io, uint32_t frames, hipStream_t st) {
   groove_ctx* ctx = fx->ctx;
   const uint32_t n = fx->n;
   const size_t chs = (size_t)io->cap * n;
@@ -1663,39 +1848,39 @@ static int fx_launch_serial(groove_fx* fx, groove_block* io, uint32_t frames) {
     case GROOVE_FX_BIQUAD_HSHELF12:
       // few lane-channels: one wavefront each, frames over its lanes (fx_tp.h); many: one thread each, frames serial
       if (frames <= kTpMaxFrames && 2 * (size_t)n <= ctx->fx_tp_max_lanes && ctx->tp_max_voices) {
-        if (2 * (size_t)n >= ctx->fx_tp_wide_min_lanes) hipLaunchKernelGGL(fx_biquad_tp_kernel<kFxTileWide>, dim3((n + kFxTileWide - 1) / kFxTileWide, 2), dim3(kFxTpThreads), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
-        else hipLaunchKernelGGL(fx_biquad_tp_kernel<kFxTile>, dim3((n + kFxTile - 1) / kFxTile, 2), dim3(kFxTpThreads), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+        if (2 * (size_t)n >= ctx->fx_tp_wide_min_lanes) hipLaunchKernelGGL(fx_biquad_tp_kernel<kFxTileWide>, dim3((n + kFxTileWide - 1) / kFxTileWide, 2), dim3(kFxTpThreads), 0, st, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+        else hipLaunchKernelGGL(fx_biquad_tp_kernel<kFxTile>, dim3((n + kFxTile - 1) / kFxTile, 2), dim3(kFxTpThreads), 0, st, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       }
       else if (frames <= (uint32_t)(kBqSegs * kBqSegMax) && frames >= 16 && 2 * (size_t)n <= ctx->fx_seg_max_lanes) // four time segments per lane-channel
-        hipLaunchKernelGGL(fx_biquad_seg_kernel, dim3((2 * n + 63) / 64), blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+        hipLaunchKernelGGL(fx_biquad_seg_kernel, dim3((2 * n + 63) / 64), blk, 0, st, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       else
-        hipLaunchKernelGGL(fx_biquad_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+        hipLaunchKernelGGL(fx_biquad_kernel<16>, lanes_grid, blk, 0, st, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       break;
     case GROOVE_FX_BIQUAD_LP24:
       if (frames <= kTpMaxFrames && 4 * (size_t)n <= ctx->fx_tp_max_lanes && ctx->tp_max_voices) {
-        if (2 * (size_t)n >= ctx->fx_tp_wide_min_lanes) hipLaunchKernelGGL(fx_lp24_tp_kernel<kFxTileWide>, dim3((n + kFxTileWide - 1) / kFxTileWide, 2), dim3(kFxTpThreads), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
-        else hipLaunchKernelGGL(fx_lp24_tp_kernel<kFxTile>, dim3((n + kFxTile - 1) / kFxTile, 2), dim3(kFxTpThreads), 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+        if (2 * (size_t)n >= ctx->fx_tp_wide_min_lanes) hipLaunchKernelGGL(fx_lp24_tp_kernel<kFxTileWide>, dim3((n + kFxTileWide - 1) / kFxTileWide, 2), dim3(kFxTpThreads), 0, st, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+        else hipLaunchKernelGGL(fx_lp24_tp_kernel<kFxTile>, dim3((n + kFxTile - 1) / kFxTile, 2), dim3(kFxTpThreads), 0, st, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       }
       else
-        hipLaunchKernelGGL(fx_lp24_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
+        hipLaunchKernelGGL(fx_lp24_kernel<16>, lanes_grid, blk, 0, st, io->d, n, frames, chs, fx->d_coef, fx->d_st, fx->d_wet);
       break;
     case GROOVE_FX_DELAY:
       if (fx->N >= 16) // chunked loads need every read of a chunk to precede its writes: N >= chunk
-        hipLaunchKernelGGL(fx_delay_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->N, fx->w, fx->d_wet);
-      else hipLaunchKernelGGL(fx_delay_kernel<1>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->N, fx->w, fx->d_wet);
+        hipLaunchKernelGGL(fx_delay_kernel<16>, lanes_grid, blk, 0, st, io->d, n, frames, chs, fx->d_ring, fx->N, fx->w, fx->d_wet);
+      else hipLaunchKernelGGL(fx_delay_kernel<1>, lanes_grid, blk, 0, st, io->d, n, frames, chs, fx->d_ring, fx->N, fx->w, fx->d_wet);
       break;
     case GROOVE_FX_CHORUS: {
       const uint32_t nearest = fx->N - (fx->voices - 1) * fx->spacing;
       if (nearest >= 16 && (fx->voices == 1 || fx->spacing >= 16))
-        hipLaunchKernelGGL(fx_chorus_kernel<16>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->N, fx->w, fx->voices, fx->spacing, fx->d_wet);
-      else hipLaunchKernelGGL(fx_chorus_kernel<1>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->N, fx->w, fx->voices, fx->spacing, fx->d_wet);
+        hipLaunchKernelGGL(fx_chorus_kernel<16>, lanes_grid, blk, 0, st, io->d, n, frames, chs, fx->d_ring, fx->N, fx->w, fx->voices, fx->spacing, fx->d_wet);
+      else hipLaunchKernelGGL(fx_chorus_kernel<1>, lanes_grid, blk, 0, st, io->d, n, frames, chs, fx->d_ring, fx->N, fx->w, fx->voices, fx->spacing, fx->d_wet);
       break;
     }
     case GROOVE_FX_REVERB: {
       uint32_t shortest = fx->geo.N[0];
       for (int i = 1; i < 6; ++i) shortest = std::min(shortest, fx->geo.N[i]);
-      if (shortest >= 8) hipLaunchKernelGGL(fx_reverb_kernel<8>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->geo, fx->d_fa, fx->d_wet);
-      else hipLaunchKernelGGL(fx_reverb_kernel<1>, lanes_grid, blk, 0, ctx->stream, io->d, n, frames, chs, fx->d_ring, fx->geo, fx->d_fa, fx->d_wet);
+      if (shortest >= 8) hipLaunchKernelGGL(fx_reverb_kernel<8>, lanes_grid, blk, 0, st, io->d, n, frames, chs, fx->d_ring, fx->geo, fx->d_fa, fx->d_wet);
+      else hipLaunchKernelGGL(fx_reverb_kernel<1>, lanes_grid, blk, 0, st, io->d, n, frames, chs, fx->d_ring, fx->geo, fx->d_fa, fx->d_wet);
       break;
     }
     default: return fail(ctx, "groove_fx_process: unknown kind");
@@ -1704,41 +1889,91 @@ static int fx_launch_serial(groove_fx* fx, groove_block* io, uint32_t frames) {
   GHIP(ctx, hipGetLastError());
   return 0;
 }
-int groove_fx_chain_process(groove_fx* const* chain, uint32_t n_fx, groove_block* io, uint32_t frames) {
-  if (!io || (n_fx && !chain)) return fail(nullptr, "groove_fx_chain_process: NULL argument");
+static int fx_chain_check(groove_fx* const* chain, uint32_t n_fx, groove_block* io, uint32_t frames, const char* who) {
+  if (!io || (n_fx && !chain)) return fail(nullptr, std::string(who) + ": NULL argument");
   groove_ctx* ctx = io->ctx;
   for (uint32_t i = 0; i < n_fx; ++i) {
-    if (!chain[i]) return fail(ctx, "groove_fx_chain_process: NULL effect");
-    if (chain[i]->ctx != ctx) return fail(ctx, "groove_fx_chain_process: effect and block belong to different contexts");
-    if (chain[i]->n != io->n) return fail(ctx, "groove_fx_chain_process: block lanes != effect lanes");
+    if (!chain[i]) return fail(ctx, std::string(who) + ": NULL effect");
+    if (chain[i]->ctx != ctx) return fail(ctx, std::string(who) + ": effect and block belong to different contexts");
+    if (chain[i]->n != io->n) return fail(ctx, std::string(who) + ": block lanes != effect lanes");
     for (uint32_t j = 0; j < i; ++j)
-      if (chain[j] == chain[i]) return fail(ctx, "groove_fx_chain_process: the same effect twice in one chain");
+      if (chain[j] == chain[i]) return fail(ctx, std::string(who) + ": the same effect twice in one chain");
   }
-  if (frames > io->cap) return fail(ctx, "groove_fx_chain_process: frames > block capacity");
+  if (frames > io->cap) return fail(ctx, std::string(who) + ": frames > block capacity");
+  return 0;
+}
+int groove_fx_chain_process(groove_fx* const* chain, uint32_t n_fx, groove_block* io, uint32_t frames) {
+  if (fx_chain_check(chain, n_fx, io, frames, "groove_fx_chain_process")) return 1;
+  groove_ctx* ctx = io->ctx;
   if (frames == 0 || n_fx == 0) return 0;
   GHIP(ctx, hipSetDevice(ctx->device));
   if (block_acquire(io)) return 1;
+  uint32_t last_stage = n_fx; // the last stage that launches anything (the Mixer is the identity)
+  for (uint32_t i = 0; i < n_fx; ++i) if (chain[i]->kind != GROOVE_FX_MIXER) last_stage = i;
   groove_fx* run[kRunMaxStages];
   uint32_t count = 0;
-  auto flush = [&]() -> int {
+  auto flush = [&](bool last) -> int {
     if (!count) return 0;
-    const int rc = fx_launch_run(ctx, run, count, io, frames);
+    const int rc = fx_launch_run(ctx, run, count, io, frames, ctx->stream, last);
     count = 0;
     return rc;
   };
   for (uint32_t i = 0; i < n_fx; ++i) {
     groove_fx* fx = chain[i];
     if (fx->kind == GROOVE_FX_MIXER) continue; // identity
+    if (fx_acquire_ctx(fx)) return 1;
     io->sums_valid = false; // the block is transformed in place
     if (fx_run_capable(fx, frames)) {
       run[count++] = fx;
-      if (count == kRunMaxStages || fx->kind == GROOVE_FX_REVERB) { if (flush()) return 1; }
+      if (count == kRunMaxStages || fx->kind == GROOVE_FX_REVERB) { if (flush(i == last_stage)) return 1; }
     } else {
-      if (flush()) return 1;
-      if (fx_launch_serial(fx, io, frames)) return 1;
+      if (flush(false)) return 1;
+      if (fx_launch_serial(fx, io, frames, ctx->stream)) return 1;
     }
   }
-  return flush();
+  return flush(true);
+}
+// The LEADING stages of a chain that walk the block's frames one lane-channel per thread (the IIR filters, delay lines
+// shorter than the block) on the side stream that carries `io`'s pending asynchronous render, right behind it: these
+// are latency-bound kernels of a few hundred wavefronts, and behind the render of block b+1 they run beside the wide,
+// HBM-bound stages of block b on the ctx stream instead of in front of them (config #3: the BiQuad took 29 us of the
+// ctx stream's 82 us per block).  *n_done = how many stages were taken; the caller passes the rest of the chain to
+// groove_fx_chain_process when it gets to the block.  Nothing is taken (and 0 returned) when the block has no pending
+// render on exactly one side stream, or when the chain does not start with such a stage.
+int groove_fx_chain_process_async(groove_fx* const* chain, uint32_t n_fx, groove_block* io, uint32_t frames, uint32_t* n_done) {
+  if (!n_done) return fail(nullptr, "groove_fx_chain_process_async: n_done is NULL");
+  *n_done = 0;
+  if (fx_chain_check(chain, n_fx, io, frames, "groove_fx_chain_process_async")) return 1;
+  groove_ctx* ctx = io->ctx;
+  if (frames == 0 || n_fx == 0) return 0;
+  int k = -1;
+  for (int j = 0; j < kSideStreams; ++j)
+    if (io->ready_mask & (1u << j)) k = (k == -1) ? j : -2;
+  if (k < 0) return 0; // no pending render, or one spread over several kind streams
+  GHIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = side_stream_of(ctx, k);
+  uint32_t done = 0;
+  for (uint32_t i = 0; i < n_fx; ++i) {
+    groove_fx* fx = chain[i];
+    if (fx->kind == GROOVE_FX_MIXER) { ++done; continue; }
+    if (fx_run_capable(fx, frames)) break;
+    if (fx->last_side != k) { // the stream that used the effect last: the ctx stream (or another side stream)
+      if (!fx->ev_done) GHIP(ctx, hipEventCreateWithFlags(&fx->ev_done, kSyncEventFlags));
+      if (fx->last_side < 0) GHIP(ctx, hipEventRecord(fx->ev_done, ctx->stream));
+      GHIP(ctx, hipStreamWaitEvent(st, fx->ev_done, 0));
+    }
+    io->sums_valid = false;
+    if (fx_launch_serial(fx, io, frames, st)) return 1;
+    GHIP(ctx, hipEventRecord(fx->ev_done, st));
+    fx->last_side = k;
+    ++done;
+  }
+  if (done) {
+    GHIP(ctx, hipEventRecord(io->ev_ready[k], st)); // the block is ready when these stages are
+    ctx->side_busy[k] = true;
+  }
+  *n_done = done;
+  return 0;
 }
 int groove_fx_process(groove_fx* fx, groove_block* io, uint32_t frames) {
   if (!fx || !io) return fail(nullptr, "groove_fx_process: NULL argument");
@@ -1757,7 +1992,8 @@ int groove_fx_set_params(groove_fx* fx, const groove_fx_params* p, uint32_t n) {
     fx->p = old;
     return fail(ctx, "groove_fx_set_params: delay-line geometry cannot change after creation");
   }
-  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (fx_acquire_ctx(fx)) return 1;
+  GHIP(ctx, ctx_wait(ctx));
   return fx_upload_params(fx);
 }
 int groove_fx_set_param(groove_fx* fx, uint32_t lane, uint32_t control_index, double value01) {
@@ -1779,7 +2015,8 @@ int groove_fx_set_param(groove_fx* fx, uint32_t lane, uint32_t control_index, do
       default: return fail(ctx, "groove_fx_set_param: unknown control index");
     }
   }
-  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (fx_acquire_ctx(fx)) return 1;
+  GHIP(ctx, ctx_wait(ctx));
   return fx_upload_params(fx);
 }
 
@@ -1842,7 +2079,7 @@ int groove_bus_create(groove_ctx* ctx, size_t frames, float** out_dev) {
 }
 int groove_bus_destroy(groove_ctx* ctx, float* bus_dev) {
   if (!ctx) return fail(nullptr, "groove_bus_destroy: ctx is NULL");
-  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  GHIP(ctx, ctx_wait(ctx));
   GHIP(ctx, hipFree(bus_dev));
   return 0;
 }
@@ -1854,13 +2091,13 @@ int groove_bus_zero(groove_ctx* ctx, float* bus_dev, size_t frames) {
 int groove_download(groove_ctx* ctx, const float* dev, float* host, size_t n_floats) {
   if (!ctx || !dev || !host) return fail(ctx, "groove_download: NULL argument");
   GHIP(ctx, hipMemcpyAsync(host, dev, n_floats * 4, hipMemcpyDeviceToHost, ctx->stream));
-  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  GHIP(ctx, ctx_wait(ctx));
   return 0;
 }
 int groove_upload(groove_ctx* ctx, float* dev, const float* host, size_t n_floats) {
   if (!ctx || !dev || !host) return fail(ctx, "groove_upload: NULL argument");
   GHIP(ctx, hipMemcpyAsync(dev, host, n_floats * 4, hipMemcpyHostToDevice, ctx->stream));
-  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  GHIP(ctx, ctx_wait(ctx));
   return 0;
 }
 int groove_bus_to_i16(groove_ctx* ctx, const float* bus_dev, size_t frames, int16_t* host_out) {
@@ -1875,15 +2112,15 @@ int groove_bus_to_i16(groove_ctx* ctx, const float* bus_dev, size_t frames, int1
   hipLaunchKernelGGL(bus_to_i16_kernel, dim3(blocks_for(count)), dim3(kThreads), 0, ctx->stream, bus_dev, count, ctx->d_i16);
   GHIP(ctx, hipGetLastError());
   GHIP(ctx, hipMemcpyAsync(host_out, ctx->d_i16, count * 2, hipMemcpyDeviceToHost, ctx->stream));
-  GHIP(ctx, hipStreamSynchronize(ctx->stream));
+  GHIP(ctx, ctx_wait(ctx));
   return 0;
 }
 
 // ============================================================================ multi-GPU
-int groove_comm_unique_id(groove_ctx* ctx, uint8_t id_out[128]) {
-  if (!ctx || !id_out) return fail(ctx, "groove_comm_unique_id: NULL argument");
+int groove_comm_unique_id(groove_ctx* ctx, uint8_t id_out[128]) { // ctx may be NULL (groove_init_comm wants the id before any ctx exists)
+  if (!id_out) return fail(ctx, "groove_comm_unique_id: NULL argument");
   if (rccl_open(ctx)) return 1;
-  auto f = (nccl_get_uid_fn)dlsym(ctx->rccl, "ncclGetUniqueId");
+  auto f = (nccl_get_uid_fn)dlsym(g_rccl, "ncclGetUniqueId");
   if (!f) return fail(ctx, "ncclGetUniqueId not found");
   ncclUniqueId id;
   const ncclResult_t rc = f(&id);
@@ -1891,9 +2128,9 @@ int groove_comm_unique_id(groove_ctx* ctx, uint8_t id_out[128]) {
   std::memcpy(id_out, &id, sizeof(id));
   return 0;
 }
-int groove_comm_init(groove_ctx* ctx, const uint8_t id[128], int rank, int world_size) {
-  if (!ctx || !id) return fail(ctx, "groove_comm_init: NULL argument");
+static int comm_init_rank(groove_ctx* ctx, const uint8_t id[128], int rank, int world_size) {
   if (world_size < 1 || rank < 0 || rank >= world_size) return fail(ctx, "groove_comm_init: bad rank/world");
+  if (ctx->comm) return fail(ctx, "groove_comm_init: this ctx already has a communicator");
   if (rccl_open(ctx)) return 1;
   GHIP(ctx, hipSetDevice(ctx->device));
   auto f = (nccl_init_rank_fn)dlsym(ctx->rccl, "ncclCommInitRank");
@@ -1908,6 +2145,10 @@ int groove_comm_init(groove_ctx* ctx, const uint8_t id[128], int rank, int world
   }
   ctx->comm = comm; ctx->rank = rank; ctx->world = world_size;
   return 0;
+}
+int groove_comm_init(groove_ctx* ctx, const uint8_t id[128], int rank, int world_size) {
+  if (!ctx || !id) return fail(ctx, "groove_comm_init: NULL argument");
+  return comm_init_rank(ctx, id, rank, world_size);
 }
 int groove_comm_ranks(groove_ctx* ctx, int* out_ranks) {
   if (!ctx || !out_ranks) return fail(ctx, "groove_comm_ranks: NULL argument");

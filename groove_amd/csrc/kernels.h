@@ -388,8 +388,21 @@ __device__ __forceinline__ void welsh_uniform_body_impl(UniformArgsPtr a) {
   welsh_block<FUSED, RETUNE, LFO_MODE, true, C1, C2, CL, REST>(d.p, s, rc, a->frames, n, v, active, a->ch_stride, a->out, a->rows, wg);
   if (active) soa_store(a->state, n, v, s);
 }
+// Internal linkage + no `tail` marker on the kernels' calls: the compiler's inter-procedural register allocation then
+// knows every caller of a body, the body saves and restores NO callee-saved registers (TargetFrameLowering's no-CSR
+// path wants a local, non-recursive function none of whose call sites is a tail call), and the kernel — which keeps
+// nothing alive across the call — pays nothing either.  As linkonce_odr functions every body spilled 24-38 VGPRs to
+// scratch in its prologue and read them back at its end: 84-172 bytes of scratch per lane, ~0.2-0.3 GB per
+// million-voice block of HBM traffic that served nothing (round 2's PMC passes).
+#ifdef GROOVE_BODIES_EXTERN /* A/B: the round-2 form */
+#define GROOVE_NO_TAIL_CALLS
+#define GROOVE_BODY_LINKAGE
+#else
+#define GROOVE_NO_TAIL_CALLS __attribute__((disable_tail_calls))
+#define GROOVE_BODY_LINKAGE static
+#endif
 template <bool FUSED, int LFO_MODE, bool RETUNE, int C1, int C2, int CL>
-__device__ __attribute__((noinline)) void welsh_uniform_body(UniformArgsPtr a) {
+GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_uniform_body(UniformArgsPtr a) {
   // the class bodies of the class-specialised kinds only ever see waves of their own classes (dsp_core.h, REST)
   welsh_uniform_body_impl<FUSED, LFO_MODE, RETUNE, C1, C2, CL, LFO_MODE != LFO_F64>(uniform_args_scalar(a));
 }
@@ -443,7 +456,7 @@ __device__ __forceinline__ void welsh_dispatch_class(uint32_t cls, UniformArgsPt
 }
 // SPECIALISED = false: the whole launch runs the OSC_ANY x OSC_ANY body (wg_cls is not read).
 template <bool FUSED, int LFO_MODE, bool RETUNE, bool SPECIALISED>
-__global__ __launch_bounds__(kThreads, (WavesBudget<LFO_MODE, RETUNE>::value)) void welsh_render_uniform_kernel(UniformArgs a) {
+__global__ __launch_bounds__(kThreads, (WavesBudget<LFO_MODE, RETUNE>::value)) GROOVE_NO_TAIL_CALLS void welsh_render_uniform_kernel(UniformArgs a) {
   // (No s_setprio: raising the f64-LFO kinds' wave priority paid when a block's kernels were forked and
   // joined; with the blocks pipelined the longest kernel is the most numerous kind, and any priority
   // costs 5 % — measured: none 0.460 ms, f64-LFO kinds raised 0.484, F32-retune raised 0.513.)
@@ -461,7 +474,7 @@ __global__ __launch_bounds__(kThreads, (WavesBudget<LFO_MODE, RETUNE>::value)) v
 // the few hardware queues that several per-kind launches share.  wg_base[] = base kind per workgroup.
 #ifdef GROOVE_WELSH_ANY_TU // defined by the two translation units that own this kernel (fused form, block-writing form)
 template <bool FUSED>
-__global__ __launch_bounds__(kThreads, GROOVE_WAVES_ANY) void welsh_render_uniform_any_kernel(UniformArgs a, const uint8_t* __restrict__ wg_base) {
+__global__ __launch_bounds__(kThreads, GROOVE_WAVES_ANY) GROOVE_NO_TAIL_CALLS void welsh_render_uniform_any_kernel(UniformArgs a, const uint8_t* __restrict__ wg_base) {
   const UniformArgsPtr ka = (UniformArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   if constexpr (FUSED) { if (welsh_idle_workgroup(a)) return; }
   const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wg_base[blockIdx.x]);
@@ -1130,12 +1143,28 @@ struct FxRunArgs {
   float* dst;
   size_t src_chs, dst_chs;
   uint32_t n_stages, n;
+  float* rows;          // not null: the launch also leaves the block's lane sums, rows[wg_per_ch][2][frames] (fx_row_sum)
+  uint32_t frames, wg_per_ch;
 };
+// Grid of the (frame, lane-channel) effect kernels: blockIdx.y = frame, blockIdx.x = (channel, group of 256 * V lanes) —
+// a workgroup never straddles the two channels, so its sum is one entry of the block's lane sums.
+__host__ __device__ inline uint32_t fx_wg_per_ch(uint32_t n, uint32_t v) { return (n + kThreads * v - 1) / (kThreads * v); }
+// The last launch of an effect chain hands groove_mix the block's lane sums the way the renders do (run_frames): every
+// workgroup adds up what it stored and writes ONE float, rows[group][ch][frame]; the mix then reduces `wg_per_ch` short rows
+// instead of reading the 8 bytes per voice-frame back (config #3: 4 rows of 2 KiB instead of 8 MiB per block).
+__device__ __forceinline__ void fx_row_sum(float mine, float* __restrict__ rows, uint32_t frames, uint32_t group, uint32_t ch, uint32_t f) {
+  __shared__ float red[kWaves];
+  const float t = wave_sum_lane63(mine);
+  if ((threadIdx.x & 63u) == 63u) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) rows[((size_t)group * 2 + ch) * frames + f] = (red[0] + red[1]) + (red[2] + red[3]);
+}
 template <int V>
 __global__ __launch_bounds__(kThreads) void fx_run_kernel(FxRunArgs a) {
-  const uint32_t t = (blockIdx.x * kThreads + threadIdx.x) * V, f = blockIdx.y;
-  if (t >= 2 * a.n) return;
-  const uint32_t ch = t / a.n, lane = t % a.n;
+  const uint32_t ch = blockIdx.x / a.wg_per_ch, group = blockIdx.x % a.wg_per_ch;
+  const uint32_t lane = (group * kThreads + threadIdx.x) * V, f = blockIdx.y;
+  if (lane >= a.n) { if (a.rows) fx_row_sum(0.0f, a.rows, a.frames, group, ch, f); return; }
+  const uint32_t t = ch * a.n + lane;
   const size_t ln = 2 * (size_t)a.n;
   VecF<V> x = vload<V>(a.src + ch * a.src_chs + (size_t)f * a.n + lane);
 #pragma unroll
@@ -1194,6 +1223,12 @@ __global__ __launch_bounds__(kThreads) void fx_run_kernel(FxRunArgs a) {
     for (int j = 0; j < V; ++j) x.v[j] = wm.v[j] < 1.0f ? fmaf(y.v[j], wm.v[j], x.v[j] * (1.0f - wm.v[j])) : y.v[j];
   }
   vstore<V>(a.dst + ch * a.dst_chs + (size_t)f * a.n + lane, x);
+  if (a.rows) {
+    float mine = 0.0f;
+#pragma unroll
+    for (int j = 0; j < V; ++j) mine += x.v[j];
+    fx_row_sum(mine, a.rows, a.frames, group, ch, f);
+  }
 }
 // Reverb, stage 2: the two short Schroeder all-passes (5 ms, 1.7 ms: shorter than a block, so
 // sequential per lane), chunked like the other delay-line kernels.
@@ -1310,12 +1345,15 @@ struct AllpassDirectArgs {
   uint32_t N[2], w[2];
   float g[2];
   uint32_t n, frames;
+  float* rows;          // not null: the block's lane sums, rows[wg_per_ch][2][frames] (fx_row_sum)
+  uint32_t wg_per_ch;
 };
 template <int V>
 __global__ __launch_bounds__(kThreads) void fx_reverb_allpass_direct_kernel(AllpassDirectArgs a) {
-  const uint32_t t = (blockIdx.x * kThreads + threadIdx.x) * V, f = blockIdx.y;
-  if (t >= 2 * a.n) return;
-  const uint32_t ch = t / a.n, lane = t % a.n;
+  const uint32_t ch = blockIdx.x / a.wg_per_ch, group = blockIdx.x % a.wg_per_ch;
+  const uint32_t lane = (group * kThreads + threadIdx.x) * V, f = blockIdx.y;
+  if (lane >= a.n) { if (a.rows && f < a.frames) fx_row_sum(0.0f, a.rows, a.frames, group, ch, f); return; }
+  const uint32_t t = ch * a.n + lane;
   const size_t ln = 2 * (size_t)a.n;
   if (f >= a.frames) { // ring rows this block leaves as they are
 #pragma unroll
@@ -1349,6 +1387,12 @@ __global__ __launch_bounds__(kThreads) void fx_reverb_allpass_direct_kernel(Allp
   vstore<V>(a.dst + ch * a.dst_chs + (size_t)f * a.n + lane, out);
   if (f + a.N[0] >= a.frames) vstore<V>(a.ring + (a.new_base[0] + (a.w[0] + f) % a.N[0]) * ln + t, v0);
   if (f + a.N[1] >= a.frames) vstore<V>(a.ring + (a.new_base[1] + slot1) * ln + t, u);
+  if (a.rows) {
+    float mine = 0.0f;
+#pragma unroll
+    for (int k = 0; k < V; ++k) mine += out.v[k];
+    fx_row_sum(mine, a.rows, a.frames, group, ch, f);
+  }
 }
 
 #endif // GROOVE_WELSH_CLASS_TU

@@ -20,12 +20,43 @@ _fp = C.POINTER(C.c_float)
 class Context:
     """One GPU + one HIP stream (groove_ctx)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, comm=None):
+        """comm = (unique id bytes, rank, world): groove_init_comm — the rank's RCCL communicator before the streams."""
         self.L = _lib.load()
         h = C.c_void_p()
-        _lib.check(self.L.groove_init(device, C.byref(h)))
+        if comm is None:
+            _lib.check(self.L.groove_init(device, C.byref(h)))
+        else:
+            uid, rank, world = comm
+            buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+            _lib.check(self.L.groove_init_comm(device, buf, rank, world, C.byref(h)))
         self.h = h
         self.device = device
+
+    @staticmethod
+    def new_comm_unique_id():
+        """groove_comm_unique_id(NULL, ...): rank 0's id, before any ctx exists."""
+        L = _lib.load()
+        buf = (C.c_uint8 * 128)()
+        _lib.check(L.groove_comm_unique_id(None, buf))
+        return bytes(buf)
+
+    @property
+    def sync_timeout_ms(self):
+        return self.L.groove_sync_timeout_ms(self.h)
+
+    @sync_timeout_ms.setter
+    def sync_timeout_ms(self, ms):
+        _lib.check(self.L.groove_set_sync_timeout_ms(self.h, int(ms)), self.h)
+
+    def debug_spin(self, side_stream, ms):
+        _lib.check(self.L.groove_debug_spin(self.h, side_stream, ms), self.h)
+
+    def debug_info(self):
+        import json
+        buf = C.create_string_buffer(1024)
+        _lib.check(self.L.groove_debug_info(self.h, buf, len(buf)), self.h)
+        return json.loads(buf.value.decode())
 
     # Configurable
     def update_sample_rate(self, hz):
@@ -42,6 +73,14 @@ class Context:
     @time_parallel_max_voices.setter
     def time_parallel_max_voices(self, n):
         _lib.check(self.L.groove_set_time_parallel_max_voices(self.h, n), self.h)
+
+    @property
+    def pipeline_min_waves(self):
+        return self.L.groove_pipeline_min_waves(self.h)
+
+    @pipeline_min_waves.setter
+    def pipeline_min_waves(self, n):
+        _lib.check(self.L.groove_set_pipeline_min_waves(self.h, n), self.h)
 
     def set_stream(self, hip_stream):
         _lib.check(self.L.groove_set_stream(self.h, C.c_void_p(hip_stream)), self.h)
@@ -79,6 +118,15 @@ class Context:
         frames = block.cap if frames is None else frames
         arr = (C.c_void_p * len(effects))(*[e.h for e in effects])
         _lib.check(self.L.groove_fx_chain_process(arr, len(effects), block.h, frames), self.h)
+
+    def transform_chain_async(self, effects, block, frames=None):
+        """groove_fx_chain_process_async: the chain's leading IIR stages behind the block's pending render, on its side
+        stream.  Returns how many stages were taken (the rest goes to transform_chain later)."""
+        frames = block.cap if frames is None else frames
+        arr = (C.c_void_p * len(effects))(*[e.h for e in effects])
+        done = C.c_uint32(0)
+        _lib.check(self.L.groove_fx_chain_process_async(arr, len(effects), block.h, frames, C.byref(done)), self.h)
+        return done.value
 
     # multi-GPU
     def comm_unique_id(self):
@@ -123,6 +171,12 @@ class Block:
         out = np.empty((2, frames, self.n), dtype=np.float32)
         _lib.check(self.ctx.L.groove_block_download(self.h, out.ctypes.data_as(_fp), frames), self.ctx.h)
         return out
+
+    def device_ptr(self):
+        return self.ctx.L.groove_block_device_ptr(self.h)
+
+    def mark_dirty(self):
+        _lib.check(self.ctx.L.groove_block_mark_dirty(self.h), self.ctx.h)
 
     def release(self):
         """groove_block_release: the block's consumers so far are all that the next asynchronous render into it waits for."""
@@ -215,6 +269,9 @@ class Instrument:
     def render_mix(self, bus, frames, accumulate=False, at_frame=0):
         ptr = bus.at(at_frame) if at_frame else bus.ptr
         _lib.check(self.ctx.L.groove_bank_render_mix(self.h, frames, ptr, 1 if accumulate else 0), self.ctx.h)
+
+    def kernel_form(self, frames=T.BLOCK_FRAMES, fused=True):
+        return self.ctx.L.groove_bank_kernel_form(self.h, frames, 1 if fused else 0).decode()
 
     def reset(self):
         """groove_bank_reset: every voice back to its freshly created state."""

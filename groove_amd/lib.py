@@ -22,10 +22,19 @@ SYMBOLS = {
     "groove_last_error": (C.c_char_p, [_vp]),
     "groove_set_stream": (_i, [_vp, _vp]),
     "groove_synchronize": (_i, [_vp]),
+    "groove_set_sync_timeout_ms": (_i, [_vp, _u32]),
+    "groove_sync_timeout_ms": (_u32, [_vp]),
+    "groove_debug_spin": (_i, [_vp, _i, _u32]),
+    "groove_debug_info": (_i, [_vp, C.c_char_p, C.c_size_t]),
+    "groove_init_comm": (_i, [_i, C.POINTER(C.c_uint8), _i, _i, _vpp]),
+    "groove_block_mark_dirty": (_i, [_vp]),
     "groove_update_sample_rate": (_i, [_vp, _u32]),
     "groove_sample_rate": (_u32, [_vp]),
     "groove_set_time_parallel_max_voices": (_i, [_vp, _u32]),
     "groove_time_parallel_max_voices": (_u32, [_vp]),
+    "groove_set_pipeline_min_waves": (_i, [_vp, _u32]),
+    "groove_pipeline_min_waves": (_u32, [_vp]),
+    "groove_bank_kernel_form": (C.c_char_p, [_vp, _u32, _i]),
     "groove_event_create": (_i, [_vp, _vpp]),
     "groove_event_destroy": (_i, [_vp, _vp]),
     "groove_event_record": (_i, [_vp, _vp]),
@@ -59,6 +68,7 @@ SYMBOLS = {
     "groove_fx_reset": (_i, [_vp]),
     "groove_fx_process": (_i, [_vp, _vp, _u32]),
     "groove_fx_chain_process": (_i, [_vp, _u32, _vp, _u32]),
+    "groove_fx_chain_process_async": (_i, [_vp, _u32, _vp, _u32, C.POINTER(_u32)]),
     "groove_fx_set_param": (_i, [_vp, _u32, _u32, _d]),
     "groove_fx_set_params": (_i, [_vp, C.POINTER(T.FxParams), _u32]),
     "groove_mix": (_i, [_vp, _vpp, _u32, _u32, _vp, _i]),

@@ -121,8 +121,10 @@ class Project:
     (instruments render, their chains run, the mix bus sums: Orchestrator::tick / gather_audio,
     /root/reference/orchestration/src/orchestrator.rs:856-877, 367-470)."""
 
-    def __init__(self, ctx, workload, sel, fused=True, grouped=True, render_ahead=True, bank_scale=1.0):
+    def __init__(self, ctx, workload, sel, fused=True, grouped=True, render_ahead=True, bank_scale=1.0, head_ahead=True):
         self.ctx, self.fused, self.workload = ctx, fused, workload
+        self.head_ahead = head_ahead      # render-ahead walk: the chain's leading IIR stages ride behind the render (groove_fx_chain_process_async)
+        self.head_done = {}               # block handle -> stages of its chain already processed
         self.period = WORKLOADS[workload]["blocks"]
         self.render_ahead = render_ahead  # instruments with an effect chain: render block b+1 beside the effects of block b
         self.ahead = {}                   # instrument -> [current block, next block, spare] (rotating), created on first use
@@ -150,6 +152,7 @@ class Project:
             for e in fx:
                 e.reset()
         self.primed = False  # (the three blocks per instrument stay)
+        self.head_done = {}
         self.block_index = 0
 
     def _events(self, block_index):
@@ -173,22 +176,28 @@ class Project:
                 if inst not in self.ahead:
                     self.ahead[inst] = [block, ctx.block(inst.n, FRAMES), ctx.block(inst.n, FRAMES)]
                 inst.generate_batch_values_async(self.ahead[inst][0], FRAMES)
+                self._head(fx, self.ahead[inst][0])
             self.primed = True
         self._events(self.block_index + 1)
         self.block_index += 1
         for inst, _, fx, _ in self.banks:
             # the block this render fills was released a whole step ago: no cross-queue wait (groove_block_release)
             inst.generate_batch_values_async(self.ahead[inst][1], FRAMES)
+            self._head(fx, self.ahead[inst][1])
         first = True
         for inst, _, fx, _ in self.banks:
             cur = self.ahead[inst][0]
-            ctx.transform_chain(fx, cur, FRAMES)
+            ctx.transform_chain(fx[self.head_done.pop(id(cur), 0):], cur, FRAMES)
             ctx.mix([cur], FRAMES, E._Slice(bus, frame0), accumulate=not first)
             cur.release()
             self.ahead[inst] = self.ahead[inst][1:] + [cur]
             first = False
         if ev_pair is not None and ev_pair[1] is not None:
             ctx.record(ev_pair[1])
+
+    def _head(self, fx, block):
+        if fx and self.head_ahead:
+            self.head_done[id(block)] = self.ctx.transform_chain_async(fx, block, FRAMES)
 
     def step(self, bus, frame0, ev_pair=None):
         """One block: every instrument renders, its effect chain runs, the mix bus sums."""

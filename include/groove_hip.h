@@ -38,12 +38,32 @@ typedef struct groove_block groove_block; /* device stereo block [2][frames_cap]
 /* ---- context ------------------------------------------------------------------------ */
 /* Orchestrator::new_with + device selection (orchestrator.rs:522-568). */
 int groove_init(int device_ordinal, groove_ctx** out);
+/* groove_init for one rank of a multi-GPU job: the rank's RCCL communicator is created FIRST (id from
+ * groove_comm_unique_id(NULL, ...) on rank 0, broadcast by the launcher), the library's own streams after it, so
+ * that RCCL's internal streams do not land between them.  Equivalent to groove_init followed by
+ * groove_comm_init otherwise.  GROOVE_SAFE_STREAMS=1 in the environment selects the conservative stream layout (one
+ * priority, four streams in all) for either form. */
+int groove_init_comm(int device_ordinal, const uint8_t id[128], int rank, int world_size, groove_ctx** out);
 void groove_shutdown(groove_ctx* ctx);
 /* ctx may be NULL: returns the last error of the calling thread. */
 const char* groove_last_error(groove_ctx* ctx);
 /* Use the caller's hipStream_t (e.g. a torch stream) instead of the ctx's own. */
 int groove_set_stream(groove_ctx* ctx, void* hip_stream);
+/* Waits for everything submitted so far (every stream of the library).  Like every blocking call of this API
+ * (downloads, groove_bus_to_i16, groove_event_elapsed_ms ...) it polls with a DEADLINE: if the work has not completed
+ * after groove_sync_timeout_ms() milliseconds the call returns non-zero and groove_last_error() names the streams
+ * that are still busy — a stalled kernel surfaces as an error, never as a hang and never as an abort.  Nothing is
+ * cancelled; the caller may wait again or tear the process down.  Default 60,000 ms (GROOVE_SYNC_TIMEOUT_MS in the
+ * environment at groove_init), 0 = wait for ever.  No reference counterpart (the reference's audio path is
+ * synchronous CPU code, orchestrator.rs:367-470). */
 int groove_synchronize(groove_ctx* ctx);
+int groove_set_sync_timeout_ms(groove_ctx* ctx, uint32_t ms);
+uint32_t groove_sync_timeout_ms(groove_ctx* ctx);
+/* Test / diagnosis hooks.  groove_debug_spin: one idle kernel that occupies a library stream for `ms` milliseconds
+ * (side_stream = -1: the ctx stream; 0..5 kind streams; 6.. bank streams) — how the tests block a stream on purpose.
+ * groove_debug_info: the stream layout of this ctx as a JSON object (bench.py puts it on its line). */
+int groove_debug_spin(groove_ctx* ctx, int side_stream, uint32_t ms);
+int groove_debug_info(groove_ctx* ctx, char* out, size_t cap);
 /* Configurable::update_sample_rate fan-out (orchestrator.rs:125-127, 1019-1022, 1389-1394).
  * Re-derives every bank/effect created on this ctx and resets their state. */
 int groove_update_sample_rate(groove_ctx* ctx, uint32_t hz);
@@ -55,6 +75,12 @@ uint32_t groove_sample_rate(groove_ctx* ctx);
  * the environment overrides it at groove_init).  No reference counterpart. */
 int groove_set_time_parallel_max_voices(groove_ctx* ctx, uint32_t max_voices);
 uint32_t groove_time_parallel_max_voices(groove_ctx* ctx);
+/* Tuning: Welsh banks of at least this many (virtual) wavefronts — 64 voices each; default 8,600 = ~550,000 voices — run
+ * one kernel per base kind and pipeline consecutive fused blocks; smaller ones take one launch for all kinds.  1 forces
+ * the per-kind pipelined form for every size (tests and bench.py's parity sample use it to run the kernels of the
+ * million-voice path on a small bank).  GROOVE_PIPELINE_MIN_WAVES in the environment sets it at groove_init. */
+int groove_set_pipeline_min_waves(groove_ctx* ctx, uint32_t waves);
+uint32_t groove_pipeline_min_waves(groove_ctx* ctx);
 /* HIP events on the ctx stream, for measurement (bench.py): create / record / elapsed. */
 int groove_event_create(groove_ctx* ctx, void** out_event);
 int groove_event_destroy(groove_ctx* ctx, void* event);
@@ -66,7 +92,11 @@ int groove_event_elapsed_ms(groove_ctx* ctx, void* start, void* stop, float* out
  * (entities/src/instruments/metronome.rs:23-35), for n lanes at once. */
 int groove_block_create(groove_ctx* ctx, uint32_t n, uint32_t frames_cap, groove_block** out);
 int groove_block_destroy(groove_block* b);
+/* The raw device pointer.  Handing it out invalidates the lane sums the last render left with the block (groove_mix
+ * then reads the block itself); a caller that keeps the pointer and writes the block again later calls
+ * groove_block_mark_dirty (or groove_block_acquire) before the next groove_mix. */
 float* groove_block_device_ptr(groove_block* b);
+int groove_block_mark_dirty(groove_block* b);
 uint32_t groove_block_lanes(groove_block* b);
 uint32_t groove_block_frames_cap(groove_block* b);
 /* host [2][frames][n] fp32 <-> device */
@@ -136,6 +166,9 @@ int groove_bank_render_mix(groove_bank* bank, uint32_t frames, float* bus_dev, i
  * the Configurable::update_sample_rate fan-out that resets every entity (orchestrator.rs:125-127) —
  * without re-deriving or re-uploading the parameter tables. */
 int groove_bank_reset(groove_bank* bank);
+/* Which kernel form a render of `frames` frames of this bank takes right now (a static string; diagnosis: bench.py
+ * prints it beside every parity figure so that the figure names the kernels it checked). */
+const char* groove_bank_kernel_form(groove_bank* bank, uint32_t frames, int fused);
 /* Raw state snapshot (checkpoint / debugging): words = groove_bank_state_words(). */
 uint32_t groove_bank_state_words(groove_bank* bank);
 int groove_bank_download_state(groove_bank* bank, uint32_t* host_words /* [words][n] */);
@@ -154,6 +187,15 @@ int groove_fx_process(groove_fx* fx, groove_block* inout, uint32_t frames);
  * the library fuses the stages that have no feedback inside a block (element-wise kinds, delay lines at least a block
  * long) into one pass over the block.  An effect may appear once. */
 int groove_fx_chain_process(groove_fx* const* chain, uint32_t n_fx, groove_block* inout, uint32_t frames);
+/* The chain's LEADING stages that have feedback inside a block (the IIR filters; delay lines shorter than the block),
+ * submitted to the side stream that carries `inout`'s pending groove_bank_render_async, right behind that render:
+ * *n_done stages are taken (0 when the block has no pending render on one side stream, or when the chain starts with a
+ * stage of the other sort); the caller hands chain + *n_done to groove_fx_chain_process when it reaches the block.  Same
+ * bits as processing the whole chain there.  Purpose: in the render-ahead walk (groove_bank_render_async above) these
+ * narrow, latency-bound kernels then run beside the wide stages of the PREVIOUS block instead of in front of them on
+ * the ctx stream.  Parameter changes of those effects must be made before this call for the block it processes
+ * (the effect is one block ahead of the ctx stream's walk).  No reference counterpart. */
+int groove_fx_chain_process_async(groove_fx* const* chain, uint32_t n_fx, groove_block* inout, uint32_t frames, uint32_t* n_done);
 /* Controllable for effects; lane = GROOVE_ALL_VOICES for all lanes. */
 int groove_fx_set_param(groove_fx* fx, uint32_t lane, uint32_t control_index, double value01);
 /* Replace all per-lane parameters (non-UNIFORM fields only may change). */
@@ -177,7 +219,7 @@ int groove_bus_to_i16(groove_ctx* ctx, const float* bus_dev, size_t frames, int1
 /* One process per GPU.  Rank 0 calls groove_comm_unique_id, the launcher broadcasts the 128
  * bytes, every rank calls groove_comm_init; groove_bus_reduce sums bus_dev[frames_total][2]
  * (fp32) onto `root` with one RCCL reduce over xGMI. */
-int groove_comm_unique_id(groove_ctx* ctx, uint8_t id_out[128]);
+int groove_comm_unique_id(groove_ctx* ctx /* may be NULL */, uint8_t id_out[128]);
 int groove_comm_init(groove_ctx* ctx, const uint8_t id[128], int rank, int world_size);
 /* Ranks that joined the communicator (ncclCommCount); 1 when no communicator has been set up.  The
  * launcher checks it against the number of GPUs it asked for (bench.py: `rccl_ranks`). */

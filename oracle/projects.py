@@ -17,18 +17,18 @@ FRAMES = T.BLOCK_FRAMES
 class OracleProject:
     """The voices `sel` of a workload on the f64 scalar oracle; step() returns one block of the bus."""
 
-    def __init__(self, workload, sel, grouped=True, bank_scale=1.0):
+    def __init__(self, workload, sel, grouped=True, bank_scale=1.0, lib_=None):
         self.period = PJ.WORKLOADS[workload]["blocks"]
         self.block_index = 0
         self.n = int(len(sel))
         self.banks = []
         for spec in PJ.plan(workload, sel, grouped, bank_scale):
             if spec["kind"] == "welsh":
-                bank = O.Bank.welsh(spec["params"])
+                bank = O.Bank.welsh(spec["params"], lib_=lib_)
             elif spec["kind"] == "fm":
-                bank = O.Bank.fm(spec["params"])
+                bank = O.Bank.fm(spec["params"], lib_=lib_)
             else:
-                bank = O.Bank.sampler(spec["pcm"], spec["descs"], spec["params"])
+                bank = O.Bank.sampler(spec["pcm"], spec["descs"], spec["params"], lib_=lib_)
             fx = [O.Fx(k, p) for k, p in spec["fx"]]
             self.banks.append((bank, fx, spec["events"]))
 

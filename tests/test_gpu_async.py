@@ -23,7 +23,8 @@ def _twin(make):
     return make(), make()
 
 
-def _render_ahead(gpu_ctx, sync_inst, async_inst, n, blocks, events, fx_sync=(), fx_async=(), frames_of=lambda b: FRAMES, rotation=2):
+def _render_ahead(gpu_ctx, sync_inst, async_inst, n, blocks, events, fx_sync=(), fx_async=(), frames_of=lambda b: FRAMES, rotation=2,
+                  head_async=None):
     """Walk `blocks` blocks twice: instrument A the plain way (render, effects, mix into bus A);
     instrument B software-pipelined (render of block b+1 submitted before the effects of block b,
     two blocks alternating).  events(b) -> note events applied before block b.  Returns both buses
@@ -52,6 +53,10 @@ def _render_ahead(gpu_ctx, sync_inst, async_inst, n, blocks, events, fx_sync=(),
     if ev is not None:
         async_inst.handle_midi_events(ev)
     async_inst.generate_batch_values_async(blk_a[0], frames_of(0))
+    head = {}  # block index in the rotation -> stages of the chain already processed behind the render
+    if head_async is not None:
+        head[0] = gpu_ctx.transform_chain_async(list(fx_async), blk_a[0], frames_of(0))
+        head_async.append(head[0])
     for b in range(blocks):
         cur, nxt = blk_a[b % rotation], blk_a[(b + 1) % rotation]
         f = frames_of(b)
@@ -60,8 +65,14 @@ def _render_ahead(gpu_ctx, sync_inst, async_inst, n, blocks, events, fx_sync=(),
             if ev is not None:
                 async_inst.handle_midi_events(ev)
             async_inst.generate_batch_values_async(nxt, frames_of(b + 1))
-        for e in fx_async:
-            e.transform_audio(cur, f)
+            if head_async is not None:  # groove_fx_chain_process_async: the chain's IIR head right behind the render, on its stream
+                head[(b + 1) % rotation] = gpu_ctx.transform_chain_async(list(fx_async), nxt, frames_of(b + 1))
+                head_async.append(head[(b + 1) % rotation])
+        if head_async is not None:
+            gpu_ctx.transform_chain(list(fx_async)[head.pop(b % rotation, 0):], cur, f)
+        else:
+            for e in fx_async:
+                e.transform_audio(cur, f)
         gpu_ctx.mix([cur], f, E._Slice(bus_a, at), accumulate=False)
         if rotation > 2:
             cur.release()
@@ -105,6 +116,37 @@ def test_welsh_chain_render_ahead_is_identical(gpu_ctx):
     fx_a = [E.Effect(gpu_ctx, k, p) for k, p in _short_chain(n)]
     fx_b = [E.Effect(gpu_ctx, k, p) for k, p in _short_chain(n)]
     _render_ahead(gpu_ctx, a, b, n, blocks, lambda k: on if k == 0 else (off if k == 8 else None), fx_a, fx_b)
+    for x in (a, b, *fx_a, *fx_b):
+        x.destroy()
+
+
+@pytest.mark.parametrize("rotation", [2, 3])
+def test_chain_head_behind_the_render_is_identical(gpu_ctx, rotation):
+    """groove_fx_chain_process_async: the chain's leading BiQuad processed on the render's side stream, one block ahead of
+    the ctx stream's walk, the rest of the chain (fused run, all-passes, row sums for the mix) on the ctx stream: same
+    blocks and same bus, bit for bit, as effect by effect on the ctx stream — through a note-off, ragged blocks, a reset."""
+    from groove_amd import entities as E
+    n, blocks = 1024, 14
+    params, idx = P.welsh_voices_grouped(n, 0)
+    on, off = P.grouped_note_events(idx, True), P.grouped_note_events(idx, False)
+    a, b = _twin(lambda: E.WelshSynth(gpu_ctx, params))
+    fx_a = [E.Effect(gpu_ctx, k, p) for k, p in _short_chain(n)]
+    fx_b = [E.Effect(gpu_ctx, k, p) for k, p in _short_chain(n)]
+    sizes = [256, 256, 100, 256, 7, 256, 255, 256, 256, 256, 64, 256, 256, 256]
+    for rep in range(2):
+        taken = []
+        _render_ahead(gpu_ctx, a, b, n, blocks, lambda k: on if k == 0 else (off if k == 8 else None), fx_a, fx_b,
+                      frames_of=lambda k: sizes[k], rotation=rotation, head_async=taken)
+        assert taken and all(t == 1 for t in taken), taken   # the BiQuad, and only it, rides behind the render
+        for x in (a, b, *fx_a, *fx_b):
+            x.reset()
+    # a block with no pending render: nothing is taken, and the whole chain still works on the ctx stream
+    blk = gpu_ctx.block(n, FRAMES)
+    assert gpu_ctx.transform_chain_async(fx_b, blk, FRAMES) == 0
+    b.generate_batch_values_async(blk, FRAMES)
+    assert gpu_ctx.transform_chain_async(fx_b[1:], blk, FRAMES) == 0   # starts with a stage of the other sort
+    gpu_ctx.transform_chain(fx_b, blk, FRAMES)
+    blk.destroy()
     for x in (a, b, *fx_a, *fx_b):
         x.destroy()
 

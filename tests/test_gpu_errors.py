@@ -147,3 +147,75 @@ def test_delay_line_geometry_from_hostile_parameters(gpu_ctx):
     assert L.groove_fx_create(h, T.FX_DELAY, (T.FxParams * 2)(*[T.fx_params(delay_seconds=1e30)] * 2), 2, C.byref(out)) != 0
     assert L.groove_fx_create(h, T.FX_CHORUS, (T.FxParams * 2)(*[T.fx_params(voices=4_000_000_000, delay_seconds=0.01)] * 2), 2, C.byref(out)) != 0
     assert b"voices" in L.groove_last_error(h)
+
+
+def test_synchronize_deadline_names_the_blocked_stream():
+    """A kernel that does not complete must come back as an ERROR, not as a hang: a library stream
+    is blocked on purpose (groove_debug_spin: one idle kernel), groove_synchronize and a download return non-zero within
+    the deadline and name the stream; nothing is cancelled — a later wait sees the work complete and the ctx works on."""
+    import time
+    from groove_amd import entities as E
+    ctx = E.Context(0)
+    try:
+        assert ctx.sync_timeout_ms == 60000
+        ctx.sync_timeout_ms = 250
+        ctx.debug_spin(1, 1500)            # kind stream 1 busy for 1.5 s
+        t0 = time.time()
+        with pytest.raises(lib.GrooveError, match="groove_synchronize: not complete after 250 ms.*kind stream 1"):
+            ctx.synchronize()
+        assert time.time() - t0 < 1.2
+        ctx.sync_timeout_ms = 20000
+        ctx.synchronize()                  # the same wait, long enough: completes
+        # the ctx stream itself: a blocking copy hits the deadline too
+        bus = ctx.bus(256)
+        ctx.sync_timeout_ms = 200
+        ctx.debug_spin(-1, 1200)
+        with pytest.raises(lib.GrooveError, match="copy on the ctx stream: not complete after 200 ms.*ctx stream"):
+            bus.download()
+        ctx.sync_timeout_ms = 0            # wait for ever: plain hipStreamSynchronize
+        ctx.synchronize()
+        assert not bus.download().any()
+        # still a working context
+        ctx.sync_timeout_ms = 20000
+        n = 64
+        synth = E.WelshSynth(ctx, P.welsh_voices(n))
+        synth.handle_midi_events(P.note_on_all(n))
+        synth.render_mix(bus, 256)
+        assert np.abs(bus.download()).max() > 1e-3
+        info = ctx.debug_info()
+        assert info["streams_created"] == 8 and info["placeholder_fifth"] is True and info["comm_before_streams"] is False
+    finally:
+        ctx.close()
+
+
+def test_init_with_communicator_first_and_safe_stream_layout():
+    """groove_init_comm (the rank's RCCL communicator before the library's streams) on one rank, and the conservative
+    stream layout (GROOVE_SAFE_STREAMS=1: one priority, four streams): same bus bits as the default layout for a project
+    that uses every bank stream (mixed Welsh / FM / sampler, fused, note events in most blocks)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = (
+        "import sys, json, hashlib, numpy as np; sys.path.insert(0, %r)\n"
+        "from groove_amd import entities as E, projects as PJ\n"
+        "uid = E.Context.new_comm_unique_id()\n"
+        "ctx = E.Context(0, comm=(uid, 0, 1))\n"
+        "proj = PJ.Project(ctx, 'mixed-131072', np.arange(8192, dtype=np.int64), bank_scale=0.05)\n"
+        "bus = ctx.bus(10 * 256)\n"
+        "[proj.step(bus, b * 256) for b in range(10)]\n"
+        "ctx.bus_reduce(bus, 10 * 256, 0)\n"
+        "out = bus.download()\n"
+        "print(json.dumps({'sha': hashlib.sha256(out.tobytes()).hexdigest(), 'peak': float(np.abs(out).max()), 'ranks': ctx.comm_ranks(), 'info': ctx.debug_info()}))\n"
+        "proj.destroy(); ctx.close()\n" % repo)
+    res = {}
+    for safe in ("0", "1"):
+        env = dict(os.environ, GROOVE_SAFE_STREAMS=safe, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[safe] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["0"]["peak"] > 1.0 and res["0"]["sha"] == res["1"]["sha"]
+    assert res["0"]["ranks"] == 1 and res["0"]["info"]["comm_before_streams"] is True
+    assert res["0"]["info"]["streams_created"] == 8 and res["1"]["info"]["streams_created"] == 4
+    assert res["1"]["info"]["layout"].startswith("safe") and res["1"]["info"]["placeholder_fifth"] is False

@@ -24,13 +24,20 @@ def _subset(params, idx):
     return out
 
 
+NOTE_OFF_BLOCK = 12
+BLOCKS = 36   # note-on at block 0, note-off at block 12; the short-release patches (28, then 2 and 18) have BOTH envelopes
+              # idle from blocks ~21 / ~33 on, so whole workgroups take the idle exit (kernels.h welsh_idle_workgroup)
+
+
 def test_full_size_properties_and_sampled_parity(gpu_ctx, oracle):
+    """1,000,000 voices through the kernels bench.py times (one kernel per base kind, class-specialised bodies, blocks
+    pipelined): 36 blocks with the note-off inside, i.e. attack / decay / sustain, release, and the idle-workgroup exit."""
     from groove_amd import entities as E, lib
     params, vidx = P.welsh_voices_grouped(V)
     keys = (36 + (7 * vidx) % 49).astype(np.uint8)
-    on = P.grouped_note_events(vidx, True)
+    on, off = P.grouped_note_events(vidx, True), P.grouped_note_events(vidx, False)
     full = E.WelshSynth(gpu_ctx, params)
-    frames, blocks = 256, 3
+    frames, blocks = 256, BLOCKS
     bus = gpu_ctx.bus(blocks * frames)
     # silence before note-on
     full.render_mix(bus, frames)
@@ -39,50 +46,74 @@ def test_full_size_properties_and_sampled_parity(gpu_ctx, oracle):
 
     # fused bus of the whole project
     full = E.WelshSynth(gpu_ctx, params)
-    full.handle_midi_events(on)
     for b in range(blocks):
+        if b == 0:
+            full.handle_midi_events(on)
+        if b == NOTE_OFF_BLOCK:
+            full.handle_midi_events(off)
         full.render_mix(bus, frames, at_frame=b * frames)
     whole = bus.download().astype(np.float64)
     assert np.isfinite(whole).all() and np.abs(whole).max() > 1.0
+    state = full.download_state()
     full.destroy()
+    # the voices of the short-release patches really are idle at the end (so their workgroups took the idle exit)
+    # WelshState words (dsp_core.h): 3 x OscState {u64 phase, x1, x2}, 2 x u64 increments, EnvState amp (16..22, stage first),
+    # EnvState fil (23..29), 4 x f64 filter, vflags, pad; stage 0 = ENV_IDLE
+    for patch in (28, 2, 18):
+        lanes = np.nonzero(vidx % P.N_PATCHES == patch)[0]
+        assert len(lanes) and (state[16, lanes] == 0).all() and (state[23, lanes] == 0).all(), f"patch {patch} is not idle at the end"
+    assert (state[16] != 0).any(), "every voice idle: the long-release patches should still sound"
 
-    # the same project as 4 contiguous shards, buses summed (what the multi-GPU path does)
+    # the same project as 4 contiguous shards, buses summed (what the multi-GPU path does), first 3 blocks
     from groove_amd.parallel import voice_range
-    acc = np.zeros_like(whole)
-    sbus = gpu_ctx.bus(blocks * frames)
+    sb_blocks = 3
+    acc = np.zeros((sb_blocks * frames, 2))
+    sbus = gpu_ctx.bus(sb_blocks * frames)
     for r in range(4):
         lo, hi = voice_range(V, r, 4)
         sp = (T.WelshParams * (hi - lo)).from_buffer_copy(bytes(memoryview(params))[lo * C.sizeof(T.WelshParams):hi * C.sizeof(T.WelshParams)])
         shard = E.WelshSynth(gpu_ctx, sp)
         shard.handle_midi_events(T.note_events_np(np.arange(hi - lo, dtype=np.uint32), keys[lo:hi], True))
-        for b in range(blocks):
+        for b in range(sb_blocks):
             shard.render_mix(sbus, frames, at_frame=b * frames)
         acc += sbus.download().astype(np.float64)
         shard.destroy()
-    assert np.max(np.abs(acc - whole)) / V <= 1e-6, "sharded sum differs from the single-bank bus"
+    assert np.max(np.abs(acc - whole[:sb_blocks * frames])) / V <= 1e-6, "sharded sum differs from the single-bank bus"
 
-    # materialised form at full size: sampled voices and frames against the oracle
+    # materialised form at full size: sampled voices and frames against the oracle, at every block
     mat = E.WelshSynth(gpu_ctx, params)
-    mat.handle_midi_events(on)
     block = gpu_ctx.block(V, frames)
     bus2 = gpu_ctx.bus(blocks * frames)
     sample = np.unique((np.arange(512, dtype=np.int64) * 1953 + 7) % V)
+    assert len(set((vidx[sample] % P.N_PATCHES).tolist())) == P.N_PATCHES  # every patch is in the sample
     ob = oracle.Bank.welsh(_subset(params, sample))
-    ob.note_events(T.note_events_np(np.arange(len(sample), dtype=np.uint32), keys[sample], True))
+    sample_lanes = np.arange(len(sample), dtype=np.uint32)
     row = np.empty(V, dtype=np.float32)
-    dev = gpu_ctx.L.groove_block_device_ptr(block.h)
+    worst = 0.0
     for b in range(blocks):
+        if b == 0:
+            mat.handle_midi_events(on)
+            ob.note_events(T.note_events_np(sample_lanes, keys[sample], True))
+        if b == NOTE_OFF_BLOCK:
+            mat.handle_midi_events(off)
+            ob.note_events(T.note_events_np(sample_lanes, keys[sample], False))
         mat.generate_batch_values(block, frames)
-        gpu_ctx.mix([block], frames, E._Slice(bus2, b * frames))
+        gpu_ctx.mix([block], frames, E._Slice(bus2, b * frames))  # reduces the render's own row sums
         want = ob.render(frames)
+        dev = gpu_ctx.L.groove_block_device_ptr(block.h)
         for ch in (0, 1):
             for f in (0, 1, 63, 200, 255):
-                off = (ch * frames + f) * V * 4
-                lib.check(gpu_ctx.L.groove_download(gpu_ctx.h, C.c_void_p(dev + off), row.ctypes.data_as(C.POINTER(C.c_float)), V), gpu_ctx.h)
+                off_b = (ch * frames + f) * V * 4
+                lib.check(gpu_ctx.L.groove_download(gpu_ctx.h, C.c_void_p(dev + off_b), row.ctypes.data_as(C.POINTER(C.c_float)), V), gpu_ctx.h)
                 err = row[sample].astype(np.float64) - want[ch, f, :]
+                worst = max(worst, float(np.max(np.abs(err))))
                 assert np.max(np.abs(err)) <= 2e-5, f"block {b} ch {ch} frame {f}: {np.max(np.abs(err)):.3e}"
+    print(f"1,000,000 voices, {blocks} blocks, note-off at {NOTE_OFF_BLOCK}: worst sampled |gpu - oracle| = {worst:.3e}")
     mbus = bus2.download().astype(np.float64)
     assert np.max(np.abs(mbus - whole)) / V <= 1e-6, "fused and materialised buses differ"
+    # ... block by block too: the release and the idle tail must agree, not only the loud part
+    per_block = np.abs(mbus - whole).reshape(blocks, -1).max(axis=1) / V
+    assert per_block.max() <= 1e-6, per_block
     mat.destroy(); block.destroy()
 
 
@@ -91,7 +122,7 @@ def test_repeated_renders_are_bit_identical(gpu_ctx):
     kernels ran on and however the blocks overlapped: two renders of the same project give the same bits.
     One size per launch form: all-kinds kernel (small bank), per-kind kernels with the block pipeline."""
     from groove_amd import entities as E
-    for n in (40_000, 400_000):
+    for n in (40_000, 700_000):  # below and above the pipeline threshold (~550,000 voices, groove_hip.hip pipeline_min_waves)
         params, vidx = P.welsh_voices_grouped(n)
         on, off = P.grouped_note_events(vidx, True), P.grouped_note_events(vidx, False)
         runs = []

@@ -269,6 +269,80 @@ def test_chain_process_equals_stage_by_stage(gpu_ctx, n):
     ba.destroy(); bb.destroy()
 
 
+@pytest.mark.parametrize("n", [6, 64, 1000, 4100])
+def test_chain_leaves_the_blocks_lane_sums_for_the_mix(gpu_ctx, n):
+    """The last launch of a chain writes the block's lane sums (kernels.h fx_row_sum) and groove_mix reduces those instead
+    of reading the block back: the bus must be the sum over the lanes of what the block holds — for chains that end in the
+    fused run kernel, in the direct all-pass kernel, in a serial kernel (no sums: the mix reads the block), for ragged
+    blocks, lane counts that are no multiple of 4 or of a workgroup, and after the caller wrote the block itself."""
+    import ctypes as C
+    from groove_amd import entities as E, lib
+    chains = {
+        "run": [(T.FX_GAIN, _params(n, ceiling=0.8)), (T.FX_DELAY, _params(n, delay_seconds=0.01, wet=0.7))],
+        "reverb": [(T.FX_CHORUS, _params(n, voices=3, delay_seconds=0.03)), (T.FX_REVERB, _params(n, attenuation=0.9, reverb_seconds=0.5))],
+        "reverb+limiter": [(T.FX_REVERB, _params(n, attenuation=0.9, reverb_seconds=0.5)), (T.FX_LIMITER, _params(n, limit_min=0.0, limit_max=0.6))],
+        "serial-last": [(T.FX_GAIN, _params(n, ceiling=0.8)), (T.FX_BIQUAD_LP12, _params(n, cutoff_hz=900.0, q=0.707))],
+        "mixer-last": [(T.FX_GAIN, _params(n, ceiling=0.8)), (T.FX_MIXER, _params(n))],
+    }
+    sizes = [256, 100, 256, 1, 255, 256]
+    x = _audio(n, sum(sizes), seed=5)
+    for name, chain in chains.items():
+        fx = [E.Effect(gpu_ctx, k, p) for k, p in chain]
+        blk, bus = gpu_ctx.block(n, 256), gpu_ctx.bus(256)
+        pos = 0
+        for fr in sizes:
+            blk.upload(np.ascontiguousarray(x[:, pos:pos + fr, :]))
+            gpu_ctx.transform_chain(fx, blk, fr)
+            gpu_ctx.mix([blk], fr, bus)
+            got = bus.download(fr).astype(np.float64)
+            held = blk.download(fr).astype(np.float64)
+            want = held.sum(axis=2).T  # [frames][2]
+            scale = max(1.0, float(np.abs(held).sum(axis=2).max()))
+            assert np.max(np.abs(got - want)) <= 2e-6 * scale, (name, n, fr, float(np.max(np.abs(got - want))))
+            pos += fr
+        # the caller writes the block through the raw pointer: the sums the chain left are stale, and the mix must not use them
+        blk.upload(np.ascontiguousarray(x[:, :256, :]))
+        gpu_ctx.transform_chain(fx, blk, 256)
+        dev = blk.device_ptr()   # invalidates the sums (the pointer escapes)
+        row = np.full(n, 0.25, dtype=np.float32)
+        lib.check(gpu_ctx.L.groove_upload(gpu_ctx.h, C.c_void_p(dev), row.ctypes.data_as(C.POINTER(C.c_float)), n), gpu_ctx.h)  # frame 0, left
+        gpu_ctx.mix([blk], 256, bus)
+        assert abs(float(bus.download(1)[0, 0]) - 0.25 * n) <= 1e-4 * n, name
+        # ... and when it keeps the pointer and writes again later, groove_block_mark_dirty says so
+        gpu_ctx.transform_chain(fx, blk, 256)
+        row[:] = -0.5
+        lib.check(gpu_ctx.L.groove_upload(gpu_ctx.h, C.c_void_p(dev), row.ctypes.data_as(C.POINTER(C.c_float)), n), gpu_ctx.h)
+        blk.mark_dirty()
+        gpu_ctx.mix([blk], 256, bus)
+        assert abs(float(bus.download(1)[0, 0]) + 0.5 * n) <= 1e-4 * n, name
+        for e in fx:
+            e.destroy()
+        blk.destroy(); bus.destroy()
+
+
+def test_rendered_block_written_through_its_pointer_is_mixed_as_written(gpu_ctx):
+    """a render leaves the block's lane sums; a caller that scales the block through groove_block_device_ptr and
+    then mixes it must hear the scaled block."""
+    import ctypes as C
+    from groove_amd import entities as E, lib, patches as P
+    n = 512
+    synth = E.WelshSynth(gpu_ctx, P.welsh_voices(n))
+    synth.handle_midi_events(P.note_on_all(n))
+    blk, bus = gpu_ctx.block(n, 256), gpu_ctx.bus(256)
+    synth.generate_batch_values(blk, 256)
+    gpu_ctx.mix([blk], 256, bus)
+    before = bus.download().astype(np.float64)
+    host = blk.download(256)
+    dev = blk.device_ptr()
+    scaled = np.ascontiguousarray(host * np.float32(0.5))
+    lib.check(gpu_ctx.L.groove_upload(gpu_ctx.h, C.c_void_p(dev), scaled.ctypes.data_as(C.POINTER(C.c_float)), scaled.size), gpu_ctx.h)
+    gpu_ctx.mix([blk], 256, bus)
+    after = bus.download().astype(np.float64)
+    assert np.abs(before).max() > 1e-2
+    assert np.max(np.abs(after - 0.5 * before)) <= 1e-5 * max(1.0, np.abs(before).max())
+    synth.destroy(); blk.destroy(); bus.destroy()
+
+
 def test_reverb_long_blocks_and_sample_rate_change(oracle):
     """The direct all-pass form unrolls at most 8 hops per frame; a block longer than 8 x the shorter line (592 frames at
     44.1 kHz) takes the chunk-parallel form with the comb sum written in place — same result.  And a sample-rate change

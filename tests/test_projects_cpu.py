@@ -129,5 +129,66 @@ def test_bench_watchdog_kills_a_stalled_child_and_retries(tmp_path):
                        env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     d = json.loads(r.stdout.strip().splitlines()[-1])
-    assert d["metric"] == "fake" and d["watchdog"] == {"attempts": 2, "killed": 1, "seconds_allowed": 3.0}
+    assert d["metric"] == "fake" and d["watchdog"] == {"attempts": 2, "killed": 1, "seconds_allowed": 3.0, "tainted": True}
     assert "killed" in r.stderr
+
+
+def test_bench_watchdog_restarts_a_child_that_reports_a_stalled_stream(tmp_path):
+    """... and a child whose library reported the stalled stream itself (groove_synchronize's deadline -> exit code 75) is
+    replaced at once, without waiting for the watchdog's own limit."""
+    import time
+    marker = tmp_path / "stalled_once"
+    env = dict(os.environ, GROOVE_BENCH_FAKE_STALL_ONCE=str(marker), GROOVE_BENCH_FAKE_STALL_EXIT="1")
+    env.pop("WORLD_SIZE", None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--watchdog-seconds", "60"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["watchdog"]["attempts"] == 2 and d["watchdog"]["killed"] == 1 and d["watchdog"]["tainted"] is True
+    assert "stalled stream" in r.stderr and time.time() - t0 < 50
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "GROOVE_BENCH_CHILD")}
+    env.update(extra)
+    return env
+
+
+@pytest.mark.parametrize("mode", ["hang", "exit75"])
+def test_bench_rank_launcher_has_a_deadline_and_restarts_all_ranks(tmp_path, mode):
+    """bench.py --gpus 2 started plain launches its ranks itself: when one rank stalls (here a stand-in that hangs, or
+    that reports a stalled stream, the first time), the whole group is killed at the deadline — exactly the PIDs started —
+    and two FRESH ranks are started; the line says so."""
+    marker = tmp_path / "stalled_once"
+    env = _clean_env(GROOVE_BENCH_FAKE_STALL_ONCE=str(marker), GROOVE_BENCH_RANKS_DEADLINE_S="6")
+    if mode == "exit75":
+        env.update(GROOVE_BENCH_FAKE_STALL_EXIT="1", GROOVE_BENCH_RANKS_DEADLINE_S="120")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-launch"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["dry_launch"] is True and line["ranks"] == 2
+    assert line["watchdog"]["attempts"] == 2 and line["watchdog"]["killed"] == 1 and line["watchdog"]["ranks"] == 2
+    assert ("had not finished" in r.stderr) if mode == "hang" else ("stalled stream" in r.stderr)
+
+
+def test_bench_ranks_under_an_external_launcher_are_supervised(tmp_path):
+    """Started the way the driver starts it for N > 1 (torch.distributed.run: RANK / WORLD_SIZE / MASTER_* in the
+    environment), every rank process only supervises a child; a child that reports a stalled stream makes ALL supervisors
+    replace their children, and rank 0 prints the line of the second attempt."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    marker = tmp_path / "stalled_once"
+    procs = []
+    for rank in range(2):
+        env = _clean_env(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                         GROOVE_BENCH_FAKE_STALL_ONCE=str(marker), GROOVE_BENCH_FAKE_STALL_EXIT="1", TORCHELASTIC_RUN_ID="test")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-launch"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=240) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], [o[1][-1500:] for o in outs]
+    line = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1])
+    assert line["dry_launch"] is True and line["ranks"] == 2
+    assert line["watchdog"]["supervised_under_launcher"] is True and line["watchdog"]["attempts"] == 2 and line["watchdog"]["killed"] == 1
+    assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]   # only rank 0 prints

@@ -10,8 +10,8 @@ for lib in "$@"; do
   name=$(basename $lib .so)
   cp "$lib" groove_amd/libgroove_hip.so
   rm -rf gpurun_out/pmc_$name
-  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/pmc_$name -- python3 bench.py $ARGS --no-cpu-baseline --no-configs --no-parity --repeats 1 > gpurun_out/pmc_$name.log 2>&1
-  rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmcg_$name -- python3 bench.py $ARGS --no-cpu-baseline --no-configs --no-parity --repeats 1 > gpurun_out/pmcg_$name.log 2>&1
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/pmc_$name -- python3 bench.py $ARGS --no-cpu-baseline --no-configs --no-parity --no-shard-curve --repeats 1 --no-watchdog > gpurun_out/pmc_$name.log 2>&1
+  rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmcg_$name -- python3 bench.py $ARGS --no-cpu-baseline --no-configs --no-parity --no-shard-curve --repeats 1 --no-watchdog > gpurun_out/pmcg_$name.log 2>&1
   python3 - "$name" <<'PY'
 import csv, glob, sys, collections
 name = sys.argv[1]

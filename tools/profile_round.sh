@@ -18,11 +18,18 @@ TO="timeout ${PASS_TIMEOUT:-420}"   # one pass of one workload takes 20-60 s; a 
 for W in $WORKLOADS; do
   OUT=gpurun_out/prof_${ROUND}_$W
   rm -rf $OUT; mkdir -p $OUT
-  BENCH="python3 bench.py --workload $W --no-cpu-baseline --no-configs --no-parity --repeats 1 --no-watchdog"   # (the watchdog would start a child from under the profiler)
+  # "<workload>-window": the same workload under the DRIVER's command line (--steps 20 --warmup 5), so that the counters
+  # describe the blocks the driver's line times (blocks 5..24: every voice sounding)
+  WL=${W%-window}; WIN=""; [ "$WL" != "$W" ] && WIN="--steps 20 --warmup 5"
+  BENCH="python3 bench.py --workload $WL $WIN --no-cpu-baseline --no-configs --no-parity --no-shard-curve --repeats 1 --no-watchdog"   # (the watchdog would start a child from under the profiler)
   $TO rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/bench_kt.log 2>&1
   $TO rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH > $OUT/bench_fetch.log 2>&1
   $TO rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH > $OUT/bench_write.log 2>&1
   $TO rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq -- $BENCH > $OUT/bench_sq.log 2>&1
   $TO rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/grbm -- $BENCH > $OUT/bench_grbm.log 2>&1
+  if [ "${MIX:-1}" = "1" ]; then   # measured instruction classes (f64 / conversions / transcendental / integer / fp32)
+    $TO rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 --output-format csv -d $OUT/mix1 -- $BENCH > $OUT/bench_mix1.log 2>&1
+    $TO rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 --output-format csv -d $OUT/mix2 -- $BENCH > $OUT/bench_mix2.log 2>&1
+  fi
   python3 tools/summarize_prof.py $OUT $ROUND $W
 done

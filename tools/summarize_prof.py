@@ -10,8 +10,11 @@ import sys
 
 out, rnd, workload = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "welsh-1m")
 os.makedirs("profiles", exist_ok=True)
+# "<workload>-window" = the same workload under the driver's command line (--steps 20 --warmup 5): tools/profile_round.sh
+base_workload, windowed = (workload[:-len("-window")], True) if workload.endswith("-window") else (workload, False)
 summary = {"round": rnd, "workload": workload,
-           "command": f"python3 bench.py --workload {workload} --no-cpu-baseline --no-configs --no-parity --repeats 1 --no-watchdog   (defaults: --gpus 1 --steps 172 --warmup 4)"}
+           "command": f"python3 bench.py --workload {base_workload} --no-cpu-baseline --no-configs --no-parity --no-shard-curve --repeats 1 --no-watchdog"
+                      + (" --steps 20 --warmup 5   (the driver's window: blocks 5..24 of the timeline)" if windowed else "   (defaults: --gpus 1 --steps 172 --warmup 4)")}
 STEP_KERNELS = ("render", "_tp_kernel", "partial_", "mix_", "fx_", "block_", "_events_")   # what one step of the hot path launches
 
 ks = glob.glob(f"{out}/kt/*/*_kernel_stats.csv")
@@ -29,7 +32,7 @@ if kt:
     for marker in ("partial_final_kernel", "partial_rows_kernel", "mix_final_kernel", "mix_partial_kernel"):
         ends = sorted(int(r["End_Timestamp"]) for r in rows if marker in r["Kernel_Name"])
         if len(ends) > 40:
-            n_steps = 176
+            n_steps = 25 if windowed else 176
             per = max(1, round(len(ends) / n_steps))       # a step may end with several launches of the marker (one per bank)
             ends = ends[per - 1::per]
             steady = ends[4:]
@@ -59,13 +62,14 @@ def counters(sub):
                 **meta[k]} for k, cs in agg.items() if "rocclr" not in k}
 
 
-for sub in ("fetch", "write", "sq", "grbm"):
+for sub in ("fetch", "write", "sq", "grbm", "mix1", "mix2"):
     summary[sub] = counters(sub)
 STEPS = 176.0   # 172 timed + 4 warm-up steps per run, unless the bench line of the run says otherwise
 _bl = summary.get("bench_line_under_profiler", {})
 if _bl.get("steps"):
     STEPS = float(_bl["steps"] + _bl.get("warmup", 0))
 summary["steps_per_run"] = STEPS
+summary["steps"], summary["warmup"] = _bl.get("steps"), _bl.get("warmup")
 
 
 # Per STEP (one 256-frame block of the whole project): per-kernel totals over the run divided by the steps, summed over
@@ -83,6 +87,26 @@ w, f = per_step("write", "WRITE_SIZE") * 1024.0, per_step("fetch", "FETCH_SIZE")
 summary["hbm_traffic_bytes_per_step"] = {"write": w, "fetch_raw": f, "fetch_x2_gfx950": 2 * f, "total_raw": w + f, "total_corrected": w + 2 * f}
 summary["instructions_per_step"] = {"valu_wave_insts": per_step("sq", "SQ_INSTS_VALU"), "salu_wave_insts": per_step("sq", "SQ_INSTS_SALU"),
                                     "note": "SQ_INSTS_VALU / SQ_INSTS_SALU summed over the step's kernels (wave-level instructions)"}
+# Measured instruction classes of a step (passes mix1 / mix2; wave-level instruction counts).  "plain" = everything the class
+# counters do not name (moves, compares, selects, DPP, bit operations ...).  Cost weights from docs/VALU_COSTS.md (measured on
+# this chip, in units of one plain fp32 operation = 2 issue cycles of a wave64 on a SIMD-32... see the file): f64 2x, conversions 2x
+# (to / from f64; the mix here is dominated by those), transcendental 4x, everything else 1x.
+mix_names = ("SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F32",
+             "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32")
+if summary.get("mix1"):
+    mix = {}
+    for nm in mix_names:
+        v = per_step("mix1", nm) or per_step("mix2", nm)
+        mix[nm[len("SQ_INSTS_"):].lower()] = v
+    total = mix.get("valu") or 0.0
+    f64 = mix["valu_add_f64"] + mix["valu_mul_f64"] + mix["valu_fma_f64"]
+    named = f64 + mix["valu_trans_f32"] + mix["valu_cvt"] + mix["valu_int32"] + mix["valu_int64"] + mix["valu_add_f32"] + mix["valu_mul_f32"] + mix["valu_fma_f32"]
+    mix["f64_total"] = f64
+    mix["other_plain"] = max(0.0, total - named)
+    # issue cycles per wave instruction: plain fp32 / int 2 (a wave64 on a SIMD-32 datapath... the spec rate bench.py uses), f64 4, conversions 4, transcendental 8
+    mix["cost_weighted_cycles"] = 2.0 * (total - f64 - mix["valu_cvt"] - mix["valu_trans_f32"]) + 4.0 * f64 + 4.0 * mix["valu_cvt"] + 8.0 * mix["valu_trans_f32"]
+    mix["note"] = "wave-level instructions per step by class (PMC); cost_weighted_cycles = 2 x plain + 4 x f64 + 4 x conversions + 8 x transcendental SIMD issue cycles"
+    summary["valu_mix_per_step"] = mix
 # The clock the chip held under each kernel (MI355X_MICROARCH.md, DVFS give-back): GRBM_GUI_ACTIVE is summed over the 8
 # XCDs, so clock = GRBM_GUI_ACTIVE / 8 / the dispatch's duration IN THE SAME PASS (a counter pass runs the kernels one
 # at a time, so these are a kernel's own cycles and its own time — NOT the clock of the real run, where four render kernels
