@@ -746,6 +746,7 @@ def main():
                     help="workloads with effect chains: render block b, then its effects (default: the render of block b+1 "
                          "is submitted to the side streams before the effects of block b)")
     ap.add_argument("--no-head-ahead", action="store_true", help="render-ahead walk: keep the chain's leading IIR stage on the ctx stream (A/B)")
+    ap.add_argument("--head-unfused", action="store_true", help="render-ahead walk: the IIR head behind the render as its own launch, not fused into the render kernel (A/B)")
     ap.add_argument("--dry-launch", action="store_true", help="rendezvous of the ranks over gloo only (no GPU): launcher test")
     ap.add_argument("--no-canary", action="store_true", help="(kept for old command lines; the watchdog replaced the canary)")
     ap.add_argument("--no-watchdog", action="store_true", help="run the measurement in this process (default on one GPU: in a child process that is killed and restarted if it crawls)")
@@ -824,7 +825,8 @@ def measure(args, world, rank, local_rank):
     K, W, R = args.steps, args.warmup, max(1, args.repeats)
     sel = np.arange(lo, hi, dtype=np.int64)
     m = bench_workload(ctx, args.workload, sel, K, W, R, fused=fused, grouped=not args.interleaved,
-                       render_ahead=not args.no_render_ahead, dist=dist, head_ahead=not args.no_head_ahead)
+                       render_ahead=not args.no_render_ahead, dist=dist,
+                       head_ahead=False if args.no_head_ahead else ("unfused" if args.head_unfused else True))
     line = None
     if rank == 0:
         i = m["median"]

@@ -13,24 +13,8 @@
 
 namespace groove {
 
-// y-recurrence of the Direct Form 1 biquad as an affine map of (y1, y2): y = w - a1 y1 - a2 y2, w = b0 x + b1 x1 + b2 x2
-struct BqAffine { double m00, m01, m10, m11, z0, z1; }; // (y1, y2)' = M (y1, y2) + z
-__device__ __forceinline__ void bq_affine_identity(BqAffine& m) { m.m00 = 1.0; m.m01 = 0.0; m.m10 = 0.0; m.m11 = 1.0; m.z0 = 0.0; m.z1 = 0.0; }
-__device__ __forceinline__ void bq_affine_push(BqAffine& m, double a1, double a2, double w) {
-  // one more frame: (y1, y2) -> (w - a1 y1 - a2 y2, y1)
-  const double n00 = -a1 * m.m00 - a2 * m.m10, n01 = -a1 * m.m01 - a2 * m.m11, nz0 = (w - a1 * m.z0) - a2 * m.z1;
-  m.m10 = m.m00; m.m11 = m.m01; m.z1 = m.z0;
-  m.m00 = n00; m.m01 = n01; m.z0 = nz0;
-}
-__device__ __forceinline__ void bq_affine_compose(BqAffine& later, const BqAffine& e) { // later <- later o e
-  BqAffine r;
-  r.m00 = later.m00 * e.m00 + later.m01 * e.m10; r.m01 = later.m00 * e.m01 + later.m01 * e.m11;
-  r.m10 = later.m10 * e.m00 + later.m11 * e.m10; r.m11 = later.m10 * e.m01 + later.m11 * e.m11;
-  r.z0 = later.m00 * e.z0 + later.m01 * e.z1 + later.z0;
-  r.z1 = later.m10 * e.z0 + later.m11 * e.z1 + later.z1;
-  later = r;
-}
-
+// (BqAffine and bq_tp_wave — one lane-channel's block on one wavefront — live in welsh_tp.h: the time-parallel Welsh kernel
+// applies the same scan to its own output when a BiQuad is fused behind it.)
 // Workgroup = 8 adjacent lane-channels of one channel x the block's frames (one per wave).  The block is planar [frame][lane], so a
 // lane-channel's frames are 4 n bytes apart: read per wavefront they would cost one 128-byte line per sample.  The
 // workgroup therefore moves its [frames][32] tile through LDS with whole-line accesses (two 128-byte rows per wave
@@ -88,50 +72,12 @@ __global__ __launch_bounds__(kFxTpThreads) void fx_biquad_tp_kernel(
 #pragma unroll
       for (uint32_t j = 0; j < kTpChunk; ++j) if (j >= cnt) xf[j] = 0.0f;
     }
-    // the two inputs before this lane's first frame: the previous lane's last two, or the state
-    double px1 = tp_shfl((double)xf[kTpChunk - 1], (int)lane - 1), px2 = tp_shfl((double)xf[kTpChunk - 2], (int)lane - 1);
-    if (lane == 0) { px1 = sx1; px2 = sx2; }
-    double w[kTpChunk];
-    BqAffine mine;
-    bq_affine_identity(mine);
-    {
-      double x1 = px1, x2 = px2;
-#pragma unroll
-      for (uint32_t j = 0; j < kTpChunk; ++j) {
-        const double x = (double)xf[j];
-        w[j] = b0 * x + b1 * x1 + b2 * x2;
-        if (j < cnt) bq_affine_push(mine, a1, a2, w[j]);
-        x2 = x1; x1 = x;
-      }
-    }
-    BqAffine incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      BqAffine o;
-      o.m00 = tp_shfl(incl.m00, (int)lane - d); o.m01 = tp_shfl(incl.m01, (int)lane - d);
-      o.m10 = tp_shfl(incl.m10, (int)lane - d); o.m11 = tp_shfl(incl.m11, (int)lane - d);
-      o.z0 = tp_shfl(incl.z0, (int)lane - d); o.z1 = tp_shfl(incl.z1, (int)lane - d);
-      if ((int)lane >= d) bq_affine_compose(incl, o);
-    }
-    const double e1 = incl.m00 * sy1 + incl.m01 * sy2 + incl.z0, e2 = incl.m10 * sy1 + incl.m11 * sy2 + incl.z1; // (y1, y2) after this lane
-    double y1 = tp_shfl(e1, (int)lane - 1), y2 = tp_shfl(e2, (int)lane - 1);
-    if (lane == 0) { y1 = sy1; y2 = sy2; }
     float o[kTpChunk];
-#pragma unroll
-    for (uint32_t j = 0; j < kTpChunk; ++j) {
-      o[j] = 0.0f;
-      if (j < cnt) {
-        const double y = w[j] - a1 * y1 - a2 * y2;
-        y2 = y1; y1 = y;
-        o[j] = (float)y;
-        if (wm < 1.0f) o[j] = fmaf(o[j], wm, xf[j] * (1.0f - wm));
-      }
-    }
+    double ns[4];
+    const BiquadCoefD cf{b0, b1, b2, a1, a2};
+    const bool holds_end = bq_tp_wave(xf, cnt, lane, frames, cf, sx1, sx2, sy1, sy2, wm, o, ns);
     if (cnt) *reinterpret_cast<float4*>(&tile.t[c][n0]) = make_float4(o[0], o[1], o[2], o[3]); // (frames past the block: never stored)
-    if (frames && lane == (frames - 1) / kTpChunk) { // x1, x2 = the block's last two inputs; y1, y2 = its last two outputs
-      const double nx1 = (double)xf[cnt - 1], nx2 = cnt >= 2 ? (double)xf[cnt - 2] : px1;
-      s_st[0][c] = nx1; s_st[1][c] = nx2; s_st[2][c] = y1; s_st[3][c] = y2;
-    }
+    if (holds_end) { s_st[0][c] = ns[0]; s_st[1][c] = ns[1]; s_st[2][c] = ns[2]; s_st[3][c] = ns[3]; }
   }
   __syncthreads();
   if (threadIdx.x < lanes && frames) {

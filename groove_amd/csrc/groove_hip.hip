@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
+#include <memory>
 #include <thread>
 #include <new>
 
@@ -27,10 +28,27 @@ namespace {
 thread_local std::string g_last_error;
 }
 
+// The lane order of a bank that keeps its voices in another order than the caller gave them (patch-major regrouping,
+// welsh_upload_params): src_lane[caller's lane] = the library's lane.  Shared by the bank and by every block its renders
+// filled, so that a block outlives a re-grouping (or the bank) with the order its content has.
+struct LaneOrder {
+  uint32_t n = 0;
+  uint32_t* d_src_lane = nullptr;
+  ~LaneOrder() { if (d_src_lane) (void)hipFree(d_src_lane); }
+};
+
 struct groove_block {
   groove_ctx* ctx;
   uint32_t n, cap;
   float* d;
+  // LAZY LANE ORDER.  A render of a regrouped bank fills `d_alt` in the LIBRARY's lane order (coalesced rows) and tags the
+  // block with that order; `d` — the pointer the caller can ask for — is only produced (one gather pass, block_normalise)
+  // when something needs the caller's order: an effect (per-lane parameters), an element-wise accumulate, a download,
+  // groove_block_device_ptr.  The mix bus never does (a sum over the lanes has no order), so render + mix of a regrouped
+  // bank costs what it costs for a grouped one (round 2 gathered every block: 2.85 ms against 0.97 at 1,000,000 voices).
+  float* d_alt = nullptr;
+  std::shared_ptr<LaneOrder> order; // set: the block's current content is d_alt, in this order
+  uint32_t order_frames = 0;
   // groove_bank_render_async: the producer kernels run on side streams; ev_ready[k] is recorded on
   // side stream k behind them, ready_mask says which are outstanding (block_acquire clears it).
   hipEvent_t ev_free = nullptr, ev_ready[16] = {};
@@ -76,13 +94,11 @@ struct groove_bank {
   int stream_slot = 0; // side stream of a single-kernel bank (FM, sampler, per-lane Welsh) in the asynchronous fused path
   bool ctx_touched = true; // the ctx stream has worked on this bank's state since its last asynchronous render waited for it
   int side_mode = 0;    // which side streams carried this bank's last asynchronous work: 0 none, 1 one per base kind, 2 stream_slot
-  hipEvent_t ev_gather = nullptr; // groove_bank_render_async of a regrouped bank: the scratch block has been gathered
-  bool gather_recorded = false;
   // welsh: lane permutation.  A bank whose patches are interleaved voice by voice is kept patch-major inside
   // the library (params, state, cold values in INTERNAL lane order) so that it runs on the wave-uniform kernels;
   // perm[internal lane] = caller's voice index, inv = its inverse.  Empty = identity.
   std::vector<uint32_t> perm, inv;
-  uint32_t* d_inv = nullptr;      // device copy of inv (materialised renders are handed out in the caller's lane order)
+  std::shared_ptr<LaneOrder> order; // device copy of inv, shared with the blocks this bank's renders fill (groove_block: lazy lane order)
   uint8_t* d_wg_cls = nullptr;   // welsh: oscillator class pair of each entry of d_wg_list
   uint8_t* d_wg_base = nullptr;  // welsh: base kind of each entry of d_wg_list (the all-kinds kernel of small banks)
   uint32_t* d_wg_list = nullptr; // welsh: workgroup ids (groups of 4 virtual waves) sorted by kind (kernels.h)
@@ -254,7 +270,11 @@ hipError_t wait_deadline(groove_ctx* ctx, hipStream_t st, hipEvent_t ev, const c
 }
 hipError_t ctx_wait(groove_ctx* ctx, const char* what = "wait for the ctx stream") { return wait_deadline(ctx, ctx->stream, nullptr, what); }
 hipError_t ctx_memcpy(groove_ctx* ctx, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
-  hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, ctx->stream);
+  // (a copy from or to pageable host memory blocks INSIDE hipMemcpyAsync until the stream gets to it: the deadline has to
+  // be applied to the stream first)
+  hipError_t e = ctx_wait(ctx, "copy on the ctx stream");
+  if (e != hipSuccess) return e;
+  e = hipMemcpyAsync(dst, src, bytes, kind, ctx->stream);
   if (e != hipSuccess) return e;
   return ctx_wait(ctx, "copy on the ctx stream");
 }
@@ -289,6 +309,34 @@ int block_acquire(groove_block* blk) {
   for (int k = 0; k < kSideStreams; ++k)
     if (blk->ready_mask & (1u << k)) GHIP(ctx, hipStreamWaitEvent(ctx->stream, blk->ev_ready[k], 0));
   blk->ready_mask = 0;
+  return 0;
+}
+// The block's current content, whichever lane order it is in (for readers that do not care: lane sums).
+inline const float* block_data(const groove_block* blk) { return blk->order ? blk->d_alt : blk->d; }
+// Where a render of bank order `order` (null: the caller's own order) writes; tags the block.
+int block_render_target(groove_block* blk, const std::shared_ptr<LaneOrder>& order, uint32_t frames, float** out) {
+  if (!order) { blk->order.reset(); *out = blk->d; return 0; }
+  if (!blk->d_alt) {
+    hipError_t e = hipMalloc(&blk->d_alt, (size_t)2 * blk->cap * blk->n * 4);
+    if (e != hipSuccess) return fail(blk->ctx, std::string("block (library lane order): hipMalloc: ") + hipGetErrorString(e));
+  }
+  blk->order = order;
+  blk->order_frames = frames;
+  *out = blk->d_alt;
+  return 0;
+}
+// Produce the caller's lane order in blk->d (ctx stream; the caller has acquired the block).
+int block_normalise(groove_block* blk) {
+  if (!blk->order) return 0;
+  groove_ctx* ctx = blk->ctx;
+  const uint32_t frames = std::min(blk->order_frames, blk->cap);
+  const size_t chs = (size_t)blk->cap * blk->n;
+  if (frames) {
+    hipLaunchKernelGGL(block_gather_kernel, dim3((blk->n + kThreads - 1) / kThreads, std::min<uint32_t>(frames, 64)), dim3(kThreads), 0, ctx->stream, blk->d, chs,
+                       blk->d_alt, chs, blk->order->d_src_lane, blk->n, frames);
+    GHIP(ctx, hipGetLastError());
+  }
+  blk->order.reset();
   return 0;
 }
 // An effect's memory (IIR state, rings, parameter arrays) is touched by one stream at a time: the ctx stream, or — for the
@@ -375,10 +423,13 @@ int welsh_upload_params(groove_bank* b, bool regroup) {
         for (uint32_t i = 0; i < n; ++i) b->inv[b->perm[i]] = i;
       }
     }
-    if (b->d_inv) { GHIP(ctx, hipFree(b->d_inv)); b->d_inv = nullptr; }
+    b->order.reset(); // blocks filled under the old order keep it alive for as long as they hold that content
     if (!b->perm.empty()) {
-      GHIP(ctx, hipMalloc(&b->d_inv, (size_t)n * sizeof(uint32_t)));
-      GHIP(ctx, ctx_memcpy(ctx, b->d_inv, b->inv.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+      auto o = std::make_shared<LaneOrder>();
+      o->n = n;
+      GHIP(ctx, hipMalloc(&o->d_src_lane, (size_t)n * sizeof(uint32_t)));
+      GHIP(ctx, ctx_memcpy(ctx, o->d_src_lane, b->inv.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+      b->order = std::move(o);
     }
   }
   // everything below is in INTERNAL lane order
@@ -686,12 +737,12 @@ int mix_one(groove_ctx* ctx, const groove_block* b, uint32_t frames, float* bus,
   const uint32_t rows = 2 * frames;
   if (ensure_partial(ctx, (size_t)rows * n_seg)) return 1;
   if (n_seg == 1) { // one segment per row: the partial sums are the totals
-    hipLaunchKernelGGL(mix_partial_kernel, dim3(1, rows), dim3(kThreads), 0, ctx->stream, b->d, b->n, frames,
+    hipLaunchKernelGGL(mix_partial_kernel, dim3(1, rows), dim3(kThreads), 0, ctx->stream, block_data(b), b->n, frames,
                        (size_t)b->cap * b->n, kMixSeg, ctx->d_partial, 1u, bus, accumulate, planar_stride);
     GHIP(ctx, hipGetLastError());
     return 0;
   }
-  hipLaunchKernelGGL(mix_partial_kernel, dim3(n_seg, rows), dim3(kThreads), 0, ctx->stream, b->d, b->n, frames,
+  hipLaunchKernelGGL(mix_partial_kernel, dim3(n_seg, rows), dim3(kThreads), 0, ctx->stream, block_data(b), b->n, frames,
                      (size_t)b->cap * b->n, kMixSeg, ctx->d_partial, n_seg, (float*)nullptr, 0, (size_t)0);
   hipLaunchKernelGGL(mix_final_kernel, dim3(blocks_for(rows)), dim3(kThreads), 0, ctx->stream, ctx->d_partial,
                      frames, n_seg, bus, accumulate, planar_stride);
@@ -1074,7 +1125,8 @@ int groove_block_create(groove_ctx* ctx, uint32_t n, uint32_t frames_cap, groove
   if (!ctx || !out) return fail(ctx, "groove_block_create: NULL argument");
   if (n == 0 || frames_cap == 0) return fail(ctx, "groove_block_create: empty block");
   GHIP(ctx, hipSetDevice(ctx->device));
-  groove_block* b = new groove_block{ctx, n, frames_cap, nullptr};
+  groove_block* b = new groove_block();
+  b->ctx = ctx; b->n = n; b->cap = frames_cap; b->d = nullptr;
   const size_t bytes = (size_t)2 * frames_cap * n * 4;
   hipError_t e = hipMalloc(&b->d, bytes);
   if (e != hipSuccess) { delete b; return fail(ctx, std::string("groove_block_create: hipMalloc: ") + hipGetErrorString(e)); }
@@ -1087,6 +1139,7 @@ int groove_block_destroy(groove_block* b) {
   if (b->ready_mask) (void)ctx_join(b->ctx);
   (void)hipStreamSynchronize(b->ctx->stream);
   (void)hipFree(b->d);
+  (void)hipFree(b->d_alt);
   (void)hipFree(b->d_sums);
   if (b->ev_free) (void)hipEventDestroy(b->ev_free);
   for (hipEvent_t e : b->ev_ready) if (e) (void)hipEventDestroy(e);
@@ -1096,8 +1149,10 @@ int groove_block_destroy(groove_block* b) {
 float* groove_block_device_ptr(groove_block* b) {
   // The pointer escapes: whatever the caller's own kernels do to the block, the row sums the last render left no
   // longer describe it (groove_mix would put the pre-modification audio on the bus).
-  if (b) b->sums_valid = false;
-  return b ? b->d : nullptr;
+  if (!b) return nullptr;
+  if (b->order && (block_acquire(b) || block_normalise(b))) return nullptr; // the caller's lane order, now that somebody looks
+  b->sums_valid = false;
+  return b->d;
 }
 int groove_block_mark_dirty(groove_block* b) {
   if (!b) return fail(nullptr, "groove_block_mark_dirty: block is NULL");
@@ -1112,6 +1167,7 @@ int groove_block_upload(groove_block* b, const float* host, uint32_t frames) {
   if (frames > b->cap) return fail(ctx, "groove_block_upload: frames > capacity");
   if (block_acquire(b)) return 1;
   b->sums_valid = false;
+  b->order.reset(); // the content is replaced
   const size_t per = (size_t)frames * b->n;
   for (int ch = 0; ch < 2; ++ch)
     GHIP(ctx, hipMemcpyAsync(b->d + (size_t)ch * b->cap * b->n, host + ch * per, per * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1122,7 +1178,8 @@ int groove_block_download(groove_block* b, float* host, uint32_t frames) {
   if (!b || !host) return fail(nullptr, "groove_block_download: NULL argument");
   groove_ctx* ctx = b->ctx;
   if (frames > b->cap) return fail(ctx, "groove_block_download: frames > capacity");
-  if (block_acquire(b)) return 1;
+  if (block_acquire(b) || block_normalise(b)) return 1;
+  GHIP(ctx, ctx_wait(ctx, "copy on the ctx stream"));
   const size_t per = (size_t)frames * b->n;
   for (int ch = 0; ch < 2; ++ch)
     GHIP(ctx, hipMemcpyAsync(host + ch * per, b->d + (size_t)ch * b->cap * b->n, per * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1198,9 +1255,8 @@ int groove_bank_destroy(groove_bank* b) {
   auto it = std::find(ctx->banks.begin(), ctx->banks.end(), b);
   if (it != ctx->banks.end()) ctx->banks.erase(it);
   if (b->scratch) groove_block_destroy(b->scratch);
-  if (b->ev_gather) (void)hipEventDestroy(b->ev_gather);
   for (int k = 0; k < 2; ++k) { if (b->h_ev[k]) (void)hipHostFree(b->h_ev[k]); if (b->ev_staged[k]) (void)hipEventDestroy(b->ev_staged[k]); }
-  (void)hipFree(b->d_params); (void)hipFree(b->d_state); (void)hipFree(b->d_cold); (void)hipFree(b->d_pcm); (void)hipFree(b->d_ev[0]); (void)hipFree(b->d_ev[1]); (void)hipFree(b->d_waves); (void)hipFree(b->d_wg_list); (void)hipFree(b->d_wg_cls); (void)hipFree(b->d_wg_base); (void)hipFree(b->d_inv);
+  (void)hipFree(b->d_params); (void)hipFree(b->d_state); (void)hipFree(b->d_cold); (void)hipFree(b->d_pcm); (void)hipFree(b->d_ev[0]); (void)hipFree(b->d_ev[1]); (void)hipFree(b->d_waves); (void)hipFree(b->d_wg_list); (void)hipFree(b->d_wg_cls); (void)hipFree(b->d_wg_base);
   delete b;
   return 0;
 }
@@ -1255,9 +1311,10 @@ static bool use_tp(const groove_bank* b, uint32_t frames) {
   if (b->kind == BANK_SAMPLER) return b->n <= kSamplerTpMaxVoices; // a pure gather
   return false;
 }
-static void launch_tp(groove_bank* b, uint32_t frames, bool fused, size_t chs, float* out, float* rows, hipStream_t st) {
+static void launch_tp(groove_bank* b, uint32_t frames, bool fused, size_t chs, float* out, float* rows, hipStream_t st, const groove_fx* head = nullptr) {
   groove_ctx* ctx = b->ctx;
-  const TpArgs a{b->d_params, b->d_state, out, rows, chs, render_consts(ctx->sr), b->n, frames};
+  TpArgs a{b->d_params, b->d_state, out, rows, chs, render_consts(ctx->sr), b->n, frames};
+  if (head) { a.bq_coef = head->d_coef; a.bq_st = head->d_st; a.bq_wet = head->d_wet; } // Welsh, block-writing form: the BiQuad head fused (welsh_tp.h)
   if (b->kind == BANK_FM) launch_fm_tp(a, st, fused);
   else if (b->kind == BANK_SAMPLER) { launch_sampler_tp(a, b->d_pcm, b->inline_ev, st, fused); b->inline_ev.n = 0; }
   else launch_welsh_tp(a, st, fused);
@@ -1375,17 +1432,11 @@ int groove_bank_render(groove_bank* b, uint32_t frames, groove_block* out) {
   float* rows = block_sums(out, rows_n, frames);
   if (!rows) return 1;
   auto rendered = [&]() { out->sum_rows = rows_n; out->sum_frames = frames; out->sums_valid = true; return 0; };
-  if (b->perm.empty()) return launch_render(b, frames, false, (size_t)out->cap * out->n, out->d, rows) || rendered();
-  // regrouped bank: render in the internal lane order (coalesced rows), then hand the caller's order out
-  if (!b->scratch || b->scratch->cap < frames) {
-    if (b->scratch) { GHIP(ctx, ctx_wait(ctx)); groove_block_destroy(b->scratch); b->scratch = nullptr; }
-    if (groove_block_create(ctx, b->n, std::max<uint32_t>(frames, GROOVE_BLOCK_FRAMES), &b->scratch)) return 1;
-  }
-  if (launch_render(b, frames, false, (size_t)b->scratch->cap * b->n, b->scratch->d, rows)) return 1; // (a sum has no lane order)
-  hipLaunchKernelGGL(block_gather_kernel, dim3(blocks_for(b->n), std::min<uint32_t>(frames, 64)), dim3(kThreads), 0, ctx->stream, out->d,
-                     (size_t)out->cap * out->n, b->scratch->d, (size_t)b->scratch->cap * b->n, b->d_inv, b->n, frames);
-  GHIP(ctx, hipGetLastError());
-  return rendered();
+  // a regrouped bank renders in ITS lane order (coalesced rows) into the block's second buffer; the caller's order is
+  // produced when — and if — something asks for it (groove_block: lazy lane order)
+  float* dst = nullptr;
+  if (block_render_target(out, b->order, frames, &dst)) return 1;
+  return launch_render(b, frames, false, (size_t)out->cap * out->n, dst, rows) || rendered();
 }
 // groove_bank_render on the side streams: the render kernels start once everything submitted to the
 // ctx stream so far has finished (that covers the previous users of `out` and of the bank), and run
@@ -1393,7 +1444,19 @@ int groove_bank_render(groove_bank* b, uint32_t frames, groove_block* out) {
 // them (block_acquire).  A host that keeps two blocks per instrument and submits the render of block
 // b+1 before the effect chain of block b overlaps the two (bench.py, workload chain-4096: the Welsh
 // render of a 4,096-voice bank is one wavefront's serial walk, 0.2 ms whatever else runs).
-int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out) {
+static bool fx_is_biquad12(uint32_t kind) {
+  switch (kind) {
+    case GROOVE_FX_BIQUAD_LP12: case GROOVE_FX_BIQUAD_HP12: case GROOVE_FX_BIQUAD_BP12: case GROOVE_FX_BIQUAD_BS12:
+    case GROOVE_FX_BIQUAD_AP12: case GROOVE_FX_BIQUAD_PEAK12: case GROOVE_FX_BIQUAD_LSHELF12: case GROOVE_FX_BIQUAD_HSHELF12: return true;
+    default: return false;
+  }
+}
+// `head` (may be null): a 12 dB BiQuad effect bank to be applied to the block inside the render kernel — only honoured
+// (*head_fused = true) when the bank renders time-parallel and its lanes are in the caller's order.
+static int render_async_impl(groove_bank* b, uint32_t frames, groove_block* out, groove_fx* head, bool* head_fused);
+int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out) { return render_async_impl(b, frames, out, nullptr, nullptr); }
+static int render_async_impl(groove_bank* b, uint32_t frames, groove_block* out, groove_fx* head, bool* head_fused) {
+  if (head_fused) *head_fused = false;
   if (!b || !out) return fail(nullptr, "groove_bank_render_async: NULL argument");
   groove_ctx* ctx = b->ctx;
   if (out->n != b->n) return fail(ctx, "groove_bank_render_async: block lanes != bank voices");
@@ -1411,24 +1474,12 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
     GHIP(ctx, hipEventCreateWithFlags(&out->ev_free, kSyncEventFlags));
     for (int k = 0; k < kSideStreams; ++k) GHIP(ctx, hipEventCreateWithFlags(&out->ev_ready[k], kSyncEventFlags));
   }
-  float* dst = out->d;
-  size_t chs = (size_t)out->cap * out->n;
+  const size_t chs = (size_t)out->cap * out->n;
   const uint32_t rows_n = fused_rows(b, frames);
   float* rows = block_sums(out, rows_n, frames);
   if (!rows) return 1;
-  const bool regrouped = !b->perm.empty();
-  if (regrouped) { // render in the internal lane order, gather into the caller's order afterwards
-    if (!b->scratch || b->scratch->cap < frames) {
-      if (ctx_join(ctx)) return 1;
-      GHIP(ctx, ctx_wait(ctx));
-      if (b->scratch) { groove_block_destroy(b->scratch); b->scratch = nullptr; }
-      if (groove_block_create(ctx, b->n, std::max<uint32_t>(frames, GROOVE_BLOCK_FRAMES), &b->scratch)) return 1;
-      b->gather_recorded = false;
-    }
-    if (!b->ev_gather) GHIP(ctx, hipEventCreateWithFlags(&b->ev_gather, kSyncEventFlags));
-    dst = b->scratch->d;
-    chs = (size_t)b->scratch->cap * b->n;
-  }
+  float* dst = nullptr; // a regrouped bank: the block's library-order buffer (lazy lane order)
+  if (block_render_target(out, b->order, frames, &dst)) return 1;
   // What the render has to wait for on the ctx stream: the block's consumers, and the bank's state if
   // the ctx stream has worked on it.  A block the host has released (groove_block_release) carries the
   // event of that moment, typically long past, so the render follows the previous one on its stream
@@ -1441,7 +1492,6 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
   auto begin = [&](int k) -> hipStream_t {
     hipStream_t st = side_stream_of(ctx, k);
     (void)hipStreamWaitEvent(st, out->ev_free, 0);
-    if (regrouped && b->gather_recorded) (void)hipStreamWaitEvent(st, b->ev_gather, 0); // the scratch block is free again
     // An ev_free recorded in this call is later than any ev_fork; the event of an earlier release may
     // predate one, and then this (shared) side stream still owes the wait for the fork.
     if (ctx->fork_pending[k] && !free_recorded_now) (void)hipStreamWaitEvent(st, ctx->ev_fork, 0);
@@ -1474,7 +1524,20 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
     hipStream_t st = begin(k);
     const dim3 grid(blocks_for(b->n));
     if (tp) {
-      launch_tp(b, frames, false, chs, dst, rows, st);
+      const bool fuse = head && b->kind == BANK_WELSH && !b->order && fx_is_biquad12(head->kind) && head->n == b->n && head->ctx == ctx;
+      if (fuse) { // the effect's state moves to this side stream (fx_acquire_ctx)
+        if (head->last_side != k) {
+          if (!head->ev_done) GHIP(ctx, hipEventCreateWithFlags(&head->ev_done, kSyncEventFlags));
+          if (head->last_side < 0) GHIP(ctx, hipEventRecord(head->ev_done, ctx->stream));
+          GHIP(ctx, hipStreamWaitEvent(st, head->ev_done, 0));
+        }
+      }
+      launch_tp(b, frames, false, chs, dst, rows, st, fuse ? head : nullptr);
+      if (fuse) {
+        GHIP(ctx, hipEventRecord(head->ev_done, st));
+        head->last_side = k;
+        *head_fused = true;
+      }
     } else if (small_uniform) { // all base kinds in one launch
       const RenderConsts rc = render_consts(ctx->sr);
       UniformArgs a{b->d_waves, b->d_state, dst, rows, b->d_wg_list, b->d_wg_cls, chs, rc, b->n_vwaves, b->n, frames, b->n_vwaves / kWaves};
@@ -1488,19 +1551,6 @@ int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out)
       hipLaunchKernelGGL(sampler_render_kernel<false>, grid, blk, 0, st, b->d_params, b->d_state, b->n, frames, chs, dst, rows, b->d_pcm);
     }
     end(k);
-  }
-  if (regrouped) {
-    const int g = b->stream_slot;
-    hipStream_t st = side_stream_of(ctx, g);
-    for (int k = 0; k < kSideStreams; ++k)
-      if ((used & (1u << k)) && k != g) GHIP(ctx, hipStreamWaitEvent(st, out->ev_ready[k], 0));
-    hipLaunchKernelGGL(block_gather_kernel, dim3(blocks_for(b->n), std::min<uint32_t>(frames, 64)), blk, 0, st, out->d,
-                       (size_t)out->cap * out->n, b->scratch->d, (size_t)b->scratch->cap * b->n, b->d_inv, b->n, frames);
-    GHIP(ctx, hipEventRecord(b->ev_gather, st));
-    b->gather_recorded = true;
-    GHIP(ctx, hipEventRecord(out->ev_ready[g], st));
-    ctx->side_busy[g] = true;
-    used = 1u << g;
   }
   out->ready_mask = used;
   out->sum_rows = rows_n; out->sum_frames = frames; out->sums_valid = true;
@@ -1755,6 +1805,14 @@ static bool fx_run_capable(const groove_fx* fx, uint32_t frames) {
     default: return false;
   }
 }
+static bool fx_is_iir(uint32_t kind) {
+  switch (kind) {
+    case GROOVE_FX_BIQUAD_LP12: case GROOVE_FX_BIQUAD_HP12: case GROOVE_FX_BIQUAD_BP12: case GROOVE_FX_BIQUAD_BS12:
+    case GROOVE_FX_BIQUAD_AP12: case GROOVE_FX_BIQUAD_PEAK12: case GROOVE_FX_BIQUAD_LSHELF12: case GROOVE_FX_BIQUAD_HSHELF12:
+    case GROOVE_FX_BIQUAD_LP24: return true;
+    default: return false;
+  }
+}
 static void fx_advance(groove_fx* fx, uint32_t frames) { // the delay lines' write positions after a block
   if (fx->kind == GROOVE_FX_DELAY || fx->kind == GROOVE_FX_CHORUS) fx->w = (uint32_t)(((uint64_t)fx->w + frames) % fx->N);
   if (fx->kind == GROOVE_FX_REVERB)
@@ -1907,7 +1965,7 @@ int groove_fx_chain_process(groove_fx* const* chain, uint32_t n_fx, groove_block
   groove_ctx* ctx = io->ctx;
   if (frames == 0 || n_fx == 0) return 0;
   GHIP(ctx, hipSetDevice(ctx->device));
-  if (block_acquire(io)) return 1;
+  if (block_acquire(io) || block_normalise(io)) return 1; // effects carry per-lane parameters in the caller's order
   uint32_t last_stage = n_fx; // the last stage that launches anything (the Mixer is the identity)
   for (uint32_t i = 0; i < n_fx; ++i) if (chain[i]->kind != GROOVE_FX_MIXER) last_stage = i;
   groove_fx* run[kRunMaxStages];
@@ -1950,13 +2008,18 @@ int groove_fx_chain_process_async(groove_fx* const* chain, uint32_t n_fx, groove
   for (int j = 0; j < kSideStreams; ++j)
     if (io->ready_mask & (1u << j)) k = (k == -1) ? j : -2;
   if (k < 0) return 0; // no pending render, or one spread over several kind streams
+  if (io->order) return 0; // the block is in the library's lane order: the ctx stream produces the caller's first
   GHIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = side_stream_of(ctx, k);
   uint32_t done = 0;
   for (uint32_t i = 0; i < n_fx; ++i) {
     groove_fx* fx = chain[i];
     if (fx->kind == GROOVE_FX_MIXER) { ++done; continue; }
-    if (fx_run_capable(fx, frames)) break;
+    // Only the IIR filters: they walk the frames serially whatever the block length, so an effect is EITHER always ahead
+    // of the ctx stream's walk OR never.  (A delay line is a serial kernel for blocks longer than the line and a stage of the
+    // fused run otherwise: taken here for some blocks and left to the ctx stream for others, its blocks would be
+    // submitted out of order — found by the ragged-block test.)
+    if (!fx_is_iir(fx->kind)) break;
     if (fx->last_side != k) { // the stream that used the effect last: the ctx stream (or another side stream)
       if (!fx->ev_done) GHIP(ctx, hipEventCreateWithFlags(&fx->ev_done, kSyncEventFlags));
       if (fx->last_side < 0) GHIP(ctx, hipEventRecord(fx->ev_done, ctx->stream));
@@ -1973,6 +2036,26 @@ int groove_fx_chain_process_async(groove_fx* const* chain, uint32_t n_fx, groove
     ctx->side_busy[k] = true;
   }
   *n_done = done;
+  return 0;
+}
+// groove_bank_render_async + groove_fx_chain_process_async in one call, which lets the library FUSE the chain's first
+// stage into the render kernel when it can (a 12 dB BiQuad behind a bank that renders time-parallel: welsh_tp.h HEAD_BQ).
+int groove_bank_render_chain_async(groove_bank* b, uint32_t frames, groove_block* out, groove_fx* const* chain, uint32_t n_fx, uint32_t* n_done) {
+  if (!n_done) return fail(nullptr, "groove_bank_render_chain_async: n_done is NULL");
+  *n_done = 0;
+  if (!b || !out) return fail(nullptr, "groove_bank_render_chain_async: NULL argument");
+  if (fx_chain_check(chain, n_fx, out, frames, "groove_bank_render_chain_async")) return 1;
+  uint32_t first = 0; // the first stage that does anything (the Mixer is the identity)
+  while (first < n_fx && chain[first]->kind == GROOVE_FX_MIXER) ++first;
+  groove_fx* head = first < n_fx ? chain[first] : nullptr;
+  bool fused = false;
+  if (render_async_impl(b, frames, out, head, &fused)) return 1;
+  if (frames == 0) return 0;
+  uint32_t taken = 0;
+  if (fused) taken = first + 1;
+  uint32_t more = 0;
+  if (taken < n_fx && groove_fx_chain_process_async(chain + taken, n_fx - taken, out, frames, &more)) return 1;
+  *n_done = taken + more;
   return 0;
 }
 int groove_fx_process(groove_fx* fx, groove_block* io, uint32_t frames) {
@@ -2051,6 +2134,9 @@ int groove_block_accumulate(groove_block* dst, groove_block* src, uint32_t frame
   if (block_acquire(dst) || block_acquire(src)) return 1;
   dst->sums_valid = false;
   if (src->n == dst->n) {
+    if (block_normalise(src)) return 1;                 // element-wise: both in the caller's lane order
+    if (accumulate ? block_normalise(dst) : 0) return 1;
+    if (!accumulate) dst->order.reset();
     const size_t total = (size_t)2 * frames * src->n;
     const uint32_t g = (uint32_t)std::min<size_t>(blocks_for(total), 256 * 16);
     hipLaunchKernelGGL(block_add_kernel, dim3(g), dim3(kThreads), 0, ctx->stream, dst->d, (size_t)dst->cap * dst->n,
@@ -2058,13 +2144,14 @@ int groove_block_accumulate(groove_block* dst, groove_block* src, uint32_t frame
     GHIP(ctx, hipGetLastError());
     return 0;
   }
-  if (dst->n == 1) return mix_one(ctx, src, frames, dst->d, accumulate, (size_t)dst->cap);
+  if (dst->n == 1) { dst->order.reset(); return mix_one(ctx, src, frames, dst->d, accumulate, (size_t)dst->cap); } // a lane sum has no order
   return fail(ctx, "groove_block_accumulate: lane counts differ and the destination is not a 1-lane block");
 }
 int groove_block_zero(groove_block* b) {
   if (!b) return fail(nullptr, "groove_block_zero: NULL argument");
   if (block_acquire(b)) return 1;
   b->sums_valid = false;
+  b->order.reset();
   GHIP(b->ctx, hipMemsetAsync(b->d, 0, (size_t)2 * b->cap * b->n * 4, b->ctx->stream));
   return 0;
 }
@@ -2090,12 +2177,14 @@ int groove_bus_zero(groove_ctx* ctx, float* bus_dev, size_t frames) {
 }
 int groove_download(groove_ctx* ctx, const float* dev, float* host, size_t n_floats) {
   if (!ctx || !dev || !host) return fail(ctx, "groove_download: NULL argument");
+  GHIP(ctx, ctx_wait(ctx, "copy on the ctx stream"));
   GHIP(ctx, hipMemcpyAsync(host, dev, n_floats * 4, hipMemcpyDeviceToHost, ctx->stream));
   GHIP(ctx, ctx_wait(ctx));
   return 0;
 }
 int groove_upload(groove_ctx* ctx, float* dev, const float* host, size_t n_floats) {
   if (!ctx || !dev || !host) return fail(ctx, "groove_upload: NULL argument");
+  GHIP(ctx, ctx_wait(ctx, "copy on the ctx stream"));
   GHIP(ctx, hipMemcpyAsync(dev, host, n_floats * 4, hipMemcpyHostToDevice, ctx->stream));
   GHIP(ctx, ctx_wait(ctx));
   return 0;
@@ -2111,6 +2200,7 @@ int groove_bus_to_i16(groove_ctx* ctx, const float* bus_dev, size_t frames, int1
   }
   hipLaunchKernelGGL(bus_to_i16_kernel, dim3(blocks_for(count)), dim3(kThreads), 0, ctx->stream, bus_dev, count, ctx->d_i16);
   GHIP(ctx, hipGetLastError());
+  GHIP(ctx, ctx_wait(ctx, "copy on the ctx stream"));
   GHIP(ctx, hipMemcpyAsync(host_out, ctx->d_i16, count * 2, hipMemcpyDeviceToHost, ctx->stream));
   GHIP(ctx, ctx_wait(ctx));
   return 0;

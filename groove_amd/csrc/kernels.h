@@ -1160,10 +1160,7 @@ __device__ __forceinline__ void fx_row_sum(float mine, float* __restrict__ rows,
   if (threadIdx.x == 0) rows[((size_t)group * 2 + ch) * frames + f] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 template <int V>
-__global__ __launch_bounds__(kThreads) void fx_run_kernel(FxRunArgs a) {
-  const uint32_t ch = blockIdx.x / a.wg_per_ch, group = blockIdx.x % a.wg_per_ch;
-  const uint32_t lane = (group * kThreads + threadIdx.x) * V, f = blockIdx.y;
-  if (lane >= a.n) { if (a.rows) fx_row_sum(0.0f, a.rows, a.frames, group, ch, f); return; }
+__device__ __forceinline__ float fx_run_element(const FxRunArgs& a, uint32_t ch, uint32_t lane, uint32_t f) {
   const uint32_t t = ch * a.n + lane;
   const size_t ln = 2 * (size_t)a.n;
   VecF<V> x = vload<V>(a.src + ch * a.src_chs + (size_t)f * a.n + lane);
@@ -1223,12 +1220,18 @@ __global__ __launch_bounds__(kThreads) void fx_run_kernel(FxRunArgs a) {
     for (int j = 0; j < V; ++j) x.v[j] = wm.v[j] < 1.0f ? fmaf(y.v[j], wm.v[j], x.v[j] * (1.0f - wm.v[j])) : y.v[j];
   }
   vstore<V>(a.dst + ch * a.dst_chs + (size_t)f * a.n + lane, x);
-  if (a.rows) {
-    float mine = 0.0f;
+  float mine = 0.0f;
 #pragma unroll
-    for (int j = 0; j < V; ++j) mine += x.v[j];
-    fx_row_sum(mine, a.rows, a.frames, group, ch, f);
-  }
+  for (int j = 0; j < V; ++j) mine += x.v[j];
+  return mine;
+}
+template <int V>
+__global__ __launch_bounds__(kThreads) void fx_run_kernel(FxRunArgs a) {
+  const uint32_t ch = blockIdx.x / a.wg_per_ch, group = blockIdx.x % a.wg_per_ch;
+  const uint32_t lane = (group * kThreads + threadIdx.x) * V, f = blockIdx.y;
+  // (every thread of the workgroup reaches the ONE fx_row_sum call below: it holds a barrier)
+  const float mine = lane < a.n ? fx_run_element<V>(a, ch, lane, f) : 0.0f;
+  if (a.rows) fx_row_sum(mine, a.rows, a.frames, group, ch, f);
 }
 // Reverb, stage 2: the two short Schroeder all-passes (5 ms, 1.7 ms: shorter than a block, so
 // sequential per lane), chunked like the other delay-line kernels.
@@ -1349,10 +1352,7 @@ struct AllpassDirectArgs {
   uint32_t wg_per_ch;
 };
 template <int V>
-__global__ __launch_bounds__(kThreads) void fx_reverb_allpass_direct_kernel(AllpassDirectArgs a) {
-  const uint32_t ch = blockIdx.x / a.wg_per_ch, group = blockIdx.x % a.wg_per_ch;
-  const uint32_t lane = (group * kThreads + threadIdx.x) * V, f = blockIdx.y;
-  if (lane >= a.n) { if (a.rows && f < a.frames) fx_row_sum(0.0f, a.rows, a.frames, group, ch, f); return; }
+__device__ __forceinline__ float allpass_direct_element(const AllpassDirectArgs& a, uint32_t ch, uint32_t lane, uint32_t f) {
   const uint32_t t = ch * a.n + lane;
   const size_t ln = 2 * (size_t)a.n;
   if (f >= a.frames) { // ring rows this block leaves as they are
@@ -1362,7 +1362,7 @@ __global__ __launch_bounds__(kThreads) void fx_reverb_allpass_direct_kernel(Allp
         const uint32_t slot = (a.w[i] + f) % a.N[i];
         vstore<V>(a.ring + (a.new_base[i] + slot) * ln + t, vload<V>(a.ring + (a.old_base[i] + slot) * ln + t));
       }
-    return;
+    return 0.0f;
   }
   const float* __restrict__ x = a.src + ch * a.src_chs + lane;
   const uint32_t slot1 = (a.w[1] + f) % a.N[1];
@@ -1387,12 +1387,17 @@ __global__ __launch_bounds__(kThreads) void fx_reverb_allpass_direct_kernel(Allp
   vstore<V>(a.dst + ch * a.dst_chs + (size_t)f * a.n + lane, out);
   if (f + a.N[0] >= a.frames) vstore<V>(a.ring + (a.new_base[0] + (a.w[0] + f) % a.N[0]) * ln + t, v0);
   if (f + a.N[1] >= a.frames) vstore<V>(a.ring + (a.new_base[1] + slot1) * ln + t, u);
-  if (a.rows) {
-    float mine = 0.0f;
+  float mine = 0.0f;
 #pragma unroll
-    for (int k = 0; k < V; ++k) mine += out.v[k];
-    fx_row_sum(mine, a.rows, a.frames, group, ch, f);
-  }
+  for (int k = 0; k < V; ++k) mine += out.v[k];
+  return mine;
+}
+template <int V>
+__global__ __launch_bounds__(kThreads) void fx_reverb_allpass_direct_kernel(AllpassDirectArgs a) {
+  const uint32_t ch = blockIdx.x / a.wg_per_ch, group = blockIdx.x % a.wg_per_ch;
+  const uint32_t lane = (group * kThreads + threadIdx.x) * V, f = blockIdx.y;
+  const float mine = lane < a.n ? allpass_direct_element<V>(a, ch, lane, f) : 0.0f;
+  if (a.rows && f < a.frames) fx_row_sum(mine, a.rows, a.frames, group, ch, f); // (uniform in the workgroup: it holds a barrier)
 }
 
 #endif // GROOVE_WELSH_CLASS_TU

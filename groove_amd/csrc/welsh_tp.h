@@ -232,8 +232,79 @@ __device__ __forceinline__ void tp_shfl_affine(const Lp24Affine& m, int src, Lp2
 #pragma unroll
   for (int i = 0; i < 2; ++i) { out.c2[i] = tp_shfl(m.c2[i], src); out.c3[i] = tp_shfl(m.c3[i], src); }
 }
+// y-recurrence of the Direct Form 1 biquad as an affine map of (y1, y2): y = w - a1 y1 - a2 y2, w = b0 x + b1 x1 + b2 x2
+struct BqAffine { double m00, m01, m10, m11, z0, z1; }; // (y1, y2)' = M (y1, y2) + z
+__device__ __forceinline__ void bq_affine_identity(BqAffine& m) { m.m00 = 1.0; m.m01 = 0.0; m.m10 = 0.0; m.m11 = 1.0; m.z0 = 0.0; m.z1 = 0.0; }
+__device__ __forceinline__ void bq_affine_push(BqAffine& m, double a1, double a2, double w) {
+  // one more frame: (y1, y2) -> (w - a1 y1 - a2 y2, y1)
+  const double n00 = -a1 * m.m00 - a2 * m.m10, n01 = -a1 * m.m01 - a2 * m.m11, nz0 = (w - a1 * m.z0) - a2 * m.z1;
+  m.m10 = m.m00; m.m11 = m.m01; m.z1 = m.z0;
+  m.m00 = n00; m.m01 = n01; m.z0 = nz0;
+}
+__device__ __forceinline__ void bq_affine_compose(BqAffine& later, const BqAffine& e) { // later <- later o e
+  BqAffine r;
+  r.m00 = later.m00 * e.m00 + later.m01 * e.m10; r.m01 = later.m00 * e.m01 + later.m01 * e.m11;
+  r.m10 = later.m10 * e.m00 + later.m11 * e.m10; r.m11 = later.m10 * e.m01 + later.m11 * e.m11;
+  r.z0 = later.m00 * e.z0 + later.m01 * e.z1 + later.z0;
+  r.z1 = later.m10 * e.z0 + later.m11 * e.z1 + later.z1;
+  later = r;
+}
+
+// One lane-channel's block on one wavefront: lane l holds frames 4l .. 4l+3 (xf; `cnt` of them exist).  o = the outputs of
+// this lane's frames (wet mix applied); returns true in the lane that holds the block's last frame, with ns = the state
+// after the block (x1, x2 = the last two inputs, y1, y2 = the last two outputs).  Pass B performs biquad_step's operations
+// in their order from a start state that agrees with the serial walk's to f64 rounding.
+__device__ __forceinline__ bool bq_tp_wave(const float (&xf)[kTpChunk], uint32_t cnt, uint32_t lane, uint32_t frames, const BiquadCoefD& c,
+                                           double sx1, double sx2, double sy1, double sy2, float wm, float (&o)[kTpChunk], double (&ns)[4]) {
+  // the two inputs before this lane's first frame: the previous lane's last two, or the state
+  double px1 = tp_shfl((double)xf[kTpChunk - 1], (int)lane - 1), px2 = tp_shfl((double)xf[kTpChunk - 2], (int)lane - 1);
+  if (lane == 0) { px1 = sx1; px2 = sx2; }
+  double w[kTpChunk];
+  BqAffine mine;
+  bq_affine_identity(mine);
+  {
+    double x1 = px1, x2 = px2;
+#pragma unroll
+    for (uint32_t j = 0; j < kTpChunk; ++j) {
+      const double x = (double)xf[j];
+      w[j] = c.b0 * x + c.b1 * x1 + c.b2 * x2;
+      if (j < cnt) bq_affine_push(mine, c.a1, c.a2, w[j]);
+      x2 = x1; x1 = x;
+    }
+  }
+  BqAffine incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    BqAffine e;
+    e.m00 = tp_shfl(incl.m00, (int)lane - d); e.m01 = tp_shfl(incl.m01, (int)lane - d);
+    e.m10 = tp_shfl(incl.m10, (int)lane - d); e.m11 = tp_shfl(incl.m11, (int)lane - d);
+    e.z0 = tp_shfl(incl.z0, (int)lane - d); e.z1 = tp_shfl(incl.z1, (int)lane - d);
+    if ((int)lane >= d) bq_affine_compose(incl, e);
+  }
+  const double e1 = incl.m00 * sy1 + incl.m01 * sy2 + incl.z0, e2 = incl.m10 * sy1 + incl.m11 * sy2 + incl.z1; // (y1, y2) after this lane
+  double y1 = tp_shfl(e1, (int)lane - 1), y2 = tp_shfl(e2, (int)lane - 1);
+  if (lane == 0) { y1 = sy1; y2 = sy2; }
+#pragma unroll
+  for (uint32_t j = 0; j < kTpChunk; ++j) {
+    o[j] = 0.0f;
+    if (j < cnt) {
+      const double y = w[j] - c.a1 * y1 - c.a2 * y2;
+      y2 = y1; y1 = y;
+      o[j] = (float)y;
+      if (wm < 1.0f) o[j] = fmaf(o[j], wm, xf[j] * (1.0f - wm));
+    }
+  }
+  const bool holds_end = frames && lane == (frames - 1) / kTpChunk;
+  if (holds_end) { // x1, x2 = the block's last two inputs; y1, y2 = its last two outputs
+    ns[0] = (double)xf[cnt - 1]; ns[1] = cnt >= 2 ? (double)xf[cnt - 2] : px1; ns[2] = y1; ns[3] = y2;
+  }
+  return holds_end;
+}
 struct TpArgs {
   const uint32_t* params; uint32_t* state; float* out; float* rows; size_t ch_stride; RenderConsts rc; uint32_t n, frames;
+  // welsh_tp_kernel<false, true>: a 12 dB BiQuad effect bank (one lane per voice) applied to the voice's block before it is
+  // stored — coefficients [5][n] f64, state [4][2n] f64, wet [n], the layouts of fx_biquad_tp_kernel (fx_tp.h)
+  const double* bq_coef = nullptr; double* bq_st = nullptr; const float* bq_wet = nullptr;
 };
 // A block's note events, small enough to ride in the kernel's argument block (4 KB): strictly increasing voices, so a
 // wavefront finds its voice's event (there is at most one) by bisection with scalar loads and applies it to the state
@@ -243,8 +314,14 @@ constexpr uint32_t kInlineEvents = 440;
 struct InlineEvents { uint32_t n; groove_note_event ev[kInlineEvents]; };
 // rows = partial[workgroup][ch][frame] (the bus reduction's rows), written by both forms; !FUSED also stores the planar
 // block out[ch][frame][voice] (kernels.h run_frames: the rows are then the block's own lane sums for groove_mix).
-template <bool FUSED>
+// HEAD_BQ (block-writing form only): the voice's (L, R) block goes through a BiQuad effect lane before it is stored — the
+// effect chain's leading IIR stage, fused (groove_bank_render_chain_async): the 256 frames are already spread over the
+// wavefront's lanes, so the filter is one more affine scan (bq_tp_wave, what fx_biquad_tp_kernel runs per lane-channel) on
+// values that are in registers; a separate launch read and wrote the whole block again and, as a few hundred latency-bound
+// wavefronts beside the HBM-bound stages of the previous block, took three times its own time (config #3: 29 us of 82).
+template <bool FUSED, bool HEAD_BQ = false>
 __global__ __launch_bounds__(kTpThreads, 2) void welsh_tp_kernel(TpArgs a) {
+  static_assert(!(FUSED && HEAD_BQ), "an effect needs the voice blocks: the fused bus form has none");
   __shared__ float s_noise[kTpWaves][3][kTpMaxFrames];
   __shared__ uint64_t s_sum2[kTpWaves][kTpMaxFrames];
   __shared__ float s_tile[kTpWaves][2][kTpMaxFrames];
@@ -394,6 +471,23 @@ __global__ __launch_bounds__(kTpThreads, 2) void welsh_tp_kernel(TpArgs a) {
     if (lives[j]) y = (float)lp24_step_v(st, coef[j], (double)x[j]);
     const float m = y * amp[j];
     oL[j] = m * p.gl; oR[j] = m * p.gr;
+  }
+  if constexpr (HEAD_BQ) { // this voice's lane of the BiQuad bank, left then right
+    const size_t tn = 2 * (size_t)n;
+    const BiquadCoefD cf{a.bq_coef[v], a.bq_coef[(size_t)n + v], a.bq_coef[(size_t)2 * n + v], a.bq_coef[(size_t)3 * n + v], a.bq_coef[(size_t)4 * n + v]};
+    const float wm = a.bq_wet[v];
+#pragma unroll
+    for (uint32_t ch = 0; ch < 2; ++ch) {
+      const size_t t = (size_t)ch * n + v;
+      float xin[kTpChunk], y[kTpChunk];
+      double ns[4];
+#pragma unroll
+      for (uint32_t j = 0; j < kTpChunk; ++j) xin[j] = j < cnt ? (ch ? oR[j] : oL[j]) : 0.0f;
+      const bool holds_end = bq_tp_wave(xin, cnt, lane, frames, cf, a.bq_st[t], a.bq_st[tn + t], a.bq_st[2 * tn + t], a.bq_st[3 * tn + t], wm, y, ns);
+#pragma unroll
+      for (uint32_t j = 0; j < kTpChunk; ++j) { if (ch) oR[j] = y[j]; else oL[j] = y[j]; }
+      if (voice && holds_end) { a.bq_st[t] = ns[0]; a.bq_st[tn + t] = ns[1]; a.bq_st[2 * tn + t] = ns[2]; a.bq_st[3 * tn + t] = ns[3]; }
+    }
   }
 
   // ---- outputs
@@ -655,7 +749,7 @@ __global__ __launch_bounds__(kSamplerTpThreads) void sampler_tp_kernel(TpArgs a,
     soa_store(a.state, n, v, s);
   }
 }
-void launch_welsh_tp(const TpArgs& a, hipStream_t st, bool fused);
+void launch_welsh_tp(const TpArgs& a, hipStream_t st, bool fused); // a.bq_coef set (block-writing form): the BiQuad head fused
 void launch_fm_tp(const TpArgs& a, hipStream_t st, bool fused);
 void launch_sampler_tp(const TpArgs& a, const float* bank, const InlineEvents& ie, hipStream_t st, bool fused);
 inline uint32_t welsh_tp_workgroups(uint32_t n) { return (n + kTpWaves - 1) / kTpWaves; }

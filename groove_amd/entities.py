@@ -266,6 +266,15 @@ class Instrument:
         frames = block.cap if frames is None else frames
         _lib.check(self.ctx.L.groove_bank_render_async(self.h, frames, block.h), self.ctx.h)
 
+    def generate_batch_values_chain_async(self, block, effects, frames=None):
+        """groove_bank_render_chain_async: the asynchronous render with the chain's leading IIR stages behind it (the first
+        one fused into the render kernel when the library can).  Returns how many stages of `effects` were taken."""
+        frames = block.cap if frames is None else frames
+        arr = (C.c_void_p * len(effects))(*[e.h for e in effects])
+        done = C.c_uint32(0)
+        _lib.check(self.ctx.L.groove_bank_render_chain_async(self.h, frames, block.h, arr, len(effects), C.byref(done)), self.ctx.h)
+        return done.value
+
     def render_mix(self, bus, frames, accumulate=False, at_frame=0):
         ptr = bus.at(at_frame) if at_frame else bus.ptr
         _lib.check(self.ctx.L.groove_bank_render_mix(self.h, frames, ptr, 1 if accumulate else 0), self.ctx.h)

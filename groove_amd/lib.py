@@ -69,6 +69,7 @@ SYMBOLS = {
     "groove_fx_process": (_i, [_vp, _vp, _u32]),
     "groove_fx_chain_process": (_i, [_vp, _u32, _vp, _u32]),
     "groove_fx_chain_process_async": (_i, [_vp, _u32, _vp, _u32, C.POINTER(_u32)]),
+    "groove_bank_render_chain_async": (_i, [_vp, _u32, _vp, _vp, _u32, C.POINTER(_u32)]),
     "groove_fx_set_param": (_i, [_vp, _u32, _u32, _d]),
     "groove_fx_set_params": (_i, [_vp, C.POINTER(T.FxParams), _u32]),
     "groove_mix": (_i, [_vp, _vpp, _u32, _u32, _vp, _i]),

@@ -175,15 +175,13 @@ class Project:
             for inst, block, fx, _ in self.banks:
                 if inst not in self.ahead:
                     self.ahead[inst] = [block, ctx.block(inst.n, FRAMES), ctx.block(inst.n, FRAMES)]
-                inst.generate_batch_values_async(self.ahead[inst][0], FRAMES)
-                self._head(fx, self.ahead[inst][0])
+                self._render_ahead(inst, fx, self.ahead[inst][0])
             self.primed = True
         self._events(self.block_index + 1)
         self.block_index += 1
         for inst, _, fx, _ in self.banks:
             # the block this render fills was released a whole step ago: no cross-queue wait (groove_block_release)
-            inst.generate_batch_values_async(self.ahead[inst][1], FRAMES)
-            self._head(fx, self.ahead[inst][1])
+            self._render_ahead(inst, fx, self.ahead[inst][1])
         first = True
         for inst, _, fx, _ in self.banks:
             cur = self.ahead[inst][0]
@@ -195,7 +193,13 @@ class Project:
         if ev_pair is not None and ev_pair[1] is not None:
             ctx.record(ev_pair[1])
 
-    def _head(self, fx, block):
+    def _render_ahead(self, inst, fx, block):
+        """The instrument's next block on the side streams; with head_ahead, the chain's leading IIR stages ride behind it
+        (head_ahead == "unfused": as a launch of their own; otherwise fused into the render kernel where the library can)."""
+        if fx and self.head_ahead and self.head_ahead != "unfused":
+            self.head_done[id(block)] = inst.generate_batch_values_chain_async(block, fx, FRAMES)
+            return
+        inst.generate_batch_values_async(block, FRAMES)
         if fx and self.head_ahead:
             self.head_done[id(block)] = self.ctx.transform_chain_async(fx, block, FRAMES)
 

@@ -189,13 +189,21 @@ int groove_fx_process(groove_fx* fx, groove_block* inout, uint32_t frames);
 int groove_fx_chain_process(groove_fx* const* chain, uint32_t n_fx, groove_block* inout, uint32_t frames);
 /* The chain's LEADING stages that have feedback inside a block (the IIR filters; delay lines shorter than the block),
  * submitted to the side stream that carries `inout`'s pending groove_bank_render_async, right behind that render:
- * *n_done stages are taken (0 when the block has no pending render on one side stream, or when the chain starts with a
- * stage of the other sort); the caller hands chain + *n_done to groove_fx_chain_process when it reaches the block.  Same
+ * *n_done stages are taken — IIR filters only (0 when the block has no pending render on one side stream, or when the chain
+ * starts with another kind of stage); an effect that is processed ahead like this must be processed ahead in EVERY block
+ * (its blocks would otherwise be submitted out of order); the caller hands chain + *n_done to groove_fx_chain_process when it reaches the block.  Same
  * bits as processing the whole chain there.  Purpose: in the render-ahead walk (groove_bank_render_async above) these
  * narrow, latency-bound kernels then run beside the wide stages of the PREVIOUS block instead of in front of them on
  * the ctx stream.  Parameter changes of those effects must be made before this call for the block it processes
  * (the effect is one block ahead of the ctx stream's walk).  No reference counterpart. */
 int groove_fx_chain_process_async(groove_fx* const* chain, uint32_t n_fx, groove_block* inout, uint32_t frames, uint32_t* n_done);
+/* groove_bank_render_async(bank, frames, out) followed by groove_fx_chain_process_async(chain, n_fx, out, frames, n_done) as ONE
+ * call — which lets the library fuse the chain's first stage into the render kernel itself when it can: a 12 dB BiQuad
+ * behind a bank that renders time-parallel (the frames of a voice's block are then already spread over a wavefront's lanes,
+ * and the filter is one more scan on values that sit in registers: no separate launch, and the block is not read and
+ * written a second time).  Same results as the two calls to f64 rounding of the filter's start states.  *n_done as above. */
+int groove_bank_render_chain_async(groove_bank* bank, uint32_t frames, groove_block* out, groove_fx* const* chain, uint32_t n_fx,
+                                   uint32_t* n_done);
 /* Controllable for effects; lane = GROOVE_ALL_VOICES for all lanes. */
 int groove_fx_set_param(groove_fx* fx, uint32_t lane, uint32_t control_index, double value01);
 /* Replace all per-lane parameters (non-UNIFORM fields only may change). */

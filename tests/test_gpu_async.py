@@ -24,7 +24,7 @@ def _twin(make):
 
 
 def _render_ahead(gpu_ctx, sync_inst, async_inst, n, blocks, events, fx_sync=(), fx_async=(), frames_of=lambda b: FRAMES, rotation=2,
-                  head_async=None):
+                  head_async=None, fused_head=False):
     """Walk `blocks` blocks twice: instrument A the plain way (render, effects, mix into bus A);
     instrument B software-pipelined (render of block b+1 submitted before the effects of block b,
     two blocks alternating).  events(b) -> note events applied before block b.  Returns both buses
@@ -52,9 +52,13 @@ def _render_ahead(gpu_ctx, sync_inst, async_inst, n, blocks, events, fx_sync=(),
     ev = events(0)
     if ev is not None:
         async_inst.handle_midi_events(ev)
-    async_inst.generate_batch_values_async(blk_a[0], frames_of(0))
     head = {}  # block index in the rotation -> stages of the chain already processed behind the render
-    if head_async is not None:
+    if fused_head:    # groove_bank_render_chain_async: the render with the chain's IIR head fused into / queued behind it
+        head[0] = async_inst.generate_batch_values_chain_async(blk_a[0], list(fx_async), frames_of(0))
+        head_async.append(head[0])
+    else:
+        async_inst.generate_batch_values_async(blk_a[0], frames_of(0))
+    if head_async is not None and not fused_head:
         head[0] = gpu_ctx.transform_chain_async(list(fx_async), blk_a[0], frames_of(0))
         head_async.append(head[0])
     for b in range(blocks):
@@ -64,8 +68,12 @@ def _render_ahead(gpu_ctx, sync_inst, async_inst, n, blocks, events, fx_sync=(),
             ev = events(b + 1)
             if ev is not None:
                 async_inst.handle_midi_events(ev)
-            async_inst.generate_batch_values_async(nxt, frames_of(b + 1))
-            if head_async is not None:  # groove_fx_chain_process_async: the chain's IIR head right behind the render, on its stream
+            if fused_head:
+                head[(b + 1) % rotation] = async_inst.generate_batch_values_chain_async(nxt, list(fx_async), frames_of(b + 1))
+                head_async.append(head[(b + 1) % rotation])
+            else:
+                async_inst.generate_batch_values_async(nxt, frames_of(b + 1))
+            if head_async is not None and not fused_head:  # groove_fx_chain_process_async: the chain's IIR head right behind the render, on its stream
                 head[(b + 1) % rotation] = gpu_ctx.transform_chain_async(list(fx_async), nxt, frames_of(b + 1))
                 head_async.append(head[(b + 1) % rotation])
         if head_async is not None:
@@ -82,8 +90,15 @@ def _render_ahead(gpu_ctx, sync_inst, async_inst, n, blocks, events, fx_sync=(),
     gpu_ctx.synchronize()
     got_s, got_a = bus_s.download(), bus_a.download()
     for b, o in outs_a:
-        assert np.array_equal(o, outs_s[b]), f"block {b}: render-ahead block differs from the plain walk"
-    assert np.array_equal(got_s, got_a), "bus of the render-ahead walk differs from the plain walk"
+        if fused_head:  # the fused filter's start states agree with the separate kernel's to f64 rounding, not bit for bit
+            err = float(np.max(np.abs(o.astype(np.float64) - outs_s[b])))
+            assert err <= 2e-6 * max(1.0, float(np.abs(outs_s[b]).max())), f"block {b}: {err:.3e}"
+        else:
+            assert np.array_equal(o, outs_s[b]), f"block {b}: render-ahead block differs from the plain walk"
+    if fused_head:
+        assert np.max(np.abs(got_s.astype(np.float64) - got_a)) <= 2e-6 * n * max(1.0, float(np.abs(outs_s[0]).max()))
+    else:
+        assert np.array_equal(got_s, got_a), "bus of the render-ahead walk differs from the plain walk"
     assert np.abs(got_s).max() > 1e-3
     for x in (blk_s, *blk_a, bus_s, bus_a):
         x.destroy()
@@ -116,6 +131,32 @@ def test_welsh_chain_render_ahead_is_identical(gpu_ctx):
     fx_a = [E.Effect(gpu_ctx, k, p) for k, p in _short_chain(n)]
     fx_b = [E.Effect(gpu_ctx, k, p) for k, p in _short_chain(n)]
     _render_ahead(gpu_ctx, a, b, n, blocks, lambda k: on if k == 0 else (off if k == 8 else None), fx_a, fx_b)
+    for x in (a, b, *fx_a, *fx_b):
+        x.destroy()
+
+
+@pytest.mark.parametrize("n", [1024, 5])
+def test_chain_head_fused_into_the_render(gpu_ctx, kernel_form, n):
+    """groove_bank_render_chain_async: behind a bank that renders time-parallel the chain's leading BiQuad is applied INSIDE
+    the render kernel (welsh_tp.h HEAD_BQ); behind the serial kernels it rides as its own launch.  Either way one stage is
+    taken, and blocks and bus agree with effect-by-effect processing on the ctx stream (to f64 rounding of the filter's
+    start states when fused) — through a note-off, ragged blocks and a reset."""
+    from groove_amd import entities as E
+    blocks = 14
+    params, idx = P.welsh_voices_grouped(n, 0)
+    on, off = P.grouped_note_events(idx, True), P.grouped_note_events(idx, False)
+    a, b = _twin(lambda: E.WelshSynth(gpu_ctx, params))
+    fx_a = [E.Effect(gpu_ctx, k, p) for k, p in _short_chain(n)]
+    fx_b = [E.Effect(gpu_ctx, k, p) for k, p in _short_chain(n)]
+    sizes = [256, 256, 100, 256, 7, 256, 255, 256, 256, 256, 64, 256, 256, 256]
+    assert ("time-parallel" in b.kernel_form(256, False)) == (kernel_form == "time-parallel")
+    for rep in range(2):
+        taken = []
+        _render_ahead(gpu_ctx, a, b, n, blocks, lambda k: on if k == 0 else (off if k == 8 else None), fx_a, fx_b,
+                      frames_of=lambda k: sizes[k], rotation=3, head_async=taken, fused_head=True)
+        assert taken and all(t == 1 for t in taken), taken
+        for x in (a, b, *fx_a, *fx_b):
+            x.reset()
     for x in (a, b, *fx_a, *fx_b):
         x.destroy()
 

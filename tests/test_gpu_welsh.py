@@ -396,3 +396,70 @@ def test_mix_uses_the_blocks_row_sums_only_while_they_are_valid(gpu_ctx, oracle)
     assert not mixed().any()                                                          # zero
     for x in (g, synth, block, other, bus):
         x.destroy()
+
+
+def test_regrouped_bank_blocks_keep_the_library_order_until_someone_looks(gpu_ctx, oracle):
+    """Lazy lane order (groove_hip.hip, groove_block): a render of a regrouped bank leaves the block in the library's
+    lane order; the mix needs no other (same bus as after a download, which produces the caller's order), an effect
+    with per-lane parameters, an element-wise accumulate and the raw pointer all see the caller's order, and rendering
+    again after any of these is consistent."""
+    import ctypes as C
+    from groove_amd import entities as E, lib
+    n, frames = 8192, 256
+    params = P.welsh_voices(n)          # voice i: patch i mod 32 -> regrouped patch-major inside the library
+    keys = P.voice_keys(n)
+    def fresh():
+        s_ = E.WelshSynth(gpu_ctx, params)
+        s_.handle_midi_events(T.note_events_np(np.arange(0, n, 2, dtype=np.uint32), keys[::2], True))  # even voices only
+        return s_
+    a, b = fresh(), fresh()
+    blk_a, blk_b = gpu_ctx.block(n, frames), gpu_ctx.block(n, frames)
+    bus_a, bus_b = gpu_ctx.bus(frames), gpu_ctx.bus(frames)
+    gains = np.linspace(0.25, 1.0, n).astype(np.float32)           # a per-lane parameter: lane order matters
+    fp = (T.FxParams * n)()
+    for i in range(n):
+        fp[i] = T.fx_params(ceiling=float(gains[i]))
+    fx = E.Effect(gpu_ctx, T.FX_GAIN, fp)
+    for it in range(3):
+        # A: render, mix straight away (library order, lane sums); B: render, download first (caller's order), then mix
+        a.generate_batch_values(blk_a, frames)
+        gpu_ctx.mix([blk_a], frames, bus_a)
+        b.generate_batch_values(blk_b, frames)
+        host_b = blk_b.download(frames)
+        gpu_ctx.mix([blk_b], frames, bus_b)
+        ga, gb = bus_a.download().astype(np.float64), bus_b.download().astype(np.float64)
+        assert np.abs(ga).max() > 1e-2 and np.array_equal(ga, gb), it
+        assert np.abs(host_b[:, :, 1::2]).max() == 0.0 and np.abs(host_b[:, :, 0::2]).max() > 1e-3   # the caller's lanes
+        want = host_b.astype(np.float64).sum(axis=2).T
+        assert np.max(np.abs(ga - want)) <= 2e-6 * max(1.0, np.abs(host_b).sum(axis=2).max())
+        host_a = blk_a.download(frames)                               # now A is asked too: same block, bit for bit
+        assert np.array_equal(host_a.view(np.uint32), host_b.view(np.uint32))
+        # an effect with per-lane parameters on a freshly rendered (library-order) block
+        a.generate_batch_values(blk_a, frames)
+        b.generate_batch_values(blk_b, frames)
+        ref = blk_b.download(frames)
+        fx.transform_audio(blk_a, frames)
+        got = blk_a.download(frames)
+        assert np.array_equal(got, ref * gains[None, None, :])
+    # the raw pointer of a library-order block is the caller's order
+    a.generate_batch_values(blk_a, frames)
+    b.generate_batch_values(blk_b, frames)
+    ref = blk_b.download(frames)
+    dev = blk_a.device_ptr()
+    row = np.empty(n, dtype=np.float32)
+    lib.check(gpu_ctx.L.groove_download(gpu_ctx.h, C.c_void_p(dev + 17 * n * 4), row.ctypes.data_as(C.POINTER(C.c_float)), n), gpu_ctx.h)
+    assert np.array_equal(row, ref[0, 17, :])
+    # element-wise accumulate of two library-order blocks, and the lane sum into a one-lane block
+    a.generate_batch_values(blk_a, frames)
+    b.generate_batch_values(blk_b, frames)
+    one = gpu_ctx.block(1, frames)
+    gpu_ctx.L.groove_block_accumulate(one.h, blk_a.h, frames, 0)
+    s1 = one.download(frames)[:, :, 0].astype(np.float64)
+    hb = blk_b.download(frames).astype(np.float64)                    # (same voices, same state history)
+    gpu_ctx.L.groove_block_accumulate(blk_b.h, blk_a.h, frames, 1)
+    both = blk_b.download(frames).astype(np.float64)
+    ha = blk_a.download(frames).astype(np.float64)
+    assert np.max(np.abs(both - (ha + hb))) <= 1e-6
+    assert np.max(np.abs(s1 - ha.sum(axis=2))) <= 2e-6 * max(1.0, np.abs(ha).sum(axis=2).max())
+    for x in (a, b, fx, blk_a, blk_b, bus_a, bus_b, one):
+        x.destroy()
