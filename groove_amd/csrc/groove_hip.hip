@@ -184,6 +184,7 @@ struct groove_ctx {
   uint32_t fm_tp_max_voices = kFmTpMaxVoices; // GROOVE_FM_TP_MAX_VOICES
   uint32_t fx_seg_max_lanes = 49152;     // biquad banks of up to this many lane-channels take the four-segment kernel (measured, tools/fx_bench.py: 8,192 lane-channels 17.5 -> 9.3 us, 32,768 19.4 -> 15.6, 131,072 42.9 -> 58.4; GROOVE_FX_SEG_MAX_LANES, 0 = never)
   uint32_t fx_tp_wide_min_lanes = 8192;  // from this many lane-channels the time-parallel IIR kernels take 32-wide tiles (GROOVE_FX_TP_WIDE_MIN_LANES)
+  bool fx_lds_staging = false;          // GROOVE_FX_LDS_STAGING=1 (A/B): the fused run kernel stages the chorus taps through LDS
   bool seq_allpass = false;             // GROOVE_FX_SEQ_ALLPASS=1: the sequential all-pass kernel (A/B and bit-identity tests)
   bool chunked_allpass = false;         // GROOVE_FX_CHUNKED_ALLPASS=1: the chunk-parallel all-pass kernel instead of the direct one
   uint32_t sr = GROOVE_DEFAULT_SAMPLE_RATE;
@@ -960,6 +961,7 @@ static int init_impl(int device_ordinal, const uint8_t* comm_id, int rank, int w
   if (!ctx) return fail(nullptr, "groove_init: out of memory");
   ctx->device = device_ordinal;
   if (const char* e = std::getenv("GROOVE_FX_SEQ_ALLPASS")) ctx->seq_allpass = e[0] == '1';
+  if (const char* e = std::getenv("GROOVE_FX_LDS_STAGING")) ctx->fx_lds_staging = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_SAFE_STREAMS")) ctx->safe_streams = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_SYNC_TIMEOUT_MS")) ctx->sync_timeout_ms = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_KIND_STREAMS")) ctx->kind_streams = std::atoi(e) == 4 ? 4 : 3;
@@ -1321,7 +1323,7 @@ static void launch_tp(groove_bank* b, uint32_t frames, bool fused, size_t chs, f
 }
 // rows of partial[][2][frames] a bank's fused render writes
 static uint32_t fused_rows(const groove_bank* b, uint32_t frames) {
-  if (use_tp(b, frames)) return b->kind == BANK_SAMPLER ? sampler_tp_workgroups(b->n) : welsh_tp_workgroups(b->n);
+  if (use_tp(b, frames)) return b->kind == BANK_SAMPLER ? sampler_tp_workgroups(b->n) : b->kind == BANK_WELSH ? welsh_tp_grid(b->n) : welsh_tp_workgroups(b->n);
   return (b->kind == BANK_WELSH && b->n_vwaves) ? (b->n_vwaves + kWaves - 1) / kWaves : blocks_for(b->n);
 }
 // One base kind's uniform Welsh kernel (kernels.h, "Workgroup KINDS") on stream `st`.
@@ -1854,6 +1856,7 @@ static int fx_launch_run(groove_ctx* ctx, groove_fx* const* run, uint32_t count,
   float* rows = last ? block_sums(io, wg_per_ch, frames) : nullptr;
   if (last && !rows) return 1;
   a.frames = frames; a.wg_per_ch = wg_per_ch;
+  a.lds_taps = (ctx->fx_lds_staging && V == 4 && n % (kThreads * 4) == 0) ? 1u : 0u;
   a.rows = (rv && direct) ? nullptr : rows;
   if (rv && !direct) rows = nullptr; // the sequential / chunked all-pass kernels run last and leave none
   if (V == 4) hipLaunchKernelGGL(fx_run_kernel<4>, dim3(2 * wg_per_ch, frames), blk, 0, st, a);

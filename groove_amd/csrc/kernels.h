@@ -179,6 +179,15 @@ using FusedAcc = FusedAccDpp;
 using FusedAcc = FusedAccLds;
 #endif
 
+// The planar block's stores.  GROOVE_NT_STORES (A/B): marked non-temporal — 2 GB per million-voice block that nothing reads
+// back before it has long left every cache.
+__device__ __forceinline__ void block_store(float* __restrict__ p, float x) {
+#ifdef GROOVE_NT_STORES
+  __builtin_nontemporal_store(x, p);
+#else
+  *p = x;
+#endif
+}
 // Shared frame loop of the instrument kernels: `frame(f, L, R)` computes one frame of this
 // lane's voice; the epilogue either stores the planar block or feeds the fused bus sum.
 // FUSED: only the rows of the fused bus sum (partial[workgroup][ch][frame]) are produced.  Otherwise the planar block is
@@ -197,8 +206,8 @@ __device__ __forceinline__ void run_frames(uint32_t frames, uint32_t n, uint32_t
     if (!FUSED && active) { // uniform row base + 32-bit lane offset
       float* __restrict__ rowL = out + (size_t)f * n;
       float* __restrict__ rowR = out + ch_stride + (size_t)f * n;
-      rowL[v] = L;
-      rowR[v] = R;
+      block_store(rowL + v, L);
+      block_store(rowR + v, R);
     }
   }
   if (frames & (C - 1)) acc.flush(rows, frames, frames & ~(C - 1), frames & (C - 1));
@@ -237,8 +246,8 @@ __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n
     else acc.add(L, R, f);
     if ((f & (C - 1)) == C - 1) acc.flush(rows, frames, f - (C - 1), C);
     if (!FUSED && active) {
-      out[(size_t)f * n + v] = L;
-      out[ch_stride + (size_t)f * n + v] = R;
+      block_store(out + (size_t)f * n + v, L);
+      block_store(out + ch_stride + (size_t)f * n + v, R);
     }
   };
   {
@@ -1145,6 +1154,7 @@ struct FxRunArgs {
   uint32_t n_stages, n;
   float* rows;          // not null: the launch also leaves the block's lane sums, rows[wg_per_ch][2][frames] (fx_row_sum)
   uint32_t frames, wg_per_ch;
+  uint32_t lds_taps;    // A/B (GROOVE_FX_LDS_STAGING=1; host: only when every thread of every workgroup is live): the chorus taps staged through LDS
 };
 // Grid of the (frame, lane-channel) effect kernels: blockIdx.y = frame, blockIdx.x = (channel, group of 256 * V lanes) —
 // a workgroup never straddles the two channels, so its sum is one entry of the block's lane sums.
@@ -1196,6 +1206,24 @@ __device__ __forceinline__ float fx_run_element(const FxRunArgs& a, uint32_t ch,
 #pragma unroll
       for (int j = 0; j < V; ++j) y.v[j] = 0.0f;
       uint32_t tp = p;
+      if (V == 4 && a.lds_taps && st.voices <= 4) {
+        // A/B only ("LDS staging"): the taps' ring segments of the workgroup's 1,024 lane-channels are loaded
+        // cooperatively — every thread fetches the 16 bytes its NEIGHBOUR WAVE's thread will consume — parked in LDS, and
+        // read back after a barrier: the staging north_star describes, for data that is read exactly once.
+        __shared__ float4 s_taps[4][kThreads];
+        const uint32_t other = (threadIdx.x + 64u) & (kThreads - 1u);
+        const uint32_t t_other = t - threadIdx.x * 4u + other * 4u;
+        for (uint32_t k = 0; k < st.voices; ++k) {
+          s_taps[k][other] = *reinterpret_cast<const float4*>(st.ring + (size_t)tp * ln + t_other);
+          tp += st.spacing; if (tp >= st.N) tp -= st.N;
+        }
+        __syncthreads();
+        for (uint32_t k = 0; k < st.voices; ++k) {
+          const float4 d = s_taps[k][threadIdx.x];
+          y.v[0] += d.x; y.v[1] += d.y; y.v[2] += d.z; y.v[3] += d.w;
+        }
+        __syncthreads();
+      } else
       for (uint32_t k = 0; k < st.voices; ++k) {
         const VecF<V> d = vload<V>(st.ring + (size_t)tp * ln + t);
 #pragma unroll

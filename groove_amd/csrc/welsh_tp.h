@@ -210,6 +210,11 @@ GROOVE_HD uint64_t fm_tp_carrier_inc(const FmParams& p, uint64_t c_inc, uint64_t
 // ------------------------------------------------------------------ the kernel
 constexpr int kTpWaves = 4;                 // voices per workgroup
 constexpr int kTpThreads = kTpWaves * 64;
+// Voice group of workgroup `i` of a grid of `grid` workgroups (welsh_tp_kernel, "XCD-aware voice mapping"); the host pads
+// the grid of a bank of 16 or more groups to a multiple of 8 (welsh_tp_grid), smaller grids keep the plain order.
+__host__ __device__ inline uint32_t tp_group_of_block(uint32_t i, uint32_t grid) {
+  return ((grid & 7u) == 0 && grid >= 16u) ? (i & 7u) * (grid >> 3) + (i >> 3) : i;
+}
 // sampler voices are a gather and nothing else: sixteen to a workgroup, so that the bus reduction behind the render has
 // a quarter of the partial rows to read (sampler-16384: 4,096 rows of 2 KB -> 1,024)
 constexpr int kSamplerTpWaves = 16;
@@ -326,7 +331,13 @@ __global__ __launch_bounds__(kTpThreads, 2) void welsh_tp_kernel(TpArgs a) {
   __shared__ uint64_t s_sum2[kTpWaves][kTpMaxFrames];
   __shared__ float s_tile[kTpWaves][2][kTpMaxFrames];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint32_t v0 = blockIdx.x * kTpWaves + wave;
+  // XCD-aware voice mapping.  Workgroups go to the 8 XCDs round-robin (workgroup i -> XCD i mod 8), each XCD with its own L2.
+  // A workgroup stores 4 adjacent voices x 256 frames of the planar block [frame][voice]: 16 bytes per row.  With the plain
+  // mapping the 8 workgroups that share a 128-byte line of a row sit on 8 DIFFERENT XCDs — eight L2s each hold an eighth
+  // of every line and write it back masked; with group = (i mod 8) * (grid / 8) + i / 8 an XCD owns a contiguous range
+  // of voices, the workgroups that share a line follow each other on ONE XCD, and its L2 writes whole lines.
+  const uint32_t grp = tp_group_of_block(blockIdx.x, gridDim.x);
+  const uint32_t v0 = grp * kTpWaves + wave;
   const bool voice = v0 < a.n;
   const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(voice ? v0 : a.n - 1));
   const uint32_t frames = a.frames, n = a.n;
@@ -498,20 +509,26 @@ __global__ __launch_bounds__(kTpThreads, 2) void welsh_tp_kernel(TpArgs a) {
       s_tile[wave][1][n0 + j] = (voice && j < cnt) ? oR[j] : 0.0f;
     }
     __syncthreads();
+    // block-writing form: the workgroup's four voices of one (channel, frame) leave as ONE 16-byte store when the row
+    // segment is whole and aligned (instead of four 4-byte stores from four wavefronts)
+    const uint32_t vbase = grp * kTpWaves;
+    const bool vec = !FUSED && kTpWaves == 4 && (n & 3u) == 0 && vbase + kTpWaves <= n && (a.ch_stride & 3u) == 0;
     for (uint32_t t = threadIdx.x; t < 2 * frames; t += kTpThreads) {
       const uint32_t ch = t / frames, f = t % frames;
+      float q[kTpWaves];
       float acc = 0.0f;
 #pragma unroll
-      for (int w = 0; w < kTpWaves; ++w) acc += s_tile[w][ch][f];
+      for (int w = 0; w < kTpWaves; ++w) { q[w] = s_tile[w][ch][f]; acc += q[w]; }
       a.rows[((size_t)blockIdx.x * 2 + ch) * frames + f] = acc;
+      if (vec) *reinterpret_cast<float4*>(a.out + ch * a.ch_stride + (size_t)f * n + vbase) = make_float4(q[0], q[1], q[2], q[3]);
     }
-  }
-  if (!FUSED && voice) {
+    if (!FUSED && !vec && voice) {
 #pragma unroll
-    for (uint32_t j = 0; j < kTpChunk; ++j) {
-      if (j < cnt) {
-        a.out[(size_t)(n0 + j) * n + v] = oL[j];
-        a.out[a.ch_stride + (size_t)(n0 + j) * n + v] = oR[j];
+      for (uint32_t j = 0; j < kTpChunk; ++j) {
+        if (j < cnt) {
+          a.out[(size_t)(n0 + j) * n + v] = oL[j];
+          a.out[a.ch_stride + (size_t)(n0 + j) * n + v] = oR[j];
+        }
       }
     }
   }
@@ -752,7 +769,11 @@ __global__ __launch_bounds__(kSamplerTpThreads) void sampler_tp_kernel(TpArgs a,
 void launch_welsh_tp(const TpArgs& a, hipStream_t st, bool fused); // a.bq_coef set (block-writing form): the BiQuad head fused
 void launch_fm_tp(const TpArgs& a, hipStream_t st, bool fused);
 void launch_sampler_tp(const TpArgs& a, const float* bank, const InlineEvents& ie, hipStream_t st, bool fused);
-inline uint32_t welsh_tp_workgroups(uint32_t n) { return (n + kTpWaves - 1) / kTpWaves; }
+inline uint32_t welsh_tp_workgroups(uint32_t n) { return (n + kTpWaves - 1) / kTpWaves; } // FM: one group of 4 voices per workgroup, plain order
+inline uint32_t welsh_tp_grid(uint32_t n) { // Welsh: padded for the XCD-aware mapping (idle workgroups write zero rows)
+  const uint32_t g = welsh_tp_workgroups(n);
+  return g >= 16 ? (g + 7u) & ~7u : g;
+}
 #endif // __HIPCC__
 
 } // namespace groove

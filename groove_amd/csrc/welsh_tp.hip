@@ -5,7 +5,7 @@
 #include "welsh_tp.h"
 namespace groove {
 void launch_welsh_tp(const TpArgs& a, hipStream_t st, bool fused) {
-  const dim3 grid(welsh_tp_workgroups(a.n)), blk(kTpThreads);
+  const dim3 grid(welsh_tp_grid(a.n)), blk(kTpThreads);
   if (fused) hipLaunchKernelGGL(welsh_tp_kernel<true>, grid, blk, 0, st, a);
   else if (a.bq_coef) hipLaunchKernelGGL((welsh_tp_kernel<false, true>), grid, blk, 0, st, a);
   else hipLaunchKernelGGL(welsh_tp_kernel<false>, grid, blk, 0, st, a);

@@ -259,6 +259,11 @@ def test_rccl_single_rank_bus_reduce(gpu_ctx):
     gpu_ctx.bus_reduce(bus, 512, 0)
     gpu_ctx.synchronize()
     assert np.array_equal(bus.download().reshape(-1), vals)
+    with pytest.raises(lib.GrooveError, match="already has a communicator"):
+        gpu_ctx.comm_init(uid, 0, 1)
+    assert gpu_ctx.L.groove_comm_destroy(gpu_ctx.h) == 0   # (the session's ctx goes on without one)
+    assert gpu_ctx.comm_ranks() == 1
+    bus.destroy()
 
 
 def test_pipelined_blocks_with_events_controls_and_state_reads(oracle, monkeypatch):
