@@ -293,7 +293,7 @@ def committed_profile(workload, window=None):
                 salu += m.get("SQ_INSTS_SALU", 0.0)
     out["valu_per_step"], out["salu_per_step"] = (valu or None), (salu or None)
     out["valu_mix_per_step"] = d.get("valu_mix_per_step")   # measured classes (f64 / conversions / transcendental / ...), if the pass was run
-    out["valu_cycles_per_step"] = (d.get("valu_mix_per_step") or {}).get("cost_weighted_cycles")
+    out["valu_simd_ns_per_step"] = (d.get("valu_mix_per_step") or {}).get("cost_weighted_simd_ns")
     out["clock_ghz"] = (d.get("clock_in_counter_pass") or {}).get("ghz_weighted_long_kernels")
     return out
 
@@ -593,13 +593,17 @@ def roofline_block(workload, n_local, kern_ms, span_mode, fused, window=None):
                      # (GRBM_GUI_ACTIVE / 8 XCDs / dispatch time; MI355X_MICROARCH.md "DVFS give-back"): the spec clock holds
                      "clock_ghz_in_counter_pass": prof.get("clock_ghz"),
                      "source": prof.get("source"), "same_window": prof.get("same_window_as_this_run")}
-        if prof.get("valu_cycles_per_step"):
-            # measured instruction classes: cycles = 2 x plain + 4 x f64 + 4 x conversions + 8 x transcendental (tools/summarize_prof.py)
-            cyc = prof["valu_cycles_per_step"] * scale
-            r["valu"]["cost_weighted_issue_cycles_per_step"] = cyc
-            r["valu"]["cost_weighted_frac"] = cyc / (kern_ms * 1e-3) / (1024 * 2.4e9)
-            r["valu"]["mix_per_step"] = {k: (v * scale if isinstance(v, (int, float)) else v) for k, v in (prof.get("valu_mix_per_step") or {}).items()}
-            valu_frac = max(valu_frac, r["valu"]["cost_weighted_frac"])
+        if prof.get("valu_simd_ns_per_step"):
+            # the measured instruction classes at their measured issue costs (tools/summarize_prof.py, docs/VALU_COSTS.md): the SIMD
+            # time the step's VALU instructions need, against the SIMD time the step had (1,024 SIMDs x its duration)
+            cw = prof["valu_simd_ns_per_step"]
+            have = 1024.0 * kern_ms * 1e6
+            lo, hi = cw["other_all_fast"] * scale / have, cw["other_all_normal"] * scale / have
+            r["valu"]["cost_weighted_frac"] = {"low": lo, "high": hi,
+                                               "note": "SIMD time of the step's VALU instructions at their measured issue costs / SIMD time available; "
+                                                       "low / high: the unclassified instructions (moves, compares, selects, DPP) all fast / all normal"}
+            r["valu"]["mix_shares"] = (prof.get("valu_mix_per_step") or {}).get("shares")
+            valu_frac = max(valu_frac, lo)
     fr = {"hbm": hbm_frac or 0.0, "valu-issue": valu_frac or 0.0}
     top = max(fr, key=fr.get)
     r["bound"] = (top if fr[top] >= 0.25 else "latency (few short dependent launches: neither HBM nor VALU issue is a quarter busy)") if (hbm_frac is not None or valu_frac is not None) \

@@ -390,9 +390,11 @@ GROOVE_HD float med3f(float x, float lo, float hi) {
   return fminf(fmaxf(x, lo), hi);
 #endif
 }
-GROOVE_HD Lp24CoefD lp24_coefd_from_pct(const Lp24Consts& c, float pct, const RenderConsts& rc) {
+// (In two halves, so that the role-split kernel — welsh_split.h — can run them on different wavefronts: the tangent of the
+// cutoff, and the coefficients from it.  lp24_coefd_from_pct is their composition: same operations, same order.)
+GROOVE_HD float lp24_t_from_pct(float pct, const RenderConsts& rc, bool& hi) {
   const float x = med3f(fast_exp2(fmaf(clamp01f(pct), 9.6438561897747244f, rc.log2_x0)), rc.x_lo, rc.x_hi);
-  const bool hi = x > 0.78539816339744831f;
+  hi = x > 0.78539816339744831f;
   const float z = fminf(x, 1.57079632679489662f - x);
   // tan(z) = z P(z^2), the polynomial of tan_reduced by Estrin's scheme (four dependent steps instead of seven)
   const float w = z * z, w2 = w * w;
@@ -400,7 +402,9 @@ GROOVE_HD Lp24CoefD lp24_coefd_from_pct(const Lp24Consts& c, float pct, const Re
   const float e2 = fmaf(2.985451510e-03f, w, rc.tan_k2);
   const float w4 = w2 * w2;
   const float f0 = fmaf(e1, w2, e0), f1 = fmaf(9.449327447e-03f, w2, e2);
-  const float t = fmaf(f1, w4, f0) * z;
+  return fmaf(f1, w4, f0) * z;
+}
+GROOVE_HD Lp24CoefD lp24_coefd_from_t(const Lp24Consts& c, float t, bool hi) {
   const float T2 = t * t;
   const float dta = c.d1 * t, dtb = c.d3 * t;
   Lp24CoefD d;
@@ -421,6 +425,11 @@ GROOVE_HD Lp24CoefD lp24_coefd_from_pct(const Lp24Consts& c, float pct, const Re
     d.b0b = (double)ib; d.a1b = fma(4.0, pb, q2b - 2.0); d.a2b = q2b - 1.0;
   }
   return d;
+}
+GROOVE_HD Lp24CoefD lp24_coefd_from_pct(const Lp24Consts& c, float pct, const RenderConsts& rc) {
+  bool hi;
+  const float t = lp24_t_from_pct(pct, rc, hi);
+  return lp24_coefd_from_t(c, t, hi);
 }
 // SCALAR_COEF: the coefficients are wave-uniform values the caller keeps in SGPRs (device only).
 template <bool SCALAR_COEF = false>
@@ -620,14 +629,17 @@ GROOVE_HD float osc_value_classed(uint32_t w, uint64_t phase, uint64_t duty64, f
     return osc_value(w, phase, duty64, noise_value);
   }
 }
-// HOIST (with SEGMENT): the caller keeps the envelopes' stage counters for the segment — as floats in sc.ta /
-// sc.tf, which this frame reads and bumps (exact below 2^24 frames per stage), the integer counters moving once,
-// after the segment (welsh_segment_end) — and an unused LFO's phase moves there too: two conversions, two integer
-// adds and a 64-bit add less on every frame.
+// The frame in three parts (welsh_frame is their composition; the role-split kernel of welsh_split.h runs them on
+// different wavefronts):
+//   FRONT  everything feed-forward — envelopes, LFO, the two oscillators and their mix (`sum`, the filter's input), the cutoff
+//          percent (`pct`; `retune` = the filter is to be retuned to it) and the output gain `a` (amplitude envelope x LFO);
+//          returns false when the voice is idle on this (checked, non-SEGMENT) frame: it then contributes zeros and the
+//          filter does not run.  `lfo` is handed out for the resonance routing.
+//   COEF   the filter coefficients for `pct` (kept in sc.coef; an unchanged percent leaves them standing);
+//   BACK   the f64 filter recurrence on `sum`, the gain, the pan gains.
 template <bool FIRST, bool RETUNE, int LFO_MODE = LFO_F64, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool SEGMENT = false, bool REST = false,
           bool HOIST = false>
-GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc,
-                           WelshScratch& sc, float& L, float& R) {
+GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScratch& sc, float& sum, float& a, float& pct, bool& retune, float& lfo) {
   static_assert(!HOIST || (SEGMENT && !FIRST), "hoisted counters belong to a segment");
   if (SEGMENT && HOIST) {
     const float ta = sc.ta * s.amp.inv_len, tf = sc.tf * s.fil.inv_len;
@@ -640,7 +652,7 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
   } else {
     env_tick(s.amp, p.amp);
     env_tick(s.fil, p.fil);
-    if (s.amp.state == ENV_IDLE) { L = 0.0f; R = 0.0f; return; }
+    if (s.amp.state == ENV_IDLE) return false;
   }
   const uint32_t w1 = osc_class_wave<C1>((p.flags >> WF_O1_WAVE_SHIFT) & 15u), w2 = osc_class_wave<C2>((p.flags >> WF_O2_WAVE_SHIFT) & 15u);
   // LFO class: an unused LFO has no routing; a classed LFO in a static-filter f32 kind can only be
@@ -670,7 +682,7 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
   const uint64_t half = 0x8000000000000000ull;
   uint64_t inc1 = s.o1_inc, inc2 = s.o2_inc;
   uint64_t d1 = p.o1_duty64, d2 = p.o2_duty64;
-  float lfo = 0.0f;
+  lfo = 0.0f;
   if (r_edge) {
     constexpr bool SMOOTH = LFO_MODE == LFO_F64_SMOOTH;
     double l;
@@ -728,12 +740,12 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
   if (w2 == GROOVE_WAVE_NOISE) nz2 = noise_tick(s.o2);
   const float v1 = osc_value_classed<C1, REST>(w1, s.o1.phase, d1, nz1);
   const float v2 = osc_value_classed<C2, REST>(w2, s.o2.phase, d2, nz2);
-  const float sum = fmaf(v1, p.mix, v2 * (1.0f - p.mix));
+  sum = fmaf(v1, p.mix, v2 * (1.0f - p.mix));
 
   // filter cutoff
+  retune = false;
+  pct = 0.0f;
   if (RETUNE) {
-    bool retune = false;
-    float pct = 0.0f;
     // (an unused LFO cannot drive the cutoff: in a retuned kind the envelope must)
     if (CL == LFO_UNUSED || (p.flags & WF_RETUNE_ENV)) {
       pct = fmaf((1.0f - p.cutoff_start) * p.cutoff_end, s.fil.value, p.cutoff_start);
@@ -742,6 +754,16 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
       pct = p.cutoff_start * fmaf(lfo, p.lfo_depth, 1.0f);
       retune = true;
     }
+  }
+  a = s.amp.value;
+  if (r_amp) a *= fmaf(lfo, p.lfo_depth, 1.0f);
+  return true;
+}
+template <bool RETUNE, int LFO_MODE, int CL>
+GROOVE_HD void welsh_frame_coef(const WelshParams& p, const RenderConsts& rc, WelshScratch& sc, float pct, bool retune, float lfo) {
+  if (RETUNE) {
+    constexpr bool RESO = LFO_MODE == LFO_F64 && RETUNE;
+    const bool r_res = RESO && CL != LFO_UNUSED ? (p.flags & WF_LFO_RESO) != 0 : false;
     if (RESO && r_res) { // the ripple moves every frame: constants and coefficients are recomputed
       const Lp24Consts c = lp24_consts_from_ripple(p.ripple * fmaf(lfo, p.lfo_depth, 1.0f));
       const float fc = retune ? 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f) : p.cutoff_hz;
@@ -755,12 +777,27 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
       sc.prev_pct = pct;
     }
   }
-  const float y = (float)lp24_step<SEGMENT && !RETUNE>(s.filt, sc.coef, (double)sum); // uniform static kinds: coefficients in SGPRs
-  float a = s.amp.value;
-  if (r_amp) a *= fmaf(lfo, p.lfo_depth, 1.0f);
+}
+template <bool SCALAR_COEF>
+GROOVE_HD void welsh_frame_back(const WelshParams& p, Lp24StateD& filt, const Lp24CoefD& coef, float sum, float a, float& L, float& R) {
+  const float y = (float)lp24_step<SCALAR_COEF>(filt, coef, (double)sum); // uniform static kinds: coefficients in SGPRs
   const float m = y * a;
   L = m * p.gl;
   R = m * p.gr;
+}
+// HOIST (with SEGMENT): the caller keeps the envelopes' stage counters for the segment — as floats in sc.ta /
+// sc.tf, which this frame reads and bumps (exact below 2^24 frames per stage), the integer counters moving once,
+// after the segment (welsh_segment_end) — and an unused LFO's phase moves there too: two conversions, two integer
+// adds and a 64-bit add less on every frame.
+template <bool FIRST, bool RETUNE, int LFO_MODE = LFO_F64, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool SEGMENT = false, bool REST = false,
+          bool HOIST = false>
+GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc,
+                           WelshScratch& sc, float& L, float& R) {
+  float sum, a, pct, lfo;
+  bool retune;
+  if (!welsh_frame_front<FIRST, RETUNE, LFO_MODE, C1, C2, CL, SEGMENT, REST, HOIST>(p, s, sc, sum, a, pct, retune, lfo)) { L = 0.0f; R = 0.0f; return; }
+  welsh_frame_coef<RETUNE, LFO_MODE, CL>(p, rc, sc, pct, retune, lfo);
+  welsh_frame_back<SEGMENT && !RETUNE>(p, s.filt, sc.coef, sum, a, L, R);
 }
 // Segments.  Between two envelope stage boundaries nothing about a voice's control flow changes: the
 // boundary checks of both envelopes and the idle test can be made once, and the frames up to the next

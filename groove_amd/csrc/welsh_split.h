@@ -1,0 +1,324 @@
+// welsh_split.h — the ROLE-SPLIT form of the wave-uniform Welsh render (mid-size banks).
+//
+// One voice per lane leaves a bank that does not fill the chip waiting for ONE wavefront's serial walk of the block: a lone
+// wavefront issues one instruction per ~9 cycles WHATEVER the instruction mix or its instruction-level parallelism
+// (docs/VALU_COSTS.md: four independent chains in one wave issue no faster), so a 256-frame block of a retuning patch
+// (~90 instructions per frame) takes ~0.11 ms on a SIMD that could issue four times as much.  More voices per SIMD would use
+// the slack — a 65,536-voice bank has none to offer.  The time-parallel form (welsh_tp.h) has no such floor but costs ~4x
+// the work per voice and loses above ~24,000 voices.
+//
+// What is left is to give ONE voice-wave's frame to SEVERAL wavefronts.  A frame of a Welsh voice is a feed-forward front
+// (envelopes, LFO, oscillators, cutoff percent), the filter coefficients' tangent, and the f64 filter recurrence with the
+// output gains; nothing flows backwards (dsp_core.h: welsh_frame = FRONT / COEF / BACK).  Three wavefronts per 64 voices
+// form a pipeline over the block's frames, kSplitChunk frames per step, through LDS:
+//     A  front:  frames of chunk c     -> {sum, gain} and the cutoff percent
+//     B  mid:    chunk c - 1: tangent of the cutoff (exp2, polynomial); every eighth frame it also turns the bus tile
+//     C  back:   chunk c - 2: coefficients from the tangent, filter step, gains -> bus tile (and the planar block)
+// one workgroup barrier per step.  Every quantity is computed by the statements of the serial kernels in their order, so
+// the results — bus rows, blocks, state — are the serial kernels' BIT FOR BIT (tests/test_gpu_split.py).  The walk of a
+// block is then as long as its longest role (~40 of ~90 instructions per frame) instead of their sum.
+//
+// Scope: the four class-specialised base kinds (f32 / smooth-f64 LFO x static / retuned filter); workgroups of the two
+// exact-f64 kinds (rare) keep the all-kinds kernel.  Workgroup = 4 virtual waves x 3 roles = 768 threads, 72 KB of LDS.
+#pragma once
+#include "kernels.h"
+
+namespace groove {
+
+constexpr int kSplitVw = kWaves;                       // virtual waves per workgroup (the host's workgroup = 4 virtual waves)
+constexpr int kSplitLanes = kSplitVw * 64;             // 256 voices
+constexpr int kSplitThreads = 3 * kSplitLanes;         // roles A, B, C
+constexpr uint32_t kSplitChunk = 4;                    // frames per pipeline step
+constexpr uint32_t kSplitGroup = 8;                    // frames per turn of the bus tile (FusedAccLds::kChunk)
+static_assert(kSplitGroup % kSplitChunk == 0 && kSplitGroup == FusedAccLds::kChunk, "the bus tile is turned every second step");
+
+struct SplitLds {
+  float2 ac[3][kSplitChunk][kSplitLanes];  // A -> C: {sum (NaN: the lane is silent this frame), gain}; three steps deep
+  float ab[2][kSplitChunk][kSplitLanes];   // A -> B: cutoff percent (NaN: no retune this frame)
+  float bc[2][kSplitChunk][kSplitLanes];   // B -> C: tan of the cutoff, negated above SR/4 (NaN: coefficients stand)
+  float2 tile[2][kSplitGroup][kSplitLanes]; // C -> B: (L, R) of eight frames, two groups in rotation
+};
+static_assert(sizeof(SplitLds) <= 72 * 1024, "two workgroups per CU");
+
+// Word ranges of WelshState (dsp_core.h): [0, 30) oscillators, increments, envelopes — role A; [30, 38) the filter — role C;
+// [38, 40) flags — role A.
+constexpr uint32_t kStateFiltWord = offsetof(WelshState, filt) / 4, kStateFlagsWord = offsetof(WelshState, vflags) / 4;
+static_assert(kStateFiltWord == 30 && kStateFlagsWord == 38 && sizeof(WelshState) == 160, "role A / role C state words");
+template <class T>
+__device__ __forceinline__ void soa_store_range(uint32_t* __restrict__ buf, uint32_t n, uint32_t v, const T& x, uint32_t w0, uint32_t w1) {
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(buf, 0, (int)(sizeof(T) / 4 * n * 4u), 0x00020000);
+  const WordsOf<T> t = __builtin_bit_cast(WordsOf<T>, x);
+#pragma unroll
+  for (uint32_t i = 0; i < sizeof(T) / 4; ++i)
+    if (i >= w0 && i < w1) __builtin_amdgcn_raw_buffer_store_b32((int)t.w[i], rsrc, (int)(v * 4u), (int)(i * n * 4u), 0);
+}
+
+// What every role needs of its virtual wave.
+struct SplitWave { WaveDesc d; uint32_t wg, l, v; bool active; };
+__device__ __forceinline__ SplitWave split_wave(UniformArgsPtr a, uint32_t local /* 0 .. 255 within the role */) {
+  SplitWave w;
+  w.wg = a->wg_list[blockIdx.x];
+  w.l = local;
+  const uint32_t lane = local & 63u;
+  const uint32_t w0 = w.wg * kSplitVw + (local >> 6);
+  const uint32_t wi = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(w0, a->n_waves - 1));
+  w.d = make_scalar(a->waves[wi]);
+  w.active = (w0 < a->n_waves) && (lane < w.d.count);
+  w.v = w.active ? w.d.vbase + lane : w.d.vbase; // idle lanes shadow the run's first voice
+  return w;
+}
+__device__ __forceinline__ SplitLds& split_lds() {
+  __shared__ SplitLds lds;
+  return lds;
+}
+__device__ __forceinline__ uint32_t split_steps(uint32_t frames) { return (frames + kSplitChunk - 1) / kSplitChunk + 2; }
+
+// ---- role A: the front of every frame of the block (run_frames_segmented's walk, one chunk per step)
+template <int LFO_MODE, bool RETUNE, int C1, int C2, int CL>
+__device__ __forceinline__ void welsh_split_front_impl(UniformArgsPtr a) {
+  constexpr bool REST = LFO_MODE != LFO_F64;
+  SplitLds& lds = split_lds();
+  const SplitWave w = split_wave(a, threadIdx.x);
+  const uint32_t n = a->n, frames = a->frames;
+  const WelshParams& p = w.d.p;
+  WelshState s = soa_load<WelshState>(a->state, n, w.v);
+  WelshScratch sc;
+  sc.prev_pct = 0.0f; sc.ls = 0.0; sc.lc = 1.0; sc.lm = 1.0; sc.ta = 0.0f; sc.tf = 0.0f; // (coefficients: role C's business)
+  const uint32_t steps = split_steps(frames), nch = steps - 2;
+  uint32_t seg_left = 0, seg_len = 0;
+  bool live = false;
+  const float kNan = __builtin_nanf("");
+  for (uint32_t it = 0; it < steps; ++it) {
+    if (it < nch) {
+      const uint32_t f0 = it * kSplitChunk;
+#pragma unroll
+      for (uint32_t j = 0; j < kSplitChunk; ++j) {
+        const uint32_t f = f0 + j;
+        if (f < frames) {
+          float sum = 0.0f, g = 0.0f, pct = 0.0f, lfo = 0.0f;
+          bool retune = false, ok;
+          if (f == 0) { // the checked form (first tick after a note event, envelope boundaries, the idle test)
+            ok = welsh_frame_front<true, RETUNE, LFO_MODE, C1, C2, CL, false, REST>(p, s, sc, sum, g, pct, retune, lfo) && w.active;
+          } else {
+            if (seg_left == 0) { // a new boundary-free segment (kernels.h run_frames_segmented)
+              const uint32_t mine = welsh_segment_begin(p, s, live);
+              welsh_segment_start_hoisted(s, sc);
+              live = live && w.active;
+              seg_len = seg_left = min(wave_min_u32(mine), frames - f);
+            }
+            ok = live;
+            if (live) welsh_frame_front<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true>(p, s, sc, sum, g, pct, retune, lfo);
+            if (--seg_left == 0) welsh_segment_end_hoisted<CL == LFO_UNUSED>(p, s, seg_len, live);
+          }
+          lds.ac[it % 3][j][w.l] = make_float2(ok ? sum : kNan, g);
+          if (RETUNE) lds.ab[it & 1][j][w.l] = (ok && retune) ? pct : kNan;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (w.active) {
+    soa_store_range(a->state, n, w.v, s, 0, kStateFiltWord);
+    soa_store_range(a->state, n, w.v, s, kStateFlagsWord, (uint32_t)(sizeof(WelshState) / 4));
+  }
+}
+template <int LFO_MODE, bool RETUNE, int C1, int C2, int CL>
+GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split_front(UniformArgsPtr a) {
+  welsh_split_front_impl<LFO_MODE, RETUNE, C1, C2, CL>(uniform_args_scalar(a));
+}
+
+// ---- role B: the tangent of the cutoff, one step behind A; and the bus tile's turn (FusedAccLds::flush, on the
+// group of eight frames role C finished in the previous step)
+template <bool RETUNE>
+GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split_mid(UniformArgsPtr ka) {
+  const UniformArgsPtr a = uniform_args_scalar(ka);
+  SplitLds& lds = split_lds();
+  const uint32_t l = threadIdx.x - kSplitLanes;
+  const uint32_t frames = a->frames, wg = a->wg_list[blockIdx.x];
+  RenderConsts rc{a->rc.pi_over_sr, a->rc.fc_max, a->rc.log2_x0, a->rc.x_lo, a->rc.x_hi};
+  if constexpr (RETUNE) asm volatile("" : "+v"(rc.tan_k1), "+v"(rc.tan_k2), "+v"(rc.log2_x0), "+v"(rc.x_hi));
+  float* __restrict__ rows = a->rows;
+  const uint32_t steps = split_steps(frames), nch = steps - 2;
+  const float kNan = __builtin_nanf("");
+  for (uint32_t it = 0; it < steps; ++it) {
+    if (RETUNE && it >= 1 && it <= nch) {
+      const uint32_t c = it - 1, f0 = c * kSplitChunk;
+#pragma unroll
+      for (uint32_t j = 0; j < kSplitChunk; ++j) {
+        if (f0 + j < frames) {
+          const float pct = lds.ab[c & 1][j][l];
+          float t = kNan;
+          if (pct == pct) {
+            bool hi;
+            t = lp24_t_from_pct(pct, rc, hi);
+            if (hi) t = -t; // t > 0 always: the sign carries the side of SR/4
+          }
+          lds.bc[c & 1][j][l] = t;
+        }
+      }
+    }
+    // the group of frames whose last chunk role C wrote in the PREVIOUS step (it - 1 -> chunk it - 3)
+    if (it >= 3) {
+      const uint32_t c = it - 3, f_end = min((c + 1) * kSplitChunk, frames);
+      if ((f_end % kSplitGroup) == 0 || f_end == frames) {
+        const uint32_t f_lo = (f_end - 1) / kSplitGroup * kSplitGroup, count = f_end - f_lo, g = (f_lo / kSplitGroup) & 1u;
+        const uint32_t row = l >> 5, col = l & 31u; // 32 lanes per frame row
+        const float2* __restrict__ src = &lds.tile[g][0][0] + row * kSplitLanes + col;
+        float sl = 0.0f, sr = 0.0f;
+#pragma unroll
+        for (uint32_t j = 0; j < kSplitLanes / 32; ++j) { const float2 v = src[j * 32]; sl += v.x; sr += v.y; }
+        sl = dpp_add<0xb1, 0xf>(sl); sr = dpp_add<0xb1, 0xf>(sr);
+        sl = dpp_add<0x4e, 0xf>(sl); sr = dpp_add<0x4e, 0xf>(sr);
+        sl = dpp_add<0x124, 0xf>(sl); sr = dpp_add<0x124, 0xf>(sr);
+        sl = dpp_add<0x128, 0xf>(sl); sr = dpp_add<0x128, 0xf>(sr);
+        sl = dpp_add<0x142, 0xa>(sl); sr = dpp_add<0x142, 0xa>(sr);
+        if (col == 31 && row < count) {
+          rows[((size_t)wg * 2 + 0) * frames + f_lo + row] = sl;
+          rows[((size_t)wg * 2 + 1) * frames + f_lo + row] = sr;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // the last group: role C wrote its final chunk in the last step
+  {
+    const uint32_t f_end = frames, c_last = nch - 1;
+    const bool done_in_loop = false;
+    (void)c_last; (void)done_in_loop;
+    const uint32_t f_lo = (f_end - 1) / kSplitGroup * kSplitGroup, count = f_end - f_lo, g = (f_lo / kSplitGroup) & 1u;
+    const uint32_t row = l >> 5, col = l & 31u;
+    const float2* __restrict__ src = &lds.tile[g][0][0] + row * kSplitLanes + col;
+    float sl = 0.0f, sr = 0.0f;
+#pragma unroll
+    for (uint32_t j = 0; j < kSplitLanes / 32; ++j) { const float2 v = src[j * 32]; sl += v.x; sr += v.y; }
+    sl = dpp_add<0xb1, 0xf>(sl); sr = dpp_add<0xb1, 0xf>(sr);
+    sl = dpp_add<0x4e, 0xf>(sl); sr = dpp_add<0x4e, 0xf>(sr);
+    sl = dpp_add<0x124, 0xf>(sl); sr = dpp_add<0x124, 0xf>(sr);
+    sl = dpp_add<0x128, 0xf>(sl); sr = dpp_add<0x128, 0xf>(sr);
+    sl = dpp_add<0x142, 0xa>(sl); sr = dpp_add<0x142, 0xa>(sr);
+    if (col == 31 && row < count) {
+      rows[((size_t)wg * 2 + 0) * frames + f_lo + row] = sl;
+      rows[((size_t)wg * 2 + 1) * frames + f_lo + row] = sr;
+    }
+  }
+}
+
+// ---- role C: coefficients from the tangent, the filter recurrence, the gains; two steps behind A
+template <bool FUSED, bool RETUNE>
+GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split_back(UniformArgsPtr ka) {
+  const UniformArgsPtr a = uniform_args_scalar(ka);
+  SplitLds& lds = split_lds();
+  const SplitWave w = split_wave(a, threadIdx.x - 2 * kSplitLanes);
+  const uint32_t n = a->n, frames = a->frames;
+  const WelshParams& p = w.d.p;
+  const RenderConsts rc{a->rc.pi_over_sr, a->rc.fc_max, a->rc.log2_x0, a->rc.x_lo, a->rc.x_hi};
+  WelshState s = soa_load<WelshState>(a->state, n, w.v); // (only the filter words are used: the other loads fall away)
+  Lp24StateD filt = s.filt;
+  Lp24CoefD coef = lp24_coefd_from_fc(p.fc, p.cutoff_hz, rc.pi_over_sr, rc.fc_max); // welsh_scratch_init
+  if (!RETUNE) coef = make_scalar(coef);
+  float* __restrict__ out = a->out;
+  const size_t chs = a->ch_stride;
+  const uint32_t steps = split_steps(frames);
+  for (uint32_t it = 0; it < steps; ++it) {
+    if (it >= 2) {
+      const uint32_t c = it - 2, f0 = c * kSplitChunk;
+#pragma unroll
+      for (uint32_t j = 0; j < kSplitChunk; ++j) {
+        const uint32_t f = f0 + j;
+        if (f < frames) {
+          const float2 in = lds.ac[c % 3][j][w.l];
+          float L = 0.0f, R = 0.0f;
+          if (in.x == in.x) { // the voice sounds on this frame
+            if (RETUNE) {
+              const float t = lds.bc[c & 1][j][w.l];
+              if (t == t) coef = lp24_coefd_from_t(p.fc, fabsf(t), t < 0.0f);
+            }
+            welsh_frame_back<!RETUNE>(p, filt, coef, in.x, in.y, L, R);
+          }
+          lds.tile[(f / kSplitGroup) & 1u][f & (kSplitGroup - 1)][w.l] = make_float2(L, R);
+          if (!FUSED && w.active) {
+            block_store(out + (size_t)f * n + w.v, L);
+            block_store(out + chs + (size_t)f * n + w.v, R);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (w.active) { s.filt = filt; soa_store_range(a->state, n, w.v, s, kStateFiltWord, kStateFlagsWord); }
+}
+
+// A workgroup whose voices are all silent with both envelopes idle writes its zero rows and leaves (kernels.h
+// welsh_idle_workgroup); every role-wave looks at its own virtual wave.
+__device__ __forceinline__ bool welsh_split_idle_workgroup(const UniformArgs& a) {
+  const uint32_t wg = a.wg_list[blockIdx.x];
+  const uint32_t local = threadIdx.x % kSplitLanes;
+  const uint32_t w0 = wg * kSplitVw + (local >> 6);
+  const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(w0, a.n_waves - 1));
+  const uint32_t vbase = a.waves[w].vbase, count = a.waves[w].count;
+  const bool active = (w0 < a.n_waves) && ((local & 63u) < count);
+  const uint32_t v = active ? vbase + (local & 63u) : vbase;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(a.state, 0, (int)(sizeof(WelshState) / 4 * a.n * 4u), 0x00020000);
+  constexpr uint32_t kAmpWord = offsetof(WelshState, amp) / 4 + offsetof(EnvState, state) / 4;
+  constexpr uint32_t kFilWord = offsetof(WelshState, fil) / 4 + offsetof(EnvState, state) / 4;
+  const uint32_t sa = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(v * 4u), (int)(kAmpWord * a.n * 4u), 0);
+  const uint32_t sf = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(v * 4u), (int)(kFilWord * a.n * 4u), 0);
+  __shared__ int busy_waves;
+  if (threadIdx.x == 0) busy_waves = 0;
+  __syncthreads();
+  if (!__all(!active || (sa == ENV_IDLE && sf == ENV_IDLE)) && (threadIdx.x & 63u) == 0) atomicAdd(&busy_waves, 1);
+  __syncthreads();
+  if (busy_waves != 0) return false;
+  float* __restrict__ rows = a.rows + (size_t)wg * 2 * a.frames;
+  for (uint32_t t = threadIdx.x; t < 2 * a.frames; t += kSplitThreads) rows[t] = 0.0f;
+  return true;
+}
+template <int LFO_MODE, bool RETUNE>
+__device__ __forceinline__ void welsh_split_dispatch_front(uint32_t cls, UniformArgsPtr ka) {
+#define GROOVE_CLS_CASE(CL, C1, C2) case wg_class_combo(CL, C1, C2): welsh_split_front<LFO_MODE, RETUNE, C1, C2, CL>(ka); break;
+#define GROOVE_CLS_ROW(CL, C1) GROOVE_CLS_CASE(CL, C1, 0) GROOVE_CLS_CASE(CL, C1, 1) GROOVE_CLS_CASE(CL, C1, 2) GROOVE_CLS_CASE(CL, C1, 3) GROOVE_CLS_CASE(CL, C1, 4)
+#define GROOVE_CLS_PLANE(CL) GROOVE_CLS_ROW(CL, 0) GROOVE_CLS_ROW(CL, 1) GROOVE_CLS_ROW(CL, 2) GROOVE_CLS_ROW(CL, 3) GROOVE_CLS_ROW(CL, 4)
+  switch (cls) {
+    GROOVE_CLS_PLANE(OSC_ANY) GROOVE_CLS_PLANE(OSC_TRIANGLE) GROOVE_CLS_PLANE(OSC_SINE)
+    default:
+      if constexpr (LFO_MODE == LFO_F32) {
+        switch (cls) {
+          GROOVE_CLS_PLANE(OSC_PULSE) GROOVE_CLS_PLANE(OSC_SAW) GROOVE_CLS_PLANE(LFO_UNUSED)
+          default: break;
+        }
+      }
+      break;
+  }
+#undef GROOVE_CLS_PLANE
+#undef GROOVE_CLS_ROW
+#undef GROOVE_CLS_CASE
+}
+// One launch for the workgroups of the four class-specialised base kinds of a mid-size bank (the host's workgroup list is
+// sorted by kind: they are its first `n_wgs` entries; the exact-f64 kinds behind them take the all-kinds kernel).
+#ifdef GROOVE_WELSH_SPLIT_TU
+template <bool FUSED>
+__global__ __launch_bounds__(kSplitThreads, 2) GROOVE_NO_TAIL_CALLS void welsh_render_split_kernel(UniformArgs a, const uint8_t* __restrict__ wg_base) {
+  const UniformArgsPtr ka = (UniformArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  if constexpr (FUSED) { if (welsh_split_idle_workgroup(a)) return; }
+  const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wg_base[blockIdx.x]);
+  const uint32_t cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[blockIdx.x]);
+  const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kSplitLanes));
+  const bool retune = (base & 1u) != 0;
+  if (role == 0) {
+    switch (base) {
+      case wg_base_kind_of(LFO_F32, false): welsh_split_dispatch_front<LFO_F32, false>(cls, ka); break;
+      case wg_base_kind_of(LFO_F32, true): welsh_split_dispatch_front<LFO_F32, true>(cls, ka); break;
+      case wg_base_kind_of(LFO_F64_SMOOTH, false): welsh_split_dispatch_front<LFO_F64_SMOOTH, false>(cls, ka); break;
+      default: welsh_split_dispatch_front<LFO_F64_SMOOTH, true>(cls, ka); break;
+    }
+  } else if (role == 1) {
+    if (retune) welsh_split_mid<true>(ka); else welsh_split_mid<false>(ka);
+  } else {
+    if (retune) welsh_split_back<FUSED, true>(ka); else welsh_split_back<FUSED, false>(ka);
+  }
+}
+#endif
+void launch_welsh_split(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, bool fused); // csrc/welsh_split.hip
+
+} // namespace groove

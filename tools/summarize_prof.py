@@ -87,10 +87,12 @@ w, f = per_step("write", "WRITE_SIZE") * 1024.0, per_step("fetch", "FETCH_SIZE")
 summary["hbm_traffic_bytes_per_step"] = {"write": w, "fetch_raw": f, "fetch_x2_gfx950": 2 * f, "total_raw": w + f, "total_corrected": w + 2 * f}
 summary["instructions_per_step"] = {"valu_wave_insts": per_step("sq", "SQ_INSTS_VALU"), "salu_wave_insts": per_step("sq", "SQ_INSTS_SALU"),
                                     "note": "SQ_INSTS_VALU / SQ_INSTS_SALU summed over the step's kernels (wave-level instructions)"}
-# Measured instruction classes of a step (passes mix1 / mix2; wave-level instruction counts).  "plain" = everything the class
-# counters do not name (moves, compares, selects, DPP, bit operations ...).  Cost weights from docs/VALU_COSTS.md (measured on
-# this chip, in units of one plain fp32 operation = 2 issue cycles of a wave64 on a SIMD-32... see the file): f64 2x, conversions 2x
-# (to / from f64; the mix here is dominated by those), transcendental 4x, everything else 1x.
+# Measured instruction classes of a step (passes mix1 / mix2; wave-level instruction counts).  "other" = everything the class
+# counters do not name (moves, compares, selects, DPP, bit operations, 64-bit moves ...).  Issue costs are the MEASURED ones
+# of docs/VALU_COSTS.md (SIMD time per wave64 instruction on this chip, 8 waves per SIMD): fast 1.05 ns (fp32 add / mul /
+# fma with VGPR operands, 32-bit integer), normal 1.9 ns (all f64 arithmetic, every conversion, 64-bit integer, compares,
+# selects, DPP, fp32 with an SGPR operand), slow 3.4 ns (v_exp / v_rcp).  "other" is a mixture of fast and normal
+# instructions: both bounds are kept.
 mix_names = ("SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F32",
              "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32")
 if summary.get("mix1"):
@@ -100,12 +102,17 @@ if summary.get("mix1"):
         mix[nm[len("SQ_INSTS_"):].lower()] = v
     total = mix.get("valu") or 0.0
     f64 = mix["valu_add_f64"] + mix["valu_mul_f64"] + mix["valu_fma_f64"]
-    named = f64 + mix["valu_trans_f32"] + mix["valu_cvt"] + mix["valu_int32"] + mix["valu_int64"] + mix["valu_add_f32"] + mix["valu_mul_f32"] + mix["valu_fma_f32"]
-    mix["f64_total"] = f64
-    mix["other_plain"] = max(0.0, total - named)
-    # issue cycles per wave instruction: plain fp32 / int 2 (a wave64 on a SIMD-32 datapath... the spec rate bench.py uses), f64 4, conversions 4, transcendental 8
-    mix["cost_weighted_cycles"] = 2.0 * (total - f64 - mix["valu_cvt"] - mix["valu_trans_f32"]) + 4.0 * f64 + 4.0 * mix["valu_cvt"] + 8.0 * mix["valu_trans_f32"]
-    mix["note"] = "wave-level instructions per step by class (PMC); cost_weighted_cycles = 2 x plain + 4 x f64 + 4 x conversions + 8 x transcendental SIMD issue cycles"
+    f32 = mix["valu_add_f32"] + mix["valu_mul_f32"] + mix["valu_fma_f32"]
+    named = f64 + f32 + mix["valu_trans_f32"] + mix["valu_cvt"] + mix["valu_int32"] + mix["valu_int64"]
+    other = max(0.0, total - named)
+    mix["f64_total"], mix["f32_total"], mix["other"] = f64, f32, other
+    FAST, NORMAL, SLOW = 1.05, 1.9, 3.4
+    base = FAST * (f32 + mix["valu_int32"]) + NORMAL * (f64 + mix["valu_cvt"] + mix["valu_int64"]) + SLOW * mix["valu_trans_f32"]
+    mix["cost_weighted_simd_ns"] = {"other_all_fast": base + FAST * other, "other_all_normal": base + NORMAL * other,
+                                    "costs_ns": {"fast": FAST, "normal": NORMAL, "slow": SLOW}, "source": "docs/VALU_COSTS.md (measured on this chip)"}
+    mix["shares"] = {"f64": f64 / total, "f32_arith": f32 / total, "conversions": mix["valu_cvt"] / total, "transcendental": mix["valu_trans_f32"] / total,
+                     "int32": mix["valu_int32"] / total, "int64": mix["valu_int64"] / total, "other": other / total} if total else {}
+    mix["note"] = "wave-level instructions per step by class (PMC SQ_INSTS_VALU_*); cost_weighted_simd_ns = SIMD time these instructions need at their measured issue costs"
     summary["valu_mix_per_step"] = mix
 # The clock the chip held under each kernel (MI355X_MICROARCH.md, DVFS give-back): GRBM_GUI_ACTIVE is summed over the 8
 # XCDs, so clock = GRBM_GUI_ACTIVE / 8 / the dispatch's duration IN THE SAME PASS (a counter pass runs the kernels one
