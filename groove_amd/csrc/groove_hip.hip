@@ -8,6 +8,7 @@
 #include "../../include/groove_hip.h"
 #include "kernels.h"
 #include "welsh_tp.h"
+#include "welsh_split.h"
 #include "fx_tp.h"
 #include <dlfcn.h>
 #include <rccl/rccl.h> // types, enumerators and prototypes only: the library itself is dlopen'ed (rccl_open)
@@ -168,6 +169,10 @@ struct groove_ctx {
   bool need_fork = true;                // ctx-stream work since the last fork that side streams must wait for
   uint32_t tp_max_voices = kTpMaxVoices; // Welsh banks up to this size render time-parallel (welsh_tp.h); GROOVE_TP_MAX_VOICES overrides, 0 = never
   uint32_t fx_tp_max_lanes = 4096;       // IIR effect banks of up to this many lane-channels (half as many for the 24 dB low-pass) run time-parallel (fx_tp.h: measured crossovers, tools/fx_bench.py); GROOVE_FX_TP_MAX_LANES
+  // Mid-size Welsh banks (too big for the time-parallel form, too small to fill the chip with one voice-wave per wavefront):
+  // the ROLE-SPLIT kernel (welsh_split.h: three wavefronts per 64 voices, pipelined over the block's frames) for banks of up
+  // to this many virtual waves; 0 = never.  GROOVE_SPLIT_MAX_WAVES / groove_set_split_max_waves.
+  uint32_t split_max_waves = 2048;
   uint32_t pipeline_min_waves = 8600;   // banks at least this long (~550,000 voices) run one kernel per base kind and pipeline their fused blocks; smaller ones take the all-kinds kernel (round 2, blocks 5-44 of the timeline: 300,000 voices 0.275 -> 0.250 ms per block, 500,000 0.357 -> 0.342; 600,000 0.372 against 0.400)
   // How many of the bank streams exist and are handed out (GROOVE_BANK_STREAMS).  Three: with the ctx stream and the four
   // kind streams that is eight streams; a ninth lands on a hardware queue that already carries one of the others, and a
@@ -973,6 +978,7 @@ static int init_impl(int device_ordinal, const uint8_t* comm_id, int rank, int w
   if (const char* e = std::getenv("GROOVE_FX_CHUNKED_ALLPASS")) ctx->chunked_allpass = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_TP_MAX_VOICES")) ctx->tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_TP_MAX_LANES")) ctx->fx_tp_max_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
+  if (const char* e = std::getenv("GROOVE_SPLIT_MAX_WAVES")) ctx->split_max_waves = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_PIPELINE_MIN_WAVES")) ctx->pipeline_min_waves = (uint32_t)std::strtoul(e, nullptr, 10); // tests force the pipeline on small banks
   bool ok = hipSetDevice(device_ordinal) == hipSuccess;
   // groove_init_comm: the rank's RCCL communicator first, so that whatever streams RCCL creates for itself exist BEFORE
@@ -1083,6 +1089,14 @@ int groove_set_pipeline_min_waves(groove_ctx* ctx, uint32_t waves) {
   return 0;
 }
 uint32_t groove_pipeline_min_waves(groove_ctx* ctx) { return ctx ? ctx->pipeline_min_waves : 0; }
+int groove_set_split_max_waves(groove_ctx* ctx, uint32_t waves) {
+  if (!ctx) return fail(nullptr, "groove_set_split_max_waves: ctx is NULL");
+  if (ctx_join(ctx)) return 1;
+  GHIP(ctx, ctx_wait(ctx));
+  ctx->split_max_waves = waves;
+  return 0;
+}
+uint32_t groove_split_max_waves(groove_ctx* ctx) { return ctx ? ctx->split_max_waves : 0; }
 int groove_update_sample_rate(groove_ctx* ctx, uint32_t hz) {
   if (!ctx) return fail(nullptr, "groove_update_sample_rate: ctx is NULL");
   if (hz < 1000 || hz > 768000) return fail(ctx, "groove_update_sample_rate: unsupported rate");
@@ -1326,6 +1340,29 @@ static uint32_t fused_rows(const groove_bank* b, uint32_t frames) {
   if (use_tp(b, frames)) return b->kind == BANK_SAMPLER ? sampler_tp_workgroups(b->n) : b->kind == BANK_WELSH ? welsh_tp_grid(b->n) : welsh_tp_workgroups(b->n);
   return (b->kind == BANK_WELSH && b->n_vwaves) ? (b->n_vwaves + kWaves - 1) / kWaves : blocks_for(b->n);
 }
+// A Welsh bank below the per-kind pipeline's threshold: ONE launch for all its workgroups — role-split (welsh_split.h) when the
+// bank is mid-size, for the workgroups of the four class-specialised base kinds (the workgroup list is sorted by kind: they
+// come first); the rest, or everything, through the all-kinds kernel.
+static bool use_split(const groove_bank* b, uint32_t frames) {
+  const groove_ctx* ctx = b->ctx;
+  return b->kind == BANK_WELSH && b->n_vwaves && !use_tp(b, frames) && b->n_vwaves <= ctx->split_max_waves && frames >= 2 * kSplitChunk;
+}
+static void launch_small_uniform(groove_bank* b, const UniformArgs& a, hipStream_t st, bool fused, uint32_t frames) {
+  uint32_t n_split = 0;
+  if (use_split(b, frames))
+    for (int k = 0; k < 4 * kClassCombos; ++k) n_split += b->wgs_of_kind[k];
+  if (n_split) {
+    UniformArgs s = a;
+    s.n_wgs = n_split;
+    launch_welsh_split(s, b->d_wg_base, st, fused);
+  }
+  if (n_split < a.n_wgs) {
+    UniformArgs r = a;
+    r.wg_list = a.wg_list + n_split; r.wg_cls = a.wg_cls + n_split; r.n_wgs = a.n_wgs - n_split;
+    if (fused) launch_welsh_uniform_any(r, b->d_wg_base + n_split, st);
+    else launch_welsh_uniform_any_unfused(r, b->d_wg_base + n_split, st);
+  }
+}
 // One base kind's uniform Welsh kernel (kernels.h, "Workgroup KINDS") on stream `st`.
 static void launch_welsh_kind(int k, const UniformArgs& a, hipStream_t st, bool fused) {
   const dim3 kgrid(a.n_wgs), blk(kThreads);
@@ -1372,8 +1409,7 @@ static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs
       if (b->n_vwaves < ctx->pipeline_min_waves) { // small bank: all base kinds in one launch (kernels.h)
         const uint32_t wgs = (b->n_vwaves + kWaves - 1) / kWaves;
         UniformArgs a{b->d_waves, b->d_state, out, rows, b->d_wg_list, b->d_wg_cls, chs, rc, b->n_vwaves, b->n, frames, wgs};
-        if (fused) launch_welsh_uniform_any(a, b->d_wg_base, ctx->stream);
-        else launch_welsh_uniform_any_unfused(a, b->d_wg_base, ctx->stream);
+        launch_small_uniform(b, a, ctx->stream, fused, frames);
         GHIP(ctx, hipGetLastError());
         return 0;
       }
@@ -1543,7 +1579,7 @@ static int render_async_impl(groove_bank* b, uint32_t frames, groove_block* out,
     } else if (small_uniform) { // all base kinds in one launch
       const RenderConsts rc = render_consts(ctx->sr);
       UniformArgs a{b->d_waves, b->d_state, dst, rows, b->d_wg_list, b->d_wg_cls, chs, rc, b->n_vwaves, b->n, frames, b->n_vwaves / kWaves};
-      launch_welsh_uniform_any_unfused(a, b->d_wg_base, st);
+      launch_small_uniform(b, a, st, false, frames);
     } else if (b->kind == BANK_WELSH) {
       const RenderConsts rc = render_consts(ctx->sr);
       hipLaunchKernelGGL(welsh_render_kernel<false>, grid, blk, 0, st, b->d_params, b->d_state, b->n, frames, chs, dst, rows, rc);
@@ -1642,7 +1678,7 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
       launch_tp(b, frames, true, 0, b->d_pipe_part[slot], b->d_pipe_part[slot], st);
     } else if (small_uniform) { // all base kinds in one launch on this bank's stream
       UniformArgs a{b->d_waves, b->d_state, b->d_pipe_part[slot], b->d_pipe_part[slot], b->d_wg_list, b->d_wg_cls, 0, rc, b->n_vwaves, b->n, frames, rows};
-      launch_welsh_uniform_any(a, b->d_wg_base, st);
+      launch_small_uniform(b, a, st, true, frames);
     } else if (b->kind == BANK_WELSH) {
       hipLaunchKernelGGL(welsh_render_kernel<true>, dim3(rows), blk, 0, st, b->d_params, b->d_state, b->n, frames, (size_t)0, b->d_pipe_part[slot], b->d_pipe_part[slot], rc);
     } else if (b->kind == BANK_FM) {
@@ -1705,6 +1741,7 @@ const char* groove_bank_kernel_form(groove_bank* b, uint32_t frames, int fused) 
   if (b->n_vwaves >= ctx->pipeline_min_waves || (fused && ctx->pipeline_min_waves <= 1))
     return pipelined ? "welsh_render_uniform_kernel (one launch per base kind, class-specialised bodies, blocks pipelined)"
                      : "welsh_render_uniform_kernel (one launch per base kind, class-specialised bodies)";
+  if (use_split(b, frames)) return "welsh_render_split_kernel (role-split: three wavefronts per 64 voices, pipelined over the frames)";
   return "welsh_render_uniform_any_kernel (all base kinds in one launch, class-specialised bodies)";
 }
 int groove_bank_reset(groove_bank* b) {

@@ -129,6 +129,23 @@ GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split_front(
 
 // ---- role B: the tangent of the cutoff, one step behind A; and the bus tile's turn (FusedAccLds::flush, on the
 // group of eight frames role C finished in the previous step)
+__device__ __forceinline__ void split_turn_tile(const SplitLds& lds, uint32_t l, uint32_t f_end, float* __restrict__ rows, uint32_t wg, uint32_t frames) {
+  const uint32_t f_lo = (f_end - 1) / kSplitGroup * kSplitGroup, count = f_end - f_lo, g = (f_lo / kSplitGroup) & 1u;
+  const uint32_t row = l >> 5, col = l & 31u; // 32 lanes per frame row, as FusedAccLds::flush
+  const float2* __restrict__ src = &lds.tile[g][0][0] + row * kSplitLanes + col;
+  float sl = 0.0f, sr = 0.0f;
+#pragma unroll
+  for (uint32_t j = 0; j < kSplitLanes / 32; ++j) { const float2 v = src[j * 32]; sl += v.x; sr += v.y; }
+  sl = dpp_add<0xb1, 0xf>(sl); sr = dpp_add<0xb1, 0xf>(sr);
+  sl = dpp_add<0x4e, 0xf>(sl); sr = dpp_add<0x4e, 0xf>(sr);
+  sl = dpp_add<0x124, 0xf>(sl); sr = dpp_add<0x124, 0xf>(sr);
+  sl = dpp_add<0x128, 0xf>(sl); sr = dpp_add<0x128, 0xf>(sr);
+  sl = dpp_add<0x142, 0xa>(sl); sr = dpp_add<0x142, 0xa>(sr);
+  if (col == 31 && row < count) { // lanes 31 and 63 of each wave hold the totals of their rows
+    rows[((size_t)wg * 2 + 0) * frames + f_lo + row] = sl;
+    rows[((size_t)wg * 2 + 1) * frames + f_lo + row] = sr;
+  }
+}
 template <bool RETUNE>
 GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split_mid(UniformArgsPtr ka) {
   const UniformArgsPtr a = uniform_args_scalar(ka);
@@ -157,50 +174,15 @@ GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split_mid(Un
         }
       }
     }
-    // the group of frames whose last chunk role C wrote in the PREVIOUS step (it - 1 -> chunk it - 3)
+    // role C wrote chunk it - 3 in the PREVIOUS step: when that chunk completed a group of eight frames, the group is turned
+    // now (role C is writing the other tile buffer meanwhile)
     if (it >= 3) {
-      const uint32_t c = it - 3, f_end = min((c + 1) * kSplitChunk, frames);
-      if ((f_end % kSplitGroup) == 0 || f_end == frames) {
-        const uint32_t f_lo = (f_end - 1) / kSplitGroup * kSplitGroup, count = f_end - f_lo, g = (f_lo / kSplitGroup) & 1u;
-        const uint32_t row = l >> 5, col = l & 31u; // 32 lanes per frame row
-        const float2* __restrict__ src = &lds.tile[g][0][0] + row * kSplitLanes + col;
-        float sl = 0.0f, sr = 0.0f;
-#pragma unroll
-        for (uint32_t j = 0; j < kSplitLanes / 32; ++j) { const float2 v = src[j * 32]; sl += v.x; sr += v.y; }
-        sl = dpp_add<0xb1, 0xf>(sl); sr = dpp_add<0xb1, 0xf>(sr);
-        sl = dpp_add<0x4e, 0xf>(sl); sr = dpp_add<0x4e, 0xf>(sr);
-        sl = dpp_add<0x124, 0xf>(sl); sr = dpp_add<0x124, 0xf>(sr);
-        sl = dpp_add<0x128, 0xf>(sl); sr = dpp_add<0x128, 0xf>(sr);
-        sl = dpp_add<0x142, 0xa>(sl); sr = dpp_add<0x142, 0xa>(sr);
-        if (col == 31 && row < count) {
-          rows[((size_t)wg * 2 + 0) * frames + f_lo + row] = sl;
-          rows[((size_t)wg * 2 + 1) * frames + f_lo + row] = sr;
-        }
-      }
+      const uint32_t f_end = (it - 2) * kSplitChunk; // end of chunk it - 3; a chunk inside the loop is never the block's last
+      if ((f_end % kSplitGroup) == 0) split_turn_tile(lds, l, f_end, rows, wg, frames);
     }
     __syncthreads();
   }
-  // the last group: role C wrote its final chunk in the last step
-  {
-    const uint32_t f_end = frames, c_last = nch - 1;
-    const bool done_in_loop = false;
-    (void)c_last; (void)done_in_loop;
-    const uint32_t f_lo = (f_end - 1) / kSplitGroup * kSplitGroup, count = f_end - f_lo, g = (f_lo / kSplitGroup) & 1u;
-    const uint32_t row = l >> 5, col = l & 31u;
-    const float2* __restrict__ src = &lds.tile[g][0][0] + row * kSplitLanes + col;
-    float sl = 0.0f, sr = 0.0f;
-#pragma unroll
-    for (uint32_t j = 0; j < kSplitLanes / 32; ++j) { const float2 v = src[j * 32]; sl += v.x; sr += v.y; }
-    sl = dpp_add<0xb1, 0xf>(sl); sr = dpp_add<0xb1, 0xf>(sr);
-    sl = dpp_add<0x4e, 0xf>(sl); sr = dpp_add<0x4e, 0xf>(sr);
-    sl = dpp_add<0x124, 0xf>(sl); sr = dpp_add<0x124, 0xf>(sr);
-    sl = dpp_add<0x128, 0xf>(sl); sr = dpp_add<0x128, 0xf>(sr);
-    sl = dpp_add<0x142, 0xa>(sl); sr = dpp_add<0x142, 0xa>(sr);
-    if (col == 31 && row < count) {
-      rows[((size_t)wg * 2 + 0) * frames + f_lo + row] = sl;
-      rows[((size_t)wg * 2 + 1) * frames + f_lo + row] = sr;
-    }
-  }
+  split_turn_tile(lds, l, frames, rows, wg, frames); // the group that holds the block's last frame (role C's last step)
 }
 
 // ---- role C: coefficients from the tangent, the filter recurrence, the gains; two steps behind A
@@ -212,8 +194,15 @@ GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split_back(U
   const uint32_t n = a->n, frames = a->frames;
   const WelshParams& p = w.d.p;
   const RenderConsts rc{a->rc.pi_over_sr, a->rc.fc_max, a->rc.log2_x0, a->rc.x_lo, a->rc.x_hi};
-  WelshState s = soa_load<WelshState>(a->state, n, w.v); // (only the filter words are used: the other loads fall away)
-  Lp24StateD filt = s.filt;
+  Lp24StateD filt; // the filter's words of the state record, nothing else
+  {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a->state, 0, (int)(sizeof(WelshState) / 4 * n * 4u), 0x00020000);
+    WordsOf<Lp24StateD> fw;
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof(Lp24StateD) / 4; ++i)
+      fw.w[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(w.v * 4u), (int)((kStateFiltWord + i) * n * 4u), 0);
+    filt = __builtin_bit_cast(Lp24StateD, fw);
+  }
   Lp24CoefD coef = lp24_coefd_from_fc(p.fc, p.cutoff_hz, rc.pi_over_sr, rc.fc_max); // welsh_scratch_init
   if (!RETUNE) coef = make_scalar(coef);
   float* __restrict__ out = a->out;
@@ -245,7 +234,13 @@ GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split_back(U
     }
     __syncthreads();
   }
-  if (w.active) { s.filt = filt; soa_store_range(a->state, n, w.v, s, kStateFiltWord, kStateFlagsWord); }
+  if (w.active) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a->state, 0, (int)(sizeof(WelshState) / 4 * n * 4u), 0x00020000);
+    const WordsOf<Lp24StateD> fw = __builtin_bit_cast(WordsOf<Lp24StateD>, filt);
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof(Lp24StateD) / 4; ++i)
+      __builtin_amdgcn_raw_buffer_store_b32((int)fw.w[i], rsrc, (int)(w.v * 4u), (int)((kStateFiltWord + i) * n * 4u), 0);
+  }
 }
 
 // A workgroup whose voices are all silent with both envelopes idle writes its zero rows and leaves (kernels.h
@@ -298,7 +293,10 @@ __device__ __forceinline__ void welsh_split_dispatch_front(uint32_t cls, Uniform
 // sorted by kind: they are its first `n_wgs` entries; the exact-f64 kinds behind them take the all-kinds kernel).
 #ifdef GROOVE_WELSH_SPLIT_TU
 template <bool FUSED>
-__global__ __launch_bounds__(kSplitThreads, 2) GROOVE_NO_TAIL_CALLS void welsh_render_split_kernel(UniformArgs a, const uint8_t* __restrict__ wg_base) {
+#ifndef GROOVE_WAVES_SPLIT
+#define GROOVE_WAVES_SPLIT 4 /* 128 VGPRs: one workgroup of twelve wavefronts per CU, one role of each kind per SIMD (at 6 — two workgroups — the smooth-f64-LFO fronts spill 256 bytes per lane) */
+#endif
+__global__ __launch_bounds__(kSplitThreads, GROOVE_WAVES_SPLIT) GROOVE_NO_TAIL_CALLS void welsh_render_split_kernel(UniformArgs a, const uint8_t* __restrict__ wg_base) {
   const UniformArgsPtr ka = (UniformArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   if constexpr (FUSED) { if (welsh_split_idle_workgroup(a)) return; }
   const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wg_base[blockIdx.x]);

@@ -82,6 +82,14 @@ class Context:
     def pipeline_min_waves(self, n):
         _lib.check(self.L.groove_set_pipeline_min_waves(self.h, n), self.h)
 
+    @property
+    def split_max_waves(self):
+        return self.L.groove_split_max_waves(self.h)
+
+    @split_max_waves.setter
+    def split_max_waves(self, n):
+        _lib.check(self.L.groove_set_split_max_waves(self.h, n), self.h)
+
     def set_stream(self, hip_stream):
         _lib.check(self.L.groove_set_stream(self.h, C.c_void_p(hip_stream)), self.h)
 

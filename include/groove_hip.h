@@ -81,6 +81,13 @@ uint32_t groove_time_parallel_max_voices(groove_ctx* ctx);
  * million-voice path on a small bank).  GROOVE_PIPELINE_MIN_WAVES in the environment sets it at groove_init. */
 int groove_set_pipeline_min_waves(groove_ctx* ctx, uint32_t waves);
 uint32_t groove_pipeline_min_waves(groove_ctx* ctx);
+/* Tuning: Welsh banks of up to this many (virtual) wavefronts that are too big for the time-parallel form render ROLE-SPLIT:
+ * three wavefronts per 64 voices — front (envelopes, LFO, oscillators), cutoff tangent, filter + gains — pipelined over the
+ * block's frames through LDS, so that a bank which cannot fill the chip with voices fills it with the parts of a voice's
+ * frame (csrc/welsh_split.h).  Same results bit for bit as the serial kernels.  Default 2,048 (131,072 voices);
+ * 0 = never.  GROOVE_SPLIT_MAX_WAVES in the environment sets it at groove_init.  No reference counterpart. */
+int groove_set_split_max_waves(groove_ctx* ctx, uint32_t waves);
+uint32_t groove_split_max_waves(groove_ctx* ctx);
 /* HIP events on the ctx stream, for measurement (bench.py): create / record / elapsed. */
 int groove_event_create(groove_ctx* ctx, void** out_event);
 int groove_event_destroy(groove_ctx* ctx, void* event);

@@ -41,7 +41,9 @@ def gpu_ctx():
 def serial_kernels(gpu_ctx):
     """The serial (one voice per lane) Welsh kernels whatever the bank size: tests that target them
     (class-specialised bodies, the all-kinds kernel, the per-lane kernel) switch the time-parallel form off."""
-    old = gpu_ctx.time_parallel_max_voices
+    old, old_split = gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves
     gpu_ctx.time_parallel_max_voices = 0
+    gpu_ctx.split_max_waves = 0
     yield gpu_ctx
     gpu_ctx.time_parallel_max_voices = old
+    gpu_ctx.split_max_waves = old_split

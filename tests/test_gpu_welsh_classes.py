@@ -19,13 +19,18 @@ from groove_amd import patches as P, abi_types as T
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["serial", "time-parallel"])
+@pytest.fixture(autouse=True, params=["serial", "split", "time-parallel"])
 def kernel_form(request, gpu_ctx):
-    """Both forms of the Welsh render (kernels.h: one voice per lane; welsh_tp.h: one wavefront per voice)."""
-    old = gpu_ctx.time_parallel_max_voices
-    gpu_ctx.time_parallel_max_voices = 0 if request.param == "serial" else old
+    """Every test of this module runs against the three forms of the Welsh render: one voice per lane walking the frames
+    (kernels.h), the same walk split over three wavefronts per 64 voices (welsh_split.h: "split", the default for banks
+    too big for the third form), and one wavefront per voice with the frames over its lanes (welsh_tp.h, the default
+    for banks this small)."""
+    old, old_split = gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves
+    gpu_ctx.time_parallel_max_voices = old if request.param == "time-parallel" else 0
+    gpu_ctx.split_max_waves = 0 if request.param == "serial" else old_split
     yield request.param
     gpu_ctx.time_parallel_max_voices = old
+    gpu_ctx.split_max_waves = old_split
 
 WAVES = [T.WAVE_NONE, T.WAVE_SINE, T.WAVE_SQUARE, T.WAVE_PULSE_WIDTH, T.WAVE_TRIANGLE, T.WAVE_SAWTOOTH,
          T.WAVE_NOISE, T.WAVE_TRIANGLE_SINE, T.WAVE_DEBUG_MAX]
