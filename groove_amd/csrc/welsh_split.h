@@ -19,7 +19,8 @@
 // block is then as long as its longest role (~40 of ~90 instructions per frame) instead of their sum.
 //
 // Scope: the four class-specialised base kinds (f32 / smooth-f64 LFO x static / retuned filter); workgroups of the two
-// exact-f64 kinds (rare) keep the all-kinds kernel.  Workgroup = 4 virtual waves x 3 roles = 768 threads, 72 KB of LDS.
+// exact-f64 kinds (rare) keep the all-kinds kernel.  Workgroup = 4 virtual waves x 3 roles = 768 threads, 112 KB of LDS,
+// one workgroup per CU: a role of each kind on every SIMD.
 #pragma once
 #include "kernels.h"
 
@@ -28,9 +29,9 @@ namespace groove {
 constexpr int kSplitVw = kWaves;                       // virtual waves per workgroup (the host's workgroup = 4 virtual waves)
 constexpr int kSplitLanes = kSplitVw * 64;             // 256 voices
 constexpr int kSplitThreads = 3 * kSplitLanes;         // roles A, B, C
-constexpr uint32_t kSplitChunk = 4;                    // frames per pipeline step
+constexpr uint32_t kSplitChunk = 8;                    // frames per pipeline step (= one turn of the bus tile)
 constexpr uint32_t kSplitGroup = 8;                    // frames per turn of the bus tile (FusedAccLds::kChunk)
-static_assert(kSplitGroup % kSplitChunk == 0 && kSplitGroup == FusedAccLds::kChunk, "the bus tile is turned every second step");
+static_assert(kSplitGroup == kSplitChunk && kSplitGroup == FusedAccLds::kChunk, "a step is one turn of the bus tile");
 
 struct SplitLds {
   float2 ac[3][kSplitChunk][kSplitLanes];  // A -> C: {sum (NaN: the lane is silent this frame), gain}; three steps deep
@@ -38,7 +39,7 @@ struct SplitLds {
   float bc[2][kSplitChunk][kSplitLanes];   // B -> C: tan of the cutoff, negated above SR/4 (NaN: coefficients stand)
   float2 tile[2][kSplitGroup][kSplitLanes]; // C -> B: (L, R) of eight frames, two groups in rotation
 };
-static_assert(sizeof(SplitLds) <= 72 * 1024, "two workgroups per CU");
+static_assert(sizeof(SplitLds) <= 112 * 1024, "one workgroup per CU (160 KB of LDS)");
 
 // Word ranges of WelshState (dsp_core.h): [0, 30) oscillators, increments, envelopes — role A; [30, 38) the filter — role C;
 // [38, 40) flags — role A.
@@ -90,11 +91,11 @@ __device__ __forceinline__ void welsh_split_front_impl(UniformArgsPtr a) {
   const float kNan = __builtin_nanf("");
   for (uint32_t it = 0; it < steps; ++it) {
     if (it < nch) {
-      const uint32_t f0 = it * kSplitChunk;
-#pragma unroll
-      for (uint32_t j = 0; j < kSplitChunk; ++j) {
+      const uint32_t f0 = it * kSplitChunk, cnt = min(kSplitChunk, frames - f0);
+#pragma nounroll
+      for (uint32_t j = 0; j < cnt; ++j) { // (not unrolled: this role only WRITES LDS, and there are 450 copies of it)
         const uint32_t f = f0 + j;
-        if (f < frames) {
+        {
           float sum = 0.0f, g = 0.0f, pct = 0.0f, lfo = 0.0f;
           bool retune = false, ok;
           if (f == 0) { // the checked form (first tick after a note event, envelope boundaries, the idle test)
@@ -159,27 +160,23 @@ GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split_mid(Un
   const float kNan = __builtin_nanf("");
   for (uint32_t it = 0; it < steps; ++it) {
     if (RETUNE && it >= 1 && it <= nch) {
-      const uint32_t c = it - 1, f0 = c * kSplitChunk;
+      const uint32_t c = it - 1;
+      // the step's eight percents first (one LDS round trip, not eight), then eight independent tangents
+      float pct[kSplitChunk], t[kSplitChunk];
+#pragma unroll
+      for (uint32_t j = 0; j < kSplitChunk; ++j) pct[j] = lds.ab[c & 1][j][l]; // (frames past the block: stale values, harmless)
 #pragma unroll
       for (uint32_t j = 0; j < kSplitChunk; ++j) {
-        if (f0 + j < frames) {
-          const float pct = lds.ab[c & 1][j][l];
-          float t = kNan;
-          if (pct == pct) {
-            bool hi;
-            t = lp24_t_from_pct(pct, rc, hi);
-            if (hi) t = -t; // t > 0 always: the sign carries the side of SR/4
-          }
-          lds.bc[c & 1][j][l] = t;
-        }
+        bool hi;
+        const float tj = lp24_t_from_pct(pct[j], rc, hi); // (branch-free: a NaN percent — no retune this frame — is sorted out by the select)
+        t[j] = (pct[j] == pct[j]) ? (hi ? -tj : tj) : kNan; // t > 0 always: the sign carries the side of SR/4
       }
+#pragma unroll
+      for (uint32_t j = 0; j < kSplitChunk; ++j) lds.bc[c & 1][j][l] = t[j];
     }
     // role C wrote chunk it - 3 in the PREVIOUS step: when that chunk completed a group of eight frames, the group is turned
     // now (role C is writing the other tile buffer meanwhile)
-    if (it >= 3) {
-      const uint32_t f_end = (it - 2) * kSplitChunk; // end of chunk it - 3; a chunk inside the loop is never the block's last
-      if ((f_end % kSplitGroup) == 0) split_turn_tile(lds, l, f_end, rows, wg, frames);
-    }
+    if (it >= 3) split_turn_tile(lds, l, (it - 2) * kSplitChunk, rows, wg, frames); // chunk it - 3: never the block's last inside the loop
     __syncthreads();
   }
   split_turn_tile(lds, l, frames, rows, wg, frames); // the group that holds the block's last frame (role C's last step)
@@ -210,21 +207,28 @@ GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split_back(U
   const uint32_t steps = split_steps(frames);
   for (uint32_t it = 0; it < steps; ++it) {
     if (it >= 2) {
-      const uint32_t c = it - 2, f0 = c * kSplitChunk;
+      const uint32_t c = it - 2, f0 = c * kSplitChunk, cnt = min(kSplitChunk, frames - f0);
+      // the step's inputs first: one LDS round trip for the eight frames instead of two per frame
+      float2 in[kSplitChunk];
+      float tt[kSplitChunk];
 #pragma unroll
       for (uint32_t j = 0; j < kSplitChunk; ++j) {
-        const uint32_t f = f0 + j;
-        if (f < frames) {
-          const float2 in = lds.ac[c % 3][j][w.l];
+        in[j] = lds.ac[c % 3][j][w.l];
+        tt[j] = RETUNE ? lds.bc[c & 1][j][w.l] : 0.0f;
+      }
+      float2* __restrict__ tile = &lds.tile[c & 1u][0][w.l];
+#pragma unroll
+      for (uint32_t j = 0; j < kSplitChunk; ++j) {
+        if (j < cnt) {
+          const uint32_t f = f0 + j;
           float L = 0.0f, R = 0.0f;
-          if (in.x == in.x) { // the voice sounds on this frame
+          if (in[j].x == in[j].x) { // the voice sounds on this frame
             if (RETUNE) {
-              const float t = lds.bc[c & 1][j][w.l];
-              if (t == t) coef = lp24_coefd_from_t(p.fc, fabsf(t), t < 0.0f);
+              if (tt[j] == tt[j]) coef = lp24_coefd_from_t(p.fc, fabsf(tt[j]), tt[j] < 0.0f);
             }
-            welsh_frame_back<!RETUNE>(p, filt, coef, in.x, in.y, L, R);
+            welsh_frame_back<!RETUNE>(p, filt, coef, in[j].x, in[j].y, L, R);
           }
-          lds.tile[(f / kSplitGroup) & 1u][f & (kSplitGroup - 1)][w.l] = make_float2(L, R);
+          tile[j * kSplitLanes] = make_float2(L, R);
           if (!FUSED && w.active) {
             block_store(out + (size_t)f * n + w.v, L);
             block_store(out + chs + (size_t)f * n + w.v, R);
