@@ -172,7 +172,7 @@ struct groove_ctx {
   // Mid-size Welsh banks (too big for the time-parallel form, too small to fill the chip with one voice-wave per wavefront):
   // the ROLE-SPLIT kernel (welsh_split.h: three wavefronts per 64 voices, pipelined over the block's frames) for banks of up
   // to this many virtual waves; 0 = never.  GROOVE_SPLIT_MAX_WAVES / groove_set_split_max_waves.
-  uint32_t split_max_waves = 2048;
+  uint32_t split_max_waves = 1024;      // 65,536 voices = one workgroup (twelve wavefronts) per CU; measured (round 3, blocks 5-24): 20,000 voices 0.120 -> 0.090 ms per block, 32,768 0.119 -> 0.090, 65,536 0.123 -> 0.095; 80,000 (a second round of workgroups) 0.135 -> 0.153: not above
   uint32_t pipeline_min_waves = 8600;   // banks at least this long (~550,000 voices) run one kernel per base kind and pipeline their fused blocks; smaller ones take the all-kinds kernel (round 2, blocks 5-44 of the timeline: 300,000 voices 0.275 -> 0.250 ms per block, 500,000 0.357 -> 0.342; 600,000 0.372 against 0.400)
   // How many of the bank streams exist and are handed out (GROOVE_BANK_STREAMS).  Three: with the ctx stream and the four
   // kind streams that is eight streams; a ninth lands on a hardware queue that already carries one of the others, and a

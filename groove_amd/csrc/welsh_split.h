@@ -19,8 +19,8 @@
 // block is then as long as its longest role (~40 of ~90 instructions per frame) instead of their sum.
 //
 // Scope: the four class-specialised base kinds (f32 / smooth-f64 LFO x static / retuned filter); workgroups of the two
-// exact-f64 kinds (rare) keep the all-kinds kernel.  Workgroup = 4 virtual waves x 3 roles = 768 threads, 112 KB of LDS,
-// one workgroup per CU: a role of each kind on every SIMD.
+// exact-f64 kinds (rare) keep the all-kinds kernel.  Workgroup = 4 virtual waves x 3 roles = 768 threads, 72 KB of LDS,
+// one workgroup per CU (128 VGPRs): a role of each kind on every SIMD.
 #pragma once
 #include "kernels.h"
 
@@ -29,9 +29,9 @@ namespace groove {
 constexpr int kSplitVw = kWaves;                       // virtual waves per workgroup (the host's workgroup = 4 virtual waves)
 constexpr int kSplitLanes = kSplitVw * 64;             // 256 voices
 constexpr int kSplitThreads = 3 * kSplitLanes;         // roles A, B, C
-constexpr uint32_t kSplitChunk = 8;                    // frames per pipeline step (= one turn of the bus tile)
+constexpr uint32_t kSplitChunk = 4;                    // frames per pipeline step (measured: 8 — half the barriers — is 30 % slower)
 constexpr uint32_t kSplitGroup = 8;                    // frames per turn of the bus tile (FusedAccLds::kChunk)
-static_assert(kSplitGroup == kSplitChunk && kSplitGroup == FusedAccLds::kChunk, "a step is one turn of the bus tile");
+static_assert(kSplitGroup % kSplitChunk == 0 && kSplitGroup == FusedAccLds::kChunk, "the bus tile is turned every second step");
 
 struct SplitLds {
   float2 ac[3][kSplitChunk][kSplitLanes];  // A -> C: {sum (NaN: the lane is silent this frame), gain}; three steps deep
@@ -39,7 +39,7 @@ struct SplitLds {
   float bc[2][kSplitChunk][kSplitLanes];   // B -> C: tan of the cutoff, negated above SR/4 (NaN: coefficients stand)
   float2 tile[2][kSplitGroup][kSplitLanes]; // C -> B: (L, R) of eight frames, two groups in rotation
 };
-static_assert(sizeof(SplitLds) <= 112 * 1024, "one workgroup per CU (160 KB of LDS)");
+static_assert(sizeof(SplitLds) <= 72 * 1024, "fits beside another workgroup's");
 
 // Word ranges of WelshState (dsp_core.h): [0, 30) oscillators, increments, envelopes — role A; [30, 38) the filter — role C;
 // [38, 40) flags — role A.
@@ -92,8 +92,8 @@ __device__ __forceinline__ void welsh_split_front_impl(UniformArgsPtr a) {
   for (uint32_t it = 0; it < steps; ++it) {
     if (it < nch) {
       const uint32_t f0 = it * kSplitChunk, cnt = min(kSplitChunk, frames - f0);
-#pragma nounroll
-      for (uint32_t j = 0; j < cnt; ++j) { // (not unrolled: this role only WRITES LDS, and there are 450 copies of it)
+#pragma unroll
+      for (uint32_t j = 0; j < kSplitChunk; ++j) if (j < cnt) {
         const uint32_t f = f0 + j;
         {
           float sum = 0.0f, g = 0.0f, pct = 0.0f, lfo = 0.0f;
@@ -176,7 +176,10 @@ GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split_mid(Un
     }
     // role C wrote chunk it - 3 in the PREVIOUS step: when that chunk completed a group of eight frames, the group is turned
     // now (role C is writing the other tile buffer meanwhile)
-    if (it >= 3) split_turn_tile(lds, l, (it - 2) * kSplitChunk, rows, wg, frames); // chunk it - 3: never the block's last inside the loop
+    if (it >= 3) {
+      const uint32_t f_end = (it - 2) * kSplitChunk; // end of chunk it - 3; a chunk inside the loop is never the block's last
+      if ((f_end % kSplitGroup) == 0) split_turn_tile(lds, l, f_end, rows, wg, frames);
+    }
     __syncthreads();
   }
   split_turn_tile(lds, l, frames, rows, wg, frames); // the group that holds the block's last frame (role C's last step)
@@ -216,7 +219,7 @@ GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split_back(U
         in[j] = lds.ac[c % 3][j][w.l];
         tt[j] = RETUNE ? lds.bc[c & 1][j][w.l] : 0.0f;
       }
-      float2* __restrict__ tile = &lds.tile[c & 1u][0][w.l];
+      float2* __restrict__ tile = &lds.tile[(f0 / kSplitGroup) & 1u][f0 & (kSplitGroup - 1)][w.l];
 #pragma unroll
       for (uint32_t j = 0; j < kSplitChunk; ++j) {
         if (j < cnt) {

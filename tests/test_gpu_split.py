@@ -106,12 +106,15 @@ def test_split_kernel_through_release_and_idle_tail(gpu_ctx, forms, oracle):
 def test_split_is_the_default_for_mid_size_banks(gpu_ctx):
     """Above the time-parallel form's size and below the per-kind pipeline's: the role-split kernel, unless switched off."""
     from groove_amd import entities as E
-    assert gpu_ctx.split_max_waves == 2048
+    assert gpu_ctx.split_max_waves == 1024
     params, _ = P.welsh_voices_grouped(40_000, 0)
     s = E.WelshSynth(gpu_ctx, params)
     assert "split" in s.kernel_form(256, True) and "split" in s.kernel_form(256, False)
     assert "split" not in s.kernel_form(4, True)            # a handful of frames: nothing to pipeline
     s.destroy()
+    big = E.WelshSynth(gpu_ctx, P.welsh_voices_grouped(80_000, 0)[0])   # a second round of workgroups would cost more than the split saves
+    assert "split" not in big.kernel_form(256, True)
+    big.destroy()
     small = E.WelshSynth(gpu_ctx, P.welsh_voices_grouped(1024, 0)[0])
     assert "time-parallel" in small.kernel_form(256, True)
     small.destroy()
