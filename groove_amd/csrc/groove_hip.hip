@@ -1491,9 +1491,11 @@ static bool fx_is_biquad12(uint32_t kind) {
 }
 // `head` (may be null): a 12 dB BiQuad effect bank to be applied to the block inside the render kernel — only honoured
 // (*head_fused = true) when the bank renders time-parallel and its lanes are in the caller's order.
-static int render_async_impl(groove_bank* b, uint32_t frames, groove_block* out, groove_fx* head, bool* head_fused);
+// `chained`: an effect chain follows on this block (groove_bank_render_chain_async), so the lane sums the render would leave are
+// never read — a time-parallel Welsh render then does not write them (2 MB per block for config #3's 4,096 voices).
+static int render_async_impl(groove_bank* b, uint32_t frames, groove_block* out, groove_fx* head, bool* head_fused, bool chained = false);
 int groove_bank_render_async(groove_bank* b, uint32_t frames, groove_block* out) { return render_async_impl(b, frames, out, nullptr, nullptr); }
-static int render_async_impl(groove_bank* b, uint32_t frames, groove_block* out, groove_fx* head, bool* head_fused) {
+static int render_async_impl(groove_bank* b, uint32_t frames, groove_block* out, groove_fx* head, bool* head_fused, bool chained) {
   if (head_fused) *head_fused = false;
   if (!b || !out) return fail(nullptr, "groove_bank_render_async: NULL argument");
   groove_ctx* ctx = b->ctx;
@@ -1514,8 +1516,10 @@ static int render_async_impl(groove_bank* b, uint32_t frames, groove_block* out,
   }
   const size_t chs = (size_t)out->cap * out->n;
   const uint32_t rows_n = fused_rows(b, frames);
-  float* rows = block_sums(out, rows_n, frames);
-  if (!rows) return 1;
+  const bool no_sums = chained && tp && b->kind == BANK_WELSH;
+  float* rows = no_sums ? nullptr : block_sums(out, rows_n, frames);
+  if (!rows && !no_sums) return 1;
+  if (no_sums) out->sums_valid = false;
   float* dst = nullptr; // a regrouped bank: the block's library-order buffer (lazy lane order)
   if (block_render_target(out, b->order, frames, &dst)) return 1;
   // What the render has to wait for on the ctx stream: the block's consumers, and the bank's state if
@@ -1591,7 +1595,7 @@ static int render_async_impl(groove_bank* b, uint32_t frames, groove_block* out,
     end(k);
   }
   out->ready_mask = used;
-  out->sum_rows = rows_n; out->sum_frames = frames; out->sums_valid = true;
+  if (!no_sums) { out->sum_rows = rows_n; out->sum_frames = frames; out->sums_valid = true; }
   GHIP(ctx, hipGetLastError());
   return 0;
 }
@@ -2089,7 +2093,7 @@ int groove_bank_render_chain_async(groove_bank* b, uint32_t frames, groove_block
   while (first < n_fx && chain[first]->kind == GROOVE_FX_MIXER) ++first;
   groove_fx* head = first < n_fx ? chain[first] : nullptr;
   bool fused = false;
-  if (render_async_impl(b, frames, out, head, &fused)) return 1;
+  if (render_async_impl(b, frames, out, head, &fused, head != nullptr)) return 1;
   if (frames == 0) return 0;
   uint32_t taken = 0;
   if (fused) taken = first + 1;

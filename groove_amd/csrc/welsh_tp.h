@@ -519,7 +519,7 @@ __global__ __launch_bounds__(kTpThreads, 2) void welsh_tp_kernel(TpArgs a) {
       float acc = 0.0f;
 #pragma unroll
       for (int w = 0; w < kTpWaves; ++w) { q[w] = s_tile[w][ch][f]; acc += q[w]; }
-      a.rows[((size_t)blockIdx.x * 2 + ch) * frames + f] = acc;
+      if (a.rows) a.rows[((size_t)blockIdx.x * 2 + ch) * frames + f] = acc; // (null: the block goes straight into an effect chain, which replaces its lane sums)
       if (vec) *reinterpret_cast<float4*>(a.out + ch * a.ch_stride + (size_t)f * n + vbase) = make_float4(q[0], q[1], q[2], q[3]);
     }
     if (!FUSED && !vec && voice) {
