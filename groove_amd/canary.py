@@ -45,6 +45,10 @@ def run(timeout_s=75.0, device=0):
     or 'failed' (any other non-zero exit: the real run will report the error itself)."""
     if os.environ.get("GROOVE_NO_CANARY") == "1":
         return "skipped"
+    # never start a child from under a profiler: rocprofv3's preloaded tool would follow it (and a child launched from under
+    # --pmc is the forbidden re-launch of DESIGN.md section 7)
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROFILER_", "ROCP_", "ROCPROF_")) for k in os.environ):
+        return "skipped (profiler)"
     env = dict(os.environ, GROOVE_NO_CANARY="1", GROOVE_CANARY_DEVICE=str(device))
     p = subprocess.Popen([sys.executable, "-m", "groove_amd.canary"], cwd=REPO, env=env,
                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
