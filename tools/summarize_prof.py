@@ -17,6 +17,27 @@ summary = {"round": rnd, "workload": workload,
                       + (" --steps 20 --warmup 5   (the driver's window: blocks 5..24 of the timeline)" if windowed else "   (defaults: --gpus 1 --steps 172 --warmup 4)")}
 STEP_KERNELS = ("render", "_tp_kernel", "partial_", "mix_", "fx_", "block_", "_events_")   # what one step of the hot path launches
 
+_glob = glob.glob
+
+
+def newest_run(pattern):
+    """gpurun merges a call's files INTO gpurun_out/: a pass directory that was collected twice holds both runs' files (named
+    <pid>_*.csv).  Keep the files of the most recently written run only."""
+    files = _glob(pattern)
+    if not files:
+        return files
+    by_pid = collections.defaultdict(list)
+    for f in files:
+        by_pid[os.path.basename(f).split("_", 1)[0]].append(f)
+    best = max(by_pid.values(), key=lambda fs: max(os.path.getmtime(f) for f in fs))
+    return best
+
+
+class _G:
+    glob = staticmethod(newest_run)
+
+
+glob = _G
 ks = glob.glob(f"{out}/kt/*/*_kernel_stats.csv")
 if ks:
     shutil.copy(ks[0], f"profiles/{rnd}_{workload}_kernel_stats.csv")
