@@ -306,6 +306,9 @@ template <bool FUSED>
 __global__ __launch_bounds__(kSplitThreads, GROOVE_WAVES_SPLIT) GROOVE_NO_TAIL_CALLS void welsh_render_split_kernel(UniformArgs a, const uint8_t* __restrict__ wg_base) {
   const UniformArgsPtr ka = (UniformArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   if constexpr (FUSED) { if (welsh_split_idle_workgroup(a)) return; }
+#ifdef GROOVE_SPLIT_PRIO /* A/B (measured, round 3: s_setprio 3 changes nothing — config #5 0.100-0.105 against 0.103-0.107 ms per block, 65,536 voices alone 0.095 both) */
+  __builtin_amdgcn_s_setprio(GROOVE_SPLIT_PRIO);
+#endif
   const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wg_base[blockIdx.x]);
   const uint32_t cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[blockIdx.x]);
   const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kSplitLanes));

@@ -161,7 +161,7 @@ def test_synchronize_deadline_names_the_blocked_stream():
         ctx.sync_timeout_ms = 250
         ctx.debug_spin(1, 1500)            # kind stream 1 busy for 1.5 s
         t0 = time.time()
-        with pytest.raises(lib.GrooveError, match="groove_synchronize: not complete after 250 ms.*kind stream 1"):
+        with pytest.raises(lib.GrooveError, match="groove_synchronize: not complete after 250 ms.*kind stream 1"):  # (safe layout: the same stream object)
             ctx.synchronize()
         assert time.time() - t0 < 1.2
         ctx.sync_timeout_ms = 20000
@@ -183,7 +183,9 @@ def test_synchronize_deadline_names_the_blocked_stream():
         synth.render_mix(bus, 256)
         assert np.abs(bus.download()).max() > 1e-3
         info = ctx.debug_info()
-        assert info["streams_created"] == 8 and info["placeholder_fifth"] is True and info["comm_before_streams"] is False
+        import os
+        safe = os.environ.get("GROOVE_SAFE_STREAMS") == "1"   # (the whole suite is also run once under the safe layout)
+        assert info["streams_created"] == (4 if safe else 8) and info["placeholder_fifth"] is (not safe) and info["comm_before_streams"] is False
     finally:
         ctx.close()
 
