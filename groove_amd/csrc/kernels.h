@@ -119,7 +119,9 @@ struct FusedAccDpp {
     accL = mine ? __builtin_bit_cast(float, sl) : accL;
     accR = mine ? __builtin_bit_cast(float, sr) : accR;
   }
-  __device__ __forceinline__ void flush(float* __restrict__ partial, uint32_t frames, uint32_t f0, uint32_t count) {
+  static constexpr bool kStoresRows = false; // (no per-lane tile: the block is stored frame by frame)
+  __device__ __forceinline__ void flush(float* __restrict__ partial, uint32_t frames, uint32_t f0, uint32_t count,
+                                        float* = nullptr, size_t = 0, uint32_t = 0, uint32_t = 0) {
     __shared__ float red[kWaves][2][64];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     red[wave][0][lane] = accL;
@@ -144,6 +146,7 @@ struct FusedAccDpp {
 // ≈ 5 VALU + 1 LDS write per frame instead of 17 VALU; 16 KiB of LDS per workgroup.
 struct FusedAccLds {
   static constexpr uint32_t kChunk = 8;
+  static constexpr bool kStoresRows = true;
   uint32_t prow;   // this workgroup's row pair in partial[]
   __device__ __forceinline__ explicit FusedAccLds(uint32_t row) : prow(row) {}
   __device__ __forceinline__ float2* tile() {
@@ -153,8 +156,28 @@ struct FusedAccLds {
   __device__ __forceinline__ void add(float L, float R, uint32_t f) {
     tile()[(f & (kChunk - 1)) * kThreads + threadIdx.x] = make_float2(L, R);
   }
-  __device__ __forceinline__ void flush(float* __restrict__ partial, uint32_t frames, uint32_t f0, uint32_t count) {
+  // `out` (block-writing form, workgroup whose 256 lanes are ONE run of voices starting at `vbase0`): the tile's frames also
+  // leave as rows of the planar block — every wavefront stores one whole 1 KB row (64 lanes x 16 bytes) per instruction, 16
+  // rows per turn in quick succession, instead of each wavefront storing its own 256 bytes of a row on every frame.  The
+  // million-voice block is 2 GB of stores per block whose time is the DRAM's (2.4 TB/s with the scattered 256-byte pieces:
+  // every piece its own row activation), not the kernel's.
+  __device__ __forceinline__ void flush(float* __restrict__ partial, uint32_t frames, uint32_t f0, uint32_t count,
+                                        float* __restrict__ out = nullptr, size_t ch_stride = 0, uint32_t n = 0, uint32_t vbase0 = 0) {
     __syncthreads();
+    if (out) {
+      const uint32_t q = threadIdx.x & 63u, rp = threadIdx.x >> 6; // quad of lanes; rows rp and rp + 4
+#pragma unroll
+      for (uint32_t rr = 0; rr < kChunk / kWaves; ++rr) {
+        const uint32_t row = rp + kWaves * rr;
+        if (row < count) {
+          const float4 a0 = *reinterpret_cast<const float4*>(tile() + row * kThreads + 4 * q);     // (L0, R0, L1, R1)
+          const float4 a1 = *reinterpret_cast<const float4*>(tile() + row * kThreads + 4 * q + 2); // (L2, R2, L3, R3)
+          float* __restrict__ dst = out + (size_t)(f0 + row) * n + vbase0 + 4 * q;
+          *reinterpret_cast<float4*>(dst) = make_float4(a0.x, a0.z, a1.x, a1.z);
+          *reinterpret_cast<float4*>(dst + ch_stride) = make_float4(a0.y, a0.w, a1.y, a1.w);
+        }
+      }
+    }
     const uint32_t row = threadIdx.x >> 5, col = threadIdx.x & 31u; // 32 lanes per frame row
     const float2* __restrict__ src = tile() + row * kThreads + col;
     float l = 0.0f, r = 0.0f;
@@ -233,19 +256,23 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
 // HOISTED: `begin` also prepares the segment (float stage counters), live frames leave the envelope counters
 // alone, and `end(seg, live)` moves them once per segment (welsh_segment_end_hoisted); lanes that are not `active`
 // are never live, so their L and R stay zero without a select per frame.
+// `row_base` != ~0u (block-writing form): the workgroup's 256 lanes are one run of voices starting there and the block is stored by
+// whole 1 KB rows when the bus tile is turned (FusedAccLds::flush) instead of frame by frame.
 template <bool FUSED, bool HOISTED, class FirstFn, class BeginFn, class LiveFn, class IdleFn, class EndFn>
 __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n, uint32_t v, bool active, size_t ch_stride,
                                                      float* __restrict__ out, float* __restrict__ rows, uint32_t prow, FirstFn&& first, BeginFn&& begin,
-                                                     LiveFn&& live_frame, IdleFn&& idle_frame, EndFn&& end) {
+                                                     LiveFn&& live_frame, IdleFn&& idle_frame, EndFn&& end, uint32_t row_base = ~0u) {
   if (frames == 0) return;
   constexpr uint32_t C = FusedAcc::kChunk;
   static_assert(C > 1, "frame 0 never completes a chunk");
   FusedAcc acc(prow);
+  const bool by_rows = !FUSED && FusedAcc::kStoresRows && row_base != ~0u;
+  float* __restrict__ row_out = by_rows ? out : nullptr;
   auto put = [&](uint32_t f, float L, float R, bool masked) {
     if (masked) acc.add(active ? L : 0.0f, active ? R : 0.0f, f);
     else acc.add(L, R, f);
-    if ((f & (C - 1)) == C - 1) acc.flush(rows, frames, f - (C - 1), C);
-    if (!FUSED && active) {
+    if ((f & (C - 1)) == C - 1) acc.flush(rows, frames, f - (C - 1), C, row_out, ch_stride, n, row_base);
+    if (!FUSED && !by_rows && active) {
       block_store(out + (size_t)f * n + v, L);
       block_store(out + ch_stride + (size_t)f * n + v, R);
     }
@@ -268,7 +295,7 @@ __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n
     }
     if (HOISTED) end(seg, live);
   }
-  if (frames & (C - 1)) acc.flush(rows, frames, frames & ~(C - 1), frames & (C - 1));
+  if (frames & (C - 1)) acc.flush(rows, frames, frames & ~(C - 1), frames & (C - 1), row_out, ch_stride, n, row_base);
 }
 
 // ------------------------------------------------------------------ instruments
@@ -278,7 +305,7 @@ __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n
 template <bool FUSED, bool RETUNE, int LFO_MODE = LFO_F64, bool UNIFORM = false, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool REST = false>
 __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s, const RenderConsts& rc,
                                             uint32_t frames, uint32_t n, uint32_t v, bool active,
-                                            size_t ch_stride, float* __restrict__ out, float* __restrict__ rows, uint32_t prow) {
+                                            size_t ch_stride, float* __restrict__ out, float* __restrict__ rows, uint32_t prow, uint32_t row_base = ~0u) {
   WelshScratch sc = welsh_scratch_init(p, rc);
   // Static cutoff + wave-uniform patch: the six f64 coefficients are the same in every lane and
   // never change, so they ride in SGPRs (12 VGPRs back; f64 FMAs take one scalar operand).
@@ -295,7 +322,7 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
         [&](bool& live) { const uint32_t k = welsh_segment_begin(p, s, live); if (HOIST) welsh_segment_start_hoisted(s, sc); return k; },
         [&](float& L, float& R) { welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, HOIST>(p, s, rc, sc, L, R); },
         [&]() { welsh_segment_idle_frame(s); },
-        [&](uint32_t seg, bool live) { welsh_segment_end_hoisted<CL == LFO_UNUSED>(p, s, seg, live); });
+        [&](uint32_t seg, bool live) { welsh_segment_end_hoisted<CL == LFO_UNUSED>(p, s, seg, live); }, row_base);
   } else {
     run_frames<FUSED>(frames, n, v, active, ch_stride, out, rows, prow, [&](uint32_t f, float& L, float& R) {
       if (f == 0) welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL>(p, s, rc, sc, L, R);
@@ -394,7 +421,23 @@ __device__ __forceinline__ void welsh_uniform_body_impl(UniformArgsPtr a) {
   // pinned in VGPRs for the block: as literals / SGPRs each costs a v_mov on every retuning frame (the instructions
   // that use them take one constant-bus operand): +2.5 % in the all-voices window of the million-voice project
   if constexpr (RETUNE) asm volatile("" : "+v"(rc.tan_k1), "+v"(rc.tan_k2), "+v"(rc.log2_x0), "+v"(rc.x_hi));
-  welsh_block<FUSED, RETUNE, LFO_MODE, true, C1, C2, CL, REST>(d.p, s, rc, a->frames, n, v, active, a->ch_stride, a->out, a->rows, wg);
+  // block-writing form: a workgroup whose four virtual waves are full and follow each other (the usual case in a bank laid out
+  // synth by synth) stores the block by whole 1 KB rows (run_frames_segmented); scalar loads, so the test is wave-uniform and
+  // the same in the workgroup's four waves
+  uint32_t row_base = ~0u;
+#ifndef GROOVE_NO_ROW_STORES /* A/B: the block stored frame by frame, 256 bytes per wavefront */
+  if constexpr (!FUSED) {
+    const uint32_t w4 = wg * kWaves;
+    if (w4 + kWaves <= n_waves && (n & 3u) == 0 && (a->ch_stride & 3u) == 0) {
+      const uint32_t vb0 = a->waves[w4].vbase;
+      bool one_run = (vb0 & 3u) == 0;
+#pragma unroll
+      for (uint32_t k = 0; k < (uint32_t)kWaves; ++k) one_run = one_run && a->waves[w4 + k].count == 64u && a->waves[w4 + k].vbase == vb0 + 64u * k;
+      if (one_run) row_base = vb0;
+    }
+  }
+#endif
+  welsh_block<FUSED, RETUNE, LFO_MODE, true, C1, C2, CL, REST>(d.p, s, rc, a->frames, n, v, active, a->ch_stride, a->out, a->rows, wg, row_base);
   if (active) soa_store(a->state, n, v, s);
 }
 // Internal linkage + no `tail` marker on the kernels' calls: the compiler's inter-procedural register allocation then
