@@ -156,11 +156,8 @@ struct FusedAccLds {
   __device__ __forceinline__ void add(float L, float R, uint32_t f) {
     tile()[(f & (kChunk - 1)) * kThreads + threadIdx.x] = make_float2(L, R);
   }
-  // `out` (block-writing form, workgroup whose 256 lanes are ONE run of voices starting at `vbase0`): the tile's frames also
-  // leave as rows of the planar block — every wavefront stores one whole 1 KB row (64 lanes x 16 bytes) per instruction, 16
-  // rows per turn in quick succession, instead of each wavefront storing its own 256 bytes of a row on every frame.  The
-  // million-voice block is 2 GB of stores per block whose time is the DRAM's (2.4 TB/s with the scattered 256-byte pieces:
-  // every piece its own row activation), not the kernel's.
+  // `out` (GROOVE_ROW_STORES, an A/B option that did not pay — see welsh_uniform_body_impl): the tile's frames also leave as rows
+  // of the planar block, every wavefront storing one whole 1 KB row (64 lanes x 16 bytes) per instruction.
   __device__ __forceinline__ void flush(float* __restrict__ partial, uint32_t frames, uint32_t f0, uint32_t count,
                                         float* __restrict__ out = nullptr, size_t ch_stride = 0, uint32_t n = 0, uint32_t vbase0 = 0) {
     __syncthreads();
@@ -421,11 +418,12 @@ __device__ __forceinline__ void welsh_uniform_body_impl(UniformArgsPtr a) {
   // pinned in VGPRs for the block: as literals / SGPRs each costs a v_mov on every retuning frame (the instructions
   // that use them take one constant-bus operand): +2.5 % in the all-voices window of the million-voice project
   if constexpr (RETUNE) asm volatile("" : "+v"(rc.tan_k1), "+v"(rc.tan_k2), "+v"(rc.log2_x0), "+v"(rc.x_hi));
-  // block-writing form: a workgroup whose four virtual waves are full and follow each other (the usual case in a bank laid out
-  // synth by synth) stores the block by whole 1 KB rows (run_frames_segmented); scalar loads, so the test is wave-uniform and
-  // the same in the workgroup's four waves
+  // block-writing form (A/B option): a workgroup whose four virtual waves are full and follow each other (the usual case in a
+  // bank laid out synth by synth) can store the block by whole 1 KB rows when the bus tile is turned (run_frames_segmented)
+  // instead of 256 bytes per wavefront per frame.  The idea was DRAM row locality for the 2 GB of stores; the measurement says
+  // the 256-byte pieces are no worse, so the simpler form stays.
   uint32_t row_base = ~0u;
-#ifndef GROOVE_NO_ROW_STORES /* A/B: the block stored frame by frame, 256 bytes per wavefront */
+#ifdef GROOVE_ROW_STORES /* A/B, measured in round 3 and NOT kept: 1,000,000 voices materialised 0.823 / 0.834 / 0.829 ms per block with whole-row stores against 0.816 / 0.787 / 0.810 frame by frame (in-job); 300,000 voices 0.305 / 0.309 against 0.314 / 0.304 */
   if constexpr (!FUSED) {
     const uint32_t w4 = wg * kWaves;
     if (w4 + kWaves <= n_waves && (n & 3u) == 0 && (a->ch_stride & 3u) == 0) {
