@@ -11,7 +11,7 @@
 using namespace groove;
 
 struct EmulBank {
-  int kind; uint32_t n; double sr; int generic_lfo = 0; int segmented = 1; int time_parallel = 0;
+  int kind; uint32_t n; double sr; int generic_lfo = 0; int segmented = 1; int time_parallel = 0; int role_split = 0;
   std::vector<WelshParams> wp; std::vector<WelshState> ws; std::vector<WelshCold> wc;
   std::vector<FmParams> fp; std::vector<FmState> fs; std::vector<double> ratio;
   std::vector<SamplerParams> sp; std::vector<SamplerState> ss; std::vector<float> pcm;
@@ -39,6 +39,32 @@ static void welsh_emul_segment_frame2(const WelshParams& p, WelshState& s, const
 static void welsh_emul_segment_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc, WelshScratch& sc, bool retune, int mode,
                                      float& L, float& R) {
   if (retune) welsh_emul_segment_frame2<true>(p, s, rc, sc, mode, L, R); else welsh_emul_segment_frame2<false>(p, s, rc, sc, mode, L, R);
+}
+
+// The role-split kernel's frame (csrc/welsh_split.h), role by role with what travels between the roles through LDS on the
+// device: role A = welsh_frame_front -> {sum (NaN: silent), gain} and the cutoff percent (NaN: no retune); role B = the tangent of
+// the cutoff, negated above SR/4 (NaN: coefficients stand); role C = coefficients from the tangent, the filter step, the gains.
+// `coef` is role C's running coefficient set (welsh_scratch_init's at the start of a block).
+template <bool FIRST, bool RETUNE, int MODE, bool SEG>
+static void welsh_emul_split_frame3(const WelshParams& p, WelshState& s, const RenderConsts& rc, WelshScratch& sc, Lp24CoefD& coef, float& L, float& R) {
+  const float kNan = __builtin_nanf("");
+  float sum = 0.0f, g = 0.0f, pct = 0.0f, lfo = 0.0f;
+  bool retune = false;
+  const bool ok = welsh_frame_front<FIRST, RETUNE, MODE, OSC_ANY, OSC_ANY, OSC_ANY, SEG, false, SEG>(p, s, sc, sum, g, pct, retune, lfo);
+  const float ac_sum = ok ? sum : kNan, ab_pct = (RETUNE && ok && retune) ? pct : kNan;     // role A's LDS records
+  float bc_t = kNan;                                                                          // role B
+  if (RETUNE) { bool hi; const float tj = lp24_t_from_pct(ab_pct, rc, hi); bc_t = (ab_pct == ab_pct) ? (hi ? -tj : tj) : kNan; }
+  L = 0.0f; R = 0.0f;                                                                         // role C
+  if (ac_sum == ac_sum) {
+    if (RETUNE && bc_t == bc_t) coef = lp24_coefd_from_t(p.fc, fabsf(bc_t), bc_t < 0.0f);
+    welsh_frame_back<false>(p, s.filt, coef, ac_sum, g, L, R);
+  }
+}
+template <bool FIRST, bool SEG>
+static void welsh_emul_split_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc, WelshScratch& sc, Lp24CoefD& coef, bool retune, int mode,
+                                   float& L, float& R) {
+  if (mode == LFO_F32) { if (retune) welsh_emul_split_frame3<FIRST, true, LFO_F32, SEG>(p, s, rc, sc, coef, L, R); else welsh_emul_split_frame3<FIRST, false, LFO_F32, SEG>(p, s, rc, sc, coef, L, R); }
+  else { if (retune) welsh_emul_split_frame3<FIRST, true, LFO_F64_SMOOTH, SEG>(p, s, rc, sc, coef, L, R); else welsh_emul_split_frame3<FIRST, false, LFO_F64_SMOOTH, SEG>(p, s, rc, sc, coef, L, R); }
 }
 
 // The time-parallel form (welsh_tp.h) with a loop over 64 "lanes" in place of the wavefront: the per-lane
@@ -192,6 +218,9 @@ void emul_bank_destroy(void* h) { delete (EmulBank*)h; }
 void emul_set_generic_lfo(void* h, int on) { ((EmulBank*)h)->generic_lfo = on; }
 void emul_set_segmented(void* h, int on) { ((EmulBank*)h)->segmented = on; }
 void emul_set_time_parallel(void* h, int on) { ((EmulBank*)h)->time_parallel = on; }
+// role_split != 0: Welsh voices of the four class-specialised base kinds (no exact-f64 LFO) render role by role, as the
+// role-split kernel does (welsh_split.h); must give the segmented form's bits
+void emul_set_role_split(void* h, int on) { ((EmulBank*)h)->role_split = on; }
 void emul_bank_note_events(void* h, const groove_note_event* ev, uint32_t n_ev) {
   EmulBank* b = (EmulBank*)h;
   for (uint32_t i = 0; i < n_ev; ++i) {
@@ -226,8 +255,24 @@ void emul_bank_render(void* h, uint32_t frames, float* out) {
     float sampler_buf[16] = {};
     uint32_t seg_left = 0, seg_len = 0; // segmented form (uniform kernels): frames left before the next boundary check
     bool seg_live = false;
+    const bool split = b->kind == 0 && b->role_split && b->segmented && mode != LFO_F64; // (the exact-f64 kinds keep the all-kinds kernel)
+    Lp24CoefD split_coef = sc.coef; // role C's coefficients: welsh_scratch_init's at the start of the block
     for (uint32_t f = 0; f < frames; ++f) {
       float L, R;
+      if (split) { // mirrors welsh_split_front_impl's walk (frame 0 checked, then hoisted segments) with roles B and C in line
+        if (f == 0) welsh_emul_split_frame<true, false>(b->wp[v], b->ws[v], rc, sc, split_coef, retunes, mode, L, R);
+        else {
+          if (seg_left == 0) {
+            seg_left = welsh_segment_begin(b->wp[v], b->ws[v], seg_live);
+            welsh_segment_start_hoisted(b->ws[v], sc);
+            if (seg_left > frames - f) seg_left = frames - f;
+            seg_len = seg_left;
+          }
+          L = R = 0.0f;
+          if (seg_live) welsh_emul_split_frame<false, true>(b->wp[v], b->ws[v], rc, sc, split_coef, retunes, mode, L, R);
+          if (--seg_left == 0) welsh_segment_end_hoisted<false>(b->wp[v], b->ws[v], seg_len, seg_live);
+        }
+      } else
       if (b->kind == 0 && b->segmented && f > 0) { // mirrors run_frames_segmented<HOISTED> with a one-lane wave
         if (seg_left == 0) {
           seg_left = welsh_segment_begin(b->wp[v], b->ws[v], seg_live);

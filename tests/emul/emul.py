@@ -12,7 +12,7 @@ _fp = C.POINTER(C.c_float)
 def build():
     src = os.path.join(HERE, "emul.cpp")
     out = os.path.join(HERE, "libemul.so")
-    deps = [src] + [os.path.join(HERE, "..", "..", "groove_amd", "csrc", f) for f in ("dsp_core.h", "derive.h", "welsh_tp.h")]
+    deps = [src] + [os.path.join(HERE, "..", "..", "groove_amd", "csrc", f) for f in ("dsp_core.h", "derive.h", "welsh_tp.h", "welsh_split.h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         # -ffp-contract=off: fmaf() calls stay fused, plain a*b+c stays unfused, like hipcc's default for explicit code
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", out, src], check=True)
@@ -35,6 +35,7 @@ def lib():
         L.emul_set_generic_lfo.argtypes = [vp, C.c_int]
         L.emul_set_segmented.argtypes = [vp, C.c_int]
         L.emul_set_time_parallel.argtypes = [vp, C.c_int]
+        L.emul_set_role_split.argtypes = [vp, C.c_int]
         L.emul_bank_note_events.argtypes = [vp, C.POINTER(T.NoteEvent), u32]
         L.emul_bank_render.argtypes = [vp, u32, _fp]
         L.emul_bitcrush.restype = C.c_float; L.emul_bitcrush.argtypes = [C.c_float, u32]
@@ -70,6 +71,10 @@ class Bank:
     def set_time_parallel(self, on):
         """True: Welsh voices through the time-parallel form (welsh_tp.h: 64 lanes x 4 frames, affine-map scan)."""
         lib().emul_set_time_parallel(self.h, 1 if on else 0)
+
+    def set_role_split(self, on):
+        """True: every frame role by role, with what the role-split kernel (welsh_split.h) passes between its wavefronts."""
+        lib().emul_set_role_split(self.h, 1 if on else 0)
 
     def set_generic_lfo(self, on):
         """True: exact per-frame f64 LFO (per-lane kernel); False: block-seeded recurrences where promised."""

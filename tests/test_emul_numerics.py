@@ -94,6 +94,33 @@ def test_segmented_and_checked_forms_are_bit_identical():
         assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), blk
 
 
+def test_role_split_frame_is_the_serial_frame_bit_for_bit():
+    """csrc/welsh_split.h gives a voice-wave's frame to three wavefronts: front -> {sum | NaN, gain} and the cutoff percent |
+    NaN; the cutoff's tangent, negated above SR/4 | NaN; coefficients from the tangent, filter step, gains.  The same device
+    text walked role by role on the CPU (tests/emul/emul.cpp) must give the segmented serial form's bits — every patch of
+    the table (all waveforms, routings, sync, static and retuned filters, cutoffs on both sides of SR/4), note-on, release,
+    idle, re-trigger, ragged blocks."""
+    n = 64
+    params = P.welsh_voices(n)
+    a, b = E.Bank.welsh(params), E.Bank.welsh(params)
+    a.set_role_split(True)
+    keys_hi = T.note_events_np(np.arange(n, dtype=np.uint32), np.full(n, 108, dtype=np.uint8), True)   # high keys: cutoffs above SR/4 too
+    on, off = P.note_on_all(n), P.note_off_all(n)
+    peak = 0.0
+    for blk in range(70):
+        if blk in (0, 40):
+            a.note_events(on); b.note_events(on)
+        if blk in (12, 52):
+            a.note_events(off); b.note_events(off)
+        if blk == 55:
+            a.note_events(keys_hi); b.note_events(keys_hi)
+        frames = [256, 100, 7, 1][blk % 4]
+        x, y = a.render(frames), b.render(frames)
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), blk
+        peak = max(peak, float(np.abs(x).max()))
+    assert peak > 1e-2
+
+
 def test_extended_lfo_routings_arithmetic(oracle):
     """The five routings beyond LfoRoutingType (pitch-osc2, pw-osc1, pw-osc2, resonance, cutoff-amp; SURVEY §8 f1,
     docs/DSP_SPEC.md §6): device arithmetic vs the oracle, every LFO waveform that is smooth enough to be meaningful,

@@ -192,3 +192,30 @@ def test_bench_ranks_under_an_external_launcher_are_supervised(tmp_path):
     assert line["dry_launch"] is True and line["ranks"] == 2
     assert line["watchdog"]["supervised_under_launcher"] is True and line["watchdog"]["attempts"] == 2 and line["watchdog"]["killed"] == 1
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]   # only rank 0 prints
+
+
+def test_bench_line_reads_the_profile_of_its_own_window():
+    """bench.py's roofline block: for the driver's command (--steps 20 --warmup 5) the physical figures come from the PMC
+    summary collected with that very command (profiles/rNN_welsh-1m-window_summary.json), otherwise from the whole-timeline
+    summary; the effective fraction, both physical fractions and the bound are all on the block."""
+    sys.path.insert(0, REPO)
+    import bench
+    win = bench.committed_profile("welsh-1m", window=(20, 5))
+    whole = bench.committed_profile("welsh-1m", window=(172, 4))
+    assert win and win["source"].endswith("welsh-1m-window_summary.json") and win["same_window_as_this_run"] is True
+    assert whole and whole["source"].endswith("_welsh-1m_summary.json") and whole["window_steps_warmup"] == [172, 4]
+    assert win["valu_per_step"] > whole["valu_per_step"] > 1e8        # the window is the timeline's most expensive stretch
+    assert win["traffic"] and win["valu_simd_ns_per_step"]["other_all_fast"] < win["valu_simd_ns_per_step"]["other_all_normal"]
+    r = bench.roofline_block("welsh-1m", 1_000_000, 0.55, True, True, window=(20, 5))
+    assert r["bound"] == "valu-issue" and r["traffic_same_window"] is True
+    assert 0.9 < r["frac"] < 1.2 and 0.05 < r["hbm_physical_frac"] < 0.2            # effective (can exceed 1) vs physical
+    assert 0.4 < r["valu"]["achieved_frac"] < 0.7 and 0.7 < r["valu"]["cost_weighted_frac"]["low"] <= r["valu"]["cost_weighted_frac"]["high"] < 1.2
+    lat = bench.roofline_block("sampler-16384", 16384, 0.0166, True, True)
+    assert lat["bound"].startswith("latency") and lat["hbm_physical_frac"] < 0.25
+    hbm = bench.roofline_block("chain-4096", 4096, 0.0647, True, True)
+    assert hbm["bound"] == "hbm" and 0.3 < hbm["hbm_physical_frac"] < 0.5 and 0.4 < hbm["frac"] < 0.5
+    # a shard of the workload scales the counted traffic and instructions with its voices
+    half = bench.roofline_block("welsh-1m", 500_000, 0.36, True, True, window=(20, 5))
+    assert abs(half["traffic"] / r["traffic"] - 0.5) < 1e-9
+    sel = bench.spread_sample(1_000_000, 256)
+    assert len(sel) == 256 and len(set((sel % 32).tolist())) == 32 and sel.max() < 1_000_000
