@@ -1347,20 +1347,27 @@ static bool use_split(const groove_bank* b, uint32_t frames) {
   const groove_ctx* ctx = b->ctx;
   return b->kind == BANK_WELSH && b->n_vwaves && !use_tp(b, frames) && b->n_vwaves <= ctx->split_max_waves && frames >= 2 * kSplitChunk;
 }
+static void launch_welsh_kind(int k, const UniformArgs& a, hipStream_t st, bool fused);
 static void launch_small_uniform(groove_bank* b, const UniformArgs& a, hipStream_t st, bool fused, uint32_t frames) {
-  uint32_t n_split = 0;
-  if (use_split(b, frames))
-    for (int k = 0; k < 4 * kClassCombos; ++k) n_split += b->wgs_of_kind[k];
-  if (n_split) {
+  // the workgroup list is sorted by kind: the four class-specialised base kinds first, then the two exact-f64 ones
+  uint32_t n_spec = 0, n_f64[2] = {0, 0};
+  for (int k = 0; k < 4 * kClassCombos; ++k) n_spec += b->wgs_of_kind[k];
+  for (int k = 0; k < kClassCombos; ++k) { n_f64[0] += b->wgs_of_kind[4 * kClassCombos + k]; n_f64[1] += b->wgs_of_kind[5 * kClassCombos + k]; }
+  if (n_spec) {
     UniformArgs s = a;
-    s.n_wgs = n_split;
-    launch_welsh_split(s, b->d_wg_base, st, fused);
+    s.n_wgs = n_spec;
+    if (use_split(b, frames)) launch_welsh_split(s, b->d_wg_base, st, fused);
+    else if (fused) launch_welsh_uniform_any(s, b->d_wg_base, st);
+    else launch_welsh_uniform_any_unfused(s, b->d_wg_base, st);
   }
-  if (n_split < a.n_wgs) {
+  // exact-f64 LFO kinds (rare; their bodies need 133 VGPRs): the per-kind kernels, budgeted for them, behind it on the same stream
+  uint32_t at = n_spec;
+  for (int j = 0; j < 2; ++j) {
+    if (!n_f64[j]) continue;
     UniformArgs r = a;
-    r.wg_list = a.wg_list + n_split; r.wg_cls = a.wg_cls + n_split; r.n_wgs = a.n_wgs - n_split;
-    if (fused) launch_welsh_uniform_any(r, b->d_wg_base + n_split, st);
-    else launch_welsh_uniform_any_unfused(r, b->d_wg_base + n_split, st);
+    r.wg_list = a.wg_list + at; r.wg_cls = a.wg_cls + at; r.n_wgs = n_f64[j];
+    launch_welsh_kind(4 + j, r, st, fused);
+    at += n_f64[j];
   }
 }
 // One base kind's uniform Welsh kernel (kernels.h, "Workgroup KINDS") on stream `st`.

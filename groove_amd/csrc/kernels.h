@@ -64,7 +64,10 @@ __device__ __forceinline__ void soa_store(uint32_t* __restrict__ buf, uint32_t n
 #define GROOVE_WAVES_F64 2
 #endif
 #ifndef GROOVE_WAVES_ANY
-#define GROOVE_WAVES_ANY 3 /* the all-kinds kernel of small banks: room for the exact-f64 bodies */
+#define GROOVE_WAVES_ANY 4 /* the all-kinds kernel of banks that do not fill the chip.  Round 3: 4 (128 VGPRs) instead of 3 — in-job, blocks 5-24:
+                              250,000 voices 0.212 -> 0.197 ms per block, 500,000 0.350 -> 0.331, 125,000 unchanged (5 is worse below 500,000:
+                              0.172 at 125,000); the two exact-f64 base kinds, whose bodies need 133 VGPRs, no longer run in this kernel (the
+                              host gives their workgroups to the per-kind kernels) */
 #endif
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(kThreads, (WavesBudget<LFO_MODE, RETUNE>::value)) G
     welsh_dispatch_class<FUSED, LFO_MODE, RETUNE>((uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[blockIdx.x]), ka);
   }
 }
-// All base kinds in ONE launch, for banks too small to fill the machine: there a block is
+// All (class-specialised) base kinds in ONE launch, for banks too small to fill the machine: there a block is
 // bound by one wavefront's serial walk of its frames, register budgets do not matter (the kernel takes
 // the largest), and what counts is that every workgroup starts at once instead of queueing behind
 // the few hardware queues that several per-kind launches share.  wg_base[] = base kind per workgroup.
@@ -533,9 +536,8 @@ __global__ __launch_bounds__(kThreads, GROOVE_WAVES_ANY) GROOVE_NO_TAIL_CALLS vo
     case wg_base_kind_of(LFO_F32, false): welsh_dispatch_class<FUSED, LFO_F32, false>(cls, ka); break;
     case wg_base_kind_of(LFO_F32, true): welsh_dispatch_class<FUSED, LFO_F32, true>(cls, ka); break;
     case wg_base_kind_of(LFO_F64_SMOOTH, false): welsh_dispatch_class<FUSED, LFO_F64_SMOOTH, false>(cls, ka); break;
-    case wg_base_kind_of(LFO_F64_SMOOTH, true): welsh_dispatch_class<FUSED, LFO_F64_SMOOTH, true>(cls, ka); break;
-    case wg_base_kind_of(LFO_F64, false): welsh_uniform_body<FUSED, LFO_F64, false, OSC_ANY, OSC_ANY, OSC_ANY>(ka); break;
-    default: welsh_uniform_body<FUSED, LFO_F64, true, OSC_ANY, OSC_ANY, OSC_ANY>(ka); break;
+    default: welsh_dispatch_class<FUSED, LFO_F64_SMOOTH, true>(cls, ka); break;
+    // (the exact-f64 base kinds 4 and 5 are never in this launch: groove_hip.hip launch_small_uniform)
   }
 }
 #endif // GROOVE_WELSH_ANY_TU
