@@ -219,3 +219,20 @@ def test_bench_line_reads_the_profile_of_its_own_window():
     assert abs(half["traffic"] / r["traffic"] - 0.5) < 1e-9
     sel = bench.spread_sample(1_000_000, 256)
     assert len(sel) == 256 and len(set((sel % 32).tolist())) == 32 and sel.max() < 1_000_000
+
+
+def test_bench_under_torch_distributed_run_the_way_the_driver_starts_it():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...`
+    (the driver's command for N > 1; here with --dry-launch: the rendezvous only, no GPU): every rank supervises a child,
+    rank 0 prints one line."""
+    import socket
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-launch"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["ranks"] == 2 and line["voice_ranges"] == [[0, 500000], [500000, 1000000]]
+    assert line["watchdog"]["supervised_under_launcher"] is True and line["watchdog"]["attempts"] == 1
