@@ -173,6 +173,8 @@ struct groove_ctx {
   // the ROLE-SPLIT kernel (welsh_split.h: three wavefronts per 64 voices, pipelined over the block's frames) for banks of up
   // to this many virtual waves; 0 = never.  GROOVE_SPLIT_MAX_WAVES / groove_set_split_max_waves.
   uint32_t split_max_waves = 1024;      // 65,536 voices = one workgroup (twelve wavefronts) per CU; measured (round 3, blocks 5-24): 20,000 voices 0.120 -> 0.090 ms per block, 32,768 0.119 -> 0.090, 65,536 0.123 -> 0.095; 80,000 (a second round of workgroups) 0.135 -> 0.153: not above
+  uint32_t split2_max_waves = 0;         // banks above split_max_waves and up to this many virtual waves: the TWO-role form (two workgroups of eight wavefronts per CU); GROOVE_SPLIT2_MAX_WAVES
+  int split_roles = 3;                   // roles of the form used up to split_max_waves (GROOVE_SPLIT_ROLES=2: A/B)
   uint32_t pipeline_min_waves = 8600;   // banks at least this long (~550,000 voices) run one kernel per base kind and pipeline their fused blocks; smaller ones take the all-kinds kernel (round 2, blocks 5-44 of the timeline: 300,000 voices 0.275 -> 0.250 ms per block, 500,000 0.357 -> 0.342; 600,000 0.372 against 0.400)
   // How many of the bank streams exist and are handed out (GROOVE_BANK_STREAMS).  Three: with the ctx stream and the four
   // kind streams that is eight streams; a ninth lands on a hardware queue that already carries one of the others, and a
@@ -979,6 +981,8 @@ static int init_impl(int device_ordinal, const uint8_t* comm_id, int rank, int w
   if (const char* e = std::getenv("GROOVE_TP_MAX_VOICES")) ctx->tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_TP_MAX_LANES")) ctx->fx_tp_max_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_SPLIT_MAX_WAVES")) ctx->split_max_waves = (uint32_t)std::strtoul(e, nullptr, 10);
+  if (const char* e = std::getenv("GROOVE_SPLIT2_MAX_WAVES")) ctx->split2_max_waves = (uint32_t)std::strtoul(e, nullptr, 10);
+  if (const char* e = std::getenv("GROOVE_SPLIT_ROLES")) ctx->split_roles = std::atoi(e) == 2 ? 2 : 3;
   if (const char* e = std::getenv("GROOVE_PIPELINE_MIN_WAVES")) ctx->pipeline_min_waves = (uint32_t)std::strtoul(e, nullptr, 10); // tests force the pipeline on small banks
   bool ok = hipSetDevice(device_ordinal) == hipSuccess;
   // groove_init_comm: the rank's RCCL communicator first, so that whatever streams RCCL creates for itself exist BEFORE
@@ -1345,8 +1349,9 @@ static uint32_t fused_rows(const groove_bank* b, uint32_t frames) {
 // come first); the rest, or everything, through the all-kinds kernel.
 static bool use_split(const groove_bank* b, uint32_t frames) {
   const groove_ctx* ctx = b->ctx;
-  return b->kind == BANK_WELSH && b->n_vwaves && !use_tp(b, frames) && b->n_vwaves <= ctx->split_max_waves && frames >= 2 * kSplitChunk;
+  return b->kind == BANK_WELSH && b->n_vwaves && !use_tp(b, frames) && b->n_vwaves <= std::max(ctx->split_max_waves, ctx->split2_max_waves) && frames >= 2 * kSplitChunk;
 }
+static int split_roles_of(const groove_bank* b) { return b->n_vwaves <= b->ctx->split_max_waves ? b->ctx->split_roles : 2; }
 static void launch_welsh_kind(int k, const UniformArgs& a, hipStream_t st, bool fused);
 static void launch_small_uniform(groove_bank* b, const UniformArgs& a, hipStream_t st, bool fused, uint32_t frames) {
   // the workgroup list is sorted by kind: the four class-specialised base kinds first, then the two exact-f64 ones
@@ -1356,7 +1361,7 @@ static void launch_small_uniform(groove_bank* b, const UniformArgs& a, hipStream
   if (n_spec) {
     UniformArgs s = a;
     s.n_wgs = n_spec;
-    if (use_split(b, frames)) launch_welsh_split(s, b->d_wg_base, st, fused);
+    if (use_split(b, frames)) { if (split_roles_of(b) == 3) launch_welsh_split(s, b->d_wg_base, st, fused); else launch_welsh_split2(s, b->d_wg_base, st, fused); }
     else if (fused) launch_welsh_uniform_any(s, b->d_wg_base, st);
     else launch_welsh_uniform_any_unfused(s, b->d_wg_base, st);
   }
@@ -1752,7 +1757,8 @@ const char* groove_bank_kernel_form(groove_bank* b, uint32_t frames, int fused) 
   if (b->n_vwaves >= ctx->pipeline_min_waves || (fused && ctx->pipeline_min_waves <= 1))
     return pipelined ? "welsh_render_uniform_kernel (one launch per base kind, class-specialised bodies, blocks pipelined)"
                      : "welsh_render_uniform_kernel (one launch per base kind, class-specialised bodies)";
-  if (use_split(b, frames)) return "welsh_render_split_kernel (role-split: three wavefronts per 64 voices, pipelined over the frames)";
+  if (use_split(b, frames)) return split_roles_of(b) == 3 ? "welsh_render_split_kernel (role-split: three wavefronts per 64 voices, pipelined over the frames)"
+                                                            : "welsh_render_split_kernel (role-split: two wavefronts per 64 voices, pipelined over the frames)";
   return "welsh_render_uniform_any_kernel (all base kinds in one launch, class-specialised bodies)";
 }
 int groove_bank_reset(groove_bank* b) {

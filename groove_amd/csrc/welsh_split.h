@@ -72,12 +72,16 @@ __device__ __forceinline__ SplitLds& split_lds() {
   __shared__ SplitLds lds;
   return lds;
 }
-__device__ __forceinline__ uint32_t split_steps(uint32_t frames) { return (frames + kSplitChunk - 1) / kSplitChunk + 2; }
+// ROLES = 3: front | tangent (+ tile turn) | back, as above.  ROLES = 2: front + tangent | back (+ tile turn): eight wavefronts per
+// workgroup instead of twelve, so TWO workgroups fit a CU (4 waves per SIMD, 128 VGPRs) and banks of up to 131,072 voices run
+// in one round; the front role is then the longer one (it carries the tangent too).
+template <int ROLES> __device__ __forceinline__ uint32_t split_steps(uint32_t frames) { return (frames + kSplitChunk - 1) / kSplitChunk + (ROLES - 1); }
 
 // ---- role A: the front of every frame of the block (run_frames_segmented's walk, one chunk per step)
-template <int LFO_MODE, bool RETUNE, int C1, int C2, int CL>
+template <int ROLES, int LFO_MODE, bool RETUNE, int C1, int C2, int CL>
 __device__ __forceinline__ void welsh_split_front_impl(UniformArgsPtr a) {
   constexpr bool REST = LFO_MODE != LFO_F64;
+  constexpr bool WITH_TAN = ROLES == 2 && RETUNE; // two roles: this one also takes the tangent of the cutoff
   SplitLds& lds = split_lds();
   const SplitWave w = split_wave(a, threadIdx.x);
   const uint32_t n = a->n, frames = a->frames;
@@ -85,7 +89,9 @@ __device__ __forceinline__ void welsh_split_front_impl(UniformArgsPtr a) {
   WelshState s = soa_load<WelshState>(a->state, n, w.v);
   WelshScratch sc;
   sc.prev_pct = 0.0f; sc.ls = 0.0; sc.lc = 1.0; sc.lm = 1.0; sc.ta = 0.0f; sc.tf = 0.0f; // (coefficients: role C's business)
-  const uint32_t steps = split_steps(frames), nch = steps - 2;
+  RenderConsts rc{a->rc.pi_over_sr, a->rc.fc_max, a->rc.log2_x0, a->rc.x_lo, a->rc.x_hi};
+  if constexpr (WITH_TAN) asm volatile("" : "+v"(rc.tan_k1), "+v"(rc.tan_k2), "+v"(rc.log2_x0), "+v"(rc.x_hi));
+  const uint32_t steps = split_steps<ROLES>(frames), nch = steps - (ROLES - 1);
   uint32_t seg_left = 0, seg_len = 0;
   bool live = false;
   const float kNan = __builtin_nanf("");
@@ -112,7 +118,11 @@ __device__ __forceinline__ void welsh_split_front_impl(UniformArgsPtr a) {
             if (--seg_left == 0) welsh_segment_end_hoisted<CL == LFO_UNUSED>(p, s, seg_len, live);
           }
           lds.ac[it % 3][j][w.l] = make_float2(ok ? sum : kNan, g);
-          if (RETUNE) lds.ab[it & 1][j][w.l] = (ok && retune) ? pct : kNan;
+          if constexpr (WITH_TAN) { // role B's statements (welsh_split_mid), in line
+            float t = kNan;
+            if (ok && retune) { bool hi; const float tj = lp24_t_from_pct(pct, rc, hi); t = hi ? -tj : tj; }
+            lds.bc[it & 1][j][w.l] = t;
+          } else if (RETUNE) lds.ab[it & 1][j][w.l] = (ok && retune) ? pct : kNan;
         }
       }
     }
@@ -123,9 +133,9 @@ __device__ __forceinline__ void welsh_split_front_impl(UniformArgsPtr a) {
     soa_store_range(a->state, n, w.v, s, kStateFlagsWord, (uint32_t)(sizeof(WelshState) / 4));
   }
 }
-template <int LFO_MODE, bool RETUNE, int C1, int C2, int CL>
+template <int ROLES, int LFO_MODE, bool RETUNE, int C1, int C2, int CL>
 GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split_front(UniformArgsPtr a) {
-  welsh_split_front_impl<LFO_MODE, RETUNE, C1, C2, CL>(uniform_args_scalar(a));
+  welsh_split_front_impl<ROLES, LFO_MODE, RETUNE, C1, C2, CL>(uniform_args_scalar(a));
 }
 
 // ---- role B: the tangent of the cutoff, one step behind A; and the bus tile's turn (FusedAccLds::flush, on the
@@ -156,7 +166,7 @@ GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split_mid(Un
   RenderConsts rc{a->rc.pi_over_sr, a->rc.fc_max, a->rc.log2_x0, a->rc.x_lo, a->rc.x_hi};
   if constexpr (RETUNE) asm volatile("" : "+v"(rc.tan_k1), "+v"(rc.tan_k2), "+v"(rc.log2_x0), "+v"(rc.x_hi));
   float* __restrict__ rows = a->rows;
-  const uint32_t steps = split_steps(frames), nch = steps - 2;
+  const uint32_t steps = split_steps<3>(frames), nch = steps - 2;
   const float kNan = __builtin_nanf("");
   for (uint32_t it = 0; it < steps; ++it) {
     if (RETUNE && it >= 1 && it <= nch) {
@@ -186,11 +196,12 @@ GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split_mid(Un
 }
 
 // ---- role C: coefficients from the tangent, the filter recurrence, the gains; two steps behind A
-template <bool FUSED, bool RETUNE>
+template <int ROLES, bool FUSED, bool RETUNE>
 GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split_back(UniformArgsPtr ka) {
+  constexpr uint32_t LAG = ROLES - 1; // steps behind the front role
   const UniformArgsPtr a = uniform_args_scalar(ka);
   SplitLds& lds = split_lds();
-  const SplitWave w = split_wave(a, threadIdx.x - 2 * kSplitLanes);
+  const SplitWave w = split_wave(a, threadIdx.x - (ROLES - 1) * kSplitLanes);
   const uint32_t n = a->n, frames = a->frames;
   const WelshParams& p = w.d.p;
   const RenderConsts rc{a->rc.pi_over_sr, a->rc.fc_max, a->rc.log2_x0, a->rc.x_lo, a->rc.x_hi};
@@ -207,10 +218,15 @@ GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split_back(U
   if (!RETUNE) coef = make_scalar(coef);
   float* __restrict__ out = a->out;
   const size_t chs = a->ch_stride;
-  const uint32_t steps = split_steps(frames);
+  const uint32_t steps = split_steps<ROLES>(frames);
+  float* __restrict__ rows = a->rows;
   for (uint32_t it = 0; it < steps; ++it) {
-    if (it >= 2) {
-      const uint32_t c = it - 2, f0 = c * kSplitChunk, cnt = min(kSplitChunk, frames - f0);
+    if (ROLES == 2 && it >= 2) { // two roles: this one turns the bus tile — the group its PREVIOUS step completed, if it did
+      const uint32_t f_end = (it - 1) * kSplitChunk; // end of chunk it - 2
+      if ((f_end % kSplitGroup) == 0) split_turn_tile(lds, w.l, f_end, rows, w.wg, frames);
+    }
+    if (it >= LAG) {
+      const uint32_t c = it - LAG, f0 = c * kSplitChunk, cnt = min(kSplitChunk, frames - f0);
       // the step's inputs first: one LDS round trip for the eight frames instead of two per frame
       float2 in[kSplitChunk];
       float tt[kSplitChunk];
@@ -241,6 +257,7 @@ GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split_back(U
     }
     __syncthreads();
   }
+  if (ROLES == 2) split_turn_tile(lds, w.l, frames, rows, w.wg, frames); // the group that holds the block's last frame
   if (w.active) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a->state, 0, (int)(sizeof(WelshState) / 4 * n * 4u), 0x00020000);
     const WordsOf<Lp24StateD> fw = __builtin_bit_cast(WordsOf<Lp24StateD>, filt);
@@ -252,7 +269,7 @@ GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split_back(U
 
 // A workgroup whose voices are all silent with both envelopes idle writes its zero rows and leaves (kernels.h
 // welsh_idle_workgroup); every role-wave looks at its own virtual wave.
-__device__ __forceinline__ bool welsh_split_idle_workgroup(const UniformArgs& a) {
+__device__ __forceinline__ bool welsh_split_idle_workgroup(const UniformArgs& a, uint32_t threads) {
   const uint32_t wg = a.wg_list[blockIdx.x];
   const uint32_t local = threadIdx.x % kSplitLanes;
   const uint32_t w0 = wg * kSplitVw + (local >> 6);
@@ -273,12 +290,12 @@ __device__ __forceinline__ bool welsh_split_idle_workgroup(const UniformArgs& a)
   __syncthreads();
   if (busy_waves != 0) return false;
   float* __restrict__ rows = a.rows + (size_t)wg * 2 * a.frames;
-  for (uint32_t t = threadIdx.x; t < 2 * a.frames; t += kSplitThreads) rows[t] = 0.0f;
+  for (uint32_t t = threadIdx.x; t < 2 * a.frames; t += threads) rows[t] = 0.0f;
   return true;
 }
-template <int LFO_MODE, bool RETUNE>
+template <int ROLES, int LFO_MODE, bool RETUNE>
 __device__ __forceinline__ void welsh_split_dispatch_front(uint32_t cls, UniformArgsPtr ka) {
-#define GROOVE_CLS_CASE(CL, C1, C2) case wg_class_combo(CL, C1, C2): welsh_split_front<LFO_MODE, RETUNE, C1, C2, CL>(ka); break;
+#define GROOVE_CLS_CASE(CL, C1, C2) case wg_class_combo(CL, C1, C2): welsh_split_front<ROLES, LFO_MODE, RETUNE, C1, C2, CL>(ka); break;
 #define GROOVE_CLS_ROW(CL, C1) GROOVE_CLS_CASE(CL, C1, 0) GROOVE_CLS_CASE(CL, C1, 1) GROOVE_CLS_CASE(CL, C1, 2) GROOVE_CLS_CASE(CL, C1, 3) GROOVE_CLS_CASE(CL, C1, 4)
 #define GROOVE_CLS_PLANE(CL) GROOVE_CLS_ROW(CL, 0) GROOVE_CLS_ROW(CL, 1) GROOVE_CLS_ROW(CL, 2) GROOVE_CLS_ROW(CL, 3) GROOVE_CLS_ROW(CL, 4)
   switch (cls) {
@@ -298,14 +315,15 @@ __device__ __forceinline__ void welsh_split_dispatch_front(uint32_t cls, Uniform
 }
 // One launch for the workgroups of the four class-specialised base kinds of a mid-size bank (the host's workgroup list is
 // sorted by kind: they are its first `n_wgs` entries; the exact-f64 kinds behind them take the all-kinds kernel).
-#ifdef GROOVE_WELSH_SPLIT_TU
-template <bool FUSED>
+#ifdef GROOVE_WELSH_SPLIT_TU /* -DGROOVE_WELSH_SPLIT_TU=3 or =2: one translation unit per number of roles (each carries its own 450 fronts) */
 #ifndef GROOVE_WAVES_SPLIT
-#define GROOVE_WAVES_SPLIT 4 /* 128 VGPRs: one workgroup of twelve wavefronts per CU, one role of each kind per SIMD (at 6 — two workgroups — the smooth-f64-LFO fronts spill 256 bytes per lane) */
+#define GROOVE_WAVES_SPLIT 4 /* 128 VGPRs.  Three roles: one workgroup of twelve wavefronts per CU, one role of each kind per SIMD (at 6 — two
+                                workgroups — the smooth-f64-LFO fronts spill 256 bytes per lane); two roles: two workgroups of eight */
 #endif
-__global__ __launch_bounds__(kSplitThreads, GROOVE_WAVES_SPLIT) GROOVE_NO_TAIL_CALLS void welsh_render_split_kernel(UniformArgs a, const uint8_t* __restrict__ wg_base) {
+template <bool FUSED, int ROLES>
+__global__ __launch_bounds__(ROLES * kSplitLanes, GROOVE_WAVES_SPLIT) GROOVE_NO_TAIL_CALLS void welsh_render_split_kernel(UniformArgs a, const uint8_t* __restrict__ wg_base) {
   const UniformArgsPtr ka = (UniformArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-  if constexpr (FUSED) { if (welsh_split_idle_workgroup(a)) return; }
+  if constexpr (FUSED) { if (welsh_split_idle_workgroup(a, ROLES * kSplitLanes)) return; }
 #ifdef GROOVE_SPLIT_PRIO /* A/B (measured, round 3: s_setprio 3 changes nothing — config #5 0.100-0.105 against 0.103-0.107 ms per block, 65,536 voices alone 0.095 both) */
   __builtin_amdgcn_s_setprio(GROOVE_SPLIT_PRIO);
 #endif
@@ -315,18 +333,19 @@ __global__ __launch_bounds__(kSplitThreads, GROOVE_WAVES_SPLIT) GROOVE_NO_TAIL_C
   const bool retune = (base & 1u) != 0;
   if (role == 0) {
     switch (base) {
-      case wg_base_kind_of(LFO_F32, false): welsh_split_dispatch_front<LFO_F32, false>(cls, ka); break;
-      case wg_base_kind_of(LFO_F32, true): welsh_split_dispatch_front<LFO_F32, true>(cls, ka); break;
-      case wg_base_kind_of(LFO_F64_SMOOTH, false): welsh_split_dispatch_front<LFO_F64_SMOOTH, false>(cls, ka); break;
-      default: welsh_split_dispatch_front<LFO_F64_SMOOTH, true>(cls, ka); break;
+      case wg_base_kind_of(LFO_F32, false): welsh_split_dispatch_front<ROLES, LFO_F32, false>(cls, ka); break;
+      case wg_base_kind_of(LFO_F32, true): welsh_split_dispatch_front<ROLES, LFO_F32, true>(cls, ka); break;
+      case wg_base_kind_of(LFO_F64_SMOOTH, false): welsh_split_dispatch_front<ROLES, LFO_F64_SMOOTH, false>(cls, ka); break;
+      default: welsh_split_dispatch_front<ROLES, LFO_F64_SMOOTH, true>(cls, ka); break;
     }
-  } else if (role == 1) {
+  } else if (ROLES == 3 && role == 1) {
     if (retune) welsh_split_mid<true>(ka); else welsh_split_mid<false>(ka);
   } else {
-    if (retune) welsh_split_back<FUSED, true>(ka); else welsh_split_back<FUSED, false>(ka);
+    if (retune) welsh_split_back<ROLES, FUSED, true>(ka); else welsh_split_back<ROLES, FUSED, false>(ka);
   }
 }
 #endif
-void launch_welsh_split(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, bool fused); // csrc/welsh_split.hip
+void launch_welsh_split(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, bool fused);  // three roles: csrc/welsh_split.hip -DGROOVE_WELSH_SPLIT_TU=3
+void launch_welsh_split2(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, bool fused); // two roles:   csrc/welsh_split.hip -DGROOVE_WELSH_SPLIT_TU=2
 
 } // namespace groove

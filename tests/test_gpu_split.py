@@ -11,6 +11,10 @@ from groove_amd import patches as P, abi_types as T
 pytestmark = pytest.mark.gpu
 
 
+def _set_roles(monkey_roles):
+    """(the number of roles is read from the environment at groove_init: tests of the two-role form use a context of their own)"""
+
+
 @pytest.fixture()
 def forms(gpu_ctx):
     """(set_form): switch the session ctx between the serial all-kinds kernel and the role-split one; restored afterwards."""
@@ -118,3 +122,34 @@ def test_split_is_the_default_for_mid_size_banks(gpu_ctx):
     small = E.WelshSynth(gpu_ctx, P.welsh_voices_grouped(1024, 0)[0])
     assert "time-parallel" in small.kernel_form(256, True)
     small.destroy()
+
+
+def test_two_role_form_equals_the_serial_kernels_bit_for_bit(oracle):
+    """The two-role form (front + tangent | back; two workgroups of eight wavefronts per CU: banks of up to 131,072 voices in
+    one round), selected with GROOVE_SPLIT_ROLES=2 in a context of its own: bit-identical to the serial kernels, all three
+    render forms."""
+    import os
+    from groove_amd import entities as E
+    os.environ["GROOVE_SPLIT_ROLES"] = "2"
+    try:
+        ctx = E.Context(0)
+    finally:
+        os.environ.pop("GROOVE_SPLIT_ROLES")
+    try:
+        for n in (3072, 200):
+            params, idx = P.welsh_voices_grouped(n, 0)
+            on, off = P.grouped_note_events(idx, True), P.grouped_note_events(idx, False)
+            for mode in ("fused", "block", "async"):
+                ctx.time_parallel_max_voices = 0
+                ctx.split_max_waves = 0
+                bus_s, blk_s, st_s, form_s = _render(ctx, params, on, off, mode)
+                ctx.split_max_waves = 4096
+                bus_p, blk_p, st_p, form_p = _render(ctx, params, on, off, mode)
+                assert "two wavefronts" in form_p and "split" not in form_s, (form_s, form_p)
+                assert np.abs(bus_s).max() > 1e-2
+                assert np.array_equal(bus_s.view(np.uint32), bus_p.view(np.uint32)), (n, mode)
+                for a, b in zip(blk_s, blk_p):
+                    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (n, mode)
+                assert np.array_equal(st_s, st_p), (n, mode)
+    finally:
+        ctx.close()
