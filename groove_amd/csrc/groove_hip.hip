@@ -173,7 +173,7 @@ struct groove_ctx {
   // the ROLE-SPLIT kernel (welsh_split.h: three wavefronts per 64 voices, pipelined over the block's frames) for banks of up
   // to this many virtual waves; 0 = never.  GROOVE_SPLIT_MAX_WAVES / groove_set_split_max_waves.
   uint32_t split_max_waves = 1024;      // 65,536 voices = one workgroup (twelve wavefronts) per CU; measured (round 3, blocks 5-24): 20,000 voices 0.120 -> 0.090 ms per block, 32,768 0.119 -> 0.090, 65,536 0.123 -> 0.095; 80,000 (a second round of workgroups) 0.135 -> 0.153: not above
-  uint32_t split2_max_waves = 0;         // banks above split_max_waves and up to this many virtual waves: the TWO-role form (two workgroups of eight wavefronts per CU); GROOVE_SPLIT2_MAX_WAVES
+  uint32_t split2_max_waves = 2048;      // banks above split_max_waves and up to this many virtual waves (131,072 voices): the TWO-role form, front + tangent | back — two workgroups of eight wavefronts per CU, so one round still; measured (blocks 5-24): 100,000 voices 0.1385 -> 0.134 ms per block, 125,000 0.145 -> 0.137 (three roles there: 0.164 / 0.165; two roles at 65,536: 0.106 against three roles' 0.095).  GROOVE_SPLIT2_MAX_WAVES
   int split_roles = 3;                   // roles of the form used up to split_max_waves (GROOVE_SPLIT_ROLES=2: A/B)
   uint32_t pipeline_min_waves = 8600;   // banks at least this long (~550,000 voices) run one kernel per base kind and pipeline their fused blocks; smaller ones take the all-kinds kernel (round 2, blocks 5-44 of the timeline: 300,000 voices 0.275 -> 0.250 ms per block, 500,000 0.357 -> 0.342; 600,000 0.372 against 0.400)
   // How many of the bank streams exist and are handed out (GROOVE_BANK_STREAMS).  Three: with the ctx stream and the four

@@ -84,7 +84,8 @@ uint32_t groove_pipeline_min_waves(groove_ctx* ctx);
 /* Tuning: Welsh banks of up to this many (virtual) wavefronts that are too big for the time-parallel form render ROLE-SPLIT:
  * three wavefronts per 64 voices — front (envelopes, LFO, oscillators), cutoff tangent, filter + gains — pipelined over the
  * block's frames through LDS, so that a bank which cannot fill the chip with voices fills it with the parts of a voice's
- * frame (csrc/welsh_split.h).  Same results bit for bit as the serial kernels.  Default 1,024 (65,536 voices: one workgroup per CU);
+ * frame (csrc/welsh_split.h).  Same results bit for bit as the serial kernels.  Default 1,024 (65,536 voices: one workgroup per CU;
+ * banks of up to twice that take a two-role form of the same kernel, two workgroups per CU: GROOVE_SPLIT2_MAX_WAVES);
  * 0 = never.  GROOVE_SPLIT_MAX_WAVES in the environment sets it at groove_init.  No reference counterpart. */
 int groove_set_split_max_waves(groove_ctx* ctx, uint32_t waves);
 uint32_t groove_split_max_waves(groove_ctx* ctx);

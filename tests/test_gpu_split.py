@@ -11,10 +11,6 @@ from groove_amd import patches as P, abi_types as T
 pytestmark = pytest.mark.gpu
 
 
-def _set_roles(monkey_roles):
-    """(the number of roles is read from the environment at groove_init: tests of the two-role form use a context of their own)"""
-
-
 @pytest.fixture()
 def forms(gpu_ctx):
     """(set_form): switch the session ctx between the serial all-kinds kernel and the role-split one; restored afterwards."""
@@ -116,7 +112,10 @@ def test_split_is_the_default_for_mid_size_banks(gpu_ctx):
     assert "split" in s.kernel_form(256, True) and "split" in s.kernel_form(256, False)
     assert "split" not in s.kernel_form(4, True)            # a handful of frames: nothing to pipeline
     s.destroy()
-    big = E.WelshSynth(gpu_ctx, P.welsh_voices_grouped(80_000, 0)[0])   # a second round of workgroups would cost more than the split saves
+    mid = E.WelshSynth(gpu_ctx, P.welsh_voices_grouped(80_000, 0)[0])   # above one twelve-wave workgroup per CU: the two-role form (two of eight)
+    assert "two wavefronts" in mid.kernel_form(256, True)
+    mid.destroy()
+    big = E.WelshSynth(gpu_ctx, P.welsh_voices_grouped(200_000, 0)[0])  # a second round of workgroups would cost more than the split saves
     assert "split" not in big.kernel_form(256, True)
     big.destroy()
     small = E.WelshSynth(gpu_ctx, P.welsh_voices_grouped(1024, 0)[0])
