@@ -1349,6 +1349,7 @@ static uint32_t fused_rows(const groove_bank* b, uint32_t frames) {
 // come first); the rest, or everything, through the all-kinds kernel.
 static bool use_split(const groove_bank* b, uint32_t frames) {
   const groove_ctx* ctx = b->ctx;
+  if (ctx->split_max_waves == 0) return false; // "never" switches both forms off
   return b->kind == BANK_WELSH && b->n_vwaves && !use_tp(b, frames) && b->n_vwaves <= std::max(ctx->split_max_waves, ctx->split2_max_waves) && frames >= 2 * kSplitChunk;
 }
 static int split_roles_of(const groove_bank* b) { return b->n_vwaves <= b->ctx->split_max_waves ? b->ctx->split_roles : 2; }
