@@ -618,7 +618,7 @@ def bench_workload(ctx, workload, sel, K, W, repeats, fused=True, grouped=True, 
     proj = PJ.Project(ctx, workload, sel, fused=fused, grouped=grouped, render_ahead=render_ahead, head_ahead=head_ahead)
     forms = sorted({inst.kernel_form(FRAMES, fused and not fx) for inst, _, fx, _ in proj.banks})
     bus = ctx.bus((K + W) * FRAMES)
-    span_mode = (fused and wl["kind"] != "chain") or (wl["kind"] == "chain" and render_ahead)
+    span_mode = (fused and wl["kind"] != "chain") or (render_ahead and (wl["kind"] == "chain" or not fused))
     walls, kerns = time_project(ctx, proj, bus, K, W, repeats, span_mode, dist)
     out_bus = bus.download()[W * FRAMES:] if (dist is None or dist.rank == 0) else None
     proj.destroy()
@@ -658,7 +658,8 @@ def form_entry(ctx, label, K, W, fused, grouped, note):
     ms = m["walls"][0] / K * 1e3
     byts = WORKLOADS["welsh-1m"]["bytes_per_vf"] * V * FRAMES
     fps = K * FRAMES / m["walls"][0]
-    return {"workload": label, "voices": V, "blocks_timed": f"{W}..{W + K - 1}", "note": note, "kernel_form": m["kernel_form"],
+    return {"workload": label, "voices": V, "blocks_timed": f"{W}..{W + K - 1}", "note": note + "; renders submitted with groove_bank_render_async, three blocks in rotation",
+            "kernel_form": m["kernel_form"],
             "ms_per_step": ms, "value": fps, "unit": "stereo frames/s", "x_realtime_44k1": fps / SR,
             "frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "frac_is": "algorithmic 18 B per voice-frame / time; in this form 16 of the 18 bytes are really moved (block written, state in and out; the mix reads the render's row sums)"}

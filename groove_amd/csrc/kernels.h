@@ -273,8 +273,14 @@ __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n
     else acc.add(L, R, f);
     if ((f & (C - 1)) == C - 1) acc.flush(rows, frames, f - (C - 1), C, row_out, ch_stride, n, row_base);
     if (!FUSED && !by_rows && active) {
+#if defined(GROOVE_STORE_PROBE) /* timing probes only (results are wrong): 1 = every frame into the block's first 8 rows (the stores stay in cache), 2 = left channel only */
+      const uint32_t fp = GROOVE_STORE_PROBE == 1 ? (f & 7u) : f;
+      block_store(out + (size_t)fp * n + v, L);
+      if (GROOVE_STORE_PROBE != 2) block_store(out + ch_stride + (size_t)fp * n + v, R);
+#else
       block_store(out + (size_t)f * n + v, L);
       block_store(out + ch_stride + (size_t)f * n + v, R);
+#endif
     }
   };
   {

@@ -144,6 +144,11 @@ class Project:
             self.banks.append((inst, block, fx, spec["events"]))
         self.dominant = self.banks[0][0] if self.banks else None
         self.has_chain = any(fx for _, _, fx, _ in self.banks)
+        # the entity-boundary (materialised) form takes the render-ahead walk too: with the renders on the side streams and
+        # three blocks per instrument in rotation, the per-kind kernels of consecutive blocks follow each other on their
+        # streams the way the fused path's do — one block alone costs its thinly occupied tail (0.70 against 0.54 ms at
+        # 1,000,000 voices)
+        self.ahead_walk = self.render_ahead and (self.has_chain or not fused)
 
     def reset(self):
         """Back to block 0 of the timeline with every voice and effect in its initial state."""
@@ -206,7 +211,7 @@ class Project:
     def step(self, bus, frame0, ev_pair=None):
         """One block: every instrument renders, its effect chain runs, the mix bus sums."""
         ctx = self.ctx
-        if self.render_ahead and self.has_chain:
+        if self.ahead_walk:
             return self._step_render_ahead(bus, frame0, ev_pair)
         self._events(self.block_index)
         self.block_index += 1
