@@ -426,6 +426,41 @@ GROOVE_HD Lp24CoefD lp24_coefd_from_t(const Lp24Consts& c, float t, bool hi) {
   }
   return d;
 }
+// lp24_coefd_from_t in two halves again (the four-role kernel): the fp32 quotients, and their widening.  Same operations on the
+// same values: lp24_coefd_from_q(lp24_coefq_from_t(c, t, hi), hi) == lp24_coefd_from_t(c, t, hi) bit for bit.
+struct Lp24CoefQ { float ba, qa, bb, qb, pa, pb; }; // per section: b0 (upper side: 1 / D'), q2, and on the upper side P / D'
+GROOVE_HD Lp24CoefQ lp24_coefq_from_t(const Lp24Consts& c, float t, bool hi) {
+  const float T2 = t * t;
+  const float dta = c.d1 * t, dtb = c.d3 * t;
+  Lp24CoefQ q;
+  if (!hi) {
+    const float ia = fast_rcp(c.c0 + dta + T2);
+    const float ib = fast_rcp(c.c2 + dtb + T2);
+    q.ba = T2 * ia; q.qa = (dta + dta) * ia; q.pa = 0.0f;
+    q.bb = T2 * ib; q.qb = (dtb + dtb) * ib; q.pb = 0.0f;
+  } else {
+    const float Pa = c.c0 * T2, Pb = c.c2 * T2;
+    const float ia = fast_rcp(1.0f + dta + Pa);
+    const float ib = fast_rcp(1.0f + dtb + Pb);
+    q.ba = ia; q.qa = (dta + dta) * ia; q.pa = Pa * ia;
+    q.bb = ib; q.qb = (dtb + dtb) * ib; q.pb = Pb * ib;
+  }
+  return q;
+}
+GROOVE_HD Lp24CoefD lp24_coefd_from_q(const Lp24CoefQ& q, bool hi) {
+  Lp24CoefD d;
+  const double q2a = (double)q.qa, q2b = (double)q.qb;
+  if (!hi) {
+    const double b0a = (double)q.ba, b0b = (double)q.bb;
+    d.b0a = b0a; d.a1a = fma(-4.0, b0a, 2.0 - q2a); d.a2a = q2a - 1.0;
+    d.b0b = b0b; d.a1b = fma(-4.0, b0b, 2.0 - q2b); d.a2b = q2b - 1.0;
+  } else {
+    const double pa = (double)q.pa, pb = (double)q.pb;
+    d.b0a = (double)q.ba; d.a1a = fma(4.0, pa, q2a - 2.0); d.a2a = q2a - 1.0;
+    d.b0b = (double)q.bb; d.a1b = fma(4.0, pb, q2b - 2.0); d.a2b = q2b - 1.0;
+  }
+  return d;
+}
 GROOVE_HD Lp24CoefD lp24_coefd_from_pct(const Lp24Consts& c, float pct, const RenderConsts& rc) {
   bool hi;
   const float t = lp24_t_from_pct(pct, rc, hi);
@@ -758,6 +793,126 @@ GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScrat
   a = s.amp.value;
   if (r_amp) a *= fmaf(lfo, p.lfo_depth, 1.0f);
   return true;
+}
+// FRONT once more, in two halves, for the four-role kernel of welsh_split.h, which runs them on different wavefronts.
+// The statements are welsh_frame_front's (not exact-f64 LFO kinds: LFO_F32 and LFO_F64_SMOOTH only), each on the same values
+// in the same order within its half, so CTL + OSC give FRONT's results bit for bit (tests/emul: test_emul_numerics.py;
+// tests/test_gpu_split.py on the device):
+//   CTL  the two envelopes and the LFO -> the gain `a`, the cutoff percent, and `mod`: what the LFO does to the oscillators'
+//        edges (pitch routing: the factor on their increments; pulse-width routing: LFO value x depth).  Owns the state's
+//        envelope, LFO and flag words.  `first` = the voice's first tick after a note-on (FIRST frames only).
+//   OSC  the two oscillators, hard sync, their mix.  Owns the oscillators' words; reads the base increments.
+template <bool FIRST, bool RETUNE, int LFO_MODE, int CL, bool SEGMENT = false, bool HOIST = false>
+GROOVE_HD bool welsh_frame_ctl(const WelshParams& p, WelshState& s, WelshScratch& sc, float& a, float& pct, bool& retune, double& mod, bool& first) {
+  static_assert(LFO_MODE != LFO_F64, "the exact-f64 kinds keep the whole frame on one wavefront");
+  static_assert(!HOIST || (SEGMENT && !FIRST), "hoisted counters belong to a segment");
+  if (SEGMENT && HOIST) {
+    const float ta = sc.ta * s.amp.inv_len, tf = sc.tf * s.fil.inv_len;
+    s.amp.value = fmaf(s.amp.D, fmaf(-ta, ta, 2.0f * ta), s.amp.A);
+    s.fil.value = fmaf(s.fil.D, fmaf(-tf, tf, 2.0f * tf), s.fil.A);
+    sc.ta += 1.0f; sc.tf += 1.0f;
+  } else if (SEGMENT) {
+    env_advance(s.amp);
+    env_advance(s.fil);
+  } else {
+    env_tick(s.amp, p.amp);
+    env_tick(s.fil, p.fil);
+    if (s.amp.state == ENV_IDLE) return false;
+  }
+  const uint32_t wl = CL == LFO_UNUSED ? (uint32_t)GROOVE_WAVE_NONE : osc_class_wave<CL>((p.flags >> WF_LFO_WAVE_SHIFT) & 15u);
+  constexpr bool NO_LFO = CL == LFO_UNUSED;
+  constexpr bool AMP_ONLY = !NO_LFO && CL != OSC_ANY && LFO_MODE == LFO_F32 && !RETUNE;
+  constexpr bool EDGE_ONLY = LFO_MODE == LFO_F64_SMOOTH;
+  const uint32_t fl = p.flags;
+  const bool r_edge = EDGE_ONLY && !NO_LFO;
+  const bool r_amp = NO_LFO || EDGE_ONLY ? false : (AMP_ONLY ? true : (fl & WF_LFO_AMP) != 0);
+  const bool r_cut = NO_LFO || EDGE_ONLY || AMP_ONLY || !RETUNE ? false : (fl & WF_LFO_CUTOFF) != 0;
+  first = FIRST && (s.vflags & VF_FIRST);
+  if (FIRST) s.vflags = 0;
+  if (!first && !(HOIST && NO_LFO)) s.lfo.phase += p.lfo_inc;
+  float nzl = 0.0f;
+  if (wl == GROOVE_WAVE_NOISE) nzl = noise_tick(s.lfo);
+  const uint64_t half = 0x8000000000000000ull;
+  float lfo = 0.0f;
+  mod = 0.0;
+  if (r_edge) {
+    double l;
+    if (!FIRST && wl == GROOVE_WAVE_SINE) {
+      l = sc.ls + fma(p.lfo_rs, sc.lc, -(p.lfo_rk * sc.ls));
+      sc.lc = sc.lc - fma(p.lfo_rs, sc.ls, p.lfo_rk * sc.lc);
+    } else {
+      l = osc_value_f64(wl, s.lfo.phase, half, nzl);
+      if (FIRST && wl == GROOVE_WAVE_SINE)
+        sc.lc = sin_turns_folded_f64((double)fold_quarter64((int64_t)(s.lfo.phase + 0x4000000000000000ull)) * 5.42101086242752217004e-20);
+    }
+    if (fl & WF_LFO_PITCH) {
+      double m;
+      if (!FIRST) m = sc.lm * exp_tiny_f64((l - sc.ls) * p.lfo_a);
+      else m = exp2_small_f64(l * (double)p.lfo_depth);
+      sc.lm = m;
+      mod = m;
+    } else {
+      mod = l * (double)p.lfo_depth;
+    }
+    sc.ls = l;
+    lfo = (float)l;
+  } else if (r_amp || r_cut) {
+    lfo = osc_value(wl, s.lfo.phase, half, nzl);
+  }
+  retune = false;
+  pct = 0.0f;
+  if (RETUNE) {
+    if (CL == LFO_UNUSED || (p.flags & WF_RETUNE_ENV)) {
+      pct = fmaf((1.0f - p.cutoff_start) * p.cutoff_end, s.fil.value, p.cutoff_start);
+      retune = true;
+    } else if (r_cut) {
+      pct = p.cutoff_start * fmaf(lfo, p.lfo_depth, 1.0f);
+      retune = true;
+    }
+  }
+  a = s.amp.value;
+  if (r_amp) a *= fmaf(lfo, p.lfo_depth, 1.0f);
+  return true;
+}
+// (`edge`: the LFO reaches the oscillators — every wavefront of an LFO_F64_SMOOTH kind whose LFO class is not LFO_UNUSED.)
+template <int LFO_MODE, int C1, int C2, bool REST>
+GROOVE_HD float welsh_frame_osc(const WelshParams& p, WelshState& s, bool edge, double mod, bool first) {
+  const uint32_t w1 = osc_class_wave<C1>((p.flags >> WF_O1_WAVE_SHIFT) & 15u), w2 = osc_class_wave<C2>((p.flags >> WF_O2_WAVE_SHIFT) & 15u);
+  const uint32_t fl = p.flags;
+  uint64_t inc1 = s.o1_inc, inc2 = s.o2_inc;
+  uint64_t d1 = p.o1_duty64, d2 = p.o2_duty64;
+  if (LFO_MODE == LFO_F64_SMOOTH && edge) {
+    if (fl & WF_LFO_PITCH) {
+      if (fl & WF_LFO_O1) inc1 = f64_to_u64((double)inc1 * mod);
+      if (fl & WF_LFO_O2) inc2 = f64_to_u64((double)inc2 * mod);
+    } else {
+      if (fl & WF_LFO_O1) d1 = f64_to_u64(clamp01d((double)p.o1_duty * (1.0 + mod)) * 18446744073709549568.0);
+      if (fl & WF_LFO_O2) d2 = f64_to_u64(clamp01d((double)p.o2_duty * (1.0 + mod)) * 18446744073709549568.0);
+    }
+  }
+  bool wrapped = false;
+  if (!first) {
+    const uint64_t np = s.o1.phase + inc1;
+    wrapped = np < s.o1.phase;
+    s.o1.phase = np;
+  }
+  float nz1 = 0.0f, nz2 = 0.0f;
+  if (w1 == GROOVE_WAVE_NOISE) nz1 = noise_tick(s.o1);
+  {
+    uint64_t ph2 = s.o2.phase;
+    if (!first) ph2 += inc2;
+    if (fl & WF_SYNC) {
+      if (wrapped) ph2 = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" : "+v"(ph2));
+#endif
+    }
+    s.o2.phase = ph2;
+  }
+  if (w2 == GROOVE_WAVE_NOISE) nz2 = noise_tick(s.o2);
+  const float v1 = osc_value_classed<C1, REST>(w1, s.o1.phase, d1, nz1);
+  const float v2 = osc_value_classed<C2, REST>(w2, s.o2.phase, d2, nz2);
+  return fmaf(v1, p.mix, v2 * (1.0f - p.mix));
 }
 template <bool RETUNE, int LFO_MODE, int CL>
 GROOVE_HD void welsh_frame_coef(const WelshParams& p, const RenderConsts& rc, WelshScratch& sc, float pct, bool retune, float lfo) {

@@ -174,7 +174,9 @@ struct groove_ctx {
   // to this many virtual waves; 0 = never.  GROOVE_SPLIT_MAX_WAVES / groove_set_split_max_waves.
   uint32_t split_max_waves = 1024;      // 65,536 voices = one workgroup (twelve wavefronts) per CU; measured (round 3, blocks 5-24): 20,000 voices 0.120 -> 0.090 ms per block, 32,768 0.119 -> 0.090, 65,536 0.123 -> 0.095; 80,000 (a second round of workgroups) 0.135 -> 0.153: not above
   uint32_t split2_max_waves = 2048;      // banks above split_max_waves and up to this many virtual waves (131,072 voices): the TWO-role form, front + tangent | back — two workgroups of eight wavefronts per CU, so one round still; measured (blocks 5-24): 100,000 voices 0.1385 -> 0.134 ms per block, 125,000 0.145 -> 0.137 (three roles there: 0.164 / 0.165; two roles at 65,536: 0.106 against three roles' 0.095).  GROOVE_SPLIT2_MAX_WAVES
-  int split_roles = 3;                   // roles of the form used up to split_max_waves (GROOVE_SPLIT_ROLES=2: A/B)
+  int split_roles = 4;                   // roles of the form used up to split_max_waves: four (ctl | osc | tangent + quotients | back), measured against three
+                                         // (front | tangent | back) in one job: 32,768 voices 0.0830 against 0.0888 ms per block, 65,536 0.0846-0.0855 against
+                                         // 0.0903, config #5 0.1003-0.1008 against 0.0999-0.1001.  GROOVE_SPLIT_ROLES=3 / 2: A/B
   uint32_t pipeline_min_waves = 8600;   // banks at least this long (~550,000 voices) run one kernel per base kind and pipeline their fused blocks; smaller ones take the all-kinds kernel (round 2, blocks 5-44 of the timeline: 300,000 voices 0.275 -> 0.250 ms per block, 500,000 0.357 -> 0.342; 600,000 0.372 against 0.400)
   // How many of the bank streams exist and are handed out (GROOVE_BANK_STREAMS).  Three: with the ctx stream and the four
   // kind streams that is eight streams; a ninth lands on a hardware queue that already carries one of the others, and a
@@ -982,7 +984,7 @@ static int init_impl(int device_ordinal, const uint8_t* comm_id, int rank, int w
   if (const char* e = std::getenv("GROOVE_FX_TP_MAX_LANES")) ctx->fx_tp_max_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_SPLIT_MAX_WAVES")) ctx->split_max_waves = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_SPLIT2_MAX_WAVES")) ctx->split2_max_waves = (uint32_t)std::strtoul(e, nullptr, 10);
-  if (const char* e = std::getenv("GROOVE_SPLIT_ROLES")) ctx->split_roles = std::atoi(e) == 2 ? 2 : 3;
+  if (const char* e = std::getenv("GROOVE_SPLIT_ROLES")) { const int r = std::atoi(e); ctx->split_roles = r == 2 || r == 4 ? r : 3; }
   if (const char* e = std::getenv("GROOVE_PIPELINE_MIN_WAVES")) ctx->pipeline_min_waves = (uint32_t)std::strtoul(e, nullptr, 10); // tests force the pipeline on small banks
   bool ok = hipSetDevice(device_ordinal) == hipSuccess;
   // groove_init_comm: the rank's RCCL communicator first, so that whatever streams RCCL creates for itself exist BEFORE
@@ -1362,7 +1364,12 @@ static void launch_small_uniform(groove_bank* b, const UniformArgs& a, hipStream
   if (n_spec) {
     UniformArgs s = a;
     s.n_wgs = n_spec;
-    if (use_split(b, frames)) { if (split_roles_of(b) == 3) launch_welsh_split(s, b->d_wg_base, st, fused); else launch_welsh_split2(s, b->d_wg_base, st, fused); }
+    if (use_split(b, frames)) {
+      const int roles = split_roles_of(b);
+      if (roles == 4) launch_welsh_split4(s, b->d_wg_base, st, fused);
+      else if (roles == 3) launch_welsh_split(s, b->d_wg_base, st, fused);
+      else launch_welsh_split2(s, b->d_wg_base, st, fused);
+    }
     else if (fused) launch_welsh_uniform_any(s, b->d_wg_base, st);
     else launch_welsh_uniform_any_unfused(s, b->d_wg_base, st);
   }
@@ -1758,6 +1765,7 @@ const char* groove_bank_kernel_form(groove_bank* b, uint32_t frames, int fused) 
   if (b->n_vwaves >= ctx->pipeline_min_waves || (fused && ctx->pipeline_min_waves <= 1))
     return pipelined ? "welsh_render_uniform_kernel (one launch per base kind, class-specialised bodies, blocks pipelined)"
                      : "welsh_render_uniform_kernel (one launch per base kind, class-specialised bodies)";
+  if (use_split(b, frames) && split_roles_of(b) == 4) return "welsh_render_split4_kernel (role-split: four wavefronts per 64 voices, pipelined over the frames)";
   if (use_split(b, frames)) return split_roles_of(b) == 3 ? "welsh_render_split_kernel (role-split: three wavefronts per 64 voices, pipelined over the frames)"
                                                             : "welsh_render_split_kernel (role-split: two wavefronts per 64 voices, pipelined over the frames)";
   return "welsh_render_uniform_any_kernel (all base kinds in one launch, class-specialised bodies)";

@@ -60,9 +60,35 @@ static void welsh_emul_split_frame3(const WelshParams& p, WelshState& s, const R
     welsh_frame_back<false>(p, s.filt, coef, ac_sum, g, L, R);
   }
 }
+// The four-role form: the front in two halves (welsh_frame_ctl: envelopes and LFO -> gain, percent, `mod`; welsh_frame_osc:
+// the oscillators), role B also takes the fp32 quotients of the coefficients (lp24_coefq_from_t), role C widens them.
+template <bool FIRST, bool RETUNE, int MODE, bool SEG>
+static void welsh_emul_split_frame4(const WelshParams& p, WelshState& s, const RenderConsts& rc, WelshScratch& sc, Lp24CoefD& coef, float& L, float& R) {
+  const float kNan = __builtin_nanf("");
+  float g = 0.0f, pct = 0.0f;
+  double mod = 0.0;
+  bool retune = false, first = false;
+  const bool ok = welsh_frame_ctl<FIRST, RETUNE, MODE, OSC_ANY, SEG, SEG>(p, s, sc, g, pct, retune, mod, first);          // role A1
+  const float ab_pct = (RETUNE && ok && retune) ? pct : kNan;
+  const float ac_sum = ok ? welsh_frame_osc<MODE, OSC_ANY, OSC_ANY, false>(p, s, MODE == LFO_F64_SMOOTH, mod, first) : kNan; // role A2
+  Lp24CoefQ q{kNan, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};                                                                          // role B
+  bool hi = false;
+  if (RETUNE && ab_pct == ab_pct) { const float t = lp24_t_from_pct(ab_pct, rc, hi); q = lp24_coefq_from_t(p.fc, t, hi); if (hi) q.qa = -q.qa; }
+  L = 0.0f; R = 0.0f;                                                                                                        // role C
+  if (ac_sum == ac_sum) {
+    if (RETUNE && q.ba == q.ba) { const bool up = q.qa < 0.0f; q.qa = fabsf(q.qa); coef = lp24_coefd_from_q(q, up); }
+    welsh_frame_back<false>(p, s.filt, coef, ac_sum, g, L, R);
+  }
+}
+static int g_roles = 3;
 template <bool FIRST, bool SEG>
 static void welsh_emul_split_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc, WelshScratch& sc, Lp24CoefD& coef, bool retune, int mode,
                                    float& L, float& R) {
+  if (g_roles == 4) {
+    if (mode == LFO_F32) { if (retune) welsh_emul_split_frame4<FIRST, true, LFO_F32, SEG>(p, s, rc, sc, coef, L, R); else welsh_emul_split_frame4<FIRST, false, LFO_F32, SEG>(p, s, rc, sc, coef, L, R); }
+    else { if (retune) welsh_emul_split_frame4<FIRST, true, LFO_F64_SMOOTH, SEG>(p, s, rc, sc, coef, L, R); else welsh_emul_split_frame4<FIRST, false, LFO_F64_SMOOTH, SEG>(p, s, rc, sc, coef, L, R); }
+    return;
+  }
   if (mode == LFO_F32) { if (retune) welsh_emul_split_frame3<FIRST, true, LFO_F32, SEG>(p, s, rc, sc, coef, L, R); else welsh_emul_split_frame3<FIRST, false, LFO_F32, SEG>(p, s, rc, sc, coef, L, R); }
   else { if (retune) welsh_emul_split_frame3<FIRST, true, LFO_F64_SMOOTH, SEG>(p, s, rc, sc, coef, L, R); else welsh_emul_split_frame3<FIRST, false, LFO_F64_SMOOTH, SEG>(p, s, rc, sc, coef, L, R); }
 }
@@ -220,7 +246,7 @@ void emul_set_segmented(void* h, int on) { ((EmulBank*)h)->segmented = on; }
 void emul_set_time_parallel(void* h, int on) { ((EmulBank*)h)->time_parallel = on; }
 // role_split != 0: Welsh voices of the four class-specialised base kinds (no exact-f64 LFO) render role by role, as the
 // role-split kernel does (welsh_split.h); must give the segmented form's bits
-void emul_set_role_split(void* h, int on) { ((EmulBank*)h)->role_split = on; }
+void emul_set_role_split(void* h, int on) { ((EmulBank*)h)->role_split = on; g_roles = on == 4 ? 4 : 3; } // (4: the four-role form)
 void emul_bank_note_events(void* h, const groove_note_event* ev, uint32_t n_ev) {
   EmulBank* b = (EmulBank*)h;
   for (uint32_t i = 0; i < n_ev; ++i) {

@@ -74,7 +74,7 @@ class Bank:
 
     def set_role_split(self, on):
         """True: every frame role by role, with what the role-split kernel (welsh_split.h) passes between its wavefronts."""
-        lib().emul_set_role_split(self.h, 1 if on else 0)
+        lib().emul_set_role_split(self.h, int(on))  # (4: the four-role form — front in two halves, coefficient quotients in role B)
 
     def set_generic_lfo(self, on):
         """True: exact per-frame f64 LFO (per-lane kernel); False: block-seeded recurrences where promised."""

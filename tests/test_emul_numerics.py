@@ -2,6 +2,7 @@
 tests/emul, against the f64 oracle.  This checks the fp32 / f64 / u64 arithmetic choices of the
 kernels in the GPU-less tier; the GPU tier (tests/test_gpu_*.py) checks the kernels themselves.
 Tolerance: per-voice RMS <= 1e-5, bus/V RMS <= 1e-6."""
+import pytest
 import numpy as np
 
 from groove_amd import patches as P, abi_types as T
@@ -94,16 +95,18 @@ def test_segmented_and_checked_forms_are_bit_identical():
         assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), blk
 
 
-def test_role_split_frame_is_the_serial_frame_bit_for_bit():
+@pytest.mark.parametrize("roles", [3, 4])
+def test_role_split_frame_is_the_serial_frame_bit_for_bit(roles):
     """csrc/welsh_split.h gives a voice-wave's frame to three wavefronts: front -> {sum | NaN, gain} and the cutoff percent |
     NaN; the cutoff's tangent, negated above SR/4 | NaN; coefficients from the tangent, filter step, gains.  The same device
     text walked role by role on the CPU (tests/emul/emul.cpp) must give the segmented serial form's bits — every patch of
     the table (all waveforms, routings, sync, static and retuned filters, cutoffs on both sides of SR/4), note-on, release,
-    idle, re-trigger, ragged blocks."""
+    idle, re-trigger, ragged blocks.  roles = 4: the front as its two halves (welsh_frame_ctl / welsh_frame_osc) and the
+    coefficients as fp32 quotients (role B) widened by role C."""
     n = 64
     params = P.welsh_voices(n)
     a, b = E.Bank.welsh(params), E.Bank.welsh(params)
-    a.set_role_split(True)
+    a.set_role_split(roles)
     keys_hi = T.note_events_np(np.arange(n, dtype=np.uint32), np.full(n, 108, dtype=np.uint8), True)   # high keys: cutoffs above SR/4 too
     on, off = P.note_on_all(n), P.note_off_all(n)
     peak = 0.0

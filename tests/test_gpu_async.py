@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True, params=["serial", "split", "time-parallel"])
 def kernel_form(request, gpu_ctx):
     """Every test of this module runs against the three forms of the Welsh render: one voice per lane walking the frames
-    (kernels.h), the same walk split over three wavefronts per 64 voices (welsh_split.h: "split", the default for banks
+    (kernels.h), the same walk split over four (or three, or two) wavefronts per 64 voices (welsh_split.h: "split", the default for banks
     too big for the third form), and one wavefront per voice with the frames over its lanes (welsh_tp.h, the default
     for banks this small)."""
     old, old_split = gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves

@@ -1,4 +1,4 @@
-"""GPU: the role-split Welsh kernel (csrc/welsh_split.h — three wavefronts per 64 voices: front / cutoff tangent / filter +
+"""GPU: the role-split Welsh kernels (csrc/welsh_split.h — four wavefronts per 64 voices: envelopes + LFO / oscillators / cutoff tangent + coefficient quotients / filter +
 gains, pipelined over the block's frames through LDS) computes every quantity with the serial kernels' statements in their
 order: bus rows, voice blocks and the state record must be the serial kernels' BIT FOR BIT, for every patch of the
 synthetic table (every waveform class, LFO routing, sync, both filter modes), through note-on, note-off, release, the idle
@@ -123,13 +123,16 @@ def test_split_is_the_default_for_mid_size_banks(gpu_ctx):
     small.destroy()
 
 
-def test_two_role_form_equals_the_serial_kernels_bit_for_bit(oracle):
+@pytest.mark.parametrize("roles", [2, 3, 4])
+def test_every_role_count_equals_the_serial_kernels_bit_for_bit(oracle, roles):
     """The two-role form (front + tangent | back; two workgroups of eight wavefronts per CU: banks of up to 131,072 voices in
-    one round), selected with GROOVE_SPLIT_ROLES=2 in a context of its own: bit-identical to the serial kernels, all three
-    render forms."""
+    one round), the three-role form (front | tangent | back) and the four-role form (envelopes + LFO | oscillators | tangent +
+    coefficient quotients | back; sixteen wavefronts per CU), each selected with GROOVE_SPLIT_ROLES in a context of its own:
+    bit-identical to the serial kernels, all three render forms."""
     import os
     from groove_amd import entities as E
-    os.environ["GROOVE_SPLIT_ROLES"] = "2"
+    os.environ["GROOVE_SPLIT_ROLES"] = str(roles)
+    word = {2: "two", 3: "three", 4: "four"}[roles] + " wavefronts"
     try:
         ctx = E.Context(0)
     finally:
@@ -144,7 +147,7 @@ def test_two_role_form_equals_the_serial_kernels_bit_for_bit(oracle):
                 bus_s, blk_s, st_s, form_s = _render(ctx, params, on, off, mode)
                 ctx.split_max_waves = 4096
                 bus_p, blk_p, st_p, form_p = _render(ctx, params, on, off, mode)
-                assert "two wavefronts" in form_p and "split" not in form_s, (form_s, form_p)
+                assert word in form_p and "split" not in form_s, (form_s, form_p)
                 assert np.abs(bus_s).max() > 1e-2
                 assert np.array_equal(bus_s.view(np.uint32), bus_p.view(np.uint32)), (n, mode)
                 for a, b in zip(blk_s, blk_p):
