@@ -101,6 +101,8 @@ struct groove_bank {
   std::vector<uint32_t> perm, inv;
   std::shared_ptr<LaneOrder> order; // device copy of inv, shared with the blocks this bank's renders fill (groove_block: lazy lane order)
   uint8_t* d_wg_cls = nullptr;   // welsh: oscillator class pair of each entry of d_wg_list
+  bool tp_full_coef = false;     // welsh: some voice routes the LFO to the resonance (welsh_tp_kernel<.., FULL_COEF>)
+  bool tp_pairs = false;         // welsh: every pair of adjacent voices (2i, 2i + 1) shares a patch (welsh_tp_kernel<.., VPW = 2>)
   uint8_t* d_wg_base = nullptr;  // welsh: base kind of each entry of d_wg_list (the all-kinds kernel of small banks)
   uint32_t* d_wg_list = nullptr; // welsh: workgroup ids (groups of 4 virtual waves) sorted by kind (kernels.h)
   size_t wg_list_cap = 0;
@@ -191,6 +193,9 @@ struct groove_ctx {
   int kind_streams = 3;
   int next_stream_slot = 0;             // round-robin side-stream assignment of single-kernel banks
   uint32_t fm_tp_max_voices = kFmTpMaxVoices; // GROOVE_FM_TP_MAX_VOICES
+  // Welsh banks of at least this many voices whose adjacent pairs share a patch render two voices per wavefront
+  // (welsh_tp_kernel<.., VPW = 2>): above 3,072 voices the one-voice form no longer fits the SIMDs in one round
+  uint32_t tp_vpw2_min_voices = 3073; // GROOVE_TP_VPW2_MIN_VOICES (0 = never)
   uint32_t fx_seg_max_lanes = 49152;     // biquad banks of up to this many lane-channels take the four-segment kernel (measured, tools/fx_bench.py: 8,192 lane-channels 17.5 -> 9.3 us, 32,768 19.4 -> 15.6, 131,072 42.9 -> 58.4; GROOVE_FX_SEG_MAX_LANES, 0 = never)
   uint32_t fx_tp_wide_min_lanes = 8192;  // from this many lane-channels the time-parallel IIR kernels take 32-wide tiles (GROOVE_FX_TP_WIDE_MIN_LANES)
   bool fx_lds_staging = false;          // GROOVE_FX_LDS_STAGING=1 (A/B): the fused run kernel stages the chorus taps through LDS
@@ -453,6 +458,10 @@ int welsh_upload_params(groove_bank* b, bool regroup) {
   }
   if (upload_soa(ctx, b->d_params, P)) return 1;
   GHIP(ctx, ctx_memcpy(ctx, b->d_cold, cold.data(), cold.size() * 8, hipMemcpyHostToDevice));
+  b->tp_pairs = true; // time-parallel form, two voices per wavefront: voices 2i and 2i + 1 share their parameter words
+  for (uint32_t i = 0; i + 1 < n && b->tp_pairs; i += 2) b->tp_pairs = std::memcmp(&P[i], &P[i + 1], sizeof(WelshParams)) == 0;
+  b->tp_full_coef = false; // time-parallel form: a voice with the resonance routing keeps six f64 coefficients per frame (welsh_tp.h)
+  for (uint32_t i = 0; i < n; ++i) if (P[i].flags & WF_LFO_RESO) { b->tp_full_coef = true; break; }
   // Virtual waves: maximal runs of consecutive voices with identical parameter words, cut at 64.
   std::vector<WaveDesc> W;
   W.reserve((size_t)n / 64 + 64);
@@ -977,6 +986,7 @@ static int init_impl(int device_ordinal, const uint8_t* comm_id, int rank, int w
   if (ctx->safe_streams) ctx->kind_streams = 3;
   if (const char* e = std::getenv("GROOVE_BANK_STREAMS")) ctx->bank_streams = std::max(1, std::min(kBankStreams, std::atoi(e)));
   if (const char* e = std::getenv("GROOVE_FM_TP_MAX_VOICES")) ctx->fm_tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
+  if (const char* e = std::getenv("GROOVE_TP_VPW2_MIN_VOICES")) ctx->tp_vpw2_min_voices = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_SEG_MAX_LANES")) ctx->fx_seg_max_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_TP_WIDE_MIN_LANES")) ctx->fx_tp_wide_min_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_CHUNKED_ALLPASS")) ctx->chunked_allpass = e[0] == '1';
@@ -1087,6 +1097,14 @@ int groove_set_time_parallel_max_voices(groove_ctx* ctx, uint32_t max_voices) {
   return 0;
 }
 uint32_t groove_time_parallel_max_voices(groove_ctx* ctx) { return ctx ? ctx->tp_max_voices : 0; }
+int groove_set_time_parallel_pair_min_voices(groove_ctx* ctx, uint32_t min_voices) {
+  if (!ctx) return fail(nullptr, "groove_set_time_parallel_pair_min_voices: ctx is NULL");
+  if (ctx_join(ctx)) return 1; // the partial-row count of a bank's renders changes with the form
+  GHIP(ctx, ctx_wait(ctx));
+  ctx->tp_vpw2_min_voices = min_voices;
+  return 0;
+}
+uint32_t groove_time_parallel_pair_min_voices(groove_ctx* ctx) { return ctx ? ctx->tp_vpw2_min_voices : 0; }
 int groove_set_pipeline_min_waves(groove_ctx* ctx, uint32_t waves) {
   if (!ctx) return fail(nullptr, "groove_set_pipeline_min_waves: ctx is NULL");
   if (ctx_join(ctx)) return 1; // banks change kernels (and side streams) at their next render
@@ -1333,17 +1351,20 @@ static bool use_tp(const groove_bank* b, uint32_t frames) {
   if (b->kind == BANK_SAMPLER) return b->n <= kSamplerTpMaxVoices; // a pure gather
   return false;
 }
+static uint32_t tp_vpw(const groove_bank* b) { // voices per wavefront of the time-parallel Welsh kernel
+  return (b->kind == BANK_WELSH && b->tp_pairs && b->ctx->tp_vpw2_min_voices && b->n >= b->ctx->tp_vpw2_min_voices) ? 2u : 1u;
+}
 static void launch_tp(groove_bank* b, uint32_t frames, bool fused, size_t chs, float* out, float* rows, hipStream_t st, const groove_fx* head = nullptr) {
   groove_ctx* ctx = b->ctx;
   TpArgs a{b->d_params, b->d_state, out, rows, chs, render_consts(ctx->sr), b->n, frames};
   if (head) { a.bq_coef = head->d_coef; a.bq_st = head->d_st; a.bq_wet = head->d_wet; } // Welsh, block-writing form: the BiQuad head fused (welsh_tp.h)
   if (b->kind == BANK_FM) launch_fm_tp(a, st, fused);
   else if (b->kind == BANK_SAMPLER) { launch_sampler_tp(a, b->d_pcm, b->inline_ev, st, fused); b->inline_ev.n = 0; }
-  else launch_welsh_tp(a, st, fused);
+  else { a.full_coef = b->tp_full_coef; a.vpw = tp_vpw(b); launch_welsh_tp(a, st, fused); }
 }
 // rows of partial[][2][frames] a bank's fused render writes
 static uint32_t fused_rows(const groove_bank* b, uint32_t frames) {
-  if (use_tp(b, frames)) return b->kind == BANK_SAMPLER ? sampler_tp_workgroups(b->n) : b->kind == BANK_WELSH ? welsh_tp_grid(b->n) : welsh_tp_workgroups(b->n);
+  if (use_tp(b, frames)) return b->kind == BANK_SAMPLER ? sampler_tp_workgroups(b->n) : b->kind == BANK_WELSH ? welsh_tp_grid(b->n, tp_vpw(b)) : welsh_tp_workgroups(b->n);
   return (b->kind == BANK_WELSH && b->n_vwaves) ? (b->n_vwaves + kWaves - 1) / kWaves : blocks_for(b->n);
 }
 // A Welsh bank below the per-kind pipeline's threshold: ONE launch for all its workgroups — role-split (welsh_split.h) when the
@@ -1757,7 +1778,7 @@ int groove_bank_render_mix(groove_bank* b, uint32_t frames, float* bus_dev, int 
 const char* groove_bank_kernel_form(groove_bank* b, uint32_t frames, int fused) {
   if (!b) return "";
   groove_ctx* ctx = b->ctx;
-  if (use_tp(b, frames)) return b->kind == BANK_WELSH ? "welsh_tp_kernel (time-parallel, one wavefront per voice)" : b->kind == BANK_FM ? "fm_tp_kernel (time-parallel)" : "sampler_tp_kernel (time-parallel)";
+  if (use_tp(b, frames)) return b->kind == BANK_WELSH ? (tp_vpw(b) == 2 ? "welsh_tp_kernel (time-parallel, two voices per wavefront)" : "welsh_tp_kernel (time-parallel, one wavefront per voice)") : b->kind == BANK_FM ? "fm_tp_kernel (time-parallel)" : "sampler_tp_kernel (time-parallel)";
   if (b->kind == BANK_FM) return "fm_render_kernel (serial, one voice per lane)";
   if (b->kind == BANK_SAMPLER) return "sampler_render_kernel (serial, one voice per lane)";
   if (!b->n_vwaves) return "welsh_render_kernel (per-lane parameters)";

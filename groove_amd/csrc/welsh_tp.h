@@ -143,10 +143,12 @@ GROOVE_HD void welsh_tp_incs(const WelshParams& p, const WelshState& s0, uint64_
 // `s` is the lane's running state: both envelopes have been ticked for this frame by the caller; the LFO
 // phase and (constant-increment kinds) the oscillator phases are advanced here exactly as welsh_frame does;
 // kinds with scanned phases pass this frame's phases in (ext_phase).
-template <bool RETUNE>
+// RESO: the resonance routing is compiled in.  t_out / hi_out: the tangent (and its side of SR/4) behind the coefficients, set
+// whenever they are recomputed from a cutoff percent (lp24_coefd_from_t(p.fc, t_out, hi_out) == coef, bit for bit).
+template <bool RETUNE, bool RESO = true>
 GROOVE_HD void welsh_tp_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc, bool is_first, bool ext_phase,
                               uint64_t ph1, uint64_t ph2, float nz1, float nz2, float nzl,
-                              Lp24CoefD& coef, float& prev_pct, float& x, float& a) {
+                              Lp24CoefD& coef, float& prev_pct, float& x, float& a, float& t_out, bool& hi_out) {
   const uint32_t fl = p.flags;
   const uint32_t w1 = (fl >> WF_O1_WAVE_SHIFT) & 15u, w2 = (fl >> WF_O2_WAVE_SHIFT) & 15u, wl = (fl >> WF_LFO_WAVE_SHIFT) & 15u;
   const uint64_t half = 0x8000000000000000ull;
@@ -178,17 +180,66 @@ GROOVE_HD void welsh_tp_frame(const WelshParams& p, WelshState& s, const RenderC
       pct = p.cutoff_start * fmaf(lfo, p.lfo_depth, 1.0f);
       retune = true;
     }
-    if (fl & WF_LFO_RESO) {
+    if (RESO && (fl & WF_LFO_RESO)) {
       const Lp24Consts c = lp24_consts_from_ripple(p.ripple * fmaf(lfo, p.lfo_depth, 1.0f));
       const float fc = retune ? 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f) : p.cutoff_hz;
       coef = lp24_coefd_from_fc(c, fc, rc.pi_over_sr, rc.fc_max);
     } else if (retune && pct != prev_pct) {
-      coef = lp24_coefd_from_pct(p.fc, pct, rc);
+      t_out = lp24_t_from_pct(pct, rc, hi_out); // (lp24_coefd_from_pct in its two halves)
+      coef = lp24_coefd_from_t(p.fc, t_out, hi_out);
       prev_pct = pct;
     }
   }
   a = s.amp.value;
   if (fl & WF_LFO_AMP) a *= fmaf(lfo, p.lfo_depth, 1.0f);
+}
+// What pass B needs of a lane's frames: the filter's input, the amplitude factor, and — retuned kinds — the tangent the frame's
+// coefficients are made from (lp24_coefd_from_t; bit j of `hi` = its side of SR/4).  Recomputing six f64 coefficients from one
+// float costs ~25 instructions per frame and keeps CH x 12 registers free across the affine scan (the kernel's register peak:
+// three 32-register maps are alive there).
+template <int CH> struct TpChunkOut { float x[CH], amp[CH], t[CH]; uint32_t hi, live; };
+// Pass 2 of a lane: frames n0 .. n0 + cnt - 1 (the first `nlive` of them sound).  `s` arrives at frame n0 (envelopes sought,
+// phases advanced); it leaves as the serial walk leaves it after the lane's last frame.  FULL_COEF: the resonance routing's
+// coefficients do not come from a tangent alone; such banks keep the six f64 coefficients per frame (coef_full).
+// (A stage-by-stage form — every oscillator's waveform dispatched once per lane instead of once per frame — was built and
+// measured in round 3: same time, 20 more registers.  The frames are walked one by one.)
+template <bool RETUNE, bool FULL_COEF, int CH>
+GROOVE_HD void welsh_tp_chunk(const WelshParams& p, WelshState& s, const RenderConsts& rc, bool first0, uint32_t n0, uint32_t cnt, uint32_t nlive,
+                              bool ext_phase, const uint64_t (&ph1)[CH], const uint64_t (&ph2)[CH],
+                              const float* nz1, const float* nz2, const float* nzl /* the voice's noise rows (by frame), or null */,
+                              const Lp24CoefD& cur0, TpChunkOut<CH>& o, Lp24CoefD (&coef_full)[FULL_COEF ? CH : 1], Lp24Affine& mine) {
+  Lp24CoefD cur = cur0;
+  float prev_pct = __builtin_nanf(""), t_cur = 0.0f;
+  bool hi_cur = false;
+  o.live = 0; o.hi = 0;
+  _Pragma("unroll") for (uint32_t j = 0; j < (uint32_t)CH; ++j) {
+    o.x[j] = 0.0f; o.amp[j] = 0.0f;
+    if (j < cnt) {
+      env_tick(s.amp, p.amp);
+      env_tick(s.fil, p.fil);
+      if (j < nlive) {
+        o.live |= 1u << j;
+        const bool is_first = first0 && n0 + j == 0;
+        const uint32_t f = n0 + j;
+        welsh_tp_frame<RETUNE, FULL_COEF>(p, s, rc, is_first, ext_phase, ph1[j], ph2[j], nz1 ? nz1[f] : 0.0f, nz2 ? nz2[f] : 0.0f, nzl ? nzl[f] : 0.0f,
+                                          cur, prev_pct, o.x[j], o.amp[j], t_cur, hi_cur);
+        s.vflags = 0;
+        lp24_affine_push(mine, cur, (double)o.x[j]);
+      } else if (ext_phase) { // phases stay where the last live frame left them
+        s.o1.phase = ph1[j]; s.o2.phase = ph2[j];
+      }
+    }
+    o.t[j] = t_cur;
+    if (hi_cur) o.hi |= 1u << j;
+    if (FULL_COEF) coef_full[FULL_COEF ? j : 0] = cur;
+  }
+}
+// The coefficients pass B applies at frame j of the lane: what pass 2 pushed into the affine map, bit for bit.
+template <bool RETUNE, bool FULL_COEF, int CH>
+GROOVE_HD Lp24CoefD welsh_tp_coef_at(const WelshParams& p, const TpChunkOut<CH>& o, const Lp24CoefD& cur0, const Lp24CoefD (&coef_full)[FULL_COEF ? CH : 1], uint32_t j) {
+  if (FULL_COEF) return coef_full[FULL_COEF ? j : 0];
+  if (RETUNE && (p.flags & (WF_RETUNE_ENV | WF_LFO_CUTOFF))) return lp24_coefd_from_t(p.fc, o.t[j], ((o.hi >> j) & 1u) != 0);
+  return cur0;
 }
 GROOVE_HD bool welsh_tp_scans(const WelshParams& p) { return (p.flags & (WF_LFO_PITCH | WF_SYNC)) != 0; }
 GROOVE_HD bool welsh_tp_noise(const WelshParams& p, int osc /*0: osc 1, 1: osc 2, 2: LFO*/) {
@@ -208,6 +259,9 @@ GROOVE_HD uint64_t fm_tp_carrier_inc(const FmParams& p, uint64_t c_inc, uint64_t
 
 #if defined(__HIPCC__)
 // ------------------------------------------------------------------ the kernel
+#ifndef GROOVE_TP_WAVES
+#define GROOVE_TP_WAVES 3
+#endif
 constexpr int kTpWaves = 4;                 // voices per workgroup
 constexpr int kTpThreads = kTpWaves * 64;
 // Voice group of workgroup `i` of a grid of `grid` workgroups (welsh_tp_kernel, "XCD-aware voice mapping"); the host pads
@@ -259,18 +313,20 @@ __device__ __forceinline__ void bq_affine_compose(BqAffine& later, const BqAffin
 // this lane's frames (wet mix applied); returns true in the lane that holds the block's last frame, with ns = the state
 // after the block (x1, x2 = the last two inputs, y1, y2 = the last two outputs).  Pass B performs biquad_step's operations
 // in their order from a start state that agrees with the serial walk's to f64 rounding.
-__device__ __forceinline__ bool bq_tp_wave(const float (&xf)[kTpChunk], uint32_t cnt, uint32_t lane, uint32_t frames, const BiquadCoefD& c,
-                                           double sx1, double sx2, double sy1, double sy2, float wm, float (&o)[kTpChunk], double (&ns)[4]) {
+template <int CH = (int)kTpChunk, int LPV = 64> // LPV lanes of the wavefront hold one lane-channel, CH frames each (welsh_tp_kernel's VPW = 64 / LPV)
+__device__ __forceinline__ bool bq_tp_wave(const float (&xf)[CH], uint32_t cnt, uint32_t lane, uint32_t frames, const BiquadCoefD& c,
+                                           double sx1, double sx2, double sy1, double sy2, float wm, float (&o)[CH], double (&ns)[4]) {
+  const uint32_t vl = lane & (uint32_t)(LPV - 1);
   // the two inputs before this lane's first frame: the previous lane's last two, or the state
-  double px1 = tp_shfl((double)xf[kTpChunk - 1], (int)lane - 1), px2 = tp_shfl((double)xf[kTpChunk - 2], (int)lane - 1);
-  if (lane == 0) { px1 = sx1; px2 = sx2; }
-  double w[kTpChunk];
+  double px1 = tp_shfl((double)xf[CH - 1], (int)lane - 1), px2 = tp_shfl((double)xf[CH - 2], (int)lane - 1);
+  if (vl == 0) { px1 = sx1; px2 = sx2; }
+  double w[CH];
   BqAffine mine;
   bq_affine_identity(mine);
   {
     double x1 = px1, x2 = px2;
 #pragma unroll
-    for (uint32_t j = 0; j < kTpChunk; ++j) {
+    for (uint32_t j = 0; j < CH; ++j) {
       const double x = (double)xf[j];
       w[j] = c.b0 * x + c.b1 * x1 + c.b2 * x2;
       if (j < cnt) bq_affine_push(mine, c.a1, c.a2, w[j]);
@@ -279,18 +335,18 @@ __device__ __forceinline__ bool bq_tp_wave(const float (&xf)[kTpChunk], uint32_t
   }
   BqAffine incl = mine;
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
+  for (int d = 1; d < LPV; d <<= 1) {
     BqAffine e;
     e.m00 = tp_shfl(incl.m00, (int)lane - d); e.m01 = tp_shfl(incl.m01, (int)lane - d);
     e.m10 = tp_shfl(incl.m10, (int)lane - d); e.m11 = tp_shfl(incl.m11, (int)lane - d);
     e.z0 = tp_shfl(incl.z0, (int)lane - d); e.z1 = tp_shfl(incl.z1, (int)lane - d);
-    if ((int)lane >= d) bq_affine_compose(incl, e);
+    if ((int)vl >= d) bq_affine_compose(incl, e);
   }
   const double e1 = incl.m00 * sy1 + incl.m01 * sy2 + incl.z0, e2 = incl.m10 * sy1 + incl.m11 * sy2 + incl.z1; // (y1, y2) after this lane
   double y1 = tp_shfl(e1, (int)lane - 1), y2 = tp_shfl(e2, (int)lane - 1);
-  if (lane == 0) { y1 = sy1; y2 = sy2; }
+  if (vl == 0) { y1 = sy1; y2 = sy2; }
 #pragma unroll
-  for (uint32_t j = 0; j < kTpChunk; ++j) {
+  for (uint32_t j = 0; j < CH; ++j) {
     o[j] = 0.0f;
     if (j < cnt) {
       const double y = w[j] - c.a1 * y1 - c.a2 * y2;
@@ -299,7 +355,7 @@ __device__ __forceinline__ bool bq_tp_wave(const float (&xf)[kTpChunk], uint32_t
       if (wm < 1.0f) o[j] = fmaf(o[j], wm, xf[j] * (1.0f - wm));
     }
   }
-  const bool holds_end = frames && lane == (frames - 1) / kTpChunk;
+  const bool holds_end = frames && vl == (frames - 1) / CH;
   if (holds_end) { // x1, x2 = the block's last two inputs; y1, y2 = its last two outputs
     ns[0] = (double)xf[cnt - 1]; ns[1] = cnt >= 2 ? (double)xf[cnt - 2] : px1; ns[2] = y1; ns[3] = y2;
   }
@@ -310,6 +366,8 @@ struct TpArgs {
   // welsh_tp_kernel<false, true>: a 12 dB BiQuad effect bank (one lane per voice) applied to the voice's block before it is
   // stored — coefficients [5][n] f64, state [4][2n] f64, wet [n], the layouts of fx_biquad_tp_kernel (fx_tp.h)
   const double* bq_coef = nullptr; double* bq_st = nullptr; const float* bq_wet = nullptr;
+  bool full_coef = false; // some voice of the bank has the resonance routing: the kernel form that keeps whole coefficient sets
+  uint32_t vpw = 1;       // voices per wavefront (welsh_tp_kernel's VPW; 2 needs every pair of adjacent voices on one patch)
 };
 // A block's note events, small enough to ride in the kernel's argument block (4 KB): strictly increasing voices, so a
 // wavefront finds its voice's event (there is at most one) by bisection with scalar loads and applies it to the state
@@ -324,44 +382,71 @@ struct InlineEvents { uint32_t n; groove_note_event ev[kInlineEvents]; };
 // wavefront's lanes, so the filter is one more affine scan (bq_tp_wave, what fx_biquad_tp_kernel runs per lane-channel) on
 // values that are in registers; a separate launch read and wrote the whole block again and, as a few hundred latency-bound
 // wavefronts beside the HBM-bound stages of the previous block, took three times its own time (config #3: 29 us of 82).
-template <bool FUSED, bool HEAD_BQ = false>
-__global__ __launch_bounds__(kTpThreads, 2) void welsh_tp_kernel(TpArgs a) {
+#ifdef GROOVE_TP_PROBE /* measurement build only (tools/tp_probe.py): s_memtime ticks a wavefront spends in each phase of the kernel */
+static __device__ unsigned long long g_tp_probe[16]; // [phase 0..11] ticks, [12] realtime ticks of the whole kernel, [15] wavefronts
+#define TP_PROBE_BEGIN uint64_t pb_t[12]; const uint64_t pb_r0 = __builtin_amdgcn_s_memrealtime(); int pb_i = 0; TP_PROBE
+#define TP_PROBE { __builtin_amdgcn_sched_barrier(0); pb_t[pb_i++] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define TP_PROBE_END { TP_PROBE const uint64_t pb_r1 = __builtin_amdgcn_s_memrealtime(); if ((threadIdx.x & 63u) == 0) { \
+    for (int i = 1; i < pb_i; ++i) atomicAdd(&g_tp_probe[i - 1], pb_t[i] - pb_t[i - 1]); \
+    atomicAdd(&g_tp_probe[12], pb_r1 - pb_r0); atomicAdd(&g_tp_probe[15], 1ull); } }
+#else
+#define TP_PROBE_BEGIN
+#define TP_PROBE
+#define TP_PROBE_END
+#endif
+// VPW = voices per wavefront (round 3).  VPW = 1: lanes = the 64 four-frame chunks of one voice.  VPW = 2: the wavefront's
+// halves take two ADJACENT voices of one patch (the host checks that every pair shares its parameter words, so the patch
+// stays in SGPRs), 32 lanes x 8 frames each: half the wavefronts, five scan steps instead of six, and the fixed costs of a
+// wavefront (parameters, envelope seeks, the scan, the tile turn) paid once per two voices — ~3,500 instructions deep per
+// wavefront instead of ~2,350, so 25 % less issue per voice and, where VPW = 1 needs more wavefronts than the SIMDs hold at
+// once (165 registers: three per SIMD, i.e. banks over 3,072 voices), a shorter block.  Same per-frame operations: a voice's
+// output differs from the VPW = 1 form's only by the f64 rounding of the filter scan's composition order.
+template <bool FUSED, bool HEAD_BQ = false, bool FULL_COEF = false, int VPW = 1>
+__global__ __launch_bounds__(kTpThreads, VPW == 1 ? GROOVE_TP_WAVES : 2) void welsh_tp_kernel(TpArgs a) {
   static_assert(!(FUSED && HEAD_BQ), "an effect needs the voice blocks: the fused bus form has none");
-  __shared__ float s_noise[kTpWaves][3][kTpMaxFrames];
-  __shared__ uint64_t s_sum2[kTpWaves][kTpMaxFrames];
-  __shared__ float s_tile[kTpWaves][2][kTpMaxFrames];
+  static_assert(VPW == 1 || VPW == 2, "");
+  constexpr uint32_t LPV = 64 / VPW, CH = kTpChunk * VPW, WGV = kTpWaves * VPW; // lanes per voice, frames per lane, voices per workgroup
+  __shared__ float s_noise[WGV][3][kTpMaxFrames];
+  __shared__ uint64_t s_sum2[WGV][kTpMaxFrames];
+  __shared__ float s_tile[WGV][2][kTpMaxFrames];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t vl = lane & (LPV - 1u), sub = lane / LPV, wv = wave * VPW + sub; // lane within the voice, voice within the wave / workgroup
+  const int lbase = (int)(sub * LPV);                                             // the voice's first lane
+  TP_PROBE_BEGIN // 0
   // XCD-aware voice mapping.  Workgroups go to the 8 XCDs round-robin (workgroup i -> XCD i mod 8), each XCD with its own L2.
   // A workgroup stores 4 adjacent voices x 256 frames of the planar block [frame][voice]: 16 bytes per row.  With the plain
   // mapping the 8 workgroups that share a 128-byte line of a row sit on 8 DIFFERENT XCDs — eight L2s each hold an eighth
   // of every line and write it back masked; with group = (i mod 8) * (grid / 8) + i / 8 an XCD owns a contiguous range
   // of voices, the workgroups that share a line follow each other on ONE XCD, and its L2 writes whole lines.
   const uint32_t grp = tp_group_of_block(blockIdx.x, gridDim.x);
-  const uint32_t v0 = grp * kTpWaves + wave;
+  const uint32_t v0 = grp * WGV + wv;
   const bool voice = v0 < a.n;
-  const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(voice ? v0 : a.n - 1));
+  const uint32_t vme = voice ? v0 : a.n - 1; // (per lane when VPW > 1)
+  const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)vme);
   const uint32_t frames = a.frames, n = a.n;
-  const WelshParams p = make_scalar(soa_load<WelshParams>(a.params, n, v));
-  const WelshState s0 = soa_load<WelshState>(a.state, n, v); // the same in every lane
+  const WelshParams p = make_scalar(soa_load<WelshParams>(a.params, n, v)); // VPW > 1: the wave's voices share the patch (host)
+  const WelshState s0 = soa_load<WelshState>(a.state, n, VPW == 1 ? v : vme); // the same in every lane of the voice
   const RenderConsts rc = a.rc;
   const bool first0 = (s0.vflags & VF_FIRST) != 0;
   const uint32_t live_total = env_idle_at(s0.amp, p.amp, frames);
   const bool retunes = welsh_retunes(p), scans = welsh_tp_scans(p);
   const bool nz_any = welsh_tp_noise(p, 0) || welsh_tp_noise(p, 1) || welsh_tp_noise(p, 2);
+  TP_PROBE // 1: parameters, state, env_idle_at
 
   // ---- noise oscillators: one lane each, serially, values through LDS; end states stay in those lanes
-  OscState nz_end = lane == 0 ? s0.o1 : (lane == 1 ? s0.o2 : s0.lfo);
+  OscState nz_end = vl == 0 ? s0.o1 : (vl == 1 ? s0.o2 : s0.lfo);
   if (nz_any) {
-    if (lane < 3 && welsh_tp_noise(p, (int)lane)) {
-      for (uint32_t j = 0; j < live_total; ++j) s_noise[wave][lane][j] = noise_tick(nz_end);
+    if (vl < 3 && welsh_tp_noise(p, (int)vl)) {
+      for (uint32_t j = 0; j < live_total; ++j) s_noise[wv][vl][j] = noise_tick(nz_end);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
   }
 
+  TP_PROBE // 2: noise
   // ---- this lane's frames
-  const uint32_t n0 = lane * kTpChunk;
-  const uint32_t cnt = n0 < frames ? (frames - n0 < kTpChunk ? frames - n0 : kTpChunk) : 0u;
+  const uint32_t n0 = vl * CH;
+  const uint32_t cnt = n0 < frames ? (frames - n0 < CH ? frames - n0 : CH) : 0u;
   WelshState s = s0;
   env_seek(s.amp, p.amp, n0 < frames ? n0 : 0u);
   env_seek(s.fil, p.fil, n0 < frames ? n0 : 0u);
@@ -372,178 +457,178 @@ __global__ __launch_bounds__(kTpThreads, 2) void welsh_tp_kernel(TpArgs a) {
   s.o2.phase = s0.o2.phase + adv * s0.o2_inc;
   if (live_before >= 1u) s.vflags = 0;
 
+  TP_PROBE // 3: env_seek, closed-form phases
   // pass 1 (scanned phases): per-frame increments, prefix sums over the block, wrap positions
-  uint64_t ph1[kTpChunk] = {}, ph2[kTpChunk] = {};
+  uint64_t ph1[CH] = {}, ph2[CH] = {};
   if (scans) {
-    uint64_t inc1[kTpChunk], inc2[kTpChunk], run1 = 0, run2 = 0, loc1[kTpChunk], loc2[kTpChunk];
+    uint64_t inc1[CH], inc2[CH], run1 = 0, run2 = 0, loc1[CH], loc2[CH];
     uint64_t lph = s.lfo.phase;
 #pragma unroll
-    for (uint32_t j = 0; j < kTpChunk; ++j) {
+    for (uint32_t j = 0; j < CH; ++j) {
       const uint32_t f = n0 + j;
       const bool live = j < cnt && f < live_total, is_first = first0 && f == 0;
       inc1[j] = 0; inc2[j] = 0;
       if (live) {
         if (!is_first) lph += p.lfo_inc;
-        const float nzl = welsh_tp_noise(p, 2) ? s_noise[wave][2][f] : 0.0f;
+        const float nzl = welsh_tp_noise(p, 2) ? s_noise[wv][2][f] : 0.0f;
         if (!is_first) welsh_tp_incs(p, s0, lph, nzl, inc1[j], inc2[j]);
       }
       run1 += inc1[j]; run2 += inc2[j];
       loc1[j] = run1; loc2[j] = run2;
     }
-    // exclusive prefix over the lanes of the lane totals (Hillis-Steele on the inclusive sums)
+    // exclusive prefix over the voice's lanes of the lane totals (Hillis-Steele on the inclusive sums)
     uint64_t t1 = run1, t2 = run2;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
+    for (int d = 1; d < (int)LPV; d <<= 1) {
       const uint64_t o1 = tp_shfl(t1, (int)lane - d), o2 = tp_shfl(t2, (int)lane - d);
-      if ((int)lane >= d) { t1 += o1; t2 += o2; }
+      if ((int)vl >= d) { t1 += o1; t2 += o2; }
     }
     const uint64_t base1 = t1 - run1, base2 = t2 - run2;
     int wlast = -1; // last frame <= f at which oscillator 1 wrapped (hard sync), within this lane so far
 #pragma unroll
-    for (uint32_t j = 0; j < kTpChunk; ++j) {
+    for (uint32_t j = 0; j < CH; ++j) {
       ph1[j] = s0.o1.phase + base1 + loc1[j];
       if (ph1[j] < inc1[j]) wlast = (int)(n0 + j); // carry out of the add (inc 0: never)
       loc2[j] += base2;                              // inclusive prefix of the oscillator-2 increments at frame n0 + j
     }
     if (p.flags & WF_SYNC) {
 #pragma unroll
-      for (uint32_t j = 0; j < kTpChunk; ++j) if (j < cnt) s_sum2[wave][n0 + j] = loc2[j];
-      int wl_incl = wlast; // max-scan over the lanes
+      for (uint32_t j = 0; j < CH; ++j) if (j < cnt) s_sum2[wv][n0 + j] = loc2[j];
+      int wl_incl = wlast; // max-scan over the voice's lanes
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
+      for (int d = 1; d < (int)LPV; d <<= 1) {
         const int o = __shfl(wl_incl, (int)lane - d, 64);
-        if ((int)lane >= d && o > wl_incl) wl_incl = o;
+        if ((int)vl >= d && o > wl_incl) wl_incl = o;
       }
       int wprev = __shfl(wl_incl, (int)lane - 1, 64);
-      if (lane == 0) wprev = -1;
+      if (vl == 0) wprev = -1;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
       int w = wprev;
 #pragma unroll
-      for (uint32_t j = 0; j < kTpChunk; ++j) {
+      for (uint32_t j = 0; j < CH; ++j) {
         if (ph1[j] < inc1[j]) w = (int)(n0 + j);
-        if (j < cnt) ph2[j] = w >= 0 ? loc2[j] - s_sum2[wave][w] : s0.o2.phase + loc2[j];
+        if (j < cnt) ph2[j] = w >= 0 ? loc2[j] - s_sum2[wv][w] : s0.o2.phase + loc2[j];
       }
     } else {
 #pragma unroll
-      for (uint32_t j = 0; j < kTpChunk; ++j) ph2[j] = s0.o2.phase + loc2[j];
+      for (uint32_t j = 0; j < CH; ++j) ph2[j] = s0.o2.phase + loc2[j];
     }
   }
 
-  // pass 2: the frames' feed-forward values; the filter's affine map of this chunk
-  float x[kTpChunk], amp[kTpChunk];
-  Lp24CoefD coef[kTpChunk];
-  bool lives[kTpChunk];
-  Lp24CoefD cur = lp24_coefd_from_fc(p.fc, p.cutoff_hz, rc.pi_over_sr, rc.fc_max);
-  float prev_pct = __builtin_nanf("");
+  TP_PROBE // 4: pass 1 (scanned phases)
+  // pass 2: the frames' feed-forward values, stage by stage (welsh_tp_chunk); the filter's affine map of this chunk
+  const Lp24CoefD cur0 = lp24_coefd_from_fc(p.fc, p.cutoff_hz, rc.pi_over_sr, rc.fc_max);
+  const uint32_t nlive = n0 < live_total ? (live_total - n0 < cnt ? live_total - n0 : cnt) : 0u;
+  TpChunkOut<CH> co;
+  Lp24CoefD coef_full[FULL_COEF ? CH : 1];
   Lp24Affine mine;
   lp24_affine_identity(mine);
-#pragma unroll
-  for (uint32_t j = 0; j < kTpChunk; ++j) {
-    const uint32_t f = n0 + j;
-    x[j] = 0.0f; amp[j] = 0.0f; lives[j] = false;
-    if (j < cnt) {
-      env_tick(s.amp, p.amp);
-      env_tick(s.fil, p.fil);
-      if (f < live_total) {
-        lives[j] = true;
-        const bool is_first = first0 && f == 0;
-        const float nz1 = welsh_tp_noise(p, 0) ? s_noise[wave][0][f] : 0.0f;
-        const float nz2 = welsh_tp_noise(p, 1) ? s_noise[wave][1][f] : 0.0f;
-        const float nzl = welsh_tp_noise(p, 2) ? s_noise[wave][2][f] : 0.0f;
-        if (retunes) welsh_tp_frame<true>(p, s, rc, is_first, scans, ph1[j], ph2[j], nz1, nz2, nzl, cur, prev_pct, x[j], amp[j]);
-        else welsh_tp_frame<false>(p, s, rc, is_first, scans, ph1[j], ph2[j], nz1, nz2, nzl, cur, prev_pct, x[j], amp[j]);
-        s.vflags = 0;
-        lp24_affine_push(mine, cur, (double)x[j]);
-      } else if (scans) { // phases stay where the last live frame left them
-        s.o1.phase = ph1[j]; s.o2.phase = ph2[j];
-      }
-    }
-    coef[j] = cur;
+  {
+    const float* nz1 = welsh_tp_noise(p, 0) ? s_noise[wv][0] : nullptr;
+    const float* nz2 = welsh_tp_noise(p, 1) ? s_noise[wv][1] : nullptr;
+    const float* nzl = welsh_tp_noise(p, 2) ? s_noise[wv][2] : nullptr;
+    if (retunes) welsh_tp_chunk<true, FULL_COEF, CH>(p, s, rc, first0, n0, cnt, nlive, scans, ph1, ph2, nz1, nz2, nzl, cur0, co, coef_full, mine);
+    else welsh_tp_chunk<false, FULL_COEF, CH>(p, s, rc, first0, n0, cnt, nlive, scans, ph1, ph2, nz1, nz2, nzl, cur0, co, coef_full, mine);
   }
-  // inclusive scan of the affine maps over the lanes, then every lane's start state
+  TP_PROBE // 5: pass 2 (feed-forward + affine push)
+  // inclusive scan of the affine maps over the voice's lanes, then every lane's start state
   Lp24Affine incl = mine;
 #pragma unroll 1
-  for (int d = 1; d < 64; d <<= 1) {
+  for (int d = 1; d < (int)LPV; d <<= 1) {
     Lp24Affine other;
     tp_shfl_affine(incl, (int)lane - d, other);
-    if ((int)lane >= d) lp24_affine_compose(incl, other);
+    if ((int)vl >= d) lp24_affine_compose(incl, other);
   }
   const double s_init[4] = {s0.filt.s0, s0.filt.s1, s0.filt.s2, s0.filt.s3};
   double s_end[4];
   lp24_affine_mul(incl, s_init, s_end, true);
   double st[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { st[i] = tp_shfl(s_end[i], (int)lane - 1); if (lane == 0) st[i] = s_init[i]; }
-  float oL[kTpChunk], oR[kTpChunk];
+  for (int i = 0; i < 4; ++i) { st[i] = tp_shfl(s_end[i], (int)lane - 1); if (vl == 0) st[i] = s_init[i]; }
+  TP_PROBE // 6: affine scan + start state
+  float oL[CH], oR[CH];
 #pragma unroll
-  for (uint32_t j = 0; j < kTpChunk; ++j) {
+  for (uint32_t j = 0; j < CH; ++j) {
     float y = 0.0f;
-    if (lives[j]) y = (float)lp24_step_v(st, coef[j], (double)x[j]);
-    const float m = y * amp[j];
+    if ((co.live >> j) & 1u) {
+      const Lp24CoefD cj = retunes ? welsh_tp_coef_at<true, FULL_COEF, CH>(p, co, cur0, coef_full, j) : cur0;
+      y = (float)lp24_step_v(st, cj, (double)co.x[j]);
+    }
+    const float m = y * co.amp[j];
     oL[j] = m * p.gl; oR[j] = m * p.gr;
   }
+  TP_PROBE // 7: pass B (filter outputs)
   if constexpr (HEAD_BQ) { // this voice's lane of the BiQuad bank, left then right
     const size_t tn = 2 * (size_t)n;
-    const BiquadCoefD cf{a.bq_coef[v], a.bq_coef[(size_t)n + v], a.bq_coef[(size_t)2 * n + v], a.bq_coef[(size_t)3 * n + v], a.bq_coef[(size_t)4 * n + v]};
-    const float wm = a.bq_wet[v];
+    const uint32_t vb = VPW == 1 ? v : vme;
+    const BiquadCoefD cf{a.bq_coef[vb], a.bq_coef[(size_t)n + vb], a.bq_coef[(size_t)2 * n + vb], a.bq_coef[(size_t)3 * n + vb], a.bq_coef[(size_t)4 * n + vb]};
+    const float wm = a.bq_wet[vb];
 #pragma unroll
     for (uint32_t ch = 0; ch < 2; ++ch) {
-      const size_t t = (size_t)ch * n + v;
-      float xin[kTpChunk], y[kTpChunk];
+      const size_t t = (size_t)ch * n + vb;
+      float xin[CH], y[CH];
       double ns[4];
 #pragma unroll
-      for (uint32_t j = 0; j < kTpChunk; ++j) xin[j] = j < cnt ? (ch ? oR[j] : oL[j]) : 0.0f;
-      const bool holds_end = bq_tp_wave(xin, cnt, lane, frames, cf, a.bq_st[t], a.bq_st[tn + t], a.bq_st[2 * tn + t], a.bq_st[3 * tn + t], wm, y, ns);
+      for (uint32_t j = 0; j < CH; ++j) xin[j] = j < cnt ? (ch ? oR[j] : oL[j]) : 0.0f;
+      const bool holds_end = bq_tp_wave<CH, LPV>(xin, cnt, lane, frames, cf, a.bq_st[t], a.bq_st[tn + t], a.bq_st[2 * tn + t], a.bq_st[3 * tn + t], wm, y, ns);
 #pragma unroll
-      for (uint32_t j = 0; j < kTpChunk; ++j) { if (ch) oR[j] = y[j]; else oL[j] = y[j]; }
+      for (uint32_t j = 0; j < CH; ++j) { if (ch) oR[j] = y[j]; else oL[j] = y[j]; }
       if (voice && holds_end) { a.bq_st[t] = ns[0]; a.bq_st[tn + t] = ns[1]; a.bq_st[2 * tn + t] = ns[2]; a.bq_st[3 * tn + t] = ns[3]; }
     }
   }
 
+  TP_PROBE // 8: BiQuad head
   // ---- outputs
   {
 #pragma unroll
-    for (uint32_t j = 0; j < kTpChunk; ++j) {
-      s_tile[wave][0][n0 + j] = (voice && j < cnt) ? oL[j] : 0.0f;
-      s_tile[wave][1][n0 + j] = (voice && j < cnt) ? oR[j] : 0.0f;
+    for (uint32_t j = 0; j < CH; ++j) {
+      s_tile[wv][0][n0 + j] = (voice && j < cnt) ? oL[j] : 0.0f;
+      s_tile[wv][1][n0 + j] = (voice && j < cnt) ? oR[j] : 0.0f;
     }
     __syncthreads();
-    // block-writing form: the workgroup's four voices of one (channel, frame) leave as ONE 16-byte store when the row
-    // segment is whole and aligned (instead of four 4-byte stores from four wavefronts)
-    const uint32_t vbase = grp * kTpWaves;
-    const bool vec = !FUSED && kTpWaves == 4 && (n & 3u) == 0 && vbase + kTpWaves <= n && (a.ch_stride & 3u) == 0;
+    TP_PROBE // 9: tile + barrier
+    // block-writing form: the workgroup's adjacent voices of one (channel, frame) leave as 16-byte stores when the row
+    // segment is whole and aligned (instead of 4-byte stores from every wavefront)
+    const uint32_t vbase = grp * WGV;
+    const bool vec = !FUSED && kTpWaves == 4 && (n & 3u) == 0 && vbase + WGV <= n && (a.ch_stride & 3u) == 0;
     for (uint32_t t = threadIdx.x; t < 2 * frames; t += kTpThreads) {
       const uint32_t ch = t / frames, f = t % frames;
-      float q[kTpWaves];
+      float q[WGV];
       float acc = 0.0f;
 #pragma unroll
-      for (int w = 0; w < kTpWaves; ++w) { q[w] = s_tile[w][ch][f]; acc += q[w]; }
+      for (uint32_t w = 0; w < WGV; ++w) { q[w] = s_tile[w][ch][f]; acc += q[w]; }
       if (a.rows) a.rows[((size_t)blockIdx.x * 2 + ch) * frames + f] = acc; // (null: the block goes straight into an effect chain, which replaces its lane sums)
-      if (vec) *reinterpret_cast<float4*>(a.out + ch * a.ch_stride + (size_t)f * n + vbase) = make_float4(q[0], q[1], q[2], q[3]);
+      if (vec) {
+#pragma unroll
+        for (uint32_t w = 0; w < WGV; w += 4)
+          *reinterpret_cast<float4*>(a.out + ch * a.ch_stride + (size_t)f * n + vbase + w) = make_float4(q[w], q[w + 1], q[w + 2], q[w + 3]);
+      }
     }
     if (!FUSED && !vec && voice) {
 #pragma unroll
-      for (uint32_t j = 0; j < kTpChunk; ++j) {
+      for (uint32_t j = 0; j < CH; ++j) {
         if (j < cnt) {
-          a.out[(size_t)(n0 + j) * n + v] = oL[j];
-          a.out[a.ch_stride + (size_t)(n0 + j) * n + v] = oR[j];
+          a.out[(size_t)(n0 + j) * n + vme] = oL[j];
+          a.out[a.ch_stride + (size_t)(n0 + j) * n + vme] = oR[j];
         }
       }
     }
   }
 
+  TP_PROBE // 10: rows / block stores
   // ---- state after the block: the lane that holds the last frame has every running value
-  const uint32_t last = frames ? (frames - 1) / kTpChunk : 0u;
+  const uint32_t last = frames ? (frames - 1) / CH : 0u;
   OscState e1 = nz_end, e2 = nz_end, el = nz_end;
-  e1.x1 = tp_shfl(nz_end.x1, 0); e1.x2 = tp_shfl(nz_end.x2, 0);
-  e2.x1 = tp_shfl(nz_end.x1, 1); e2.x2 = tp_shfl(nz_end.x2, 1);
-  el.x1 = tp_shfl(nz_end.x1, 2); el.x2 = tp_shfl(nz_end.x2, 2);
-  if (voice && lane == last && frames) {
+  e1.x1 = tp_shfl(nz_end.x1, lbase + 0); e1.x2 = tp_shfl(nz_end.x2, lbase + 0);
+  e2.x1 = tp_shfl(nz_end.x1, lbase + 1); e2.x2 = tp_shfl(nz_end.x2, lbase + 1);
+  el.x1 = tp_shfl(nz_end.x1, lbase + 2); el.x2 = tp_shfl(nz_end.x2, lbase + 2);
+  if (voice && vl == last && frames) {
     s.o1.x1 = e1.x1; s.o1.x2 = e1.x2; s.o2.x1 = e2.x1; s.o2.x2 = e2.x2; s.lfo.x1 = el.x1; s.lfo.x2 = el.x2;
     s.filt.s0 = s_end[0]; s.filt.s1 = s_end[1]; s.filt.s2 = s_end[2]; s.filt.s3 = s_end[3];
-    soa_store(a.state, n, v, s);
+    soa_store(a.state, n, vme, s);
   }
+  TP_PROBE_END // 11: state store
 }
 // FmVoice: one wavefront per voice, 64 lanes x 4 frames (same argument block; rows / out as above).
 constexpr uint32_t kFmTpMaxVoices = 131072; // the serial kernel's 256-frame walk costs ~0.09 ms whatever the size; above this it has the wavefronts
@@ -769,9 +854,9 @@ __global__ __launch_bounds__(kSamplerTpThreads) void sampler_tp_kernel(TpArgs a,
 void launch_welsh_tp(const TpArgs& a, hipStream_t st, bool fused); // a.bq_coef set (block-writing form): the BiQuad head fused
 void launch_fm_tp(const TpArgs& a, hipStream_t st, bool fused);
 void launch_sampler_tp(const TpArgs& a, const float* bank, const InlineEvents& ie, hipStream_t st, bool fused);
-inline uint32_t welsh_tp_workgroups(uint32_t n) { return (n + kTpWaves - 1) / kTpWaves; } // FM: one group of 4 voices per workgroup, plain order
-inline uint32_t welsh_tp_grid(uint32_t n) { // Welsh: padded for the XCD-aware mapping (idle workgroups write zero rows)
-  const uint32_t g = welsh_tp_workgroups(n);
+inline uint32_t welsh_tp_workgroups(uint32_t n, uint32_t vpw = 1) { return (n + kTpWaves * vpw - 1) / (kTpWaves * vpw); } // FM: one group of 4 voices per workgroup, plain order
+inline uint32_t welsh_tp_grid(uint32_t n, uint32_t vpw = 1) { // Welsh: padded for the XCD-aware mapping (idle workgroups write zero rows)
+  const uint32_t g = welsh_tp_workgroups(n, vpw);
   return g >= 16 ? (g + 7u) & ~7u : g;
 }
 #endif // __HIPCC__

@@ -5,16 +5,26 @@
 #include "welsh_tp.h"
 #include <cstdlib>
 namespace groove {
-void launch_welsh_tp(const TpArgs& a, hipStream_t st, bool fused) {
-  const dim3 grid(welsh_tp_grid(a.n)), blk(kTpThreads);
-  if (fused) hipLaunchKernelGGL(welsh_tp_kernel<true>, grid, blk, 0, st, a);
+template <int VPW>
+static void launch_welsh_tp_vpw(const TpArgs& a, hipStream_t st, bool fused) {
+  const dim3 grid(welsh_tp_grid(a.n, VPW)), blk(kTpThreads);
+  if (a.full_coef) { // (rare: the resonance routing)
+    if (fused) hipLaunchKernelGGL((welsh_tp_kernel<true, false, true, VPW>), grid, blk, 0, st, a);
+    else if (a.bq_coef) hipLaunchKernelGGL((welsh_tp_kernel<false, true, true, VPW>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((welsh_tp_kernel<false, false, true, VPW>), grid, blk, 0, st, a);
+  }
+  else if (fused) hipLaunchKernelGGL((welsh_tp_kernel<true, false, false, VPW>), grid, blk, 0, st, a);
   else if (a.bq_coef) {
     // (experiment knob, round 3: unused dynamic LDS caps how many of this kernel's 163-VGPR wavefronts a CU takes, leaving
     // registers for the effect kernels that run beside it on the ctx stream — docs/STREAMS.md item 11)
     static const unsigned pad = [] { const char* e = std::getenv("GROOVE_TP_PAD_LDS"); return e ? (unsigned)std::strtoul(e, nullptr, 10) : 0u; }();
-    hipLaunchKernelGGL((welsh_tp_kernel<false, true>), grid, blk, pad, st, a);
+    hipLaunchKernelGGL((welsh_tp_kernel<false, true, false, VPW>), grid, blk, pad, st, a);
   }
-  else hipLaunchKernelGGL(welsh_tp_kernel<false>, grid, blk, 0, st, a);
+  else hipLaunchKernelGGL((welsh_tp_kernel<false, false, false, VPW>), grid, blk, 0, st, a);
+}
+void launch_welsh_tp(const TpArgs& a, hipStream_t st, bool fused) {
+  if (a.vpw == 2) launch_welsh_tp_vpw<2>(a, st, fused);
+  else launch_welsh_tp_vpw<1>(a, st, fused);
 }
 void launch_fm_tp(const TpArgs& a, hipStream_t st, bool fused) {
   const dim3 grid(welsh_tp_workgroups(a.n)), blk(kTpThreads);
@@ -28,3 +38,11 @@ void launch_sampler_tp(const TpArgs& a, const float* bank, const InlineEvents& i
   else hipLaunchKernelGGL(sampler_tp_kernel<false>, grid, blk, 0, st, a, bank, ie, vpw);
 }
 } // namespace groove
+#ifdef GROOVE_TP_PROBE
+extern "C" int groove_debug_tp_probe_read(unsigned long long out[16], int reset) { // measurement build only (tools/tp_probe.py)
+  if (hipDeviceSynchronize() != hipSuccess) return 2;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(groove::g_tp_probe), sizeof(groove::g_tp_probe)) != hipSuccess) return 3;
+  if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(groove::g_tp_probe), z, sizeof(z)) != hipSuccess) return 4; }
+  return 0;
+}
+#endif

@@ -75,6 +75,14 @@ class Context:
         _lib.check(self.L.groove_set_time_parallel_max_voices(self.h, n), self.h)
 
     @property
+    def time_parallel_pair_min_voices(self):
+        return self.L.groove_time_parallel_pair_min_voices(self.h)
+
+    @time_parallel_pair_min_voices.setter
+    def time_parallel_pair_min_voices(self, n):
+        _lib.check(self.L.groove_set_time_parallel_pair_min_voices(self.h, n), self.h)
+
+    @property
     def pipeline_min_waves(self):
         return self.L.groove_pipeline_min_waves(self.h)
 

@@ -32,6 +32,8 @@ SYMBOLS = {
     "groove_sample_rate": (_u32, [_vp]),
     "groove_set_time_parallel_max_voices": (_i, [_vp, _u32]),
     "groove_time_parallel_max_voices": (_u32, [_vp]),
+    "groove_set_time_parallel_pair_min_voices": (_i, [_vp, _u32]),
+    "groove_time_parallel_pair_min_voices": (_u32, [_vp]),
     "groove_set_pipeline_min_waves": (_i, [_vp, _u32]),
     "groove_pipeline_min_waves": (_u32, [_vp]),
     "groove_set_split_max_waves": (_i, [_vp, _u32]),

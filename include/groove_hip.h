@@ -75,6 +75,13 @@ uint32_t groove_sample_rate(groove_ctx* ctx);
  * the environment overrides it at groove_init).  No reference counterpart. */
 int groove_set_time_parallel_max_voices(groove_ctx* ctx, uint32_t max_voices);
 uint32_t groove_time_parallel_max_voices(groove_ctx* ctx);
+/* Tuning: time-parallel Welsh banks of at least this many voices, whose adjacent voices (2i, 2i + 1) share a patch, render
+ * TWO voices per wavefront (32 lanes x 8 frames each) instead of one (64 lanes x 4 frames): half the wavefronts, 25 % less
+ * issue per voice, the right trade once the one-voice form needs more wavefronts than the SIMDs hold at once.  Default 3,073;
+ * 0 = never; 1 = whenever the pairs allow (tests).  GROOVE_TP_VPW2_MIN_VOICES in the environment sets it at groove_init.
+ * No reference counterpart. */
+int groove_set_time_parallel_pair_min_voices(groove_ctx* ctx, uint32_t min_voices);
+uint32_t groove_time_parallel_pair_min_voices(groove_ctx* ctx);
 /* Tuning: Welsh banks of at least this many (virtual) wavefronts — 64 voices each; default 8,600 = ~550,000 voices — run
  * one kernel per base kind and pipeline consecutive fused blocks; smaller ones take one launch for all kinds.  1 forces
  * the per-kind pipelined form for every size (tests and bench.py's parity sample use it to run the kernels of the

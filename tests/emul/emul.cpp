@@ -174,8 +174,9 @@ static void welsh_tp_render_voice(const WelshParams& p, WelshState& state, const
         if (f < live_total) {
           l.lives[j] = true;
           const bool is_first = first0 && f == 0;
-          if (retunes) welsh_tp_frame<true>(p, l.s, rc, is_first, scans, l.ph1[j], l.ph2[j], nz[0][f], nz[1][f], nz[2][f], cur, prev_pct, l.x[j], l.amp[j]);
-          else welsh_tp_frame<false>(p, l.s, rc, is_first, scans, l.ph1[j], l.ph2[j], nz[0][f], nz[1][f], nz[2][f], cur, prev_pct, l.x[j], l.amp[j]);
+          float t_unused = 0.0f; bool hi_unused = false;
+          if (retunes) welsh_tp_frame<true>(p, l.s, rc, is_first, scans, l.ph1[j], l.ph2[j], nz[0][f], nz[1][f], nz[2][f], cur, prev_pct, l.x[j], l.amp[j], t_unused, hi_unused);
+          else welsh_tp_frame<false>(p, l.s, rc, is_first, scans, l.ph1[j], l.ph2[j], nz[0][f], nz[1][f], nz[2][f], cur, prev_pct, l.x[j], l.amp[j], t_unused, hi_unused);
           l.s.vflags = 0;
           lp24_affine_push(l.mine, cur, (double)l.x[j]);
         } else if (scans) { l.s.o1.phase = l.ph1[j]; l.s.o2.phase = l.ph2[j]; }

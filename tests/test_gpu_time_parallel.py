@@ -26,11 +26,21 @@ def _patches():
     return pats
 
 
-def test_time_parallel_matches_serial_kernels_and_oracle(gpu_ctx, oracle):
+@pytest.mark.parametrize("vpw", [1, 2])
+def test_time_parallel_matches_serial_kernels_and_oracle(gpu_ctx, oracle, vpw):
+    """vpw = 2: the two-voices-per-wavefront form (welsh_tp_kernel<.., VPW = 2>: 32 lanes x 8 frames per voice) on a bank whose
+    adjacent voices share a patch — forced for this small bank by groove_set_time_parallel_pair_min_voices(1); the bank's size
+    is odd, so the last wavefront holds one voice."""
     from groove_amd import entities as E
     pats = _patches()
-    n = len(pats) * 3            # three voices per patch, different keys; not a multiple of the 4 voices per workgroup
-    params = (T.WelshParams * n)(*[pats[i % len(pats)] for i in range(n)])
+    if vpw == 1:
+        n = len(pats) * 3        # three voices per patch, different keys; not a multiple of the 4 voices per workgroup
+        params = (T.WelshParams * n)(*[pats[i % len(pats)] for i in range(n)])
+    else:
+        n = len(pats) * 2 + 1    # voices 2k and 2k + 1 on patch k; not a multiple of the 8 voices per workgroup
+        params = (T.WelshParams * n)(*[pats[(i // 2) % len(pats)] for i in range(n)])
+    old_pair = gpu_ctx.time_parallel_pair_min_voices
+    gpu_ctx.time_parallel_pair_min_voices = 1 if vpw == 2 else 0
     keys = (38 + (7 * np.arange(n)) % 40).astype(np.uint8)
     keys[keys % 12 == 9] += 1    # no A notes: exact edge ties (DSP_SPEC §2)
     on = T.note_events_np(np.arange(n, dtype=np.uint32), keys, True)
@@ -38,6 +48,7 @@ def test_time_parallel_matches_serial_kernels_and_oracle(gpu_ctx, oracle):
     old = gpu_ctx.time_parallel_max_voices
     assert old >= n
     tp, ser = E.WelshSynth(gpu_ctx, params), E.WelshSynth(gpu_ctx, params)
+    assert ("two voices per wavefront" in tp.kernel_form(256, False)) == (vpw == 2), tp.kernel_form(256, False)
     orc = oracle.Bank.welsh(params)
     block = gpu_ctx.block(n, 256)
     worst_ser = worst_orc = 0.0
@@ -77,6 +88,7 @@ def test_time_parallel_matches_serial_kernels_and_oracle(gpu_ctx, oracle):
             assert np.max(np.abs(f_tp - f_ser) / np.maximum(1e-3, np.abs(f_ser))) <= 1e-6, blk
     finally:
         gpu_ctx.time_parallel_max_voices = old
+        gpu_ctx.time_parallel_pair_min_voices = old_pair
     assert worst_ser <= 2e-6, worst_ser
     assert worst_orc <= 1e-5, worst_orc
     tp.destroy(); ser.destroy(); block.destroy()
@@ -97,3 +109,49 @@ def test_time_parallel_fused_bus_config2(gpu_ctx, oracle):
     proj.destroy(); bus.destroy()
     assert np.sqrt(np.mean(want ** 2)) > 1e-3
     assert np.sqrt(np.mean((got - want) ** 2)) <= 1e-6
+
+
+def test_two_voices_per_wavefront_fused_and_chained_forms(gpu_ctx, oracle):
+    """Config #3's shape at a size the oracle renders in seconds: 256 Welsh voices laid out synth by synth (8 per patch, so
+    adjacent voices share a patch), the BiQuad -> Chorus -> Delay -> Reverb chain with its IIR head fused into the render, the
+    time-parallel kernel forced to two voices per wavefront.  Bus against the oracle; and the fused render + mix of a plain
+    Welsh project in the same form against the one-voice form (the forms differ by f64 rounding of the filter scan only)."""
+    from groove_amd import projects as PJ
+    from oracle.projects import OracleProject
+    old_pair = gpu_ctx.time_parallel_pair_min_voices
+    try:
+        sel = np.arange(256)
+        blocks = 80  # (the chain's 11,025-frame delay line is wet only: the bus is silent for the first 43 blocks)
+        buses = {}
+        for pair_min in (0, 1):
+            gpu_ctx.time_parallel_pair_min_voices = pair_min
+            proj = PJ.Project(gpu_ctx, "chain-4096", sel)
+            forms = [inst.kernel_form(256, False) for inst, _, _, _ in proj.banks]
+            bus = gpu_ctx.bus(blocks * 256)
+            for b in range(blocks):
+                proj.step(bus, b * 256)
+            buses[pair_min] = bus.download().astype(np.float64) / 256
+            proj.destroy(); bus.destroy()
+            if forms:
+                assert any("two voices per wavefront" in f for f in forms) == (pair_min == 1), forms
+        want = OracleProject("chain-4096", sel).render(blocks) / 256
+        sig = np.sqrt(np.mean(want ** 2))
+        assert sig > 1e-3
+        for k, got in buses.items():
+            assert np.sqrt(np.mean((got - want) ** 2)) <= 1e-5 * max(1.0, sig / 0.1), k
+        assert np.max(np.abs(buses[0] - buses[1])) <= 2e-6 * max(1.0, np.abs(want).max())
+        fused = {}
+        for pair_min in (0, 1):
+            gpu_ctx.time_parallel_pair_min_voices = pair_min
+            proj = PJ.Project(gpu_ctx, "welsh-1m", sel)
+            bus = gpu_ctx.bus(100 * 256)
+            for b in range(100):
+                proj.step(bus, b * 256)
+            fused[pair_min] = bus.download().astype(np.float64) / 256
+            proj.destroy(); bus.destroy()
+        want = OracleProject("welsh-1m", sel).render(100) / 256
+        for k, got in fused.items():
+            assert np.sqrt(np.mean((got - want) ** 2)) <= 1e-6, k
+        assert np.max(np.abs(fused[0] - fused[1])) <= 1e-6
+    finally:
+        gpu_ctx.time_parallel_pair_min_voices = old_pair
