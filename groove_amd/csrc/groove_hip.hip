@@ -11,6 +11,7 @@
 #include "welsh_split.h"
 #include "fx_tp.h"
 #include <dlfcn.h>
+#include <hip/hip_ext.h> // hipExtLaunchKernelGGL: an event bound to a kernel's own completion signal (launch_reduce, launch_welsh_tp)
 #include <rccl/rccl.h> // types, enumerators and prototypes only: the library itself is dlopen'ed (rccl_open)
 #include <string>
 #include <vector>
@@ -55,6 +56,7 @@ struct groove_block {
   hipEvent_t ev_free = nullptr, ev_ready[16] = {};
   uint32_t ready_mask = 0;
   bool released = false; // groove_block_release: ev_free marks the end of the block's consumers so far
+  bool free_marked = false; // ev_free already completes with the block's last consumer (groove_mix bound it to its last kernel): a release needs no record
   // The lane sums of the block, as the render that filled it left them: sums[row][ch][frame], `sum_rows` rows whose
   // column totals are the block's bus contribution (the fused path's partial rows).  groove_mix reduces these 8 MB
   // instead of reading 2 GB of voice block back; anything else that writes the block clears sums_valid.
@@ -149,6 +151,7 @@ struct groove_fx {
   uint32_t tmp_cap = 0; // frames
   int last_side = -1;           // side stream whose kernels touched this effect last (-1: the ctx stream); fx_acquire_ctx
   hipEvent_t ev_done = nullptr; // end of that use
+  bool done_recorded = true;    // false: the last use was a kernel whose end another event marks (a fused render's): ev_done is recorded on demand
 };
 
 // Events that only order the library's own streams on one device: no timing, and no system-scope fence
@@ -196,6 +199,9 @@ struct groove_ctx {
   // Welsh banks of at least this many voices whose adjacent pairs share a patch render two voices per wavefront
   // (welsh_tp_kernel<.., VPW = 2>): above 3,072 voices the one-voice form no longer fits the SIMDs in one round
   uint32_t tp_vpw2_min_voices = 3073; // GROOVE_TP_VPW2_MIN_VOICES (0 = never)
+  // events that mark the end of ONE kernel (a block's render, a block's last reduction) are bound to that dispatch's own
+  // completion signal instead of being recorded behind it (a barrier packet each, ~5 us of the stream's timeline)
+  bool bind_events = true;            // GROOVE_BIND_EVENTS=0: always hipEventRecord (A/B)
   uint32_t fx_seg_max_lanes = 49152;     // biquad banks of up to this many lane-channels take the four-segment kernel (measured, tools/fx_bench.py: 8,192 lane-channels 17.5 -> 9.3 us, 32,768 19.4 -> 15.6, 131,072 42.9 -> 58.4; GROOVE_FX_SEG_MAX_LANES, 0 = never)
   uint32_t fx_tp_wide_min_lanes = 8192;  // from this many lane-channels the time-parallel IIR kernels take 32-wide tiles (GROOVE_FX_TP_WIDE_MIN_LANES)
   bool fx_lds_staging = false;          // GROOVE_FX_LDS_STAGING=1 (A/B): the fused run kernel stages the chorus taps through LDS
@@ -319,6 +325,7 @@ int ctx_join(groove_ctx* ctx) {
 // Every ctx-stream operation that reads or writes a block calls this first.
 int block_acquire(groove_block* blk) {
   blk->released = false; // the ctx stream is about to use the block again
+  blk->free_marked = false;
   if (!blk->ready_mask) return 0;
   groove_ctx* ctx = blk->ctx;
   for (int k = 0; k < kSideStreams; ++k)
@@ -357,8 +364,18 @@ int block_normalise(groove_block* blk) {
 // An effect's memory (IIR state, rings, parameter arrays) is touched by one stream at a time: the ctx stream, or — for the
 // stages groove_fx_chain_process_async runs behind a block's asynchronous render — that render's side stream.  ev_done
 // marks the end of its last side-stream use; the ctx stream waits for it before it touches the effect again.
+hipStream_t side_stream_of(groove_ctx* ctx, int k);
+// ev_done of an effect whose last side-stream use was not followed by a record of its own: the CURRENT end of that stream
+// (later than needed, never earlier: the stream runs in order)
+int fx_done_event(groove_fx* fx) {
+  if (fx->done_recorded) return 0;
+  GHIP(fx->ctx, hipEventRecord(fx->ev_done, side_stream_of(fx->ctx, fx->last_side)));
+  fx->done_recorded = true;
+  return 0;
+}
 int fx_acquire_ctx(groove_fx* fx) {
   if (fx->last_side < 0) return 0;
+  if (fx_done_event(fx)) return 1;
   GHIP(fx->ctx, hipStreamWaitEvent(fx->ctx->stream, fx->ev_done, 0));
   fx->last_side = -1;
   return 0;
@@ -731,20 +748,25 @@ int ensure_seg_buffer(groove_ctx* ctx, float** buf, size_t* cap, size_t seg_floa
 // bus[f][ch] (+)= column sums of partial[row][ch][frame] on the ctx stream (fixed order: segments of 64 rows, then the
 // segments in index order; a single segment's sums go straight to the bus).
 constexpr uint32_t kRowsPerSeg = 64;
-void launch_reduce(groove_ctx* ctx, const float* partial, uint32_t rows, uint32_t frames, float* seg_buf, float* bus_dev, int accumulate) {
+// `done` (optional): an event that completes with the LAST kernel of the reduction — bound to that dispatch's own completion
+// signal (hipExtLaunchKernelGGL), not recorded behind it: a recorded event is a barrier packet of its own, ~5 us of the
+// stream's timeline (docs/STREAMS.md).
+void launch_reduce(groove_ctx* ctx, const float* partial, uint32_t rows, uint32_t frames, float* seg_buf, float* bus_dev, int accumulate, hipEvent_t done = nullptr) {
   const uint32_t cols = 2 * frames, segs = (rows + kRowsPerSeg - 1) / kRowsPerSeg;
   const dim3 blk(kThreads);
   if (segs == 1) {
-    hipLaunchKernelGGL(partial_rows_kernel, dim3(blocks_for(cols), 1), blk, 0, ctx->stream, partial, rows, cols, kRowsPerSeg, seg_buf, bus_dev, accumulate);
+    if (done) hipExtLaunchKernelGGL(partial_rows_kernel, dim3(blocks_for(cols), 1), blk, 0, ctx->stream, nullptr, done, 0, partial, rows, cols, kRowsPerSeg, seg_buf, bus_dev, accumulate);
+    else hipLaunchKernelGGL(partial_rows_kernel, dim3(blocks_for(cols), 1), blk, 0, ctx->stream, partial, rows, cols, kRowsPerSeg, seg_buf, bus_dev, accumulate);
   } else {
     hipLaunchKernelGGL(partial_rows_kernel, dim3(blocks_for(cols), segs), blk, 0, ctx->stream, partial, rows, cols, kRowsPerSeg, seg_buf, (float*)nullptr, 0);
-    hipLaunchKernelGGL(partial_final_kernel, dim3(blocks_for(cols)), blk, 0, ctx->stream, seg_buf, segs, frames, bus_dev, accumulate);
+    if (done) hipExtLaunchKernelGGL(partial_final_kernel, dim3(blocks_for(cols)), blk, 0, ctx->stream, nullptr, done, 0, seg_buf, segs, frames, bus_dev, accumulate);
+    else hipLaunchKernelGGL(partial_final_kernel, dim3(blocks_for(cols)), blk, 0, ctx->stream, seg_buf, segs, frames, bus_dev, accumulate);
   }
 }
-int reduce_rows(groove_ctx* ctx, const float* rows_dev, uint32_t rows, uint32_t frames, float* bus_dev, int accumulate) {
+int reduce_rows(groove_ctx* ctx, const float* rows_dev, uint32_t rows, uint32_t frames, float* bus_dev, int accumulate, hipEvent_t done = nullptr) {
   const uint32_t cols = 2 * frames, segs = (rows + kRowsPerSeg - 1) / kRowsPerSeg;
   if (ensure_seg_buffer(ctx, &ctx->d_fseg, &ctx->fseg_cap, (size_t)segs * cols)) return 1;
-  launch_reduce(ctx, rows_dev, rows, frames, ctx->d_fseg, bus_dev, accumulate);
+  launch_reduce(ctx, rows_dev, rows, frames, ctx->d_fseg, bus_dev, accumulate, done);
   GHIP(ctx, hipGetLastError());
   return 0;
 }
@@ -986,6 +1008,7 @@ static int init_impl(int device_ordinal, const uint8_t* comm_id, int rank, int w
   if (ctx->safe_streams) ctx->kind_streams = 3;
   if (const char* e = std::getenv("GROOVE_BANK_STREAMS")) ctx->bank_streams = std::max(1, std::min(kBankStreams, std::atoi(e)));
   if (const char* e = std::getenv("GROOVE_FM_TP_MAX_VOICES")) ctx->fm_tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
+  if (const char* e = std::getenv("GROOVE_BIND_EVENTS")) ctx->bind_events = std::atoi(e) != 0;
   if (const char* e = std::getenv("GROOVE_TP_VPW2_MIN_VOICES")) ctx->tp_vpw2_min_voices = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_SEG_MAX_LANES")) ctx->fx_seg_max_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_TP_WIDE_MIN_LANES")) ctx->fx_tp_wide_min_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
@@ -1354,13 +1377,14 @@ static bool use_tp(const groove_bank* b, uint32_t frames) {
 static uint32_t tp_vpw(const groove_bank* b) { // voices per wavefront of the time-parallel Welsh kernel
   return (b->kind == BANK_WELSH && b->tp_pairs && b->ctx->tp_vpw2_min_voices && b->n >= b->ctx->tp_vpw2_min_voices) ? 2u : 1u;
 }
-static void launch_tp(groove_bank* b, uint32_t frames, bool fused, size_t chs, float* out, float* rows, hipStream_t st, const groove_fx* head = nullptr) {
+static void launch_tp(groove_bank* b, uint32_t frames, bool fused, size_t chs, float* out, float* rows, hipStream_t st, const groove_fx* head = nullptr,
+                      hipEvent_t done = nullptr /* Welsh only: completes with the kernel (bound to the dispatch) */) {
   groove_ctx* ctx = b->ctx;
   TpArgs a{b->d_params, b->d_state, out, rows, chs, render_consts(ctx->sr), b->n, frames};
   if (head) { a.bq_coef = head->d_coef; a.bq_st = head->d_st; a.bq_wet = head->d_wet; } // Welsh, block-writing form: the BiQuad head fused (welsh_tp.h)
   if (b->kind == BANK_FM) launch_fm_tp(a, st, fused);
   else if (b->kind == BANK_SAMPLER) { launch_sampler_tp(a, b->d_pcm, b->inline_ev, st, fused); b->inline_ev.n = 0; }
-  else { a.full_coef = b->tp_full_coef; a.vpw = tp_vpw(b); launch_welsh_tp(a, st, fused); }
+  else { a.full_coef = b->tp_full_coef; a.vpw = tp_vpw(b); launch_welsh_tp(a, st, fused, done); }
 }
 // rows of partial[][2][frames] a bank's fused render writes
 static uint32_t fused_rows(const groove_bank* b, uint32_t frames) {
@@ -1581,8 +1605,9 @@ static int render_async_impl(groove_bank* b, uint32_t frames, groove_block* out,
     ctx->fork_pending[k] = false;
     return st;
   };
+  bool ready_bound = false; // the launch itself carries out->ev_ready[k]
   auto end = [&](int k) {
-    (void)hipEventRecord(out->ev_ready[k], side_stream_of(ctx, k));
+    if (!ready_bound) (void)hipEventRecord(out->ev_ready[k], side_stream_of(ctx, k));
     used |= 1u << k;
     ctx->side_busy[k] = true;
   };
@@ -1612,15 +1637,20 @@ static int render_async_impl(groove_bank* b, uint32_t frames, groove_block* out,
         if (head->last_side != k) {
           if (!head->ev_done) GHIP(ctx, hipEventCreateWithFlags(&head->ev_done, kSyncEventFlags));
           if (head->last_side < 0) GHIP(ctx, hipEventRecord(head->ev_done, ctx->stream));
+          else if (fx_done_event(head)) return 1;
           GHIP(ctx, hipStreamWaitEvent(st, head->ev_done, 0));
         }
       }
-      launch_tp(b, frames, false, chs, dst, rows, st, fuse ? head : nullptr);
-      if (fuse) {
-        GHIP(ctx, hipEventRecord(head->ev_done, st));
+      // the block's "ready" event completes with the render kernel itself (no record behind it)
+      const bool bind = ctx->bind_events && b->kind == BANK_WELSH;
+      launch_tp(b, frames, false, chs, dst, rows, st, fuse ? head : nullptr, bind ? out->ev_ready[k] : nullptr);
+      if (fuse) { // the effect's last use ends with that kernel too: its own event is recorded when somebody asks (fx_done_event)
+        if (bind) head->done_recorded = false;
+        else { GHIP(ctx, hipEventRecord(head->ev_done, st)); head->done_recorded = true; }
         head->last_side = k;
         *head_fused = true;
       }
+      ready_bound = bind;
     } else if (small_uniform) { // all base kinds in one launch
       const RenderConsts rc = render_consts(ctx->sr);
       UniformArgs a{b->d_waves, b->d_state, dst, rows, b->d_wg_list, b->d_wg_cls, chs, rc, b->n_vwaves, b->n, frames, b->n_vwaves / kWaves};
@@ -1643,12 +1673,13 @@ static int render_async_impl(groove_bank* b, uint32_t frames, groove_block* out,
 int groove_block_release(groove_block* b) {
   if (!b) return fail(nullptr, "groove_block_release: block is NULL");
   groove_ctx* ctx = b->ctx;
+  const bool marked = b->free_marked; // nothing has taken the block since the mix that bound ev_free to its last kernel
   if (block_acquire(b)) return 1;
   if (!b->ev_free) {
     GHIP(ctx, hipEventCreateWithFlags(&b->ev_free, kSyncEventFlags));
     for (int k = 0; k < kSideStreams; ++k) GHIP(ctx, hipEventCreateWithFlags(&b->ev_ready[k], kSyncEventFlags));
   }
-  GHIP(ctx, hipEventRecord(b->ev_free, ctx->stream));
+  if (!marked) GHIP(ctx, hipEventRecord(b->ev_free, ctx->stream));
   b->released = true;
   return 0;
 }
@@ -2110,11 +2141,13 @@ int groove_fx_chain_process_async(groove_fx* const* chain, uint32_t n_fx, groove
     if (fx->last_side != k) { // the stream that used the effect last: the ctx stream (or another side stream)
       if (!fx->ev_done) GHIP(ctx, hipEventCreateWithFlags(&fx->ev_done, kSyncEventFlags));
       if (fx->last_side < 0) GHIP(ctx, hipEventRecord(fx->ev_done, ctx->stream));
+      else if (fx_done_event(fx)) return 1;
       GHIP(ctx, hipStreamWaitEvent(st, fx->ev_done, 0));
     }
     io->sums_valid = false;
     if (fx_launch_serial(fx, io, frames, st)) return 1;
     GHIP(ctx, hipEventRecord(fx->ev_done, st));
+    fx->done_recorded = true;
     fx->last_side = k;
     ++done;
   }
@@ -2205,9 +2238,13 @@ int groove_mix(groove_ctx* ctx, groove_block* const* blocks, uint32_t n_blocks, 
     if (!blocks[i]) return fail(ctx, "groove_mix: NULL block");
     if (frames > blocks[i]->cap) return fail(ctx, "groove_mix: frames > block capacity");
     if (block_acquire(blocks[i])) return 1;
-    const groove_block* blk = blocks[i];
+    groove_block* blk = blocks[i];
     if (blk->sums_valid && blk->sum_frames == frames) { // the render left the block's lane sums: reduce those rows
-      if (reduce_rows(ctx, blk->d_sums, blk->sum_rows, frames, bus_dev, accumulate || i > 0)) return 1;
+      // a block of the render-ahead rotation (it has its events): this reduction is normally its last consumer before the host
+      // releases it, so the block's "free" event is bound to the reduction's last kernel and the release records nothing
+      const bool mark = blk->ev_free && ctx->bind_events;
+      if (reduce_rows(ctx, blk->d_sums, blk->sum_rows, frames, bus_dev, accumulate || i > 0, mark ? blk->ev_free : nullptr)) return 1;
+      blk->free_marked = mark;
     } else if (mix_one(ctx, blocks[i], frames, bus_dev, accumulate || i > 0)) return 1;
   }
   return 0;

@@ -851,7 +851,7 @@ __global__ __launch_bounds__(kSamplerTpThreads) void sampler_tp_kernel(TpArgs a,
     soa_store(a.state, n, v, s);
   }
 }
-void launch_welsh_tp(const TpArgs& a, hipStream_t st, bool fused); // a.bq_coef set (block-writing form): the BiQuad head fused
+void launch_welsh_tp(const TpArgs& a, hipStream_t st, bool fused, hipEvent_t done = nullptr); // a.bq_coef set (block-writing form): the BiQuad head fused; done: an event bound to the dispatch
 void launch_fm_tp(const TpArgs& a, hipStream_t st, bool fused);
 void launch_sampler_tp(const TpArgs& a, const float* bank, const InlineEvents& ie, hipStream_t st, bool fused);
 inline uint32_t welsh_tp_workgroups(uint32_t n, uint32_t vpw = 1) { return (n + kTpWaves * vpw - 1) / (kTpWaves * vpw); } // FM: one group of 4 voices per workgroup, plain order

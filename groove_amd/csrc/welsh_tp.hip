@@ -4,27 +4,35 @@
 #include "kernels.h"
 #include "welsh_tp.h"
 #include <cstdlib>
+#include <hip/hip_ext.h>
 namespace groove {
+// `done` (optional): an event that completes with this kernel, bound to the dispatch's own completion signal
+// (hipExtLaunchKernelGGL) instead of recorded behind it (a barrier packet of its own)
+template <class K>
+static void tp_launch(K kernel, dim3 grid, dim3 blk, unsigned lds, hipStream_t st, hipEvent_t done, const TpArgs& a) {
+  if (done) hipExtLaunchKernelGGL(kernel, grid, blk, lds, st, nullptr, done, 0, a);
+  else hipLaunchKernelGGL(kernel, grid, blk, lds, st, a);
+}
 template <int VPW>
-static void launch_welsh_tp_vpw(const TpArgs& a, hipStream_t st, bool fused) {
+static void launch_welsh_tp_vpw(const TpArgs& a, hipStream_t st, bool fused, hipEvent_t done) {
   const dim3 grid(welsh_tp_grid(a.n, VPW)), blk(kTpThreads);
   if (a.full_coef) { // (rare: the resonance routing)
-    if (fused) hipLaunchKernelGGL((welsh_tp_kernel<true, false, true, VPW>), grid, blk, 0, st, a);
-    else if (a.bq_coef) hipLaunchKernelGGL((welsh_tp_kernel<false, true, true, VPW>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((welsh_tp_kernel<false, false, true, VPW>), grid, blk, 0, st, a);
+    if (fused) tp_launch(welsh_tp_kernel<true, false, true, VPW>, grid, blk, 0, st, done, a);
+    else if (a.bq_coef) tp_launch(welsh_tp_kernel<false, true, true, VPW>, grid, blk, 0, st, done, a);
+    else tp_launch(welsh_tp_kernel<false, false, true, VPW>, grid, blk, 0, st, done, a);
   }
-  else if (fused) hipLaunchKernelGGL((welsh_tp_kernel<true, false, false, VPW>), grid, blk, 0, st, a);
+  else if (fused) tp_launch(welsh_tp_kernel<true, false, false, VPW>, grid, blk, 0, st, done, a);
   else if (a.bq_coef) {
-    // (experiment knob, round 3: unused dynamic LDS caps how many of this kernel's 163-VGPR wavefronts a CU takes, leaving
+    // (experiment knob, round 3: unused dynamic LDS caps how many of this kernel's wavefronts a CU takes, leaving
     // registers for the effect kernels that run beside it on the ctx stream — docs/STREAMS.md item 11)
     static const unsigned pad = [] { const char* e = std::getenv("GROOVE_TP_PAD_LDS"); return e ? (unsigned)std::strtoul(e, nullptr, 10) : 0u; }();
-    hipLaunchKernelGGL((welsh_tp_kernel<false, true, false, VPW>), grid, blk, pad, st, a);
+    tp_launch(welsh_tp_kernel<false, true, false, VPW>, grid, blk, pad, st, done, a);
   }
-  else hipLaunchKernelGGL((welsh_tp_kernel<false, false, false, VPW>), grid, blk, 0, st, a);
+  else tp_launch(welsh_tp_kernel<false, false, false, VPW>, grid, blk, 0, st, done, a);
 }
-void launch_welsh_tp(const TpArgs& a, hipStream_t st, bool fused) {
-  if (a.vpw == 2) launch_welsh_tp_vpw<2>(a, st, fused);
-  else launch_welsh_tp_vpw<1>(a, st, fused);
+void launch_welsh_tp(const TpArgs& a, hipStream_t st, bool fused, hipEvent_t done) {
+  if (a.vpw == 2) launch_welsh_tp_vpw<2>(a, st, fused, done);
+  else launch_welsh_tp_vpw<1>(a, st, fused, done);
 }
 void launch_fm_tp(const TpArgs& a, hipStream_t st, bool fused) {
   const dim3 grid(welsh_tp_workgroups(a.n)), blk(kTpThreads);
