@@ -528,8 +528,11 @@ __global__ __launch_bounds__(kTpThreads, VPW == 1 ? GROOVE_TP_WAVES : 2) void we
     const float* nz1 = welsh_tp_noise(p, 0) ? s_noise[wv][0] : nullptr;
     const float* nz2 = welsh_tp_noise(p, 1) ? s_noise[wv][1] : nullptr;
     const float* nzl = welsh_tp_noise(p, 2) ? s_noise[wv][2] : nullptr;
-    if (retunes) welsh_tp_chunk<true, FULL_COEF, CH>(p, s, rc, first0, n0, cnt, nlive, scans, ph1, ph2, nz1, nz2, nzl, cur0, co, coef_full, mine);
-    else welsh_tp_chunk<false, FULL_COEF, CH>(p, s, rc, first0, n0, cnt, nlive, scans, ph1, ph2, nz1, nz2, nzl, cur0, co, coef_full, mine);
+    // ONE instantiation for retuned and static patches (the retune's tests are scalar branches on the patch flags): a second
+    // copy of the unrolled frames is ~3,000 more instructions of kernel text, and this kernel — latency-bound, a handful of
+    // wavefronts per CU — pays for text it does not keep in the 64 KB instruction cache two CUs share (round 3, tools/tp_probe.py:
+    // the same first 340 instructions took 3,100 cycles in one build and 15,900 in a build 12 % longer).
+    welsh_tp_chunk<true, FULL_COEF, CH>(p, s, rc, first0, n0, cnt, nlive, scans, ph1, ph2, nz1, nz2, nzl, cur0, co, coef_full, mine);
   }
   TP_PROBE // 5: pass 2 (feed-forward + affine push)
   // inclusive scan of the affine maps over the voice's lanes, then every lane's start state
