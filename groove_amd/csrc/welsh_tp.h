@@ -407,8 +407,11 @@ __global__ __launch_bounds__(kTpThreads, VPW == 1 ? GROOVE_TP_WAVES : 2) void we
   static_assert(VPW == 1 || VPW == 2, "");
   constexpr uint32_t LPV = 64 / VPW, CH = kTpChunk * VPW, WGV = kTpWaves * VPW; // lanes per voice, frames per lane, voices per workgroup
   __shared__ float s_noise[WGV][3][kTpMaxFrames];
+  // hard sync's prefix sums (pass 1) and the output tile (the end) share their 2 KB per voice: until the workgroup barrier in
+  // front of the tile turn a wavefront touches its own voices' rows only, and its tile writes follow its last sync gather
   __shared__ uint64_t s_sum2[WGV][kTpMaxFrames];
-  __shared__ float s_tile[WGV][2][kTpMaxFrames];
+  float (*s_tile)[2][kTpMaxFrames] = reinterpret_cast<float (*)[2][kTpMaxFrames]>(&s_sum2[0][0]);
+  static_assert(sizeof(uint64_t) * kTpMaxFrames == sizeof(float) * 2 * kTpMaxFrames, "a voice's tile row is its prefix-sum row");
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t vl = lane & (LPV - 1u), sub = lane / LPV, wv = wave * VPW + sub; // lane within the voice, voice within the wave / workgroup
   const int lbase = (int)(sub * LPV);                                             // the voice's first lane
