@@ -315,26 +315,41 @@ def under_profiler():
 
 
 class timed_kernel_form:
-    """Make a SMALL sample project run the kernels the full-size workload's timed region runs: welsh-1m (and any Welsh
-    bank above ~550,000 voices) takes one welsh_render_uniform_kernel per base kind with pipelined blocks, but a bank of
-    a few hundred voices would take the time-parallel kernel — so the time-parallel form is switched off and the per-kind
-    pipeline forced for the duration (groove_set_time_parallel_max_voices 0, groove_set_pipeline_min_waves 1)."""
+    """Make a SMALL sample project run the Welsh kernel form the full-size workload's timed region runs.  The library picks the
+    form by bank size: time-parallel with one voice per wavefront (up to 3,072 voices) or two (up to
+    16,384), role-split (up to 65,536 / 131,072), all kinds in one serial launch (up to ~550,000), one launch per base kind with
+    pipelined blocks above — and a sample of a few dozen voices would always take the first.  The tuning knobs of the C ABI
+    force the timed bank's form for the duration; `matches` (after the sample project is built) says whether the sample's Welsh
+    form is the timed one."""
 
     def __init__(self, ctx, workload, v_total):
         self.ctx = ctx
-        wl = WORKLOADS[workload]
-        self.force = wl["kind"] == "welsh" and v_total >= 550_000
+        kind = WORKLOADS[workload]["kind"]
+        vw = {"welsh": v_total, "chain": v_total, "mixed": v_total // 2}.get(kind, 0)  # Welsh voices of the timed bank
+        tp_max, pair_min = ctx.time_parallel_max_voices, ctx.time_parallel_pair_min_voices
+        split_max, pipe_min = ctx.split_max_waves * 64, ctx.pipeline_min_waves * 64
+        self.set = {}
+        if vw == 0 or (vw <= tp_max and (pair_min == 0 or vw < pair_min)):
+            self.form = "default (time-parallel, one voice per wavefront)"
+        elif vw <= tp_max:
+            self.form, self.set = "time-parallel, two voices per wavefront", {"time_parallel_pair_min_voices": 1}
+        elif vw <= split_max:
+            self.form, self.set = "role-split (four wavefronts per 64 voices)", {"time_parallel_max_voices": 0, "split_max_waves": max(ctx.split_max_waves, 4096)}
+        elif vw < pipe_min:
+            self.form, self.set = "serial, all kinds in one launch", {"time_parallel_max_voices": 0, "split_max_waves": 0}
+        else:
+            self.form, self.set = "serial, one launch per base kind, blocks pipelined", {"time_parallel_max_voices": 0, "pipeline_min_waves": 1}
+        self.force = bool(self.set)
 
     def __enter__(self):
-        if self.force:
-            self.old = (self.ctx.time_parallel_max_voices, self.ctx.pipeline_min_waves)
-            self.ctx.time_parallel_max_voices = 0
-            self.ctx.pipeline_min_waves = 1
+        self.old = {k: getattr(self.ctx, k) for k in self.set}
+        for k, v in self.set.items():
+            setattr(self.ctx, k, v)
         return self
 
     def __exit__(self, *exc):
-        if self.force:
-            self.ctx.time_parallel_max_voices, self.ctx.pipeline_min_waves = self.old
+        for k, v in self.old.items():
+            setattr(self.ctx, k, v)
 
 
 def sampled_parity(ctx, workload, v_total, blocks, sample=64, fused=True, grouped=True):
@@ -359,7 +374,7 @@ def sampled_parity(ctx, workload, v_total, blocks, sample=64, fused=True, groupe
     per_block = np.sqrt(np.mean((got - want).reshape(blocks, -1) ** 2, axis=1))
     return {"voices_sampled": int(len(sel)), "blocks": blocks, "timeline_blocks": f"0..{blocks - 1}",
             "normalisation": "bus / voices sampled",
-            "kernel_form": forms, "kernel_form_forced_to_match_timed_region": bool(forced.force),
+            "kernel_form": forms, "kernel_form_forced_to_match_timed_region": bool(forced.force), "kernel_form_forced_to": forced.form,
             "bus_rms_err": rms, "bus_rms_err_worst_block": float(per_block.max()), "worst_block": int(per_block.argmax()),
             "signal_rms": float(np.sqrt(np.mean(want ** 2))), "signal_peak": peak,
             # an effect chain with gain (config #3: chorus taps + recirculating combs) lifts signal and error alike
