@@ -275,6 +275,16 @@ constexpr int kSamplerTpWaves = 16;
 constexpr int kSamplerTpThreads = kSamplerTpWaves * 64;
 constexpr uint32_t kTpMaxVoices = 16384;    // measured crossover with the serial kernels ~24,000 voices (tools/tp_bench.py)
 
+// N ticks of the noise generator on the scalar unit (wave-uniform state x1, x2): the value of tick I — x2 before the add —
+// goes to lane I of `acc` (v_writelane_b32 with the lane as an inline constant)
+template <int N, int I = 0> __device__ __forceinline__ void tp_noise_ticks(uint32_t& x1, uint32_t& x2, int& acc) {
+  if constexpr (I < N) {
+    x1 ^= x2;
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(acc) : "s"(x2), "i"(I));
+    x2 += x1;
+    tp_noise_ticks<N, I + 1>(x1, x2, acc);
+  }
+}
 template <class T> __device__ __forceinline__ T tp_shfl(T x, int src) {
   static_assert(sizeof(T) == 8 || sizeof(T) == 4, "");
   if constexpr (sizeof(T) == 8) {
@@ -436,11 +446,33 @@ __global__ __launch_bounds__(kTpThreads, VPW == 1 ? GROOVE_TP_WAVES : 2) void we
   const bool nz_any = welsh_tp_noise(p, 0) || welsh_tp_noise(p, 1) || welsh_tp_noise(p, 2);
   TP_PROBE // 1: parameters, state, env_idle_at
 
-  // ---- noise oscillators: one lane each, serially, values through LDS; end states stay in those lanes
+  // ---- noise oscillators: the generator has no jump-ahead, so its `live_total` values are produced serially — on the SCALAR
+  // unit (round 3): a voice's generator state is wave-uniform, a tick is s_xor + s_add, and the value lands in lane (tick mod 64)
+  // of a register by v_writelane; after 64 ticks the 64 lanes convert and store their values together.  Three instructions per
+  // tick instead of the eight of a one-lane VALU loop with its LDS store (a noise voice's wavefront was the slowest of its
+  // workgroup by ~17,000 cycles per block: the tail of config #2's kernel).  ONE copy of the 64-tick body serves the three
+  // oscillators and the wavefront's voices (kernel text is not free here, see pass 2).  End states: lanes 0 .. 2 of the voice.
   OscState nz_end = vl == 0 ? s0.o1 : (vl == 1 ? s0.o2 : s0.lfo);
   if (nz_any) {
-    if (vl < 3 && welsh_tp_noise(p, (int)vl)) {
-      for (uint32_t j = 0; j < live_total; ++j) s_noise[wv][vl][j] = noise_tick(nz_end);
+#pragma unroll 1
+    for (uint32_t job = 0; job < 3u * VPW; ++job) { // (oscillator k, voice sv of the wavefront)
+      const uint32_t k = job % 3u, sv = job / 3u;
+      if (!welsh_tp_noise(p, (int)k)) continue;
+      const uint32_t ox1 = k == 0 ? s0.o1.x1 : (k == 1 ? s0.o2.x1 : s0.lfo.x1), ox2 = k == 0 ? s0.o1.x2 : (k == 1 ? s0.o2.x2 : s0.lfo.x2);
+      const int src = (int)(sv * LPV); // a lane of that voice (they all hold its state)
+      uint32_t x1 = (uint32_t)__builtin_amdgcn_readlane((int)ox1, src), x2 = (uint32_t)__builtin_amdgcn_readlane((int)ox2, src);
+      const uint32_t lt = (uint32_t)__builtin_amdgcn_readlane((int)live_total, src);
+      float* row = s_noise[wave * VPW + sv][k];
+#pragma unroll 1
+      for (uint32_t base = 0; base < lt; base += 64) {
+        int acc = 0;
+        uint32_t y1 = x1, y2 = x2;
+        tp_noise_ticks<64>(y1, y2, acc); // (past lt inside the last 64: values nobody reads; the end state is taken below)
+        row[base + lane] = (float)acc * 4.6566128730773926e-10f; // noise_tick's value: x2 before the add, as int32 * 2^-31
+        if (base + 64 <= lt) { x1 = y1; x2 = y2; }
+        else { for (uint32_t i = base; i < lt; ++i) { x1 ^= x2; x2 += x1; } } // a ragged tail's end state: two scalar operations per tick
+      }
+      if (sub == sv && vl == k) { nz_end.x1 = x1; nz_end.x2 = x2; }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
