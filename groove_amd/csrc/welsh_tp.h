@@ -301,6 +301,45 @@ __device__ __forceinline__ void tp_shfl_affine(const Lp24Affine& m, int src, Lp2
 #pragma unroll
   for (int i = 0; i < 2; ++i) { out.c2[i] = tp_shfl(m.c2[i], src); out.c3[i] = tp_shfl(m.c3[i], src); }
 }
+// Inclusive scan of the affine maps over each group of LPV lanes, by DPP (round 3).  Rows of 16 lanes first (row_shr 1, 2, 4, 8),
+// then the rows' totals into the rows behind them (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3 — the second
+// only when a voice spans the wavefront).  A lane with nothing to receive gets the IDENTITY map from the instruction itself (the
+// `old` operand of a DPP move whose source is out of range or whose row is masked), and composing with the identity is exact, so
+// there is no select; and a DPP move is a register move, where ds_bpermute is an LDS round trip a lone wavefront cannot hide:
+// six steps of 32 ds_bpermute + 32 v_cndmask + 44 f64 operations became 32 DPP moves + 44 f64 operations each.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double tp_dpp_f64(double old, double x) {
+  const uint64_t o = __builtin_bit_cast(uint64_t, old), b = __builtin_bit_cast(uint64_t, x);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)o, (int)(uint32_t)b, CTRL, ROW_MASK, 0xF, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(o >> 32), (int)(uint32_t)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void tp_dpp_compose(Lp24Affine& incl) { // incl <- incl o (the map CTRL brings, or the identity)
+  Lp24Affine e;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    e.c0[i] = tp_dpp_f64<CTRL, ROW_MASK>(i == 0 ? 1.0 : 0.0, incl.c0[i]);
+    e.c1[i] = tp_dpp_f64<CTRL, ROW_MASK>(i == 1 ? 1.0 : 0.0, incl.c1[i]);
+    e.z[i] = tp_dpp_f64<CTRL, ROW_MASK>(0.0, incl.z[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    e.c2[i] = tp_dpp_f64<CTRL, ROW_MASK>(i == 0 ? 1.0 : 0.0, incl.c2[i]);
+    e.c3[i] = tp_dpp_f64<CTRL, ROW_MASK>(i == 1 ? 1.0 : 0.0, incl.c3[i]);
+  }
+  lp24_affine_compose(incl, e);
+}
+template <int LPV>
+__device__ __forceinline__ void tp_scan_affine(Lp24Affine& incl) {
+  static_assert(LPV == 64 || LPV == 32, "");
+  tp_dpp_compose<0x111, 0xF>(incl); // row_shr:1
+  tp_dpp_compose<0x112, 0xF>(incl); // row_shr:2
+  tp_dpp_compose<0x114, 0xF>(incl); // row_shr:4
+  tp_dpp_compose<0x118, 0xF>(incl); // row_shr:8
+  tp_dpp_compose<0x142, 0xA>(incl); // row_bcast:15 -> rows 1 and 3
+  if constexpr (LPV == 64) tp_dpp_compose<0x143, 0xC>(incl); // row_bcast:31 -> rows 2 and 3
+}
 // y-recurrence of the Direct Form 1 biquad as an affine map of (y1, y2): y = w - a1 y1 - a2 y2, w = b0 x + b1 x1 + b2 x2
 struct BqAffine { double m00, m01, m10, m11, z0, z1; }; // (y1, y2)' = M (y1, y2) + z
 __device__ __forceinline__ void bq_affine_identity(BqAffine& m) { m.m00 = 1.0; m.m01 = 0.0; m.m10 = 0.0; m.m11 = 1.0; m.z0 = 0.0; m.z1 = 0.0; }
@@ -572,12 +611,7 @@ __global__ __launch_bounds__(kTpThreads, VPW == 1 ? GROOVE_TP_WAVES : 2) void we
   TP_PROBE // 5: pass 2 (feed-forward + affine push)
   // inclusive scan of the affine maps over the voice's lanes, then every lane's start state
   Lp24Affine incl = mine;
-#pragma unroll 1
-  for (int d = 1; d < (int)LPV; d <<= 1) {
-    Lp24Affine other;
-    tp_shfl_affine(incl, (int)lane - d, other);
-    if ((int)vl >= d) lp24_affine_compose(incl, other);
-  }
+  tp_scan_affine<LPV>(incl);
   const double s_init[4] = {s0.filt.s0, s0.filt.s1, s0.filt.s2, s0.filt.s3};
   double s_end[4];
   lp24_affine_mul(incl, s_init, s_end, true);

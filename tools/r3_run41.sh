@@ -1,9 +1,9 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out
-L="groove_amd/libgroove_hip.so groove_amd/libvar_nz.so"
+L="groove_amd/libgroove_hip.so groove_amd/libvar_dpp.so"
 {
 REPS=3 tools/ab_bench.sh "--workload welsh-256" $L 2>&1 | sed "s/^/welsh-256 /"
 REPS=2 tools/ab_bench.sh "--workload chain-4096" $L 2>&1 | sed "s/^/chain-4096 /"
 REPS=2 tools/ab_bench.sh "--voices 16384" $L 2>&1 | sed "s/^/welsh-16384 /"
-cp groove_amd/libvar_nz.so groove_amd/libgroove_hip.so
+cp groove_amd/libvar_dpp.so groove_amd/libgroove_hip.so
 timeout 900 python3 -m pytest tests/test_gpu_time_parallel.py tests/test_gpu_welsh.py tests/test_gpu_welsh_classes.py -x -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -4
-} | tee gpurun_out/r3_nz_ab.log
+} | tee gpurun_out/r3_dpp_ab.log
