@@ -340,6 +340,30 @@ __device__ __forceinline__ void tp_scan_affine(Lp24Affine& incl) {
   tp_dpp_compose<0x142, 0xA>(incl); // row_bcast:15 -> rows 1 and 3
   if constexpr (LPV == 64) tp_dpp_compose<0x143, 0xC>(incl); // row_bcast:31 -> rows 2 and 3
 }
+// the same pattern for the prefix sums of the two oscillators' increments (identity 0) and the running maximum of the wrap
+// positions (identity -1: "none")
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t tp_dpp_u64(uint64_t old, uint64_t x) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)old, (int)(uint32_t)x, CTRL, ROW_MASK, 0xF, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(old >> 32), (int)(uint32_t)(x >> 32), CTRL, ROW_MASK, 0xF, false);
+  return ((uint64_t)hi << 32) | lo;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void tp_dpp_add2(uint64_t& a, uint64_t& b) { a += tp_dpp_u64<CTRL, ROW_MASK>(0, a); b += tp_dpp_u64<CTRL, ROW_MASK>(0, b); }
+template <int LPV>
+__device__ __forceinline__ void tp_scan_add_u64(uint64_t& a, uint64_t& b) {
+  tp_dpp_add2<0x111, 0xF>(a, b); tp_dpp_add2<0x112, 0xF>(a, b); tp_dpp_add2<0x114, 0xF>(a, b); tp_dpp_add2<0x118, 0xF>(a, b);
+  tp_dpp_add2<0x142, 0xA>(a, b);
+  if constexpr (LPV == 64) tp_dpp_add2<0x143, 0xC>(a, b);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void tp_dpp_max(int& x) { const int o = __builtin_amdgcn_update_dpp(-1, x, CTRL, ROW_MASK, 0xF, false); x = o > x ? o : x; }
+template <int LPV>
+__device__ __forceinline__ void tp_scan_max_i32(int& x) {
+  tp_dpp_max<0x111, 0xF>(x); tp_dpp_max<0x112, 0xF>(x); tp_dpp_max<0x114, 0xF>(x); tp_dpp_max<0x118, 0xF>(x);
+  tp_dpp_max<0x142, 0xA>(x);
+  if constexpr (LPV == 64) tp_dpp_max<0x143, 0xC>(x);
+}
 // y-recurrence of the Direct Form 1 biquad as an affine map of (y1, y2): y = w - a1 y1 - a2 y2, w = b0 x + b1 x1 + b2 x2
 struct BqAffine { double m00, m01, m10, m11, z0, z1; }; // (y1, y2)' = M (y1, y2) + z
 __device__ __forceinline__ void bq_affine_identity(BqAffine& m) { m.m00 = 1.0; m.m01 = 0.0; m.m10 = 0.0; m.m11 = 1.0; m.z0 = 0.0; m.z1 = 0.0; }
@@ -552,11 +576,7 @@ __global__ __launch_bounds__(kTpThreads, VPW == 1 ? GROOVE_TP_WAVES : 2) void we
     }
     // exclusive prefix over the voice's lanes of the lane totals (Hillis-Steele on the inclusive sums)
     uint64_t t1 = run1, t2 = run2;
-#pragma unroll
-    for (int d = 1; d < (int)LPV; d <<= 1) {
-      const uint64_t o1 = tp_shfl(t1, (int)lane - d), o2 = tp_shfl(t2, (int)lane - d);
-      if ((int)vl >= d) { t1 += o1; t2 += o2; }
-    }
+    tp_scan_add_u64<LPV>(t1, t2);
     const uint64_t base1 = t1 - run1, base2 = t2 - run2;
     int wlast = -1; // last frame <= f at which oscillator 1 wrapped (hard sync), within this lane so far
 #pragma unroll
@@ -569,11 +589,7 @@ __global__ __launch_bounds__(kTpThreads, VPW == 1 ? GROOVE_TP_WAVES : 2) void we
 #pragma unroll
       for (uint32_t j = 0; j < CH; ++j) if (j < cnt) s_sum2[wv][n0 + j] = loc2[j];
       int wl_incl = wlast; // max-scan over the voice's lanes
-#pragma unroll
-      for (int d = 1; d < (int)LPV; d <<= 1) {
-        const int o = __shfl(wl_incl, (int)lane - d, 64);
-        if ((int)vl >= d && o > wl_incl) wl_incl = o;
-      }
+      tp_scan_max_i32<LPV>(wl_incl);
       int wprev = __shfl(wl_incl, (int)lane - 1, 64);
       if (vl == 0) wprev = -1;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
