@@ -331,7 +331,7 @@ class timed_kernel_form:
         self.set = {}
         if vw == 0 or (vw <= tp_max and (pair_min == 0 or vw < pair_min)):
             self.form = "default (time-parallel, one voice per wavefront)"
-        elif vw <= tp_max:
+        elif vw <= tp_max + tp_max * 3 // 8 and pair_min:  # (the paired form's limit: groove_hip.hip use_tp; the projects' banks are laid out synth by synth)
             self.form, self.set = "time-parallel, two voices per wavefront", {"time_parallel_pair_min_voices": 1}
         elif vw <= split_max:
             self.form, self.set = "role-split (four wavefronts per 64 voices)", {"time_parallel_max_voices": 0, "split_max_waves": max(ctx.split_max_waves, 4096)}

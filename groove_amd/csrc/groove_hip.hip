@@ -1369,7 +1369,13 @@ static float* block_sums(groove_block* blk, uint32_t rows, uint32_t frames) {
 // Small Welsh banks and blocks of up to 256 frames: one wavefront per voice, lanes = time (welsh_tp.h).
 static bool use_tp(const groove_bank* b, uint32_t frames) {
   if (frames > kTpMaxFrames || b->ctx->tp_max_voices == 0) return false;
-  if (b->kind == BANK_WELSH) return b->n <= b->ctx->tp_max_voices;
+  if (b->kind == BANK_WELSH) {
+    // two voices per wavefront move the crossover with the role-split kernel up by three eighths (measured, round 3: 18,432
+    // voices 0.069 ms per block against 0.083, 22,528 0.080 against 0.084, 24,576 0.084 against 0.083)
+    const uint32_t tmax = b->ctx->tp_max_voices;
+    const bool pairs = b->tp_pairs && b->ctx->tp_vpw2_min_voices && b->n >= b->ctx->tp_vpw2_min_voices;
+    return b->n <= (pairs ? tmax + (uint32_t)std::min<uint64_t>((uint64_t)tmax * 3 / 8, 0x40000000u) : tmax);
+  }
   if (b->kind == BANK_FM) return b->n <= b->ctx->fm_tp_max_voices; // no filter scan: far cheaper per voice than a Welsh voice
   if (b->kind == BANK_SAMPLER) return b->n <= kSamplerTpMaxVoices; // a pure gather
   return false;

@@ -77,7 +77,8 @@ int groove_set_time_parallel_max_voices(groove_ctx* ctx, uint32_t max_voices);
 uint32_t groove_time_parallel_max_voices(groove_ctx* ctx);
 /* Tuning: time-parallel Welsh banks of at least this many voices, whose adjacent voices (2i, 2i + 1) share a patch, render
  * TWO voices per wavefront (32 lanes x 8 frames each) instead of one (64 lanes x 4 frames): half the wavefronts, 25 % less
- * issue per voice, the right trade once the one-voice form needs more wavefronts than the SIMDs hold at once.  Default 3,073;
+ * issue per voice, the right trade once the one-voice form needs more wavefronts than the SIMDs hold at once; such banks stay
+ * time-parallel up to 11/8 of groove_set_time_parallel_max_voices' limit (22,528 voices by default).  Default 3,073;
  * 0 = never; 1 = whenever the pairs allow (tests).  GROOVE_TP_VPW2_MIN_VOICES in the environment sets it at groove_init.
  * No reference counterpart. */
 int groove_set_time_parallel_pair_min_voices(groove_ctx* ctx, uint32_t min_voices);
