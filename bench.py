@@ -319,8 +319,8 @@ class timed_kernel_form:
     form by bank size: time-parallel with one voice per wavefront (up to 3,072 voices) or two (up to
     16,384), role-split (up to 65,536 / 131,072), all kinds in one serial launch (up to ~550,000), one launch per base kind with
     pipelined blocks above — and a sample of a few dozen voices would always take the first.  The tuning knobs of the C ABI
-    force the timed bank's form for the duration; `matches` (after the sample project is built) says whether the sample's Welsh
-    form is the timed one."""
+    force the timed bank's form for the duration.  (A Welsh limit of ONE voice, not zero: zero would switch the FM and sampler
+    banks of a mixed project to their serial kernels too.)"""
 
     def __init__(self, ctx, workload, v_total):
         self.ctx = ctx
@@ -334,11 +334,11 @@ class timed_kernel_form:
         elif vw <= tp_max + tp_max * 3 // 8 and pair_min:  # (the paired form's limit: groove_hip.hip use_tp; the projects' banks are laid out synth by synth)
             self.form, self.set = "time-parallel, two voices per wavefront", {"time_parallel_pair_min_voices": 1}
         elif vw <= split_max:
-            self.form, self.set = "role-split (four wavefronts per 64 voices)", {"time_parallel_max_voices": 0, "split_max_waves": max(ctx.split_max_waves, 4096)}
+            self.form, self.set = "role-split (four wavefronts per 64 voices)", {"time_parallel_max_voices": 1, "split_max_waves": max(ctx.split_max_waves, 4096)}
         elif vw < pipe_min:
-            self.form, self.set = "serial, all kinds in one launch", {"time_parallel_max_voices": 0, "split_max_waves": 0}
+            self.form, self.set = "serial, all kinds in one launch", {"time_parallel_max_voices": 1, "split_max_waves": 0}
         else:
-            self.form, self.set = "serial, one launch per base kind, blocks pipelined", {"time_parallel_max_voices": 0, "pipeline_min_waves": 1}
+            self.form, self.set = "serial, one launch per base kind, blocks pipelined", {"time_parallel_max_voices": 1, "pipeline_min_waves": 1}
         self.force = bool(self.set)
 
     def __enter__(self):
