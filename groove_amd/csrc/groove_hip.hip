@@ -202,6 +202,7 @@ struct groove_ctx {
   // events that mark the end of ONE kernel (a block's render, a block's last reduction) are bound to that dispatch's own
   // completion signal instead of being recorded behind it (a barrier packet each, ~5 us of the stream's timeline)
   bool bind_events = true;            // GROOVE_BIND_EVENTS=0: always hipEventRecord (A/B)
+  bool defer_bus = true;              // GROOVE_DEFER_BUS=0: groove_bank_render_mix_deferred == groove_bank_render_mix (A/B)
   uint32_t fx_seg_max_lanes = 49152;     // biquad banks of up to this many lane-channels take the four-segment kernel (measured, tools/fx_bench.py: 8,192 lane-channels 17.5 -> 9.3 us, 32,768 19.4 -> 15.6, 131,072 42.9 -> 58.4; GROOVE_FX_SEG_MAX_LANES, 0 = never)
   uint32_t fx_tp_wide_min_lanes = 8192;  // from this many lane-channels the time-parallel IIR kernels take 32-wide tiles (GROOVE_FX_TP_WIDE_MIN_LANES)
   bool fx_lds_staging = false;          // GROOVE_FX_LDS_STAGING=1 (A/B): the fused run kernel stages the chorus taps through LDS
@@ -222,6 +223,12 @@ struct groove_ctx {
   size_t partial_cap = 0;
   float* d_fpart = nullptr;  // fused path: partial[workgroup][2][frames]
   size_t fpart_cap = 0;
+  // groove_bank_render_mix_deferred: two more row buffers in alternation, and the block whose rows are waiting for the next
+  // deferred render (or bus_flush) to put them on the bus
+  float* d_dpart[2] = {nullptr, nullptr};
+  size_t dpart_cap[2] = {0, 0};
+  int dpart_next = 0;
+  struct { const float* rows = nullptr; float* bus = nullptr; uint32_t n_rows = 0, frames = 0; int accumulate = 0; } deferred;
   float* d_fseg = nullptr;   // fused path: seg[segments][2*frames]
   size_t fseg_cap = 0;
   int16_t* d_i16 = nullptr;
@@ -289,7 +296,11 @@ hipError_t wait_deadline(groove_ctx* ctx, hipStream_t st, hipEvent_t ev, const c
                 ".  The work stays queued; a kernel that crawls like this does so for the life of the process (DESIGN.md section 7): tear the process down and start again.");
   return hipErrorNotReady;
 }
-hipError_t ctx_wait(groove_ctx* ctx, const char* what = "wait for the ctx stream") { return wait_deadline(ctx, ctx->stream, nullptr, what); }
+int bus_flush(groove_ctx* ctx); // a deferred block's rows onto its bus (groove_bank_render_mix_deferred), defined with the reductions below
+hipError_t ctx_wait(groove_ctx* ctx, const char* what = "wait for the ctx stream") {
+  if (bus_flush(ctx)) return hipErrorUnknown; // whoever waits for the ctx stream expects every bus to be complete behind it
+  return wait_deadline(ctx, ctx->stream, nullptr, what);
+}
 hipError_t ctx_memcpy(groove_ctx* ctx, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
   // (a copy from or to pageable host memory blocks INSIDE hipMemcpyAsync until the stream gets to it: the deadline has to
   // be applied to the stream first)
@@ -763,6 +774,14 @@ void launch_reduce(groove_ctx* ctx, const float* partial, uint32_t rows, uint32_
     else hipLaunchKernelGGL(partial_final_kernel, dim3(blocks_for(cols)), blk, 0, ctx->stream, seg_buf, segs, frames, bus_dev, accumulate);
   }
 }
+int bus_flush(groove_ctx* ctx) {
+  if (!ctx->deferred.rows) return 0;
+  const auto d = ctx->deferred;
+  ctx->deferred.rows = nullptr;
+  if (ensure_seg_buffer(ctx, &ctx->d_fseg, &ctx->fseg_cap, (size_t)((d.n_rows + kRowsPerSeg - 1) / kRowsPerSeg) * 2 * d.frames)) return 1;
+  launch_reduce(ctx, d.rows, d.n_rows, d.frames, ctx->d_fseg, d.bus, d.accumulate);
+  return hipGetLastError() == hipSuccess ? 0 : fail(ctx, "bus_flush: launch failed");
+}
 int reduce_rows(groove_ctx* ctx, const float* rows_dev, uint32_t rows, uint32_t frames, float* bus_dev, int accumulate, hipEvent_t done = nullptr) {
   const uint32_t cols = 2 * frames, segs = (rows + kRowsPerSeg - 1) / kRowsPerSeg;
   if (ensure_seg_buffer(ctx, &ctx->d_fseg, &ctx->fseg_cap, (size_t)segs * cols)) return 1;
@@ -1009,6 +1028,7 @@ static int init_impl(int device_ordinal, const uint8_t* comm_id, int rank, int w
   if (const char* e = std::getenv("GROOVE_BANK_STREAMS")) ctx->bank_streams = std::max(1, std::min(kBankStreams, std::atoi(e)));
   if (const char* e = std::getenv("GROOVE_FM_TP_MAX_VOICES")) ctx->fm_tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_BIND_EVENTS")) ctx->bind_events = std::atoi(e) != 0;
+  if (const char* e = std::getenv("GROOVE_DEFER_BUS")) ctx->defer_bus = std::atoi(e) != 0;
   if (const char* e = std::getenv("GROOVE_TP_VPW2_MIN_VOICES")) ctx->tp_vpw2_min_voices = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_SEG_MAX_LANES")) ctx->fx_seg_max_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_TP_WIDE_MIN_LANES")) ctx->fx_tp_wide_min_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
@@ -1050,6 +1070,7 @@ void groove_shutdown(groove_ctx* ctx) {
   groove_comm_destroy(ctx);
   if (ctx->d_partial) (void)hipFree(ctx->d_partial);
   if (ctx->d_fpart) (void)hipFree(ctx->d_fpart);
+  for (float* q : ctx->d_dpart) if (q) (void)hipFree(q);
   if (ctx->d_fseg) (void)hipFree(ctx->d_fseg);
   if (ctx->d_i16) (void)hipFree(ctx->d_i16);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1173,6 +1194,7 @@ int groove_event_destroy(groove_ctx* ctx, void* event) {
 }
 int groove_event_record(groove_ctx* ctx, void* event) {
   if (!ctx || !event) return fail(ctx, "groove_event_record: NULL argument");
+  if (bus_flush(ctx)) return 1; // the event marks the end of everything asked for so far
   GHIP(ctx, hipEventRecord((hipEvent_t)event, ctx->stream));
   return 0;
 }
@@ -1384,9 +1406,10 @@ static uint32_t tp_vpw(const groove_bank* b) { // voices per wavefront of the ti
   return (b->kind == BANK_WELSH && b->tp_pairs && b->ctx->tp_vpw2_min_voices && b->n >= b->ctx->tp_vpw2_min_voices) ? 2u : 1u;
 }
 static void launch_tp(groove_bank* b, uint32_t frames, bool fused, size_t chs, float* out, float* rows, hipStream_t st, const groove_fx* head = nullptr,
-                      hipEvent_t done = nullptr /* Welsh only: completes with the kernel (bound to the dispatch) */) {
+                      hipEvent_t done = nullptr /* Welsh only: completes with the kernel (bound to the dispatch) */, const TpPrev* prev = nullptr) {
   groove_ctx* ctx = b->ctx;
   TpArgs a{b->d_params, b->d_state, out, rows, chs, render_consts(ctx->sr), b->n, frames};
+  if (prev) a.prev = *prev;
   if (head) { a.bq_coef = head->d_coef; a.bq_st = head->d_st; a.bq_wet = head->d_wet; } // Welsh, block-writing form: the BiQuad head fused (welsh_tp.h)
   if (b->kind == BANK_FM) launch_fm_tp(a, st, fused);
   else if (b->kind == BANK_SAMPLER) { launch_sampler_tp(a, b->d_pcm, b->inline_ev, st, fused); b->inline_ev.n = 0; }
@@ -1779,10 +1802,48 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
   GHIP(ctx, hipGetLastError());
   return 0;
 }
+// Fused render + mix whose bus reduction is left to the bank's NEXT deferred render (welsh_tp.h, tp_reduce_prev) — or to
+// whatever waits for the ctx stream, records an event on it or touches a bus (bus_flush).  For banks that render time-parallel
+// on the ctx stream with at most 64 partial rows; anything else is groove_bank_render_mix.
+int groove_bank_render_mix_deferred(groove_bank* b, uint32_t frames, float* bus_dev, int accumulate) {
+  if (!b || !bus_dev) return fail(nullptr, "groove_bank_render_mix_deferred: NULL argument");
+  groove_ctx* ctx = b->ctx;
+  if (frames == 0) return 0;
+  const bool lone = !(ctx->pipeline_min_waves <= 1 || ctx->banks.size() > 1) || kNoPipeline;
+  const uint32_t rows = use_tp(b, frames) ? fused_rows(b, frames) : 0;
+  if (!ctx->defer_bus || !lone || rows == 0 || rows > 64 || frames > kTpMaxFrames) return groove_bank_render_mix(b, frames, bus_dev, accumulate);
+  GHIP(ctx, hipSetDevice(ctx->device));
+  if (flush_events(b, true)) return 1;
+  if (ctx_join(ctx)) return 1;
+  const int slot = ctx->dpart_next;
+  ctx->dpart_next ^= 1;
+  const size_t need = (size_t)rows * 2 * frames;
+  if (ctx->dpart_cap[slot] < need) {
+    if (bus_flush(ctx)) return 1;                    // (the pending rows may live in the buffer that is about to go)
+    GHIP(ctx, wait_deadline(ctx, ctx->stream, nullptr, "deferred partial rows"));
+    if (ctx->d_dpart[slot]) GHIP(ctx, hipFree(ctx->d_dpart[slot]));
+    GHIP(ctx, hipMalloc(&ctx->d_dpart[slot], need * 4));
+    ctx->dpart_cap[slot] = need;
+  }
+  TpPrev prev;
+  if (ctx->deferred.rows) { prev.rows = ctx->deferred.rows; prev.bus = ctx->deferred.bus; prev.n_rows = ctx->deferred.n_rows; prev.frames = ctx->deferred.frames; prev.accumulate = ctx->deferred.accumulate; }
+  ctx->deferred.rows = nullptr;
+  b->ctx_touched = true;
+  launch_tp(b, frames, true, 0, ctx->d_dpart[slot], ctx->d_dpart[slot], ctx->stream, nullptr, nullptr, prev.rows ? &prev : nullptr);
+  GHIP(ctx, hipGetLastError());
+  ctx->deferred.rows = ctx->d_dpart[slot]; ctx->deferred.bus = bus_dev; ctx->deferred.n_rows = rows; ctx->deferred.frames = frames; ctx->deferred.accumulate = accumulate;
+  return 0;
+}
+int groove_bus_flush(groove_ctx* ctx) {
+  if (!ctx) return fail(nullptr, "groove_bus_flush: ctx is NULL");
+  GHIP(ctx, hipSetDevice(ctx->device));
+  return bus_flush(ctx);
+}
 int groove_bank_render_mix(groove_bank* b, uint32_t frames, float* bus_dev, int accumulate) {
   if (!b || !bus_dev) return fail(nullptr, "groove_bank_render_mix: NULL argument");
   groove_ctx* ctx = b->ctx;
   if (frames == 0) return 0;
+  if (bus_flush(ctx)) return 1;
   if (frames > 4096) return fail(ctx, "groove_bank_render_mix: frames > 4096");
   GHIP(ctx, hipSetDevice(ctx->device));
   if (flush_events(b, use_tp(b, frames))) return 1;
@@ -2233,6 +2294,7 @@ int groove_fx_set_param(groove_fx* fx, uint32_t lane, uint32_t control_index, do
 int groove_mix(groove_ctx* ctx, groove_block* const* blocks, uint32_t n_blocks, uint32_t frames,
                float* bus_dev, int accumulate) {
   if (!ctx || !bus_dev) return fail(ctx, "groove_mix: NULL argument");
+  if (bus_flush(ctx)) return 1;
   if (n_blocks && !blocks) return fail(ctx, "groove_mix: blocks is NULL");
   if (frames == 0) return 0;
   GHIP(ctx, hipSetDevice(ctx->device));
@@ -2302,6 +2364,7 @@ int groove_bus_destroy(groove_ctx* ctx, float* bus_dev) {
 }
 int groove_bus_zero(groove_ctx* ctx, float* bus_dev, size_t frames) {
   if (!ctx || !bus_dev) return fail(ctx, "groove_bus_zero: NULL argument");
+  if (bus_flush(ctx)) return 1;
   GHIP(ctx, hipMemsetAsync(bus_dev, 0, frames * 8, ctx->stream));
   return 0;
 }
@@ -2321,6 +2384,7 @@ int groove_upload(groove_ctx* ctx, float* dev, const float* host, size_t n_float
 }
 int groove_bus_to_i16(groove_ctx* ctx, const float* bus_dev, size_t frames, int16_t* host_out) {
   if (!ctx || !bus_dev || !host_out) return fail(ctx, "groove_bus_to_i16: NULL argument");
+  if (bus_flush(ctx)) return 1;
   const size_t count = frames * 2;
   if (count == 0) return 0;
   if (ctx->i16_cap < count) {
@@ -2391,6 +2455,7 @@ int groove_comm_destroy(groove_ctx* ctx) {
 }
 int groove_bus_reduce(groove_ctx* ctx, float* bus_dev, size_t frames_total, int root) {
   if (!ctx || !bus_dev) return fail(ctx, "groove_bus_reduce: NULL argument");
+  if (bus_flush(ctx)) return 1;
   if (ctx->world == 1 && !ctx->comm) return 0; // single GPU: the bus is already complete
   if (!ctx->comm) return fail(ctx, "groove_bus_reduce: communicator not initialised");
   auto f = (nccl_reduce_fn)dlsym(ctx->rccl, "ncclReduce");

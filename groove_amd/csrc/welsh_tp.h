@@ -434,8 +434,36 @@ __device__ __forceinline__ bool bq_tp_wave(const float (&xf)[CH], uint32_t cnt, 
   }
   return holds_end;
 }
+// groove_bank_render_mix_deferred: the PREVIOUS block's bus reduction rides in this launch.  A small bank's fused step is two
+// launches — the render, and a reduction of its <= 64 partial rows that is all launch and latency (4 us of config #2's 16) — and
+// the next block's render is on the same stream right behind: its workgroups each add up a slice of the previous block's rows
+// (wavefront 0, a few lanes: one column each, all rows in flight, fixed order) while their own parameter loads are under way.
+struct TpPrev { const float* rows = nullptr; float* bus = nullptr; uint32_t n_rows = 0, frames = 0; int accumulate = 0; };
+__device__ __forceinline__ void tp_reduce_prev(const TpPrev& pv, uint32_t tid, uint32_t wg, uint32_t n_wg) {
+  if (!pv.rows || tid >= 64u) return; // wavefront 0
+  const uint32_t cols = 2 * pv.frames, per = (cols + n_wg - 1) / n_wg; // columns of this workgroup
+  const uint32_t g = tid & 7u, cl = tid >> 3;                          // lane = (column of the pass, group of 8 rows)
+  for (uint32_t c0 = 0; c0 < per; c0 += 8) {                           // eight columns per pass, eight lanes per column
+    const uint32_t c = wg * per + c0 + cl;
+    const bool ok = c0 + cl < per && c < cols;
+    float t[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) { // (<= 64 rows: host) eight loads in flight per lane, one round trip for the pass
+      const uint32_t r = g * 8 + k;
+      t[k] = (ok && r < pv.n_rows) ? pv.rows[(size_t)r * cols + c] : 0.0f; // rows[workgroup][ch][frame]: column c = ch * frames + f
+    }
+    float acc = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64); // the column's eight lanes (fixed order)
+    if (ok && g == 0) {
+      const uint32_t ch = c / pv.frames, f = c % pv.frames;
+      float* o = pv.bus + (size_t)f * 2 + ch;
+      *o = pv.accumulate ? *o + acc : acc;
+    }
+  }
+}
 struct TpArgs {
   const uint32_t* params; uint32_t* state; float* out; float* rows; size_t ch_stride; RenderConsts rc; uint32_t n, frames;
+  TpPrev prev; // (fused form only)
   // welsh_tp_kernel<false, true>: a 12 dB BiQuad effect bank (one lane per voice) applied to the voice's block before it is
   // stored — coefficients [5][n] f64, state [4][2n] f64, wet [n], the layouts of fx_biquad_tp_kernel (fx_tp.h)
   const double* bq_coef = nullptr; double* bq_st = nullptr; const float* bq_wet = nullptr;
@@ -502,6 +530,7 @@ __global__ __launch_bounds__(kTpThreads, VPW == 1 ? GROOVE_TP_WAVES : 2) void we
   const uint32_t frames = a.frames, n = a.n;
   const WelshParams p = make_scalar(soa_load<WelshParams>(a.params, n, v)); // VPW > 1: the wave's voices share the patch (host)
   const WelshState s0 = soa_load<WelshState>(a.state, n, VPW == 1 ? v : vme); // the same in every lane of the voice
+  if constexpr (FUSED) tp_reduce_prev(a.prev, threadIdx.x, blockIdx.x, gridDim.x);
   const RenderConsts rc = a.rc;
   const bool first0 = (s0.vflags & VF_FIRST) != 0;
   const uint32_t live_total = env_idle_at(s0.amp, p.amp, frames);
@@ -730,6 +759,7 @@ __global__ __launch_bounds__(kTpThreads) void fm_tp_kernel(TpArgs a) {
   const uint32_t frames = a.frames, n = a.n;
   const FmParams p = make_scalar(soa_load<FmParams>(a.params, n, v));
   const FmState s0 = soa_load<FmState>(a.state, n, v);
+  if constexpr (FUSED) tp_reduce_prev(a.prev, threadIdx.x, blockIdx.x, gridDim.x);
   const bool first0 = (s0.vflags & VF_FIRST) != 0;
   const uint32_t live_total = env_idle_at(s0.cenv, p.cenv, frames);
   const uint32_t n0 = lane * kTpChunk;
@@ -834,6 +864,7 @@ __global__ __launch_bounds__(kSamplerTpThreads) void sampler_tp_kernel(TpArgs a,
   const uint32_t v = mine ? v_begin + lane : (n - 1);
   const SamplerParams p = soa_load<SamplerParams>(a.params, n, v);
   SamplerState s0 = soa_load<SamplerState>(a.state, n, v);
+  if constexpr (FUSED) tp_reduce_prev(a.prev, threadIdx.x, blockIdx.x, gridDim.x);
   if (ie.n && cnt) { // this block's note events (strictly increasing voices): those of this wave's voice range
     uint32_t lo = 0, hi = ie.n;
     while (lo < hi) { // first event at or after v_begin (scalar loads)

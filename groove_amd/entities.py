@@ -98,6 +98,9 @@ class Context:
     def split_max_waves(self, n):
         _lib.check(self.L.groove_set_split_max_waves(self.h, n), self.h)
 
+    def flush_bus(self):
+        _lib.check(self.L.groove_bus_flush(self.h), self.h)
+
     def set_stream(self, hip_stream):
         _lib.check(self.L.groove_set_stream(self.h, C.c_void_p(hip_stream)), self.h)
 
@@ -294,6 +297,12 @@ class Instrument:
     def render_mix(self, bus, frames, accumulate=False, at_frame=0):
         ptr = bus.at(at_frame) if at_frame else bus.ptr
         _lib.check(self.ctx.L.groove_bank_render_mix(self.h, frames, ptr, 1 if accumulate else 0), self.ctx.h)
+
+    def render_mix_deferred(self, bus, frames, accumulate=False, at_frame=0):
+        """groove_bank_render_mix_deferred: the block's bus reduction is left to this bank's next deferred render (or to the next
+        call that waits for the ctx stream, records an event on it or touches a bus)."""
+        ptr = bus.at(at_frame) if at_frame else bus.ptr
+        _lib.check(self.ctx.L.groove_bank_render_mix_deferred(self.h, frames, ptr, 1 if accumulate else 0), self.ctx.h)
 
     def kernel_form(self, frames=T.BLOCK_FRAMES, fused=True):
         return self.ctx.L.groove_bank_kernel_form(self.h, frames, 1 if fused else 0).decode()

@@ -220,7 +220,10 @@ class Project:
             if ev_pair is not None and ev_pair[0] is not None and inst is self.dominant:
                 ctx.record(ev_pair[0])
             if self.fused and not fx:
-                inst.render_mix(bus, FRAMES, accumulate=not first, at_frame=frame0)
+                if len(self.banks) == 1:  # a lone bank, block after block: its bus reduction rides in the next block's render
+                    inst.render_mix_deferred(bus, FRAMES, accumulate=not first, at_frame=frame0)
+                else:
+                    inst.render_mix(bus, FRAMES, accumulate=not first, at_frame=frame0)
                 if ev_pair is not None and ev_pair[1] is not None and inst is self.banks[-1][0]:
                     ctx.record(ev_pair[1])  # fused steps are bracketed whole: after the last bank's bus sum
             else:

@@ -1,0 +1,112 @@
+"""GPU tier: groove_bank_render_mix_deferred — the bus reduction of a lone time-parallel bank's block done by the bank's NEXT
+render (welsh_tp.h tp_reduce_prev) or by whatever flushes it — against groove_bank_render_mix on an identical bank: Welsh, FM and
+sampler banks, ragged block lengths, overwrite and accumulate, flushes by download / event record / explicit call in the middle of
+a run, a bank too big for the form (falls back), and the project walk that uses it (config #2 against the oracle)."""
+import numpy as np
+import pytest
+
+from groove_amd import patches as P, abi_types as T
+
+pytestmark = pytest.mark.gpu
+
+
+def _banks(gpu_ctx, kind, n):
+    from groove_amd import entities as E
+    from groove_amd import projects as PJ
+    if kind == "welsh":
+        params = P.welsh_voices(n)
+        mk = lambda: E.WelshSynth(gpu_ctx, params)  # noqa: E731
+        on, off = P.note_on_all(n), P.note_off_all(n)
+    elif kind == "fm":
+        spec = [s for s in PJ.plan("mixed-131072", np.arange(4 * n)) if s["kind"] == "fm"][0]
+        mk = lambda: E.FmSynth(gpu_ctx, spec["params"])  # noqa: E731
+        on, off = spec["events"][0], spec["events"][PJ.NOTE_OFF_BLOCK]
+    else:
+        spec = PJ.plan("sampler-16384", np.arange(n))[0]
+        mk = lambda: E.Sampler(gpu_ctx, spec["pcm"], spec["descs"], spec["params"])  # noqa: E731
+        ev = T.note_events_np(np.arange(n, dtype=np.uint32), np.full(n, 60, dtype=np.uint8), True)
+        on, off = ev, None
+    return mk, on, off
+
+
+@pytest.mark.parametrize("kind,n", [("welsh", 256), ("welsh", 61), ("fm", 200), ("sampler", 4096)])
+def test_deferred_equals_immediate(gpu_ctx, kind, n):
+    mk, on, off = _banks(gpu_ctx, kind, n)
+    a = mk()
+    frames_seq = [256, 256, 100, 256, 7, 1, 256, 255, 256, 256, 64, 256]
+    total = sum(frames_seq)
+    bus_a, bus_b = gpu_ctx.bus(total), gpu_ctx.bus(total)
+    ev = gpu_ctx.event()
+    # the deferred walk first (the form needs the bank to be the context's only one), then the immediate walk on a twin
+    a.handle_midi_events(on)
+    at = 0
+    for i, fr in enumerate(frames_seq):
+        if off is not None and i == 6:
+            a.handle_midi_events(off)
+        a.render_mix_deferred(bus_a, fr, accumulate=False, at_frame=at)
+        if i == 3:
+            gpu_ctx.flush_bus()
+        if i == 5:
+            gpu_ctx.record(ev)          # an event on the ctx stream: everything asked for so far is behind it
+        if i == 8:
+            part = bus_a.download()     # a download in the middle of the run
+            assert np.isfinite(part).all()
+        at += fr
+    got = bus_a.download().astype(np.float64)
+    # accumulate on top of the first pass: twice the bus
+    a.reset(); a.handle_midi_events(on)
+    at = 0
+    for i, fr in enumerate(frames_seq):
+        if off is not None and i == 6:
+            a.handle_midi_events(off)
+        a.render_mix_deferred(bus_a, fr, accumulate=True, at_frame=at)
+        at += fr
+    got2 = bus_a.download().astype(np.float64)
+    a.destroy()
+    b = mk()
+    b.handle_midi_events(on)
+    at = 0
+    for i, fr in enumerate(frames_seq):
+        if off is not None and i == 6:
+            b.handle_midi_events(off)
+        b.render_mix(bus_b, fr, accumulate=False, at_frame=at)
+        at += fr
+    want = bus_b.download().astype(np.float64)
+    b.destroy(); bus_a.destroy(); bus_b.destroy()
+    scale = max(1e-3, float(np.abs(want).max()))
+    assert float(np.sqrt(np.mean(want ** 2))) > 1e-4
+    assert np.abs(got - want).max() <= 2e-6 * scale * max(1.0, np.sqrt(n) / 8)
+    assert np.abs(got2 - 2.0 * want).max() <= 4e-6 * scale * max(1.0, np.sqrt(n) / 8)
+
+
+def test_deferred_falls_back_for_banks_it_does_not_fit(gpu_ctx):
+    """More than 64 partial rows (1,024 Welsh voices: 256 workgroups): groove_bank_render_mix itself, bit for bit."""
+    from groove_amd import entities as E
+    n = 1024
+    params = P.welsh_voices(n)
+    on = P.note_on_all(n)
+    buses = []
+    for deferred in (True, False):
+        s = E.WelshSynth(gpu_ctx, params)
+        s.handle_midi_events(on)
+        bus = gpu_ctx.bus(4 * 256)
+        for b in range(4):
+            (s.render_mix_deferred if deferred else s.render_mix)(bus, 256, accumulate=False, at_frame=b * 256)
+        buses.append(bus.download())
+        s.destroy(); bus.destroy()
+    assert np.array_equal(buses[0], buses[1])
+
+
+def test_config2_project_walk_uses_the_deferred_form(gpu_ctx, oracle):
+    from groove_amd import projects as PJ
+    from oracle.projects import OracleProject
+    sel = np.arange(256)
+    proj = PJ.Project(gpu_ctx, "welsh-256", sel)
+    bus = gpu_ctx.bus(60 * 256)
+    for b in range(60):
+        proj.step(bus, b * 256)
+    got = bus.download().astype(np.float64) / 256
+    want = OracleProject("welsh-256", sel).render(60) / 256
+    proj.destroy(); bus.destroy()
+    assert np.sqrt(np.mean(want ** 2)) > 1e-3
+    assert np.sqrt(np.mean((got - want) ** 2)) <= 1e-6
