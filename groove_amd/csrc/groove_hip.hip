@@ -1804,14 +1804,14 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
 }
 // Fused render + mix whose bus reduction is left to the bank's NEXT deferred render (welsh_tp.h, tp_reduce_prev) — or to
 // whatever waits for the ctx stream, records an event on it or touches a bus (bus_flush).  For banks that render time-parallel
-// on the ctx stream with at most 64 partial rows; anything else is groove_bank_render_mix.
+// on the ctx stream with at most 512 partial rows; anything else is groove_bank_render_mix.
 int groove_bank_render_mix_deferred(groove_bank* b, uint32_t frames, float* bus_dev, int accumulate) {
   if (!b || !bus_dev) return fail(nullptr, "groove_bank_render_mix_deferred: NULL argument");
   groove_ctx* ctx = b->ctx;
   if (frames == 0) return 0;
   const bool lone = !(ctx->pipeline_min_waves <= 1 || ctx->banks.size() > 1) || kNoPipeline;
   const uint32_t rows = use_tp(b, frames) ? fused_rows(b, frames) : 0;
-  if (!ctx->defer_bus || !lone || rows == 0 || rows > 64 || frames > kTpMaxFrames) return groove_bank_render_mix(b, frames, bus_dev, accumulate);
+  if (!ctx->defer_bus || !lone || rows == 0 || rows > 512 || frames > kTpMaxFrames) return groove_bank_render_mix(b, frames, bus_dev, accumulate);
   GHIP(ctx, hipSetDevice(ctx->device));
   if (flush_events(b, true)) return 1;
   if (ctx_join(ctx)) return 1;

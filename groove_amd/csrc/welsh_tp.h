@@ -442,18 +442,24 @@ struct TpPrev { const float* rows = nullptr; float* bus = nullptr; uint32_t n_ro
 __device__ __forceinline__ void tp_reduce_prev(const TpPrev& pv, uint32_t tid, uint32_t wg, uint32_t n_wg) {
   if (!pv.rows || tid >= 64u) return; // wavefront 0
   const uint32_t cols = 2 * pv.frames, per = (cols + n_wg - 1) / n_wg; // columns of this workgroup
-  const uint32_t g = tid & 7u, cl = tid >> 3;                          // lane = (column of the pass, group of 8 rows)
-  for (uint32_t c0 = 0; c0 < per; c0 += 8) {                           // eight columns per pass, eight lanes per column
+  // CP columns per pass, 64 / CP lanes per column, eight rows per lane and batch: a bank of R <= 512 workgroups left R rows and
+  // gives every workgroup ceil(512 / R) columns — all of a column's rows are in flight at once, one round trip per pass
+  const uint32_t cp = per <= 1 ? 1u : (per <= 2 ? 2u : (per <= 4 ? 4u : 8u)), lpc = 64u / cp;
+  const uint32_t g = tid % lpc, cl = tid / lpc; // lane = (column of the pass, group of rows)
+  for (uint32_t c0 = 0; c0 < per; c0 += cp) {
     const uint32_t c = wg * per + c0 + cl;
     const bool ok = c0 + cl < per && c < cols;
-    float t[8];
+    float acc = 0.0f;
+    for (uint32_t rb = 0; rb < pv.n_rows; rb += lpc * 8) {
+      float t[8];
 #pragma unroll
-    for (uint32_t k = 0; k < 8; ++k) { // (<= 64 rows: host) eight loads in flight per lane, one round trip for the pass
-      const uint32_t r = g * 8 + k;
-      t[k] = (ok && r < pv.n_rows) ? pv.rows[(size_t)r * cols + c] : 0.0f; // rows[workgroup][ch][frame]: column c = ch * frames + f
+      for (uint32_t k = 0; k < 8; ++k) {
+        const uint32_t r = rb + g * 8 + k;
+        t[k] = (ok && r < pv.n_rows) ? pv.rows[(size_t)r * cols + c] : 0.0f; // rows[workgroup][ch][frame]: column c = ch * frames + f
+      }
+      acc += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
     }
-    float acc = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
-    acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64); // the column's eight lanes (fixed order)
+    for (uint32_t m = 1; m < lpc; m <<= 1) acc += __shfl_xor(acc, (int)m, 64); // the column's lanes (a fixed order)
     if (ok && g == 0) {
       const uint32_t ch = c / pv.frames, f = c % pv.frames;
       float* o = pv.bus + (size_t)f * 2 + ch;

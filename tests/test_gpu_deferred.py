@@ -29,7 +29,7 @@ def _banks(gpu_ctx, kind, n):
     return mk, on, off
 
 
-@pytest.mark.parametrize("kind,n", [("welsh", 256), ("welsh", 61), ("fm", 200), ("sampler", 4096)])
+@pytest.mark.parametrize("kind,n", [("welsh", 256), ("welsh", 61), ("welsh", 700), ("welsh", 2048), ("fm", 200), ("sampler", 4096)])
 def test_deferred_equals_immediate(gpu_ctx, kind, n):
     mk, on, off = _banks(gpu_ctx, kind, n)
     a = mk()
@@ -80,9 +80,9 @@ def test_deferred_equals_immediate(gpu_ctx, kind, n):
 
 
 def test_deferred_falls_back_for_banks_it_does_not_fit(gpu_ctx):
-    """More than 64 partial rows (1,024 Welsh voices: 256 workgroups): groove_bank_render_mix itself, bit for bit."""
+    """More than 512 partial rows (2,052 Welsh voices: 513 workgroups): groove_bank_render_mix itself, bit for bit."""
     from groove_amd import entities as E
-    n = 1024
+    n = 2052
     params = P.welsh_voices(n)
     on = P.note_on_all(n)
     buses = []
