@@ -621,7 +621,7 @@ def roofline_block(workload, n_local, kern_ms, span_mode, fused, window=None):
             valu_frac = max(valu_frac, lo)
     fr = {"hbm": hbm_frac or 0.0, "valu-issue": valu_frac or 0.0}
     top = max(fr, key=fr.get)
-    r["bound"] = (top if fr[top] >= 0.25 else "latency (few short dependent launches: neither HBM nor VALU issue is a quarter busy)") if (hbm_frac is not None or valu_frac is not None) \
+    r["bound"] = (top if fr[top] >= 0.25 else "latency (one or two short launches per block: neither HBM nor VALU issue is a quarter busy)") if (hbm_frac is not None or valu_frac is not None) \
         else ("valu-issue" if wl["kind"] in ("welsh", "mixed") else "hbm")
     r["physical"] = {"hbm_frac": hbm_frac, "valu_frac": valu_frac}
     return r

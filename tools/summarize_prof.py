@@ -50,7 +50,9 @@ if ks:
 kt = glob.glob(f"{out}/kt/*/*_kernel_trace.csv")
 if kt:
     rows = list(csv.DictReader(open(kt[0])))
-    for marker in ("partial_final_kernel", "partial_rows_kernel", "mix_final_kernel", "mix_partial_kernel"):
+    # (a lone time-parallel bank's reduction rides in its next render — groove_bank_render_mix_deferred — so its step ends with
+    # the render kernel itself)
+    for marker in ("partial_final_kernel", "partial_rows_kernel", "mix_final_kernel", "mix_partial_kernel", "welsh_tp_kernel", "sampler_tp_kernel", "fm_tp_kernel"):
         ends = sorted(int(r["End_Timestamp"]) for r in rows if marker in r["Kernel_Name"])
         if len(ends) > 40:
             n_steps = 25 if windowed else 176
