@@ -201,6 +201,7 @@ struct groove_ctx {
   uint32_t tp_vpw2_min_voices = 3073; // GROOVE_TP_VPW2_MIN_VOICES (0 = never)
   // events that mark the end of ONE kernel (a block's render, a block's last reduction) are bound to that dispatch's own
   // completion signal instead of being recorded behind it (a barrier packet each, ~5 us of the stream's timeline)
+  uint32_t fm_tp_vpw4_min_voices = 4096; // GROOVE_FM_TP_VPW4_MIN_VOICES (0 = never): FM banks of at least this many voices, four voices per wavefront
   bool bind_events = true;            // GROOVE_BIND_EVENTS=0: always hipEventRecord (A/B)
   bool defer_bus = true;              // GROOVE_DEFER_BUS=0: groove_bank_render_mix_deferred == groove_bank_render_mix (A/B)
   uint32_t fx_seg_max_lanes = 49152;     // biquad banks of up to this many lane-channels take the four-segment kernel (measured, tools/fx_bench.py: 8,192 lane-channels 17.5 -> 9.3 us, 32,768 19.4 -> 15.6, 131,072 42.9 -> 58.4; GROOVE_FX_SEG_MAX_LANES, 0 = never)
@@ -1027,6 +1028,7 @@ static int init_impl(int device_ordinal, const uint8_t* comm_id, int rank, int w
   if (ctx->safe_streams) ctx->kind_streams = 3;
   if (const char* e = std::getenv("GROOVE_BANK_STREAMS")) ctx->bank_streams = std::max(1, std::min(kBankStreams, std::atoi(e)));
   if (const char* e = std::getenv("GROOVE_FM_TP_MAX_VOICES")) ctx->fm_tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
+  if (const char* e = std::getenv("GROOVE_FM_TP_VPW4_MIN_VOICES")) ctx->fm_tp_vpw4_min_voices = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_BIND_EVENTS")) ctx->bind_events = std::atoi(e) != 0;
   if (const char* e = std::getenv("GROOVE_DEFER_BUS")) ctx->defer_bus = std::atoi(e) != 0;
   if (const char* e = std::getenv("GROOVE_TP_VPW2_MIN_VOICES")) ctx->tp_vpw2_min_voices = (uint32_t)std::strtoul(e, nullptr, 10);
@@ -1402,7 +1404,11 @@ static bool use_tp(const groove_bank* b, uint32_t frames) {
   if (b->kind == BANK_SAMPLER) return b->n <= kSamplerTpMaxVoices; // a pure gather
   return false;
 }
-static uint32_t tp_vpw(const groove_bank* b) { // voices per wavefront of the time-parallel Welsh kernel
+static uint32_t tp_vpw(const groove_bank* b) { // voices per wavefront of the time-parallel Welsh / FM kernels
+  if (b->kind == BANK_FM) { // (parameters per lane: no condition on the patches) four once the one-voice form is past ~3 wavefronts per SIMD
+    const uint32_t m = b->ctx->fm_tp_vpw4_min_voices;
+    return (m && b->n >= m) ? 4u : 1u;
+  }
   return (b->kind == BANK_WELSH && b->tp_pairs && b->ctx->tp_vpw2_min_voices && b->n >= b->ctx->tp_vpw2_min_voices) ? 2u : 1u;
 }
 static void launch_tp(groove_bank* b, uint32_t frames, bool fused, size_t chs, float* out, float* rows, hipStream_t st, const groove_fx* head = nullptr,
@@ -1411,13 +1417,13 @@ static void launch_tp(groove_bank* b, uint32_t frames, bool fused, size_t chs, f
   TpArgs a{b->d_params, b->d_state, out, rows, chs, render_consts(ctx->sr), b->n, frames};
   if (prev) a.prev = *prev;
   if (head) { a.bq_coef = head->d_coef; a.bq_st = head->d_st; a.bq_wet = head->d_wet; } // Welsh, block-writing form: the BiQuad head fused (welsh_tp.h)
-  if (b->kind == BANK_FM) launch_fm_tp(a, st, fused);
+  if (b->kind == BANK_FM) { a.vpw = tp_vpw(b); launch_fm_tp(a, st, fused); }
   else if (b->kind == BANK_SAMPLER) { launch_sampler_tp(a, b->d_pcm, b->inline_ev, st, fused); b->inline_ev.n = 0; }
   else { a.full_coef = b->tp_full_coef; a.vpw = tp_vpw(b); launch_welsh_tp(a, st, fused, done); }
 }
 // rows of partial[][2][frames] a bank's fused render writes
 static uint32_t fused_rows(const groove_bank* b, uint32_t frames) {
-  if (use_tp(b, frames)) return b->kind == BANK_SAMPLER ? sampler_tp_workgroups(b->n) : b->kind == BANK_WELSH ? welsh_tp_grid(b->n, tp_vpw(b)) : welsh_tp_workgroups(b->n);
+  if (use_tp(b, frames)) return b->kind == BANK_SAMPLER ? sampler_tp_workgroups(b->n) : b->kind == BANK_WELSH ? welsh_tp_grid(b->n, tp_vpw(b)) : welsh_tp_workgroups(b->n, tp_vpw(b));
   return (b->kind == BANK_WELSH && b->n_vwaves) ? (b->n_vwaves + kWaves - 1) / kWaves : blocks_for(b->n);
 }
 // A Welsh bank below the per-kind pipeline's threshold: ONE launch for all its workgroups — role-split (welsh_split.h) when the
@@ -1876,7 +1882,7 @@ int groove_bank_render_mix(groove_bank* b, uint32_t frames, float* bus_dev, int 
 const char* groove_bank_kernel_form(groove_bank* b, uint32_t frames, int fused) {
   if (!b) return "";
   groove_ctx* ctx = b->ctx;
-  if (use_tp(b, frames)) return b->kind == BANK_WELSH ? (tp_vpw(b) == 2 ? "welsh_tp_kernel (time-parallel, two voices per wavefront)" : "welsh_tp_kernel (time-parallel, one wavefront per voice)") : b->kind == BANK_FM ? "fm_tp_kernel (time-parallel)" : "sampler_tp_kernel (time-parallel)";
+  if (use_tp(b, frames)) return b->kind == BANK_WELSH ? (tp_vpw(b) == 2 ? "welsh_tp_kernel (time-parallel, two voices per wavefront)" : "welsh_tp_kernel (time-parallel, one wavefront per voice)") : b->kind == BANK_FM ? (tp_vpw(b) == 4 ? "fm_tp_kernel (time-parallel, four voices per wavefront)" : "fm_tp_kernel (time-parallel)") : "sampler_tp_kernel (time-parallel)";
   if (b->kind == BANK_FM) return "fm_render_kernel (serial, one voice per lane)";
   if (b->kind == BANK_SAMPLER) return "sampler_render_kernel (serial, one voice per lane)";
   if (!b->n_vwaves) return "welsh_render_kernel (per-lane parameters)";

@@ -755,21 +755,31 @@ __global__ __launch_bounds__(kTpThreads, VPW == 1 ? GROOVE_TP_WAVES : 2) void we
 }
 // FmVoice: one wavefront per voice, 64 lanes x 4 frames (same argument block; rows / out as above).
 constexpr uint32_t kFmTpMaxVoices = 131072; // the serial kernel's 256-frame walk costs ~0.09 ms whatever the size; above this it has the wavefronts
-template <bool FUSED>
+// VPW voices per wavefront (round 3): an FM voice's per-wavefront costs (parameters, two envelope seeks, the scan, the tile turn)
+// outweigh its frames (two sines and a conversion each), and a big FM bank is throughput-bound — config #5's 32,768 FM voices
+// were 32,768 wavefronts beside the Welsh bank that bounds the step.  With four voices per wavefront (16 lanes x 16 frames each;
+// parameters per lane: FM patches differ from voice to voice) a voice costs ~40 % fewer issued instructions, and the prefix sum
+// of the carrier increments is four DPP row shifts.
+template <bool FUSED, int VPW = 1>
 __global__ __launch_bounds__(kTpThreads) void fm_tp_kernel(TpArgs a) {
-  __shared__ float s_tile[kTpWaves][2][kTpMaxFrames];
+  static_assert(VPW == 1 || VPW == 2 || VPW == 4, "");
+  constexpr uint32_t LPV = 64 / VPW, CH = kTpChunk * VPW, WGV = kTpWaves * VPW;
+  __shared__ float s_tile[WGV][2][kTpMaxFrames];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint32_t v0 = blockIdx.x * kTpWaves + wave;
+  const uint32_t vl = lane & (LPV - 1u), sub = lane / LPV, wv = wave * VPW + sub;
+  const uint32_t v0 = blockIdx.x * WGV + wv;
   const bool voice = v0 < a.n;
-  const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(voice ? v0 : a.n - 1));
+  const uint32_t vq = voice ? v0 : a.n - 1; // (per lane when VPW > 1)
+  const uint32_t v = VPW == 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)vq) : vq;
   const uint32_t frames = a.frames, n = a.n;
-  const FmParams p = make_scalar(soa_load<FmParams>(a.params, n, v));
+  const FmParams pl = soa_load<FmParams>(a.params, n, v);
+  const FmParams p = VPW == 1 ? make_scalar(pl) : pl; // one voice per wavefront: the patch in SGPRs
   const FmState s0 = soa_load<FmState>(a.state, n, v);
   if constexpr (FUSED) tp_reduce_prev(a.prev, threadIdx.x, blockIdx.x, gridDim.x);
   const bool first0 = (s0.vflags & VF_FIRST) != 0;
   const uint32_t live_total = env_idle_at(s0.cenv, p.cenv, frames);
-  const uint32_t n0 = lane * kTpChunk;
-  const uint32_t cnt = n0 < frames ? (frames - n0 < kTpChunk ? frames - n0 : kTpChunk) : 0u;
+  const uint32_t n0 = vl * CH;
+  const uint32_t cnt = n0 < frames ? (frames - n0 < CH ? frames - n0 : CH) : 0u;
   FmState s = s0;
   env_seek(s.cenv, p.cenv, n0 < frames ? n0 : 0u);
   env_seek(s.menv, p.menv, n0 < frames ? n0 : 0u);
@@ -777,19 +787,19 @@ __global__ __launch_bounds__(kTpThreads) void fm_tp_kernel(TpArgs a) {
   const uint64_t adv = (uint64_t)(live_before - ((first0 && live_before >= 1u) ? 1u : 0u));
   uint64_t mph = s0.modulator.phase + adv * s0.m_inc;
   if (live_before >= 1u) s.vflags = 0;
-  uint64_t loc[kTpChunk], run = 0;
-  float cval[kTpChunk];
-  bool lives[kTpChunk];
+  uint64_t loc[CH], run = 0;
+  float cval[CH];
+  uint32_t lives = 0;
 #pragma unroll
-  for (uint32_t j = 0; j < kTpChunk; ++j) {
+  for (uint32_t j = 0; j < CH; ++j) {
     const uint32_t f = n0 + j;
-    lives[j] = false; cval[j] = 0.0f;
+    cval[j] = 0.0f;
     uint64_t inc = 0;
     if (j < cnt) {
       env_tick(s.cenv, p.cenv);
       env_tick(s.menv, p.menv);
       if (f < live_total) {
-        lives[j] = true;
+        lives |= 1u << j;
         const bool is_first = first0 && f == 0;
         if (!is_first) mph += s0.m_inc;
         const uint64_t ci = fm_tp_carrier_inc(p, s0.c_inc, mph, s.menv.value);
@@ -801,46 +811,47 @@ __global__ __launch_bounds__(kTpThreads) void fm_tp_kernel(TpArgs a) {
     run += inc;
     loc[j] = run;
   }
-  uint64_t t = run; // inclusive scan of the lane totals
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint64_t o = tp_shfl(t, (int)lane - d);
-    if ((int)lane >= d) t += o;
+  uint64_t t = run; // inclusive scan of the lane totals over the voice's lanes
+  if constexpr (VPW == 4) { // 16 lanes = one DPP row
+    t += tp_dpp_u64<0x111, 0xF>(0, t); t += tp_dpp_u64<0x112, 0xF>(0, t); t += tp_dpp_u64<0x114, 0xF>(0, t); t += tp_dpp_u64<0x118, 0xF>(0, t);
+  } else {
+    uint64_t unused = 0;
+    tp_scan_add_u64<LPV>(t, unused);
   }
   const uint64_t base = s0.carrier.phase + (t - run);
-  float oL[kTpChunk], oR[kTpChunk];
+  float oL[CH], oR[CH];
 #pragma unroll
-  for (uint32_t j = 0; j < kTpChunk; ++j) {
+  for (uint32_t j = 0; j < CH; ++j) {
     float m = 0.0f;
-    if (lives[j]) m = osc_value(GROOVE_WAVE_SINE, base + loc[j], 0, 0.0f) * cval[j];
+    if ((lives >> j) & 1u) m = osc_value(GROOVE_WAVE_SINE, base + loc[j], 0, 0.0f) * cval[j];
     oL[j] = m * p.gl; oR[j] = m * p.gr;
   }
   {
 #pragma unroll
-    for (uint32_t j = 0; j < kTpChunk; ++j) {
-      s_tile[wave][0][n0 + j] = (voice && j < cnt) ? oL[j] : 0.0f;
-      s_tile[wave][1][n0 + j] = (voice && j < cnt) ? oR[j] : 0.0f;
+    for (uint32_t j = 0; j < CH; ++j) {
+      s_tile[wv][0][n0 + j] = (voice && j < cnt) ? oL[j] : 0.0f;
+      s_tile[wv][1][n0 + j] = (voice && j < cnt) ? oR[j] : 0.0f;
     }
     __syncthreads();
     for (uint32_t tt = threadIdx.x; tt < 2 * frames; tt += kTpThreads) {
       const uint32_t ch = tt / frames, f = tt % frames;
       float acc = 0.0f;
 #pragma unroll
-      for (int w = 0; w < kTpWaves; ++w) acc += s_tile[w][ch][f];
+      for (uint32_t w = 0; w < WGV; ++w) acc += s_tile[w][ch][f];
       a.rows[((size_t)blockIdx.x * 2 + ch) * frames + f] = acc;
     }
   }
   if (!FUSED && voice) {
 #pragma unroll
-    for (uint32_t j = 0; j < kTpChunk; ++j) {
+    for (uint32_t j = 0; j < CH; ++j) {
       if (j < cnt) {
         a.out[(size_t)(n0 + j) * n + v] = oL[j];
         a.out[a.ch_stride + (size_t)(n0 + j) * n + v] = oR[j];
       }
     }
   }
-  const uint32_t last = frames ? (frames - 1) / kTpChunk : 0u;
-  if (voice && lane == last && frames) {
+  const uint32_t last = frames ? (frames - 1) / CH : 0u;
+  if (voice && vl == last && frames) {
     s.modulator.phase = mph;
     s.carrier.phase = base + run;
     soa_store(a.state, n, v, s);
@@ -977,9 +988,9 @@ __global__ __launch_bounds__(kSamplerTpThreads) void sampler_tp_kernel(TpArgs a,
   }
 }
 void launch_welsh_tp(const TpArgs& a, hipStream_t st, bool fused, hipEvent_t done = nullptr); // a.bq_coef set (block-writing form): the BiQuad head fused; done: an event bound to the dispatch
-void launch_fm_tp(const TpArgs& a, hipStream_t st, bool fused);
+void launch_fm_tp(const TpArgs& a, hipStream_t st, bool fused); // a.vpw voices per wavefront (1, 2, 4)
 void launch_sampler_tp(const TpArgs& a, const float* bank, const InlineEvents& ie, hipStream_t st, bool fused);
-inline uint32_t welsh_tp_workgroups(uint32_t n, uint32_t vpw = 1) { return (n + kTpWaves * vpw - 1) / (kTpWaves * vpw); } // FM: one group of 4 voices per workgroup, plain order
+inline uint32_t welsh_tp_workgroups(uint32_t n, uint32_t vpw = 1) { return (n + kTpWaves * vpw - 1) / (kTpWaves * vpw); } // FM: groups of 4 vpw voices per workgroup, plain order
 inline uint32_t welsh_tp_grid(uint32_t n, uint32_t vpw = 1) { // Welsh: padded for the XCD-aware mapping (idle workgroups write zero rows)
   const uint32_t g = welsh_tp_workgroups(n, vpw);
   return g >= 16 ? (g + 7u) & ~7u : g;

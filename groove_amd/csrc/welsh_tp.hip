@@ -34,10 +34,16 @@ void launch_welsh_tp(const TpArgs& a, hipStream_t st, bool fused, hipEvent_t don
   if (a.vpw == 2) launch_welsh_tp_vpw<2>(a, st, fused, done);
   else launch_welsh_tp_vpw<1>(a, st, fused, done);
 }
+template <int VPW>
+static void launch_fm_tp_vpw(const TpArgs& a, hipStream_t st, bool fused) {
+  const dim3 grid(welsh_tp_workgroups(a.n, VPW)), blk(kTpThreads);
+  if (fused) hipLaunchKernelGGL((fm_tp_kernel<true, VPW>), grid, blk, 0, st, a);
+  else hipLaunchKernelGGL((fm_tp_kernel<false, VPW>), grid, blk, 0, st, a);
+}
 void launch_fm_tp(const TpArgs& a, hipStream_t st, bool fused) {
-  const dim3 grid(welsh_tp_workgroups(a.n)), blk(kTpThreads);
-  if (fused) hipLaunchKernelGGL(fm_tp_kernel<true>, grid, blk, 0, st, a);
-  else hipLaunchKernelGGL(fm_tp_kernel<false>, grid, blk, 0, st, a);
+  if (a.vpw == 4) launch_fm_tp_vpw<4>(a, st, fused);
+  else if (a.vpw == 2) launch_fm_tp_vpw<2>(a, st, fused);
+  else launch_fm_tp_vpw<1>(a, st, fused);
 }
 void launch_sampler_tp(const TpArgs& a, const float* bank, const InlineEvents& ie, hipStream_t st, bool fused) {
   const dim3 grid(sampler_tp_workgroups(a.n)), blk(kSamplerTpThreads);

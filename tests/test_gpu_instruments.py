@@ -51,6 +51,44 @@ def _fm_parity(gpu_ctx, oracle, E):
     synth.destroy(); block.destroy()
 
 
+def test_fm_four_voices_per_wavefront_parity(gpu_ctx, oracle, kernel_form):
+    """The FM kernel's four-voices-per-wavefront form (16 lanes x 16 frames per voice; banks of 4,096 voices and more by
+    default) forced for a 50-voice bank by GROOVE_FM_TP_VPW4_MIN_VOICES=1 in a context of its own: the per-voice parity test
+    above, and fused render + mix against the one-voice form's bus."""
+    import os
+    from groove_amd import entities as E
+    if kernel_form == "serial":
+        pytest.skip("a form of the time-parallel kernel")
+    os.environ["GROOVE_FM_TP_VPW4_MIN_VOICES"] = "1"
+    try:
+        ctx2 = E.Context(0)
+    finally:
+        del os.environ["GROOVE_FM_TP_VPW4_MIN_VOICES"]
+    try:
+        probe = E.FmSynth(ctx2, P.fm_voices(50))
+        assert "four voices per wavefront" in probe.kernel_form(256, True)
+        probe.destroy()
+        _fm_parity(ctx2, oracle, E)
+        n = 203  # not a multiple of the 16 voices per workgroup
+        params = P.fm_voices(n)
+        on = P.note_on_all(n)
+        buses = []
+        for c in (ctx2, gpu_ctx):
+            s = E.FmSynth(c, params)
+            s.handle_midi_events(on)
+            bus = c.bus(6 * 256)
+            at = 0
+            for fr in (256, 100, 256, 7, 256, 255):
+                s.render_mix(bus, fr, at_frame=at)
+                at += fr
+            buses.append(bus.download()[:at].astype(np.float64))
+            s.destroy(); bus.destroy()
+        assert np.sqrt(np.mean(buses[1] ** 2)) > 1e-3
+        assert np.abs(buses[0] - buses[1]).max() <= 2e-5 * max(1.0, float(np.abs(buses[1]).max()))
+    finally:
+        ctx2.close()
+
+
 def test_fm_forms_leave_the_same_state(gpu_ctx, kernel_form):
     from groove_amd import entities as E
     if kernel_form == "serial":

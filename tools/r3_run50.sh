@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out
+{
+timeout 1500 python3 -m pytest tests/test_gpu_instruments.py -x -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -8
+B="python3 bench.py --no-cpu-baseline --no-parity --no-watchdog --no-configs --no-shard-curve"
+for v in 1024 2048 4096 8192 32768; do for m in 0 1; do
+GROOVE_FM_TP_VPW4_MIN_VOICES=$m timeout 200 $B --workload mixed-131072 --voices $((v*4)) 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('mixed with $v FM voices fm_vpw4_min=$m', round(d['ms_per_step'],4), [round(x,4) for x in d['timed_region']['ms_per_step_repeats']])"
+done; done
+} 2>&1 | tee gpurun_out/r3_fm_vpw_sweep.log
