@@ -1412,13 +1412,14 @@ static uint32_t tp_vpw(const groove_bank* b) { // voices per wavefront of the ti
   return (b->kind == BANK_WELSH && b->tp_pairs && b->ctx->tp_vpw2_min_voices && b->n >= b->ctx->tp_vpw2_min_voices) ? 2u : 1u;
 }
 static void launch_tp(groove_bank* b, uint32_t frames, bool fused, size_t chs, float* out, float* rows, hipStream_t st, const groove_fx* head = nullptr,
-                      hipEvent_t done = nullptr /* Welsh only: completes with the kernel (bound to the dispatch) */, const TpPrev* prev = nullptr) {
+                      hipEvent_t done = nullptr /* Welsh only: completes with the kernel (bound to the dispatch) */, const TpPrev* prev = nullptr,
+                      uint32_t sampler_vpw = 0 /* sampler only: voices per wavefront (0: the default rule) */) {
   groove_ctx* ctx = b->ctx;
   TpArgs a{b->d_params, b->d_state, out, rows, chs, render_consts(ctx->sr), b->n, frames};
   if (prev) a.prev = *prev;
   if (head) { a.bq_coef = head->d_coef; a.bq_st = head->d_st; a.bq_wet = head->d_wet; } // Welsh, block-writing form: the BiQuad head fused (welsh_tp.h)
   if (b->kind == BANK_FM) { a.vpw = tp_vpw(b); launch_fm_tp(a, st, fused); }
-  else if (b->kind == BANK_SAMPLER) { launch_sampler_tp(a, b->d_pcm, b->inline_ev, st, fused); b->inline_ev.n = 0; }
+  else if (b->kind == BANK_SAMPLER) { a.vpw = sampler_vpw; launch_sampler_tp(a, b->d_pcm, b->inline_ev, st, fused); b->inline_ev.n = 0; }
   else { a.full_coef = b->tp_full_coef; a.vpw = tp_vpw(b); launch_welsh_tp(a, st, fused, done); }
 }
 // rows of partial[][2][frames] a bank's fused render writes
@@ -1816,7 +1817,9 @@ int groove_bank_render_mix_deferred(groove_bank* b, uint32_t frames, float* bus_
   groove_ctx* ctx = b->ctx;
   if (frames == 0) return 0;
   const bool lone = !(ctx->pipeline_min_waves <= 1 || ctx->banks.size() > 1) || kNoPipeline;
-  const uint32_t rows = use_tp(b, frames) ? fused_rows(b, frames) : 0;
+  uint32_t svpw = 0; // sampler: spread over more workgroups than the form with a reduction launch would (welsh_tp.h)
+  if (b->kind == BANK_SAMPLER && use_tp(b, frames)) { svpw = sampler_tp_vpw_deferred(b->n); if (sampler_tp_workgroups(b->n, svpw) > 512) svpw = 0; }
+  const uint32_t rows = !use_tp(b, frames) ? 0 : (svpw ? sampler_tp_workgroups(b->n, svpw) : fused_rows(b, frames));
   if (!ctx->defer_bus || !lone || rows == 0 || rows > 512 || frames > kTpMaxFrames) return groove_bank_render_mix(b, frames, bus_dev, accumulate);
   GHIP(ctx, hipSetDevice(ctx->device));
   if (flush_events(b, true)) return 1;
@@ -1835,7 +1838,7 @@ int groove_bank_render_mix_deferred(groove_bank* b, uint32_t frames, float* bus_
   if (ctx->deferred.rows) { prev.rows = ctx->deferred.rows; prev.bus = ctx->deferred.bus; prev.n_rows = ctx->deferred.n_rows; prev.frames = ctx->deferred.frames; prev.accumulate = ctx->deferred.accumulate; }
   ctx->deferred.rows = nullptr;
   b->ctx_touched = true;
-  launch_tp(b, frames, true, 0, ctx->d_dpart[slot], ctx->d_dpart[slot], ctx->stream, nullptr, nullptr, prev.rows ? &prev : nullptr);
+  launch_tp(b, frames, true, 0, ctx->d_dpart[slot], ctx->d_dpart[slot], ctx->stream, nullptr, nullptr, prev.rows ? &prev : nullptr, svpw);
   GHIP(ctx, hipGetLastError());
   ctx->deferred.rows = ctx->d_dpart[slot]; ctx->deferred.bus = bus_dev; ctx->deferred.n_rows = rows; ctx->deferred.frames = frames; ctx->deferred.accumulate = accumulate;
   return 0;

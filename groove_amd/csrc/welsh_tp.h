@@ -867,7 +867,10 @@ __global__ __launch_bounds__(kTpThreads) void fm_tp_kernel(TpArgs a) {
 // two reduction launches -> render + one); bigger banks keep 16 voices per wave and more workgroups.
 constexpr uint32_t kSamplerTpMaxVoices = 65536;
 inline uint32_t sampler_tp_vpw(uint32_t n) { return n <= 1024 ? 1u : std::min<uint32_t>((n + 1023) / 1024, 16u); } // (32 voices per wave for 32,768 voices: 38 us against ~20 with 16)
-inline uint32_t sampler_tp_workgroups(uint32_t n) { const uint32_t per = kSamplerTpWaves * sampler_tp_vpw(n); return (n + per - 1) / per; }
+inline uint32_t sampler_tp_workgroups(uint32_t n, uint32_t vpw = 0) { const uint32_t per = kSamplerTpWaves * (vpw ? vpw : sampler_tp_vpw(n)); return (n + per - 1) / per; }
+// groove_bank_render_mix_deferred: no reduction launch to keep short, so the voices are spread over the chip — at most 512 rows
+// (config #4: 4 voices per wavefront, 256 workgroups on 256 CUs instead of 64 on 64)
+inline uint32_t sampler_tp_vpw_deferred(uint32_t n) { return n <= 1024 ? 1u : std::min<uint32_t>((n + 8191) / 8192 * 2, 16u); }
 template <bool FUSED>
 __global__ __launch_bounds__(kSamplerTpThreads) void sampler_tp_kernel(TpArgs a, const float* __restrict__ bank, InlineEvents ie, uint32_t vpw) {
   __shared__ float s_tile[kSamplerTpWaves][kTpMaxFrames];

@@ -46,8 +46,8 @@ void launch_fm_tp(const TpArgs& a, hipStream_t st, bool fused) {
   else launch_fm_tp_vpw<1>(a, st, fused);
 }
 void launch_sampler_tp(const TpArgs& a, const float* bank, const InlineEvents& ie, hipStream_t st, bool fused) {
-  const dim3 grid(sampler_tp_workgroups(a.n)), blk(kSamplerTpThreads);
-  const uint32_t vpw = sampler_tp_vpw(a.n);
+  const uint32_t vpw = a.vpw > 1 ? a.vpw : sampler_tp_vpw(a.n); // (a.vpw: the deferred form's choice)
+  const dim3 grid(sampler_tp_workgroups(a.n, vpw)), blk(kSamplerTpThreads);
   if (fused) hipLaunchKernelGGL(sampler_tp_kernel<true>, grid, blk, 0, st, a, bank, ie, vpw);
   else hipLaunchKernelGGL(sampler_tp_kernel<false>, grid, blk, 0, st, a, bank, ie, vpw);
 }

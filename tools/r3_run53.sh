@@ -1,0 +1,9 @@
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out
+{
+timeout 1500 python3 -m pytest tests/test_gpu_deferred.py tests/test_gpu_configs.py tests/test_gpu_instruments.py -x -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -6
+B="python3 bench.py --no-cpu-baseline --no-parity --no-watchdog --no-configs --no-shard-curve"
+for rep in 1 2; do
+for w in "--workload sampler-16384" "--workload sampler-16384 --voices 4096" "--workload sampler-16384 --voices 65536"; do
+timeout 200 $B $w 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$w', round(d['ms_per_step'],4), [round(x,4) for x in d['timed_region']['ms_per_step_repeats']])"
+done; done
+} 2>&1 | tee gpurun_out/r3_sampler_vpw.log
