@@ -1811,16 +1811,19 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
 }
 // Fused render + mix whose bus reduction is left to the bank's NEXT deferred render (welsh_tp.h, tp_reduce_prev) — or to
 // whatever waits for the ctx stream, records an event on it or touches a bus (bus_flush).  For banks that render time-parallel
-// on the ctx stream with at most 512 partial rows; anything else is groove_bank_render_mix.
+// on the ctx stream with at most 2,048 partial rows; anything else is groove_bank_render_mix.
 int groove_bank_render_mix_deferred(groove_bank* b, uint32_t frames, float* bus_dev, int accumulate) {
   if (!b || !bus_dev) return fail(nullptr, "groove_bank_render_mix_deferred: NULL argument");
   groove_ctx* ctx = b->ctx;
   if (frames == 0) return 0;
-  const bool lone = !(ctx->pipeline_min_waves <= 1 || ctx->banks.size() > 1) || kNoPipeline;
+  // (several banks of a small project may take turns on the ctx stream this way — each render carries the reduction of the one
+  // before it, in submission order — instead of side by side on side streams with their cross-queue waits: the caller's choice)
+  const bool lone = ctx->pipeline_min_waves > 1 || kNoPipeline;
   uint32_t svpw = 0; // sampler: spread over more workgroups than the form with a reduction launch would (welsh_tp.h)
   if (b->kind == BANK_SAMPLER && use_tp(b, frames)) { svpw = sampler_tp_vpw_deferred(b->n); if (sampler_tp_workgroups(b->n, svpw) > 512) svpw = 0; }
+  // (up to 2,048 rows: the 512 columns' workgroups then take two to four batches of rows, a few us of a render that is long by then)
   const uint32_t rows = !use_tp(b, frames) ? 0 : (svpw ? sampler_tp_workgroups(b->n, svpw) : fused_rows(b, frames));
-  if (!ctx->defer_bus || !lone || rows == 0 || rows > 512 || frames > kTpMaxFrames) return groove_bank_render_mix(b, frames, bus_dev, accumulate);
+  if (!ctx->defer_bus || !lone || rows == 0 || rows > 2048 || frames > kTpMaxFrames) return groove_bank_render_mix(b, frames, bus_dev, accumulate);
   GHIP(ctx, hipSetDevice(ctx->device));
   if (flush_events(b, true)) return 1;
   if (ctx_join(ctx)) return 1;

@@ -30,6 +30,7 @@ from . import entities as E
 from . import patches as P
 
 FRAMES = T.BLOCK_FRAMES
+TAKE_TURNS_MAX_VOICES = int(__import__("os").environ.get("GROOVE_TAKE_TURNS_MAX_VOICES", "16384"))  # multi-bank projects up to this size: banks in turn on the ctx stream
 
 WORKLOADS = {
     "welsh-1m": dict(voices=1_000_000, kind="welsh", bytes_per_vf=18.0, dominant_bytes=10.0, blocks=172),
@@ -149,6 +150,11 @@ class Project:
         # streams the way the fused path's do — one block alone costs its thinly occupied tail (0.70 against 0.54 ms at
         # 1,000,000 voices)
         self.ahead_walk = self.render_ahead and (self.has_chain or not fused)
+        # A small fused project (a lone bank; or a few small banks — config #5's 16,384-voice share of a GPU) renders its banks one
+        # after the other on the ctx stream, every render carrying the bus reduction of the one before it
+        # (groove_bank_render_mix_deferred): one launch per bank and block, no cross-queue waits.  Bigger banks render side by side.
+        total = sum(inst.n for inst, _, _, _ in self.banks)
+        self.take_turns = fused and not self.has_chain and (len(self.banks) == 1 or total <= TAKE_TURNS_MAX_VOICES)
 
     def reset(self):
         """Back to block 0 of the timeline with every voice and effect in its initial state."""
@@ -220,7 +226,7 @@ class Project:
             if ev_pair is not None and ev_pair[0] is not None and inst is self.dominant:
                 ctx.record(ev_pair[0])
             if self.fused and not fx:
-                if len(self.banks) == 1:  # a lone bank, block after block: its bus reduction rides in the next block's render
+                if self.take_turns:  # small banks, one after the other on the ctx stream: a render carries the reduction of the one before it
                     inst.render_mix_deferred(bus, FRAMES, accumulate=not first, at_frame=frame0)
                 else:
                     inst.render_mix(bus, FRAMES, accumulate=not first, at_frame=frame0)

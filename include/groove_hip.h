@@ -181,8 +181,10 @@ int groove_bank_render_mix(groove_bank* bank, uint32_t frames, float* bus_dev, i
  * by the next call that waits for the ctx stream (groove_synchronize, downloads), records an event on it, or touches a bus
  * (groove_mix, groove_bank_render_mix, groove_bus_zero / _to_i16 / _reduce, groove_bus_flush).  For a host that renders a lone
  * small bank block after block (the reference's offline loop, orchestrator.rs:367-470, with one instrument): a time-parallel
- * bank's step is then one launch instead of two (256 Welsh voices 0.016 -> 0.012 ms per block).  Banks it does not apply to
- * (not time-parallel, more than 512 partial rows — 2,048 Welsh voices —, several banks in the context) are rendered by groove_bank_render_mix.  The bus
+ * bank's step is then one launch instead of two (256 Welsh voices 0.016 -> 0.013 ms per block).  The banks of a small project may
+ * also take turns this way — each render carries the reduction of the one before it, in submission order, all on the ctx stream —
+ * instead of running side by side with their cross-queue waits (config #5's 16,384-voice share of a GPU).  Banks it does not apply to
+ * (not time-parallel, more than 2,048 partial rows — 16,384 paired Welsh voices) are rendered by groove_bank_render_mix.  The bus
  * is the same sum in a fixed order (row by row instead of in segments of rows: equal to fp32 rounding). */
 int groove_bank_render_mix_deferred(groove_bank* bank, uint32_t frames, float* bus_dev, int accumulate);
 int groove_bus_flush(groove_ctx* ctx);

@@ -29,7 +29,7 @@ def _banks(gpu_ctx, kind, n):
     return mk, on, off
 
 
-@pytest.mark.parametrize("kind,n", [("welsh", 256), ("welsh", 61), ("welsh", 700), ("welsh", 2048), ("fm", 200), ("sampler", 4096)])
+@pytest.mark.parametrize("kind,n", [("welsh", 256), ("welsh", 61), ("welsh", 700), ("welsh", 2048), ("welsh", 5000), ("fm", 200), ("sampler", 4096)])
 def test_deferred_equals_immediate(gpu_ctx, kind, n):
     mk, on, off = _banks(gpu_ctx, kind, n)
     a = mk()
@@ -80,9 +80,10 @@ def test_deferred_equals_immediate(gpu_ctx, kind, n):
 
 
 def test_deferred_falls_back_for_banks_it_does_not_fit(gpu_ctx):
-    """More than 512 partial rows (2,052 Welsh voices: 513 workgroups): groove_bank_render_mix itself, bit for bit."""
+    """More than 2,048 partial rows (8,196 Welsh voices in the one-voice form: 2,049 workgroups): groove_bank_render_mix itself,
+    bit for bit."""
     from groove_amd import entities as E
-    n = 2052
+    n = 8196
     params = P.welsh_voices(n)
     on = P.note_on_all(n)
     buses = []
@@ -110,3 +111,31 @@ def test_config2_project_walk_uses_the_deferred_form(gpu_ctx, oracle):
     proj.destroy(); bus.destroy()
     assert np.sqrt(np.mean(want ** 2)) > 1e-3
     assert np.sqrt(np.mean((got - want) ** 2)) <= 1e-6
+
+
+def test_banks_taking_turns_equal_banks_side_by_side(gpu_ctx, oracle):
+    """Config #5's per-GPU share (Welsh + FM + sampler banks, 2,048 voices here): the banks in turn on the ctx stream, each
+    render carrying the reduction of the one before it, against the side-by-side form (GROOVE_TAKE_TURNS_MAX_VOICES=0) and the
+    oracle."""
+    from groove_amd import projects as PJ
+    from oracle.projects import OracleProject
+    sel = np.arange(2048)
+    buses = []
+    old = PJ.TAKE_TURNS_MAX_VOICES
+    try:
+        for limit in (16384, 0):
+            PJ.TAKE_TURNS_MAX_VOICES = limit
+            proj = PJ.Project(gpu_ctx, "mixed-131072", sel)
+            assert proj.take_turns == (limit > 0)
+            bus = gpu_ctx.bus(40 * 256)
+            for b in range(40):
+                proj.step(bus, b * 256)
+            buses.append(bus.download().astype(np.float64) / len(sel))
+            proj.destroy(); bus.destroy()
+    finally:
+        PJ.TAKE_TURNS_MAX_VOICES = old
+    want = OracleProject("mixed-131072", sel).render(40) / len(sel)
+    assert np.sqrt(np.mean(want ** 2)) > 1e-3
+    for got in buses:
+        assert np.sqrt(np.mean((got - want) ** 2)) <= 1e-6
+    assert np.abs(buses[0] - buses[1]).max() <= 1e-6
