@@ -357,6 +357,7 @@ def sampled_parity(ctx, workload, v_total, blocks, sample=64, fused=True, groupe
     whole index range, rendered by the product path — by the SAME kernel form the timed region ran — and by the CPU
     oracle over the first `blocks` blocks of the timeline.  Outside every timed region."""
     from oracle.projects import OracleProject
+    phase(f"parity sample of {workload} ({sample} voices, {blocks} blocks)")
     sel = spread_sample(v_total, sample)
     with timed_kernel_form(ctx, workload, v_total) as forced:
         proj = PJ.Project(ctx, workload, sel, fused=fused, grouped=grouped)
@@ -627,7 +628,15 @@ def roofline_block(workload, n_local, kern_ms, span_mode, fused, window=None):
     return r
 
 
+PHASE = {"now": "start"}  # what the measurement was doing, for the message of a stall
+
+
+def phase(text):
+    PHASE["now"] = text
+
+
 def bench_workload(ctx, workload, sel, K, W, repeats, fused=True, grouped=True, render_ahead=True, dist=None, head_ahead=True):
+    phase(f"timing {workload}, {len(sel)} voices, fused={fused}, grouped={grouped}, blocks {W}..{W + K - 1} x {repeats}")
     """Build the shard `sel` of a workload, time it, return the measurements (no parity, no JSON)."""
     wl = WORKLOADS[workload]
     proj = PJ.Project(ctx, workload, sel, fused=fused, grouped=grouped, render_ahead=render_ahead, head_ahead=head_ahead)
@@ -813,7 +822,7 @@ def main():
         measure(args, world, rank, local_rank)
     except GrooveError as e:
         if "not complete after" in str(e):   # groove_synchronize's deadline: a stalled stream.  The ctx cannot be torn down
-            sys.stderr.write(f"bench.py rank {rank}: {e}\n")  # (hipFree would wait for the stalled kernel): leave at once
+            sys.stderr.write(f"bench.py rank {rank}: {e}\n[bench] the stall was seen while: {PHASE['now']}\n")  # (hipFree would wait for the stalled kernel): leave at once
             sys.stderr.flush()
             os._exit(RANK_STALL_EXIT)
         raise
