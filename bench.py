@@ -462,10 +462,9 @@ class Dist:
         self.ctx = None
 
     def make_context(self):
-        """The rank's library context with its RCCL communicator created BEFORE the library's streams (groove_init_comm:
-        RCCL's own streams then do not land between them)."""
+        """The rank's library context and its RCCL communicator (one ncclReduce of the bus per render)."""
         torch, dist, rank, world, local_rank = self.torch, self.dist, self.rank, self.world, self.local_rank
-        self.reduce_via = "groove_bus_reduce (RCCL ncclReduce on the ctx stream; communicator created before the library's streams)"
+        self.reduce_via = "groove_bus_reduce (RCCL ncclReduce on the ctx stream; communicator created " + ("before" if os.environ.get("GROOVE_COMM_BEFORE_STREAMS") == "1" else "after") + " the library's streams)"
         try:
             uid = [E.Context.new_comm_unique_id() if rank == 0 else None]
         except Exception as e:  # noqa: BLE001
@@ -478,7 +477,17 @@ class Dist:
             try:
                 if os.environ.get("GROOVE_BENCH_BREAK_COMM") == "1":  # exercise the fallback below
                     raise RuntimeError("GROOVE_BENCH_BREAK_COMM=1")
-                ctx = E.Context(local_rank, comm=(uid[0], rank, world))
+                # The library's streams FIRST, the communicator after them.  (groove_init_comm — the communicator before the
+                # streams, so that RCCL's own streams cannot land between the library's — was this round's first answer to the
+                # queue-mapping question of DESIGN.md section 7, and measured it costs every rank a fifth of its speed: 1,000,000
+                # voices on one GPU through this path 0.630 / 0.635 / 0.630 ms per block against 0.517 / 0.522 / 0.517 in this
+                # order and 0.534 / 0.533 / 0.531 with no communicator at all, gpurun_out/r3_dist_ab.log.
+                # GROOVE_COMM_BEFORE_STREAMS=1 selects it.)
+                if os.environ.get("GROOVE_COMM_BEFORE_STREAMS") == "1":
+                    ctx = E.Context(local_rank, comm=(uid[0], rank, world))
+                else:
+                    ctx = E.Context(local_rank)
+                    ctx.comm_init(uid[0], rank, world)
             except Exception as e:  # noqa: BLE001
                 ok = [0]
                 self.reduce_via = f"torch.distributed.reduce over nccl (groove_init_comm failed: {e})"
