@@ -41,7 +41,8 @@ int groove_init(int device_ordinal, groove_ctx** out);
 /* groove_init for one rank of a multi-GPU job: the rank's RCCL communicator is created FIRST (id from
  * groove_comm_unique_id(NULL, ...) on rank 0, broadcast by the launcher), the library's own streams after it, so
  * that RCCL's internal streams do not land between them.  Equivalent to groove_init followed by
- * groove_comm_init otherwise.  GROOVE_SAFE_STREAMS=1 in the environment selects the conservative stream layout (one
+ * groove_comm_init otherwise — which is the faster order on this part (measured, DESIGN.md section 6: the communicator first
+ * costs the million-voice path 19 %) and the one bench.py's ranks use.  GROOVE_SAFE_STREAMS=1 in the environment selects the conservative stream layout (one
  * priority, four streams in all) for either form. */
 int groove_init_comm(int device_ordinal, const uint8_t id[128], int rank, int world_size, groove_ctx** out);
 void groove_shutdown(groove_ctx* ctx);
