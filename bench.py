@@ -7,7 +7,7 @@ A "step" is one pass of the hot path over one 256-frame block of the whole proje
 ticks 256 frames (render kernels), its effect chain runs, and the mix bus sums the voice blocks
 (Orchestrator::gather_audio).  `value` = stereo bus frames of the project rendered per second,
 with all inputs (patch parameters, voice state, sample bank) resident in HBM before the timed
-region.  The timed region is repeated (--repeats, default 3) from a reset state — W warm-up steps,
+region.  The timed region is repeated (--repeats; default 7 for windows of up to 40 steps, 3 otherwise) from a reset state — W warm-up steps,
 then exactly K timed steps, i.e. blocks W .. W+K-1 of the project's timeline each time — and
 `value` is the median repeat; every repeat is on the line.
 
@@ -637,6 +637,7 @@ def roofline_block(workload, n_local, kern_ms, span_mode, fused, window=None):
     return r
 
 
+SHORT_WINDOW_REPEATS = 7  # timed regions of a short window (see main)
 PHASE = {"now": "start"}  # what the measurement was doing, for the message of a stall
 
 
@@ -687,12 +688,13 @@ def form_entry(ctx, label, K, W, fused, grouped, note):
     window as the headline: what a host that calls Generates::generate_batch_values and then gather_audio gets
     (/root/reference/entities/src/instruments/metronome.rs:23-35, orchestration/src/orchestrator.rs:397-410)."""
     V = WORKLOADS["welsh-1m"]["voices"]
-    m = bench_workload(ctx, "welsh-1m", np.arange(V, dtype=np.int64), K, W, 1, fused=fused, grouped=grouped)
-    ms = m["walls"][0] / K * 1e3
+    m = bench_workload(ctx, "welsh-1m", np.arange(V, dtype=np.int64), K, W, SHORT_WINDOW_REPEATS, fused=fused, grouped=grouped)
+    wall = m["walls"][m["median"]]
+    ms = wall / K * 1e3
     byts = WORKLOADS["welsh-1m"]["bytes_per_vf"] * V * FRAMES
-    fps = K * FRAMES / m["walls"][0]
+    fps = K * FRAMES / wall
     return {"workload": label, "voices": V, "blocks_timed": f"{W}..{W + K - 1}", "note": note + "; renders submitted with groove_bank_render_async, three blocks in rotation",
-            "kernel_form": m["kernel_form"],
+            "kernel_form": m["kernel_form"], "ms_per_step_repeats": [w / K * 1e3 for w in m["walls"]], "statistic": "median region",
             "ms_per_step": ms, "value": fps, "unit": "stereo frames/s", "x_realtime_44k1": fps / SR,
             "frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "frac_is": "algorithmic 18 B per voice-frame / time; in this form 16 of the 18 bytes are really moved (block written, state in and out; the mix reads the render's row sums)"}
@@ -707,11 +709,11 @@ def shard_curve(ctx, K, W, ms_full):
     rows = [{"gpus": 1, "voices_per_gpu": V, "ms_per_step": ms_full, "implied_speedup": 1.0, "implied_efficiency": 1.0}]
     for n in (2, 4, 8):
         lo, hi = voice_range(V, 0, n)
-        m = bench_workload(ctx, "welsh-1m", np.arange(lo, hi, dtype=np.int64), K, W, 1)
-        ms = m["walls"][0] / K * 1e3
-        rows.append({"gpus": n, "voices_per_gpu": hi - lo, "ms_per_step": ms, "kernel_form": m["kernel_form"],
-                     "implied_speedup": ms_full / ms, "implied_efficiency": ms_full / ms / n})
-    out = {"welsh-1m": rows, "window_blocks": f"{W}..{W + K - 1}", "repeats": 1}
+        m = bench_workload(ctx, "welsh-1m", np.arange(lo, hi, dtype=np.int64), K, W, SHORT_WINDOW_REPEATS)
+        ms = m["walls"][m["median"]] / K * 1e3
+        rows.append({"gpus": n, "voices_per_gpu": hi - lo, "ms_per_step": ms, "ms_per_step_repeats": [w / K * 1e3 for w in m["walls"]],
+                     "kernel_form": m["kernel_form"], "implied_speedup": ms_full / ms, "implied_efficiency": ms_full / ms / n})
+    out = {"welsh-1m": rows, "window_blocks": f"{W}..{W + K - 1}", "repeats": SHORT_WINDOW_REPEATS, "statistic": "median region"}
     Vm, Km = WORKLOADS["mixed-131072"]["voices"], WORKLOADS["mixed-131072"]["blocks"]
     lo, hi = voice_range(Vm, 0, 8)
     m = bench_workload(ctx, "mixed-131072", np.arange(lo, hi, dtype=np.int64), Km, 0, 3)  # (three small banks on three streams: the noisiest entry of the line, so three regions and their median)
@@ -766,7 +768,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=172, help="default: one full 172-block project (44,032 frames)")
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--repeats", type=int, default=3, help="timed regions, each from a reset state (value = the median)")
+    ap.add_argument("--repeats", type=int, default=0, help="timed regions, each from a reset state (value = the median); default: 7 for windows of up to 40 steps, 3 otherwise")
     ap.add_argument("--workload", default="welsh-1m", choices=sorted(WORKLOADS))
     ap.add_argument("--voices", type=int, default=0, help="override the workload's total voice count")
     ap.add_argument("--materialise", action="store_true",
@@ -861,7 +863,12 @@ def measure(args, world, rank, local_rank):
         sys.exit(3)
 
     fused = not args.materialise
-    K, W, R = args.steps, args.warmup, max(1, args.repeats)
+    # A short window is 10 - 15 ms of GPU work and the first regions of a process (or after the seconds the host spends in the
+    # oracle between phases) run 5 - 12 % slower than the ones after them — 1,000,000 voices, nine regions of 20 steps:
+    # 0.548 0.534 0.514 0.488 0.483 0.486 0.486 0.485 0.486 ms per block (gpurun_out/r3_regions.log): three regions put the
+    # median on the slope, seven put it on what the device sustains.  Every region is on the line.
+    K, W = args.steps, args.warmup
+    R = max(1, args.repeats) if args.repeats else (SHORT_WINDOW_REPEATS if K <= 40 else 3)
     sel = np.arange(lo, hi, dtype=np.int64)
     m = bench_workload(ctx, args.workload, sel, K, W, R, fused=fused, grouped=not args.interleaved,
                        render_ahead=not args.no_render_ahead, dist=dist,
@@ -920,8 +927,12 @@ def measure(args, world, rank, local_rank):
             line["configs"].append(form_entry(ctx, "welsh-1m-interleaved-materialised", Kf, Wf, False, False,
                                               "the same with patch i mod 32 on voice i (no two neighbouring voices share a patch): regrouped inside the library"))
         if default_line and not args.no_shard_curve:
-            line["shard_curve"] = shard_curve(ctx, min(K, 20), min(W, 5), line["ms_per_step"] if (K, W) == (min(K, 20), min(W, 5)) else
-                                              bench_workload(ctx, "welsh-1m", sel, min(K, 20), min(W, 5), 1)["walls"][0] / min(K, 20) * 1e3)
+            if (K, W) == (min(K, 20), min(W, 5)) and R == SHORT_WINDOW_REPEATS:
+                ms_full = line["ms_per_step"]
+            else:  # (the same statistic as the shards': the median of the window's regions)
+                mf = bench_workload(ctx, "welsh-1m", sel, min(K, 20), min(W, 5), SHORT_WINDOW_REPEATS)
+                ms_full = mf["walls"][mf["median"]] / min(K, 20) * 1e3
+            line["shard_curve"] = shard_curve(ctx, min(K, 20), min(W, 5), ms_full)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload)
     ctx.close()
