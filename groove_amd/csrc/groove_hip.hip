@@ -1459,6 +1459,7 @@ static void launch_small_uniform(groove_bank* b, const UniformArgs& a, hipStream
   for (int j = 0; j < 2; ++j) {
     if (!n_f64[j]) continue;
     UniformArgs r = a;
+    r.prev = TpPrev{}; // (the launch above carried the previous block's rows)
     r.wg_list = a.wg_list + at; r.wg_cls = a.wg_cls + at; r.n_wgs = n_f64[j];
     launch_welsh_kind(4 + j, r, st, fused);
     at += n_f64[j];
@@ -1819,6 +1820,38 @@ int groove_bank_render_mix_deferred(groove_bank* b, uint32_t frames, float* bus_
   // (several banks of a small project may take turns on the ctx stream this way — each render carries the reduction of the one
   // before it, in submission order — instead of side by side on side streams with their cross-queue waits: the caller's choice)
   const bool lone = ctx->pipeline_min_waves > 1 || kNoPipeline;
+  // A Welsh bank too big for the time-parallel form and too small for the per-kind pipeline (the all-kinds or a role-split
+  // kernel on the ctx stream, then two reduction launches in line behind it: ~18 us of a 125,000-voice shard's 130): the same
+  // deferral, the next block's kernel summing the rows — when the launch that would carry them exists (some workgroup of the four
+  // class-specialised kinds) and the rows are few enough.
+  if (ctx->defer_bus && lone && !use_tp(b, frames) && b->kind == BANK_WELSH && b->n_vwaves && b->n_vwaves < ctx->pipeline_min_waves) {
+    uint32_t n_spec = 0;
+    for (int k = 0; k < 4 * kClassCombos; ++k) n_spec += b->wgs_of_kind[k];
+    const uint32_t urows = fused_rows(b, frames);
+    if (n_spec && urows <= 2048) {
+      GHIP(ctx, hipSetDevice(ctx->device));
+      if (flush_events(b, false)) return 1;
+      if (ctx_join(ctx)) return 1;
+      const int slot = ctx->dpart_next;
+      ctx->dpart_next ^= 1;
+      const size_t need = (size_t)urows * 2 * frames;
+      if (ctx->dpart_cap[slot] < need) {
+        if (bus_flush(ctx)) return 1;
+        GHIP(ctx, wait_deadline(ctx, ctx->stream, nullptr, "deferred partial rows"));
+        if (ctx->d_dpart[slot]) GHIP(ctx, hipFree(ctx->d_dpart[slot]));
+        GHIP(ctx, hipMalloc(&ctx->d_dpart[slot], need * 4));
+        ctx->dpart_cap[slot] = need;
+      }
+      UniformArgs a{b->d_waves, b->d_state, ctx->d_dpart[slot], ctx->d_dpart[slot], b->d_wg_list, b->d_wg_cls, 0, render_consts(ctx->sr), b->n_vwaves, b->n, frames, urows};
+      if (ctx->deferred.rows) { a.prev.rows = ctx->deferred.rows; a.prev.bus = ctx->deferred.bus; a.prev.n_rows = ctx->deferred.n_rows; a.prev.frames = ctx->deferred.frames; a.prev.accumulate = ctx->deferred.accumulate; }
+      ctx->deferred.rows = nullptr;
+      b->ctx_touched = true;
+      launch_small_uniform(b, a, ctx->stream, true, frames);
+      GHIP(ctx, hipGetLastError());
+      ctx->deferred.rows = ctx->d_dpart[slot]; ctx->deferred.bus = bus_dev; ctx->deferred.n_rows = urows; ctx->deferred.frames = frames; ctx->deferred.accumulate = accumulate;
+      return 0;
+    }
+  }
   uint32_t svpw = 0; // sampler: spread over more workgroups than the form with a reduction launch would (welsh_tp.h)
   if (b->kind == BANK_SAMPLER && use_tp(b, frames)) { svpw = sampler_tp_vpw_deferred(b->n); if (sampler_tp_workgroups(b->n, svpw) > 512) svpw = 0; }
   // (up to 2,048 rows: the 512 columns' workgroups then take two to four batches of rows, a few us of a render that is long by then)

@@ -86,6 +86,40 @@ __device__ __forceinline__ T make_scalar(const T& x) {
   return __builtin_bit_cast(T, w);
 }
 
+// groove_bank_render_mix_deferred: the PREVIOUS block's bus reduction rides in this launch.  A small bank's fused step is two
+// launches — the render, and a reduction of its <= 64 partial rows that is all launch and latency (4 us of config #2's 16) — and
+// the next block's render is on the same stream right behind: its workgroups each add up a slice of the previous block's rows
+// (wavefront 0, a few lanes: one column each, all rows in flight, fixed order) while their own parameter loads are under way.
+struct TpPrev { const float* rows = nullptr; float* bus = nullptr; uint32_t n_rows = 0, frames = 0; int accumulate = 0; };
+__device__ __forceinline__ void tp_reduce_prev(const TpPrev& pv, uint32_t tid, uint32_t wg, uint32_t n_wg) {
+  if (!pv.rows || tid >= 64u) return; // wavefront 0
+  const uint32_t cols = 2 * pv.frames, per = (cols + n_wg - 1) / n_wg; // columns of this workgroup
+  // CP columns per pass, 64 / CP lanes per column, eight rows per lane and batch: a bank of R <= 512 workgroups left R rows and
+  // gives every workgroup ceil(512 / R) columns — all of a column's rows are in flight at once, one round trip per pass
+  const uint32_t cp = per <= 1 ? 1u : (per <= 2 ? 2u : (per <= 4 ? 4u : 8u)), lpc = 64u / cp;
+  const uint32_t g = tid % lpc, cl = tid / lpc; // lane = (column of the pass, group of rows)
+  for (uint32_t c0 = 0; c0 < per; c0 += cp) {
+    const uint32_t c = wg * per + c0 + cl;
+    const bool ok = c0 + cl < per && c < cols;
+    float acc = 0.0f;
+    for (uint32_t rb = 0; rb < pv.n_rows; rb += lpc * 8) {
+      float t[8];
+#pragma unroll
+      for (uint32_t k = 0; k < 8; ++k) {
+        const uint32_t r = rb + g * 8 + k;
+        t[k] = (ok && r < pv.n_rows) ? pv.rows[(size_t)r * cols + c] : 0.0f; // rows[workgroup][ch][frame]: column c = ch * frames + f
+      }
+      acc += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+    for (uint32_t m = 1; m < lpc; m <<= 1) acc += __shfl_xor(acc, (int)m, 64); // the column's lanes (a fixed order)
+    if (ok && g == 0) {
+      const uint32_t ch = c / pv.frames, f = c % pv.frames;
+      float* o = pv.bus + (size_t)f * 2 + ch;
+      *o = pv.accumulate ? *o + acc : acc;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ fused mix-bus epilogue
 // Orchestrator::gather_audio's "sum += entity.value()" (orchestrator.rs:397-410) without
 // materialising the voice block: per frame the 64 lanes of a wave are summed with DPP
@@ -404,6 +438,7 @@ template <> struct WavesBudget<LFO_F64, true> { static constexpr int value = GRO
 struct UniformArgs {
   const WaveDesc* waves; uint32_t* state; float* out; float* rows; const uint32_t* wg_list; const uint8_t* wg_cls;
   size_t ch_stride; RenderConsts rc; uint32_t n_waves, n, frames, n_wgs; // out: the planar block (block-writing form); rows: partial[workgroup][ch][frame] (both forms)
+  TpPrev prev; // groove_bank_render_mix_deferred: the previous block's rows, to be put on their bus by this launch (the all-kinds and role-split kernels)
 };
 typedef const __attribute__((address_space(4))) UniformArgs* UniformArgsPtr; // kernarg segment: scalar loads
 __device__ __forceinline__ UniformArgsPtr uniform_args_scalar(UniformArgsPtr a) { // arguments of a call travel in VGPRs
@@ -535,7 +570,7 @@ __global__ __launch_bounds__(kThreads, (WavesBudget<LFO_MODE, RETUNE>::value)) G
 template <bool FUSED>
 __global__ __launch_bounds__(kThreads, GROOVE_WAVES_ANY) GROOVE_NO_TAIL_CALLS void welsh_render_uniform_any_kernel(UniformArgs a, const uint8_t* __restrict__ wg_base) {
   const UniformArgsPtr ka = (UniformArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-  if constexpr (FUSED) { if (welsh_idle_workgroup(a)) return; }
+  if constexpr (FUSED) { tp_reduce_prev(a.prev, threadIdx.x, blockIdx.x, gridDim.x); if (welsh_idle_workgroup(a)) return; }
   const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wg_base[blockIdx.x]);
   const uint32_t cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[blockIdx.x]);
   switch (base) {

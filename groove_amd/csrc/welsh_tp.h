@@ -434,39 +434,6 @@ __device__ __forceinline__ bool bq_tp_wave(const float (&xf)[CH], uint32_t cnt, 
   }
   return holds_end;
 }
-// groove_bank_render_mix_deferred: the PREVIOUS block's bus reduction rides in this launch.  A small bank's fused step is two
-// launches — the render, and a reduction of its <= 64 partial rows that is all launch and latency (4 us of config #2's 16) — and
-// the next block's render is on the same stream right behind: its workgroups each add up a slice of the previous block's rows
-// (wavefront 0, a few lanes: one column each, all rows in flight, fixed order) while their own parameter loads are under way.
-struct TpPrev { const float* rows = nullptr; float* bus = nullptr; uint32_t n_rows = 0, frames = 0; int accumulate = 0; };
-__device__ __forceinline__ void tp_reduce_prev(const TpPrev& pv, uint32_t tid, uint32_t wg, uint32_t n_wg) {
-  if (!pv.rows || tid >= 64u) return; // wavefront 0
-  const uint32_t cols = 2 * pv.frames, per = (cols + n_wg - 1) / n_wg; // columns of this workgroup
-  // CP columns per pass, 64 / CP lanes per column, eight rows per lane and batch: a bank of R <= 512 workgroups left R rows and
-  // gives every workgroup ceil(512 / R) columns — all of a column's rows are in flight at once, one round trip per pass
-  const uint32_t cp = per <= 1 ? 1u : (per <= 2 ? 2u : (per <= 4 ? 4u : 8u)), lpc = 64u / cp;
-  const uint32_t g = tid % lpc, cl = tid / lpc; // lane = (column of the pass, group of rows)
-  for (uint32_t c0 = 0; c0 < per; c0 += cp) {
-    const uint32_t c = wg * per + c0 + cl;
-    const bool ok = c0 + cl < per && c < cols;
-    float acc = 0.0f;
-    for (uint32_t rb = 0; rb < pv.n_rows; rb += lpc * 8) {
-      float t[8];
-#pragma unroll
-      for (uint32_t k = 0; k < 8; ++k) {
-        const uint32_t r = rb + g * 8 + k;
-        t[k] = (ok && r < pv.n_rows) ? pv.rows[(size_t)r * cols + c] : 0.0f; // rows[workgroup][ch][frame]: column c = ch * frames + f
-      }
-      acc += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
-    }
-    for (uint32_t m = 1; m < lpc; m <<= 1) acc += __shfl_xor(acc, (int)m, 64); // the column's lanes (a fixed order)
-    if (ok && g == 0) {
-      const uint32_t ch = c / pv.frames, f = c % pv.frames;
-      float* o = pv.bus + (size_t)f * 2 + ch;
-      *o = pv.accumulate ? *o + acc : acc;
-    }
-  }
-}
 struct TpArgs {
   const uint32_t* params; uint32_t* state; float* out; float* rows; size_t ch_stride; RenderConsts rc; uint32_t n, frames;
   TpPrev prev; // (fused form only)
