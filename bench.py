@@ -481,7 +481,7 @@ class Dist:
                 # streams, so that RCCL's own streams cannot land between the library's — was this round's first answer to the
                 # queue-mapping question of DESIGN.md section 7, and measured it costs every rank a fifth of its speed: 1,000,000
                 # voices on one GPU through this path 0.630 / 0.635 / 0.630 ms per block against 0.517 / 0.522 / 0.517 in this
-                # order and 0.534 / 0.533 / 0.531 with no communicator at all, gpurun_out/r3_dist_ab.log.
+                # order and 0.534 / 0.533 / 0.531 with no communicator at all, profiles/r03_ab_logs_second_half.txt (r3_dist_ab).
                 # GROOVE_COMM_BEFORE_STREAMS=1 selects it.)
                 if os.environ.get("GROOVE_COMM_BEFORE_STREAMS") == "1":
                     ctx = E.Context(local_rank, comm=(uid[0], rank, world))
@@ -865,7 +865,7 @@ def measure(args, world, rank, local_rank):
     fused = not args.materialise
     # A short window is 10 - 15 ms of GPU work and the first regions of a process (or after the seconds the host spends in the
     # oracle between phases) run 5 - 12 % slower than the ones after them — 1,000,000 voices, nine regions of 20 steps:
-    # 0.548 0.534 0.514 0.488 0.483 0.486 0.486 0.485 0.486 ms per block (gpurun_out/r3_regions.log): three regions put the
+    # 0.548 0.534 0.514 0.488 0.483 0.486 0.486 0.485 0.486 ms per block (profiles/r03_timed_regions.log): three regions put the
     # median on the slope, seven put it on what the device sustains.  Every region is on the line.
     K, W = args.steps, args.warmup
     R = max(1, args.repeats) if args.repeats else (SHORT_WINDOW_REPEATS if K <= 40 else 3)
