@@ -1824,7 +1824,7 @@ int groove_bank_render_mix_deferred(groove_bank* b, uint32_t frames, float* bus_
   // kernel on the ctx stream, then two reduction launches in line behind it: ~18 us of a 125,000-voice shard's 130): the same
   // deferral, the next block's kernel summing the rows — when the launch that would carry them exists (some workgroup of the four
   // class-specialised kinds) and the rows are few enough.
-  if (ctx->defer_bus && lone && !use_tp(b, frames) && b->kind == BANK_WELSH && b->n_vwaves && b->n_vwaves < ctx->pipeline_min_waves) {
+  if (ctx->defer_bus && lone && frames <= 4096 && !use_tp(b, frames) && b->kind == BANK_WELSH && b->n_vwaves && b->n_vwaves < ctx->pipeline_min_waves) {
     uint32_t n_spec = 0;
     for (int k = 0; k < 4 * kClassCombos; ++k) n_spec += b->wgs_of_kind[k];
     const uint32_t urows = fused_rows(b, frames);

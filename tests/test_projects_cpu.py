@@ -236,3 +236,35 @@ def test_bench_under_torch_distributed_run_the_way_the_driver_starts_it():
     line = json.loads(lines[0])
     assert line["ranks"] == 2 and line["voice_ranges"] == [[0, 500000], [500000, 1000000]]
     assert line["watchdog"]["supervised_under_launcher"] is True and line["watchdog"]["attempts"] == 1
+
+
+def test_parity_sample_is_forced_to_the_timed_kernel_form():
+    """bench.py timed_kernel_form: which tuning knobs make a few dozen sample voices run the Welsh kernel form the full-size
+    workload's timed region ran (the library picks the form by bank size)."""
+    import bench
+
+    class Ctx:  # the library's defaults
+        time_parallel_max_voices = 16384
+        time_parallel_pair_min_voices = 3073
+        split_max_waves = 1024
+        pipeline_min_waves = 8600
+
+    def forced(workload, v):
+        t = bench.timed_kernel_form(Ctx(), workload, v)
+        return t.form, t.set
+
+    assert forced("welsh-256", 256)[1] == {}
+    assert forced("sampler-16384", 16384)[1] == {}
+    f, s = forced("chain-4096", 4096)
+    assert "two voices per wavefront" in f and s == {"time_parallel_pair_min_voices": 1}
+    f, s = forced("mixed-131072", 131072)   # 65,536 Welsh voices: role-split; the FM / sampler banks keep their time-parallel kernels
+    assert "role-split" in f and s["time_parallel_max_voices"] == 1 and s["split_max_waves"] >= 1024
+    f, s = forced("mixed-131072", 16384)    # 8,192 Welsh voices: two per wavefront
+    assert "two voices per wavefront" in f
+    f, s = forced("welsh-1m", 250_000)
+    assert "all kinds" in f and s["split_max_waves"] == 0
+    f, s = forced("welsh-1m", 1_000_000)
+    assert "per base kind" in f and s["pipeline_min_waves"] == 1 and s["time_parallel_max_voices"] == 1
+    with bench.timed_kernel_form(Ctx(), "chain-4096", 4096) as t:
+        assert t.ctx.time_parallel_pair_min_voices == 1
+    assert t.ctx.time_parallel_pair_min_voices == 3073
