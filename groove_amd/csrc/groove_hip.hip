@@ -202,7 +202,10 @@ struct groove_ctx {
   // events that mark the end of ONE kernel (a block's render, a block's last reduction) are bound to that dispatch's own
   // completion signal instead of being recorded behind it (a barrier packet each, ~5 us of the stream's timeline)
   uint32_t fm_tp_vpw4_min_voices = 4096; // GROOVE_FM_TP_VPW4_MIN_VOICES (0 = never): FM banks of at least this many voices, four voices per wavefront
-  bool bind_events = true;            // GROOVE_BIND_EVENTS=0: always hipEventRecord (A/B)
+  // OFF by default since the end of round 3: with the binding on, 4 of 36 fresh runs of the driver's command stalled in the
+  // materialised million-voice forms (the kind streams waiting for a block's bound "free" event, profiles/r03_stall_hunt2.log);
+  // the binding was worth ~1 % there.  GROOVE_BIND_EVENTS=1 switches it on.
+  bool bind_events = false;
   bool defer_bus = true;              // GROOVE_DEFER_BUS=0: groove_bank_render_mix_deferred == groove_bank_render_mix (A/B)
   uint32_t fx_seg_max_lanes = 49152;     // biquad banks of up to this many lane-channels take the four-segment kernel (measured, tools/fx_bench.py: 8,192 lane-channels 17.5 -> 9.3 us, 32,768 19.4 -> 15.6, 131,072 42.9 -> 58.4; GROOVE_FX_SEG_MAX_LANES, 0 = never)
   uint32_t fx_tp_wide_min_lanes = 8192;  // from this many lane-channels the time-parallel IIR kernels take 32-wide tiles (GROOVE_FX_TP_WIDE_MIN_LANES)
