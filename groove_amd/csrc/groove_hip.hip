@@ -294,7 +294,21 @@ hipError_t wait_deadline(groove_ctx* ctx, hipStream_t st, hipEvent_t ev, const c
     if (dup) continue;
     if (hipStreamQuery(s) == hipErrorNotReady) { if (!busy.empty()) busy += ", "; busy += side_stream_name(k); }
   }
+  // which events of the block pipelines are still pending (render_mix_pipelined): a render that is pending although the
+  // reduction it waited for is done is a kernel that does not finish; pending reductions behind done renders would be the ctx
+  // stream itself
+  std::string pipes;
+  for (size_t bi = 0; bi < ctx->banks.size() && bi < 4; ++bi) {
+    const groove_bank* bk = ctx->banks[bi];
+    for (int slot = 0; slot < 2; ++slot) {
+      if (!bk->ev_reduce_done[slot]) continue;
+      pipes += "; bank " + std::to_string(bi) + " slot " + std::to_string(slot) + ": reduction " + (hipEventQuery(bk->ev_reduce_done[slot]) == hipSuccess ? "done" : "PENDING") + ", renders";
+      for (int k = 0; k < kSideStreams; ++k)
+        if (bk->ev_render_done[k][slot]) pipes += std::string(" ") + std::to_string(k) + (hipEventQuery(bk->ev_render_done[k][slot]) == hipSuccess ? ":done" : ":PENDING");
+    }
+  }
   (void)hipGetLastError(); // hipErrorNotReady is sticky in the runtime's last-error slot
+  busy += pipes;
   fail(ctx, std::string(what) + ": not complete after " + std::to_string(ctx->sync_timeout_ms) + " ms (GROOVE_SYNC_TIMEOUT_MS / groove_set_sync_timeout_ms); still busy: " +
                 (busy.empty() ? "nothing (the wait itself raced the completion)" : busy) +
                 ".  The work stays queued; a kernel that crawls like this does so for the life of the process (DESIGN.md section 7): tear the process down and start again.");
