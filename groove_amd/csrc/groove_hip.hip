@@ -1956,6 +1956,13 @@ int groove_bank_reset(groove_bank* b) {
   groove_ctx* ctx = b->ctx;
   GHIP(ctx, hipSetDevice(ctx->device));
   if (ctx_join(ctx)) return 1;
+  // (experiment, GROOVE_RESET_HOST_SYNC=1: the host waits here until every stream is idle, and the block pipeline's slot
+  // events are forgotten — does the stall of DESIGN.md section 7 need a reset that is only ordered on the device?)
+  static const bool reset_host_sync = [] { const char* e = std::getenv("GROOVE_RESET_HOST_SYNC"); return e && e[0] == '1'; }();
+  if (reset_host_sync) {
+    GHIP(ctx, ctx_wait(ctx, "groove_bank_reset"));
+    for (int slot = 0; slot < 2; ++slot) b->reduce_recorded[slot] = false;
+  }
   b->side_mode = 0;
   b->ctx_touched = true;
   b->pending.clear();
