@@ -168,6 +168,7 @@ struct groove_ctx {
   bool own_stream = true;
   hipStream_t side_stream[kSideStreams] = {}; // kernels of the other workgroup kinds run beside the main one
   hipStream_t placeholder_stream = nullptr;   // created, never used (groove_init)
+  unsigned long long* hb = nullptr;           // -DGROOVE_HEARTBEAT (diagnostic build): [workgroups started, finished] of the per-kind kernels, in coherent host memory
   hipEvent_t ev_fork = nullptr, ev_join[kSideStreams] = {};
   bool side_busy[kSideStreams] = {};    // work enqueued on the side stream since the last join
   bool fork_pending[kSideStreams] = {}; // the side stream has not yet waited for ev_fork
@@ -309,6 +310,14 @@ hipError_t wait_deadline(groove_ctx* ctx, hipStream_t st, hipEvent_t ev, const c
   }
   (void)hipGetLastError(); // hipErrorNotReady is sticky in the runtime's last-error slot
   busy += pipes;
+#ifdef GROOVE_HEARTBEAT
+  if (ctx->hb) {
+    const unsigned long long s0 = ((volatile unsigned long long*)ctx->hb)[0], f0 = ((volatile unsigned long long*)ctx->hb)[1];
+    std::this_thread::sleep_for(std::chrono::milliseconds(500));
+    const unsigned long long s1 = ((volatile unsigned long long*)ctx->hb)[0], f1 = ((volatile unsigned long long*)ctx->hb)[1];
+    busy += "; heartbeat of the per-kind kernels: workgroups started " + std::to_string(s0) + " finished " + std::to_string(f0) + ", half a second later started " + std::to_string(s1) + " finished " + std::to_string(f1);
+  }
+#endif
   fail(ctx, std::string(what) + ": not complete after " + std::to_string(ctx->sync_timeout_ms) + " ms (GROOVE_SYNC_TIMEOUT_MS / groove_set_sync_timeout_ms); still busy: " +
                 (busy.empty() ? "nothing (the wait itself raced the completion)" : busy) +
                 ".  The work stays queued; a kernel that crawls like this does so for the life of the process (DESIGN.md section 7): tear the process down and start again.");
@@ -1067,6 +1076,9 @@ static int init_impl(int device_ordinal, const uint8_t* comm_id, int rank, int w
     ctx->comm_before_streams = true;
   }
   ok = ok && create_streams(ctx);
+#ifdef GROOVE_HEARTBEAT
+  if (ok && hipHostMalloc(reinterpret_cast<void**>(&ctx->hb), 64, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) { ctx->hb[0] = 0; ctx->hb[1] = 0; }
+#endif
   if (!ok) {
     groove_shutdown(ctx);
     return fail(nullptr, "groove_init: hipSetDevice/hipStreamCreate failed");
@@ -1796,6 +1808,9 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
     if (b->reduce_recorded[slot]) GHIP(ctx, hipStreamWaitEvent(st, b->ev_reduce_done[slot], 0));
     if (uniform) {
       UniformArgs a{b->d_waves, b->d_state, b->d_pipe_part[slot], b->d_pipe_part[slot], b->d_wg_list + offset[k], b->d_wg_cls + offset[k], 0, rc, b->n_vwaves, b->n, frames, count[k]};
+#ifdef GROOVE_HEARTBEAT
+      a.prev.bus = reinterpret_cast<float*>(ctx->hb);
+#endif
       switch (k) {
         case 0: launch_welsh_uniform_specialised_0(a, st, true); break;
         case 1: launch_welsh_uniform_specialised_1(a, st, true); break;

@@ -327,7 +327,8 @@ __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n
     bool live;
     const uint32_t mine = begin(live);
     if (HOISTED) live = live && active;
-    const uint32_t seg = min(wave_min_u32(mine), frames - f);
+    // (at least one frame: `begin` promises >= 1, and a segment of zero frames would spin here for ever — DESIGN.md section 7)
+    const uint32_t seg = max(1u, min(wave_min_u32(mine), frames - f));
     for (uint32_t k = 0; k < seg; ++k, ++f) {
       float L = 0.0f, R = 0.0f;
       if (live) live_frame(L, R); else if (!HOISTED) idle_frame();
@@ -555,12 +556,21 @@ __global__ __launch_bounds__(kThreads, (WavesBudget<LFO_MODE, RETUNE>::value)) G
   // joined; with the blocks pipelined the longest kernel is the most numerous kind, and any priority
   // costs 5 % — measured: none 0.460 ms, f64-LFO kinds raised 0.484, F32-retune raised 0.513.)
   const UniformArgsPtr ka = (UniformArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(); // == &a, in the constant address space
-  if constexpr (FUSED) { if (welsh_idle_workgroup(a)) return; }
+#ifdef GROOVE_HEARTBEAT /* diagnostic build: workgroups started / finished, counted in host memory the host can read while the device is stuck; the pointer rides in the (here unused) prev.bus */
+  unsigned long long* hb = reinterpret_cast<unsigned long long*>(a.prev.bus);
+  if (hb && threadIdx.x == 0) __hip_atomic_fetch_add(hb + 0, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#define GROOVE_HB_DONE do { __syncthreads(); if (hb && threadIdx.x == 0) __hip_atomic_fetch_add(hb + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
+#else
+#define GROOVE_HB_DONE do { } while (0)
+#endif
+  if constexpr (FUSED) { if (welsh_idle_workgroup(a)) { GROOVE_HB_DONE; return; } }
   if constexpr (!SPECIALISED) {
     welsh_uniform_body_impl<FUSED, LFO_MODE, RETUNE, OSC_ANY, OSC_ANY, OSC_ANY>(ka);
   } else {
     welsh_dispatch_class<FUSED, LFO_MODE, RETUNE>((uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[blockIdx.x]), ka);
   }
+  GROOVE_HB_DONE;
+#undef GROOVE_HB_DONE
 }
 // All (class-specialised) base kinds in ONE launch, for banks too small to fill the machine: there a block is
 // bound by one wavefront's serial walk of its frames, register budgets do not matter (the kernel takes
