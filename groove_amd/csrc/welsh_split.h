@@ -128,7 +128,7 @@ __device__ __forceinline__ void welsh_split_front_impl(UniformArgsPtr a) {
               const uint32_t mine = welsh_segment_begin(p, s, live);
               welsh_segment_start_hoisted(s, sc);
               live = live && w.active;
-              seg_len = seg_left = min(wave_min_u32(mine), frames - f);
+              seg_len = seg_left = max(1u, min(wave_min_u32(mine), frames - f)); // (at least one frame: kernels.h run_frames_segmented)
             }
             ok = live;
             if (live) welsh_frame_front<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true>(p, s, sc, sum, g, pct, retune, lfo);
@@ -360,7 +360,7 @@ GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split4_ctl(U
             const uint32_t mine = welsh_segment_begin(p, s, live);
             welsh_segment_start_hoisted(s, sc);
             live = live && w.active;
-            seg_len = seg_left = min(wave_min_u32(mine), frames - f);
+            seg_len = seg_left = max(1u, min(wave_min_u32(mine), frames - f)); // (at least one frame: kernels.h run_frames_segmented)
           }
           ok = live;
           if (live) welsh_frame_ctl<false, RETUNE, LFO_MODE, CL, true, true>(p, s, sc, g, pct, retune, mod, first);
