@@ -7,7 +7,7 @@ A "step" is one pass of the hot path over one 256-frame block of the whole proje
 ticks 256 frames (render kernels), its effect chain runs, and the mix bus sums the voice blocks
 (Orchestrator::gather_audio).  `value` = stereo bus frames of the project rendered per second,
 with all inputs (patch parameters, voice state, sample bank) resident in HBM before the timed
-region.  The timed region is repeated (--repeats; default 5 for windows of up to 40 steps, 3 otherwise) from a reset state — W warm-up steps,
+region.  The timed region is repeated (--repeats; default 7 for windows of up to 40 steps, 3 otherwise) from a reset state — W warm-up steps,
 then exactly K timed steps, i.e. blocks W .. W+K-1 of the project's timeline each time — and
 `value` is the median repeat; every repeat is on the line.
 
@@ -637,8 +637,8 @@ def roofline_block(workload, n_local, kern_ms, span_mode, fused, window=None):
     return r
 
 
-SHORT_WINDOW_REPEATS = 5  # timed regions of a short window (see main)
-FORM_REPEATS = 3          # ... of the materialised million-voice forms (secondary entries; every block of the multi-stream million-voice path is exposure to the stall of DESIGN.md section 7)
+SHORT_WINDOW_REPEATS = 7  # timed regions of a short window (see main)
+FORM_REPEATS = 5          # ... of the materialised million-voice forms (secondary entries)
 PHASE = {"now": "start"}  # what the measurement was doing, for the message of a stall
 
 
@@ -769,7 +769,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=172, help="default: one full 172-block project (44,032 frames)")
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--repeats", type=int, default=0, help="timed regions, each from a reset state (value = the median); default: 5 for windows of up to 40 steps, 3 otherwise")
+    ap.add_argument("--repeats", type=int, default=0, help="timed regions, each from a reset state (value = the median); default: 7 for windows of up to 40 steps, 3 otherwise")
     ap.add_argument("--workload", default="welsh-1m", choices=sorted(WORKLOADS))
     ap.add_argument("--voices", type=int, default=0, help="override the workload's total voice count")
     ap.add_argument("--materialise", action="store_true",
@@ -867,7 +867,7 @@ def measure(args, world, rank, local_rank):
     # A short window is 10 - 15 ms of GPU work and the first regions of a process (or after the seconds the host spends in the
     # oracle between phases) run 5 - 12 % slower than the ones after them — 1,000,000 voices, nine regions of 20 steps:
     # 0.548 0.534 0.514 0.488 0.483 0.486 0.486 0.485 0.486 ms per block (profiles/r03_timed_regions.log): three regions put the
-    # median on the slope, five put it on what the device sustains.  Every region is on the line.
+    # median on the slope, seven put it on what the device sustains.  Every region is on the line.
     K, W = args.steps, args.warmup
     R = max(1, args.repeats) if args.repeats else (SHORT_WINDOW_REPEATS if K <= 40 else 3)
     sel = np.arange(lo, hi, dtype=np.int64)
