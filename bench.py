@@ -242,10 +242,16 @@ def dry_launch(world, rank):
     lo, hi = voice_range(WORKLOADS["welsh-1m"]["voices"], rank, world)
     spans = [None] * world
     dist.all_gather_object(spans, (lo, hi))
+    plans = [None] * world
+    dist.all_gather_object(plans, section_plan(world, rank))
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"dry_launch": True, "ranks": int(t.item()), "world": world, "voice_ranges": spans}), flush=True)
+        # the real run's `sections`, as far as they exist without a GPU: every rank's voice range per section, and the number of
+        # ranks that joined in the place of the communicator's size (`rccl_ranks`: ncclCommCount in the real run)
+        sections = {name: {"workload": plans[0][name]["workload"], "voices_total": plans[0][name]["voices_total"],
+                           "ranges": [pl[name]["range"] for pl in plans], "rccl_ranks": int(t.item())} for name in plans[0]}
+        print(json.dumps({"dry_launch": True, "ranks": int(t.item()), "world": world, "voice_ranges": spans, "sections": sections}), flush=True)
     return 0 if int(t.item()) == world else 1
 
 
@@ -525,6 +531,11 @@ class Dist:
             host[frame0:frame0 + frames] = t.cpu().numpy()
             bus.upload(host)
 
+    def gather(self, obj):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
     def max_over_ranks(self, x):
         t = self.torch.tensor([x], dtype=self.torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
@@ -534,7 +545,7 @@ class Dist:
 def time_project(ctx, proj, bus, K, W, repeats, span_mode, dist=None):
     """`repeats` x (reset, W warm-up steps, K timed steps bracketed by a synchronisation — and a barrier
     across ranks — on both sides).  Returns per-repeat wall seconds (max over ranks) and HIP-event ms per step."""
-    walls, kerns = [], []
+    walls, kerns, own = [], [], []
     for _ in range(repeats):
         proj.reset()
         for s in range(W):
@@ -557,6 +568,7 @@ def time_project(ctx, proj, bus, K, W, repeats, span_mode, dist=None):
         else:
             ctx.synchronize()
         el = time.perf_counter() - t0
+        own.append(el)
         walls.append(dist.max_over_ranks(el) if dist else el)
         if span_mode:
             kerns.append(ctx.elapsed_ms(pairs[0][0], pairs[-1][1]) / K)
@@ -566,7 +578,18 @@ def time_project(ctx, proj, bus, K, W, repeats, span_mode, dist=None):
             for e in (a, b):
                 if e is not None:
                     ctx.L.groove_event_destroy(ctx.h, e)
-    return walls, kerns
+    extra = {"own_walls": own}
+    if dist:  # outside every timed region: what the ONE collective of a render costs by itself (barrier, reduce, sync; max over ranks)
+        alone = []
+        for _ in range(3):
+            dist.sync()
+            t0 = time.perf_counter()
+            dist.reduce_bus(bus, W * FRAMES, K * FRAMES)
+            dist.sync()
+            alone.append(dist.max_over_ranks(time.perf_counter() - t0))
+        extra["reduce_alone_ms"] = sorted(alone)[1] * 1e3
+        extra["walls_by_rank"] = dist.gather(own)  # [rank][repeat]
+    return walls, kerns, extra
 
 
 def roofline_block(workload, n_local, kern_ms, span_mode, fused, window=None):
@@ -654,13 +677,40 @@ def bench_workload(ctx, workload, sel, K, W, repeats, fused=True, grouped=True, 
     forms = sorted({inst.kernel_form(FRAMES, fused and not fx) for inst, _, fx, _ in proj.banks})
     bus = ctx.bus((K + W) * FRAMES)
     span_mode = (fused and wl["kind"] != "chain") or (render_ahead and (wl["kind"] == "chain" or not fused))
-    walls, kerns = time_project(ctx, proj, bus, K, W, repeats, span_mode, dist)
+    walls, kerns, extra = time_project(ctx, proj, bus, K, W, repeats, span_mode, dist)
     out_bus = bus.download()[W * FRAMES:] if (dist is None or dist.rank == 0) else None
     proj.destroy()
     bus.destroy()
     order = np.argsort(walls)
     med = int(order[len(order) // 2])
-    return {"walls": walls, "kerns": kerns, "median": med, "span_mode": span_mode, "bus": out_bus, "kernel_form": forms}
+    return {"walls": walls, "kerns": kerns, "median": med, "span_mode": span_mode, "bus": out_bus, "kernel_form": forms, **extra}
+
+
+def section_plan(world, rank, workload="welsh-1m", voices=0):
+    """The three measurements ONE `bench.py --gpus N` run makes (N > 1), as voice ranges of this rank — shared by the real run and
+    by --dry-launch (tests/test_projects_cpu.py):
+      strong        the workload's voices split N ways (contiguous index ranges): the line's `value`
+      weak          the workload's voice count on EVERY rank: the project grows with N
+      mixed-131072  config #5 as BASELINE.json writes it: 131,072 mixed voices split N ways (16,384 per GPU at N = 8)."""
+    V = voices or WORKLOADS[workload]["voices"]
+    Vm = WORKLOADS["mixed-131072"]["voices"]
+    return {"strong": {"workload": workload, "voices_total": V, "range": list(voice_range(V, rank, world))},
+            "weak": {"workload": workload, "voices_total": V * world, "range": list(voice_range(V * world, rank, world))},
+            "mixed-131072": {"workload": "mixed-131072", "voices_total": Vm, "range": list(voice_range(Vm, rank, world))}}
+
+
+def section_summary(m, K, plan, dist, scaling):
+    """One entry of the line's `sections` (rank 0): the whole job's frames/s, the ranks' own clocks, the communicator, the reduce."""
+    i = m["median"]
+    per_rank = [w[i] / K * 1e3 for w in m.get("walls_by_rank") or [m["own_walls"]]]
+    fps = K * FRAMES / m["walls"][i]
+    return {"workload": plan["workload"], "scaling": scaling, "voices_total": plan["voices_total"], "voices_per_gpu": plan["range"][1] - plan["range"][0],
+            "value": fps, "unit": "stereo frames/s", "x_realtime_44k1": fps / SR, "voice_frames_per_s": fps * plan["voices_total"],
+            "ms_per_step": m["walls"][i] / K * 1e3, "ms_per_step_repeats": [w / K * 1e3 for w in m["walls"]],
+            "ms_per_step_by_rank": {"max": max(per_rank), "min": min(per_rank), "all": per_rank,
+                                    "note": "each rank's own clock over the same region (the region ends with the bus reduce and a barrier, so the ranks' clocks differ by what they waited at its start)"},
+            "kernel_ms_rank0": m["kerns"][i], "rccl_ranks": dist.rccl_ranks, "bus_reduce": dist.reduce_via,
+            "bus_reduce_alone_ms": m.get("reduce_alone_ms"), "kernel_form": m["kernel_form"]}
 
 
 def config_entry(ctx, workload, repeats, parity_voices=64):
@@ -698,7 +748,8 @@ def form_entry(ctx, label, K, W, fused, grouped, note):
             "kernel_form": m["kernel_form"], "ms_per_step_repeats": [w / K * 1e3 for w in m["walls"]], "statistic": "median region",
             "ms_per_step": ms, "value": fps, "unit": "stereo frames/s", "x_realtime_44k1": fps / SR,
             "frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "frac_is": "algorithmic 18 B per voice-frame / time; in this form 16 of the 18 bytes are really moved (block written, state in and out; the mix reads the render's row sums)"}
+            "frac_is": "algorithmic 18 B per voice-frame / time; in this form 10 of the 18 bytes are really moved (8 B of block written + 2 B of state in and out; the mix reads the render's row sums, not the block)",
+            "hbm_physical_frac": 10.0 * V * FRAMES / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
 def shard_curve(ctx, K, W, ms_full):
@@ -790,7 +841,7 @@ def main():
     ap.add_argument("--no-head-ahead", action="store_true", help="render-ahead walk: keep the chain's leading IIR stage on the ctx stream (A/B)")
     ap.add_argument("--head-unfused", action="store_true", help="render-ahead walk: the IIR head behind the render as its own launch, not fused into the render kernel (A/B)")
     ap.add_argument("--dry-launch", action="store_true", help="rendezvous of the ranks over gloo only (no GPU): launcher test")
-    ap.add_argument("--no-canary", action="store_true", help="(kept for old command lines; the watchdog replaced the canary)")
+    ap.add_argument("--no-sections", action="store_true", help="N > 1: only the measurement the flags ask for (default: strong, weak and mixed-131072 from one run)")
     ap.add_argument("--no-watchdog", action="store_true", help="run the measurement in this process (default on one GPU: in a child process that is killed and restarted if it crawls)")
     ap.add_argument("--watchdog-seconds", type=float, default=0.0, help="time allowed per attempt (default: 240 s for up to 50 steps, 420 s otherwise)")
     args = ap.parse_args()
@@ -822,11 +873,12 @@ def main():
         print(json.dumps({"metric": "fake", "value": 1.0}), flush=True)
         sys.exit(0)
 
-    # Watchdog (one GPU, not under a launcher): about one process in fifteen on this pool crawls on the multi-stream path
-    # (one render kernel of the million-voice step takes seconds, block after block, for as long as
-    # the process lives; the next process is fine).  The measurement therefore runs in a child process; a child that
-    # has not finished in time — or whose library reported the stalled stream itself — is killed (its exact PID) and the
-    # run starts again, and the line says how often.  Never from under a profiler.
+    # Watchdog (one GPU, not under a launcher).  Rounds 2 and 3 saw the million-voice path stall in some processes; round 4
+    # found the cause (an endless loop in one workgroup of a render kernel) and removed it, and the
+    # line's `zero_segments` counts its trigger.  The watchdog stays as what it always was — a harness that cannot hang:
+    # the measurement runs in a child process; a child that has not finished in time — or whose library reported a
+    # stalled stream itself — is killed (its exact PID) and the run starts again, and the line says so (`tainted`).
+    # Never from under a profiler.
     if world == 1 and "WORLD_SIZE" not in os.environ and supervise and not is_child:
         sys.exit(run_under_watchdog(sys.argv[1:], args))
     from groove_amd.lib import GrooveError
@@ -912,6 +964,33 @@ def measure(args, world, rank, local_rank):
         }
         if dist is not None:
             line["rccl_ranks"] = dist.rccl_ranks
+        line["zero_segments"] = line["streams"].get("zero_segments")
+        if line["zero_segments"]:
+            line["tainted"] = "the Welsh kernels counted zero-frame segments (csrc/diag.h; DESIGN.md section 7): this must not happen"
+    if dist is not None and not args.no_sections and not args.materialise and not args.interleaved:
+        # ONE run of the driver's command carries all three N-GPU measurements (section_plan): the line's own measurement is one of
+        # them, the other scaling mode of the same workload and config #5 follow with the same ranks and the same communicator
+        plans = section_plan(world, rank, args.workload, args.voices)
+        mine = "weak" if weak else "strong"
+        sections = {}
+        if rank == 0:
+            sections[mine] = section_summary(m, K, plans[mine], dist, mine)
+        other = "strong" if weak else "weak"
+        lo2, hi2 = plans[other]["range"]
+        m2 = bench_workload(ctx, args.workload, np.arange(lo2, hi2, dtype=np.int64), K, W, R, dist=dist)
+        if rank == 0:
+            sections[other] = section_summary(m2, K, plans[other], dist, other)
+        if args.workload != "mixed-131072":
+            lo3, hi3 = plans["mixed-131072"]["range"]
+            Km = WORKLOADS["mixed-131072"]["blocks"]
+            m3 = bench_workload(ctx, "mixed-131072", np.arange(lo3, hi3, dtype=np.int64), Km, 0, 3, dist=dist)
+            if rank == 0:
+                sections["mixed-131072"] = section_summary(m3, Km, plans["mixed-131072"], dist, "strong")
+                sections["mixed-131072"]["blocks_timed"] = f"0..{Km - 1} (the whole project)"
+        if rank == 0:
+            line["sections"] = sections
+            line["sections_note"] = ("one run, the same ranks and communicator: `strong` = the workload split N ways (the line's value unless --weak), "
+                                     "`weak` = the workload's voice count on every rank, `mixed-131072` = config #5 split N ways")
     if dist is not None:
         dist.dist.barrier()
         dist.dist.destroy_process_group()

@@ -169,6 +169,7 @@ struct groove_ctx {
   hipStream_t side_stream[kSideStreams] = {}; // kernels of the other workgroup kinds run beside the main one
   hipStream_t placeholder_stream = nullptr;   // created, never used (groove_init)
   unsigned long long* hb = nullptr;           // -DGROOVE_HEARTBEAT (diagnostic build): [workgroups started, finished] of the per-kind kernels, in coherent host memory
+  uint32_t* d_diag = nullptr;                 // DiagCounters (diag.h): the segment guard's counter, read by groove_debug_info
   hipEvent_t ev_fork = nullptr, ev_join[kSideStreams] = {};
   bool side_busy[kSideStreams] = {};    // work enqueued on the side stream since the last join
   bool fork_pending[kSideStreams] = {}; // the side stream has not yet waited for ev_fork
@@ -246,6 +247,8 @@ struct groove_ctx {
 
 namespace {
 
+// Returned through hipError_t-typed helpers whose failure is already described in ctx->err: GHIP passes it on untouched.
+constexpr hipError_t kGrooveFailed = hipErrorAssert;
 int fail(groove_ctx* ctx, const std::string& msg) {
   g_last_error = msg;
   if (ctx) ctx->err = msg;
@@ -255,6 +258,7 @@ int fail(groove_ctx* ctx, const std::string& msg) {
   do {                                                                                     \
     hipError_t e_ = (expr);                                                                \
     if (e_ == hipErrorNotReady) return 2; /* a deadline passed: wait_deadline wrote the message */ \
+    if (e_ == kGrooveFailed) return 1;    /* the callee has written the message (ctx_wait: bus_flush) */ \
     if (e_ != hipSuccess)                                                                  \
       return fail(ctx, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
   } while (0)
@@ -320,12 +324,12 @@ hipError_t wait_deadline(groove_ctx* ctx, hipStream_t st, hipEvent_t ev, const c
 #endif
   fail(ctx, std::string(what) + ": not complete after " + std::to_string(ctx->sync_timeout_ms) + " ms (GROOVE_SYNC_TIMEOUT_MS / groove_set_sync_timeout_ms); still busy: " +
                 (busy.empty() ? "nothing (the wait itself raced the completion)" : busy) +
-                ".  The work stays queued; a kernel that crawls like this does so for the life of the process (DESIGN.md section 7): tear the process down and start again.");
+                ".  The work stays queued and a later wait may still see it complete; if it does not, tear the process down (DESIGN.md section 7: the one stall this path has known was an endless loop in a render kernel, fixed in round 4; groove_debug_info's zero_segments counts its trigger).");
   return hipErrorNotReady;
 }
 int bus_flush(groove_ctx* ctx); // a deferred block's rows onto its bus (groove_bank_render_mix_deferred), defined with the reductions below
 hipError_t ctx_wait(groove_ctx* ctx, const char* what = "wait for the ctx stream") {
-  if (bus_flush(ctx)) return hipErrorUnknown; // whoever waits for the ctx stream expects every bus to be complete behind it
+  if (bus_flush(ctx)) return kGrooveFailed; // (its own message stands.)  Whoever waits for the ctx stream expects every bus to be complete behind it
   return wait_deadline(ctx, ctx->stream, nullptr, what);
 }
 hipError_t ctx_memcpy(groove_ctx* ctx, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
@@ -1076,6 +1080,7 @@ static int init_impl(int device_ordinal, const uint8_t* comm_id, int rank, int w
     ctx->comm_before_streams = true;
   }
   ok = ok && create_streams(ctx);
+  ok = ok && hipMalloc(reinterpret_cast<void**>(&ctx->d_diag), sizeof(DiagCounters)) == hipSuccess && hipMemsetAsync(ctx->d_diag, 0, sizeof(DiagCounters), ctx->stream) == hipSuccess;
 #ifdef GROOVE_HEARTBEAT
   if (ok && hipHostMalloc(reinterpret_cast<void**>(&ctx->hb), 64, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) { ctx->hb[0] = 0; ctx->hb[1] = 0; }
 #endif
@@ -1104,6 +1109,7 @@ void groove_shutdown(groove_ctx* ctx) {
   for (float* q : ctx->d_dpart) if (q) (void)hipFree(q);
   if (ctx->d_fseg) (void)hipFree(ctx->d_fseg);
   if (ctx->d_i16) (void)hipFree(ctx->d_i16);
+  if (ctx->d_diag) (void)hipFree(ctx->d_diag);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   for (int i = 0; i < kSideStreams; ++i) {
     if (side_stream_owned(ctx, i)) { (void)hipStreamSynchronize(ctx->side_stream[i]); (void)hipStreamDestroy(ctx->side_stream[i]); }
@@ -1155,12 +1161,26 @@ int groove_debug_info(groove_ctx* ctx, char* out, size_t cap) {
     for (int j = 0; j < k && !dup; ++j) dup = ctx->side_stream[j] == ctx->side_stream[k];
     distinct += dup ? 0 : 1;
   }
+  // the segment guard's counter (diag.h): what the kernels have counted so far (groove_synchronize first for a final figure)
+  DiagCounters dc{};
+  GHIP(ctx, ctx_memcpy(ctx, &dc, ctx->d_diag, sizeof(dc), hipMemcpyDeviceToHost));
+  std::string diag = "\"zero_segments\": " + std::to_string(dc.zero_segments);
+#ifdef GROOVE_DIAG_SHADOW_IN_MIN
+  diag += ", \"diag_build\": \"GROOVE_DIAG_SHADOW_IN_MIN\", \"shadow_zero_lanes\": " + std::to_string(dc.shadow_zero_lanes) + ", \"shadow_zero_waves\": " + std::to_string(dc.shadow_zero_waves) + ", \"records\": [";
+  for (uint32_t i = 0; i < std::min(dc.records, kDiagRecords); ++i) {
+    const DiagRecord& r = dc.rec[i];
+    diag += std::string(i ? ", " : "") + "{\"wg\": " + std::to_string(r.wg) + ", \"wave\": " + std::to_string(r.wave) + ", \"lane\": " + std::to_string(r.lane) + ", \"active\": " + std::to_string(r.active) +
+            ", \"count\": " + std::to_string(r.count) + ", \"frame\": " + std::to_string(r.frame) + ", \"amp\": [" + std::to_string(r.amp_state) + ", " + std::to_string(r.amp_n) + ", " + std::to_string(r.amp_N) +
+            "], \"fil\": [" + std::to_string(r.fil_state) + ", " + std::to_string(r.fil_n) + ", " + std::to_string(r.fil_N) + "]}";
+  }
+  diag += "]";
+#endif
   std::snprintf(out, cap,
                 "{\"layout\": \"%s\", \"streams_created\": %d, \"distinct_side_streams\": %d, \"kind_streams\": %d, \"bank_streams\": %d, "
-                "\"placeholder_fifth\": %s, \"comm_before_streams\": %s, \"own_ctx_stream\": %s, \"sync_timeout_ms\": %u}",
+                "\"placeholder_fifth\": %s, \"comm_before_streams\": %s, \"own_ctx_stream\": %s, \"sync_timeout_ms\": %u, %s}",
                 ctx->safe_streams ? "safe (one priority, ctx + 3 shared side streams)" : "default (ctx high, 3 kind streams normal, placeholder, bank streams low)",
                 ctx->streams_created, distinct, ctx->kind_streams, ctx->safe_streams ? 0 : ctx->bank_streams, ctx->placeholder_stream ? "true" : "false",
-                ctx->comm_before_streams ? "true" : "false", ctx->own_stream ? "true" : "false", ctx->sync_timeout_ms);
+                ctx->comm_before_streams ? "true" : "false", ctx->own_stream ? "true" : "false", ctx->sync_timeout_ms, diag.c_str());
   return 0;
 }
 uint32_t groove_sample_rate(groove_ctx* ctx) { return ctx ? ctx->sr : 0; }
@@ -1456,6 +1476,15 @@ static uint32_t fused_rows(const groove_bank* b, uint32_t frames) {
   if (use_tp(b, frames)) return b->kind == BANK_SAMPLER ? sampler_tp_workgroups(b->n) : b->kind == BANK_WELSH ? welsh_tp_grid(b->n, tp_vpw(b)) : welsh_tp_workgroups(b->n, tp_vpw(b));
   return (b->kind == BANK_WELSH && b->n_vwaves) ? (b->n_vwaves + kWaves - 1) / kWaves : blocks_for(b->n);
 }
+// The one argument block of the wave-uniform Welsh kernels: workgroups [wg_off, wg_off + n_wgs) of the bank's kind-sorted list.
+static UniformArgs uniform_args(const groove_bank* b, float* out, float* rows, uint32_t wg_off, size_t chs, uint32_t frames, uint32_t n_wgs) {
+  UniformArgs a{b->d_waves, b->d_state, out, rows, b->d_wg_list + wg_off, b->d_wg_cls + wg_off, chs, render_consts(b->ctx->sr), b->n_vwaves, b->n, frames, n_wgs};
+  a.diag = b->ctx->d_diag;
+#ifdef GROOVE_HEARTBEAT
+  a.heartbeat = b->ctx->hb;
+#endif
+  return a;
+}
 // A Welsh bank below the per-kind pipeline's threshold: ONE launch for all its workgroups — role-split (welsh_split.h) when the
 // bank is mid-size, for the workgroups of the four class-specialised base kinds (the workgroup list is sorted by kind: they
 // come first); the rest, or everything, through the all-kinds kernel.
@@ -1539,7 +1568,7 @@ static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs
       // forked from it, and the ctx stream joins them before the bus reduction.
       if (b->n_vwaves < ctx->pipeline_min_waves) { // small bank: all base kinds in one launch (kernels.h)
         const uint32_t wgs = (b->n_vwaves + kWaves - 1) / kWaves;
-        UniformArgs a{b->d_waves, b->d_state, out, rows, b->d_wg_list, b->d_wg_cls, chs, rc, b->n_vwaves, b->n, frames, wgs};
+        UniformArgs a = uniform_args(b, out, rows, 0, chs, frames, wgs);
         launch_small_uniform(b, a, ctx->stream, fused, frames);
         GHIP(ctx, hipGetLastError());
         return 0;
@@ -1565,7 +1594,7 @@ static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs
           st = side_stream_of(ctx, side);
           GHIP(ctx, hipStreamWaitEvent(st, ctx->ev_fork, 0));
         }
-        UniformArgs a{b->d_waves, b->d_state, out, rows, b->d_wg_list + offset[k], b->d_wg_cls + offset[k], chs, rc, b->n_vwaves, b->n, frames, count[k]};
+        UniformArgs a = uniform_args(b, out, rows, offset[k], chs, frames, count[k]);
         launch_welsh_kind(k, a, st, fused);
         if (!first_kind) {
           GHIP(ctx, hipEventRecord(ctx->ev_join[side], st));
@@ -1678,7 +1707,6 @@ static int render_async_impl(groove_bank* b, uint32_t frames, groove_block* out,
     ctx->side_busy[k] = true;
   };
   if (uniform) {
-    const RenderConsts rc = render_consts(ctx->sr);
     uint32_t at = 0;
     uint32_t count[kBaseKinds] = {}, offset[kBaseKinds] = {};
     for (int base = 0; base < kBaseKinds; ++base) {
@@ -1689,7 +1717,7 @@ static int render_async_impl(groove_bank* b, uint32_t frames, groove_block* out,
     for (int k = kBaseKinds - 1; k >= 0; --k) { // most expensive kind first
       if (!count[k]) continue;
       hipStream_t st = begin(k);
-      UniformArgs a{b->d_waves, b->d_state, dst, rows, b->d_wg_list + offset[k], b->d_wg_cls + offset[k], chs, rc, b->n_vwaves, b->n, frames, count[k]};
+      UniformArgs a = uniform_args(b, dst, rows, offset[k], chs, frames, count[k]);
       launch_welsh_kind(k, a, st, false);
       end(k);
     }
@@ -1718,8 +1746,7 @@ static int render_async_impl(groove_bank* b, uint32_t frames, groove_block* out,
       }
       ready_bound = bind;
     } else if (small_uniform) { // all base kinds in one launch
-      const RenderConsts rc = render_consts(ctx->sr);
-      UniformArgs a{b->d_waves, b->d_state, dst, rows, b->d_wg_list, b->d_wg_cls, chs, rc, b->n_vwaves, b->n, frames, b->n_vwaves / kWaves};
+      UniformArgs a = uniform_args(b, dst, rows, 0, chs, frames, fused_rows(b, frames));
       launch_small_uniform(b, a, st, false, frames);
     } else if (b->kind == BANK_WELSH) {
       const RenderConsts rc = render_consts(ctx->sr);
@@ -1807,10 +1834,7 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
     if (ctx->fork_pending[k]) { GHIP(ctx, hipStreamWaitEvent(st, ctx->ev_fork, 0)); ctx->fork_pending[k] = false; }
     if (b->reduce_recorded[slot]) GHIP(ctx, hipStreamWaitEvent(st, b->ev_reduce_done[slot], 0));
     if (uniform) {
-      UniformArgs a{b->d_waves, b->d_state, b->d_pipe_part[slot], b->d_pipe_part[slot], b->d_wg_list + offset[k], b->d_wg_cls + offset[k], 0, rc, b->n_vwaves, b->n, frames, count[k]};
-#ifdef GROOVE_HEARTBEAT
-      a.prev.bus = reinterpret_cast<float*>(ctx->hb);
-#endif
+      UniformArgs a = uniform_args(b, b->d_pipe_part[slot], b->d_pipe_part[slot], offset[k], 0, frames, count[k]);
       switch (k) {
         case 0: launch_welsh_uniform_specialised_0(a, st, true); break;
         case 1: launch_welsh_uniform_specialised_1(a, st, true); break;
@@ -1822,7 +1846,7 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
     } else if (tp) {
       launch_tp(b, frames, true, 0, b->d_pipe_part[slot], b->d_pipe_part[slot], st);
     } else if (small_uniform) { // all base kinds in one launch on this bank's stream
-      UniformArgs a{b->d_waves, b->d_state, b->d_pipe_part[slot], b->d_pipe_part[slot], b->d_wg_list, b->d_wg_cls, 0, rc, b->n_vwaves, b->n, frames, rows};
+      UniformArgs a = uniform_args(b, b->d_pipe_part[slot], b->d_pipe_part[slot], 0, 0, frames, rows);
       launch_small_uniform(b, a, st, true, frames);
     } else if (b->kind == BANK_WELSH) {
       hipLaunchKernelGGL(welsh_render_kernel<true>, dim3(rows), blk, 0, st, b->d_params, b->d_state, b->n, frames, (size_t)0, b->d_pipe_part[slot], b->d_pipe_part[slot], rc);
@@ -1874,7 +1898,7 @@ int groove_bank_render_mix_deferred(groove_bank* b, uint32_t frames, float* bus_
         GHIP(ctx, hipMalloc(&ctx->d_dpart[slot], need * 4));
         ctx->dpart_cap[slot] = need;
       }
-      UniformArgs a{b->d_waves, b->d_state, ctx->d_dpart[slot], ctx->d_dpart[slot], b->d_wg_list, b->d_wg_cls, 0, render_consts(ctx->sr), b->n_vwaves, b->n, frames, urows};
+      UniformArgs a = uniform_args(b, ctx->d_dpart[slot], ctx->d_dpart[slot], 0, 0, frames, urows);
       if (ctx->deferred.rows) { a.prev.rows = ctx->deferred.rows; a.prev.bus = ctx->deferred.bus; a.prev.n_rows = ctx->deferred.n_rows; a.prev.frames = ctx->deferred.frames; a.prev.accumulate = ctx->deferred.accumulate; }
       ctx->deferred.rows = nullptr;
       b->ctx_touched = true;

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include "dsp_core.h"
 #include "derive.h"
+#include "diag.h"
 
 namespace groove {
 
@@ -122,10 +123,8 @@ __device__ __forceinline__ void tp_reduce_prev(const TpPrev& pv, uint32_t tid, u
 
 // ------------------------------------------------------------------ fused mix-bus epilogue
 // Orchestrator::gather_audio's "sum += entity.value()" (orchestrator.rs:397-410) without
-// materialising the voice block: per frame the 64 lanes of a wave are summed with DPP
-// (no LDS, no memory), the wave total is parked in lane (frame mod 64) of an accumulator
-// register (one compare + two selects), and every 64 frames the four waves of the workgroup are summed
-// through LDS and one coalesced 256-byte row per channel is written:
+// materialising the voice block: every frame a lane parks its (L, R) in an LDS tile, every eight frames the
+// workgroup turns the tile and writes one row segment per channel (FusedAcc below):
 //     partial[workgroup][ch][frame]
 // A second, tiny kernel pair sums the partial rows over workgroups (deterministic order).
 template <int CTRL, int ROW_MASK>
@@ -143,49 +142,16 @@ __device__ __forceinline__ float wave_sum_lane63(float x) {
   x = dpp_add<0x143, 0xc>(x);  // row_bcast:31 into rows 2 and 3
   return x;
 }
-// (kept for reference / A-B: the all-DPP form, 17 VALU per frame)
-struct FusedAccDpp {
-  uint32_t prow;   // this workgroup's row pair in partial[]
-  float accL = 0.0f, accR = 0.0f;
-  __device__ __forceinline__ explicit FusedAccDpp(uint32_t row) : prow(row) {}
-  __device__ __forceinline__ void add(float L, float R, uint32_t f) {
-    const float tl = wave_sum_lane63(L), tr = wave_sum_lane63(R);
-    const int sl = __builtin_amdgcn_readlane(__builtin_bit_cast(int, tl), 63);
-    const int sr = __builtin_amdgcn_readlane(__builtin_bit_cast(int, tr), 63);
-    const bool mine = (threadIdx.x & 63u) == (f & 63u); // park the totals in lane (f mod 64)
-    accL = mine ? __builtin_bit_cast(float, sl) : accL;
-    accR = mine ? __builtin_bit_cast(float, sr) : accR;
-  }
-  static constexpr bool kStoresRows = false; // (no per-lane tile: the block is stored frame by frame)
-  __device__ __forceinline__ void flush(float* __restrict__ partial, uint32_t frames, uint32_t f0, uint32_t count,
-                                        float* = nullptr, size_t = 0, uint32_t = 0, uint32_t = 0) {
-    __shared__ float red[kWaves][2][64];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    red[wave][0][lane] = accL;
-    red[wave][1][lane] = accR;
-    __syncthreads();
-    if (wave < 2 && lane < count) { // wave 0 → left, wave 1 → right
-      float t = 0.0f;
-#pragma unroll
-      for (int w = 0; w < kWaves; ++w) t += red[w][wave][lane];
-      partial[((size_t)prow * 2 + wave) * frames + f0 + lane] = t;
-    }
-    __syncthreads();
-    accL = 0.0f; accR = 0.0f;
-  }
-  static constexpr uint32_t kChunk = 64;
-};
-
-// LDS-transposed form (default).  Every frame each lane drops its (L, R) pair into a
+// LDS-transposed form.  Every frame each lane drops its (L, R) pair into a
 // [8 frames][256 lanes] float2 tile with one ds_write_b64; every 8 frames the workgroup turns
 // the tile: 32 lanes per frame row, each sums 8 pairs (conflict-free 256-byte row segments),
 // then 5 DPP steps finish the 32-lane sum and two lanes per wave store the row totals.
-// ≈ 5 VALU + 1 LDS write per frame instead of 17 VALU; 16 KiB of LDS per workgroup.
-struct FusedAccLds {
+// ≈ 5 VALU + 1 LDS write per frame (an all-DPP form without LDS was 17 VALU per frame and 1.5 % slower: docs/HISTORY.md);
+// 16 KiB of LDS per workgroup.
+struct FusedAcc {
   static constexpr uint32_t kChunk = 8;
-  static constexpr bool kStoresRows = true;
   uint32_t prow;   // this workgroup's row pair in partial[]
-  __device__ __forceinline__ explicit FusedAccLds(uint32_t row) : prow(row) {}
+  __device__ __forceinline__ explicit FusedAcc(uint32_t row) : prow(row) {}
   __device__ __forceinline__ float2* tile() {
     __shared__ float2 t[kChunk][kThreads];
     return &t[0][0];
@@ -193,25 +159,8 @@ struct FusedAccLds {
   __device__ __forceinline__ void add(float L, float R, uint32_t f) {
     tile()[(f & (kChunk - 1)) * kThreads + threadIdx.x] = make_float2(L, R);
   }
-  // `out` (GROOVE_ROW_STORES, an A/B option that did not pay — see welsh_uniform_body_impl): the tile's frames also leave as rows
-  // of the planar block, every wavefront storing one whole 1 KB row (64 lanes x 16 bytes) per instruction.
-  __device__ __forceinline__ void flush(float* __restrict__ partial, uint32_t frames, uint32_t f0, uint32_t count,
-                                        float* __restrict__ out = nullptr, size_t ch_stride = 0, uint32_t n = 0, uint32_t vbase0 = 0) {
+  __device__ __forceinline__ void flush(float* __restrict__ partial, uint32_t frames, uint32_t f0, uint32_t count) {
     __syncthreads();
-    if (out) {
-      const uint32_t q = threadIdx.x & 63u, rp = threadIdx.x >> 6; // quad of lanes; rows rp and rp + 4
-#pragma unroll
-      for (uint32_t rr = 0; rr < kChunk / kWaves; ++rr) {
-        const uint32_t row = rp + kWaves * rr;
-        if (row < count) {
-          const float4 a0 = *reinterpret_cast<const float4*>(tile() + row * kThreads + 4 * q);     // (L0, R0, L1, R1)
-          const float4 a1 = *reinterpret_cast<const float4*>(tile() + row * kThreads + 4 * q + 2); // (L2, R2, L3, R3)
-          float* __restrict__ dst = out + (size_t)(f0 + row) * n + vbase0 + 4 * q;
-          *reinterpret_cast<float4*>(dst) = make_float4(a0.x, a0.z, a1.x, a1.z);
-          *reinterpret_cast<float4*>(dst + ch_stride) = make_float4(a0.y, a0.w, a1.y, a1.w);
-        }
-      }
-    }
     const uint32_t row = threadIdx.x >> 5, col = threadIdx.x & 31u; // 32 lanes per frame row
     const float2* __restrict__ src = tile() + row * kThreads + col;
     float l = 0.0f, r = 0.0f;
@@ -230,21 +179,9 @@ struct FusedAccLds {
     __syncthreads();
   }
 };
-#ifdef GROOVE_FUSED_DPP
-using FusedAcc = FusedAccDpp;
-#else
-using FusedAcc = FusedAccLds;
-#endif
-
-// The planar block's stores.  GROOVE_NT_STORES (A/B): marked non-temporal — 2 GB per million-voice block that nothing reads
-// back before it has long left every cache.
-__device__ __forceinline__ void block_store(float* __restrict__ p, float x) {
-#ifdef GROOVE_NT_STORES
-  __builtin_nontemporal_store(x, p);
-#else
-  *p = x;
-#endif
-}
+// The planar block's stores.  (Non-temporal stores and whole 1 KB rows out of the bus tile were both measured in round 3 and
+// lost to this plain form: docs/HISTORY.md.)
+__device__ __forceinline__ void block_store(float* __restrict__ p, float x) { *p = x; }
 // Shared frame loop of the instrument kernels: `frame(f, L, R)` computes one frame of this
 // lane's voice; the epilogue either stores the planar block or feeds the fused bus sum.
 // FUSED: only the rows of the fused bus sum (partial[workgroup][ch][frame]) are produced.  Otherwise the planar block is
@@ -286,57 +223,82 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
 }
 // Frame 0 by `first` (checked form); then boundary-free SEGMENTS (dsp_core.h): `begin(live)` handles the
 // envelope boundaries due now and returns the frames this lane can run unchecked, the wave takes the
-// minimum, and `live_frame` / `idle_frame` run that many frames without boundary or idle tests.
-// HOISTED: `begin` also prepares the segment (float stage counters), live frames leave the envelope counters
+// minimum over its ACTIVE lanes, and `live_frame` runs that many frames without boundary or idle tests.
+// `begin` also prepares the segment (float stage counters), live frames leave the envelope counters
 // alone, and `end(seg, live)` moves them once per segment (welsh_segment_end_hoisted); lanes that are not `active`
 // are never live, so their L and R stay zero without a select per frame.
-// `row_base` != ~0u (block-writing form): the workgroup's 256 lanes are one run of voices starting there and the block is stored by
-// whole 1 KB rows when the bus tile is turned (FusedAccLds::flush) instead of frame by frame.
-template <bool FUSED, bool HOISTED, class FirstFn, class BeginFn, class LiveFn, class IdleFn, class EndFn>
+//
+// Why ACTIVE lanes only (the stall of rounds 2-3).  A lane that is not active carries a SHADOW of some
+// voice's state record so that its loads have an address: in a partly filled wave its own wave's first voice, in a PADDING
+// wave (count 0: welsh_upload_params fills every kind's last workgroup up to four waves) the first voice of the kind's first
+// wave — a voice that another workgroup of the SAME launch owns, and stores at the end of its block while this workgroup, in a
+// later round of the grid, may be loading it.  The shadow can therefore be a torn record: after a note-on an instant-attack
+// voice holds (ATTACK, n 0, N 0), one block later (SUSTAIN, n, N 2^32-1), and the mixture (SUSTAIN, N 0) is a plateau that is
+// "at its boundary" on every frame: frames-to-boundary 0, for ever.  With the shadow lanes in the minimum that was a segment
+// of zero frames — the endless loop of rounds 2 and 3 (one workgroup per ~10^5, never a wrong sample: shadows are never
+// stored or summed).  Shadow lanes now contribute 2^32-1.  `on_zero(f, mine, wmin)` is called (wave-uniformly) if the minimum
+// is 0 all the same — it counts (diag.h) — and the segment is then one frame, which is what the checked form would do.
+template <bool FUSED, class FirstFn, class BeginFn, class LiveFn, class EndFn, class ZeroFn>
 __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n, uint32_t v, bool active, size_t ch_stride,
                                                      float* __restrict__ out, float* __restrict__ rows, uint32_t prow, FirstFn&& first, BeginFn&& begin,
-                                                     LiveFn&& live_frame, IdleFn&& idle_frame, EndFn&& end, uint32_t row_base = ~0u) {
+                                                     LiveFn&& live_frame, EndFn&& end, ZeroFn&& on_zero) {
   if (frames == 0) return;
   constexpr uint32_t C = FusedAcc::kChunk;
   static_assert(C > 1, "frame 0 never completes a chunk");
   FusedAcc acc(prow);
-  const bool by_rows = !FUSED && FusedAcc::kStoresRows && row_base != ~0u;
-  float* __restrict__ row_out = by_rows ? out : nullptr;
-  auto put = [&](uint32_t f, float L, float R, bool masked) {
-    if (masked) acc.add(active ? L : 0.0f, active ? R : 0.0f, f);
-    else acc.add(L, R, f);
-    if ((f & (C - 1)) == C - 1) acc.flush(rows, frames, f - (C - 1), C, row_out, ch_stride, n, row_base);
-    if (!FUSED && !by_rows && active) {
-#if defined(GROOVE_STORE_PROBE) /* timing probes only (results are wrong): 1 = every frame into the block's first 8 rows (the stores stay in cache), 2 = left channel only */
-      const uint32_t fp = GROOVE_STORE_PROBE == 1 ? (f & 7u) : f;
-      block_store(out + (size_t)fp * n + v, L);
-      if (GROOVE_STORE_PROBE != 2) block_store(out + ch_stride + (size_t)fp * n + v, R);
-#else
+  auto put = [&](uint32_t f, float L, float R) {
+    acc.add(L, R, f);
+    if ((f & (C - 1)) == C - 1) acc.flush(rows, frames, f - (C - 1), C);
+    if (!FUSED && active) {
       block_store(out + (size_t)f * n + v, L);
       block_store(out + ch_stride + (size_t)f * n + v, R);
-#endif
     }
   };
   {
     float L, R;
     first(L, R);
-    put(0, L, R, true);
+    put(0, active ? L : 0.0f, active ? R : 0.0f);
   }
   uint32_t f = 1;
   while (f < frames) {
     bool live;
     const uint32_t mine = begin(live);
-    if (HOISTED) live = live && active;
-    // (at least one frame: `begin` promises >= 1, and a segment of zero frames would spin here for ever — DESIGN.md section 7)
-    const uint32_t seg = max(1u, min(wave_min_u32(mine), frames - f));
+    live = live && active;
+#ifdef GROOVE_DIAG_SHADOW_IN_MIN /* diag.h: round 3's minimum, shadows included */
+    const uint32_t wmin = wave_min_u32(mine);
+#else
+    const uint32_t wmin = wave_min_u32(active ? mine : 0xFFFFFFFFu);
+#endif
+    if (wmin == 0) on_zero(f, mine);
+    const uint32_t seg = max(1u, min(wmin, frames - f));
     for (uint32_t k = 0; k < seg; ++k, ++f) {
       float L = 0.0f, R = 0.0f;
-      if (live) live_frame(L, R); else if (!HOISTED) idle_frame();
-      put(f, L, R, !HOISTED);
+      if (live) live_frame(L, R);
+      put(f, L, R);
     }
-    if (HOISTED) end(seg, live);
+    end(seg, live);
   }
-  if (frames & (C - 1)) acc.flush(rows, frames, frames & ~(C - 1), frames & (C - 1), row_out, ch_stride, n, row_base);
+  if (frames & (C - 1)) acc.flush(rows, frames, frames & ~(C - 1), frames & (C - 1));
+}
+// Where a wave is, for the diagnostics of diag.h.
+struct DiagWhere { uint32_t* diag; uint32_t wg, wave, count; };
+// run_frames_segmented's `on_zero` for a Welsh wave: the guard's counter; in the GROOVE_DIAG_SHADOW_IN_MIN build also who it was.
+__device__ __forceinline__ void welsh_diag_zero(const DiagWhere& dw, const WelshState& s, bool active, uint32_t f, uint32_t mine) {
+  if (!dw.diag) return;
+#ifdef GROOVE_DIAG_SHADOW_IN_MIN
+  DiagCounters* dc = reinterpret_cast<DiagCounters*>(dw.diag);
+  const bool active_zero = __any(active && mine == 0);
+  if ((threadIdx.x & 63u) == 0) atomicAdd(active_zero ? &dc->zero_segments : &dc->shadow_zero_waves, 1u);
+  if (mine == 0) {
+    atomicAdd(&dc->shadow_zero_lanes, 1u);
+    const uint32_t slot = atomicAdd(&dc->records, 1u);
+    if (slot < kDiagRecords)
+      dc->rec[slot] = DiagRecord{dw.wg, dw.wave, threadIdx.x & 63u, active ? 1u : 0u, dw.count, f, s.amp.state, s.amp.n, s.amp.N, s.fil.state, s.fil.n, s.fil.N};
+  }
+#else
+  (void)s; (void)active; (void)f; (void)mine;
+  if ((threadIdx.x & 63u) == 0) diag_count_zero_segment(dw.diag);
+#endif
 }
 
 // ------------------------------------------------------------------ instruments
@@ -346,24 +308,19 @@ __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n
 template <bool FUSED, bool RETUNE, int LFO_MODE = LFO_F64, bool UNIFORM = false, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool REST = false>
 __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s, const RenderConsts& rc,
                                             uint32_t frames, uint32_t n, uint32_t v, bool active,
-                                            size_t ch_stride, float* __restrict__ out, float* __restrict__ rows, uint32_t prow, uint32_t row_base = ~0u) {
+                                            size_t ch_stride, float* __restrict__ out, float* __restrict__ rows, uint32_t prow, const DiagWhere& dw = DiagWhere{nullptr, 0, 0, 0}) {
   WelshScratch sc = welsh_scratch_init(p, rc);
   // Static cutoff + wave-uniform patch: the six f64 coefficients are the same in every lane and
   // never change, so they ride in SGPRs (12 VGPRs back; f64 FMAs take one scalar operand).
   if (UNIFORM && !RETUNE) sc.coef = make_scalar(sc.coef);
   if constexpr (UNIFORM) {
-#ifdef GROOVE_SEG_PLAIN /* A/B: counters and selects on every frame */
-    constexpr bool HOIST = false;
-#else
-    constexpr bool HOIST = true;
-#endif
-    run_frames_segmented<FUSED, HOIST>(
+    run_frames_segmented<FUSED>(
         frames, n, v, active, ch_stride, out, rows, prow,
         [&](float& L, float& R) { welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL, false, REST>(p, s, rc, sc, L, R); },
-        [&](bool& live) { const uint32_t k = welsh_segment_begin(p, s, live); if (HOIST) welsh_segment_start_hoisted(s, sc); return k; },
-        [&](float& L, float& R) { welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, HOIST>(p, s, rc, sc, L, R); },
-        [&]() { welsh_segment_idle_frame(s); },
-        [&](uint32_t seg, bool live) { welsh_segment_end_hoisted<CL == LFO_UNUSED>(p, s, seg, live); }, row_base);
+        [&](bool& live) { const uint32_t k = welsh_segment_begin(p, s, live); welsh_segment_start_hoisted(s, sc); return k; },
+        [&](float& L, float& R) { welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true>(p, s, rc, sc, L, R); },
+        [&](uint32_t seg, bool live) { welsh_segment_end_hoisted<CL == LFO_UNUSED>(p, s, seg, live); },
+        [&](uint32_t f, uint32_t mine) { welsh_diag_zero(dw, s, active, f, mine); });
   } else {
     run_frames<FUSED>(frames, n, v, active, ch_stride, out, rows, prow, [&](uint32_t f, float& L, float& R) {
       if (f == 0) welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL>(p, s, rc, sc, L, R);
@@ -440,6 +397,8 @@ struct UniformArgs {
   const WaveDesc* waves; uint32_t* state; float* out; float* rows; const uint32_t* wg_list; const uint8_t* wg_cls;
   size_t ch_stride; RenderConsts rc; uint32_t n_waves, n, frames, n_wgs; // out: the planar block (block-writing form); rows: partial[workgroup][ch][frame] (both forms)
   TpPrev prev; // groove_bank_render_mix_deferred: the previous block's rows, to be put on their bus by this launch (the all-kinds and role-split kernels)
+  uint32_t* diag = nullptr; // the context's DiagCounters (diag.h)
+  unsigned long long* heartbeat = nullptr; // -DGROOVE_HEARTBEAT builds only (diag.h)
 };
 typedef const __attribute__((address_space(4))) UniformArgs* UniformArgsPtr; // kernarg segment: scalar loads
 __device__ __forceinline__ UniformArgsPtr uniform_args_scalar(UniformArgsPtr a) { // arguments of a call travel in VGPRs
@@ -463,24 +422,7 @@ __device__ __forceinline__ void welsh_uniform_body_impl(UniformArgsPtr a) {
   // pinned in VGPRs for the block: as literals / SGPRs each costs a v_mov on every retuning frame (the instructions
   // that use them take one constant-bus operand): +2.5 % in the all-voices window of the million-voice project
   if constexpr (RETUNE) asm volatile("" : "+v"(rc.tan_k1), "+v"(rc.tan_k2), "+v"(rc.log2_x0), "+v"(rc.x_hi));
-  // block-writing form (A/B option): a workgroup whose four virtual waves are full and follow each other (the usual case in a
-  // bank laid out synth by synth) can store the block by whole 1 KB rows when the bus tile is turned (run_frames_segmented)
-  // instead of 256 bytes per wavefront per frame.  The idea was DRAM row locality for the 2 GB of stores; the measurement says
-  // the 256-byte pieces are no worse, so the simpler form stays.
-  uint32_t row_base = ~0u;
-#ifdef GROOVE_ROW_STORES /* A/B, measured in round 3 and NOT kept: 1,000,000 voices materialised 0.823 / 0.834 / 0.829 ms per block with whole-row stores against 0.816 / 0.787 / 0.810 frame by frame (in-job); 300,000 voices 0.305 / 0.309 against 0.314 / 0.304 */
-  if constexpr (!FUSED) {
-    const uint32_t w4 = wg * kWaves;
-    if (w4 + kWaves <= n_waves && (n & 3u) == 0 && (a->ch_stride & 3u) == 0) {
-      const uint32_t vb0 = a->waves[w4].vbase;
-      bool one_run = (vb0 & 3u) == 0;
-#pragma unroll
-      for (uint32_t k = 0; k < (uint32_t)kWaves; ++k) one_run = one_run && a->waves[w4 + k].count == 64u && a->waves[w4 + k].vbase == vb0 + 64u * k;
-      if (one_run) row_base = vb0;
-    }
-  }
-#endif
-  welsh_block<FUSED, RETUNE, LFO_MODE, true, C1, C2, CL, REST>(d.p, s, rc, a->frames, n, v, active, a->ch_stride, a->out, a->rows, wg, row_base);
+  welsh_block<FUSED, RETUNE, LFO_MODE, true, C1, C2, CL, REST>(d.p, s, rc, a->frames, n, v, active, a->ch_stride, a->out, a->rows, wg, DiagWhere{a->diag, wg, w, d.count});
   if (active) soa_store(a->state, n, v, s);
 }
 // Internal linkage + no `tail` marker on the kernels' calls: the compiler's inter-procedural register allocation then
@@ -489,13 +431,8 @@ __device__ __forceinline__ void welsh_uniform_body_impl(UniformArgsPtr a) {
 // nothing alive across the call — pays nothing either.  As linkonce_odr functions every body spilled 24-38 VGPRs to
 // scratch in its prologue and read them back at its end: 84-172 bytes of scratch per lane, ~0.2-0.3 GB per
 // million-voice block of HBM traffic that served nothing (round 2's PMC passes).
-#ifdef GROOVE_BODIES_EXTERN /* A/B: the round-2 form */
-#define GROOVE_NO_TAIL_CALLS
-#define GROOVE_BODY_LINKAGE
-#else
 #define GROOVE_NO_TAIL_CALLS __attribute__((disable_tail_calls))
 #define GROOVE_BODY_LINKAGE static
-#endif
 template <bool FUSED, int LFO_MODE, bool RETUNE, int C1, int C2, int CL>
 GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_uniform_body(UniformArgsPtr a) {
   // the class bodies of the class-specialised kinds only ever see waves of their own classes (dsp_core.h, REST)
@@ -556,8 +493,8 @@ __global__ __launch_bounds__(kThreads, (WavesBudget<LFO_MODE, RETUNE>::value)) G
   // joined; with the blocks pipelined the longest kernel is the most numerous kind, and any priority
   // costs 5 % — measured: none 0.460 ms, f64-LFO kinds raised 0.484, F32-retune raised 0.513.)
   const UniformArgsPtr ka = (UniformArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(); // == &a, in the constant address space
-#ifdef GROOVE_HEARTBEAT /* diagnostic build: workgroups started / finished, counted in host memory the host can read while the device is stuck; the pointer rides in the (here unused) prev.bus */
-  unsigned long long* hb = reinterpret_cast<unsigned long long*>(a.prev.bus);
+#ifdef GROOVE_HEARTBEAT /* diag.h: workgroups started / finished, counted in host memory the host can read while the device is stuck */
+  unsigned long long* hb = a.heartbeat;
   if (hb && threadIdx.x == 0) __hip_atomic_fetch_add(hb + 0, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #define GROOVE_HB_DONE do { __syncthreads(); if (hb && threadIdx.x == 0) __hip_atomic_fetch_add(hb + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
 #else

@@ -30,8 +30,8 @@ constexpr int kSplitVw = kWaves;                       // virtual waves per work
 constexpr int kSplitLanes = kSplitVw * 64;             // 256 voices
 constexpr int kSplitThreads = 3 * kSplitLanes;         // roles A, B, C
 constexpr uint32_t kSplitChunk = 4;                    // frames per pipeline step (measured: 8 — half the barriers — is 30 % slower)
-constexpr uint32_t kSplitGroup = 8;                    // frames per turn of the bus tile (FusedAccLds::kChunk)
-static_assert(kSplitGroup % kSplitChunk == 0 && kSplitGroup == FusedAccLds::kChunk, "the bus tile is turned every second step");
+constexpr uint32_t kSplitGroup = 8;                    // frames per turn of the bus tile (FusedAcc::kChunk)
+static_assert(kSplitGroup % kSplitChunk == 0 && kSplitGroup == FusedAcc::kChunk, "the bus tile is turned every second step");
 
 struct SplitLds {
   float2 ac[3][kSplitChunk][kSplitLanes];  // A -> C: {sum (NaN: the lane is silent this frame), gain}; three steps deep
@@ -67,6 +67,17 @@ __device__ __forceinline__ SplitWave split_wave(UniformArgsPtr a, uint32_t local
   w.active = (w0 < a->n_waves) && (lane < w.d.count);
   w.v = w.active ? w.d.vbase + lane : w.d.vbase; // idle lanes shadow the run's first voice
   return w;
+}
+// Length of a new boundary-free segment at frame f: the wave minimum over the ACTIVE lanes (shadow lanes may hold a torn
+// record — kernels.h run_frames_segmented), at least one frame, counted if the minimum is 0 all the same (diag.h).
+__device__ __forceinline__ uint32_t split_segment(UniformArgsPtr a, const SplitWave& w, const WelshState& s, uint32_t mine, uint32_t f, uint32_t frames) {
+#ifdef GROOVE_DIAG_SHADOW_IN_MIN
+  const uint32_t wmin = wave_min_u32(mine);
+#else
+  const uint32_t wmin = wave_min_u32(w.active ? mine : 0xFFFFFFFFu);
+#endif
+  if (wmin == 0) welsh_diag_zero(DiagWhere{a->diag, w.wg, w.wg * kSplitVw + (w.l >> 6), w.d.count}, s, w.active, f, mine);
+  return max(1u, min(wmin, frames - f));
 }
 __device__ __forceinline__ SplitLds& split_lds() {
   __shared__ SplitLds lds;
@@ -128,7 +139,7 @@ __device__ __forceinline__ void welsh_split_front_impl(UniformArgsPtr a) {
               const uint32_t mine = welsh_segment_begin(p, s, live);
               welsh_segment_start_hoisted(s, sc);
               live = live && w.active;
-              seg_len = seg_left = max(1u, min(wave_min_u32(mine), frames - f)); // (at least one frame: kernels.h run_frames_segmented)
+              seg_len = seg_left = split_segment(a, w, s, mine, f, frames);
             }
             ok = live;
             if (live) welsh_frame_front<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true>(p, s, sc, sum, g, pct, retune, lfo);
@@ -158,12 +169,12 @@ GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split_front(
   welsh_split_front_impl<ROLES, LFO_MODE, RETUNE, C1, C2, CL>(uniform_args_scalar(a));
 }
 
-// ---- role B: the tangent of the cutoff, one step behind A; and the bus tile's turn (FusedAccLds::flush, on the
+// ---- role B: the tangent of the cutoff, one step behind A; and the bus tile's turn (FusedAcc::flush, on the
 // group of eight frames role C finished in the previous step)
 template <class Lds>
 __device__ __forceinline__ void split_turn_tile(const Lds& lds, uint32_t l, uint32_t f_end, float* __restrict__ rows, uint32_t wg, uint32_t frames) {
   const uint32_t f_lo = (f_end - 1) / kSplitGroup * kSplitGroup, count = f_end - f_lo, g = (f_lo / kSplitGroup) & 1u;
-  const uint32_t row = l >> 5, col = l & 31u; // 32 lanes per frame row, as FusedAccLds::flush
+  const uint32_t row = l >> 5, col = l & 31u; // 32 lanes per frame row, as FusedAcc::flush
   const float2* __restrict__ src = &lds.tile[g][0][0] + row * kSplitLanes + col;
   float sl = 0.0f, sr = 0.0f;
 #pragma unroll
@@ -360,7 +371,7 @@ GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split4_ctl(U
             const uint32_t mine = welsh_segment_begin(p, s, live);
             welsh_segment_start_hoisted(s, sc);
             live = live && w.active;
-            seg_len = seg_left = max(1u, min(wave_min_u32(mine), frames - f)); // (at least one frame: kernels.h run_frames_segmented)
+            seg_len = seg_left = split_segment(a, w, s, mine, f, frames);
           }
           ok = live;
           if (live) welsh_frame_ctl<false, RETUNE, LFO_MODE, CL, true, true>(p, s, sc, g, pct, retune, mod, first);

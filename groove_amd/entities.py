@@ -54,7 +54,7 @@ class Context:
 
     def debug_info(self):
         import json
-        buf = C.create_string_buffer(1024)
+        buf = C.create_string_buffer(8192)
         _lib.check(self.L.groove_debug_info(self.h, buf, len(buf)), self.h)
         return json.loads(buf.value.decode())
 

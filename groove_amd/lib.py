@@ -10,7 +10,9 @@ import os
 from . import abi_types as T
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgroove_hip.so")
+# GROOVE_LIB_PATH: another BUILD of the same library (tools/ab_bench.sh variants, the diagnostic builds of csrc/diag.h) —
+# same ABI, same loader; there is still no other implementation to fall back to.
+LIB_PATH = os.environ.get("GROOVE_LIB_PATH") or os.path.join(HERE, "libgroove_hip.so")
 
 # Every symbol include/groove_hip.h declares: name → (restype, argtypes).
 _vp, _u32, _i, _d = C.c_void_p, C.c_uint32, C.c_int, C.c_double

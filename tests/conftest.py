@@ -12,16 +12,6 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def pytest_collection_finish(session):
-    """GPU tier only: on this pool a process now and then crawls on the multi-stream million-voice path, mostly a box's
-    first GPU process (groove_amd/canary.py); a child process takes that position before the first
-    test touches the GPU."""
-    if any(item.get_closest_marker("gpu") for item in session.items):
-        from groove_amd import canary
-        outcome = canary.run()
-        print(f"\n[groove] first-process canary: {outcome}")
-
-
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as O
@@ -34,7 +24,12 @@ def gpu_ctx():
     from groove_amd import entities as E
     ctx = E.Context(0)  # raises loudly if libgroove_hip.so or the GPU is missing
     yield ctx
+    # the segment guard of the Welsh kernels is a COUNTED assertion (csrc/diag.h): no kernel of the whole session may have
+    # seen a wave whose active lanes reported zero frames to their next envelope boundary
+    ctx.synchronize()
+    zeros = ctx.debug_info()["zero_segments"]
     ctx.close()
+    assert zeros == 0, f"{zeros} zero-frame segments counted during the GPU session (DESIGN.md section 7)"
 
 
 @pytest.fixture()

@@ -12,6 +12,7 @@ using namespace groove;
 
 struct EmulBank {
   int kind; uint32_t n; double sr; int generic_lfo = 0; int segmented = 1; int time_parallel = 0; int role_split = 0;
+  uint32_t min_seg = 0xFFFFFFFFu; // the smallest value welsh_segment_begin has returned for any voice of this bank (must stay >= 1)
   std::vector<WelshParams> wp; std::vector<WelshState> ws; std::vector<WelshCold> wc;
   std::vector<FmParams> fp; std::vector<FmState> fs; std::vector<double> ratio;
   std::vector<SamplerParams> sp; std::vector<SamplerState> ss; std::vector<float> pcm;
@@ -291,6 +292,8 @@ void emul_bank_render(void* h, uint32_t frames, float* out) {
         else {
           if (seg_left == 0) {
             seg_left = welsh_segment_begin(b->wp[v], b->ws[v], seg_live);
+            if (seg_left < b->min_seg) b->min_seg = seg_left;
+            if (seg_left == 0) seg_left = 1; // the kernels' guard (kernels.h run_frames_segmented): never taken by a consistent record
             welsh_segment_start_hoisted(b->ws[v], sc);
             if (seg_left > frames - f) seg_left = frames - f;
             seg_len = seg_left;
@@ -303,6 +306,8 @@ void emul_bank_render(void* h, uint32_t frames, float* out) {
       if (b->kind == 0 && b->segmented && f > 0) { // mirrors run_frames_segmented<HOISTED> with a one-lane wave
         if (seg_left == 0) {
           seg_left = welsh_segment_begin(b->wp[v], b->ws[v], seg_live);
+          if (seg_left < b->min_seg) b->min_seg = seg_left;
+          if (seg_left == 0) seg_left = 1; // the kernels' guard
           if (seg_left > frames - f) seg_left = frames - f;
           seg_len = seg_left;
           welsh_segment_start_hoisted(b->ws[v], sc);
@@ -322,6 +327,18 @@ void emul_bank_render(void* h, uint32_t frames, float* out) {
       out[((size_t)frames + f) * n + v] = R;
     }
   }
+}
+uint32_t emul_bank_min_segment(void* h) { return ((EmulBank*)h)->min_seg; }
+// welsh_segment_begin on a voice whose two envelope records are given word by word (state, n, N): what a lane that loaded
+// such a record — consistent, or TORN between two stores — contributes to its wave's minimum.
+uint32_t emul_segment_begin_of(const groove_welsh_params* p, uint32_t sr, const uint32_t amp[3], const uint32_t fil[3]) {
+  WelshCold cold;
+  const WelshParams wp = derive_welsh(*p, (double)sr, cold);
+  WelshState s = initial_welsh_state();
+  s.amp.state = amp[0]; s.amp.n = amp[1]; s.amp.N = amp[2];
+  s.fil.state = fil[0]; s.fil.n = fil[1]; s.fil.N = fil[2];
+  bool live;
+  return welsh_segment_begin(wp, s, live);
 }
 float emul_bitcrush(float x, uint32_t bits) { return bitcrush(x, bits); }
 // both forms of the 24 dB coefficient computation (dsp_core.h): out[0..5] two-step, out[6..11] fused

@@ -38,10 +38,20 @@ def lib():
         L.emul_set_role_split.argtypes = [vp, C.c_int]
         L.emul_bank_note_events.argtypes = [vp, C.POINTER(T.NoteEvent), u32]
         L.emul_bank_render.argtypes = [vp, u32, _fp]
+        L.emul_bank_min_segment.restype = u32; L.emul_bank_min_segment.argtypes = [vp]
+        L.emul_segment_begin_of.restype = u32
+        L.emul_segment_begin_of.argtypes = [C.POINTER(T.WelshParams), u32, C.POINTER(u32), C.POINTER(u32)]
         L.emul_bitcrush.restype = C.c_float; L.emul_bitcrush.argtypes = [C.c_float, u32]
         L.emul_lp24_coef_both.argtypes = [C.c_double, C.c_float, C.c_float, C.POINTER(C.c_double)]
         _LIB = L
     return _LIB
+
+
+def segment_begin_of(params, amp, fil, sr=T.DEFAULT_SAMPLE_RATE):
+    """welsh_segment_begin for a voice of patch `params` whose envelope records are (state, n, N) = amp / fil."""
+    a = (C.c_uint32 * 3)(*amp)
+    f = (C.c_uint32 * 3)(*fil)
+    return lib().emul_segment_begin_of(C.byref(params), sr, a, f)
 
 
 class Bank:
@@ -79,6 +89,11 @@ class Bank:
     def set_generic_lfo(self, on):
         """True: exact per-frame f64 LFO (per-lane kernel); False: block-seeded recurrences where promised."""
         lib().emul_set_generic_lfo(self.h, 1 if on else 0)
+
+    @property
+    def min_segment(self):
+        """Smallest frames-to-next-boundary any voice has reported at a segment start so far (the kernels rely on >= 1)."""
+        return lib().emul_bank_min_segment(self.h)
 
     def render(self, frames):
         out = np.zeros((2, frames, self.n), dtype=np.float32)

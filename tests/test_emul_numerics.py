@@ -198,3 +198,41 @@ def test_time_parallel_form_matches_serial_and_oracle(oracle):
     assert sig > 0.1
     assert worst_ser <= 2e-6, worst_ser     # same fp32 feed-forward values; the filter differs by f64 rounding only
     assert worst_orc <= 1e-5, worst_orc
+
+
+# ---- the segment promise (kernels.h run_frames_segmented)
+ENV_IDLE, ENV_ATTACK, ENV_DECAY, ENV_SUSTAIN, ENV_RELEASE = range(5)
+PLATEAU_N = 0xFFFFFFFF
+
+
+def test_segment_begin_promises_a_frame_for_every_consistent_record():
+    """welsh_segment_begin >= 1 for every record the kernels themselves can produce: all 32 patches (instant attacks,
+    zero-length decays, sustain 1.0, sustain 0.0 among them) through note-on, ragged blocks, a re-trigger in the
+    attack, the decay and the release, note-off, and the idle tail."""
+    n = 32
+    params = P.welsh_voices(n)
+    on, off = P.note_on_all(n), P.note_off_all(n)
+    for sizes, plan in (((256,) * 12, {0: on, 4: off, 6: on, 9: off}),
+                        ((1, 2, 255, 7, 256, 64, 33, 256, 256, 5), {0: on, 1: on, 2: off, 3: on, 6: off}),
+                        ((221, 1, 34, 256, 256), {0: on, 2: off, 3: on})):
+        bank = E.Bank.welsh(params)
+        for b, frames in enumerate(sizes):
+            if b in plan:
+                bank.note_events(plan[b])
+            bank.render(frames)
+        assert 1 <= bank.min_segment < PLATEAU_N, bank.min_segment
+
+
+def test_a_torn_record_is_the_only_way_to_a_zero_frame_segment():
+    """The stall of rounds 2-3, restated on the CPU.  Patch 5's filter envelope has an instant attack and no decay
+    (sustain 1.0): the note-on leaves (ATTACK, n 0, N 0) in memory, the first block's store (SUSTAIN, n, N 2^32-1).
+    A SHADOW lane that loads the record while its owner stores it can see the new state word with the old N — a
+    plateau that is at its boundary on every frame: 0 frames to go.  Every consistent record gives >= 1."""
+    p = P.welsh_patch(5)
+    sus = (ENV_SUSTAIN, 255, PLATEAU_N)
+    assert E.segment_begin_of(p, amp=(ENV_ATTACK, 0, 1), fil=(ENV_ATTACK, 0, 0)) >= 1           # after the note-on
+    assert E.segment_begin_of(p, amp=sus, fil=sus) >= 1                                          # after block 0
+    assert E.segment_begin_of(p, amp=sus, fil=(ENV_SUSTAIN, 0, 0)) == 0                          # torn: new state, old n and N
+    assert E.segment_begin_of(p, amp=sus, fil=(ENV_SUSTAIN, 255, 0)) == 0                        # torn: new state and n, old N
+    assert E.segment_begin_of(p, amp=sus, fil=(ENV_ATTACK, 255, PLATEAU_N)) >= 1                 # torn the other way: harmless
+    assert E.segment_begin_of(p, amp=sus, fil=(ENV_IDLE, 0, 0)) == 0                             # reset's state word, the note-on's N

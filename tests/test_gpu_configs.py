@@ -162,3 +162,31 @@ def test_config4_sampler_16384_full_size(gpu_ctx, oracle):
             checked += 1
     assert checked > 50
     s.destroy(); block.destroy()
+
+
+def test_bench_n_gpu_code_path_on_one_gpu():
+    """GROOVE_BENCH_FORCE_DIST=1: the whole N > 1 path of bench.py — gloo rendezvous, the library's RCCL communicator, the bus
+    reduce inside the timed region — with ONE rank on this box's one GPU, so that it cannot rot between the rounds in which a
+    multi-GPU node is available.  The line carries the three sections of one run (strong, weak, config #5), each with the
+    communicator's size, the ranks' clocks and the reduce timed alone."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GROOVE_BENCH_FORCE_DIST="1", MASTER_PORT="29541")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "4", "--warmup", "1", "--repeats", "1", "--voices", "200000",
+                        "--no-configs", "--no-shard-curve", "--no-cpu-baseline", "--no-parity", "--no-watchdog"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["rccl_ranks"] == 1 and line["n_gpus"] == 1 and line["zero_segments"] == 0 and "tainted" not in line
+    assert line["config"]["bus_reduce"].startswith("groove_bus_reduce")
+    sec = line["sections"]
+    assert sorted(sec) == ["mixed-131072", "strong", "weak"]
+    for name, s in sec.items():
+        assert s["rccl_ranks"] == 1 and s["bus_reduce_alone_ms"] > 0.0 and s["value"] > 0.0, (name, s)
+        assert s["ms_per_step_by_rank"]["max"] >= s["ms_per_step_by_rank"]["min"] > 0.0
+    assert sec["strong"]["voices_total"] == sec["weak"]["voices_total"] == 200000 and sec["mixed-131072"]["voices_per_gpu"] == 131072

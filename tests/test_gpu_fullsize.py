@@ -138,3 +138,49 @@ def test_repeated_renders_are_bit_identical(gpu_ctx):
             runs.append(bus.download())
             synth.destroy(); bus.destroy()
         assert np.array_equal(runs[0].view(np.uint32), runs[1].view(np.uint32)), n
+
+
+def test_million_voice_restarts_are_bit_identical_to_the_safe_stream_layout(gpu_ctx):
+    """The window in which rounds 2-3 stalled: reset, note-on for every voice, the first blocks of
+    1,000,000 voices through the per-kind pipelined kernels.  Three such restarts in the default stream layout, three in
+    a second context with the safe layout (one priority, four streams): all six buses are the same bits, and neither
+    context has counted a zero-frame segment (csrc/diag.h)."""
+    import os
+    from groove_amd import entities as E
+    params, vidx = P.welsh_voices_grouped(V)
+    on = P.grouped_note_events(vidx, True)
+    frames, blocks = 256, 8
+
+    def restarts(ctx):
+        synth = E.WelshSynth(ctx, params)
+        assert "blocks pipelined" in synth.kernel_form(frames, True)
+        bus = ctx.bus(blocks * frames)
+        out = []
+        for _ in range(3):
+            synth.reset()
+            synth.handle_midi_events(on)
+            for b in range(blocks):
+                synth.render_mix(bus, frames, at_frame=b * frames)
+            out.append(bus.download().view(np.uint32).copy())
+        ctx.synchronize()
+        zeros = ctx.debug_info()["zero_segments"]
+        synth.destroy(); bus.destroy()
+        return out, zeros
+
+    a, za = restarts(gpu_ctx)
+    old = os.environ.get("GROOVE_SAFE_STREAMS")
+    os.environ["GROOVE_SAFE_STREAMS"] = "1"  # read by groove_init
+    try:
+        safe = E.Context(0)
+    finally:
+        if old is None:
+            del os.environ["GROOVE_SAFE_STREAMS"]
+        else:
+            os.environ["GROOVE_SAFE_STREAMS"] = old
+    assert safe.debug_info()["layout"].startswith("safe")
+    b, zb = restarts(safe)
+    safe.close()
+    assert za == 0 and zb == 0, (za, zb)
+    assert np.abs(a[0].view(np.float32)).max() > 1.0
+    for k, run in enumerate(a + b):
+        assert np.array_equal(run, a[0]), f"restart {k} differs"

@@ -1,0 +1,315 @@
+"""CPU tier: the oracle against INDEPENDENT implementations of the published algorithms it claims.
+
+Most rows of SURVEY.md section 8(a) are "parity unpinned": the reference holds no vector for them, so `oracle/` is a
+restatement of a recollection and the golden file is its own output.  Nothing can turn that green.
+What CAN be done is to make the restatement harder to doubt: every test here computes the same thing a second time by a
+differently written route — scipy.signal's filter design and `lfilter`, closed forms in extended precision, exact integer
+arithmetic — and asks the oracle to agree to f64 rounding.  A typo in one of the oracle's recurrences, a swapped
+coefficient, an off-by-one delay length or a wrong constant fails here; a wrong RECOLLECTION of what Groove does cannot.
+
+  a1  Oscillator        closed-form phase n f / SR in extended precision + waveform formulas; musicdsp noise in Python ints
+  a2  Envelope          closed-form quadratic stages from the stage boundaries
+  a3  BiQuad 12 dB      the cookbook's ANALOG prototypes through scipy.signal.bilinear (pre-warped), then lfilter
+  a4  24 dB low-pass    scipy.signal.cheby1 (4th order, type I): analog poles, and the digital filter up to its DC gain
+  a9  Bitcrusher        integer numpy
+  a10 Chorus, a11 Delay, a12 Reverb   sparse-coefficient lfilter (combs, all-passes, taps)
+  a13 Dca               the pan law at its anchor points
+"""
+import math
+
+import numpy as np
+import pytest
+from scipy import signal
+
+from groove_amd import abi_types as T
+
+SR = 44100.0
+TOL = 1e-12
+
+
+def _dp(a):
+    import ctypes as C
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _noise(n, seed=7):
+    return np.random.default_rng(seed).uniform(-1.0, 1.0, n)
+
+
+# ------------------------------------------------------------------------------------------ a3 BiQuad 12 dB
+def _analog_prototype(kind, f0, q, bw_hz, db_gain):
+    """(b, a) of the cookbook's s-domain prototype at unit cutoff (doc/Audio-EQ-Cookbook.txt: "H(s) = ..." of every mode),
+    with the 1/Q each mode's digital `alpha` corresponds to (alpha = sin(w0) / (2 Q))."""
+    w0 = 2.0 * math.pi * f0 / SR
+    A = 10.0 ** (db_gain / 40.0)
+    if kind in (T.FX_BIQUAD_BP12, T.FX_BIQUAD_BS12):
+        lo, hi = f0 - bw_hz / 2.0, f0 + bw_hz / 2.0
+        octaves = math.log2(hi / lo) if lo > 0.0 and hi / lo <= 256.0 else 8.0
+        inv_q = 2.0 * math.sinh(math.log(2.0) / 2.0 * octaves * w0 / math.sin(w0))  # the cookbook's digital-compensated BW
+    elif kind == T.FX_BIQUAD_PEAK12:
+        inv_q = math.sqrt(2.0)                                                          # Q = 1 / sqrt 2 (DSP_SPEC)
+    elif kind in (T.FX_BIQUAD_LSHELF12, T.FX_BIQUAD_HSHELF12):
+        inv_q = math.sqrt((A + 1.0 / A) * (1.0 / 1.0 - 1.0) + 2.0)                      # shelf slope S = 1
+    else:
+        inv_q = 1.0 / q
+    if kind == T.FX_BIQUAD_LP12:
+        return [1.0], [1.0, inv_q, 1.0]
+    if kind == T.FX_BIQUAD_HP12:
+        return [1.0, 0.0, 0.0], [1.0, inv_q, 1.0]
+    if kind == T.FX_BIQUAD_BP12:
+        return [inv_q, 0.0], [1.0, inv_q, 1.0]
+    if kind == T.FX_BIQUAD_BS12:
+        return [1.0, 0.0, 1.0], [1.0, inv_q, 1.0]
+    if kind == T.FX_BIQUAD_AP12:
+        return [1.0, -inv_q, 1.0], [1.0, inv_q, 1.0]
+    if kind == T.FX_BIQUAD_PEAK12:
+        return [1.0, A * inv_q, 1.0], [1.0, inv_q / A, 1.0]
+    sa = math.sqrt(A)
+    if kind == T.FX_BIQUAD_LSHELF12:
+        return [A, A * sa * inv_q, A * A], [A, sa * inv_q, 1.0]
+    return [A * A, A * sa * inv_q, A], [1.0, sa * inv_q, A]  # high shelf
+
+
+BIQUAD_KINDS = ["FX_BIQUAD_LP12", "FX_BIQUAD_HP12", "FX_BIQUAD_BP12", "FX_BIQUAD_BS12", "FX_BIQUAD_AP12", "FX_BIQUAD_PEAK12",
+                "FX_BIQUAD_LSHELF12", "FX_BIQUAD_HSHELF12"]
+
+
+@pytest.mark.parametrize("name", BIQUAD_KINDS)
+@pytest.mark.parametrize("f0,q,bw,db", [(1000.0, 0.707, 500.0, 6.0), (120.0, 4.0, 60.0, -9.0), (9000.0, 0.5, 4000.0, 3.0)])
+def test_rbj_modes_are_the_bilinear_transform_of_the_cookbooks_analog_prototypes(oracle, name, f0, q, bw, db):
+    kind = getattr(T, name)
+    b_s, a_s = _analog_prototype(kind, f0, q, bw, db)
+    # pre-warping: the prototype's unit frequency lands on w0 when s is scaled by tan(w0 / 2) and the transform is (z-1)/(z+1)
+    k = math.tan(math.pi * f0 / SR)
+    nb, na = len(b_s), len(a_s)
+    b_w = [c / k ** (nb - 1 - i) for i, c in enumerate(b_s)]
+    a_w = [c / k ** (na - 1 - i) for i, c in enumerate(a_s)]
+    bz, az = signal.bilinear(b_w, a_w, fs=0.5)
+    bz, az = bz / az[0], az / az[0]
+    p = T.fx_params(cutoff_hz=f0, q=q, bandwidth_hz=bw, db_gain=db)
+    got = np.zeros(5)
+    assert oracle.lib().oracle_rbj_for_kind(kind, p, SR, _dp(got)) == 1
+    # the parameters travel as fp32: rebuild the expectation from what the oracle saw
+    f0f, qf, bwf, dbf = (float(np.float32(v)) for v in (f0, q, bw, db))
+    b_s, a_s = _analog_prototype(kind, f0f, qf, bwf, dbf)
+    k = math.tan(math.pi * f0f / SR)
+    bz, az = signal.bilinear([c / k ** (len(b_s) - 1 - i) for i, c in enumerate(b_s)], [c / k ** (len(a_s) - 1 - i) for i, c in enumerate(a_s)], fs=0.5)
+    bz, az = bz / az[0], az / az[0]
+    want = np.array([bz[0], bz[1], bz[2], az[1], az[2]])
+    assert np.max(np.abs(got - want)) <= 1e-11 * max(1.0, np.max(np.abs(want))), (got, want)
+    # Direct Form 1 run == lfilter with the oracle's own coefficients
+    x = _noise(4096)
+    y = np.zeros_like(x)
+    oracle.lib().oracle_biquad_df1_run(_dp(got), _dp(x), _dp(y), len(x))
+    ref = signal.lfilter(got[:3], np.concatenate([[1.0], got[3:]]), x)
+    assert np.max(np.abs(y - ref)) <= 1e-10 * max(1.0, np.max(np.abs(ref)))
+
+
+# ------------------------------------------------------------------------------------------ a4 24 dB low-pass
+@pytest.mark.parametrize("ripple", [0.2, 0.707, 1.607, 2.2])  # (beyond ~3 the dB figure scipy takes, 10 log10(1 + eps^2), no longer resolves eps)
+def test_lp24_sections_are_a_fourth_order_chebyshev_type_one(oracle, ripple):
+    """The two s-plane sections the oracle transforms, 1 / (c s^2 + d s + 1) with the Appendix-A.4 constants, have exactly
+    the poles of scipy's analog 4th-order Chebyshev type I filter whose ripple parameter is `ripple`
+    (mu = asinh(1 / eps) / 4 = ripple)."""
+    eps = 1.0 / math.sinh(4.0 * ripple)
+    rp_db = 10.0 * math.log10(1.0 + eps * eps)
+    _, poles, _ = signal.cheby1(4, rp_db, 1.0, analog=True, output="zpk")
+    sg, cg = math.sinh(ripple), math.cosh(ripple) ** 2
+    mine = []
+    for sin2, two_sin in ((math.cos(math.pi / 8) ** 2, 2.0 * math.cos(math.pi / 8)), (math.sin(math.pi / 8) ** 2, 2.0 * math.sin(math.pi / 8))):
+        c = 1.0 / (cg - sin2)
+        mine.extend(np.roots([c, c * sg * two_sin, 1.0]))
+    key = lambda z: (round(z.real, 9), round(z.imag, 9))
+    assert np.allclose(sorted(mine, key=key), sorted(poles, key=key), rtol=1e-9, atol=1e-12)
+    # and the constants the oracle spells out are those trigonometric values
+    assert abs(math.cos(math.pi / 8) ** 2 - 0.85355339059327376220) < 1e-15 and abs(2 * math.cos(math.pi / 8) - 1.84775906502257351226) < 1e-15
+    assert abs(math.sin(math.pi / 8) ** 2 - 0.14644660940672623780) < 1e-15 and abs(2 * math.sin(math.pi / 8) - 0.76536686473017954346) < 1e-15
+
+
+@pytest.mark.parametrize("fc,ripple", [(1000.0, 0.707), (250.0, 1.607), (6000.0, 0.3), (40.0, 0.707)])
+def test_lp24_run_is_scipys_digital_chebyshev_up_to_its_dc_gain(oracle, fc, ripple):
+    """scipy.signal.cheby1(4, rp, fc, fs) — pre-warped bilinear transform, as the oracle — filters the same input to the
+    same output times sqrt(1 + eps^2): an even-order Chebyshev has DC gain 1 / sqrt(1 + eps^2), the oracle's sections are
+    each normalised to DC gain 1."""
+    eps = 1.0 / math.sinh(4.0 * ripple)
+    rp_db = 10.0 * math.log10(1.0 + eps * eps)
+    sos = signal.cheby1(4, rp_db, fc, fs=SR, output="sos")
+    x = _noise(6000, seed=11)
+    y = np.zeros_like(x)
+    oracle.lib().oracle_lp24_run(fc, ripple, SR, _dp(x), _dp(y), len(x))
+    ref = signal.sosfilt(sos, x) * math.sqrt(1.0 + eps * eps)
+    scale = max(1e-3, np.max(np.abs(ref)))
+    assert np.max(np.abs(y - ref)) <= 1e-9 * scale, np.max(np.abs(y - ref)) / scale
+    # the oracle's own six coefficients through lfilter, section by section (its transposed form II == any other form)
+    c = np.zeros(6)
+    oracle.lib().oracle_lp24_coeffs(fc, ripple, SR, _dp(c))
+    z = x
+    for b0, a1, a2 in (c[:3], c[3:]):  # the oracle carries a1, a2 with the feedback's sign folded in: y = ... + a1 y1 + a2 y2
+        z = signal.lfilter([b0, 2 * b0, b0], [1.0, -a1, -a2], z)
+    assert np.max(np.abs(y - z)) <= 1e-10 * scale
+
+
+# ------------------------------------------------------------------------------------------ a10-a12 delay lines
+def _fx_run(oracle, kind, x, **kw):
+    fx = oracle.Fx(kind, (T.FxParams * 1)(T.fx_params(**kw)))
+    blk = np.zeros((2, len(x), 1))
+    blk[0, :, 0] = x
+    blk[1, :, 0] = -0.5 * x
+    fx.process(blk)
+    return blk[0, :, 0], blk[1, :, 0]
+
+
+def _delay_frames(seconds):
+    return max(1, int(math.floor(float(np.float32(seconds)) * SR + 0.5)))
+
+
+def test_delay_is_a_pure_delay(oracle):
+    x = _noise(12000, seed=3)
+    N = _delay_frames(0.1)
+    yl, yr = _fx_run(oracle, T.FX_DELAY, x, delay_seconds=0.1)
+    b = np.zeros(N + 1); b[N] = 1.0
+    assert np.array_equal(yl, signal.lfilter(b, [1.0], x)) and np.array_equal(yr, signal.lfilter(b, [1.0], -0.5 * x))
+
+
+def test_chorus_is_its_taps(oracle):
+    x = _noise(30000, seed=4)
+    N, voices = _delay_frames(0.25), 4
+    spacing = N // voices
+    yl, _ = _fx_run(oracle, T.FX_CHORUS, x, delay_seconds=0.25, voices=voices)
+    b = np.zeros(N + 1)
+    for k in range(voices):
+        b[N - k * spacing] += 1.0
+    assert np.max(np.abs(yl - signal.lfilter(b, [1.0], x))) <= TOL
+
+
+def test_reverb_is_four_recirculating_combs_and_two_allpasses(oracle):
+    x = _noise(20000, seed=5)
+    att, seconds = 0.95, 1.25
+    yl, yr = _fx_run(oracle, T.FX_REVERB, x, attenuation=att, reverb_seconds=seconds)
+
+    def expect(inp):
+        u = inp * float(np.float32(att))
+        s = np.zeros_like(u)
+        for d in (0.0297, 0.0371, 0.0411, 0.0437):      # out[n] = g (in[n - N] + out[n - N])
+            N = max(1, int(math.floor(d * SR + 0.5)))
+            g = 0.001 ** (d / float(np.float32(seconds)))
+            b = np.zeros(N + 1); b[N] = g
+            a = np.zeros(N + 1); a[0] = 1.0; a[N] = -g
+            s += signal.lfilter(b, a, u)
+        for d, dec in ((0.005, 0.09683), (0.0017, 0.03292)):  # H(z) = (z^-N - g) / (1 - g z^-N)
+            N = max(1, int(math.floor(d * SR + 0.5)))
+            g = 0.001 ** (d / dec)
+            b = np.zeros(N + 1); b[0] = -g; b[N] = 1.0
+            a = np.zeros(N + 1); a[0] = 1.0; a[N] = -g
+            s = signal.lfilter(b, a, s)
+        return s
+
+    for got, inp in ((yl, x), (yr, -0.5 * x)):
+        ref = expect(inp)
+        assert np.max(np.abs(got - ref)) <= 1e-11 * max(1.0, np.max(np.abs(ref)))
+
+
+# ------------------------------------------------------------------------------------------ a1 Oscillator
+def _osc(oracle, waveform, freq, n, duty=0.5, tune=1.0, fm=None):
+    import ctypes as C
+    p = T.OscillatorParams(waveform=waveform, duty=duty, tune=tune, fixed_hz=0.0)
+    out = np.zeros(n)
+    st = (C.c_uint32 * 2)()
+    oracle.lib().oracle_oscillator_run(C.byref(p), freq, SR, _dp(fm) if fm is not None else None, _dp(out), n, st)
+    return out, (st[0], st[1])
+
+
+@pytest.mark.parametrize("freq", [440.0, 61.735, 5274.04])
+def test_oscillator_is_a_phase_accumulator_with_the_published_waveforms(oracle, freq):
+    n = 20000
+    # position of frame i: frac(i f / SR) (the first tick emits position 0), here in extended precision
+    pos = np.arange(n, dtype=np.longdouble) * (np.longdouble(freq) / np.longdouble(SR))
+    pos = (pos - np.floor(pos)).astype(np.float64)
+    away = lambda edge: np.abs(pos - edge) > 1e-7   # a frame within rounding of a waveform edge may legitimately fall on either side
+
+    sine, _ = _osc(oracle, T.WAVE_SINE, freq, n)
+    assert np.max(np.abs(sine - np.sin(2 * np.pi * pos))) <= 1e-8                      # (accumulated phase: n additions of f / SR)
+    tri, _ = _osc(oracle, T.WAVE_TRIANGLE, freq, n)
+    assert np.max(np.abs(tri - (4.0 * np.abs(pos - np.floor(pos + 0.5)) - 1.0))) <= 1e-8
+    saw, _ = _osc(oracle, T.WAVE_SAWTOOTH, freq, n)
+    ok = away(0.5)
+    assert np.max(np.abs(saw - 2.0 * (pos - np.floor(pos + 0.5)))[ok]) <= 1e-8
+    sq, _ = _osc(oracle, T.WAVE_SQUARE, freq, n)
+    ok = away(0.5) & away(0.0) & away(1.0)
+    assert np.array_equal(sq[ok], np.where(pos < 0.5, 1.0, -1.0)[ok])
+    pw, _ = _osc(oracle, T.WAVE_PULSE_WIDTH, freq, n, duty=0.25)
+    ok = away(0.25) & away(0.0) & away(1.0)
+    assert np.array_equal(pw[ok], np.where(pos < 0.25, 1.0, -1.0)[ok])
+    # frequency tune and 2^fm modulation scale the increment
+    tuned, _ = _osc(oracle, T.WAVE_SINE, freq / 2.0, n, tune=2.0)
+    assert np.max(np.abs(tuned - sine)) <= 1e-9
+    fm = np.full(n, 1.0)
+    up, _ = _osc(oracle, T.WAVE_SINE, freq / 2.0, n, fm=fm)
+    assert np.max(np.abs(up - sine)) <= 1e-9
+
+
+def test_noise_is_the_musicdsp_generator_in_exact_integers(oracle):
+    n = 5000
+    got, (s1, s2) = _osc(oracle, T.WAVE_NOISE, 440.0, n)
+    x1, x2 = 0x70F4F854, 0xE1E9F0A7
+    want = np.zeros(n)
+    for i in range(n):
+        x1 ^= x2
+        want[i] = (x2 - (1 << 32) if x2 & 0x80000000 else x2) / 2147483648.0
+        x2 = (x2 + x1) & 0xFFFFFFFF
+    assert np.array_equal(got, want) and (s1, s2) == (x1, x2)
+
+
+# ------------------------------------------------------------------------------------------ a2 Envelope
+@pytest.mark.parametrize("a,d,s,r,off", [(0.01, 0.05, 0.6, 0.1, 6000), (0.0, 0.02, 0.25, 0.03, 3000), (0.05, 0.0, 1.0, 0.0, 4000),
+                                          (0.2, 0.3, 0.5, 0.2, 2000)])
+def test_envelope_is_four_closed_form_stages(oracle, a, d, s, r, off):
+    """value = A + (B - A) (2t - t^2), t = frames into the stage / stage length; stage lengths scale with the distance to
+    cover; zero-length stages are skipped in the same frame; a note-off releases from the current level."""
+    import ctypes as C
+    n = 12000
+    p = T.EnvelopeParams(a, d, s, r)
+    got = np.zeros(n)
+    oracle.lib().oracle_envelope_run(C.byref(p), SR, off, _dp(got), n)
+    af, df, sf, rf = a, d, s, r  # (envelope parameters travel as f64)
+    want = np.zeros(n)
+
+    def stage(start, A, B, length):
+        """Frames start .. of a stage from A towards B over `length` frames; returns the frame after its last one."""
+        N = int(math.ceil(length)) if length > 0.0 else 0
+        i = np.arange(N)
+        t = i / length if N else i
+        seg = A + (B - A) * (2.0 * t - t * t)
+        end = min(n, start + N)
+        want[start:end] = seg[: end - start]
+        return start + N
+
+    f = stage(0, 0.0, 1.0, af * SR)                 # attack
+    if f < off:
+        f = stage(f, 1.0, sf, df * SR * (1.0 - sf))  # decay
+    want[min(f, n):off] = sf                         # sustain
+    want[off:] = 0.0
+    level = want[off - 1] if off > 0 else 0.0        # release from the level of the last tick
+    stage(off, level, 0.0, rf * SR * level)
+    assert np.max(np.abs(got - want)) <= TOL
+
+
+# ------------------------------------------------------------------------------------------ a9 Bitcrusher, a13 Dca
+def test_bitcrusher_is_an_integer_quantise(oracle):
+    xs = np.concatenate([_noise(4000, seed=9) * 1.2, [0.0, 1.0, -1.0, 0.5, 3e-5]]).astype(np.float32)
+    for bits in (0, 1, 5, 8, 13, 15):
+        got = np.array([oracle.lib().oracle_bitcrush_f32(float(x), bits) for x in xs], dtype=np.float32)
+        q = (np.abs(xs) * np.float32(32767.0)).astype(np.uint32)           # truncation on the 16-bit scale
+        q = (q >> np.uint32(bits)) << np.uint32(bits)
+        want = np.copysign(q.astype(np.float32) * np.float32(1.0 / 32767.0), xs)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), bits
+
+
+def test_dca_pan_law_anchor_points(oracle):
+    lr = np.zeros(2)
+    L = oracle.lib()
+    L.oracle_dca(1.0, 1.0, 0.0, _dp(lr)); assert np.allclose(lr, [0.75, 0.75], atol=1e-15)   # centre
+    L.oracle_dca(1.0, 1.0, -1.0, _dp(lr)); assert np.allclose(lr, [1.0, 0.0], atol=1e-15)    # hard left
+    L.oracle_dca(1.0, 1.0, 1.0, _dp(lr)); assert np.allclose(lr, [0.0, 1.0], atol=1e-15)     # hard right
+    L.oracle_dca(0.5, 0.5, 0.3, _dp(lr))
+    assert np.allclose(lr, [0.25 * (1 - 0.25 * 1.3 ** 2), 0.25 * (1 - (0.15 - 0.5) ** 2)], atol=1e-15)

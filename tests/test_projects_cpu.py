@@ -94,6 +94,24 @@ def test_bench_dry_launch_starts_two_ranks():
     line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["dry_launch"] is True and line["ranks"] == 2 and line["world"] == 2
     assert line["voice_ranges"] == [[0, 500000], [500000, 1000000]]
+    # the three measurements one `bench.py --gpus N` run makes (bench.py section_plan), with every rank in the communicator
+    sec = line["sections"]
+    assert sorted(sec) == ["mixed-131072", "strong", "weak"]
+    assert all(s["rccl_ranks"] == line["world"] for s in sec.values())
+    assert sec["strong"]["voices_total"] == 1_000_000 and sec["strong"]["ranges"] == [[0, 500000], [500000, 1000000]]
+    assert sec["weak"]["voices_total"] == 2_000_000 and sec["weak"]["ranges"] == [[0, 1000000], [1000000, 2000000]]
+    assert sec["mixed-131072"]["voices_total"] == 131072 and sec["mixed-131072"]["ranges"] == [[0, 65536], [65536, 131072]]
+
+
+def test_section_plan_is_config_5_at_eight_gpus():
+    """BASELINE.json config #5: 131,072 mixed voices sharded over 8 GPUs = 16,384 contiguous voices per rank."""
+    sys.path.insert(0, REPO)
+    import bench
+    for r in range(8):
+        pl = bench.section_plan(8, r)
+        assert pl["mixed-131072"]["range"] == [16384 * r, 16384 * (r + 1)]
+        assert pl["strong"]["range"] == [125000 * r, 125000 * (r + 1)]
+        assert pl["weak"]["range"] == [1000000 * r, 1000000 * (r + 1)] and pl["weak"]["voices_total"] == 8_000_000
 
 
 def test_bench_refuses_a_world_size_that_is_not_the_gpu_count():
@@ -101,22 +119,6 @@ def test_bench_refuses_a_world_size_that_is_not_the_gpu_count():
     p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--dry-launch"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=2" in (p.stderr + p.stdout)
-
-
-def test_first_process_canary_outcomes(monkeypatch):
-    """groove_amd/canary.py on a box without a GPU: switched off it says so; switched on, its child fails at once
-    (no HIP device: the library has no CPU path) and the parent reports 'failed' — not 'killed', and not an exception."""
-    import time
-    from groove_amd import canary
-    monkeypatch.setenv("GROOVE_NO_CANARY", "1")
-    assert canary.run() == "skipped"
-    monkeypatch.delenv("GROOVE_NO_CANARY")
-    import torch
-    if torch.cuda.is_available():
-        pytest.skip("a GPU is present: the child would run the real path")
-    t0 = time.time()
-    assert canary.run(timeout_s=60.0) == "failed"
-    assert time.time() - t0 < 60.0
 
 
 def test_bench_watchdog_kills_a_stalled_child_and_retries(tmp_path):
