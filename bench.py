@@ -304,6 +304,21 @@ def committed_profile(workload, window=None):
     return out
 
 
+def measured_mix_bound():
+    """The newest committed profiles/rNN_mix_bound.json (tools/micro/mix_bound, run on an MI355X): ns of SIMD time per
+    wave-instruction of the million-voice window's VALU class mix, the best variant at 5 and at 4 waves per SIMD."""
+    import re
+    pdir = os.path.join(REPO, "profiles")
+    found = sorted((int(m.group(1)), n) for n in (os.listdir(pdir) if os.path.isdir(pdir) else []) for m in [re.match(r"^r(\d+)_mix_bound\.json$", n)] if m)
+    for _, n in reversed(found):
+        try:
+            d = json.load(open(os.path.join(pdir, n)))["ns_per_wave_instruction"]
+            return {"ns_at_5_waves": min(d["5"].values()), "ns_at_4_waves": min(d["4"].values()), "source": n}
+        except Exception:
+            continue
+    return None
+
+
 def spread_sample(v_total, count):
     """`count` project voice indices spread over [0, v_total) with an ODD stride, so that the sample meets every
     residue of the voice rules' moduli (32 patches, 16 FM patches, 4 kinds, 60 buffers ...)."""
@@ -651,7 +666,20 @@ def roofline_block(workload, n_local, kern_ms, span_mode, fused, window=None):
                                                "note": "SIMD time of the step's VALU instructions at their measured issue costs / SIMD time available; "
                                                        "low / high: the unclassified instructions (moves, compares, selects, DPP) all fast / all normal"}
             r["valu"]["mix_shares"] = (prof.get("valu_mix_per_step") or {}).get("shares")
-            valu_frac = max(valu_frac, lo)
+        mb = measured_mix_bound()
+        if mb and wl["kind"] == "welsh" and WORKLOADS[workload]["voices"] >= 500_000:
+            # The issue bound of THIS instruction stream, measured (tools/micro/mix_bound.hip: the window's class mix issued as
+            # independent chains at the render kernels' occupancies): the time below which no schedule of the step's VALU
+            # instructions can finish, and the step's duration against it.  <= 1 by construction; what is left to 1 is
+            # dependent-chain latency the real kernels have and the synthetic one has not.
+            t5, t4 = wi * mb["ns_at_5_waves"] * 1e-9 / 1024.0 * 1e3, wi * mb["ns_at_4_waves"] * 1e-9 / 1024.0 * 1e3
+            r["valu"]["measured_bound"] = {"ns_per_wave_instruction": {"5_waves_per_simd": mb["ns_at_5_waves"], "4_waves_per_simd": mb["ns_at_4_waves"]},
+                                           "bound_ms": {"at_5_waves": t5, "at_4_waves": t4}, "source": mb["source"],
+                                           "note": "the render kernels run at 5 / 5 / 4 / 4 waves per SIMD; the fraction uses the faster rate"}
+            r["valu"]["frac_of_measured_bound"] = t5 / kern_ms
+            valu_frac = max(valu_frac, t5 / kern_ms)
+        elif prof.get("valu_simd_ns_per_step"):
+            valu_frac = max(valu_frac, r["valu"]["cost_weighted_frac"]["low"])
     fr = {"hbm": hbm_frac or 0.0, "valu-issue": valu_frac or 0.0}
     top = max(fr, key=fr.get)
     r["bound"] = (top if fr[top] >= 0.25 else "latency (one or two short launches per block: neither HBM nor VALU issue is a quarter busy)") if (hbm_frac is not None or valu_frac is not None) \

@@ -756,10 +756,6 @@ GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScrat
   }
   float nz1 = 0.0f, nz2 = 0.0f;
   if (w1 == GROOVE_WAVE_NOISE) nz1 = noise_tick(s.o1);
-#ifdef GROOVE_SEG_PLAIN /* A/B */
-  if ((p.flags & WF_SYNC) && wrapped) s.o2.phase = 0;
-  else if (!first) s.o2.phase += inc2;
-#else
   {
     uint64_t ph2 = s.o2.phase;
     if (!first) ph2 += inc2;
@@ -771,7 +767,6 @@ GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScrat
     }
     s.o2.phase = ph2;
   }
-#endif
   if (w2 == GROOVE_WAVE_NOISE) nz2 = noise_tick(s.o2);
   const float v1 = osc_value_classed<C1, REST>(w1, s.o1.phase, d1, nz1);
   const float v2 = osc_value_classed<C2, REST>(w2, s.o2.phase, d2, nz2);
@@ -924,11 +919,7 @@ GROOVE_HD void welsh_frame_coef(const WelshParams& p, const RenderConsts& rc, We
       const float fc = retune ? 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f) : p.cutoff_hz;
       sc.coef = lp24_coefd_from_fc(c, fc, rc.pi_over_sr, rc.fc_max);
     } else if (retune && pct != sc.prev_pct) { // unchanged percent (e.g. envelope plateau): coefficients stand
-#ifdef GROOVE_RETUNE_V1 /* A/B: the two-step form */
-      sc.coef = lp24_coefd_from_fc(p.fc, 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f), rc.pi_over_sr, rc.fc_max);
-#else
       sc.coef = lp24_coefd_from_pct(p.fc, pct, rc);
-#endif
       sc.prev_pct = pct;
     }
   }

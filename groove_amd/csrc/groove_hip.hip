@@ -67,11 +67,6 @@ struct groove_block {
 };
 
 enum BankKind { BANK_WELSH = 0, BANK_FM = 1, BANK_SAMPLER = 2 };
-#ifdef GROOVE_NO_PIPELINE
-constexpr bool kNoPipeline = true; // A/B: every block forks and joins around its own kernels
-#else
-constexpr bool kNoPipeline = false;
-#endif
 
 
 struct groove_bank {
@@ -208,10 +203,8 @@ struct groove_ctx {
   // materialised million-voice forms (the kind streams waiting for a block's bound "free" event, profiles/r03_stall_hunt2.log);
   // the binding was worth ~1 % there.  GROOVE_BIND_EVENTS=1 switches it on.
   bool bind_events = false;
-  bool defer_bus = true;              // GROOVE_DEFER_BUS=0: groove_bank_render_mix_deferred == groove_bank_render_mix (A/B)
   uint32_t fx_seg_max_lanes = 49152;     // biquad banks of up to this many lane-channels take the four-segment kernel (measured, tools/fx_bench.py: 8,192 lane-channels 17.5 -> 9.3 us, 32,768 19.4 -> 15.6, 131,072 42.9 -> 58.4; GROOVE_FX_SEG_MAX_LANES, 0 = never)
   uint32_t fx_tp_wide_min_lanes = 8192;  // from this many lane-channels the time-parallel IIR kernels take 32-wide tiles (GROOVE_FX_TP_WIDE_MIN_LANES)
-  bool fx_lds_staging = false;          // GROOVE_FX_LDS_STAGING=1 (A/B): the fused run kernel stages the chorus taps through LDS
   bool seq_allpass = false;             // GROOVE_FX_SEQ_ALLPASS=1: the sequential all-pass kernel (A/B and bit-identity tests)
   bool chunked_allpass = false;         // GROOVE_FX_CHUNKED_ALLPASS=1: the chunk-parallel all-pass kernel instead of the direct one
   uint32_t sr = GROOVE_DEFAULT_SAMPLE_RATE;
@@ -1002,9 +995,8 @@ static bool create_streams(groove_ctx* ctx) {
   // config #3 was gone: 0.25 ms per block against 0.14), and its short bus reductions, which every
   // pipelined block waits for, are dispatched ahead of the long render kernels.
   int prio_least = 0, prio_greatest = 0;
-  const char* flat = std::getenv("GROOVE_STREAM_PRIORITIES"); // "0": every stream at the normal priority (A/B)
   bool ok = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess;
-  if (ok && ((flat && flat[0] == '0') || ctx->safe_streams)) prio_least = prio_greatest = 0;
+  if (ok && ctx->safe_streams) prio_least = prio_greatest = 0;
   auto make = [&](hipStream_t* st, int prio) {
     const bool made = hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio) == hipSuccess;
     if (made) ctx->streams_created += 1;
@@ -1051,24 +1043,12 @@ static int init_impl(int device_ordinal, const uint8_t* comm_id, int rank, int w
   if (!ctx) return fail(nullptr, "groove_init: out of memory");
   ctx->device = device_ordinal;
   if (const char* e = std::getenv("GROOVE_FX_SEQ_ALLPASS")) ctx->seq_allpass = e[0] == '1';
-  if (const char* e = std::getenv("GROOVE_FX_LDS_STAGING")) ctx->fx_lds_staging = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_SAFE_STREAMS")) ctx->safe_streams = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_SYNC_TIMEOUT_MS")) ctx->sync_timeout_ms = (uint32_t)std::strtoul(e, nullptr, 10);
-  if (const char* e = std::getenv("GROOVE_KIND_STREAMS")) ctx->kind_streams = std::atoi(e) == 4 ? 4 : 3;
-  if (ctx->safe_streams) ctx->kind_streams = 3;
-  if (const char* e = std::getenv("GROOVE_BANK_STREAMS")) ctx->bank_streams = std::max(1, std::min(kBankStreams, std::atoi(e)));
-  if (const char* e = std::getenv("GROOVE_FM_TP_MAX_VOICES")) ctx->fm_tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FM_TP_VPW4_MIN_VOICES")) ctx->fm_tp_vpw4_min_voices = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_BIND_EVENTS")) ctx->bind_events = std::atoi(e) != 0;
-  if (const char* e = std::getenv("GROOVE_DEFER_BUS")) ctx->defer_bus = std::atoi(e) != 0;
-  if (const char* e = std::getenv("GROOVE_TP_VPW2_MIN_VOICES")) ctx->tp_vpw2_min_voices = (uint32_t)std::strtoul(e, nullptr, 10);
-  if (const char* e = std::getenv("GROOVE_FX_SEG_MAX_LANES")) ctx->fx_seg_max_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
-  if (const char* e = std::getenv("GROOVE_FX_TP_WIDE_MIN_LANES")) ctx->fx_tp_wide_min_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FX_CHUNKED_ALLPASS")) ctx->chunked_allpass = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_TP_MAX_VOICES")) ctx->tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
-  if (const char* e = std::getenv("GROOVE_FX_TP_MAX_LANES")) ctx->fx_tp_max_lanes = (uint32_t)std::strtoul(e, nullptr, 10);
-  if (const char* e = std::getenv("GROOVE_SPLIT_MAX_WAVES")) ctx->split_max_waves = (uint32_t)std::strtoul(e, nullptr, 10);
-  if (const char* e = std::getenv("GROOVE_SPLIT2_MAX_WAVES")) ctx->split2_max_waves = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_SPLIT_ROLES")) { const int r = std::atoi(e); ctx->split_roles = r == 2 || r == 4 ? r : 3; }
   if (const char* e = std::getenv("GROOVE_PIPELINE_MIN_WAVES")) ctx->pipeline_min_waves = (uint32_t)std::strtoul(e, nullptr, 10); // tests force the pipeline on small banks
   bool ok = hipSetDevice(device_ordinal) == hipSuccess;
@@ -1875,12 +1855,12 @@ int groove_bank_render_mix_deferred(groove_bank* b, uint32_t frames, float* bus_
   if (frames == 0) return 0;
   // (several banks of a small project may take turns on the ctx stream this way — each render carries the reduction of the one
   // before it, in submission order — instead of side by side on side streams with their cross-queue waits: the caller's choice)
-  const bool lone = ctx->pipeline_min_waves > 1 || kNoPipeline;
+  const bool lone = ctx->pipeline_min_waves > 1;
   // A Welsh bank too big for the time-parallel form and too small for the per-kind pipeline (the all-kinds or a role-split
   // kernel on the ctx stream, then two reduction launches in line behind it: ~18 us of a 125,000-voice shard's 130): the same
   // deferral, the next block's kernel summing the rows — when the launch that would carry them exists (some workgroup of the four
   // class-specialised kinds) and the rows are few enough.
-  if (ctx->defer_bus && lone && frames <= 4096 && !use_tp(b, frames) && b->kind == BANK_WELSH && b->n_vwaves && b->n_vwaves < ctx->pipeline_min_waves) {
+  if (lone && frames <= 4096 && !use_tp(b, frames) && b->kind == BANK_WELSH && b->n_vwaves && b->n_vwaves < ctx->pipeline_min_waves) {
     uint32_t n_spec = 0;
     for (int k = 0; k < 4 * kClassCombos; ++k) n_spec += b->wgs_of_kind[k];
     const uint32_t urows = fused_rows(b, frames);
@@ -1912,7 +1892,7 @@ int groove_bank_render_mix_deferred(groove_bank* b, uint32_t frames, float* bus_
   if (b->kind == BANK_SAMPLER && use_tp(b, frames)) { svpw = sampler_tp_vpw_deferred(b->n); if (sampler_tp_workgroups(b->n, svpw) > 512) svpw = 0; }
   // (up to 2,048 rows: the 512 columns' workgroups then take two to four batches of rows, a few us of a render that is long by then)
   const uint32_t rows = !use_tp(b, frames) ? 0 : (svpw ? sampler_tp_workgroups(b->n, svpw) : fused_rows(b, frames));
-  if (!ctx->defer_bus || !lone || rows == 0 || rows > 2048 || frames > kTpMaxFrames) return groove_bank_render_mix(b, frames, bus_dev, accumulate);
+  if (!lone || rows == 0 || rows > 2048 || frames > kTpMaxFrames) return groove_bank_render_mix(b, frames, bus_dev, accumulate);
   GHIP(ctx, hipSetDevice(ctx->device));
   if (flush_events(b, true)) return 1;
   if (ctx_join(ctx)) return 1;
@@ -1957,7 +1937,7 @@ int groove_bank_render_mix(groove_bank* b, uint32_t frames, float* bus_dev, int 
   //    run beside each other instead of one after the other (mixed-131072: 0.46 -> 0.2x ms per block).
   const bool force = ctx->pipeline_min_waves <= 1;
   const bool big = b->kind == BANK_WELSH && b->n_vwaves >= ctx->pipeline_min_waves;
-  if (!kNoPipeline && (big || force || ctx->banks.size() > 1)) return render_mix_pipelined(b, frames, bus_dev, accumulate);
+  if (big || force || ctx->banks.size() > 1) return render_mix_pipelined(b, frames, bus_dev, accumulate);
   if (ctx_join(ctx)) return 1; // earlier pipelined blocks of this bank may still be running on the side streams
   const uint32_t rows = fused_rows(b, frames);
   const uint32_t cols = 2 * frames;
@@ -1995,13 +1975,6 @@ int groove_bank_reset(groove_bank* b) {
   groove_ctx* ctx = b->ctx;
   GHIP(ctx, hipSetDevice(ctx->device));
   if (ctx_join(ctx)) return 1;
-  // (experiment, GROOVE_RESET_HOST_SYNC=1: the host waits here until every stream is idle, and the block pipeline's slot
-  // events are forgotten — does the stall of DESIGN.md section 7 need a reset that is only ordered on the device?)
-  static const bool reset_host_sync = [] { const char* e = std::getenv("GROOVE_RESET_HOST_SYNC"); return e && e[0] == '1'; }();
-  if (reset_host_sync) {
-    GHIP(ctx, ctx_wait(ctx, "groove_bank_reset"));
-    for (int slot = 0; slot < 2; ++slot) b->reduce_recorded[slot] = false;
-  }
   b->side_mode = 0;
   b->ctx_touched = true;
   b->pending.clear();
@@ -2146,7 +2119,6 @@ static int fx_launch_run(groove_ctx* ctx, groove_fx* const* run, uint32_t count,
   float* rows = last ? block_sums(io, wg_per_ch, frames) : nullptr;
   if (last && !rows) return 1;
   a.frames = frames; a.wg_per_ch = wg_per_ch;
-  a.lds_taps = (ctx->fx_lds_staging && V == 4 && n % (kThreads * 4) == 0) ? 1u : 0u;
   a.rows = (rv && direct) ? nullptr : rows;
   if (rv && !direct) rows = nullptr; // the sequential / chunked all-pass kernels run last and leave none
   if (V == 4) hipLaunchKernelGGL(fx_run_kernel<4>, dim3(2 * wg_per_ch, frames), blk, 0, st, a);

@@ -1185,7 +1185,6 @@ struct FxRunArgs {
   uint32_t n_stages, n;
   float* rows;          // not null: the launch also leaves the block's lane sums, rows[wg_per_ch][2][frames] (fx_row_sum)
   uint32_t frames, wg_per_ch;
-  uint32_t lds_taps;    // A/B (GROOVE_FX_LDS_STAGING=1; host: only when every thread of every workgroup is live): the chorus taps staged through LDS
 };
 // Grid of the (frame, lane-channel) effect kernels: blockIdx.y = frame, blockIdx.x = (channel, group of 256 * V lanes) —
 // a workgroup never straddles the two channels, so its sum is one entry of the block's lane sums.
@@ -1237,24 +1236,9 @@ __device__ __forceinline__ float fx_run_element(const FxRunArgs& a, uint32_t ch,
 #pragma unroll
       for (int j = 0; j < V; ++j) y.v[j] = 0.0f;
       uint32_t tp = p;
-      if (V == 4 && a.lds_taps && st.voices <= 4) {
-        // A/B only ("LDS staging"): the taps' ring segments of the workgroup's 1,024 lane-channels are loaded
-        // cooperatively — every thread fetches the 16 bytes its NEIGHBOUR WAVE's thread will consume — parked in LDS, and
-        // read back after a barrier: the staging north_star describes, for data that is read exactly once.
-        __shared__ float4 s_taps[4][kThreads];
-        const uint32_t other = (threadIdx.x + 64u) & (kThreads - 1u);
-        const uint32_t t_other = t - threadIdx.x * 4u + other * 4u;
-        for (uint32_t k = 0; k < st.voices; ++k) {
-          s_taps[k][other] = *reinterpret_cast<const float4*>(st.ring + (size_t)tp * ln + t_other);
-          tp += st.spacing; if (tp >= st.N) tp -= st.N;
-        }
-        __syncthreads();
-        for (uint32_t k = 0; k < st.voices; ++k) {
-          const float4 d = s_taps[k][threadIdx.x];
-          y.v[0] += d.x; y.v[1] += d.y; y.v[2] += d.z; y.v[3] += d.w;
-        }
-        __syncthreads();
-      } else
+      // (the taps staged through LDS — every thread fetching its neighbour wavefront's 16 bytes, a barrier, read back — was built and
+      // measured in round 3: 27.04 against 26.87 us and identical FETCH / WRITE bytes, profiles/r03_lds_staging_ab.log: every lane owns
+      // its delay lines, a ring window is read exactly once by exactly one lane, there is no reuse for LDS to capture)
       for (uint32_t k = 0; k < st.voices; ++k) {
         const VecF<V> d = vload<V>(st.ring + (size_t)tp * ln + t);
 #pragma unroll

@@ -610,9 +610,7 @@ template <bool FUSED, int ROLES>
 __global__ __launch_bounds__(ROLES * kSplitLanes, GROOVE_WAVES_SPLIT) GROOVE_NO_TAIL_CALLS void welsh_render_split_kernel(UniformArgs a, const uint8_t* __restrict__ wg_base) {
   const UniformArgsPtr ka = (UniformArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   if constexpr (FUSED) { tp_reduce_prev(a.prev, threadIdx.x, blockIdx.x, gridDim.x); if (welsh_split_idle_workgroup(a, ROLES * kSplitLanes)) return; }
-#ifdef GROOVE_SPLIT_PRIO /* A/B (measured, round 3: s_setprio 3 changes nothing — config #5 0.100-0.105 against 0.103-0.107 ms per block, 65,536 voices alone 0.095 both) */
-  __builtin_amdgcn_s_setprio(GROOVE_SPLIT_PRIO);
-#endif
+  // (s_setprio 3 here changes nothing: config #5 0.100-0.105 against 0.103-0.107 ms per block, round 3)
   const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wg_base[blockIdx.x]);
   const uint32_t cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[blockIdx.x]);
   const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kSplitLanes));

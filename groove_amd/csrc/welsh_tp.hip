@@ -23,10 +23,7 @@ static void launch_welsh_tp_vpw(const TpArgs& a, hipStream_t st, bool fused, hip
   }
   else if (fused) tp_launch(welsh_tp_kernel<true, false, false, VPW>, grid, blk, 0, st, done, a);
   else if (a.bq_coef) {
-    // (experiment knob, round 3: unused dynamic LDS caps how many of this kernel's wavefronts a CU takes, leaving
-    // registers for the effect kernels that run beside it on the ctx stream — docs/STREAMS.md item 11)
-    static const unsigned pad = [] { const char* e = std::getenv("GROOVE_TP_PAD_LDS"); return e ? (unsigned)std::strtoul(e, nullptr, 10) : 0u; }();
-    tp_launch(welsh_tp_kernel<false, true, false, VPW>, grid, blk, pad, st, done, a);
+    tp_launch(welsh_tp_kernel<false, true, false, VPW>, grid, blk, 0, st, done, a);
   }
   else tp_launch(welsh_tp_kernel<false, false, false, VPW>, grid, blk, 0, st, done, a);
 }

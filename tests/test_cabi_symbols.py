@@ -57,3 +57,22 @@ def test_param_struct_sizes_match_the_c_headers(tmp_path):
     want = [C.sizeof(t) for t in (T.EnvelopeParams, T.OscillatorParams, T.WelshParams, T.FmParams, T.SampleDesc,
                                   T.SamplerParams, T.NoteEvent, T.FxParams)]
     assert got == want
+
+
+def test_integration_doc_binds_every_declared_symbol_and_struct():
+    """INTEGRATION.md's `extern "C"` block — the reference-side binding a maintainer would add — names every function the
+    header declares (and nothing else), with the same number of arguments, and spells out every parameter struct."""
+    doc = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    block = doc[doc.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    bound = dict(re.findall(r"pub fn (groove_[a-z0-9_]+)\((.*?)\)(?: -> [^;]+)?;", block))
+    assert sorted(bound) == _declared()
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(REPO, "include", "groove_hip.h")).read(), flags=re.S)
+    for name, args in bound.items():
+        c_args = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", header, flags=re.S).group(1)
+        n_c = 0 if c_args.strip() in ("", "void") else c_args.count(",") + 1
+        n_rust = 0 if not args.strip() else args.count(",") + 1
+        assert n_c == n_rust, (name, c_args, args)
+    types = re.sub(r"/\*.*?\*/", "", open(os.path.join(REPO, "include", "groove_types.h")).read(), flags=re.S)
+    for struct in re.findall(r"\}\s*(groove_[a-z_]+_(?:params|desc|event))\s*;", types):
+        assert f"pub struct {struct} " in doc, struct

@@ -302,41 +302,56 @@ def test_control_step_shapes_match_oracle(oracle):
                 assert abs(L.gh_control_step_value(kind, a, b, t) - OL.oracle_control_step_value(kind, a, b, t)) <= 1e-15
 
 
+SYNTH_SHUFFLE = ([46, 0, 42, 42, 46, 0, 42, 44], [36, 0, 0, 36, 0, 0, 40, 0], [0, 0, 49, 0, 0, 45, 0, 47])   # eighth notes
+SYNTH_FILL = ([41, 43, 45, 47, 41, 43, 45, 47, 48, 48, 50, 50, 39, 39, 37, 37],)                           # sixteenth notes
+
+
+def _synthetic_project_notes():
+    """(key, start beat) of tests/data/synthetic-kit-sweep.json5: track = shuffle, fill, shuffle — one measure each; the rows of
+    a pattern are simultaneous."""
+    notes = []
+    for measure, (rows, step) in enumerate(((SYNTH_SHUFFLE, 0.5), (SYNTH_FILL, 0.25), (SYNTH_SHUFFLE, 0.5))):
+        notes += [(k, measure * 4 + i * step) for row in rows for i, k in enumerate(row) if k]
+    return notes
+
+
 def test_cli_renders_synthetic_config1_project(tmp_path, oracle):
-    """groove-cli-hip --wav on the committed synthetic config-#1 project (drumkit → 24 dB low-pass
-    with an exponential cutoff trip), synthetic sample bank: 16-bit stereo WAV of the expected length,
-    equal within ±1 LSB to the oracle graph's quantised render of the same project, and the rising
-    cutoff lets progressively more high-frequency energy through."""
+    """groove-cli-hip --wav on the committed synthetic project (config #1's features: drumkit -> 24 dB low-pass with a control
+    trip on the cutoff; content of its own), synthetic sample bank: 16-bit stereo WAV of the expected length, equal within
+    +-1 LSB to the oracle graph's quantised render of the same project, and the cutoff that closes (logarithmic 0.9 -> 0.2
+    over the first measure) takes high-frequency energy away."""
     import os
     import shutil
     import subprocess
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cli = os.path.join(repo, "groove_amd", "host", "groove-cli-hip")
-    proj = tmp_path / "drums.json5"
-    shutil.copy(os.path.join(repo, "tests", "data", "drums-filtered-synthetic.json5"), proj)
+    proj = tmp_path / "kit.json5"
+    shutil.copy(os.path.join(repo, "tests", "data", "synthetic-kit-sweep.json5"), proj)
     r = subprocess.run([cli, "--wav", "--synthetic-kit", "--perf", str(proj)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert "x real time" in r.stdout
-    raw = (tmp_path / "drums.wav").read_bytes()
+    raw = (tmp_path / "kit.wav").read_bytes()
     fmt, ch, sr, _, _, bits = struct.unpack("<HHIIHH", raw[20:36])
     assert (fmt, ch, sr, bits) == (1, 2, 44100, 16)
     pcm = np.frombuffer(raw[44:], dtype="<i2").reshape(-1, 2).astype(np.float64)
-    assert len(pcm) == 165375 - 165375 % 256
+    total = math.ceil(12.0 * 60 / 96 * 44100)              # three measures of 4/4 at 96 bpm
+    assert len(pcm) == total - total % 256
     assert np.abs(pcm).max() > 500
-    # end-to-end parity: the same project on the oracle graph (loader semantics restated here: rows are
-    # simultaneous, sixteenth notes, two measures; the 'double' path is one 8-beat exponential step)
+    # end-to-end parity: the same project on the oracle graph (loader semantics restated here: rows are simultaneous, the
+    # track's patterns follow each other measure by measure; the path's two 'whole'-note steps are 4 beats each)
     from groove_amd import host_binding as H
     kpcm, kdescs, k2s = H.synthetic_kit()
-    want = _quantise(oracle, _oracle_config1(oracle, kpcm, kdescs, k2s, _config1_notes(), len(pcm), 256,
-                                             trip_steps=[(H.STEP_EXPONENTIAL, 0.0, 1.0, 8.0)]))
+    want = _quantise(oracle, _oracle_config1(oracle, kpcm, kdescs, k2s, _synthetic_project_notes(), len(pcm), 256, bpm=96.0, cutoff=2400.0, ripple=0.55,
+                                             trip_steps=[(H.STEP_LOGARITHMIC, 0.9, 0.2, 4.0), (H.STEP_SLOPE, 0.2, 0.7, 4.0)]))
     assert np.max(np.abs(pcm.astype(np.int32) - want)) <= 1
-    # high-band (> 4 kHz) share of the energy in the first vs the last quarter of the render
+    # high-band (> 4 kHz) share of the energy: the two shuffle measures play the same notes, the first under a cutoff that falls
+    # from 0.9 to 0.2 of the range, the third after the trip has ended at 0.7
     def hi_share(x):
         spec = np.abs(np.fft.rfft(x[:, 0])) ** 2
         k = int(4000 / 44100 * len(x))
         return spec[k:].sum() / max(spec.sum(), 1e-30)
-    q = len(pcm) // 4
-    assert hi_share(pcm[-q:]) > 5 * hi_share(pcm[:q])
+    m = len(pcm) // 3
+    assert hi_share(pcm[2 * m:]) > 2 * hi_share(pcm[m // 2:m])
     # unknown input → non-zero exit and a message, never an abort
     r = subprocess.run([cli, str(tmp_path / "missing.json5")], capture_output=True, text=True)
     assert r.returncode != 0 and "couldn't read" in r.stderr

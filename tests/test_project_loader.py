@@ -1,7 +1,7 @@
 """Host logic of the compiled loader (groove_amd/host/project.cpp): project JSON/JSON5 and Welsh
 patch JSON → device-independent description.  CPU tier, no GPU calls.  Reference files are read
-only when /root/reference exists (this container); a synthetic project of the same shape is
-committed for the GPU box."""
+only when /root/reference exists (this container); a synthetic project with the same schema
+features and content of its own is committed for the GPU box (tests/data/synthetic-kit-sweep.json5)."""
 import ctypes as C
 import glob
 import json
@@ -55,10 +55,22 @@ def check_config1_shape(d):
     assert math.ceil(d["end_beats"] * 60 / d["bpm"] * 44100) == 165375
 
 
+SYNTHETIC = os.path.join(REPO, "tests", "data", "synthetic-kit-sweep.json5")
+
+
 def test_synthetic_json5_project(host):
-    d = describe(host, path=os.path.join(REPO, "tests", "data", "drums-filtered-synthetic.json5"))
-    check_config1_shape(d)
-    assert d["warnings"] == 0
+    """The committed synthetic project (the one the GPU box renders end to end): the same schema features as config #1 —
+    drumkit on channel 10, a 24 dB low-pass, a patch cable to the main mixer, patterns x tracks, a control trip on the
+    cutoff — with content of its own."""
+    d = describe(host, path=SYNTHETIC)
+    assert d["bpm"] == 96 and d["time_signature"] == [4, 4] and d["warnings"] == 0
+    kinds = {x["id"]: x for x in d["devices"]}
+    assert kinds["kit"]["kind"] == "drumkit" and kinds["kit"]["midi_in"] == 10 and kinds["kit"]["name"] == "707"
+    lp = kinds["sweep-lp"]
+    assert lp["effect"] and lp["fx_kind"] == T.FX_BIQUAD_LP24 and lp["cutoff"] == 2400 and abs(lp["passband_ripple"] - 0.55) < 1e-6
+    assert d["patch_cables"] == [["kit", "sweep-lp", "main-mixer"]]
+    assert d["n_notes"] == 2 * (6 + 3 + 3) + 16 and d["end_beats"] == 12.0      # shuffle, fill, shuffle: three measures of 4/4
+    assert d["trips"] == [{"id": "sweep", "target": "sweep-lp", "param": "cutoff", "steps": 2, "beats": 8.0, "first_kind": 2}]
 
 
 @pytest.mark.skipif(not os.path.exists(REF), reason="reference tree not present")
@@ -216,7 +228,7 @@ def test_hostile_project_text_is_rejected_not_crashed(host):
         describe(host, text="[" * 100000)
     with pytest.raises(RuntimeError, match="nesting"):
         describe(host, text='{"a":' * 5000 + "1" + "}" * 5000)
-    base = open(os.path.join(REPO, "tests", "data", "drums-filtered-synthetic.json5")).read()
+    base = open(SYNTHETIC).read()
     for cut in (1, len(base) // 3, len(base) - 2):
         with pytest.raises(RuntimeError):
             describe(host, text=base[:cut])

@@ -77,10 +77,14 @@ for name, ctype, init, asm, ins, sreg in K:
     c = "s" if sreg else "v"
     decl = "".join(f"  {ctype} a{i} = ({ctype})({init}) + {i};\n" for i in range(4))
     decl += "".join(f"  {t} b{j} = {v};\n" for j, (_, t, v) in enumerate(ins))
+    # eight instructions per asm statement (round 4): the compiler pads EVERY inline-asm statement with an `s_nop 0` it cannot
+    # prove unnecessary, and with one instruction per statement round 3's figures had a scalar instruction between every two
+    import re as _re
     body = ""
-    for r in range(32):
-        cons_in = ", ".join(f'"{cc}"(b{j})' for j, (cc, _, _) in enumerate(ins))
-        body += f'      asm volatile("{asm}" : "+{c}"(a{r % 4}) : {cons_in}{"" if not ins else ""} : "vcc", "scc", "s20", "s21", "s22", "s23");\n'
+    cons_in = ", ".join(f'"{cc}"(b{j})' for j, (cc, _, _) in enumerate(ins))
+    for g in range(4):
+        lines = [_re.sub(r"%(\d)", lambda m, r=r: f"%{r % 4}" if m.group(1) == "0" else f"%{3 + int(m.group(1))}", asm) for r in range(8 * g, 8 * g + 8)]
+        body += '      asm volatile("' + "\\n ".join(lines) + '" : ' + ", ".join(f'"+{c}"(a{i})' for i in range(4)) + f' : {cons_in} : "vcc", "scc", "s20", "s21", "s22", "s23");\n'
     ident = lambda n: "".join(ch if ch.isalnum() else "_" for ch in n)
     out.append(f'''__global__ __launch_bounds__(64) void k_{ident(name)}(float* out, int iters) {{
 {decl}  for (int it = 0; it < iters; ++it) {{

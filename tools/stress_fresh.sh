@@ -20,5 +20,5 @@ for i in $(seq 1 $N); do
   else bad=$((bad + 1)); echo "process $i: TIMEOUT or failure  $out" >> $LOG; fi
 done
 crcs=$(grep "^process .*: ok" $LOG | tail -$ok | sed 's/.* crc \([0-9a-f]*\) .*/\1/' | sort -u | wc -l)
-zeros=$(grep "^process .*: ok" $LOG | tail -$ok | sed 's/.*zero_segments \([0-9]*\).*/\1/' | paste -sd+ | bc)
+zeros=$(grep "^process .*: ok" $LOG | tail -$ok | sed 's/.*zero_segments \([0-9]*\).*/\1/' | awk '{s += $1} END {print s + 0}')
 echo "stress_fresh: $ok ok, $bad stalled or failed of $N; distinct bus CRCs $crcs; zero segments counted $zeros" | tee -a $LOG

@@ -12,8 +12,12 @@ out, rnd, workload = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3
 os.makedirs("profiles", exist_ok=True)
 # "<workload>-window" = the same workload under the driver's command line (--steps 20 --warmup 5): tools/profile_round.sh
 base_workload, windowed = (workload[:-len("-window")], True) if workload.endswith("-window") else (workload, False)
-summary = {"round": rnd, "workload": workload,
-           "command": f"python3 bench.py --workload {base_workload} --no-cpu-baseline --no-configs --no-parity --no-shard-curve --repeats 1 --no-watchdog"
+# REPEATS (environment, as tools/profile_round.sh ran the bench): timed regions per run.  A process's first regions run 5 - 12 %
+# slower than what the device then sustains (profiles/r03_timed_regions.log), so DURATIONS are read off the LAST region only;
+# counts (bytes, instructions) are the same in every region and are averaged over all of them.
+REPEATS = int(os.environ.get("REPEATS", "1"))
+summary = {"round": rnd, "workload": workload, "regions_per_run": REPEATS,
+           "command": f"python3 bench.py --workload {base_workload} --no-cpu-baseline --no-configs --no-parity --no-shard-curve --repeats {REPEATS} --no-watchdog"
                       + (" --steps 20 --warmup 5   (the driver's window: blocks 5..24 of the timeline)" if windowed else "   (defaults: --gpus 1 --steps 172 --warmup 4)")}
 STEP_KERNELS = ("render", "_tp_kernel", "partial_", "mix_", "fx_", "block_", "_events_")   # what one step of the hot path launches
 
@@ -56,18 +60,32 @@ if kt:
         ends = sorted(int(r["End_Timestamp"]) for r in rows if marker in r["Kernel_Name"])
         if len(ends) > 40:
             n_steps = 25 if windowed else 176
-            per = max(1, round(len(ends) / n_steps))       # a step may end with several launches of the marker (one per bank)
+            per = max(1, round(len(ends) / (n_steps * REPEATS)))       # a step may end with several launches of the marker (one per bank)
             ends = ends[per - 1::per]
-            steady = ends[4:]
+            ends = ends[-n_steps:]                                     # the last region of the run
+            steady = ends[5 if windowed else 4:]                       # its timed steps
             summary["step_period_from_trace"] = {
                 "mean_us": (steady[-1] - steady[0]) / (len(steady) - 1) / 1e3, "steps": len(steady) - 1, "marker": marker,
                 "note": "spacing of the step-ending kernel's completions over the timed steps; compare with roofline.kernel_ms of the bench line"}
             break
+    # durations of every kernel over the LAST region only (its share of the dispatches, by start time)
+    by_name = collections.defaultdict(list)
+    for r in rows:
+        by_name[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    last = []
+    for name, ds in by_name.items():
+        if not any(m in name for m in STEP_KERNELS):
+            continue
+        ds.sort()
+        n_last = max(1, len(ds) // REPEATS)
+        tail = [d for _, d in ds[-n_last:]]
+        last.append({"name": name[:110], "calls_in_last_region": len(tail), "avg_ns": sum(tail) / len(tail), "max_ns": max(tail), "avg_ns_all_regions": sum(d for _, d in ds) / len(ds)})
+    summary["kernel_durations_last_region"] = sorted(last, key=lambda r: -r["avg_ns"] * r["calls_in_last_region"])[:12]
 for log in glob.glob(f"{out}/bench_kt.log"):
     for line in open(log):
         if line.startswith("{"):
             summary["bench_line_under_profiler"] = {k: v for k, v in json.loads(line).items() if k in
-                                                    ("value", "ms_per_step", "steps", "warmup", "config", "roofline", "timed_region")}
+                                                    ("value", "ms_per_step", "steps", "warmup", "config", "roofline", "timed_region", "zero_segments")}
 
 
 def counters(sub):
@@ -90,7 +108,7 @@ for sub in ("fetch", "write", "sq", "grbm", "mix1", "mix2"):
 STEPS = 176.0   # 172 timed + 4 warm-up steps per run, unless the bench line of the run says otherwise
 _bl = summary.get("bench_line_under_profiler", {})
 if _bl.get("steps"):
-    STEPS = float(_bl["steps"] + _bl.get("warmup", 0))
+    STEPS = float(_bl["steps"] + _bl.get("warmup", 0)) * REPEATS
 summary["steps_per_run"] = STEPS
 summary["steps"], summary["warmup"] = _bl.get("steps"), _bl.get("warmup")
 
@@ -129,13 +147,13 @@ if summary.get("mix1"):
     named = f64 + f32 + mix["valu_trans_f32"] + mix["valu_cvt"] + mix["valu_int32"] + mix["valu_int64"]
     other = max(0.0, total - named)
     mix["f64_total"], mix["f32_total"], mix["other"] = f64, f32, other
-    FAST, NORMAL, SLOW = 1.05, 1.9, 3.4
+    FAST, NORMAL, SLOW = 1.05, 1.75, 3.4  # re-measured in round 4 without the s_nop the compiler puts behind every inline-asm statement (profiles/r04_inst_cost.log): normal 1.9 -> 1.75
     base = FAST * (f32 + mix["valu_int32"]) + NORMAL * (f64 + mix["valu_cvt"] + mix["valu_int64"]) + SLOW * mix["valu_trans_f32"]
     mix["cost_weighted_simd_ns"] = {"other_all_fast": base + FAST * other, "other_all_normal": base + NORMAL * other,
                                     "costs_ns": {"fast": FAST, "normal": NORMAL, "slow": SLOW}, "source": "docs/VALU_COSTS.md (measured on this chip)"}
     mix["shares"] = {"f64": f64 / total, "f32_arith": f32 / total, "conversions": mix["valu_cvt"] / total, "transcendental": mix["valu_trans_f32"] / total,
                      "int32": mix["valu_int32"] / total, "int64": mix["valu_int64"] / total, "other": other / total} if total else {}
-    mix["note"] = "wave-level instructions per step by class (PMC SQ_INSTS_VALU_*); cost_weighted_simd_ns = SIMD time these instructions need at their measured issue costs"
+    mix["note"] = "wave-level instructions per step by class (PMC SQ_INSTS_VALU_*); cost_weighted_simd_ns = the per-class prices of single-instruction loops summed over the mix: it OVER-prices (classes overlap in the pipe) and is not a bound — profiles/rNN_mix_bound.json (tools/micro/mix_bound.hip) is the measured one"
     summary["valu_mix_per_step"] = mix
 # The clock the chip held under each kernel (MI355X_MICROARCH.md, DVFS give-back): GRBM_GUI_ACTIVE is summed over the 8
 # XCDs, so clock = GRBM_GUI_ACTIVE / 8 / the dispatch's duration IN THE SAME PASS (a counter pass runs the kernels one
