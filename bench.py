@@ -697,12 +697,14 @@ def phase(text):
     PHASE["now"] = text
 
 
-def bench_workload(ctx, workload, sel, K, W, repeats, fused=True, grouped=True, render_ahead=True, dist=None, head_ahead=True):
+def bench_workload(ctx, workload, sel, K, W, repeats, fused=True, grouped=True, render_ahead=True, dist=None, head_ahead=True, paced=None):
     phase(f"timing {workload}, {len(sel)} voices, fused={fused}, grouped={grouped}, blocks {W}..{W + K - 1} x {repeats}")
     """Build the shard `sel` of a workload, time it, return the measurements (no parity, no JSON)."""
     wl = WORKLOADS[workload]
-    proj = PJ.Project(ctx, workload, sel, fused=fused, grouped=grouped, render_ahead=render_ahead, head_ahead=head_ahead)
+    proj = PJ.Project(ctx, workload, sel, fused=fused, grouped=grouped, render_ahead=render_ahead, head_ahead=head_ahead, paced=paced)
     forms = sorted({inst.kernel_form(FRAMES, fused and not fx) for inst, _, fx, _ in proj.banks})
+    walk = ("paced: renders two blocks ahead, four blocks in rotation, the host waits for the events itself, the bus reduction deferred into the next chain launch"
+            if proj.paced else "render-ahead (one block, device-side waits)" if proj.ahead_walk else "block by block")
     bus = ctx.bus((K + W) * FRAMES)
     span_mode = (fused and wl["kind"] != "chain") or (render_ahead and (wl["kind"] == "chain" or not fused))
     walls, kerns, extra = time_project(ctx, proj, bus, K, W, repeats, span_mode, dist)
@@ -711,7 +713,7 @@ def bench_workload(ctx, workload, sel, K, W, repeats, fused=True, grouped=True, 
     bus.destroy()
     order = np.argsort(walls)
     med = int(order[len(order) // 2])
-    return {"walls": walls, "kerns": kerns, "median": med, "span_mode": span_mode, "bus": out_bus, "kernel_form": forms, **extra}
+    return {"walls": walls, "kerns": kerns, "median": med, "span_mode": span_mode, "bus": out_bus, "kernel_form": forms, "walk": walk, **extra}
 
 
 def section_plan(world, rank, workload="welsh-1m", voices=0):
@@ -754,7 +756,7 @@ def config_entry(ctx, workload, repeats, parity_voices=64):
     return {"workload": workload, "voices": V, "blocks_timed": f"0..{K - 1} (the whole project, {K * FRAMES} frames)",
             "ms_per_step": ms[i], "ms_per_step_min": min(ms), "ms_per_step_repeats": ms,
             "value": fps, "unit": "stereo frames/s", "x_realtime_44k1": fps / SR,
-            "kernel_ms": m["kerns"][i], "kernel_form": m["kernel_form"],
+            "kernel_ms": m["kerns"][i], "kernel_form": m["kernel_form"], "walk": m["walk"],
             "frac": roof["frac"], "frac_is": "effective (SURVEY §8d algorithmic bytes / time)", "bound": roof["bound"],
             "hbm_physical_frac": roof.get("hbm_physical_frac"), "valu_achieved_frac": (roof.get("valu") or {}).get("achieved_frac"),
             "algorithmic_bytes_per_voice_frame": roof["algorithmic_bytes_per_voice_frame"],
@@ -866,6 +868,7 @@ def main():
     ap.add_argument("--no-render-ahead", action="store_true",
                     help="workloads with effect chains: render block b, then its effects (default: the render of block b+1 "
                          "is submitted to the side streams before the effects of block b)")
+    ap.add_argument("--no-pacing", action="store_true", help="workloads with effect chains: round 3's walk — renders one block ahead, device-side event waits, a reduction launch per block (A/B)")
     ap.add_argument("--no-head-ahead", action="store_true", help="render-ahead walk: keep the chain's leading IIR stage on the ctx stream (A/B)")
     ap.add_argument("--head-unfused", action="store_true", help="render-ahead walk: the IIR head behind the render as its own launch, not fused into the render kernel (A/B)")
     ap.add_argument("--dry-launch", action="store_true", help="rendezvous of the ranks over gloo only (no GPU): launcher test")
@@ -953,7 +956,8 @@ def measure(args, world, rank, local_rank):
     sel = np.arange(lo, hi, dtype=np.int64)
     m = bench_workload(ctx, args.workload, sel, K, W, R, fused=fused, grouped=not args.interleaved,
                        render_ahead=not args.no_render_ahead, dist=dist,
-                       head_ahead=False if args.no_head_ahead else ("unfused" if args.head_unfused else True))
+                       head_ahead=False if args.no_head_ahead else ("unfused" if args.head_unfused else True),
+                       paced=False if args.no_pacing else None)
     line = None
     if rank == 0:
         i = m["median"]
@@ -971,7 +975,7 @@ def measure(args, world, rank, local_rank):
             "config": {"workload": f"{args.workload}: {V_total} voices total, {FRAMES}-frame blocks, {SR} Hz, "
                                    f"{'fused render+mix' if fused else 'materialised blocks + mix kernels'}",
                        "voices_total": V_total, "voices_per_gpu": n_local,
-                       "kernel_form": m["kernel_form"],
+                       "kernel_form": m["kernel_form"], "walk": m["walk"],
                        "bus_reduce": (dist.reduce_via if dist else "none (one rank)"),
                        "parallelism": (f"voices sharded x{world} ("
                                        + (f"weak: {V} voices per GPU, the project grows with N; value = the merged project's frames/s, voice_frames_per_s scales"

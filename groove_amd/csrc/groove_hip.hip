@@ -199,10 +199,9 @@ struct groove_ctx {
   // events that mark the end of ONE kernel (a block's render, a block's last reduction) are bound to that dispatch's own
   // completion signal instead of being recorded behind it (a barrier packet each, ~5 us of the stream's timeline)
   uint32_t fm_tp_vpw4_min_voices = 4096; // GROOVE_FM_TP_VPW4_MIN_VOICES (0 = never): FM banks of at least this many voices, four voices per wavefront
-  // OFF by default since the end of round 3: with the binding on, 4 of 36 fresh runs of the driver's command stalled in the
-  // materialised million-voice forms (the kind streams waiting for a block's bound "free" event, profiles/r03_stall_hunt2.log);
-  // the binding was worth ~1 % there.  GROOVE_BIND_EVENTS=1 switches it on.
-  bool bind_events = false;
+  // (Round 3 switched this off when fresh runs stalled with it on; the stall was the zero-frame segment of DESIGN.md section 7,
+  // which had nothing to do with events.  On again in round 4; GROOVE_BIND_EVENTS=0 for A/B.)
+  bool bind_events = true;
   uint32_t fx_seg_max_lanes = 49152;     // biquad banks of up to this many lane-channels take the four-segment kernel (measured, tools/fx_bench.py: 8,192 lane-channels 17.5 -> 9.3 us, 32,768 19.4 -> 15.6, 131,072 42.9 -> 58.4; GROOVE_FX_SEG_MAX_LANES, 0 = never)
   uint32_t fx_tp_wide_min_lanes = 8192;  // from this many lane-channels the time-parallel IIR kernels take 32-wide tiles (GROOVE_FX_TP_WIDE_MIN_LANES)
   bool seq_allpass = false;             // GROOVE_FX_SEQ_ALLPASS=1: the sequential all-pass kernel (A/B and bit-identity tests)
@@ -227,7 +226,10 @@ struct groove_ctx {
   float* d_dpart[2] = {nullptr, nullptr};
   size_t dpart_cap[2] = {0, 0};
   int dpart_next = 0;
-  struct { const float* rows = nullptr; float* bus = nullptr; uint32_t n_rows = 0, frames = 0; int accumulate = 0; } deferred;
+  struct { const float* rows = nullptr; float* bus = nullptr; uint32_t n_rows = 0, frames = 0; int accumulate = 0; size_t owned_cap = 0; } deferred;
+  // groove_mix_deferred takes the block's row-sum buffer AWAY from the block (owned_cap != 0: the pending rows live in a buffer
+  // nobody else can write) and hands the block one of these instead; a consumed buffer comes back here (deferred_taken)
+  std::vector<std::pair<float*, size_t>> spare_sums;
   float* d_fseg = nullptr;   // fused path: seg[segments][2*frames]
   size_t fseg_cap = 0;
   int16_t* d_i16 = nullptr;
@@ -798,10 +800,17 @@ void launch_reduce(groove_ctx* ctx, const float* partial, uint32_t rows, uint32_
     else hipLaunchKernelGGL(partial_final_kernel, dim3(blocks_for(cols)), blk, 0, ctx->stream, seg_buf, segs, frames, bus_dev, accumulate);
   }
 }
+// The pending rows have been handed to a launch (or to bus_flush's reduction): a buffer groove_mix_deferred took from a block is
+// a spare from now on (stream order protects it: whoever is given it next writes it behind that launch — DESIGN.md section 5).
+void deferred_taken(groove_ctx* ctx) {
+  if (ctx->deferred.rows && ctx->deferred.owned_cap) ctx->spare_sums.emplace_back(const_cast<float*>(ctx->deferred.rows), ctx->deferred.owned_cap);
+  ctx->deferred.rows = nullptr;
+  ctx->deferred.owned_cap = 0;
+}
 int bus_flush(groove_ctx* ctx) {
   if (!ctx->deferred.rows) return 0;
   const auto d = ctx->deferred;
-  ctx->deferred.rows = nullptr;
+  deferred_taken(ctx);
   if (ensure_seg_buffer(ctx, &ctx->d_fseg, &ctx->fseg_cap, (size_t)((d.n_rows + kRowsPerSeg - 1) / kRowsPerSeg) * 2 * d.frames)) return 1;
   launch_reduce(ctx, d.rows, d.n_rows, d.frames, ctx->d_fseg, d.bus, d.accumulate);
   return hipGetLastError() == hipSuccess ? 0 : fail(ctx, "bus_flush: launch failed");
@@ -1090,6 +1099,8 @@ void groove_shutdown(groove_ctx* ctx) {
   if (ctx->d_fseg) (void)hipFree(ctx->d_fseg);
   if (ctx->d_i16) (void)hipFree(ctx->d_i16);
   if (ctx->d_diag) (void)hipFree(ctx->d_diag);
+  if (ctx->deferred.rows && ctx->deferred.owned_cap) (void)hipFree(const_cast<float*>(ctx->deferred.rows));
+  for (auto& sp : ctx->spare_sums) (void)hipFree(sp.first);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   for (int i = 0; i < kSideStreams; ++i) {
     if (side_stream_owned(ctx, i)) { (void)hipStreamSynchronize(ctx->side_stream[i]); (void)hipStreamDestroy(ctx->side_stream[i]); }
@@ -1880,7 +1891,7 @@ int groove_bank_render_mix_deferred(groove_bank* b, uint32_t frames, float* bus_
       }
       UniformArgs a = uniform_args(b, ctx->d_dpart[slot], ctx->d_dpart[slot], 0, 0, frames, urows);
       if (ctx->deferred.rows) { a.prev.rows = ctx->deferred.rows; a.prev.bus = ctx->deferred.bus; a.prev.n_rows = ctx->deferred.n_rows; a.prev.frames = ctx->deferred.frames; a.prev.accumulate = ctx->deferred.accumulate; }
-      ctx->deferred.rows = nullptr;
+      deferred_taken(ctx);
       b->ctx_touched = true;
       launch_small_uniform(b, a, ctx->stream, true, frames);
       GHIP(ctx, hipGetLastError());
@@ -1908,7 +1919,7 @@ int groove_bank_render_mix_deferred(groove_bank* b, uint32_t frames, float* bus_
   }
   TpPrev prev;
   if (ctx->deferred.rows) { prev.rows = ctx->deferred.rows; prev.bus = ctx->deferred.bus; prev.n_rows = ctx->deferred.n_rows; prev.frames = ctx->deferred.frames; prev.accumulate = ctx->deferred.accumulate; }
-  ctx->deferred.rows = nullptr;
+  deferred_taken(ctx);
   b->ctx_touched = true;
   launch_tp(b, frames, true, 0, ctx->d_dpart[slot], ctx->d_dpart[slot], ctx->stream, nullptr, nullptr, prev.rows ? &prev : nullptr, svpw);
   GHIP(ctx, hipGetLastError());
@@ -2119,6 +2130,10 @@ static int fx_launch_run(groove_ctx* ctx, groove_fx* const* run, uint32_t count,
   float* rows = last ? block_sums(io, wg_per_ch, frames) : nullptr;
   if (last && !rows) return 1;
   a.frames = frames; a.wg_per_ch = wg_per_ch;
+  if (ctx->deferred.rows && st == ctx->stream) { // groove_mix_deferred: this launch sums the pending block's rows onto its bus
+    a.prev.rows = ctx->deferred.rows; a.prev.bus = ctx->deferred.bus; a.prev.n_rows = ctx->deferred.n_rows; a.prev.frames = ctx->deferred.frames; a.prev.accumulate = ctx->deferred.accumulate;
+    deferred_taken(ctx);
+  }
   a.rows = (rv && direct) ? nullptr : rows;
   if (rv && !direct) rows = nullptr; // the sequential / chunked all-pass kernels run last and leave none
   if (V == 4) hipLaunchKernelGGL(fx_run_kernel<4>, dim3(2 * wg_per_ch, frames), blk, 0, st, a);
@@ -2395,6 +2410,40 @@ int groove_mix(groove_ctx* ctx, groove_block* const* blocks, uint32_t n_blocks, 
       blk->free_marked = mark;
     } else if (mix_one(ctx, blocks[i], frames, bus_dev, accumulate || i > 0)) return 1;
   }
+  return 0;
+}
+// groove_mix for ONE block whose lane sums are valid (a render or an effect chain has just left them), with the reduction of
+// those few rows DEFERRED: the next fused effect-chain launch on the ctx stream (fx_run_kernel), the next deferred render, or
+// bus_flush puts them on the bus.  Anything else: groove_mix.
+int groove_mix_deferred(groove_ctx* ctx, groove_block* blk, uint32_t frames, float* bus_dev, int accumulate) {
+  if (!ctx || !bus_dev || !blk) return fail(ctx, "groove_mix_deferred: NULL argument");
+  if (frames == 0) return 0;
+  if (!(blk->sums_valid && blk->sum_frames == frames && blk->sum_rows <= 2048 && frames <= 4096)) return groove_mix(ctx, &blk, 1, frames, bus_dev, accumulate);
+  GHIP(ctx, hipSetDevice(ctx->device));
+  if (bus_flush(ctx)) return 1; // an earlier pending block nobody carried: its own reduction launch, first (order of the bus's sums)
+  if (block_acquire(blk)) return 1;
+  ctx->deferred.rows = blk->d_sums; ctx->deferred.bus = bus_dev; ctx->deferred.n_rows = blk->sum_rows; ctx->deferred.frames = frames; ctx->deferred.accumulate = accumulate;
+  // the rows leave the block: whatever writes the block's lane sums next (its next render may run on another stream) cannot touch them
+  ctx->deferred.owned_cap = blk->sums_cap;
+  blk->d_sums = nullptr; blk->sums_cap = 0; blk->sums_valid = false;
+  if (!ctx->spare_sums.empty()) { blk->d_sums = ctx->spare_sums.back().first; blk->sums_cap = ctx->spare_sums.back().second; ctx->spare_sums.pop_back(); }
+  return 0;
+}
+// HOST PACING.  A wait for another queue's event costs the waiting stream 7 - 9 us of its timeline whether or not the event has
+// completed by the time the stream gets there (docs/STREAMS.md item 13), but the runtime drops a wait whose event is already
+// complete when the call is made.  An offline host has nothing else to do: it can wait for the event itself, and the streams
+// then carry no wait packets at all.
+int groove_block_wait_ready(groove_block* b) {
+  if (!b) return fail(nullptr, "groove_block_wait_ready: block is NULL");
+  groove_ctx* ctx = b->ctx;
+  for (int k = 0; k < kSideStreams; ++k)
+    if (b->ready_mask & (1u << k)) GHIP(ctx, wait_deadline(ctx, nullptr, b->ev_ready[k], "groove_block_wait_ready"));
+  b->ready_mask = 0; // complete: what the host submits from now on is ordered behind it without a device-side wait
+  return 0;
+}
+int groove_block_wait_released(groove_block* b) {
+  if (!b) return fail(nullptr, "groove_block_wait_released: block is NULL");
+  if (b->released && b->ev_free) GHIP(b->ctx, wait_deadline(b->ctx, nullptr, b->ev_free, "groove_block_wait_released"));
   return 0;
 }
 int groove_block_accumulate(groove_block* dst, groove_block* src, uint32_t frames, int accumulate) {

@@ -72,6 +72,12 @@ __device__ __forceinline__ void soa_store(uint32_t* __restrict__ buf, uint32_t n
 #endif
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
+// Which entry of the kind-sorted workgroup list (cheapest base kind first) workgroup blockIdx.x of a launch takes: from the END.
+// The most expensive kinds start first (longest-processing-time-first), so that a launch of more than one round of workgroups does
+// not end with its longest workgroups alone on the chip.  Same results (a workgroup's voices do not care when they run); measured
+// against the forward order in one job, blocks 5-24 (profiles/r04_wg_order_ab.log): 250,000 voices 0.188 / 0.183 -> 0.177 / 0.181 ms
+// per block, 350,000 0.242 / 0.246 -> 0.230 / 0.235, 500,000 0.302 / 0.319 -> 0.290 / 0.290; 125,000, 1,000,000 and config #5 unchanged.
+#define GROOVE_WG_SLOT(n_wgs) ((n_wgs) - 1u - blockIdx.x)
 
 // ------------------------------------------------------------------ wave-uniform parameters
 // Voices of one synth share a patch (the reference's WelshSynth is one patch + a voice
@@ -180,7 +186,10 @@ struct FusedAcc {
   }
 };
 // The planar block's stores.  (Non-temporal stores and whole 1 KB rows out of the bus tile were both measured in round 3 and
-// lost to this plain form: docs/HISTORY.md.)
+// lost to this plain form: docs/HISTORY.md.  So did, in round 4, a STORE WAVE — a fifth wavefront per workgroup that drains a
+// double-buffered tile, so that the four voice wavefronts issue no store, no address arithmetic and no tile turn: the
+// materialised million-voice window 0.885 - 0.891 ms per block against 0.790 - 0.796 in one job, profiles/r04_store_wave_ab.log.
+// The stores are not what the voice waves wait for; a fifth wave per workgroup is a fifth of the wave slots.)
 __device__ __forceinline__ void block_store(float* __restrict__ p, float x) { *p = x; }
 // Shared frame loop of the instrument kernels: `frame(f, L, R)` computes one frame of this
 // lane's voice; the epilogue either stores the planar block or feeds the fused bus sum.
@@ -409,7 +418,7 @@ __device__ __forceinline__ UniformArgsPtr uniform_args_scalar(UniformArgsPtr a) 
 }
 template <bool FUSED, int LFO_MODE, bool RETUNE, int C1, int C2, int CL, bool REST = false>
 __device__ __forceinline__ void welsh_uniform_body_impl(UniformArgsPtr a) {
-  const uint32_t wg = a->wg_list[blockIdx.x]; // scalar load: the workgroup of virtual waves this block renders
+  const uint32_t wg = a->wg_list[GROOVE_WG_SLOT(a->n_wgs)]; // scalar load: the workgroup of virtual waves this block renders
   const uint32_t n_waves = a->n_waves, n = a->n;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t w0 = wg * kWaves + (threadIdx.x >> 6);
@@ -443,7 +452,7 @@ GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_uniform_body
 // rows and leaves.  Two state words per lane, one vote; nothing else is loaded.  Returns true if
 // the workgroup is done.
 __device__ __forceinline__ bool welsh_idle_workgroup(const UniformArgs& a) {
-  const uint32_t wg = a.wg_list[blockIdx.x];
+  const uint32_t wg = a.wg_list[GROOVE_WG_SLOT(a.n_wgs)];
   const uint32_t w0 = wg * kWaves + (threadIdx.x >> 6);
   const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(w0, a.n_waves - 1));
   const uint32_t vbase = a.waves[w].vbase, count = a.waves[w].count;
@@ -504,7 +513,7 @@ __global__ __launch_bounds__(kThreads, (WavesBudget<LFO_MODE, RETUNE>::value)) G
   if constexpr (!SPECIALISED) {
     welsh_uniform_body_impl<FUSED, LFO_MODE, RETUNE, OSC_ANY, OSC_ANY, OSC_ANY>(ka);
   } else {
-    welsh_dispatch_class<FUSED, LFO_MODE, RETUNE>((uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[blockIdx.x]), ka);
+    welsh_dispatch_class<FUSED, LFO_MODE, RETUNE>((uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[GROOVE_WG_SLOT(a.n_wgs)]), ka);
   }
   GROOVE_HB_DONE;
 #undef GROOVE_HB_DONE
@@ -518,8 +527,8 @@ template <bool FUSED>
 __global__ __launch_bounds__(kThreads, GROOVE_WAVES_ANY) GROOVE_NO_TAIL_CALLS void welsh_render_uniform_any_kernel(UniformArgs a, const uint8_t* __restrict__ wg_base) {
   const UniformArgsPtr ka = (UniformArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   if constexpr (FUSED) { tp_reduce_prev(a.prev, threadIdx.x, blockIdx.x, gridDim.x); if (welsh_idle_workgroup(a)) return; }
-  const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wg_base[blockIdx.x]);
-  const uint32_t cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[blockIdx.x]);
+  const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wg_base[GROOVE_WG_SLOT(a.n_wgs)]);
+  const uint32_t cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[GROOVE_WG_SLOT(a.n_wgs)]);
   switch (base) {
     case wg_base_kind_of(LFO_F32, false): welsh_dispatch_class<FUSED, LFO_F32, false>(cls, ka); break;
     case wg_base_kind_of(LFO_F32, true): welsh_dispatch_class<FUSED, LFO_F32, true>(cls, ka); break;
@@ -1185,6 +1194,7 @@ struct FxRunArgs {
   uint32_t n_stages, n;
   float* rows;          // not null: the launch also leaves the block's lane sums, rows[wg_per_ch][2][frames] (fx_row_sum)
   uint32_t frames, wg_per_ch;
+  TpPrev prev;          // groove_mix_deferred: an earlier block's lane sums, put on their bus by this launch (tp_reduce_prev)
 };
 // Grid of the (frame, lane-channel) effect kernels: blockIdx.y = frame, blockIdx.x = (channel, group of 256 * V lanes) —
 // a workgroup never straddles the two channels, so its sum is one entry of the block's lane sums.
@@ -1272,6 +1282,7 @@ template <int V>
 __global__ __launch_bounds__(kThreads) void fx_run_kernel(FxRunArgs a) {
   const uint32_t ch = blockIdx.x / a.wg_per_ch, group = blockIdx.x % a.wg_per_ch;
   const uint32_t lane = (group * kThreads + threadIdx.x) * V, f = blockIdx.y;
+  tp_reduce_prev(a.prev, threadIdx.x, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
   // (every thread of the workgroup reaches the ONE fx_row_sum call below: it holds a barrier)
   const float mine = lane < a.n ? fx_run_element<V>(a, ch, lane, f) : 0.0f;
   if (a.rows) fx_row_sum(mine, a.rows, a.frames, group, ch, f);

@@ -58,7 +58,7 @@ __device__ __forceinline__ void soa_store_range(uint32_t* __restrict__ buf, uint
 struct SplitWave { WaveDesc d; uint32_t wg, l, v; bool active; };
 __device__ __forceinline__ SplitWave split_wave(UniformArgsPtr a, uint32_t local /* 0 .. 255 within the role */) {
   SplitWave w;
-  w.wg = a->wg_list[blockIdx.x];
+  w.wg = a->wg_list[GROOVE_WG_SLOT(a->n_wgs)];
   w.l = local;
   const uint32_t lane = local & 63u;
   const uint32_t w0 = w.wg * kSplitVw + (local >> 6);
@@ -194,7 +194,7 @@ GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split_mid(Un
   const UniformArgsPtr a = uniform_args_scalar(ka);
   SplitLds& lds = split_lds();
   const uint32_t l = threadIdx.x - kSplitLanes;
-  const uint32_t frames = a->frames, wg = a->wg_list[blockIdx.x];
+  const uint32_t frames = a->frames, wg = a->wg_list[GROOVE_WG_SLOT(a->n_wgs)];
   RenderConsts rc{a->rc.pi_over_sr, a->rc.fc_max, a->rc.log2_x0, a->rc.x_lo, a->rc.x_hi};
   if constexpr (RETUNE) asm volatile("" : "+v"(rc.tan_k1), "+v"(rc.tan_k2), "+v"(rc.log2_x0), "+v"(rc.x_hi));
   float* __restrict__ rows = a->rows;
@@ -549,7 +549,7 @@ GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split4_back(
 // A workgroup whose voices are all silent with both envelopes idle writes its zero rows and leaves (kernels.h
 // welsh_idle_workgroup); every role-wave looks at its own virtual wave.
 __device__ __forceinline__ bool welsh_split_idle_workgroup(const UniformArgs& a, uint32_t threads) {
-  const uint32_t wg = a.wg_list[blockIdx.x];
+  const uint32_t wg = a.wg_list[GROOVE_WG_SLOT(a.n_wgs)];
   const uint32_t local = threadIdx.x % kSplitLanes;
   const uint32_t w0 = wg * kSplitVw + (local >> 6);
   const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(w0, a.n_waves - 1));
@@ -611,8 +611,8 @@ __global__ __launch_bounds__(ROLES * kSplitLanes, GROOVE_WAVES_SPLIT) GROOVE_NO_
   const UniformArgsPtr ka = (UniformArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   if constexpr (FUSED) { tp_reduce_prev(a.prev, threadIdx.x, blockIdx.x, gridDim.x); if (welsh_split_idle_workgroup(a, ROLES * kSplitLanes)) return; }
   // (s_setprio 3 here changes nothing: config #5 0.100-0.105 against 0.103-0.107 ms per block, round 3)
-  const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wg_base[blockIdx.x]);
-  const uint32_t cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[blockIdx.x]);
+  const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wg_base[GROOVE_WG_SLOT(a.n_wgs)]);
+  const uint32_t cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[GROOVE_WG_SLOT(a.n_wgs)]);
   const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kSplitLanes));
   const bool retune = (base & 1u) != 0;
   if (role == 0) {
@@ -661,8 +661,8 @@ template <bool FUSED>
 __global__ __launch_bounds__(4 * kSplitLanes, GROOVE_WAVES_SPLIT) GROOVE_NO_TAIL_CALLS void welsh_render_split4_kernel(UniformArgs a, const uint8_t* __restrict__ wg_base) {
   const UniformArgsPtr ka = (UniformArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   if constexpr (FUSED) { tp_reduce_prev(a.prev, threadIdx.x, blockIdx.x, gridDim.x); if (welsh_split_idle_workgroup(a, 4 * kSplitLanes)) return; }
-  const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wg_base[blockIdx.x]);
-  const uint32_t cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[blockIdx.x]);
+  const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wg_base[GROOVE_WG_SLOT(a.n_wgs)]);
+  const uint32_t cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[GROOVE_WG_SLOT(a.n_wgs)]);
   const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kSplitLanes));
   const bool retune = (base & 1u) != 0;
   const bool f32 = base == (uint32_t)wg_base_kind_of(LFO_F32, false) || base == (uint32_t)wg_base_kind_of(LFO_F32, true);

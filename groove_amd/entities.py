@@ -132,6 +132,10 @@ class Context:
         arr = (C.c_void_p * len(blocks))(*[b.h for b in blocks])
         _lib.check(self.L.groove_mix(self.h, arr, len(blocks), frames, bus.ptr, 1 if accumulate else 0), self.h)
 
+    def mix_deferred(self, block, frames, bus, accumulate=False):
+        """groove_mix_deferred: the block's few lane-sum rows ride in the next effect-chain launch (or flush_bus)."""
+        _lib.check(self.L.groove_mix_deferred(self.h, block.h, frames, bus.ptr, 1 if accumulate else 0), self.h)
+
     # the effects patched behind one instrument, in patch order, over one block (same bits as one transform_audio each)
     def transform_chain(self, effects, block, frames=None):
         frames = block.cap if frames is None else frames
@@ -200,6 +204,14 @@ class Block:
     def release(self):
         """groove_block_release: the block's consumers so far are all that the next asynchronous render into it waits for."""
         _lib.check(self.ctx.L.groove_block_release(self.h), self.ctx.h)
+
+    def wait_ready(self):
+        """Host pacing: block the host until the asynchronous render that last filled this block has finished."""
+        _lib.check(self.ctx.L.groove_block_wait_ready(self.h), self.ctx.h)
+
+    def wait_released(self):
+        """Host pacing: block the host until the point of the last release() has passed on the ctx stream."""
+        _lib.check(self.ctx.L.groove_block_wait_released(self.h), self.ctx.h)
 
     def destroy(self):
         if self.h:

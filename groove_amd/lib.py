@@ -65,6 +65,9 @@ SYMBOLS = {
     "groove_bank_render_async": (_i, [_vp, _u32, _vp]),
     "groove_block_acquire": (_i, [_vp]),
     "groove_block_release": (_i, [_vp]),
+    "groove_block_wait_ready": (_i, [_vp]),
+    "groove_block_wait_released": (_i, [_vp]),
+    "groove_mix_deferred": (_i, [_vp, _vp, _u32, _vp, _i]),
     "groove_bank_render_mix": (_i, [_vp, _u32, _vp, _i]),
     "groove_bank_render_mix_deferred": (_i, [_vp, _u32, _vp, _i]),
     "groove_bus_flush": (_i, [_vp]),

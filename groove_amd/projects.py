@@ -30,6 +30,9 @@ from . import entities as E
 from . import patches as P
 
 FRAMES = T.BLOCK_FRAMES
+PACED_SLACK = 0  # extra blocks in a paced rotation (Project).  Measured, chain-4096, two runs each in one job (ms per block): 0 extra blocks
+                 # 0.0507 / 0.0505, 1: 0.0510 / 0.0513, 2: 0.0513 / 0.0513, 3: 0.0514 / 0.0521, 5: 0.0526 / 0.0526 (unpaced: 0.0535 / 0.0547) —
+                 # the host keeping further ahead buys nothing, and every extra block is 8 MB more for the caches to hold
 TAKE_TURNS_MAX_VOICES = int(__import__("os").environ.get("GROOVE_TAKE_TURNS_MAX_VOICES", "16384"))  # multi-bank projects up to this size: banks in turn on the ctx stream
 
 WORKLOADS = {
@@ -122,8 +125,15 @@ class Project:
     (instruments render, their chains run, the mix bus sums: Orchestrator::tick / gather_audio,
     /root/reference/orchestration/src/orchestrator.rs:856-877, 367-470)."""
 
-    def __init__(self, ctx, workload, sel, fused=True, grouped=True, render_ahead=True, bank_scale=1.0, head_ahead=True):
+    def __init__(self, ctx, workload, sel, fused=True, grouped=True, render_ahead=True, bank_scale=1.0, head_ahead=True, paced=None):
         self.ctx, self.fused, self.workload = ctx, fused, workload
+        # PACED walk (instruments with an effect chain; default for them): the renders go out TWO blocks ahead into a rotation of
+        # four blocks, and the host itself waits for the two events a step depends on — the release of the block the new render
+        # fills (two steps old) and the render of the block the chain is about to take (two steps old as well) — so that both are
+        # complete when the calls are made and neither stream carries a cross-queue wait packet (groove_block_wait_released /
+        # _ready; docs/STREAMS.md item 13: 7 - 9 us of the waiting stream's timeline each).  The block's bus reduction rides in
+        # the next block's chain launch (groove_mix_deferred).  paced=False: round 3's walk (one block ahead, device-side waits).
+        self.paced = paced
         self.head_ahead = head_ahead      # render-ahead walk: the chain's leading IIR stages ride behind the render (groove_fx_chain_process_async)
         self.head_done = {}               # block handle -> stages of its chain already processed
         self.period = WORKLOADS[workload]["blocks"]
@@ -150,6 +160,10 @@ class Project:
         # streams the way the fused path's do — one block alone costs its thinly occupied tail (0.70 against 0.54 ms at
         # 1,000,000 voices)
         self.ahead_walk = self.render_ahead and (self.has_chain or not fused)
+        if self.paced is None:
+            self.paced = self.ahead_walk and self.has_chain
+        self.paced = bool(self.paced and self.ahead_walk)
+        self.lookahead = 2 if self.paced else 1
         # A small fused project (a lone bank; or a few small banks — config #5's 16,384-voice share of a GPU) renders its banks one
         # after the other on the ctx stream, every render carrying the bus reduction of the one before it
         # (groove_bank_render_mix_deferred): one launch per bank and block, no cross-queue waits.  Bigger banks render side by side.
@@ -181,23 +195,37 @@ class Project:
         ctx = self.ctx
         if ev_pair is not None and ev_pair[0] is not None:
             ctx.record(ev_pair[0])
+        L = self.lookahead
         if not self.primed:
-            self._events(self.block_index)
             for inst, block, fx, _ in self.banks:
                 if inst not in self.ahead:
-                    self.ahead[inst] = [block, ctx.block(inst.n, FRAMES), ctx.block(inst.n, FRAMES)]
-                self._render_ahead(inst, fx, self.ahead[inst][0])
+                    # L + 1 blocks are in use at any time; the paced walk adds slack: the block a render fills was released
+                    # PACED_SLACK + 1 steps ago, so the host — which waits for that release — may run that far ahead of the GPU
+                    self.ahead[inst] = [block] + [ctx.block(inst.n, FRAMES) for _ in range(L + 1 + (PACED_SLACK if self.paced else 0))]
+            for d in range(L):  # blocks b .. b + L - 1
+                self._events(self.block_index + d)
+                for inst, _, fx, _ in self.banks:
+                    self._render_ahead(inst, fx, self.ahead[inst][d])
             self.primed = True
-        self._events(self.block_index + 1)
+        self._events(self.block_index + L)
         self.block_index += 1
         for inst, _, fx, _ in self.banks:
-            # the block this render fills was released a whole step ago: no cross-queue wait (groove_block_release)
-            self._render_ahead(inst, fx, self.ahead[inst][1])
+            # the block this render fills was released L steps ago: no cross-queue wait (groove_block_release) — and in the paced walk
+            # the host has SEEN that release complete, so the side stream carries no wait packet at all
+            nxt = self.ahead[inst][L]
+            if self.paced:
+                nxt.wait_released()
+            self._render_ahead(inst, fx, nxt)
         first = True
         for inst, _, fx, _ in self.banks:
             cur = self.ahead[inst][0]
+            if self.paced:
+                cur.wait_ready()
             ctx.transform_chain(fx[self.head_done.pop(id(cur), 0):], cur, FRAMES)
-            ctx.mix([cur], FRAMES, E._Slice(bus, frame0), accumulate=not first)
+            if self.paced:
+                ctx.mix_deferred(cur, FRAMES, E._Slice(bus, frame0), accumulate=not first)
+            else:
+                ctx.mix([cur], FRAMES, E._Slice(bus, frame0), accumulate=not first)
             cur.release()
             self.ahead[inst] = self.ahead[inst][1:] + [cur]
             first = False

@@ -158,6 +158,16 @@ int groove_bank_render(groove_bank* bank, uint32_t frames, groove_block* out);
 int groove_bank_render_async(groove_bank* bank, uint32_t frames, groove_block* out);
 /* Orders the ctx stream after the asynchronous render that last filled `b` (no-op otherwise). */
 int groove_block_acquire(groove_block* b);
+/* HOST PACING (no reference counterpart; the reference's audio path is synchronous).  A device-side wait for another queue's
+ * event costs the waiting stream 7 - 9 us whether or not the event has completed when the stream gets there, but a wait whose
+ * event is already complete WHEN THE CALL IS MADE is dropped.  An offline host that has nothing else to do waits itself:
+ * groove_block_wait_ready blocks the host (with the deadline of groove_synchronize) until the asynchronous render — and chain
+ * head — that last filled `b` has finished, after which the ctx-stream operations on `b` carry no wait;
+ * groove_block_wait_released blocks it until the point marked by the last groove_block_release(b) has passed, after which the
+ * next groove_bank_render_async into `b` carries none.  With four blocks per instrument in rotation and the renders submitted
+ * two blocks ahead both return at once in steady state (bench.py --workload chain-4096). */
+int groove_block_wait_ready(groove_block* b);
+int groove_block_wait_released(groove_block* b);
 /* Marks the end of the block's consumers so far (one event on the ctx stream).  The next
  * groove_bank_render_async into `b` then waits for this point only — not for everything submitted to
  * the ctx stream by the time of that call — provided nothing uses the block on the ctx stream in
@@ -186,7 +196,10 @@ int groove_bank_render_mix(groove_bank* bank, uint32_t frames, float* bus_dev, i
  * also take turns this way — each render carries the reduction of the one before it, in submission order, all on the ctx stream —
  * instead of running side by side with their cross-queue waits (config #5's 16,384-voice share of a GPU).  Banks it does not apply to
  * (not time-parallel, more than 2,048 partial rows — 16,384 paired Welsh voices) are rendered by groove_bank_render_mix.  The bus
- * is the same sum in a fixed order (row by row instead of in segments of rows: equal to fp32 rounding). */
+ * is the same sum to fp32 rounding, but NOT the same bits as groove_bank_render_mix's, nor from one call pattern to another: the
+ * order in which a column's rows are added depends on which launch carries them (a following deferred render adds them in batches
+ * of eight rows per lane, partitioned by ITS grid; groove_bus_flush and the flush points add them in segments of 64 rows).  A
+ * host that needs bit-reproducible buses calls groove_bank_render_mix. */
 int groove_bank_render_mix_deferred(groove_bank* bank, uint32_t frames, float* bus_dev, int accumulate);
 int groove_bus_flush(groove_ctx* ctx);
 /* Every voice back to its freshly created state (oscillator phases, envelopes idle, filter memory,
@@ -242,6 +255,14 @@ int groove_fx_set_params(groove_fx* fx, const groove_fx_params* p, uint32_t n);
 /* bus_dev[f][ch] (+)= sum over blocks and lanes of block[ch][f][lane]. */
 int groove_mix(groove_ctx* ctx, groove_block* const* blocks, uint32_t n_blocks, uint32_t frames,
                float* bus_dev, int accumulate);
+/* groove_mix of ONE block that a render or an effect chain has just filled (its lane sums are still valid: a few short rows),
+ * with the reduction of those rows DEFERRED the way groove_bank_render_mix_deferred defers a render's: the next effect-chain
+ * launch on the ctx stream (or the next deferred render) sums them onto the bus in passing, and groove_bus_flush — or any call
+ * that waits for the ctx stream, records an event on it or touches a bus — does it at the latest.  For the host that walks a
+ * chain block after block (render, effects, main-mixer sum: orchestrator.rs:397-457): the step loses a launch that is all
+ * latency.  A block without valid lane sums (or with more than 2,048 rows) is mixed by groove_mix at once.  No reference
+ * counterpart. */
+int groove_mix_deferred(groove_ctx* ctx, groove_block* block, uint32_t frames, float* bus_dev, int accumulate);
 /* Device scratch the caller can use as a bus: frames*2 floats, zeroed. */
 int groove_bus_create(groove_ctx* ctx, size_t frames, float** out_dev);
 int groove_bus_destroy(groove_ctx* ctx, float* bus_dev);

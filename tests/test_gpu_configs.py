@@ -122,9 +122,13 @@ def test_config3_chain_4096_full_size(gpu_ctx, oracle):
     for e in fx:
         e.destroy()
     synth.destroy(); block.destroy(); bus.destroy()
-    # bench.py's software-pipelined walk (render of block b+1 beside the effects of block b) gives the same bus
-    ahead = _render(gpu_ctx, "chain-4096", np.arange(V), blocks)
-    assert np.array_equal(ahead.astype(np.float32).view(np.uint32), plain.astype(np.float32).view(np.uint32))
+    # bench.py's software-pipelined walks give the same bus, bit for bit: the paced one (renders two blocks ahead, the host
+    # waits for the events itself, the bus reduction deferred into the next chain launch — four lane-sum rows, summed in the same
+    # order by either path) and round 3's (one block ahead, device-side waits, a reduction launch per block)
+    for paced in (True, False):
+        ahead = _render(gpu_ctx, "chain-4096", np.arange(V), blocks, paced=paced)
+        assert np.array_equal(ahead.astype(np.float32).view(np.uint32), plain.astype(np.float32).view(np.uint32)), paced
+    assert gpu_ctx.debug_info()["zero_segments"] == 0
 
 
 def test_config4_sampler_16384_full_size(gpu_ctx, oracle):

@@ -161,3 +161,39 @@ def test_deferred_serial_small_bank_forms(gpu_ctx, n, blocks):
     assert "role-split" in forms[0] or "all base kinds" in forms[0], forms
     assert np.sqrt(np.mean(buses[1] ** 2)) > 1e-3
     assert np.abs(buses[0] - buses[1]).max() <= 2e-6
+
+
+def test_mix_deferred_rides_in_the_next_chain_launch_or_a_flush(gpu_ctx):
+    """groove_mix_deferred: a chain's lane sums are put on the bus by the NEXT effect-chain launch on the ctx stream, or by
+    groove_bus_flush / anything that waits for the ctx stream — the same bus as groove_mix (1,024-lane groups: <= 8 rows, equal
+    to fp32 rounding; here 2 rows: the same bits).  A block without valid lane sums is mixed at once."""
+    from groove_amd import entities as E
+    n, frames, blocks = 2048, 256, 6
+    params, vidx = P.welsh_voices_grouped(n)
+    on = P.grouped_note_events(vidx, True)
+    fxp = lambda **kw: (T.FxParams * n)(*[T.fx_params(**kw) for _ in range(n)])
+    outs = []
+    for deferred in (False, True):
+        synth = E.WelshSynth(gpu_ctx, params)
+        chain = [E.Effect(gpu_ctx, T.FX_GAIN, fxp(ceiling=0.5)), E.Effect(gpu_ctx, T.FX_DELAY, fxp(delay_seconds=0.01))]  # one fused run launch
+        block = gpu_ctx.block(n, frames)
+        bus = gpu_ctx.bus(blocks * frames)
+        synth.handle_midi_events(on)
+        for b in range(blocks):
+            synth.generate_batch_values(block, frames)
+            gpu_ctx.transform_chain(chain, block, frames)      # in the deferred walk this launch carries block b - 1's rows
+            if deferred:
+                gpu_ctx.mix_deferred(block, frames, E._Slice(bus, b * frames))
+            else:
+                gpu_ctx.mix([block], frames, E._Slice(bus, b * frames))
+        outs.append(bus.download())                            # (a download waits for the ctx stream: the last block is flushed)
+        # a block whose lane sums are gone (an upload) takes the plain path at once
+        block.upload(np.ones((2, frames, n), dtype=np.float32))
+        bus2 = gpu_ctx.bus(frames)
+        gpu_ctx.mix_deferred(block, frames, bus2)
+        assert np.allclose(bus2.download(), float(n), rtol=1e-6)
+        for e in chain:
+            e.destroy()
+        synth.destroy(); block.destroy(); bus.destroy(); bus2.destroy()
+    assert np.abs(outs[0]).max() > 1.0
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
