@@ -596,12 +596,14 @@ def time_project(ctx, proj, bus, K, W, repeats, span_mode, dist=None):
     extra = {"own_walls": own}
     if dist:  # outside every timed region: what the ONE collective of a render costs by itself (barrier, reduce, sync; max over ranks)
         alone = []
+        scratch = ctx.bus(K * FRAMES)  # (a bus of the same size: the timed region's own bus keeps what the render left in it)
         for _ in range(3):
             dist.sync()
             t0 = time.perf_counter()
-            dist.reduce_bus(bus, W * FRAMES, K * FRAMES)
+            dist.reduce_bus(scratch, 0, K * FRAMES)
             dist.sync()
             alone.append(dist.max_over_ranks(time.perf_counter() - t0))
+        scratch.destroy()
         extra["reduce_alone_ms"] = sorted(alone)[1] * 1e3
         extra["walls_by_rank"] = dist.gather(own)  # [rank][repeat]
     return walls, kerns, extra
