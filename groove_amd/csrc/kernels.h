@@ -1169,6 +1169,27 @@ template <int V> __device__ __forceinline__ VecF<V> vload(const float* p) {
   }
   return r;
 }
+// Ring accesses of the fused run are NON-TEMPORAL: every ring row is read once and written once per trip round the ring, a ring
+// length apart (hundreds of MB later), so keeping it in L2 / MALL only displaces what the chain does re-read — the block the render
+// has just written, the comb sums the all-pass kernel is about to take.  Config #3, one job: 0.0507 / 0.0509 / 0.0511 -> 0.0487 /
+// 0.0487 / 0.0481 ms per block (profiles/r04_ring_nt_ab.log); same bits.
+typedef float groove_v4f __attribute__((ext_vector_type(4)));
+template <int V> __device__ __forceinline__ VecF<V> vload_ring(const float* p) {
+  VecF<V> r;
+  if constexpr (V == 4) { const groove_v4f q = __builtin_nontemporal_load(reinterpret_cast<const groove_v4f*>(p)); r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; r.v[3] = q.w; }
+  else {
+#pragma unroll
+    for (int j = 0; j < V; ++j) r.v[j] = __builtin_nontemporal_load(p + j);
+  }
+  return r;
+}
+template <int V> __device__ __forceinline__ void vstore_ring(float* p, const VecF<V>& x) {
+  if constexpr (V == 4) { groove_v4f q = {x.v[0], x.v[1], x.v[2], x.v[3]}; __builtin_nontemporal_store(q, reinterpret_cast<groove_v4f*>(p)); }
+  else {
+#pragma unroll
+    for (int j = 0; j < V; ++j) __builtin_nontemporal_store(x.v[j], p + j);
+  }
+}
 template <int V> __device__ __forceinline__ void vstore(float* p, const VecF<V>& x) {
   if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
   else {
@@ -1228,10 +1249,10 @@ __device__ __forceinline__ float fx_run_element(const FxRunArgs& a, uint32_t ch,
       for (int i = 0; i < 4; ++i) {
         uint32_t p = a.geo.w[i] + f; if (p >= a.geo.N[i]) p -= a.geo.N[i];
         float* r = st.ring + (a.geo.base[i] + p) * ln + t;
-        VecF<V> d = vload<V>(r);
+        VecF<V> d = vload_ring<V>(r);
 #pragma unroll
         for (int j = 0; j < V; ++j) { const float out = a.geo.g[i] * d.v[j]; d.v[j] = in.v[j] + out; y.v[j] += out; }
-        vstore<V>(r, d);
+        vstore_ring<V>(r, d);
       }
       x = y;
       continue;
@@ -1239,8 +1260,8 @@ __device__ __forceinline__ float fx_run_element(const FxRunArgs& a, uint32_t ch,
     if (st.kind == GROOVE_FX_DELAY) {
       uint32_t p = st.w + f; if (p >= st.N) p -= st.N;
       float* pr = st.ring + (size_t)p * ln + t;
-      y = vload<V>(pr);
-      vstore<V>(pr, x);
+      y = vload_ring<V>(pr);
+      vstore_ring<V>(pr, x);
     } else if (st.kind == GROOVE_FX_CHORUS) {
       uint32_t p = st.w + f; if (p >= st.N) p -= st.N;
 #pragma unroll
@@ -1250,12 +1271,12 @@ __device__ __forceinline__ float fx_run_element(const FxRunArgs& a, uint32_t ch,
       // measured in round 3: 27.04 against 26.87 us and identical FETCH / WRITE bytes, profiles/r03_lds_staging_ab.log: every lane owns
       // its delay lines, a ring window is read exactly once by exactly one lane, there is no reuse for LDS to capture)
       for (uint32_t k = 0; k < st.voices; ++k) {
-        const VecF<V> d = vload<V>(st.ring + (size_t)tp * ln + t);
+        const VecF<V> d = vload_ring<V>(st.ring + (size_t)tp * ln + t);
 #pragma unroll
         for (int j = 0; j < V; ++j) y.v[j] += d.v[j];
         tp += st.spacing; if (tp >= st.N) tp -= st.N;
       }
-      vstore<V>(st.ring + (size_t)p * ln + t, x);
+      vstore_ring<V>(st.ring + (size_t)p * ln + t, x);
     } else {
 #pragma unroll
       for (int j = 0; j < V; ++j) {

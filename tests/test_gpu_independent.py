@@ -1,0 +1,130 @@
+"""GPU tier: the HIP effect kernels against INDEPENDENT implementations of the published algorithms, directly — not through
+`oracle/`.  tests/test_oracle_independent.py cross-checks the oracle on the CPU; this file closes the other side of the
+triangle for every row of SURVEY.md section 8(a) that has a published form and can be driven alone through the C ABI:
+
+  a3  BiQuad 12 dB      scipy.signal.lfilter with coefficients from scipy.signal.bilinear of the cookbook's analog prototype
+  a4  24 dB low-pass    scipy.signal.cheby1(4, ...) — pre-warped bilinear transform — up to its DC gain
+  a8  Gain, a9 Bitcrusher   numpy (the quantise in integers: bit-exact)
+  a10 Chorus, a11 Delay, a12 Reverb   sparse-coefficient lfilter (taps, pure delay, four combs + two all-passes)
+
+Blocks are fp32 in HBM and the IIR state is f64: the bar is 2e-6 of the signal's peak per block of input (a delay is exact).
+Lane counts and block lengths are chosen so that the serial, the segmented, the time-parallel and the fused-run kernels are
+all taken (groove_hip.hip fx_launch_serial / fx_launch_run)."""
+import math
+
+import numpy as np
+import pytest
+from scipy import signal
+
+from groove_amd import abi_types as T
+
+pytestmark = pytest.mark.gpu
+SR = 44100.0
+FR = 256
+
+
+def _run(gpu_ctx, kind, n, x, **kw):
+    """x: [2][frames][n] float32 through one effect bank of n lanes, in blocks of FR frames (the last one ragged)."""
+    from groove_amd import entities as E
+    fx = E.Effect(gpu_ctx, kind, (T.FxParams * n)(*[T.fx_params(**kw) for _ in range(n)]))
+    block = gpu_ctx.block(n, FR)
+    out = np.empty_like(x)
+    for f0 in range(0, x.shape[1], FR):
+        f1 = min(x.shape[1], f0 + FR)
+        block.upload(np.ascontiguousarray(x[:, f0:f1, :]))
+        fx.transform_audio(block, f1 - f0)
+        out[:, f0:f1, :] = block.download(f1 - f0)
+    fx.destroy(); block.destroy()
+    return out
+
+
+def _signal(n, frames, seed):
+    rng = np.random.default_rng(seed)
+    return rng.uniform(-1.0, 1.0, (2, frames, n)).astype(np.float32)
+
+
+def _close(got, want, tol=2e-6):
+    scale = max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(got.astype(np.float64) - want).max()) / scale
+    assert err <= tol, err
+
+
+@pytest.mark.parametrize("n", [3, 700, 5000])   # time-parallel / segmented / serial IIR kernels
+def test_biquad_low_pass_is_the_bilinear_transform_of_its_analog_prototype(gpu_ctx, n):
+    f0, q = 1000.0, 0.707
+    x = _signal(n, 3 * FR + 37, 1)
+    got = _run(gpu_ctx, T.FX_BIQUAD_LP12, n, x, cutoff_hz=f0, q=q)
+    qf = float(np.float32(q))
+    k = math.tan(math.pi * f0 / SR)
+    b, a = signal.bilinear([1.0], [1.0 / k ** 2, 1.0 / (qf * k), 1.0], fs=0.5)   # H(s) = 1 / (s^2 + s / Q + 1), s -> s / k
+    _close(got, signal.lfilter(b / a[0], a / a[0], x.astype(np.float64), axis=1))
+
+
+@pytest.mark.parametrize("n", [2, 3000])
+def test_24db_low_pass_is_scipys_chebyshev(gpu_ctx, n):
+    fc, ripple = 1500.0, 0.707
+    r = float(np.float32(ripple))
+    eps = 1.0 / math.sinh(4.0 * r)
+    sos = signal.cheby1(4, 10.0 * math.log10(1.0 + eps * eps), fc, fs=SR, output="sos")
+    x = _signal(n, 2 * FR + 5, 2)
+    got = _run(gpu_ctx, T.FX_BIQUAD_LP24, n, x, cutoff_hz=fc, passband_ripple=ripple)
+    _close(got, signal.sosfilt(sos, x.astype(np.float64), axis=1) * math.sqrt(1.0 + eps * eps), tol=5e-6)
+
+
+def test_gain_and_bitcrusher(gpu_ctx):
+    n = 1024
+    x = _signal(n, FR, 3)
+    assert np.array_equal(_run(gpu_ctx, T.FX_GAIN, n, x, ceiling=0.5), x * np.float32(0.5))
+    for bits in (3, 8, 13):
+        q = (np.abs(x) * np.float32(32767.0)).astype(np.uint32)
+        q = (q >> np.uint32(bits)) << np.uint32(bits)
+        want = np.copysign(q.astype(np.float32) * np.float32(1.0 / 32767.0), x)
+        assert np.array_equal(_run(gpu_ctx, T.FX_BITCRUSHER, n, x, bits=bits).view(np.uint32), want.view(np.uint32)), bits
+
+
+def _frames_of(seconds):
+    return max(1, int(math.floor(float(np.float32(seconds)) * SR + 0.5)))
+
+
+@pytest.mark.parametrize("seconds", [0.1, 0.003])   # a line longer than a block (fused run) and a shorter one (serial kernel)
+def test_delay_is_a_pure_delay(gpu_ctx, seconds):
+    n = 512
+    N = _frames_of(seconds)
+    x = _signal(n, 2 * N + 3 * FR, 4)
+    got = _run(gpu_ctx, T.FX_DELAY, n, x, delay_seconds=seconds)
+    want = np.zeros_like(x)
+    want[:, N:, :] = x[:, :-N, :]
+    assert np.array_equal(got, want)
+
+
+def test_chorus_is_the_sum_of_its_taps(gpu_ctx):
+    n, voices, seconds = 256, 4, 0.05
+    N = _frames_of(seconds)
+    spacing = N // voices
+    x = _signal(n, N + 4 * FR, 5)
+    got = _run(gpu_ctx, T.FX_CHORUS, n, x, voices=voices, delay_seconds=seconds)
+    b = np.zeros(N + 1)
+    for k in range(voices):
+        b[N - k * spacing] += 1.0
+    _close(got, signal.lfilter(b, [1.0], x.astype(np.float64), axis=1))
+
+
+def test_reverb_is_four_combs_and_two_allpasses(gpu_ctx):
+    n, att, seconds = 256, 0.9, 0.8
+    x = _signal(n, 14 * FR, 6)
+    got = _run(gpu_ctx, T.FX_REVERB, n, x, attenuation=att, reverb_seconds=seconds)
+    u = x.astype(np.float64) * float(np.float32(att))
+    s = np.zeros_like(u)
+    for d in (0.0297, 0.0371, 0.0411, 0.0437):           # out[n] = g (in[n - N] + out[n - N])
+        N = max(1, int(math.floor(d * SR + 0.5)))
+        g = float(np.float32(0.001 ** (d / float(np.float32(seconds)))))
+        b = np.zeros(N + 1); b[N] = g
+        a = np.zeros(N + 1); a[0] = 1.0; a[N] = -g
+        s += signal.lfilter(b, a, u, axis=1)
+    for d, dec in ((0.005, 0.09683), (0.0017, 0.03292)):   # H(z) = (z^-N - g) / (1 - g z^-N)
+        N = max(1, int(math.floor(d * SR + 0.5)))
+        g = float(np.float32(0.001 ** (d / dec)))
+        b = np.zeros(N + 1); b[0] = -g; b[N] = 1.0
+        a = np.zeros(N + 1); a[0] = 1.0; a[N] = -g
+        s = signal.lfilter(b, a, s, axis=1)
+    _close(got, s, tol=5e-6)
