@@ -170,17 +170,17 @@ struct groove_ctx {
   bool fork_pending[kSideStreams] = {}; // the side stream has not yet waited for ev_fork
   bool need_fork = true;                // ctx-stream work since the last fork that side streams must wait for
   uint32_t tp_max_voices = kTpMaxVoices; // Welsh banks up to this size render time-parallel (welsh_tp.h); GROOVE_TP_MAX_VOICES overrides, 0 = never
-  uint32_t fx_tp_max_lanes = 4096;       // IIR effect banks of up to this many lane-channels (half as many for the 24 dB low-pass) run time-parallel (fx_tp.h: measured crossovers, tools/fx_bench.py); GROOVE_FX_TP_MAX_LANES
+  uint32_t fx_tp_max_lanes = 4096;       // IIR effect banks of up to this many lane-channels (half as many for the 24 dB low-pass) run time-parallel (fx_tp.h: measured crossovers, tools/fx_bench.py)
   // Mid-size Welsh banks (too big for the time-parallel form, too small to fill the chip with one voice-wave per wavefront):
   // the ROLE-SPLIT kernel (welsh_split.h: three wavefronts per 64 voices, pipelined over the block's frames) for banks of up
-  // to this many virtual waves; 0 = never.  GROOVE_SPLIT_MAX_WAVES / groove_set_split_max_waves.
+  // to this many virtual waves; 0 = never.  groove_set_split_max_waves.
   uint32_t split_max_waves = 1024;      // 65,536 voices = one workgroup (twelve wavefronts) per CU; measured (round 3, blocks 5-24): 20,000 voices 0.120 -> 0.090 ms per block, 32,768 0.119 -> 0.090, 65,536 0.123 -> 0.095; 80,000 (a second round of workgroups) 0.135 -> 0.153: not above
-  uint32_t split2_max_waves = 2048;      // banks above split_max_waves and up to this many virtual waves (131,072 voices): the TWO-role form, front + tangent | back — two workgroups of eight wavefronts per CU, so one round still; measured (blocks 5-24): 100,000 voices 0.1385 -> 0.134 ms per block, 125,000 0.145 -> 0.137 (three roles there: 0.164 / 0.165; two roles at 65,536: 0.106 against three roles' 0.095).  GROOVE_SPLIT2_MAX_WAVES
+  uint32_t split2_max_waves = 2048;      // banks above split_max_waves and up to this many virtual waves (131,072 voices): the TWO-role form, front + tangent | back — two workgroups of eight wavefronts per CU, so one round still; measured (blocks 5-24): 100,000 voices 0.1385 -> 0.134 ms per block, 125,000 0.145 -> 0.137 (three roles there: 0.164 / 0.165; two roles at 65,536: 0.106 against three roles' 0.095)
   int split_roles = 4;                   // roles of the form used up to split_max_waves: four (ctl | osc | tangent + quotients | back), measured against three
                                          // (front | tangent | back) in one job: 32,768 voices 0.0830 against 0.0888 ms per block, 65,536 0.0846-0.0855 against
                                          // 0.0903, config #5 0.1003-0.1008 against 0.0999-0.1001.  GROOVE_SPLIT_ROLES=3 / 2: A/B
   uint32_t pipeline_min_waves = 8600;   // banks at least this long (~550,000 voices) run one kernel per base kind and pipeline their fused blocks; smaller ones take the all-kinds kernel (round 2, blocks 5-44 of the timeline: 300,000 voices 0.275 -> 0.250 ms per block, 500,000 0.357 -> 0.342; 600,000 0.372 against 0.400)
-  // How many of the bank streams exist and are handed out (GROOVE_BANK_STREAMS).  Three: with the ctx stream and the four
+  // How many of the bank streams exist and are handed out.  Three: with the ctx stream and the four
   // kind streams that is eight streams; a ninth lands on a hardware queue that already carries one of the others, and a
   // project with a bank on it ran three times slower (mixed-131072: 0.12 -> 0.39 ms per block whenever a bank had the
   // fourth bank stream, whichever bank it was; tools/micro/slot_probe.py).
@@ -188,22 +188,21 @@ struct groove_ctx {
   // Normal-priority streams for the class-specialised Welsh kinds.  Three: the fourth kind shares the first kind's stream
   // (1,000,000 voices: 0.511 against 0.515 ms per block with four).  docs/STREAMS.md item 10: the k-th stream a process
   // creates lands on hardware queue (k - 1) mod 4, so the fifth (and the ninth) shares the ctx stream's queue; the fifth
-  // used to be the fourth kind stream — the one whose kernel crawled in the incidents of DESIGN.md section 7 — and is now
-  // a placeholder nobody uses.  GROOVE_KIND_STREAMS=4 brings the old layout back.
+  // used to be the fourth kind stream and is now a placeholder nobody uses.
   int kind_streams = 3;
   int next_stream_slot = 0;             // round-robin side-stream assignment of single-kernel banks
-  uint32_t fm_tp_max_voices = kFmTpMaxVoices; // GROOVE_FM_TP_MAX_VOICES
+  uint32_t fm_tp_max_voices = kFmTpMaxVoices;
   // Welsh banks of at least this many voices whose adjacent pairs share a patch render two voices per wavefront
   // (welsh_tp_kernel<.., VPW = 2>): above 3,072 voices the one-voice form no longer fits the SIMDs in one round
-  uint32_t tp_vpw2_min_voices = 3073; // GROOVE_TP_VPW2_MIN_VOICES (0 = never)
+  uint32_t tp_vpw2_min_voices = 3073; // groove_set_time_parallel_pair_min_voices (0 = never)
   // events that mark the end of ONE kernel (a block's render, a block's last reduction) are bound to that dispatch's own
   // completion signal instead of being recorded behind it (a barrier packet each, ~5 us of the stream's timeline)
   uint32_t fm_tp_vpw4_min_voices = 4096; // GROOVE_FM_TP_VPW4_MIN_VOICES (0 = never): FM banks of at least this many voices, four voices per wavefront
   // (Round 3 switched this off when fresh runs stalled with it on; the stall was the zero-frame segment of DESIGN.md section 7,
   // which had nothing to do with events.  On again in round 4; GROOVE_BIND_EVENTS=0 for A/B.)
   bool bind_events = true;
-  uint32_t fx_seg_max_lanes = 49152;     // biquad banks of up to this many lane-channels take the four-segment kernel (measured, tools/fx_bench.py: 8,192 lane-channels 17.5 -> 9.3 us, 32,768 19.4 -> 15.6, 131,072 42.9 -> 58.4; GROOVE_FX_SEG_MAX_LANES, 0 = never)
-  uint32_t fx_tp_wide_min_lanes = 8192;  // from this many lane-channels the time-parallel IIR kernels take 32-wide tiles (GROOVE_FX_TP_WIDE_MIN_LANES)
+  uint32_t fx_seg_max_lanes = 49152;     // biquad banks of up to this many lane-channels take the four-segment kernel (measured, tools/fx_bench.py: 8,192 lane-channels 17.5 -> 9.3 us, 32,768 19.4 -> 15.6, 131,072 42.9 -> 58.4; 0 = never)
+  uint32_t fx_tp_wide_min_lanes = 8192;  // from this many lane-channels the time-parallel IIR kernels take 32-wide tiles
   bool seq_allpass = false;             // GROOVE_FX_SEQ_ALLPASS=1: the sequential all-pass kernel (A/B and bit-identity tests)
   bool chunked_allpass = false;         // GROOVE_FX_CHUNKED_ALLPASS=1: the chunk-parallel all-pass kernel instead of the direct one
   uint32_t sr = GROOVE_DEFAULT_SAMPLE_RATE;

@@ -62,7 +62,10 @@ int groove_set_sync_timeout_ms(groove_ctx* ctx, uint32_t ms);
 uint32_t groove_sync_timeout_ms(groove_ctx* ctx);
 /* Test / diagnosis hooks.  groove_debug_spin: one idle kernel that occupies a library stream for `ms` milliseconds
  * (side_stream = -1: the ctx stream; 0..5 kind streams; 6.. bank streams) — how the tests block a stream on purpose.
- * groove_debug_info: the stream layout of this ctx as a JSON object (bench.py puts it on its line). */
+ * groove_debug_info: a JSON object with the stream layout of this ctx and `zero_segments` — how often a Welsh kernel's wave
+ * found that its ACTIVE lanes had zero frames to their next envelope boundary (csrc/diag.h: the counted assertion behind
+ * DESIGN.md section 7; it must read 0, and the GPU tests, smoke() and bench.py require that).  It waits for the ctx stream;
+ * call groove_synchronize first for a figure that includes the side streams' latest kernels. */
 int groove_debug_spin(groove_ctx* ctx, int side_stream, uint32_t ms);
 int groove_debug_info(groove_ctx* ctx, char* out, size_t cap);
 /* Configurable::update_sample_rate fan-out (orchestrator.rs:125-127, 1019-1022, 1389-1394).
@@ -80,7 +83,7 @@ uint32_t groove_time_parallel_max_voices(groove_ctx* ctx);
  * TWO voices per wavefront (32 lanes x 8 frames each) instead of one (64 lanes x 4 frames): half the wavefronts, 25 % less
  * issue per voice, the right trade once the one-voice form needs more wavefronts than the SIMDs hold at once; such banks stay
  * time-parallel up to 11/8 of groove_set_time_parallel_max_voices' limit (22,528 voices by default).  Default 3,073;
- * 0 = never; 1 = whenever the pairs allow (tests).  GROOVE_TP_VPW2_MIN_VOICES in the environment sets it at groove_init.
+ * 0 = never; 1 = whenever the pairs allow (tests).
  * No reference counterpart. */
 int groove_set_time_parallel_pair_min_voices(groove_ctx* ctx, uint32_t min_voices);
 uint32_t groove_time_parallel_pair_min_voices(groove_ctx* ctx);
@@ -94,8 +97,8 @@ uint32_t groove_pipeline_min_waves(groove_ctx* ctx);
  * three wavefronts per 64 voices — front (envelopes, LFO, oscillators), cutoff tangent, filter + gains — pipelined over the
  * block's frames through LDS, so that a bank which cannot fill the chip with voices fills it with the parts of a voice's
  * frame (csrc/welsh_split.h).  Same results bit for bit as the serial kernels.  Default 1,024 (65,536 voices: one workgroup per CU;
- * banks of up to twice that take a two-role form of the same kernel, two workgroups per CU: GROOVE_SPLIT2_MAX_WAVES);
- * 0 = never.  GROOVE_SPLIT_MAX_WAVES in the environment sets it at groove_init.  No reference counterpart. */
+ * banks of up to twice that take a two-role form of the same kernel, two workgroups per CU);
+ * 0 = never.  No reference counterpart. */
 int groove_set_split_max_waves(groove_ctx* ctx, uint32_t waves);
 uint32_t groove_split_max_waves(groove_ctx* ctx);
 /* HIP events on the ctx stream, for measurement (bench.py): create / record / elapsed. */
