@@ -705,8 +705,10 @@ def bench_workload(ctx, workload, sel, K, W, repeats, fused=True, grouped=True, 
     wl = WORKLOADS[workload]
     proj = PJ.Project(ctx, workload, sel, fused=fused, grouped=grouped, render_ahead=render_ahead, head_ahead=head_ahead, paced=paced)
     forms = sorted({inst.kernel_form(FRAMES, fused and not fx) for inst, _, fx, _ in proj.banks})
-    walk = ("paced: renders two blocks ahead, four blocks in rotation, the host waits for the events itself, the bus reduction deferred into the next chain launch"
-            if proj.paced else "render-ahead (one block, device-side waits)" if proj.ahead_walk else "block by block")
+    walk = ("paced: renders two blocks ahead, the host waits for the events itself, the bus reduction deferred into the next chain launch"
+            if proj.paced else "render-ahead (one block, device-side waits)" if proj.ahead_walk
+            else "fused render + mix on the library's streams, paced by the host (groove_bank_render_mix_paced)" if proj.paced_fused
+            else "banks in turn on the ctx stream (groove_bank_render_mix_deferred)" if proj.take_turns else "block by block")
     bus = ctx.bus((K + W) * FRAMES)
     span_mode = (fused and wl["kind"] != "chain") or (render_ahead and (wl["kind"] == "chain" or not fused))
     walls, kerns, extra = time_project(ctx, proj, bus, K, W, repeats, span_mode, dist)
@@ -870,7 +872,7 @@ def main():
     ap.add_argument("--no-render-ahead", action="store_true",
                     help="workloads with effect chains: render block b, then its effects (default: the render of block b+1 "
                          "is submitted to the side streams before the effects of block b)")
-    ap.add_argument("--no-pacing", action="store_true", help="workloads with effect chains: round 3's walk — renders one block ahead, device-side event waits, a reduction launch per block (A/B)")
+    ap.add_argument("--no-pacing", action="store_true", help="round 3's walks: device-side event waits instead of the host waiting for the events itself (effect chains: renders one block ahead and a reduction launch per block; fused projects: groove_bank_render_mix) (A/B)")
     ap.add_argument("--no-head-ahead", action="store_true", help="render-ahead walk: keep the chain's leading IIR stage on the ctx stream (A/B)")
     ap.add_argument("--head-unfused", action="store_true", help="render-ahead walk: the IIR head behind the render as its own launch, not fused into the render kernel (A/B)")
     ap.add_argument("--dry-launch", action="store_true", help="rendezvous of the ranks over gloo only (no GPU): launcher test")

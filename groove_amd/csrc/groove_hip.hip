@@ -89,6 +89,8 @@ struct groove_bank {
   hipEvent_t ev_reduce_done[2] = {nullptr, nullptr};
   bool reduce_recorded[2] = {false, false};
   int pipe_slot = 0;
+  // groove_bank_render_mix_paced: the reduction of the block rendered by the last paced call, launched by the next one (or a flush)
+  struct { bool active = false; int slot = 0; uint32_t rows = 0, frames = 0, used = 0; float* bus = nullptr; int accumulate = 0; } paced;
   int stream_slot = 0; // side stream of a single-kernel bank (FM, sampler, per-lane Welsh) in the asynchronous fused path
   bool ctx_touched = true; // the ctx stream has worked on this bank's state since its last asynchronous render waited for it
   int side_mode = 0;    // which side streams carried this bank's last asynchronous work: 0 none, 1 one per base kind, 2 stream_slot
@@ -229,6 +231,7 @@ struct groove_ctx {
   // groove_mix_deferred takes the block's row-sum buffer AWAY from the block (owned_cap != 0: the pending rows live in a buffer
   // nobody else can write) and hands the block one of these instead; a consumed buffer comes back here (deferred_taken)
   std::vector<std::pair<float*, size_t>> spare_sums;
+  std::vector<groove_bank*> paced_order; // banks with a pending paced reduction, in call order (= the order of their sums on a bus)
   float* d_fseg = nullptr;   // fused path: seg[segments][2*frames]
   size_t fseg_cap = 0;
   int16_t* d_i16 = nullptr;
@@ -787,7 +790,8 @@ constexpr uint32_t kRowsPerSeg = 64;
 // `done` (optional): an event that completes with the LAST kernel of the reduction — bound to that dispatch's own completion
 // signal (hipExtLaunchKernelGGL), not recorded behind it: a recorded event is a barrier packet of its own, ~5 us of the
 // stream's timeline (docs/STREAMS.md).
-void launch_reduce(groove_ctx* ctx, const float* partial, uint32_t rows, uint32_t frames, float* seg_buf, float* bus_dev, int accumulate, hipEvent_t done = nullptr) {
+void launch_reduce(groove_ctx* ctx, const float* partial, uint32_t rows, uint32_t frames, float* seg_buf, float* bus_dev, int accumulate, hipEvent_t done = nullptr);
+void launch_reduce(groove_ctx* ctx, const float* partial, uint32_t rows, uint32_t frames, float* seg_buf, float* bus_dev, int accumulate, hipEvent_t done) {
   const uint32_t cols = 2 * frames, segs = (rows + kRowsPerSeg - 1) / kRowsPerSeg;
   const dim3 blk(kThreads);
   if (segs == 1) {
@@ -806,7 +810,35 @@ void deferred_taken(groove_ctx* ctx) {
   ctx->deferred.rows = nullptr;
   ctx->deferred.owned_cap = 0;
 }
+void launch_reduce(groove_ctx* ctx, const float* partial, uint32_t rows, uint32_t frames, float* seg_buf, float* bus_dev, int accumulate, hipEvent_t done);
+// The pending reduction of a bank's last paced block onto its bus (ctx stream).  host_wait: the HOST waits for the block's render
+// kernels (they were submitted a whole call ago), so that the ctx stream carries no cross-queue wait; otherwise (flush points) the
+// ctx stream waits for them itself.
+int paced_reduce(groove_bank* b, bool host_wait) {
+  if (!b->paced.active) return 0;
+  groove_ctx* ctx = b->ctx;
+  const auto p = b->paced;
+  b->paced.active = false;
+  ctx->paced_order.erase(std::remove(ctx->paced_order.begin(), ctx->paced_order.end(), b), ctx->paced_order.end());
+  for (int k = 0; k < kSideStreams; ++k) {
+    if (!(p.used & (1u << k))) continue;
+    if (host_wait) GHIP(ctx, wait_deadline(ctx, nullptr, b->ev_render_done[k][p.slot], "groove_bank_render_mix_paced: the previous block's render"));
+    else GHIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_render_done[k][p.slot], 0));
+  }
+  launch_reduce(ctx, b->d_pipe_part[p.slot], p.rows, p.frames, b->d_pipe_seg[p.slot], p.bus, p.accumulate, nullptr);
+  GHIP(ctx, hipEventRecord(b->ev_reduce_done[p.slot], ctx->stream));
+  b->reduce_recorded[p.slot] = true;
+  GHIP(ctx, hipGetLastError());
+  return 0;
+}
+int bus_flush_deferred(groove_ctx* ctx);
 int bus_flush(groove_ctx* ctx) {
+  if (bus_flush_deferred(ctx)) return 1;
+  while (!ctx->paced_order.empty()) // (call order: the order of the banks' sums on a bus)
+    if (paced_reduce(ctx->paced_order.front(), false)) return 1;
+  return 0;
+}
+int bus_flush_deferred(groove_ctx* ctx) {
   if (!ctx->deferred.rows) return 0;
   const auto d = ctx->deferred;
   deferred_taken(ctx);
@@ -1371,6 +1403,7 @@ int groove_sampler_create(groove_ctx* ctx, const float* bank_pcm, uint64_t bank_
 int groove_bank_destroy(groove_bank* b) {
   if (!b) return 0;
   groove_ctx* ctx = b->ctx;
+  (void)paced_reduce(b, false);
   (void)ctx_join(ctx);
   (void)hipStreamSynchronize(ctx->stream);
   for (int slot = 0; slot < 2; ++slot) {
@@ -1778,7 +1811,7 @@ int groove_block_acquire(groove_block* b) {
 // thinly occupied tail of one block (the last, partly filled round of waves) overlaps the head of
 // the next: ≈ 15 % at 1,000,000 voices, more for smaller banks.  Two slots of partial rows; a kind's
 // render of block b+2 waits for the reduction of block b.
-static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev, int accumulate) {
+static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev, int accumulate, bool paced = false) {
   groove_ctx* ctx = b->ctx;
   const bool tp = use_tp(b, frames);
   const bool small_uniform = !tp && b->kind == BANK_WELSH && b->n_vwaves && b->n_vwaves < ctx->pipeline_min_waves && ctx->pipeline_min_waves > 1;
@@ -1788,7 +1821,9 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
   if (bank_side_mode(b, uniform ? 1 : 2)) return 1;
   const int slot = b->pipe_slot;
   b->pipe_slot ^= 1;
+  if (b->paced.active && (!paced || b->paced.slot == slot) && paced_reduce(b, false)) return 1; // (an unpaced call, or the slot's rows still owed)
   if (b->pipe_part_cap[slot] < (size_t)rows * cols || b->pipe_seg_cap[slot] < (size_t)segs * cols) {
+    if (b->paced.active && paced_reduce(b, false)) return 1;
     if (ctx_join(ctx)) return 1;
     GHIP(ctx, ctx_wait(ctx));
     if (b->d_pipe_part[slot]) GHIP(ctx, hipFree(b->d_pipe_part[slot]));
@@ -1818,9 +1853,14 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
   }
   const RenderConsts rc = render_consts(ctx->sr);
   const dim3 blk(kThreads);
+  // paced: the HOST waits for the reduction that frees this slot's rows (two blocks back: long done), so that the waits below are
+  // dropped when they are made and the render streams carry no wait packet (docs/STREAMS.md item 13)
+  if (paced && b->reduce_recorded[slot]) GHIP(ctx, wait_deadline(ctx, nullptr, b->ev_reduce_done[slot], "groove_bank_render_mix_paced: the slot's previous reduction"));
+  uint32_t used = 0;
   for (int k = kSideStreams - 1; k >= 0; --k) { // most expensive Welsh kind first
     if (!count[k]) continue;
     hipStream_t st = side_stream_of(ctx, k);
+    used |= 1u << k;
     if (ctx->fork_pending[k]) { GHIP(ctx, hipStreamWaitEvent(st, ctx->ev_fork, 0)); ctx->fork_pending[k] = false; }
     if (b->reduce_recorded[slot]) GHIP(ctx, hipStreamWaitEvent(st, b->ev_reduce_done[slot], 0));
     if (uniform) {
@@ -1846,15 +1886,36 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
       hipLaunchKernelGGL(sampler_render_kernel<true>, dim3(rows), blk, 0, st, b->d_params, b->d_state, b->n, frames, (size_t)0, b->d_pipe_part[slot], b->d_pipe_part[slot], b->d_pcm);
     }
     GHIP(ctx, hipEventRecord(b->ev_render_done[k][slot], st));
-    GHIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_render_done[k][slot], 0));
+    if (!paced) GHIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_render_done[k][slot], 0));
     ctx->side_busy[k] = true;
   }
   b->ctx_touched = false; // the bank's stream(s) have waited for whatever the ctx stream did to its state (ev_fork above)
+  if (paced) {
+    // this block's reduction is launched by the bank's NEXT paced call (or a flush point); the previous block's is launched now: its
+    // renders were submitted a whole call ago, the host waits for them (this block's are already queued behind them)
+    if (b->paced.active && paced_reduce(b, true)) return 1;
+    b->paced.active = true; b->paced.slot = slot; b->paced.rows = rows; b->paced.frames = frames; b->paced.used = used; b->paced.bus = bus_dev; b->paced.accumulate = accumulate;
+    b->reduce_recorded[slot] = false; // (recorded when the reduction is launched)
+    ctx->paced_order.push_back(b);
+    GHIP(ctx, hipGetLastError());
+    return 0;
+  }
   launch_reduce(ctx, b->d_pipe_part[slot], rows, frames, b->d_pipe_seg[slot], bus_dev, accumulate);
   GHIP(ctx, hipEventRecord(b->ev_reduce_done[slot], ctx->stream));
   b->reduce_recorded[slot] = true;
   GHIP(ctx, hipGetLastError());
   return 0;
+}
+// groove_bank_render_mix for a project whose banks render side by side, PACED by the host (include/groove_hip.h).
+int groove_bank_render_mix_paced(groove_bank* b, uint32_t frames, float* bus_dev, int accumulate) {
+  if (!b || !bus_dev) return fail(nullptr, "groove_bank_render_mix_paced: NULL argument");
+  groove_ctx* ctx = b->ctx;
+  if (frames == 0) return 0;
+  if (frames > 4096) return fail(ctx, "groove_bank_render_mix_paced: frames > 4096");
+  GHIP(ctx, hipSetDevice(ctx->device));
+  if (bus_flush_deferred(ctx)) return 1; // (the other deferral's pending rows come first; paced reductions of other banks stay pending)
+  if (flush_events(b, use_tp(b, frames))) return 1;
+  return render_mix_pipelined(b, frames, bus_dev, accumulate, true);
 }
 // Fused render + mix whose bus reduction is left to the bank's NEXT deferred render (welsh_tp.h, tp_reduce_prev) — or to
 // whatever waits for the ctx stream, records an event on it or touches a bus (bus_flush).  For banks that render time-parallel

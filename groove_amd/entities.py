@@ -310,6 +310,12 @@ class Instrument:
         ptr = bus.at(at_frame) if at_frame else bus.ptr
         _lib.check(self.ctx.L.groove_bank_render_mix(self.h, frames, ptr, 1 if accumulate else 0), self.ctx.h)
 
+    def render_mix_paced(self, bus, frames, accumulate=False, at_frame=0):
+        """groove_bank_render_mix_paced: banks side by side, the host waits for the events itself; this block's bus reduction is
+        launched by the bank's next paced call (or a flush point)."""
+        ptr = bus.at(at_frame) if at_frame else bus.ptr
+        _lib.check(self.ctx.L.groove_bank_render_mix_paced(self.h, frames, ptr, 1 if accumulate else 0), self.ctx.h)
+
     def render_mix_deferred(self, bus, frames, accumulate=False, at_frame=0):
         """groove_bank_render_mix_deferred: the block's bus reduction is left to this bank's next deferred render (or to the next
         call that waits for the ctx stream, records an event on it or touches a bus)."""

@@ -71,6 +71,7 @@ SYMBOLS = {
     "groove_bank_render_mix": (_i, [_vp, _u32, _vp, _i]),
     "groove_bank_render_mix_deferred": (_i, [_vp, _u32, _vp, _i]),
     "groove_bus_flush": (_i, [_vp]),
+    "groove_bank_render_mix_paced": (_i, [_vp, _u32, _vp, _i]),
     "groove_bank_reset": (_i, [_vp]),
     "groove_bank_state_words": (_u32, [_vp]),
     "groove_bank_download_state": (_i, [_vp, C.POINTER(C.c_uint32)]),

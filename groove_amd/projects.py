@@ -169,6 +169,16 @@ class Project:
         # (groove_bank_render_mix_deferred): one launch per bank and block, no cross-queue waits.  Bigger banks render side by side.
         total = sum(inst.n for inst, _, _, _ in self.banks)
         self.take_turns = fused and not self.has_chain and (len(self.banks) == 1 or total <= TAKE_TURNS_MAX_VOICES)
+        # Every other fused project — banks side by side on the library's streams, or one bank big enough for the per-kind block
+        # pipeline — is PACED by default (groove_bank_render_mix_paced: the host waits for the events, every bank's bus reduction is
+        # launched by its next call); paced=False: device-side waits.  Measured in one job (profiles/r04_paced_fused_ab.log):
+        # 1,000,000 voices 0.4885 / 0.4916 / 0.4885 against 0.4974 / 0.4939 / 0.4925 ms per block, config #5 on one GPU 0.0914 / 0.0914
+        # against 0.0946 / 0.0942; its 16,384-voice share of eight GPUs gains nothing side by side (0.055 - 0.059 against 0.056) and
+        # keeps taking turns.
+        pipelined = len(self.banks) == 1 and "blocks pipelined" in self.banks[0][0].kernel_form(FRAMES, True)  # (a lone bank of >= ~550,000 Welsh voices)
+        if pipelined:
+            self.take_turns = False  # (groove_bank_render_mix_deferred would hand such a bank to groove_bank_render_mix anyway)
+        self.paced_fused = fused and not self.has_chain and (paced is not False) and not self.take_turns
 
     def reset(self):
         """Back to block 0 of the timeline with every voice and effect in its initial state."""
@@ -256,6 +266,8 @@ class Project:
             if self.fused and not fx:
                 if self.take_turns:  # small banks, one after the other on the ctx stream: a render carries the reduction of the one before it
                     inst.render_mix_deferred(bus, FRAMES, accumulate=not first, at_frame=frame0)
+                elif self.paced_fused:
+                    inst.render_mix_paced(bus, FRAMES, accumulate=not first, at_frame=frame0)
                 else:
                     inst.render_mix(bus, FRAMES, accumulate=not first, at_frame=frame0)
                 if ev_pair is not None and ev_pair[1] is not None and inst is self.banks[-1][0]:

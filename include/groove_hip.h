@@ -205,6 +205,15 @@ int groove_bank_render_mix(groove_bank* bank, uint32_t frames, float* bus_dev, i
  * host that needs bit-reproducible buses calls groove_bank_render_mix. */
 int groove_bank_render_mix_deferred(groove_bank* bank, uint32_t frames, float* bus_dev, int accumulate);
 int groove_bus_flush(groove_ctx* ctx);
+/* groove_bank_render_mix for a project whose banks render SIDE BY SIDE on the library's streams, PACED by the host (see
+ * groove_block_wait_ready): the call blocks the host, as needed, until the reduction that frees this bank's slot of partial rows
+ * (two of its blocks back) and the render of its PREVIOUS block have finished, so that neither the render streams nor the ctx
+ * stream ever carry a cross-queue wait; the reduction of the block rendered by THIS call is launched by the bank's next paced
+ * call, or by whatever flushes a bus (groove_bus_flush, groove_synchronize, a download, groove_event_record, any unpaced render
+ * or mix).  The banks' sums reach a bus in the order of the calls, as with groove_bank_render_mix; same bits.  For the offline
+ * host that renders several instruments patched straight into the main mixer block after block (orchestrator.rs:397-410):
+ * config #5 on one GPU and its per-GPU share of eight.  No reference counterpart. */
+int groove_bank_render_mix_paced(groove_bank* bank, uint32_t frames, float* bus_dev, int accumulate);
 /* Every voice back to its freshly created state (oscillator phases, envelopes idle, filter memory,
  * sampler cursors); parameters stay; queued note events are dropped.  What the reference gets by
  * re-running a project from the top: Orchestrator::skip_to_start (orchestrator.rs:971-983) followed by

@@ -197,3 +197,46 @@ def test_mix_deferred_rides_in_the_next_chain_launch_or_a_flush(gpu_ctx):
         synth.destroy(); block.destroy(); bus.destroy(); bus2.destroy()
     assert np.abs(outs[0]).max() > 1.0
     assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+
+
+def test_paced_render_mix_gives_the_bus_of_render_mix(gpu_ctx):
+    """groove_bank_render_mix_paced — several banks side by side, the host waiting for the events, every bank's bus reduction
+    launched by its NEXT paced call or a flush point — against groove_bank_render_mix on identical banks: the same bits (the
+    reduction kernels and their order on the bus are the same), with note events in the middle, ragged blocks, a flush by a
+    download half way, and an unpaced call in between."""
+    from groove_amd import entities as E, projects as PJ
+    sel = np.arange(6000, dtype=np.int64)
+    lens = [256, 256, 100, 256, 33, 256, 256, 256]
+    outs = []
+    for paced in (False, True):
+        specs = PJ.plan("mixed-131072", sel)
+        banks = []
+        for spec in specs:
+            if spec["kind"] == "welsh":
+                inst = E.WelshSynth(gpu_ctx, spec["params"])
+            elif spec["kind"] == "fm":
+                inst = E.FmSynth(gpu_ctx, spec["params"])
+            else:
+                inst = E.Sampler(gpu_ctx, spec["pcm"], spec["descs"], spec["params"])
+            banks.append((inst, spec["events"]))
+        bus = gpu_ctx.bus(sum(lens))
+        at, mid = 0, None
+        for b, frames in enumerate(lens):
+            for i, (inst, events) in enumerate(banks):
+                ev = events.get(b)
+                if ev is not None:
+                    inst.handle_midi_events(ev)
+                if paced and not (b == 5 and i == 1):     # (one unpaced call in the middle: it flushes what is pending first)
+                    inst.render_mix_paced(bus, frames, accumulate=i > 0, at_frame=at)
+                else:
+                    inst.render_mix(bus, frames, accumulate=i > 0, at_frame=at)
+            at += frames
+            if b == 3:
+                mid = bus.download(at).copy()             # a flush point: every block so far is complete
+        outs.append((mid, bus.download()))
+        for inst, _ in banks:
+            inst.destroy()
+        bus.destroy()
+    assert np.abs(outs[0][1]).max() > 1.0
+    assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
+    assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))
