@@ -14,6 +14,8 @@ coefficient, an off-by-one delay length or a wrong constant fails here; a wrong 
   a9  Bitcrusher        integer numpy
   a10 Chorus, a11 Delay, a12 Reverb   sparse-coefficient lfilter (combs, all-passes, taps)
   a13 Dca               the pan law at its anchor points
+  a5  WelshVoice        the whole voice for static-filter patches, composed as array arithmetic (phases, scipy filter, envelopes, pan)
+  a6  FM voice          running-sum carrier phase under the enveloped modulator;  a7 sampler: pointer stepping, exact
 """
 import math
 
@@ -313,3 +315,165 @@ def test_dca_pan_law_anchor_points(oracle):
     L.oracle_dca(1.0, 1.0, 1.0, _dp(lr)); assert np.allclose(lr, [0.0, 1.0], atol=1e-15)     # hard right
     L.oracle_dca(0.5, 0.5, 0.3, _dp(lr))
     assert np.allclose(lr, [0.25 * (1 - 0.25 * 1.3 ** 2), 0.25 * (1 - (0.15 - 0.5) ** 2)], atol=1e-15)
+
+
+# ------------------------------------------------------------------------------------------ a5 WelshVoice, composed independently
+def _closed_form_envelope(a, d, s, r, off, n):
+    """The four quadratic stages (docs/DSP_SPEC.md section 3) with note-on at frame 0 and note-off at frame `off`; returns the
+    values and the first frame at which the envelope is idle again."""
+    v = np.zeros(n)
+
+    def stage(start, A, B, length):
+        N = int(math.ceil(length)) if length > 0.0 else 0
+        i = np.arange(N)
+        t = i / length if N else i
+        end = min(n, start + N)
+        v[start:end] = (A + (B - A) * (2.0 * t - t * t))[: end - start]
+        return start + N
+
+    f = stage(0, 0.0, 1.0, a * SR)
+    if f < off:
+        f = stage(f, 1.0, s, d * SR * (1.0 - s))
+    v[min(f, n):off] = s
+    v[off:] = 0.0
+    level = v[off - 1]
+    idle_from = stage(off, level, 0.0, r * SR * level)
+    return v, idle_from
+
+
+def _independent_welsh_voice(p, key, n, off):
+    """A Welsh voice whose filter is STATIC (no envelope or LFO on the cutoff) and whose LFO is unused or routed to the amplitude,
+    written as array arithmetic from the published pieces — closed-form phases and envelopes, scipy's Chebyshev for the
+    24 dB low-pass, the pan law — without one line of oracle/: the frame order of SURVEY Appendix A.6 is what is under test."""
+    f_note = 440.0 * 2.0 ** ((key - 69) / 12.0)
+    i = np.arange(n, dtype=np.longdouble)
+
+    def osc(o):
+        f = o.fixed_hz if o.fixed_hz > 0.0 else f_note * o.tune
+        pos = i * (np.longdouble(f) / np.longdouble(SR))
+        pos = (pos - np.floor(pos)).astype(np.float64)
+        w = o.waveform
+        if w == T.WAVE_SINE:
+            return np.sin(2.0 * np.pi * pos)
+        if w in (T.WAVE_SQUARE, T.WAVE_PULSE_WIDTH):
+            return np.where(pos < (float(np.float32(o.duty)) if w == T.WAVE_PULSE_WIDTH else 0.5), 1.0, -1.0)
+        if w == T.WAVE_TRIANGLE:
+            return 4.0 * np.abs(pos - np.floor(pos + 0.5)) - 1.0
+        if w == T.WAVE_SAWTOOTH:
+            return 2.0 * (pos - np.floor(pos + 0.5))
+        return np.zeros(n)
+
+    mix = float(np.float32(p.oscillator_mix))
+    s = osc(p.oscillator_1) * mix + osc(p.oscillator_2) * (1.0 - mix)
+    ripple = float(np.float32(p.filter_passband_ripple))
+    eps = 1.0 / math.sinh(4.0 * ripple)
+    sos = signal.cheby1(4, 10.0 * math.log10(1.0 + eps * eps), float(np.float32(p.filter_cutoff_hz)), fs=SR, output="sos")
+    y = signal.sosfilt(sos, s) * math.sqrt(1.0 + eps * eps)
+    e = p.amp_envelope
+    amp, idle_from = _closed_form_envelope(e.attack, e.decay, e.sustain, e.release, off, n)
+    if p.lfo_routing == T.LFO_AMPLITUDE:
+        lpos = i * (np.longdouble(p.lfo_frequency) / np.longdouble(SR))
+        lpos = (lpos - np.floor(lpos)).astype(np.float64)
+        amp = amp * (1.0 + np.sin(2.0 * np.pi * lpos) * float(np.float32(p.lfo_depth)))
+    m = y * amp * float(np.float32(p.dca_gain))
+    pan = float(np.float32(p.dca_pan))
+    out = np.stack([m * (1.0 - 0.25 * (pan + 1.0) ** 2), m * (1.0 - (0.5 * pan - 0.5) ** 2)])
+    out[:, min(idle_from, n):] = 0.0
+    return out, idle_from
+
+
+def _welsh_patch(w1, w2, tune2, mix, env, cutoff, ripple, pan, lfo=None, duty=0.3, fixed2=0.0):
+    p = T.WelshParams()
+    p.oscillator_1 = T.OscillatorParams(w1, duty, 1.0, 0.0)
+    p.oscillator_2 = T.OscillatorParams(w2, duty, tune2, fixed2)
+    p.oscillator_2_sync, p.oscillator_mix = 0, mix
+    p.amp_envelope = T.EnvelopeParams(*env)
+    p.filter_envelope = T.EnvelopeParams(0.01, 0.1, 0.5, 0.1)    # (runs, but drives nothing: filter_cutoff_end = 0)
+    p.lfo_waveform, p.lfo_routing, p.lfo_frequency, p.lfo_depth = T.WAVE_SINE, (T.LFO_AMPLITUDE if lfo else T.LFO_NONE), (lfo or (1.0, 0.0))[0], (lfo or (1.0, 0.0))[1]
+    p.filter_cutoff_hz, p.filter_passband_ripple, p.filter_cutoff_start, p.filter_cutoff_end = cutoff, ripple, 0.5, 0.0
+    p.dca_gain, p.dca_pan = 0.8, pan
+    return p
+
+
+def test_welsh_voice_composition_against_an_independent_array_implementation(oracle):
+    """Six hand-built patches x two keys: oscillator pair -> mix -> static 24 dB low-pass -> amplitude envelope (x LFO) -> Dca, with
+    the note-off inside the render and the idle tail after the release.  Bar: 1e-8 of full scale (n additions of the phase
+    increment against a closed form; a sample whose phase is within rounding of a waveform edge is skipped)."""
+    patches = [
+        _welsh_patch(T.WAVE_SAWTOOTH, T.WAVE_SINE, 2.0 ** (7 / 12), 0.6, (0.01, 0.05, 0.6, 0.08), 1200.0, 0.9, -0.4),
+        _welsh_patch(T.WAVE_SINE, T.WAVE_TRIANGLE, 2.0, 0.5, (0.0, 0.02, 0.3, 0.05), 400.0, 0.707, 0.25, lfo=(5.13, 0.3)),
+        _welsh_patch(T.WAVE_TRIANGLE, T.WAVE_SAWTOOTH, 1.0, 0.25, (0.03, 0.0, 1.0, 0.02), 3000.0, 1.607, 1.0),
+        _welsh_patch(T.WAVE_SINE, T.WAVE_SINE, 2.0 ** (5 / 1200), 0.5, (0.002, 0.3, 0.0, 0.3), 800.0, 1.2, 0.0, lfo=(0.53, 0.5)),
+        _welsh_patch(T.WAVE_TRIANGLE, T.WAVE_NONE, 1.0, 1.0, (0.05, 0.1, 0.8, 0.1), 150.0, 0.8, -1.0),
+        _welsh_patch(T.WAVE_SINE, T.WAVE_SAWTOOTH, 1.0, 0.7, (0.01, 0.05, 0.5, 0.04), 2000.0, 0.707, 0.5, fixed2=261.6255653),
+    ]
+    n, off = 12000, 5000
+    for key in (45, 72):
+        params = (T.WelshParams * len(patches))(*patches)
+        bank = oracle.Bank.welsh(params)
+        lanes = np.arange(len(patches), dtype=np.uint32)
+        bank.note_events(T.note_events_np(lanes, np.full(len(patches), key, dtype=np.uint8), True))
+        got = bank.render(off)
+        bank.note_events(T.note_events_np(lanes, np.full(len(patches), key, dtype=np.uint8), False))
+        got = np.concatenate([got, bank.render(n - off)], axis=1)
+        for k, p in enumerate(patches):
+            want, idle_from = _independent_welsh_voice(p, key, n, off)
+            assert idle_from < n, "the render must reach the idle tail"
+            err = np.abs(got[:, :, k] - want)
+            # saw / triangle: frames within rounding of the waveform's discontinuity may land on either side in either implementation
+            suspicious = err.max(axis=0) > 1e-8
+            assert suspicious.sum() <= 2 and err[:, ~suspicious].max() <= 1e-8, (key, k, err.max(), int(suspicious.sum()))
+            assert np.abs(want).max() > 1e-3
+
+
+# ------------------------------------------------------------------------------------------ a6 FM voice, a7 sampler
+def test_fm_voice_is_a_phase_modulated_sine(oracle):
+    """Carrier phase = running sum of f_c / SR (1 + modulator x modulator envelope x depth x beta) — the first tick emits phase 0 —,
+    modulator at f_c x ratio, output = sin(carrier) x carrier envelope -> Dca."""
+    n, off, key = 9000, 4000, 57
+    for ratio, depth, beta, pan in ((2.0, 1.0, 1.0, 0.0), (3.5, 0.7, 10.0, -0.6), (0.5, 1.0, 0.1, 0.8)):
+        p = T.FmParams(ratio, depth, beta, T.EnvelopeParams(0.01, 0.05, 0.7, 0.05), T.EnvelopeParams(0.0, 0.2, 0.4, 0.02), 0.9, pan)
+        bank = oracle.Bank.fm((T.FmParams * 1)(p))
+        ev = lambda on: T.note_events_np(np.zeros(1, dtype=np.uint32), np.full(1, key, dtype=np.uint8), on)  # noqa: E731
+        bank.note_events(ev(True))
+        got = bank.render(off)
+        bank.note_events(ev(False))
+        got = np.concatenate([got, bank.render(n - off)], axis=1)[:, :, 0]
+        fc = 440.0 * 2.0 ** ((key - 69) / 12.0)
+        i = np.arange(n, dtype=np.longdouble)
+        mpos = i * (np.longdouble(fc * ratio) / np.longdouble(SR))
+        mod = np.sin(2.0 * np.pi * (mpos - np.floor(mpos)).astype(np.float64))
+        cenv, idle_from = _closed_form_envelope(0.01, 0.05, 0.7, 0.05, off, n)
+        menv, _ = _closed_form_envelope(0.0, 0.2, 0.4, 0.02, off, n)
+        lfm = mod * menv * float(np.float32(depth)) * float(np.float32(beta))
+        delta = (np.longdouble(fc) / np.longdouble(SR)) * (1.0 + lfm.astype(np.longdouble))
+        cpos = np.concatenate([[np.longdouble(0.0)], np.cumsum(delta[1:])])
+        car = np.sin(2.0 * np.pi * (cpos - np.floor(cpos)).astype(np.float64))
+        m = car * cenv * float(np.float32(0.9))
+        pf = float(np.float32(pan))
+        want = np.stack([m * (1.0 - 0.25 * (pf + 1.0) ** 2), m * (1.0 - (0.5 * pf - 0.5) ** 2)])
+        want[:, min(idle_from, n):] = 0.0
+        # (the oracle stops ticking its oscillators while the carrier envelope is idle; nothing sounds there either way)
+        assert idle_from < n and np.abs(want).max() > 0.3
+        assert np.abs(got - want).max() <= 2e-8, (ratio, np.abs(got - want).max())
+
+
+def test_sampler_is_pointer_stepping_without_interpolation(oracle):
+    """out[i] = pcm[floor(i x step)] x gain until the pointer runs off the end; step = note frequency / root frequency, or 1 for a
+    drumkit buffer (root 0); mono duplicated to both channels."""
+    rng = np.random.default_rng(12)
+    pcm = rng.uniform(-1, 1, 3000).astype(np.float32)
+    descs = (T.SampleDesc * 2)(T.SampleDesc(0, 2000, 440.0), T.SampleDesc(2000, 1000, 0.0))
+    params = (T.SamplerParams * 2)(T.SamplerParams(0, 1, 0.5), T.SamplerParams(1, 1, 1.0))
+    for key in (69, 76, 60):
+        bank = oracle.Bank.sampler(pcm, descs, params)
+        bank.note_events(T.note_events_np(np.arange(2, dtype=np.uint32), np.full(2, key, dtype=np.uint8), True))
+        n = 3500
+        got = bank.render(n)
+        for lane, (off0, length, root, gain) in enumerate(((0, 2000, 440.0, 0.5), (2000, 1000, 0.0, 1.0))):
+            step = (440.0 * 2.0 ** ((key - 69) / 12.0)) / root if root > 0 else 1.0
+            pos = np.arange(n) * step
+            idx = np.floor(pos).astype(np.int64)
+            want = np.where(idx < length, pcm[off0 + np.minimum(idx, length - 1)].astype(np.float64) * gain, 0.0)
+            safe = np.abs(pos - np.round(pos)) > 1e-6 if step != 1.0 and key != 69 else np.ones(n, dtype=bool)  # (an accumulated pointer within rounding of an integer)
+            assert np.array_equal(got[0, safe, lane], want[safe]) and np.array_equal(got[0, :, lane], got[1, :, lane]), (key, lane)
