@@ -347,10 +347,17 @@ def _independent_welsh_voice(p, key, n, off):
     24 dB low-pass, the pan law — without one line of oracle/: the frame order of SURVEY Appendix A.6 is what is under test."""
     f_note = 440.0 * 2.0 ** ((key - 69) / 12.0)
     i = np.arange(n, dtype=np.longdouble)
+    lpos = i * (np.longdouble(p.lfo_frequency) / np.longdouble(SR))
+    lfo = np.sin(2.0 * np.pi * (lpos - np.floor(lpos)).astype(np.float64))   # (sine LFOs only here; its first tick emits phase 0 too)
+    depth = float(np.float32(p.lfo_depth))
 
     def osc(o):
         f = o.fixed_hz if o.fixed_hz > 0.0 else f_note * o.tune
-        pos = i * (np.longdouble(f) / np.longdouble(SR))
+        if p.lfo_routing == T.LFO_PITCH:   # the increment of frame j is f 2^(lfo_j depth) / SR; frame 0 emits phase 0
+            inc = (np.longdouble(f) / np.longdouble(SR)) * np.exp2((lfo * depth).astype(np.longdouble))
+            pos = np.concatenate([[np.longdouble(0.0)], np.cumsum(inc[1:])])
+        else:
+            pos = i * (np.longdouble(f) / np.longdouble(SR))
         pos = (pos - np.floor(pos)).astype(np.float64)
         w = o.waveform
         if w == T.WAVE_SINE:
@@ -372,9 +379,7 @@ def _independent_welsh_voice(p, key, n, off):
     e = p.amp_envelope
     amp, idle_from = _closed_form_envelope(e.attack, e.decay, e.sustain, e.release, off, n)
     if p.lfo_routing == T.LFO_AMPLITUDE:
-        lpos = i * (np.longdouble(p.lfo_frequency) / np.longdouble(SR))
-        lpos = (lpos - np.floor(lpos)).astype(np.float64)
-        amp = amp * (1.0 + np.sin(2.0 * np.pi * lpos) * float(np.float32(p.lfo_depth)))
+        amp = amp * (1.0 + lfo * depth)
     m = y * amp * float(np.float32(p.dca_gain))
     pan = float(np.float32(p.dca_pan))
     out = np.stack([m * (1.0 - 0.25 * (pan + 1.0) ** 2), m * (1.0 - (0.5 * pan - 0.5) ** 2)])
@@ -382,21 +387,21 @@ def _independent_welsh_voice(p, key, n, off):
     return out, idle_from
 
 
-def _welsh_patch(w1, w2, tune2, mix, env, cutoff, ripple, pan, lfo=None, duty=0.3, fixed2=0.0):
+def _welsh_patch(w1, w2, tune2, mix, env, cutoff, ripple, pan, lfo=None, duty=0.3, fixed2=0.0, routing=None):
     p = T.WelshParams()
     p.oscillator_1 = T.OscillatorParams(w1, duty, 1.0, 0.0)
     p.oscillator_2 = T.OscillatorParams(w2, duty, tune2, fixed2)
     p.oscillator_2_sync, p.oscillator_mix = 0, mix
     p.amp_envelope = T.EnvelopeParams(*env)
     p.filter_envelope = T.EnvelopeParams(0.01, 0.1, 0.5, 0.1)    # (runs, but drives nothing: filter_cutoff_end = 0)
-    p.lfo_waveform, p.lfo_routing, p.lfo_frequency, p.lfo_depth = T.WAVE_SINE, (T.LFO_AMPLITUDE if lfo else T.LFO_NONE), (lfo or (1.0, 0.0))[0], (lfo or (1.0, 0.0))[1]
+    p.lfo_waveform, p.lfo_routing, p.lfo_frequency, p.lfo_depth = T.WAVE_SINE, (routing if routing is not None else (T.LFO_AMPLITUDE if lfo else T.LFO_NONE)), (lfo or (1.0, 0.0))[0], (lfo or (1.0, 0.0))[1]
     p.filter_cutoff_hz, p.filter_passband_ripple, p.filter_cutoff_start, p.filter_cutoff_end = cutoff, ripple, 0.5, 0.0
     p.dca_gain, p.dca_pan = 0.8, pan
     return p
 
 
 def test_welsh_voice_composition_against_an_independent_array_implementation(oracle):
-    """Six hand-built patches x two keys: oscillator pair -> mix -> static 24 dB low-pass -> amplitude envelope (x LFO) -> Dca, with
+    """Seven hand-built patches x two keys (the last one with the LFO on the pitch of both oscillators): oscillator pair -> mix -> static 24 dB low-pass -> amplitude envelope (x LFO) -> Dca, with
     the note-off inside the render and the idle tail after the release.  Bar: 1e-8 of full scale (n additions of the phase
     increment against a closed form; a sample whose phase is within rounding of a waveform edge is skipped)."""
     patches = [
@@ -406,6 +411,7 @@ def test_welsh_voice_composition_against_an_independent_array_implementation(ora
         _welsh_patch(T.WAVE_SINE, T.WAVE_SINE, 2.0 ** (5 / 1200), 0.5, (0.002, 0.3, 0.0, 0.3), 800.0, 1.2, 0.0, lfo=(0.53, 0.5)),
         _welsh_patch(T.WAVE_TRIANGLE, T.WAVE_NONE, 1.0, 1.0, (0.05, 0.1, 0.8, 0.1), 150.0, 0.8, -1.0),
         _welsh_patch(T.WAVE_SINE, T.WAVE_SAWTOOTH, 1.0, 0.7, (0.01, 0.05, 0.5, 0.04), 2000.0, 0.707, 0.5, fixed2=261.6255653),
+        _welsh_patch(T.WAVE_SINE, T.WAVE_TRIANGLE, 2.0 ** (12 / 12), 0.5, (0.005, 0.1, 0.7, 0.06), 1500.0, 0.9, -0.2, lfo=(5.13, 0.05), routing=T.LFO_PITCH),  # vibrato
     ]
     n, off = 12000, 5000
     for key in (45, 72):
