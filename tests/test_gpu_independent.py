@@ -6,6 +6,8 @@ triangle for every row of SURVEY.md section 8(a) that has a published form and c
   a4  24 dB low-pass    scipy.signal.cheby1(4, ...) — pre-warped bilinear transform — up to its DC gain
   a8  Gain, a9 Bitcrusher   numpy (the quantise in integers: bit-exact)
   a10 Chorus, a11 Delay, a12 Reverb   sparse-coefficient lfilter (taps, pure delay, four combs + two all-passes)
+  a5  WelshVoice        static-filter patches end to end (time-parallel and serial kernels) against the array composition of
+                        tests/test_oracle_independent.py: closed-form phases and envelopes, scipy's filter, the pan law
 
 Blocks are fp32 in HBM and the IIR state is f64: the bar is 2e-6 of the signal's peak per block of input (a delay is exact).
 Lane counts and block lengths are chosen so that the serial, the segmented, the time-parallel and the fused-run kernels are
@@ -128,3 +130,49 @@ def test_reverb_is_four_combs_and_two_allpasses(gpu_ctx):
         a = np.zeros(N + 1); a[0] = 1.0; a[N] = -g
         s = signal.lfilter(b, a, s, axis=1)
     _close(got, s, tol=5e-6)
+
+
+@pytest.mark.parametrize("form", ["time-parallel", "serial"])
+def test_welsh_voice_against_the_independent_array_composition(gpu_ctx, form):
+    """a5 end to end on the GPU against the array composition of tests/test_oracle_independent.py (closed-form phases and envelopes,
+    scipy's Chebyshev, the pan law — nothing of oracle/): seven static-filter patches through note-on, note-off and the idle tail,
+    in the time-parallel and in the serial kernel forms.  fp32 feed-forward math: 1e-5 of full scale per sample."""
+    from groove_amd import entities as E
+    from tests.test_oracle_independent import _independent_welsh_voice, _welsh_patch
+    patches = [
+        _welsh_patch(T.WAVE_SAWTOOTH, T.WAVE_SINE, 2.0 ** (7 / 12), 0.6, (0.01, 0.05, 0.6, 0.08), 1200.0, 0.9, -0.4),
+        _welsh_patch(T.WAVE_SINE, T.WAVE_TRIANGLE, 2.0, 0.5, (0.0, 0.02, 0.3, 0.05), 400.0, 0.707, 0.25, lfo=(5.13, 0.3)),
+        _welsh_patch(T.WAVE_TRIANGLE, T.WAVE_SAWTOOTH, 1.0, 0.25, (0.03, 0.0, 1.0, 0.02), 3000.0, 1.607, 1.0),
+        _welsh_patch(T.WAVE_SINE, T.WAVE_SINE, 2.0 ** (5 / 1200), 0.5, (0.002, 0.3, 0.0, 0.3), 800.0, 1.2, 0.0, lfo=(0.53, 0.5)),
+        _welsh_patch(T.WAVE_TRIANGLE, T.WAVE_NONE, 1.0, 1.0, (0.05, 0.1, 0.8, 0.1), 150.0, 0.8, -1.0),
+        _welsh_patch(T.WAVE_SINE, T.WAVE_SAWTOOTH, 1.0, 0.7, (0.01, 0.05, 0.5, 0.04), 2000.0, 0.707, 0.5, fixed2=261.6255653),
+        _welsh_patch(T.WAVE_SINE, T.WAVE_TRIANGLE, 2.0, 0.5, (0.005, 0.1, 0.7, 0.06), 1500.0, 0.9, -0.2, lfo=(5.13, 0.05), routing=T.LFO_PITCH),
+    ]
+    blocks, off_block, key = 47, 20, 57          # 12,032 frames, note-off at frame 5,120
+    n = len(patches)
+    old = gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves
+    if form == "serial":
+        gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves = 0, 0
+    try:
+        synth = E.WelshSynth(gpu_ctx, (T.WelshParams * n)(*patches))
+        assert ("tp" in synth.kernel_form(FR, False)) == (form == "time-parallel")
+        block = gpu_ctx.block(n, FR)
+        lanes = np.arange(n, dtype=np.uint32)
+        got = []
+        for b in range(blocks):
+            if b == 0:
+                synth.handle_midi_events(T.note_events_np(lanes, np.full(n, key, dtype=np.uint8), True))
+            if b == off_block:
+                synth.handle_midi_events(T.note_events_np(lanes, np.full(n, key, dtype=np.uint8), False))
+            synth.generate_batch_values(block, FR)
+            got.append(block.download(FR))
+        got = np.concatenate(got, axis=1).astype(np.float64)
+        synth.destroy(); block.destroy()
+    finally:
+        gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves = old
+    for k, p in enumerate(patches):
+        want, idle_from = _independent_welsh_voice(p, key, blocks * FR, off_block * FR)
+        assert idle_from < blocks * FR
+        err = np.abs(got[:, :, k] - want)
+        suspicious = err.max(axis=0) > 1e-5          # a sawtooth / triangle sample within rounding of the waveform's edge
+        assert suspicious.sum() <= 2 and err[:, ~suspicious].max() <= 1e-5, (form, k, float(err.max()), int(suspicious.sum()))
