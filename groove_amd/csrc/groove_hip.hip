@@ -1917,6 +1917,22 @@ int groove_bank_render_mix_paced(groove_bank* b, uint32_t frames, float* bus_dev
   if (flush_events(b, use_tp(b, frames))) return 1;
   return render_mix_pipelined(b, frames, bus_dev, accumulate, true);
 }
+// The two row buffers of the deferred renders, BOTH sized at once: growing one of them later would have to flush the pending block
+// through the reduction kernels — whose order of additions differs from the carried reduction's — and a project's first run would
+// then round one block differently from every later run (seen by tools/soak.py: 1 CRC in 138,107 repeats of config #4).
+static int ensure_dpart(groove_ctx* ctx, size_t need) {
+  if (ctx->dpart_cap[0] >= need && ctx->dpart_cap[1] >= need) return 0;
+  if (bus_flush(ctx)) return 1;                      // (the pending rows may live in a buffer that is about to go)
+  GHIP(ctx, wait_deadline(ctx, ctx->stream, nullptr, "deferred partial rows"));
+  for (int slot = 0; slot < 2; ++slot) {
+    if (ctx->dpart_cap[slot] >= need) continue;
+    if (ctx->d_dpart[slot]) GHIP(ctx, hipFree(ctx->d_dpart[slot]));
+    ctx->d_dpart[slot] = nullptr; ctx->dpart_cap[slot] = 0;
+    GHIP(ctx, hipMalloc(&ctx->d_dpart[slot], need * 4));
+    ctx->dpart_cap[slot] = need;
+  }
+  return 0;
+}
 // Fused render + mix whose bus reduction is left to the bank's NEXT deferred render (welsh_tp.h, tp_reduce_prev) — or to
 // whatever waits for the ctx stream, records an event on it or touches a bus (bus_flush).  For banks that render time-parallel
 // on the ctx stream with at most 2,048 partial rows; anything else is groove_bank_render_mix.
@@ -1942,13 +1958,7 @@ int groove_bank_render_mix_deferred(groove_bank* b, uint32_t frames, float* bus_
       const int slot = ctx->dpart_next;
       ctx->dpart_next ^= 1;
       const size_t need = (size_t)urows * 2 * frames;
-      if (ctx->dpart_cap[slot] < need) {
-        if (bus_flush(ctx)) return 1;
-        GHIP(ctx, wait_deadline(ctx, ctx->stream, nullptr, "deferred partial rows"));
-        if (ctx->d_dpart[slot]) GHIP(ctx, hipFree(ctx->d_dpart[slot]));
-        GHIP(ctx, hipMalloc(&ctx->d_dpart[slot], need * 4));
-        ctx->dpart_cap[slot] = need;
-      }
+      if (ensure_dpart(ctx, need)) return 1;
       UniformArgs a = uniform_args(b, ctx->d_dpart[slot], ctx->d_dpart[slot], 0, 0, frames, urows);
       if (ctx->deferred.rows) { a.prev.rows = ctx->deferred.rows; a.prev.bus = ctx->deferred.bus; a.prev.n_rows = ctx->deferred.n_rows; a.prev.frames = ctx->deferred.frames; a.prev.accumulate = ctx->deferred.accumulate; }
       deferred_taken(ctx);
@@ -1970,13 +1980,7 @@ int groove_bank_render_mix_deferred(groove_bank* b, uint32_t frames, float* bus_
   const int slot = ctx->dpart_next;
   ctx->dpart_next ^= 1;
   const size_t need = (size_t)rows * 2 * frames;
-  if (ctx->dpart_cap[slot] < need) {
-    if (bus_flush(ctx)) return 1;                    // (the pending rows may live in the buffer that is about to go)
-    GHIP(ctx, wait_deadline(ctx, ctx->stream, nullptr, "deferred partial rows"));
-    if (ctx->d_dpart[slot]) GHIP(ctx, hipFree(ctx->d_dpart[slot]));
-    GHIP(ctx, hipMalloc(&ctx->d_dpart[slot], need * 4));
-    ctx->dpart_cap[slot] = need;
-  }
+  if (ensure_dpart(ctx, need)) return 1;
   TpPrev prev;
   if (ctx->deferred.rows) { prev.rows = ctx->deferred.rows; prev.bus = ctx->deferred.bus; prev.n_rows = ctx->deferred.n_rows; prev.frames = ctx->deferred.frames; prev.accumulate = ctx->deferred.accumulate; }
   deferred_taken(ctx);
