@@ -212,6 +212,7 @@ struct groove_ctx {
   // instead of sleeping inside hipStreamSynchronize: a kernel that does not complete then comes
   // back as an ERROR that names the streams still busy, not as a hang.  0 = wait for ever.  GROOVE_SYNC_TIMEOUT_MS.
   uint32_t sync_timeout_ms = 60000;
+  unsigned long long host_waits = 0, host_waits_blocked = 0, host_wait_ns = 0; // wait_deadline: calls, calls that found work pending, time blocked (groove_debug_info)
   bool safe_streams = false;            // GROOVE_SAFE_STREAMS=1: one priority, four streams in all (ctx + three that kinds and banks share)
   bool comm_before_streams = false;     // groove_init_comm: the RCCL communicator (and its streams) existed before the library's own
   int streams_created = 0;              // hipStreamCreate* calls of this ctx, in order: ctx, kind streams, placeholder, bank streams
@@ -278,7 +279,11 @@ hipError_t wait_deadline(groove_ctx* ctx, hipStream_t st, hipEvent_t ev, const c
   const auto limit = std::chrono::milliseconds(ctx->sync_timeout_ms);
   for (uint32_t spins = 0;; ++spins) {
     const hipError_t q = ev ? hipEventQuery(ev) : hipStreamQuery(st);
-    if (q != hipErrorNotReady) return q;
+    if (q != hipErrorNotReady) {
+      ctx->host_waits += 1;
+      if (spins) { ctx->host_waits_blocked += 1; ctx->host_wait_ns += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+      return q;
+    }
     const auto waited = std::chrono::steady_clock::now() - t0;
     if (waited > limit) break;
     // the first ~100 us busy-poll (most waits of this path are that short), then yield, then sleep in growing steps
@@ -1186,7 +1191,8 @@ int groove_debug_info(groove_ctx* ctx, char* out, size_t cap) {
   // the segment guard's counter (diag.h): what the kernels have counted so far (groove_synchronize first for a final figure)
   DiagCounters dc{};
   GHIP(ctx, ctx_memcpy(ctx, &dc, ctx->d_diag, sizeof(dc), hipMemcpyDeviceToHost));
-  std::string diag = "\"zero_segments\": " + std::to_string(dc.zero_segments);
+  std::string diag = "\"host_waits\": " + std::to_string(ctx->host_waits) + ", \"host_waits_blocked\": " + std::to_string(ctx->host_waits_blocked) + ", \"host_wait_ms\": " + std::to_string((double)ctx->host_wait_ns * 1e-6) +
+                     ", \"zero_segments\": " + std::to_string(dc.zero_segments);
 #ifdef GROOVE_DIAG_SHADOW_IN_MIN
   diag += ", \"diag_build\": \"GROOVE_DIAG_SHADOW_IN_MIN\", \"shadow_zero_lanes\": " + std::to_string(dc.shadow_zero_lanes) + ", \"shadow_zero_waves\": " + std::to_string(dc.shadow_zero_waves) + ", \"records\": [";
   for (uint32_t i = 0; i < std::min(dc.records, kDiagRecords); ++i) {
@@ -1484,14 +1490,14 @@ static uint32_t tp_vpw(const groove_bank* b) { // voices per wavefront of the ti
   return (b->kind == BANK_WELSH && b->tp_pairs && b->ctx->tp_vpw2_min_voices && b->n >= b->ctx->tp_vpw2_min_voices) ? 2u : 1u;
 }
 static void launch_tp(groove_bank* b, uint32_t frames, bool fused, size_t chs, float* out, float* rows, hipStream_t st, const groove_fx* head = nullptr,
-                      hipEvent_t done = nullptr /* Welsh only: completes with the kernel (bound to the dispatch) */, const TpPrev* prev = nullptr,
+                      hipEvent_t done = nullptr /* completes with the kernel (bound to the dispatch: kernels.h launch_bound) */, const TpPrev* prev = nullptr,
                       uint32_t sampler_vpw = 0 /* sampler only: voices per wavefront (0: the default rule) */) {
   groove_ctx* ctx = b->ctx;
   TpArgs a{b->d_params, b->d_state, out, rows, chs, render_consts(ctx->sr), b->n, frames};
   if (prev) a.prev = *prev;
   if (head) { a.bq_coef = head->d_coef; a.bq_st = head->d_st; a.bq_wet = head->d_wet; } // Welsh, block-writing form: the BiQuad head fused (welsh_tp.h)
-  if (b->kind == BANK_FM) { a.vpw = tp_vpw(b); launch_fm_tp(a, st, fused); }
-  else if (b->kind == BANK_SAMPLER) { a.vpw = sampler_vpw; launch_sampler_tp(a, b->d_pcm, b->inline_ev, st, fused); b->inline_ev.n = 0; }
+  if (b->kind == BANK_FM) { a.vpw = tp_vpw(b); launch_fm_tp(a, st, fused, done); }
+  else if (b->kind == BANK_SAMPLER) { a.vpw = sampler_vpw; launch_sampler_tp(a, b->d_pcm, b->inline_ev, st, fused, done); b->inline_ev.n = 0; }
   else { a.full_coef = b->tp_full_coef; a.vpw = tp_vpw(b); launch_welsh_tp(a, st, fused, done); }
 }
 // rows of partial[][2][frames] a bank's fused render writes
@@ -1517,8 +1523,8 @@ static bool use_split(const groove_bank* b, uint32_t frames) {
   return b->kind == BANK_WELSH && b->n_vwaves && !use_tp(b, frames) && b->n_vwaves <= std::max(ctx->split_max_waves, ctx->split2_max_waves) && frames >= 2 * kSplitChunk;
 }
 static int split_roles_of(const groove_bank* b) { return b->n_vwaves <= b->ctx->split_max_waves ? b->ctx->split_roles : 2; }
-static void launch_welsh_kind(int k, const UniformArgs& a, hipStream_t st, bool fused);
-static void launch_small_uniform(groove_bank* b, const UniformArgs& a, hipStream_t st, bool fused, uint32_t frames) {
+static void launch_welsh_kind(int k, const UniformArgs& a, hipStream_t st, bool fused, hipEvent_t done = nullptr);
+static void launch_small_uniform(groove_bank* b, const UniformArgs& a, hipStream_t st, bool fused, uint32_t frames, hipEvent_t done = nullptr /* bound to the last launch */) {
   // the workgroup list is sorted by kind: the four class-specialised base kinds first, then the two exact-f64 ones
   uint32_t n_spec = 0, n_f64[2] = {0, 0};
   for (int k = 0; k < 4 * kClassCombos; ++k) n_spec += b->wgs_of_kind[k];
@@ -1526,14 +1532,15 @@ static void launch_small_uniform(groove_bank* b, const UniformArgs& a, hipStream
   if (n_spec) {
     UniformArgs s = a;
     s.n_wgs = n_spec;
+    const hipEvent_t d = (n_f64[0] || n_f64[1]) ? nullptr : done;
     if (use_split(b, frames)) {
       const int roles = split_roles_of(b);
-      if (roles == 4) launch_welsh_split4(s, b->d_wg_base, st, fused);
-      else if (roles == 3) launch_welsh_split(s, b->d_wg_base, st, fused);
-      else launch_welsh_split2(s, b->d_wg_base, st, fused);
+      if (roles == 4) launch_welsh_split4(s, b->d_wg_base, st, fused, d);
+      else if (roles == 3) launch_welsh_split(s, b->d_wg_base, st, fused, d);
+      else launch_welsh_split2(s, b->d_wg_base, st, fused, d);
     }
-    else if (fused) launch_welsh_uniform_any(s, b->d_wg_base, st);
-    else launch_welsh_uniform_any_unfused(s, b->d_wg_base, st);
+    else if (fused) launch_welsh_uniform_any(s, b->d_wg_base, st, d);
+    else launch_welsh_uniform_any_unfused(s, b->d_wg_base, st, d);
   }
   // exact-f64 LFO kinds (rare; their bodies need 133 VGPRs): the per-kind kernels, budgeted for them, behind it on the same stream
   uint32_t at = n_spec;
@@ -1542,26 +1549,26 @@ static void launch_small_uniform(groove_bank* b, const UniformArgs& a, hipStream
     UniformArgs r = a;
     r.prev = TpPrev{}; // (the launch above carried the previous block's rows)
     r.wg_list = a.wg_list + at; r.wg_cls = a.wg_cls + at; r.n_wgs = n_f64[j];
-    launch_welsh_kind(4 + j, r, st, fused);
+    launch_welsh_kind(4 + j, r, st, fused, (j == 1 || !n_f64[1]) ? done : nullptr);
     at += n_f64[j];
   }
 }
 // One base kind's uniform Welsh kernel (kernels.h, "Workgroup KINDS") on stream `st`.
-static void launch_welsh_kind(int k, const UniformArgs& a, hipStream_t st, bool fused) {
+static void launch_welsh_kind(int k, const UniformArgs& a, hipStream_t st, bool fused, hipEvent_t done) {
   const dim3 kgrid(a.n_wgs), blk(kThreads);
   if (wg_base_kind_specialised(k)) {
     switch (k) {
-      case 0: launch_welsh_uniform_specialised_0(a, st, fused); break;
-      case 1: launch_welsh_uniform_specialised_1(a, st, fused); break;
-      case 2: launch_welsh_uniform_specialised_2(a, st, fused); break;
-      default: launch_welsh_uniform_specialised_3(a, st, fused); break;
+      case 0: launch_welsh_uniform_specialised_0(a, st, fused, done); break;
+      case 1: launch_welsh_uniform_specialised_1(a, st, fused, done); break;
+      case 2: launch_welsh_uniform_specialised_2(a, st, fused, done); break;
+      default: launch_welsh_uniform_specialised_3(a, st, fused, done); break;
     }
     return;
   }
 #define GROOVE_LAUNCH_UNIFORM(MODE, RETUNE)                                                                              \
   do {                                                                                                                   \
-    if (fused) hipLaunchKernelGGL((welsh_render_uniform_kernel<true, MODE, RETUNE, false>), kgrid, blk, 0, st, a);        \
-    else hipLaunchKernelGGL((welsh_render_uniform_kernel<false, MODE, RETUNE, false>), kgrid, blk, 0, st, a);             \
+    if (fused) launch_bound(welsh_render_uniform_kernel<true, MODE, RETUNE, false>, kgrid, blk, st, done, a);             \
+    else launch_bound(welsh_render_uniform_kernel<false, MODE, RETUNE, false>, kgrid, blk, st, done, a);                  \
   } while (0)
   switch (k) {
     case wg_base_kind_of(LFO_F32, false): GROOVE_LAUNCH_UNIFORM(LFO_F32, false); break;
@@ -1863,29 +1870,25 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
     used |= 1u << k;
     if (ctx->fork_pending[k]) { GHIP(ctx, hipStreamWaitEvent(st, ctx->ev_fork, 0)); ctx->fork_pending[k] = false; }
     if (b->reduce_recorded[slot]) GHIP(ctx, hipStreamWaitEvent(st, b->ev_reduce_done[slot], 0));
+    // the block's "render done" event completes with the render kernel itself (kernels.h launch_bound): no record packet between
+    // this block's kernel and the next block's on the stream
+    const hipEvent_t done = ctx->bind_events ? b->ev_render_done[k][slot] : nullptr;
     if (uniform) {
       UniformArgs a = uniform_args(b, b->d_pipe_part[slot], b->d_pipe_part[slot], offset[k], 0, frames, count[k]);
-      switch (k) {
-        case 0: launch_welsh_uniform_specialised_0(a, st, true); break;
-        case 1: launch_welsh_uniform_specialised_1(a, st, true); break;
-        case 2: launch_welsh_uniform_specialised_2(a, st, true); break;
-        case 3: launch_welsh_uniform_specialised_3(a, st, true); break;
-        case 4: hipLaunchKernelGGL((welsh_render_uniform_kernel<true, LFO_F64, false, false>), dim3(count[k]), blk, 0, st, a); break;
-        default: hipLaunchKernelGGL((welsh_render_uniform_kernel<true, LFO_F64, true, false>), dim3(count[k]), blk, 0, st, a); break;
-      }
+      launch_welsh_kind(k, a, st, true, done);
     } else if (tp) {
-      launch_tp(b, frames, true, 0, b->d_pipe_part[slot], b->d_pipe_part[slot], st);
+      launch_tp(b, frames, true, 0, b->d_pipe_part[slot], b->d_pipe_part[slot], st, nullptr, done);
     } else if (small_uniform) { // all base kinds in one launch on this bank's stream
       UniformArgs a = uniform_args(b, b->d_pipe_part[slot], b->d_pipe_part[slot], 0, 0, frames, rows);
-      launch_small_uniform(b, a, st, true, frames);
+      launch_small_uniform(b, a, st, true, frames, done);
     } else if (b->kind == BANK_WELSH) {
-      hipLaunchKernelGGL(welsh_render_kernel<true>, dim3(rows), blk, 0, st, b->d_params, b->d_state, b->n, frames, (size_t)0, b->d_pipe_part[slot], b->d_pipe_part[slot], rc);
+      launch_bound(welsh_render_kernel<true>, dim3(rows), blk, st, done, b->d_params, b->d_state, b->n, frames, (size_t)0, b->d_pipe_part[slot], b->d_pipe_part[slot], rc);
     } else if (b->kind == BANK_FM) {
-      hipLaunchKernelGGL(fm_render_kernel<true>, dim3(rows), blk, 0, st, b->d_params, b->d_state, b->n, frames, (size_t)0, b->d_pipe_part[slot], b->d_pipe_part[slot]);
+      launch_bound(fm_render_kernel<true>, dim3(rows), blk, st, done, b->d_params, b->d_state, b->n, frames, (size_t)0, b->d_pipe_part[slot], b->d_pipe_part[slot]);
     } else {
-      hipLaunchKernelGGL(sampler_render_kernel<true>, dim3(rows), blk, 0, st, b->d_params, b->d_state, b->n, frames, (size_t)0, b->d_pipe_part[slot], b->d_pipe_part[slot], b->d_pcm);
+      launch_bound(sampler_render_kernel<true>, dim3(rows), blk, st, done, b->d_params, b->d_state, b->n, frames, (size_t)0, b->d_pipe_part[slot], b->d_pipe_part[slot], (const float*)b->d_pcm);
     }
-    GHIP(ctx, hipEventRecord(b->ev_render_done[k][slot], st));
+    if (!done) GHIP(ctx, hipEventRecord(b->ev_render_done[k][slot], st));
     if (!paced) GHIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_render_done[k][slot], 0));
     ctx->side_busy[k] = true;
   }

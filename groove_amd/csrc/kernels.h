@@ -12,6 +12,7 @@
 // DESIGN.md §5 for the op budget), the effect and mix kernels HBM-bound.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include "dsp_core.h"
 #include "derive.h"
 #include "diag.h"
@@ -541,12 +542,20 @@ __global__ __launch_bounds__(kThreads, GROOVE_WAVES_ANY) GROOVE_NO_TAIL_CALLS vo
 static_assert(OSC_CLASSES == 5 && LFO_CLASSES == 6 && kClassCombos <= 256, "the class switch above lists 6 x 5 x 5 combinations, one byte each");
 // Launchers of the four class-specialised fused kernels, one translation unit each
 // (csrc/welsh_class.hip, -DGROOVE_BASE_KIND=0..3) so that they compile in parallel.
-void launch_welsh_uniform_specialised_0(const UniformArgs& a, hipStream_t st, bool fused);
-void launch_welsh_uniform_specialised_1(const UniformArgs& a, hipStream_t st, bool fused);
-void launch_welsh_uniform_specialised_2(const UniformArgs& a, hipStream_t st, bool fused);
-void launch_welsh_uniform_specialised_3(const UniformArgs& a, hipStream_t st, bool fused);
-void launch_welsh_uniform_any(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st);         // fused: csrc/welsh_class.hip, -DGROOVE_BASE_KIND=9
-void launch_welsh_uniform_any_unfused(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st); // writes the voice block: -DGROOVE_BASE_KIND=8
+// `done` (optional, every launcher below): an event that completes WITH the kernel — bound to the dispatch's own completion signal
+// (hipExtLaunchKernelGGL) instead of recorded behind it: a recorded event is a barrier packet of its own, ~5 us of its stream's timeline
+// before the next kernel of the stream starts.
+template <class K, class... Args>
+static inline void launch_bound(K kernel, dim3 grid, dim3 blk, hipStream_t st, hipEvent_t done, Args... args) {
+  if (done) hipExtLaunchKernelGGL(kernel, grid, blk, 0, st, nullptr, done, 0, args...);
+  else hipLaunchKernelGGL(kernel, grid, blk, 0, st, args...);
+}
+void launch_welsh_uniform_specialised_0(const UniformArgs& a, hipStream_t st, bool fused, hipEvent_t done = nullptr);
+void launch_welsh_uniform_specialised_1(const UniformArgs& a, hipStream_t st, bool fused, hipEvent_t done = nullptr);
+void launch_welsh_uniform_specialised_2(const UniformArgs& a, hipStream_t st, bool fused, hipEvent_t done = nullptr);
+void launch_welsh_uniform_specialised_3(const UniformArgs& a, hipStream_t st, bool fused, hipEvent_t done = nullptr);
+void launch_welsh_uniform_any(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, hipEvent_t done = nullptr); // fused: csrc/welsh_class.hip, -DGROOVE_BASE_KIND=9
+void launch_welsh_uniform_any_unfused(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, hipEvent_t done = nullptr); // writes the voice block: -DGROOVE_BASE_KIND=8
 
 template <bool FUSED>
 __global__ __launch_bounds__(kThreads) void fm_render_kernel(

@@ -12,32 +12,32 @@
 #endif
 namespace groove {
 #if GROOVE_BASE_KIND == 0
-void launch_welsh_uniform_specialised_0(const UniformArgs& a, hipStream_t st, bool fused) {
-  if (fused) hipLaunchKernelGGL((welsh_render_uniform_kernel<true, LFO_F32, false, true>), dim3(a.n_wgs), dim3(kThreads), 0, st, a);
-  else hipLaunchKernelGGL((welsh_render_uniform_kernel<false, LFO_F32, false, true>), dim3(a.n_wgs), dim3(kThreads), 0, st, a);
+void launch_welsh_uniform_specialised_0(const UniformArgs& a, hipStream_t st, bool fused, hipEvent_t done) {
+  if (fused) launch_bound(welsh_render_uniform_kernel<true, LFO_F32, false, true>, dim3(a.n_wgs), dim3(kThreads), st, done, a);
+  else launch_bound(welsh_render_uniform_kernel<false, LFO_F32, false, true>, dim3(a.n_wgs), dim3(kThreads), st, done, a);
 }
 #elif GROOVE_BASE_KIND == 1
-void launch_welsh_uniform_specialised_1(const UniformArgs& a, hipStream_t st, bool fused) {
-  if (fused) hipLaunchKernelGGL((welsh_render_uniform_kernel<true, LFO_F32, true, true>), dim3(a.n_wgs), dim3(kThreads), 0, st, a);
-  else hipLaunchKernelGGL((welsh_render_uniform_kernel<false, LFO_F32, true, true>), dim3(a.n_wgs), dim3(kThreads), 0, st, a);
+void launch_welsh_uniform_specialised_1(const UniformArgs& a, hipStream_t st, bool fused, hipEvent_t done) {
+  if (fused) launch_bound(welsh_render_uniform_kernel<true, LFO_F32, true, true>, dim3(a.n_wgs), dim3(kThreads), st, done, a);
+  else launch_bound(welsh_render_uniform_kernel<false, LFO_F32, true, true>, dim3(a.n_wgs), dim3(kThreads), st, done, a);
 }
 #elif GROOVE_BASE_KIND == 2
-void launch_welsh_uniform_specialised_2(const UniformArgs& a, hipStream_t st, bool fused) {
-  if (fused) hipLaunchKernelGGL((welsh_render_uniform_kernel<true, LFO_F64_SMOOTH, false, true>), dim3(a.n_wgs), dim3(kThreads), 0, st, a);
-  else hipLaunchKernelGGL((welsh_render_uniform_kernel<false, LFO_F64_SMOOTH, false, true>), dim3(a.n_wgs), dim3(kThreads), 0, st, a);
+void launch_welsh_uniform_specialised_2(const UniformArgs& a, hipStream_t st, bool fused, hipEvent_t done) {
+  if (fused) launch_bound(welsh_render_uniform_kernel<true, LFO_F64_SMOOTH, false, true>, dim3(a.n_wgs), dim3(kThreads), st, done, a);
+  else launch_bound(welsh_render_uniform_kernel<false, LFO_F64_SMOOTH, false, true>, dim3(a.n_wgs), dim3(kThreads), st, done, a);
 }
 #elif GROOVE_BASE_KIND == 3
-void launch_welsh_uniform_specialised_3(const UniformArgs& a, hipStream_t st, bool fused) {
-  if (fused) hipLaunchKernelGGL((welsh_render_uniform_kernel<true, LFO_F64_SMOOTH, true, true>), dim3(a.n_wgs), dim3(kThreads), 0, st, a);
-  else hipLaunchKernelGGL((welsh_render_uniform_kernel<false, LFO_F64_SMOOTH, true, true>), dim3(a.n_wgs), dim3(kThreads), 0, st, a);
+void launch_welsh_uniform_specialised_3(const UniformArgs& a, hipStream_t st, bool fused, hipEvent_t done) {
+  if (fused) launch_bound(welsh_render_uniform_kernel<true, LFO_F64_SMOOTH, true, true>, dim3(a.n_wgs), dim3(kThreads), st, done, a);
+  else launch_bound(welsh_render_uniform_kernel<false, LFO_F64_SMOOTH, true, true>, dim3(a.n_wgs), dim3(kThreads), st, done, a);
 }
 #elif GROOVE_BASE_KIND == 9
-void launch_welsh_uniform_any(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st) {
-  hipLaunchKernelGGL(welsh_render_uniform_any_kernel<true>, dim3(a.n_wgs), dim3(kThreads), 0, st, a, wg_base);
+void launch_welsh_uniform_any(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, hipEvent_t done) {
+  launch_bound(welsh_render_uniform_any_kernel<true>, dim3(a.n_wgs), dim3(kThreads), st, done, a, wg_base);
 }
 #elif GROOVE_BASE_KIND == 8
-void launch_welsh_uniform_any_unfused(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st) {
-  hipLaunchKernelGGL(welsh_render_uniform_any_kernel<false>, dim3(a.n_wgs), dim3(kThreads), 0, st, a, wg_base);
+void launch_welsh_uniform_any_unfused(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, hipEvent_t done) {
+  launch_bound(welsh_render_uniform_any_kernel<false>, dim3(a.n_wgs), dim3(kThreads), st, done, a, wg_base);
 }
 #else
 #error "GROOVE_BASE_KIND out of range"

@@ -681,8 +681,8 @@ __global__ __launch_bounds__(4 * kSplitLanes, GROOVE_WAVES_SPLIT) GROOVE_NO_TAIL
 }
 #endif
 #endif
-void launch_welsh_split4(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, bool fused); // four roles:  csrc/welsh_split.hip -DGROOVE_WELSH_SPLIT_TU=4
-void launch_welsh_split(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, bool fused);  // three roles: csrc/welsh_split.hip -DGROOVE_WELSH_SPLIT_TU=3
-void launch_welsh_split2(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, bool fused); // two roles:   csrc/welsh_split.hip -DGROOVE_WELSH_SPLIT_TU=2
+void launch_welsh_split4(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, bool fused, hipEvent_t done = nullptr); // four roles:  csrc/welsh_split.hip -DGROOVE_WELSH_SPLIT_TU=4
+void launch_welsh_split(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, bool fused, hipEvent_t done = nullptr);  // three roles: csrc/welsh_split.hip -DGROOVE_WELSH_SPLIT_TU=3
+void launch_welsh_split2(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, bool fused, hipEvent_t done = nullptr); // two roles:   csrc/welsh_split.hip -DGROOVE_WELSH_SPLIT_TU=2
 
 } // namespace groove

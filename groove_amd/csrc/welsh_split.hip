@@ -8,19 +8,19 @@
 #include "welsh_split.h"
 namespace groove {
 #if GROOVE_WELSH_SPLIT_TU == 3
-void launch_welsh_split(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, bool fused) {
-  if (fused) hipLaunchKernelGGL((welsh_render_split_kernel<true, 3>), dim3(a.n_wgs), dim3(3 * kSplitLanes), 0, st, a, wg_base);
-  else hipLaunchKernelGGL((welsh_render_split_kernel<false, 3>), dim3(a.n_wgs), dim3(3 * kSplitLanes), 0, st, a, wg_base);
+void launch_welsh_split(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, bool fused, hipEvent_t done) {
+  if (fused) launch_bound(welsh_render_split_kernel<true, 3>, dim3(a.n_wgs), dim3(3 * kSplitLanes), st, done, a, wg_base);
+  else launch_bound(welsh_render_split_kernel<false, 3>, dim3(a.n_wgs), dim3(3 * kSplitLanes), st, done, a, wg_base);
 }
 #elif GROOVE_WELSH_SPLIT_TU == 4
-void launch_welsh_split4(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, bool fused) {
-  if (fused) hipLaunchKernelGGL((welsh_render_split4_kernel<true>), dim3(a.n_wgs), dim3(4 * kSplitLanes), 0, st, a, wg_base);
-  else hipLaunchKernelGGL((welsh_render_split4_kernel<false>), dim3(a.n_wgs), dim3(4 * kSplitLanes), 0, st, a, wg_base);
+void launch_welsh_split4(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, bool fused, hipEvent_t done) {
+  if (fused) launch_bound(welsh_render_split4_kernel<true>, dim3(a.n_wgs), dim3(4 * kSplitLanes), st, done, a, wg_base);
+  else launch_bound(welsh_render_split4_kernel<false>, dim3(a.n_wgs), dim3(4 * kSplitLanes), st, done, a, wg_base);
 }
 #else
-void launch_welsh_split2(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, bool fused) {
-  if (fused) hipLaunchKernelGGL((welsh_render_split_kernel<true, 2>), dim3(a.n_wgs), dim3(2 * kSplitLanes), 0, st, a, wg_base);
-  else hipLaunchKernelGGL((welsh_render_split_kernel<false, 2>), dim3(a.n_wgs), dim3(2 * kSplitLanes), 0, st, a, wg_base);
+void launch_welsh_split2(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, bool fused, hipEvent_t done) {
+  if (fused) launch_bound(welsh_render_split_kernel<true, 2>, dim3(a.n_wgs), dim3(2 * kSplitLanes), st, done, a, wg_base);
+  else launch_bound(welsh_render_split_kernel<false, 2>, dim3(a.n_wgs), dim3(2 * kSplitLanes), st, done, a, wg_base);
 }
 #endif
 } // namespace groove

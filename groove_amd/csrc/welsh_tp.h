@@ -958,8 +958,8 @@ __global__ __launch_bounds__(kSamplerTpThreads) void sampler_tp_kernel(TpArgs a,
   }
 }
 void launch_welsh_tp(const TpArgs& a, hipStream_t st, bool fused, hipEvent_t done = nullptr); // a.bq_coef set (block-writing form): the BiQuad head fused; done: an event bound to the dispatch
-void launch_fm_tp(const TpArgs& a, hipStream_t st, bool fused); // a.vpw voices per wavefront (1, 2, 4)
-void launch_sampler_tp(const TpArgs& a, const float* bank, const InlineEvents& ie, hipStream_t st, bool fused);
+void launch_fm_tp(const TpArgs& a, hipStream_t st, bool fused, hipEvent_t done = nullptr); // a.vpw voices per wavefront (1, 2, 4)
+void launch_sampler_tp(const TpArgs& a, const float* bank, const InlineEvents& ie, hipStream_t st, bool fused, hipEvent_t done = nullptr);
 inline uint32_t welsh_tp_workgroups(uint32_t n, uint32_t vpw = 1) { return (n + kTpWaves * vpw - 1) / (kTpWaves * vpw); } // FM: groups of 4 vpw voices per workgroup, plain order
 inline uint32_t welsh_tp_grid(uint32_t n, uint32_t vpw = 1) { // Welsh: padded for the XCD-aware mapping (idle workgroups write zero rows)
   const uint32_t g = welsh_tp_workgroups(n, vpw);

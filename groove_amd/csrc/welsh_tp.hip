@@ -32,21 +32,21 @@ void launch_welsh_tp(const TpArgs& a, hipStream_t st, bool fused, hipEvent_t don
   else launch_welsh_tp_vpw<1>(a, st, fused, done);
 }
 template <int VPW>
-static void launch_fm_tp_vpw(const TpArgs& a, hipStream_t st, bool fused) {
+static void launch_fm_tp_vpw(const TpArgs& a, hipStream_t st, bool fused, hipEvent_t done) {
   const dim3 grid(welsh_tp_workgroups(a.n, VPW)), blk(kTpThreads);
-  if (fused) hipLaunchKernelGGL((fm_tp_kernel<true, VPW>), grid, blk, 0, st, a);
-  else hipLaunchKernelGGL((fm_tp_kernel<false, VPW>), grid, blk, 0, st, a);
+  if (fused) tp_launch(fm_tp_kernel<true, VPW>, grid, blk, 0, st, done, a);
+  else tp_launch(fm_tp_kernel<false, VPW>, grid, blk, 0, st, done, a);
 }
-void launch_fm_tp(const TpArgs& a, hipStream_t st, bool fused) {
-  if (a.vpw == 4) launch_fm_tp_vpw<4>(a, st, fused);
-  else if (a.vpw == 2) launch_fm_tp_vpw<2>(a, st, fused);
-  else launch_fm_tp_vpw<1>(a, st, fused);
+void launch_fm_tp(const TpArgs& a, hipStream_t st, bool fused, hipEvent_t done) {
+  if (a.vpw == 4) launch_fm_tp_vpw<4>(a, st, fused, done);
+  else if (a.vpw == 2) launch_fm_tp_vpw<2>(a, st, fused, done);
+  else launch_fm_tp_vpw<1>(a, st, fused, done);
 }
-void launch_sampler_tp(const TpArgs& a, const float* bank, const InlineEvents& ie, hipStream_t st, bool fused) {
+void launch_sampler_tp(const TpArgs& a, const float* bank, const InlineEvents& ie, hipStream_t st, bool fused, hipEvent_t done) {
   const uint32_t vpw = a.vpw > 1 ? a.vpw : sampler_tp_vpw(a.n); // (a.vpw: the deferred form's choice)
   const dim3 grid(sampler_tp_workgroups(a.n, vpw)), blk(kSamplerTpThreads);
-  if (fused) hipLaunchKernelGGL(sampler_tp_kernel<true>, grid, blk, 0, st, a, bank, ie, vpw);
-  else hipLaunchKernelGGL(sampler_tp_kernel<false>, grid, blk, 0, st, a, bank, ie, vpw);
+  if (fused) launch_bound(sampler_tp_kernel<true>, grid, blk, st, done, a, bank, ie, vpw);
+  else launch_bound(sampler_tp_kernel<false>, grid, blk, st, done, a, bank, ie, vpw);
 }
 } // namespace groove
 #ifdef GROOVE_TP_PROBE

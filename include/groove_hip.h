@@ -65,7 +65,10 @@ uint32_t groove_sync_timeout_ms(groove_ctx* ctx);
  * groove_debug_info: a JSON object with the stream layout of this ctx and `zero_segments` — how often a Welsh kernel's wave
  * found that its ACTIVE lanes had zero frames to their next envelope boundary (csrc/diag.h: the counted assertion behind
  * DESIGN.md section 7; it must read 0, and the GPU tests, smoke() and bench.py require that).  It waits for the ctx stream;
- * call groove_synchronize first for a figure that includes the side streams' latest kernels. */
+ * call groove_synchronize first for a figure that includes the side streams' latest kernels.  `host_waits`,
+ * `host_waits_blocked`, `host_wait_ms`: how often the library's own waits (groove_synchronize, the paced calls, ...) ran, how
+ * many of them found the device still busy, and for how long in total the calling thread was blocked in them — a paced walk
+ * that is never blocked is bound by the host's submission, not by the device. */
 int groove_debug_spin(groove_ctx* ctx, int side_stream, uint32_t ms);
 int groove_debug_info(groove_ctx* ctx, char* out, size_t cap);
 /* Configurable::update_sample_rate fan-out (orchestrator.rs:125-127, 1019-1022, 1389-1394).

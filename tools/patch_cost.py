@@ -55,8 +55,12 @@ def main():
     ap.add_argument("--blocks", type=int, default=172)
     ap.add_argument("--subsets", default="", help="extra comma lists separated by ';' (e.g. '0,1;2,6')")
     ap.add_argument("--only", default="", help="comma list of single patches to time (default: all 32)")
+    ap.add_argument("--serial", action="store_true", help="force the serial kernels (no role split, no time-parallel form)")
     a = ap.parse_args()
     ctx = E.Context(0)
+    if a.serial:
+        ctx.split_max_waves = 0
+        ctx.time_parallel_max_voices = 0
     rows = []
     sets = [[j] for j in (map(int, a.only.split(",")) if a.only else range(P.N_PATCHES))]
     routing = [P.welsh_patch(j).lfo_routing for j in range(P.N_PATCHES)]
@@ -77,7 +81,7 @@ def main():
             desc = (f"o1={p.oscillator_1.waveform} o2={p.oscillator_2.waveform} lfo={p.lfo_waveform} route={p.lfo_routing} "
                     f"sync={p.oscillator_2_sync} env_end={p.filter_cutoff_end:.1f}")
         ns_vb = t.mean() * 1e6 / a.voices
-        print(f"{label:>12}  mean {t.mean():7.4f} ms  first {t[1:5].mean():7.4f}  sustain {t[60:80].mean():7.4f}  tail {t[-20:].mean():7.4f}"
+        print(f"{label:>12}  mean {t.mean():7.4f} ms  first {t[1:5].mean():7.4f}  window {t[5:25].mean():7.4f}  sustain {t[60:80].mean():7.4f}  tail {t[-20:].mean():7.4f}"
               f"  {ns_vb:6.3f} ns/voice-block  {desc}", flush=True)
     ctx.close()
 
