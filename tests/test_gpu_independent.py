@@ -8,6 +8,8 @@ triangle for every row of SURVEY.md section 8(a) that has a published form and c
   a10 Chorus, a11 Delay, a12 Reverb   sparse-coefficient lfilter (taps, pure delay, four combs + two all-passes)
   a5  WelshVoice        static-filter patches end to end (time-parallel and serial kernels) against the array composition of
                         tests/test_oracle_independent.py: closed-form phases and envelopes, scipy's filter, the pan law
+  a6  FmVoice           the extended-precision phase-modulated sine of tests/test_oracle_independent.py (one and four voices per wavefront)
+  a7  Sampler / Drumkit pcm[floor(i x step)] x gain, exact (time-parallel gather and the serial kernel's pointer stepping)
 
 Blocks are fp32 in HBM and the IIR state is f64: the bar is 2e-6 of the signal's peak per block of input (a delay is exact).
 Lane counts and block lengths are chosen so that the serial, the segmented, the time-parallel and the fused-run kernels are
@@ -176,3 +178,80 @@ def test_welsh_voice_against_the_independent_array_composition(gpu_ctx, form):
         err = np.abs(got[:, :, k] - want)
         suspicious = err.max(axis=0) > 1e-5          # a sawtooth / triangle sample within rounding of the waveform's edge
         assert suspicious.sum() <= 2 and err[:, ~suspicious].max() <= 1e-5, (form, k, float(err.max()), int(suspicious.sum()))
+
+
+@pytest.mark.parametrize("n", [3, 4100])   # one voice per wavefront / four voices per wavefront (groove_hip.hip tp_vpw)
+def test_fm_voice_against_the_independent_phase_modulated_sine(gpu_ctx, n):
+    """a6 on the GPU against tests/test_oracle_independent.py's extended-precision form (nothing of oracle/), through note-on, note-off
+    and the idle tail.  The carrier phase is a 64-bit counter fed by an f64 increment; the sines and envelopes are fp32: 2e-6 of full
+    scale, and at modulation index 10 the phase error of ~9,000 accumulated increments shows as 2e-5."""
+    from groove_amd import entities as E
+    from tests.test_oracle_independent import FM_CASES, _fm_params, _independent_fm_voice
+    blocks, off_block, key = 36, 16, 57
+    params = (T.FmParams * n)(*[_fm_params(*FM_CASES[i % len(FM_CASES)]) for i in range(n)])
+    synth = E.FmSynth(gpu_ctx, params)
+    block = gpu_ctx.block(n, FR)
+    lanes = np.arange(n, dtype=np.uint32)
+    look = sorted({0, 1, 2, n - 3, n - 2, n - 1})
+    got = []
+    for b in range(blocks):
+        if b == 0:
+            synth.handle_midi_events(T.note_events_np(lanes, np.full(n, key, dtype=np.uint8), True))
+        if b == off_block:
+            synth.handle_midi_events(T.note_events_np(lanes, np.full(n, key, dtype=np.uint8), False))
+        synth.generate_batch_values(block, FR)
+        got.append(block.download(FR)[:, :, look])
+    got = np.concatenate(got, axis=1).astype(np.float64)
+    synth.destroy(); block.destroy()
+    for j, lane in enumerate(look):
+        case = FM_CASES[lane % len(FM_CASES)]
+        want, idle_from = _independent_fm_voice(*case, key, blocks * FR, off_block * FR)
+        assert idle_from < blocks * FR and np.abs(want).max() > 0.3
+        err = float(np.abs(got[:, :, j] - want).max())
+        assert err <= (2e-5 if case[2] >= 10.0 else 2e-6), (n, lane, case, err)
+
+
+@pytest.mark.parametrize("form", ["time-parallel", "serial"])
+def test_sampler_against_the_independent_pointer_stepping(gpu_ctx, form):
+    """a7: out[i] = pcm[floor(i x step)] x gain until the pointer runs off the end (step = note / root frequency, 1 for a drumkit
+    buffer), mono on both channels — exact, except where an accumulated pointer sits within rounding of an integer."""
+    from groove_amd import entities as E
+    rng = np.random.default_rng(12)
+    pcm = rng.uniform(-1, 1, 3000).astype(np.float32)
+    descs = (T.SampleDesc * 2)(T.SampleDesc(0, 2000, 440.0), T.SampleDesc(2000, 1000, 0.0))
+    n = 6
+    which = [(k % 2, 1, (0.5, 1.0)[k % 2]) for k in range(n)]
+    params = (T.SamplerParams * n)(*[T.SamplerParams(*w) for w in which])
+    frames = 14 * FR
+    old = gpu_ctx.time_parallel_max_voices
+    if form == "serial":
+        gpu_ctx.time_parallel_max_voices = 0             # "never": the serial kernels for every bank kind
+    try:
+        _sampler_cases(gpu_ctx, form, pcm, descs, params, n, frames)
+    finally:
+        gpu_ctx.time_parallel_max_voices = old
+
+
+def _sampler_cases(gpu_ctx, form, pcm, descs, params, n, frames):
+    from groove_amd import entities as E
+    for key in (69, 76, 60):
+        smp = E.Sampler(gpu_ctx, pcm, descs, params)
+        assert ("tp" in smp.kernel_form(FR, False)) == (form == "time-parallel")
+        block = gpu_ctx.block(n, FR)
+        smp.handle_midi_events(T.note_events_np(np.arange(n, dtype=np.uint32), np.full(n, key, dtype=np.uint8), True))
+        look = [0, 1, n - 2, n - 1]
+        got = []
+        for b in range(frames // FR):
+            smp.generate_batch_values(block, FR)
+            got.append(block.download(FR)[:, :, look])
+        got = np.concatenate(got, axis=1)
+        smp.destroy(); block.destroy()
+        for j, lane in enumerate(look):
+            off0, length, root = ((0, 2000, 440.0), (2000, 1000, 0.0))[lane % 2]
+            gain = np.float32((0.5, 1.0)[lane % 2])
+            step = (440.0 * 2.0 ** ((key - 69) / 12.0)) / root if root > 0 else 1.0
+            pos = np.arange(frames) * step
+            idx = np.floor(pos).astype(np.int64)
+            want = np.where(idx < length, pcm[off0 + np.minimum(idx, length - 1)] * gain, np.float32(0.0)).astype(np.float32)
+            safe = np.abs(pos - np.round(pos)) > 1e-6 if step != 1.0 and key != 69 else np.ones(frames, dtype=bool)
+            assert np.array_equal(got[0, safe, j], want[safe]) and np.array_equal(got[0, :, j], got[1, :, j]), (form, key, lane)

@@ -433,33 +433,45 @@ def test_welsh_voice_composition_against_an_independent_array_implementation(ora
 
 
 # ------------------------------------------------------------------------------------------ a6 FM voice, a7 sampler
-def test_fm_voice_is_a_phase_modulated_sine(oracle):
+FM_CASES = ((2.0, 1.0, 1.0, 0.0), (3.5, 0.7, 10.0, -0.6), (0.5, 1.0, 0.1, 0.8))   # ratio, depth, beta, pan
+FM_CARRIER_ENV, FM_MODULATOR_ENV, FM_GAIN = (0.01, 0.05, 0.7, 0.05), (0.0, 0.2, 0.4, 0.02), 0.9
+
+
+def _fm_params(ratio, depth, beta, pan):
+    return T.FmParams(ratio, depth, beta, T.EnvelopeParams(*FM_CARRIER_ENV), T.EnvelopeParams(*FM_MODULATOR_ENV), FM_GAIN, pan)
+
+
+def _independent_fm_voice(ratio, depth, beta, pan, key, n, off):
     """Carrier phase = running sum of f_c / SR (1 + modulator x modulator envelope x depth x beta) — the first tick emits phase 0 —,
-    modulator at f_c x ratio, output = sin(carrier) x carrier envelope -> Dca."""
+    modulator at f_c x ratio, output = sin(carrier) x carrier envelope -> Dca; extended precision, nothing of
+    oracle/.  Returns ([2][n], first idle frame)."""
+    fc = 440.0 * 2.0 ** ((key - 69) / 12.0)
+    i = np.arange(n, dtype=np.longdouble)
+    mpos = i * (np.longdouble(fc * ratio) / np.longdouble(SR))
+    mod = np.sin(2.0 * np.pi * (mpos - np.floor(mpos)).astype(np.float64))
+    cenv, idle_from = _closed_form_envelope(*FM_CARRIER_ENV, off, n)
+    menv, _ = _closed_form_envelope(*FM_MODULATOR_ENV, off, n)
+    lfm = mod * menv * float(np.float32(depth)) * float(np.float32(beta))
+    delta = (np.longdouble(fc) / np.longdouble(SR)) * (1.0 + lfm.astype(np.longdouble))
+    cpos = np.concatenate([[np.longdouble(0.0)], np.cumsum(delta[1:])])
+    car = np.sin(2.0 * np.pi * (cpos - np.floor(cpos)).astype(np.float64))
+    m = car * cenv * float(np.float32(FM_GAIN))
+    pf = float(np.float32(pan))
+    want = np.stack([m * (1.0 - 0.25 * (pf + 1.0) ** 2), m * (1.0 - (0.5 * pf - 0.5) ** 2)])
+    want[:, min(idle_from, n):] = 0.0   # (the oscillators stop ticking while the carrier envelope is idle; nothing sounds there either way)
+    return want, idle_from
+
+
+def test_fm_voice_is_a_phase_modulated_sine(oracle):
     n, off, key = 9000, 4000, 57
-    for ratio, depth, beta, pan in ((2.0, 1.0, 1.0, 0.0), (3.5, 0.7, 10.0, -0.6), (0.5, 1.0, 0.1, 0.8)):
-        p = T.FmParams(ratio, depth, beta, T.EnvelopeParams(0.01, 0.05, 0.7, 0.05), T.EnvelopeParams(0.0, 0.2, 0.4, 0.02), 0.9, pan)
-        bank = oracle.Bank.fm((T.FmParams * 1)(p))
+    for ratio, depth, beta, pan in FM_CASES:
+        bank = oracle.Bank.fm((T.FmParams * 1)(_fm_params(ratio, depth, beta, pan)))
         ev = lambda on: T.note_events_np(np.zeros(1, dtype=np.uint32), np.full(1, key, dtype=np.uint8), on)  # noqa: E731
         bank.note_events(ev(True))
         got = bank.render(off)
         bank.note_events(ev(False))
         got = np.concatenate([got, bank.render(n - off)], axis=1)[:, :, 0]
-        fc = 440.0 * 2.0 ** ((key - 69) / 12.0)
-        i = np.arange(n, dtype=np.longdouble)
-        mpos = i * (np.longdouble(fc * ratio) / np.longdouble(SR))
-        mod = np.sin(2.0 * np.pi * (mpos - np.floor(mpos)).astype(np.float64))
-        cenv, idle_from = _closed_form_envelope(0.01, 0.05, 0.7, 0.05, off, n)
-        menv, _ = _closed_form_envelope(0.0, 0.2, 0.4, 0.02, off, n)
-        lfm = mod * menv * float(np.float32(depth)) * float(np.float32(beta))
-        delta = (np.longdouble(fc) / np.longdouble(SR)) * (1.0 + lfm.astype(np.longdouble))
-        cpos = np.concatenate([[np.longdouble(0.0)], np.cumsum(delta[1:])])
-        car = np.sin(2.0 * np.pi * (cpos - np.floor(cpos)).astype(np.float64))
-        m = car * cenv * float(np.float32(0.9))
-        pf = float(np.float32(pan))
-        want = np.stack([m * (1.0 - 0.25 * (pf + 1.0) ** 2), m * (1.0 - (0.5 * pf - 0.5) ** 2)])
-        want[:, min(idle_from, n):] = 0.0
-        # (the oracle stops ticking its oscillators while the carrier envelope is idle; nothing sounds there either way)
+        want, idle_from = _independent_fm_voice(ratio, depth, beta, pan, key, n, off)
         assert idle_from < n and np.abs(want).max() > 0.3
         assert np.abs(got - want).max() <= 2e-8, (ratio, np.abs(got - want).max())
 
