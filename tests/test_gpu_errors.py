@@ -186,6 +186,8 @@ def test_synchronize_deadline_names_the_blocked_stream():
         import os
         safe = os.environ.get("GROOVE_SAFE_STREAMS") == "1"   # (the whole suite is also run once under the safe layout)
         assert info["streams_created"] == (4 if safe else 8) and info["placeholder_fifth"] is (not safe) and info["comm_before_streams"] is False
+        # the library's own host waits are counted (tools/host_blocked.py reads them): this context waited at least for the spin above
+        assert info["host_waits"] >= 1 and info["host_waits_blocked"] >= 1 and info["host_wait_ms"] > 1.0 and info["zero_segments"] == 0
     finally:
         ctx.close()
 
