@@ -1,3 +1,5 @@
+# RECORD of a round-3 measurement job (kept because docs/HISTORY.md cites its log): the build variants and GROOVE_* knobs it names were
+# measured, not kept, and removed in round 4 — the script documents how the numbers were taken; it no longer runs against this tree.
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out
 B="python3 bench.py --no-cpu-baseline --no-parity --no-watchdog --no-configs --no-shard-curve"
 # non-temporal block stores, in-job A/B (materialised million-voice form)

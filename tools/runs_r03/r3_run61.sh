@@ -1,3 +1,5 @@
+# RECORD of a round-3 measurement job (kept because docs/HISTORY.md cites its log): the build variants and GROOVE_* knobs it names were
+# measured, not kept, and removed in round 4 — the script documents how the numbers were taken; it no longer runs against this tree.
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out
 B="python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-configs --no-shard-curve --no-parity"
 for rep in 1 2 3; do
