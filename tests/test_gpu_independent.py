@@ -6,8 +6,9 @@ triangle for every row of SURVEY.md section 8(a) that has a published form and c
   a4  24 dB low-pass    scipy.signal.cheby1(4, ...) — pre-warped bilinear transform — up to its DC gain
   a8  Gain, a9 Bitcrusher   numpy (the quantise in integers: bit-exact)
   a10 Chorus, a11 Delay, a12 Reverb   sparse-coefficient lfilter (taps, pure delay, four combs + two all-passes)
-  a5  WelshVoice        static-filter patches end to end (time-parallel and serial kernels) against the array composition of
-                        tests/test_oracle_independent.py: closed-form phases and envelopes, scipy's filter, the pan law
+  a5  WelshVoice        static-filter patches AND patches whose filter envelope retunes the filter every frame, end to end (time-parallel,
+                        role-split and serial kernels) against the array composition of tests/test_oracle_independent.py: closed-form
+                        phases and envelopes, scipy's filter design (per frame for the retuned kinds), the pan law
   a6  FmVoice           the extended-precision phase-modulated sine of tests/test_oracle_independent.py (one and four voices per wavefront)
   a7  Sampler / Drumkit pcm[floor(i x step)] x gain, exact (time-parallel gather and the serial kernel's pointer stepping)
 
@@ -134,13 +135,15 @@ def test_reverb_is_four_combs_and_two_allpasses(gpu_ctx):
     _close(got, s, tol=5e-6)
 
 
-@pytest.mark.parametrize("form", ["time-parallel", "serial"])
+@pytest.mark.parametrize("form", ["time-parallel", "role-split", "serial"])
 def test_welsh_voice_against_the_independent_array_composition(gpu_ctx, form):
     """a5 end to end on the GPU against the array composition of tests/test_oracle_independent.py (closed-form phases and envelopes,
-    scipy's Chebyshev, the pan law — nothing of oracle/): seven static-filter patches through note-on, note-off and the idle tail,
-    in the time-parallel and in the serial kernel forms.  fp32 feed-forward math: 1e-5 of full scale per sample."""
+    scipy's Chebyshev / scipy's bilinear transform per frame for the retuned filter, the pan law — nothing of oracle/): seven
+    static-filter patches and three whose filter envelope retunes the 24 dB low-pass every frame, through note-on, note-off and the
+    idle tail, in the time-parallel, role-split and serial kernel forms.  fp32 feed-forward math, coefficients computed in fp32 before
+    they are widened: 5e-6 of full scale per sample (measured: 1e-7 - 1.1e-6, the three forms alike)."""
     from groove_amd import entities as E
-    from tests.test_oracle_independent import _independent_welsh_voice, _welsh_patch
+    from tests.test_oracle_independent import RETUNED_PATCHES, _independent_welsh_voice, _welsh_patch
     patches = [
         _welsh_patch(T.WAVE_SAWTOOTH, T.WAVE_SINE, 2.0 ** (7 / 12), 0.6, (0.01, 0.05, 0.6, 0.08), 1200.0, 0.9, -0.4),
         _welsh_patch(T.WAVE_SINE, T.WAVE_TRIANGLE, 2.0, 0.5, (0.0, 0.02, 0.3, 0.05), 400.0, 0.707, 0.25, lfo=(5.13, 0.3)),
@@ -150,14 +153,18 @@ def test_welsh_voice_against_the_independent_array_composition(gpu_ctx, form):
         _welsh_patch(T.WAVE_SINE, T.WAVE_SAWTOOTH, 1.0, 0.7, (0.01, 0.05, 0.5, 0.04), 2000.0, 0.707, 0.5, fixed2=261.6255653),
         _welsh_patch(T.WAVE_SINE, T.WAVE_TRIANGLE, 2.0, 0.5, (0.005, 0.1, 0.7, 0.06), 1500.0, 0.9, -0.2, lfo=(5.13, 0.05), routing=T.LFO_PITCH),
     ]
+    patches += RETUNED_PATCHES()
     blocks, off_block, key = 47, 20, 57          # 12,032 frames, note-off at frame 5,120
     n = len(patches)
     old = gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves
+    if form != "time-parallel":
+        gpu_ctx.time_parallel_max_voices = 0
     if form == "serial":
-        gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves = 0, 0
+        gpu_ctx.split_max_waves = 0
     try:
         synth = E.WelshSynth(gpu_ctx, (T.WelshParams * n)(*patches))
-        assert ("tp" in synth.kernel_form(FR, False)) == (form == "time-parallel")
+        kf = synth.kernel_form(FR, False)
+        assert ("tp" in kf) == (form == "time-parallel") and ("split" in kf) == (form == "role-split"), kf
         block = gpu_ctx.block(n, FR)
         lanes = np.arange(n, dtype=np.uint32)
         got = []
@@ -176,8 +183,73 @@ def test_welsh_voice_against_the_independent_array_composition(gpu_ctx, form):
         want, idle_from = _independent_welsh_voice(p, key, blocks * FR, off_block * FR)
         assert idle_from < blocks * FR
         err = np.abs(got[:, :, k] - want)
-        suspicious = err.max(axis=0) > 1e-5          # a sawtooth / triangle sample within rounding of the waveform's edge
-        assert suspicious.sum() <= 2 and err[:, ~suspicious].max() <= 1e-5, (form, k, float(err.max()), int(suspicious.sum()))
+        tol = 5e-6
+        suspicious = err.max(axis=0) > tol          # a sawtooth / triangle sample within rounding of the waveform's edge
+        assert suspicious.sum() <= 2 and err[:, ~suspicious].max() <= tol, (form, k, float(err.max()), int(suspicious.sum()))
+
+
+_BENCHMARK_WANT = {}
+
+
+def _benchmark_want(blocks, off_block):
+    """The 32 independent voices, computed once for the three kernel forms."""
+    from groove_amd import patches as P
+    from tests.test_oracle_independent import BENCHMARK_KEYS, _independent_welsh_voice
+    if (blocks, off_block) not in _BENCHMARK_WANT:
+        keys = BENCHMARK_KEYS()
+        _BENCHMARK_WANT[(blocks, off_block)] = [_independent_welsh_voice(P.welsh_patch(j), int(keys[j]), blocks * FR, off_block * FR)[0] for j in range(P.N_PATCHES)]
+    return _BENCHMARK_WANT[(blocks, off_block)]
+
+
+@pytest.mark.parametrize("form", ["time-parallel", "role-split", "serial"])
+def test_every_synthetic_benchmark_patch_against_the_independent_voice(gpu_ctx, form):
+    """The benchmark's own 32 Welsh patches (every waveform, hard sync, the five LFO routings, static / envelope-retuned /
+    LFO-retuned filters) on the GPU, in the three kernel forms, against tests/test_oracle_independent.py's independent voice — not
+    through oracle/.  Keys: the benchmark's, minus the rational-frequency ties (BENCHMARK_KEYS).  The bar is per voice: RMS error
+    <= 4e-6 of full scale (DESIGN.md section 4's figure against the oracle) and no sample off by more than 2e-5 (measured on
+    MI355X: RMS 1.5e-9 - 2.3e-6, worst sample 5.1e-6, the three forms alike) — except within a hundred frames of a waveform edge
+    that rounding put on the other side of a frame (counted, at most two such edges per voice; none occur with these keys)."""
+    from groove_amd import entities as E, patches as P
+    from tests.test_oracle_independent import BENCHMARK_KEYS
+    table = [P.welsh_patch(j) for j in range(P.N_PATCHES)]
+    keys = BENCHMARK_KEYS()
+    n = len(table)
+    blocks, off_block = 16, 7
+    wants = _benchmark_want(blocks, off_block)
+    old = gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves
+    if form != "time-parallel":
+        gpu_ctx.time_parallel_max_voices = 0
+    if form == "serial":
+        gpu_ctx.split_max_waves = 0
+    try:
+        synth = E.WelshSynth(gpu_ctx, (T.WelshParams * n)(*table))
+        kf = synth.kernel_form(FR, False)
+        assert ("tp" in kf) == (form == "time-parallel") and ("split" in kf) == (form == "role-split"), kf
+        block = gpu_ctx.block(n, FR)
+        lanes = np.arange(n, dtype=np.uint32)
+        got = []
+        for b in range(blocks):
+            if b == 0:
+                synth.handle_midi_events(T.note_events_np(lanes, keys, True))
+            if b == off_block:
+                synth.handle_midi_events(T.note_events_np(lanes, keys, False))
+            synth.generate_batch_values(block, FR)
+            got.append(block.download(FR))
+        got = np.concatenate(got, axis=1).astype(np.float64)
+        synth.destroy(); block.destroy()
+    finally:
+        gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves = old
+    for k, want in enumerate(wants):
+        err = np.abs(got[:, :, k] - want).max(axis=0)
+        big = np.flatnonzero(err > 2e-5)
+        edges = 0
+        keep = np.ones(len(err), dtype=bool)
+        while big.size and edges < 3:       # an edge tie: mask the hundred frames the filter rings for
+            keep[big[0]:big[0] + 100] = False
+            edges += 1
+            big = np.flatnonzero((err > 2e-5) & keep)
+        rms = float(np.sqrt(np.mean((got[:, keep, k] - want[:, keep]) ** 2)))
+        assert edges <= 2 and rms <= 4e-6 and err[keep].max() <= 2e-5, (form, k, rms, float(err[keep].max()), edges)
 
 
 @pytest.mark.parametrize("n", [3, 4100])   # one voice per wavefront / four voices per wavefront (groove_hip.hip tp_vpw)

@@ -341,45 +341,137 @@ def _closed_form_envelope(a, d, s, r, off, n):
     return v, idle_from
 
 
+def _lp24_sections(ripple):
+    """(c, d) of the two analog sections 1 / (c s^2 + d s + 1): the 4th-order Chebyshev pole pairs (docs/DSP_SPEC.md section 4; the
+    tests above show them equal to scipy's cheb1ap up to the DC gain)."""
+    cg, sg = math.cosh(ripple) ** 2, math.sinh(ripple)
+    half = math.sqrt(0.5)
+    out = []
+    for cr, dk in ((0.5 + 0.5 * half, 2.0 * math.cos(math.pi / 8)), (0.5 - 0.5 * half, 2.0 * math.cos(3 * math.pi / 8))):  # 0.853553.., 1.847759..; 0.146446.., 0.765366..
+        c = 1.0 / (cg - cr)
+        out.append((c, c * sg * dk))
+    return out
+
+
+def _lp24_time_varying(x_in, fc, ripple):
+    """The 24 dB low-pass with the cutoff of EVERY frame given (fc[j], Hz, clamped to [1 Hz, 0.49 SR]): each of the two sections is
+    scipy's bilinear transform of its analog prototype at k = tan(pi fc / SR), recomputed for the frame BEFORE the frame's sample
+    goes through it, in transposed direct form II (the state carries what the OLD coefficients left in it)."""
+    fc = np.clip(fc, 1.0, 0.49 * SR)
+    sections = _lp24_sections(ripple)
+    n = len(x_in)
+    y = np.empty(n)
+    z = [[0.0, 0.0], [0.0, 0.0]]
+    coef = [None, None]
+    last_fc = None
+    for j in range(n):
+        if fc[j] != last_fc:
+            k = math.tan(math.pi * fc[j] / SR)
+            for q, (c, d) in enumerate(sections):
+                b, a = signal.bilinear([1.0], [c / (k * k), d / k, 1.0], fs=0.5)
+                coef[q] = (b / a[0], a / a[0])
+            last_fc = fc[j]
+        x = x_in[j]
+        for q in range(2):
+            b, a = coef[q]
+            out = b[0] * x + z[q][0]
+            z[q][0] = b[1] * x - a[1] * out + z[q][1]
+            z[q][1] = b[2] * x - a[2] * out
+            x = out
+        y[j] = x
+    return y
+
+
+def _waveform(w, pos, duty=0.5, noise=None):
+    """docs/DSP_SPEC.md section 2, value() at position pos in [0, 1)."""
+    if w == T.WAVE_SINE:
+        return np.sin(2.0 * np.pi * pos)
+    if w == T.WAVE_SQUARE or w == T.WAVE_PULSE_WIDTH:
+        return np.where(pos < duty, 1.0, -1.0)
+    if w == T.WAVE_TRIANGLE:
+        return 4.0 * np.abs(pos - np.floor(pos + 0.5)) - 1.0
+    if w == T.WAVE_SAWTOOTH:
+        return 2.0 * (pos - np.floor(pos + 0.5))
+    if w == T.WAVE_TRIANGLE_SINE:
+        return 4.0 * np.abs(pos - np.floor(pos + 0.75) + 0.25) - 1.0
+    if w == T.WAVE_NOISE:
+        return noise
+    return np.zeros(len(pos))
+
+
+def _musicdsp_noise(n):
+    x1, x2 = 0x70F4F854, 0xE1E9F0A7
+    v = np.zeros(n)
+    for i in range(n):
+        x1 ^= x2
+        v[i] = (x2 - (1 << 32) if x2 & 0x80000000 else x2) / 2147483648.0
+        x2 = (x2 + x1) & 0xFFFFFFFF
+    return v
+
+
 def _independent_welsh_voice(p, key, n, off):
-    """A Welsh voice whose filter is STATIC (no envelope or LFO on the cutoff) and whose LFO is unused or routed to the amplitude,
-    written as array arithmetic from the published pieces — closed-form phases and envelopes, scipy's Chebyshev for the
-    24 dB low-pass, the pan law — without one line of oracle/: the frame order of SURVEY Appendix A.6 is what is under test."""
+    """A Welsh voice written from the published pieces without one line of oracle/ (docs/DSP_SPEC.md section 6 is what is under
+    test): oscillator pair (every waveform; hard sync; osc 2 fixed or tuned) under an LFO (sine / triangle / square / sawtooth) routed
+    to nothing, the amplitude, the pitch, the pulse width or the filter cutoff; mix; the 24 dB low-pass — static, or RETUNED every
+    frame by the filter envelope or the LFO (_lp24_time_varying: scipy's bilinear transform per frame); amplitude envelope; pan.
+    Closed-form phases in extended precision.  Returns ([2][n], first idle frame)."""
     f_note = 440.0 * 2.0 ** ((key - 69) / 12.0)
     i = np.arange(n, dtype=np.longdouble)
-    lpos = i * (np.longdouble(p.lfo_frequency) / np.longdouble(SR))
-    lfo = np.sin(2.0 * np.pi * (lpos - np.floor(lpos)).astype(np.float64))   # (sine LFOs only here; its first tick emits phase 0 too)
+    lpos = i * (np.longdouble(p.lfo_frequency) / np.longdouble(SR))    # (the LFO's first tick emits phase 0 too)
+    lfo = _waveform(p.lfo_waveform, (lpos - np.floor(lpos)).astype(np.float64))
     depth = float(np.float32(p.lfo_depth))
+    routing = p.lfo_routing
+    ld = lfo * depth
 
-    def osc(o):
+    def positions(o):
         f = o.fixed_hz if o.fixed_hz > 0.0 else f_note * o.tune
-        if p.lfo_routing == T.LFO_PITCH:   # the increment of frame j is f 2^(lfo_j depth) / SR; frame 0 emits phase 0
-            inc = (np.longdouble(f) / np.longdouble(SR)) * np.exp2((lfo * depth).astype(np.longdouble))
-            pos = np.concatenate([[np.longdouble(0.0)], np.cumsum(inc[1:])])
-        else:
-            pos = i * (np.longdouble(f) / np.longdouble(SR))
-        pos = (pos - np.floor(pos)).astype(np.float64)
-        w = o.waveform
-        if w == T.WAVE_SINE:
-            return np.sin(2.0 * np.pi * pos)
-        if w in (T.WAVE_SQUARE, T.WAVE_PULSE_WIDTH):
-            return np.where(pos < (float(np.float32(o.duty)) if w == T.WAVE_PULSE_WIDTH else 0.5), 1.0, -1.0)
-        if w == T.WAVE_TRIANGLE:
-            return 4.0 * np.abs(pos - np.floor(pos + 0.5)) - 1.0
-        if w == T.WAVE_SAWTOOTH:
-            return 2.0 * (pos - np.floor(pos + 0.5))
-        return np.zeros(n)
+        if routing == T.LFO_PITCH:   # the increment of frame j is f 2^(lfo_j depth) / SR; frame 0 emits phase 0
+            inc = (np.longdouble(f) / np.longdouble(SR)) * np.exp2(ld.astype(np.longdouble))
+            return np.concatenate([[np.longdouble(0.0)], np.cumsum(inc[1:])])
+        return i * (np.longdouble(f) / np.longdouble(SR))
 
+    def duty_of(o):
+        d = 0.5 if o.waveform == T.WAVE_SQUARE else float(np.float32(o.duty))
+        return np.clip(d * (1.0 + ld), 0.0, 1.0) if routing == T.LFO_PULSE_WIDTH else d
+
+    noise = _musicdsp_noise(n) if T.WAVE_NOISE in (p.oscillator_1.waveform, p.oscillator_2.waveform) else None
+    pos1 = positions(p.oscillator_1)
+    wraps = np.floor(pos1)
+    v1 = _waveform(p.oscillator_1.waveform, (pos1 - wraps).astype(np.float64), duty_of(p.oscillator_1), noise)
+    pos2 = positions(p.oscillator_2)
+    if p.oscillator_2_sync:          # osc 2 restarts at 0 on every frame at which osc 1 wrapped (constant increments here)
+        assert routing != T.LFO_PITCH
+        wrapped = np.concatenate([[False], wraps[1:] != wraps[:-1]])
+        last = np.maximum.accumulate(np.where(wrapped, np.arange(n), 0))
+        d2 = pos2[1] - pos2[0]
+        pos2 = (i - last.astype(np.longdouble)) * d2
+    v2 = _waveform(p.oscillator_2.waveform, (pos2 - np.floor(pos2)).astype(np.float64), duty_of(p.oscillator_2), noise)
     mix = float(np.float32(p.oscillator_mix))
-    s = osc(p.oscillator_1) * mix + osc(p.oscillator_2) * (1.0 - mix)
+    s = v1 * mix + v2 * (1.0 - mix)
+
     ripple = float(np.float32(p.filter_passband_ripple))
-    eps = 1.0 / math.sinh(4.0 * ripple)
-    sos = signal.cheby1(4, 10.0 * math.log10(1.0 + eps * eps), float(np.float32(p.filter_cutoff_hz)), fs=SR, output="sos")
-    y = signal.sosfilt(sos, s) * math.sqrt(1.0 + eps * eps)
+    start, end = float(np.float32(p.filter_cutoff_start)), float(np.float32(p.filter_cutoff_end))
+    if end != 0.0:                   # the filter envelope retunes the filter every frame
+        fe = p.filter_envelope
+        env, _ = _closed_form_envelope(fe.attack, fe.decay, fe.sustain, fe.release, off, n)
+        fc = 25.0 * 800.0 ** np.clip(start + (1.0 - start) * end * env, 0.0, 1.0)
+    elif routing == T.LFO_FILTER_CUTOFF:
+        fc = 25.0 * 800.0 ** np.clip(start * (1.0 + ld), 0.0, 1.0)
+    else:
+        fc = None
+    if fc is not None:
+        y = _lp24_time_varying(s, fc, ripple)
+    elif ripple <= 2.2:              # static: scipy's own 4th-order Chebyshev design, up to its DC gain (beyond ~3 the dB figure no longer resolves eps)
+        eps = 1.0 / math.sinh(4.0 * ripple)
+        sos = signal.cheby1(4, 10.0 * math.log10(1.0 + eps * eps), float(np.float32(p.filter_cutoff_hz)), fs=SR, output="sos")
+        y = signal.sosfilt(sos, s) * math.sqrt(1.0 + eps * eps)
+    else:
+        y = _lp24_time_varying(s, np.full(n, float(np.float32(p.filter_cutoff_hz))), ripple)
+
     e = p.amp_envelope
     amp, idle_from = _closed_form_envelope(e.attack, e.decay, e.sustain, e.release, off, n)
-    if p.lfo_routing == T.LFO_AMPLITUDE:
-        amp = amp * (1.0 + lfo * depth)
+    if routing == T.LFO_AMPLITUDE:
+        amp = amp * (1.0 + ld)
     m = y * amp * float(np.float32(p.dca_gain))
     pan = float(np.float32(p.dca_pan))
     out = np.stack([m * (1.0 - 0.25 * (pan + 1.0) ** 2), m * (1.0 - (0.5 * pan - 0.5) ** 2)])
@@ -387,7 +479,7 @@ def _independent_welsh_voice(p, key, n, off):
     return out, idle_from
 
 
-def _welsh_patch(w1, w2, tune2, mix, env, cutoff, ripple, pan, lfo=None, duty=0.3, fixed2=0.0, routing=None):
+def _welsh_patch(w1, w2, tune2, mix, env, cutoff, ripple, pan, lfo=None, duty=0.3, fixed2=0.0, routing=None, sweep=None):
     p = T.WelshParams()
     p.oscillator_1 = T.OscillatorParams(w1, duty, 1.0, 0.0)
     p.oscillator_2 = T.OscillatorParams(w2, duty, tune2, fixed2)
@@ -396,6 +488,8 @@ def _welsh_patch(w1, w2, tune2, mix, env, cutoff, ripple, pan, lfo=None, duty=0.
     p.filter_envelope = T.EnvelopeParams(0.01, 0.1, 0.5, 0.1)    # (runs, but drives nothing: filter_cutoff_end = 0)
     p.lfo_waveform, p.lfo_routing, p.lfo_frequency, p.lfo_depth = T.WAVE_SINE, (routing if routing is not None else (T.LFO_AMPLITUDE if lfo else T.LFO_NONE)), (lfo or (1.0, 0.0))[0], (lfo or (1.0, 0.0))[1]
     p.filter_cutoff_hz, p.filter_passband_ripple, p.filter_cutoff_start, p.filter_cutoff_end = cutoff, ripple, 0.5, 0.0
+    if sweep:   # (cutoff percent start, end, filter envelope): the envelope retunes the filter every frame
+        p.filter_cutoff_start, p.filter_cutoff_end, p.filter_envelope = sweep[0], sweep[1], T.EnvelopeParams(*sweep[2])
     p.dca_gain, p.dca_pan = 0.8, pan
     return p
 
@@ -430,6 +524,69 @@ def test_welsh_voice_composition_against_an_independent_array_implementation(ora
             suspicious = err.max(axis=0) > 1e-8
             assert suspicious.sum() <= 2 and err[:, ~suspicious].max() <= 1e-8, (key, k, err.max(), int(suspicious.sum()))
             assert np.abs(want).max() > 1e-3
+
+
+RETUNED_PATCHES = lambda: [  # noqa: E731
+    _welsh_patch(T.WAVE_SAWTOOTH, T.WAVE_SINE, 2.0 ** (7 / 12), 0.6, (0.01, 0.05, 0.6, 0.08), 1200.0, 0.9, -0.4, sweep=(0.2, 0.6, (0.02, 0.08, 0.4, 0.06))),
+    _welsh_patch(T.WAVE_SINE, T.WAVE_TRIANGLE, 2.0, 0.5, (0.0, 0.02, 0.3, 0.05), 400.0, 0.707, 0.25, lfo=(5.13, 0.3), sweep=(0.45, 0.9, (0.0, 0.05, 0.2, 0.03))),
+    _welsh_patch(T.WAVE_TRIANGLE, T.WAVE_SAWTOOTH, 1.0, 0.25, (0.03, 0.0, 1.0, 0.02), 3000.0, 1.607, 1.0, sweep=(0.7, 0.3, (0.05, 0.0, 1.0, 0.02))),
+]
+
+
+def test_retuned_welsh_voice_against_an_independent_time_varying_filter(oracle):
+    """The kinds three voices in four of the benchmark belong to: the filter envelope retunes the 24 dB low-pass every frame.
+    Independent side: closed-form envelope -> cutoff law -> scipy's bilinear transform of each analog section per frame -> a
+    transposed-direct-form-II loop written here.  Bar: 1e-8 of full scale (f64 on both sides)."""
+    patches = RETUNED_PATCHES()
+    n, off, key = 6000, 2500, 52
+    params = (T.WelshParams * len(patches))(*patches)
+    bank = oracle.Bank.welsh(params)
+    lanes = np.arange(len(patches), dtype=np.uint32)
+    bank.note_events(T.note_events_np(lanes, np.full(len(patches), key, dtype=np.uint8), True))
+    got = bank.render(off)
+    bank.note_events(T.note_events_np(lanes, np.full(len(patches), key, dtype=np.uint8), False))
+    got = np.concatenate([got, bank.render(n - off)], axis=1)
+    for k, p in enumerate(patches):
+        want, idle_from = _independent_welsh_voice(p, key, n, off)
+        assert idle_from < n and np.abs(want).max() > 1e-3
+        err = np.abs(got[:, :, k] - want)
+        suspicious = err.max(axis=0) > 1e-8
+        assert suspicious.sum() <= 2 and err[:, ~suspicious].max() <= 1e-8, (k, err.max(), int(suspicious.sum()))
+
+
+def BENCHMARK_KEYS():
+    """The key the benchmark gives each patch's first voice (36 + 7 w mod 49) — except that an A (220 Hz x 2^k: a rational
+    frequency / SR pair) moves up a semitone: at 220 Hz a waveform edge lands EXACTLY on frame 2,205, a tie that accumulated f64
+    rounding decides in the oracle, exact integer arithmetic on the device and extended precision here (docs/DSP_SPEC.md section 2),
+    and one flipped square-wave sample rings through the filter for a hundred frames."""
+    from groove_amd import patches as P
+    keys = (36 + (7 * np.arange(P.N_PATCHES)) % 49).astype(np.uint8)
+    keys[keys % 12 == 9] += 1
+    return keys
+
+
+def test_every_synthetic_benchmark_patch_against_the_independent_voice(oracle):
+    """All 32 synthetic Welsh patches of the benchmark projects (groove_amd/patches.py: every waveform incl. noise and triangle-sine,
+    hard sync, fixed-frequency osc 2, LFOs of four waveforms routed to nothing / amplitude / pitch / pulse width / filter cutoff,
+    static and envelope-retuned filters, ripples up to 3.2), each at the key the benchmark gives its first voice (BENCHMARK_KEYS),
+    through note-on, note-off and the release: the oracle against _independent_welsh_voice.  1e-8 of full scale; a frame whose phase is within
+    rounding of a waveform edge may fall on either side in either implementation (skipped, at most a handful)."""
+    from groove_amd import patches as P
+    n, off = 4000, 1800
+    table = [P.welsh_patch(j) for j in range(P.N_PATCHES)]
+    keys = BENCHMARK_KEYS()
+    bank = oracle.Bank.welsh((T.WelshParams * len(table))(*table))
+    lanes = np.arange(len(table), dtype=np.uint32)
+    bank.note_events(T.note_events_np(lanes, keys, True))
+    got = bank.render(off)
+    bank.note_events(T.note_events_np(lanes, keys, False))
+    got = np.concatenate([got, bank.render(n - off)], axis=1)
+    for k, p in enumerate(table):
+        want, _ = _independent_welsh_voice(p, int(keys[k]), n, off)
+        assert np.abs(want).max() > 1e-3, k
+        err = np.abs(got[:, :, k] - want)
+        suspicious = err.max(axis=0) > 1e-8
+        assert suspicious.sum() <= 2 and err[:, ~suspicious].max() <= 1e-8, (k, float(err.max()), int(suspicious.sum()), np.flatnonzero(suspicious)[:8])
 
 
 # ------------------------------------------------------------------------------------------ a6 FM voice, a7 sampler
