@@ -599,24 +599,46 @@ def _fm_params(ratio, depth, beta, pan):
 
 
 def _independent_fm_voice(ratio, depth, beta, pan, key, n, off):
+    return _independent_fm_voice_of(_fm_params(ratio, depth, beta, pan), key, n, off)
+
+
+def _independent_fm_voice_of(p, key, n, off):
     """Carrier phase = running sum of f_c / SR (1 + modulator x modulator envelope x depth x beta) — the first tick emits phase 0 —,
     modulator at f_c x ratio, output = sin(carrier) x carrier envelope -> Dca; extended precision, nothing of
     oracle/.  Returns ([2][n], first idle frame)."""
     fc = 440.0 * 2.0 ** ((key - 69) / 12.0)
     i = np.arange(n, dtype=np.longdouble)
-    mpos = i * (np.longdouble(fc * ratio) / np.longdouble(SR))
+    mpos = i * (np.longdouble(fc * p.ratio) / np.longdouble(SR))
     mod = np.sin(2.0 * np.pi * (mpos - np.floor(mpos)).astype(np.float64))
-    cenv, idle_from = _closed_form_envelope(*FM_CARRIER_ENV, off, n)
-    menv, _ = _closed_form_envelope(*FM_MODULATOR_ENV, off, n)
-    lfm = mod * menv * float(np.float32(depth)) * float(np.float32(beta))
+    ce, me = p.carrier_envelope, p.modulator_envelope
+    cenv, idle_from = _closed_form_envelope(ce.attack, ce.decay, ce.sustain, ce.release, off, n)
+    menv, _ = _closed_form_envelope(me.attack, me.decay, me.sustain, me.release, off, n)
+    lfm = mod * menv * float(np.float32(p.depth)) * float(np.float32(p.beta))
     delta = (np.longdouble(fc) / np.longdouble(SR)) * (1.0 + lfm.astype(np.longdouble))
     cpos = np.concatenate([[np.longdouble(0.0)], np.cumsum(delta[1:])])
     car = np.sin(2.0 * np.pi * (cpos - np.floor(cpos)).astype(np.float64))
-    m = car * cenv * float(np.float32(FM_GAIN))
-    pf = float(np.float32(pan))
+    m = car * cenv * float(np.float32(p.dca_gain))
+    pf = float(np.float32(p.dca_pan))
     want = np.stack([m * (1.0 - 0.25 * (pf + 1.0) ** 2), m * (1.0 - (0.5 * pf - 0.5) ** 2)])
     want[:, min(idle_from, n):] = 0.0   # (the oscillators stop ticking while the carrier envelope is idle; nothing sounds there either way)
     return want, idle_from
+
+
+def test_every_synthetic_fm_patch_against_the_independent_voice(oracle):
+    """The 16 FM patches of config #5 (modulation indices 0.1 - 15), at the benchmark's keys, through note-off and release."""
+    from groove_amd import patches as P
+    n, off = 6000, 2500
+    table = [P.fm_patch(j) for j in range(16)]
+    keys = (36 + (7 * np.arange(16)) % 49).astype(np.uint8)
+    bank = oracle.Bank.fm((T.FmParams * 16)(*table))
+    lanes = np.arange(16, dtype=np.uint32)
+    bank.note_events(T.note_events_np(lanes, keys, True))
+    got = bank.render(off)
+    bank.note_events(T.note_events_np(lanes, keys, False))
+    got = np.concatenate([got, bank.render(n - off)], axis=1)
+    for k, p in enumerate(table):
+        want, _ = _independent_fm_voice_of(p, int(keys[k]), n, off)
+        assert np.abs(want).max() > 0.05 and np.abs(got[:, :, k] - want).max() <= 5e-8, (k, float(np.abs(got[:, :, k] - want).max()))
 
 
 def test_fm_voice_is_a_phase_modulated_sine(oracle):
