@@ -286,10 +286,12 @@ hipError_t wait_deadline(groove_ctx* ctx, hipStream_t st, hipEvent_t ev, const c
     }
     const auto waited = std::chrono::steady_clock::now() - t0;
     if (waited > limit) break;
-    // the first ~100 us busy-poll (most waits of this path are that short), then yield, then sleep in growing steps
+    // the first ~100 us busy-poll (most waits of this path are that short), then yield, then sleep in growing steps.  (A sleep of
+    // 50 us returns after 100 - 150: with sleeps from 2 ms on, a 2.5 ms wait — the end of a 20-block window of a 125,000-voice shard —
+    // came back up to 0.1 ms late, 5 us per block of a 0.12 ms block; waits of up to 20 ms now yield.)
     if (spins < 64) continue;
-    if (waited < std::chrono::milliseconds(2)) std::this_thread::yield();
-    else std::this_thread::sleep_for(std::chrono::microseconds(waited < std::chrono::milliseconds(50) ? 50 : 500));
+    if (waited < std::chrono::milliseconds(20)) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(waited < std::chrono::milliseconds(200) ? 50 : 500));
   }
   std::string busy;
   if (hipStreamQuery(ctx->stream) == hipErrorNotReady) busy += "ctx stream";
