@@ -90,11 +90,14 @@ def launch_ranks(n, argv, deadline_s=None, attempts=3):
     here are killed and n FRESH ones are started, up to `attempts` times; rank 0's JSON line gets a `watchdog` entry."""
     deadline_s = deadline_s or float(os.environ.get("GROOVE_BENCH_RANKS_DEADLINE_S", "420"))
     killed = 0
+    base_env = dict(os.environ)
+    if "--dry-launch" not in argv and not os.environ.get("GROOVE_BENCH_FAKE_STALL_ONCE"):
+        mix_bound_env(base_env)   # GPU 0's measured issue bound, before any rank starts
     for attempt in range(1, attempts + 1):
         port = str(_free_port())  # a fresh rendezvous per attempt
         procs = []
         for r in range(n):
-            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+            env = dict(base_env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                        MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0", GROOVE_BENCH_CHILD="1",
                        GROOVE_BENCH_ATTEMPT=str(attempt))
             out = subprocess.PIPE if r == 0 else sys.stderr  # only rank 0 prints the JSON line
@@ -126,9 +129,8 @@ def launch_ranks(n, argv, deadline_s=None, attempts=3):
             for i in range(len(lines) - 1, -1, -1):
                 if lines[i].startswith("{"):
                     try:
-                        d = json.loads(lines[i])
-                        d["watchdog"] = {"attempts": attempt, "killed": killed, "seconds_allowed": deadline_s, "ranks": n}
-                        lines[i] = json.dumps(d)
+                        lines[i] = add_watchdog(lines[i], {"attempts": attempt, "killed": killed, "seconds_allowed": deadline_s, "ranks": n,
+                                                           "tainted": killed > 0})
                     except Exception:
                         pass
                     break
@@ -168,6 +170,12 @@ def supervise_rank(argv, rank, world, deadline_s=None, attempts=3):
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     killed = 0
     rc_final = 3
+    mb = [None]
+    if rank == 0 and "--dry-launch" not in argv and not os.environ.get("GROOVE_BENCH_FAKE_STALL_ONCE"):
+        mb = [mix_bound_env({}, int(os.environ.get("LOCAL_RANK", "0"))).get(MIX_BOUND_ENV)]  # rank 0's GPU, before any child starts
+    dist.broadcast_object_list(mb, src=0)
+    if mb[0]:
+        os.environ[MIX_BOUND_ENV] = mb[0]
     for attempt in range(1, attempts + 1):
         port = [_free_port() if rank == 0 else None]
         dist.broadcast_object_list(port, src=0)
@@ -202,10 +210,8 @@ def supervise_rank(argv, rank, world, deadline_s=None, attempts=3):
                 for i in range(len(lines) - 1, -1, -1):
                     if lines[i].startswith("{"):
                         try:
-                            d = json.loads(lines[i])
-                            d["watchdog"] = {"attempts": attempt, "killed": killed, "seconds_allowed": deadline_s, "ranks": world,
-                                             "supervised_under_launcher": True}
-                            lines[i] = json.dumps(d)
+                            lines[i] = add_watchdog(lines[i], {"attempts": attempt, "killed": killed, "seconds_allowed": deadline_s, "ranks": world,
+                                                               "tainted": killed > 0, "supervised_under_launcher": True})
                         except Exception:
                             pass
                         break
@@ -255,6 +261,123 @@ def dry_launch(world, rank):
     return 0 if int(t.item()) == world else 1
 
 
+# ------------------------------------------------------------------------------------------ the line
+DETAIL_PATH = os.environ.get("GROOVE_BENCH_DETAIL", os.path.join(REPO, "bench_detail.json"))
+COMPACT_LIMIT = 4096   # bytes; the final stdout line is gated to this (tests/test_bench_line.py): the driver parses that line
+
+
+def _r(x, digits=6):
+    """Round a float to `digits` significant digits for the compact line (the detail file keeps every digit)."""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def _short(text, n):
+    text = str(text)
+    return text if len(text) <= n else text[: n - 3] + "..."
+
+
+def compact_line(line):
+    """The line the driver parses: the contract keys, the headline's roofline and cpu_baseline, one row per other workload —
+    and nothing else.  Every repeat, instruction mix, note and stream table of the run is in bench_detail.json (`detail`).
+    Model: the reference's own perf print, two figures on two lines (/root/reference/src/bin/groove-cli.rs:123-139)."""
+    if "error" in line and "metric" not in line:
+        return line
+    cfg, roof = line.get("config") or {}, line.get("roofline") or {}
+    valu = roof.get("valu") or {}
+    forms = cfg.get("kernel_form") or []
+    out = {k: _r(line.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                       "vs_baseline", "dtype", "data", "x_realtime_44k1")}
+    out["config"] = {"workload": _short(cfg.get("workload"), 120), "voices_total": cfg.get("voices_total"), "voices_per_gpu": cfg.get("voices_per_gpu"),
+                     "kernel_form": _short("; ".join(forms) if isinstance(forms, list) else forms, 140), "bus_reduce": _short(cfg.get("bus_reduce"), 80)}
+    out["roofline"] = {"bound": _short(roof.get("bound"), 24), "frac": _r(roof.get("frac")),
+                       "frac_is": "effective: SURVEY 8d algorithmic bytes / time (fused kernels do not move them)",
+                       "achieved": _r(roof.get("achieved")), "peak": roof.get("peak"), "unit": roof.get("unit"),
+                       "algorithmic_bytes_per_step": _r(roof.get("algorithmic_bytes_per_step")), "kernel_ms": _r(roof.get("kernel_ms")),
+                       "traffic": _r(roof.get("traffic")), "traffic_source": roof.get("traffic_source"),
+                       "hbm_physical_frac": _r(roof.get("hbm_physical_frac"), 4), "valu_achieved_frac": _r(valu.get("achieved_frac"), 4),
+                       "frac_of_measured_bound": _r(valu.get("frac_of_measured_bound"), 4), "bound_source": valu.get("bound_source"),
+                       "measured_bound_ms": _r((valu.get("measured_bound") or {}).get("bound_ms"), 4)}
+    cb = line.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                               "sample": _short(cb.get("sample"), 110),
+                               "all_cores_value": _r((cb.get("all_cores") or {}).get("value")), "all_cores": (cb.get("all_cores") or {}).get("cores")}
+    par = line.get("parity_vs_oracle")
+    if par:
+        out["parity_rms"] = _r(par.get("bus_rms_err"), 4)
+        out["parity_sample"] = f"{par.get('voices_sampled')} voices x {par.get('blocks')} blocks, same kernel form, bus / voices"
+    out["zero_segments"] = line.get("zero_segments")
+    if line.get("tainted"):
+        out["tainted"] = True
+    if line.get("configs"):
+        out["configs"] = [{"workload": c.get("workload"), "ms_per_step": _r(c.get("ms_per_step"), 4), "frac": _r(c.get("frac"), 4),
+                           "hbm_physical_frac": _r(c.get("hbm_physical_frac"), 3),
+                           "bus_rms_err": _r((c.get("parity_vs_oracle") or {}).get("bus_rms_err"), 3)} for c in line["configs"]]
+    sc = line.get("shard_curve")
+    if sc:
+        out["shard_curve_ms"] = {str(r_["voices_per_gpu"]): _r(r_["ms_per_step"], 4) for r_ in sc.get("welsh-1m", [])}
+        if "mixed-131072_shard_of_8" in sc:
+            out["shard_curve_ms"]["mixed_16384"] = _r(sc["mixed-131072_shard_of_8"]["ms_per_step"], 4)
+    if line.get("sections"):
+        # N > 1: the curve this design defends first (weak: the workload's voice count on every rank), then strong and config #5
+        order = [k for k in ("weak", "strong", "mixed-131072") if k in line["sections"]]
+        out["sections"] = {k: {"scaling": v.get("scaling"), "value": _r(v.get("value")), "ms_per_step": _r(v.get("ms_per_step"), 5),
+                               "voices_total": v.get("voices_total"), "voices_per_gpu": v.get("voices_per_gpu"),
+                               "voice_frames_per_s": _r(v.get("voice_frames_per_s")), "rccl_ranks": v.get("rccl_ranks"),
+                               "rank_ms_min": _r((v.get("ms_per_step_by_rank") or {}).get("min"), 5),
+                               "rank_ms_max": _r((v.get("ms_per_step_by_rank") or {}).get("max"), 5),
+                               "bus_reduce_alone_ms": _r(v.get("bus_reduce_alone_ms"), 4)}
+                           for k, v in ((k, line["sections"][k]) for k in order)}
+        out["rccl_ranks"] = line.get("rccl_ranks")
+    if line.get("watchdog"):
+        out["watchdog"] = line["watchdog"]
+    out["detail"] = os.path.basename(DETAIL_PATH)
+    return out
+
+
+def emit(line):
+    """Write the whole measurement to bench_detail.json, then print the compact line — the LAST line of stdout, the only
+    JSON line on it."""
+    try:
+        with open(DETAIL_PATH, "w") as f:
+            json.dump(line, f, indent=1)
+            f.write("\n")
+    except OSError as e:
+        sys.stderr.write(f"bench.py: could not write {DETAIL_PATH}: {e}\n")
+    text = json.dumps(compact_line(line), allow_nan=False, separators=(", ", ": "))
+    if len(text.encode()) > COMPACT_LIMIT:   # never print a line the driver cannot take: drop the optional tables, keep the contract
+        c = compact_line(line)
+        for k in ("shard_curve_ms", "configs", "parity_sample"):
+            c.pop(k, None)
+            text = json.dumps(c, allow_nan=False, separators=(", ", ": "))
+            if len(text.encode()) <= COMPACT_LIMIT:
+                break
+    print(text, flush=True)
+
+
+def add_watchdog(text, watchdog):
+    """A parent that supervised the measurement adds its `watchdog` record to the child's compact line (and to the detail file)."""
+    d = json.loads(text)
+    d["watchdog"] = watchdog
+    if d.get("detail"):
+        try:
+            full = json.load(open(DETAIL_PATH))
+            full["watchdog"] = watchdog
+            with open(DETAIL_PATH, "w") as f:
+                json.dump(full, f, indent=1)
+                f.write("\n")
+        except Exception:  # noqa: BLE001
+            pass
+    return json.dumps(d, allow_nan=False, separators=(", ", ": "))
+
+
+
 # ------------------------------------------------------------------------------------------ evidence
 def committed_profile(workload, window=None):
     """The committed rocprofv3 summary of a workload (profiles/rNN_<workload>_summary.json, or round 1's single
@@ -298,22 +421,71 @@ def committed_profile(workload, window=None):
                 valu += m.get("SQ_INSTS_VALU", 0.0)
                 salu += m.get("SQ_INSTS_SALU", 0.0)
     out["valu_per_step"], out["salu_per_step"] = (valu or None), (salu or None)
+    # VALU wave-instructions per step of each kernel of the step (the weights of the measured issue bound below)
+    steps_per_run = d.get("steps_per_run") or 0.0
+    by_kernel = {}
+    if steps_per_run:
+        for k, v in (d.get("sq") or {}).items():
+            n = (v.get("mean_per_dispatch") or {}).get("SQ_INSTS_VALU", 0.0) * (v.get("dispatches") or 0) / steps_per_run
+            if n and ("render" in k or "partial_" in k):
+                by_kernel[k] = n
+    out["valu_by_kernel"] = by_kernel or None
     out["valu_mix_per_step"] = d.get("valu_mix_per_step")   # measured classes (f64 / conversions / transcendental / ...), if the pass was run
     out["valu_simd_ns_per_step"] = (d.get("valu_mix_per_step") or {}).get("cost_weighted_simd_ns")
     out["clock_ghz"] = (d.get("clock_in_counter_pass") or {}).get("ghz_weighted_long_kernels")
     return out
 
 
+MIX_BOUND_BIN = os.path.join(REPO, "tools", "micro", "mix_bound")
+MIX_BOUND_ENV = "GROOVE_BENCH_MIX_BOUND"
+
+
+def run_mix_bound(device=0, timeout=60.0):
+    """Run tools/micro/mix_bound (built by __graft_entry__.build()) as a child process on GPU `device` and return its figures
+    ({"ns_at_5_waves", "ns_at_4_waves", "source": "this run"}), or None.  Called by the watchdog PARENT / the launcher /
+    the rank-0 supervisor — processes that never touch a GPU themselves — BEFORE the measurement children start, so that the
+    issue bound and the step it is compared with come from the same box, the same minute and the same clocks."""
+    if not os.path.exists(MIX_BOUND_BIN) or os.environ.get("GROOVE_BENCH_NO_MIX_BOUND") == "1":
+        return None
+    try:
+        env = dict(os.environ, HIP_VISIBLE_DEVICES=str(device))
+        out = subprocess.run([MIX_BOUND_BIN], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout, text=True)
+        if out.returncode != 0:
+            return None
+        d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])["ns_per_wave_instruction"]
+        r = {"ns_at_5_waves": min(d["5"].values()), "ns_at_4_waves": min(d["4"].values()), "source": "this run"}
+        return r if 0.3 < r["ns_at_5_waves"] < 10.0 and 0.3 < r["ns_at_4_waves"] < 10.0 else None
+    except Exception:  # noqa: BLE001  (no binary for this host, no GPU, a garbled line: the committed figure is used, and the line says so)
+        return None
+
+
+def mix_bound_env(env, device=0):
+    """Put this box's measured issue bound into a child's environment (the children of run_under_watchdog / launch_ranks /
+    supervise_rank read it in measured_mix_bound)."""
+    if MIX_BOUND_ENV not in env:
+        mb = run_mix_bound(device)
+        if mb:
+            env[MIX_BOUND_ENV] = json.dumps(mb)
+    return env
+
+
 def measured_mix_bound():
-    """The newest committed profiles/rNN_mix_bound.json (tools/micro/mix_bound, run on an MI355X): ns of SIMD time per
-    wave-instruction of the million-voice window's VALU class mix, the best variant at 5 and at 4 waves per SIMD."""
+    """ns of SIMD time per wave-instruction of the million-voice window's VALU class mix (tools/micro/mix_bound), the best
+    variant at 5 and at 4 waves per SIMD: measured on THIS box by the parent of this process just before it started
+    (`source: "this run"`), else the newest committed profiles/rNN_mix_bound.json (`source: "committed: <file>"`)."""
     import re
+    try:
+        d = json.loads(os.environ.get(MIX_BOUND_ENV, ""))
+        if d.get("source") == "this run":
+            return {"ns_at_5_waves": float(d["ns_at_5_waves"]), "ns_at_4_waves": float(d["ns_at_4_waves"]), "source": "this run"}
+    except Exception:  # noqa: BLE001
+        pass
     pdir = os.path.join(REPO, "profiles")
     found = sorted((int(m.group(1)), n) for n in (os.listdir(pdir) if os.path.isdir(pdir) else []) for m in [re.match(r"^r(\d+)_mix_bound\.json$", n)] if m)
     for _, n in reversed(found):
         try:
             d = json.load(open(os.path.join(pdir, n)))["ns_per_wave_instruction"]
-            return {"ns_at_5_waves": min(d["5"].values()), "ns_at_4_waves": min(d["4"].values()), "source": n}
+            return {"ns_at_5_waves": min(d["5"].values()), "ns_at_4_waves": min(d["4"].values()), "source": "committed: " + n}
         except Exception:
             continue
     return None
@@ -614,9 +786,9 @@ def roofline_block(workload, n_local, kern_ms, span_mode, fused, window=None):
     the step divided by its duration — what an implementation that materialised every voice block would have to move;
     a fused kernel does not move them and the figure can exceed 1.  PHYSICAL: what the PMC passes of the committed
     profile counted for the same command — HBM bytes (`traffic`, `hbm_physical_frac`) and VALU wave-instructions
-    (`valu.achieved_frac` of the spec issue rate, and of the cost-weighted issue cycles when the instruction-class pass
-    was collected).  `bound` names the larger of the two physical fractions, or "latency" when both are under 0.25 (a
-    step of a few short, dependent launches)."""
+    (`valu.achieved_frac` of the spec issue rate; `valu.frac_of_measured_bound` against the issue time of the same class
+    mix measured by tools/micro/mix_bound, a separate labelled figure).  `bound` names the larger of the two physical
+    fractions (both on spec peaks), or "latency" when both are under 0.25 (a step of a few short, dependent launches)."""
     wl = WORKLOADS[workload]
     whole = span_mode
     dom_bytes = wl["bytes_per_vf"] if whole else wl["dominant_bytes"]
@@ -672,16 +844,29 @@ def roofline_block(workload, n_local, kern_ms, span_mode, fused, window=None):
         if mb and wl["kind"] == "welsh" and WORKLOADS[workload]["voices"] >= 500_000:
             # The issue bound of THIS instruction stream, measured (tools/micro/mix_bound.hip: the window's class mix issued as
             # independent chains at the render kernels' occupancies): the time below which no schedule of the step's VALU
-            # instructions can finish, and the step's duration against it.  <= 1 by construction; what is left to 1 is
-            # dependent-chain latency the real kernels have and the synthetic one has not.
-            t5, t4 = wi * mb["ns_at_5_waves"] * 1e-9 / 1024.0 * 1e3, wi * mb["ns_at_4_waves"] * 1e-9 / 1024.0 * 1e3
-            r["valu"]["measured_bound"] = {"ns_per_wave_instruction": {"5_waves_per_simd": mb["ns_at_5_waves"], "4_waves_per_simd": mb["ns_at_4_waves"]},
-                                           "bound_ms": {"at_5_waves": t5, "at_4_waves": t4}, "source": mb["source"],
-                                           "note": "the render kernels run at 5 / 5 / 4 / 4 waves per SIMD; the fraction uses the faster rate"}
-            r["valu"]["frac_of_measured_bound"] = t5 / kern_ms
-            valu_frac = max(valu_frac, t5 / kern_ms)
-        elif prof.get("valu_simd_ns_per_step"):
-            valu_frac = max(valu_frac, r["valu"]["cost_weighted_frac"]["low"])
+            # instructions can finish, and the step's duration against it.  Each kernel's instructions are priced at ITS
+            # occupancy (LFO_F32 kinds 5 waves per SIMD, LFO_F64_SMOOTH kinds 4: kernels.h WavesBudget; the committed SQ pass
+            # has the per-kernel counts).  A separate, labelled field: `valu.achieved_frac` stays on the spec issue rate.
+            share4 = 0.0
+            byk = prof.get("valu_by_kernel") or {}
+            if byk:
+                tot = sum(byk.values())
+                share4 = sum(v for k, v in byk.items() if "welsh_render_uniform_kernel<true, 2," in k or "welsh_render_uniform_kernel<false, 2," in k) / tot if tot else 0.0
+            ns = mb["ns_at_5_waves"] * (1.0 - share4) + mb["ns_at_4_waves"] * share4
+            bound_ms = wi * ns * 1e-9 / 1024.0 * 1e3
+            fmb = bound_ms / kern_ms
+            r["valu"]["measured_bound"] = {"ns_per_wave_instruction": {"5_waves_per_simd": mb["ns_at_5_waves"], "4_waves_per_simd": mb["ns_at_4_waves"], "weighted": ns},
+                                           "share_of_instructions_at_4_waves": share4, "bound_ms": bound_ms, "source": mb["source"],
+                                           "instruction_count_source": prof.get("source"), "same_window": prof.get("same_window_as_this_run")}
+            r["valu"]["frac_of_measured_bound"] = fmb
+            r["valu"]["bound_source"] = mb["source"]
+            flags = []
+            if fmb > 1.0:
+                flags.append("above 1: the step beat the synthetic stream's issue time (instruction count from another window, or clocks moved between the two measurements)")
+            if not prof.get("same_window_as_this_run"):
+                flags.append("instruction count taken from a profile of a different window")
+            if flags:
+                r["valu"]["frac_of_measured_bound_flags"] = flags
     fr = {"hbm": hbm_frac or 0.0, "valu-issue": valu_frac or 0.0}
     top = max(fr, key=fr.get)
     r["bound"] = (top if fr[top] >= 0.25 else "latency (one or two short launches per block: neither HBM nor VALU issue is a quarter busy)") if (hbm_frac is not None or valu_frac is not None) \
@@ -815,6 +1000,8 @@ def run_under_watchdog(argv, args, attempts=3):
     `watchdog` added; returns the exit code."""
     limit = args.watchdog_seconds or (240.0 if args.steps <= 50 else 420.0)  # a healthy run takes 40-70 s / 100-140 s
     env = dict(os.environ, GROOVE_BENCH_CHILD="1")
+    if not os.environ.get("GROOVE_BENCH_FAKE_STALL_ONCE"):
+        mix_bound_env(env)   # this box's issue bound, measured by a fresh child BEFORE the measurement child (this process never touches the GPU)
     killed = 0
     for attempt in range(1, attempts + 1):
         p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=subprocess.PIPE, text=True)
@@ -835,11 +1022,9 @@ def run_under_watchdog(argv, args, attempts=3):
         lines = [ln for ln in out.splitlines() if ln.startswith("{")]
         if p.returncode == 0 and lines:
             try:
-                d = json.loads(lines[-1])
-                d["watchdog"] = {"attempts": attempt, "killed": killed, "seconds_allowed": limit,
-                                 "tainted": killed > 0,  # a restarted run: quote it as such
-                                 }
-                print(json.dumps(d), flush=True)
+                print(add_watchdog(lines[-1], {"attempts": attempt, "killed": killed, "seconds_allowed": limit,
+                                               "tainted": killed > 0}),  # a restarted run: quote it as such
+                      flush=True)
             except Exception:
                 print(lines[-1], flush=True)
             return 0
@@ -905,7 +1090,13 @@ def main():
     if args.dry_launch:
         sys.exit(dry_launch(world, rank))
     if fake and is_child and world == 1:
-        print(json.dumps({"metric": "fake", "value": 1.0}), flush=True)
+        # (GROOVE_BENCH_FAKE_LINE: a whole measurement as a real child would have assembled it — tests/test_bench_line.py feeds
+        # round 4's 20 KB line through emit() this way)
+        src = os.environ.get("GROOVE_BENCH_FAKE_LINE")
+        if src:
+            emit(json.load(open(src)))
+        else:
+            print(json.dumps({"metric": "fake", "value": 1.0}), flush=True)
         sys.exit(0)
 
     # Watchdog (one GPU, not under a launcher).  Rounds 2 and 3 saw the million-voice path stall in some processes; round 4
@@ -1060,7 +1251,7 @@ def measure(args, world, rank, local_rank):
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(line), flush=True)
+        emit(line)
 
 
 if __name__ == "__main__":

@@ -178,19 +178,59 @@ def test_bench_n_gpu_code_path_on_one_gpu():
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GROOVE_BENCH_FORCE_DIST="1", MASTER_PORT="29541")
+    import tempfile
+    detail = os.path.join(tempfile.mkdtemp(), "bench_detail.json")
+    env = dict(os.environ, GROOVE_BENCH_FORCE_DIST="1", MASTER_PORT="29541", GROOVE_BENCH_DETAIL=detail)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "4", "--warmup", "1", "--repeats", "1", "--voices", "200000",
                         "--no-configs", "--no-shard-curve", "--no-cpu-baseline", "--no-parity", "--no-watchdog"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
-    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    json_lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(json_lines) == 1 and p.stdout.strip().splitlines()[-1] == json_lines[0]
+    from test_bench_line import _check_compact
+    line = _check_compact(json_lines[0])          # <= 4,096 bytes, strict JSON, the contract keys, the roofline block
     assert line["rccl_ranks"] == 1 and line["n_gpus"] == 1 and line["zero_segments"] == 0 and "tainted" not in line
     assert line["config"]["bus_reduce"].startswith("groove_bus_reduce")
     sec = line["sections"]
-    assert sorted(sec) == ["mixed-131072", "strong", "weak"]
+    assert list(sec) == ["weak", "strong", "mixed-131072"]     # the curve the design defends first
     for name, s in sec.items():
         assert s["rccl_ranks"] == 1 and s["bus_reduce_alone_ms"] > 0.0 and s["value"] > 0.0, (name, s)
-        assert s["ms_per_step_by_rank"]["max"] >= s["ms_per_step_by_rank"]["min"] > 0.0
+        assert s["rank_ms_max"] >= s["rank_ms_min"] > 0.0
     assert sec["strong"]["voices_total"] == sec["weak"]["voices_total"] == 200000 and sec["mixed-131072"]["voices_per_gpu"] == 131072
+    full = json.load(open(detail))                 # everything else is in the detail file
+    assert sorted(full["sections"]) == ["mixed-131072", "strong", "weak"] and "streams" in full and "timed_region" in full
+    assert full["sections"]["strong"]["ms_per_step_by_rank"]["max"] >= full["sections"]["strong"]["ms_per_step_by_rank"]["min"] > 0.0
+
+
+def test_bench_default_line_is_compact_and_carries_this_runs_bound():
+    """The driver's own command, through the watchdog parent: ONE JSON line on stdout, <= 4,096 bytes, strict JSON, with `roofline`
+    (incl. the issue bound measured on THIS box by the parent's mix_bound child: `bound_source: "this run"`) and `cpu_baseline`."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(repo, "tools", "micro", "mix_bound")):
+        pytest.fail("tools/micro/mix_bound is not built (__graft_entry__.build())")
+    detail = os.path.join(tempfile.mkdtemp(), "bench_detail.json")
+    env = dict(os.environ, GROOVE_BENCH_DETAIL=detail)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GROOVE_BENCH_CHILD"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--repeats", "3",
+                        "--no-configs", "--no-shard-curve"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    json_lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(json_lines) == 1 and p.stdout.strip().splitlines()[-1] == json_lines[0]
+    from test_bench_line import _check_compact
+    line = _check_compact(json_lines[0])
+    assert line["config"]["voices_total"] == 1_000_000 and line["steps"] == 20 and line["warmup"] == 5
+    r = line["roofline"]
+    assert r["bound_source"] == "this run" and 0.5 < r["frac_of_measured_bound"] <= 1.0, r
+    assert r["bound"] == "valu-issue" and 0.3 < r["valu_achieved_frac"] < 0.9 and 0.05 < r["hbm_physical_frac"] < 0.3
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0 and line["parity_rms"] <= 1e-5
+    assert line["watchdog"]["attempts"] == 1 and line["watchdog"]["tainted"] is False and line["zero_segments"] == 0
+    full = json.load(open(detail))
+    assert full["roofline"]["valu"]["measured_bound"]["source"] == "this run"
