@@ -794,6 +794,7 @@ int ensure_seg_buffer(groove_ctx* ctx, float** buf, size_t* cap, size_t seg_floa
 // bus[f][ch] (+)= column sums of partial[row][ch][frame] on the ctx stream (fixed order: segments of 64 rows, then the
 // segments in index order; a single segment's sums go straight to the bus).
 constexpr uint32_t kRowsPerSeg = 64;
+constexpr size_t kMaxSpareSums = 8; // lane-sum buffers groove_mix_deferred keeps for blocks to take (deferred_taken)
 // `done` (optional): an event that completes with the LAST kernel of the reduction — bound to that dispatch's own completion
 // signal (hipExtLaunchKernelGGL), not recorded behind it: a recorded event is a barrier packet of its own, ~5 us of the
 // stream's timeline (docs/STREAMS.md).
@@ -813,7 +814,14 @@ void launch_reduce(groove_ctx* ctx, const float* partial, uint32_t rows, uint32_
 // The pending rows have been handed to a launch (or to bus_flush's reduction): a buffer groove_mix_deferred took from a block is
 // a spare from now on (stream order protects it: whoever is given it next writes it behind that launch — DESIGN.md section 5).
 void deferred_taken(groove_ctx* ctx) {
-  if (ctx->deferred.rows && ctx->deferred.owned_cap) ctx->spare_sums.emplace_back(const_cast<float*>(ctx->deferred.rows), ctx->deferred.owned_cap);
+  if (ctx->deferred.rows && ctx->deferred.owned_cap) {
+    ctx->spare_sums.emplace_back(const_cast<float*>(ctx->deferred.rows), ctx->deferred.owned_cap);
+    if (ctx->spare_sums.size() > kMaxSpareSums) { // (a rotation holds one spare per block in flight; beyond that the list only grows when blocks die)
+      // the smallest goes; hipFree waits for the device, which is why this only happens past the cap
+      auto it = std::min_element(ctx->spare_sums.begin(), ctx->spare_sums.end(), [](const auto& x, const auto& y) { return x.second < y.second; });
+      if (it->first != ctx->deferred.rows) { (void)hipFree(it->first); ctx->spare_sums.erase(it); }
+    }
+  }
   ctx->deferred.rows = nullptr;
   ctx->deferred.owned_cap = 0;
 }
@@ -825,13 +833,15 @@ int paced_reduce(groove_bank* b, bool host_wait) {
   if (!b->paced.active) return 0;
   groove_ctx* ctx = b->ctx;
   const auto p = b->paced;
-  b->paced.active = false;
-  ctx->paced_order.erase(std::remove(ctx->paced_order.begin(), ctx->paced_order.end(), b), ctx->paced_order.end());
+  // The fallible steps FIRST: a wait whose deadline passes (return code 2) leaves the record pending — the next call, or any flush
+  // point, tries again — so a caller that carries on after a timeout never gets a bus that silently lacks this block.
   for (int k = 0; k < kSideStreams; ++k) {
     if (!(p.used & (1u << k))) continue;
     if (host_wait) GHIP(ctx, wait_deadline(ctx, nullptr, b->ev_render_done[k][p.slot], "groove_bank_render_mix_paced: the previous block's render"));
     else GHIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_render_done[k][p.slot], 0));
   }
+  b->paced.active = false;
+  ctx->paced_order.erase(std::remove(ctx->paced_order.begin(), ctx->paced_order.end(), b), ctx->paced_order.end());
   launch_reduce(ctx, b->d_pipe_part[p.slot], p.rows, p.frames, b->d_pipe_seg[p.slot], p.bus, p.accumulate, nullptr);
   GHIP(ctx, hipEventRecord(b->ev_reduce_done[p.slot], ctx->stream));
   b->reduce_recorded[p.slot] = true;
@@ -842,7 +852,7 @@ int bus_flush_deferred(groove_ctx* ctx);
 int bus_flush(groove_ctx* ctx) {
   if (bus_flush_deferred(ctx)) return 1;
   while (!ctx->paced_order.empty()) // (call order: the order of the banks' sums on a bus)
-    if (paced_reduce(ctx->paced_order.front(), false)) return 1;
+    if (const int rc = paced_reduce(ctx->paced_order.front(), false)) return rc;
   return 0;
 }
 int bus_flush_deferred(groove_ctx* ctx) {
@@ -1830,9 +1840,10 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
   if (bank_side_mode(b, uniform ? 1 : 2)) return 1;
   const int slot = b->pipe_slot;
   b->pipe_slot ^= 1;
-  if (b->paced.active && (!paced || b->paced.slot == slot) && paced_reduce(b, false)) return 1; // (an unpaced call, or the slot's rows still owed)
+  if (b->paced.active && (!paced || b->paced.slot == slot)) // (an unpaced call, or the slot's rows still owed)
+    if (const int rc = paced_reduce(b, false)) return rc;
   if (b->pipe_part_cap[slot] < (size_t)rows * cols || b->pipe_seg_cap[slot] < (size_t)segs * cols) {
-    if (b->paced.active && paced_reduce(b, false)) return 1;
+    if (b->paced.active) if (const int rc = paced_reduce(b, false)) return rc;
     if (ctx_join(ctx)) return 1;
     GHIP(ctx, ctx_wait(ctx));
     if (b->d_pipe_part[slot]) GHIP(ctx, hipFree(b->d_pipe_part[slot]));
@@ -1898,12 +1909,23 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
   if (paced) {
     // this block's reduction is launched by the bank's NEXT paced call (or a flush point); the previous block's is launched now: its
     // renders were submitted a whole call ago, the host waits for them (this block's are already queued behind them)
-    if (b->paced.active && paced_reduce(b, true)) return 1;
+    int late = 0;
+    if (b->paced.active) {
+      int rc = paced_reduce(b, true);
+      if (rc == 2) {
+        // The host's wait for the previous block's renders passed its deadline.  This block's kernels are already queued and a
+        // bank has ONE pending record: the previous block's reduction is queued behind device-side waits instead (it completes
+        // when the renders do), this block is registered below, and the call still reports the deadline (2, unchanged).
+        late = 2;
+        rc = paced_reduce(b, false);
+      }
+      if (rc) return rc;
+    }
     b->paced.active = true; b->paced.slot = slot; b->paced.rows = rows; b->paced.frames = frames; b->paced.used = used; b->paced.bus = bus_dev; b->paced.accumulate = accumulate;
     b->reduce_recorded[slot] = false; // (recorded when the reduction is launched)
     ctx->paced_order.push_back(b);
     GHIP(ctx, hipGetLastError());
-    return 0;
+    return late;
   }
   launch_reduce(ctx, b->d_pipe_part[slot], rows, frames, b->d_pipe_seg[slot], bus_dev, accumulate);
   GHIP(ctx, hipEventRecord(b->ev_reduce_done[slot], ctx->stream));
@@ -1922,11 +1944,35 @@ int groove_bank_render_mix_paced(groove_bank* b, uint32_t frames, float* bus_dev
   if (flush_events(b, use_tp(b, frames))) return 1;
   return render_mix_pipelined(b, frames, bus_dev, accumulate, true);
 }
-// The two row buffers of the deferred renders, BOTH sized at once: growing one of them later would have to flush the pending block
-// through the reduction kernels — whose order of additions differs from the carried reduction's — and a project's first run would
-// then round one block differently from every later run (seen by tools/soak.py: 1 CRC in 138,107 repeats of config #4).
-static int ensure_dpart(groove_ctx* ctx, size_t need) {
+// How many partial rows a bank's deferred render writes (0: the bank does not take a deferred form and goes through
+// groove_bank_render_mix), and for a sampler bank the voices-per-workgroup spread of that form.
+static uint32_t deferred_rows_of(groove_bank* b, uint32_t frames, uint32_t* svpw_out = nullptr) {
+  groove_ctx* ctx = b->ctx;
+  if (svpw_out) *svpw_out = 0;
+  if (ctx->pipeline_min_waves <= 1 || frames == 0 || frames > 4096) return 0;
+  if (!use_tp(b, frames)) { // the all-kinds / role-split kernel of a mid-size Welsh bank, its rows summed by the next block's launch
+    if (!(b->kind == BANK_WELSH && b->n_vwaves && b->n_vwaves < ctx->pipeline_min_waves)) return 0;
+    uint32_t n_spec = 0;
+    for (int k = 0; k < 4 * kClassCombos; ++k) n_spec += b->wgs_of_kind[k];
+    const uint32_t urows = fused_rows(b, frames);
+    return n_spec && urows <= 2048 ? urows : 0;
+  }
+  uint32_t svpw = 0; // sampler: spread over more workgroups than the form with a reduction launch would (welsh_tp.h)
+  if (b->kind == BANK_SAMPLER) { svpw = sampler_tp_vpw_deferred(b->n); if (sampler_tp_workgroups(b->n, svpw) > 512) svpw = 0; }
+  // (up to 2,048 rows: the 512 columns' workgroups then take two to four batches of rows, a few us of a render that is long by then)
+  const uint32_t rows = svpw ? sampler_tp_workgroups(b->n, svpw) : fused_rows(b, frames);
+  if (rows == 0 || rows > 2048 || frames > kTpMaxFrames) return 0;
+  if (svpw_out) *svpw_out = svpw;
+  return rows;
+}
+// The two row buffers of the deferred renders, BOTH sized at once and for the LARGEST need among the ctx's banks: growing one of
+// them later would have to flush the pending block through the reduction kernels — whose order of additions differs from the
+// carried reduction's — and a project's first run would then round one block differently from every later run (seen by
+// tools/soak.py: 1 CRC in 138,107 repeats of config #4; with banks of different row counts taking turns — config #5's per-GPU
+// share — the later banks of the first block would still have grown the buffers had they been sized for the first caller only).
+static int ensure_dpart(groove_ctx* ctx, size_t need, uint32_t frames) {
   if (ctx->dpart_cap[0] >= need && ctx->dpart_cap[1] >= need) return 0;
+  for (groove_bank* o : ctx->banks) need = std::max(need, (size_t)deferred_rows_of(o, frames) * 2 * frames);
   if (bus_flush(ctx)) return 1;                      // (the pending rows may live in a buffer that is about to go)
   GHIP(ctx, wait_deadline(ctx, ctx->stream, nullptr, "deferred partial rows"));
   for (int slot = 0; slot < 2; ++slot) {
@@ -1938,6 +1984,13 @@ static int ensure_dpart(groove_ctx* ctx, size_t need) {
   }
   return 0;
 }
+// Pending PACED reductions of any bank go onto their buses before a call of another form adds to a bus (include/groove_hip.h: "any
+// unpaced render or mix flushes them"): call order is the order of a bus's sums.
+static int flush_paced(groove_ctx* ctx) {
+  while (!ctx->paced_order.empty())
+    if (const int rc = paced_reduce(ctx->paced_order.front(), false)) return rc;
+  return 0;
+}
 // Fused render + mix whose bus reduction is left to the bank's NEXT deferred render (welsh_tp.h, tp_reduce_prev) — or to
 // whatever waits for the ctx stream, records an event on it or touches a bus (bus_flush).  For banks that render time-parallel
 // on the ctx stream with at most 2,048 partial rows; anything else is groove_bank_render_mix.
@@ -1947,50 +2000,33 @@ int groove_bank_render_mix_deferred(groove_bank* b, uint32_t frames, float* bus_
   if (frames == 0) return 0;
   // (several banks of a small project may take turns on the ctx stream this way — each render carries the reduction of the one
   // before it, in submission order — instead of side by side on side streams with their cross-queue waits: the caller's choice)
-  const bool lone = ctx->pipeline_min_waves > 1;
   // A Welsh bank too big for the time-parallel form and too small for the per-kind pipeline (the all-kinds or a role-split
-  // kernel on the ctx stream, then two reduction launches in line behind it: ~18 us of a 125,000-voice shard's 130): the same
+  // kernel on the ctx stream, then two reduction launches in line behind it: ~18 us of a 125,000-voice shard's 130) takes the same
   // deferral, the next block's kernel summing the rows — when the launch that would carry them exists (some workgroup of the four
-  // class-specialised kinds) and the rows are few enough.
-  if (lone && frames <= 4096 && !use_tp(b, frames) && b->kind == BANK_WELSH && b->n_vwaves && b->n_vwaves < ctx->pipeline_min_waves) {
-    uint32_t n_spec = 0;
-    for (int k = 0; k < 4 * kClassCombos; ++k) n_spec += b->wgs_of_kind[k];
-    const uint32_t urows = fused_rows(b, frames);
-    if (n_spec && urows <= 2048) {
-      GHIP(ctx, hipSetDevice(ctx->device));
-      if (flush_events(b, false)) return 1;
-      if (ctx_join(ctx)) return 1;
-      const int slot = ctx->dpart_next;
-      ctx->dpart_next ^= 1;
-      const size_t need = (size_t)urows * 2 * frames;
-      if (ensure_dpart(ctx, need)) return 1;
-      UniformArgs a = uniform_args(b, ctx->d_dpart[slot], ctx->d_dpart[slot], 0, 0, frames, urows);
-      if (ctx->deferred.rows) { a.prev.rows = ctx->deferred.rows; a.prev.bus = ctx->deferred.bus; a.prev.n_rows = ctx->deferred.n_rows; a.prev.frames = ctx->deferred.frames; a.prev.accumulate = ctx->deferred.accumulate; }
-      deferred_taken(ctx);
-      b->ctx_touched = true;
-      launch_small_uniform(b, a, ctx->stream, true, frames);
-      GHIP(ctx, hipGetLastError());
-      ctx->deferred.rows = ctx->d_dpart[slot]; ctx->deferred.bus = bus_dev; ctx->deferred.n_rows = urows; ctx->deferred.frames = frames; ctx->deferred.accumulate = accumulate;
-      return 0;
-    }
-  }
-  uint32_t svpw = 0; // sampler: spread over more workgroups than the form with a reduction launch would (welsh_tp.h)
-  if (b->kind == BANK_SAMPLER && use_tp(b, frames)) { svpw = sampler_tp_vpw_deferred(b->n); if (sampler_tp_workgroups(b->n, svpw) > 512) svpw = 0; }
-  // (up to 2,048 rows: the 512 columns' workgroups then take two to four batches of rows, a few us of a render that is long by then)
-  const uint32_t rows = !use_tp(b, frames) ? 0 : (svpw ? sampler_tp_workgroups(b->n, svpw) : fused_rows(b, frames));
-  if (!lone || rows == 0 || rows > 2048 || frames > kTpMaxFrames) return groove_bank_render_mix(b, frames, bus_dev, accumulate);
+  // class-specialised kinds) and the rows are few enough (deferred_rows_of).
+  uint32_t svpw = 0;
+  const uint32_t rows = deferred_rows_of(b, frames, &svpw);
+  if (rows == 0) return groove_bank_render_mix(b, frames, bus_dev, accumulate);
+  const bool tp = use_tp(b, frames);
   GHIP(ctx, hipSetDevice(ctx->device));
-  if (flush_events(b, true)) return 1;
+  if (const int rc = flush_paced(ctx)) return rc;
+  if (flush_events(b, tp)) return 1;
   if (ctx_join(ctx)) return 1;
+  const size_t need = (size_t)rows * 2 * frames;
+  if (ensure_dpart(ctx, need, frames)) return 1;
   const int slot = ctx->dpart_next;
   ctx->dpart_next ^= 1;
-  const size_t need = (size_t)rows * 2 * frames;
-  if (ensure_dpart(ctx, need)) return 1;
   TpPrev prev;
   if (ctx->deferred.rows) { prev.rows = ctx->deferred.rows; prev.bus = ctx->deferred.bus; prev.n_rows = ctx->deferred.n_rows; prev.frames = ctx->deferred.frames; prev.accumulate = ctx->deferred.accumulate; }
   deferred_taken(ctx);
   b->ctx_touched = true;
-  launch_tp(b, frames, true, 0, ctx->d_dpart[slot], ctx->d_dpart[slot], ctx->stream, nullptr, nullptr, prev.rows ? &prev : nullptr, svpw);
+  if (!tp) {
+    UniformArgs a = uniform_args(b, ctx->d_dpart[slot], ctx->d_dpart[slot], 0, 0, frames, rows);
+    a.prev = prev;
+    launch_small_uniform(b, a, ctx->stream, true, frames);
+  } else {
+    launch_tp(b, frames, true, 0, ctx->d_dpart[slot], ctx->d_dpart[slot], ctx->stream, nullptr, nullptr, prev.rows ? &prev : nullptr, svpw);
+  }
   GHIP(ctx, hipGetLastError());
   ctx->deferred.rows = ctx->d_dpart[slot]; ctx->deferred.bus = bus_dev; ctx->deferred.n_rows = rows; ctx->deferred.frames = frames; ctx->deferred.accumulate = accumulate;
   return 0;
@@ -2487,6 +2523,7 @@ int groove_mix(groove_ctx* ctx, groove_block* const* blocks, uint32_t n_blocks, 
 int groove_mix_deferred(groove_ctx* ctx, groove_block* blk, uint32_t frames, float* bus_dev, int accumulate) {
   if (!ctx || !bus_dev || !blk) return fail(ctx, "groove_mix_deferred: NULL argument");
   if (frames == 0) return 0;
+  if (blk->ctx != ctx) return fail(ctx, "groove_mix_deferred: the block belongs to another ctx");
   if (!(blk->sums_valid && blk->sum_frames == frames && blk->sum_rows <= 2048 && frames <= 4096)) return groove_mix(ctx, &blk, 1, frames, bus_dev, accumulate);
   GHIP(ctx, hipSetDevice(ctx->device));
   if (bus_flush(ctx)) return 1; // an earlier pending block nobody carried: its own reduction launch, first (order of the bus's sums)
@@ -2495,7 +2532,12 @@ int groove_mix_deferred(groove_ctx* ctx, groove_block* blk, uint32_t frames, flo
   // the rows leave the block: whatever writes the block's lane sums next (its next render may run on another stream) cannot touch them
   ctx->deferred.owned_cap = blk->sums_cap;
   blk->d_sums = nullptr; blk->sums_cap = 0; blk->sums_valid = false;
-  if (!ctx->spare_sums.empty()) { blk->d_sums = ctx->spare_sums.back().first; blk->sums_cap = ctx->spare_sums.back().second; ctx->spare_sums.pop_back(); }
+  // a spare at least as large as the buffer that left (a smaller one would make block_sums free and reallocate — device-wide
+  // synchronisations inside the paced walk — until every buffer of the rotation had grown): the smallest that fits
+  int pick = -1;
+  for (int i = 0; i < (int)ctx->spare_sums.size(); ++i)
+    if (ctx->spare_sums[i].second >= ctx->deferred.owned_cap && (pick < 0 || ctx->spare_sums[i].second < ctx->spare_sums[pick].second)) pick = i;
+  if (pick >= 0) { blk->d_sums = ctx->spare_sums[pick].first; blk->sums_cap = ctx->spare_sums[pick].second; ctx->spare_sums.erase(ctx->spare_sums.begin() + pick); }
   return 0;
 }
 // HOST PACING.  A wait for another queue's event costs the waiting stream 7 - 9 us of its timeline whether or not the event has

@@ -240,3 +240,131 @@ def test_paced_render_mix_gives_the_bus_of_render_mix(gpu_ctx):
     assert np.abs(outs[0][1]).max() > 1.0
     assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
     assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))
+
+
+def _mixed_banks(ctx, sel):
+    from groove_amd import entities as E, projects as PJ
+    banks = []
+    for spec in PJ.plan("mixed-131072", sel):
+        if spec["kind"] == "welsh":
+            inst = E.WelshSynth(ctx, spec["params"])
+        elif spec["kind"] == "fm":
+            inst = E.FmSynth(ctx, spec["params"])
+        else:
+            inst = E.Sampler(ctx, spec["pcm"], spec["descs"], spec["params"])
+        banks.append((inst, spec["events"]))
+    return banks
+
+
+def test_a_deferred_render_flushes_pending_paced_reductions_first(gpu_ctx):
+    """include/groove_hip.h: any unpaced render or mix puts the pending PACED reductions on their buses first.  A paced bank that
+    OVERWRITES the bus followed by a deferred bank that ACCUMULATES onto it (round 4's advisor: the deferred call skipped the
+    flush, bus_flush later applied the deferred rows first and the paced, non-accumulating reduction then overwrote them)."""
+    sel = np.arange(3000, dtype=np.int64)
+    outs = []
+    for mode in ("plain", "paced+deferred"):
+        banks = _mixed_banks(gpu_ctx, sel)
+        bus = gpu_ctx.bus(5 * 256)
+        for b in range(5):
+            for i, (inst, events) in enumerate(banks):
+                if events.get(b) is not None:
+                    inst.handle_midi_events(events[b])
+                if mode == "plain":
+                    inst.render_mix(bus, 256, accumulate=i > 0, at_frame=b * 256)
+                elif i == 0:
+                    inst.render_mix_paced(bus, 256, accumulate=False, at_frame=b * 256)
+                else:
+                    inst.render_mix_deferred(bus, 256, accumulate=True, at_frame=b * 256)
+        outs.append(bus.download().astype(np.float64))
+        for inst, _ in banks:
+            inst.destroy()
+        bus.destroy()
+    scale = float(np.abs(outs[0]).max())
+    assert scale > 1.0
+    assert np.abs(outs[0] - outs[1]).max() <= 2e-6 * scale * np.sqrt(len(sel)) / 8
+
+
+def test_a_paced_call_whose_wait_times_out_loses_no_block():
+    """groove_bank_render_mix_paced's host wait for the previous block's render passes its deadline (a side stream blocked on
+    purpose): the call reports it — and NOTHING is forgotten: the previous block's reduction is queued behind device-side waits,
+    the new block is registered, and a caller that carries on gets the bus of an undisturbed run, bit for bit."""
+    from groove_amd import entities as E, lib
+    sel = np.arange(3000, dtype=np.int64)
+    outs = []
+    for disturbed in (False, True):
+        ctx = E.Context(0)
+        try:
+            banks = _mixed_banks(ctx, sel)
+            bus = ctx.bus(6 * 256)
+            timeouts = 0
+            for b in range(6):
+                if disturbed and b == 2:
+                    for k in range(8):
+                        try:
+                            ctx.debug_spin(k, 700)      # every side stream busy for 0.7 s: block 2's renders queue behind it
+                        except lib.GrooveError:
+                            break
+                for i, (inst, events) in enumerate(banks):
+                    if events.get(b) is not None:
+                        inst.handle_midi_events(events[b])
+                    if disturbed and b == 3:
+                        ctx.sync_timeout_ms = 100        # the wait for block 2's render cannot make it
+                    try:
+                        inst.render_mix_paced(bus, 256, accumulate=i > 0, at_frame=b * 256)
+                    except lib.GrooveError as e:
+                        assert "not complete after 100 ms" in str(e), str(e)
+                        timeouts += 1
+                    ctx.sync_timeout_ms = 20000
+            outs.append(bus.download().copy())
+            assert timeouts == (len(banks) if disturbed else 0), timeouts
+            assert ctx.debug_info()["zero_segments"] == 0
+        finally:
+            ctx.close()
+    assert np.abs(outs[0]).max() > 1.0
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+
+
+def test_mix_deferred_refuses_a_block_of_another_ctx(gpu_ctx):
+    from groove_amd import entities as E, lib
+    other = E.Context(0)
+    try:
+        n = 128
+        synth = E.WelshSynth(other, P.welsh_voices(n))
+        synth.handle_midi_events(P.note_on_all(n))
+        block = other.block(n, 256)
+        synth.generate_batch_values(block, 256)
+        bus = gpu_ctx.bus(256)
+        with pytest.raises(lib.GrooveError, match="another ctx"):
+            gpu_ctx.mix_deferred(block, 256, bus)
+        bus.destroy()
+    finally:
+        other.close()
+
+
+def test_deferred_forms_are_bit_reproducible_run_to_run(gpu_ctx):
+    """The forms bench.py times for configs #2, #4 and #5's per-GPU share (groove_bank_render_mix_deferred: a lone bank, and banks
+    of different row counts taking turns): two identical call sequences from a reset state give identical bits — the FIRST run
+    included (both row buffers are sized for the largest bank before anything is pending, so no block of the first run is flushed
+    through the other reduction order).  What is NOT promised: equal bits across different call patterns (include/groove_hip.h)."""
+    from groove_amd import entities as E, projects as PJ
+    for workload, sel, blocks in (("welsh-256", np.arange(256), 40), ("sampler-16384", np.arange(16384), 60), ("mixed-131072", np.arange(16384), 40),
+                                  ("chain-4096", np.arange(4096), 30)):   # (config #3: the paced render-ahead walk with groove_mix_deferred)
+        ctx = E.Context(0)   # a fresh ctx: its first run is the project's first run
+        try:
+            proj = PJ.Project(ctx, workload, sel.astype(np.int64))
+            assert proj.take_turns or (proj.paced and proj.ahead_walk), workload
+            runs = []
+            for rep in range(3):
+                if rep:
+                    proj.reset()
+                bus = ctx.bus(blocks * 256)
+                for b in range(blocks):
+                    proj.step(bus, b * 256)
+                runs.append(bus.download().copy())
+                bus.destroy()
+            proj.destroy()
+        finally:
+            ctx.close()
+        assert np.abs(runs[0]).max() > 0.1, workload
+        assert np.array_equal(runs[0].view(np.uint32), runs[1].view(np.uint32)), workload
+        assert np.array_equal(runs[1].view(np.uint32), runs[2].view(np.uint32)), workload
