@@ -232,6 +232,8 @@ struct groove_ctx {
   // groove_mix_deferred takes the block's row-sum buffer AWAY from the block (owned_cap != 0: the pending rows live in a buffer
   // nobody else can write) and hands the block one of these instead; a consumed buffer comes back here (deferred_taken)
   std::vector<std::pair<float*, size_t>> spare_sums;
+  uint32_t mixed_sampler_vpw = 8; // tp_mixed_kernel: voices per sampler wavefront
+  bool mixed_launch = true;       // groove_banks_render_mix_deferred: one launch for several small banks (false: bank by bank)
   std::vector<groove_bank*> paced_order; // banks with a pending paced reduction, in call order (= the order of their sums on a bus)
   float* d_fseg = nullptr;   // fused path: seg[segments][2*frames]
   size_t fseg_cap = 0;
@@ -1107,6 +1109,8 @@ static int init_impl(int device_ordinal, const uint8_t* comm_id, int rank, int w
   if (const char* e = std::getenv("GROOVE_FX_CHUNKED_ALLPASS")) ctx->chunked_allpass = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_TP_MAX_VOICES")) ctx->tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_SPLIT_ROLES")) { const int r = std::atoi(e); ctx->split_roles = r == 2 || r == 4 ? r : 3; }
+  if (const char* e = std::getenv("GROOVE_MIXED_SAMPLER_VPW")) ctx->mixed_sampler_vpw = (uint32_t)std::strtoul(e, nullptr, 10); // (A/B: tools/mixed_ab.py)
+  if (const char* e = std::getenv("GROOVE_MIXED_LAUNCH")) ctx->mixed_launch = e[0] != '0';
   if (const char* e = std::getenv("GROOVE_PIPELINE_MIN_WAVES")) ctx->pipeline_min_waves = (uint32_t)std::strtoul(e, nullptr, 10); // tests force the pipeline on small banks
   bool ok = hipSetDevice(device_ordinal) == hipSuccess;
   // groove_init_comm: the rank's RCCL communicator first, so that whatever streams RCCL creates for itself exist BEFORE
@@ -2029,6 +2033,67 @@ int groove_bank_render_mix_deferred(groove_bank* b, uint32_t frames, float* bus_
   }
   GHIP(ctx, hipGetLastError());
   ctx->deferred.rows = ctx->d_dpart[slot]; ctx->deferred.bus = bus_dev; ctx->deferred.n_rows = rows; ctx->deferred.frames = frames; ctx->deferred.accumulate = accumulate;
+  return 0;
+}
+// groove_bank_render_mix_deferred for SEVERAL small banks of different kinds at once: ONE launch for the whole block (welsh_tp.h
+// tp_mixed_kernel: a grid whose workgroups dispatch on their index into the Welsh / FM / sampler time-parallel bodies), one row
+// buffer, one carried reduction — Orchestrator::gather_audio's one sum over all instruments (orchestrator.rs:397-410).  Takes
+// projects with at most one time-parallel bank of each kind and at most 2,048 rows in all; anything else goes bank by bank
+// through groove_bank_render_mix_deferred, in the order given.
+int groove_banks_render_mix_deferred(groove_ctx* ctx, groove_bank* const* banks, uint32_t n_banks, uint32_t frames, float* bus_dev, int accumulate) {
+  if (!ctx || !bus_dev || (n_banks && !banks)) return fail(ctx, "groove_banks_render_mix_deferred: NULL argument");
+  if (frames == 0) return 0;
+  if (n_banks == 0) { // nothing patched: silence (orchestrator.rs:1452-1455)
+    if (bus_flush(ctx)) return 1;
+    if (!accumulate) GHIP(ctx, hipMemsetAsync(bus_dev, 0, (size_t)frames * 8, ctx->stream));
+    return 0;
+  }
+  groove_bank* of_kind[3] = {nullptr, nullptr, nullptr}; // BANK_WELSH, BANK_FM, BANK_SAMPLER
+  bool ok = n_banks >= 2 && n_banks <= 3 && ctx->pipeline_min_waves > 1 && frames <= kTpMaxFrames && ctx->mixed_launch;
+  for (uint32_t i = 0; i < n_banks; ++i) {
+    groove_bank* b = banks[i];
+    if (!b) return fail(ctx, "groove_banks_render_mix_deferred: NULL bank");
+    if (b->ctx != ctx) return fail(ctx, "groove_banks_render_mix_deferred: a bank of another ctx");
+    const int k = b->kind == BANK_WELSH ? 0 : b->kind == BANK_FM ? 1 : 2;
+    if (of_kind[k] || !use_tp(b, frames) || (k == 0 && b->tp_full_coef)) ok = false;
+    of_kind[k] = b;
+  }
+  TpMixedArgs m{};
+  uint32_t grid = 0;
+  if (ok) {
+    if (groove_bank* b = of_kind[0]) { const uint32_t v = tp_vpw(b); m.welsh = TpMixedBank{b->d_params, b->d_state, b->n, v, grid, welsh_tp_grid(b->n, v)}; grid += m.welsh.n_wg; }
+    m.fm.wg0 = grid;
+    if (groove_bank* b = of_kind[1]) { const uint32_t v = tp_vpw(b); m.fm = TpMixedBank{b->d_params, b->d_state, b->n, v, grid, welsh_tp_workgroups(b->n, v)}; grid += m.fm.n_wg; }
+    m.sampler.wg0 = grid;
+    if (groove_bank* b = of_kind[2]) {
+      const uint32_t v = std::min<uint32_t>(std::max<uint32_t>(ctx->mixed_sampler_vpw, 1u), 64u);
+      m.sampler = TpMixedBank{b->d_params, b->d_state, b->n, v, grid, mixed_sampler_workgroups(b->n, v)}; grid += m.sampler.n_wg;
+      m.pcm = b->d_pcm;
+    }
+    if (grid == 0 || grid > 2048) ok = false;
+  }
+  if (!ok) {
+    for (uint32_t i = 0; i < n_banks; ++i)
+      if (const int rc = groove_bank_render_mix_deferred(banks[i], frames, bus_dev, accumulate || i > 0)) return rc;
+    return 0;
+  }
+  GHIP(ctx, hipSetDevice(ctx->device));
+  if (const int rc = flush_paced(ctx)) return rc;
+  for (uint32_t i = 0; i < n_banks; ++i)
+    if (flush_events(banks[i], true)) return 1;
+  if (ctx_join(ctx)) return 1;
+  if (ensure_dpart(ctx, (size_t)grid * 2 * frames, frames)) return 1;
+  const int slot = ctx->dpart_next;
+  ctx->dpart_next ^= 1;
+  if (ctx->deferred.rows) { m.prev.rows = ctx->deferred.rows; m.prev.bus = ctx->deferred.bus; m.prev.n_rows = ctx->deferred.n_rows; m.prev.frames = ctx->deferred.frames; m.prev.accumulate = ctx->deferred.accumulate; }
+  deferred_taken(ctx);
+  m.rows = ctx->d_dpart[slot]; m.rc = render_consts(ctx->sr); m.frames = frames;
+  static const InlineEvents no_events{};
+  launch_tp_mixed(m, of_kind[2] ? of_kind[2]->inline_ev : no_events, grid, ctx->stream);
+  for (uint32_t i = 0; i < n_banks; ++i) banks[i]->ctx_touched = true;
+  if (of_kind[2]) of_kind[2]->inline_ev.n = 0;
+  GHIP(ctx, hipGetLastError());
+  ctx->deferred.rows = ctx->d_dpart[slot]; ctx->deferred.bus = bus_dev; ctx->deferred.n_rows = grid; ctx->deferred.frames = frames; ctx->deferred.accumulate = accumulate;
   return 0;
 }
 int groove_bus_flush(groove_ctx* ctx) {

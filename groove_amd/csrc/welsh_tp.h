@@ -475,15 +475,25 @@ static __device__ unsigned long long g_tp_probe[16]; // [phase 0..11] ticks, [12
 // wavefront instead of ~2,350, so 25 % less issue per voice and, where VPW = 1 needs more wavefronts than the SIMDs hold at
 // once (165 registers: three per SIMD, i.e. banks over 3,072 voices), a shorter block.  Same per-frame operations: a voice's
 // output differs from the VPW = 1 form's only by the f64 rounding of the filter scan's composition order.
-template <bool FUSED, bool HEAD_BQ = false, bool FULL_COEF = false, int VPW = 1>
-__global__ __launch_bounds__(kTpThreads, VPW == 1 ? GROOVE_TP_WAVES : 2) void welsh_tp_kernel(TpArgs a) {
+// Which workgroup of which launch a time-parallel body is (round 5): `wg` of `n_wg` workgroups of ITS bank (voice mapping), `row` =
+// its row pair in rows[][2][frames], and (`pwg`, `pn_wg`) = its index among all workgroups of the launch, which share out the
+// previous block's bus reduction (tp_reduce_prev).  A bank's own kernel: all of them blockIdx.x / gridDim.x; the mixed kernel of
+// several small banks (tp_mixed_kernel below) gives every bank a range of its grid.
+struct TpWg { uint32_t wg, n_wg, row, pwg, pn_wg; };
+__device__ __forceinline__ TpWg tp_wg_own() { return TpWg{blockIdx.x, gridDim.x, blockIdx.x, blockIdx.x, gridDim.x}; }
+template <int VPW> struct WelshTpSmem {
+  float noise[kTpWaves * VPW][3][kTpMaxFrames];
+  // hard sync's prefix sums (pass 1) and the output tile (the end) share their 2 KB per voice: until the workgroup barrier in
+  // front of the tile turn a wavefront touches its own voices' rows only, and its tile writes follow its last sync gather
+  uint64_t sum2[kTpWaves * VPW][kTpMaxFrames];
+};
+template <bool FUSED, bool HEAD_BQ, bool FULL_COEF, int VPW>
+__device__ __forceinline__ void welsh_tp_body(const TpArgs& a, const TpWg g, WelshTpSmem<VPW>& sm) {
   static_assert(!(FUSED && HEAD_BQ), "an effect needs the voice blocks: the fused bus form has none");
   static_assert(VPW == 1 || VPW == 2, "");
   constexpr uint32_t LPV = 64 / VPW, CH = kTpChunk * VPW, WGV = kTpWaves * VPW; // lanes per voice, frames per lane, voices per workgroup
-  __shared__ float s_noise[WGV][3][kTpMaxFrames];
-  // hard sync's prefix sums (pass 1) and the output tile (the end) share their 2 KB per voice: until the workgroup barrier in
-  // front of the tile turn a wavefront touches its own voices' rows only, and its tile writes follow its last sync gather
-  __shared__ uint64_t s_sum2[WGV][kTpMaxFrames];
+  float (&s_noise)[WGV][3][kTpMaxFrames] = sm.noise;
+  uint64_t (&s_sum2)[WGV][kTpMaxFrames] = sm.sum2;
   float (*s_tile)[2][kTpMaxFrames] = reinterpret_cast<float (*)[2][kTpMaxFrames]>(&s_sum2[0][0]);
   static_assert(sizeof(uint64_t) * kTpMaxFrames == sizeof(float) * 2 * kTpMaxFrames, "a voice's tile row is its prefix-sum row");
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -495,7 +505,7 @@ __global__ __launch_bounds__(kTpThreads, VPW == 1 ? GROOVE_TP_WAVES : 2) void we
   // mapping the 8 workgroups that share a 128-byte line of a row sit on 8 DIFFERENT XCDs — eight L2s each hold an eighth
   // of every line and write it back masked; with group = (i mod 8) * (grid / 8) + i / 8 an XCD owns a contiguous range
   // of voices, the workgroups that share a line follow each other on ONE XCD, and its L2 writes whole lines.
-  const uint32_t grp = tp_group_of_block(blockIdx.x, gridDim.x);
+  const uint32_t grp = tp_group_of_block(g.wg, g.n_wg);
   const uint32_t v0 = grp * WGV + wv;
   const bool voice = v0 < a.n;
   const uint32_t vme = voice ? v0 : a.n - 1; // (per lane when VPW > 1)
@@ -503,7 +513,7 @@ __global__ __launch_bounds__(kTpThreads, VPW == 1 ? GROOVE_TP_WAVES : 2) void we
   const uint32_t frames = a.frames, n = a.n;
   const WelshParams p = make_scalar(soa_load<WelshParams>(a.params, n, v)); // VPW > 1: the wave's voices share the patch (host)
   const WelshState s0 = soa_load<WelshState>(a.state, n, VPW == 1 ? v : vme); // the same in every lane of the voice
-  if constexpr (FUSED) tp_reduce_prev(a.prev, threadIdx.x, blockIdx.x, gridDim.x);
+  if constexpr (FUSED) tp_reduce_prev(a.prev, threadIdx.x, g.pwg, g.pn_wg);
   const RenderConsts rc = a.rc;
   const bool first0 = (s0.vflags & VF_FIRST) != 0;
   const uint32_t live_total = env_idle_at(s0.amp, p.amp, frames);
@@ -688,7 +698,7 @@ __global__ __launch_bounds__(kTpThreads, VPW == 1 ? GROOVE_TP_WAVES : 2) void we
       float acc = 0.0f;
 #pragma unroll
       for (uint32_t w = 0; w < WGV; ++w) { q[w] = s_tile[w][ch][f]; acc += q[w]; }
-      if (a.rows) a.rows[((size_t)blockIdx.x * 2 + ch) * frames + f] = acc; // (null: the block goes straight into an effect chain, which replaces its lane sums)
+      if (a.rows) a.rows[((size_t)g.row * 2 + ch) * frames + f] = acc; // (null: the block goes straight into an effect chain, which replaces its lane sums)
       if (vec) {
 #pragma unroll
         for (uint32_t w = 0; w < WGV; w += 4)
@@ -720,6 +730,11 @@ __global__ __launch_bounds__(kTpThreads, VPW == 1 ? GROOVE_TP_WAVES : 2) void we
   }
   TP_PROBE_END // 11: state store
 }
+template <bool FUSED, bool HEAD_BQ = false, bool FULL_COEF = false, int VPW = 1>
+__global__ __launch_bounds__(kTpThreads, VPW == 1 ? GROOVE_TP_WAVES : 2) void welsh_tp_kernel(TpArgs a) {
+  __shared__ WelshTpSmem<VPW> sm;
+  welsh_tp_body<FUSED, HEAD_BQ, FULL_COEF, VPW>(a, tp_wg_own(), sm);
+}
 // FmVoice: one wavefront per voice, 64 lanes x 4 frames (same argument block; rows / out as above).
 constexpr uint32_t kFmTpMaxVoices = 131072; // the serial kernel's 256-frame walk costs ~0.09 ms whatever the size; above this it has the wavefronts
 // VPW voices per wavefront (round 3): an FM voice's per-wavefront costs (parameters, two envelope seeks, the scan, the tile turn)
@@ -727,14 +742,15 @@ constexpr uint32_t kFmTpMaxVoices = 131072; // the serial kernel's 256-frame wal
 // were 32,768 wavefronts beside the Welsh bank that bounds the step.  With four voices per wavefront (16 lanes x 16 frames each;
 // parameters per lane: FM patches differ from voice to voice) a voice costs ~40 % fewer issued instructions, and the prefix sum
 // of the carrier increments is four DPP row shifts.
-template <bool FUSED, int VPW = 1>
-__global__ __launch_bounds__(kTpThreads) void fm_tp_kernel(TpArgs a) {
+template <int VPW> struct FmTpSmem { float tile[kTpWaves * VPW][2][kTpMaxFrames]; };
+template <bool FUSED, int VPW>
+__device__ __forceinline__ void fm_tp_body(const TpArgs& a, const TpWg g, FmTpSmem<VPW>& sm) {
   static_assert(VPW == 1 || VPW == 2 || VPW == 4, "");
   constexpr uint32_t LPV = 64 / VPW, CH = kTpChunk * VPW, WGV = kTpWaves * VPW;
-  __shared__ float s_tile[WGV][2][kTpMaxFrames];
+  float (&s_tile)[WGV][2][kTpMaxFrames] = sm.tile;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t vl = lane & (LPV - 1u), sub = lane / LPV, wv = wave * VPW + sub;
-  const uint32_t v0 = blockIdx.x * WGV + wv;
+  const uint32_t v0 = g.wg * WGV + wv;
   const bool voice = v0 < a.n;
   const uint32_t vq = voice ? v0 : a.n - 1; // (per lane when VPW > 1)
   const uint32_t v = VPW == 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)vq) : vq;
@@ -742,7 +758,7 @@ __global__ __launch_bounds__(kTpThreads) void fm_tp_kernel(TpArgs a) {
   const FmParams pl = soa_load<FmParams>(a.params, n, v);
   const FmParams p = VPW == 1 ? make_scalar(pl) : pl; // one voice per wavefront: the patch in SGPRs
   const FmState s0 = soa_load<FmState>(a.state, n, v);
-  if constexpr (FUSED) tp_reduce_prev(a.prev, threadIdx.x, blockIdx.x, gridDim.x);
+  if constexpr (FUSED) tp_reduce_prev(a.prev, threadIdx.x, g.pwg, g.pn_wg);
   const bool first0 = (s0.vflags & VF_FIRST) != 0;
   const uint32_t live_total = env_idle_at(s0.cenv, p.cenv, frames);
   const uint32_t n0 = vl * CH;
@@ -805,7 +821,7 @@ __global__ __launch_bounds__(kTpThreads) void fm_tp_kernel(TpArgs a) {
       float acc = 0.0f;
 #pragma unroll
       for (uint32_t w = 0; w < WGV; ++w) acc += s_tile[w][ch][f];
-      a.rows[((size_t)blockIdx.x * 2 + ch) * frames + f] = acc;
+      a.rows[((size_t)g.row * 2 + ch) * frames + f] = acc;
     }
   }
   if (!FUSED && voice) {
@@ -824,6 +840,11 @@ __global__ __launch_bounds__(kTpThreads) void fm_tp_kernel(TpArgs a) {
     soa_store(a.state, n, v, s);
   }
 }
+template <bool FUSED, int VPW = 1>
+__global__ __launch_bounds__(kTpThreads) void fm_tp_kernel(TpArgs a) {
+  __shared__ FmTpSmem<VPW> sm;
+  fm_tp_body<FUSED, VPW>(a, tp_wg_own(), sm);
+}
 // SamplerVoice: pointer stepping is a closed form in the frame index (idx0 + k * step, Q20.44), so a voice's block is a
 // pure gather (the serial form walks 256 frames in chunks of 16 fetches: 45 us for a one-wave-per-SIMD bank).  Exact,
 // like the serial form.  A wavefront takes `vpw` ADJACENT voices (<= 64), one after the other, its 64 lanes x 4 frames
@@ -838,20 +859,25 @@ inline uint32_t sampler_tp_workgroups(uint32_t n, uint32_t vpw = 0) { const uint
 // groove_bank_render_mix_deferred: no reduction launch to keep short, so the voices are spread over the chip — at most 512 rows
 // (config #4: 4 voices per wavefront, 256 workgroups on 256 CUs instead of 64 on 64)
 inline uint32_t sampler_tp_vpw_deferred(uint32_t n) { return n <= 1024 ? 1u : std::min<uint32_t>((n + 8191) / 8192 * 2, 16u); }
-template <bool FUSED>
-__global__ __launch_bounds__(kSamplerTpThreads) void sampler_tp_kernel(TpArgs a, const float* __restrict__ bank, InlineEvents ie, uint32_t vpw) {
-  __shared__ float s_tile[kSamplerTpWaves][kTpMaxFrames];
-  __shared__ volatile uint32_t s_ev[kSamplerTpWaves][64]; // volatile: lanes read what OTHER lanes of the wave wrote, with no barrier the compiler knows of
+template <int WAVES> struct SamplerTpSmem {
+  float tile[WAVES][kTpMaxFrames];
+  volatile uint32_t ev[WAVES][64]; // volatile: lanes read what OTHER lanes of the wave wrote, with no barrier the compiler knows of
+};
+// WAVES wavefronts per workgroup: 16 in the bank's own kernel, 4 in the mixed kernel (whose workgroups are 256 threads)
+template <bool FUSED, int WAVES>
+__device__ __forceinline__ void sampler_tp_body(const TpArgs& a, const float* __restrict__ bank, const InlineEvents& ie, const uint32_t vpw, const TpWg g, SamplerTpSmem<WAVES>& sm) {
+  float (&s_tile)[WAVES][kTpMaxFrames] = sm.tile;
+  volatile uint32_t (&s_ev)[WAVES][64] = sm.ev;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t frames = a.frames, n = a.n;
-  const uint32_t v_begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * kSamplerTpWaves + wave) * vpw));
+  const uint32_t v_begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)((g.wg * WAVES + wave) * vpw));
   const uint32_t cnt = v_begin < n ? min(vpw, n - v_begin) : 0u; // this wave's voices (wave-uniform)
   // lane l < cnt: voice v_begin + l
   const bool mine = lane < cnt;
   const uint32_t v = mine ? v_begin + lane : (n - 1);
   const SamplerParams p = soa_load<SamplerParams>(a.params, n, v);
   SamplerState s0 = soa_load<SamplerState>(a.state, n, v);
-  if constexpr (FUSED) tp_reduce_prev(a.prev, threadIdx.x, blockIdx.x, gridDim.x);
+  if constexpr (FUSED) tp_reduce_prev(a.prev, threadIdx.x, g.pwg, g.pn_wg);
   if (ie.n && cnt) { // this block's note events (strictly increasing voices): those of this wave's voice range
     uint32_t lo = 0, hi = ie.n;
     while (lo < hi) { // first event at or after v_begin (scalar loads)
@@ -943,12 +969,12 @@ __global__ __launch_bounds__(kSamplerTpThreads) void sampler_tp_kernel(TpArgs a,
 #pragma unroll
   for (uint32_t j = 0; j < kTpChunk; ++j) s_tile[wave][n0 + j] = acc[j];
   __syncthreads();
-  for (uint32_t t = threadIdx.x; t < frames; t += kSamplerTpThreads) {
+  for (uint32_t t = threadIdx.x; t < frames; t += WAVES * 64) {
     float sum = 0.0f;
 #pragma unroll
-    for (int w = 0; w < kSamplerTpWaves; ++w) sum += s_tile[w][t];
-    a.rows[((size_t)blockIdx.x * 2 + 0) * frames + t] = sum; // mono voices: the same sum on both channels
-    a.rows[((size_t)blockIdx.x * 2 + 1) * frames + t] = sum;
+    for (int w = 0; w < WAVES; ++w) sum += s_tile[w][t];
+    a.rows[((size_t)g.row * 2 + 0) * frames + t] = sum; // mono voices: the same sum on both channels
+    a.rows[((size_t)g.row * 2 + 1) * frames + t] = sum;
   }
   if (mine && frames) {
     SamplerState s = s0;
@@ -957,6 +983,49 @@ __global__ __launch_bounds__(kSamplerTpThreads) void sampler_tp_kernel(TpArgs a,
     soa_store(a.state, n, v, s);
   }
 }
+template <bool FUSED>
+__global__ __launch_bounds__(kSamplerTpThreads) void sampler_tp_kernel(TpArgs a, const float* __restrict__ bank, InlineEvents ie, uint32_t vpw) {
+  __shared__ SamplerTpSmem<kSamplerTpWaves> sm;
+  sampler_tp_body<FUSED, kSamplerTpWaves>(a, bank, ie, vpw, tp_wg_own(), sm);
+}
+// ------------------------------------------------------------------ several small banks in ONE launch (round 5)
+// A project of a few small banks of different kinds (config #5's share of one of eight GPUs: 8,192 Welsh + 4,096 FM + 4,096
+// sampler voices) rendered its banks in turn, three launches per block whose durations add (35 + 13 + 7.5 us).  They cannot
+// overlap as separate launches either: the Welsh time-parallel kernel's two wavefronts per SIMD hold the whole register file.
+// ONE grid of 256-thread workgroups, each dispatching on its index into the Welsh / FM / sampler body (the most expensive kind
+// first), ONE row buffer and ONE carried bus reduction (tp_reduce_prev over all of the launch's workgroups) for the project:
+// the FM and sampler wavefronts — latency-bound, 7 - 13 us as launches of their own because each is a lone wavefront per SIMD —
+// now fill wavefront slots as the Welsh ones retire, and the step costs the sum of the wavefronts' SLOT-time over the chip's
+// slots instead of the sum of three launch durations.  (Same register budget for all: the FM / sampler bodies run at the Welsh
+// body's occupancy; they are few.)  The bus is one sum over all instruments, orchestrator.rs:397-410.
+struct TpMixedBank { const uint32_t* params; uint32_t* state; uint32_t n, vpw, wg0, n_wg; }; // n_wg 0: no bank of this kind
+struct TpMixedArgs {
+  TpMixedBank welsh, fm, sampler; // the grid: [welsh | fm | sampler] workgroup ranges (wg0 = the range's first workgroup)
+  float* rows;                    // rows[workgroup of the grid][ch][frame]
+  const float* pcm;               // the sampler bank's sample memory
+  RenderConsts rc; uint32_t frames;
+  TpPrev prev;
+};
+template <int WVPW, int FVPW>
+__global__ __launch_bounds__(kTpThreads, WVPW == 1 ? GROOVE_TP_WAVES : 2) void tp_mixed_kernel(TpMixedArgs m, InlineEvents ie) {
+  union Smem { WelshTpSmem<WVPW> w; FmTpSmem<FVPW> f; SamplerTpSmem<kTpWaves> s; };
+  __shared__ Smem sm;
+  const uint32_t i = blockIdx.x;
+  TpArgs a{nullptr, nullptr, nullptr, m.rows, 0, m.rc, 0, m.frames};
+  a.prev = m.prev;
+  if (i < m.fm.wg0) {
+    a.params = m.welsh.params; a.state = m.welsh.state; a.n = m.welsh.n; a.vpw = WVPW;
+    welsh_tp_body<true, false, false, WVPW>(a, TpWg{i, m.welsh.n_wg, i, i, gridDim.x}, sm.w);
+  } else if (i < m.sampler.wg0) {
+    a.params = m.fm.params; a.state = m.fm.state; a.n = m.fm.n; a.vpw = FVPW;
+    fm_tp_body<true, FVPW>(a, TpWg{i - m.fm.wg0, m.fm.n_wg, i, i, gridDim.x}, sm.f);
+  } else {
+    a.params = m.sampler.params; a.state = m.sampler.state; a.n = m.sampler.n; a.vpw = m.sampler.vpw;
+    sampler_tp_body<true, kTpWaves>(a, m.pcm, ie, m.sampler.vpw, TpWg{i - m.sampler.wg0, m.sampler.n_wg, i, i, gridDim.x}, sm.s);
+  }
+}
+inline uint32_t mixed_sampler_workgroups(uint32_t n, uint32_t vpw) { const uint32_t per = kTpWaves * vpw; return (n + per - 1) / per; }
+void launch_tp_mixed(const TpMixedArgs& m, const InlineEvents& ie, uint32_t grid, hipStream_t st, hipEvent_t done = nullptr); // welsh.vpw 1 | 2, fm.vpw 1 | 4
 void launch_welsh_tp(const TpArgs& a, hipStream_t st, bool fused, hipEvent_t done = nullptr); // a.bq_coef set (block-writing form): the BiQuad head fused; done: an event bound to the dispatch
 void launch_fm_tp(const TpArgs& a, hipStream_t st, bool fused, hipEvent_t done = nullptr); // a.vpw voices per wavefront (1, 2, 4)
 void launch_sampler_tp(const TpArgs& a, const float* bank, const InlineEvents& ie, hipStream_t st, bool fused, hipEvent_t done = nullptr);

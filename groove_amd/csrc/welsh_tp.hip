@@ -48,6 +48,14 @@ void launch_sampler_tp(const TpArgs& a, const float* bank, const InlineEvents& i
   if (fused) launch_bound(sampler_tp_kernel<true>, grid, blk, st, done, a, bank, ie, vpw);
   else launch_bound(sampler_tp_kernel<false>, grid, blk, st, done, a, bank, ie, vpw);
 }
+void launch_tp_mixed(const TpMixedArgs& m, const InlineEvents& ie, uint32_t grid, hipStream_t st, hipEvent_t done) {
+  const dim3 g(grid), blk(kTpThreads);
+  const bool w2 = m.welsh.n_wg && m.welsh.vpw == 2, f4 = m.fm.n_wg && m.fm.vpw == 4;
+  if (w2 && f4) launch_bound(tp_mixed_kernel<2, 4>, g, blk, st, done, m, ie);
+  else if (w2) launch_bound(tp_mixed_kernel<2, 1>, g, blk, st, done, m, ie);
+  else if (f4) launch_bound(tp_mixed_kernel<1, 4>, g, blk, st, done, m, ie);
+  else launch_bound(tp_mixed_kernel<1, 1>, g, blk, st, done, m, ie);
+}
 } // namespace groove
 #ifdef GROOVE_TP_PROBE
 extern "C" int groove_debug_tp_probe_read(unsigned long long out[16], int reset) { // measurement build only (tools/tp_probe.py)

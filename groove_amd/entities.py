@@ -132,6 +132,13 @@ class Context:
         arr = (C.c_void_p * len(blocks))(*[b.h for b in blocks])
         _lib.check(self.L.groove_mix(self.h, arr, len(blocks), frames, bus.ptr, 1 if accumulate else 0), self.h)
 
+    def render_mix_banks_deferred(self, instruments, bus, frames, accumulate=False, at_frame=0):
+        """groove_banks_render_mix_deferred: one block of several small instruments of different kinds in ONE launch (one bus sum
+        over all of them, deferred); projects it does not fit are rendered instrument by instrument, in the order given."""
+        arr = (C.c_void_p * len(instruments))(*[i.h for i in instruments])
+        ptr = bus.at(at_frame) if at_frame else bus.ptr
+        _lib.check(self.L.groove_banks_render_mix_deferred(self.h, arr, len(instruments), frames, ptr, 1 if accumulate else 0), self.h)
+
     def mix_deferred(self, block, frames, bus, accumulate=False):
         """groove_mix_deferred: the block's few lane-sum rows ride in the next effect-chain launch (or flush_bus)."""
         _lib.check(self.L.groove_mix_deferred(self.h, block.h, frames, bus.ptr, 1 if accumulate else 0), self.h)

@@ -440,11 +440,14 @@ void synthetic_707_kit(uint32_t sample_rate, std::vector<float>& pcm, std::vecto
     pcm.insert(pcm.end(), one.begin(), one.end());
   }
 }
+#ifndef GROOVE_HOST_PARSER_ONLY
 extern "C" int gh_add_drumkit(void*, const float*, uint64_t, const groove_sample_desc*, uint32_t, const int*);
 extern "C" int gh_add_welsh(void*, const groove_welsh_params*, uint32_t);
 extern "C" int gh_add_fm(void*, const groove_fm_params*, uint32_t);
+#endif
 } // namespace
 
+#ifndef GROOVE_HOST_PARSER_ONLY // (the sanitizer build of the parser half — parse_check.cpp, `make asan` — needs no device library)
 int instantiate(Orchestrator& o, const ProjectDesc& p, const std::string& assets_root, bool synthetic_kit) {
   std::map<std::string, Uid> uid_of;
   uid_of["main-mixer"] = kMainMixerUid;
@@ -511,6 +514,7 @@ int instantiate(Orchestrator& o, const ProjectDesc& p, const std::string& assets
   return 0;
 }
 
+#endif // GROOVE_HOST_PARSER_ONLY
 } // namespace groove_host
 
 // ---- C surface ------------------------------------------------------------------------------
@@ -579,6 +583,7 @@ int gh_synthetic_kit(uint32_t sample_rate, float* pcm_out, uint64_t pcm_cap, gro
   std::memcpy(key_to_sample, k2s, sizeof(k2s));
   return 0;
 }
+#ifndef GROOVE_HOST_PARSER_ONLY
 // Load a project into an existing orchestrator (GPU).
 int gh_load_project(void* h, const char* path, const char* assets_root, int synthetic_kit) {
   Orchestrator* o = (Orchestrator*)h;
@@ -589,4 +594,5 @@ int gh_load_project(void* h, const char* path, const char* assets_root, int synt
     return o->fail(e.what());
   }
 }
+#endif
 }

@@ -70,6 +70,7 @@ SYMBOLS = {
     "groove_mix_deferred": (_i, [_vp, _vp, _u32, _vp, _i]),
     "groove_bank_render_mix": (_i, [_vp, _u32, _vp, _i]),
     "groove_bank_render_mix_deferred": (_i, [_vp, _u32, _vp, _i]),
+    "groove_banks_render_mix_deferred": (_i, [_vp, _vpp, _u32, _u32, _vp, _i]),
     "groove_bus_flush": (_i, [_vp]),
     "groove_bank_render_mix_paced": (_i, [_vp, _u32, _vp, _i]),
     "groove_bank_reset": (_i, [_vp]),

@@ -125,7 +125,7 @@ class Project:
     (instruments render, their chains run, the mix bus sums: Orchestrator::tick / gather_audio,
     /root/reference/orchestration/src/orchestrator.rs:856-877, 367-470)."""
 
-    def __init__(self, ctx, workload, sel, fused=True, grouped=True, render_ahead=True, bank_scale=1.0, head_ahead=True, paced=None):
+    def __init__(self, ctx, workload, sel, fused=True, grouped=True, render_ahead=True, bank_scale=1.0, head_ahead=True, paced=None, one_launch=True):
         self.ctx, self.fused, self.workload = ctx, fused, workload
         # PACED walk (instruments with an effect chain; default for them): the renders go out TWO blocks ahead into a rotation of
         # four blocks, and the host itself waits for the two events a step depends on — the release of the block the new render
@@ -169,6 +169,9 @@ class Project:
         # (groove_bank_render_mix_deferred): one launch per bank and block, no cross-queue waits.  Bigger banks render side by side.
         total = sum(inst.n for inst, _, _, _ in self.banks)
         self.take_turns = fused and not self.has_chain and (len(self.banks) == 1 or total <= TAKE_TURNS_MAX_VOICES)
+        # ... and since round 5 in ONE launch per block where the library can (groove_banks_render_mix_deferred: at most one
+        # time-parallel bank of each kind): the banks' durations no longer add.  one_launch=False: the banks in turn (A/B).
+        self.one_launch = self.take_turns and len(self.banks) > 1 and one_launch
         # Every other fused project — banks side by side on the library's streams, or one bank big enough for the per-kind block
         # pipeline — is PACED by default (groove_bank_render_mix_paced: the host waits for the events, every bank's bus reduction is
         # launched by its next call); paced=False: device-side waits.  Measured in one job (profiles/r04_paced_fused_ab.log):
@@ -259,6 +262,13 @@ class Project:
             return self._step_render_ahead(bus, frame0, ev_pair)
         self._events(self.block_index)
         self.block_index += 1
+        if self.one_launch:
+            if ev_pair is not None and ev_pair[0] is not None:
+                ctx.record(ev_pair[0])
+            ctx.render_mix_banks_deferred([inst for inst, _, _, _ in self.banks], bus, FRAMES, accumulate=False, at_frame=frame0)
+            if ev_pair is not None and ev_pair[1] is not None:
+                ctx.record(ev_pair[1])
+            return
         first = True
         for inst, block, fx, _ in self.banks:
             if ev_pair is not None and ev_pair[0] is not None and inst is self.dominant:

@@ -207,6 +207,16 @@ int groove_bank_render_mix(groove_bank* bank, uint32_t frames, float* bus_dev, i
  * of eight rows per lane, partitioned by ITS grid; groove_bus_flush and the flush points add them in segments of 64 rows).  A
  * host that needs bit-reproducible buses calls groove_bank_render_mix. */
 int groove_bank_render_mix_deferred(groove_bank* bank, uint32_t frames, float* bus_dev, int accumulate);
+/* One block of a project of several SMALL banks of different kinds — Orchestrator::gather_audio's one sum over all instruments
+ * (orchestrator.rs:397-410) — in ONE launch: the workgroups of one grid dispatch on their index into the Welsh / FM / sampler
+ * time-parallel bodies (the most expensive kind first), they share one buffer of partial rows, and the block's one bus reduction is
+ * deferred exactly as above (carried by the next such call, or flushed).  For projects with at most one time-parallel bank of each
+ * kind and at most 2,048 partial rows in all (config #5's share of one of eight GPUs: 8,192 Welsh + 4,096 FM + 4,096 sampler
+ * voices, three launches whose durations added -> one); anything else is rendered bank by bank by groove_bank_render_mix_deferred in
+ * the order given (bus = banks[0] (+)= ... ).  Bit-reproducible from run to run; the same sum as bank by bank to fp32 rounding, not
+ * the same bits (one reduction over all rows instead of one per bank).  No reference counterpart as a call: the reference ticks
+ * every instrument inside gather_audio. */
+int groove_banks_render_mix_deferred(groove_ctx* ctx, groove_bank* const* banks, uint32_t n_banks, uint32_t frames, float* bus_dev, int accumulate);
 int groove_bus_flush(groove_ctx* ctx);
 /* groove_bank_render_mix for a project whose banks render SIDE BY SIDE on the library's streams, PACED by the host (see
  * groove_block_wait_ready): the call blocks the host, as needed, until the reduction that frees this bank's slot of partial rows

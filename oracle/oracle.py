@@ -93,7 +93,9 @@ def lib(native=False):
     if native:
         return _bind(_load("liboracle_native.so"))
     if _LIB is None:
-        _LIB = _bind(_load("liboracle.so"))
+        # GROOVE_ORACLE_LIB: another build of the same oracle (liboracle_asan.so: tests/test_host_sanitizers.py runs the
+        # known-answer tests against the AddressSanitizer + UBSan build in a child process)
+        _LIB = _bind(_load(os.environ.get("GROOVE_ORACLE_LIB", "liboracle.so")))
     return _LIB
 
 
