@@ -232,8 +232,6 @@ struct groove_ctx {
   // groove_mix_deferred takes the block's row-sum buffer AWAY from the block (owned_cap != 0: the pending rows live in a buffer
   // nobody else can write) and hands the block one of these instead; a consumed buffer comes back here (deferred_taken)
   std::vector<std::pair<float*, size_t>> spare_sums;
-  uint32_t mixed_sampler_vpw = 8; // tp_mixed_kernel: voices per sampler wavefront
-  bool mixed_launch = true;       // groove_banks_render_mix_deferred: one launch for several small banks (false: bank by bank)
   std::vector<groove_bank*> paced_order; // banks with a pending paced reduction, in call order (= the order of their sums on a bus)
   float* d_fseg = nullptr;   // fused path: seg[segments][2*frames]
   size_t fseg_cap = 0;
@@ -1109,8 +1107,6 @@ static int init_impl(int device_ordinal, const uint8_t* comm_id, int rank, int w
   if (const char* e = std::getenv("GROOVE_FX_CHUNKED_ALLPASS")) ctx->chunked_allpass = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_TP_MAX_VOICES")) ctx->tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_SPLIT_ROLES")) { const int r = std::atoi(e); ctx->split_roles = r == 2 || r == 4 ? r : 3; }
-  if (const char* e = std::getenv("GROOVE_MIXED_SAMPLER_VPW")) ctx->mixed_sampler_vpw = (uint32_t)std::strtoul(e, nullptr, 10); // (A/B: tools/mixed_ab.py)
-  if (const char* e = std::getenv("GROOVE_MIXED_LAUNCH")) ctx->mixed_launch = e[0] != '0';
   if (const char* e = std::getenv("GROOVE_PIPELINE_MIN_WAVES")) ctx->pipeline_min_waves = (uint32_t)std::strtoul(e, nullptr, 10); // tests force the pipeline on small banks
   bool ok = hipSetDevice(device_ordinal) == hipSuccess;
   // groove_init_comm: the rank's RCCL communicator first, so that whatever streams RCCL creates for itself exist BEFORE
@@ -2049,7 +2045,7 @@ int groove_banks_render_mix_deferred(groove_ctx* ctx, groove_bank* const* banks,
     return 0;
   }
   groove_bank* of_kind[3] = {nullptr, nullptr, nullptr}; // BANK_WELSH, BANK_FM, BANK_SAMPLER
-  bool ok = n_banks >= 2 && n_banks <= 3 && ctx->pipeline_min_waves > 1 && frames <= kTpMaxFrames && ctx->mixed_launch;
+  bool ok = n_banks >= 2 && n_banks <= 3 && ctx->pipeline_min_waves > 1 && frames <= kTpMaxFrames;
   for (uint32_t i = 0; i < n_banks; ++i) {
     groove_bank* b = banks[i];
     if (!b) return fail(ctx, "groove_banks_render_mix_deferred: NULL bank");
@@ -2061,13 +2057,13 @@ int groove_banks_render_mix_deferred(groove_ctx* ctx, groove_bank* const* banks,
   TpMixedArgs m{};
   uint32_t grid = 0;
   if (ok) {
+    // the kinds' workgroup ranges in dispatch order, the most expensive kind first (measured, profiles/r05_mixed_ab.log: Welsh | FM |
+    // sampler 0.0408 ms per block for config #5's share, sampler-first orders 0.0414 - 0.0423; 8 sampler voices per wavefront: 2 / 4 /
+    // 8 / 16 -> 0.0426 / 0.0413 / 0.0408 / 0.0407, and 16 costs the 4,096-voice project 0.0199 against 0.0183)
     if (groove_bank* b = of_kind[0]) { const uint32_t v = tp_vpw(b); m.welsh = TpMixedBank{b->d_params, b->d_state, b->n, v, grid, welsh_tp_grid(b->n, v)}; grid += m.welsh.n_wg; }
-    m.fm.wg0 = grid;
     if (groove_bank* b = of_kind[1]) { const uint32_t v = tp_vpw(b); m.fm = TpMixedBank{b->d_params, b->d_state, b->n, v, grid, welsh_tp_workgroups(b->n, v)}; grid += m.fm.n_wg; }
-    m.sampler.wg0 = grid;
     if (groove_bank* b = of_kind[2]) {
-      const uint32_t v = std::min<uint32_t>(std::max<uint32_t>(ctx->mixed_sampler_vpw, 1u), 64u);
-      m.sampler = TpMixedBank{b->d_params, b->d_state, b->n, v, grid, mixed_sampler_workgroups(b->n, v)}; grid += m.sampler.n_wg;
+      m.sampler = TpMixedBank{b->d_params, b->d_state, b->n, kMixedSamplerVpw, grid, mixed_sampler_workgroups(b->n, kMixedSamplerVpw)}; grid += m.sampler.n_wg;
       m.pcm = b->d_pcm;
     }
     if (grid == 0 || grid > 2048) ok = false;

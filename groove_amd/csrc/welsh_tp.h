@@ -1013,10 +1013,10 @@ __global__ __launch_bounds__(kTpThreads, WVPW == 1 ? GROOVE_TP_WAVES : 2) void t
   const uint32_t i = blockIdx.x;
   TpArgs a{nullptr, nullptr, nullptr, m.rows, 0, m.rc, 0, m.frames};
   a.prev = m.prev;
-  if (i < m.fm.wg0) {
+  if (i - m.welsh.wg0 < m.welsh.n_wg) {
     a.params = m.welsh.params; a.state = m.welsh.state; a.n = m.welsh.n; a.vpw = WVPW;
-    welsh_tp_body<true, false, false, WVPW>(a, TpWg{i, m.welsh.n_wg, i, i, gridDim.x}, sm.w);
-  } else if (i < m.sampler.wg0) {
+    welsh_tp_body<true, false, false, WVPW>(a, TpWg{i - m.welsh.wg0, m.welsh.n_wg, i, i, gridDim.x}, sm.w);
+  } else if (i - m.fm.wg0 < m.fm.n_wg) {
     a.params = m.fm.params; a.state = m.fm.state; a.n = m.fm.n; a.vpw = FVPW;
     fm_tp_body<true, FVPW>(a, TpWg{i - m.fm.wg0, m.fm.n_wg, i, i, gridDim.x}, sm.f);
   } else {
@@ -1024,6 +1024,7 @@ __global__ __launch_bounds__(kTpThreads, WVPW == 1 ? GROOVE_TP_WAVES : 2) void t
     sampler_tp_body<true, kTpWaves>(a, m.pcm, ie, m.sampler.vpw, TpWg{i - m.sampler.wg0, m.sampler.n_wg, i, i, gridDim.x}, sm.s);
   }
 }
+constexpr uint32_t kMixedSamplerVpw = 8; // sampler voices per wavefront in the mixed kernel
 inline uint32_t mixed_sampler_workgroups(uint32_t n, uint32_t vpw) { const uint32_t per = kTpWaves * vpw; return (n + per - 1) / per; }
 void launch_tp_mixed(const TpMixedArgs& m, const InlineEvents& ie, uint32_t grid, hipStream_t st, hipEvent_t done = nullptr); // welsh.vpw 1 | 2, fm.vpw 1 | 4
 void launch_welsh_tp(const TpArgs& a, hipStream_t st, bool fused, hipEvent_t done = nullptr); // a.bq_coef set (block-writing form): the BiQuad head fused; done: an event bound to the dispatch

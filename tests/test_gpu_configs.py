@@ -189,6 +189,7 @@ def test_bench_n_gpu_code_path_on_one_gpu():
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     json_lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(json_lines) == 1 and p.stdout.strip().splitlines()[-1] == json_lines[0]
+    sys.path.insert(0, os.path.join(repo, "tests"))
     from test_bench_line import _check_compact
     line = _check_compact(json_lines[0])          # <= 4,096 bytes, strict JSON, the contract keys, the roofline block
     assert line["rccl_ranks"] == 1 and line["n_gpus"] == 1 and line["zero_segments"] == 0 and "tainted" not in line
@@ -224,6 +225,7 @@ def test_bench_default_line_is_compact_and_carries_this_runs_bound():
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     json_lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(json_lines) == 1 and p.stdout.strip().splitlines()[-1] == json_lines[0]
+    sys.path.insert(0, os.path.join(repo, "tests"))
     from test_bench_line import _check_compact
     line = _check_compact(json_lines[0])
     assert line["config"]["voices_total"] == 1_000_000 and line["steps"] == 20 and line["warmup"] == 5

@@ -142,7 +142,7 @@ def test_banks_taking_turns_equal_banks_side_by_side(gpu_ctx, oracle):
 
 
 @pytest.mark.parametrize("voices,blocks", [(16384, 100), (2048, 40), (600, 40), (30000, 20)])
-def test_small_mixed_project_in_one_launch(gpu_ctx, oracle, voices, blocks):
+def test_small_mixed_project_in_one_launch(gpu_ctx, oracle, monkeypatch, voices, blocks):
     """groove_banks_render_mix_deferred (welsh_tp.h tp_mixed_kernel): config #5's per-GPU share — 8,192 Welsh (two per wavefront)
     + 4,096 FM (four per wavefront) + 4,096 sampler voices — and smaller mixes (one Welsh voice per wavefront; one FM voice per
     wavefront) in ONE launch per block, against the banks in turn (each render carrying the reduction of the one before it), the
@@ -153,6 +153,7 @@ def test_small_mixed_project_in_one_launch(gpu_ctx, oracle, voices, blocks):
     from oracle.projects import OracleProject
     sel = np.arange(voices, dtype=np.int64)
     buses = {}
+    monkeypatch.setattr(PJ, "TAKE_TURNS_MAX_VOICES", max(PJ.TAKE_TURNS_MAX_VOICES, voices))
     for one in (True, False):
         proj = PJ.Project(gpu_ctx, "mixed-131072", sel, one_launch=one)
         assert proj.take_turns and proj.one_launch == one
@@ -395,7 +396,8 @@ def test_deferred_forms_are_bit_reproducible_run_to_run(gpu_ctx):
     through the other reduction order).  What is NOT promised: equal bits across different call patterns (include/groove_hip.h)."""
     from groove_amd import entities as E, projects as PJ
     for workload, sel, blocks in (("welsh-256", np.arange(256), 40), ("sampler-16384", np.arange(16384), 60), ("mixed-131072", np.arange(16384), 40),
-                                  ("chain-4096", np.arange(4096), 30)):   # (config #3: the paced render-ahead walk with groove_mix_deferred)
+                                  ("chain-4096", np.arange(4096), 72)):   # (config #3: the paced render-ahead walk with groove_mix_deferred; its all-wet chorus and
+                                                                           #  delay lines keep the bus silent for the first 15,435 frames)
         ctx = E.Context(0)   # a fresh ctx: its first run is the project's first run
         try:
             proj = PJ.Project(ctx, workload, sel.astype(np.int64))

@@ -1,6 +1,7 @@
 """Config #5's per-GPU share (and other small mixed projects): ONE launch per block (groove_banks_render_mix_deferred,
-csrc/welsh_tp.h tp_mixed_kernel) against the banks in turn, and the sampler's voices per wavefront inside the mixed launch, over
-the project's whole timeline in ONE gpurun job; every variant in its own process (the knobs are read when the ctx is created).
+csrc/welsh_tp.h tp_mixed_kernel) against the banks in turn, over the project's whole timeline in ONE gpurun job, every variant in
+its own process.  (--vpw / --orders need a measurement build that reads GROOVE_MIXED_SAMPLER_VPW / GROOVE_MIXED_ORDER when the ctx
+is created — round 5's experiment, results in profiles/r05_mixed_ab.log; the product build has the winners as constants.)
 
     python3 tools/mixed_ab.py [--voices 16384,4096,32768] [--vpw 2,4,8,16] [--rounds 2]
 """
@@ -34,7 +35,8 @@ def child(voices, one_launch, blocks, repeats):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--voices", default="16384")
-    ap.add_argument("--vpw", default="2,4,8,16")
+    ap.add_argument("--vpw", default="8")
+    ap.add_argument("--orders", default="")
     ap.add_argument("--blocks", type=int, default=172)
     ap.add_argument("--repeats", type=int, default=5)
     ap.add_argument("--rounds", type=int, default=2)
@@ -45,6 +47,7 @@ def main():
     for rnd in range(args.rounds):
         for v in (int(x) for x in args.voices.split(",")):
             variants = [("in turn", "0", {})] + [(f"one launch, sampler vpw {w}", "1", {"GROOVE_MIXED_SAMPLER_VPW": w}) for w in args.vpw.split(",")]
+            variants += [(f"one launch, order {o}", "1", {"GROOVE_MIXED_ORDER": o}) for o in args.orders.split(",") if o]
             for label, one, extra in variants:
                 env = dict(os.environ, **extra)
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(v), one, "--blocks", str(args.blocks), "--repeats", str(args.repeats)],
