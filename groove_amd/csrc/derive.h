@@ -90,6 +90,58 @@ inline WelshParams derive_welsh(const groove_welsh_params& p, double sr, WelshCo
   cold.fixed1 = p.oscillator_1.fixed_hz; cold.fixed2 = p.oscillator_2.fixed_hz;
   return o;
 }
+// WF_FILTER_F32 (dsp_core.h "fp32 recurrence"): may this patch's 24 dB filter run in fp32?  MEASURED, not estimated: the fp32
+// recurrence loses accuracy where a pole pair approaches the unit circle — at z = +1 (low cutoffs) and at z = -1 (cutoffs near
+// SR/2) — by an amount that depends on the ripple too, and no closed form predicted the emulated voices' errors to better than
+// 30x (docs/DSP_SPEC.md).  So the host runs the two recurrences side by side — the device's own coefficient formulas, a sawtooth
+// at 110 Hz and at 1,760 Hz, 2,048 frames — at the lowest, the highest and the middle cutoff the patch can reach (static cutoff;
+// envelope sweep start .. start + (1 - start) end; LFO sweep start (1 -+ depth)), and promises fp32 only if the worst RMS
+// difference is <= 2e-6 of full scale.  The 32 benchmark patches: 16 qualify, their voices' RMS error against the oracle stays
+// <= 1.2e-6 (f64 filter: <= 2.0e-6 over all 32); tests/test_emul_numerics.py holds the bar.  ~0.2 ms per distinct patch.
+inline double welsh_filter_f32_error(const WelshParams& o, double sr) {
+  const RenderConsts rc = render_consts(sr);
+  float lo_fc, hi_fc;
+  const auto fc_of_pct = [](float pct) { return 25.0f * powf(800.0f, fminf(fmaxf(pct, 0.0f), 1.0f)); };
+  if (o.flags & WF_RETUNE_ENV) {
+    lo_fc = fc_of_pct(o.cutoff_start); hi_fc = fc_of_pct(o.cutoff_start + (1.0f - o.cutoff_start) * o.cutoff_end);
+  } else if (o.flags & WF_LFO_CUTOFF) {
+    lo_fc = fc_of_pct(o.cutoff_start * (1.0f - fabsf(o.lfo_depth))); hi_fc = fc_of_pct(o.cutoff_start * (1.0f + fabsf(o.lfo_depth)));
+  } else {
+    lo_fc = hi_fc = o.cutoff_hz;
+  }
+  if (lo_fc > hi_fc) { const float t = lo_fc; lo_fc = hi_fc; hi_fc = t; }
+  lo_fc = fminf(fmaxf(lo_fc, 1.0f), rc.fc_max); hi_fc = fminf(fmaxf(hi_fc, 1.0f), rc.fc_max);
+  const float cut[3] = {lo_fc, sqrtf(lo_fc * hi_fc), hi_fc};
+  const double pitch[2] = {110.0, 1760.0};
+  constexpr int kWarm = 512, kFrames = 2048;
+  double worst = 0.0;
+  for (int ci = 0; ci < (lo_fc == hi_fc ? 1 : 3); ++ci) {
+    const Lp24CoefD cd = lp24_coefd_from_fc(o.fc, cut[ci], rc.pi_over_sr, rc.fc_max);
+    const Lp24CoefF cf = lp24_coeff_from_fc(o.fc, cut[ci], rc.pi_over_sr, rc.fc_max);
+    for (double f0 : pitch) {
+      Lp24StateD sd{0.0, 0.0, 0.0, 0.0};
+      Lp24StateF sf{0.0f, 0.0f, 0.0f, 0.0f};
+      double acc = 0.0, ph = 0.0;
+      const double dph = f0 / sr;
+      for (int i = 0; i < kWarm + kFrames; ++i) {
+        const float x = (float)(ph - 0.5); // a sawtooth of amplitude 0.5: an oscillator mix's level
+        ph += dph; if (ph >= 1.0) ph -= 1.0;
+        const double yd = lp24_step(sd, cd, (double)x);
+        const double yf = (double)lp24_step_f32(sf, cf, x);
+        if (i >= kWarm) acc += (yf - yd) * (yf - yd);
+      }
+      const double rms = sqrt(acc / kFrames);
+      if (!(rms <= worst)) worst = rms; // (NaN counts as failure)
+    }
+  }
+  return worst;
+}
+constexpr double kFilterF32MaxError = 2e-6;
+inline bool welsh_filter_f32_ok(const WelshParams& o, double sr) {
+  if (o.flags & WF_LFO_RESO) return false; // the ripple moves every frame: the exact-f64 kind
+  const double e = welsh_filter_f32_error(o, sr);
+  return e == e && e <= kFilterF32MaxError;
+}
 inline WelshState initial_welsh_state() {
   WelshState s{};
   osc_reset(s.o1); osc_reset(s.o2); osc_reset(s.lfo);

@@ -466,6 +466,37 @@ GROOVE_HD Lp24CoefD lp24_coefd_from_pct(const Lp24Consts& c, float pct, const Re
   const float t = lp24_t_from_pct(pct, rc, hi);
   return lp24_coefd_from_t(c, t, hi);
 }
+#ifdef GROOVE_EMUL_F32_FILTER_HOOK
+// The same two transposed-direct-form-II sections with fp32 state and fp32 arithmetic (the state fields hold float values).
+// form 1: plain coefficients a1, a2 rounded to fp32 (ten operations a frame, what an fp32 kernel kind would issue);
+// form 2: the "small quantity" form q1 = 2 - |a1|, q2 = 1 + a2 kept in fp32 (fourteen operations a frame).
+extern int groove_emul_f32_filter;
+inline double groove_emul_lp24_step_f32(Lp24StateD& s, const Lp24CoefD& c, double xd, int form) {
+  const float x = (float)xd;
+  float st[4] = {(float)s.s0, (float)s.s1, (float)s.s2, (float)s.s3};
+  const double b0[2] = {c.b0a, c.b0b}, a1[2] = {c.a1a, c.a1b}, a2[2] = {c.a2a, c.a2b};
+  float in = x;
+  for (int k = 0; k < 2; ++k) {
+    const float b = (float)b0[k];
+    const float bx = b * in;
+    const float y = bx + st[2 * k];
+    if (form == 1) {
+      const float fa1 = (float)a1[k], fa2 = (float)a2[k];
+      st[2 * k] = fmaf(fa1, y, fmaf(2.0f, bx, st[2 * k + 1]));
+      st[2 * k + 1] = fmaf(fa2, y, bx);
+    } else {
+      const float sg = a1[k] < 0.0 ? -1.0f : 1.0f;
+      const float q1 = (float)(2.0 - (a1[k] < 0.0 ? -a1[k] : a1[k])), q2 = (float)(a2[k] + 1.0);
+      const float t = fmaf(2.0f, bx, st[2 * k + 1]);
+      st[2 * k] = fmaf(-sg * q1, y, fmaf(2.0f * sg, y, t));
+      st[2 * k + 1] = fmaf(q2, y, bx - y);
+    }
+    in = y;
+  }
+  s.s0 = st[0]; s.s1 = st[1]; s.s2 = st[2]; s.s3 = st[3];
+  return (double)in;
+}
+#endif
 // SCALAR_COEF: the coefficients are wave-uniform values the caller keeps in SGPRs (device only).
 template <bool SCALAR_COEF = false>
 GROOVE_HD double lp24_step(Lp24StateD& s, const Lp24CoefD& c, double x) {
@@ -506,6 +537,9 @@ GROOVE_HD double lp24_step(Lp24StateD& s, const Lp24CoefD& c, double x) {
   }
   return y2;
 #else
+#ifdef GROOVE_EMUL_F32_FILTER_HOOK /* tests/emul only: the arithmetic-policy experiment of docs/DSP_SPEC.md ("an fp32 filter kind?") */
+  if (groove_emul_f32_filter) return groove_emul_lp24_step_f32(s, c, x, groove_emul_f32_filter);
+#endif
   const double bx = c.b0a * x;
   const double y1 = bx + s.s0;
   s.s0 = fma(c.a1a, y1, 2.0 * bx + s.s1);
@@ -518,6 +552,55 @@ GROOVE_HD double lp24_step(Lp24StateD& s, const Lp24CoefD& c, double x) {
 #endif
 }
 
+// ------------------------------------------------------------------ 24 dB low-pass, fp32 recurrence (round 5)
+// The same two transposed-direct-form-II sections with fp32 coefficients and fp32 state: ten fp32 operations a frame instead of
+// ten f64 ones, no widening of the coefficients on a retuning frame (four conversions and four f64 operations), no conversion of
+// the input and the output.  Only for voices whose filter stays away from z = +1 AND z = -1 over its whole cutoff range
+// (WF_FILTER_F32: the host measures it when the bank is uploaded, derive.h welsh_filter_f32_ok), and only in the per-kind serial
+// kernels of big banks (kernels.h welsh_block<..., F32OK>): every other form keeps the f64 recurrence of DESIGN.md section 4.
+// docs/DSP_SPEC.md "An fp32 filter kind" has the measurements that decided it.
+struct Lp24CoefF { float b0a, a1a, a2a, b0b, a1b, a2b; };
+struct Lp24StateF { float s0, s1, s2, s3; };
+GROOVE_HD Lp24CoefF lp24_coeff_from_t(const Lp24Consts& c, float t, bool hi) { // lp24_coefd_from_t's quotients, finished in fp32
+  const float T2 = t * t;
+  const float dta = c.d1 * t, dtb = c.d3 * t;
+  Lp24CoefF d;
+  if (!hi) {
+    const float ia = fast_rcp(c.c0 + dta + T2), ib = fast_rcp(c.c2 + dtb + T2);
+    const float b0a = T2 * ia, q2a = (dta + dta) * ia, b0b = T2 * ib, q2b = (dtb + dtb) * ib;
+    d.b0a = b0a; d.a1a = fmaf(-4.0f, b0a, 2.0f - q2a); d.a2a = q2a - 1.0f;
+    d.b0b = b0b; d.a1b = fmaf(-4.0f, b0b, 2.0f - q2b); d.a2b = q2b - 1.0f;
+  } else {
+    const float Pa = c.c0 * T2, Pb = c.c2 * T2;
+    const float ia = fast_rcp(1.0f + dta + Pa), ib = fast_rcp(1.0f + dtb + Pb);
+    const float q2a = (dta + dta) * ia, pa = Pa * ia, q2b = (dtb + dtb) * ib, pb = Pb * ib;
+    d.b0a = ia; d.a1a = fmaf(4.0f, pa, q2a - 2.0f); d.a2a = q2a - 1.0f;
+    d.b0b = ib; d.a1b = fmaf(4.0f, pb, q2b - 2.0f); d.a2b = q2b - 1.0f;
+  }
+  return d;
+}
+GROOVE_HD Lp24CoefF lp24_coeff_from_fc(const Lp24Consts& c, float fc, float pi_over_sr, float fc_max) {
+  fc = fminf(fmaxf(fc, 1.0f), fc_max);
+  bool hi;
+  const float t = tan_reduced(fc * pi_over_sr, hi);
+  return lp24_coeff_from_t(c, t, hi);
+}
+GROOVE_HD Lp24CoefF lp24_coeff_from_pct(const Lp24Consts& c, float pct, const RenderConsts& rc) {
+  bool hi;
+  const float t = lp24_t_from_pct(pct, rc, hi);
+  return lp24_coeff_from_t(c, t, hi);
+}
+GROOVE_HD float lp24_step_f32(Lp24StateF& s, const Lp24CoefF& c, float x) { // lp24_step's ten operations
+  const float bx = c.b0a * x;
+  const float y1 = bx + s.s0;
+  s.s0 = fmaf(c.a1a, y1, fmaf(2.0f, bx, s.s1));
+  s.s1 = fmaf(c.a2a, y1, bx);
+  const float by = c.b0b * y1;
+  const float y2 = by + s.s2;
+  s.s2 = fmaf(c.a1b, y2, fmaf(2.0f, by, s.s3));
+  s.s3 = fmaf(c.a2b, y2, by);
+  return y2;
+}
 // ------------------------------------------------------------------ WelshVoice (a5)
 // Packed per-voice flags word.
 enum : uint32_t {
@@ -528,7 +611,8 @@ enum : uint32_t {
   // test is one bit: pitch- or pulse-width-like (the edge-moving routings) and which oscillators they
   // reach, amplitude, cutoff percent, passband ripple.
   WF_LFO_PITCH = 1u << 20, WF_LFO_PW = 1u << 21, WF_LFO_O1 = 1u << 22, WF_LFO_O2 = 1u << 23,
-  WF_LFO_AMP = 1u << 24, WF_LFO_CUTOFF = 1u << 25, WF_LFO_RESO = 1u << 26
+  WF_LFO_AMP = 1u << 24, WF_LFO_CUTOFF = 1u << 25, WF_LFO_RESO = 1u << 26,
+  WF_FILTER_F32 = 1u << 27 // host promise (derive.h welsh_filter_f32_ok): the fp32 filter recurrence stays within 2e-6 of the f64 one over this patch's cutoff range
 };
 GROOVE_HD uint32_t lfo_routing_bits(uint32_t routing) {
   switch (routing) {
@@ -573,6 +657,7 @@ struct WelshState {
 // Per-block scratch that lives in registers across frames but is not persisted.
 struct WelshScratch {
   Lp24CoefD coef;  // current filter coefficients
+  Lp24CoefF coef_f; Lp24StateF filt_f; // ... and the filter's state, in the fp32 form (welsh_frame<..., F32FILT>: WF_FILTER_F32 voices)
   float prev_pct;  // cutoff percent the coefficients were computed for (NaN = none)
   double ls, lc;   // LFO_F64_SMOOTH: LFO value of the previous frame (sine: sin), and cos of the sine LFO's angle
   double lm;       // LFO_F64_SMOOTH, pitch routing: 2^(ls * depth)
@@ -936,14 +1021,30 @@ GROOVE_HD void welsh_frame_back(const WelshParams& p, Lp24StateD& filt, const Lp
 // after the segment (welsh_segment_end) — and an unused LFO's phase moves there too: two conversions, two integer
 // adds and a 64-bit add less on every frame.
 template <bool FIRST, bool RETUNE, int LFO_MODE = LFO_F64, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool SEGMENT = false, bool REST = false,
-          bool HOIST = false>
+          bool HOIST = false, bool F32FILT = false>
 GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc,
                            WelshScratch& sc, float& L, float& R) {
+  static_assert(!(F32FILT && LFO_MODE == LFO_F64), "the exact-f64 kinds (resonance routing) keep the f64 filter");
   float sum, a, pct, lfo;
   bool retune;
   if (!welsh_frame_front<FIRST, RETUNE, LFO_MODE, C1, C2, CL, SEGMENT, REST, HOIST>(p, s, sc, sum, a, pct, retune, lfo)) { L = 0.0f; R = 0.0f; return; }
-  welsh_frame_coef<RETUNE, LFO_MODE, CL>(p, rc, sc, pct, retune, lfo);
-  welsh_frame_back<SEGMENT && !RETUNE>(p, s.filt, sc.coef, sum, a, L, R);
+  if constexpr (F32FILT) { // sc.coef_f / sc.filt_f were set by welsh_scratch_f32_begin; the caller hands the state back with welsh_scratch_f32_end
+    if (RETUNE && retune && pct != sc.prev_pct) { sc.coef_f = lp24_coeff_from_pct(p.fc, pct, rc); sc.prev_pct = pct; }
+    const float m = lp24_step_f32(sc.filt_f, sc.coef_f, sum) * a;
+    L = m * p.gl; R = m * p.gr;
+  } else {
+    welsh_frame_coef<RETUNE, LFO_MODE, CL>(p, rc, sc, pct, retune, lfo);
+    welsh_frame_back<SEGMENT && !RETUNE>(p, s.filt, sc.coef, sum, a, L, R);
+  }
+}
+// The fp32 filter form's block bracket: the state is PERSISTED in the f64 fields of WelshState (which then hold fp32 values
+// exactly), so every other kernel form can pick the voice up with its f64 recurrence.
+GROOVE_HD void welsh_scratch_f32_begin(const WelshParams& p, const WelshState& s, const RenderConsts& rc, WelshScratch& sc) {
+  sc.coef_f = lp24_coeff_from_fc(p.fc, p.cutoff_hz, rc.pi_over_sr, rc.fc_max);
+  sc.filt_f = Lp24StateF{(float)s.filt.s0, (float)s.filt.s1, (float)s.filt.s2, (float)s.filt.s3};
+}
+GROOVE_HD void welsh_scratch_f32_end(WelshState& s, const WelshScratch& sc) {
+  s.filt.s0 = (double)sc.filt_f.s0; s.filt.s1 = (double)sc.filt_f.s1; s.filt.s2 = (double)sc.filt_f.s2; s.filt.s3 = (double)sc.filt_f.s3;
 }
 // Segments.  Between two envelope stage boundaries nothing about a voice's control flow changes: the
 // boundary checks of both envelopes and the idle test can be made once, and the frames up to the next

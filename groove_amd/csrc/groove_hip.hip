@@ -14,6 +14,7 @@
 #include <hip/hip_ext.h> // hipExtLaunchKernelGGL: an event bound to a kernel's own completion signal (launch_reduce, launch_welsh_tp)
 #include <rccl/rccl.h> // types, enumerators and prototypes only: the library itself is dlopen'ed (rccl_open)
 #include <string>
+#include <map>
 #include <vector>
 #include <algorithm>
 #include <cstring>
@@ -103,6 +104,7 @@ struct groove_bank {
   bool tp_full_coef = false;     // welsh: some voice routes the LFO to the resonance (welsh_tp_kernel<.., FULL_COEF>)
   bool tp_pairs = false;         // welsh: every pair of adjacent voices (2i, 2i + 1) shares a patch (welsh_tp_kernel<.., VPW = 2>)
   uint8_t* d_wg_base = nullptr;  // welsh: base kind of each entry of d_wg_list (the all-kinds kernel of small banks)
+  uint8_t* d_wg_f32 = nullptr;   // welsh: 1 where the entry's patches carry WF_FILTER_F32 (the fused per-kind kernels)
   uint32_t* d_wg_list = nullptr; // welsh: workgroup ids (groups of 4 virtual waves) sorted by kind (kernels.h)
   size_t wg_list_cap = 0;
   uint32_t wgs_of_kind[kWgKinds] = {};  // slice lengths of d_wg_list, in kind order
@@ -232,6 +234,7 @@ struct groove_ctx {
   // groove_mix_deferred takes the block's row-sum buffer AWAY from the block (owned_cap != 0: the pending rows live in a buffer
   // nobody else can write) and hands the block one of these instead; a consumed buffer comes back here (deferred_taken)
   std::vector<std::pair<float*, size_t>> spare_sums;
+  bool f32_filter = true; // WF_FILTER_F32: patches whose 24 dB filter is measured safe in fp32 take the fp32 recurrence in the per-kind kernels (GROOVE_F32_FILTER=0: never)
   std::vector<groove_bank*> paced_order; // banks with a pending paced reduction, in call order (= the order of their sums on a bus)
   float* d_fseg = nullptr;   // fused path: seg[segments][2*frames]
   size_t fseg_cap = 0;
@@ -481,6 +484,19 @@ int welsh_upload_params(groove_bank* b, bool regroup) {
   std::vector<WelshParams> Pext(n);
   std::vector<WelshCold> Cext(n);
   for (uint32_t v = 0; v < n; ++v) Pext[v] = derive_welsh(b->welsh[v], sr, Cext[v]);
+  if (ctx->f32_filter) { // WF_FILTER_F32 (derive.h welsh_filter_f32_ok): measured once per distinct filter description
+    struct Key { float c0, d1, c2, d3, hz, start, end, depth; uint32_t bits; bool operator<(const Key& o) const { return std::memcmp(this, &o, sizeof(Key)) < 0; } };
+    std::map<Key, bool> memo;
+    for (uint32_t v = 0; v < n; ++v) {
+      const WelshParams& o = Pext[v];
+      Key k{};
+      k.c0 = o.fc.c0; k.d1 = o.fc.d1; k.c2 = o.fc.c2; k.d3 = o.fc.d3; k.hz = o.cutoff_hz; k.start = o.cutoff_start; k.end = o.cutoff_end;
+      k.depth = (o.flags & WF_LFO_CUTOFF) ? o.lfo_depth : 0.0f; k.bits = o.flags & (WF_RETUNE_ENV | WF_LFO_CUTOFF | WF_LFO_RESO);
+      auto it = memo.find(k);
+      if (it == memo.end()) it = memo.emplace(k, welsh_filter_f32_ok(o, sr)).first;
+      if (it->second) Pext[v].flags |= WF_FILTER_F32;
+    }
+  }
   if (regroup) {
     b->perm.clear(); b->inv.clear();
     if (!runs_are_long(count_virtual_waves(Pext, n, [](uint32_t i) { return i; }), n)) {
@@ -558,10 +574,11 @@ int welsh_upload_params(groove_bank* b, bool regroup) {
     return (uint16_t)wg_kind_of(base, cl, spec ? c1 : (int)OSC_ANY, spec ? c2 : (int)OSC_ANY);
   };
   std::vector<uint16_t> kind; // per workgroup
+  std::vector<uint8_t> f32_of; // per workgroup: its waves' patches carry WF_FILTER_F32 (a workgroup is uniform in it too: sort key bit 0)
   {
-    std::vector<uint16_t> wave_kind(W.size());
+    std::vector<uint32_t> wave_kind(W.size()); // (kind << 1) | fp32-filter flag
     std::vector<uint32_t> order(W.size());
-    for (uint32_t w = 0; w < W.size(); ++w) { wave_kind[w] = kind_of_wave(W[w].p); order[w] = w; }
+    for (uint32_t w = 0; w < W.size(); ++w) { wave_kind[w] = ((uint32_t)kind_of_wave(W[w].p) << 1) | ((W[w].p.flags & WF_FILTER_F32) ? 1u : 0u); order[w] = w; }
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) { return wave_kind[a] < wave_kind[c]; });
     std::vector<WaveDesc> packed;
     packed.reserve(W.size() + (size_t)kWaves * 64);
@@ -569,7 +586,7 @@ int welsh_upload_params(groove_bank* b, bool regroup) {
       size_t e = i;
       while (e < order.size() && wave_kind[order[e]] == wave_kind[order[i]]) ++e;
       for (size_t j = i; j < e; ++j) {
-        if ((j - i) % kWaves == 0) kind.push_back(wave_kind[order[i]]);
+        if ((j - i) % kWaves == 0) { kind.push_back((uint16_t)(wave_kind[order[i]] >> 1)); f32_of.push_back((uint8_t)(wave_kind[order[i]] & 1u)); }
         packed.push_back(W[order[j]]);
       }
       while (packed.size() % kWaves) { // empty waves: no lane active, the first wave's voice as the shadow address
@@ -584,7 +601,7 @@ int welsh_upload_params(groove_bank* b, bool regroup) {
   b->n_vwaves = (uint32_t)W.size();
   const uint32_t wgs = b->n_vwaves / kWaves;
   std::vector<uint32_t> wg_list(wgs);
-  std::vector<uint8_t> wg_cls(wgs), wg_base(wgs);
+  std::vector<uint8_t> wg_cls(wgs), wg_base(wgs), wg_f32(wgs);
   {
     std::vector<uint32_t> at(kWgKinds + 1, 0);
     for (uint16_t k : kind) b->wgs_of_kind[k] += 1;
@@ -594,6 +611,7 @@ int welsh_upload_params(groove_bank* b, bool regroup) {
       wg_list[slot] = g;
       wg_cls[slot] = (uint8_t)(kind[g] % kClassCombos);
       wg_base[slot] = (uint8_t)(kind[g] / kClassCombos);
+      wg_f32[slot] = f32_of[g];
     }
   }
   if (b->vwaves_cap < W.size()) {
@@ -609,11 +627,14 @@ int welsh_upload_params(groove_bank* b, bool regroup) {
     GHIP(ctx, hipMalloc(&b->d_wg_cls, b->wg_list_cap));
     if (b->d_wg_base) GHIP(ctx, hipFree(b->d_wg_base));
     GHIP(ctx, hipMalloc(&b->d_wg_base, b->wg_list_cap));
+    if (b->d_wg_f32) GHIP(ctx, hipFree(b->d_wg_f32));
+    GHIP(ctx, hipMalloc(&b->d_wg_f32, b->wg_list_cap));
   }
   GHIP(ctx, ctx_memcpy(ctx, b->d_waves, W.data(), W.size() * sizeof(WaveDesc), hipMemcpyHostToDevice));
   GHIP(ctx, ctx_memcpy(ctx, b->d_wg_list, wg_list.data(), (size_t)wgs * sizeof(uint32_t), hipMemcpyHostToDevice));
   GHIP(ctx, ctx_memcpy(ctx, b->d_wg_cls, wg_cls.data(), wgs, hipMemcpyHostToDevice));
   GHIP(ctx, ctx_memcpy(ctx, b->d_wg_base, wg_base.data(), wgs, hipMemcpyHostToDevice));
+  GHIP(ctx, ctx_memcpy(ctx, b->d_wg_f32, wg_f32.data(), wgs, hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -1107,6 +1128,7 @@ static int init_impl(int device_ordinal, const uint8_t* comm_id, int rank, int w
   if (const char* e = std::getenv("GROOVE_FX_CHUNKED_ALLPASS")) ctx->chunked_allpass = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_TP_MAX_VOICES")) ctx->tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_SPLIT_ROLES")) { const int r = std::atoi(e); ctx->split_roles = r == 2 || r == 4 ? r : 3; }
+  if (const char* e = std::getenv("GROOVE_F32_FILTER")) ctx->f32_filter = e[0] != '0'; // (A/B and the bit-identity tests between kernel forms)
   if (const char* e = std::getenv("GROOVE_PIPELINE_MIN_WAVES")) ctx->pipeline_min_waves = (uint32_t)std::strtoul(e, nullptr, 10); // tests force the pipeline on small banks
   bool ok = hipSetDevice(device_ordinal) == hipSuccess;
   // groove_init_comm: the rank's RCCL communicator first, so that whatever streams RCCL creates for itself exist BEFORE
@@ -1433,7 +1455,7 @@ int groove_bank_destroy(groove_bank* b) {
   if (it != ctx->banks.end()) ctx->banks.erase(it);
   if (b->scratch) groove_block_destroy(b->scratch);
   for (int k = 0; k < 2; ++k) { if (b->h_ev[k]) (void)hipHostFree(b->h_ev[k]); if (b->ev_staged[k]) (void)hipEventDestroy(b->ev_staged[k]); }
-  (void)hipFree(b->d_params); (void)hipFree(b->d_state); (void)hipFree(b->d_cold); (void)hipFree(b->d_pcm); (void)hipFree(b->d_ev[0]); (void)hipFree(b->d_ev[1]); (void)hipFree(b->d_waves); (void)hipFree(b->d_wg_list); (void)hipFree(b->d_wg_cls); (void)hipFree(b->d_wg_base);
+  (void)hipFree(b->d_params); (void)hipFree(b->d_state); (void)hipFree(b->d_cold); (void)hipFree(b->d_pcm); (void)hipFree(b->d_ev[0]); (void)hipFree(b->d_ev[1]); (void)hipFree(b->d_waves); (void)hipFree(b->d_wg_list); (void)hipFree(b->d_wg_cls); (void)hipFree(b->d_wg_base); (void)hipFree(b->d_wg_f32);
   delete b;
   return 0;
 }
@@ -1519,7 +1541,7 @@ static uint32_t fused_rows(const groove_bank* b, uint32_t frames) {
 }
 // The one argument block of the wave-uniform Welsh kernels: workgroups [wg_off, wg_off + n_wgs) of the bank's kind-sorted list.
 static UniformArgs uniform_args(const groove_bank* b, float* out, float* rows, uint32_t wg_off, size_t chs, uint32_t frames, uint32_t n_wgs) {
-  UniformArgs a{b->d_waves, b->d_state, out, rows, b->d_wg_list + wg_off, b->d_wg_cls + wg_off, chs, render_consts(b->ctx->sr), b->n_vwaves, b->n, frames, n_wgs};
+  UniformArgs a{b->d_waves, b->d_state, out, rows, b->d_wg_list + wg_off, b->d_wg_cls + wg_off, b->d_wg_f32 + wg_off, chs, render_consts(b->ctx->sr), b->n_vwaves, b->n, frames, n_wgs};
   a.diag = b->ctx->d_diag;
 #ifdef GROOVE_HEARTBEAT
   a.heartbeat = b->ctx->hb;

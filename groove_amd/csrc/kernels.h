@@ -315,13 +315,31 @@ __device__ __forceinline__ void welsh_diag_zero(const DiagWhere& dw, const Welsh
 // a5 WelshVoice: Ticks::tick(frames) + Generates::generate_batch_values.
 // Frame 0 is peeled (first-tick flag); RETUNE=false variants keep the filter coefficients
 // loop-invariant so their f64 widening is hoisted out of the frame loop.
-template <bool FUSED, bool RETUNE, int LFO_MODE = LFO_F64, bool UNIFORM = false, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool REST = false>
+template <bool FUSED, bool RETUNE, int LFO_MODE = LFO_F64, bool UNIFORM = false, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool REST = false, bool F32OK = false>
 __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s, const RenderConsts& rc,
                                             uint32_t frames, uint32_t n, uint32_t v, bool active,
                                             size_t ch_stride, float* __restrict__ out, float* __restrict__ rows, uint32_t prow, const DiagWhere& dw = DiagWhere{nullptr, 0, 0, 0}) {
   WelshScratch sc = welsh_scratch_init(p, rc);
   // Static cutoff + wave-uniform patch: the six f64 coefficients are the same in every lane and
   // never change, so they ride in SGPRs (12 VGPRs back; f64 FMAs take one scalar operand).
+  if constexpr (UNIFORM && F32OK && LFO_MODE != LFO_F64) {
+    // F32OK: the copy of the block for workgroups whose patches carry WF_FILTER_F32 (the host builds workgroups that are uniform in
+    // it and lists them in UniformArgs::wg_f32) — the same segmented block with the filter's recurrence in fp32 (dsp_core.h "fp32
+    // recurrence"); the state goes back into the f64 fields of the record.  A function of its own per class triple, like the f64
+    // copies: both forms in ONE function (a scalar branch per block) spilled 100 - 150 bytes per lane in their hot loops and gave
+    // back two thirds of the gain (profiles/r05_f32_filter.log).
+    welsh_scratch_f32_begin(p, s, rc, sc);
+    if (!RETUNE) sc.coef_f = make_scalar(sc.coef_f);
+    run_frames_segmented<FUSED>(
+        frames, n, v, active, ch_stride, out, rows, prow,
+        [&](float& L, float& R) { welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL, false, REST, false, true>(p, s, rc, sc, L, R); },
+        [&](bool& live) { const uint32_t k = welsh_segment_begin(p, s, live); welsh_segment_start_hoisted(s, sc); return k; },
+        [&](float& L, float& R) { welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true, true>(p, s, rc, sc, L, R); },
+        [&](uint32_t seg, bool live) { welsh_segment_end_hoisted<CL == LFO_UNUSED>(p, s, seg, live); },
+        [&](uint32_t f, uint32_t mine) { welsh_diag_zero(dw, s, active, f, mine); });
+    welsh_scratch_f32_end(s, sc);
+    return;
+  }
   if (UNIFORM && !RETUNE) sc.coef = make_scalar(sc.coef);
   if constexpr (UNIFORM) {
     run_frames_segmented<FUSED>(
@@ -405,6 +423,7 @@ template <> struct WavesBudget<LFO_F64, true> { static constexpr int value = GRO
 // with scalar loads instead of taking a dozen uniform values through VGPR arguments).
 struct UniformArgs {
   const WaveDesc* waves; uint32_t* state; float* out; float* rows; const uint32_t* wg_list; const uint8_t* wg_cls;
+  const uint8_t* wg_f32; // per workgroup of the list: its patches carry WF_FILTER_F32 (read by the fused per-kind kernels only)
   size_t ch_stride; RenderConsts rc; uint32_t n_waves, n, frames, n_wgs; // out: the planar block (block-writing form); rows: partial[workgroup][ch][frame] (both forms)
   TpPrev prev; // groove_bank_render_mix_deferred: the previous block's rows, to be put on their bus by this launch (the all-kinds and role-split kernels)
   uint32_t* diag = nullptr; // the context's DiagCounters (diag.h)
@@ -417,7 +436,7 @@ __device__ __forceinline__ UniformArgsPtr uniform_args_scalar(UniformArgsPtr a) 
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bits >> 32));
   return (UniformArgsPtr)(((uint64_t)hi << 32) | lo);
 }
-template <bool FUSED, int LFO_MODE, bool RETUNE, int C1, int C2, int CL, bool REST = false>
+template <bool FUSED, int LFO_MODE, bool RETUNE, int C1, int C2, int CL, bool REST = false, bool F32OK = false>
 __device__ __forceinline__ void welsh_uniform_body_impl(UniformArgsPtr a) {
   const uint32_t wg = a->wg_list[GROOVE_WG_SLOT(a->n_wgs)]; // scalar load: the workgroup of virtual waves this block renders
   const uint32_t n_waves = a->n_waves, n = a->n;
@@ -432,7 +451,7 @@ __device__ __forceinline__ void welsh_uniform_body_impl(UniformArgsPtr a) {
   // pinned in VGPRs for the block: as literals / SGPRs each costs a v_mov on every retuning frame (the instructions
   // that use them take one constant-bus operand): +2.5 % in the all-voices window of the million-voice project
   if constexpr (RETUNE) asm volatile("" : "+v"(rc.tan_k1), "+v"(rc.tan_k2), "+v"(rc.log2_x0), "+v"(rc.x_hi));
-  welsh_block<FUSED, RETUNE, LFO_MODE, true, C1, C2, CL, REST>(d.p, s, rc, a->frames, n, v, active, a->ch_stride, a->out, a->rows, wg, DiagWhere{a->diag, wg, w, d.count});
+  welsh_block<FUSED, RETUNE, LFO_MODE, true, C1, C2, CL, REST, F32OK>(d.p, s, rc, a->frames, n, v, active, a->ch_stride, a->out, a->rows, wg, DiagWhere{a->diag, wg, w, d.count});
   if (active) soa_store(a->state, n, v, s);
 }
 // Internal linkage + no `tail` marker on the kernels' calls: the compiler's inter-procedural register allocation then
@@ -443,10 +462,10 @@ __device__ __forceinline__ void welsh_uniform_body_impl(UniformArgsPtr a) {
 // million-voice block of HBM traffic that served nothing (round 2's PMC passes).
 #define GROOVE_NO_TAIL_CALLS __attribute__((disable_tail_calls))
 #define GROOVE_BODY_LINKAGE static
-template <bool FUSED, int LFO_MODE, bool RETUNE, int C1, int C2, int CL>
+template <bool FUSED, int LFO_MODE, bool RETUNE, int C1, int C2, int CL, bool F32OK = false>
 GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_uniform_body(UniformArgsPtr a) {
   // the class bodies of the class-specialised kinds only ever see waves of their own classes (dsp_core.h, REST)
-  welsh_uniform_body_impl<FUSED, LFO_MODE, RETUNE, C1, C2, CL, LFO_MODE != LFO_F64>(uniform_args_scalar(a));
+  welsh_uniform_body_impl<FUSED, LFO_MODE, RETUNE, C1, C2, CL, LFO_MODE != LFO_F64, F32OK>(uniform_args_scalar(a));
 }
 // A workgroup whose voices are all silent with both envelopes idle (unused polyphony, voices past
 // their release) contributes zeros and changes nothing but idle-plateau counters: it writes its zero
@@ -476,9 +495,9 @@ __device__ __forceinline__ bool welsh_idle_workgroup(const UniformArgs& a) {
   return true;
 }
 // One scalar switch on the workgroup's class combination, to the block body compiled for it.
-template <bool FUSED, int LFO_MODE, bool RETUNE>
+template <bool FUSED, int LFO_MODE, bool RETUNE, bool F32OK = false>
 __device__ __forceinline__ void welsh_dispatch_class(uint32_t cls, UniformArgsPtr ka) {
-#define GROOVE_CLS_CASE(CL, C1, C2) case wg_class_combo(CL, C1, C2): welsh_uniform_body<FUSED, LFO_MODE, RETUNE, C1, C2, CL>(ka); break;
+#define GROOVE_CLS_CASE(CL, C1, C2) case wg_class_combo(CL, C1, C2): welsh_uniform_body<FUSED, LFO_MODE, RETUNE, C1, C2, CL, F32OK>(ka); break;
 #define GROOVE_CLS_ROW(CL, C1) GROOVE_CLS_CASE(CL, C1, 0) GROOVE_CLS_CASE(CL, C1, 1) GROOVE_CLS_CASE(CL, C1, 2) GROOVE_CLS_CASE(CL, C1, 3) GROOVE_CLS_CASE(CL, C1, 4)
 #define GROOVE_CLS_PLANE(CL) GROOVE_CLS_ROW(CL, 0) GROOVE_CLS_ROW(CL, 1) GROOVE_CLS_ROW(CL, 2) GROOVE_CLS_ROW(CL, 3) GROOVE_CLS_ROW(CL, 4)
   switch (cls) {
@@ -514,7 +533,15 @@ __global__ __launch_bounds__(kThreads, (WavesBudget<LFO_MODE, RETUNE>::value)) G
   if constexpr (!SPECIALISED) {
     welsh_uniform_body_impl<FUSED, LFO_MODE, RETUNE, OSC_ANY, OSC_ANY, OSC_ANY>(ka);
   } else {
-    welsh_dispatch_class<FUSED, LFO_MODE, RETUNE>((uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[GROOVE_WG_SLOT(a.n_wgs)]), ka);
+    // The FUSED per-kind kernels honour WF_FILTER_F32 (a second set of block bodies); the block-writing per-kind kernels and the
+    // all-kinds, role-split and time-parallel kernels keep the f64 filter for every voice.
+    const uint32_t cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[GROOVE_WG_SLOT(a.n_wgs)]);
+    if constexpr (FUSED && LFO_MODE != LFO_F64) {
+      if (__builtin_amdgcn_readfirstlane((int)a.wg_f32[GROOVE_WG_SLOT(a.n_wgs)])) welsh_dispatch_class<FUSED, LFO_MODE, RETUNE, true>(cls, ka);
+      else welsh_dispatch_class<FUSED, LFO_MODE, RETUNE, false>(cls, ka);
+    } else {
+      welsh_dispatch_class<FUSED, LFO_MODE, RETUNE, false>(cls, ka);
+    }
   }
   GROOVE_HB_DONE;
 #undef GROOVE_HB_DONE

@@ -4,6 +4,8 @@
 // DEVELOPMENT / TEST HARNESS ONLY.  It exists so the fp32/f64 arithmetic choices of the
 // device code can be checked against the f64 oracle in the GPU-less CI tier.  It is not
 // shipped, not linked into libgroove_hip.so, and the product never calls it.
+#define GROOVE_EMUL_F32_FILTER_HOOK 1
+namespace groove { int groove_emul_f32_filter = 0; } // 0: the product's f64 recurrence; 1 / 2: the fp32 forms of dsp_core.h's experiment hook
 #include "../../groove_amd/csrc/derive.h"
 #include "../../groove_amd/csrc/welsh_tp.h"
 #include <vector>
@@ -11,7 +13,7 @@
 using namespace groove;
 
 struct EmulBank {
-  int kind; uint32_t n; double sr; int generic_lfo = 0; int segmented = 1; int time_parallel = 0; int role_split = 0;
+  int kind; uint32_t n; double sr; int generic_lfo = 0; int segmented = 1; int time_parallel = 0; int role_split = 0; int f32_kind = 0;
   uint32_t min_seg = 0xFFFFFFFFu; // the smallest value welsh_segment_begin has returned for any voice of this bank (must stay >= 1)
   std::vector<WelshParams> wp; std::vector<WelshState> ws; std::vector<WelshCold> wc;
   std::vector<FmParams> fp; std::vector<FmState> fs; std::vector<double> ratio;
@@ -30,6 +32,13 @@ static void welsh_emul_frame(const WelshParams& p, WelshState& s, const RenderCo
   else { if (retune) welsh_emul_frame2<false, true>(p, s, rc, sc, mode, L, R); else welsh_emul_frame2<false, false>(p, s, rc, sc, mode, L, R); }
 }
 
+// the per-kind kernels' fp32-filter copy of the block (kernels.h welsh_block<..., F32OK>, WF_FILTER_F32 patches): frame 0 checked,
+// then hoisted segments, the filter's recurrence in fp32
+template <bool FIRST, bool RETUNE>
+static void welsh_emul_f32_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc, WelshScratch& sc, int mode, float& L, float& R) {
+  if (mode == LFO_F32) welsh_frame<FIRST, RETUNE, LFO_F32, OSC_ANY, OSC_ANY, OSC_ANY, !FIRST, false, !FIRST, true>(p, s, rc, sc, L, R);
+  else welsh_frame<FIRST, RETUNE, LFO_F64_SMOOTH, OSC_ANY, OSC_ANY, OSC_ANY, !FIRST, false, !FIRST, true>(p, s, rc, sc, L, R);
+}
 template <bool RETUNE>
 static void welsh_emul_segment_frame2(const WelshParams& p, WelshState& s, const RenderConsts& rc, WelshScratch& sc, int mode, float& L, float& R) {
   // the uniform kernels' form: boundary-free segment, envelope counters hoisted (welsh_frame<..., HOIST>)
@@ -214,6 +223,7 @@ static void welsh_tp_render_voice(const WelshParams& p, WelshState& state, const
 }
 
 extern "C" {
+void emul_set_f32_filter(int form) { groove::groove_emul_f32_filter = form; }
 // time_parallel != 0: Welsh voices render through the time-parallel form (blocks of up to 256 frames)
 void emul_set_time_parallel(void* h, int on);
 // segmented != 0 (default): frames after the first run in boundary-free segments, as in the uniform kernels
@@ -244,6 +254,19 @@ void* emul_sampler_create(const float* pcm, uint64_t frames, const groove_sample
 }
 void emul_bank_destroy(void* h) { delete (EmulBank*)h; }
 void emul_set_generic_lfo(void* h, int on) { ((EmulBank*)h)->generic_lfo = on; }
+// f32_kind != 0: what the per-kind kernels of big banks do — patches the host measures safe (derive.h welsh_filter_f32_ok ->
+// WF_FILTER_F32) run their filter's recurrence in fp32 (segmented form only).  Returns how many voices carry the flag.
+uint32_t emul_set_f32_kind(void* h, int on) {
+  EmulBank* b = (EmulBank*)h;
+  b->f32_kind = on;
+  uint32_t flagged = 0;
+  for (uint32_t v = 0; v < b->n && b->kind == 0; ++v) {
+    b->wp[v].flags &= ~WF_FILTER_F32;
+    if (on && welsh_filter_f32_ok(b->wp[v], b->sr)) { b->wp[v].flags |= WF_FILTER_F32; ++flagged; }
+  }
+  return flagged;
+}
+double emul_filter_f32_error(const groove_welsh_params* p, uint32_t sr) { WelshCold c; return welsh_filter_f32_error(derive_welsh(*p, (double)sr, c), (double)sr); }
 void emul_set_segmented(void* h, int on) { ((EmulBank*)h)->segmented = on; }
 void emul_set_time_parallel(void* h, int on) { ((EmulBank*)h)->time_parallel = on; }
 // role_split != 0: Welsh voices of the four class-specialised base kinds (no exact-f64 LFO) render role by role, as the
@@ -283,6 +306,8 @@ void emul_bank_render(void* h, uint32_t frames, float* out) {
     float sampler_buf[16] = {};
     uint32_t seg_left = 0, seg_len = 0; // segmented form (uniform kernels): frames left before the next boundary check
     bool seg_live = false;
+    const bool f32 = b->kind == 0 && b->f32_kind && b->segmented && mode != LFO_F64 && (b->wp[v].flags & WF_FILTER_F32);
+    if (f32) welsh_scratch_f32_begin(b->wp[v], b->ws[v], rc, sc);
     const bool split = b->kind == 0 && b->role_split && b->segmented && mode != LFO_F64; // (the exact-f64 kinds keep the all-kinds kernel)
     Lp24CoefD split_coef = sc.coef; // role C's coefficients: welsh_scratch_init's at the start of the block
     for (uint32_t f = 0; f < frames; ++f) {
@@ -313,8 +338,11 @@ void emul_bank_render(void* h, uint32_t frames, float* out) {
           welsh_segment_start_hoisted(b->ws[v], sc);
         }
         L = R = 0.0f;
-        if (seg_live) welsh_emul_segment_frame(b->wp[v], b->ws[v], rc, sc, retunes, mode, L, R);
+        if (seg_live && f32) { if (retunes) welsh_emul_f32_frame<false, true>(b->wp[v], b->ws[v], rc, sc, mode, L, R); else welsh_emul_f32_frame<false, false>(b->wp[v], b->ws[v], rc, sc, mode, L, R); }
+        else if (seg_live) welsh_emul_segment_frame(b->wp[v], b->ws[v], rc, sc, retunes, mode, L, R);
         if (--seg_left == 0) welsh_segment_end_hoisted<false>(b->wp[v], b->ws[v], seg_len, seg_live);
+      } else if (b->kind == 0 && f32) { // (frame 0 of the fp32-filter copy)
+        if (retunes) welsh_emul_f32_frame<true, true>(b->wp[v], b->ws[v], rc, sc, mode, L, R); else welsh_emul_f32_frame<true, false>(b->wp[v], b->ws[v], rc, sc, mode, L, R);
       } else if (b->kind == 0) { // mirrors the kernels' checked form: frame 0 peeled, RETUNE and the LFO mode chosen per voice
         welsh_emul_frame(b->wp[v], b->ws[v], rc, sc, f == 0, retunes, mode, L, R);
       } else if (b->kind == 1) {
@@ -326,6 +354,7 @@ void emul_bank_render(void* h, uint32_t frames, float* out) {
       out[(size_t)f * n + v] = L;
       out[((size_t)frames + f) * n + v] = R;
     }
+    if (f32) welsh_scratch_f32_end(b->ws[v], sc);
   }
 }
 uint32_t emul_bank_min_segment(void* h) { return ((EmulBank*)h)->min_seg; }

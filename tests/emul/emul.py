@@ -33,6 +33,9 @@ def lib():
         L.emul_sampler_create.argtypes = [_fp, C.c_uint64, C.POINTER(T.SampleDesc), u32, C.POINTER(T.SamplerParams), u32, u32]
         L.emul_bank_destroy.argtypes = [vp]
         L.emul_set_generic_lfo.argtypes = [vp, C.c_int]
+        L.emul_set_f32_filter.argtypes = [C.c_int]
+        L.emul_set_f32_kind.restype = u32; L.emul_set_f32_kind.argtypes = [vp, C.c_int]
+        L.emul_filter_f32_error.restype = C.c_double; L.emul_filter_f32_error.argtypes = [C.POINTER(T.WelshParams), u32]
         L.emul_set_segmented.argtypes = [vp, C.c_int]
         L.emul_set_time_parallel.argtypes = [vp, C.c_int]
         L.emul_set_role_split.argtypes = [vp, C.c_int]
@@ -85,6 +88,11 @@ class Bank:
     def set_role_split(self, on):
         """True: every frame role by role, with what the role-split kernel (welsh_split.h) passes between its wavefronts."""
         lib().emul_set_role_split(self.h, int(on))  # (4: the four-role form — front in two halves, coefficient quotients in role B)
+
+    def set_f32_kind(self, on):
+        """True: the per-kind kernels' arithmetic — patches measured safe by the host criterion (WF_FILTER_F32) filter in fp32.
+        Returns how many voices carry the flag."""
+        return lib().emul_set_f32_kind(self.h, 1 if on else 0)
 
     def set_generic_lfo(self, on):
         """True: exact per-frame f64 LFO (per-lane kernel); False: block-seeded recurrences where promised."""

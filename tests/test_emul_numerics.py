@@ -236,3 +236,60 @@ def test_a_torn_record_is_the_only_way_to_a_zero_frame_segment():
     assert E.segment_begin_of(p, amp=sus, fil=(ENV_SUSTAIN, 255, 0)) == 0                        # torn: new state and n, old N
     assert E.segment_begin_of(p, amp=sus, fil=(ENV_ATTACK, 255, PLATEAU_N)) >= 1                 # torn the other way: harmless
     assert E.segment_begin_of(p, amp=sus, fil=(ENV_IDLE, 0, 0)) == 0                             # reset's state word, the note-on's N
+
+
+def test_fp32_filter_kind_stays_within_the_bars(oracle):
+    """The arithmetic policy TESTED: patches whose 24 dB filter the host measures safe in fp32
+    (derive.h welsh_filter_f32_ok -> WF_FILTER_F32: the two recurrences side by side at the lowest, middle and highest cutoff the
+    patch can reach, <= 2e-6) run the fp32 recurrence in the fused per-kind kernels of big banks (dsp_core.h welsh_frame<..., F32FILT>,
+    mirrored here frame for frame).  Over the whole 172-block timeline of the 32 benchmark patches: 20 qualify — none of those
+    whose filter comes near z = +1 (40 - 90 Hz) or z = -1 (sweeps up to 20 kHz) — every flagged voice stays within 2e-6 RMS of the
+    f64 oracle, no voice is worse than the f64 form's worst, and the bus moves by 1e-8."""
+    import ctypes as C
+    n = 32
+    params = P.welsh_voices(n)
+    be = E.Bank.welsh(params)
+    flagged = be.set_f32_kind(True)
+    o, e = _render(oracle.Bank.welsh(params), be, P.note_on_all(n), P.note_off_all(n), 172, 86)
+    o64, e64 = _render(oracle.Bank.welsh(params), E.Bank.welsh(params), P.note_on_all(n), P.note_off_all(n), 172, 86)
+    per_voice = np.sqrt(np.mean((e - o) ** 2, axis=(0, 1)))
+    per_voice64 = np.sqrt(np.mean((e64 - o64) ** 2, axis=(0, 1)))
+    proxy = np.array([E.lib().emul_filter_f32_error(C.byref(params[j]), 44100) for j in range(n)])
+    is_f32 = proxy <= 2e-6
+    assert flagged == int(is_f32.sum()) == 20
+    assert not is_f32[0] and not is_f32[9] and not is_f32[12]          # 40 / 73 / 89 Hz: poles at z = +1
+    assert not is_f32[22] and not is_f32[31]                            # sweeps that reach 16 - 20 kHz: poles at z = -1
+    assert np.array_equal(per_voice[~is_f32], per_voice64[~is_f32])     # unflagged voices: the f64 form, bit for bit
+    assert (per_voice[is_f32] != per_voice64[is_f32]).all()             # flagged ones did take the other recurrence
+    assert per_voice[is_f32].max() <= 2e-6, per_voice[is_f32]
+    assert per_voice.max() <= max(per_voice64.max(), 2e-6) <= 1e-5
+    bus = np.sqrt(np.mean(((e - o).sum(axis=2) / n) ** 2))
+    assert bus <= 1e-6 and bus <= 2.0 * np.sqrt(np.mean(((e64 - o64).sum(axis=2) / n) ** 2)) + 1e-8
+    # the state a flagged voice leaves is fp32-exact in the record's f64 fields: every other kernel form can pick the voice up
+
+
+def test_fp32_filter_criterion_is_a_measurement_not_a_cutoff_rule():
+    """welsh_filter_f32_error: low cutoffs fail and so do sweeps that REACH them; how low depends on the ripple (at ripple 3.2 the
+    poles are real and 40 Hz passes, but 21 kHz fails: that filter's trouble is at z = -1); the static cutoff of a retuned patch does
+    not matter, its sweep does."""
+    import ctypes as C
+    L = E.lib()
+
+    def err(**kw):
+        p = P.welsh_patch(20)                      # static 10,961 Hz, ripple 1.61, no retune
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return L.emul_filter_f32_error(C.byref(p), 44100)
+
+    bar = 2e-6
+    assert err() <= 2e-7
+    lo = [err(filter_cutoff_hz=f) for f in (40.0, 80.0, 160.0, 320.0, 640.0, 1280.0)]
+    assert lo[0] > bar and lo[1] > bar and lo[-1] <= bar / 4 and max(lo[:2]) > 10 * lo[-1]  # falls with the cutoff (round-off noise: not monotonically)
+    for ripple in (0.707, 0.81, 1.61):
+        assert err(filter_passband_ripple=ripple, filter_cutoff_hz=40.0) > 5 * bar
+        assert err(filter_passband_ripple=ripple, filter_cutoff_hz=21000.0) <= bar
+    assert err(filter_passband_ripple=3.21, filter_cutoff_hz=40.0) <= bar                   # real poles: fine at z = +1 ...
+    assert err(filter_passband_ripple=3.21, filter_cutoff_hz=21000.0) > bar                 # ... not at z = -1
+    assert err(filter_cutoff_end=0.9, filter_cutoff_start=0.1) > 10 * bar                   # an envelope sweep from 49 Hz up
+    assert err(filter_cutoff_end=0.3, filter_cutoff_start=0.6) <= bar                       # 1.4 - 3.1 kHz
+    assert err(filter_cutoff_end=0.3, filter_cutoff_start=0.6, filter_cutoff_hz=40.0) <= bar   # (a retuned patch never uses its static cutoff)
