@@ -255,8 +255,14 @@ def dry_launch(world, rank):
     if rank == 0:
         # the real run's `sections`, as far as they exist without a GPU: every rank's voice range per section, and the number of
         # ranks that joined in the place of the communicator's size (`rccl_ranks`: ncclCommCount in the real run)
-        sections = {name: {"workload": plans[0][name]["workload"], "voices_total": plans[0][name]["voices_total"],
-                           "ranges": [pl[name]["range"] for pl in plans], "rccl_ranks": int(t.item())} for name in plans[0]}
+        # ... in the compact line's own shape and order (compact_line: the weak-scaling section first), the measured fields null
+        sections = {}
+        for name in ("weak", "strong", "mixed-131072"):
+            rng = [pl[name]["range"] for pl in plans]
+            sections[name] = {"scaling": "weak" if name == "weak" else "strong", "value": None, "ms_per_step": None,
+                              "voices_total": plans[0][name]["voices_total"], "voices_per_gpu": rng[0][1] - rng[0][0],
+                              "voice_frames_per_s": None, "rccl_ranks": int(t.item()), "rank_ms_min": None, "rank_ms_max": None,
+                              "bus_reduce_alone_ms": None, "workload": plans[0][name]["workload"], "ranges": rng}
         print(json.dumps({"dry_launch": True, "ranks": int(t.item()), "world": world, "voice_ranges": spans, "sections": sections}), flush=True)
     return 0 if int(t.item()) == world else 1
 

@@ -96,7 +96,11 @@ def test_bench_dry_launch_starts_two_ranks():
     assert line["voice_ranges"] == [[0, 500000], [500000, 1000000]]
     # the three measurements one `bench.py --gpus N` run makes (bench.py section_plan), with every rank in the communicator
     sec = line["sections"]
-    assert sorted(sec) == ["mixed-131072", "strong", "weak"]
+    assert list(sec) == ["weak", "strong", "mixed-131072"]     # the compact N > 1 line's order: the curve the design defends first
+    compact_keys = {"scaling", "value", "ms_per_step", "voices_total", "voices_per_gpu", "voice_frames_per_s", "rccl_ranks", "rank_ms_min",
+                    "rank_ms_max", "bus_reduce_alone_ms"}   # == bench.compact_line's section entries (tests/test_bench_line.py)
+    assert all(set(s) == compact_keys | {"workload", "ranges"} for s in sec.values())
+    assert sec["weak"]["scaling"] == "weak" and sec["strong"]["scaling"] == "strong" and sec["weak"]["voices_per_gpu"] == 1_000_000
     assert all(s["rccl_ranks"] == line["world"] for s in sec.values())
     assert sec["strong"]["voices_total"] == 1_000_000 and sec["strong"]["ranges"] == [[0, 500000], [500000, 1000000]]
     assert sec["weak"]["voices_total"] == 2_000_000 and sec["weak"]["ranges"] == [[0, 1000000], [1000000, 2000000]]
