@@ -1006,8 +1006,11 @@ struct TpMixedArgs {
   RenderConsts rc; uint32_t frames;
   TpPrev prev;
 };
+#ifndef GROOVE_MIXED_WAVES
+#define GROOVE_MIXED_WAVES 2
+#endif
 template <int WVPW, int FVPW>
-__global__ __launch_bounds__(kTpThreads, WVPW == 1 ? GROOVE_TP_WAVES : 2) void tp_mixed_kernel(TpMixedArgs m, InlineEvents ie) {
+__global__ __launch_bounds__(kTpThreads, WVPW == 1 ? GROOVE_TP_WAVES : GROOVE_MIXED_WAVES) void tp_mixed_kernel(TpMixedArgs m, InlineEvents ie) {
   union Smem { WelshTpSmem<WVPW> w; FmTpSmem<FVPW> f; SamplerTpSmem<kTpWaves> s; };
   __shared__ Smem sm;
   const uint32_t i = blockIdx.x;
