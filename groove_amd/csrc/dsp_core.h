@@ -272,15 +272,26 @@ GROOVE_HD void env_boundary(EnvState& s, const EnvParams& p) {
     }
   }
 }
+// The stage's shape A + D (2t - t^2), t = n / len, as a polynomial in the frame counter: n (c1 - c2 n) + A with c1 = 2 D / len,
+// c2 = D / len^2.  Every form evaluates THESE operations in THIS order (the hoisted frames of the uniform kernels keep c1 and c2 for
+// a segment — welsh_segment_start_hoisted — and pay two operations per envelope and frame instead of four), so the forms stay
+// bit-identical; no accumulation, within an ulp or two of the factored form (round 5; the oracle is f64 and does not care).
+GROOVE_HD void env_shape_consts(float D, float inv_len, float& c1, float& c2) {
+  const float di = D * inv_len;
+  c1 = di + di; c2 = di * inv_len;
+}
+GROOVE_HD float env_shape(float n, float A, float c1, float c2) { return fmaf(n, fmaf(-c2, n, c1), A); }
 GROOVE_HD void env_advance(EnvState& s) {
-  const float t = (float)s.n * s.inv_len;
-  s.value = fmaf(s.D, fmaf(-t, t, 2.0f * t), s.A);
+  float c1, c2;
+  env_shape_consts(s.D, s.inv_len, c1, c2);
+  s.value = env_shape((float)s.n, s.A, c1, c2);
   s.n += 1;
 }
 // value of the most recent tick (the stage counter has already moved past it)
 GROOVE_HD float env_last_value_of(const EnvState& s) {
-  const float t = (float)(s.n - 1u) * s.inv_len;
-  return fmaf(s.D, fmaf(-t, t, 2.0f * t), s.A);
+  float c1, c2;
+  env_shape_consts(s.D, s.inv_len, c1, c2);
+  return env_shape((float)(s.n - 1u), s.A, c1, c2);
 }
 GROOVE_HD void env_tick(EnvState& s, const EnvParams& p) {
   env_boundary(s, p);
@@ -590,7 +601,45 @@ GROOVE_HD Lp24CoefF lp24_coeff_from_pct(const Lp24Consts& c, float pct, const Re
   const float t = lp24_t_from_pct(pct, rc, hi);
   return lp24_coeff_from_t(c, t, hi);
 }
+// SCALAR_COEF: the coefficients are wave-uniform values the caller keeps in SGPRs (device only; static kinds).
+template <bool SCALAR_COEF = false>
 GROOVE_HD float lp24_step_f32(Lp24StateF& s, const Lp24CoefF& c, float x) { // lp24_step's ten operations
+#if defined(__HIP_DEVICE_COMPILE__)
+  // Written out for the same reason as the f64 step: left to itself the compiler picks the two-operand v_fmac_f32 for the state
+  // updates and copies the four loop-carried state values (and two temporaries) back with six v_mov_b32 every frame — 6 of 16
+  // instructions.  Three-operand v_fma_f32 updates each state value in place.  Same operations, same order, same roundings as the C.
+  float bx, y1, t, by, y2, u;
+  if constexpr (SCALAR_COEF) {
+    asm("v_mul_f32 %[bx], %[b0a], %[x]\n\t"
+        "v_add_f32 %[y1], %[bx], %[s0]\n\t"
+        "v_fma_f32 %[t], %[bx], 2.0, %[s1]\n\t"
+        "v_fma_f32 %[s0], %[a1a], %[y1], %[t]\n\t"
+        "v_fma_f32 %[s1], %[a2a], %[y1], %[bx]\n\t"
+        "v_mul_f32 %[by], %[b0b], %[y1]\n\t"
+        "v_add_f32 %[y2], %[by], %[s2]\n\t"
+        "v_fma_f32 %[u], %[by], 2.0, %[s3]\n\t"
+        "v_fma_f32 %[s2], %[a1b], %[y2], %[u]\n\t"
+        "v_fma_f32 %[s3], %[a2b], %[y2], %[by]"
+        : [s0] "+v"(s.s0), [s1] "+v"(s.s1), [s2] "+v"(s.s2), [s3] "+v"(s.s3), [bx] "=&v"(bx), [y1] "=&v"(y1), [t] "=&v"(t),
+          [by] "=&v"(by), [y2] "=&v"(y2), [u] "=&v"(u)
+        : [x] "v"(x), [b0a] "s"(c.b0a), [a1a] "s"(c.a1a), [a2a] "s"(c.a2a), [b0b] "s"(c.b0b), [a1b] "s"(c.a1b), [a2b] "s"(c.a2b));
+  } else {
+    asm("v_mul_f32 %[bx], %[b0a], %[x]\n\t"
+        "v_add_f32 %[y1], %[bx], %[s0]\n\t"
+        "v_fma_f32 %[t], %[bx], 2.0, %[s1]\n\t"
+        "v_fma_f32 %[s0], %[a1a], %[y1], %[t]\n\t"
+        "v_fma_f32 %[s1], %[a2a], %[y1], %[bx]\n\t"
+        "v_mul_f32 %[by], %[b0b], %[y1]\n\t"
+        "v_add_f32 %[y2], %[by], %[s2]\n\t"
+        "v_fma_f32 %[u], %[by], 2.0, %[s3]\n\t"
+        "v_fma_f32 %[s2], %[a1b], %[y2], %[u]\n\t"
+        "v_fma_f32 %[s3], %[a2b], %[y2], %[by]"
+        : [s0] "+v"(s.s0), [s1] "+v"(s.s1), [s2] "+v"(s.s2), [s3] "+v"(s.s3), [bx] "=&v"(bx), [y1] "=&v"(y1), [t] "=&v"(t),
+          [by] "=&v"(by), [y2] "=&v"(y2), [u] "=&v"(u)
+        : [x] "v"(x), [b0a] "v"(c.b0a), [a1a] "v"(c.a1a), [a2a] "v"(c.a2a), [b0b] "v"(c.b0b), [a1b] "v"(c.a1b), [a2b] "v"(c.a2b));
+  }
+  return y2;
+#else
   const float bx = c.b0a * x;
   const float y1 = bx + s.s0;
   s.s0 = fmaf(c.a1a, y1, fmaf(2.0f, bx, s.s1));
@@ -600,6 +649,7 @@ GROOVE_HD float lp24_step_f32(Lp24StateF& s, const Lp24CoefF& c, float x) { // l
   s.s2 = fmaf(c.a1b, y2, fmaf(2.0f, by, s.s3));
   s.s3 = fmaf(c.a2b, y2, by);
   return y2;
+#endif
 }
 // ------------------------------------------------------------------ WelshVoice (a5)
 // Packed per-voice flags word.
@@ -662,6 +712,7 @@ struct WelshScratch {
   double ls, lc;   // LFO_F64_SMOOTH: LFO value of the previous frame (sine: sin), and cos of the sine LFO's angle
   double lm;       // LFO_F64_SMOOTH, pitch routing: 2^(ls * depth)
   float ta, tf;    // HOIST: the two envelopes' stage counters as floats, for the frames of one segment
+  float ac1, ac2, fc1, fc2; // HOIST: 2 D / len and D / len^2 of the two envelopes' current stages (value = n (c1 - c2 n) + A)
 };
 GROOVE_HD bool welsh_retunes(const WelshParams& p) {
   return (p.flags & (WF_RETUNE_ENV | WF_LFO_CUTOFF | WF_LFO_RESO)) != 0;
@@ -762,9 +813,9 @@ template <bool FIRST, bool RETUNE, int LFO_MODE = LFO_F64, int C1 = OSC_ANY, int
 GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScratch& sc, float& sum, float& a, float& pct, bool& retune, float& lfo) {
   static_assert(!HOIST || (SEGMENT && !FIRST), "hoisted counters belong to a segment");
   if (SEGMENT && HOIST) {
-    const float ta = sc.ta * s.amp.inv_len, tf = sc.tf * s.fil.inv_len;
-    s.amp.value = fmaf(s.amp.D, fmaf(-ta, ta, 2.0f * ta), s.amp.A);
-    s.fil.value = fmaf(s.fil.D, fmaf(-tf, tf, 2.0f * tf), s.fil.A);
+    // env_shape with the segment's constants (welsh_segment_start_hoisted): two operations per envelope and frame
+    s.amp.value = env_shape(sc.ta, s.amp.A, sc.ac1, sc.ac2);
+    s.fil.value = env_shape(sc.tf, s.fil.A, sc.fc1, sc.fc2);
     sc.ta += 1.0f; sc.tf += 1.0f;
   } else if (SEGMENT) {
     env_advance(s.amp);
@@ -836,7 +887,7 @@ GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScrat
   bool wrapped = false;
   if (!first) {
     const uint64_t np = s.o1.phase + inc1;
-    wrapped = np < s.o1.phase;
+    wrapped = np < inc1; // carry out of the add (== np < the old phase): compared with the increment, so that the add is in place
     s.o1.phase = np;
   }
   float nz1 = 0.0f, nz2 = 0.0f;
@@ -887,9 +938,9 @@ GROOVE_HD bool welsh_frame_ctl(const WelshParams& p, WelshState& s, WelshScratch
   static_assert(LFO_MODE != LFO_F64, "the exact-f64 kinds keep the whole frame on one wavefront");
   static_assert(!HOIST || (SEGMENT && !FIRST), "hoisted counters belong to a segment");
   if (SEGMENT && HOIST) {
-    const float ta = sc.ta * s.amp.inv_len, tf = sc.tf * s.fil.inv_len;
-    s.amp.value = fmaf(s.amp.D, fmaf(-ta, ta, 2.0f * ta), s.amp.A);
-    s.fil.value = fmaf(s.fil.D, fmaf(-tf, tf, 2.0f * tf), s.fil.A);
+    // env_shape with the segment's constants (welsh_segment_start_hoisted): two operations per envelope and frame
+    s.amp.value = env_shape(sc.ta, s.amp.A, sc.ac1, sc.ac2);
+    s.fil.value = env_shape(sc.tf, s.fil.A, sc.fc1, sc.fc2);
     sc.ta += 1.0f; sc.tf += 1.0f;
   } else if (SEGMENT) {
     env_advance(s.amp);
@@ -973,7 +1024,7 @@ GROOVE_HD float welsh_frame_osc(const WelshParams& p, WelshState& s, bool edge, 
   bool wrapped = false;
   if (!first) {
     const uint64_t np = s.o1.phase + inc1;
-    wrapped = np < s.o1.phase;
+    wrapped = np < inc1; // carry out of the add (== np < the old phase): compared with the increment, so that the add is in place
     s.o1.phase = np;
   }
   float nz1 = 0.0f, nz2 = 0.0f;
@@ -1030,7 +1081,7 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
   if (!welsh_frame_front<FIRST, RETUNE, LFO_MODE, C1, C2, CL, SEGMENT, REST, HOIST>(p, s, sc, sum, a, pct, retune, lfo)) { L = 0.0f; R = 0.0f; return; }
   if constexpr (F32FILT) { // sc.coef_f / sc.filt_f were set by welsh_scratch_f32_begin; the caller hands the state back with welsh_scratch_f32_end
     if (RETUNE && retune && pct != sc.prev_pct) { sc.coef_f = lp24_coeff_from_pct(p.fc, pct, rc); sc.prev_pct = pct; }
-    const float m = lp24_step_f32(sc.filt_f, sc.coef_f, sum) * a;
+    const float m = lp24_step_f32<SEGMENT && !RETUNE>(sc.filt_f, sc.coef_f, sum) * a; // uniform static kinds: coefficients in SGPRs
     L = m * p.gl; R = m * p.gr;
   } else {
     welsh_frame_coef<RETUNE, LFO_MODE, CL>(p, rc, sc, pct, retune, lfo);
@@ -1068,6 +1119,8 @@ GROOVE_HD void welsh_segment_idle_frame(WelshState& s) {
 // their envelope VALUES set by their frames; an idle voice's are what its last tick would have produced.
 GROOVE_HD void welsh_segment_start_hoisted(const WelshState& s, WelshScratch& sc) {
   sc.ta = (float)s.amp.n; sc.tf = (float)s.fil.n;
+  env_shape_consts(s.amp.D, s.amp.inv_len, sc.ac1, sc.ac2);
+  env_shape_consts(s.fil.D, s.fil.inv_len, sc.fc1, sc.fc2);
 }
 template <bool LFO_TOO>
 GROOVE_HD void welsh_segment_end_hoisted(const WelshParams& p, WelshState& s, uint32_t seg, bool live) {
