@@ -253,7 +253,7 @@ def test_parity_sample_is_forced_to_the_timed_kernel_form():
         time_parallel_max_voices = 16384
         time_parallel_pair_min_voices = 3073
         split_max_waves = 1024
-        pipeline_min_waves = 8600
+        pipeline_min_waves = 7000
 
     def forced(workload, v):
         t = bench.timed_kernel_form(Ctx(), workload, v)
