@@ -316,8 +316,38 @@ uint32_t Orchestrator::fanout(Uid uid) {
   }
   return uid < fanout_.size() ? fanout_[uid] : 0;
 }
+bool Orchestrator::direct_banks(std::vector<groove_bank*>& direct, std::vector<Uid>& rest) {
+  direct.clear(); rest.clear();
+  if (!fused_direct_ || ahead_eval_) return false; // (render-ahead walk: the instruments already hold their blocks)
+  for (Uid s : nodes_[kMainMixerUid].sources) {
+    Entity* e = nodes_[s].entity.get();
+    groove_bank* b = (e && e->is_instrument() && fanout(s) == 1) ? static_cast<Instrument*>(e)->fused_bank() : nullptr;
+    if (b && std::find(direct.begin(), direct.end(), b) == direct.end()) direct.push_back(b); else rest.push_back(s);
+  }
+  return !direct.empty();
+}
 int Orchestrator::gather_audio(uint32_t frames) {
   if (frames > bus_frames_) return fail("gather_audio: frames > block size");
+  // Fast path: the main mixer is the identity, its output is the sum of its sources' lanes — so a bank
+  // patched straight into it contributes its voices' sum and nothing else needs its block.  Everything else the mixer hears is
+  // evaluated as before and summed onto the bus first; the direct banks then render fused onto it (one launch for several small
+  // ones).  gather_audio's one sum over all sources, orchestrator.rs:397-410, in another order of additions.
+  std::vector<groove_bank*> direct;
+  std::vector<Uid> rest;
+  if (direct_banks(direct, rest)) {
+    int acc = 0;
+    for (Uid u : rest) {
+      groove_block* sb = nullptr;
+      uint32_t sl = 0;
+      if (eval(u, frames, &sb, &sl)) return 1;
+      if (!sb) continue;
+      groove_block* one[1] = {sb};
+      if (groove_mix(ctx_, one, 1, frames, bus_, acc)) return fail(groove_last_error(ctx_));
+      acc = 1;
+    }
+    if (groove_banks_render_mix_deferred(ctx_, direct.data(), (uint32_t)direct.size(), frames, bus_, acc)) return fail(groove_last_error(ctx_));
+    return 0;
+  }
   groove_block* b = nullptr;
   uint32_t lanes = 0;
   if (eval(kMainMixerUid, frames, &b, &lanes)) return 1;
@@ -416,6 +446,11 @@ int Orchestrator::tick_ahead(StereoSample* out, uint32_t frames, uint32_t* ticks
 }
 int Orchestrator::tick_offline(StereoSample* out, uint32_t frames, uint32_t* ticks_completed) {
   std::vector<Instrument*> instruments;
+  {
+    std::vector<groove_bank*> direct;
+    std::vector<Uid> rest;
+    if (direct_banks(direct, rest) && rest.empty()) return tick(out, frames, ticks_completed); // nothing but fused banks: nothing to render ahead of
+  }
   if (render_ahead_ && performing_ && ahead_instruments(instruments)) return tick_ahead(out, frames, ticks_completed, instruments);
   return tick(out, frames, ticks_completed);
 }
@@ -575,6 +610,7 @@ int gh_patch_chain_to_main_mixer(void* h, const int* uids, uint32_t n) {
 }
 void gh_unpatch_all(void* h) { ((Orchestrator*)h)->unpatch_all(); }
 void gh_set_render_ahead(void* h, int mode) { ((Orchestrator*)h)->set_render_ahead(mode); }
+void gh_set_fused_direct(void* h, int on) { ((Orchestrator*)h)->set_fused_direct(on != 0); }
 int gh_connect_midi_downstream(void* h, int uid, int channel) { return ((Orchestrator*)h)->connect_midi_downstream((Uid)uid, (uint8_t)channel); }
 int gh_add_timer(void* h, double beats) { return (int)((Orchestrator*)h)->add(std::unique_ptr<Entity>(new Timer(beats))); }
 int gh_add_sequencer(void* h) { return (int)((Orchestrator*)h)->add(std::unique_ptr<Entity>(new Sequencer())); }

@@ -86,6 +86,10 @@ class Instrument : public Entity {
   virtual bool render_ahead_pays() const { return true; }
   virtual int render_ahead(uint32_t frames) { (void)frames; return 0; }
   virtual int finish(uint32_t frames) { return tick(frames); }
+  // The library bank behind the instrument, if all it does is render that bank: patched STRAIGHT into the main mixer and heard by
+  // nothing else, such an instrument needs no voice block at all — the orchestrator renders it fused onto the bus
+  // (Orchestrator::gather_audio's fast path).
+  virtual groove_bank* fused_bank() { return nullptr; }
 };
 
 // IsEffect: TransformsAudio.
@@ -131,6 +135,7 @@ class VoiceBankInstrument : public Instrument {
   void note_on(uint8_t key, uint8_t velocity, uint64_t now_frame) override;
   void note_off(uint8_t key, uint8_t velocity, uint64_t now_frame) override;
   groove_bank* bank() { return bank_; }
+  groove_bank* fused_bank() override { return bank_; }
   uint32_t last_allocated_voice() const { return last_voice_; }
  private:
   groove_ctx* ctx_;
@@ -272,6 +277,10 @@ class Orchestrator {
   // graph of block b runs (same samples; DESIGN.md "Render-ahead").  On by default; off = block by block.
   // 0 = block by block, 1 = where it pays (default), 2 = whenever the graph allows it (tests).
   void set_render_ahead(int mode) { render_ahead_ = mode; }
+  // Instruments patched straight into the main mixer (and heard by nothing else) render FUSED onto the bus — no voice block, one
+  // launch for all of them when they are small (groove_banks_render_mix_deferred) — instead of block by block through the mixer's
+  // accumulator.  Same sum to fp32 rounding.  On by default; off = the entity-boundary walk for every source (tests, A/B).
+  void set_fused_direct(bool on) { fused_direct_ = on; }
   // ControlTrip -> effect parameter.  While the controllers are run one block ahead of the effects
   // the update is held back until the effects have processed the current block.
   int control_effect(Uid target, uint32_t index, double value01);
@@ -297,6 +306,8 @@ class Orchestrator {
   void sequence_block(uint64_t at_frame, uint32_t frames);
   // the instruments the main mixer hears, if every one of them is heard exactly once and can render ahead
   bool ahead_instruments(std::vector<Instrument*>& out);
+  // the main mixer's sources split into banks that can render fused onto the bus and the rest (chains, toy sources, shared instruments)
+  bool direct_banks(std::vector<groove_bank*>& direct, std::vector<Uid>& rest);
   int tick_ahead(StereoSample* out, uint32_t frames, uint32_t* ticks_completed, const std::vector<Instrument*>& instruments);
   int tick_offline(StereoSample* out, uint32_t frames, uint32_t* ticks_completed);
 
@@ -313,6 +324,7 @@ class Orchestrator {
   uint64_t frames_ = 0;
   bool performing_ = false;
   int render_ahead_ = 1;
+  bool fused_direct_ = true;
   bool ahead_primed_ = false;   // the current block's instruments were rendered by the previous tick_ahead
   bool ahead_eval_ = false;     // eval(): instruments already hold their block
   bool deferring_ = false;      // controllers are being run for the NEXT block

@@ -26,7 +26,7 @@ def load():
         "gh_add_drumkit": (i, [vp, _fp, C.c_uint64, C.POINTER(T.SampleDesc), u32, C.POINTER(C.c_int)]),
         "gh_add_effect": (i, [vp, u32, C.POINTER(T.FxParams)]),
         "gh_patch": (i, [vp, i, i]), "gh_patch_chain_to_main_mixer": (i, [vp, C.POINTER(C.c_int), u32]),
-        "gh_unpatch_all": (None, [vp]), "gh_set_render_ahead": (None, [vp, i]), "gh_connect_midi_downstream": (i, [vp, i, i]),
+        "gh_unpatch_all": (None, [vp]), "gh_set_render_ahead": (None, [vp, i]), "gh_set_fused_direct": (None, [vp, i]), "gh_connect_midi_downstream": (i, [vp, i, i]),
         "gh_add_timer": (i, [vp, d]), "gh_add_sequencer": (i, [vp]),
         "gh_sequencer_insert": (i, [vp, i, i, i, d, d]), "gh_sequencer_set_end": (i, [vp, i, d]),
         "gh_add_control_trip": (i, [vp, i, C.c_char_p, d]), "gh_control_trip_add_step": (i, [vp, i, i, d, d, d]),
@@ -83,6 +83,10 @@ class Orchestrator:
         return self.L.gh_patch_chain_to_main_mixer(self.h, arr, len(uids))
 
     def unpatch_all(self): self.L.gh_unpatch_all(self.h)
+    def set_fused_direct(self, on):
+        """Instruments patched straight into the main mixer render fused onto the bus (default) or through their blocks."""
+        self.L.gh_set_fused_direct(self.h, 1 if on else 0)
+
     def set_render_ahead(self, on):
         """Offline runs: False = block by block, True = instruments one block ahead of the effects whenever the graph allows
         (the default, "auto", does so only for instruments whose render is long enough to be worth the hand-over)."""

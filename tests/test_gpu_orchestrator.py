@@ -395,3 +395,46 @@ def test_render_ahead_run_is_identical_to_block_by_block(buffer_frames, performa
     assert len(outs[0]) == len(outs[1]) > 0
     assert np.sqrt(np.mean(outs[0].astype(np.float64) ** 2)) > 1e-3
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_instruments_patched_straight_into_the_main_mixer_render_fused(oracle):
+    """Orchestrator::gather_audio's fast path (INTEGRATION.md section 3): a drumkit, a Welsh synth and an FM synth patched STRAIGHT
+    into the main mixer need no voice blocks — their banks render fused onto the bus, in one launch (groove_banks_render_mix_deferred) —
+    while a second Welsh synth behind a Gain goes the entity-boundary way and a toy source is summed as before.  The same sequenced
+    performance (block 64 and block 256, whole run) with the fast path off is the reference walk: same sum to fp32 rounding."""
+    from groove_amd.host_binding import Orchestrator, synthetic_kit
+    pcm, descs, k2s = synthetic_kit()
+    outs = {}
+    for fused in (True, False):
+        for block in (64, 256):
+            o = Orchestrator(0)
+            try:
+                o.set_fused_direct(fused)
+                kit = o.add_drumkit(pcm, descs, k2s)
+                w1 = o.add_welsh(P.welsh_patch(5), voices=6)
+                fm = o.add_fm(P.fm_patch(3), voices=4)
+                w2 = o.add_welsh(P.welsh_patch(11), voices=4)
+                gain = o.add_effect(T.FX_GAIN, T.fx_params(ceiling=0.5))
+                toy = o.add_toy_source(0.05)
+                for u in (kit, w1, fm, toy):
+                    assert o.patch(u, o.MAIN_MIXER) == 0
+                assert o.patch_chain_to_main_mixer([w2, gain]) == 0
+                for ch, u in enumerate((kit, w1, fm, w2)):
+                    o.connect_midi_downstream(u, ch)
+                seq = o.add_sequencer()
+                for i in range(12):                                   # drums on every half beat
+                    o.sequencer_insert(seq, 0, [35, 38, 42, 46][i % 4], 0.5 * i, 0.25)
+                for k, s, d in ((60, 0.0, 1.5), (64, 0.5, 1.0), (67, 1.0, 2.0), (72, 2.5, 0.5), (55, 3.0, 2.0)):
+                    o.sequencer_insert(seq, 1, k, s, d)
+                    o.sequencer_insert(seq, 2, k + 12, s + 0.25, d)
+                    o.sequencer_insert(seq, 3, k - 12, s + 0.125, d * 0.5)
+                o.sequencer_set_end(seq, 6.0)
+                outs[(fused, block)] = o.run(block).astype(np.float64)
+            finally:
+                o.close()
+    for block in (64, 256):                                          # (events are block-granular: every block size is its own performance)
+        want, got = outs[(False, block)], outs[(True, block)]
+        assert len(want) == len(got) == math.ceil(6.0 * 60 / 128 * 44100) and np.sqrt(np.mean(want ** 2)) > 0.05
+        scale = np.abs(want).max()
+        assert np.abs(got - want).max() <= 2e-6 * scale, (block, np.abs(got - want).max(), scale)
+        assert not np.array_equal(got, want)                         # (the fast path did run: another order of additions)
