@@ -26,9 +26,13 @@ def main():
     ctx.sync_timeout_ms = 30000
     out = {}
     bad = False
-    for workload in ("welsh-1m", "chain-4096", "mixed-131072", "sampler-16384", "welsh-256"):
-        V = PJ.WORKLOADS[workload]["voices"]
-        proj = PJ.Project(ctx, workload, np.arange(V, dtype=np.int64))
+    # (label, workload, voices, Project options): the five bench workloads, config #5's share of one of eight GPUs in ONE launch per
+    # block (groove_banks_render_mix_deferred) and with its banks in turn (three row counts sharing the deferred row buffers)
+    for label, workload, V, opts in (("welsh-1m", "welsh-1m", 0, {}), ("chain-4096", "chain-4096", 0, {}), ("mixed-131072", "mixed-131072", 0, {}),
+                                     ("sampler-16384", "sampler-16384", 0, {}), ("welsh-256", "welsh-256", 0, {}),
+                                     ("mixed-16384 one launch", "mixed-131072", 16384, {}), ("mixed-16384 banks in turn", "mixed-131072", 16384, {"one_launch": False})):
+        V = V or PJ.WORKLOADS[workload]["voices"]
+        proj = PJ.Project(ctx, workload, np.arange(V, dtype=np.int64), **opts)
         bus = ctx.bus(args.blocks * PJ.FRAMES)
         crcs = collections.Counter()
         t0 = time.perf_counter()
@@ -41,7 +45,7 @@ def main():
             crcs[zlib.crc32(bus.download().tobytes())] += 1
             reps += 1
         proj.destroy(); bus.destroy()
-        out[workload] = {"repeats": reps, "distinct_bus_crcs": len(crcs), "crc": [f"{k:08x}" for k in crcs]}
+        out[label] = {"repeats": reps, "distinct_bus_crcs": len(crcs), "crc": [f"{k:08x}" for k in crcs]}
         bad = bad or len(crcs) != 1
     ctx.synchronize()
     out["zero_segments"] = ctx.debug_info()["zero_segments"]
