@@ -850,14 +850,11 @@ def roofline_block(workload, n_local, kern_ms, span_mode, fused, window=None):
         if mb and wl["kind"] == "welsh" and WORKLOADS[workload]["voices"] >= 500_000:
             # The issue bound of THIS instruction stream, measured (tools/micro/mix_bound.hip: the window's class mix issued as
             # independent chains at the render kernels' occupancies): the time below which no schedule of the step's VALU
-            # instructions can finish, and the step's duration against it.  Each kernel's instructions are priced at ITS
-            # occupancy (LFO_F32 kinds 5 waves per SIMD, LFO_F64_SMOOTH kinds 4: kernels.h WavesBudget; the committed SQ pass
-            # has the per-kernel counts).  A separate, labelled field: `valu.achieved_frac` stays on the spec issue rate.
+            # instructions can finish, and the step's duration against it, priced at the render kernels' occupancy (five waves per
+            # SIMD: kernels.h WavesBudget).  A separate, labelled field: `valu.achieved_frac` stays on the spec issue rate.
+            # (since round 5 all four class-specialised per-kind kernels are budgeted for FIVE waves per SIMD — kernels.h WavesBudget; until
+            # then the two LFO_F64_SMOOTH kernels ran at four and their share of the step's instructions was priced at that rate)
             share4 = 0.0
-            byk = prof.get("valu_by_kernel") or {}
-            if byk:
-                tot = sum(byk.values())
-                share4 = sum(v for k, v in byk.items() if "welsh_render_uniform_kernel<true, 2," in k or "welsh_render_uniform_kernel<false, 2," in k) / tot if tot else 0.0
             ns = mb["ns_at_5_waves"] * (1.0 - share4) + mb["ns_at_4_waves"] * share4
             bound_ms = wi * ns * 1e-9 / 1024.0 * 1e3
             fmb = bound_ms / kern_ms

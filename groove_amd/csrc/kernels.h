@@ -57,10 +57,12 @@ __device__ __forceinline__ void soa_store(uint32_t* __restrict__ buf, uint32_t n
 #define GROOVE_WAVES_F32_RETUNE 5
 #endif
 #ifndef GROOVE_WAVES_SMOOTH_STATIC
-#define GROOVE_WAVES_SMOOTH_STATIC 4
+#define GROOVE_WAVES_SMOOTH_STATIC 5 /* round 5: 5 (102 VGPRs) instead of 4 for both smooth-f64 kinds — after the polynomial envelopes and the in-place phase
+                                        add their bodies fit: the driver's window 0.4395 -> 0.4329 ms per block (median of five, in-job, profiles/r05_budgets_ab.log);
+                                        the fp32-LFO kinds at 6 lose (0.4555 against 0.4439) */
 #endif
 #ifndef GROOVE_WAVES_SMOOTH_RETUNE
-#define GROOVE_WAVES_SMOOTH_RETUNE 4
+#define GROOVE_WAVES_SMOOTH_RETUNE 5
 #endif
 #ifndef GROOVE_WAVES_F64
 #define GROOVE_WAVES_F64 2

@@ -8,7 +8,7 @@ VALU instructions the shares `profiles/r03_welsh-1m-window_summary.json` measure
 conversions 9.3 %, transcendental 2.1 %, 64-bit integer 4.3 %, 32-bit integer 2.6 %, f32 add / mul / fma 44.6 % — 19 % of
 them with an SGPR operand, the static share in the class-specialised bodies' text —, everything else 16.4 %: moves,
 selects, compares), interleaved evenly, as INDEPENDENT chains (eight accumulators per class, so no instruction waits for
-the one before it), at the occupancies the real kernels run at (5 / 5 / 4 / 4 waves per SIMD) and at 8.  What it prints —
+the one before it), at the occupancies the real kernels run at (5 / 5 / 4 / 4 waves per SIMD through round 5; all 5 since `profiles/r05_budgets_ab.log`) and at 8.  What it prints —
 ns of SIMD time per wave-instruction of this mix — times the step's measured instruction count is the time below which no
 schedule of this instruction stream can finish: bench.py reports step time against it as valu.frac_of_measured_bound.
 
