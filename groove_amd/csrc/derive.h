@@ -96,8 +96,11 @@ inline WelshParams derive_welsh(const groove_welsh_params& p, double sr, WelshCo
 // 30x (docs/DSP_SPEC.md).  So the host runs the two recurrences side by side — the device's own coefficient formulas, a sawtooth
 // at 110 Hz and at 1,760 Hz, 2,048 frames — at the lowest, the highest and the middle cutoff the patch can reach (static cutoff;
 // envelope sweep start .. start + (1 - start) end; LFO sweep start (1 -+ depth)), and promises fp32 only if the worst RMS
-// difference is <= 2e-6 of full scale.  The 32 benchmark patches: 16 qualify, their voices' RMS error against the oracle stays
-// <= 1.2e-6 (f64 filter: <= 2.0e-6 over all 32); tests/test_emul_numerics.py holds the bar.  ~0.2 ms per distinct patch.
+// difference is <= 2e-6 of full scale.  The figure is NOT a bound on the voice's own error: low static cutoffs just under it play
+// 2x off it (240 - 320 Hz at ripple 1.61: measured 1.7e-6 - 2.3e-6, voices 1.9e-6 - 4.8e-6), which is the margin the 2e-6 keeps
+// to the path's 1e-5; at 5e-6 (tried at the end of round 5: three more benchmark patches, 2 % of the million-voice step) a static
+// 40 Hz slipped through at 4.3e-6 and its voices were off by 4e-5.  The 32 benchmark patches: see docs/DSP_SPEC.md section 11;
+// tests/test_emul_numerics.py holds the bars.  ~0.6 ms per distinct patch.
 inline double welsh_filter_f32_error(const WelshParams& o, double sr) {
   const RenderConsts rc = render_consts(sr);
   float lo_fc, hi_fc;
@@ -112,31 +115,40 @@ inline double welsh_filter_f32_error(const WelshParams& o, double sr) {
   if (lo_fc > hi_fc) { const float t = lo_fc; lo_fc = hi_fc; hi_fc = t; }
   lo_fc = fminf(fmaxf(lo_fc, 1.0f), rc.fc_max); hi_fc = fminf(fmaxf(hi_fc, 1.0f), rc.fc_max);
   const float cut[3] = {lo_fc, sqrtf(lo_fc * hi_fc), hi_fc};
+  // Round-off noise is not a smooth function of the cutoff (a static 40 Hz at ripple 1.61 reads 4e-6 where 38 and 42 Hz read 3e-5,
+  // and the voice itself is off by 4e-5): every cutoff is measured with two neighbours, 6 % either side, and the worst counts.
+  const float near[3] = {1.0f, 0.94f, 1.06f};
   const double pitch[2] = {110.0, 1760.0};
   constexpr int kWarm = 512, kFrames = 2048;
   double worst = 0.0;
   for (int ci = 0; ci < (lo_fc == hi_fc ? 1 : 3); ++ci) {
-    const Lp24CoefD cd = lp24_coefd_from_fc(o.fc, cut[ci], rc.pi_over_sr, rc.fc_max);
-    const Lp24CoefF cf = lp24_coeff_from_fc(o.fc, cut[ci], rc.pi_over_sr, rc.fc_max);
-    for (double f0 : pitch) {
-      Lp24StateD sd{0.0, 0.0, 0.0, 0.0};
-      Lp24StateF sf{0.0f, 0.0f, 0.0f, 0.0f};
-      double acc = 0.0, ph = 0.0;
-      const double dph = f0 / sr;
-      for (int i = 0; i < kWarm + kFrames; ++i) {
-        const float x = (float)(ph - 0.5); // a sawtooth of amplitude 0.5: an oscillator mix's level
-        ph += dph; if (ph >= 1.0) ph -= 1.0;
-        const double yd = lp24_step(sd, cd, (double)x);
-        const double yf = (double)lp24_step_f32(sf, cf, x);
-        if (i >= kWarm) acc += (yf - yd) * (yf - yd);
+    for (float nb : near) {
+      const float fc = fminf(fmaxf(cut[ci] * nb, 1.0f), rc.fc_max);
+      const Lp24CoefD cd = lp24_coefd_from_fc(o.fc, fc, rc.pi_over_sr, rc.fc_max);
+      const Lp24CoefF cf = lp24_coeff_from_fc(o.fc, fc, rc.pi_over_sr, rc.fc_max);
+      for (double f0 : pitch) {
+        Lp24StateD sd{0.0, 0.0, 0.0, 0.0};
+        Lp24StateF sf{0.0f, 0.0f, 0.0f, 0.0f};
+        double acc = 0.0, ph = 0.0;
+        const double dph = f0 / sr;
+        for (int i = 0; i < kWarm + kFrames; ++i) {
+          const float x = (float)(ph - 0.5); // a sawtooth of amplitude 0.5: an oscillator mix's level
+          ph += dph; if (ph >= 1.0) ph -= 1.0;
+          const double yd = lp24_step(sd, cd, (double)x);
+          const double yf = (double)lp24_step_f32(sf, cf, x);
+          if (i >= kWarm) acc += (yf - yd) * (yf - yd);
+        }
+        const double rms = sqrt(acc / kFrames);
+        if (!(rms <= worst)) worst = rms; // (NaN counts as failure)
       }
-      const double rms = sqrt(acc / kFrames);
-      if (!(rms <= worst)) worst = rms; // (NaN counts as failure)
     }
   }
   return worst;
 }
-constexpr double kFilterF32MaxError = 2e-6;
+#ifndef GROOVE_F32_FILTER_MAX_ERROR
+#define GROOVE_F32_FILTER_MAX_ERROR 2e-6
+#endif
+constexpr double kFilterF32MaxError = GROOVE_F32_FILTER_MAX_ERROR;
 inline bool welsh_filter_f32_ok(const WelshParams& o, double sr) {
   if (o.flags & WF_LFO_RESO) return false; // the ripple moves every frame: the exact-f64 kind
   const double e = welsh_filter_f32_error(o, sr);

@@ -2340,8 +2340,21 @@ static int fx_launch_run(groove_ctx* ctx, groove_fx* const* run, uint32_t count,
       d.n = n; d.frames = frames;
       d.rows = rows; d.wg_per_ch = wg_per_ch;
       const uint32_t grid_rows = std::max(frames, std::max(g.N[4], g.N[5]));
-      if (V == 4) hipLaunchKernelGGL(fx_reverb_allpass_direct_kernel<4>, dim3(2 * wg_per_ch, grid_rows), blk, 0, st, d);
-      else hipLaunchKernelGGL(fx_reverb_allpass_direct_kernel<1>, dim3(2 * wg_per_ch, grid_rows), blk, 0, st, d);
+      hipStream_t ast = st;
+#ifdef GROOVE_EXPERIMENT_AP_STREAM  // timing experiment only (results race): the all-passes of block b beside the run of block b+1
+      static int ap_k = std::getenv("GROOVE_FX_AP_STREAM") ? atoi(std::getenv("GROOVE_FX_AP_STREAM")) : -1;
+      static hipEvent_t ap_ev = nullptr;
+      static float* tmp2 = nullptr;
+      if (ap_k >= 0) {
+        if (!ap_ev) { GHIP(ctx, hipEventCreateWithFlags(&ap_ev, kSyncEventFlags)); GHIP(ctx, hipMalloc(&tmp2, (size_t)2 * rv->tmp_cap * n * 4)); }
+        ast = side_stream_of(ctx, ap_k);
+        GHIP(ctx, hipEventRecord(ap_ev, st));
+        GHIP(ctx, hipStreamWaitEvent(ast, ap_ev, 0));
+        std::swap(rv->d_tmp, tmp2);
+      }
+#endif
+      if (V == 4) hipLaunchKernelGGL(fx_reverb_allpass_direct_kernel<4>, dim3(2 * wg_per_ch, grid_rows), blk, 0, ast, d);
+      else hipLaunchKernelGGL(fx_reverb_allpass_direct_kernel<1>, dim3(2 * wg_per_ch, grid_rows), blk, 0, ast, d);
       for (int i = 0; i < 2; ++i) std::swap(rv->geo.base[4 + i], rv->ap_alt[i]);
     } else if (ctx->seq_allpass) {
       hipLaunchKernelGGL(fx_reverb_allpass_kernel<32>, dim3(blocks_for(2 * (size_t)n)), blk, 0, st, io->d, n, frames, chs, rv->d_ring, g);

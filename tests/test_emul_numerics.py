@@ -242,7 +242,7 @@ def test_fp32_filter_kind_stays_within_the_bars(oracle):
     """The arithmetic policy TESTED: patches whose 24 dB filter the host measures safe in fp32
     (derive.h welsh_filter_f32_ok -> WF_FILTER_F32: the two recurrences side by side at the lowest, middle and highest cutoff the
     patch can reach, <= 2e-6) run the fp32 recurrence in the fused per-kind kernels of big banks (dsp_core.h welsh_frame<..., F32FILT>,
-    mirrored here frame for frame).  Over the whole 172-block timeline of the 32 benchmark patches: 20 qualify — none of those
+    mirrored here frame for frame).  Over the whole 172-block timeline of the 32 benchmark patches: 19 qualify — none of those
     whose filter comes near z = +1 (40 - 90 Hz) or z = -1 (sweeps up to 20 kHz) — every flagged voice stays within 2e-6 RMS of the
     f64 oracle, no voice is worse than the f64 form's worst, and the bus moves by 1e-8."""
     import ctypes as C
@@ -256,7 +256,7 @@ def test_fp32_filter_kind_stays_within_the_bars(oracle):
     per_voice64 = np.sqrt(np.mean((e64 - o64) ** 2, axis=(0, 1)))
     proxy = np.array([E.lib().emul_filter_f32_error(C.byref(params[j]), 44100) for j in range(n)])
     is_f32 = proxy <= 2e-6
-    assert flagged == int(is_f32.sum()) == 20
+    assert flagged == int(is_f32.sum()) == 19
     assert not is_f32[0] and not is_f32[9] and not is_f32[12]          # 40 / 73 / 89 Hz: poles at z = +1
     assert not is_f32[22] and not is_f32[31]                            # sweeps that reach 16 - 20 kHz: poles at z = -1
     assert np.array_equal(per_voice[~is_f32], per_voice64[~is_f32])     # unflagged voices: the f64 form, bit for bit
@@ -285,11 +285,47 @@ def test_fp32_filter_criterion_is_a_measurement_not_a_cutoff_rule():
     assert err() <= 2e-7
     lo = [err(filter_cutoff_hz=f) for f in (40.0, 80.0, 160.0, 320.0, 640.0, 1280.0)]
     assert lo[0] > bar and lo[1] > bar and lo[-1] <= bar / 4 and max(lo[:2]) > 10 * lo[-1]  # falls with the cutoff (round-off noise: not monotonically)
+    assert all(a > b for a, b in zip(lo, lo[1:]))   # every cutoff is measured with two neighbours 6 % either side: at the cutoff alone
+    # the figure jumps about (this patch at 40 Hz read 4.3e-6 between 3e-5 and 3e-5, and its voices were off by 9e-6 - 4e-5)
     for ripple in (0.707, 0.81, 1.61):
         assert err(filter_passband_ripple=ripple, filter_cutoff_hz=40.0) > 5 * bar
-        assert err(filter_passband_ripple=ripple, filter_cutoff_hz=21000.0) <= bar
-    assert err(filter_passband_ripple=3.21, filter_cutoff_hz=40.0) <= bar                   # real poles: fine at z = +1 ...
+        assert err(filter_passband_ripple=ripple, filter_cutoff_hz=21000.0) <= (bar if ripple < 1.0 else 2 * bar)
+    assert err(filter_passband_ripple=3.21, filter_cutoff_hz=80.0) <= bar                   # real poles: fine near z = +1 (0.707 at 80 Hz: 1e-4) ...
     assert err(filter_passband_ripple=3.21, filter_cutoff_hz=21000.0) > bar                 # ... not at z = -1
     assert err(filter_cutoff_end=0.9, filter_cutoff_start=0.1) > 10 * bar                   # an envelope sweep from 49 Hz up
     assert err(filter_cutoff_end=0.3, filter_cutoff_start=0.6) <= bar                       # 1.4 - 3.1 kHz
     assert err(filter_cutoff_end=0.3, filter_cutoff_start=0.6, filter_cutoff_hz=40.0) <= bar   # (a retuned patch never uses its static cutoff)
+
+
+def test_fp32_filter_criterion_holds_where_the_fp32_recurrence_is_worst(oracle):
+    """The criterion is a MEASUREMENT of round-off noise at a few cutoffs, not a bound, so it is tested where the fp32 recurrence
+    is at its worst: static-cutoff variants of three benchmark patches from 40 to 320 Hz (poles next to z = +1).  Whatever it flags
+    must still play within the path's bar.  (With the cutoff measured alone and the bar at 5e-6 — tried at the end of round 5 for three
+    more benchmark patches, 2 % of the million-voice step — the 40 Hz variants passed at 4.3e-6 and played 9e-6 - 4e-5 off: hence the
+    two neighbouring cutoffs in derive.h welsh_filter_f32_error, and the 2e-6.)"""
+    import ctypes as C
+    cuts = (40.0, 60.0, 80.0, 120.0, 160.0, 240.0, 320.0, 480.0, 640.0)
+    base = (20, 28, 4)                                  # static cutoff, ripple 1.61
+    ps = []
+    for f in cuts:
+        for j in base:
+            p = P.welsh_patch(j)
+            p.filter_cutoff_hz = f
+            ps.append(p)
+    n = len(ps)
+    params = (T.WelshParams * n)(*ps)
+    proxy = np.array([E.lib().emul_filter_f32_error(C.byref(params[j]), 44100) for j in range(n)])
+    lanes, key = np.arange(n, dtype=np.uint32), np.full(n, 48, dtype=np.uint8)
+    on, off = T.note_events_np(lanes, key, True), T.note_events_np(lanes, key, False)
+    be = E.Bank.welsh(params)
+    flagged = be.set_f32_kind(True)
+    o, e = _render(oracle.Bank.welsh(params), be, on, off, 100, 60)
+    o64, e64 = _render(oracle.Bank.welsh(params), E.Bank.welsh(params), on, off, 100, 60)
+    per_voice = np.sqrt(np.mean((e - o) ** 2, axis=(0, 1)))
+    per_voice64 = np.sqrt(np.mean((e64 - o64) ** 2, axis=(0, 1)))
+    is_f32 = proxy <= 2e-6
+    assert flagged == int(is_f32.sum()) and 3 <= flagged <= n - 12          # the lowest four cutoffs never pass, the highest does
+    assert not is_f32[: 4 * len(base)].any() and is_f32[-len(base):].all()
+    assert np.array_equal(per_voice[~is_f32], per_voice64[~is_f32])
+    assert per_voice[is_f32].max() <= 5e-6, (proxy, per_voice)               # half the path's bar
+    assert per_voice64.max() <= 5e-6

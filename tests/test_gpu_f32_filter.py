@@ -4,7 +4,7 @@ f64 recurrence.  Checked here on the 32 benchmark patches, one patch per workgro
 voice per patch), whole 172-block timeline with its note-off:
   * per-kind kernels (forced by the ABI's tuning knob) against the oracle, patch by patch: flagged patches <= 2e-6 RMS, all <= 1e-5;
   * against the all-kinds kernel (f64 filter for everybody): unflagged patches bit for bit, flagged patches not — they did take
-    the other recurrence — and exactly the 20 patches the emulation tier's criterion names;
+    the other recurrence — and exactly the 19 patches the emulation tier's criterion names;
   * GROOVE_F32_FILTER=0 in a fresh process: the per-kind kernels' bus is the all-kinds kernel's, bit for bit, for all 32;
   * a voice can change kernel form between blocks (the fp32 state lives in the record's f64 fields): per-kind for 40 blocks, then
     time-parallel, stays within the bar."""
@@ -69,7 +69,7 @@ def _oracle_voices(oracle, blocks=BLOCKS):
 def test_fp32_filter_kind_against_the_oracle_and_the_f64_form(gpu_ctx, oracle):
     from tests.emul import emul as EM
     flagged = np.array([EM.lib().emul_filter_f32_error(C.byref(P.welsh_patch(j)), 44100) <= 2e-6 for j in range(P.N_PATCHES)])
-    assert flagged.sum() == 20
+    assert flagged.sum() == 19
     want = _oracle_voices(oracle)
     kind = _per_patch_buses(gpu_ctx, "per-kind")
     f64 = _per_patch_buses(gpu_ctx, "all-kinds")

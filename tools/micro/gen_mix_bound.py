@@ -18,7 +18,7 @@ import os
 import re
 
 # (class, asm, accumulator type, [(constraint, type, value)], count per 100 in round 4, ... in round 5)
-# Round 5 (profiles/r05_welsh-1m-window_summary.json: 20 of the 32 patches run the filter in fp32, docs/DSP_SPEC.md section 11):
+# Round 5 (profiles/r05_welsh-1m-window_summary.json: 20 (19 since the last build) of the 32 patches run the filter in fp32, docs/DSP_SPEC.md section 11):
 # 3.69e8 -> 3.37e8 wave-instructions per step, of which f64 20.8 -> 12.4 %, conversions 9.3 -> 6.3 %, fp32 add / mul / fma 44.6 -> 54.6 %,
 # everything else 16.4 -> 16.9 %, transcendental 2.1 -> 2.3 %, 64-bit integer 4.3 -> 4.7 %, 32-bit integer 2.6 -> 2.8 % (the fp32 step in
 # three-operand assembly and the polynomial envelopes took instructions out; the shares of what stayed grew).
@@ -45,6 +45,11 @@ _MIX_BOTH = [
 ]
 ROUND = int(os.environ.get("MIX_ROUND", "5"))   # MIX_ROUND=4 regenerates round 4's kernel (profiles/r04_mix_bound.json)
 MIX = [m[:4] + (m[4] if ROUND == 4 else m[5],) for m in _MIX_BOTH]
+# MIX_NO_SGPR=1: the same mix with every SGPR operand of an fp32 instruction replaced by a VGPR (what the bound would be if the kernels
+# kept their wave-uniform constants in vector registers; written to mix_bound_nosgpr.hip)
+NO_SGPR = os.environ.get("MIX_NO_SGPR", "0") == "1"
+if NO_SGPR:
+    MIX = [m[:3] + ([("v",) + i[1:] for i in m[3]],) + m[4:] for m in MIX]
 assert sum(m[4] for m in MIX) == 100
 ACC = 2  # independent chains per class (eight need 183 VGPRs: two waves per SIMD whatever the grid — measured, round 4 — and the figure then describes that occupancy, not the one asked for)
 
@@ -133,4 +138,4 @@ int main() {{
   return 0;
 }}
 '''
-open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "mix_bound.hip"), "w").write(SRC)
+open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "mix_bound_nosgpr.hip" if NO_SGPR else "mix_bound.hip"), "w").write(SRC)
