@@ -102,7 +102,7 @@ def test_switched_off_the_per_kind_kernels_give_the_f64_forms_bits():
         "b = M._per_patch_buses(ctx, 'all-kinds', blocks=24)\n"
         "print('SAME', int(sum(np.array_equal(a[j], b[j]) for j in range(32))))\n"
         "ctx.close()\n")
-    for value, want in (("0", 32), ("1", 12)):
+    for value, want in (("0", 32), ("1", 13)):   # 32 - 19 flagged patches
         r = subprocess.run([sys.executable, "-c", prog], env=dict(os.environ, GROOVE_F32_FILTER=value), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         assert f"SAME {want}" in r.stdout, (value, r.stdout[-300:])
