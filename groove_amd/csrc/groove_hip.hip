@@ -65,6 +65,17 @@ struct groove_block {
   size_t sums_cap = 0;
   uint32_t sum_rows = 0, sum_frames = 0;
   bool sums_valid = false;
+  // The all-pass stream (groove_set_fx_allpass_stream; fx_launch_run): a chain that ends in a reverb leaves the block's last
+  // kernel — the reverb's two all-passes — on a side stream, beside the next block's fused run.  That kernel reads the comb sum
+  // from the BLOCK's own staging buffer (no other block's kernels touch it) and writes the lane sums into one of two buffers the
+  // block keeps for that stream alone (only all-pass kernels, all on that one stream, and flushes that order themselves against
+  // it, ever touch them): nothing here needs a cross-stream wait in the steady state.
+  float* d_stage = nullptr;
+  uint32_t stage_cap = 0; // frames
+  float* d_sums_ap[2] = {nullptr, nullptr};
+  size_t sums_ap_cap[2] = {0, 0};
+  int ap_flip = 0;
+  bool sums_on_ap = false; // the valid lane sums are d_sums_ap[ap_flip], written on the all-pass stream
 };
 
 enum BankKind { BANK_WELSH = 0, BANK_FM = 1, BANK_SAMPLER = 2 };
@@ -148,6 +159,7 @@ struct groove_fx {
   uint64_t ap_alt[2] = {0, 0};
   float* d_tmp = nullptr;
   uint32_t tmp_cap = 0; // frames
+  bool ap_busy = false;         // the all-pass lines' last kernel went to the all-pass stream (ap_join before the ctx stream touches them)
   int last_side = -1;           // side stream whose kernels touched this effect last (-1: the ctx stream); fx_acquire_ctx
   hipEvent_t ev_done = nullptr; // end of that use
   bool done_recorded = true;    // false: the last use was a kernel whose end another event marks (a fused render's): ev_done is recorded on demand
@@ -207,6 +219,12 @@ struct groove_ctx {
   bool bind_events = true;
   uint32_t fx_seg_max_lanes = 49152;     // biquad banks of up to this many lane-channels take the four-segment kernel (measured, tools/fx_bench.py: 8,192 lane-channels 17.5 -> 9.3 us, 32,768 19.4 -> 15.6, 131,072 42.9 -> 58.4; 0 = never)
   uint32_t fx_tp_wide_min_lanes = 8192;  // from this many lane-channels the time-parallel IIR kernels take 32-wide tiles
+  // groove_set_fx_allpass_stream: the side stream that carries the all-passes of chains that END in a reverb (-1: the ctx stream
+  // carries them, behind the run).  deferred_ap: lane sums written on that stream that groove_mix_deferred has taken and the NEXT
+  // all-pass launch (same stream: ordered) puts on their bus.
+  int fx_ap_stream = -1;
+  struct { const float* rows = nullptr; float* bus = nullptr; uint32_t n_rows = 0, frames = 0; int accumulate = 0; } deferred_ap;
+  hipEvent_t ev_ap_run = nullptr, ev_ap_x = nullptr;
   bool seq_allpass = false;             // GROOVE_FX_SEQ_ALLPASS=1: the sequential all-pass kernel (A/B and bit-identity tests)
   bool chunked_allpass = false;         // GROOVE_FX_CHUNKED_ALLPASS=1: the chunk-parallel all-pass kernel instead of the direct one
   uint32_t sr = GROOVE_DEFAULT_SAMPLE_RATE;
@@ -870,8 +888,45 @@ int paced_reduce(groove_bank* b, bool host_wait) {
   return 0;
 }
 int bus_flush_deferred(groove_ctx* ctx);
+// ---- the all-pass stream (groove_set_fx_allpass_stream)
+static hipStream_t ap_stream(groove_ctx* ctx) { return side_stream_of(ctx, ctx->fx_ap_stream); }
+static int ap_events(groove_ctx* ctx) {
+  if (!ctx->ev_ap_run) GHIP(ctx, hipEventCreateWithFlags(&ctx->ev_ap_run, kSyncEventFlags));
+  if (!ctx->ev_ap_x) GHIP(ctx, hipEventCreateWithFlags(&ctx->ev_ap_x, kSyncEventFlags));
+  return 0;
+}
+// The ctx stream behind everything the all-pass stream has been given ...
+int ap_join(groove_ctx* ctx) {
+  if (ctx->fx_ap_stream < 0 || !ctx->side_busy[ctx->fx_ap_stream]) return 0;
+  if (ap_events(ctx)) return 1;
+  GHIP(ctx, hipEventRecord(ctx->ev_ap_x, ap_stream(ctx)));
+  GHIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_ap_x, 0));
+  return 0;
+}
+// ... and the all-pass stream behind everything the ctx stream has been given.
+static int ap_follow(groove_ctx* ctx) {
+  if (ctx->fx_ap_stream < 0) return 0;
+  if (ap_events(ctx)) return 1;
+  GHIP(ctx, hipEventRecord(ctx->ev_ap_run, ctx->stream));
+  GHIP(ctx, hipStreamWaitEvent(ap_stream(ctx), ctx->ev_ap_run, 0));
+  return 0;
+}
+void launch_reduce(groove_ctx* ctx, const float* partial, uint32_t rows, uint32_t frames, float* seg_buf, float* bus_dev, int accumulate, hipEvent_t done);
+// Lane sums that wait for the next all-pass launch and will not get one: the ctx stream reduces them itself, behind the kernel that
+// wrote them and ahead of whichever all-pass writes that buffer next.
+int bus_flush_ap(groove_ctx* ctx) {
+  if (!ctx->deferred_ap.rows) return 0;
+  const auto d = ctx->deferred_ap;
+  ctx->deferred_ap.rows = nullptr;
+  if (ap_join(ctx)) return 1;
+  if (ensure_seg_buffer(ctx, &ctx->d_fseg, &ctx->fseg_cap, (size_t)((d.n_rows + kRowsPerSeg - 1) / kRowsPerSeg) * 2 * d.frames)) return 1;
+  launch_reduce(ctx, d.rows, d.n_rows, d.frames, ctx->d_fseg, d.bus, d.accumulate, nullptr);
+  if (hipGetLastError() != hipSuccess) return fail(ctx, "bus_flush: launch failed");
+  return ap_follow(ctx);
+}
 int bus_flush(groove_ctx* ctx) {
   if (bus_flush_deferred(ctx)) return 1;
+  if (bus_flush_ap(ctx)) return 1;
   while (!ctx->paced_order.empty()) // (call order: the order of the banks' sums on a bus)
     if (const int rc = paced_reduce(ctx->paced_order.front(), false)) return rc;
   return 0;
@@ -1178,6 +1233,8 @@ void groove_shutdown(groove_ctx* ctx) {
   }
   if (ctx->placeholder_stream) (void)hipStreamDestroy(ctx->placeholder_stream);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_ap_run) (void)hipEventDestroy(ctx->ev_ap_run);
+  if (ctx->ev_ap_x) (void)hipEventDestroy(ctx->ev_ap_x);
   delete ctx;
 }
 const char* groove_last_error(groove_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
@@ -1270,6 +1327,17 @@ int groove_set_pipeline_min_waves(groove_ctx* ctx, uint32_t waves) {
   return 0;
 }
 uint32_t groove_pipeline_min_waves(groove_ctx* ctx) { return ctx ? ctx->pipeline_min_waves : 0; }
+int groove_set_fx_allpass_stream(groove_ctx* ctx, int on) {
+  if (!ctx) return fail(nullptr, "groove_set_fx_allpass_stream: ctx is NULL");
+  if (bus_flush(ctx) || ctx_join(ctx)) return 1; // nothing of the old arrangement is in flight when the next chain is submitted
+  GHIP(ctx, ctx_wait(ctx));
+  for (groove_fx* fx : ctx->fxs) fx->ap_busy = false;
+  // the second of the low-priority bank streams: a lone bank renders on the first (measured, tools/ap_stream_ab.sh: 0.0489 -> 0.044
+  // ms per block of config #3 there, 0.045 - 0.048 on a normal-priority kind stream, 0.063 - 0.070 on the first kind stream)
+  ctx->fx_ap_stream = on ? kBaseKinds + 1 : -1;
+  return 0;
+}
+int groove_fx_allpass_stream(groove_ctx* ctx) { return ctx ? (ctx->fx_ap_stream >= 0 ? 1 : 0) : 0; }
 int groove_set_split_max_waves(groove_ctx* ctx, uint32_t waves) {
   if (!ctx) return fail(nullptr, "groove_set_split_max_waves: ctx is NULL");
   if (ctx_join(ctx)) return 1;
@@ -1339,6 +1407,7 @@ int groove_block_destroy(groove_block* b) {
   (void)hipFree(b->d);
   (void)hipFree(b->d_alt);
   (void)hipFree(b->d_sums);
+  (void)hipFree(b->d_stage); (void)hipFree(b->d_sums_ap[0]); (void)hipFree(b->d_sums_ap[1]);
   if (b->ev_free) (void)hipEventDestroy(b->ev_free);
   for (hipEvent_t e : b->ev_ready) if (e) (void)hipEventDestroy(e);
   delete b;
@@ -1500,6 +1569,7 @@ static float* block_sums(groove_block* blk, uint32_t rows, uint32_t frames) {
     blk->sums_cap = cap;
   }
   blk->sums_valid = false;
+  blk->sums_on_ap = false;
   return blk->d_sums;
 }
 // Small Welsh banks and blocks of up to 256 frames: one wavefront per voice, lanes = time (welsh_tp.h).
@@ -1831,6 +1901,13 @@ int groove_block_release(groove_block* b) {
   if (!b) return fail(nullptr, "groove_block_release: block is NULL");
   groove_ctx* ctx = b->ctx;
   const bool marked = b->free_marked; // nothing has taken the block since the mix that bound ev_free to its last kernel
+  if (ctx->fx_ap_stream >= 0 && b->ev_free && b->ready_mask == (1u << ctx->fx_ap_stream)) {
+    // the block's last kernel is on the all-pass stream and nothing of the ctx stream's is behind it: the release is recorded there
+    // (the ctx stream does not wait for the block); the block stays "pending" for the ctx stream until somebody has waited
+    GHIP(ctx, hipEventRecord(b->ev_free, ap_stream(ctx)));
+    b->released = true; b->free_marked = false;
+    return 0;
+  }
   if (block_acquire(b)) return 1;
   if (!b->ev_free) {
     GHIP(ctx, hipEventCreateWithFlags(&b->ev_free, kSyncEventFlags));
@@ -1962,7 +2039,7 @@ int groove_bank_render_mix_paced(groove_bank* b, uint32_t frames, float* bus_dev
   if (frames == 0) return 0;
   if (frames > 4096) return fail(ctx, "groove_bank_render_mix_paced: frames > 4096");
   GHIP(ctx, hipSetDevice(ctx->device));
-  if (bus_flush_deferred(ctx)) return 1; // (the other deferral's pending rows come first; paced reductions of other banks stay pending)
+  if (bus_flush_deferred(ctx) || bus_flush_ap(ctx)) return 1; // (the other deferrals' pending rows come first; paced reductions of other banks stay pending)
   if (flush_events(b, use_tp(b, frames))) return 1;
   return render_mix_pipelined(b, frames, bus_dev, accumulate, true);
 }
@@ -2009,6 +2086,7 @@ static int ensure_dpart(groove_ctx* ctx, size_t need, uint32_t frames) {
 // Pending PACED reductions of any bank go onto their buses before a call of another form adds to a bus (include/groove_hip.h: "any
 // unpaced render or mix flushes them"): call order is the order of a bus's sums.
 static int flush_paced(groove_ctx* ctx) {
+  if (bus_flush_ap(ctx)) return 1; // (lane sums waiting on the all-pass stream: the order of a bus's sums is the order of the calls)
   while (!ctx->paced_order.empty())
     if (const int rc = paced_reduce(ctx->paced_order.front(), false)) return rc;
   return 0;
@@ -2225,10 +2303,17 @@ int groove_fx_create(groove_ctx* ctx, uint32_t kind, const groove_fx_params* p, 
   *out = fx;
   return 0;
 }
+// A reverb whose all-passes went to the all-pass stream last: the ctx stream waits for them before it touches the lines itself.
+static int fx_ap_settle(groove_fx* fx) {
+  if (!fx->ap_busy) return 0;
+  fx->ap_busy = false;
+  return ap_join(fx->ctx);
+}
 int groove_fx_destroy(groove_fx* fx) {
   if (!fx) return 0;
   groove_ctx* ctx = fx->ctx;
   (void)fx_acquire_ctx(fx);
+  (void)fx_ap_settle(fx);
   (void)hipStreamSynchronize(ctx->stream);
   if (fx->ev_done) (void)hipEventDestroy(fx->ev_done);
   auto it = std::find(ctx->fxs.begin(), ctx->fxs.end(), fx);
@@ -2242,7 +2327,7 @@ int groove_fx_reset(groove_fx* fx) {
   if (!fx) return fail(nullptr, "groove_fx_reset: fx is NULL");
   groove_ctx* ctx = fx->ctx;
   GHIP(ctx, hipSetDevice(ctx->device));
-  if (fx_acquire_ctx(fx)) return 1;
+  if (fx_acquire_ctx(fx) || fx_ap_settle(fx)) return 1;
   const size_t ln = 2 * (size_t)fx->n;
   if (fx->d_st) GHIP(ctx, hipMemsetAsync(fx->d_st, 0, 4 * ln * 8, ctx->stream));
   if (fx->d_ring) GHIP(ctx, hipMemsetAsync(fx->d_ring, 0, fx->ring_rows * ln * 4, ctx->stream));
@@ -2296,13 +2381,24 @@ static int fx_launch_run(groove_ctx* ctx, groove_fx* const* run, uint32_t count,
   a.src = io->d; a.src_chs = chs;
   a.dst = io->d; a.dst_chs = chs;
   groove_fx* rv = run[count - 1]->kind == GROOVE_FX_REVERB ? run[count - 1] : nullptr;
-  bool direct = false;
+  bool direct = false, on_ap = false;
   if (rv) {
     a.geo = rv->geo;
     // the direct all-pass form wants the comb sum in a staging block (it reads other frames than the one it writes)
     const uint32_t shortest_ap = std::min(rv->geo.N[4], rv->geo.N[5]);
     direct = !ctx->seq_allpass && !ctx->chunked_allpass && frames <= 8 * shortest_ap && (size_t)2 * io->cap * n * 4 <= ((size_t)1 << 30);
-    if (direct) {
+    // The all-pass stream: the chain's LAST launch (nothing on the ctx stream reads the block behind it; its lane sums go to the
+    // bus through groove_mix / groove_mix_deferred) leaves the ctx stream, so the next block's run follows this one directly.
+    on_ap = direct && last && ctx->fx_ap_stream >= 0 && st == ctx->stream && io->ev_free;
+    if (!on_ap && rv->ap_busy) { if (ap_join(ctx)) return 1; rv->ap_busy = false; }
+    if (direct && on_ap) {
+      if (io->stage_cap < io->cap) { // (first use of the block on this path: nothing of the block's is in flight on that stream yet)
+        if (io->d_stage) { if (ap_join(ctx)) return 1; GHIP(ctx, wait_deadline(ctx, st, nullptr, "effect staging block")); GHIP(ctx, hipFree(io->d_stage)); io->d_stage = nullptr; io->stage_cap = 0; }
+        GHIP(ctx, hipMalloc(&io->d_stage, (size_t)2 * io->cap * n * 4));
+        io->stage_cap = io->cap;
+      }
+      a.dst = io->d_stage; a.dst_chs = (size_t)io->stage_cap * n;
+    } else if (direct) {
       if (rv->tmp_cap < io->cap) {
         GHIP(ctx, wait_deadline(ctx, st, nullptr, "effect staging block"));
         if (rv->d_tmp) { GHIP(ctx, hipFree(rv->d_tmp)); rv->d_tmp = nullptr; rv->tmp_cap = 0; }
@@ -2315,8 +2411,22 @@ static int fx_launch_run(groove_ctx* ctx, groove_fx* const* run, uint32_t count,
   const dim3 blk(kThreads);
   const uint32_t V = n % 4 == 0 ? 4 : 1, wg_per_ch = fx_wg_per_ch(n, V);
   // the chain's last launch leaves the block's lane sums for groove_mix (kernels.h, fx_row_sum)
-  float* rows = last ? block_sums(io, wg_per_ch, frames) : nullptr;
-  if (last && !rows) return 1;
+  float* rows = nullptr;
+  if (on_ap) { // one of the block's two buffers that only that stream's kernels write
+    const int f = io->ap_flip;
+    const size_t need = (size_t)wg_per_ch * 2 * frames;
+    if (io->sums_ap_cap[f] < need) {
+      if (io->d_sums_ap[f]) { if (bus_flush_ap(ctx) || ap_join(ctx)) return 1; GHIP(ctx, wait_deadline(ctx, st, nullptr, "block row sums")); GHIP(ctx, hipFree(io->d_sums_ap[f])); io->d_sums_ap[f] = nullptr; io->sums_ap_cap[f] = 0; }
+      const size_t cap = std::max(need, (size_t)wg_per_ch * 2 * std::min<uint32_t>(io->cap, 4096));
+      GHIP(ctx, hipMalloc(&io->d_sums_ap[f], cap * 4));
+      io->sums_ap_cap[f] = cap;
+    }
+    io->sums_valid = false;
+    rows = io->d_sums_ap[f];
+  } else if (last) {
+    rows = block_sums(io, wg_per_ch, frames);
+    if (!rows) return 1;
+  }
   a.frames = frames; a.wg_per_ch = wg_per_ch;
   if (ctx->deferred.rows && st == ctx->stream) { // groove_mix_deferred: this launch sums the pending block's rows onto its bus
     a.prev.rows = ctx->deferred.rows; a.prev.bus = ctx->deferred.bus; a.prev.n_rows = ctx->deferred.n_rows; a.prev.frames = ctx->deferred.frames; a.prev.accumulate = ctx->deferred.accumulate;
@@ -2330,7 +2440,7 @@ static int fx_launch_run(groove_ctx* ctx, groove_fx* const* run, uint32_t count,
     const ReverbGeom& g = rv->geo;
     if (direct) {
       AllpassDirectArgs d{};
-      d.src = rv->d_tmp; d.src_chs = (size_t)rv->tmp_cap * n;
+      d.src = a.dst; d.src_chs = a.dst_chs;
       d.dst = io->d; d.dst_chs = chs;
       d.ring = rv->d_ring;
       for (int i = 0; i < 2; ++i) {
@@ -2341,20 +2451,26 @@ static int fx_launch_run(groove_ctx* ctx, groove_fx* const* run, uint32_t count,
       d.rows = rows; d.wg_per_ch = wg_per_ch;
       const uint32_t grid_rows = std::max(frames, std::max(g.N[4], g.N[5]));
       hipStream_t ast = st;
-#ifdef GROOVE_EXPERIMENT_AP_STREAM  // timing experiment only (results race): the all-passes of block b beside the run of block b+1
-      static int ap_k = std::getenv("GROOVE_FX_AP_STREAM") ? atoi(std::getenv("GROOVE_FX_AP_STREAM")) : -1;
-      static hipEvent_t ap_ev = nullptr;
-      static float* tmp2 = nullptr;
-      if (ap_k >= 0) {
-        if (!ap_ev) { GHIP(ctx, hipEventCreateWithFlags(&ap_ev, kSyncEventFlags)); GHIP(ctx, hipMalloc(&tmp2, (size_t)2 * rv->tmp_cap * n * 4)); }
-        ast = side_stream_of(ctx, ap_k);
-        GHIP(ctx, hipEventRecord(ap_ev, st));
-        GHIP(ctx, hipStreamWaitEvent(ast, ap_ev, 0));
-        std::swap(rv->d_tmp, tmp2);
+      if (on_ap) {
+        const int k = ctx->fx_ap_stream;
+        ast = ap_stream(ctx);
+        if (ap_events(ctx)) return 1;
+        GHIP(ctx, hipEventRecord(ctx->ev_ap_run, st));
+        GHIP(ctx, hipStreamWaitEvent(ast, ctx->ev_ap_run, 0));
+        if (ctx->deferred_ap.rows) { // the previous block's lane sums: written by that stream's last kernel, summed by this one
+          d.prev.rows = ctx->deferred_ap.rows; d.prev.bus = ctx->deferred_ap.bus; d.prev.n_rows = ctx->deferred_ap.n_rows; d.prev.frames = ctx->deferred_ap.frames; d.prev.accumulate = ctx->deferred_ap.accumulate;
+          ctx->deferred_ap.rows = nullptr;
+        }
+        if (V == 4) hipLaunchKernelGGL(fx_reverb_allpass_direct_kernel<4>, dim3(2 * wg_per_ch, grid_rows), blk, 0, ast, d);
+        else hipLaunchKernelGGL(fx_reverb_allpass_direct_kernel<1>, dim3(2 * wg_per_ch, grid_rows), blk, 0, ast, d);
+        GHIP(ctx, hipEventRecord(io->ev_ready[k], ast)); // the block is ready when that kernel is
+        io->ready_mask |= 1u << k;
+        ctx->side_busy[k] = true;
+        rv->ap_busy = true;
+      } else {
+        if (V == 4) hipLaunchKernelGGL(fx_reverb_allpass_direct_kernel<4>, dim3(2 * wg_per_ch, grid_rows), blk, 0, ast, d);
+        else hipLaunchKernelGGL(fx_reverb_allpass_direct_kernel<1>, dim3(2 * wg_per_ch, grid_rows), blk, 0, ast, d);
       }
-#endif
-      if (V == 4) hipLaunchKernelGGL(fx_reverb_allpass_direct_kernel<4>, dim3(2 * wg_per_ch, grid_rows), blk, 0, ast, d);
-      else hipLaunchKernelGGL(fx_reverb_allpass_direct_kernel<1>, dim3(2 * wg_per_ch, grid_rows), blk, 0, ast, d);
       for (int i = 0; i < 2; ++i) std::swap(rv->geo.base[4 + i], rv->ap_alt[i]);
     } else if (ctx->seq_allpass) {
       hipLaunchKernelGGL(fx_reverb_allpass_kernel<32>, dim3(blocks_for(2 * (size_t)n)), blk, 0, st, io->d, n, frames, chs, rv->d_ring, g);
@@ -2365,7 +2481,7 @@ static int fx_launch_run(groove_ctx* ctx, groove_fx* const* run, uint32_t count,
   }
   for (uint32_t s = 0; s < count; ++s) fx_advance(run[s], frames);
   GHIP(ctx, hipGetLastError());
-  if (rows) { io->sum_rows = wg_per_ch; io->sum_frames = frames; io->sums_valid = true; }
+  if (rows) { io->sum_rows = wg_per_ch; io->sum_frames = frames; io->sums_valid = true; io->sums_on_ap = on_ap; }
   return 0;
 }
 // The kinds with feedback inside a block: the IIR filters, and delay lines shorter than the block.
@@ -2416,6 +2532,7 @@ static int fx_launch_serial(groove_fx* fx, groove_block* io, uint32_t frames, hi
       break;
     }
     case GROOVE_FX_REVERB: {
+      if (fx_ap_settle(fx)) return 1;
       uint32_t shortest = fx->geo.N[0];
       for (int i = 1; i < 6; ++i) shortest = std::min(shortest, fx->geo.N[i]);
       if (shortest >= 8) hipLaunchKernelGGL(fx_reverb_kernel<8>, lanes_grid, blk, 0, st, io->d, n, frames, chs, fx->d_ring, fx->geo, fx->d_fa, fx->d_wet);
@@ -2558,7 +2675,7 @@ int groove_fx_set_params(groove_fx* fx, const groove_fx_params* p, uint32_t n) {
     fx->p = old;
     return fail(ctx, "groove_fx_set_params: delay-line geometry cannot change after creation");
   }
-  if (fx_acquire_ctx(fx)) return 1;
+  if (fx_acquire_ctx(fx) || fx_ap_settle(fx)) return 1;
   GHIP(ctx, ctx_wait(ctx));
   return fx_upload_params(fx);
 }
@@ -2581,7 +2698,7 @@ int groove_fx_set_param(groove_fx* fx, uint32_t lane, uint32_t control_index, do
       default: return fail(ctx, "groove_fx_set_param: unknown control index");
     }
   }
-  if (fx_acquire_ctx(fx)) return 1;
+  if (fx_acquire_ctx(fx) || fx_ap_settle(fx)) return 1;
   GHIP(ctx, ctx_wait(ctx));
   return fx_upload_params(fx);
 }
@@ -2607,7 +2724,8 @@ int groove_mix(groove_ctx* ctx, groove_block* const* blocks, uint32_t n_blocks, 
       // a block of the render-ahead rotation (it has its events): this reduction is normally its last consumer before the host
       // releases it, so the block's "free" event is bound to the reduction's last kernel and the release records nothing
       const bool mark = blk->ev_free && ctx->bind_events;
-      if (reduce_rows(ctx, blk->d_sums, blk->sum_rows, frames, bus_dev, accumulate || i > 0, mark ? blk->ev_free : nullptr)) return 1;
+      if (reduce_rows(ctx, blk->sums_on_ap ? blk->d_sums_ap[blk->ap_flip] : blk->d_sums, blk->sum_rows, frames, bus_dev, accumulate || i > 0, mark ? blk->ev_free : nullptr)) return 1;
+      if (blk->sums_on_ap && ap_follow(ctx)) return 1; // (that stream's later all-passes rewrite the buffer)
       blk->free_marked = mark;
     } else if (mix_one(ctx, blocks[i], frames, bus_dev, accumulate || i > 0)) return 1;
   }
@@ -2622,8 +2740,19 @@ int groove_mix_deferred(groove_ctx* ctx, groove_block* blk, uint32_t frames, flo
   if (blk->ctx != ctx) return fail(ctx, "groove_mix_deferred: the block belongs to another ctx");
   if (!(blk->sums_valid && blk->sum_frames == frames && blk->sum_rows <= 2048 && frames <= 4096)) return groove_mix(ctx, &blk, 1, frames, bus_dev, accumulate);
   GHIP(ctx, hipSetDevice(ctx->device));
+  if (blk->sums_on_ap && ctx->fx_ap_stream >= 0 && blk->ready_mask == (1u << ctx->fx_ap_stream)) {
+    // The rows are being written on the all-pass stream: that stream's NEXT all-pass launch sums them (ordered behind their
+    // writer without a wait; the ctx stream is not held up for the block).  Pending rows of any other kind go first, and the
+    // all-pass stream behind them: the order of a bus's sums is the order of the calls.
+    if (ctx->deferred.rows || ctx->deferred_ap.rows || !ctx->paced_order.empty()) { if (bus_flush(ctx) || ap_follow(ctx)) return 1; }
+    ctx->deferred_ap.rows = blk->d_sums_ap[blk->ap_flip]; ctx->deferred_ap.bus = bus_dev; ctx->deferred_ap.n_rows = blk->sum_rows; ctx->deferred_ap.frames = frames; ctx->deferred_ap.accumulate = accumulate;
+    blk->ap_flip ^= 1; // the block's next chain writes the other buffer: this one is read one launch from now
+    blk->sums_valid = false; blk->sums_on_ap = false;
+    return 0;
+  }
   if (bus_flush(ctx)) return 1; // an earlier pending block nobody carried: its own reduction launch, first (order of the bus's sums)
   if (block_acquire(blk)) return 1;
+  if (blk->sums_on_ap) { const int rc = groove_mix(ctx, &blk, 1, frames, bus_dev, accumulate); return rc; } // (not this path's buffers)
   ctx->deferred.rows = blk->d_sums; ctx->deferred.bus = bus_dev; ctx->deferred.n_rows = blk->sum_rows; ctx->deferred.frames = frames; ctx->deferred.accumulate = accumulate;
   // the rows leave the block: whatever writes the block's lane sums next (its next render may run on another stream) cannot touch them
   ctx->deferred.owned_cap = blk->sums_cap;
@@ -2650,7 +2779,11 @@ int groove_block_wait_ready(groove_block* b) {
 }
 int groove_block_wait_released(groove_block* b) {
   if (!b) return fail(nullptr, "groove_block_wait_released: block is NULL");
-  if (b->released && b->ev_free) GHIP(b->ctx, wait_deadline(b->ctx, nullptr, b->ev_free, "groove_block_wait_released"));
+  if (b->released && b->ev_free) {
+    GHIP(b->ctx, wait_deadline(b->ctx, nullptr, b->ev_free, "groove_block_wait_released"));
+    // a release recorded on the all-pass stream sits behind the block's last kernel there: the host has seen that complete
+    if (b->ctx->fx_ap_stream >= 0) b->ready_mask &= ~(1u << b->ctx->fx_ap_stream);
+  }
   return 0;
 }
 int groove_block_accumulate(groove_block* dst, groove_block* src, uint32_t frames, int accumulate) {

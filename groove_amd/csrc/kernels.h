@@ -1463,6 +1463,7 @@ struct AllpassDirectArgs {
   uint32_t n, frames;
   float* rows;          // not null: the block's lane sums, rows[wg_per_ch][2][frames] (fx_row_sum)
   uint32_t wg_per_ch;
+  TpPrev prev;          // the all-pass stream (groove_set_fx_allpass_stream): the previous block's lane sums, put on their bus by this launch
 };
 template <int V>
 __device__ __forceinline__ float allpass_direct_element(const AllpassDirectArgs& a, uint32_t ch, uint32_t lane, uint32_t f) {
@@ -1507,6 +1508,7 @@ __device__ __forceinline__ float allpass_direct_element(const AllpassDirectArgs&
 }
 template <int V>
 __global__ __launch_bounds__(kThreads) void fx_reverb_allpass_direct_kernel(AllpassDirectArgs a) {
+  tp_reduce_prev(a.prev, threadIdx.x, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
   const uint32_t ch = blockIdx.x / a.wg_per_ch, group = blockIdx.x % a.wg_per_ch;
   const uint32_t lane = (group * kThreads + threadIdx.x) * V, f = blockIdx.y;
   const float mine = lane < a.n ? allpass_direct_element<V>(a, ch, lane, f) : 0.0f;

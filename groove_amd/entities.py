@@ -91,6 +91,15 @@ class Context:
         _lib.check(self.L.groove_set_pipeline_min_waves(self.h, n), self.h)
 
     @property
+    def fx_allpass_stream(self):
+        """A chain's closing reverb leaves its all-passes on a side stream (include/groove_hip.h groove_set_fx_allpass_stream)."""
+        return bool(self.L.groove_fx_allpass_stream(self.h))
+
+    @fx_allpass_stream.setter
+    def fx_allpass_stream(self, on):
+        _lib.check(self.L.groove_set_fx_allpass_stream(self.h, 1 if on else 0), self.h)
+
+    @property
     def split_max_waves(self):
         return self.L.groove_split_max_waves(self.h)
 

@@ -23,6 +23,8 @@ Voice rules:
         i div 4; 3 -> sampler voice i div 4 (every contiguous range keeps the 50 / 25 / 25 mix).
 The timeline loops with the project's length.
 """
+import os
+
 import numpy as np
 
 from . import abi_types as T
@@ -125,7 +127,7 @@ class Project:
     (instruments render, their chains run, the mix bus sums: Orchestrator::tick / gather_audio,
     /root/reference/orchestration/src/orchestrator.rs:856-877, 367-470)."""
 
-    def __init__(self, ctx, workload, sel, fused=True, grouped=True, render_ahead=True, bank_scale=1.0, head_ahead=True, paced=None, one_launch=True):
+    def __init__(self, ctx, workload, sel, fused=True, grouped=True, render_ahead=True, bank_scale=1.0, head_ahead=True, paced=None, one_launch=True, allpass_stream=None):
         self.ctx, self.fused, self.workload = ctx, fused, workload
         # PACED walk (instruments with an effect chain; default for them): the renders go out TWO blocks ahead into a rotation of
         # four blocks, and the host itself waits for the two events a step depends on — the release of the block the new render
@@ -164,6 +166,20 @@ class Project:
             self.paced = self.ahead_walk and self.has_chain
         self.paced = bool(self.paced and self.ahead_walk)
         self.lookahead = 2 if self.paced else 1
+        # The paced walk of a chain that ends in a reverb: the reverb's all-passes (the block's last kernel) go to a side stream of
+        # the library, beside the next block's fused run (groove_set_fx_allpass_stream; round 5: config #3 0.0489 -> 0.044 ms per
+        # block).  allpass_stream=False: on the ctx stream behind the run (A/B).  A ctx-wide knob: restored by destroy().
+        if allpass_stream is None:   # (GROOVE_PROJECT_ALLPASS_STREAM=0: off, for in-job A/B runs of bench.py)
+            allpass_stream = os.environ.get("GROOVE_PROJECT_ALLPASS_STREAM", "1") != "0" and self.has_chain
+        self.allpass_stream = bool(allpass_stream and self.paced)
+        # (the release of a block is then recorded behind its all-passes on that stream, and the host waits for the release of the block
+        # the next render fills: with no slack that is the previous step's, and the host would hold back this step's run until those
+        # all-passes are done — the very overlap the stream is for.  Two extra blocks in the rotation, the host waits three steps back:
+        # in one job 0.0489 (ctx stream) / 0.0473 - 0.0508 (no slack) / 0.0399 - 0.0436 (one) / 0.0401 - 0.0407 (two), profiles/r05_ap_stream_ab.log.)
+        self.paced_slack = int(os.environ.get("GROOVE_PROJECT_PACED_SLACK", PACED_SLACK + (2 if self.allpass_stream else 0)))
+        self._allpass_stream_before = ctx.fx_allpass_stream
+        if self.allpass_stream != self._allpass_stream_before:
+            ctx.fx_allpass_stream = self.allpass_stream
         # A small fused project (a lone bank; or a few small banks — config #5's 16,384-voice share of a GPU) renders its banks one
         # after the other on the ctx stream, every render carrying the bus reduction of the one before it
         # (groove_bank_render_mix_deferred): one launch per bank and block, no cross-queue waits.  Bigger banks render side by side.
@@ -214,7 +230,7 @@ class Project:
                 if inst not in self.ahead:
                     # L + 1 blocks are in use at any time; the paced walk adds slack: the block a render fills was released
                     # PACED_SLACK + 1 steps ago, so the host — which waits for that release — may run that far ahead of the GPU
-                    self.ahead[inst] = [block] + [ctx.block(inst.n, FRAMES) for _ in range(L + 1 + (PACED_SLACK if self.paced else 0))]
+                    self.ahead[inst] = [block] + [ctx.block(inst.n, FRAMES) for _ in range(L + 1 + (self.paced_slack if self.paced else 0))]
             for d in range(L):  # blocks b .. b + L - 1
                 self._events(self.block_index + d)
                 for inst, _, fx, _ in self.banks:
@@ -300,3 +316,5 @@ class Project:
                     b.destroy()
         self.ahead = {}
         self.banks = []
+        if self.ctx.fx_allpass_stream != self._allpass_stream_before:
+            self.ctx.fx_allpass_stream = self._allpass_stream_before

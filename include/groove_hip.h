@@ -96,6 +96,17 @@ uint32_t groove_time_parallel_pair_min_voices(groove_ctx* ctx);
  * million-voice path on a small bank).  GROOVE_PIPELINE_MIN_WAVES in the environment sets it at groove_init. */
 int groove_set_pipeline_min_waves(groove_ctx* ctx, uint32_t waves);
 uint32_t groove_pipeline_min_waves(groove_ctx* ctx);
+/* Tuning, for a render-ahead walk of blocks through an effect chain that ENDS in a reverb (config #3): on = the reverb's two
+ * all-passes — the chain's last kernel, which nothing on the ctx stream reads behind — are launched on a side stream of the
+ * library, so that the NEXT block's fused run follows this block's run directly and the all-passes overlap it (0.0489 -> 0.044 ms
+ * per block of config #3).  Semantics are unchanged: the block is "pending" like one a groove_bank_render_async is filling
+ * (every call that reads it orders itself behind the kernel; groove_block_wait_ready / groove_block_wait_released wait for it);
+ * its lane sums reach the bus through groove_mix, or — deferred — through groove_mix_deferred, in which case the next all-pass
+ * launch (or any flush point) sums them.  Only blocks that have been through groove_block_release or an asynchronous render
+ * (they have their events) take the side stream; everything else runs as before.  Results are bit-identical either way.
+ * Default off.  No reference counterpart (the reference transforms one sample at a time, orchestrator.rs:446-454). */
+int groove_set_fx_allpass_stream(groove_ctx* ctx, int on);
+int groove_fx_allpass_stream(groove_ctx* ctx);
 /* Tuning: Welsh banks of up to this many (virtual) wavefronts that are too big for the time-parallel form render ROLE-SPLIT:
  * three wavefronts per 64 voices — front (envelopes, LFO, oscillators), cutoff tangent, filter + gains — pipelined over the
  * block's frames through LDS, so that a bank which cannot fill the chip with voices fills it with the parts of a voice's

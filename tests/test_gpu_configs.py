@@ -125,9 +125,13 @@ def test_config3_chain_4096_full_size(gpu_ctx, oracle):
     # bench.py's software-pipelined walks give the same bus, bit for bit: the paced one (renders two blocks ahead, the host
     # waits for the events itself, the bus reduction deferred into the next chain launch — four lane-sum rows, summed in the same
     # order by either path) and round 3's (one block ahead, device-side waits, a reduction launch per block)
-    for paced in (True, False):
-        ahead = _render(gpu_ctx, "chain-4096", np.arange(V), blocks, paced=paced)
-        assert np.array_equal(ahead.astype(np.float32).view(np.uint32), plain.astype(np.float32).view(np.uint32)), paced
+    # ... and, round 5, the paced walk with the reverb's all-passes on the library's all-pass stream (the default for it: the
+    # all-passes of block b beside the run of block b+1, the lane sums summed by the NEXT all-pass launch) or behind the run
+    for paced, ap in ((True, True), (True, False), (False, False)):
+        assert not gpu_ctx.fx_allpass_stream
+        ahead = _render(gpu_ctx, "chain-4096", np.arange(V), blocks, paced=paced, allpass_stream=ap)
+        assert np.array_equal(ahead.astype(np.float32).view(np.uint32), plain.astype(np.float32).view(np.uint32)), (paced, ap)
+    assert not gpu_ctx.fx_allpass_stream   # (a ctx-wide knob the project restores)
     assert gpu_ctx.debug_info()["zero_segments"] == 0
 
 

@@ -417,3 +417,74 @@ def test_deferred_forms_are_bit_reproducible_run_to_run(gpu_ctx):
         assert np.abs(runs[0]).max() > 0.1, workload
         assert np.array_equal(runs[0].view(np.uint32), runs[1].view(np.uint32)), workload
         assert np.array_equal(runs[1].view(np.uint32), runs[2].view(np.uint32)), workload
+
+
+def _chain_bits(ctx, ap, frames_of, probe=(), n=512, between=None):
+    """A 512-voice Welsh bank through BiQuad -> Delay -> Reverb, render-ahead by hand (the calls bench.py's paced walk makes) with the
+    all-pass stream on or off; returns the bus and the probed blocks' content."""
+    from groove_amd import entities as E, patches as P
+    assert not ctx.fx_allpass_stream
+    ctx.fx_allpass_stream = ap
+    params = P.welsh_voices(n)
+    synth = E.WelshSynth(ctx, params)
+    fxp = (T.FxParams * n)(*[T.fx_params(cutoff_hz=900.0 + 13 * (i % 40), delay_seconds=0.05, attenuation=0.9, reverb_seconds=0.8) for i in range(n)])
+    fx = [E.Effect(ctx, T.FX_BIQUAD_LP12, fxp), E.Effect(ctx, T.FX_DELAY, fxp), E.Effect(ctx, T.FX_REVERB, fxp)]
+    rot = [ctx.block(n, 256) for _ in range(4)]
+    total = sum(frames_of)
+    bus = ctx.bus(total)
+    synth.handle_midi_events(P.note_on_all(n))
+    got = {}
+    at = 0
+    for b, fr in enumerate(frames_of):
+        blk = rot[b % 4]
+        blk.wait_released()
+        synth.generate_batch_values_async(blk, fr)
+        blk.wait_ready()
+        ctx.transform_chain(fx, blk, fr)
+        ctx.mix_deferred(blk, fr, E._Slice(bus, at), accumulate=False)
+        if b in probe:
+            got[b] = blk.download(fr).copy()       # a reader of the block: ordered behind its all-passes, wherever they run
+        if between is not None:
+            between(b, fx, bus, at)
+        blk.release()
+        at += fr
+    out = bus.download().copy()
+    for e in fx:
+        e.destroy()
+    for blk in rot:
+        blk.destroy()
+    synth.destroy(); bus.destroy()
+    ctx.fx_allpass_stream = False
+    return out, got
+
+
+def test_allpass_stream_gives_the_same_bits(gpu_ctx):
+    """groove_set_fx_allpass_stream: a chain's closing reverb leaves its all-passes — the block's last kernel — on a side stream, the
+    lane sums reach the bus through the NEXT all-pass launch.  Same kernels, same arithmetic, same order of sums: the bus and the
+    blocks are bit-identical to the ctx-stream form, on whole and on ragged blocks (a 100-frame block takes the same path, a
+    2,000-frame one the chunked all-pass kernel on the ctx stream: the hand-over between the two forms is ordered)."""
+    shapes = ([256] * 40, [256] * 6 + [100, 256, 37, 256, 256, 1, 256] + [256] * 6)
+    for frames_of in shapes:
+        a, ga = _chain_bits(gpu_ctx, False, frames_of, probe=(0, 5, 9, len(frames_of) - 1))
+        b, gb = _chain_bits(gpu_ctx, True, frames_of, probe=(0, 5, 9, len(frames_of) - 1))
+        assert np.abs(a).max() > 1e-3
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        for k in ga:
+            assert np.array_equal(ga[k].view(np.uint32), gb[k].view(np.uint32)), k
+    assert gpu_ctx.debug_info()["zero_segments"] == 0
+
+
+def test_allpass_stream_flush_points_keep_every_block(gpu_ctx):
+    """Whatever interrupts the walk — a bus download in the middle (a flush: the ctx stream sums the pending rows itself), a parameter
+    change of the reverb, a reset of the chain — the bus has every block and the same bits as the ctx-stream form."""
+    def meddle(b, fx, bus, at):
+        if b == 7:
+            bus.download()                                        # flush point: rows pending on the all-pass stream
+        if b == 11:
+            fx[2].control_set_param_by_index(T.CTL_FX_ATTENUATION, 0.7)   # the reverb's parameters: its lines are settled first
+        if b == 15:
+            fx[0].control_set_param_by_index(T.CTL_FX_CUTOFF, 0.6)
+    a, _ = _chain_bits(gpu_ctx, False, [256] * 24, between=meddle)
+    b, _ = _chain_bits(gpu_ctx, True, [256] * 24, between=meddle)
+    assert np.abs(a[20 * 256:]).max() > 1e-3
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
