@@ -1332,9 +1332,13 @@ int groove_set_fx_allpass_stream(groove_ctx* ctx, int on) {
   if (bus_flush(ctx) || ctx_join(ctx)) return 1; // nothing of the old arrangement is in flight when the next chain is submitted
   GHIP(ctx, ctx_wait(ctx));
   for (groove_fx* fx : ctx->fxs) fx->ap_busy = false;
+  const int k_ap = kBaseKinds + 1;
+  if (on && ctx->bank_streams > 1) // banks that render on that stream move to the others (everything is idle here; their next events go through the ctx stream)
+    for (groove_bank* b : ctx->banks)
+      if (b->stream_slot == k_ap) { b->stream_slot = kBaseKinds + (ctx->next_stream_slot++ % 2 ? 2 % ctx->bank_streams : 0); b->ctx_touched = true; }
   // the second of the low-priority bank streams: a lone bank renders on the first (measured, tools/ap_stream_ab.sh: 0.0489 -> 0.044
   // ms per block of config #3 there, 0.045 - 0.048 on a normal-priority kind stream, 0.063 - 0.070 on the first kind stream)
-  ctx->fx_ap_stream = on ? kBaseKinds + 1 : -1;
+  ctx->fx_ap_stream = on ? k_ap : -1;
   return 0;
 }
 int groove_fx_allpass_stream(groove_ctx* ctx) { return ctx ? (ctx->fx_ap_stream >= 0 ? 1 : 0) : 0; }
@@ -1455,8 +1459,15 @@ int groove_block_download(groove_block* b, float* host, uint32_t frames) {
 }
 
 // ============================================================================ instruments
+// Round-robin side-stream assignment of single-kernel banks; the all-pass stream (groove_set_fx_allpass_stream), while there is
+// one, is left to the all-passes: a bank that rendered on it would queue its renders behind them.
+static int next_bank_slot(groove_ctx* ctx) {
+  int slot = kBaseKinds + ctx->next_stream_slot++ % ctx->bank_streams;
+  if (slot == ctx->fx_ap_stream && ctx->bank_streams > 1) slot = kBaseKinds + ctx->next_stream_slot++ % ctx->bank_streams;
+  return slot;
+}
 static int bank_finish_create(groove_bank* b, groove_bank** out) {
-  b->stream_slot = kBaseKinds + b->ctx->next_stream_slot++ % b->ctx->bank_streams;
+  b->stream_slot = next_bank_slot(b->ctx);
   if (bank_alloc(b) || bank_derive_and_upload(b)) { groove_bank_destroy(b); return 1; }
   b->ctx->banks.push_back(b);
   *out = b;
