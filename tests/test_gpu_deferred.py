@@ -503,3 +503,52 @@ def test_allpass_stream_flush_points_keep_every_block(gpu_ctx):
     b, _ = _chain_bits(gpu_ctx, True, [256] * 24, between=meddle)
     assert np.abs(a[20 * 256:]).max() > 1e-3
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_allpass_stream_keeps_the_order_of_a_bus_with_several_sources(gpu_ctx):
+    """Two chained instruments and a small fused bank onto ONE bus slice per block (accumulate = 0, 1, 1): the deferred lane sums of
+    the chains wait on the all-pass stream, the bank's on the ctx stream — whichever is pending when the other kind arrives is flushed
+    first, so the bus is the ctx-stream form's bit for bit."""
+    from groove_amd import entities as E, patches as P
+
+    def run(ap):
+        assert not gpu_ctx.fx_allpass_stream
+        gpu_ctx.fx_allpass_stream = ap
+        n = 256
+        synths = [E.WelshSynth(gpu_ctx, P.welsh_voices(n)) for _ in range(2)]
+        lone = E.FmSynth(gpu_ctx, P.fm_voices(128))
+        chains = []
+        for c in range(2):
+            fxp = (T.FxParams * n)(*[T.fx_params(cutoff_hz=700.0 + 300 * c + 11 * (i % 30), delay_seconds=0.03 + 0.02 * c, attenuation=0.85, reverb_seconds=0.6 + 0.3 * c) for i in range(n)])
+            chains.append([E.Effect(gpu_ctx, T.FX_DELAY, fxp), E.Effect(gpu_ctx, T.FX_REVERB, fxp)])
+        rots = [[gpu_ctx.block(n, 256) for _ in range(4)] for _ in range(2)]
+        blocks = 20
+        bus = gpu_ctx.bus(blocks * 256)
+        for s in synths:
+            s.handle_midi_events(P.note_on_all(n))
+        lone.handle_midi_events(P.note_on_all(128))
+        for b in range(blocks):
+            at = E._Slice(bus, b * 256)
+            for c in range(2):
+                blk = rots[c][b % 4]
+                blk.wait_released()
+                synths[c].generate_batch_values_async(blk, 256)
+                blk.wait_ready()
+                gpu_ctx.transform_chain(chains[c], blk, 256)
+                gpu_ctx.mix_deferred(blk, 256, at, accumulate=c > 0)
+                blk.release()
+            lone.render_mix_deferred(bus, 256, accumulate=True, at_frame=b * 256)
+        out = bus.download().copy()
+        for c in range(2):
+            for e in chains[c]:
+                e.destroy()
+            for blk in rots[c]:
+                blk.destroy()
+            synths[c].destroy()
+        lone.destroy(); bus.destroy()
+        gpu_ctx.fx_allpass_stream = False
+        return out
+
+    a, b = run(False), run(True)
+    assert np.abs(a).max() > 1e-2
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
