@@ -1406,6 +1406,8 @@ int groove_block_create(groove_ctx* ctx, uint32_t n, uint32_t frames_cap, groove
 }
 int groove_block_destroy(groove_block* b) {
   if (!b) return 0;
+  // lane sums of this block that still wait for the next all-pass launch: onto their bus first (the buffer dies with the block)
+  if (b->ctx->deferred_ap.rows && (b->ctx->deferred_ap.rows == b->d_sums_ap[0] || b->ctx->deferred_ap.rows == b->d_sums_ap[1])) (void)bus_flush_ap(b->ctx);
   if (b->ready_mask) (void)ctx_join(b->ctx);
   (void)hipStreamSynchronize(b->ctx->stream);
   (void)hipFree(b->d);

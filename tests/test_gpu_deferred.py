@@ -419,7 +419,7 @@ def test_deferred_forms_are_bit_reproducible_run_to_run(gpu_ctx):
         assert np.array_equal(runs[1].view(np.uint32), runs[2].view(np.uint32)), workload
 
 
-def _chain_bits(ctx, ap, frames_of, probe=(), n=512, between=None):
+def _chain_bits(ctx, ap, frames_of, probe=(), n=512, between=None, destroy_first=False):
     """A 512-voice Welsh bank through BiQuad -> Delay -> Reverb, render-ahead by hand (the calls bench.py's paced walk makes) with the
     all-pass stream on or off; returns the bus and the probed blocks' content."""
     from groove_amd import entities as E, patches as P
@@ -448,11 +448,15 @@ def _chain_bits(ctx, ap, frames_of, probe=(), n=512, between=None):
             between(b, fx, bus, at)
         blk.release()
         at += fr
+    if destroy_first:   # the last block's lane sums still wait for an all-pass launch that will not come: the block's destruction flushes them
+        for blk in rot:
+            blk.destroy()
     out = bus.download().copy()
     for e in fx:
         e.destroy()
-    for blk in rot:
-        blk.destroy()
+    if not destroy_first:
+        for blk in rot:
+            blk.destroy()
     synth.destroy(); bus.destroy()
     ctx.fx_allpass_stream = False
     return out, got
@@ -503,6 +507,9 @@ def test_allpass_stream_flush_points_keep_every_block(gpu_ctx):
     b, _ = _chain_bits(gpu_ctx, True, [256] * 24, between=meddle)
     assert np.abs(a[20 * 256:]).max() > 1e-3
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    c, _ = _chain_bits(gpu_ctx, True, [256] * 24, destroy_first=True)     # the blocks die before anybody has asked for the bus
+    d, _ = _chain_bits(gpu_ctx, False, [256] * 24)
+    assert np.abs(c[23 * 256:]).max() > 1e-3 and np.array_equal(c.view(np.uint32), d.view(np.uint32))
 
 
 def test_allpass_stream_keeps_the_order_of_a_bus_with_several_sources(gpu_ctx):
