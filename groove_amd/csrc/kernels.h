@@ -185,9 +185,7 @@ struct FusedAcc {
       partial[((size_t)prow * 2 + 0) * frames + f0 + row] = l;
       partial[((size_t)prow * 2 + 1) * frames + f0 + row] = r;
     }
-#ifndef GROOVE_EXPERIMENT_ONE_BARRIER  /* timing experiment only: what the second barrier of a tile turn costs */
     __syncthreads();
-#endif
   }
 };
 // The planar block's stores.  (Non-temporal stores and whole 1 KB rows out of the bus tile were both measured in round 3 and
