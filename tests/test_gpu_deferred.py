@@ -559,3 +559,85 @@ def test_allpass_stream_keeps_the_order_of_a_bus_with_several_sources(gpu_ctx):
     a, b = run(False), run(True)
     assert np.abs(a).max() > 1e-2
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_allpass_stream_random_walks(gpu_ctx):
+    """Seeded random call sequences over two chained instruments (one chain ends in a reverb, the other in a delay — whose run is its
+    last kernel and stays on the ctx stream): per block each instrument is rendered ahead or in place, its chain run whole or stage
+    by stage, mixed deferred / at once / not at all, released or not, waited for or not, with downloads, parameter changes, ragged
+    blocks and effect resets in between.  Every sequence is played twice, all-pass stream off and on: same buses, same blocks."""
+    from groove_amd import entities as E, patches as P
+
+    def play(seed, ap):
+        rng = np.random.default_rng(seed)
+        assert not gpu_ctx.fx_allpass_stream
+        gpu_ctx.fx_allpass_stream = ap
+        n = 192
+        synths = [E.WelshSynth(gpu_ctx, P.welsh_voices(n, first_voice=7 * c)) for c in range(2)]
+        fxp = [(T.FxParams * n)(*[T.fx_params(cutoff_hz=600.0 + 400 * c + 9 * (i % 50), delay_seconds=0.02 + 0.015 * c, attenuation=0.8, reverb_seconds=0.5 + 0.4 * c) for i in range(n)]) for c in range(2)]
+        chains = [[E.Effect(gpu_ctx, T.FX_BIQUAD_LP12, fxp[0]), E.Effect(gpu_ctx, T.FX_DELAY, fxp[0]), E.Effect(gpu_ctx, T.FX_REVERB, fxp[0])],
+                  [E.Effect(gpu_ctx, T.FX_REVERB, fxp[1]), E.Effect(gpu_ctx, T.FX_DELAY, fxp[1])]]
+        rots = [[gpu_ctx.block(n, 256) for _ in range(3)] for _ in range(2)]
+        blocks = 26
+        frames_of = [int(rng.choice([256, 256, 256, 100, 37, 256, 1])) for _ in range(blocks)]
+        bus = gpu_ctx.bus(sum(frames_of))
+        seen = []
+        for s in synths:
+            s.handle_midi_events(P.note_on_all(n))
+        at = 0
+        for b, fr in enumerate(frames_of):
+            first = True
+            for c in range(2):
+                blk = rots[c][b % 3]
+                if rng.random() < 0.6:
+                    blk.wait_released()
+                if rng.random() < 0.7:
+                    synths[c].generate_batch_values_async(blk, fr)
+                    if rng.random() < 0.6:
+                        blk.wait_ready()
+                else:
+                    synths[c].generate_batch_values(blk, fr)
+                if rng.random() < 0.75:
+                    gpu_ctx.transform_chain(chains[c], blk, fr)
+                else:
+                    for e in chains[c]:
+                        e.transform_audio(blk, fr)
+                how = rng.random()
+                if how < 0.55:
+                    gpu_ctx.mix_deferred(blk, fr, E._Slice(bus, at), accumulate=not first)
+                    first = False
+                elif how < 0.85:
+                    gpu_ctx.mix([blk], fr, E._Slice(bus, at), accumulate=not first)
+                    first = False
+                if rng.random() < 0.15:
+                    seen.append(blk.download(fr).copy())
+                if rng.random() < 0.7:
+                    blk.release()
+            if first:
+                gpu_ctx.mix([], fr, E._Slice(bus, at))
+            r = rng.random()
+            if r < 0.08:
+                seen.append(bus.download().copy())
+            elif r < 0.14:
+                chains[0][2].control_set_param_by_index(T.CTL_FX_ATTENUATION, float(rng.random()))
+            elif r < 0.18:
+                for e in chains[int(rng.integers(2))]:
+                    e.reset()
+            at += fr
+        seen.append(bus.download().copy())
+        for c in range(2):
+            for e in chains[c]:
+                e.destroy()
+            for blk in rots[c]:
+                blk.destroy()
+            synths[c].destroy()
+        bus.destroy()
+        gpu_ctx.fx_allpass_stream = False
+        return seen
+
+    for seed in range(24):
+        a, b = play(seed, False), play(seed, True)
+        assert len(a) == len(b) and np.abs(a[-1]).max() > 1e-3, seed
+        for k, (x, y) in enumerate(zip(a, b)):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (seed, k)
+    assert gpu_ctx.debug_info()["zero_segments"] == 0
