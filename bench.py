@@ -953,7 +953,8 @@ def config_entry(ctx, workload, repeats, parity_voices=64):
             "hbm_physical_frac": roof.get("hbm_physical_frac"), "valu_achieved_frac": (roof.get("valu") or {}).get("achieved_frac"),
             "algorithmic_bytes_per_voice_frame": roof["algorithmic_bytes_per_voice_frame"],
             "traffic": roof.get("traffic"), "traffic_source": roof.get("traffic_source"), "valu": roof.get("valu"),
-            "parity_vs_oracle": par}
+            "parity_vs_oracle": par,
+            "library_counters_after": {k: v for k, v in ctx.debug_info().items() if k in ("host_waits", "host_waits_blocked", "host_wait_ms", "zero_segments")}}
 
 
 def form_entry(ctx, label, K, W, fused, grouped, note):
