@@ -1987,7 +1987,16 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
   const dim3 blk(kThreads);
   // paced: the HOST waits for the reduction that frees this slot's rows (two blocks back: long done), so that the waits below are
   // dropped when they are made and the render streams carry no wait packet (docs/STREAMS.md item 13)
-  if (paced && b->reduce_recorded[slot]) GHIP(ctx, wait_deadline(ctx, nullptr, b->ev_reduce_done[slot], "groove_bank_render_mix_paced: the slot's previous reduction"));
+  // (A deadline that passes here loses nothing either: the streams wait for that reduction themselves below — with a wait packet this
+  // once — the block is rendered and registered, and the call reports the deadline when it returns.  Found under GROOVE_SAFE_STREAMS=1,
+  // where the bank streams are the kind streams and a blocked stream holds back more: the call used to return BEFORE its render, and a
+  // caller that carried on had skipped a block of that bank.)
+  int late = 0;
+  if (paced && b->reduce_recorded[slot]) {
+    const hipError_t e = wait_deadline(ctx, nullptr, b->ev_reduce_done[slot], "groove_bank_render_mix_paced: the slot's previous reduction");
+    if (e == hipErrorNotReady) late = 2;
+    else GHIP(ctx, e);
+  }
   uint32_t used = 0;
   for (int k = kSideStreams - 1; k >= 0; --k) { // most expensive Welsh kind first
     if (!count[k]) continue;
@@ -2021,7 +2030,6 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
   if (paced) {
     // this block's reduction is launched by the bank's NEXT paced call (or a flush point); the previous block's is launched now: its
     // renders were submitted a whole call ago, the host waits for them (this block's are already queued behind them)
-    int late = 0;
     if (b->paced.active) {
       int rc = paced_reduce(b, true);
       if (rc == 2) {

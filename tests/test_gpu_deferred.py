@@ -332,11 +332,17 @@ def test_a_deferred_render_flushes_pending_paced_reductions_first(gpu_ctx):
     assert np.abs(outs[0] - outs[1]).max() <= 2e-6 * scale * np.sqrt(len(sel)) / 8
 
 
-def test_a_paced_call_whose_wait_times_out_loses_no_block():
+@pytest.mark.parametrize("safe_streams", [False, True])
+def test_a_paced_call_whose_wait_times_out_loses_no_block(safe_streams, monkeypatch):
     """groove_bank_render_mix_paced's host wait for the previous block's render passes its deadline (a side stream blocked on
     purpose): the call reports it — and NOTHING is forgotten: the previous block's reduction is queued behind device-side waits,
-    the new block is registered, and a caller that carries on gets the bus of an undisturbed run, bit for bit."""
+    the new block is registered, and a caller that carries on gets the bus of an undisturbed run, bit for bit.  Under
+    GROOVE_SAFE_STREAMS=1 (the bank streams are the kind streams: a blocked stream holds back more) the deadline that passes is
+    the OTHER host wait of the call, for the reduction that frees the slot's rows: until the end of round 5 that one returned before
+    the render, and the caller that carried on had skipped a block."""
     from groove_amd import entities as E, lib
+    if safe_streams:
+        monkeypatch.setenv("GROOVE_SAFE_STREAMS", "1")
     sel = np.arange(3000, dtype=np.int64)
     outs = []
     for disturbed in (False, True):
