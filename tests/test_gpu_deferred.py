@@ -647,3 +647,56 @@ def test_allpass_stream_random_walks(gpu_ctx):
         for k, (x, y) in enumerate(zip(a, b)):
             assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (seed, k)
     assert gpu_ctx.debug_info()["zero_segments"] == 0
+
+
+def test_allpass_stream_waits_that_time_out_lose_nothing(gpu_ctx):
+    """The all-pass stream held up on purpose (a 0.4 s spin on it) and a 50 ms deadline: the host's waits for a block's release and
+    for its render come back as errors; a caller that carries on — the streams still order themselves — gets the undisturbed bus."""
+    from groove_amd import entities as E, lib, patches as P
+
+    def run(disturb):
+        assert not gpu_ctx.fx_allpass_stream
+        gpu_ctx.fx_allpass_stream = True
+        n = 256
+        synth = E.WelshSynth(gpu_ctx, P.welsh_voices(n))
+        fxp = (T.FxParams * n)(*[T.fx_params(cutoff_hz=800.0 + 7 * (i % 60), delay_seconds=0.04, attenuation=0.9, reverb_seconds=0.7) for i in range(n)])
+        fx = [E.Effect(gpu_ctx, T.FX_DELAY, fxp), E.Effect(gpu_ctx, T.FX_REVERB, fxp)]
+        rot = [gpu_ctx.block(n, 256) for _ in range(5)]
+        blocks = 16
+        bus = gpu_ctx.bus(blocks * 256)
+        synth.handle_midi_events(P.note_on_all(n))
+        errors = 0
+        old = gpu_ctx.sync_timeout_ms
+        try:
+            for b in range(blocks):
+                blk = rot[b % 5]
+                if disturb and b == 7:
+                    gpu_ctx.debug_spin(7, 400)          # side stream 7: the all-pass stream (the second bank stream)
+                    gpu_ctx.sync_timeout_ms = 50
+                for wait in (blk.wait_released, None, blk.wait_ready):
+                    if wait is None:
+                        synth.generate_batch_values_async(blk, 256)
+                        continue
+                    try:
+                        wait()
+                    except lib.GrooveError as e:
+                        assert "not complete after 50 ms" in str(e), str(e)
+                        errors += 1
+                gpu_ctx.transform_chain(fx, blk, 256)
+                gpu_ctx.mix_deferred(blk, 256, E._Slice(bus, b * 256), accumulate=False)
+                blk.release()
+        finally:
+            gpu_ctx.sync_timeout_ms = old
+        out = bus.download().copy()
+        for e in fx:
+            e.destroy()
+        for blk in rot:
+            blk.destroy()
+        synth.destroy(); bus.destroy()
+        gpu_ctx.fx_allpass_stream = False
+        return out, errors
+
+    a, ea = run(False)
+    b, eb = run(True)
+    assert ea == 0 and eb >= 1, (ea, eb)
+    assert np.abs(a).max() > 1e-3 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
