@@ -1,3 +1,5 @@
+"""The last kernels of a rocprofv3 --kernel-trace run as a timeline: start (us), duration, gap to the previous kernel's end, queue, grid, name.
+    python3 tools/kernel_gaps.py <rocprofv3 output dir> [kernels = 24]"""
 import csv, glob, sys
 d = sys.argv[1]
 f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)[0]

@@ -1,3 +1,5 @@
+"""tests/test_gpu_deferred.py::test_a_paced_call_whose_wait_times_out_loses_no_block by hand: which deadlines pass, and which blocks of the
+bus differ from the undisturbed run (run it with and without GROOVE_SAFE_STREAMS=1; docs/HISTORY.md section 10 item 15)."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(sys.path[0], "tests"))
 import numpy as np
