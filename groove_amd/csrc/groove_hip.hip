@@ -1142,7 +1142,8 @@ static bool create_streams(groove_ctx* ctx) {
   // so no two of them are serialised behind each other by the runtime (see bank_streams).
   // SAFE layout (GROOVE_SAFE_STREAMS=1): one priority and four streams in all — the ctx stream and three side streams
   // that kinds and banks share — so that no two streams of this library ever share a hardware queue and nothing rests
-  // on the order in which the process created its streams.  Measured cost: about 8 % at 1,000,000 voices.
+  // on the order in which the process created its streams.  Measured cost: about 8 % at 1,000,000 voices in round 3; none since the
+  // walks are paced by the host (profiles/r05_layout_ab.log).
   for (int i = 0; ok && i < kSideStreams; ++i) {
     if (i >= kBaseKinds + ctx->bank_streams) { ok = hipEventCreateWithFlags(&ctx->ev_join[i], kSyncEventFlags) == hipSuccess; continue; }
     if (i == 4 || i == 5) ctx->side_stream[i] = ctx->side_stream[i - 4];
