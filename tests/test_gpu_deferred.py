@@ -720,6 +720,14 @@ def test_random_walks_of_the_fused_call_forms_against_the_plain_walk():
         ctx = E.Context(0)
         try:
             n_sel = int(rng.choice([600, 3000, 9000]))
+            # the Welsh bank's kernel form, the same in both walks: time-parallel (the default at these sizes), the all-kinds serial
+            # kernel, the role-split kernel, or the per-kind pipelined kernels (the ABI's tuning knobs)
+            form = str(rng.choice(["tp", "tp", "any", "split", "per-kind"]))
+            if form != "tp":
+                ctx.time_parallel_max_voices = 0
+                ctx.split_max_waves = 1 << 20 if form == "split" else 0
+                if form == "per-kind":
+                    ctx.pipeline_min_waves = 1
             banks = _mixed_banks(ctx, np.arange(n_sel, dtype=np.int64))
             insts = [inst for inst, _ in banks]
             rot = {id(inst): [ctx.block(inst.n, 256) for _ in range(3)] for inst in insts}
