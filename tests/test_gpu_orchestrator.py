@@ -438,3 +438,77 @@ def test_instruments_patched_straight_into_the_main_mixer_render_fused(oracle):
         scale = np.abs(want).max()
         assert np.abs(got - want).max() <= 2e-6 * scale, (block, np.abs(got - want).max(), scale)
         assert not np.array_equal(got, want)                         # (the fast path did run: another order of additions)
+
+
+def test_random_graphs_every_walk_of_the_orchestrator_agrees():
+    """Seeded random projects on the compiled host layer: two to five instruments (Welsh, FM, the synthetic drumkit, toy sources), each
+    straight into the main mixer, or through a random chain of one to three effects (gain, 12 / 24 dB low-pass, delay, chorus, reverb), or
+    into an effect another instrument already feeds (fan-in: an effect sums ALL its sources, orchestrator.rs:438-457); sequenced notes on
+    every channel; a control trip on one effect.  The block-by-block entity-boundary walk (render-ahead off, fused path off) is the
+    reference walk; render-ahead, the fused fast path and both together must leave the same performance to fp32 rounding of the sums."""
+    import os
+    from groove_amd import host_binding as H
+    pcm, descs, k2s = H.synthetic_kit()
+    fx_menu = [(T.FX_GAIN, dict(ceiling=0.6)), (T.FX_BIQUAD_LP12, dict(cutoff_hz=1200.0, q=0.9)), (T.FX_BIQUAD_LP24, dict(cutoff_hz=900.0, passband_ripple=0.8)),
+               (T.FX_DELAY, dict(delay_seconds=0.004)), (T.FX_CHORUS, dict(voices=3, delay_seconds=0.006)), (T.FX_REVERB, dict(attenuation=0.7, reverb_seconds=0.4))]
+
+    def build(o, seed):
+        rng = np.random.default_rng(seed)
+        n_inst = int(rng.integers(2, 6))
+        seq = o.add_sequencer()
+        effects, filters = [], []
+        for ch in range(n_inst):
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                u = o.add_welsh(P.welsh_patch(int(rng.integers(0, P.N_PATCHES))), voices=int(rng.integers(2, 7)))
+            elif kind == 1:
+                u = o.add_fm(P.fm_patch(int(rng.integers(0, 8))), voices=int(rng.integers(2, 5)))
+            elif kind == 2:
+                u = o.add_drumkit(pcm, descs, k2s)
+            else:
+                u = o.add_toy_source(float(rng.uniform(0.01, 0.1)))
+            route = rng.random()
+            if route < 0.35 or (route < 0.5 and not effects):
+                assert o.patch(u, o.MAIN_MIXER) == 0
+            elif route < 0.5:                                      # fan-in: into an effect that already has a source
+                assert o.patch(u, effects[int(rng.integers(len(effects)))]) == 0
+            else:
+                chain = [u]
+                for _ in range(int(rng.integers(1, 4))):
+                    k, kw = fx_menu[int(rng.integers(len(fx_menu)))]
+                    chain.append(o.add_effect(k, T.fx_params(**kw)))
+                    if k in (T.FX_BIQUAD_LP12, T.FX_BIQUAD_LP24):
+                        filters.append(chain[-1])
+                effects += [e for e in chain[1:]]
+                assert o.patch_chain_to_main_mixer(chain) == 0
+            if kind != 3:
+                o.connect_midi_downstream(u, ch)
+                for _ in range(int(rng.integers(3, 9))):
+                    key = int(rng.choice([35, 38, 42, 46])) if kind == 2 else int(rng.integers(40, 84))
+                    o.sequencer_insert(seq, ch, key, float(rng.uniform(0.0, 1.6)), float(rng.uniform(0.1, 0.8)))
+        o.sequencer_set_end(seq, 2.0)
+        if filters:                                                # a cutoff sweep on one of the filters
+            trip = o.add_control_trip(filters[int(rng.integers(len(filters)))], "cutoff", float(rng.uniform(0.0, 0.5)))
+            a, b = float(rng.uniform(0.2, 0.9)), float(rng.uniform(0.2, 0.9))
+            o.control_trip_add_step(trip, int(rng.choice([H.STEP_SLOPE, H.STEP_EXPONENTIAL, H.STEP_LOGARITHMIC])), a, b, float(rng.uniform(0.3, 1.2)))
+            o.control_trip_add_step(trip, H.STEP_FLAT, b, b, 0.25)
+        return rng
+
+    n_seeds = int(os.environ.get("GROOVE_TEST_SEEDS", "6"))   # (a campaign of 150 seeds ran clean at the end of round 5)
+    for seed in range(n_seeds):
+        outs = {}
+        for ahead, fused in ((False, False), (True, False), (False, True), (True, True)):
+            o = H.Orchestrator(0, 44100, 128.0)
+            try:
+                o.set_render_ahead(ahead)
+                o.set_fused_direct(fused)
+                build(o, seed)
+                outs[(ahead, fused)] = o.run(256).astype(np.float64)
+            finally:
+                o.close()
+        want = outs[(False, False)]
+        scale = max(1e-3, float(np.abs(want).max()))
+        assert len(want) == math.ceil(2.0 * 60 / 128 * 44100), seed
+        for mode, got in outs.items():
+            assert len(got) == len(want), (seed, mode)
+            assert float(np.abs(got - want).max()) <= 4e-6 * scale, (seed, mode, float(np.abs(got - want).max()), scale)
