@@ -101,6 +101,41 @@ def welsh_patch(j):
     return p
 
 
+
+def random_welsh_patch(rng):
+    """A Welsh patch with every continuous parameter DRAWN (numpy Generator `rng`) instead of taken from the 32-entry benchmark table: any
+    waveform pair, duty 0.05 - 0.95, oscillator 2 an octave either way (or at a fixed pitch), hard sync, envelopes with instant attacks and
+    zero sustains among them, every LFO routing and waveform, cutoffs 40 Hz - 20 kHz at ripples 0.71 - 4.3, sweeps of any extent.  For the
+    randomised parity tests (tests/test_gpu_welsh_classes.py) and tools/random_patch_probe.py."""
+    waves = [T.WAVE_NONE, T.WAVE_SINE, T.WAVE_SQUARE, T.WAVE_PULSE_WIDTH, T.WAVE_TRIANGLE, T.WAVE_SAWTOOTH, T.WAVE_NOISE]
+    p = T.WelshParams()
+    w1, w2 = int(rng.choice(waves)), int(rng.choice(waves))
+    if w1 == T.WAVE_NONE and w2 == T.WAVE_NONE:
+        w2 = T.WAVE_SAWTOOTH
+    p.oscillator_1.waveform, p.oscillator_1.duty, p.oscillator_1.tune, p.oscillator_1.fixed_hz = w1, float(rng.uniform(0.05, 0.95)), 1.0, 0.0
+    p.oscillator_2.waveform, p.oscillator_2.duty = w2, float(rng.uniform(0.05, 0.95))
+    p.oscillator_2.tune = float(2.0 ** rng.uniform(-1.0, 1.0))
+    p.oscillator_2.fixed_hz = float(rng.uniform(100.0, 2000.0)) if rng.random() < 0.15 else 0.0
+    p.oscillator_2_sync = int(rng.random() < 0.25)
+    p.oscillator_mix = 1.0 if w2 == T.WAVE_NONE else 0.0 if w1 == T.WAVE_NONE else float(rng.uniform(0.1, 0.9))
+
+    def env():
+        return T.EnvelopeParams(0.0 if rng.random() < 0.2 else float(rng.uniform(0.001, 0.3)), float(rng.uniform(0.05, 2.0)),
+                                0.0 if rng.random() < 0.15 else float(rng.uniform(0.1, 1.0)), float(rng.uniform(0.05, 1.5)))
+    p.amp_envelope, p.filter_envelope = env(), env()
+    if p.amp_envelope.sustain == 0.0 and p.amp_envelope.decay < 0.3:
+        p.amp_envelope.decay = 0.3
+    p.lfo_waveform = int(rng.choice([T.WAVE_SINE, T.WAVE_SQUARE, T.WAVE_TRIANGLE, T.WAVE_SAWTOOTH, T.WAVE_PULSE_WIDTH]))
+    p.lfo_routing = int(rng.integers(0, 10))
+    p.lfo_frequency = float(rng.uniform(0.1, 12.0))
+    p.lfo_depth = float(rng.uniform(0.0, 0.5))
+    p.filter_cutoff_hz = float(40.0 * 500.0 ** rng.uniform(0.0, 1.0))
+    p.filter_passband_ripple = denormalize_q(float(rng.uniform(0.0, 0.6)))
+    p.filter_cutoff_start = float(rng.uniform(0.0, 1.0))
+    p.filter_cutoff_end = 0.0 if p.lfo_routing == T.LFO_FILTER_CUTOFF or rng.random() < 0.3 else float(rng.uniform(0.0, 1.0))
+    p.dca_gain, p.dca_pan = float(rng.uniform(0.3, 1.0)), float(rng.uniform(-1.0, 1.0))
+    return p
+
 def _tile(table, n, ctype):
     """Tile a short ctypes table to n entries by index modulo (vectorised via numpy)."""
     size = C.sizeof(ctype)

@@ -94,3 +94,55 @@ def test_every_class_combination_against_oracle(gpu_ctx, oracle):
         assert rms <= 1e-6, (start, rms)
         synth.destroy(); bus.destroy()
     assert worst > 0.0
+
+
+def test_random_patches_every_kernel_form_against_the_oracle(gpu_ctx, oracle):
+    """Patches DRAWN from a seed (groove_amd.patches.random_welsh_patch: every continuous parameter, every routing, instant attacks, zero
+    sustains, cutoffs from 40 Hz to 20 kHz) instead of the 32 benchmark ones, eight per bank in runs of eight voices on random keys, 40 blocks
+    with a note-off: every kernel form — time-parallel, the all-kinds serial kernel, role-split, the per-kind kernels with their fp32 filter
+    bodies — against the f64 oracle voice by voice (<= 1e-5 RMS; measured worst of 60 x 64 voices: 2.1e-6), role-split bit for bit the
+    serial kernel's.  No key is an A: 55 and 110 Hz are rational in 44,100 and put a square's edge EXACTLY on a frame, which the oracle's
+    accumulated f64 phase and the device's 64-bit counter decide differently (docs/DSP_SPEC.md section 2)."""
+    import os
+    from groove_amd import entities as E
+    n, blocks, off_at = 64, 40, 24
+    old = (gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves, gpu_ctx.pipeline_min_waves)
+    lanes = np.arange(n, dtype=np.uint32)
+    try:
+        for seed in range(int(os.environ.get("GROOVE_TEST_SEEDS", "6"))):   # (60 seeds ran clean at the end of round 5)
+            rng = np.random.default_rng(seed)
+            patches = [P.random_welsh_patch(rng) for _ in range(8)]
+            params = (T.WelshParams * n)(*[patches[(i // 8) % 8] for i in range(n)])
+            keys = rng.integers(30, 96, size=n).astype(np.uint8)
+            keys[keys % 12 == 9] += 1
+            ob = oracle.Bank.welsh(params)
+            ob.note_events(T.note_events_np(lanes, keys, True))
+            want = []
+            for b in range(blocks):
+                if b == off_at:
+                    ob.note_events(T.note_events_np(lanes, keys, False))
+                want.append(ob.render(256))
+            want = np.concatenate(want, axis=1)
+            assert np.sqrt(np.mean(want ** 2)) > 1e-2
+            got = {}
+            for form in ("tp", "any", "split", "per-kind"):
+                gpu_ctx.time_parallel_max_voices = old[0] if form == "tp" else 0
+                gpu_ctx.split_max_waves = (1 << 20) if form == "split" else 0
+                gpu_ctx.pipeline_min_waves = 1 if form == "per-kind" else old[2]
+                s = E.WelshSynth(gpu_ctx, params)
+                blk = gpu_ctx.block(n, 256)
+                s.handle_midi_events(T.note_events_np(lanes, keys, True))
+                out = []
+                for b in range(blocks):
+                    if b == off_at:
+                        s.handle_midi_events(T.note_events_np(lanes, keys, False))
+                    s.generate_batch_values(blk, 256)
+                    out.append(blk.download(256))
+                got[form] = np.concatenate(out, axis=1)
+                rms = np.sqrt(np.mean((got[form].astype(np.float64) - want) ** 2, axis=(0, 1)))
+                assert np.isfinite(got[form]).all() and rms.max() <= 1e-5, (seed, form, int(np.argmax(rms)), float(rms.max()))
+                s.destroy(); blk.destroy()
+            assert np.array_equal(got["split"].view(np.uint32), got["any"].view(np.uint32)), seed
+    finally:
+        gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves, gpu_ctx.pipeline_min_waves = old
+    assert gpu_ctx.debug_info()["zero_segments"] == 0
