@@ -19,7 +19,7 @@ def main():
     ctx = E.Context(0)
     old = (ctx.time_parallel_max_voices, ctx.split_max_waves, ctx.pipeline_min_waves)
     blocks, off_at = 40, 24
-    worst = {}
+    worst, top = {}, []
     for seed in range(seeds):
         rng = np.random.default_rng(seed)
         patches = [random_patch(rng) for _ in range(8)]
@@ -53,6 +53,10 @@ def main():
             sig = np.sqrt(np.mean(want ** 2, axis=(0, 1)))
             j = int(np.argmax(rms))
             worst[(seed, form)] = (float(rms.max()), j, float(sig[j]))
+            if form == "any":
+                pj = patches[(j // 8) % 8]
+                top.append((float(rms.max()), seed, j, int(keys[j]), f"w {pj.oscillator_1.waveform}/{pj.oscillator_2.waveform} sync {pj.oscillator_2_sync} lfo {pj.lfo_waveform}/{pj.lfo_routing} f {pj.lfo_frequency:.2f} d {pj.lfo_depth:.2f} "
+                            f"cutoff {pj.filter_cutoff_hz:.0f} ripple {pj.filter_passband_ripple:.2f} sweep {pj.filter_cutoff_start:.2f}->{pj.filter_cutoff_end:.2f} signal {float(sig[j]):.2e}"))
             if rms.max() > 1e-5 or not np.isfinite(got).all():
                 pj = patches[(j // 8) % 8]
                 print(f"seed {seed} form {form}: voice {j} rms {rms.max():.3e} (signal {sig[j]:.3e}) key {keys[j]} w1 {pj.oscillator_1.waveform} w2 {pj.oscillator_2.waveform} sync {pj.oscillator_2_sync} "
@@ -63,6 +67,8 @@ def main():
     for form in ("tp", "any", "split", "per-kind"):
         v = [worst[(s, form)][0] for s in range(seeds)]
         print(f"{form:9s} worst voice RMS over {seeds} seeds: max {max(v):.3e}  median {float(np.median(v)):.3e}")
+    for t in sorted(top, reverse=True)[:6]:
+        print("worst voices (all-kinds form): rms %.2e seed %d voice %d key %d  %s" % t)
     ctx.close()
 
 
