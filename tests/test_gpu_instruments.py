@@ -337,3 +337,28 @@ def test_random_fm_patches_against_the_oracle(gpu_ctx, oracle, kernel_form):
         bar = np.array([2e-5 if p.beta * p.depth >= 10.0 else 1e-5 for p in ps])
         assert np.isfinite(got).all() and (rms <= bar).all(), (seed, kernel_form, int(np.argmax(rms / bar)), float((rms / bar).max()))
         synth.destroy(); block.destroy()
+
+
+def test_random_sampler_walks_are_exact(gpu_ctx, oracle, kernel_form):
+    """Seeded random sampler walks: voices over the (scaled-down) synthetic bank with random sample, gain and one-shot flag, random note-ons
+    (any key: pitched steps from 0.1 to 12 samples per frame) and note-offs on a few voices per block, ragged blocks: pointer stepping without
+    interpolation is a fetch, so every block equals the oracle's bit for bit, in both kernel forms, samples running off their ends included."""
+    import os
+    from groove_amd import entities as E
+    pcm, descs, lengths = P.drum_bank(scale=0.03)
+    n = 200
+    for seed in range(int(os.environ.get("GROOVE_TEST_SEEDS", "6"))):   # (300 seeds ran clean at the end of round 5)
+        rng = np.random.default_rng(seed)
+        params = (T.SamplerParams * n)(*[T.SamplerParams(int(rng.integers(len(descs))), int(rng.random() < 0.7), float(rng.uniform(0.1, 1.0))) for _ in range(n)])
+        s, ob = E.Sampler(gpu_ctx, pcm, descs, params), oracle.Bank.sampler(pcm, descs, params)
+        block = gpu_ctx.block(n, 256)
+        for b in range(30):
+            k = int(rng.integers(0, 24)) if b else n // 2
+            if k:
+                voices = np.sort(rng.choice(n, size=k, replace=False)).astype(np.uint32)
+                ev = T.note_events_np(voices, rng.integers(24, 108, size=k).astype(np.uint8), bool(b == 0 or rng.random() < 0.75))
+                s.handle_midi_events(ev); ob.note_events(ev)
+            fr = int(rng.choice([256, 256, 256, 100, 33, 17, 7, 1]))
+            s.generate_batch_values(block, fr)
+            assert np.array_equal(block.download(fr), ob.render(fr).astype(np.float32)), (seed, kernel_form, b, fr)
+        s.destroy(); block.destroy()
