@@ -387,7 +387,7 @@ def test_reverb_long_blocks_and_sample_rate_change(oracle):
 
 def test_random_chains_fused_equal_stage_by_stage_and_follow_the_oracle(gpu_ctx, oracle):
     """Seeded random effect chains — two to seven stages drawn from all seventeen kinds with random (uniform-geometry) parameters, 3 to 1,500
-    lanes, ragged blocks, a reset in the middle: groove_fx_chain_process (stages grouped into fused runs, IIR stages in between, the reverb's
+    lanes, ragged blocks, a reset in the middle, new parameters for a stage between blocks (automation): groove_fx_chain_process (stages grouped into fused runs, IIR stages in between, the reverb's
     all-passes behind its run) is the stage-by-stage result BIT FOR BIT, whatever the grouping; and chains of linear stages follow the f64
     oracle chain to 4e-6 of the signal's scale per stage."""
     import os
@@ -426,6 +426,18 @@ def test_random_chains_fused_equal_stage_by_stage_and_follow_the_oracle(gpu_ctx,
                 for e in a + b:
                     e.reset()
                 o = [oracle.Fx(k, p) for k, p in chain] if only_linear else None
+            if i != reset_at and rng.random() < 0.25:   # automation between blocks: new parameters for one stage (same line geometry), all three chains
+                j = int(rng.integers(len(chain)))
+                k, old_p = chain[j]
+                _, new_p = draw(rng, n, [k])
+                for lane in range(n):                  # delay-line geometry cannot change after creation
+                    new_p[lane].voices, new_p[lane].delay_seconds, new_p[lane].reverb_seconds = old_p[lane].voices, old_p[lane].delay_seconds, old_p[lane].reverb_seconds
+                    if k == T.FX_REVERB:
+                        new_p[lane].wet = old_p[lane].wet   # (all-wet or not decides which kernels a reverb takes: kept)
+                chain[j] = (k, new_p)
+                a[j].set_params(new_p); b[j].set_params(new_p)
+                if only_linear:
+                    o[j].set_params(new_p)
             chunk = np.ascontiguousarray(x[:, pos:pos + fr, :])
             ba.upload(chunk); bb.upload(chunk)
             for e in a:
