@@ -730,9 +730,11 @@ def test_random_walks_of_the_fused_call_forms_against_the_plain_walk():
                     ctx.pipeline_min_waves = 1
             banks = _mixed_banks(ctx, np.arange(n_sel, dtype=np.int64))
             insts = [inst for inst, _ in banks]
-            rot = {id(inst): [ctx.block(inst.n, 256) for _ in range(3)] for inst in insts}
-            blocks = 18
-            frames_of = [int(rng.choice([256, 256, 256, 256, 100, 37, 1])) for _ in range(blocks)]
+            long_blocks = rng.random() < 0.3     # calls of up to 4,096 frames (the time-parallel forms end at 256: the banks change kernels)
+            cap = 4096 if long_blocks else 256
+            rot = {id(inst): [ctx.block(inst.n, cap) for _ in range(3)] for inst in insts}
+            blocks = 10 if long_blocks else 18
+            frames_of = [int(rng.choice([256, 257, 1000, 4096, 4095, 100, 2048, 1] if long_blocks else [256, 256, 256, 256, 100, 37, 1])) for _ in range(blocks)]
             bus = ctx.bus(sum(frames_of))
             at = 0
             for b, fr in enumerate(frames_of):
