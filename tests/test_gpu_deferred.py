@@ -427,7 +427,7 @@ def test_deferred_forms_are_bit_reproducible_run_to_run(gpu_ctx):
         assert np.array_equal(runs[1].view(np.uint32), runs[2].view(np.uint32)), workload
 
 
-def _chain_bits(ctx, ap, frames_of, probe=(), n=512, between=None, destroy_first=False):
+def _chain_bits(ctx, ap, frames_of, probe=(), n=512, between=None, destroy_first=False, cap=256):
     """A 512-voice Welsh bank through BiQuad -> Delay -> Reverb, render-ahead by hand (the calls bench.py's paced walk makes) with the
     all-pass stream on or off; returns the bus and the probed blocks' content."""
     from groove_amd import entities as E, patches as P
@@ -437,7 +437,7 @@ def _chain_bits(ctx, ap, frames_of, probe=(), n=512, between=None, destroy_first
     synth = E.WelshSynth(ctx, params)
     fxp = (T.FxParams * n)(*[T.fx_params(cutoff_hz=900.0 + 13 * (i % 40), delay_seconds=0.05, attenuation=0.9, reverb_seconds=0.8) for i in range(n)])
     fx = [E.Effect(ctx, T.FX_BIQUAD_LP12, fxp), E.Effect(ctx, T.FX_DELAY, fxp), E.Effect(ctx, T.FX_REVERB, fxp)]
-    rot = [ctx.block(n, 256) for _ in range(4)]
+    rot = [ctx.block(n, cap) for _ in range(4)]
     total = sum(frames_of)
     bus = ctx.bus(total)
     synth.handle_midi_events(P.note_on_all(n))
@@ -475,10 +475,11 @@ def test_allpass_stream_gives_the_same_bits(gpu_ctx):
     lane sums reach the bus through the NEXT all-pass launch.  Same kernels, same arithmetic, same order of sums: the bus and the
     blocks are bit-identical to the ctx-stream form, on whole and on ragged blocks (a 100-frame block takes the same path, a
     2,000-frame one the chunked all-pass kernel on the ctx stream: the hand-over between the two forms is ordered)."""
-    shapes = ([256] * 40, [256] * 6 + [100, 256, 37, 256, 256, 1, 256] + [256] * 6)
+    shapes = ([256] * 40, [256] * 6 + [100, 256, 37, 256, 256, 1, 256] + [256] * 6, [256, 256, 2000, 256, 300, 1024, 256, 2048, 100, 256, 256, 512, 256])
     for frames_of in shapes:
-        a, ga = _chain_bits(gpu_ctx, False, frames_of, probe=(0, 5, 9, len(frames_of) - 1))
-        b, gb = _chain_bits(gpu_ctx, True, frames_of, probe=(0, 5, 9, len(frames_of) - 1))
+        cap = max(frames_of)
+        a, ga = _chain_bits(gpu_ctx, False, frames_of, probe=(0, 5, 9, len(frames_of) - 1), cap=cap)
+        b, gb = _chain_bits(gpu_ctx, True, frames_of, probe=(0, 5, 9, len(frames_of) - 1), cap=cap)
         assert np.abs(a).max() > 1e-3
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
         for k in ga:
