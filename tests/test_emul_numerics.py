@@ -329,3 +329,32 @@ def test_fp32_filter_criterion_holds_where_the_fp32_recurrence_is_worst(oracle):
     assert np.array_equal(per_voice[~is_f32], per_voice64[~is_f32])
     assert per_voice[is_f32].max() <= 5e-6, (proxy, per_voice)               # half the path's bar
     assert per_voice64.max() <= 5e-6
+
+
+def test_random_patches_emulated_device_arithmetic_against_the_oracle(oracle):
+    """The CPU tier's share of the randomised parity tests (tests/test_gpu_welsh_classes.py runs the same patches through the four kernel
+    forms on the GPU): patches drawn from a seed (groove_amd.patches.random_welsh_patch: every continuous parameter, every routing, envelope
+    corners) on random keys — no A: an edge exactly on a frame is decided differently by the oracle's f64 phase and the device's counter,
+    docs/DSP_SPEC.md section 2 — through the DEVICE's frame text compiled for the host (tests/emul), 40 blocks with a note-off, against the
+    f64 oracle voice by voice: <= 1e-5 RMS, with the fp32 filter kind switched on for the patches the host criterion flags as well."""
+    import os
+    n, blocks, off_at = 32, 40, 24
+    lanes = np.arange(n, dtype=np.uint32)
+    worst = 0.0
+    for seed in range(int(os.environ.get("GROOVE_TEST_SEEDS", "10"))):
+        rng = np.random.default_rng(seed)
+        patches = [P.random_welsh_patch(rng) for _ in range(8)]
+        params = (T.WelshParams * n)(*[patches[(i // 4) % 8] for i in range(n)])
+        keys = rng.integers(30, 96, size=n).astype(np.uint8)
+        keys[keys % 12 == 9] += 1
+        on, off = T.note_events_np(lanes, keys, True), T.note_events_np(lanes, keys, False)
+        for f32_kind in (False, True):
+            be = E.Bank.welsh(params)
+            if f32_kind:
+                be.set_f32_kind(True)
+            o, e = _render(oracle.Bank.welsh(params), be, on, off, blocks, off_at)
+            assert np.sqrt(np.mean(o ** 2)) > 1e-2
+            per_voice = np.sqrt(np.mean((e - o) ** 2, axis=(0, 1)))
+            worst = max(worst, float(per_voice.max()))
+            assert np.isfinite(e).all() and per_voice.max() <= 1e-5, (seed, f32_kind, int(np.argmax(per_voice)), float(per_voice.max()))
+    assert worst > 1e-9   # (the two are different arithmetic: fp32 feed-forward against f64)
