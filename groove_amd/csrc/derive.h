@@ -8,9 +8,9 @@
 
 namespace groove {
 
-inline uint32_t frames_f64(double len) {
+inline uint32_t frames_f64(double len) { // (dsp_core.h env_frames, in f64: the stage lengths that never change are counted on the host)
   if (!(len > 0.0)) return 0u;
-  double c = ceil(len);
+  double c = ceil(len * (1.0 - 1.0 / 65536.0));
   return c > 4.0e9 ? 4000000000u : (uint32_t)c;
 }
 inline double clamp01_h(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }

@@ -233,9 +233,13 @@ struct EnvState {
   uint32_t state, n, N;
   float A, D, inv_len, value;
 };
+// N = ceil(len (1 - 2^-16)) (docs/DSP_SPEC.md section 3): a hair below `len`, so that a length that is a whole number of frames in exact
+// arithmetic keeps that count on either side of its binary rounding — fp32 here, f64 in the oracle.  With a plain ceil a voice
+// released from a round sustain level (0.3 s x 44,100 x 0.6 = 7,938 frames; 7,938.0003 in fp32) went idle one frame later here than in
+// the oracle, froze its oscillators a frame apart and came back from its next note-on 0.3 of full scale off (round 5).
 GROOVE_HD uint32_t env_frames(float len) {
   if (!(len > 0.0f)) return 0u;
-  const float c = ceilf(len);
+  const float c = ceilf(len * (1.0f - 1.0f / 65536.0f));
   return c > 4.0e9f ? 4000000000u : (uint32_t)c;
 }
 GROOVE_HD void env_enter_len(EnvState& s, uint32_t st, float from, float to, float len, uint32_t N) {

@@ -166,9 +166,12 @@ struct Envelope {
     attack = p.attack; decay = p.decay; sustain = clamp01(p.sustain); release = p.release;
   }
   void update_sample_rate(double sr) { sample_rate = sr; }
+  // N = ceil(len (1 - 2^-16)): the stage's frame count, taken a hair below `len` so that a length which IS a whole number of frames in
+  // exact arithmetic — 0.3 s x 44,100 x 0.6 = 7,938, what round patch values give — stays that number whichever side of it binary
+  // rounding puts `len` (f64 here, fp32 on the device: docs/DSP_SPEC.md section 3, round 5).
   static uint32_t frames(double len) {
     if (!(len > 0.0)) return 0;
-    double c = std::ceil(len);
+    double c = std::ceil(len * (1.0 - 1.0 / 65536.0));
     return c > 4.0e9 ? 4000000000u : (uint32_t)c;
   }
   void enter(uint32_t st, double from) {

@@ -278,7 +278,7 @@ def test_envelope_is_four_closed_form_stages(oracle, a, d, s, r, off):
 
     def stage(start, A, B, length):
         """Frames start .. of a stage from A towards B over `length` frames; returns the frame after its last one."""
-        N = int(math.ceil(length)) if length > 0.0 else 0
+        N = int(math.ceil(length * (1.0 - 2.0 ** -16))) if length > 0.0 else 0
         i = np.arange(N)
         t = i / length if N else i
         seg = A + (B - A) * (2.0 * t - t * t)
@@ -324,7 +324,7 @@ def _closed_form_envelope(a, d, s, r, off, n):
     v = np.zeros(n)
 
     def stage(start, A, B, length):
-        N = int(math.ceil(length)) if length > 0.0 else 0
+        N = int(math.ceil(length * (1.0 - 2.0 ** -16))) if length > 0.0 else 0
         i = np.arange(N)
         t = i / length if N else i
         end = min(n, start + N)
