@@ -518,7 +518,7 @@ def test_random_graphs_against_the_oracle_graph(oracle):
     """The same kind of seeded random project as above, this time against the ORACLE: its patch graph (per-frame DFS from the main mixer, an
     effect sums all its sources before it transforms: orchestrator.rs:367-470) fed by a Python restatement of the host's control side —
     the sequencer's events block by block in time order (equal times in insertion order), first-idle voice allocation with stealing of the
-    voice that started first (busy until note-off + the patch's release), a cutoff trip valued at block starts.  Welsh and FM synths and toy
+    voice that started first (busy until note-off + the patch's release), a cutoff trip valued at block starts.  Welsh and FM synths, the synthetic drumkit and toy
     sources, through random chains with fan-in; bus RMS against the oracle's <= 1e-5 of the bus's scale."""
     import os
     from groove_amd import host_binding as H
@@ -527,6 +527,11 @@ def test_random_graphs_against_the_oracle_graph(oracle):
                (T.FX_DELAY, dict(delay_seconds=0.004)), (T.FX_CHORUS, dict(voices=3, delay_seconds=0.006)), (T.FX_REVERB, dict(attenuation=0.7, reverb_seconds=0.4))]
     end_beats = 1.5
     total = math.ceil(end_beats * 60 / bpm * sr)
+    pcm, descs, k2s = H.synthetic_kit()
+    kit_params = (T.SamplerParams * 128)()       # the drumkit as the host builds it: voice = MIDI key, one-shot, step 1
+    for k in range(128):
+        kit_params[k].sample_index, kit_params[k].one_shot, kit_params[k].gain = (k2s[k] if k2s[k] >= 0 else 0), 1, (1.0 if k2s[k] >= 0 else 0.0)
+    kit_descs = (T.SampleDesc * len(descs))(*[T.SampleDesc(d.offset, d.length, 0.0) for d in descs])
 
     class Alloc:   # VoiceBankInstrument::note_on / note_off (groove_amd/host/groove_host.cpp) restated
         def __init__(self, voices, release_seconds):
@@ -558,8 +563,12 @@ def test_random_graphs_against_the_oracle_graph(oracle):
             allocs, events, effects, filters = {}, [], [], []   # events: (units, insertion index, channel, key, on)
             n_inst = int(rng.integers(2, 6))
             for ch in range(n_inst):
-                kind = int(rng.integers(0, 3))
-                if kind == 0:
+                kind = int(rng.integers(0, 4))
+                if kind == 3:
+                    u = o.add_drumkit(pcm, descs, k2s)
+                    gu = g.add_instrument(oracle.Bank.sampler(pcm, kit_descs, kit_params, sr))
+                    allocs[ch] = (gu, None)
+                elif kind == 0:
                     patch, voices = P.welsh_patch(int(rng.integers(0, P.N_PATCHES))), int(rng.integers(2, 7))
                     u = o.add_welsh(patch, voices=voices)
                     gu = g.add_instrument(oracle.Bank.welsh((T.WelshParams * voices)(*[patch] * voices)))
@@ -592,6 +601,8 @@ def test_random_graphs_against_the_oracle_graph(oracle):
                     for _ in range(int(rng.integers(3, 9))):
                         key, start, dur = int(rng.integers(40, 84)), float(rng.uniform(0.0, 1.2)), float(rng.uniform(0.1, 0.6))
                         key += key % 12 == 9                     # (no A: docs/DSP_SPEC.md section 2, exact ties)
+                        if kind == 3:
+                            key = int(rng.choice([35, 38, 42, 46]))
                         o.sequencer_insert(seq, ch, key, start, dur)
                         events.append((int(start * upb + 0.5), len(events), ch, key, True))
                         events.append((int((start + dur) * upb + 0.5), len(events), ch, key, False))
@@ -612,6 +623,10 @@ def test_random_graphs_against_the_oracle_graph(oracle):
                 for at, _, ch, key, on in events:
                     if t0 <= at < t1:
                         gu, al = allocs[ch]
+                        if al is None:                           # drumkit: voice = key, note-offs ignored (one-shots)
+                            if on:
+                                g.note_events(gu, T.note_events([(key, key, True)]))
+                            continue
                         for ev in (al.on(key, pos) if on else al.off(key, pos)):
                             g.note_events(gu, T.note_events([ev]))
                 want.append(g.tick(fr)); pos += fr
