@@ -556,6 +556,7 @@ def test_random_graphs_against_the_oracle_graph(oracle):
 
     for seed in range(int(os.environ.get("GROOVE_TEST_SEEDS", "6"))):   # (150 seeds ran clean at the end of round 5)
         rng = np.random.default_rng(5000 + seed)
+        block = int(rng.choice([256, 256, 64, 100]))    # (events are block-granular: every block size is its own performance, on both sides)
         o, g = H.Orchestrator(0, sr, bpm), oracle.Graph(sr)
         try:
             g.set_bpm(bpm)
