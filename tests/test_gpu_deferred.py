@@ -600,16 +600,21 @@ def test_allpass_stream_random_walks(gpu_ctx):
                 blk = rots[c][b % 3]
                 if rng.random() < 0.6:
                     blk.wait_released()
-                if rng.random() < 0.7:
+                done, r = 0, rng.random()
+                if r < 0.25:       # the render with the chain's leading IIR stage behind it on its side stream (fused into the kernel where it can be)
+                    done = synths[c].generate_batch_values_chain_async(blk, chains[c], fr)
+                elif r < 0.7:
                     synths[c].generate_batch_values_async(blk, fr)
-                    if rng.random() < 0.6:
-                        blk.wait_ready()
+                    if rng.random() < 0.3:
+                        done = gpu_ctx.transform_chain_async(chains[c], blk, fr)
                 else:
                     synths[c].generate_batch_values(blk, fr)
+                if r < 0.7 and rng.random() < 0.6:
+                    blk.wait_ready()
                 if rng.random() < 0.75:
-                    gpu_ctx.transform_chain(chains[c], blk, fr)
+                    gpu_ctx.transform_chain(chains[c][done:], blk, fr)
                 else:
-                    for e in chains[c]:
+                    for e in chains[c][done:]:
                         e.transform_audio(blk, fr)
                 how = rng.random()
                 if how < 0.55:
