@@ -574,10 +574,11 @@ def test_allpass_stream_random_walks(gpu_ctx):
     """Seeded random call sequences over two chained instruments (one chain ends in a reverb, the other in a delay — whose run is its
     last kernel and stays on the ctx stream): per block each instrument is rendered ahead or in place, its chain run whole or stage
     by stage, mixed deferred / at once / not at all, released or not, waited for or not, with downloads, parameter changes, ragged
-    blocks and effect resets in between.  Every sequence is played twice, all-pass stream off and on: same buses, same blocks."""
+    blocks and effect resets in between.  Every sequence is played twice, all-pass stream off and on: same buses, same blocks; and a
+    third time as the plain walk — rendered in place, stage by stage, mixed at once — whose bus the others must match to rounding."""
     from groove_amd import entities as E, patches as P
 
-    def play(seed, ap):
+    def play(seed, ap, plain=False):
         rng = np.random.default_rng(seed)
         assert not gpu_ctx.fx_allpass_stream
         gpu_ctx.fx_allpass_stream = ap
@@ -601,23 +602,26 @@ def test_allpass_stream_random_walks(gpu_ctx):
                 if rng.random() < 0.6:
                     blk.wait_released()
                 done, r = 0, rng.random()
-                if r < 0.25:       # the render with the chain's leading IIR stage behind it on its side stream (fused into the kernel where it can be)
+                r2, r3, r4 = rng.random(), rng.random(), rng.random()   # (drawn whatever the branch: the plain walk stays aligned)
+                if plain:          # the reference walk: rendered in place, stage by stage, mixed at once
+                    synths[c].generate_batch_values(blk, fr)
+                elif r < 0.25:     # the render with the chain's leading IIR stage behind it on its side stream (fused into the kernel where it can be)
                     done = synths[c].generate_batch_values_chain_async(blk, chains[c], fr)
                 elif r < 0.7:
                     synths[c].generate_batch_values_async(blk, fr)
-                    if rng.random() < 0.3:
+                    if r2 < 0.3:
                         done = gpu_ctx.transform_chain_async(chains[c], blk, fr)
                 else:
                     synths[c].generate_batch_values(blk, fr)
-                if r < 0.7 and rng.random() < 0.6:
+                if not plain and r < 0.7 and r3 < 0.6:
                     blk.wait_ready()
-                if rng.random() < 0.75:
+                if not plain and r4 < 0.75:
                     gpu_ctx.transform_chain(chains[c][done:], blk, fr)
                 else:
                     for e in chains[c][done:]:
                         e.transform_audio(blk, fr)
                 how = rng.random()
-                if how < 0.55:
+                if how < 0.55 and not plain:
                     gpu_ctx.mix_deferred(blk, fr, E._Slice(bus, at), accumulate=not first)
                     first = False
                 elif how < 0.85:
@@ -656,6 +660,8 @@ def test_allpass_stream_random_walks(gpu_ctx):
         sounding += int(np.abs(a[-1]).max() > 1e-3)   # (a reset late in a walk can leave the chains' delay lines silent to its end: seed 131)
         for k, (x, y) in enumerate(zip(a, b)):
             assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (seed, k)
+        ref = play(seed, False, plain=True)[-1]       # ... and the plain walk's bus (the forms' sums differ in order: 2e-6 of its scale)
+        assert np.abs(a[-1].astype(np.float64) - ref).max() <= 2e-6 * max(1.0, float(np.abs(ref).max())) * np.sqrt(192) / 8, seed
     assert sounding >= 0.9 * n_seeds
     assert gpu_ctx.debug_info()["zero_segments"] == 0
 
