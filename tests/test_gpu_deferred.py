@@ -570,12 +570,13 @@ def test_allpass_stream_keeps_the_order_of_a_bus_with_several_sources(gpu_ctx):
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
-def test_allpass_stream_random_walks(gpu_ctx):
+def test_allpass_stream_random_walks(gpu_ctx, oracle):
     """Seeded random call sequences over two chained instruments (one chain ends in a reverb, the other in a delay — whose run is its
     last kernel and stays on the ctx stream): per block each instrument is rendered ahead or in place, its chain run whole or stage
     by stage, mixed deferred / at once / not at all, released or not, waited for or not, with downloads, parameter changes, ragged
     blocks and effect resets in between.  Every sequence is played twice, all-pass stream off and on: same buses, same blocks; and a
-    third time as the plain walk — rendered in place, stage by stage, mixed at once — whose bus the others must match to rounding."""
+    third time as the plain walk — rendered in place, stage by stage, mixed at once — whose bus the others must match to rounding and
+    which itself is held to the f64 oracle playing the same sequence."""
     from groove_amd import entities as E, patches as P
 
     def play(seed, ap, plain=False):
@@ -592,6 +593,14 @@ def test_allpass_stream_random_walks(gpu_ctx):
         frames_of = [int(rng.choice([256, 256, 256, 256, 256, 100, 37, 1])) for _ in range(blocks)]
         bus = gpu_ctx.bus(sum(frames_of))
         seen = []
+        kinds = [[T.FX_BIQUAD_LP12, T.FX_DELAY, T.FX_REVERB], [T.FX_REVERB, T.FX_DELAY]]
+        if plain:          # the oracle beside the plain walk: the same voices, chains, parameter changes and resets in f64
+            ob = [oracle.Bank.welsh(P.welsh_voices(n, first_voice=7 * c)) for c in range(2)]
+            cur = [[fxp[c] for _ in kinds[c]] for c in range(2)]
+            ofx = [[oracle.Fx(k, cur[c][i]) for i, k in enumerate(kinds[c])] for c in range(2)]
+            for o_ in ob:
+                o_.note_events(P.note_on_all(n))
+            want = np.zeros((sum(frames_of), 2))
         for s in synths:
             s.handle_midi_events(P.note_on_all(n))
         at = 0
@@ -621,6 +630,12 @@ def test_allpass_stream_random_walks(gpu_ctx):
                     for e in chains[c][done:]:
                         e.transform_audio(blk, fr)
                 how = rng.random()
+                if plain:
+                    w = ob[c].render(fr)
+                    for e_ in ofx[c]:
+                        e_.process(w)
+                    if how < 0.85:
+                        want[at:at + fr] = (0.0 if first else want[at:at + fr]) + w.sum(axis=2).T
                 if how < 0.55 and not plain:
                     gpu_ctx.mix_deferred(blk, fr, E._Slice(bus, at), accumulate=not first)
                     first = False
@@ -637,12 +652,24 @@ def test_allpass_stream_random_walks(gpu_ctx):
             if r < 0.08:
                 seen.append(bus.download().copy())
             elif r < 0.14:
-                chains[0][2].control_set_param_by_index(T.CTL_FX_ATTENUATION, float(rng.random()))
+                v = float(rng.random())
+                chains[0][2].control_set_param_by_index(T.CTL_FX_ATTENUATION, v)
+                if plain:
+                    newp = (T.FxParams * n)(*cur[0][2])
+                    for i in range(n):
+                        newp[i].attenuation = v
+                    cur[0][2] = newp
+                    ofx[0][2].set_params(newp)
             elif r < 0.16:
-                for e in chains[int(rng.integers(2))]:
+                which = int(rng.integers(2))
+                for e in chains[which]:
                     e.reset()
+                if plain:
+                    ofx[which] = [oracle.Fx(k, cur[which][i]) for i, k in enumerate(kinds[which])]
             at += fr
         seen.append(bus.download().copy())
+        if plain:
+            seen.append(want)
         for c in range(2):
             for e in chains[c]:
                 e.destroy()
@@ -660,8 +687,12 @@ def test_allpass_stream_random_walks(gpu_ctx):
         sounding += int(np.abs(a[-1]).max() > 1e-3)   # (a reset late in a walk can leave the chains' delay lines silent to its end: seed 131)
         for k, (x, y) in enumerate(zip(a, b)):
             assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (seed, k)
-        ref = play(seed, False, plain=True)[-1]       # ... and the plain walk's bus (the forms' sums differ in order: 2e-6 of its scale)
+        *_, ref, want = play(seed, False, plain=True)  # ... and the plain walk's bus (the forms' sums differ in order: 2e-6 of its scale)
         assert np.abs(a[-1].astype(np.float64) - ref).max() <= 2e-6 * max(1.0, float(np.abs(ref).max())) * np.sqrt(192) / 8, seed
+        # ... which follows the ORACLE's — the same voices through the same chains, parameter changes and resets, in f64: bus / voices RMS
+        # <= 1e-5 of the larger of 1 and the bus's own peak (the chains have gain)
+        err = np.sqrt(np.mean(((ref.astype(np.float64) - want) / 192) ** 2))
+        assert err <= 1e-5 * max(1.0, float(np.abs(want).max()) / 192), (seed, err)
     assert sounding >= 0.9 * n_seeds
     assert gpu_ctx.debug_info()["zero_segments"] == 0
 
