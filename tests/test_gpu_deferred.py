@@ -292,17 +292,21 @@ def test_paced_render_mix_gives_the_bus_of_render_mix(gpu_ctx):
     assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))
 
 
-def _mixed_banks(ctx, sel):
+def _mixed_banks(ctx, sel, oracle=None):
+    """The instruments of a mixed project (groove_amd.projects.plan); with `oracle`, the same banks on the oracle as a third element."""
     from groove_amd import entities as E, projects as PJ
     banks = []
     for spec in PJ.plan("mixed-131072", sel):
         if spec["kind"] == "welsh":
             inst = E.WelshSynth(ctx, spec["params"])
+            ob = oracle.Bank.welsh(spec["params"]) if oracle else None
         elif spec["kind"] == "fm":
             inst = E.FmSynth(ctx, spec["params"])
+            ob = oracle.Bank.fm(spec["params"]) if oracle else None
         else:
             inst = E.Sampler(ctx, spec["pcm"], spec["descs"], spec["params"])
-        banks.append((inst, spec["events"]))
+            ob = oracle.Bank.sampler(spec["pcm"], spec["descs"], spec["params"]) if oracle else None
+        banks.append((inst, spec["events"], ob) if oracle else (inst, spec["events"]))
     return banks
 
 
@@ -750,12 +754,13 @@ def test_allpass_stream_waits_that_time_out_lose_nothing(gpu_ctx):
     assert np.abs(a).max() > 1e-3 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
-def test_random_walks_of_the_fused_call_forms_against_the_plain_walk():
+def test_random_walks_of_the_fused_call_forms_against_the_plain_walk(oracle):
     """Seeded random call sequences over a mixed project (Welsh, FM and sampler banks of a few hundred to a few thousand voices): per
     block and bank one of the fused forms — groove_bank_render_mix, _paced, _deferred, the three banks in one launch, or an asynchronous
     render into a block and a (deferred) mix of it — with random note events, ragged blocks, downloads and event records in between.
     Every form must leave what the plain walk (render_mix, bank after bank) leaves: the forms' sums differ in order, so the bar is
-    2e-6 of the bus's scale, which a skipped block, a lost reduction or a bank one block early misses by five orders."""
+    2e-6 of the bus's scale, which a skipped block, a lost reduction or a bank one block early misses by five orders.  The plain walk of the
+    smaller projects is itself held to the f64 oracle playing the same events (bus / voices RMS <= 1e-5)."""
     from groove_amd import entities as E
 
     def play(seed, plain):
@@ -771,8 +776,10 @@ def test_random_walks_of_the_fused_call_forms_against_the_plain_walk():
                 ctx.split_max_waves = 1 << 20 if form == "split" else 0
                 if form == "per-kind":
                     ctx.pipeline_min_waves = 1
-            banks = _mixed_banks(ctx, np.arange(n_sel, dtype=np.int64))
-            insts = [inst for inst, _ in banks]
+            banks = _mixed_banks(ctx, np.arange(n_sel, dtype=np.int64), oracle if (plain and n_sel <= 3000) else None)
+            insts = [b_[0] for b_ in banks]
+            obs = [b_[2] for b_ in banks] if (plain and n_sel <= 3000) else None   # the oracle beside the plain walk (the small projects: it is a scalar loop)
+            want = None
             long_blocks = rng.random() < 0.3     # calls of up to 4,096 frames (the time-parallel forms end at 256: the banks change kernels)
             cap = 4096 if long_blocks else 256
             rot = {id(inst): [ctx.block(inst.n, cap) for _ in range(3)] for inst in insts}
@@ -786,7 +793,11 @@ def test_random_walks_of_the_fused_call_forms_against_the_plain_walk():
                     if b == 0 or k:
                         voices = np.sort(rng.choice(inst.n, size=min(inst.n, 40 if b == 0 else k), replace=False)).astype(np.uint32)
                         keys = rng.integers(36, 84, size=voices.size).astype(np.uint8)
-                        inst.handle_midi_events(T.note_events_np(voices, keys, bool(b == 0 or rng.random() < 0.7)))
+                        keys += (keys % 12 == 9).astype(np.uint8)       # (no A: docs/DSP_SPEC.md section 2, exact ties against the oracle)
+                        ev = T.note_events_np(voices, keys, bool(b == 0 or rng.random() < 0.7))
+                        inst.handle_midi_events(ev)
+                        if obs:
+                            obs[insts.index(inst)].note_events(ev)
                 r1 = rng.random()
                 one_launch = (not plain) and r1 < 0.2
                 modes = [int(rng.integers(0, 5)) for _ in insts]   # (drawn in both walks: the sequences stay aligned)
@@ -794,6 +805,9 @@ def test_random_walks_of_the_fused_call_forms_against_the_plain_walk():
                 if plain:
                     for i, inst in enumerate(insts):
                         inst.render_mix(bus, fr, accumulate=i > 0, at_frame=at)
+                    if obs:
+                        w = sum(o_.render_bus(fr) for o_ in obs)
+                        want = w if want is None else np.concatenate([want, w], axis=0)
                 elif one_launch:
                     ctx.render_mix_banks_deferred(insts, bus, fr, accumulate=False, at_frame=at)
                 else:
@@ -823,6 +837,9 @@ def test_random_walks_of_the_fused_call_forms_against_the_plain_walk():
                 at += fr
             out = bus.download().astype(np.float64)
             assert ctx.debug_info()["zero_segments"] == 0
+            if obs:   # the plain walk against the f64 oracle playing the same events: bus / voices RMS <= 1e-5 (SURVEY section 8d's bar)
+                err = float(np.sqrt(np.mean(((out - want) / n_sel) ** 2)))
+                assert err <= 1e-5, (seed, err)
             return out, n_sel
         finally:
             ctx.close()
