@@ -106,7 +106,7 @@ def random_welsh_patch(rng):
     """A Welsh patch with every continuous parameter DRAWN (numpy Generator `rng`) instead of taken from the 32-entry benchmark table: any
     waveform pair, duty 0.05 - 0.95, oscillator 2 an octave either way (or at a fixed pitch), hard sync, envelopes with instant attacks and
     zero sustains among them, every LFO routing and waveform, cutoffs 40 Hz - 20 kHz at ripples 0.71 - 4.3, sweeps of any extent.  For the
-    randomised parity tests (tests/test_gpu_welsh_classes.py) and tools/random_patch_probe.py."""
+    randomised parity tests (tests/test_gpu_random_inputs.py) and tools/random_patch_probe.py."""
     waves = [T.WAVE_NONE, T.WAVE_SINE, T.WAVE_SQUARE, T.WAVE_PULSE_WIDTH, T.WAVE_TRIANGLE, T.WAVE_SAWTOOTH, T.WAVE_NOISE]
     p = T.WelshParams()
     w1, w2 = int(rng.choice(waves)), int(rng.choice(waves))

@@ -59,6 +59,7 @@ def _bind(lib):
         "oracle_bank_destroy": (None, [vp]),
         "oracle_bank_note_events": (None, [vp, C.POINTER(T.NoteEvent), u32]),
         "oracle_bank_render": (None, [vp, u32, _dp]),
+        "oracle_bank_set_param": (C.c_int, [vp, u32, u32, C.c_double]),
         "oracle_bank_render_bus": (None, [vp, u32, _dp]),
         "oracle_bank_render_bus_mt": (None, [vp, u32, _dp, u32]),
         "oracle_hardware_concurrency": (C.c_uint, []),
@@ -145,6 +146,10 @@ class Bank:
 
     def note_events(self, ev):
         self.L.oracle_bank_note_events(self.h, ev, len(ev))
+
+    def set_param(self, control_index, value01, voice=T.ALL_VOICES):
+        """Controllable::control_set_param_by_index on a sounding instrument (the voices' state stays)."""
+        assert self.L.oracle_bank_set_param(self.h, voice, control_index, value01) == 0
 
     def render(self, frames):
         out = np.zeros((2, frames, self.n), dtype=np.float64)

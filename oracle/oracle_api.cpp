@@ -231,6 +231,30 @@ void oracle_bank_note_events(void* h, const groove_note_event* ev, uint32_t n_ev
   for (uint32_t i = 0; i < n_ev; ++i) b->note(ev[i]);
 }
 // Generates::generate_batch_values: out[2][frames][n] f64.
+// Controllable on an instrument (include/groove_hip.h groove_bank_set_param: Welsh banks; ControlValue 0..1 -> dca gain, pan as a
+// BipolarNormal, the static filter cutoff through percent_to_frequency), applied between blocks with the voices' state untouched —
+// what `#[derive(Control)]` generates for the reference's entities (proc-macros/src/control.rs:171-183).  Returns 0, or -1 for an
+// instrument or index that has no control.
+int oracle_bank_set_param(void* h, uint32_t voice, uint32_t control_index, double value01) {
+  Bank* b = (Bank*)h;
+  if (b->kind != Bank::WELSH) return -1;
+  const double v01 = value01 < 0.0 ? 0.0 : (value01 > 1.0 ? 1.0 : value01);
+  uint32_t lo = voice, hi = voice + 1;
+  if (voice == GROOVE_ALL_VOICES) { lo = 0; hi = b->n(); }
+  for (uint32_t v = lo; v < hi && v < b->n(); ++v) {
+    WelshVoice& w = b->welsh[v];
+    switch (control_index) {
+      case GROOVE_CTL_WELSH_DCA_GAIN: w.p.dca_gain = (float)v01; break;
+      case GROOVE_CTL_WELSH_DCA_PAN: w.p.dca_pan = (float)(v01 * 2.0 - 1.0); break;
+      case GROOVE_CTL_WELSH_CUTOFF:
+        w.p.filter_cutoff_hz = (float)percent_to_frequency(v01);
+        w.coeffs = lp24_coeffs(w.p.filter_cutoff_hz, w.p.filter_passband_ripple, w.sample_rate);
+        break;
+      default: return -1;
+    }
+  }
+  return 0;
+}
 void oracle_bank_render(void* h, uint32_t frames, double* out) {
   Bank* b = (Bank*)h;
   const uint32_t n = b->n();

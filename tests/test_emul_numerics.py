@@ -332,7 +332,7 @@ def test_fp32_filter_criterion_holds_where_the_fp32_recurrence_is_worst(oracle):
 
 
 def test_random_patches_emulated_device_arithmetic_against_the_oracle(oracle):
-    """The CPU tier's share of the randomised parity tests (tests/test_gpu_welsh_classes.py runs the same patches through the four kernel
+    """The CPU tier's share of the randomised parity tests (tests/test_gpu_random_inputs.py runs the same patches through the four kernel
     forms on the GPU): patches drawn from a seed (groove_amd.patches.random_welsh_patch: every continuous parameter, every routing, envelope
     corners) on random keys — no A: an edge exactly on a frame is decided differently by the oracle's f64 phase and the device's counter,
     docs/DSP_SPEC.md section 2 — through the DEVICE's frame text compiled for the host (tests/emul), 40 blocks with a note-off, against the

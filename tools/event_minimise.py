@@ -1,4 +1,4 @@
-"""Delta-debugging of tests/test_gpu_welsh_classes.py::test_random_note_event_sequences_in_every_kernel_form: the events ONE voice of a seed's
+"""Delta-debugging of tests/test_gpu_random_inputs.py::test_random_note_event_sequences_in_every_kernel_form: the events ONE voice of a seed's
 script received, replayed on a one-patch bank and shrunk greedily while the deviation from the oracle stays above the bar.
     python3 tools/event_minimise.py <seed> <voice>"""
 import os

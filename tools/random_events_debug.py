@@ -1,4 +1,4 @@
-"""tests/test_gpu_welsh_classes.py::test_random_note_event_sequences_in_every_kernel_form by hand for one seed: per form the worst voice, where
+"""tests/test_gpu_random_inputs.py::test_random_note_event_sequences_in_every_kernel_form by hand for one seed: per form the worst voice, where
 its error sits and the events that voice received.   python3 tools/random_events_debug.py <seed>"""
 import os
 import sys

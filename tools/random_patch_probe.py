@@ -1,5 +1,5 @@
 """Random Welsh patches (continuous parameters drawn from a seed, not the 32 benchmark patches) through every kernel form against the f64
-oracle: per-voice RMS error over a short timeline with a note-off.  Exploration tool behind tests/test_gpu_welsh_classes.py's random test.
+oracle: per-voice RMS error over a short timeline with a note-off.  Exploration tool behind tests/test_gpu_random_inputs.py's random test.
     python3 tools/random_patch_probe.py [seeds = 20] [voices per seed = 64]"""
 import os
 import sys
