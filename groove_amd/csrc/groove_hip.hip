@@ -81,9 +81,17 @@ struct groove_block {
 enum BankKind { BANK_WELSH = 0, BANK_FM = 1, BANK_SAMPLER = 2 };
 
 
+// One distinct filter description of a Welsh patch: what derive.h welsh_filter_f32_error depends on (welsh_upload_params).
+struct F32FilterKey {
+  float c0, d1, c2, d3, hz, start, end, depth;
+  uint32_t bits;
+  bool operator<(const F32FilterKey& o) const { return std::memcmp(this, &o, sizeof(F32FilterKey)) < 0; }
+};
 struct groove_bank {
   groove_ctx* ctx;
   BankKind kind;
+  std::map<F32FilterKey, bool> f32_memo; // WF_FILTER_F32 verdicts measured so far at f32_memo_sr (0.6 ms each: not again for every control change)
+  double f32_memo_sr = 0.0;
   uint32_t n;
   uint32_t pw, sw; // param / state words per lane
   uint32_t* d_params = nullptr;
@@ -503,8 +511,9 @@ int welsh_upload_params(groove_bank* b, bool regroup) {
   std::vector<WelshCold> Cext(n);
   for (uint32_t v = 0; v < n; ++v) Pext[v] = derive_welsh(b->welsh[v], sr, Cext[v]);
   if (ctx->f32_filter) { // WF_FILTER_F32 (derive.h welsh_filter_f32_ok): measured once per distinct filter description
-    struct Key { float c0, d1, c2, d3, hz, start, end, depth; uint32_t bits; bool operator<(const Key& o) const { return std::memcmp(this, &o, sizeof(Key)) < 0; } };
-    std::map<Key, bool> memo;
+    using Key = F32FilterKey;
+    if (b->f32_memo_sr != sr) { b->f32_memo.clear(); b->f32_memo_sr = sr; } // (kept across uploads: a control change re-derives the bank, groove_bank_set_param)
+    std::map<Key, bool>& memo = b->f32_memo;
     for (uint32_t v = 0; v < n; ++v) {
       const WelshParams& o = Pext[v];
       Key k{};
