@@ -145,10 +145,7 @@ inline double welsh_filter_f32_error(const WelshParams& o, double sr) {
   }
   return worst;
 }
-#ifndef GROOVE_F32_FILTER_MAX_ERROR
-#define GROOVE_F32_FILTER_MAX_ERROR 2e-6
-#endif
-constexpr double kFilterF32MaxError = GROOVE_F32_FILTER_MAX_ERROR;
+constexpr double kFilterF32MaxError = 2e-6; // (5e-6 / 6e-6 / 1e-5 were measured and rejected: profiles/r05_f32_threshold_ab.log, docs/DSP_SPEC.md section 11)
 inline bool welsh_filter_f32_ok(const WelshParams& o, double sr) {
   if (o.flags & WF_LFO_RESO) return false; // the ripple moves every frame: the exact-f64 kind
   const double e = welsh_filter_f32_error(o, sr);
