@@ -188,3 +188,52 @@ def test_random_controls_on_a_sounding_bank_in_every_kernel_form(gpu_ctx, oracle
     finally:
         gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves, gpu_ctx.pipeline_min_waves = old
     assert gpu_ctx.debug_info()["zero_segments"] == 0
+
+
+def test_random_patches_at_other_sample_rates(oracle):
+    """Configurable::update_sample_rate with drawn patches: a context of its own at 22,050 / 48,000 / 96,000 Hz (envelope lengths, phase
+    increments, filter coefficients, the Nyquist clamp of the cutoffs and the fp32-filter criterion are all re-derived for the rate), eight
+    random patches on 64 voices, three kernel forms, against the oracle at the same rate (<= 1e-5 RMS per voice)."""
+    import os
+    from groove_amd import entities as E
+    n, blocks, off_at = 64, 30, 18
+    lanes = np.arange(n, dtype=np.uint32)
+    for seed in range(int(os.environ.get("GROOVE_TEST_SEEDS", "3"))):   # (60 seeds ran clean at the end of round 5)
+        rng = np.random.default_rng(900 + seed)
+        sr = int(rng.choice([22050, 48000, 96000]))
+        patches = [P.random_welsh_patch(rng) for _ in range(8)]
+        params = (T.WelshParams * n)(*[patches[(i // 8) % 8] for i in range(n)])
+        keys = rng.integers(30, 96, size=n).astype(np.uint8)
+        keys[keys % 12 == 9] += 1            # (the A's are rational in every integer sample rate: exact ties, docs/DSP_SPEC.md section 2)
+        ob = oracle.Bank.welsh(params, sr=sr)
+        ob.note_events(T.note_events_np(lanes, keys, True))
+        want = []
+        for b in range(blocks):
+            if b == off_at:
+                ob.note_events(T.note_events_np(lanes, keys, False))
+            want.append(ob.render(256))
+        want = np.concatenate(want, axis=1)
+        ctx = E.Context(0)
+        try:
+            ctx.update_sample_rate(sr)
+            old = (ctx.time_parallel_max_voices, ctx.pipeline_min_waves)
+            for form in ("tp", "any", "per-kind"):
+                ctx.time_parallel_max_voices = old[0] if form == "tp" else 0
+                ctx.split_max_waves = 0
+                ctx.pipeline_min_waves = 1 if form == "per-kind" else old[1]
+                s = E.WelshSynth(ctx, params)
+                blk = ctx.block(n, 256)
+                s.handle_midi_events(T.note_events_np(lanes, keys, True))
+                got = []
+                for b in range(blocks):
+                    if b == off_at:
+                        s.handle_midi_events(T.note_events_np(lanes, keys, False))
+                    s.generate_batch_values(blk, 256)
+                    got.append(blk.download(256))
+                got = np.concatenate(got, axis=1).astype(np.float64)
+                rms = np.sqrt(np.mean((got - want) ** 2, axis=(0, 1)))
+                assert np.isfinite(got).all() and rms.max() <= 1e-5, (seed, sr, form, int(np.argmax(rms)), float(rms.max()))
+                s.destroy(); blk.destroy()
+            assert ctx.debug_info()["zero_segments"] == 0
+        finally:
+            ctx.close()
