@@ -457,3 +457,50 @@ def test_random_chains_fused_equal_stage_by_stage_and_follow_the_oracle(gpu_ctx,
         for e in a + b:
             e.destroy()
         ba.destroy(); bb.destroy()
+
+
+def test_random_linear_chains_at_other_sample_rates(oracle):
+    """Effect chains drawn from a seed in a context of its own at 22,050 / 48,000 / 96,000 Hz: delay-line geometry (frames = seconds x rate),
+    the reverb's comb and all-pass lengths and the RBJ / 24 dB coefficients are re-derived for the rate; the fused chain against the f64
+    oracle chain at the same rate, 4e-6 of the signal's scale per stage."""
+    import os
+    from groove_amd import entities as E
+    linear = [T.FX_GAIN, T.FX_BIQUAD_LP12, T.FX_BIQUAD_LP24, T.FX_CHORUS, T.FX_DELAY, T.FX_REVERB, T.FX_BIQUAD_HP12, T.FX_BIQUAD_BP12,
+              T.FX_BIQUAD_PEAK12, T.FX_BIQUAD_LSHELF12, T.FX_BIQUAD_HSHELF12]
+    for seed in range(int(os.environ.get("GROOVE_TEST_SEEDS", "3"))):   # (60 seeds ran clean at the end of round 5)
+        rng = np.random.default_rng(7000 + seed)
+        sr = int(rng.choice([22050, 48000, 96000]))
+        n = int(rng.choice([5, 64, 600]))
+        chain = []
+        for _ in range(int(rng.integers(2, 6))):
+            k = int(rng.choice(linear))
+            lane = lambda lo, hi: [float(v) for v in rng.uniform(lo, hi, size=n)]   # noqa: E731
+            chain.append((k, _params(n, ceiling=lane(0.3, 1.0), cutoff_hz=lane(150.0, 0.4 * sr), q=lane(0.5, 3.0), passband_ripple=lane(0.71, 3.0),
+                                     wet=1.0 if k == T.FX_REVERB else lane(0.3, 1.0), attenuation=lane(0.5, 0.95), bandwidth_hz=lane(100.0, 2000.0),
+                                     db_gain=lane(-9.0, 9.0), voices=int(rng.integers(1, 5)), delay_seconds=float(rng.choice([0.002, 0.004, 0.012, 0.03])),
+                                     reverb_seconds=float(rng.uniform(0.3, 1.5)))))
+        sizes = [int(rng.choice([256, 256, 256, 100, 37, 1])) for _ in range(12)]
+        x = _audio(n, sum(sizes), seed=seed)
+        ctx = E.Context(0)
+        try:
+            ctx.update_sample_rate(sr)
+            fx = [E.Effect(ctx, k, p) for k, p in chain]
+            o = [oracle.Fx(k, p, sr) for k, p in chain]
+            blk = ctx.block(n, 256)
+            pos, worst, scale = 0, 0.0, 1.0
+            for fr in sizes:
+                chunk = np.ascontiguousarray(x[:, pos:pos + fr, :])
+                blk.upload(chunk)
+                ctx.transform_chain(fx, blk, fr)
+                w = chunk.astype(np.float64)
+                for e in o:
+                    e.process(w)
+                scale = max(scale, float(np.abs(w).max()))
+                worst = max(worst, float(np.abs(blk.download(fr).astype(np.float64) - w).max()))
+                pos += fr
+            assert worst <= 4e-6 * scale * len(chain), (seed, sr, worst, scale, [k for k, _ in chain])
+            for e in fx:
+                e.destroy()
+            blk.destroy()
+        finally:
+            ctx.close()
