@@ -851,3 +851,36 @@ def test_random_walks_of_the_fused_call_forms_against_the_plain_walk(oracle):
         assert float(np.abs(want).max()) > 0.05, seed
         err = float(np.abs(got - want).max())
         assert err <= 2e-6 * scale * max(1.0, np.sqrt(n_sel) / 8), (seed, err, scale, n_sel)
+
+
+def test_two_contexts_interleaved_on_one_device():
+    """Two library contexts on one GPU — each with its own streams, buffers and deferred state — walking two projects in lock step, call by
+    call (a mixed project through the fused forms on one, a chained instrument through the all-pass stream on the other): each leaves the
+    bus it leaves alone, bit for bit.  Nothing in the library is process-wide except the RCCL handle."""
+    from groove_amd import entities as E, projects as PJ
+
+    def walk(ctxs, which):
+        projs, buses = {}, {}
+        for name in which:
+            ctx = ctxs[name]
+            projs[name] = PJ.Project(ctx, "mixed-131072", np.arange(3000, dtype=np.int64)) if name == "mixed" else PJ.Project(ctx, "chain-4096", np.arange(512, dtype=np.int64))
+            buses[name] = ctx.bus(72 * 256)
+        for b in range(72):   # (config #3's chain is silent for its first 15,435 frames: its delay lines)
+            for name in which:
+                projs[name].step(buses[name], b * 256)
+        out = {name: buses[name].download().copy() for name in which}
+        for name in which:
+            projs[name].destroy(); buses[name].destroy()
+        return out
+
+    ctxs = {"mixed": E.Context(0), "chain": E.Context(0)}
+    try:
+        together = walk(ctxs, ("mixed", "chain"))
+        alone = {**walk(ctxs, ("mixed",)), **walk(ctxs, ("chain",))}
+        for name in ("mixed", "chain"):
+            assert np.abs(alone[name]).max() > 1e-3
+            assert np.array_equal(together[name].view(np.uint32), alone[name].view(np.uint32)), name
+            assert ctxs[name].debug_info()["zero_segments"] == 0
+    finally:
+        for c in ctxs.values():
+            c.close()
