@@ -14,7 +14,9 @@
  *     return anyhow::Result, orchestrator.rs:263-304 — the library never aborts);
  *   - the caller owns host memory; the library owns device memory behind opaque handles;
  *   - handles are not thread-safe: one HIP stream per ctx, matching the reference's
- *     single-threaded audio path (orchestrator.rs:367-470);
+ *     single-threaded audio path (orchestrator.rs:367-470).  A ctx and everything created
+ *     from it belong to one thread at a time; different contexts are independent and may be
+ *     driven from different threads at once (tests/test_gpu_deferred.py::test_two_contexts_*);
  *   - device blocks are planar, frame-major fp32:  block[ch][frame][voice], ch 0 = left,
  *     so one wavefront's store is 64 consecutive floats; the bus is bus[frame][2];
  *   - note events and parameter changes take effect at the next block start, exactly the

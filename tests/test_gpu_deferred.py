@@ -884,3 +884,39 @@ def test_two_contexts_interleaved_on_one_device():
     finally:
         for c in ctxs.values():
             c.close()
+
+
+def test_two_contexts_on_two_threads():
+    """The ABI's threading contract (include/groove_hip.h: a ctx and its handles belong to one thread at a time; different contexts are
+    independent): two host threads, a context each, walking the same mixed project at the same time (ctypes releases the GIL inside every
+    call) — both buses equal the bus of a lone walk, bit for bit."""
+    import threading
+    from groove_amd import entities as E, projects as PJ
+
+    def walk(out, key):
+        ctx = E.Context(0)
+        try:
+            proj = PJ.Project(ctx, "mixed-131072", np.arange(6000, dtype=np.int64))
+            bus = ctx.bus(40 * 256)
+            for b in range(40):
+                proj.step(bus, b * 256)
+            out[key] = (bus.download().copy(), ctx.debug_info()["zero_segments"])
+            proj.destroy(); bus.destroy()
+        except Exception as e:   # noqa: BLE001
+            out[key] = e
+        finally:
+            ctx.close()
+
+    res = {}
+    walk(res, "alone")
+    threads = [threading.Thread(target=walk, args=(res, k)) for k in ("a", "b")]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    for k in ("alone", "a", "b"):
+        assert not isinstance(res.get(k), Exception) and res.get(k) is not None, (k, res.get(k))
+        assert res[k][1] == 0
+    assert np.abs(res["alone"][0]).max() > 1e-2
+    for k in ("a", "b"):
+        assert np.array_equal(res[k][0].view(np.uint32), res["alone"][0].view(np.uint32)), k
