@@ -7,6 +7,7 @@ import numpy as np
 
 from groove_amd import patches as P, abi_types as T
 from tests.emul import emul as E
+from tests.seeds import drawn_seeds
 
 
 def _render(bank_o, bank_e, on, off, blocks, off_block, frames=256):
@@ -341,7 +342,7 @@ def test_random_patches_emulated_device_arithmetic_against_the_oracle(oracle):
     n, blocks, off_at = 32, 40, 24
     lanes = np.arange(n, dtype=np.uint32)
     worst = 0.0
-    for seed in range(int(os.environ.get("GROOVE_TEST_SEEDS", "10"))):
+    for seed in drawn_seeds(10):
         rng = np.random.default_rng(seed)
         patches = [P.random_welsh_patch(rng) for _ in range(8)]
         params = (T.WelshParams * n)(*[patches[(i // 4) % 8] for i in range(n)])

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from groove_amd import patches as P, abi_types as T
+from tests.seeds import drawn_seeds
 
 pytestmark = pytest.mark.gpu
 
@@ -684,8 +685,8 @@ def test_allpass_stream_random_walks(gpu_ctx, oracle):
         gpu_ctx.fx_allpass_stream = False
         return seen
 
-    sounding, n_seeds = 0, int(os.environ.get("GROOVE_TEST_SEEDS", "16"))
-    for seed in range(n_seeds):   # (a campaign of 1,000 seeds ran clean at the end of round 5)
+    sounding, seeds = 0, drawn_seeds(16)
+    for seed in seeds:   # (a campaign of 1,000 seeds ran clean at the end of round 5)
         a, b = play(seed, False), play(seed, True)
         assert len(a) == len(b), seed
         sounding += int(np.abs(a[-1]).max() > 1e-3)   # (a reset late in a walk can leave the chains' delay lines silent to its end: seed 131)
@@ -697,7 +698,7 @@ def test_allpass_stream_random_walks(gpu_ctx, oracle):
         # <= 1e-5 of the larger of 1 and the bus's own peak (the chains have gain)
         err = np.sqrt(np.mean(((ref.astype(np.float64) - want) / 192) ** 2))
         assert err <= 1e-5 * max(1.0, float(np.abs(want).max()) / 192), (seed, err)
-    assert sounding >= 0.9 * n_seeds
+    assert sounding >= 0.9 * len(seeds)
     assert gpu_ctx.debug_info()["zero_segments"] == 0
 
 
@@ -844,8 +845,8 @@ def test_random_walks_of_the_fused_call_forms_against_the_plain_walk(oracle):
         finally:
             ctx.close()
 
-    n_seeds = int(os.environ.get("GROOVE_TEST_SEEDS", "10"))   # (a campaign of 300 seeds ran clean at the end of round 5)
-    for seed in range(n_seeds):
+    seeds = drawn_seeds(10)   # (a campaign of 300 seeds ran clean at the end of round 5)
+    for seed in seeds:
         (want, n_sel), (got, _) = play(seed, True), play(seed, False)
         scale = max(1.0, float(np.abs(want).max()))
         assert float(np.abs(want).max()) > 0.05, seed

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from groove_amd import patches as P, abi_types as T
+from tests.seeds import drawn_seeds
 
 pytestmark = pytest.mark.gpu
 
@@ -407,8 +408,8 @@ def test_random_chains_fused_equal_stage_by_stage_and_follow_the_oracle(gpu_ctx,
             kw["wet"] = 1.0 if rng.random() < 0.7 else lane(0.3, 1.0)      # (all wet: the combs ride in the fused run)
         return k, _params(n, **kw)
 
-    n_seeds = int(os.environ.get("GROOVE_TEST_SEEDS", "8"))   # (a campaign of 300 seeds ran clean at the end of round 5)
-    for seed in range(n_seeds):
+    seeds = drawn_seeds(8)   # (a campaign of 300 seeds ran clean at the end of round 5)
+    for seed in seeds:
         rng = np.random.default_rng(1000 + seed)
         n = int(rng.choice([3, 64, 130, 1000, 1500]))
         only_linear = rng.random() < 0.5
@@ -467,7 +468,7 @@ def test_random_linear_chains_at_other_sample_rates(oracle):
     from groove_amd import entities as E
     linear = [T.FX_GAIN, T.FX_BIQUAD_LP12, T.FX_BIQUAD_LP24, T.FX_CHORUS, T.FX_DELAY, T.FX_REVERB, T.FX_BIQUAD_HP12, T.FX_BIQUAD_BP12,
               T.FX_BIQUAD_PEAK12, T.FX_BIQUAD_LSHELF12, T.FX_BIQUAD_HSHELF12]
-    for seed in range(int(os.environ.get("GROOVE_TEST_SEEDS", "3"))):   # (60 seeds ran clean at the end of round 5)
+    for seed in drawn_seeds(3):   # (60 seeds ran clean at the end of round 5)
         rng = np.random.default_rng(7000 + seed)
         sr = int(rng.choice([22050, 48000, 96000]))
         n = int(rng.choice([5, 64, 600]))

@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 from groove_amd import patches as P, abi_types as T
+from tests.seeds import drawn_seeds
 
 pytestmark = pytest.mark.gpu
 
@@ -304,7 +305,7 @@ def test_random_fm_patches_against_the_oracle(gpu_ctx, oracle, kernel_form):
     from groove_amd import entities as E
     n, blocks = 48, 40
     lanes = np.arange(n, dtype=np.uint32)
-    for seed in range(int(os.environ.get("GROOVE_TEST_SEEDS", "6"))):   # (400 seeds ran clean at the end of round 5)
+    for seed in drawn_seeds(6):   # (400 seeds ran clean at the end of round 5)
         rng = np.random.default_rng(seed)
         ps = []
         for _ in range(n):
@@ -347,7 +348,7 @@ def test_random_sampler_walks_are_exact(gpu_ctx, oracle, kernel_form):
     from groove_amd import entities as E
     pcm, descs, lengths = P.drum_bank(scale=0.03)
     n = 200
-    for seed in range(int(os.environ.get("GROOVE_TEST_SEEDS", "6"))):   # (300 seeds ran clean at the end of round 5)
+    for seed in drawn_seeds(6):   # (300 seeds ran clean at the end of round 5)
         rng = np.random.default_rng(seed)
         params = (T.SamplerParams * n)(*[T.SamplerParams(int(rng.integers(len(descs))), int(rng.random() < 0.7), float(rng.uniform(0.1, 1.0))) for _ in range(n)])
         s, ob = E.Sampler(gpu_ctx, pcm, descs, params), oracle.Bank.sampler(pcm, descs, params)

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from groove_amd import patches as P, abi_types as T
+from tests.seeds import drawn_seeds
 
 pytestmark = pytest.mark.gpu
 
@@ -494,8 +495,8 @@ def test_random_graphs_every_walk_of_the_orchestrator_agrees():
             o.control_trip_add_step(trip, H.STEP_FLAT, b, b, 0.25)
         return rng
 
-    n_seeds = int(os.environ.get("GROOVE_TEST_SEEDS", "6"))   # (a campaign of 150 seeds ran clean at the end of round 5)
-    for seed in range(n_seeds):
+    seeds = drawn_seeds(6)   # (a campaign of 150 seeds ran clean at the end of round 5)
+    for seed in seeds:
         outs = {}
         for ahead, fused in ((False, False), (True, False), (False, True), (True, True)):
             o = H.Orchestrator(0, 44100, 128.0)
@@ -554,7 +555,7 @@ def test_random_graphs_against_the_oracle_graph(oracle):
                     self.busy[i] = now + self.rel
             return out
 
-    for seed in range(int(os.environ.get("GROOVE_TEST_SEEDS", "6"))):   # (150 seeds ran clean at the end of round 5)
+    for seed in drawn_seeds(6):   # (150 seeds ran clean at the end of round 5)
         rng = np.random.default_rng(5000 + seed)
         block = int(rng.choice([256, 256, 64, 100]))    # (events are block-granular: every block size is its own performance, on both sides)
         o, g = H.Orchestrator(0, sr, bpm), oracle.Graph(sr)

@@ -1,11 +1,12 @@
 """GPU tier: Welsh parity tests whose INPUTS are drawn from a seed — patches (every continuous parameter), note-event scripts, control changes
-on a sounding bank — through every kernel form against the f64 oracle.  GROOVE_TEST_SEEDS sets how many seeds each test plays (the tier's
+on a sounding bank — through every kernel form against the f64 oracle.  GROOVE_TEST_SEEDS / GROOVE_TEST_SEED_BASE (tests/seeds.py) set how many seeds each test plays and from where (the tier's
 defaults are small; docs/HISTORY.md section 10 items 17 - 22 say what campaigns of hundreds found).  The tests pick the kernel forms
 themselves (the ABI's tuning knobs), so they run once each."""
 import numpy as np
 import pytest
 
 from groove_amd import patches as P, abi_types as T
+from tests.seeds import drawn_seeds
 
 pytestmark = pytest.mark.gpu
 
@@ -23,7 +24,7 @@ def test_random_patches_every_kernel_form_against_the_oracle(gpu_ctx, oracle):
     old = (gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves, gpu_ctx.pipeline_min_waves)
     lanes = np.arange(n, dtype=np.uint32)
     try:
-        for seed in range(int(os.environ.get("GROOVE_TEST_SEEDS", "6"))):   # (60 seeds ran clean at the end of round 5)
+        for seed in drawn_seeds(6):   # (60 seeds ran clean at the end of round 5)
             rng = np.random.default_rng(seed)
             patches = [P.random_welsh_patch(rng) for _ in range(8)]
             params = (T.WelshParams * n)(*[patches[(i // 8) % 8] for i in range(n)])
@@ -78,7 +79,7 @@ def test_random_note_event_sequences_in_every_kernel_form(gpu_ctx, oracle):
     params = P.welsh_voices(n)
     old = (gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves, gpu_ctx.pipeline_min_waves)
     try:
-        for seed in range(int(os.environ.get("GROOVE_TEST_SEEDS", "4"))):   # (100 seeds ran clean at the end of round 5)
+        for seed in drawn_seeds(4):   # (100 seeds ran clean at the end of round 5)
             rng = np.random.default_rng(seed)
             script, sizes = [], []
             for b in range(blocks):
@@ -142,7 +143,7 @@ def test_random_controls_on_a_sounding_bank_in_every_kernel_form(gpu_ctx, oracle
     keys = (36 + (7 * np.arange(n)) % 49).astype(np.uint8)
     old = (gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves, gpu_ctx.pipeline_min_waves)
     try:
-        for seed in range(int(os.environ.get("GROOVE_TEST_SEEDS", "4"))):   # (100 seeds ran clean at the end of round 5)
+        for seed in drawn_seeds(4):   # (100 seeds ran clean at the end of round 5)
             rng = np.random.default_rng(seed)
             script, sizes = [], []
             for b in range(blocks):
@@ -198,7 +199,7 @@ def test_random_patches_at_other_sample_rates(oracle):
     from groove_amd import entities as E
     n, blocks, off_at = 64, 30, 18
     lanes = np.arange(n, dtype=np.uint32)
-    for seed in range(int(os.environ.get("GROOVE_TEST_SEEDS", "3"))):   # (60 seeds ran clean at the end of round 5)
+    for seed in drawn_seeds(3):   # (60 seeds ran clean at the end of round 5)
         rng = np.random.default_rng(900 + seed)
         sr = int(rng.choice([22050, 48000, 96000]))
         patches = [P.random_welsh_patch(rng) for _ in range(8)]
