@@ -81,6 +81,10 @@ inline WelshParams derive_welsh(const groove_welsh_params& p, double sr, WelshCo
   o.amp = derive_env(p.amp_envelope, sr);
   o.fil = derive_env(p.filter_envelope, sr);
   o.fc = derive_lp24_consts((double)p.filter_passband_ripple);
+  // a retuned filter with c below 1/512 (ripple above ~3.8) takes its per-frame coefficients in the two-sided form (dsp_core.h WF_COEF_WIDE):
+  // the one-sided form the fast kinds carry is measured 4e-7 off the oracle at ripple 3.5, 9e-7 at 4.0, 4e-6 at 5, 7e-5 at 7.1
+  // (tools/reference_patches_emul.py: the reference's penny-whistle patch)
+  if ((o.flags & (WF_RETUNE_ENV | WF_LFO_CUTOFF)) && o.fc.c0 < 1.0f / 512.0f) o.flags |= WF_COEF_WIDE;
   o.ripple = p.filter_passband_ripple;
   o.cutoff_hz = p.filter_cutoff_hz;
   o.cutoff_start = p.filter_cutoff_start;
@@ -147,7 +151,7 @@ inline double welsh_filter_f32_error(const WelshParams& o, double sr) {
 }
 constexpr double kFilterF32MaxError = 2e-6; // (5e-6 / 6e-6 / 1e-5 were measured and rejected: profiles/r05_f32_threshold_ab.log, docs/DSP_SPEC.md section 11)
 inline bool welsh_filter_f32_ok(const WelshParams& o, double sr) {
-  if (o.flags & WF_LFO_RESO) return false; // the ripple moves every frame: the exact-f64 kind
+  if (o.flags & (WF_LFO_RESO | WF_COEF_WIDE)) return false; // the ripple moves every frame / the two-sided coefficient form: the exact-f64 kind
   const double e = welsh_filter_f32_error(o, sr);
   return e == e && e <= kFilterF32MaxError;
 }

@@ -335,42 +335,11 @@ struct Lp24Consts { float c0, d1, c2, d3; };
 // of q1 = 2 + a1, q2 = 1 + a2 written in t = 1/k.  Both cases are one formula in
 // t = min(k, 1/k):   D' = Q + d t + P,  b0 = N / D',  q1 = 2 (d t + 2 P) / D',  q2 = 2 d t / D'
 // with (P, Q, N) = (t^2, c, t^2) below and (c t^2, 1, 1) above; a1 = sgn (2 - q1), a2 = q2 - 1.
-struct Lp24Coef { float b0a, q1a, q2a, b0b, q1b, q2b, sgn; };
-GROOVE_HD Lp24Coef lp24_coef_from_t(const Lp24Consts& c, float t, bool hi) {
-  const float T2 = t * t;
-  const float Pa = hi ? c.c0 * T2 : T2, Qa = hi ? 1.0f : c.c0;
-  const float Pb = hi ? c.c2 * T2 : T2, Qb = hi ? 1.0f : c.c2;
-  const float N = hi ? 1.0f : T2;
-  const float dta = c.d1 * t, dtb = c.d3 * t;
-  const float ia = fast_rcp(Qa + dta + Pa);
-  const float ib = fast_rcp(Qb + dtb + Pb);
-  Lp24Coef o;
-  o.b0a = N * ia; o.q1a = 2.0f * (dta + 2.0f * Pa) * ia; o.q2a = 2.0f * dta * ia;
-  o.b0b = N * ib; o.q1b = 2.0f * (dtb + 2.0f * Pb) * ib; o.q2b = 2.0f * dtb * ib;
-  o.sgn = hi ? -1.0f : 1.0f;
-  return o;
-}
-// Coefficients for cutoff fc (Hz); pi_over_sr = pi / SR; fc clamped to [1, 0.49 SR].
-GROOVE_HD Lp24Coef lp24_coef_from_fc(const Lp24Consts& c, float fc, float pi_over_sr, float fc_max) {
-  fc = fminf(fmaxf(fc, 1.0f), fc_max);
-  bool hi;
-  const float t = tan_reduced(fc * pi_over_sr, hi);
-  return lp24_coef_from_t(c, t, hi);
-}
 struct Lp24StateD { double s0, s1, s2, s3; };
 // f64 coefficient set derived from the fp32 small-quantity form (exact conversions).
 struct Lp24CoefD { double b0a, a1a, a2a, b0b, a1b, a2b; };
-GROOVE_HD Lp24CoefD lp24_widen(const Lp24Coef& c) {
-  Lp24CoefD d;
-  const double sg = (double)c.sgn;
-  d.b0a = (double)c.b0a; d.a1a = sg * (2.0 - (double)c.q1a); d.a2a = (double)c.q2a - 1.0;
-  d.b0b = (double)c.b0b; d.a1b = sg * (2.0 - (double)c.q1b); d.a2b = (double)c.q2b - 1.0;
-  return d;
-}
-// The two steps above in one, branching on the side of SR/4 instead of selecting per term (on the
-// device the upper side is an exec-mask region that a wave with no lane above SR/4 skips), and with
-// the sign folded into the f64 subtraction (q - 2 == -(2 - q) exactly).  Same operations on the
-// same values in either case, so the result is bit-identical to lp24_widen(lp24_coef_from_fc(...)).
+// Coefficients for cutoff fc (Hz); pi_over_sr = pi / SR; fc clamped to [1, 0.49 SR].  The fp32 quotients, widened exactly; the
+// upper side of SR/4 is an exec-mask region that a wave with no lane above SR/4 skips.
 GROOVE_HD Lp24CoefD lp24_coefd_from_fc(const Lp24Consts& c, float fc, float pi_over_sr, float fc_max) {
   fc = fminf(fmaxf(fc, 1.0f), fc_max);
   bool hi;
@@ -379,10 +348,18 @@ GROOVE_HD Lp24CoefD lp24_coefd_from_fc(const Lp24Consts& c, float fc, float pi_o
   const float dta = c.d1 * t, dtb = c.d3 * t;
   Lp24CoefD d;
   if (!hi) {
-    const float ia = fast_rcp(c.c0 + dta + T2);
-    const float ib = fast_rcp(c.c2 + dtb + T2);
-    d.b0a = (double)(T2 * ia); d.a1a = 2.0 - (double)(2.0f * (dta + 2.0f * T2) * ia); d.a2a = (double)(2.0f * dta * ia) - 1.0;
-    d.b0b = (double)(T2 * ib); d.a1b = 2.0 - (double)(2.0f * (dtb + 2.0f * T2) * ib); d.a2b = (double)(2.0f * dtb * ib) - 1.0;
+    // q1 = 2 - a1 is the small quantity while the pole pair sits towards z = +1 (k^2 <= c + d k).  A section whose c is far below
+    // k^2 (ripples above ~4: c = 1 / (cosh^2 r - ..) ~ 1e-3 .. 1e-9) has its poles towards z = -1 on THIS side of SR/4 too: b0 -> 1,
+    // q1 -> 4, and 2 - q1 cancels (a reference patch with ripple 7.1 under a cutoff sweep played 6e-5 off the oracle through that;
+    // docs/HISTORY.md section 10 item 27).  There the small quantity is 2 + a1 = q2 + 4 c / D.
+    const float sa = c.c0 + dta, sb = c.c2 + dtb;
+    const float ia = fast_rcp(sa + T2);
+    const float ib = fast_rcp(sb + T2);
+    const double q2a = (double)(2.0f * dta * ia), q2b = (double)(2.0f * dtb * ib);
+    d.b0a = (double)(T2 * ia); d.a2a = q2a - 1.0;
+    d.b0b = (double)(T2 * ib); d.a2b = q2b - 1.0;
+    d.a1a = T2 > sa ? fma(4.0, (double)(c.c0 * ia), q2a - 2.0) : 2.0 - (double)(2.0f * (dta + 2.0f * T2) * ia);
+    d.a1b = T2 > sb ? fma(4.0, (double)(c.c2 * ib), q2b - 2.0) : 2.0 - (double)(2.0f * (dtb + 2.0f * T2) * ib);
   } else {
     const float Pa = c.c0 * T2, Pb = c.c2 * T2;
     const float ia = fast_rcp(1.0f + dta + Pa);
@@ -666,6 +643,7 @@ enum : uint32_t {
   // reach, amplitude, cutoff percent, passband ripple.
   WF_LFO_PITCH = 1u << 20, WF_LFO_PW = 1u << 21, WF_LFO_O1 = 1u << 22, WF_LFO_O2 = 1u << 23,
   WF_LFO_AMP = 1u << 24, WF_LFO_CUTOFF = 1u << 25, WF_LFO_RESO = 1u << 26,
+  WF_COEF_WIDE = 1u << 28, // host (derive.h): a RETUNED filter whose section constant c is below 1/512 (ripple above ~3.8): its poles sit towards z = -1 at any cutoff above c's own, and the per-frame coefficients take lp24_coefd_from_fc's two-sided form in the exact-f64 kind (welsh_lfo_mode)
   WF_FILTER_F32 = 1u << 27 // host promise (derive.h welsh_filter_f32_ok): the fp32 filter recurrence stays within 2e-6 of the f64 one over this patch's cutoff range
 };
 GROOVE_HD uint32_t lfo_routing_bits(uint32_t routing) {
@@ -745,7 +723,7 @@ enum : int { LFO_F32 = 0, LFO_F64 = 1, LFO_F64_SMOOTH = 2 };
 GROOVE_HD int welsh_lfo_mode(const WelshParams& p) {
   // the resonance routing (per-frame sinh / cosh) is only compiled into the exact-f64 retuned kind: rare, and
   // it keeps the other five kinds free of its code and registers
-  if (p.flags & WF_LFO_RESO) return LFO_F64;
+  if (p.flags & (WF_LFO_RESO | WF_COEF_WIDE)) return LFO_F64; // (WF_COEF_WIDE: the two-sided coefficient form lives there too)
   if (!(p.flags & (WF_LFO_PITCH | WF_LFO_PW))) return LFO_F32;
   return (p.flags & WF_LFO_SMOOTH) ? LFO_F64_SMOOTH : LFO_F64;
 }
@@ -1054,10 +1032,16 @@ GROOVE_HD void welsh_frame_coef(const WelshParams& p, const RenderConsts& rc, We
   if (RETUNE) {
     constexpr bool RESO = LFO_MODE == LFO_F64 && RETUNE;
     const bool r_res = RESO && CL != LFO_UNUSED ? (p.flags & WF_LFO_RESO) != 0 : false;
+    const bool r_wide = RESO ? (p.flags & WF_COEF_WIDE) != 0 : false;
     if (RESO && r_res) { // the ripple moves every frame: constants and coefficients are recomputed
       const Lp24Consts c = lp24_consts_from_ripple(p.ripple * fmaf(lfo, p.lfo_depth, 1.0f));
       const float fc = retune ? 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f) : p.cutoff_hz;
       sc.coef = lp24_coefd_from_fc(c, fc, rc.pi_over_sr, rc.fc_max);
+    } else if (RESO && r_wide) { // WF_COEF_WIDE: the two-sided form, from the patch's own constants
+      if (retune && pct != sc.prev_pct) {
+        sc.coef = lp24_coefd_from_fc(p.fc, 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f), rc.pi_over_sr, rc.fc_max);
+        sc.prev_pct = pct;
+      }
     } else if (retune && pct != sc.prev_pct) { // unchanged percent (e.g. envelope plateau): coefficients stand
       sc.coef = lp24_coefd_from_pct(p.fc, pct, rc);
       sc.prev_pct = pct;

@@ -518,7 +518,7 @@ int welsh_upload_params(groove_bank* b, bool regroup) {
       const WelshParams& o = Pext[v];
       Key k{};
       k.c0 = o.fc.c0; k.d1 = o.fc.d1; k.c2 = o.fc.c2; k.d3 = o.fc.d3; k.hz = o.cutoff_hz; k.start = o.cutoff_start; k.end = o.cutoff_end;
-      k.depth = (o.flags & WF_LFO_CUTOFF) ? o.lfo_depth : 0.0f; k.bits = o.flags & (WF_RETUNE_ENV | WF_LFO_CUTOFF | WF_LFO_RESO);
+      k.depth = (o.flags & WF_LFO_CUTOFF) ? o.lfo_depth : 0.0f; k.bits = o.flags & (WF_RETUNE_ENV | WF_LFO_CUTOFF | WF_LFO_RESO | WF_COEF_WIDE);
       auto it = memo.find(k);
       // (~0.6 ms per distinct filter description: a bank of more than 4,096 of them — no project of the reference's shape, one patch
       // per synth — keeps the f64 recurrence, always safe, for the descriptions beyond, instead of seconds of measuring at upload)
@@ -569,7 +569,7 @@ int welsh_upload_params(groove_bank* b, bool regroup) {
   b->tp_pairs = true; // time-parallel form, two voices per wavefront: voices 2i and 2i + 1 share their parameter words
   for (uint32_t i = 0; i + 1 < n && b->tp_pairs; i += 2) b->tp_pairs = std::memcmp(&P[i], &P[i + 1], sizeof(WelshParams)) == 0;
   b->tp_full_coef = false; // time-parallel form: a voice with the resonance routing keeps six f64 coefficients per frame (welsh_tp.h)
-  for (uint32_t i = 0; i < n; ++i) if (P[i].flags & WF_LFO_RESO) { b->tp_full_coef = true; break; }
+  for (uint32_t i = 0; i < n; ++i) if (P[i].flags & (WF_LFO_RESO | WF_COEF_WIDE)) { b->tp_full_coef = true; break; }
   // Virtual waves: maximal runs of consecutive voices with identical parameter words, cut at 64.
   std::vector<WaveDesc> W;
   W.reserve((size_t)n / 64 + 64);

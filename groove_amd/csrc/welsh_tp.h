@@ -184,6 +184,11 @@ GROOVE_HD void welsh_tp_frame(const WelshParams& p, WelshState& s, const RenderC
       const Lp24Consts c = lp24_consts_from_ripple(p.ripple * fmaf(lfo, p.lfo_depth, 1.0f));
       const float fc = retune ? 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f) : p.cutoff_hz;
       coef = lp24_coefd_from_fc(c, fc, rc.pi_over_sr, rc.fc_max);
+    } else if (RESO && (fl & WF_COEF_WIDE)) { // welsh_frame_coef's third case: the two-sided form from the patch's own constants
+      if (retune && pct != prev_pct) {
+        coef = lp24_coefd_from_fc(p.fc, 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f), rc.pi_over_sr, rc.fc_max);
+        prev_pct = pct;
+      }
     } else if (retune && pct != prev_pct) {
       t_out = lp24_t_from_pct(pct, rc, hi_out); // (lp24_coefd_from_pct in its two halves)
       coef = lp24_coefd_from_t(p.fc, t_out, hi_out);

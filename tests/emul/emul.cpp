@@ -370,12 +370,11 @@ uint32_t emul_segment_begin_of(const groove_welsh_params* p, uint32_t sr, const 
   return welsh_segment_begin(wp, s, live);
 }
 float emul_bitcrush(float x, uint32_t bits) { return bitcrush(x, bits); }
-// both forms of the 24 dB coefficient computation (dsp_core.h): out[0..5] two-step, out[6..11] fused
+// the device's 24 dB coefficients (dsp_core.h lp24_coefd_from_fc) and the same in f64 throughout (derive.h lp24_coeffs_h): out[0..5], out[6..11]
 void emul_lp24_coef_both(double ripple, float fc, float sr, double* out) {
   const Lp24Consts c = derive_lp24_consts(ripple);
-  const Lp24CoefD a = lp24_widen(lp24_coef_from_fc(c, fc, 3.14159265358979323846f / sr, 0.49f * sr));
-  const Lp24CoefD b = lp24_coefd_from_fc(c, fc, 3.14159265358979323846f / sr, 0.49f * sr);
+  const Lp24CoefD a = lp24_coefd_from_fc(c, fc, (float)(3.14159265358979323846 / sr), (float)(0.49 * sr));
   std::memcpy(out, &a, sizeof a);
-  std::memcpy(out + 6, &b, sizeof b);
+  lp24_coeffs_h((double)fc, ripple, (double)sr, out + 6);
 }
 }
