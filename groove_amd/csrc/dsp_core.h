@@ -152,10 +152,19 @@ GROOVE_HD uint64_t turns_to_phase(double turns) {
   double frac = turns - fl; // [0,1)
   return (uint64_t)(frac * 18446744073709551616.0);
 }
-// signed increment: turns may be negative (FM through zero); two's complement add.
+// signed increment: turns may be negative (FM through zero); two's complement add.  Whole turns drop out (the oracle's pos -= floor(pos)):
+// an FM index of 100 on A4 — the reference's own demo project — swings the carrier past a whole turn per frame, and a u64 conversion of
+// 2^64 or more is not a wrap (docs/HISTORY.md section 10 item 29).  |turns| < 1 passes through fract() unchanged: the same bits as before.
+GROOVE_HD double fract_f64(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_fract(x);
+#else
+  return x - floor(x);
+#endif
+}
 GROOVE_HD uint64_t turns_to_inc(double turns) {
-  if (turns >= 0.0) return (uint64_t)(turns * 18446744073709551616.0);
-  return (uint64_t)0 - (uint64_t)(-turns * 18446744073709551616.0);
+  if (turns >= 0.0) return (uint64_t)(fract_f64(turns) * 18446744073709551616.0);
+  return (uint64_t)0 - (uint64_t)(fract_f64(-turns) * 18446744073709551616.0);
 }
 
 // ------------------------------------------------------------------ Oscillator (a1)

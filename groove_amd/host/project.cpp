@@ -219,9 +219,12 @@ ProjectDesc parse_project(const std::string& text, const std::string& assets_roo
       d.kind = pair.arr[1]->obj[0].first;
       const json5::Value& body = *pair.arr[1]->obj[0].second;
       if (cls == "instrument") {
-        if (!body.is_array() || body.arr.size() != 2) { p.warnings.push_back("malformed instrument " + d.id); continue; }
+        // [midi, params] (instruments.rs:26-39: tuple variants); the FM demos of the generation before (projects/demos/instruments/
+        // fm-synthesizer-beta-*.json) carry ONE object, {"midi-in": .., "voice": {..}}: taken as the same two things
+        const bool flat = body.is_array() && body.arr.size() == 1 && body.arr[0]->is_object() && body.arr[0]->get("voice") && body.arr[0]->get("voice")->is_object();
+        if (!flat && (!body.is_array() || body.arr.size() != 2)) { p.warnings.push_back("malformed instrument " + d.id); continue; }
         d.midi_in = (int)json5::to_int(body.arr[0]->number_or("midi-in", 0), 0, 255, 0);
-        const json5::Value& params = *body.arr[1];
+        const json5::Value& params = flat ? *body.arr[0]->get("voice") : *body.arr[1];
         if (d.kind == "welsh") {
           d.name = params.string_or("name", "");
           const std::string path = assets_root + "/patches/welsh/" + patch_name_to_settings_name(d.name) + ".json";

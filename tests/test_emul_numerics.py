@@ -40,6 +40,25 @@ def test_fm_arithmetic(oracle):
     assert np.sqrt(np.mean((e - o) ** 2, axis=(0, 1))).max() <= 1e-5
 
 
+def test_fm_index_of_the_reference_demo_projects(oracle):
+    """tests/test_gpu_instruments.py's test of the same name on the emulated device arithmetic: ratio 2, depth 1, beta up to 100 on A4 and
+    above — the carrier advances by more than a whole turn per frame, which the 64-bit phase counter has to drop as the oracle's floor does."""
+    ps, ks = [], []
+    for beta in (0.0, 0.1, 1.0, 10.0, 100.0):
+        for key in (45, 57, 60, 69, 72, 81, 93, 100):
+            p = T.FmParams()
+            p.ratio, p.depth, p.beta = 2.0, 1.0, beta
+            p.carrier_envelope = T.EnvelopeParams(0.0, 0.0, 1.0, 0.0)
+            p.modulator_envelope = T.EnvelopeParams(0.0, 0.0, 1.0, 0.0)
+            p.dca_gain, p.dca_pan = 1.0, 0.0
+            ps.append(p); ks.append(key)
+    n = len(ps)
+    params, lanes = (T.FmParams * n)(*ps), np.arange(n, dtype=np.uint32)
+    on = T.note_events_np(lanes, np.array(ks, dtype=np.uint8), True)
+    o, e = _render(oracle.Bank.fm(params), E.Bank.fm(params), on, on, 172, 10 ** 6)
+    assert np.sqrt(np.mean((e - o) ** 2, axis=(0, 1))).max() <= 1e-6
+
+
 def test_sampler_fetch_is_exact(oracle):
     n = 120
     pcm, descs, _ = P.drum_bank(scale=0.02)

@@ -52,6 +52,40 @@ def _fm_parity(gpu_ctx, oracle, E):
     synth.destroy(); block.destroy()
 
 
+def test_fm_index_of_the_reference_demo_projects(gpu_ctx, oracle, kernel_form):
+    """The parameter sets of the reference's FM demo projects (projects/demos/instruments/fm-synthesizer-beta-*.json: ratio 2, depth 1, beta
+    0 / 0.1 / 1 / 10 / 100, flat envelopes, one long A4) on the demo's key and others up to 93.  An index of 100 on A4 swings the carrier to
+    101 x 440 Hz — more than a whole turn per frame; the oracle's phase drops whole turns (`pos -= floor(pos)`), and so must the device's
+    64-bit counter (dsp_core.h turns_to_inc; until the end of round 5 it converted 2^64 and more to u64: every key from 69 up played 0.74
+    off at beta 100).  Both forms of the FM render, 172 blocks, <= 1e-5 RMS per voice."""
+    from groove_amd import entities as E
+    betas, keys = (0.0, 0.1, 1.0, 10.0, 100.0), (45, 57, 60, 69, 72, 81, 93, 100)
+    ps, ks = [], []
+    for beta in betas:
+        for key in keys:
+            p = T.FmParams()
+            p.ratio, p.depth, p.beta = 2.0, 1.0, beta
+            p.carrier_envelope = T.EnvelopeParams(0.0, 0.0, 1.0, 0.0)
+            p.modulator_envelope = T.EnvelopeParams(0.0, 0.0, 1.0, 0.0)
+            p.dca_gain, p.dca_pan = 1.0, 0.0
+            ps.append(p); ks.append(key)
+    n = len(ps)
+    params, keys_np, lanes = (T.FmParams * n)(*ps), np.array(ks, dtype=np.uint8), np.arange(n, dtype=np.uint32)
+    synth, ob = E.FmSynth(gpu_ctx, params), oracle.Bank.fm(params)
+    block = gpu_ctx.block(n, 256)
+    ev = T.note_events_np(lanes, keys_np, True)
+    synth.handle_midi_events(ev); ob.note_events(ev)
+    got, want = [], []
+    for b in range(172):
+        synth.generate_batch_values(block, 256)
+        got.append(block.download(256)); want.append(ob.render(256))
+    got = np.concatenate(got, axis=1).astype(np.float64); want = np.concatenate(want, axis=1)
+    rms = np.sqrt(np.mean((got - want) ** 2, axis=(0, 1)))
+    assert np.sqrt(np.mean(want ** 2, axis=(0, 1))).min() > 0.1
+    assert rms.max() <= 1e-5, (int(np.argmax(rms)), float(rms.max()), betas[int(np.argmax(rms)) // len(keys)], ks[int(np.argmax(rms))])
+    synth.destroy(); block.destroy()
+
+
 def test_fm_four_voices_per_wavefront_parity(gpu_ctx, oracle, kernel_form):
     """The FM kernel's four-voices-per-wavefront form (16 lanes x 16 frames per voice; banks of 4,096 voices and more by
     default) forced for a 50-voice bank by GROOVE_FM_TP_VPW4_MIN_VOICES=1 in a context of its own: the per-voice parity test

@@ -95,6 +95,19 @@ def test_reference_demo_projects_parse(host):
     assert ok >= 30, (ok, schema_fail[:5])
 
 
+@pytest.mark.skipif(not os.path.exists(REF), reason="reference tree not present")
+def test_fm_demo_projects_of_both_generations_load_their_synth(host):
+    """projects/demos/instruments/fm-synthesizer*.json: one file in the current [midi, params] form, five (the beta sweep 0 - 100) with one
+    object {"midi-in", "voice": {..}} — each yields its FM synth, its gain and its one note (the beta-100 file is what found the carrier's
+    whole-turn wrap: tests/test_gpu_instruments.py::test_fm_index_of_the_reference_demo_projects)."""
+    files = sorted(glob.glob(f"{REF}/projects/demos/instruments/fm-synthesizer*.json"))
+    assert len(files) == 6
+    for f in files:
+        d = describe(host, path=f, assets=f"{REF}/assets")
+        assert [x["kind"] for x in d["devices"]] == ["fm-synthesizer", "gain"], f
+        assert d["warnings"] == 0 and d["n_notes"] >= 1, f
+
+
 def test_json5_syntax_and_errors(host):
     d = describe(host, text="{clock:{bpm:90,'time-signature':{top:3,bottom:4}},devices:[],/*c*/tracks:[],}")
     assert d["bpm"] == 90 and d["time_signature"] == [3, 4]
