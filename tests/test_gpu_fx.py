@@ -155,6 +155,49 @@ def test_limiter_compressor_mixer(gpu_ctx, oracle):
     assert np.array_equal(got, x)
 
 
+def test_effect_parameter_sets_of_the_reference_demo_projects(gpu_ctx, oracle):
+    """The parameter sets the reference's own demo projects give its effects (projects/demos/effects/*.json; values only): 12 dB filters at
+    1,000 Hz with q 0.707 and 20, bandwidths of 2, 30 and 2,000 Hz, shelf / peak gains of 6 and 30 dB, the swept low-pass's cutoffs from 20 kHz
+    down to its clamp, the 24 dB low-pass at 1,000 Hz over the ripple sweep, gain ceilings, limiter windows, bitcrusher depths 8 and 13, the
+    compressor's ratio 0.1 over its threshold ramp, chorus 4 x 0.25 s, delay 0.1 s, reverb 0.95 / 1.25 s — on a sine and on noise, the
+    demos' two sources, against the oracle (IIR: 4e-6 of the larger of 1 and the output's peak; the integer and copy effects exact)."""
+    frames_total = 8192
+    rng = np.random.default_rng(5)
+    t = np.arange(frames_total)
+    sine = 0.8 * np.sin(2 * np.pi * 440.0 * t / 44100.0)
+    noise = rng.uniform(-0.8, 0.8, frames_total)
+    iir = [(T.FX_BIQUAD_LP12, [dict(cutoff_hz=1000.0, q=q) for q in (0.707, 20.0)] + [dict(cutoff_hz=c, q=1.0) for c in (20000.0, 5000.0, 300.0, 20.0, 0.0)]),
+           (T.FX_BIQUAD_HP12, [dict(cutoff_hz=1000.0, q=q) for q in (0.707, 20.0)]),
+           (T.FX_BIQUAD_AP12, [dict(cutoff_hz=1000.0, q=q) for q in (0.707, 20.0)]),
+           (T.FX_BIQUAD_BP12, [dict(cutoff_hz=1000.0, bandwidth_hz=b) for b in (30.0, 2000.0)]),
+           (T.FX_BIQUAD_BS12, [dict(cutoff_hz=1000.0, bandwidth_hz=b) for b in (2.0, 30.0, 2000.0)]),
+           (T.FX_BIQUAD_PEAK12, [dict(cutoff_hz=1000.0, db_gain=g) for g in (6.0, 30.0)]),
+           (T.FX_BIQUAD_LSHELF12, [dict(cutoff_hz=1000.0, db_gain=g) for g in (6.0, 30.0)]),
+           (T.FX_BIQUAD_HSHELF12, [dict(cutoff_hz=1000.0, db_gain=g) for g in (6.0, 30.0)]),
+           (T.FX_BIQUAD_LP24, [dict(cutoff_hz=1000.0, passband_ripple=r) for r in (0.1, 0.25, 0.5, 0.75, 1.0)]),
+           (T.FX_REVERB, [dict(attenuation=0.95, reverb_seconds=1.25)]),
+           (T.FX_CHORUS, [dict(voices=4, delay_seconds=0.25)]),
+           (T.FX_COMPRESSOR, [dict(limit_min=th, limit_max=0.1) for th in (0.0, 0.25, 0.5, 1.0)])]
+    exact = [(T.FX_GAIN, [dict(ceiling=c) for c in (0.1, 0.5, 1.0, 0.0)]),
+             (T.FX_LIMITER, [dict(limit_min=a, limit_max=b) for a, b in ((0.1, 0.9), (0.4, 0.6))]),
+             (T.FX_BITCRUSHER, [dict(bits=b) for b in (8, 13)]),
+             (T.FX_DELAY, [dict(delay_seconds=0.1)])]
+    for kind, sets in iir + exact:
+        n = 2 * len(sets)   # each set on the sine and on the noise
+        x = np.empty((2, frames_total, n), dtype=np.float32)
+        x[:, :, 0::2] = sine[None, :, None]; x[:, :, 1::2] = noise[None, :, None]
+        x[:, frames_total * 3 // 4:, :] = 0.0
+        kws = [kw for kw in sets for _ in range(2)]
+        params = (T.FxParams * n)(*[T.fx_params(**kw) for kw in kws])
+        got, want = _run(gpu_ctx, oracle, kind, params, x)
+        assert np.isfinite(got).all() and np.abs(want).max() > 0.05, kind
+        if (kind, sets) in exact:
+            assert np.array_equal(got, want.astype(np.float32)), (kind, float(np.abs(got - want).max()))
+        else:
+            err = np.abs(got - want).max(axis=(0, 1)); peak = np.maximum(1.0, np.abs(want).max(axis=(0, 1)))
+            assert (err <= 4e-6 * peak).all(), (kind, kws[int(np.argmax(err / peak))], float((err / peak).max()))
+
+
 def test_config3_chain_bus_parity(gpu_ctx, oracle):
     """Config #3 shape at a size the oracle finishes in seconds: 64 Welsh voices, each through
     BiQuad LP12 → Chorus → Delay → Reverb, summed on the bus; 40 blocks.  Bus/V RMS <= 1e-5."""
