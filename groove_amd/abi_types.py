@@ -20,7 +20,7 @@ FX_GAIN, FX_BITCRUSHER, FX_BIQUAD_LP12, FX_BIQUAD_LP24, FX_CHORUS, FX_DELAY, FX_
     FX_BIQUAD_HP12, FX_LIMITER, FX_COMPRESSOR, FX_BIQUAD_BP12, FX_BIQUAD_BS12, FX_BIQUAD_AP12, FX_BIQUAD_PEAK12, \
     FX_BIQUAD_LSHELF12, FX_BIQUAD_HSHELF12 = range(17)
 # groove_control_index
-CTL_FX_CEILING, CTL_FX_BITS, CTL_FX_CUTOFF, CTL_FX_Q, CTL_FX_PASSBAND_RIPPLE, CTL_FX_ATTENUATION, CTL_FX_WET = range(7)
+CTL_FX_CEILING, CTL_FX_BITS, CTL_FX_CUTOFF, CTL_FX_Q, CTL_FX_PASSBAND_RIPPLE, CTL_FX_ATTENUATION, CTL_FX_WET, CTL_FX_THRESHOLD = range(8)
 CTL_WELSH_DCA_GAIN, CTL_WELSH_DCA_PAN, CTL_WELSH_CUTOFF = 32, 33, 34
 
 

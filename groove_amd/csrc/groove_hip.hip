@@ -2728,6 +2728,7 @@ int groove_fx_set_param(groove_fx* fx, uint32_t lane, uint32_t control_index, do
       case GROOVE_CTL_FX_PASSBAND_RIPPLE: p.passband_ripple = (float)(v * v * 10.0 + 0.707); break;
       case GROOVE_CTL_FX_ATTENUATION: p.attenuation = (float)v; break;
       case GROOVE_CTL_FX_WET: p.wet = (float)v; break;
+      case GROOVE_CTL_FX_THRESHOLD: p.limit_min = (float)v; break; /* Compressor threshold (limit_min doubles as it: groove_types.h) */
       default: return fail(ctx, "groove_fx_set_param: unknown control index");
     }
   }

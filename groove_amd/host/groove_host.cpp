@@ -98,7 +98,7 @@ int FxEffect::control_index_for_name(const std::string& name) const {
   static const std::pair<const char*, int> table[] = {
       {"ceiling", GROOVE_CTL_FX_CEILING}, {"bits", GROOVE_CTL_FX_BITS}, {"bits-to-crush", GROOVE_CTL_FX_BITS},
       {"cutoff", GROOVE_CTL_FX_CUTOFF}, {"q", GROOVE_CTL_FX_Q}, {"passband-ripple", GROOVE_CTL_FX_PASSBAND_RIPPLE},
-      {"attenuation", GROOVE_CTL_FX_ATTENUATION}, {"wet-dry-mix", GROOVE_CTL_FX_WET}};
+      {"attenuation", GROOVE_CTL_FX_ATTENUATION}, {"wet-dry-mix", GROOVE_CTL_FX_WET}, {"threshold", GROOVE_CTL_FX_THRESHOLD}};
   for (auto& t : table) if (name == t.first) return t.second;
   return -1;
 }

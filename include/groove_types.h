@@ -183,6 +183,7 @@ typedef enum {
   GROOVE_CTL_FX_PASSBAND_RIPPLE = 4, /* "passband-ripple"  */
   GROOVE_CTL_FX_ATTENUATION = 5,     /* "attenuation"      */
   GROOVE_CTL_FX_WET = 6,             /* "wet-dry-mix"      */
+  GROOVE_CTL_FX_THRESHOLD = 7,       /* "threshold" (Compressor; the reference's compressor demo ramps it) */
   GROOVE_CTL_WELSH_DCA_GAIN = 32,    /* "dca-gain"         */
   GROOVE_CTL_WELSH_DCA_PAN = 33,     /* "dca-pan"          */
   GROOVE_CTL_WELSH_CUTOFF = 34       /* "filter-cutoff" (value01 → Hz) */

@@ -93,6 +93,7 @@ void effect_set_control(Effect& fx, uint32_t index, double v) {
     case GROOVE_CTL_FX_PASSBAND_RIPPLE: fx.p.passband_ripple = (float)denormalize_q(v); break;
     case GROOVE_CTL_FX_ATTENUATION: fx.p.attenuation = (float)v; break;
     case GROOVE_CTL_FX_WET: fx.p.wet = (float)v; break;
+    case GROOVE_CTL_FX_THRESHOLD: fx.p.limit_min = (float)v; break;
     default: return;
   }
   fx.retune();

@@ -174,7 +174,7 @@ def test_effect_parameter_sets_of_the_reference_demo_projects(gpu_ctx, oracle):
            (T.FX_BIQUAD_PEAK12, [dict(cutoff_hz=1000.0, db_gain=g) for g in (6.0, 30.0)]),
            (T.FX_BIQUAD_LSHELF12, [dict(cutoff_hz=1000.0, db_gain=g) for g in (6.0, 30.0)]),
            (T.FX_BIQUAD_HSHELF12, [dict(cutoff_hz=1000.0, db_gain=g) for g in (6.0, 30.0)]),
-           (T.FX_BIQUAD_LP24, [dict(cutoff_hz=1000.0, passband_ripple=r) for r in (0.1, 0.25, 0.5, 0.75, 1.0)]),
+           (T.FX_BIQUAD_LP24, [dict(cutoff_hz=1000.0, passband_ripple=r) for r in (0.1, 0.707, 1.332, 3.207, 6.332, 10.707)]),   # (the sweep: 0.707 + 10 v^2)
            (T.FX_REVERB, [dict(attenuation=0.95, reverb_seconds=1.25)]),
            (T.FX_CHORUS, [dict(voices=4, delay_seconds=0.25)]),
            (T.FX_COMPRESSOR, [dict(limit_min=th, limit_max=0.1) for th in (0.0, 0.25, 0.5, 1.0)])]

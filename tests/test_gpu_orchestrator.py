@@ -154,6 +154,27 @@ def test_control_trip_steps_and_filter_sweep(orch):
         orch.add_control_trip(lp, "no-such-param")
 
 
+def test_compressor_threshold_trip_of_the_reference_demo(orch):
+    """projects/demos/effects/compressor.json: a compressor (threshold 0, ratio 0.1) whose THRESHOLD a control trip ramps up — the one
+    `#[derive(Control)]` name of the reference's projects the control table lacked until the end of round 5 (GROOVE_CTL_FX_THRESHOLD).  On
+    a constant 0.5: each block plays `t + (0.5 - t) x 0.1` while the block-start threshold t is below 0.5, 0.5 from there on."""
+    from groove_amd import host_binding as H
+    src = orch.add_toy_source(0.5)
+    comp = orch.add_effect(T.FX_COMPRESSOR, T.fx_params(limit_min=0.0, limit_max=0.1))
+    orch.patch_chain_to_main_mixer([src, comp])
+    trip = orch.add_control_trip(comp, "threshold", 0.0)
+    orch.control_trip_add_step(trip, H.STEP_SLOPE, 0.0, 1.0, 2.0)
+    out = orch.run(256)
+    blocks = len(out) // 256
+    assert blocks > 100
+    t = np.minimum(1.0, (np.arange(blocks) * 256) * 128.0 / 60.0 / 44100.0 / 2.0)
+    want = np.where(t < 0.5, t + (0.5 - t) * 0.1, 0.5)
+    got = out[:blocks * 256, 0].reshape(blocks, 256)
+    assert (got == got[:, :1]).all()                       # block-granular: one threshold per block
+    assert np.abs(got[:, 0] - want).max() <= 1e-4, float(np.abs(got[:, 0] - want).max())
+    assert abs(got[0, 0] - 0.05) < 1e-6 and got[-1, 0] == 0.5
+
+
 CONFIG1_ROWS = [[42, 44] * 8, [0, 0, 0, 0, 38, 0, 0, 0, 0, 0, 0, 0, 38, 0, 0, 0], [35, 0, 0, 0] * 4]
 
 
