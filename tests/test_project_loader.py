@@ -299,3 +299,35 @@ def test_wav_reader_formats_and_malformed_files(host, tmp_path):
         n = read(_wav(truncate=cut))[0]
         assert n == -1 or 0 <= n <= 10
     assert read(b"RIFF\x00\x00\x00\x00WAVEjunk")[0] == -1
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="reference tree not present")
+def test_every_reference_sample_file_decodes_like_the_standard_library(host):
+    """The 81 WAV files of the reference's assets (16- and 24-bit, mono and stereo, 44.1 / 48 / 96 kHz: the drum kits' and the samplers'
+    sources) through read_wav_mono against Python's `wave` module: every frame, the mean of the channels scaled by 2^(bits-1), bit for bit."""
+    import wave
+    import numpy as np
+    host.gh_read_wav_mono.restype = C.c_int64
+    host.gh_read_wav_mono.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_uint64, C.POINTER(C.c_uint32), C.c_char_p, C.c_size_t]
+    files = sorted(glob.glob(f"{REF}/assets/samples/**/*.wav", recursive=True))
+    assert len(files) == 81
+    seen = set()
+    for f in files:
+        with wave.open(f, "rb") as w:
+            ch, width, rate, frames = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
+            raw = w.readframes(frames)
+        if width == 2:
+            ints = np.frombuffer(raw, dtype="<i2").astype(np.int64)
+        else:
+            assert width == 3, (f, width)
+            b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int64)
+            ints = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+            ints = np.where(ints & 0x800000, ints - (1 << 24), ints)
+        want = ((ints.reshape(-1, ch) / float(1 << (8 * width - 1))).sum(axis=1) / ch).astype(np.float32)
+        out = np.zeros(len(want) + 8, dtype=np.float32)
+        sr, err = C.c_uint32(0), C.create_string_buffer(256)
+        n = host.gh_read_wav_mono(f.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), len(out), C.byref(sr), err, 256)
+        assert n == len(want) and sr.value == rate, (f, n, len(want), err.value)
+        assert np.array_equal(out[:n].view(np.uint32), want.view(np.uint32)), f
+        seen.add((ch, width, rate))
+    assert len(seen) >= 4
