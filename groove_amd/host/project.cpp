@@ -221,10 +221,12 @@ ProjectDesc parse_project(const std::string& text, const std::string& assets_roo
       if (cls == "instrument") {
         // [midi, params] (instruments.rs:26-39: tuple variants); the FM demos of the generation before (projects/demos/instruments/
         // fm-synthesizer-beta-*.json) carry ONE object, {"midi-in": .., "voice": {..}}: taken as the same two things
-        const bool flat = body.is_array() && body.arr.size() == 1 && body.arr[0]->is_object() && body.arr[0]->get("voice") && body.arr[0]->get("voice")->is_object();
+        // (and projects/tests/load-stereo-wav.json one object with the parameters beside "midi-in")
+        const bool flat = body.is_array() && body.arr.size() == 1 && body.arr[0]->is_object();
         if (!flat && (!body.is_array() || body.arr.size() != 2)) { p.warnings.push_back("malformed instrument " + d.id); continue; }
         d.midi_in = (int)json5::to_int(body.arr[0]->number_or("midi-in", 0), 0, 255, 0);
-        const json5::Value& params = flat ? *body.arr[0]->get("voice") : *body.arr[1];
+        const json5::Value* voice = flat ? body.arr[0]->get("voice") : nullptr;
+        const json5::Value& params = flat ? (voice && voice->is_object() ? *voice : *body.arr[0]) : *body.arr[1];
         if (d.kind == "welsh") {
           d.name = params.string_or("name", "");
           const std::string path = assets_root + "/patches/welsh/" + patch_name_to_settings_name(d.name) + ".json";
@@ -248,9 +250,11 @@ ProjectDesc parse_project(const std::string& text, const std::string& assets_roo
         }
       } else if (cls == "effect") {
         parse_effect(d.kind, body, d, p.warnings);
-      } else {
+      } else if (cls == "controller") {
         p.warnings.push_back("controller device '" + d.id + "' (" + d.kind + ") skipped: only tracks and trips drive this path");
         continue;
+      } else { // DeviceSettings has three variants (settings/src/lib.rs:42-46); projects/tests/invalid-project.json "should fail to load" on a fourth
+        throw std::runtime_error("project: unknown device class '" + cls + "' (expected instrument, controller or effect)");
       }
       p.devices.push_back(d);
     }

@@ -108,6 +108,18 @@ def test_fm_demo_projects_of_both_generations_load_their_synth(host):
         assert d["warnings"] == 0 and d["n_notes"] >= 1, f
 
 
+@pytest.mark.skipif(not os.path.exists(REF), reason="reference tree not present")
+def test_the_reference_test_projects(host):
+    """projects/tests/: the invalid project "that should fail to load" fails (a device class DeviceSettings does not have, settings/src/lib.rs:
+    42-46); both WAV-loading projects yield their sampler and their note (the stereo one in the one-object form of the generation before)."""
+    with pytest.raises(RuntimeError, match="unknown device class 'instrumentx'"):
+        describe(host, path=f"{REF}/projects/tests/invalid-project.json", assets=f"{REF}/assets")
+    for name in ("load-mono-wav.json", "load-stereo-wav.json"):
+        d = describe(host, path=f"{REF}/projects/tests/{name}", assets=f"{REF}/assets")
+        assert [x["kind"] for x in d["devices"]] == ["sampler"] and d["n_notes"] == 1 and d["warnings"] == 0, name
+        assert d["devices"][0]["name"].endswith(".wav"), d["devices"][0]
+
+
 def test_json5_syntax_and_errors(host):
     d = describe(host, text="{clock:{bpm:90,'time-signature':{top:3,bottom:4}},devices:[],/*c*/tracks:[],}")
     assert d["bpm"] == 90 and d["time_signature"] == [3, 4]
@@ -116,6 +128,8 @@ def test_json5_syntax_and_errors(host):
     with pytest.raises(RuntimeError, match="note-value"):
         describe(host, text='{"patterns":[{"id":"p","note-value":"seventh","notes":[[60]]}]}')
     # a one-ID patch cable is ignored with a warning (songs.rs:136-139); unknown effects pass through
+    with pytest.raises(RuntimeError, match="unknown device class"):
+        describe(host, text='{"devices":[{"gadget":["g",{"toy":{"my-value":0.5}}]}]}')
     d = describe(host, text='{"devices":[{"effect":["e",{"toy":{"my-value":0.5}}]}],"patch-cables":[["e"]]}')
     assert d["warnings"] == 2 and d["devices"][0]["fx_kind"] == T.FX_MIXER
     d = describe(host, text='{"devices":[{"effect":["e",{"filter-band-pass-12db":{"cutoff":500,"bandwidth":30}}]}]}')
