@@ -118,9 +118,12 @@ GROOVE_HD double exp_tiny_f64(double x) {
 // tan(z) = z P(z^2) on [0, pi/4]: weighted least squares on Chebyshev nodes for the RELATIVE error
 // (the coefficient formulas need t to a relative accuracy); max relative error 1.5e-7 in fp32, the
 // same as the sin / cos quotient it replaces, in 8 instructions instead of 14 and no reciprocal.
+GROOVE_HD float tan_of_reduced(float z);
 GROOVE_HD float tan_reduced(float x, bool& hi) {
   hi = x > 0.78539816339744831f;
-  const float z = hi ? (1.57079632679489662f - x) : x;
+  return tan_of_reduced(hi ? (1.57079632679489662f - x) : x);
+}
+GROOVE_HD float tan_of_reduced(float z) {
   const float z2 = z * z;
   float p = 9.449327447e-03f;
   p = fmaf(p, z2, 2.985451510e-03f);
@@ -349,10 +352,18 @@ struct Lp24StateD { double s0, s1, s2, s3; };
 struct Lp24CoefD { double b0a, a1a, a2a, b0b, a1b, a2b; };
 // Coefficients for cutoff fc (Hz); pi_over_sr = pi / SR; fc clamped to [1, 0.49 SR].  The fp32 quotients, widened exactly; the
 // upper side of SR/4 is an exec-mask region that a wave with no lane above SR/4 skips.
-GROOVE_HD Lp24CoefD lp24_coefd_from_fc(const Lp24Consts& c, float fc, float pi_over_sr, float fc_max) {
+// t and its side of SR/4 for cutoff fc (Hz).  AT the clamp (fc >= 0.49 SR) the reduced angle is 0.01 pi, given as that: the product
+// fc_max x (pi / SR) carries two fp32 roundings of an x next to pi/2, which leave pi/2 - x only 3e-6 of relative precision — and a
+// high-ripple section thrown to the clamp by a square LFO played 2e-5 of its level off through that (docs/HISTORY.md section 10 item 31).
+GROOVE_HD float lp24_t_from_fc(float fc, float pi_over_sr, float fc_max, bool& hi) {
   fc = fminf(fmaxf(fc, 1.0f), fc_max);
-  bool hi;
   const float t = tan_reduced(fc * pi_over_sr, hi);
+  if (fc >= fc_max) { hi = true; return tan_of_reduced(3.14159265358979324e-02f); }
+  return t;
+}
+GROOVE_HD Lp24CoefD lp24_coefd_from_fc(const Lp24Consts& c, float fc, float pi_over_sr, float fc_max) {
+  bool hi;
+  const float t = lp24_t_from_fc(fc, pi_over_sr, fc_max, hi);
   const float T2 = t * t;
   const float dta = c.d1 * t, dtb = c.d3 * t;
   Lp24CoefD d;
@@ -581,9 +592,8 @@ GROOVE_HD Lp24CoefF lp24_coeff_from_t(const Lp24Consts& c, float t, bool hi) { /
   return d;
 }
 GROOVE_HD Lp24CoefF lp24_coeff_from_fc(const Lp24Consts& c, float fc, float pi_over_sr, float fc_max) {
-  fc = fminf(fmaxf(fc, 1.0f), fc_max);
   bool hi;
-  const float t = tan_reduced(fc * pi_over_sr, hi);
+  const float t = lp24_t_from_fc(fc, pi_over_sr, fc_max, hi);
   return lp24_coeff_from_t(c, t, hi);
 }
 GROOVE_HD Lp24CoefF lp24_coeff_from_pct(const Lp24Consts& c, float pct, const RenderConsts& rc) {
