@@ -17,7 +17,8 @@ n = len(keys)
 lanes = np.arange(n, dtype=np.uint32)
 on, off = T.note_events_np(lanes, keys, True), T.note_events_np(lanes, keys, False)
 params = (T.WelshParams * n)(*([p] * n))
-bo, be = O.Bank.welsh(params), E.Bank.welsh(params)
+SR = int(os.environ.get("SR", "44100"))
+bo, be = O.Bank.welsh(params, sr=SR), E.Bank.welsh(params, SR)
 o, e = [], []
 blocks = 60
 for b in range(blocks):

@@ -12,6 +12,7 @@ from oracle import oracle as O
 O.build(ref=False)
 L = C.CDLL(os.path.join(REPO, "groove_amd", "host", "libgroove_host.so"))
 L.gh_welsh_params_from_patch_json.argtypes = [C.c_char_p, C.POINTER(T.WelshParams), C.c_char_p, C.c_size_t]
+SR = int(os.environ.get("SR", "44100"))
 keys = np.array([31, 50, 64, 86], dtype=np.uint8)
 lanes = np.arange(4, dtype=np.uint32)
 on, off = T.note_events_np(lanes, keys, True), T.note_events_np(lanes, keys, False)
@@ -23,7 +24,7 @@ for f in sorted(glob.glob("/root/reference/assets/patches/welsh/*.json")):
     params = (T.WelshParams * 4)(p, p, p, p)
     res = []
     for kind in (False, True):
-        bo, be = O.Bank.welsh(params), E.Bank.welsh(params)
+        bo, be = O.Bank.welsh(params, sr=SR), E.Bank.welsh(params, SR)
         if kind: be.set_f32_kind(True)
         o, e = [], []
         for b in range(60):
