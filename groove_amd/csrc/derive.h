@@ -71,10 +71,14 @@ inline WelshParams derive_welsh(const groove_welsh_params& p, double sr, WelshCo
     o.lfo_a = (double)p.lfo_depth * 0.693147180559945309417;
     const uint32_t wl = p.lfo_waveform & 15u, r = p.lfo_routing & 15u;
     const bool tri = wl == GROOVE_WAVE_TRIANGLE || wl == GROOVE_WAVE_TRIANGLE_SINE;
-    // largest per-frame change of the LFO value: |D| for a sine, 4 |inc| (in turns) for a triangle
-    const double dl = wl == GROOVE_WAVE_SINE ? fabs(D) : 4.0 * fabs((double)(int64_t)o.lfo_inc * 5.42101086242752217004e-20);
+    const bool saw = wl == GROOVE_WAVE_SAWTOOTH, sq = wl == GROOVE_WAVE_SQUARE || wl == GROOVE_WAVE_PULSE_WIDTH;
+    // largest per-frame change of the LFO value BETWEEN its edges: |D| for a sine, 4 |inc| (in turns) for a triangle, 2 |inc| for a
+    // sawtooth, none for a square or a pulse (the frame of an edge is evaluated exactly: welsh_frame_front; round 6 — these three
+    // waveforms ran in the exact-f64 kind before).  A noise LFO has no smooth stretch and stays exact.
+    const double turns = fabs((double)(int64_t)o.lfo_inc * 5.42101086242752217004e-20);
+    const double dl = wl == GROOVE_WAVE_SINE ? fabs(D) : (tri ? 4.0 * turns : (saw ? 2.0 * turns : 0.0));
     const uint32_t rb = lfo_routing_bits(r);
-    if ((wl == GROOVE_WAVE_SINE || tri) &&
+    if ((wl == GROOVE_WAVE_SINE || tri || saw || sq) &&
         ((rb & WF_LFO_PW) || ((rb & WF_LFO_PITCH) && fabs(o.lfo_a) * dl <= 1.5e-3)))
       o.flags |= WF_LFO_SMOOTH;
   }

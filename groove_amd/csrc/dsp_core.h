@@ -416,17 +416,31 @@ GROOVE_HD float lp24_t_from_pct(float pct, const RenderConsts& rc, bool& hi) {
   const float f0 = fmaf(e1, w2, e0), f1 = fmaf(9.449327447e-03f, w2, e2);
   return fmaf(f1, w4, f0) * z;
 }
-GROOVE_HD Lp24CoefD lp24_coefd_from_t(const Lp24Consts& c, float t, bool hi) {
+// `wide` (wave-uniform; WF_COEF_WIDE patches — a section constant c below 1/512, ripple above ~3.8): the lower side's a1 in its TWO-SIDED
+// form.  With c that small the pole pair sits towards z = -1 on the lower side of SR/4 too as soon as k^2 > c + d k: b0 -> 1, and
+// 2 - q2 - 4 b0 cancels (the rounding of b0, 2^-24, against a distance from -2 of 1e-3: a reference patch with ripple 7.1 under a cutoff
+// sweep played 6e-5 off the oracle through that, docs/HISTORY.md section 10 item 27).  There the small quantity is 2 + a1 = q2 + 4 c / D,
+// the same algebra (4 b0 + 4 c / D + 2 q2 = 4) with the rounding on the small term.  The side is chosen on the quotients themselves,
+// b0 > c / D + q2 / 2 (== k^2 > c + d k), so that the four-role kernel — which hands the quotients from one wavefront to another —
+// makes the same choice from the same bits.  Until round 6 such patches ran in the exact-f64 kind (lp24_coefd_from_fc's form of the same
+// idea): 14 of the reference's 106 patch files, 13 % of a library-proportioned bank in the slowest kernel for their filter's sake alone.
+GROOVE_HD Lp24CoefD lp24_coefd_from_t(const Lp24Consts& c, float t, bool hi, bool wide = false) {
   const float T2 = t * t;
   const float dta = c.d1 * t, dtb = c.d3 * t;
   Lp24CoefD d;
   if (!hi) {
     const float ia = fast_rcp(c.c0 + dta + T2);
     const float ib = fast_rcp(c.c2 + dtb + T2);
-    const double b0a = (double)(T2 * ia), q2a = (double)((dta + dta) * ia);
-    const double b0b = (double)(T2 * ib), q2b = (double)((dtb + dtb) * ib);
+    const float fba = T2 * ia, fqa = (dta + dta) * ia, fbb = T2 * ib, fqb = (dtb + dtb) * ib;
+    const double b0a = (double)fba, q2a = (double)fqa;
+    const double b0b = (double)fbb, q2b = (double)fqb;
     d.b0a = b0a; d.a1a = fma(-4.0, b0a, 2.0 - q2a); d.a2a = q2a - 1.0;
     d.b0b = b0b; d.a1b = fma(-4.0, b0b, 2.0 - q2b); d.a2b = q2b - 1.0;
+    if (wide) {
+      const float pa = c.c0 * ia, pb = c.c2 * ib;
+      if (fba > fmaf(0.5f, fqa, pa)) d.a1a = fma(4.0, (double)pa, q2a - 2.0);
+      if (fbb > fmaf(0.5f, fqb, pb)) d.a1b = fma(4.0, (double)pb, q2b - 2.0);
+    }
   } else {
     const float Pa = c.c0 * T2, Pb = c.c2 * T2;
     const float ia = fast_rcp(1.0f + dta + Pa);
@@ -441,7 +455,7 @@ GROOVE_HD Lp24CoefD lp24_coefd_from_t(const Lp24Consts& c, float t, bool hi) {
 // lp24_coefd_from_t in two halves again (the four-role kernel): the fp32 quotients, and their widening.  Same operations on the
 // same values: lp24_coefd_from_q(lp24_coefq_from_t(c, t, hi), hi) == lp24_coefd_from_t(c, t, hi) bit for bit.
 struct Lp24CoefQ { float ba, qa, bb, qb, pa, pb; }; // per section: b0 (upper side: 1 / D'), q2, and on the upper side P / D'
-GROOVE_HD Lp24CoefQ lp24_coefq_from_t(const Lp24Consts& c, float t, bool hi) {
+GROOVE_HD Lp24CoefQ lp24_coefq_from_t(const Lp24Consts& c, float t, bool hi, bool wide = false) {
   const float T2 = t * t;
   const float dta = c.d1 * t, dtb = c.d3 * t;
   Lp24CoefQ q;
@@ -450,6 +464,7 @@ GROOVE_HD Lp24CoefQ lp24_coefq_from_t(const Lp24Consts& c, float t, bool hi) {
     const float ib = fast_rcp(c.c2 + dtb + T2);
     q.ba = T2 * ia; q.qa = (dta + dta) * ia; q.pa = 0.0f;
     q.bb = T2 * ib; q.qb = (dtb + dtb) * ib; q.pb = 0.0f;
+    if (wide) { q.pa = c.c0 * ia; q.pb = c.c2 * ib; } // (lower side, two-sided form: c / D)
   } else {
     const float Pa = c.c0 * T2, Pb = c.c2 * T2;
     const float ia = fast_rcp(1.0f + dta + Pa);
@@ -459,13 +474,17 @@ GROOVE_HD Lp24CoefQ lp24_coefq_from_t(const Lp24Consts& c, float t, bool hi) {
   }
   return q;
 }
-GROOVE_HD Lp24CoefD lp24_coefd_from_q(const Lp24CoefQ& q, bool hi) {
+GROOVE_HD Lp24CoefD lp24_coefd_from_q(const Lp24CoefQ& q, bool hi, bool wide = false) {
   Lp24CoefD d;
   const double q2a = (double)q.qa, q2b = (double)q.qb;
   if (!hi) {
     const double b0a = (double)q.ba, b0b = (double)q.bb;
     d.b0a = b0a; d.a1a = fma(-4.0, b0a, 2.0 - q2a); d.a2a = q2a - 1.0;
     d.b0b = b0b; d.a1b = fma(-4.0, b0b, 2.0 - q2b); d.a2b = q2b - 1.0;
+    if (wide) {
+      if (q.ba > fmaf(0.5f, q.qa, q.pa)) d.a1a = fma(4.0, (double)q.pa, q2a - 2.0);
+      if (q.bb > fmaf(0.5f, q.qb, q.pb)) d.a1b = fma(4.0, (double)q.pb, q2b - 2.0);
+    }
   } else {
     const double pa = (double)q.pa, pb = (double)q.pb;
     d.b0a = (double)q.ba; d.a1a = fma(4.0, pa, q2a - 2.0); d.a2a = q2a - 1.0;
@@ -473,10 +492,10 @@ GROOVE_HD Lp24CoefD lp24_coefd_from_q(const Lp24CoefQ& q, bool hi) {
   }
   return d;
 }
-GROOVE_HD Lp24CoefD lp24_coefd_from_pct(const Lp24Consts& c, float pct, const RenderConsts& rc) {
+GROOVE_HD Lp24CoefD lp24_coefd_from_pct(const Lp24Consts& c, float pct, const RenderConsts& rc, bool wide = false) {
   bool hi;
   const float t = lp24_t_from_pct(pct, rc, hi);
-  return lp24_coefd_from_t(c, t, hi);
+  return lp24_coefd_from_t(c, t, hi, wide);
 }
 #ifdef GROOVE_EMUL_F32_FILTER_HOOK
 // The same two transposed-direct-form-II sections with fp32 state and fp32 arithmetic (the state fields hold float values).
@@ -662,7 +681,7 @@ enum : uint32_t {
   // reach, amplitude, cutoff percent, passband ripple.
   WF_LFO_PITCH = 1u << 20, WF_LFO_PW = 1u << 21, WF_LFO_O1 = 1u << 22, WF_LFO_O2 = 1u << 23,
   WF_LFO_AMP = 1u << 24, WF_LFO_CUTOFF = 1u << 25, WF_LFO_RESO = 1u << 26,
-  WF_COEF_WIDE = 1u << 28, // host (derive.h): a RETUNED filter whose section constant c is below 1/512 (ripple above ~3.8): its poles sit towards z = -1 at any cutoff above c's own, and the per-frame coefficients take lp24_coefd_from_fc's two-sided form in the exact-f64 kind (welsh_lfo_mode)
+  WF_COEF_WIDE = 1u << 28, // host (derive.h): a RETUNED filter whose section constant c is below 1/512 (ripple above ~3.8): its poles sit towards z = -1 at any cutoff above c's own, and the per-frame coefficients take the two-sided form (lp24_coefd_from_t's `wide`; lp24_coefd_from_fc's in the exact-f64 kind and the time-parallel form)
   WF_FILTER_F32 = 1u << 27 // host promise (derive.h welsh_filter_f32_ok): the fp32 filter recurrence stays within 2e-6 of the f64 one over this patch's cutoff range
 };
 GROOVE_HD uint32_t lfo_routing_bits(uint32_t routing) {
@@ -732,8 +751,8 @@ GROOVE_HD Lp24Consts lp24_consts_from_ripple(float r) {
 // How the LFO is evaluated.  LFO_F32: promise that no lane routes the LFO to Pitch or PulseWidth,
 // which removes the f64 LFO / 2^x / u64<->f64 path (and ~80 VGPRs).  LFO_F64: exact per-frame
 // evaluation from the 64-bit phase (any waveform).  LFO_F64_SMOOTH: promise that every lane that
-// routes to Pitch / PulseWidth carries WF_LFO_SMOOTH (sine or triangle LFO, |lfo_a dl| <= 1.5e-3 per
-// frame): frame 0 of a render call evaluates exactly and seeds (ls, lc, lm); later frames advance
+// routes to Pitch / PulseWidth carries WF_LFO_SMOOTH (any LFO waveform but noise; |lfo_a dl| <= 1.5e-3 per
+// frame BETWEEN the edges of a square / pulse / sawtooth LFO, whose frames evaluate exactly — round 6): frame 0 of a render call evaluates exactly and seeds (ls, lc, lm); later frames advance
 // the sine by one rotation (6 f64 ops instead of a 10-term polynomial + conversions) and the
 // pitch factor by lm *= e^(lfo_a (l - ls)) with a 4-term series (instead of a 15-term one).  The
 // recurrences are re-seeded every block, so their error stays a random walk of <= 255 steps of
@@ -742,7 +761,7 @@ enum : int { LFO_F32 = 0, LFO_F64 = 1, LFO_F64_SMOOTH = 2 };
 GROOVE_HD int welsh_lfo_mode(const WelshParams& p) {
   // the resonance routing (per-frame sinh / cosh) is only compiled into the exact-f64 retuned kind: rare, and
   // it keeps the other five kinds free of its code and registers
-  if (p.flags & (WF_LFO_RESO | WF_COEF_WIDE)) return LFO_F64; // (WF_COEF_WIDE: the two-sided coefficient form lives there too)
+  if (p.flags & WF_LFO_RESO) return LFO_F64; // (WF_COEF_WIDE patches ran there too until round 6: lp24_coefd_from_t's `wide` form serves them in every kind now)
   if (!(p.flags & (WF_LFO_PITCH | WF_LFO_PW))) return LFO_F32;
   return (p.flags & WF_LFO_SMOOTH) ? LFO_F64_SMOOTH : LFO_F64;
 }
@@ -772,10 +791,30 @@ GROOVE_HD int lfo_class_of(uint32_t waveform, uint32_t routing) {
   if (lfo_routing_bits(routing) == 0u) return waveform == GROOVE_WAVE_NOISE ? (int)OSC_ANY : (int)LFO_UNUSED;
   return osc_class_of(waveform);
 }
+// Which kernel instantiation a patch asks for (kernels.h "Workgroup KINDS"): the BASE KIND (LFO mode x retune, in cost order: F32 static,
+// F32 retune, SMOOTH static, SMOOTH retune, exact-F64 static, exact-F64 retune) and the class triple of the block body inside it.  Host
+// and device share the rule (groove_hip.hip welsh_upload_params; tests/emul and tools/library_proportions.py read it through emul.cpp).
+struct WelshParams;
+GROOVE_HD int welsh_base_kind(const WelshParams& p);
+GROOVE_HD bool welsh_base_kind_specialised(int base_kind) { return base_kind < 4; } // the exact-f64 kinds keep OSC_ANY bodies
+GROOVE_HD void welsh_body_classes(const WelshParams& p, int base_kind, int& cl, int& c1, int& c2);
 template <int CLS>
 GROOVE_HD uint32_t osc_class_wave(uint32_t runtime_waveform) {
   return CLS == OSC_PULSE ? (uint32_t)GROOVE_WAVE_PULSE_WIDTH : CLS == OSC_SAW ? (uint32_t)GROOVE_WAVE_SAWTOOTH
        : CLS == OSC_TRIANGLE ? (uint32_t)GROOVE_WAVE_TRIANGLE : CLS == OSC_SINE ? (uint32_t)GROOVE_WAVE_SINE : runtime_waveform;
+}
+
+GROOVE_HD int welsh_base_kind(const WelshParams& p) {
+  const int mode = welsh_lfo_mode(p);
+  return (mode == LFO_F32 ? 0 : (mode == LFO_F64_SMOOTH ? 2 : 4)) + (welsh_retunes(p) ? 1 : 0);
+}
+GROOVE_HD void welsh_body_classes(const WelshParams& p, int base_kind, int& cl, int& c1, int& c2) {
+  const bool spec = welsh_base_kind_specialised(base_kind);
+  c1 = spec ? osc_class_of((p.flags >> WF_O1_WAVE_SHIFT) & 15u) : (int)OSC_ANY;
+  c2 = spec ? osc_class_of((p.flags >> WF_O2_WAVE_SHIFT) & 15u) : (int)OSC_ANY;
+  cl = spec ? lfo_class_of((p.flags >> WF_LFO_WAVE_SHIFT) & 15u, (p.flags >> WF_ROUTING_SHIFT) & 15u) : (int)OSC_ANY;
+  // the smooth-f64 kernels carry the sine / triangle / any LFO copies only
+  if (base_kind >= 2 && cl != OSC_SINE && cl != OSC_TRIANGLE) cl = OSC_ANY;
 }
 
 // One frame of one voice.  FIRST: this is frame 0 of a render call (the only frame on which
@@ -868,7 +907,14 @@ GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScrat
     }
     if (fl & WF_LFO_PITCH) {
       double m;
-      if (SMOOTH && !FIRST) m = sc.lm * exp_tiny_f64((l - sc.ls) * p.lfo_a);
+      if (SMOOTH && !FIRST) {
+        // an LFO with EDGES (square, pulse, sawtooth: class OSC_ANY in the smooth kinds) is smooth between them; on the frame of an
+        // edge the factor is evaluated exactly, which re-seeds the recurrence (a square's factor is then constant, bit for bit:
+        // e^0 = 1).  Until round 6 such patches ran in the exact-f64 kind, a 15-term series on every frame.
+        const double dx = (l - sc.ls) * p.lfo_a;
+        if (CL == OSC_ANY && fabs(dx) > 1.5e-3) m = exp2_small_f64(l * (double)p.lfo_depth);
+        else m = sc.lm * exp_tiny_f64(dx);
+      }
       else m = exp2_small_f64(l * (double)p.lfo_depth);
       if (SMOOTH) sc.lm = m;
       if (fl & WF_LFO_O1) inc1 = f64_to_u64((double)inc1 * m);
@@ -979,7 +1025,11 @@ GROOVE_HD bool welsh_frame_ctl(const WelshParams& p, WelshState& s, WelshScratch
     }
     if (fl & WF_LFO_PITCH) {
       double m;
-      if (!FIRST) m = sc.lm * exp_tiny_f64((l - sc.ls) * p.lfo_a);
+      if (!FIRST) { // (welsh_frame_front's statements: an LFO with edges is re-seeded exactly on the frame of an edge)
+        const double dx = (l - sc.ls) * p.lfo_a;
+        if (CL == OSC_ANY && fabs(dx) > 1.5e-3) m = exp2_small_f64(l * (double)p.lfo_depth);
+        else m = sc.lm * exp_tiny_f64(dx);
+      }
       else m = exp2_small_f64(l * (double)p.lfo_depth);
       sc.lm = m;
       mod = m;
@@ -1062,7 +1112,7 @@ GROOVE_HD void welsh_frame_coef(const WelshParams& p, const RenderConsts& rc, We
         sc.prev_pct = pct;
       }
     } else if (retune && pct != sc.prev_pct) { // unchanged percent (e.g. envelope plateau): coefficients stand
-      sc.coef = lp24_coefd_from_pct(p.fc, pct, rc);
+      sc.coef = lp24_coefd_from_pct(p.fc, pct, rc, (p.flags & WF_COEF_WIDE) != 0); // (a scalar branch in the uniform kernels)
       sc.prev_pct = pct;
     }
   }

@@ -593,14 +593,10 @@ int welsh_upload_params(groove_bank* b, bool regroup) {
   // small many-patch bank a mixture, which runs in the most demanding base kind with the run-time
   // waveform switches: config #2's 32 waves took 0.21 ms per block where their slowest patch needs 0.16.)
   auto kind_of_wave = [](const WelshParams& p) -> uint16_t {
-    const int mode = welsh_lfo_mode(p);
-    const int base = (mode == LFO_F32 ? 0 : (mode == LFO_F64_SMOOTH ? 1 : 2)) * 2 + (welsh_retunes(p) ? 1 : 0); // == wg_base_kind_of()
-    const bool spec = wg_base_kind_specialised(base);
-    const int c1 = osc_class_of((p.flags >> WF_O1_WAVE_SHIFT) & 15u), c2 = osc_class_of((p.flags >> WF_O2_WAVE_SHIFT) & 15u);
-    int cl = spec ? lfo_class_of((p.flags >> WF_LFO_WAVE_SHIFT) & 15u, (p.flags >> WF_ROUTING_SHIFT) & 15u) : (int)OSC_ANY;
-    // the smooth-f64 kernels carry the sine / triangle / any LFO copies only
-    if (base >= 2 && cl != OSC_SINE && cl != OSC_TRIANGLE) cl = OSC_ANY;
-    return (uint16_t)wg_kind_of(base, cl, spec ? c1 : (int)OSC_ANY, spec ? c2 : (int)OSC_ANY);
+    const int base = welsh_base_kind(p); // == wg_base_kind_of(welsh_lfo_mode(p), welsh_retunes(p)); dsp_core.h
+    int cl, c1, c2;
+    welsh_body_classes(p, base, cl, c1, c2);
+    return (uint16_t)wg_kind_of(base, cl, c1, c2);
   };
   std::vector<uint16_t> kind; // per workgroup
   std::vector<uint8_t> f32_of; // per workgroup: its waves' patches carry WF_FILTER_F32 (a workgroup is uniform in it too: sort key bit 0)

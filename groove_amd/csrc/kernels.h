@@ -413,7 +413,7 @@ __host__ __device__ constexpr int wg_base_kind_of(int lfo_mode, bool retune) {
 }
 __host__ __device__ constexpr int wg_class_combo(int cl, int c1, int c2) { return (cl * OSC_CLASSES + c1) * OSC_CLASSES + c2; }
 __host__ __device__ constexpr int wg_kind_of(int base_kind, int cl, int c1, int c2) { return base_kind * kClassCombos + wg_class_combo(cl, c1, c2); }
-__host__ __device__ constexpr bool wg_base_kind_specialised(int base_kind) { return base_kind < 4; } // exact-f64 kinds keep OSC_ANY
+__host__ __device__ constexpr bool wg_base_kind_specialised(int base_kind) { return base_kind < 4; } // exact-f64 kinds keep OSC_ANY (== dsp_core.h welsh_base_kind_specialised)
 template <int LFO_MODE, bool RETUNE> struct WavesBudget;
 template <> struct WavesBudget<LFO_F32, false> { static constexpr int value = GROOVE_WAVES_F32_STATIC; };
 template <> struct WavesBudget<LFO_F32, true> { static constexpr int value = GROOVE_WAVES_F32_RETUNE; };

@@ -282,7 +282,7 @@ GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split_back(U
           float L = 0.0f, R = 0.0f;
           if (in[j].x == in[j].x) { // the voice sounds on this frame
             if (RETUNE) {
-              if (tt[j] == tt[j]) coef = lp24_coefd_from_t(p.fc, fabsf(tt[j]), tt[j] < 0.0f);
+              if (tt[j] == tt[j]) coef = lp24_coefd_from_t(p.fc, fabsf(tt[j]), tt[j] < 0.0f, (p.flags & WF_COEF_WIDE) != 0);
             }
             welsh_frame_back<!RETUNE>(p, filt, coef, in[j].x, in[j].y, L, R);
           }
@@ -456,7 +456,7 @@ GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split4_mid(U
         if (pct[j] == pct[j]) {
           bool hi;
           const float t = lp24_t_from_pct(pct[j], rc, hi);
-          const Lp24CoefQ q = lp24_coefq_from_t(p.fc, t, hi);
+          const Lp24CoefQ q = lp24_coefq_from_t(p.fc, t, hi, (p.flags & WF_COEF_WIDE) != 0);
           q4 = make_float4(q.ba, hi ? -q.qa : q.qa, q.bb, q.qb); // q2 > 0 always: the sign carries the side of SR/4
           q2 = make_float2(q.pa, q.pb);
         }
@@ -520,7 +520,7 @@ GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_split4_back(
           float L = 0.0f, R = 0.0f;
           if (sum[j] == sum[j]) {
             if (RETUNE) {
-              if (q4[j].x == q4[j].x) coef = lp24_coefd_from_q(Lp24CoefQ{q4[j].x, fabsf(q4[j].y), q4[j].z, q4[j].w, q2[j].x, q2[j].y}, q4[j].y < 0.0f);
+              if (q4[j].x == q4[j].x) coef = lp24_coefd_from_q(Lp24CoefQ{q4[j].x, fabsf(q4[j].y), q4[j].z, q4[j].w, q2[j].x, q2[j].y}, q4[j].y < 0.0f, (p.flags & WF_COEF_WIDE) != 0);
             }
             welsh_frame_back<!RETUNE>(p, filt, coef, sum[j], gain[j], L, R);
           }

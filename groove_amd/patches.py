@@ -102,6 +102,105 @@ def welsh_patch(j):
 
 
 
+# ------------------------------------------------------------------ the reference library's class proportions (round 6)
+# The workload `welsh-1m-library`: 106 synthetic patches whose CATEGORIES follow the reference's 106 shipped patch files, one slot per file:
+# what the LFO is routed to, its waveform, how the filter is retuned (not at all / by its envelope / by the LFO), whether the filter's
+# ripple is above ~3.8 (WF_COEF_WIDE), the two oscillators' waveforms, hard sync.  The COUNTS below are printed by
+# tools/library_proportions.py (development container only: it reads the files where they lie; profiles/r06_library_proportions.json
+# is its output); every VALUE — cutoffs, envelopes, LFO frequencies and depths, pans, tunings — is synthetic, from the formulas of
+# welsh_patch().  The 32-patch benchmark table above pairs every edge-moving routing with a sine LFO and keeps every ripple below 3.3:
+# it has no voice in the kernels a square / sawtooth / noise LFO on the pitch or a high-ripple swept filter asks for; 18 of the
+# reference's 106 files do.
+# (count, LFO routing, LFO waveform, filter retune: "static" | "env" | "lfo" | "reso", ripple above 3.8)
+LIBRARY_LFO_ROWS = [
+    (1, T.LFO_AMPLITUDE, T.WAVE_NOISE, "static", False), (1, T.LFO_AMPLITUDE, T.WAVE_SINE, "env", False),
+    (2, T.LFO_AMPLITUDE, T.WAVE_SQUARE, "env", False), (1, T.LFO_AMPLITUDE, T.WAVE_SQUARE, "static", False),
+    (15, T.LFO_AMPLITUDE, T.WAVE_TRIANGLE, "env", False), (1, T.LFO_AMPLITUDE, T.WAVE_TRIANGLE, "env", True),
+    (6, T.LFO_AMPLITUDE, T.WAVE_TRIANGLE, "static", False),
+    (1, T.LFO_FILTER_CUTOFF, T.WAVE_NOISE, "lfo", True), (1, T.LFO_FILTER_CUTOFF, T.WAVE_TRIANGLE, "lfo", True),
+    (1, T.LFO_FILTER_CUTOFF, T.WAVE_TRIANGLE_SINE, "lfo", True), (1, T.LFO_CUTOFF_AMP, T.WAVE_TRIANGLE_SINE, "lfo", True),
+    (21, T.LFO_NONE, T.WAVE_NONE, "env", False), (3, T.LFO_NONE, T.WAVE_NONE, "env", True), (12, T.LFO_NONE, T.WAVE_NONE, "static", False),
+    (1, T.LFO_NONE, T.WAVE_SQUARE, "env", False),
+    (1, T.LFO_PITCH, T.WAVE_NOISE, "env", False), (1, T.LFO_PITCH, T.WAVE_SAWTOOTH, "static", False),
+    (3, T.LFO_PITCH, T.WAVE_SINE, "env", False), (1, T.LFO_PITCH, T.WAVE_SINE, "env", True), (1, T.LFO_PITCH, T.WAVE_SQUARE, "env", True),
+    (4, T.LFO_PITCH, T.WAVE_TRIANGLE, "env", False), (1, T.LFO_PITCH, T.WAVE_TRIANGLE, "env", True),
+    (9, T.LFO_PITCH, T.WAVE_TRIANGLE, "static", False), (1, T.LFO_PITCH, T.WAVE_TRIANGLE_SINE, "env", False),
+    (2, T.LFO_PITCH_OSC2, T.WAVE_TRIANGLE, "static", False), (1, T.LFO_PITCH_OSC2, T.WAVE_TRIANGLE_SINE, "env", True),
+    (2, T.LFO_PITCH_OSC2, T.WAVE_TRIANGLE_SINE, "static", False),
+    (1, T.LFO_PULSE_WIDTH, T.WAVE_SAWTOOTH, "env", False), (1, T.LFO_PULSE_WIDTH, T.WAVE_SINE, "env", False),
+    (1, T.LFO_PULSE_WIDTH, T.WAVE_TRIANGLE, "static", False), (2, T.LFO_PULSE_WIDTH, T.WAVE_TRIANGLE_SINE, "env", False),
+    (2, T.LFO_PULSE_WIDTH, T.WAVE_TRIANGLE_SINE, "env", True), (1, T.LFO_PULSE_WIDTH, T.WAVE_TRIANGLE_SINE, "static", False),
+    (1, T.LFO_PW_OSC1, T.WAVE_TRIANGLE, "env", False), (1, T.LFO_PW_OSC2, T.WAVE_TRIANGLE_SINE, "static", False),
+    (1, T.LFO_RESONANCE, T.WAVE_SQUARE, "reso", False),
+]
+# (count, oscillator 1 waveform, oscillator 2 waveform)
+LIBRARY_OSC_ROWS = [
+    (21, _PW, _PW), (11, T.WAVE_NONE, T.WAVE_NONE), (10, T.WAVE_SQUARE, T.WAVE_SQUARE), (9, T.WAVE_TRIANGLE, T.WAVE_TRIANGLE),
+    (6, T.WAVE_SQUARE, T.WAVE_SAWTOOTH), (6, T.WAVE_SAWTOOTH, T.WAVE_SQUARE), (5, _PW, T.WAVE_SQUARE), (5, T.WAVE_SQUARE, _PW),
+    (4, T.WAVE_SAWTOOTH, _PW), (3, T.WAVE_TRIANGLE, T.WAVE_SQUARE), (3, T.WAVE_TRIANGLE, T.WAVE_NONE), (3, _PW, T.WAVE_NONE),
+    (3, T.WAVE_SAWTOOTH, T.WAVE_SAWTOOTH), (3, _PW, T.WAVE_TRIANGLE), (3, T.WAVE_SAWTOOTH, T.WAVE_TRIANGLE), (2, T.WAVE_SAWTOOTH, T.WAVE_NONE),
+    (2, T.WAVE_TRIANGLE, T.WAVE_SAWTOOTH), (2, _PW, T.WAVE_SAWTOOTH), (1, T.WAVE_DEBUG_MAX, T.WAVE_NONE), (1, T.WAVE_NONE, T.WAVE_SQUARE),
+    (1, T.WAVE_SQUARE, T.WAVE_TRIANGLE), (1, T.WAVE_SINE, T.WAVE_NONE), (1, T.WAVE_NONE, T.WAVE_SAWTOOTH),
+]
+LIBRARY_SLOTS = sum(r[0] for r in LIBRARY_LFO_ROWS)   # 106
+assert LIBRARY_SLOTS == 106 and sum(r[0] for r in LIBRARY_OSC_ROWS) == LIBRARY_SLOTS
+LIBRARY_SYNC_SLOTS = 18      # hard sync: 18 of the 106 files
+_LIB_LFO = [r[1:] for r in LIBRARY_LFO_ROWS for _ in range(r[0])]
+_LIB_OSC = [r[1:] for r in LIBRARY_OSC_ROWS for _ in range(r[0])]
+
+
+def library_patch(s):
+    """Synthetic patch of library slot s (0..105): the categories of LIBRARY_*_ROWS, the values of welsh_patch()'s formulas."""
+    s %= LIBRARY_SLOTS
+    routing, lfo_wave, retune, wide = _LIB_LFO[s]
+    w1, w2 = _LIB_OSC[(s * 37 + 11) % LIBRARY_SLOTS]   # (37 is coprime with 106: the pairs are spread over the LFO rows)
+    # (the reference's 11 none x none files are silent in its own derivation too — patches.rs:88-109 pushes no oscillator; here the
+    # none x none slots sound a noise source, what 14 of the files mix in, so that every slot of the benchmark does its work)
+    if w1 == T.WAVE_NONE and w2 == T.WAVE_NONE:
+        w2 = T.WAVE_NOISE
+    p = T.WelshParams()
+    d1 = [.1, .25, .45, .3][s % 4] if w1 == _PW else .5
+    d2 = [.25, .45, .1, .35][(s // 2) % 4] if w2 == _PW else .5
+    p.oscillator_1.waveform, p.oscillator_1.duty, p.oscillator_1.tune, p.oscillator_1.fixed_hz = w1, d1, 1.0, 0.0
+    tune2 = [1.0, semis_and_cents(12, 0.0), semis_and_cents(7, 5.0), semis_and_cents(-12, 0.0), 1.0, semis_and_cents(0, 7.0)][s % 6]
+    fixed2 = note_to_frequency(60) if (s % 35 == 17 and w2 != T.WAVE_NONE) else 0.0   # oscillator_2_track == false: 3 of the files
+    p.oscillator_2.waveform, p.oscillator_2.duty, p.oscillator_2.tune, p.oscillator_2.fixed_hz = w2, d2, tune2, fixed2
+    p.oscillator_2_sync = 1 if (s % 6 == 1 and w1 != T.WAVE_NONE and w2 != T.WAVE_NONE) else 0   # (18 slots have s mod 6 == 1)
+    if w1 == T.WAVE_NONE or w2 == T.WAVE_NONE:
+        p.oscillator_mix = 1.0 if w2 == T.WAVE_NONE else 0.0
+    else:
+        p.oscillator_mix = 1.0 / (1.0 + [1.0, 0.5, 0.25, 0.75][s % 4])
+    a, d, su = _ATTACK[s % 8], _DECAY[(s // 2) % 8], _SUSTAIN[(s // 3) % 8]
+    if su == 0.0 and d < 0.3:
+        d = 0.3
+    p.amp_envelope = T.EnvelopeParams(a, d, su, d)
+    fa, fd, fs = _ATTACK[(s + 3) % 8], _DECAY[(s + 5) % 8], _SUSTAIN[(s + 1) % 8]
+    p.filter_envelope = T.EnvelopeParams(fa, fd, fs, fd)
+    p.lfo_waveform, p.lfo_routing = lfo_wave, routing
+    p.lfo_frequency = [0.53, 2.07, 5.13, 7.49, 2.41, 4.03, 0.71, 7.53, 31.7, 1.03][(s // 3) % 10]   # non-round: no exact phase ties at 44.1 kHz
+    p.lfo_depth = [0.02, 0.05, 0.1, 0.2, 0.3, 0.5][s % 6]
+    if routing == T.LFO_RESONANCE:
+        p.lfo_depth = 0.5
+    cutoff24 = 40.0 * 500.0 ** (((s * 11) % 32) / 31.0)
+    cutoff12 = 40.0 * 500.0 ** (((s * 7 + 5) % 32) / 31.0)
+    p.filter_cutoff_hz = cutoff24
+    # ripple = denormalize_q(filter-resonance): 61 of the files at 0 (0.707), the rest up to 1 (10.7); above ~0.556 (3.8) it is "wide"
+    p.filter_passband_ripple = denormalize_q([0.6, 0.65, 0.7, 0.8, 1.0][s % 5] if wide else [0.0, 0.0, 0.0, 0.1, 0.3, 0.0, 0.45, 0.5][(s // 2) % 8])
+    p.filter_cutoff_start = min(1.0, max(0.0, frequency_to_percent(cutoff12)))
+    p.filter_cutoff_end = [0.3, 0.6, 0.9, 0.5][s % 4] if retune == "env" else 0.0
+    p.dca_gain = 1.0
+    p.dca_pan = ((s % 5) - 2) / 4.0
+    return p
+
+
+def library_table():
+    return (T.WelshParams * LIBRARY_SLOTS)(*[library_patch(s) for s in range(LIBRARY_SLOTS)])
+
+
+# The Welsh patch tables of the synthetic workloads (groove_amd/projects.py): name -> (entries, patch function).  Voice w plays entry w mod entries.
+PATCH_TABLES = {"benchmark-32": (N_PATCHES, welsh_patch), "library-106": (LIBRARY_SLOTS, library_patch)}
+
+
 def random_welsh_patch(rng):
     """A Welsh patch with every continuous parameter DRAWN (numpy Generator `rng`) instead of taken from the 32-entry benchmark table: any
     waveform pair, duty 0.05 - 0.95, oscillator 2 an octave either way (or at a fixed pitch), hard sync, envelopes with instant attacks and

@@ -10,6 +10,7 @@ the test-side `oracle/projects.py` instantiates the same plan on the CPU oracle.
 
 Workloads (BASELINE.json `configs`):
     welsh-1m       1,000,000 Welsh voices, config-#2 voice rule            172 blocks of 256 frames
+    welsh-1m-library  the same project over the 106-slot library-proportioned patch table (patches.py)
     welsh-256      config #2                                               172 blocks
     chain-4096     config #3: + BiQuad LP12 → Chorus → Delay → Reverb      172 blocks
     sampler-16384  config #4: one-shots over the shared bank, staggered    344 blocks
@@ -39,6 +40,8 @@ TAKE_TURNS_MAX_VOICES = int(__import__("os").environ.get("GROOVE_TAKE_TURNS_MAX_
 
 WORKLOADS = {
     "welsh-1m": dict(voices=1_000_000, kind="welsh", bytes_per_vf=18.0, dominant_bytes=10.0, blocks=172),
+    # round 6: the same project over 106 synthetic patches whose class proportions follow the reference's patch library (patches.py LIBRARY_*)
+    "welsh-1m-library": dict(voices=1_000_000, kind="welsh", bytes_per_vf=18.0, dominant_bytes=10.0, blocks=172, table="library-106"),
     "welsh-256": dict(voices=256, kind="welsh", bytes_per_vf=18.0, dominant_bytes=10.0, blocks=172),
     "chain-4096": dict(voices=4096, kind="chain", bytes_per_vf=218.0, dominant_bytes=10.0, blocks=172),
     "sampler-16384": dict(voices=16384, kind="sampler", bytes_per_vf=20.25, dominant_bytes=12.25, blocks=344),
@@ -85,11 +88,12 @@ def plan(workload, sel, grouped=True, bank_scale=1.0):
     out = []
     w = kinds.get("welsh")
     if w is not None and len(w):
+        entries, patch_of = P.PATCH_TABLES[wl.get("table", "benchmark-32")]
         if grouped:  # synth-major lane order: all voices of patch 0, then patch 1, ... (stable)
-            w = w[np.argsort(w % P.N_PATCHES, kind="stable")]
-        table = (T.WelshParams * P.N_PATCHES)(*[P.welsh_patch(j) for j in range(P.N_PATCHES)])
+            w = w[np.argsort(w % entries, kind="stable")]
+        table = (T.WelshParams * entries)(*[patch_of(j) for j in range(entries)])
         n = len(w)
-        bank = dict(kind="welsh", n=n, params=_take(table, T.WelshParams, w % P.N_PATCHES), voice=w, fx=[],
+        bank = dict(kind="welsh", n=n, params=_take(table, T.WelshParams, w % entries), voice=w, fx=[],
                     events={0: T.note_events_np(_lanes(n), _keys(w), True),
                             NOTE_OFF_BLOCK: T.note_events_np(_lanes(n), _keys(w), False)})
         if wl["kind"] == "chain":

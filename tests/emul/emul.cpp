@@ -66,7 +66,7 @@ static void welsh_emul_split_frame3(const WelshParams& p, WelshState& s, const R
   if (RETUNE) { bool hi; const float tj = lp24_t_from_pct(ab_pct, rc, hi); bc_t = (ab_pct == ab_pct) ? (hi ? -tj : tj) : kNan; }
   L = 0.0f; R = 0.0f;                                                                         // role C
   if (ac_sum == ac_sum) {
-    if (RETUNE && bc_t == bc_t) coef = lp24_coefd_from_t(p.fc, fabsf(bc_t), bc_t < 0.0f);
+    if (RETUNE && bc_t == bc_t) coef = lp24_coefd_from_t(p.fc, fabsf(bc_t), bc_t < 0.0f, (p.flags & WF_COEF_WIDE) != 0);
     welsh_frame_back<false>(p, s.filt, coef, ac_sum, g, L, R);
   }
 }
@@ -83,10 +83,10 @@ static void welsh_emul_split_frame4(const WelshParams& p, WelshState& s, const R
   const float ac_sum = ok ? welsh_frame_osc<MODE, OSC_ANY, OSC_ANY, false>(p, s, MODE == LFO_F64_SMOOTH, mod, first) : kNan; // role A2
   Lp24CoefQ q{kNan, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};                                                                          // role B
   bool hi = false;
-  if (RETUNE && ab_pct == ab_pct) { const float t = lp24_t_from_pct(ab_pct, rc, hi); q = lp24_coefq_from_t(p.fc, t, hi); if (hi) q.qa = -q.qa; }
+  if (RETUNE && ab_pct == ab_pct) { const float t = lp24_t_from_pct(ab_pct, rc, hi); q = lp24_coefq_from_t(p.fc, t, hi, (p.flags & WF_COEF_WIDE) != 0); if (hi) q.qa = -q.qa; }
   L = 0.0f; R = 0.0f;                                                                                                        // role C
   if (ac_sum == ac_sum) {
-    if (RETUNE && q.ba == q.ba) { const bool up = q.qa < 0.0f; q.qa = fabsf(q.qa); coef = lp24_coefd_from_q(q, up); }
+    if (RETUNE && q.ba == q.ba) { const bool up = q.qa < 0.0f; q.qa = fabsf(q.qa); coef = lp24_coefd_from_q(q, up, (p.flags & WF_COEF_WIDE) != 0); }
     welsh_frame_back<false>(p, s.filt, coef, ac_sum, g, L, R);
   }
 }
@@ -265,6 +265,17 @@ uint32_t emul_set_f32_kind(void* h, int on) {
     if (on && welsh_filter_f32_ok(b->wp[v], b->sr)) { b->wp[v].flags |= WF_FILTER_F32; ++flagged; }
   }
   return flagged;
+}
+// What kernel instantiation the library gives this patch (dsp_core.h welsh_base_kind / welsh_body_classes; derive.h flags):
+// out = {base kind 0..5, LFO class, oscillator 1 class, oscillator 2 class, WF_FILTER_F32 promise, derived flags word}.
+void emul_welsh_classify(const groove_welsh_params* p, uint32_t sr, uint32_t out[6]) {
+  WelshCold c;
+  WelshParams o = derive_welsh(*p, (double)sr, c);
+  const int base = welsh_base_kind(o);
+  int cl, c1, c2;
+  welsh_body_classes(o, base, cl, c1, c2);
+  out[0] = (uint32_t)base; out[1] = (uint32_t)cl; out[2] = (uint32_t)c1; out[3] = (uint32_t)c2;
+  out[4] = welsh_filter_f32_ok(o, (double)sr) ? 1u : 0u; out[5] = o.flags;
 }
 double emul_filter_f32_error(const groove_welsh_params* p, uint32_t sr) { WelshCold c; return welsh_filter_f32_error(derive_welsh(*p, (double)sr, c), (double)sr); }
 void emul_set_segmented(void* h, int on) { ((EmulBank*)h)->segmented = on; }

@@ -428,3 +428,64 @@ def test_reference_patch_library_through_the_device_arithmetic(oracle):
         worst = max(worst, (float(per_voice.max()), os.path.basename(f)))
     assert played >= 100 and sounding >= 85, (played, sounding)
     assert worst[0] > 1e-9
+
+
+# ---- the library-proportioned patch table (round 6; groove_amd/patches.py LIBRARY_*, workload welsh-1m-library)
+def _library_bank(keys_of=(43, 66)):
+    S = P.LIBRARY_SLOTS
+    pats = [P.library_patch(s) for s in range(S) for _ in keys_of]
+    keys = np.array([k for _ in range(S) for k in keys_of], dtype=np.uint8)   # (no A: docs/DSP_SPEC.md section 2)
+    n = len(pats)
+    lanes = np.arange(n, dtype=np.uint32)
+    return (T.WelshParams * n)(*pats), T.note_events_np(lanes, keys, True), T.note_events_np(lanes, keys, False)
+
+
+@pytest.mark.parametrize("form", ["per-kind (fp32 filter kind on)", "four roles", "time-parallel"])
+def test_library_table_through_the_device_arithmetic(oracle, form):
+    """The 106 slots of the library-proportioned table — square / sawtooth LFOs on the pitch and the pulse width (the smooth kinds'
+    recurrences, re-seeded exactly on the frame of an LFO edge: dsp_core.h welsh_frame_front), filters with ripples up to 10.7 under
+    envelope and LFO sweeps (lp24_coefd_from_t's two-sided `wide` form, in every kind since round 6), a noise LFO on the pitch and the
+    resonance routing (the exact-f64 kind) — two keys each through note-on, note-off and release, the emulated device arithmetic
+    against the f64 oracle voice by voice: <= 6e-6 RMS of max(1, the voice's level) (measured: 3.8e-6 at worst, every form alike)."""
+    params, on, off = _library_bank()
+    be = E.Bank.welsh(params)
+    if form.startswith("per-kind"):
+        assert be.set_f32_kind(True) > 40
+    elif form == "four roles":
+        be.set_role_split(4)
+    else:
+        be.set_time_parallel(True)
+    o, e = _render(oracle.Bank.welsh(params), be, on, off, 60, 40)
+    level = np.sqrt(np.mean(o ** 2, axis=(0, 1)))
+    per_voice = np.sqrt(np.mean((e - o) ** 2, axis=(0, 1))) / np.maximum(1.0, level)
+    assert np.isfinite(e).all() and per_voice.max() <= 6e-6, (int(per_voice.argmax()) // 2, per_voice.max())
+    assert (level > 1e-3).sum() >= len(level) - 4   # (a 370 Hz triangle behind a static 40 Hz filter is 70 dB down)
+
+
+def test_library_table_has_the_class_proportions_of_the_reference_library():
+    """profiles/r06_library_proportions.json is what tools/library_proportions.py printed for the reference's 106 patch files (counts
+    only); the synthetic table's slots, put through the library's own kind rule, land in the same base kinds in the same numbers — and in
+    the development container the script is run again on the files themselves."""
+    import ctypes as C
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    want = json.load(open(os.path.join(root, "profiles", "r06_library_proportions.json")))
+    L = C.CDLL(E.build())
+    L.emul_welsh_classify.argtypes = [C.POINTER(T.WelshParams), C.c_uint32, C.POINTER(C.c_uint32)]
+    names = ["F32-static", "F32-retune", "smooth-static", "smooth-retune", "exact-f64-static", "exact-f64-retune"]
+    got = {k: 0 for k in names}
+    f32 = 0
+    for s in range(P.LIBRARY_SLOTS):
+        out = (C.c_uint32 * 6)()
+        p = P.library_patch(s)
+        L.emul_welsh_classify(C.byref(p), 44100, out)
+        got[names[out[0]]] += 1
+        f32 += int(out[4])
+    assert want["derived"] == P.LIBRARY_SLOTS == 106
+    assert got == want["base_kind"], (got, want["base_kind"])
+    ref_f32 = sum(v for k, v in want["fp32_filter_ok"].items() if k.endswith("/ fp32"))
+    assert abs(f32 - ref_f32) <= 6, (f32, ref_f32)   # (the fp32 promise is a measurement on synthetic cutoffs: close, not equal)
+    if os.path.isdir("/root/reference/assets/patches/welsh"):
+        import subprocess, sys
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "library_proportions.py"), "--json"], capture_output=True, text=True, check=True).stdout
+        assert json.loads(out) == want, "profiles/r06_library_proportions.json is stale: rerun tools/library_proportions.py --json"
