@@ -975,6 +975,25 @@ def form_entry(ctx, label, K, W, fused, grouped, note):
             "hbm_physical_frac": 10.0 * V * FRAMES / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
+def window_entry(ctx, workload, K, W, ms_headline, note):
+    """A million-voice workload other than the headline's over the headline's window (blocks W..W+K-1, fused render + mix): timed,
+    priced against the same algorithmic bytes, with its own sampled parity.  `welsh-1m-library`: the 106-slot table whose class
+    proportions follow the reference's patch library (groove_amd/patches.py LIBRARY_*)."""
+    wl = WORKLOADS[workload]
+    V = wl["voices"]
+    m = bench_workload(ctx, workload, np.arange(V, dtype=np.int64), K, W, SHORT_WINDOW_REPEATS)
+    i = m["median"]
+    ms = m["walls"][i] / K * 1e3
+    fps = K * FRAMES / m["walls"][i]
+    byts = wl["bytes_per_vf"] * V * FRAMES
+    return {"workload": workload, "voices": V, "blocks_timed": f"{W}..{W + K - 1}", "note": note, "kernel_form": m["kernel_form"], "walk": m["walk"],
+            "ms_per_step": ms, "ms_per_step_repeats": [w / K * 1e3 for w in m["walls"]], "statistic": "median region",
+            "kernel_ms": m["kerns"][i], "value": fps, "unit": "stereo frames/s", "x_realtime_44k1": fps / SR,
+            "vs_headline_step": ms / ms_headline if ms_headline else None,
+            "frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_is": "effective (SURVEY §8d algorithmic bytes / time)",
+            "parity_vs_oracle": sampled_parity(ctx, workload, V, min(K + W, 48), sample=212)}
+
+
 def shard_curve(ctx, K, W, ms_full):
     """What strong scaling can reach, measured on this one GPU: the per-GPU shard of welsh-1m on 1 / 2 / 4 / 8 GPUs (V, V/2,
     V/4, V/8 voices: the first rank's contiguous range) over the same window, and the 16,384-voice shard of
@@ -1233,6 +1252,10 @@ def measure(args, world, rank, local_rank):
         if default_line and not args.no_configs:
             line["configs"] = [config_entry(ctx, w, R) for w in ("welsh-256", "chain-4096", "sampler-16384", "mixed-131072")]
             Kf, Wf = min(K, 20), min(W, 5)
+            line["configs"].append(window_entry(ctx, "welsh-1m-library", Kf, Wf, line["ms_per_step"] if (K, W) == (Kf, Wf) else None,
+                                                "106 synthetic patches in the class proportions of the reference's patch library "
+                                                "(profiles/r06_library_proportions.json): square / sawtooth LFOs on the pitch, ripples up to 10.7 under sweeps, "
+                                                "a noise LFO on the pitch and the resonance routing (the exact-f64 kind: 1.9 % of the voices)"))
             line["configs"].append(form_entry(ctx, "welsh-1m-materialised", Kf, Wf, False, True,
                                               "entity-boundary form: every voice block written to HBM (2 GB per block), mixed from the render's row sums"))
             line["configs"].append(form_entry(ctx, "welsh-1m-interleaved-materialised", Kf, Wf, False, False,

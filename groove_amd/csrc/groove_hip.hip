@@ -124,6 +124,8 @@ struct groove_bank {
   bool tp_pairs = false;         // welsh: every pair of adjacent voices (2i, 2i + 1) shares a patch (welsh_tp_kernel<.., VPW = 2>)
   uint8_t* d_wg_base = nullptr;  // welsh: base kind of each entry of d_wg_list (the all-kinds kernel of small banks)
   uint8_t* d_wg_f32 = nullptr;   // welsh: 1 where the entry's patches carry WF_FILTER_F32 (the fused per-kind kernels)
+  uint32_t mix_off[3] = {}, mix_cnt[3] = {}; // welsh: the MIX kernel's three sections of the lists (kernels.h): entries [wg_list_cap + mix_off[s], + mix_cnt[s]) of all four arrays — the
+                                             // class-specialised workgroups of the kind-sorted list taken with a stride of three, each section kind-sorted itself
   uint32_t* d_wg_list = nullptr; // welsh: workgroup ids (groups of 4 virtual waves) sorted by kind (kernels.h)
   size_t wg_list_cap = 0;
   uint32_t wgs_of_kind[kWgKinds] = {};  // slice lengths of d_wg_list, in kind order
@@ -214,6 +216,7 @@ struct groove_ctx {
   // creates lands on hardware queue (k - 1) mod 4, so the fifth (and the ninth) shares the ctx stream's queue; the fifth
   // used to be the fourth kind stream and is now a placeholder nobody uses.
   int kind_streams = 3;
+  bool mix_kernel = true; // big Welsh banks: the four class-specialised kinds in three balanced launches (kernels.h, the MIX kernel); GROOVE_MIX_KERNEL=0: one launch per base kind (round 5's form, for A/B runs)
   int next_stream_slot = 0;             // round-robin side-stream assignment of single-kernel banks
   uint32_t fm_tp_max_voices = kFmTpMaxVoices;
   // Welsh banks of at least this many voices whose adjacent pairs share a patch render two voices per wavefront
@@ -647,19 +650,38 @@ int welsh_upload_params(groove_bank* b, bool regroup) {
   if (b->wg_list_cap < wgs) {
     if (b->d_wg_list) GHIP(ctx, hipFree(b->d_wg_list));
     b->wg_list_cap = wgs + wgs / 8 + 16;
-    GHIP(ctx, hipMalloc(&b->d_wg_list, b->wg_list_cap * sizeof(uint32_t)));
+    // (twice the capacity: the kind-sorted lists in the first half, the mix kernel's striped copy of them in the second)
+    GHIP(ctx, hipMalloc(&b->d_wg_list, 2 * b->wg_list_cap * sizeof(uint32_t)));
     if (b->d_wg_cls) GHIP(ctx, hipFree(b->d_wg_cls));
-    GHIP(ctx, hipMalloc(&b->d_wg_cls, b->wg_list_cap));
+    GHIP(ctx, hipMalloc(&b->d_wg_cls, 2 * b->wg_list_cap));
     if (b->d_wg_base) GHIP(ctx, hipFree(b->d_wg_base));
-    GHIP(ctx, hipMalloc(&b->d_wg_base, b->wg_list_cap));
+    GHIP(ctx, hipMalloc(&b->d_wg_base, 2 * b->wg_list_cap));
     if (b->d_wg_f32) GHIP(ctx, hipFree(b->d_wg_f32));
-    GHIP(ctx, hipMalloc(&b->d_wg_f32, b->wg_list_cap));
+    GHIP(ctx, hipMalloc(&b->d_wg_f32, 2 * b->wg_list_cap));
   }
   GHIP(ctx, ctx_memcpy(ctx, b->d_waves, W.data(), W.size() * sizeof(WaveDesc), hipMemcpyHostToDevice));
   GHIP(ctx, ctx_memcpy(ctx, b->d_wg_list, wg_list.data(), (size_t)wgs * sizeof(uint32_t), hipMemcpyHostToDevice));
   GHIP(ctx, ctx_memcpy(ctx, b->d_wg_cls, wg_cls.data(), wgs, hipMemcpyHostToDevice));
   GHIP(ctx, ctx_memcpy(ctx, b->d_wg_base, wg_base.data(), wgs, hipMemcpyHostToDevice));
   GHIP(ctx, ctx_memcpy(ctx, b->d_wg_f32, wg_f32.data(), wgs, hipMemcpyHostToDevice));
+  { // the mix kernel's sections: slots s, s + 3, s + 6 ... of the class-specialised part of the sorted list (the exact-f64 kinds, last in it, keep their own kernels)
+    uint32_t n_spec = 0;
+    for (int k = 0; k < 4 * kClassCombos; ++k) n_spec += b->wgs_of_kind[k];
+    std::vector<uint32_t> m_list(n_spec);
+    std::vector<uint8_t> m_cls(n_spec), m_base(n_spec), m_f32(n_spec);
+    uint32_t at = 0;
+    for (uint32_t sec = 0; sec < 3; ++sec) {
+      b->mix_off[sec] = at;
+      for (uint32_t g = sec; g < n_spec; g += 3, ++at) { m_list[at] = wg_list[g]; m_cls[at] = wg_cls[g]; m_base[at] = wg_base[g]; m_f32[at] = wg_f32[g]; }
+      b->mix_cnt[sec] = at - b->mix_off[sec];
+    }
+    if (n_spec) {
+      GHIP(ctx, ctx_memcpy(ctx, b->d_wg_list + b->wg_list_cap, m_list.data(), (size_t)n_spec * sizeof(uint32_t), hipMemcpyHostToDevice));
+      GHIP(ctx, ctx_memcpy(ctx, b->d_wg_cls + b->wg_list_cap, m_cls.data(), n_spec, hipMemcpyHostToDevice));
+      GHIP(ctx, ctx_memcpy(ctx, b->d_wg_base + b->wg_list_cap, m_base.data(), n_spec, hipMemcpyHostToDevice));
+      GHIP(ctx, ctx_memcpy(ctx, b->d_wg_f32 + b->wg_list_cap, m_f32.data(), n_spec, hipMemcpyHostToDevice));
+    }
+  }
   return 0;
 }
 
@@ -1153,7 +1175,7 @@ static bool create_streams(groove_ctx* ctx) {
   // walks are paced by the host (profiles/r05_layout_ab.log).
   for (int i = 0; ok && i < kSideStreams; ++i) {
     if (i >= kBaseKinds + ctx->bank_streams) { ok = hipEventCreateWithFlags(&ctx->ev_join[i], kSyncEventFlags) == hipSuccess; continue; }
-    if (i == 4 || i == 5) ctx->side_stream[i] = ctx->side_stream[i - 4];
+    if (i == 4 || i == 5) ctx->side_stream[i] = ctx->side_stream[i - 4]; // (safe layout; otherwise re-pointed below)
     else if (i == 3 && ctx->kind_streams == 3) { // three normal-priority streams (see kind_streams); the fifth stream the
       // process creates lands on the ctx stream's hardware queue (so does the ninth): that place is taken by a stream nobody uses
       if (!ctx->safe_streams) ok = make(&ctx->placeholder_stream, 0);
@@ -1164,6 +1186,11 @@ static bool create_streams(groove_ctx* ctx) {
     else ok = make(&ctx->side_stream[i], prio_least);
     ok = ok && hipEventCreateWithFlags(&ctx->ev_join[i], kSyncEventFlags) == hipSuccess;
   }
+  // The two exact-f64-LFO kinds run on the FIRST BANK STREAM (round 6; they shared the first two kind streams before): their few
+  // workgroups take one wavefront's walk of the block whatever their number (~210 us for 2 % of a million voices), and behind
+  // another kind's kernel on its stream that walk was added to the stream's time per block — the step's long pole with the
+  // library-proportioned table (profiles/r06_*).  On a stream of their own they run beside the others.
+  if (ok && !ctx->safe_streams && ctx->bank_streams > 0 && ctx->side_stream[kBaseKinds]) ctx->side_stream[4] = ctx->side_stream[5] = ctx->side_stream[kBaseKinds];
   return ok;
 }
 static bool side_stream_owned(const groove_ctx* ctx, int i) {
@@ -1185,6 +1212,7 @@ static int init_impl(int device_ordinal, const uint8_t* comm_id, int rank, int w
   ctx->device = device_ordinal;
   if (const char* e = std::getenv("GROOVE_FX_SEQ_ALLPASS")) ctx->seq_allpass = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_SAFE_STREAMS")) ctx->safe_streams = e[0] == '1';
+  if (const char* e = std::getenv("GROOVE_MIX_KERNEL")) ctx->mix_kernel = e[0] != '0';
   if (const char* e = std::getenv("GROOVE_SYNC_TIMEOUT_MS")) ctx->sync_timeout_ms = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FM_TP_VPW4_MIN_VOICES")) ctx->fm_tp_vpw4_min_voices = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_BIND_EVENTS")) ctx->bind_events = std::atoi(e) != 0;
@@ -1977,12 +2005,16 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
     for (int k = 0; k < kSideStreams; ++k) GHIP(ctx, hipEventCreateWithFlags(&b->ev_render_done[k][slot], kSyncEventFlags));
   }
   uint32_t count[kSideStreams] = {}, offset[kSideStreams] = {}; // per stream: Welsh base kinds first, then the bank streams
+  // The MIX kernel (kernels.h; round 6): the four class-specialised base kinds in three launches, one per kind stream, each over a
+  // third of their workgroups (every third entry of the kind-sorted list); the exact-f64 kinds keep their per-kind kernels.
+  const bool mix = uniform && ctx->mix_kernel;
   if (uniform) {
     for (uint32_t base = 0, at = 0; base < (uint32_t)kBaseKinds; ++base) {
       offset[base] = at;
       for (int c = 0; c < kClassCombos; ++c) count[base] += b->wgs_of_kind[base * kClassCombos + c];
       at += count[base];
     }
+    if (mix) { for (int sec = 0; sec < 3; ++sec) count[sec] = b->mix_cnt[sec]; count[3] = 0; }
   } else {
     count[b->stream_slot] = rows; // one kernel, on this bank's side stream (the loop below runs once)
   }
@@ -2015,7 +2047,12 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
     // the block's "render done" event completes with the render kernel itself (kernels.h launch_bound): no record packet between
     // this block's kernel and the next block's on the stream
     const hipEvent_t done = ctx->bind_events ? b->ev_render_done[k][slot] : nullptr;
-    if (uniform) {
+    if (uniform && mix && k < 3) {
+      UniformArgs a = uniform_args(b, b->d_pipe_part[slot], b->d_pipe_part[slot], 0, 0, frames, count[k]);
+      const size_t o = b->wg_list_cap + b->mix_off[k]; // the section's entries of the striped copies (welsh_upload_params)
+      a.wg_list = b->d_wg_list + o; a.wg_cls = b->d_wg_cls + o; a.wg_f32 = b->d_wg_f32 + o;
+      launch_welsh_uniform_mix(a, b->d_wg_base + o, st, done);
+    } else if (uniform) {
       UniformArgs a = uniform_args(b, b->d_pipe_part[slot], b->d_pipe_part[slot], offset[k], 0, frames, count[k]);
       launch_welsh_kind(k, a, st, true, done);
     } else if (tp) {

@@ -568,6 +568,43 @@ __global__ __launch_bounds__(kThreads, GROOVE_WAVES_ANY) GROOVE_NO_TAIL_CALLS vo
   }
 }
 #endif // GROOVE_WELSH_ANY_TU
+// The four class-specialised base kinds in ONE kernel at the per-kind kernels' own register budget (all four are budgeted for five
+// waves per SIMD since round 5), the fp32-filter bodies included: the MIX kernel of big banks (round 6).  A block of a big bank is
+// THREE launches of it, one per kind stream, each over a third of the workgroup list taken with a stride of three (groove_hip.hip
+// welsh_upload_params: every launch carries the bank's own mix of kinds, most expensive first), instead of one launch per base kind:
+// with per-kind launches a stream's time per block is what ITS kinds cost — 460 / 455 / 222 us on the three streams for the 32-patch
+// benchmark table (profiles/r05_welsh-1m-window_summary.json), 462 / 546 / 266 for the library-proportioned one — and the slowest stream is
+// the step; thirds of everything are balanced whatever the patches are, and every stream has one launch per block (a launch cannot
+// take less than one wavefront's walk of the block, ~180 us: two launches on a stream are two such floors).
+#ifndef GROOVE_WAVES_MIX
+#define GROOVE_WAVES_MIX 5
+#endif
+#ifdef GROOVE_WELSH_MIX_TU // defined by the translation units that own this kernel (csrc/welsh_class.hip, -DGROOVE_BASE_KIND=10 fused, 11 block-writing)
+template <bool FUSED>
+__global__ __launch_bounds__(kThreads, GROOVE_WAVES_MIX) GROOVE_NO_TAIL_CALLS void welsh_render_uniform_mix_kernel(UniformArgs a, const uint8_t* __restrict__ wg_base) {
+  const UniformArgsPtr ka = (UniformArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  if constexpr (FUSED) { if (welsh_idle_workgroup(a)) return; }
+  const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wg_base[GROOVE_WG_SLOT(a.n_wgs)]);
+  const uint32_t cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[GROOVE_WG_SLOT(a.n_wgs)]);
+  bool f32 = false;
+  if constexpr (FUSED) f32 = __builtin_amdgcn_readfirstlane((int)a.wg_f32[GROOVE_WG_SLOT(a.n_wgs)]) != 0;
+#define GROOVE_MIX_CASE(MODE, RETUNE)                                                          \
+  if constexpr (FUSED) {                                                                       \
+    if (f32) welsh_dispatch_class<FUSED, MODE, RETUNE, true>(cls, ka);                         \
+    else welsh_dispatch_class<FUSED, MODE, RETUNE, false>(cls, ka);                            \
+  } else {                                                                                     \
+    welsh_dispatch_class<FUSED, MODE, RETUNE, false>(cls, ka);                                 \
+  }
+  switch (base) {
+    case wg_base_kind_of(LFO_F32, false): GROOVE_MIX_CASE(LFO_F32, false) break;
+    case wg_base_kind_of(LFO_F32, true): GROOVE_MIX_CASE(LFO_F32, true) break;
+    case wg_base_kind_of(LFO_F64_SMOOTH, false): GROOVE_MIX_CASE(LFO_F64_SMOOTH, false) break;
+    default: GROOVE_MIX_CASE(LFO_F64_SMOOTH, true) break;
+    // (the exact-f64 base kinds 4 and 5 are never in this launch: their own kernels, on their own stream)
+  }
+#undef GROOVE_MIX_CASE
+}
+#endif // GROOVE_WELSH_MIX_TU
 static_assert(OSC_CLASSES == 5 && LFO_CLASSES == 6 && kClassCombos <= 256, "the class switch above lists 6 x 5 x 5 combinations, one byte each");
 // Launchers of the four class-specialised fused kernels, one translation unit each
 // (csrc/welsh_class.hip, -DGROOVE_BASE_KIND=0..3) so that they compile in parallel.
@@ -585,6 +622,8 @@ void launch_welsh_uniform_specialised_2(const UniformArgs& a, hipStream_t st, bo
 void launch_welsh_uniform_specialised_3(const UniformArgs& a, hipStream_t st, bool fused, hipEvent_t done = nullptr);
 void launch_welsh_uniform_any(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, hipEvent_t done = nullptr); // fused: csrc/welsh_class.hip, -DGROOVE_BASE_KIND=9
 void launch_welsh_uniform_any_unfused(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, hipEvent_t done = nullptr); // writes the voice block: -DGROOVE_BASE_KIND=8
+void launch_welsh_uniform_mix(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, hipEvent_t done = nullptr); // the mix kernel, fused: -DGROOVE_BASE_KIND=10
+void launch_welsh_uniform_mix_unfused(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, hipEvent_t done = nullptr); // ... writing the voice block: -DGROOVE_BASE_KIND=11
 
 template <bool FUSED>
 __global__ __launch_bounds__(kThreads) void fm_render_kernel(

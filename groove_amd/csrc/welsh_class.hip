@@ -1,14 +1,17 @@
 // welsh_class.hip — the fused, class-specialised uniform Welsh kernel of ONE base kind (compiled
 // with -DGROOVE_BASE_KIND=0..3, so the block bodies build in parallel), or (-DGROOVE_BASE_KIND=9)
-// the all-kinds kernel of small banks (=8: its block-writing form).  See
+// the all-kinds kernel of small banks (=8: its block-writing form), or (=10 / 11) the mix kernel of big banks.  See
 // kernels.h, "Workgroup KINDS".
 #define GROOVE_WELSH_CLASS_TU 1
 #if defined(GROOVE_BASE_KIND) && (GROOVE_BASE_KIND == 9 || GROOVE_BASE_KIND == 8)
 #define GROOVE_WELSH_ANY_TU 1
 #endif
+#if defined(GROOVE_BASE_KIND) && (GROOVE_BASE_KIND == 10 || GROOVE_BASE_KIND == 11)
+#define GROOVE_WELSH_MIX_TU 1
+#endif
 #include "kernels.h"
 #ifndef GROOVE_BASE_KIND
-#error "compile with -DGROOVE_BASE_KIND=<0..3, 8, 9>"
+#error "compile with -DGROOVE_BASE_KIND=<0..3, 8, 9, 10, 11>"
 #endif
 namespace groove {
 #if GROOVE_BASE_KIND == 0
@@ -38,6 +41,14 @@ void launch_welsh_uniform_any(const UniformArgs& a, const uint8_t* wg_base, hipS
 #elif GROOVE_BASE_KIND == 8
 void launch_welsh_uniform_any_unfused(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, hipEvent_t done) {
   launch_bound(welsh_render_uniform_any_kernel<false>, dim3(a.n_wgs), dim3(kThreads), st, done, a, wg_base);
+}
+#elif GROOVE_BASE_KIND == 10
+void launch_welsh_uniform_mix(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, hipEvent_t done) {
+  launch_bound(welsh_render_uniform_mix_kernel<true>, dim3(a.n_wgs), dim3(kThreads), st, done, a, wg_base);
+}
+#elif GROOVE_BASE_KIND == 11
+void launch_welsh_uniform_mix_unfused(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, hipEvent_t done) {
+  launch_bound(welsh_render_uniform_mix_kernel<false>, dim3(a.n_wgs), dim3(kThreads), st, done, a, wg_base);
 }
 #else
 #error "GROOVE_BASE_KIND out of range"

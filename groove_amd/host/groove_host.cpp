@@ -71,6 +71,19 @@ void VoiceBankInstrument::note_off(uint8_t key, uint8_t velocity, uint64_t now) 
   }
 }
 
+int VoiceBankInstrument::control_index_for_name(const std::string& name) const {
+  // #[derive(Control)] kebab-case names, nested fields joined with '-' (proc-macros/src/control.rs:127-131, 165): WelshSynth's `dca`
+  // field gives dca-gain / dca-pan; the filter's cutoff is the one Welsh voice parameter the reference's demos automate on effects
+  static const std::pair<const char*, int> table[] = {
+      {"dca-gain", GROOVE_CTL_WELSH_DCA_GAIN}, {"gain", GROOVE_CTL_WELSH_DCA_GAIN}, {"dca-pan", GROOVE_CTL_WELSH_DCA_PAN}, {"pan", GROOVE_CTL_WELSH_DCA_PAN},
+      {"filter-cutoff", GROOVE_CTL_WELSH_CUTOFF}, {"cutoff", GROOVE_CTL_WELSH_CUTOFF}};
+  for (auto& t : table) if (name == t.first) return t.second;
+  return -1;
+}
+int VoiceBankInstrument::control_set_param(uint32_t index, double value01) {
+  return groove_bank_set_param(bank_, GROOVE_ALL_VOICES, index, value01); // (fails, with the library's message, on a bank that has no such control)
+}
+
 // ------------------------------------------------------------------ ToyAudioSource
 ToyAudioSource::ToyAudioSource(groove_ctx* ctx, double level) : ctx_(ctx), level_((float)level) {
   groove_block_create(ctx_, 1, GROOVE_BLOCK_FRAMES, &block_);
@@ -368,6 +381,10 @@ int Orchestrator::control_effect(Uid target, uint32_t index, double value01) {
   if (deferring_) { deferred_.push_back({target, index, value01}); return 0; }
   Entity* e = get(target);
   if (e && e->is_effect()) return static_cast<Effect*>(e)->control_set_param(index, value01);
+  if (e && e->is_instrument()) { // Controllable is generated for every entity (proc-macros/src/control.rs:171-183)
+    if (static_cast<Instrument*>(e)->control_set_param(index, value01)) return fail(groove_last_error(ctx_));
+    return 0;
+  }
   return 0;
 }
 void Orchestrator::sequence_block(uint64_t at_frame, uint32_t frames) {
@@ -599,6 +616,32 @@ int gh_add_drumkit(void* h, const float* pcm, uint64_t frames, const groove_samp
   };
   return (int)o->add(std::unique_ptr<Entity>(new Drumkit(o->ctx(), b, 128, true, 0.0, true)));
 }
+// Sampler (settings/src/instruments.rs:34-37, 81-88): one mono buffer, `voices` voices that step through it at note / root (SURVEY A.10:
+// no interpolation), stopped by their note-off.
+int gh_add_sampler(void* h, const float* pcm, uint64_t frames, double root_hz, uint32_t voices) {
+  Orchestrator* o = (Orchestrator*)h;
+  if (!pcm || !frames || !voices) { o->fail("gh_add_sampler: empty sample"); return -1; }
+  groove_sample_desc d{0, (uint32_t)std::min<uint64_t>(frames, 0xFFFFFFFFu), (float)root_hz};
+  std::vector<groove_sampler_params> p(voices);
+  for (auto& x : p) { x.sample_index = 0; x.one_shot = 0; x.gain = 1.0f; }
+  groove_bank* b = nullptr;
+  if (groove_sampler_create(o->ctx(), pcm, frames, &d, 1, p.data(), voices, &b)) { o->fail(groove_last_error(o->ctx())); return -1; }
+  return (int)o->add(std::unique_ptr<Entity>(new VoiceBankInstrument(o->ctx(), b, voices, true, 0.0, false)));
+}
+// ToyInstrument (settings/src/instruments.rs:27-28, 67-70; the reference's own test entity, source absent: docs/DSP_SPEC.md section 7): a
+// sine oscillator at the note's pitch, gated by note-on / note-off, through a Dca — here an FM voice with index 0 and a gate for
+// an envelope; `fake-value` is a dummy control of the reference's tests and has no sound.
+int gh_add_toy_instrument(void* h, double dca_gain, double dca_pan) {
+  Orchestrator* o = (Orchestrator*)h;
+  groove_fm_params p{};
+  p.ratio = 1.0; p.depth = 0.0f; p.beta = 0.0f;
+  p.carrier_envelope = groove_envelope_params{0.0, 0.0, 1.0, 0.0};
+  p.modulator_envelope = groove_envelope_params{0.0, 0.0, 1.0, 0.0};
+  p.dca_gain = (float)dca_gain; p.dca_pan = (float)dca_pan;
+  groove_bank* b = nullptr;
+  if (groove_fm_create(o->ctx(), &p, 1, &b)) { o->fail(groove_last_error(o->ctx())); return -1; }
+  return (int)o->add(std::unique_ptr<Entity>(new VoiceBankInstrument(o->ctx(), b, 1, true, 0.0, false)));
+}
 int gh_add_effect(void* h, uint32_t kind, const groove_fx_params* p) {
   Orchestrator* o = (Orchestrator*)h;
   return (int)o->add(std::unique_ptr<Entity>(new FxEffect(o->ctx(), kind, p, 1)));
@@ -629,8 +672,8 @@ int gh_sequencer_set_end(void* h, int uid, double beats) {
 int gh_add_control_trip(void* h, int target_uid, const char* param_name, double start_beat) {
   Orchestrator* o = (Orchestrator*)h;
   Entity* e = o->get((Uid)target_uid);
-  if (!e || !e->is_effect()) { o->fail("control trip target is not an effect"); return -1; }
-  const int idx = static_cast<Effect*>(e)->control_index_for_name(param_name);
+  if (!e || !(e->is_effect() || e->is_instrument())) { o->fail("control trip target is neither an effect nor an instrument"); return -1; }
+  const int idx = e->is_effect() ? static_cast<Effect*>(e)->control_index_for_name(param_name) : static_cast<Instrument*>(e)->control_index_for_name(param_name);
   if (idx < 0) { o->fail(std::string("unknown control name ") + param_name); return -1; }
   return (int)o->add(std::unique_ptr<Entity>(new ControlTrip((Uid)target_uid, (uint32_t)idx, start_beat)));
 }

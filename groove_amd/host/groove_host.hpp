@@ -90,6 +90,10 @@ class Instrument : public Entity {
   // nothing else, such an instrument needs no voice block at all — the orchestrator renders it fused onto the bus
   // (Orchestrator::gather_audio's fast path).
   virtual groove_bank* fused_bank() { return nullptr; }
+  // Controllable (proc-macros/src/control.rs:171-249: generated for EVERY entity, instruments included): a ControlTrip whose target
+  // is an instrument drives these (entities/src/controllers/control_trip.rs:184-254).  -1 / 1: no such control.
+  virtual int control_index_for_name(const std::string&) const { return -1; }
+  virtual int control_set_param(uint32_t index, double value01) { (void)index; (void)value01; return 1; }
 };
 
 // IsEffect: TransformsAudio.
@@ -136,6 +140,9 @@ class VoiceBankInstrument : public Instrument {
   void note_off(uint8_t key, uint8_t velocity, uint64_t now_frame) override;
   groove_bank* bank() { return bank_; }
   groove_bank* fused_bank() override { return bank_; }
+  // the controls the library's banks expose (include/groove_types.h GROOVE_CTL_WELSH_*; Welsh banks only), for every voice of the synth
+  int control_index_for_name(const std::string& name) const override;
+  int control_set_param(uint32_t index, double value01) override;
   uint32_t last_allocated_voice() const { return last_voice_; }
  private:
   groove_ctx* ctx_;

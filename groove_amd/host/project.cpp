@@ -156,6 +156,54 @@ groove_welsh_params welsh_params_from_patch_json(const json5::Value& patch, std:
   return p;
 }
 
+groove_welsh_params welsh_params_from_raw_json(const json5::Value& params, std::vector<std::string>* warnings) {
+  const json5::Value* vp = params.get("voice");
+  const json5::Value& v = vp && vp->is_object() ? *vp : params;
+  groove_welsh_params p{};
+  auto osc = [&](const char* name, groove_oscillator_params& o) {
+    const json5::Value* x = v.get(name);
+    parse_waveform(x ? x->get("waveform") : nullptr, o.waveform, o.duty);
+    o.tune = 1.0; o.fixed_hz = 0.0;
+    if (x) {
+      const json5::Value* t = x->get("frequency-tune");
+      if (!t) t = x->get("tune");
+      const int note = parse_tune(t, o.tune);
+      if (note >= 0) o.fixed_hz = note_to_frequency(note);
+      const double fixed = x->number_or("fixed-frequency", 0.0);
+      if (fixed > 0.0) o.fixed_hz = fixed;
+    }
+  };
+  osc("oscillator-1", p.oscillator_1);
+  osc("oscillator-2", p.oscillator_2);
+  p.oscillator_2_sync = v.bool_or("oscillator-2-sync", false) ? 1 : 0;
+  p.oscillator_mix = (float)clamp01(v.number_or("oscillator-mix", 1.0));
+  p.amp_envelope = parse_envelope(v.get("amp-envelope"));
+  p.filter_envelope = parse_envelope(v.get("filter-envelope"));
+  const json5::Value* lfo = v.get("lfo");
+  float lfo_duty;
+  parse_waveform(lfo ? lfo->get("waveform") : nullptr, p.lfo_waveform, lfo_duty);
+  p.lfo_frequency = lfo ? lfo->number_or("frequency", 0.0) : 0.0;
+  const std::string routing = v.string_or("lfo-routing", "none");
+  static const std::pair<const char*, uint32_t> routes[] = {
+      {"none", GROOVE_LFO_NONE}, {"amplitude", GROOVE_LFO_AMPLITUDE}, {"pitch", GROOVE_LFO_PITCH}, {"pulse-width", GROOVE_LFO_PULSE_WIDTH},
+      {"filter-cutoff", GROOVE_LFO_FILTER_CUTOFF}};   // LfoRouting (patches.rs:271-290)
+  p.lfo_routing = GROOVE_LFO_NONE;
+  bool known = false;
+  for (auto& r : routes) if (routing == r.first) { p.lfo_routing = r.second; known = true; }
+  if (!known && warnings) warnings->push_back("lfo-routing '" + routing + "' is not a routing; the LFO is left unrouted");
+  p.lfo_depth = (float)clamp01(v.number_or("lfo-depth", 0.0));
+  const json5::Value* f = v.get("filter");
+  p.filter_cutoff_hz = (float)(f ? f->number_or("cutoff", 0.0) : 0.0);
+  p.filter_passband_ripple = (float)(f ? f->number_or("passband-ripple", 0.707) : 0.707);
+  p.filter_cutoff_start = (float)clamp01(v.number_or("filter-cutoff-start", 0.0));
+  p.filter_cutoff_end = (float)clamp01(v.number_or("filter-cutoff-end", 0.0));
+  const json5::Value* dca = params.get("dca");
+  if (!dca) dca = v.get("dca");
+  p.dca_gain = (float)(dca ? dca->number_or("gain", 1.0) : 1.0);
+  p.dca_pan = (float)(dca ? dca->number_or("pan", 0.0) : 0.0);
+  return p;
+}
+
 namespace {
 
 void parse_effect(const std::string& kind, const json5::Value& v, ProjectDesc::Device& d, std::vector<std::string>& warnings) {
@@ -237,6 +285,11 @@ ProjectDesc parse_project(const std::string& text, const std::string& assets_roo
         } else if (d.kind == "sampler") {
           d.name = params.string_or("filename", "");
           d.root = params.number_or("root", 0.0);
+        } else if (d.kind == "welsh-raw") {
+          d.welsh = welsh_params_from_raw_json(params, &p.warnings);
+        } else if (d.kind == "toy-instrument") {
+          d.toy_value = params.number_or("fake-value", 0.0);
+          if (const json5::Value* dca = params.get("dca")) { d.dca_gain = dca->number_or("gain", 1.0); d.dca_pan = dca->number_or("pan", 0.0); }
         } else if (d.kind == "fm-synthesizer") {
           d.fm.ratio = params.number_or("ratio", 2.0);
           d.fm.depth = (float)params.number_or("depth", 1.0);
@@ -346,7 +399,10 @@ ProjectDesc parse_project(const std::string& text, const std::string& assets_roo
 }
 
 ProjectDesc parse_project_file(const std::string& path, const std::string& assets_root) {
-  return parse_project(slurp(path), assets_root);
+  ProjectDesc p = parse_project(slurp(path), assets_root);
+  const size_t slash = path.find_last_of('/');
+  p.project_dir = slash == std::string::npos ? std::string(".") : path.substr(0, slash);
+  return p;
 }
 
 std::string describe(const ProjectDesc& p) {
@@ -418,6 +474,27 @@ bool read_wav_mono(const std::string& path, std::vector<float>& out, uint32_t* s
   return true;
 }
 
+int read_wav_root_note(const std::string& path) {
+  std::string data;
+  try { data = slurp(path); } catch (const std::exception&) { return -1; }
+  auto rd16 = [&](size_t o) { return (uint32_t)(uint8_t)data[o] | ((uint32_t)(uint8_t)data[o + 1] << 8); };
+  auto rd32 = [&](size_t o) { return rd16(o) | (rd16(o + 2) << 16); };
+  if (data.size() < 12 || data.compare(0, 4, "RIFF") != 0 || data.compare(8, 4, "WAVE") != 0) return -1;
+  int smpl = -1, acid = -1;
+  size_t pos = 12;
+  while (pos + 8 <= data.size()) {
+    const std::string id = data.substr(pos, 4);
+    const size_t len = rd32(pos + 4);
+    // smpl: manufacturer, product, sample period, MIDI unity note, pitch fraction, ... (unity note at byte 12 of the chunk)
+    if (id == "smpl" && len >= 16 && pos + 8 + 16 <= data.size()) { const uint32_t n = rd32(pos + 8 + 12); if (n <= 127) smpl = (int)n; }
+    // acid: flags (bit 1: the root note is set), root note (u16), ...
+    else if (id == "acid" && len >= 6 && pos + 8 + 6 <= data.size()) { const uint32_t fl = rd32(pos + 8), n = rd16(pos + 8 + 4); if ((fl & 2u) && n <= 127) acid = (int)n; }
+    if (len > data.size()) break;
+    pos += 8 + len + (len & 1);
+  }
+  return smpl >= 0 ? smpl : acid;
+}
+
 namespace {
 // Drumkit "707": GM percussion key → sample file (Appendix A.10).
 const std::pair<int, const char*> k707[] = {
@@ -451,6 +528,21 @@ void synthetic_707_kit(uint32_t sample_rate, std::vector<float>& pcm, std::vecto
 extern "C" int gh_add_drumkit(void*, const float*, uint64_t, const groove_sample_desc*, uint32_t, const int*);
 extern "C" int gh_add_welsh(void*, const groove_welsh_params*, uint32_t);
 extern "C" int gh_add_fm(void*, const groove_fm_params*, uint32_t);
+extern "C" int gh_add_sampler(void*, const float*, uint64_t, double, uint32_t);
+extern "C" int gh_add_toy_instrument(void*, double, double);
+// Where a sampler's file is looked for (the reference resolves it through groove_utils::Paths, absent from the tree): the assets'
+// samples directory, the assets directory, the project's own directory, the reference checkout's test-data (where the three
+// sampler projects' files lie: projects/tests/load-*-wav.json, projects/demos/instruments/sampler.json).
+std::string find_sample_file(const std::string& name, const std::string& assets_root, const std::string& project_dir) {
+  if (name.empty()) return name;
+  std::vector<std::string> tries;
+  if (name[0] == '/') tries.push_back(name);
+  if (!assets_root.empty()) { tries.push_back(assets_root + "/samples/" + name); tries.push_back(assets_root + "/" + name); }
+  if (!project_dir.empty()) tries.push_back(project_dir + "/" + name);
+  if (!assets_root.empty()) { tries.push_back(assets_root + "/../test-data/" + name); tries.push_back(assets_root + "/../test-data/samples/" + name); }
+  for (const auto& t : tries) { std::ifstream f(t, std::ios::binary); if (f) return t; }
+  return tries.empty() ? name : tries.front();
+}
 #endif
 } // namespace
 
@@ -487,8 +579,24 @@ int instantiate(Orchestrator& o, const ProjectDesc& p, const std::string& assets
         }
       }
       uid = gh_add_drumkit(&o, pcm.data(), pcm.size(), descs.data(), (uint32_t)descs.size(), key_to_sample);
+    } else if (d.kind == "welsh-raw") {
+      uid = gh_add_welsh(&o, &d.welsh, 8);
+    } else if (d.kind == "toy-instrument") {
+      uid = gh_add_toy_instrument(&o, d.dca_gain, d.dca_pan);
+    } else if (d.kind == "sampler") {
+      // SamplerParams{filename, root} (instruments.rs:81-88): root > 0 is the sample's pitch; 0 = the file's own root note (smpl /
+      // acid chunk), else 440 Hz — projects/tests/load-mono-wav.json plays a spoken sentence with root 0 on key 69 (docs/DSP_SPEC.md section 7)
+      const std::string path = find_sample_file(d.name, assets_root, p.project_dir);
+      std::vector<float> pcm;
+      std::string err;
+      uint32_t sr = 0;
+      if (!read_wav_mono(path, pcm, &sr, &err)) return o.fail(err);
+      if (pcm.empty()) return o.fail("sampler: no frames in " + path);
+      double root = d.root;
+      if (!(root > 0.0)) { const int note = read_wav_root_note(path); root = note >= 0 ? note_to_frequency(note) : 440.0; }
+      uid = gh_add_sampler(&o, pcm.data(), pcm.size(), root, 8);
     } else {
-      return o.fail("instrument kind '" + d.kind + "' cannot be instantiated on the GPU path yet");
+      return o.fail("instrument kind '" + d.kind + "' is not an instrument kind (settings/src/instruments.rs:26-39)");
     }
     if (uid < 0) return 1;
     o.get((Uid)uid)->name = d.id;
@@ -511,8 +619,10 @@ int instantiate(Orchestrator& o, const ProjectDesc& p, const std::string& assets
     auto target = uid_of.find(t.target);
     if (target == uid_of.end()) continue; // "Warning: trip … controls nonexistent entity" (songs.rs:300-304)
     Entity* e = o.get(target->second);
-    if (!e || !e->is_effect()) continue;
-    const int idx = static_cast<Effect*>(e)->control_index_for_name(t.param);
+    if (!e || !(e->is_effect() || e->is_instrument())) continue;
+    // Controllable is generated for instruments too (proc-macros/src/control.rs:171-183): the trip's values reach the synth's voices
+    // through groove_bank_set_param (round 6; trips onto instruments were dropped before)
+    const int idx = e->is_effect() ? static_cast<Effect*>(e)->control_index_for_name(t.param) : static_cast<Instrument*>(e)->control_index_for_name(t.param);
     if (idx < 0) continue; // "trip … not added because of error" (songs.rs:292-297)
     auto trip = std::unique_ptr<ControlTrip>(new ControlTrip(target->second, (uint32_t)idx, t.start_beat));
     for (const auto& s : t.steps) trip->add_step(s);
@@ -564,6 +674,8 @@ char* gh_project_describe_text(const char* text, const char* assets_root, char* 
   }
 }
 void gh_free(void* p) { std::free(p); }
+// The root note a WAV file carries (smpl chunk, else acid chunk), or -1.
+int gh_read_wav_root_note(const char* path) { return groove_host::read_wav_root_note(path ? path : ""); }
 // Welsh patch JSON text → groove_welsh_params (no GPU).
 int gh_welsh_params_from_patch_json(const char* text, groove_welsh_params* out, char* err, size_t err_len) {
   try {

@@ -17,11 +17,13 @@ namespace groove_host {
 struct ProjectDesc {
   struct Device {
     std::string id;
-    std::string kind;        // "welsh", "drumkit", "sampler", "fm-synthesizer", or an effect name
+    std::string kind;        // "welsh", "welsh-raw", "drumkit", "sampler", "fm-synthesizer", "toy-instrument", or an effect name
     bool is_effect = false;
     int midi_in = 0;
     std::string name;        // welsh patch name / drumkit name / sampler filename
-    double root = 0.0;       // sampler root frequency
+    double root = 0.0;       // sampler root frequency (0: the file's own — its smpl / acid chunk — else 440 Hz)
+    double toy_value = 0.0;  // toy-instrument: `fake-value` (a dummy control of the reference's tests)
+    double dca_gain = 1.0, dca_pan = 0.0; // toy-instrument: its Dca
     groove_welsh_params welsh{};
     groove_fm_params fm{};
     uint32_t fx_kind = GROOVE_FX_MIXER;
@@ -31,6 +33,7 @@ struct ProjectDesc {
   struct Trip { std::string id, target, param; double start_beat = 0.0; std::vector<ControlStep> steps; };
 
   std::string title;
+  std::string project_dir;   // directory of the project file (sample files are looked for there too); empty for parse_project(text)
   double bpm = 128.0;
   int ts_top = 4, ts_bottom = 4;
   std::vector<Device> devices;
@@ -54,6 +57,13 @@ ProjectDesc parse_project_file(const std::string& path, const std::string& asset
 // A compact JSON rendering of a ProjectDesc (used by the tests).
 std::string describe(const ProjectDesc& p);
 
+// WelshSynthParams as the project file carries it for `welsh-raw` (settings/src/instruments.rs:30-31; the struct settings/src/patches.rs:110-169
+// builds): {"voice": {"oscillator-1": {"waveform", "frequency-tune"}, .., "amp-envelope", "lfo", "lfo-routing", "lfo-depth", "filter":
+// {"cutoff", "passband-ripple"}, "filter-cutoff-start", "filter-cutoff-end", "filter-envelope", "dca"}, "dca"}; envelope times in seconds.
+groove_welsh_params welsh_params_from_raw_json(const json5::Value& params, std::vector<std::string>* warnings);
+// The MIDI root note a WAV file carries: the `smpl` chunk's unity note, else the `acid` chunk's root note (when its flags say it is
+// set; test-data/samples/riff-acidized.wav: 57), else -1.
+int read_wav_root_note(const std::string& path);
 // Mono PCM from a WAV file (16/24/32-bit int or 32-bit float, any channel count: channels averaged).
 bool read_wav_mono(const std::string& path, std::vector<float>& out, uint32_t* sample_rate, std::string* err);
 

@@ -162,7 +162,7 @@ def library_patch(s):
     d1 = [.1, .25, .45, .3][s % 4] if w1 == _PW else .5
     d2 = [.25, .45, .1, .35][(s // 2) % 4] if w2 == _PW else .5
     p.oscillator_1.waveform, p.oscillator_1.duty, p.oscillator_1.tune, p.oscillator_1.fixed_hz = w1, d1, 1.0, 0.0
-    tune2 = [1.0, semis_and_cents(12, 0.0), semis_and_cents(7, 5.0), semis_and_cents(-12, 0.0), 1.0, semis_and_cents(0, 7.0)][s % 6]
+    tune2 = [1.0, semis_and_cents(12, 0.0), semis_and_cents(7, 5.0), semis_and_cents(-12, 4.0), 1.0, semis_and_cents(0, 7.0)][s % 6]   # (an octave below, 4 cents sharp: exactly an octave below key 57 is 110 Hz, whose edges tie every 2,205 frames — docs/DSP_SPEC.md section 2)
     fixed2 = note_to_frequency(60) if (s % 35 == 17 and w2 != T.WAVE_NONE) else 0.0   # oscillator_2_track == false: 3 of the files
     p.oscillator_2.waveform, p.oscillator_2.duty, p.oscillator_2.tune, p.oscillator_2.fixed_hz = w2, d2, tune2, fixed2
     p.oscillator_2_sync = 1 if (s % 6 == 1 and w1 != T.WAVE_NONE and w2 != T.WAVE_NONE) else 0   # (18 slots have s mod 6 == 1)

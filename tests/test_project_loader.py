@@ -345,3 +345,87 @@ def test_every_reference_sample_file_decodes_like_the_standard_library(host):
         assert np.array_equal(out[:n].view(np.uint32), want.view(np.uint32)), f
         seen.add((ch, width, rate))
     assert len(seen) >= 4
+
+
+# ---- round 6: every instrument kind of the current schema (settings/src/instruments.rs:26-39)
+def _wav_with_chunks(frames=16, extra=b""):
+    import struct
+    payload = bytes((i * 37) & 0xFF for i in range(frames * 2))
+    hdr = struct.pack("<HHIIHH", 1, 1, 44100, 88200, 2, 16)
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(hdr)) + hdr + b"data" + struct.pack("<I", len(payload)) + payload + extra
+    return b"RIFF" + struct.pack("<I", len(body)) + body
+
+
+def smpl_chunk(unity_note):
+    import struct
+    data = struct.pack("<9I", 0, 0, 22675, unity_note, 0, 0, 0, 0, 0)
+    return b"smpl" + struct.pack("<I", len(data)) + data
+
+
+def acid_chunk(root_note, flags=2):
+    import struct
+    data = struct.pack("<IHHfIHHf", flags, root_note, 0x8000, 0.0, 4, 4, 4, 109.7)
+    return b"acid" + struct.pack("<I", len(data)) + data
+
+
+def test_sample_root_note_from_the_wav_file(host, tmp_path):
+    """SamplerParams{root: 0} takes the file's own root: the `smpl` chunk's MIDI unity note, else the `acid` chunk's root
+    note when its flags say it is set; neither, a lying length, a note above 127 or no file: -1 (the sampler then plays at 440 Hz)."""
+    host.gh_read_wav_root_note.argtypes = [C.c_char_p]
+
+    def root(blob):
+        path = tmp_path / "r.wav"
+        path.write_bytes(blob)
+        return host.gh_read_wav_root_note(str(path).encode())
+
+    assert root(_wav_with_chunks()) == -1
+    assert root(_wav_with_chunks(extra=smpl_chunk(62))) == 62
+    assert root(_wav_with_chunks(extra=acid_chunk(57))) == 57
+    assert root(_wav_with_chunks(extra=acid_chunk(57, flags=1))) == -1          # one-shot flag only: the root note is not set
+    assert root(_wav_with_chunks(extra=acid_chunk(57) + smpl_chunk(60))) == 60  # the smpl chunk wins
+    assert root(_wav_with_chunks(extra=smpl_chunk(400))) == -1
+    assert root(_wav_with_chunks(extra=b"smpl\xff\xff\xff\x7f\x00\x00")) == -1   # a chunk that claims 2 GiB
+    assert root(_wav_with_chunks(extra=b"LIST\x03\x00\x00\x00abc\x00" + smpl_chunk(48))) == 48   # odd-sized chunk before it: padded
+    assert host.gh_read_wav_root_note(str(tmp_path / "missing.wav").encode()) == -1
+    if os.path.exists(REF):   # the reference's own pair of files (test-data/samples): one carries an acid chunk with root note 57
+        assert host.gh_read_wav_root_note(f"{REF}/test-data/samples/riff-acidized.wav".encode()) == 57
+        assert host.gh_read_wav_root_note(f"{REF}/test-data/samples/riff-not-acidized.wav".encode()) == -1
+
+
+RAW_AND_TOY = """{
+  title: "welsh-raw and toy-instrument", clock: {bpm: 120, "time-signature": [4, 4]},
+  devices: [
+    {instrument: ["raw-1", {"welsh-raw": [{"midi-in": 3}, {
+        voice: {"oscillator-1": {waveform: {"pulse-width": 0.3}, "frequency-tune": 1.0},
+                "oscillator-2": {waveform: "sawtooth", "frequency-tune": {osc: {octave: -1, semi: 0, cent: 4}}},
+                "oscillator-2-sync": false, "oscillator-mix": 0.6,
+                "amp-envelope": {attack: 0.01, decay: 0.2, sustain: 0.7, release: 0.3},
+                lfo: {waveform: "square", frequency: 5.13}, "lfo-routing": "pitch", "lfo-depth": 0.05,
+                filter: {cutoff: 900, "passband-ripple": 1.2}, "filter-cutoff-start": 0.4, "filter-cutoff-end": 0.5,
+                "filter-envelope": {attack: 0.0, decay: 0.5, sustain: 0.3, release: 0.5}},
+        dca: {gain: 0.8, pan: -0.25}}]}]},
+    {instrument: ["toy-1", {"toy-instrument": [{"midi-in": 4}, {"fake-value": 0.25, dca: {gain: 0.5, pan: 0.5}}]}]},
+    {instrument: ["s-1", {sampler: [{"midi-in": 5}, {filename: "pluck.wav", root: 0}]}]},
+  ],
+  "patch-cables": [["raw-1", "main-mixer"], ["toy-1", "main-mixer"], ["s-1", "main-mixer"]],
+}"""
+
+
+def test_welsh_raw_toy_instrument_and_sampler_parse(host):
+    """InstrumentSettings::{WelshRaw, ToyInstrument, Sampler} (instruments.rs:27-37): parsed, none skipped, no warning."""
+    d = describe(host, text=RAW_AND_TOY)
+    kinds = {x["id"]: x for x in d["devices"]}
+    assert set(kinds) == {"raw-1", "toy-1", "s-1"} and d["warnings"] == 0
+    raw = kinds["raw-1"]
+    assert raw["kind"] == "welsh-raw" and raw["midi_in"] == 3 and raw["welsh_osc1"] == T.WAVE_PULSE_WIDTH
+    assert abs(raw["welsh_mix"] - 0.6) < 1e-6 and raw["welsh_cutoff"] == 900 and raw["welsh_routing"] == T.LFO_PITCH and abs(raw["welsh_release"] - 0.3) < 1e-12
+    assert kinds["toy-1"]["kind"] == "toy-instrument" and kinds["toy-1"]["midi_in"] == 4
+    assert kinds["s-1"]["kind"] == "sampler" and kinds["s-1"]["name"] == "pluck.wav"
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="reference tree not present")
+def test_the_reference_sampler_demo_parses_with_its_roots(host):
+    """projects/demos/instruments/sampler.json: two samplers over one stereo file, roots 587.33 Hz and 86 Hz."""
+    d = describe(host, path=f"{REF}/projects/demos/instruments/sampler.json", assets=f"{REF}/assets")
+    assert [x["kind"] for x in d["devices"]] == ["sampler", "sampler"] and [x["midi_in"] for x in d["devices"]] == [0, 1]
+    assert all(x["name"] == "stereo-pluck.wav" for x in d["devices"]) and d["n_notes"] >= 8 and d["warnings"] == 0
