@@ -237,6 +237,23 @@ def supervise_rank(argv, rank, world, deadline_s=None, attempts=3):
     return rc_final
 
 
+def leave_unless_every_rank_has_its_communicator(dist, torch, rank, why, ctx=None):
+    """ONE collective path (round 6): `why` is None on a rank whose library communicator stands.  The ranks agree over the host-side
+    group; if any of them failed, every rank says so and ends with code 4 — there is no second backend, so a line that exists
+    measured groove_bus_reduce.  (A rank that has touched the GPU is never re-exec'ed: the process ends, the supervisor decides.)"""
+    flag = torch.tensor([0 if why else 1], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()):
+        return
+    sys.stderr.write(f"bench.py rank {rank}: {why or 'another rank could not set up the library communicator'}; "
+                     "there is one collective path (groove_bus_reduce) and no fallback: leaving with code 4\n")
+    sys.stderr.flush()
+    if ctx is not None:
+        ctx.close()
+    dist.destroy_process_group()
+    sys.exit(4)
+
+
 def dry_launch(world, rank):
     """--dry-launch: the rendezvous of the N>1 path without a GPU (gloo); rank 0 prints how many ranks joined."""
     import torch
@@ -245,6 +262,11 @@ def dry_launch(world, rank):
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     t = torch.ones(1, dtype=torch.int64)
     dist.all_reduce(t)
+    # the real run's one way out when a rank's communicator cannot be set up (Dist.make_context), without a GPU:
+    # GROOVE_BENCH_BREAK_COMM=<rank> makes that rank fail, every rank learns it and leaves with code 4 — no line, no fallback
+    broken = os.environ.get("GROOVE_BENCH_BREAK_COMM")
+    if broken is not None:
+        leave_unless_every_rank_has_its_communicator(dist, torch, rank, "GROOVE_BENCH_BREAK_COMM" if str(rank) == broken or broken == "all" else None)
     lo, hi = voice_range(WORKLOADS["welsh-1m"]["voices"], rank, world)
     spans = [None] * world
     dist.all_gather_object(spans, (lo, hi))
@@ -313,7 +335,8 @@ def compact_line(line):
     if cb:
         out["cpu_baseline"] = {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
                                "sample": _short(cb.get("sample"), 110),
-                               "all_cores_value": _r((cb.get("all_cores") or {}).get("value")), "all_cores": (cb.get("all_cores") or {}).get("cores")}
+                               "all_cores_value": _r((cb.get("all_cores") or {}).get("value")), "all_cores": (cb.get("all_cores") or {}).get("cores"),
+                               "all_cores_efficiency": _r((cb.get("all_cores") or {}).get("parallel_efficiency"), 3)}
     par = line.get("parity_vs_oracle")
     if par:
         out["parity_rms"] = _r(par.get("bus_rms_err"), 4)
@@ -627,16 +650,25 @@ def cpu_baseline(workload, seconds_target=15.0):
         out["native"] = {"error": str(e)[:200]}
     cores = int(O.lib().oracle_hardware_concurrency()) or 1
     if WORKLOADS[workload]["kind"] in ("welsh", "mixed", "sampler"):  # mode B: voices sharded over all host cores
-        mt_voices = min(V, 64 * cores)
+        # PERSISTENT workers (round 6): every thread owns >= 64 voices for >= 16 consecutive blocks between one spawn and one join
+        # (oracle_bank_render_bus_blocks_mt; the stretch ends where the timeline has note events).  Round 5 spawned and joined 256 threads
+        # for every block of 64 voices each: that figure (10.5 x one core on 256 cores) timed the threads, not the voices.
+        mt_voices = min(V, max(64 * cores, 4096))
         mp_ = OracleProject(workload, spread_sample(V, mt_voices))
-        mp_.step(threads=cores)
-        mt_blocks = int(max(2, min(512, 0.3 * seconds_target * vf_per_s * min(cores, 16) / (mt_voices * FRAMES))))
+        mt_voices = mp_.n
+        mp_.run_mt(1, cores)                                 # block 0: the note-ons, first touch of every page by its thread
+        budget_s = 0.3 * seconds_target
+        mt_blocks = int(max(16, min(80, budget_s * vf_per_s * max(1.0, 0.5 * min(cores, 64)) / (mt_voices * FRAMES))))
         t0 = time.perf_counter()
-        for _ in range(mt_blocks):
-            mp_.step(threads=cores)
+        _, stretches = mp_.run_mt(mt_blocks, cores)
         el = time.perf_counter() - t0
-        out["all_cores"] = {"value": mt_voices * FRAMES * mt_blocks / el / V, "cores": cores,
-                            "sample": f"{mt_voices} voices x {mt_blocks} blocks, {cores} threads"}
+        mt_vf = mt_voices * FRAMES * mt_blocks / el
+        eff = mt_vf / (cores * vf_per_s)
+        out["all_cores"] = {"value": mt_vf / V, "cores": cores, "speedup_over_one_core": mt_vf / vf_per_s, "parallel_efficiency": eff,
+                            "sample": f"{mt_voices} voices ({mt_voices // max(cores, 1)} per thread) x {mt_blocks} blocks from block 1 of the timeline, {cores} persistent "
+                                      f"threads, {stretches} spawn / join stretch(es)",
+                            "note": ("hardware_concurrency counts SMT siblings: two threads of a core share its FP units, so ~0.5 of the thread count is what a "
+                                     "scalar f64 loop can gain; a box's other tenants and NUMA placement take the rest") if eff < 0.5 else None}
     return out
 
 
@@ -646,8 +678,8 @@ class Dist:
     ncclReduce of the bus on the ctx stream, groove_bus_reduce); the launcher-side process group only carries the
     128-byte unique id, the barriers and the max of the ranks' clocks, so it runs over gloo on the host and torch
     never opens a GPU context of its own in a rank: its streams and a second RCCL instance would share the device's
-    few hardware queues with the render's per-kind streams (measured on one GPU: 0.58 -> 0.69 ms per block).  Only if
-    the library communicator cannot be set up does the reduce fall back to torch.distributed over nccl."""
+    few hardware queues with the render's per-kind streams (measured on one GPU: 0.58 -> 0.69 ms per block).  If the
+    library communicator cannot be set up the rank leaves with a non-zero code: there is no second collective backend."""
 
     def __init__(self, rank, world, local_rank):
         # torch is imported (and the host-side group formed) BEFORE libgroove_hip.so is loaded: a process has one HIP
@@ -657,27 +689,32 @@ class Dist:
         import torch.distributed as dist
         self.torch, self.dist, self.rank, self.world, self.local_rank = torch, dist, rank, world, local_rank
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        self.nccl_group = None
         self.ctx = None
 
     def make_context(self):
-        """The rank's library context and its RCCL communicator (one ncclReduce of the bus per render)."""
+        """The rank's library context and its RCCL communicator (one ncclReduce of the bus per render).  ONE collective path: a rank
+        whose communicator cannot be set up says so and ends with a non-zero code (every rank learns it through the gloo group and
+        leaves the same way) — there is no second backend to fall back on, so a line that exists measured groove_bus_reduce
+        (round 6; the torch.distributed-over-nccl fallback of rounds 3 - 5 is gone).  The supervisor (supervise_rank) starts a fresh
+        child; a rank that has touched the GPU is never re-exec'ed."""
         torch, dist, rank, world, local_rank = self.torch, self.dist, self.rank, self.world, self.local_rank
         self.reduce_via = "groove_bus_reduce (RCCL ncclReduce on the ctx stream; communicator created " + ("before" if os.environ.get("GROOVE_COMM_BEFORE_STREAMS") == "1" else "after") + " the library's streams)"
+        why = None
+        uid = [None]
         try:
             uid = [E.Context.new_comm_unique_id() if rank == 0 else None]
         except Exception as e:  # noqa: BLE001
-            uid = [None]
-            self.reduce_via = f"torch.distributed.reduce over nccl (library communicator unavailable: {e})"
+            why = f"ncclGetUniqueId failed: {e}"
         dist.broadcast_object_list(uid, src=0)
-        ok = [1]
         ctx = None
-        if uid[0] is not None:
+        if uid[0] is None:
+            why = why or "rank 0 could not create the communicator's id"
+        else:
             try:
-                if os.environ.get("GROOVE_BENCH_BREAK_COMM") == "1":  # exercise the fallback below
+                if os.environ.get("GROOVE_BENCH_BREAK_COMM") == "1":  # exercise the refusal below (tests/test_projects_cpu.py)
                     raise RuntimeError("GROOVE_BENCH_BREAK_COMM=1")
                 # The library's streams FIRST, the communicator after them.  (groove_init_comm — the communicator before the
-                # streams, so that RCCL's own streams cannot land between the library's — was this round's first answer to the
+                # streams, so that RCCL's own streams cannot land between the library's — was round 3's first answer to the
                 # queue-mapping question of DESIGN.md section 7, and measured it costs every rank a fifth of its speed: 1,000,000
                 # voices on one GPU through this path 0.630 / 0.635 / 0.630 ms per block against 0.517 / 0.522 / 0.517 in this
                 # order and 0.534 / 0.533 / 0.531 with no communicator at all, profiles/r03_ab_logs_second_half.txt (r3_dist_ab).
@@ -688,41 +725,19 @@ class Dist:
                     ctx = E.Context(local_rank)
                     ctx.comm_init(uid[0], rank, world)
             except Exception as e:  # noqa: BLE001
-                ok = [0]
-                self.reduce_via = f"torch.distributed.reduce over nccl (groove_init_comm failed: {e})"
-        else:
-            ok = [0]
-        if ctx is None:
-            ctx = E.Context(local_rank)
+                why = f"the library communicator could not be set up: {e}"
+        leave_unless_every_rank_has_its_communicator(dist, torch, rank, why, ctx)   # every rank takes the same way out
         self.ctx = ctx
-        flag = torch.tensor(ok, dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # every rank takes the same path
-        self.own_comm = bool(int(flag.item()))
-        if not self.own_comm:
-            if self.reduce_via.startswith("groove_bus_reduce"):
-                self.reduce_via = "torch.distributed.reduce over nccl (another rank could not set up the library communicator)"
-            torch.cuda.set_device(local_rank)
-            self.nccl_group = dist.new_group(backend="nccl")
-        self.rccl_ranks = ctx.comm_ranks() if self.own_comm else dist.get_world_size(self.nccl_group)
+        self.rccl_ranks = ctx.comm_ranks()
         return ctx
 
     def sync(self):
         self.ctx.synchronize()      # every stream of the library on this device
-        if self.nccl_group is not None:
-            self.torch.cuda.synchronize()
         self.dist.barrier()
         self.ctx.synchronize()
 
     def reduce_bus(self, bus, frame0, frames):
-        if self.own_comm:
-            self.ctx.bus_reduce(E._Slice(bus, frame0), frames, 0)
-            return
-        host = bus.download()
-        t = self.torch.from_numpy(host[frame0:frame0 + frames].copy()).cuda()
-        self.dist.reduce(t, dst=0, op=self.dist.ReduceOp.SUM, group=self.nccl_group)
-        if self.rank == 0:
-            host[frame0:frame0 + frames] = t.cpu().numpy()
-            bus.upload(host)
+        self.ctx.bus_reduce(E._Slice(bus, frame0), frames, 0)
 
     def gather(self, obj):
         out = [None] * self.world

@@ -178,6 +178,9 @@ struct groove_fx {
 // Events that only order the library's own streams on one device: no timing, and no system-scope fence
 // (cache writeback + invalidate) when they are recorded — the host reads results through
 // hipMemcpy / hipStreamSynchronize, which fence by themselves.
+#ifndef GROOVE_SOURCE_HASH
+#define GROOVE_SOURCE_HASH "unknown" /* groove_amd/Makefile: sha256 of the library's sources, first 16 hex digits */
+#endif
 constexpr unsigned kSyncEventFlags = hipEventDisableTiming | hipEventDisableSystemFence;
 constexpr int kBankStreams = 4;                         // shared round-robin by single-kernel banks (FM, sampler, per-lane Welsh)
 constexpr int kSideStreams = kBaseKinds + kBankStreams;
@@ -1319,7 +1322,7 @@ int groove_debug_info(groove_ctx* ctx, char* out, size_t cap) {
   DiagCounters dc{};
   GHIP(ctx, ctx_memcpy(ctx, &dc, ctx->d_diag, sizeof(dc), hipMemcpyDeviceToHost));
   std::string diag = "\"host_waits\": " + std::to_string(ctx->host_waits) + ", \"host_waits_blocked\": " + std::to_string(ctx->host_waits_blocked) + ", \"host_wait_ms\": " + std::to_string((double)ctx->host_wait_ns * 1e-6) +
-                     ", \"zero_segments\": " + std::to_string(dc.zero_segments);
+                     ", \"zero_segments\": " + std::to_string(dc.zero_segments) + ", \"source_hash\": \"" GROOVE_SOURCE_HASH "\", \"mix_kernel\": " + (ctx->mix_kernel ? "true" : "false");
 #ifdef GROOVE_DIAG_SHADOW_IN_MIN
   diag += ", \"diag_build\": \"GROOVE_DIAG_SHADOW_IN_MIN\", \"shadow_zero_lanes\": " + std::to_string(dc.shadow_zero_lanes) + ", \"shadow_zero_waves\": " + std::to_string(dc.shadow_zero_waves) + ", \"records\": [";
   for (uint32_t i = 0; i < std::min(dc.records, kDiagRecords); ++i) {
@@ -1897,12 +1900,23 @@ static int render_async_impl(groove_bank* b, uint32_t frames, groove_block* out,
       for (int c = 0; c < kClassCombos; ++c) count[base] += b->wgs_of_kind[base * kClassCombos + c];
       at += count[base];
     }
+    const bool mix = ctx->mix_kernel; // (the MIX kernel, block-writing form: kernels.h; the exact-f64 kinds keep their per-kind kernels)
     for (int k = kBaseKinds - 1; k >= 0; --k) { // most expensive kind first
+      if (mix && k < 4) continue;
       if (!count[k]) continue;
       hipStream_t st = begin(k);
       UniformArgs a = uniform_args(b, dst, rows, offset[k], chs, frames, count[k]);
       launch_welsh_kind(k, a, st, false);
       end(k);
+    }
+    for (int sec = 2; mix && sec >= 0; --sec) {
+      if (!b->mix_cnt[sec]) continue;
+      hipStream_t st = begin(sec);
+      UniformArgs a = uniform_args(b, dst, rows, 0, chs, frames, b->mix_cnt[sec]);
+      const size_t o = b->wg_list_cap + b->mix_off[sec];
+      a.wg_list = b->d_wg_list + o; a.wg_cls = b->d_wg_cls + o; a.wg_f32 = b->d_wg_f32 + o;
+      launch_welsh_uniform_mix_unfused(a, b->d_wg_base + o, st);
+      end(sec);
     }
   } else {
     const int k = b->stream_slot;

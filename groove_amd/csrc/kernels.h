@@ -73,6 +73,9 @@ __device__ __forceinline__ void soa_store(uint32_t* __restrict__ buf, uint32_t n
                               0.172 at 125,000); the two exact-f64 base kinds, whose bodies need 133 VGPRs, no longer run in this kernel (the
                               host gives their workgroups to the per-kind kernels) */
 #endif
+#ifndef GROOVE_COEF_LOOKAHEAD
+#define GROOVE_COEF_LOOKAHEAD 1 /* the retuned kinds' coefficient look-ahead (below, "coefficient look-ahead"); 0: every lane retunes for itself (round 5's code, for A/B builds) */
+#endif
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 // Which entry of the kind-sorted workgroup list (cheapest base kind first) workgroup blockIdx.x of a launch takes: from the END.
@@ -250,10 +253,12 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
 // of zero frames — the endless loop of rounds 2 and 3 (one workgroup per ~10^5, never a wrong sample: shadows are never
 // stored or summed).  Shadow lanes now contribute 2^32-1.  `on_zero(f, mine, wmin)` is called (wave-uniformly) if the minimum
 // is 0 all the same — it counts (diag.h) — and the segment is then one frame, which is what the checked form would do.
-template <bool FUSED, class FirstFn, class BeginFn, class LiveFn, class EndFn, class ZeroFn>
+// `setup(live, seg)` runs once per segment (wave-uniformly: every lane of the wave is in it) once the segment's length is known, and
+// `pre(k)` before frame k of the segment, outside the `live` test: the coefficient look-ahead of the retuned kinds (welsh_block).
+template <bool FUSED, class FirstFn, class BeginFn, class SetupFn, class PreFn, class LiveFn, class EndFn, class ZeroFn>
 __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n, uint32_t v, bool active, size_t ch_stride,
                                                      float* __restrict__ out, float* __restrict__ rows, uint32_t prow, FirstFn&& first, BeginFn&& begin,
-                                                     LiveFn&& live_frame, EndFn&& end, ZeroFn&& on_zero) {
+                                                     SetupFn&& setup, PreFn&& pre, LiveFn&& live_frame, EndFn&& end, ZeroFn&& on_zero) {
   if (frames == 0) return;
   constexpr uint32_t C = FusedAcc::kChunk;
   static_assert(C > 1, "frame 0 never completes a chunk");
@@ -283,9 +288,11 @@ __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n
 #endif
     if (wmin == 0) on_zero(f, mine);
     const uint32_t seg = max(1u, min(wmin, frames - f));
+    setup(live, seg);
     for (uint32_t k = 0; k < seg; ++k, ++f) {
+      pre(k);
       float L = 0.0f, R = 0.0f;
-      if (live) live_frame(L, R);
+      if (live) live_frame(k, L, R);
       put(f, L, R);
     }
     end(seg, live);
@@ -317,6 +324,55 @@ __device__ __forceinline__ void welsh_diag_zero(const DiagWhere& dw, const Welsh
 // a5 WelshVoice: Ticks::tick(frames) + Generates::generate_batch_values.
 // Frame 0 is peeled (first-tick flag); RETUNE=false variants keep the filter coefficients
 // loop-invariant so their f64 widening is hoisted out of the frame loop.
+// ------------------------------------------------------------------ coefficient look-ahead (round 6)
+// The retune of an envelope-swept filter — cutoff percent from the filter envelope's value, one exp2, the tangent polynomial, two
+// reciprocals, the quotients and their widening — is ~45 of a retuning frame's ~75 vector instructions, and every lane of a wave
+// whose voices were struck together computes THE SAME numbers: the cutoff depends on the patch (wave-uniform) and on the filter
+// envelope, which knows nothing of the key.  There is no scalar float unit to do it once per wave; there are 64 lanes, and the
+// envelope is a closed form in the stage's frame counter: when a segment starts and all live lanes of the wave agree on the filter
+// envelope's stage (counter, start level, shape constants), lane j computes the coefficients of frame k + j of the segment, 64 frames
+// in one pass, into a table of the wave's own in LDS, and every frame then takes its six coefficients with broadcast reads.  Same
+// expressions on the same values as the per-lane path (welsh_frame_front / lp24_t_from_pct / lp24_coef*_from_t): the same bits.
+// Waves whose voices started apart, LFO-swept cutoffs and segments shorter than eight frames keep the per-lane path.
+struct CoefTab {
+  static constexpr uint32_t kFrames = 64, kMinSegment = 8;
+  static __device__ __forceinline__ double* wave_base() { // 6 x f64 (or 6 x f32 in the fp32-filter bodies) per frame; 3 KiB per wave
+    __shared__ double t[kWaves][kFrames][6];
+    return &t[threadIdx.x >> 6][0][0];
+  }
+};
+// Do the live lanes of this wave share the filter envelope's stage?  Then its description, from the first of them, in SGPRs.
+struct FilEnvUniform { bool ok; float A, c1, c2, tf; };
+__device__ __forceinline__ FilEnvUniform fil_env_uniform(const WelshState& s, const WelshScratch& sc, bool live) {
+  FilEnvUniform u{false, 0.0f, 0.0f, 0.0f, 0.0f};
+  const uint64_t mask = __ballot(live);
+  if (mask == 0) return u;
+  const int l0 = __builtin_ctzll(mask); // wave-uniform
+  u.A = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s.fil.A), l0));
+  u.c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc.fc1), l0));
+  u.c2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc.fc2), l0));
+  u.tf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc.tf), l0));
+  // bit patterns, so that a NaN (never produced; a torn shadow record could hold anything, but shadows are not live) cannot fake agreement
+  const bool same = __builtin_bit_cast(uint32_t, s.fil.A) == __builtin_bit_cast(uint32_t, u.A) && __builtin_bit_cast(uint32_t, sc.fc1) == __builtin_bit_cast(uint32_t, u.c1) &&
+                    __builtin_bit_cast(uint32_t, sc.fc2) == __builtin_bit_cast(uint32_t, u.c2) && __builtin_bit_cast(uint32_t, sc.tf) == __builtin_bit_cast(uint32_t, u.tf);
+  u.ok = __ballot(live && !same) == 0;
+  return u;
+}
+// Lane j: the coefficients of frame k0 + j of the segment, into the wave's table.  (All 64 lanes take part, live or not: the inputs
+// are wave-uniform.)
+template <bool F32>
+__device__ __forceinline__ void coef_tab_fill(const WelshParams& p, const RenderConsts& rc, const FilEnvUniform& u, uint32_t k0) {
+  const uint32_t j = threadIdx.x & 63u;
+  const float n = u.tf + (float)(k0 + j); // the hoisted frames' counter sc.tf, which grows by 1.0f a frame (exact below 2^24)
+  const float pct = welsh_env_cutoff_pct(p, env_shape(n, u.A, u.c1, u.c2));
+  bool hi;
+  const float t = lp24_t_from_pct(pct, rc, hi);
+  if constexpr (F32) reinterpret_cast<Lp24CoefF*>(CoefTab::wave_base())[j] = lp24_coeff_from_t(p.fc, t, hi);
+  else reinterpret_cast<Lp24CoefD*>(CoefTab::wave_base())[j] = lp24_coefd_from_t(p.fc, t, hi, (p.flags & WF_COEF_WIDE) != 0);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the wave's own reads below come after these writes
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <bool FUSED, bool RETUNE, int LFO_MODE = LFO_F64, bool UNIFORM = false, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool REST = false, bool F32OK = false>
 __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s, const RenderConsts& rc,
                                             uint32_t frames, uint32_t n, uint32_t v, bool active,
@@ -332,24 +388,49 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
     // back two thirds of the gain (profiles/r05_f32_filter.log).
     welsh_scratch_f32_begin(p, s, rc, sc);
     if (!RETUNE) sc.coef_f = make_scalar(sc.coef_f);
+    FilEnvUniform fu{false, 0.0f, 0.0f, 0.0f, 0.0f}; // this segment's coefficient look-ahead (RETUNE kinds; fu.ok is wave-uniform)
     run_frames_segmented<FUSED>(
         frames, n, v, active, ch_stride, out, rows, prow,
         [&](float& L, float& R) { welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL, false, REST, false, true>(p, s, rc, sc, L, R); },
         [&](bool& live) { const uint32_t k = welsh_segment_begin(p, s, live); welsh_segment_start_hoisted(s, sc); return k; },
-        [&](float& L, float& R) { welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true, true>(p, s, rc, sc, L, R); },
-        [&](uint32_t seg, bool live) { welsh_segment_end_hoisted<CL == LFO_UNUSED>(p, s, seg, live); },
+        [&](bool live, uint32_t seg) {
+          fu.ok = false;
+          if constexpr (RETUNE && GROOVE_COEF_LOOKAHEAD) { if ((p.flags & WF_RETUNE_ENV) && seg >= CoefTab::kMinSegment) fu = fil_env_uniform(s, sc, live); }
+        },
+        [&](uint32_t k) { if constexpr (RETUNE && GROOVE_COEF_LOOKAHEAD) { if (fu.ok && (k & (CoefTab::kFrames - 1)) == 0) coef_tab_fill<true>(p, rc, fu, k); } },
+        [&](uint32_t k, float& L, float& R) {
+          if constexpr (RETUNE && GROOVE_COEF_LOOKAHEAD) { if (fu.ok) sc.coef_f = reinterpret_cast<const Lp24CoefF*>(CoefTab::wave_base())[k & (CoefTab::kFrames - 1)]; }
+          welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true, true>(p, s, rc, sc, L, R, RETUNE && GROOVE_COEF_LOOKAHEAD && fu.ok);
+        },
+        [&](uint32_t seg, bool live) {
+          welsh_segment_end_hoisted<CL == LFO_UNUSED>(p, s, seg, live);
+          if constexpr (RETUNE && GROOVE_COEF_LOOKAHEAD) { if (fu.ok) { if (live) s.fil.value = env_last_value_of(s.fil); sc.prev_pct = __builtin_nanf(""); } }
+        },
         [&](uint32_t f, uint32_t mine) { welsh_diag_zero(dw, s, active, f, mine); });
     welsh_scratch_f32_end(s, sc);
     return;
   }
   if (UNIFORM && !RETUNE) sc.coef = make_scalar(sc.coef);
   if constexpr (UNIFORM) {
+    constexpr bool LOOKAHEAD = RETUNE && LFO_MODE != LFO_F64 && GROOVE_COEF_LOOKAHEAD; // (the exact-f64 kind keeps its own coefficient forms: resonance routing, lp24_coefd_from_fc)
+    FilEnvUniform fu{false, 0.0f, 0.0f, 0.0f, 0.0f};
     run_frames_segmented<FUSED>(
         frames, n, v, active, ch_stride, out, rows, prow,
         [&](float& L, float& R) { welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL, false, REST>(p, s, rc, sc, L, R); },
         [&](bool& live) { const uint32_t k = welsh_segment_begin(p, s, live); welsh_segment_start_hoisted(s, sc); return k; },
-        [&](float& L, float& R) { welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true>(p, s, rc, sc, L, R); },
-        [&](uint32_t seg, bool live) { welsh_segment_end_hoisted<CL == LFO_UNUSED>(p, s, seg, live); },
+        [&](bool live, uint32_t seg) {
+          fu.ok = false;
+          if constexpr (LOOKAHEAD) { if ((p.flags & WF_RETUNE_ENV) && seg >= CoefTab::kMinSegment) fu = fil_env_uniform(s, sc, live); }
+        },
+        [&](uint32_t k) { if constexpr (LOOKAHEAD) { if (fu.ok && (k & (CoefTab::kFrames - 1)) == 0) coef_tab_fill<false>(p, rc, fu, k); } },
+        [&](uint32_t k, float& L, float& R) {
+          if constexpr (LOOKAHEAD) { if (fu.ok) sc.coef = reinterpret_cast<const Lp24CoefD*>(CoefTab::wave_base())[k & (CoefTab::kFrames - 1)]; }
+          welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true>(p, s, rc, sc, L, R, LOOKAHEAD && fu.ok);
+        },
+        [&](uint32_t seg, bool live) {
+          welsh_segment_end_hoisted<CL == LFO_UNUSED>(p, s, seg, live);
+          if constexpr (LOOKAHEAD) { if (fu.ok) { if (live) s.fil.value = env_last_value_of(s.fil); sc.prev_pct = __builtin_nanf(""); } }
+        },
         [&](uint32_t f, uint32_t mine) { welsh_diag_zero(dw, s, active, f, mine); });
   } else {
     run_frames<FUSED>(frames, n, v, active, ch_stride, out, rows, prow, [&](uint32_t f, float& L, float& R) {

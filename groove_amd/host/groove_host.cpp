@@ -378,13 +378,15 @@ uint64_t Orchestrator::performance_frames() const {
 }
 void Orchestrator::skip_to_start() { frames_ = 0; performing_ = true; ahead_primed_ = false; deferred_.clear(); }
 int Orchestrator::control_effect(Uid target, uint32_t index, double value01) {
-  if (deferring_) { deferred_.push_back({target, index, value01}); return 0; }
   Entity* e = get(target);
-  if (e && e->is_effect()) return static_cast<Effect*>(e)->control_set_param(index, value01);
   if (e && e->is_instrument()) { // Controllable is generated for every entity (proc-macros/src/control.rs:171-183)
+    // (never held back: in the render-ahead walk the block being sequenced is the one the instruments render NEXT — its predecessor's
+    // render has been finished — while the effects are a block behind, which is what `deferring_` is for)
     if (static_cast<Instrument*>(e)->control_set_param(index, value01)) return fail(groove_last_error(ctx_));
     return 0;
   }
+  if (deferring_) { deferred_.push_back({target, index, value01}); return 0; }
+  if (e && e->is_effect()) return static_cast<Effect*>(e)->control_set_param(index, value01);
   return 0;
 }
 void Orchestrator::sequence_block(uint64_t at_frame, uint32_t frames) {

@@ -62,6 +62,7 @@ def _bind(lib):
         "oracle_bank_set_param": (C.c_int, [vp, u32, u32, C.c_double]),
         "oracle_bank_render_bus": (None, [vp, u32, _dp]),
         "oracle_bank_render_bus_mt": (None, [vp, u32, _dp, u32]),
+        "oracle_bank_render_bus_blocks_mt": (None, [vp, u32, u32, _dp, u32]),
         "oracle_hardware_concurrency": (C.c_uint, []),
         "oracle_fx_create": (vp, [u32, C.POINTER(T.FxParams), u32, u32]),
         "oracle_fx_destroy": (None, [vp]),
@@ -162,6 +163,13 @@ class Bank:
             self.L.oracle_bank_render_bus_mt(self.h, frames, _dptr(bus), threads)
         else:
             self.L.oracle_bank_render_bus(self.h, frames, _dptr(bus))
+        return bus
+
+    def render_bus_blocks(self, frames, blocks, threads):
+        """`blocks` consecutive blocks with PERSISTENT workers: each of `threads` threads owns its share of the voices from one spawn
+        to one join (oracle_bank_render_bus_blocks_mt).  Returns bus[blocks * frames][2]."""
+        bus = np.zeros((blocks * frames, 2), dtype=np.float64)
+        self.L.oracle_bank_render_bus_blocks_mt(self.h, frames, blocks, _dptr(bus), threads)
         return bus
 
     def release(self):

@@ -301,6 +301,25 @@ void oracle_bank_render_bus_mt(void* h, uint32_t frames, double* bus, uint32_t t
   for (uint32_t t = 0; t < threads; ++t)
     for (size_t i = 0; i < (size_t)frames * 2; ++i) bus[i] += part[t][i];
 }
+// The same with PERSISTENT workers (round 6; bench.py's all-cores baseline): every thread owns its voices for `blocks` consecutive
+// blocks of `frames` frames between one spawn and one join, adding into a bus of its own; bus[blocks][frames][2] (+)= the sum.
+// (oracle_bank_render_bus_mt spawns and joins once per block: with 64 voices per thread that times the threads, not the voices.)
+void oracle_bank_render_bus_blocks_mt(void* h, uint32_t frames, uint32_t blocks, double* bus, uint32_t threads) {
+  Bank* b = (Bank*)h;
+  const uint32_t n = b->n();
+  if (threads < 1) threads = 1;
+  if (threads > n) threads = n ? n : 1;
+  const size_t per = (size_t)frames * 2, total = per * blocks;
+  std::vector<std::vector<double>> part(threads, std::vector<double>(total, 0.0));
+  std::vector<std::thread> th;
+  for (uint32_t t = 0; t < threads; ++t) {
+    uint32_t v0 = (uint32_t)((uint64_t)n * t / threads), v1 = (uint32_t)((uint64_t)n * (t + 1) / threads);
+    th.emplace_back([=, &part]() { for (uint32_t k = 0; k < blocks; ++k) oracle_bank_render_bus_range(h, frames, part[t].data() + per * k, v0, v1); });
+  }
+  for (auto& x : th) x.join();
+  for (uint32_t t = 0; t < threads; ++t)
+    for (size_t i = 0; i < total; ++i) bus[i] += part[t][i];
+}
 unsigned oracle_hardware_concurrency() { return std::thread::hardware_concurrency(); }
 
 // ---------------------------------------------------------------- effect banks

@@ -50,5 +50,30 @@ class OracleProject:
                 bus += bank.render_bus(frames, threads=threads)
         return bus
 
+    def run_mt(self, blocks, threads, frames=FRAMES):
+        """`blocks` blocks of the timeline on `threads` persistent worker threads per stretch: the blocks between two note-event
+        blocks are ONE spawn / join of the workers (oracle_bank_render_bus_blocks_mt), every thread keeping its voices throughout.
+        Instruments without effect chains only (bench.py's all-cores baseline).  Returns (bus, number of spawn / join stretches)."""
+        assert not any(fx for _, fx, _ in self.banks)
+        out, stretches = [], 0
+        done = 0
+        while done < blocks:
+            b = self.block_index % self.period
+            for bank, _, events in self.banks:
+                ev = events.get(b)
+                if ev is not None:
+                    bank.note_events(ev)
+            run = 1   # ... up to the next block that carries events (or the end)
+            while done + run < blocks and not any(events.get((self.block_index + run) % self.period) is not None for _, _, events in self.banks):
+                run += 1
+            bus = np.zeros((run * frames, 2), dtype=np.float64)
+            for bank, _, _ in self.banks:
+                bus += bank.render_bus_blocks(frames, run, threads)
+            out.append(bus)
+            self.block_index += run
+            done += run
+            stretches += 1
+        return np.concatenate(out, axis=0), stretches
+
     def render(self, blocks, frames=FRAMES):
         return np.concatenate([self.step(frames) for _ in range(blocks)], axis=0)

@@ -660,3 +660,220 @@ def test_random_graphs_against_the_oracle_graph(oracle):
         scale = max(1.0, float(np.abs(want).max()))
         assert np.sqrt(np.mean(want ** 2)) > 1e-3, seed
         assert np.sqrt(np.mean((got - want) ** 2)) <= 1e-5 * scale, (seed, float(np.sqrt(np.mean((got - want) ** 2))), scale)
+
+
+# ---- round 6: every instrument kind of the current schema instantiates (settings/src/instruments.rs:26-39)
+def _wav_bytes(ints, channels, bits, extra=b""):
+    """A RIFF/WAVE file of interleaved integer samples (16- or 24-bit PCM) with optional trailing chunks."""
+    ints = np.asarray(ints, dtype=np.int64)
+    if bits == 16:
+        payload = ints.astype("<i2").tobytes()
+    else:
+        u = ints & 0xFFFFFF
+        payload = np.stack([u & 0xFF, (u >> 8) & 0xFF, (u >> 16) & 0xFF], axis=1).astype(np.uint8).tobytes()
+    bps = bits // 8
+    hdr = struct.pack("<HHIIHH", 1, channels, 44100, 44100 * channels * bps, channels * bps, bits)
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(hdr)) + hdr + b"data" + struct.pack("<I", len(payload)) + payload + (b"\x00" if len(payload) & 1 else b"") + extra
+    return b"RIFF" + struct.pack("<I", len(body)) + body
+
+
+def _mono_float(ints, channels, bits):
+    """read_wav_mono's arithmetic (groove_amd/host/project.cpp): ints scaled by 2^(bits-1), the channels' mean, rounded once to fp32."""
+    x = np.asarray(ints, dtype=np.int64).reshape(-1, channels) / float(1 << (bits - 1))
+    return (x.sum(axis=1) / channels).astype(np.float32)
+
+
+SAMPLER_PROJECT = """{
+  title: "samplers, a raw Welsh synth and a toy instrument", clock: {bpm: 120, "time-signature": [4, 4]},
+  devices: [
+    {instrument: ["s-mono16", {sampler: [{"midi-in": 0}, {filename: "a.wav", root: 587.3295358348151}]}]},
+    {instrument: ["s-stereo16", {sampler: [{"midi-in": 1}, {filename: "b.wav", root: 0}]}]},
+    {instrument: ["s-mono24", {sampler: [{"midi-in": 2}, {filename: "c.wav", root: 0}]}]},
+    {instrument: ["s-acid", {sampler: [{"midi-in": 3}, {filename: "d.wav", root: 0}]}]},
+    {instrument: ["raw-1", {"welsh-raw": [{"midi-in": 4}, {
+        voice: {"oscillator-1": {waveform: {"pulse-width": 0.3}, "frequency-tune": 1.0},
+                "oscillator-2": {waveform: "sawtooth", "frequency-tune": {osc: {octave: -1, semi: 0, cent: 4}}},
+                "oscillator-2-sync": false, "oscillator-mix": 0.6,
+                "amp-envelope": {attack: 0.01, decay: 0.2, sustain: 0.7, release: 0.3},
+                lfo: {waveform: "square", frequency: 5.13}, "lfo-routing": "pitch", "lfo-depth": 0.05,
+                filter: {cutoff: 900, "passband-ripple": 1.2}, "filter-cutoff-start": 0.4, "filter-cutoff-end": 0.5,
+                "filter-envelope": {attack: 0.0, decay: 0.5, sustain: 0.3, release: 0.5}},
+        dca: {gain: 0.8, pan: -0.25}}]}]},
+    {instrument: ["toy-1", {"toy-instrument": [{"midi-in": 5}, {"fake-value": 0.25, dca: {gain: 0.5, pan: 0.5}}]}]},
+    {effect: ["gain-1", {gain: {ceiling: 0.5}}]},
+  ],
+  "patch-cables": [["s-mono16", "main-mixer"], ["s-stereo16", "main-mixer"], ["s-mono24", "gain-1", "main-mixer"], ["s-acid", "main-mixer"],
+                   ["raw-1", "main-mixer"], ["toy-1", "main-mixer"]],
+  patterns: [
+    {id: "p0", "note-value": "eighth", notes: [[74, 0, 77, 74, 0, 69, 0, 0]]},
+    {id: "p1", "note-value": "quarter", notes: [[60, 64, 0, 67], [0, 72, 0, 0]]},
+    {id: "p2", "note-value": "eighth", notes: [[69, 71, 0, 0, 57, 0, 0, 0]]},
+    {id: "p3", "note-value": "quarter", notes: [[57, 0, 64, 0]]},
+    {id: "p4", "note-value": "quarter", notes: [[50, 62, 0, 55]]},
+    {id: "p5", "note-value": "eighth", notes: [[0, 72, 72, 0, 76, 0, 79, 0]]},
+  ],
+  tracks: [{id: "t0", "midi-channel": 0, patterns: ["p0"]}, {id: "t1", "midi-channel": 1, patterns: ["p1"]}, {id: "t2", "midi-channel": 2, patterns: ["p2"]},
+           {id: "t3", "midi-channel": 3, patterns: ["p3"]}, {id: "t4", "midi-channel": 4, patterns: ["p4"]}, {id: "t5", "midi-channel": 5, patterns: ["p5"]}],
+}"""
+SAMPLER_PATTERNS = {0: (0.5, [[74, 0, 77, 74, 0, 69, 0, 0]]), 1: (1.0, [[60, 64, 0, 67], [0, 72, 0, 0]]), 2: (0.5, [[69, 71, 0, 0, 57, 0, 0, 0]]),
+                    3: (1.0, [[57, 0, 64, 0]]), 4: (1.0, [[50, 62, 0, 55]]), 5: (0.5, [[0, 72, 72, 0, 76, 0, 79, 0]])}
+
+
+def test_cli_renders_samplers_from_wav_files_a_raw_welsh_synth_and_a_toy_instrument(tmp_path, oracle):
+    """f2: `sampler` (16-bit mono with an explicit root; 16-bit stereo whose `smpl` chunk names its root note; 24-bit
+    mono with no root anywhere: 440 Hz; 16-bit mono with an `acid` chunk), `welsh-raw` and `toy-instrument` from a project file through
+    groove-cli-hip --wav, against the oracle graph fed by a restatement of the loader's and the sequencer's semantics: +-1 LSB of the 16-bit
+    stream (the samplers' fetch is exact; the Welsh voice carries the path's fp32 tolerance)."""
+    import os
+    import subprocess
+    from tests.test_project_loader import smpl_chunk, acid_chunk
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(repo, "groove_amd", "host", "groove-cli-hip")
+    n = np.arange(9000)
+    files = {   # name: (ints, channels, bits, extra chunk)
+        "a.wav": ((9000 * np.sin(2 * np.pi * 3.0 * n[:6000] / 147.0) * np.exp(-n[:6000] / 2500.0)).astype(np.int64), 1, 16, b""),
+        "b.wav": (np.stack([(7000 * np.sin(2 * np.pi * n / 168.5)).astype(np.int64), (5000 * np.sin(2 * np.pi * n / 84.1) + 300).astype(np.int64)], axis=1).ravel(), 2, 16, smpl_chunk(60)),
+        "c.wav": ((3.0e6 * np.sin(2 * np.pi * n[:7001] / 100.2) * np.exp(-n[:7001] / 4000.0)).astype(np.int64), 1, 24, b""),
+        "d.wav": (((n[:8000] * 37) % 20001 - 10000).astype(np.int64), 1, 16, acid_chunk(57)),
+    }
+    (tmp_path / "samples").mkdir()
+    for name, (ints, ch, bits, extra) in files.items():
+        (tmp_path / "samples" / name).write_bytes(_wav_bytes(ints, ch, bits, extra))
+    proj = tmp_path / "samplers.json5"
+    proj.write_text(SAMPLER_PROJECT)
+    r = subprocess.run([cli, "--wav", "--assets", str(tmp_path), str(proj)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    raw = (tmp_path / "samplers.wav").read_bytes()
+    pcm16 = np.frombuffer(raw[44:], dtype="<i2").reshape(-1, 2).astype(np.int32)
+    bpm, sr, upb, block = 120.0, 44100, 65536, 256
+    total = math.ceil(4.0 * 60 / bpm * sr)
+    total -= total % block                              # run_performance drops the partial block
+    assert len(pcm16) == total and np.abs(pcm16).max() > 2000
+
+    # ---- the oracle graph
+    g = oracle.Graph(sr)
+    g.set_bpm(bpm)
+
+    class Alloc:   # VoiceBankInstrument::note_on / note_off restated (first idle voice, busy until note-off + release, steal the oldest)
+        def __init__(self, voices, release_seconds):
+            self.key, self.busy, self.started, self.rel = [-1] * voices, [0] * voices, [0] * voices, math.ceil(release_seconds * sr) + 1
+
+        def on(self, key, now):
+            m = len(self.key)
+            v = next((i for i in range(m) if self.key[i] < 0 and self.busy[i] <= now), None)
+            if v is None:
+                v = min(range(m), key=lambda i: self.started[i])
+            self.key[v], self.started[v], self.busy[v] = key, now, 1 << 62
+            return [(v, key, True)]
+
+        def off(self, key, now):
+            out = []
+            for i in range(len(self.key)):
+                if self.key[i] == key:
+                    out.append((i, key, False)); self.key[i] = -1; self.busy[i] = now + self.rel
+            return out
+
+    def sampler(name, root_hz):
+        ints, ch, bits, _ = files[name]
+        pcm = _mono_float(ints, ch, bits)
+        descs = (T.SampleDesc * 1)(T.SampleDesc(0, len(pcm), root_hz))
+        sp = (T.SamplerParams * 8)()
+        for k in range(8):
+            sp[k].sample_index, sp[k].one_shot, sp[k].gain = 0, 0, 1.0
+        return g.add_instrument(oracle.Bank.sampler(pcm, descs, sp, sr))
+
+    nf = lambda k: 440.0 * 2.0 ** ((k - 69) / 12.0)
+    inst = {0: (sampler("a.wav", 587.3295358348151), Alloc(8, 0.0)), 1: (sampler("b.wav", nf(60)), Alloc(8, 0.0)),
+            2: (sampler("c.wav", 440.0), Alloc(8, 0.0)), 3: (sampler("d.wav", nf(57)), Alloc(8, 0.0))}
+    wp = T.WelshParams()
+    wp.oscillator_1.waveform, wp.oscillator_1.duty, wp.oscillator_1.tune = T.WAVE_PULSE_WIDTH, 0.3, 1.0
+    wp.oscillator_2.waveform, wp.oscillator_2.duty, wp.oscillator_2.tune = T.WAVE_SAWTOOTH, 0.5, P.semis_and_cents(-12, 4.0)
+    wp.oscillator_2_sync, wp.oscillator_mix = 0, 0.6
+    wp.amp_envelope, wp.filter_envelope = T.EnvelopeParams(0.01, 0.2, 0.7, 0.3), T.EnvelopeParams(0.0, 0.5, 0.3, 0.5)
+    wp.lfo_waveform, wp.lfo_routing, wp.lfo_frequency, wp.lfo_depth = T.WAVE_SQUARE, T.LFO_PITCH, 5.13, 0.05
+    wp.filter_cutoff_hz, wp.filter_passband_ripple, wp.filter_cutoff_start, wp.filter_cutoff_end = 900.0, 1.2, 0.4, 0.5
+    wp.dca_gain, wp.dca_pan = 0.8, -0.25
+    inst[4] = (g.add_instrument(oracle.Bank.welsh((T.WelshParams * 8)(*[wp] * 8))), Alloc(8, 0.3))
+    toy = T.FmParams()
+    toy.ratio, toy.depth, toy.beta = 1.0, 0.0, 0.0
+    toy.carrier_envelope = toy.modulator_envelope = T.EnvelopeParams(0.0, 0.0, 1.0, 0.0)
+    toy.dca_gain, toy.dca_pan = 0.5, 0.5
+    inst[5] = (g.add_instrument(oracle.Bank.fm((T.FmParams * 1)(toy))), Alloc(1, 0.0))
+    gain = g.add_effect(T.FX_GAIN, T.fx_params(ceiling=0.5))
+    for ch, (u, _) in inst.items():
+        if ch == 2:
+            assert g.patch(u, gain) == 0 and g.patch(gain, g.MAIN_MIXER) == 0
+        else:
+            assert g.patch(u, g.MAIN_MIXER) == 0
+    events = []   # (units, insertion index, channel, key, on): Sequencer::insert keeps time order, equal times in insertion order
+    for ch, (beats, rows) in SAMPLER_PATTERNS.items():
+        for row in rows:
+            for i, k in enumerate(row):
+                if k:
+                    events.append((int(i * beats * upb + 0.5), len(events), ch, k, True))
+                    events.append((int((i * beats + beats) * upb + 0.5), len(events), ch, k, False))
+    # the loader inserts track by track, pattern row by row, and the sequencer sorts on insert: tracks are listed channel by channel above
+    events.sort(key=lambda e: (e[0], e[1]))
+    want, pos = [], 0
+    while pos < total:
+        t0, t1 = int(pos * bpm / 60.0 / sr * upb), int((pos + block) * bpm / 60.0 / sr * upb)
+        for at, _, ch, key, on in events:
+            if t0 <= at < t1:
+                u, al = inst[ch]
+                for ev in (al.on(key, pos) if on else al.off(key, pos)):
+                    g.note_events(u, T.note_events([ev]))
+        want.append(g.tick(block)); pos += block
+    want = _quantise(oracle, np.concatenate(want, axis=0))
+    assert want.shape == pcm16.shape
+    assert np.max(np.abs(pcm16 - want)) <= 1, int(np.max(np.abs(pcm16 - want)))
+    # a sampler whose file is missing: a message, no abort
+    (tmp_path / "samples" / "d.wav").unlink()
+    r = subprocess.run([cli, "--assets", str(tmp_path), str(proj)], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "couldn't read" in r.stderr
+
+
+def test_control_trip_onto_an_instrument_reaches_its_voices(oracle):
+    """f3's other half: Controllable is generated for every entity (proc-macros/src/control.rs:171-183), so a trip
+    may target a synth.  A Welsh synth whose `dca-pan` a trip sweeps from hard left to hard right over two beats: the bus follows the
+    oracle's bank given the same control values at the same block starts (oracle_bank_set_param), and the image really moves."""
+    from groove_amd import host_binding as H
+    bpm, sr, block = 120.0, 44100, 256
+    patch = P.welsh_patch(3)
+    o = H.Orchestrator(0, sr, bpm)
+    try:
+        w = o.add_welsh(patch, voices=4)
+        assert o.patch(w, o.MAIN_MIXER) == 0
+        o.connect_midi_downstream(w, 0)
+        seq = o.add_sequencer()
+        for k, s_, d in ((60, 0.0, 1.9), (64, 0.5, 1.0)):
+            o.sequencer_insert(seq, 0, k, s_, d)
+        o.sequencer_set_end(seq, 2.0)
+        trip = o.add_control_trip(w, "dca-pan", 0.0)
+        o.control_trip_add_step(trip, H.STEP_SLOPE, 0.0, 1.0, 2.0)
+        with pytest.raises(RuntimeError, match="unknown control name"):
+            o.add_control_trip(w, "no-such-control", 0.0)
+        got = o.run(block).astype(np.float64)
+    finally:
+        o.close()
+    total = math.ceil(2.0 * 60 / bpm * sr)
+    assert len(got) == total
+    ob = oracle.Bank.welsh((T.WelshParams * 4)(*[patch] * 4))
+    upb = 65536
+    evs = sorted([(int(0.0 * upb + 0.5), 0, 0, 60, True), (int(1.9 * upb + 0.5), 1, 0, 60, False), (int(0.5 * upb + 0.5), 2, 1, 64, True), (int(1.5 * upb + 0.5), 3, 1, 64, False)])
+    want, pos, last = [], 0, None
+    while pos < total:
+        fr = min(block, total - pos)
+        t0, t1 = int(pos * bpm / 60.0 / sr * upb), int((pos + fr) * bpm / 60.0 / sr * upb)
+        for at, _, v, key, on in evs:
+            if t0 <= at < t1:
+                ob.note_events(T.note_events([(v, key, on)]))
+        beats = t0 / upb                                  # ControlTrip::work: the value at the block's start, sent when it changes
+        val = min(1.0, max(0.0, beats / 2.0))
+        if val != last:
+            ob.set_param(T.CTL_WELSH_DCA_PAN, val); last = val
+        want.append(ob.render_bus(fr)); pos += fr
+    want = np.concatenate(want, axis=0)
+    assert np.sqrt(np.mean(want ** 2)) > 1e-2
+    assert np.sqrt(np.mean((got - want) ** 2)) <= 1e-5
+    q = total // 4
+    assert np.abs(got[:q, 0]).mean() > 3 * np.abs(got[:q, 1]).mean() and np.abs(got[-q:, 1]).mean() > 3 * np.abs(got[-q:, 0]).mean()

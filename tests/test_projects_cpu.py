@@ -107,6 +107,20 @@ def test_bench_dry_launch_starts_two_ranks():
     assert sec["mixed-131072"]["voices_total"] == 131072 and sec["mixed-131072"]["ranges"] == [[0, 65536], [65536, 131072]]
 
 
+def test_bench_has_one_collective_path_and_refuses_without_it():
+    """A rank whose library communicator cannot be set up ends the job: every rank leaves with a non-zero code and says why, nothing is
+    printed as a result — the torch.distributed-over-nccl fallback of rounds 3 - 5 is gone, so a line that
+    exists measured groove_bus_reduce.  Here through --dry-launch (the rendezvous without a GPU; GROOVE_BENCH_BREAK_COMM names the
+    rank that fails); the launcher does not retry a failure that is not a stall."""
+    src = open(os.path.join(REPO, "bench.py")).read()
+    assert "new_group(backend=\"nccl\")" not in src and "dist.reduce(" not in src      # no second collective backend in the file
+    env = _clean_env(GROOVE_BENCH_BREAK_COMM="1")
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-launch"], env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode != 0, p.stdout[-500:]
+    assert "no fallback" in p.stderr and "GROOVE_BENCH_BREAK_COMM" in p.stderr and "another rank could not set up" in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{") and "dry_launch" in ln]
+
+
 def test_section_plan_is_config_5_at_eight_gpus():
     """BASELINE.json config #5: 131,072 mixed voices sharded over 8 GPUs = 16,384 contiguous voices per rank."""
     sys.path.insert(0, REPO)
