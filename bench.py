@@ -37,6 +37,7 @@ reduce over the timed region's frames, inside the timed region.
 """
 import argparse
 import json
+import math
 import os
 import socket
 import subprocess
@@ -328,6 +329,7 @@ def compact_line(line):
                        "achieved": _r(roof.get("achieved")), "peak": roof.get("peak"), "unit": roof.get("unit"),
                        "algorithmic_bytes_per_step": _r(roof.get("algorithmic_bytes_per_step")), "kernel_ms": _r(roof.get("kernel_ms")),
                        "traffic": _r(roof.get("traffic")), "traffic_source": roof.get("traffic_source"),
+                       "traffic_source_head": (roof.get("traffic_source_head") or "")[:12] or None, "stale_profile": roof.get("stale_profile"),
                        "hbm_physical_frac": _r(roof.get("hbm_physical_frac"), 4), "valu_achieved_frac": _r(valu.get("achieved_frac"), 4),
                        "frac_of_measured_bound": _r(valu.get("frac_of_measured_bound"), 4), "bound_source": valu.get("bound_source"),
                        "measured_bound_ms": _r((valu.get("measured_bound") or {}).get("bound_ms"), 4)}
@@ -342,6 +344,8 @@ def compact_line(line):
         out["parity_rms"] = _r(par.get("bus_rms_err"), 4)
         out["parity_sample"] = f"{par.get('voices_sampled')} voices x {par.get('blocks')} blocks, same kernel form, bus / voices"
     out["zero_segments"] = line.get("zero_segments")
+    lib_id = line.get("library") or {}
+    out["library"] = {"source_hash": lib_id.get("source_hash"), "git_head": (lib_id.get("git_head") or "")[:12] or None, "dirty": lib_id.get("dirty")}
     if line.get("tainted"):
         out["tainted"] = True
     if line.get("configs"):
@@ -408,6 +412,20 @@ def add_watchdog(text, watchdog):
 
 
 # ------------------------------------------------------------------------------------------ evidence
+def library_identity(debug_info=None):
+    """Which code this is: the hash of the library's sources as the loaded library itself reports it (groove_debug_info; compiled in by
+    groove_amd/Makefile) and the commit the in-tree binaries were built at (groove_amd/build_id.json, written by __graft_entry__.build()
+    where .git exists).  On the line, and in every profile summary (tools/summarize_prof.py): a summary whose hash differs from the
+    running library's was taken with other device code (`roofline.stale_profile`)."""
+    out = {"source_hash": (debug_info or {}).get("source_hash")}
+    try:
+        b = json.load(open(os.path.join(REPO, "groove_amd", "build_id.json")))
+        out.update(git_head=b.get("git_head"), dirty=b.get("dirty"), libgroove_hip_sha256_16=b.get("libgroove_hip_sha256_16"))
+    except Exception:  # noqa: BLE001
+        out.update(git_head=None)
+    return out
+
+
 def committed_profile(workload, window=None):
     """The committed rocprofv3 summary of a workload (profiles/rNN_<workload>_summary.json, or round 1's single
     summary for welsh-1m): HBM traffic per step (FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM) and the VALU / SALU
@@ -438,7 +456,7 @@ def committed_profile(workload, window=None):
         name, d = newest(r"^r(\d+)_summary\.json$")  # round 1's layout: one summary, of the default workload
     if d is None:
         return None
-    out = {"source": name, "window_steps_warmup": [d.get("steps"), d.get("warmup")],
+    out = {"source": name, "library": d.get("library"), "window_steps_warmup": [d.get("steps"), d.get("warmup")],
            "same_window_as_this_run": window is not None and [d.get("steps"), d.get("warmup")] == list(window),
            "traffic": (d.get("hbm_traffic_bytes_per_step") or {}).get("total_corrected")}
     ins = d.get("instructions_per_step") or {}
@@ -605,6 +623,38 @@ def sampled_parity(ctx, workload, v_total, blocks, sample=64, fused=True, groupe
             "max_abs_err": float(np.max(np.abs(got - want)))}
 
 
+def usable_cpus(hardware_concurrency):
+    """How many CPUs this process can actually keep busy: its affinity mask and its cgroup's CPU quota (cpu.max: the GPU boxes of this
+    pool show 256 hardware threads and allow 16 CPUs of time — measured, round 6: the f64 oracle scales 7.0x on 8 threads, 11.3x on 16,
+    and then flat at the quota however many threads run).  Returns (threads to use, why)."""
+    n, why = hardware_concurrency, "std::thread::hardware_concurrency()"
+    try:
+        aff = len(os.sched_getaffinity(0))
+        if aff < n:
+            n, why = aff, f"the process's affinity mask ({aff} of {hardware_concurrency} hardware threads)"
+    except Exception:  # noqa: BLE001
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                q = max(1, int(math.ceil(float(quota) / float(period))))
+                if q < n:
+                    n, why = q, f"the cgroup's CPU quota ({path}: {quota} / {period} = {q} CPUs of {hardware_concurrency} hardware threads)"
+        except Exception:  # noqa: BLE001
+            pass
+    try:   # cgroup v1
+        quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if quota > 0:
+            q = max(1, -(-quota // period))
+            if q < n:
+                n, why = q, f"the cgroup's CPU quota (cfs_quota_us / cfs_period_us = {q} CPUs of {hardware_concurrency} hardware threads)"
+    except Exception:  # noqa: BLE001
+        pass
+    return n, why
+
+
 def cpu_baseline(workload, seconds_target=15.0):
     """The f64 scalar oracle ("port"; the reference Rust path cannot be built here) timed on this host,
     rank 0 only, on a bounded sample of the same workload: mode A single thread, mode B all host cores."""
@@ -648,7 +698,8 @@ def cpu_baseline(workload, seconds_target=15.0):
                          "sample": f"{sample_voices} voices x {nb} blocks"}
     except Exception as e:  # noqa: BLE001
         out["native"] = {"error": str(e)[:200]}
-    cores = int(O.lib().oracle_hardware_concurrency()) or 1
+    hw = int(O.lib().oracle_hardware_concurrency()) or 1
+    cores, why_cores = usable_cpus(hw)
     if WORKLOADS[workload]["kind"] in ("welsh", "mixed", "sampler"):  # mode B: voices sharded over all host cores
         # PERSISTENT workers (round 6): every thread owns >= 64 voices for >= 16 consecutive blocks between one spawn and one join
         # (oracle_bank_render_bus_blocks_mt; the stretch ends where the timeline has note events).  Round 5 spawned and joined 256 threads
@@ -664,7 +715,8 @@ def cpu_baseline(workload, seconds_target=15.0):
         el = time.perf_counter() - t0
         mt_vf = mt_voices * FRAMES * mt_blocks / el
         eff = mt_vf / (cores * vf_per_s)
-        out["all_cores"] = {"value": mt_vf / V, "cores": cores, "speedup_over_one_core": mt_vf / vf_per_s, "parallel_efficiency": eff,
+        out["all_cores"] = {"value": mt_vf / V, "cores": cores, "hardware_concurrency": hw, "cores_is": why_cores,
+                            "speedup_over_one_core": mt_vf / vf_per_s, "parallel_efficiency": eff,
                             "sample": f"{mt_voices} voices ({mt_voices // max(cores, 1)} per thread) x {mt_blocks} blocks from block 1 of the timeline, {cores} persistent "
                                       f"threads, {stretches} spawn / join stretch(es)",
                             "note": ("hardware_concurrency counts SMT siblings: two threads of a core share its FP units, so ~0.5 of the thread count is what a "
@@ -802,7 +854,7 @@ def time_project(ctx, proj, bus, K, W, repeats, span_mode, dist=None):
     return walls, kerns, extra
 
 
-def roofline_block(workload, n_local, kern_ms, span_mode, fused, window=None):
+def roofline_block(workload, n_local, kern_ms, span_mode, fused, window=None, source_hash=None):
     """Two views of one step.  EFFECTIVE (`achieved` / `frac`): the entity-boundary algorithmic bytes of
     the step divided by its duration — what an implementation that materialised every voice block would have to move;
     a fused kernel does not move them and the figure can exceed 1.  PHYSICAL: what the PMC passes of the committed
@@ -815,8 +867,8 @@ def roofline_block(workload, n_local, kern_ms, span_mode, fused, window=None):
     dom_bytes = wl["bytes_per_vf"] if whole else wl["dominant_bytes"]
     achieved = dom_bytes * n_local * FRAMES / (kern_ms * 1e-3) / 1e9
     prof = committed_profile(workload, window) or {}
-    kernel = ("welsh_render_uniform_kernel<fused, LFO mode, retune> (one kernel per base kind, run concurrently; "
-              "class-specialised block bodies) + partial_rows/final" if fused and wl["kind"] == "welsh"
+    kernel = ("welsh_render_uniform_mix_kernel<fused> (three launches per block, a third of every kind's workgroups each; class-specialised block bodies; "
+              "welsh_render_uniform_kernel per exact-f64 kind) + partial_rows/final" if fused and wl["kind"] == "welsh"
               else "whole step: render of block b+1 + the chain's IIR head (side stream) beside the rest of the effect chain + mix of block b" if whole and wl["kind"] == "chain"
               else "whole step: the banks' fused render kernels side by side + their bus reductions" if whole
               else "render kernel of the first bank")
@@ -832,7 +884,13 @@ def roofline_block(workload, n_local, kern_ms, span_mode, fused, window=None):
          "kernel_ms": kern_ms,
          "traffic": None, "traffic_unit": "HBM bytes per step (PMC FETCH_SIZE x2 + WRITE_SIZE, committed pass)",
          "traffic_source": prof.get("source"), "traffic_same_window": prof.get("same_window_as_this_run"),
-         "profile_window_steps_warmup": prof.get("window_steps_warmup")}
+         "profile_window_steps_warmup": prof.get("window_steps_warmup"),
+         # which code the committed counters were taken with (tools/summarize_prof.py writes the library's identity into every summary
+         # since round 6) against the library that is running: the physical fields below describe THIS code only when the two agree
+         "traffic_source_head": (prof.get("library") or {}).get("git_head"), "traffic_source_hash": (prof.get("library") or {}).get("source_hash"),
+         "running_source_hash": source_hash,
+         "stale_profile": (None if not prof else True if not (prof.get("library") or {}).get("source_hash") or not source_hash
+                           else (prof["library"]["source_hash"] != source_hash))}
     scale = n_local / WORKLOADS[workload]["voices"]   # the committed pass counted the workload's full-size step
     hbm_frac = valu_frac = None
     if prof.get("traffic"):
@@ -958,7 +1016,7 @@ def config_entry(ctx, workload, repeats, parity_voices=64):
     ms = [w / K * 1e3 for w in m["walls"]]
     i = m["median"]
     fps = K * FRAMES / m["walls"][i]
-    roof = roofline_block(workload, V, m["kerns"][i], m["span_mode"], True)
+    roof = roofline_block(workload, V, m["kerns"][i], m["span_mode"], True, source_hash=ctx.debug_info().get("source_hash"))
     par = sampled_parity(ctx, workload, V, min(K, 172), sample=parity_voices)
     return {"workload": workload, "voices": V, "blocks_timed": f"0..{K - 1} (the whole project, {K * FRAMES} frames)",
             "ms_per_step": ms[i], "ms_per_step_min": min(ms), "ms_per_step_repeats": ms,
@@ -1223,13 +1281,14 @@ def measure(args, world, rank, local_rank):
             "project_frames_per_s": project_fps,
             "voice_frames_per_s": project_fps * V_total,
             "path_effective_GBs": wl["bytes_per_vf"] * project_fps * V_total / 1e9,
-            "roofline": roofline_block(args.workload, n_local, kern_ms, m["span_mode"], fused, window=(K, W)),
+            "roofline": roofline_block(args.workload, n_local, kern_ms, m["span_mode"], fused, window=(K, W), source_hash=ctx.debug_info().get("source_hash")),
             "output_check": {"finite": bool(np.isfinite(out_bus).all()), "peak_abs_bus_over_V": float(np.abs(out_bus).max() / V_total)},
             "streams": ctx.debug_info(),
         }
         if dist is not None:
             line["rccl_ranks"] = dist.rccl_ranks
         line["zero_segments"] = line["streams"].get("zero_segments")
+        line["library"] = library_identity(line["streams"])
         if line["zero_segments"]:
             line["tainted"] = "the Welsh kernels counted zero-frame segments (csrc/diag.h; DESIGN.md section 7): this must not happen"
     if dist is not None and not args.no_sections and not args.materialise and not args.interleaved:

@@ -2320,7 +2320,8 @@ const char* groove_bank_kernel_form(groove_bank* b, uint32_t frames, int fused) 
   if (!b->n_vwaves) return "welsh_render_kernel (per-lane parameters)";
   const bool pipelined = fused && (b->n_vwaves >= ctx->pipeline_min_waves || ctx->pipeline_min_waves <= 1);
   if (b->n_vwaves >= ctx->pipeline_min_waves || (fused && ctx->pipeline_min_waves <= 1))
-    return pipelined ? "welsh_render_uniform_kernel (one launch per base kind, class-specialised bodies, blocks pipelined)"
+    return pipelined ? (ctx->mix_kernel ? "welsh_render_uniform_mix_kernel (big-bank form: three launches per block over thirds of the kind-sorted workgroups, one launch per base kind for the exact-f64 kinds only; class-specialised bodies, blocks pipelined)"
+                                        : "welsh_render_uniform_kernel (one launch per base kind, class-specialised bodies, blocks pipelined)")
                      : "welsh_render_uniform_kernel (one launch per base kind, class-specialised bodies)";
   if (use_split(b, frames) && split_roles_of(b) == 4) return "welsh_render_split4_kernel (role-split: four wavefronts per 64 voices, pipelined over the frames)";
   if (use_split(b, frames)) return split_roles_of(b) == 3 ? "welsh_render_split_kernel (role-split: three wavefronts per 64 voices, pipelined over the frames)"

@@ -197,6 +197,9 @@ struct FusedAcc {
 // materialised million-voice window 0.885 - 0.891 ms per block against 0.790 - 0.796 in one job, profiles/r04_store_wave_ab.log.
 // The stores are not what the voice waves wait for; a fifth wave per workgroup is a fifth of the wave slots.)
 __device__ __forceinline__ void block_store(float* __restrict__ p, float x) { *p = x; }
+// (Round 6 tried the two stores through a BUFFER resource — base in SGPRs, scalar row offset, one 32-bit lane offset, no 64-bit address
+// arithmetic per frame: the materialised million-voice window 0.899 ms per block against 0.736, profiles/r06_materialised_stores_ab.log.
+// The same log has the counters: the waves of this form wait three times as long as the fused form's, on the memory pipeline, not on issue.)
 // Shared frame loop of the instrument kernels: `frame(f, L, R)` computes one frame of this
 // lane's voice; the epilogue either stores the planar block or feeds the fused bus sum.
 // FUSED: only the rows of the fused bus sum (partial[workgroup][ch][frame]) are produced.  Otherwise the planar block is
@@ -601,10 +604,14 @@ __device__ __forceinline__ void welsh_dispatch_class(uint32_t cls, UniformArgsPt
 // SPECIALISED = false: the whole launch runs the OSC_ANY x OSC_ANY body (wg_cls is not read).
 template <bool FUSED, int LFO_MODE, bool RETUNE, bool SPECIALISED>
 __global__ __launch_bounds__(kThreads, (WavesBudget<LFO_MODE, RETUNE>::value)) GROOVE_NO_TAIL_CALLS void welsh_render_uniform_kernel(UniformArgs a) {
-  // (No s_setprio: raising the f64-LFO kinds' wave priority paid when a block's kernels were forked and
+  // (No s_setprio for the class-specialised kinds: raising the f64-LFO kinds' wave priority paid when a block's kernels were forked and
   // joined; with the blocks pipelined the longest kernel is the most numerous kind, and any priority
   // costs 5 % — measured: none 0.460 ms, f64-LFO kinds raised 0.484, F32-retune raised 0.513.)
   const UniformArgsPtr ka = (UniformArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(); // == &a, in the constant address space
+  // (Round 6, the exact-f64 kinds beside the mix kernel's three launches: their few wavefronts — 1.9 % of a library-proportioned bank's
+  // voices — take the block's longest walk, ~410 us beside mix launches of ~350, 227 us alone.  s_setprio(3) for these kernels changed
+  // nothing: 0.4067 against 0.4052 ms per block; a wave's walk is a serial instruction stream 2.3x the average voice's, and no priority
+  // shortens it.  Left out.)
 #ifdef GROOVE_HEARTBEAT /* diag.h: workgroups started / finished, counted in host memory the host can read while the device is stuck */
   unsigned long long* hb = a.heartbeat;
   if (hb && threadIdx.x == 0) __hip_atomic_fetch_add(hb + 0, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -21,10 +21,12 @@ for W in $WORKLOADS; do
   # "<workload>-window": the same workload under the DRIVER's command line (--steps 20 --warmup 5), so that the counters
   # describe the blocks the driver's line times (blocks 5..24: every voice sounding)
   WL=${W%-window}; WIN=""; [ "$WL" != "$W" ] && WIN="--steps 20 --warmup 5"
+  # "<workload>-materialised[-window]": the entity-boundary form (every voice block written to HBM, then mixed): bench.py --materialise
+  MAT=""; case "$WL" in *-materialised) WL=${WL%-materialised}; MAT="--materialise";; esac
   # REPEATS timed regions per run (default 5 for the window, 1 otherwise): durations are summarised from the LAST region, where the
   # device is at speed (tools/summarize_prof.py)
   R=${REPEATS:-1}; [ -n "$WIN" ] && R=${REPEATS:-5}
-  BENCH="python3 bench.py --workload $WL $WIN --no-cpu-baseline --no-configs --no-parity --no-shard-curve --repeats $R --no-watchdog"   # (the watchdog would start a child from under the profiler)
+  BENCH="python3 bench.py --workload $WL $WIN $MAT --no-cpu-baseline --no-configs --no-parity --no-shard-curve --repeats $R --no-watchdog"   # (the watchdog would start a child from under the profiler)
   $TO rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/bench_kt.log 2>&1
   $TO rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH > $OUT/bench_fetch.log 2>&1
   $TO rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH > $OUT/bench_write.log 2>&1

@@ -12,12 +12,15 @@ out, rnd, workload = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3
 os.makedirs("profiles", exist_ok=True)
 # "<workload>-window" = the same workload under the driver's command line (--steps 20 --warmup 5): tools/profile_round.sh
 base_workload, windowed = (workload[:-len("-window")], True) if workload.endswith("-window") else (workload, False)
+materialised = base_workload.endswith("-materialised")   # the entity-boundary form: bench.py --materialise
+if materialised:
+    base_workload = base_workload[:-len("-materialised")]
 # REPEATS (environment, as tools/profile_round.sh ran the bench): timed regions per run.  A process's first regions run 5 - 12 %
 # slower than what the device then sustains (profiles/r03_timed_regions.log), so DURATIONS are read off the LAST region only;
 # counts (bytes, instructions) are the same in every region and are averaged over all of them.
 REPEATS = int(os.environ.get("REPEATS", "1"))
 summary = {"round": rnd, "workload": workload, "regions_per_run": REPEATS,
-           "command": f"python3 bench.py --workload {base_workload} --no-cpu-baseline --no-configs --no-parity --no-shard-curve --repeats {REPEATS} --no-watchdog"
+           "command": f"python3 bench.py --workload {base_workload}{' --materialise' if materialised else ''} --no-cpu-baseline --no-configs --no-parity --no-shard-curve --repeats {REPEATS} --no-watchdog"
                       + (" --steps 20 --warmup 5   (the driver's window: blocks 5..24 of the timeline)" if windowed else "   (defaults: --gpus 1 --steps 172 --warmup 4)")}
 STEP_KERNELS = ("render", "_tp_kernel", "partial_", "mix_", "fx_", "block_", "_events_")   # what one step of the hot path launches
 
@@ -84,8 +87,13 @@ if kt:
 for log in glob.glob(f"{out}/bench_kt.log"):
     for line in open(log):
         if line.startswith("{"):
-            summary["bench_line_under_profiler"] = {k: v for k, v in json.loads(line).items() if k in
+            _line = json.loads(line)
+            summary["bench_line_under_profiler"] = {k: v for k, v in _line.items() if k in
                                                     ("value", "ms_per_step", "steps", "warmup", "config", "roofline", "timed_region", "zero_segments")}
+            # which code the counters describe (round 6): the running library's own source hash (groove_debug_info) and the commit the
+            # in-tree binaries were built at (groove_amd/build_id.json), as bench.py put them on the line of this very run
+            if _line.get("library"):
+                summary["library"] = _line["library"]
 
 
 def counters(sub):
