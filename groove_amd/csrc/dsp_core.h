@@ -737,6 +737,15 @@ struct WelshScratch {
 GROOVE_HD bool welsh_retunes(const WelshParams& p) {
   return (p.flags & (WF_RETUNE_ENV | WF_LFO_CUTOFF | WF_LFO_RESO)) != 0;
 }
+// "this frame computes its own coefficients": the look-ahead flag (welsh_frame's `tab`) tested as what it is, a scalar.  Through an
+// opaque asm, one per use: left to itself the compiler folds the tests of a frame into lane-mask booleans, inverts them through vector
+// instructions and evaluates what they guard before selecting it away.
+GROOVE_HD bool welsh_tab_off(uint32_t tab) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+s"(tab));
+#endif
+  return tab == 0u;
+}
 // The cutoff percent an envelope-retuned filter takes from its envelope's value (DSP_SPEC section 6: start + (1 - start) end env).
 GROOVE_HD float welsh_env_cutoff_pct(const WelshParams& p, float fil_value) {
   return fmaf((1.0f - p.cutoff_start) * p.cutoff_end, fil_value, p.cutoff_start);
@@ -852,17 +861,24 @@ GROOVE_HD float osc_value_classed(uint32_t w, uint64_t phase, uint64_t duty64, f
 //          filter does not run.  `lfo` is handed out for the resonance routing.
 //   COEF   the filter coefficients for `pct` (kept in sc.coef; an unchanged percent leaves them standing);
 //   BACK   the f64 filter recurrence on `sum`, the gain, the pan gains.
-// `tab` (wave-uniform; HOIST frames of the uniform kernels only): this segment's filter coefficients come from the wave's look-ahead
-// table (kernels.h "coefficient look-ahead"), so the frame neither evaluates the filter envelope nor derives a cutoff percent from it.
+// `tab` (a wave-uniform 0 / 1 in an SGPR; HOIST frames of the uniform kernels only): this segment's filter coefficients come from the
+// wave's look-ahead table (kernels.h "coefficient look-ahead"), so the frame neither evaluates the filter envelope nor derives a cutoff
+// percent from it.  (An integer, not a bool: as a bool the flag lived in a lane mask and its negation went through two vector instructions.)
 template <bool FIRST, bool RETUNE, int LFO_MODE = LFO_F64, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool SEGMENT = false, bool REST = false,
           bool HOIST = false>
-GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScratch& sc, float& sum, float& a, float& pct, bool& retune, float& lfo, bool tab = false) {
+GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScratch& sc, float& sum, float& a, float& pct, bool& retune, float& lfo, uint32_t tab = 0u) {
   static_assert(!HOIST || (SEGMENT && !FIRST), "hoisted counters belong to a segment");
   if (SEGMENT && HOIST) {
     // env_shape with the segment's constants (welsh_segment_start_hoisted): two operations per envelope and frame
     s.amp.value = env_shape(sc.ta, s.amp.A, sc.ac1, sc.ac2);
     sc.ta += 1.0f;
-    if (!tab) { s.fil.value = env_shape(sc.tf, s.fil.A, sc.fc1, sc.fc2); sc.tf += 1.0f; }
+    if (welsh_tab_off(tab)) {
+      s.fil.value = env_shape(sc.tf, s.fil.A, sc.fc1, sc.fc2); sc.tf += 1.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+      // keeps `tab` a scalar BRANCH: if-converted, a table frame still evaluated the envelope and the percent and selected them away
+      asm volatile("" : "+v"(s.fil.value));
+#endif
+    }
   } else if (SEGMENT) {
     env_advance(s.amp);
     env_advance(s.fil);
@@ -964,7 +980,7 @@ GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScrat
   // filter cutoff
   retune = false;
   pct = 0.0f;
-  if (RETUNE && !tab) {
+  if (RETUNE && welsh_tab_off(tab)) {
     // (an unused LFO cannot drive the cutoff: in a retuned kind the envelope must)
     if (CL == LFO_UNUSED || (p.flags & WF_RETUNE_ENV)) {
       pct = welsh_env_cutoff_pct(p, s.fil.value);
@@ -973,6 +989,9 @@ GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScrat
       pct = p.cutoff_start * fmaf(lfo, p.lfo_depth, 1.0f);
       retune = true;
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (HOIST) asm volatile("" : "+v"(pct)); // (as above)
+#endif
   }
   a = s.amp.value;
   if (r_amp) a *= fmaf(lfo, p.lfo_depth, 1.0f);
@@ -1137,18 +1156,28 @@ GROOVE_HD void welsh_frame_back(const WelshParams& p, Lp24StateD& filt, const Lp
 template <bool FIRST, bool RETUNE, int LFO_MODE = LFO_F64, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool SEGMENT = false, bool REST = false,
           bool HOIST = false, bool F32FILT = false>
 GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc,
-                           WelshScratch& sc, float& L, float& R, bool tab = false) {
+                           WelshScratch& sc, float& L, float& R, uint32_t tab = 0u) {
   static_assert(!(F32FILT && LFO_MODE == LFO_F64), "the exact-f64 kinds (resonance routing) keep the f64 filter");
   float sum, a, pct, lfo;
   bool retune;
   // (tab: the caller has put this frame's coefficients into sc.coef / sc.coef_f already — kernels.h "coefficient look-ahead")
   if (!welsh_frame_front<FIRST, RETUNE, LFO_MODE, C1, C2, CL, SEGMENT, REST, HOIST>(p, s, sc, sum, a, pct, retune, lfo, tab)) { L = 0.0f; R = 0.0f; return; }
   if constexpr (F32FILT) { // sc.coef_f / sc.filt_f were set by welsh_scratch_f32_begin; the caller hands the state back with welsh_scratch_f32_end
-    if (RETUNE && retune && pct != sc.prev_pct) { sc.coef_f = lp24_coeff_from_pct(p.fc, pct, rc); sc.prev_pct = pct; }
+    if (RETUNE && welsh_tab_off(tab)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (HOIST) asm volatile("" : "+v"(pct)); // (the comparison below stays inside this branch)
+#endif
+      if (retune && pct != sc.prev_pct) { sc.coef_f = lp24_coeff_from_pct(p.fc, pct, rc); sc.prev_pct = pct; }
+    }
     const float m = lp24_step_f32<SEGMENT && !RETUNE>(sc.filt_f, sc.coef_f, sum) * a; // uniform static kinds: coefficients in SGPRs
     L = m * p.gl; R = m * p.gr;
   } else {
-    welsh_frame_coef<RETUNE, LFO_MODE, CL>(p, rc, sc, pct, retune, lfo);
+    if (welsh_tab_off(tab)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (HOIST && RETUNE) asm volatile("" : "+v"(pct));
+#endif
+      welsh_frame_coef<RETUNE, LFO_MODE, CL>(p, rc, sc, pct, retune, lfo);
+    }
     welsh_frame_back<SEGMENT && !RETUNE>(p, s.filt, sc.coef, sum, a, L, R);
   }
 }

@@ -1194,6 +1194,9 @@ static bool create_streams(groove_ctx* ctx) {
   // another kind's kernel on its stream that walk was added to the stream's time per block — the step's long pole with the
   // library-proportioned table (profiles/r06_*).  On a stream of their own they run beside the others.
   if (ok && !ctx->safe_streams && ctx->bank_streams > 0 && ctx->side_stream[kBaseKinds]) ctx->side_stream[4] = ctx->side_stream[5] = ctx->side_stream[kBaseKinds];
+  // GROOVE_EXACT_STREAM=placeholder (A/B): the normal-priority stream nobody uses instead — the low-priority queue's workgroups are
+  // dispatched after everything of normal priority that is pending, and a big bank's mix launches always have workgroups pending
+  if (const char* e = std::getenv("GROOVE_EXACT_STREAM")) if (ok && e[0] == 'p' && ctx->placeholder_stream) ctx->side_stream[4] = ctx->side_stream[5] = ctx->placeholder_stream;
   return ok;
 }
 static bool side_stream_owned(const groove_ctx* ctx, int i) {

@@ -343,11 +343,33 @@ struct CoefTab {
     __shared__ double t[kWaves][kFrames][6];
     return &t[threadIdx.x >> 6][0][0];
   }
+  // Frame i's entry, read through an LDS (address space 3) pointer built from a 32-bit byte address.  Word by word: a struct cannot be
+  // assigned across address spaces; the compiler merges the words into wide ds_read / ds_write.
+  typedef __attribute__((address_space(3))) uint32_t* LdsWords;
+  template <class T> static __device__ __forceinline__ T load(uint32_t i) {
+    typedef __attribute__((address_space(3))) char* LdsBytes;
+    // (The address is wave-uniform; forcing it through SGPRs — two v_readfirstlane, scalar multiply and add, a move — was measured and
+    // lost to this per-lane form, whose index arithmetic the compiler does with one v_mad_u64_u32: 0.3594 - 0.3676 against 0.3516 - 0.3538
+    // ms per block in one job, tools/ab_bench.sh, round 6.)
+    const LdsWords w = (LdsWords)(uintptr_t)((uint32_t)(uintptr_t)(LdsBytes)wave_base() + i * (uint32_t)sizeof(T));
+    WordsOf<T> t;
+#pragma unroll
+    for (uint32_t k = 0; k < sizeof(T) / 4; ++k) t.w[k] = w[k];
+    return __builtin_bit_cast(T, t);
+  }
+  // ... and lane j's own entry (the fill: a per-lane address)
+  template <class T> static __device__ __forceinline__ void store_of_lane(uint32_t j, const T& x) {
+    typedef __attribute__((address_space(3))) char* LdsBytes;
+    const LdsWords w = (LdsWords)(uintptr_t)((uint32_t)(uintptr_t)(LdsBytes)wave_base() + j * (uint32_t)sizeof(T));
+    const WordsOf<T> t = __builtin_bit_cast(WordsOf<T>, x);
+#pragma unroll
+    for (uint32_t k = 0; k < sizeof(T) / 4; ++k) w[k] = t.w[k];
+  }
 };
 // Do the live lanes of this wave share the filter envelope's stage?  Then its description, from the first of them, in SGPRs.
-struct FilEnvUniform { bool ok; float A, c1, c2, tf; };
+struct FilEnvUniform { bool ok; float A, c1, c2, tf; uint32_t tab; }; // tab: `ok` as a 0 / 1 the compiler KNOWS to be in an SGPR (readfirstlane)
 __device__ __forceinline__ FilEnvUniform fil_env_uniform(const WelshState& s, const WelshScratch& sc, bool live) {
-  FilEnvUniform u{false, 0.0f, 0.0f, 0.0f, 0.0f};
+  FilEnvUniform u{false, 0.0f, 0.0f, 0.0f, 0.0f, 0u};
   const uint64_t mask = __ballot(live);
   if (mask == 0) return u;
   const int l0 = __builtin_ctzll(mask); // wave-uniform
@@ -359,6 +381,7 @@ __device__ __forceinline__ FilEnvUniform fil_env_uniform(const WelshState& s, co
   const bool same = __builtin_bit_cast(uint32_t, s.fil.A) == __builtin_bit_cast(uint32_t, u.A) && __builtin_bit_cast(uint32_t, sc.fc1) == __builtin_bit_cast(uint32_t, u.c1) &&
                     __builtin_bit_cast(uint32_t, sc.fc2) == __builtin_bit_cast(uint32_t, u.c2) && __builtin_bit_cast(uint32_t, sc.tf) == __builtin_bit_cast(uint32_t, u.tf);
   u.ok = __ballot(live && !same) == 0;
+  u.tab = (uint32_t)__builtin_amdgcn_readfirstlane(u.ok ? 1 : 0);
   return u;
 }
 // Lane j: the coefficients of frame k0 + j of the segment, into the wave's table.  (All 64 lanes take part, live or not: the inputs
@@ -370,8 +393,8 @@ __device__ __forceinline__ void coef_tab_fill(const WelshParams& p, const Render
   const float pct = welsh_env_cutoff_pct(p, env_shape(n, u.A, u.c1, u.c2));
   bool hi;
   const float t = lp24_t_from_pct(pct, rc, hi);
-  if constexpr (F32) reinterpret_cast<Lp24CoefF*>(CoefTab::wave_base())[j] = lp24_coeff_from_t(p.fc, t, hi);
-  else reinterpret_cast<Lp24CoefD*>(CoefTab::wave_base())[j] = lp24_coefd_from_t(p.fc, t, hi, (p.flags & WF_COEF_WIDE) != 0);
+  if constexpr (F32) CoefTab::store_of_lane<Lp24CoefF>(j, lp24_coeff_from_t(p.fc, t, hi));
+  else CoefTab::store_of_lane<Lp24CoefD>(j, lp24_coefd_from_t(p.fc, t, hi, (p.flags & WF_COEF_WIDE) != 0));
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the wave's own reads below come after these writes
   __builtin_amdgcn_wave_barrier();
 }
@@ -391,23 +414,27 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
     // back two thirds of the gain (profiles/r05_f32_filter.log).
     welsh_scratch_f32_begin(p, s, rc, sc);
     if (!RETUNE) sc.coef_f = make_scalar(sc.coef_f);
-    FilEnvUniform fu{false, 0.0f, 0.0f, 0.0f, 0.0f}; // this segment's coefficient look-ahead (RETUNE kinds; fu.ok is wave-uniform)
+    FilEnvUniform fu{false, 0.0f, 0.0f, 0.0f, 0.0f, 0u}; // this segment's coefficient look-ahead (RETUNE kinds; fu.ok is wave-uniform)
     run_frames_segmented<FUSED>(
         frames, n, v, active, ch_stride, out, rows, prow,
         [&](float& L, float& R) { welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL, false, REST, false, true>(p, s, rc, sc, L, R); },
         [&](bool& live) { const uint32_t k = welsh_segment_begin(p, s, live); welsh_segment_start_hoisted(s, sc); return k; },
         [&](bool live, uint32_t seg) {
-          fu.ok = false;
+          fu.ok = false; fu.tab = 0u;
           if constexpr (RETUNE && GROOVE_COEF_LOOKAHEAD) { if ((p.flags & WF_RETUNE_ENV) && seg >= CoefTab::kMinSegment) fu = fil_env_uniform(s, sc, live); }
         },
-        [&](uint32_t k) { if constexpr (RETUNE && GROOVE_COEF_LOOKAHEAD) { if (fu.ok && (k & (CoefTab::kFrames - 1)) == 0) coef_tab_fill<true>(p, rc, fu, k); } },
+        [&](uint32_t k) { if constexpr (RETUNE && GROOVE_COEF_LOOKAHEAD) { if (fu.tab != 0u && (k & (CoefTab::kFrames - 1)) == 0) coef_tab_fill<true>(p, rc, fu, k); } },
         [&](uint32_t k, float& L, float& R) {
-          if constexpr (RETUNE && GROOVE_COEF_LOOKAHEAD) { if (fu.ok) sc.coef_f = reinterpret_cast<const Lp24CoefF*>(CoefTab::wave_base())[k & (CoefTab::kFrames - 1)]; }
-          welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true, true>(p, s, rc, sc, L, R, RETUNE && GROOVE_COEF_LOOKAHEAD && fu.ok);
+          uint32_t tab = 0u;
+          if constexpr (RETUNE && GROOVE_COEF_LOOKAHEAD) {
+            tab = fu.tab;
+            if (tab != 0u) sc.coef_f = CoefTab::load<Lp24CoefF>(k & (CoefTab::kFrames - 1));
+          }
+          welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true, true>(p, s, rc, sc, L, R, tab);
         },
         [&](uint32_t seg, bool live) {
           welsh_segment_end_hoisted<CL == LFO_UNUSED>(p, s, seg, live);
-          if constexpr (RETUNE && GROOVE_COEF_LOOKAHEAD) { if (fu.ok) { if (live) s.fil.value = env_last_value_of(s.fil); sc.prev_pct = __builtin_nanf(""); } }
+          if constexpr (RETUNE && GROOVE_COEF_LOOKAHEAD) { if (fu.tab != 0u) { if (live) s.fil.value = env_last_value_of(s.fil); sc.prev_pct = __builtin_nanf(""); } }
         },
         [&](uint32_t f, uint32_t mine) { welsh_diag_zero(dw, s, active, f, mine); });
     welsh_scratch_f32_end(s, sc);
@@ -416,23 +443,27 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
   if (UNIFORM && !RETUNE) sc.coef = make_scalar(sc.coef);
   if constexpr (UNIFORM) {
     constexpr bool LOOKAHEAD = RETUNE && LFO_MODE != LFO_F64 && GROOVE_COEF_LOOKAHEAD; // (the exact-f64 kind keeps its own coefficient forms: resonance routing, lp24_coefd_from_fc)
-    FilEnvUniform fu{false, 0.0f, 0.0f, 0.0f, 0.0f};
+    FilEnvUniform fu{false, 0.0f, 0.0f, 0.0f, 0.0f, 0u};
     run_frames_segmented<FUSED>(
         frames, n, v, active, ch_stride, out, rows, prow,
         [&](float& L, float& R) { welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL, false, REST>(p, s, rc, sc, L, R); },
         [&](bool& live) { const uint32_t k = welsh_segment_begin(p, s, live); welsh_segment_start_hoisted(s, sc); return k; },
         [&](bool live, uint32_t seg) {
-          fu.ok = false;
+          fu.ok = false; fu.tab = 0u;
           if constexpr (LOOKAHEAD) { if ((p.flags & WF_RETUNE_ENV) && seg >= CoefTab::kMinSegment) fu = fil_env_uniform(s, sc, live); }
         },
-        [&](uint32_t k) { if constexpr (LOOKAHEAD) { if (fu.ok && (k & (CoefTab::kFrames - 1)) == 0) coef_tab_fill<false>(p, rc, fu, k); } },
+        [&](uint32_t k) { if constexpr (LOOKAHEAD) { if (fu.tab != 0u && (k & (CoefTab::kFrames - 1)) == 0) coef_tab_fill<false>(p, rc, fu, k); } },
         [&](uint32_t k, float& L, float& R) {
-          if constexpr (LOOKAHEAD) { if (fu.ok) sc.coef = reinterpret_cast<const Lp24CoefD*>(CoefTab::wave_base())[k & (CoefTab::kFrames - 1)]; }
-          welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true>(p, s, rc, sc, L, R, LOOKAHEAD && fu.ok);
+          uint32_t tab = 0u;
+          if constexpr (LOOKAHEAD) {
+            tab = fu.tab;
+            if (tab != 0u) sc.coef = CoefTab::load<Lp24CoefD>(k & (CoefTab::kFrames - 1));
+          }
+          welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true>(p, s, rc, sc, L, R, tab);
         },
         [&](uint32_t seg, bool live) {
           welsh_segment_end_hoisted<CL == LFO_UNUSED>(p, s, seg, live);
-          if constexpr (LOOKAHEAD) { if (fu.ok) { if (live) s.fil.value = env_last_value_of(s.fil); sc.prev_pct = __builtin_nanf(""); } }
+          if constexpr (LOOKAHEAD) { if (fu.tab != 0u) { if (live) s.fil.value = env_last_value_of(s.fil); sc.prev_pct = __builtin_nanf(""); } }
         },
         [&](uint32_t f, uint32_t mine) { welsh_diag_zero(dw, s, active, f, mine); });
   } else {

@@ -113,17 +113,21 @@ def test_measured_bound_prefers_this_runs_figure(monkeypatch):
     sys.path.insert(0, REPO)
     import bench
     monkeypatch.delenv(bench.MIX_BOUND_ENV, raising=False)
-    a = bench.roofline_block("welsh-1m", 1_000_000, 0.445, True, True, window=(20, 5))
+    # (step times taken relative to the committed window profile's own instruction count, so that the test follows the profiles)
+    prof, mb0 = bench.committed_profile("welsh-1m", window=(20, 5)), bench.measured_mix_bound()
+    bound0 = prof["valu_per_step"] * mb0["ns_at_5_waves"] * 1e-9 / 1024.0 * 1e3
+    slow, fast = bound0 / 0.88, bound0 * 0.9
+    a = bench.roofline_block("welsh-1m", 1_000_000, slow, True, True, window=(20, 5))
     assert a["valu"]["bound_source"].startswith("committed: r") and 0.8 < a["valu"]["frac_of_measured_bound"] < 1.0
     monkeypatch.setenv(bench.MIX_BOUND_ENV, json.dumps({"ns_at_5_waves": 1.30, "ns_at_4_waves": 1.34, "source": "this run"}))
-    b = bench.roofline_block("welsh-1m", 1_000_000, 0.445, True, True, window=(20, 5))
+    b = bench.roofline_block("welsh-1m", 1_000_000, slow, True, True, window=(20, 5))
     assert b["valu"]["bound_source"] == "this run" and b["valu"]["frac_of_measured_bound"] > a["valu"]["frac_of_measured_bound"]
     assert b["valu"]["achieved_frac"] == a["valu"]["achieved_frac"] and b["physical"]["valu_frac"] == b["valu"]["achieved_frac"]
     mbd = b["valu"]["measured_bound"]
     assert mbd["share_of_instructions_at_4_waves"] == 0.0         # (round 5: every per-kind kernel is budgeted for five waves per SIMD)
     assert mbd["ns_per_wave_instruction"]["weighted"] == 1.30
     assert "frac_of_measured_bound_flags" not in b["valu"] or all("above 1" not in f for f in b["valu"]["frac_of_measured_bound_flags"])
-    c = bench.roofline_block("welsh-1m", 1_000_000, 0.36, True, True, window=(20, 5))   # a step faster than the bound is flagged, not hidden
+    c = bench.roofline_block("welsh-1m", 1_000_000, fast, True, True, window=(20, 5))   # a step faster than the bound is flagged, not hidden
     assert c["valu"]["frac_of_measured_bound"] > 1.0 and any("above 1" in f for f in c["valu"]["frac_of_measured_bound_flags"])
-    d = bench.roofline_block("welsh-1m", 1_000_000, 0.445, True, True, window=(172, 4))
+    d = bench.roofline_block("welsh-1m", 1_000_000, slow, True, True, window=(172, 4))
     assert any("different window" in f for f in d["valu"].get("frac_of_measured_bound_flags", [])) or d["valu"]["measured_bound"]["same_window"]

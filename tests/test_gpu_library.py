@@ -161,3 +161,59 @@ def test_library_workload_full_size(gpu_ctx, oracle):
     per_block = np.abs(mbus - whole).reshape(blocks, -1).max(axis=1) / V
     assert per_block.max() <= 1e-6, per_block
     mat.destroy(); block.destroy(); bus.destroy(); bus2.destroy(); sbus.destroy()
+
+
+def test_coefficient_look_ahead_is_the_per_lane_retune_bit_for_bit(gpu_ctx, oracle):
+    """kernels.h "coefficient look-ahead": a wave whose live voices share the filter envelope's stage takes its filter coefficients from a
+    table that lane j filled for frame k + j; a wave whose voices started apart retunes lane by lane.  The same voices through both: 256
+    voices of ONE envelope-retuned patch in the per-kind (mix) kernels, (A) all struck in block 0 — every wave uniform — and (B) the odd
+    voices struck a block later — every wave mixed.  The even voices, whose own history is the same in A and B, must come out the same
+    BITS (a voice's samples do not depend on its neighbours), and both runs must match the oracle; for an f64-filter patch and for one
+    the host lets filter in fp32."""
+    from groove_amd import entities as E
+    old = gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves, gpu_ctx.pipeline_min_waves
+    gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves, gpu_ctx.pipeline_min_waves = 0, 0, 1
+    try:
+        n, frames, blocks = 256, 256, 14
+        for j in (1, 2, 3, 13):   # benchmark patches, all envelope-retuned: triangle LFO on the amplitude; sine LFO on the pitch (a smooth-f64 kind); no LFO, 49 Hz; sawtooth LFO on the amplitude, 809 Hz
+            patch = P.welsh_patch(j)
+            assert patch.filter_cutoff_end != 0.0
+            params = (T.WelshParams * n)(*[patch] * n)
+            keys = (40 + (np.arange(n) * 5) % 37).astype(np.uint8)
+            keys[keys % 12 == 9] += 1
+            lanes = np.arange(n, dtype=np.uint32)
+            even, odd = lanes[::2], lanes[1::2]
+            runs = {}
+            for name, late in (("A", False), ("B", True)):
+                synth, fused = E.WelshSynth(gpu_ctx, params), E.WelshSynth(gpu_ctx, params)   # (the fused kernels carry the fp32-filter bodies, whose table is fp32)
+                assert "one launch per base kind" in synth.kernel_form(frames, False)
+                block, bus = gpu_ctx.block(n, frames), gpu_ctx.bus(blocks * frames)
+                ob = oracle.Bank.welsh(params)
+                got, want = [], []
+                for b in range(blocks):
+                    evs = []
+                    if b == 0:
+                        evs.append(T.note_events_np(lanes if not late else even, keys if not late else keys[::2], True))
+                    if b == 1 and late:
+                        evs.append(T.note_events_np(odd, keys[1::2], True))
+                    if b == 9:
+                        evs.append(T.note_events_np(even, keys[::2], False))
+                    if b == 11:
+                        evs.append(T.note_events_np(odd, keys[1::2], False))
+                    for ev in evs:
+                        synth.handle_midi_events(ev); fused.handle_midi_events(ev); ob.note_events(ev)
+                    synth.generate_batch_values(block, frames)
+                    fused.render_mix(bus, frames, at_frame=b * frames)
+                    got.append(block.download(frames)); want.append(ob.render(frames))
+                got, want = np.concatenate(got, axis=1), np.concatenate(want, axis=1)
+                per_voice = np.sqrt(np.mean((got.astype(np.float64) - want) ** 2, axis=(0, 1)))
+                assert per_voice.max() <= 1e-5, (j, name, per_voice.max())
+                fbus = bus.download().astype(np.float64)
+                assert np.sqrt(np.mean(((fbus - want.sum(axis=2).T) / n) ** 2)) <= 1e-6, (j, name)
+                runs[name] = got
+                synth.destroy(); fused.destroy(); block.destroy(); bus.destroy()
+            a, b_ = runs["A"][:, :, ::2], runs["B"][:, :, ::2]
+            assert np.abs(a).max() > 1e-2
+            assert np.array_equal(a.view(np.uint32), b_.view(np.uint32)), f"patch {j}: the even voices differ between the table and the per-lane retune"
+    finally:
+        gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves, gpu_ctx.pipeline_min_waves = old
