@@ -131,3 +131,32 @@ def test_measured_bound_prefers_this_runs_figure(monkeypatch):
     assert c["valu"]["frac_of_measured_bound"] > 1.0 and any("above 1" in f for f in c["valu"]["frac_of_measured_bound_flags"])
     d = bench.roofline_block("welsh-1m", 1_000_000, slow, True, True, window=(172, 4))
     assert any("different window" in f for f in d["valu"].get("frac_of_measured_bound_flags", [])) or d["valu"]["measured_bound"]["same_window"]
+
+
+def test_round6_profiles_and_the_committed_line_describe_the_same_code():
+    """every profile summary carries the identity of the library it was taken with — the hash of the library's
+    sources as the library itself reports it (groove_debug_info) and the commit of the build — and the committed line's physical fields
+    (traffic, instruction counts) are marked stale when they come from other code.  The round's summaries were all taken at ONE hash, the
+    committed lines ran that very library, and their roofline says `stale_profile: false`."""
+    import glob
+    pdir = os.path.join(REPO, "profiles")
+    summaries = sorted(glob.glob(os.path.join(pdir, "r06_*_summary.json")))
+    names = {os.path.basename(f)[len("r06_"):-len("_summary.json")] for f in summaries}
+    assert {"welsh-1m", "welsh-1m-window", "welsh-1m-library-window", "welsh-1m-materialised-window", "welsh-256", "chain-4096", "sampler-16384",
+            "mixed-131072"} <= names
+    ids = {f: json.load(open(f)).get("library") for f in summaries}
+    assert all(i and i.get("source_hash") and i.get("git_head") for i in ids.values()), ids
+    hashes = {i["source_hash"] for i in ids.values()}
+    assert len(hashes) == 1, ids
+    for name in ("r06_bench_line_driver_command.json", "r06_bench_line_default.json"):
+        line = _strict(open(os.path.join(pdir, name)).read().strip().splitlines()[-1])
+        assert line["library"]["source_hash"] in hashes, (name, line["library"], hashes)
+        assert line["roofline"]["stale_profile"] is False and line["roofline"]["traffic_source"].startswith("r06_"), (name, line["roofline"])
+        assert line["zero_segments"] == 0 and not line.get("tainted")
+    # ... and a summary of other code is called stale: the same block against a different running hash
+    sys.path.insert(0, REPO)
+    import bench
+    r = bench.roofline_block("welsh-1m", 1_000_000, 0.36, True, True, window=(20, 5), source_hash="0000000000000000")
+    assert r["stale_profile"] is True and r["traffic_source_hash"] in hashes
+    r = bench.roofline_block("welsh-1m", 1_000_000, 0.36, True, True, window=(20, 5), source_hash=next(iter(hashes)))
+    assert r["stale_profile"] is False
