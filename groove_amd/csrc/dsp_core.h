@@ -809,7 +809,7 @@ GROOVE_HD int lfo_class_of(uint32_t waveform, uint32_t routing) {
 // and device share the rule (groove_hip.hip welsh_upload_params; tests/emul and tools/library_proportions.py read it through emul.cpp).
 struct WelshParams;
 GROOVE_HD int welsh_base_kind(const WelshParams& p);
-GROOVE_HD bool welsh_base_kind_specialised(int base_kind) { return base_kind < 4; } // the exact-f64 kinds keep OSC_ANY bodies
+GROOVE_HD bool welsh_base_kind_specialised(int base_kind) { (void)base_kind; return true; } // (round 6: the exact-f64 kinds too; they kept OSC_ANY bodies until then)
 GROOVE_HD void welsh_body_classes(const WelshParams& p, int base_kind, int& cl, int& c1, int& c2);
 template <int CLS>
 GROOVE_HD uint32_t osc_class_wave(uint32_t runtime_waveform) {
@@ -826,8 +826,9 @@ GROOVE_HD void welsh_body_classes(const WelshParams& p, int base_kind, int& cl, 
   c1 = spec ? osc_class_of((p.flags >> WF_O1_WAVE_SHIFT) & 15u) : (int)OSC_ANY;
   c2 = spec ? osc_class_of((p.flags >> WF_O2_WAVE_SHIFT) & 15u) : (int)OSC_ANY;
   cl = spec ? lfo_class_of((p.flags >> WF_LFO_WAVE_SHIFT) & 15u, (p.flags >> WF_ROUTING_SHIFT) & 15u) : (int)OSC_ANY;
-  // the smooth-f64 kernels carry the sine / triangle / any LFO copies only
-  if (base_kind >= 2 && cl != OSC_SINE && cl != OSC_TRIANGLE) cl = OSC_ANY;
+  // the smooth-f64 kernels carry the sine / triangle / any LFO copies only (a square or sawtooth LFO there runs the `any` copy, which has
+  // the exact re-seed on the frame of an LFO edge); the F32 and the exact-f64 kernels carry all six
+  if ((base_kind == 2 || base_kind == 3) && cl != OSC_SINE && cl != OSC_TRIANGLE) cl = OSC_ANY;
 }
 
 // One frame of one voice.  FIRST: this is frame 0 of a render call (the only frame on which
@@ -870,6 +871,8 @@ GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScrat
   static_assert(!HOIST || (SEGMENT && !FIRST), "hoisted counters belong to a segment");
   if (SEGMENT && HOIST) {
     // env_shape with the segment's constants (welsh_segment_start_hoisted): two operations per envelope and frame
+    // (Round 6 also tried the AMPLITUDE envelope's value in the table — three instructions a frame less, one more word per entry:
+    // 0.362 - 0.373 against 0.354 - 0.357 ms per block in one job, tools/ab_bench.sh.  Lost; the envelope stays in the lane.)
     s.amp.value = env_shape(sc.ta, s.amp.A, sc.ac1, sc.ac2);
     sc.ta += 1.0f;
     if (welsh_tab_off(tab)) {
@@ -1126,16 +1129,10 @@ GROOVE_HD void welsh_frame_coef(const WelshParams& p, const RenderConsts& rc, We
   if (RETUNE) {
     constexpr bool RESO = LFO_MODE == LFO_F64 && RETUNE;
     const bool r_res = RESO && CL != LFO_UNUSED ? (p.flags & WF_LFO_RESO) != 0 : false;
-    const bool r_wide = RESO ? (p.flags & WF_COEF_WIDE) != 0 : false;
     if (RESO && r_res) { // the ripple moves every frame: constants and coefficients are recomputed
       const Lp24Consts c = lp24_consts_from_ripple(p.ripple * fmaf(lfo, p.lfo_depth, 1.0f));
       const float fc = retune ? 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f) : p.cutoff_hz;
       sc.coef = lp24_coefd_from_fc(c, fc, rc.pi_over_sr, rc.fc_max);
-    } else if (RESO && r_wide) { // WF_COEF_WIDE: the two-sided form, from the patch's own constants
-      if (retune && pct != sc.prev_pct) {
-        sc.coef = lp24_coefd_from_fc(p.fc, 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f), rc.pi_over_sr, rc.fc_max);
-        sc.prev_pct = pct;
-      }
     } else if (retune && pct != sc.prev_pct) { // unchanged percent (e.g. envelope plateau): coefficients stand
       sc.coef = lp24_coefd_from_pct(p.fc, pct, rc, (p.flags & WF_COEF_WIDE) != 0); // (a scalar branch in the uniform kernels)
       sc.prev_pct = pct;

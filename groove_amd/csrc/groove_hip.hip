@@ -575,7 +575,7 @@ int welsh_upload_params(groove_bank* b, bool regroup) {
   b->tp_pairs = true; // time-parallel form, two voices per wavefront: voices 2i and 2i + 1 share their parameter words
   for (uint32_t i = 0; i + 1 < n && b->tp_pairs; i += 2) b->tp_pairs = std::memcmp(&P[i], &P[i + 1], sizeof(WelshParams)) == 0;
   b->tp_full_coef = false; // time-parallel form: a voice with the resonance routing keeps six f64 coefficients per frame (welsh_tp.h)
-  for (uint32_t i = 0; i < n; ++i) if (P[i].flags & (WF_LFO_RESO | WF_COEF_WIDE)) { b->tp_full_coef = true; break; }
+  for (uint32_t i = 0; i < n; ++i) if (P[i].flags & WF_LFO_RESO) { b->tp_full_coef = true; break; } // (WF_COEF_WIDE patches: from the tangent like the rest, round 6)
   // Virtual waves: maximal runs of consecutive voices with identical parameter words, cut at 64.
   std::vector<WaveDesc> W;
   W.reserve((size_t)n / 64 + 64);
@@ -1189,14 +1189,18 @@ static bool create_streams(groove_ctx* ctx) {
     else ok = make(&ctx->side_stream[i], prio_least);
     ok = ok && hipEventCreateWithFlags(&ctx->ev_join[i], kSyncEventFlags) == hipSuccess;
   }
-  // The two exact-f64-LFO kinds run on the FIRST BANK STREAM (round 6; they shared the first two kind streams before): their few
-  // workgroups take one wavefront's walk of the block whatever their number (~210 us for 2 % of a million voices), and behind
-  // another kind's kernel on its stream that walk was added to the stream's time per block — the step's long pole with the
-  // library-proportioned table (profiles/r06_*).  On a stream of their own they run beside the others.
-  if (ok && !ctx->safe_streams && ctx->bank_streams > 0 && ctx->side_stream[kBaseKinds]) ctx->side_stream[4] = ctx->side_stream[5] = ctx->side_stream[kBaseKinds];
-  // GROOVE_EXACT_STREAM=placeholder (A/B): the normal-priority stream nobody uses instead — the low-priority queue's workgroups are
-  // dispatched after everything of normal priority that is pending, and a big bank's mix launches always have workgroups pending
-  if (const char* e = std::getenv("GROOVE_EXACT_STREAM")) if (ok && e[0] == 'p' && ctx->placeholder_stream) ctx->side_stream[4] = ctx->side_stream[5] = ctx->placeholder_stream;
+  // The two exact-f64-LFO kinds run on a stream of their own (round 6; they shared the first two kind streams before): behind another
+  // kind's kernel on its stream their kernel's time per block was added to that stream's — the step's long pole with the
+  // library-proportioned table (profiles/r06_*).  Which stream: the normal-priority PLACEHOLDER (created so that no working stream shares
+  // the ctx stream's hardware queue; the exact kinds' kernel and the ctx stream's two short reductions per block get along on it) —
+  // 0.382 / 0.382 ms per block against 0.392 / 0.389 on the first (low-priority) bank stream, in one job, tools/ab_exact_stream.sh, once the
+  // kind's register budget let its workgroups be placed at all (kernels.h GROOVE_WAVES_F64).  GROOVE_EXACT_STREAM=bank: the bank stream.
+  if (ok && !ctx->safe_streams) {
+    const char* e = std::getenv("GROOVE_EXACT_STREAM");
+    const bool bank = e && e[0] == 'b';
+    if (!bank && ctx->placeholder_stream) ctx->side_stream[4] = ctx->side_stream[5] = ctx->placeholder_stream;
+    else if (ctx->bank_streams > 0 && ctx->side_stream[kBaseKinds]) ctx->side_stream[4] = ctx->side_stream[5] = ctx->side_stream[kBaseKinds];
+  }
   return ok;
 }
 static bool side_stream_owned(const groove_ctx* ctx, int i) {
@@ -1714,30 +1718,15 @@ static void launch_small_uniform(groove_bank* b, const UniformArgs& a, hipStream
 }
 // One base kind's uniform Welsh kernel (kernels.h, "Workgroup KINDS") on stream `st`.
 static void launch_welsh_kind(int k, const UniformArgs& a, hipStream_t st, bool fused, hipEvent_t done) {
-  const dim3 kgrid(a.n_wgs), blk(kThreads);
-  if (wg_base_kind_specialised(k)) {
-    switch (k) {
-      case 0: launch_welsh_uniform_specialised_0(a, st, fused, done); break;
-      case 1: launch_welsh_uniform_specialised_1(a, st, fused, done); break;
-      case 2: launch_welsh_uniform_specialised_2(a, st, fused, done); break;
-      default: launch_welsh_uniform_specialised_3(a, st, fused, done); break;
-    }
-    return;
-  }
-#define GROOVE_LAUNCH_UNIFORM(MODE, RETUNE)                                                                              \
-  do {                                                                                                                   \
-    if (fused) launch_bound(welsh_render_uniform_kernel<true, MODE, RETUNE, false>, kgrid, blk, st, done, a);             \
-    else launch_bound(welsh_render_uniform_kernel<false, MODE, RETUNE, false>, kgrid, blk, st, done, a);                  \
-  } while (0)
+  // every base kind has class-specialised bodies (round 6: the two exact-f64 kinds too), one translation unit each (csrc/welsh_class.hip)
   switch (k) {
-    case wg_base_kind_of(LFO_F32, false): GROOVE_LAUNCH_UNIFORM(LFO_F32, false); break;
-    case wg_base_kind_of(LFO_F32, true): GROOVE_LAUNCH_UNIFORM(LFO_F32, true); break;
-    case wg_base_kind_of(LFO_F64_SMOOTH, false): GROOVE_LAUNCH_UNIFORM(LFO_F64_SMOOTH, false); break;
-    case wg_base_kind_of(LFO_F64_SMOOTH, true): GROOVE_LAUNCH_UNIFORM(LFO_F64_SMOOTH, true); break;
-    case wg_base_kind_of(LFO_F64, false): GROOVE_LAUNCH_UNIFORM(LFO_F64, false); break;
-    default: GROOVE_LAUNCH_UNIFORM(LFO_F64, true); break;
+    case 0: launch_welsh_uniform_specialised_0(a, st, fused, done); break;
+    case 1: launch_welsh_uniform_specialised_1(a, st, fused, done); break;
+    case 2: launch_welsh_uniform_specialised_2(a, st, fused, done); break;
+    case 3: launch_welsh_uniform_specialised_3(a, st, fused, done); break;
+    case 4: launch_welsh_uniform_specialised_4(a, st, fused, done); break;
+    default: launch_welsh_uniform_specialised_5(a, st, fused, done); break;
   }
-#undef GROOVE_LAUNCH_UNIFORM
 }
 // fused: `rows` = partial rows only.  Otherwise `out` = the planar block and `rows` = its row sums (kernels.h run_frames).
 static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs, float* out, float* rows) {

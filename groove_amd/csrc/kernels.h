@@ -65,13 +65,20 @@ __device__ __forceinline__ void soa_store(uint32_t* __restrict__ buf, uint32_t n
 #define GROOVE_WAVES_SMOOTH_RETUNE 5
 #endif
 #ifndef GROOVE_WAVES_F64
-#define GROOVE_WAVES_F64 2
+#define GROOVE_WAVES_F64 4 /* round 6: 4 (128 VGPRs) instead of 2, with class-specialised bodies for these kinds too.  Not for their own occupancy — they
+                              are a few workgroups — but so that they can be PLACED: beside the mix kernel's five waves per SIMD (5 x 96 of 512 registers) a wave
+                              of 133+ registers only found room where a CU was draining at the end of a mix launch, and the kind's kernel took ~405 us per
+                              block beside launches of ~345 (227 us alone): the library-proportioned bank's long pole with 1.9 % of its voices.  At 128 a
+                              workgroup fits as soon as ONE mix workgroup has left its CU. */
 #endif
 #ifndef GROOVE_WAVES_ANY
 #define GROOVE_WAVES_ANY 4 /* the all-kinds kernel of banks that do not fill the chip.  Round 3: 4 (128 VGPRs) instead of 3 — in-job, blocks 5-24:
                               250,000 voices 0.212 -> 0.197 ms per block, 500,000 0.350 -> 0.331, 125,000 unchanged (5 is worse below 500,000:
                               0.172 at 125,000); the two exact-f64 base kinds, whose bodies need 133 VGPRs, no longer run in this kernel (the
                               host gives their workgroups to the per-kind kernels) */
+#endif
+#ifndef GROOVE_WHOLE_WAVE_PATH
+#define GROOVE_WHOLE_WAVE_PATH 0 /* run_frames_segmented: a second copy of the frame for waves whose 64 lanes all sound (A/B builds) */
 #endif
 #ifndef GROOVE_COEF_LOOKAHEAD
 #define GROOVE_COEF_LOOKAHEAD 1 /* the retuned kinds' coefficient look-ahead (below, "coefficient look-ahead"); 0: every lane retunes for itself (round 5's code, for A/B builds) */
@@ -292,12 +299,30 @@ __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n
     if (wmin == 0) on_zero(f, mine);
     const uint32_t seg = max(1u, min(wmin, frames - f));
     setup(live, seg);
+#if GROOVE_WHOLE_WAVE_PATH
+    // A wave all of whose 64 lanes sound (nearly every wave of a big bank) needs neither the exec-mask region around the frame nor
+    // the two moves of zero in front of it: a copy of the frame for that case, chosen by a scalar test per segment.
+    const bool whole = __builtin_amdgcn_readfirstlane((int)(__ballot(live) == ~0ull)) != 0;
+    for (uint32_t k = 0; k < seg; ++k, ++f) {
+      pre(k);
+      if (whole) {
+        float L, R;
+        live_frame(k, L, R);
+        put(f, L, R);
+      } else {
+        float L = 0.0f, R = 0.0f;
+        if (live) live_frame(k, L, R);
+        put(f, L, R);
+      }
+    }
+#else
     for (uint32_t k = 0; k < seg; ++k, ++f) {
       pre(k);
       float L = 0.0f, R = 0.0f;
       if (live) live_frame(k, L, R);
       put(f, L, R);
     }
+#endif
     end(seg, live);
   }
   if (frames & (C - 1)) acc.flush(rows, frames, frames & ~(C - 1), frames & (C - 1));
@@ -339,8 +364,12 @@ __device__ __forceinline__ void welsh_diag_zero(const DiagWhere& dw, const Welsh
 // Waves whose voices started apart, LFO-swept cutoffs and segments shorter than eight frames keep the per-lane path.
 struct CoefTab {
   static constexpr uint32_t kFrames = 64, kMinSegment = 8;
-  static __device__ __forceinline__ double* wave_base() { // 6 x f64 (or 6 x f32 in the fp32-filter bodies) per frame; 3 KiB per wave
-    __shared__ double t[kWaves][kFrames][6];
+  // One entry per frame: the six coefficients — f64 (48 bytes), or f32 padded to 32 bytes in the fp32-filter bodies (a power of two: the
+  // entry's address is then a scalar AND and one vector add instead of a 64-bit multiply-add per frame).  3 KiB per wave.
+  struct EntryF { Lp24CoefF c; float pad[2]; };
+  struct EntryD { Lp24CoefD c; };
+  static __device__ __forceinline__ double* wave_base() {
+    __shared__ double t[kWaves][kFrames][sizeof(EntryD) / 8];
     return &t[threadIdx.x >> 6][0][0];
   }
   // Frame i's entry, read through an LDS (address space 3) pointer built from a 32-bit byte address.  Word by word: a struct cannot be
@@ -367,19 +396,18 @@ struct CoefTab {
   }
 };
 // Do the live lanes of this wave share the filter envelope's stage?  Then its description, from the first of them, in SGPRs.
-struct FilEnvUniform { bool ok; float A, c1, c2, tf; uint32_t tab; }; // tab: `ok` as a 0 / 1 the compiler KNOWS to be in an SGPR (readfirstlane)
+// tab: `ok` as a 0 / 1 the compiler KNOWS to be in an SGPR (readfirstlane).
+struct FilEnvUniform { bool ok; float A, c1, c2, tf; uint32_t tab; };
+__device__ __forceinline__ float lane_value(float x, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane)); }
+__device__ __forceinline__ bool same_bits(float a, float b) { return __builtin_bit_cast(uint32_t, a) == __builtin_bit_cast(uint32_t, b); }
 __device__ __forceinline__ FilEnvUniform fil_env_uniform(const WelshState& s, const WelshScratch& sc, bool live) {
   FilEnvUniform u{false, 0.0f, 0.0f, 0.0f, 0.0f, 0u};
   const uint64_t mask = __ballot(live);
   if (mask == 0) return u;
   const int l0 = __builtin_ctzll(mask); // wave-uniform
-  u.A = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s.fil.A), l0));
-  u.c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc.fc1), l0));
-  u.c2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc.fc2), l0));
-  u.tf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc.tf), l0));
+  u.A = lane_value(s.fil.A, l0); u.c1 = lane_value(sc.fc1, l0); u.c2 = lane_value(sc.fc2, l0); u.tf = lane_value(sc.tf, l0);
   // bit patterns, so that a NaN (never produced; a torn shadow record could hold anything, but shadows are not live) cannot fake agreement
-  const bool same = __builtin_bit_cast(uint32_t, s.fil.A) == __builtin_bit_cast(uint32_t, u.A) && __builtin_bit_cast(uint32_t, sc.fc1) == __builtin_bit_cast(uint32_t, u.c1) &&
-                    __builtin_bit_cast(uint32_t, sc.fc2) == __builtin_bit_cast(uint32_t, u.c2) && __builtin_bit_cast(uint32_t, sc.tf) == __builtin_bit_cast(uint32_t, u.tf);
+  const bool same = same_bits(s.fil.A, u.A) && same_bits(sc.fc1, u.c1) && same_bits(sc.fc2, u.c2) && same_bits(sc.tf, u.tf);
   u.ok = __ballot(live && !same) == 0;
   u.tab = (uint32_t)__builtin_amdgcn_readfirstlane(u.ok ? 1 : 0);
   return u;
@@ -393,8 +421,8 @@ __device__ __forceinline__ void coef_tab_fill(const WelshParams& p, const Render
   const float pct = welsh_env_cutoff_pct(p, env_shape(n, u.A, u.c1, u.c2));
   bool hi;
   const float t = lp24_t_from_pct(pct, rc, hi);
-  if constexpr (F32) CoefTab::store_of_lane<Lp24CoefF>(j, lp24_coeff_from_t(p.fc, t, hi));
-  else CoefTab::store_of_lane<Lp24CoefD>(j, lp24_coefd_from_t(p.fc, t, hi, (p.flags & WF_COEF_WIDE) != 0));
+  if constexpr (F32) CoefTab::store_of_lane<CoefTab::EntryF>(j, CoefTab::EntryF{lp24_coeff_from_t(p.fc, t, hi), {0.0f, 0.0f}});
+  else CoefTab::store_of_lane<CoefTab::EntryD>(j, CoefTab::EntryD{lp24_coefd_from_t(p.fc, t, hi, (p.flags & WF_COEF_WIDE) != 0)});
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the wave's own reads below come after these writes
   __builtin_amdgcn_wave_barrier();
 }
@@ -428,7 +456,7 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
           uint32_t tab = 0u;
           if constexpr (RETUNE && GROOVE_COEF_LOOKAHEAD) {
             tab = fu.tab;
-            if (tab != 0u) sc.coef_f = CoefTab::load<Lp24CoefF>(k & (CoefTab::kFrames - 1));
+            if (tab != 0u) sc.coef_f = CoefTab::load<CoefTab::EntryF>(k & (CoefTab::kFrames - 1)).c;
           }
           welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true, true>(p, s, rc, sc, L, R, tab);
         },
@@ -457,7 +485,7 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
           uint32_t tab = 0u;
           if constexpr (LOOKAHEAD) {
             tab = fu.tab;
-            if (tab != 0u) sc.coef = CoefTab::load<Lp24CoefD>(k & (CoefTab::kFrames - 1));
+            if (tab != 0u) sc.coef = CoefTab::load<CoefTab::EntryD>(k & (CoefTab::kFrames - 1)).c;
           }
           welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true>(p, s, rc, sc, L, R, tab);
         },
@@ -504,9 +532,9 @@ __global__ __launch_bounds__(kThreads) void welsh_render_kernel(
 //     VGPRs (7 waves / SIMD), the most expensive needs 133 (3 waves); inside one kernel everybody
 //     paid for the maximum.
 //   - the CLASSES of the LFO and the two audio oscillators (dsp_core.h, "Oscillator CLASSES"): inside
-//     the kernels of the first four base kinds (fused and materialised form), one scalar switch per
-//     workgroup calls the copy of the whole block body compiled for its class triple (6 x 5 x 5
-//     copies; 3 x 5 x 5 for the smooth-LFO kinds).  The copies are NOT inlined:
+//     every base kind's kernel (fused and materialised form; the two exact-f64 kinds since round 6), one
+//     scalar switch per workgroup calls the copy of the whole block body compiled for its class triple
+//     (6 x 5 x 5 copies; 3 x 5 x 5 for the smooth-LFO kinds).  The copies are NOT inlined:
 //     each is a function with its own register allocation (inlined, their hoisted loop invariants
 //     all became live across the switch and every copy spilled in its hot loop), and all copies of
 //     a base kind need about the same registers, so the kernel's budget fits them all.  (One kernel
@@ -528,7 +556,7 @@ __host__ __device__ constexpr int wg_base_kind_of(int lfo_mode, bool retune) {
 }
 __host__ __device__ constexpr int wg_class_combo(int cl, int c1, int c2) { return (cl * OSC_CLASSES + c1) * OSC_CLASSES + c2; }
 __host__ __device__ constexpr int wg_kind_of(int base_kind, int cl, int c1, int c2) { return base_kind * kClassCombos + wg_class_combo(cl, c1, c2); }
-__host__ __device__ constexpr bool wg_base_kind_specialised(int base_kind) { return base_kind < 4; } // exact-f64 kinds keep OSC_ANY (== dsp_core.h welsh_base_kind_specialised)
+__host__ __device__ constexpr bool wg_base_kind_specialised(int base_kind) { (void)base_kind; return true; } // (== dsp_core.h welsh_base_kind_specialised; round 6: all six)
 template <int LFO_MODE, bool RETUNE> struct WavesBudget;
 template <> struct WavesBudget<LFO_F32, false> { static constexpr int value = GROOVE_WAVES_F32_STATIC; };
 template <> struct WavesBudget<LFO_F32, true> { static constexpr int value = GROOVE_WAVES_F32_RETUNE; };
@@ -581,8 +609,8 @@ __device__ __forceinline__ void welsh_uniform_body_impl(UniformArgsPtr a) {
 #define GROOVE_BODY_LINKAGE static
 template <bool FUSED, int LFO_MODE, bool RETUNE, int C1, int C2, int CL, bool F32OK = false>
 GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_uniform_body(UniformArgsPtr a) {
-  // the class bodies of the class-specialised kinds only ever see waves of their own classes (dsp_core.h, REST)
-  welsh_uniform_body_impl<FUSED, LFO_MODE, RETUNE, C1, C2, CL, LFO_MODE != LFO_F64, F32OK>(uniform_args_scalar(a));
+  // the class bodies only ever see waves of their own classes (dsp_core.h, REST)
+  welsh_uniform_body_impl<FUSED, LFO_MODE, RETUNE, C1, C2, CL, true, F32OK>(uniform_args_scalar(a));
 }
 // A workgroup whose voices are all silent with both envelopes idle (unused polyphony, voices past
 // their release) contributes zeros and changes nothing but idle-plateau counters: it writes its zero
@@ -620,7 +648,7 @@ __device__ __forceinline__ void welsh_dispatch_class(uint32_t cls, UniformArgsPt
   switch (cls) {
     GROOVE_CLS_PLANE(OSC_ANY) GROOVE_CLS_PLANE(OSC_TRIANGLE) GROOVE_CLS_PLANE(OSC_SINE)
     default:
-      if constexpr (LFO_MODE == LFO_F32) { // a smooth f64 LFO is a sine or a triangle (or OSC_ANY: triangle-sine)
+      if constexpr (LFO_MODE != LFO_F64_SMOOTH) { // (the smooth kinds carry the sine, triangle and `any` LFO copies only: welsh_body_classes)
         switch (cls) {
           GROOVE_CLS_PLANE(OSC_PULSE) GROOVE_CLS_PLANE(OSC_SAW) GROOVE_CLS_PLANE(LFO_UNUSED)
           default: break;
@@ -739,6 +767,8 @@ void launch_welsh_uniform_specialised_0(const UniformArgs& a, hipStream_t st, bo
 void launch_welsh_uniform_specialised_1(const UniformArgs& a, hipStream_t st, bool fused, hipEvent_t done = nullptr);
 void launch_welsh_uniform_specialised_2(const UniformArgs& a, hipStream_t st, bool fused, hipEvent_t done = nullptr);
 void launch_welsh_uniform_specialised_3(const UniformArgs& a, hipStream_t st, bool fused, hipEvent_t done = nullptr);
+void launch_welsh_uniform_specialised_4(const UniformArgs& a, hipStream_t st, bool fused, hipEvent_t done = nullptr); // exact-f64 LFO, static filter (round 6)
+void launch_welsh_uniform_specialised_5(const UniformArgs& a, hipStream_t st, bool fused, hipEvent_t done = nullptr); // exact-f64 LFO, retuned filter / resonance routing
 void launch_welsh_uniform_any(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, hipEvent_t done = nullptr); // fused: csrc/welsh_class.hip, -DGROOVE_BASE_KIND=9
 void launch_welsh_uniform_any_unfused(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, hipEvent_t done = nullptr); // writes the voice block: -DGROOVE_BASE_KIND=8
 void launch_welsh_uniform_mix(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, hipEvent_t done = nullptr); // the mix kernel, fused: -DGROOVE_BASE_KIND=10

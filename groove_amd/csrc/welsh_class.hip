@@ -1,5 +1,5 @@
 // welsh_class.hip — the fused, class-specialised uniform Welsh kernel of ONE base kind (compiled
-// with -DGROOVE_BASE_KIND=0..3, so the block bodies build in parallel), or (-DGROOVE_BASE_KIND=9)
+// with -DGROOVE_BASE_KIND=0..5, so the block bodies build in parallel), or (-DGROOVE_BASE_KIND=9)
 // the all-kinds kernel of small banks (=8: its block-writing form), or (=10 / 11) the mix kernel of big banks.  See
 // kernels.h, "Workgroup KINDS".
 #define GROOVE_WELSH_CLASS_TU 1
@@ -11,7 +11,7 @@
 #endif
 #include "kernels.h"
 #ifndef GROOVE_BASE_KIND
-#error "compile with -DGROOVE_BASE_KIND=<0..3, 8, 9, 10, 11>"
+#error "compile with -DGROOVE_BASE_KIND=<0..5, 8, 9, 10, 11>"
 #endif
 namespace groove {
 #if GROOVE_BASE_KIND == 0
@@ -33,6 +33,16 @@ void launch_welsh_uniform_specialised_2(const UniformArgs& a, hipStream_t st, bo
 void launch_welsh_uniform_specialised_3(const UniformArgs& a, hipStream_t st, bool fused, hipEvent_t done) {
   if (fused) launch_bound(welsh_render_uniform_kernel<true, LFO_F64_SMOOTH, true, true>, dim3(a.n_wgs), dim3(kThreads), st, done, a);
   else launch_bound(welsh_render_uniform_kernel<false, LFO_F64_SMOOTH, true, true>, dim3(a.n_wgs), dim3(kThreads), st, done, a);
+}
+#elif GROOVE_BASE_KIND == 4
+void launch_welsh_uniform_specialised_4(const UniformArgs& a, hipStream_t st, bool fused, hipEvent_t done) {
+  if (fused) launch_bound(welsh_render_uniform_kernel<true, LFO_F64, false, true>, dim3(a.n_wgs), dim3(kThreads), st, done, a);
+  else launch_bound(welsh_render_uniform_kernel<false, LFO_F64, false, true>, dim3(a.n_wgs), dim3(kThreads), st, done, a);
+}
+#elif GROOVE_BASE_KIND == 5
+void launch_welsh_uniform_specialised_5(const UniformArgs& a, hipStream_t st, bool fused, hipEvent_t done) {
+  if (fused) launch_bound(welsh_render_uniform_kernel<true, LFO_F64, true, true>, dim3(a.n_wgs), dim3(kThreads), st, done, a);
+  else launch_bound(welsh_render_uniform_kernel<false, LFO_F64, true, true>, dim3(a.n_wgs), dim3(kThreads), st, done, a);
 }
 #elif GROOVE_BASE_KIND == 9
 void launch_welsh_uniform_any(const UniformArgs& a, const uint8_t* wg_base, hipStream_t st, hipEvent_t done) {

@@ -184,14 +184,11 @@ GROOVE_HD void welsh_tp_frame(const WelshParams& p, WelshState& s, const RenderC
       const Lp24Consts c = lp24_consts_from_ripple(p.ripple * fmaf(lfo, p.lfo_depth, 1.0f));
       const float fc = retune ? 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f) : p.cutoff_hz;
       coef = lp24_coefd_from_fc(c, fc, rc.pi_over_sr, rc.fc_max);
-    } else if (RESO && (fl & WF_COEF_WIDE)) { // welsh_frame_coef's third case: the two-sided form from the patch's own constants
-      if (retune && pct != prev_pct) {
-        coef = lp24_coefd_from_fc(p.fc, 25.0f * fast_exp2(clamp01f(pct) * 9.6438561897747244f), rc.pi_over_sr, rc.fc_max);
-        prev_pct = pct;
-      }
     } else if (retune && pct != prev_pct) {
       t_out = lp24_t_from_pct(pct, rc, hi_out); // (lp24_coefd_from_pct in its two halves)
-      coef = lp24_coefd_from_t(p.fc, t_out, hi_out);
+      // (WF_COEF_WIDE: the two-sided form of the serial kernels' retune, round 6 — lp24_coefd_from_fc's before, which a drawn patch with a
+      // pulse LFO on the cutoff at ripple 4.0 and 22,050 Hz played 1.3e-5 of its level off the oracle where the serial forms stood at 1.1e-6)
+      coef = lp24_coefd_from_t(p.fc, t_out, hi_out, (fl & WF_COEF_WIDE) != 0);
       prev_pct = pct;
     }
   }
@@ -243,7 +240,7 @@ GROOVE_HD void welsh_tp_chunk(const WelshParams& p, WelshState& s, const RenderC
 template <bool RETUNE, bool FULL_COEF, int CH>
 GROOVE_HD Lp24CoefD welsh_tp_coef_at(const WelshParams& p, const TpChunkOut<CH>& o, const Lp24CoefD& cur0, const Lp24CoefD (&coef_full)[FULL_COEF ? CH : 1], uint32_t j) {
   if (FULL_COEF) return coef_full[FULL_COEF ? j : 0];
-  if (RETUNE && (p.flags & (WF_RETUNE_ENV | WF_LFO_CUTOFF))) return lp24_coefd_from_t(p.fc, o.t[j], ((o.hi >> j) & 1u) != 0);
+  if (RETUNE && (p.flags & (WF_RETUNE_ENV | WF_LFO_CUTOFF))) return lp24_coefd_from_t(p.fc, o.t[j], ((o.hi >> j) & 1u) != 0, (p.flags & WF_COEF_WIDE) != 0);
   return cur0;
 }
 GROOVE_HD bool welsh_tp_scans(const WelshParams& p) { return (p.flags & (WF_LFO_PITCH | WF_SYNC)) != 0; }
