@@ -326,6 +326,9 @@ struct RenderConsts {
   // two addends of the retune's tangent polynomial: carried here so that a kernel can pin them in registers for the
   // whole block (as literals the compiler re-materialises them with a v_mov on every frame)
   float tan_k1 = 1.333961619e-01f, tan_k2 = 2.453938616e-02f;
+  // which look-aheads the uniform kernels may use (kernels.h): bit 0 the filter coefficients', bit 1 the LFO's.  (A run-time word
+  // so that the tests can render the same bank with and without: groove_set_look_ahead.)
+  uint32_t look = 3u;
 };
 GROOVE_HD RenderConsts render_consts(double sr) {
   RenderConsts rc;
@@ -750,6 +753,8 @@ GROOVE_HD bool welsh_tab_off(uint32_t tab) {
 GROOVE_HD float welsh_env_cutoff_pct(const WelshParams& p, float fil_value) {
   return fmaf((1.0f - p.cutoff_start) * p.cutoff_end, fil_value, p.cutoff_start);
 }
+// ... and the one an LFO-swept filter takes from the LFO's value.
+GROOVE_HD float welsh_lfo_cutoff_pct(const WelshParams& p, float lfo) { return p.cutoff_start * fmaf(lfo, p.lfo_depth, 1.0f); }
 // Filter constants from the passband ripple r on the device (fp32): the resonance routing moves r every
 // frame.  sinh / cosh from one exp; r stays below ~22 (denormalize_q(1) (1 + depth)), far from overflow.
 GROOVE_HD Lp24Consts lp24_consts_from_ripple(float r) {
@@ -867,7 +872,8 @@ GROOVE_HD float osc_value_classed(uint32_t w, uint64_t phase, uint64_t duty64, f
 // percent from it.  (An integer, not a bool: as a bool the flag lived in a lane mask and its negation went through two vector instructions.)
 template <bool FIRST, bool RETUNE, int LFO_MODE = LFO_F64, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool SEGMENT = false, bool REST = false,
           bool HOIST = false>
-GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScratch& sc, float& sum, float& a, float& pct, bool& retune, float& lfo, uint32_t tab = 0u) {
+GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScratch& sc, float& sum, float& a, float& pct, bool& retune, float& lfo, uint32_t tab = 0u,
+                                 uint32_t ltab = 0u, double tab_mod = 0.0, float tab_lfo = 0.0f) {
   static_assert(!HOIST || (SEGMENT && !FIRST), "hoisted counters belong to a segment");
   if (SEGMENT && HOIST) {
     // env_shape with the segment's constants (welsh_segment_start_hoisted): two operations per envelope and frame
@@ -911,48 +917,72 @@ GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScrat
   const bool first = FIRST && (s.vflags & VF_FIRST);
   if (FIRST) s.vflags = 0;
 
-  // LFO
-  if (!first && !(HOIST && NO_LFO)) s.lfo.phase += p.lfo_inc;
+  // LFO.  `mod` = what it does to the oscillators' edges (r_edge): the factor on their increments (pitch routing) or LFO value x depth
+  // (pulse-width routing).  `ltab` (a wave-uniform 0 / 1 in an SGPR, like `tab`; HOIST frames, not the exact-f64 kinds): the wave's
+  // live voices share the LFO's phase, and the caller hands this frame's LFO in from the wave's look-ahead table (kernels.h "LFO
+  // look-ahead": evaluated from the phase, lane = frame) — `mod` in the smooth-f64 kinds (evaluated exactly; the caller re-seeds the
+  // recurrences after the segment), the fp32 value `lfo` in the F32 kinds (the same expression on the same phase: the same bits) — and
+  // moves the phase once per segment.
+  constexpr bool LTAB = HOIST && LFO_MODE != LFO_F64 && CL != LFO_UNUSED;
   float nzl = 0.0f;
-  if (wl == GROOVE_WAVE_NOISE) nzl = noise_tick(s.lfo);
   const uint64_t half = 0x8000000000000000ull;
   uint64_t inc1 = s.o1_inc, inc2 = s.o2_inc;
   uint64_t d1 = p.o1_duty64, d2 = p.o2_duty64;
   lfo = 0.0f;
-  if (r_edge) {
-    constexpr bool SMOOTH = LFO_MODE == LFO_F64_SMOOTH;
-    double l;
-    if (SMOOTH && !FIRST && wl == GROOVE_WAVE_SINE) { // one rotation step (an idle voice never gets here: see above)
-      l = sc.ls + fma(p.lfo_rs, sc.lc, -(p.lfo_rk * sc.ls));
-      sc.lc = sc.lc - fma(p.lfo_rs, sc.ls, p.lfo_rk * sc.lc);
-    } else {
-      l = osc_value_f64(wl, s.lfo.phase, half, nzl);
-      if (SMOOTH && FIRST && wl == GROOVE_WAVE_SINE) // cos(2 pi x) = sin(2 pi (x + 1/4))
-        sc.lc = sin_turns_folded_f64((double)fold_quarter64((int64_t)(s.lfo.phase + 0x4000000000000000ull)) * 5.42101086242752217004e-20);
-    }
-    if (fl & WF_LFO_PITCH) {
-      double m;
-      if (SMOOTH && !FIRST) {
-        // an LFO with EDGES (square, pulse, sawtooth: class OSC_ANY in the smooth kinds) is smooth between them; on the frame of an
-        // edge the factor is evaluated exactly, which re-seeds the recurrence (a square's factor is then constant, bit for bit:
-        // e^0 = 1).  Until round 6 such patches ran in the exact-f64 kind, a 15-term series on every frame.
-        const double dx = (l - sc.ls) * p.lfo_a;
-        if (CL == OSC_ANY && fabs(dx) > 1.5e-3) m = exp2_small_f64(l * (double)p.lfo_depth);
-        else m = sc.lm * exp_tiny_f64(dx);
+  double mod = 0.0;
+  if (!LTAB || welsh_tab_off(ltab)) {
+    if (!first && !(HOIST && NO_LFO)) s.lfo.phase += p.lfo_inc;
+    if (wl == GROOVE_WAVE_NOISE) nzl = noise_tick(s.lfo);
+    if (r_edge) {
+      constexpr bool SMOOTH = LFO_MODE == LFO_F64_SMOOTH;
+      double l;
+      if (SMOOTH && !FIRST && wl == GROOVE_WAVE_SINE) { // one rotation step (an idle voice never gets here: see above)
+        l = sc.ls + fma(p.lfo_rs, sc.lc, -(p.lfo_rk * sc.ls));
+        sc.lc = sc.lc - fma(p.lfo_rs, sc.ls, p.lfo_rk * sc.lc);
+      } else {
+        l = osc_value_f64(wl, s.lfo.phase, half, nzl);
+        if (SMOOTH && FIRST && wl == GROOVE_WAVE_SINE) // cos(2 pi x) = sin(2 pi (x + 1/4))
+          sc.lc = sin_turns_folded_f64((double)fold_quarter64((int64_t)(s.lfo.phase + 0x4000000000000000ull)) * 5.42101086242752217004e-20);
       }
-      else m = exp2_small_f64(l * (double)p.lfo_depth);
-      if (SMOOTH) sc.lm = m;
-      if (fl & WF_LFO_O1) inc1 = f64_to_u64((double)inc1 * m);
-      if (fl & WF_LFO_O2) inc2 = f64_to_u64((double)inc2 * m); // fm applies to a fixed-frequency osc too
-    } else {
-      const double ld = l * (double)p.lfo_depth;
-      if (fl & WF_LFO_O1) d1 = f64_to_u64(clamp01d((double)p.o1_duty * (1.0 + ld)) * 18446744073709549568.0);
-      if (fl & WF_LFO_O2) d2 = f64_to_u64(clamp01d((double)p.o2_duty * (1.0 + ld)) * 18446744073709549568.0);
+      if (fl & WF_LFO_PITCH) {
+        double m;
+        if (SMOOTH && !FIRST) {
+          // an LFO with EDGES (square, pulse, sawtooth: class OSC_ANY in the smooth kinds) is smooth between them; on the frame of an
+          // edge the factor is evaluated exactly, which re-seeds the recurrence (a square's factor is then constant, bit for bit:
+          // e^0 = 1).  Until round 6 such patches ran in the exact-f64 kind, a 15-term series on every frame.
+          const double dx = (l - sc.ls) * p.lfo_a;
+          if (CL == OSC_ANY && fabs(dx) > 1.5e-3) m = exp2_small_f64(l * (double)p.lfo_depth);
+          else m = sc.lm * exp_tiny_f64(dx);
+        }
+        else m = exp2_small_f64(l * (double)p.lfo_depth);
+        if (SMOOTH) sc.lm = m;
+        mod = m;
+      } else {
+        mod = l * (double)p.lfo_depth;
+      }
+      if (SMOOTH) sc.ls = l;
+      lfo = (float)l;
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (LTAB) asm volatile("" : "+v"(mod)); // keeps `ltab` a scalar BRANCH (as `tab` below)
+#endif
+    } else if (r_amp || r_cut || r_res) {
+      lfo = osc_value(wl, s.lfo.phase, half, nzl);
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (LTAB) asm volatile("" : "+v"(lfo));
+#endif
     }
-    if (SMOOTH) sc.ls = l;
-    lfo = (float)l;
-  } else if (r_amp || r_cut || r_res) {
-    lfo = osc_value(wl, s.lfo.phase, half, nzl);
+  } else {
+    mod = tab_mod;
+    lfo = tab_lfo;
+  }
+  if (r_edge) {
+    if (fl & WF_LFO_PITCH) {
+      if (fl & WF_LFO_O1) inc1 = f64_to_u64((double)inc1 * mod);
+      if (fl & WF_LFO_O2) inc2 = f64_to_u64((double)inc2 * mod); // fm applies to a fixed-frequency osc too
+    } else {
+      if (fl & WF_LFO_O1) d1 = f64_to_u64(clamp01d((double)p.o1_duty * (1.0 + mod)) * 18446744073709549568.0);
+      if (fl & WF_LFO_O2) d2 = f64_to_u64(clamp01d((double)p.o2_duty * (1.0 + mod)) * 18446744073709549568.0);
+    }
   }
 
   // oscillators (+ hard sync): carry out of the 64-bit add = osc 1 wrapped
@@ -989,7 +1019,7 @@ GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScrat
       pct = welsh_env_cutoff_pct(p, s.fil.value);
       retune = true;
     } else if (r_cut) {
-      pct = p.cutoff_start * fmaf(lfo, p.lfo_depth, 1.0f);
+      pct = welsh_lfo_cutoff_pct(p, lfo);
       retune = true;
     }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1153,12 +1183,12 @@ GROOVE_HD void welsh_frame_back(const WelshParams& p, Lp24StateD& filt, const Lp
 template <bool FIRST, bool RETUNE, int LFO_MODE = LFO_F64, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool SEGMENT = false, bool REST = false,
           bool HOIST = false, bool F32FILT = false>
 GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc,
-                           WelshScratch& sc, float& L, float& R, uint32_t tab = 0u) {
+                           WelshScratch& sc, float& L, float& R, uint32_t tab = 0u, uint32_t ltab = 0u, double tab_mod = 0.0, float tab_lfo = 0.0f) {
   static_assert(!(F32FILT && LFO_MODE == LFO_F64), "the exact-f64 kinds (resonance routing) keep the f64 filter");
   float sum, a, pct, lfo;
   bool retune;
   // (tab: the caller has put this frame's coefficients into sc.coef / sc.coef_f already — kernels.h "coefficient look-ahead")
-  if (!welsh_frame_front<FIRST, RETUNE, LFO_MODE, C1, C2, CL, SEGMENT, REST, HOIST>(p, s, sc, sum, a, pct, retune, lfo, tab)) { L = 0.0f; R = 0.0f; return; }
+  if (!welsh_frame_front<FIRST, RETUNE, LFO_MODE, C1, C2, CL, SEGMENT, REST, HOIST>(p, s, sc, sum, a, pct, retune, lfo, tab, ltab, tab_mod, tab_lfo)) { L = 0.0f; R = 0.0f; return; }
   if constexpr (F32FILT) { // sc.coef_f / sc.filt_f were set by welsh_scratch_f32_begin; the caller hands the state back with welsh_scratch_f32_end
     if (RETUNE && welsh_tab_off(tab)) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1217,6 +1247,30 @@ GROOVE_HD void welsh_segment_end_hoisted(const WelshParams& p, WelshState& s, ui
   s.amp.n += seg; s.fil.n += seg;
   if (!live) { s.amp.value = env_last_value_of(s.amp); s.fil.value = env_last_value_of(s.fil); }
   else if (LFO_TOO) s.lfo.phase += (uint64_t)seg * p.lfo_inc;
+}
+// LFO look-ahead (kernels.h) of the smooth-f64 kinds.  What the LFO does to the oscillators' edges on the frame whose LFO phase is
+// `phase`, evaluated exactly — the exact-f64 kind's expressions (welsh_frame_front, LFO_MODE == LFO_F64) ...
+template <int CL>
+GROOVE_HD double welsh_lfo_mod_exact(const WelshParams& p, uint64_t phase) {
+  const uint32_t wl = osc_class_wave<CL>((p.flags >> WF_LFO_WAVE_SHIFT) & 15u);
+  const double ld = osc_value_f64(wl, phase, 0x8000000000000000ull, 0.0f) * (double)p.lfo_depth; // (never a noise LFO: WF_LFO_SMOOTH)
+  return (p.flags & WF_LFO_PITCH) ? exp2_small_f64(ld) : ld;
+}
+// (the F32 kinds' LFO value on the frame whose phase is `phase`: welsh_frame_front's expression; never a noise LFO — the caller checks)
+template <int CL>
+GROOVE_HD float welsh_lfo_value_f32(const WelshParams& p, uint64_t phase) {
+  return osc_value(osc_class_wave<CL>((p.flags >> WF_LFO_WAVE_SHIFT) & 15u), phase, 0x8000000000000000ull, 0.0f);
+}
+// ... and, after a segment whose frames took `mod` from the table and whose phase moved once, the recurrences' state as a FIRST frame
+// seeds it: the frames of a later segment that has to run lane by lane continue from it.
+template <int CL>
+GROOVE_HD void welsh_lfo_reseed_smooth(const WelshParams& p, const WelshState& s, WelshScratch& sc) {
+  const uint32_t wl = osc_class_wave<CL>((p.flags >> WF_LFO_WAVE_SHIFT) & 15u);
+  const double l = osc_value_f64(wl, s.lfo.phase, 0x8000000000000000ull, 0.0f);
+  if (wl == GROOVE_WAVE_SINE)
+    sc.lc = sin_turns_folded_f64((double)fold_quarter64((int64_t)(s.lfo.phase + 0x4000000000000000ull)) * 5.42101086242752217004e-20);
+  if (p.flags & WF_LFO_PITCH) sc.lm = exp2_small_f64(l * (double)p.lfo_depth);
+  sc.ls = l;
 }
 GROOVE_HD WelshScratch welsh_scratch_init(const WelshParams& p, const RenderConsts& rc) {
   WelshScratch sc;

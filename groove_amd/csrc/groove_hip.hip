@@ -219,6 +219,7 @@ struct groove_ctx {
   // creates lands on hardware queue (k - 1) mod 4, so the fifth (and the ninth) shares the ctx stream's queue; the fifth
   // used to be the fourth kind stream and is now a placeholder nobody uses.
   int kind_streams = 3;
+  uint32_t look_ahead = 3u; // RenderConsts::look: bit 0 the coefficient look-ahead, bit 1 the LFO look-ahead (kernels.h); GROOVE_LOOK_AHEAD=<bits>, groove_set_look_ahead (tests render the same bank with and without)
   bool mix_kernel = true; // big Welsh banks: the four class-specialised kinds in three balanced launches (kernels.h, the MIX kernel); GROOVE_MIX_KERNEL=0: one launch per base kind (round 5's form, for A/B runs)
   int next_stream_slot = 0;             // round-robin side-stream assignment of single-kernel banks
   uint32_t fm_tp_max_voices = kFmTpMaxVoices;
@@ -299,6 +300,7 @@ int fail(groove_ctx* ctx, const std::string& msg) {
 // Synchronous copies go through the CTX stream, never the null stream: the null stream is one more normal-priority
 // stream for the runtime to map, and with the four kind streams it made five on four hardware queues — the fourth kind
 // stream shared its queue with it (rocprofv3 trace, round 2).
+RenderConsts render_consts_of(const groove_ctx* ctx) { RenderConsts rc = render_consts(ctx->sr); rc.look = ctx->look_ahead; return rc; }
 const char* side_stream_name(int k) {
   static const char* names[] = {"kind stream 0 (Welsh F32 static; also kinds 3 and 4)", "kind stream 1 (Welsh F32 retune; also kind 5)",
                                 "kind stream 2 (Welsh smooth-LFO static)", "kind stream 3 (Welsh smooth-LFO retune)",
@@ -1223,6 +1225,7 @@ static int init_impl(int device_ordinal, const uint8_t* comm_id, int rank, int w
   if (const char* e = std::getenv("GROOVE_FX_SEQ_ALLPASS")) ctx->seq_allpass = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_SAFE_STREAMS")) ctx->safe_streams = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_MIX_KERNEL")) ctx->mix_kernel = e[0] != '0';
+  if (const char* e = std::getenv("GROOVE_LOOK_AHEAD")) ctx->look_ahead = (uint32_t)std::strtoul(e, nullptr, 10) & 3u;
   if (const char* e = std::getenv("GROOVE_SYNC_TIMEOUT_MS")) ctx->sync_timeout_ms = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FM_TP_VPW4_MIN_VOICES")) ctx->fm_tp_vpw4_min_voices = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_BIND_EVENTS")) ctx->bind_events = std::atoi(e) != 0;
@@ -1365,6 +1368,12 @@ int groove_set_time_parallel_pair_min_voices(groove_ctx* ctx, uint32_t min_voice
   return 0;
 }
 uint32_t groove_time_parallel_pair_min_voices(groove_ctx* ctx) { return ctx ? ctx->tp_vpw2_min_voices : 0; }
+int groove_set_look_ahead(groove_ctx* ctx, uint32_t bits) {
+  if (!ctx) return fail(nullptr, "groove_set_look_ahead: ctx is NULL");
+  ctx->look_ahead = bits & 3u;
+  return 0;
+}
+uint32_t groove_look_ahead(groove_ctx* ctx) { return ctx ? ctx->look_ahead : 0; }
 int groove_set_pipeline_min_waves(groove_ctx* ctx, uint32_t waves) {
   if (!ctx) return fail(nullptr, "groove_set_pipeline_min_waves: ctx is NULL");
   if (ctx_join(ctx)) return 1; // banks change kernels (and side streams) at their next render
@@ -1656,7 +1665,7 @@ static void launch_tp(groove_bank* b, uint32_t frames, bool fused, size_t chs, f
                       hipEvent_t done = nullptr /* completes with the kernel (bound to the dispatch: kernels.h launch_bound) */, const TpPrev* prev = nullptr,
                       uint32_t sampler_vpw = 0 /* sampler only: voices per wavefront (0: the default rule) */) {
   groove_ctx* ctx = b->ctx;
-  TpArgs a{b->d_params, b->d_state, out, rows, chs, render_consts(ctx->sr), b->n, frames};
+  TpArgs a{b->d_params, b->d_state, out, rows, chs, render_consts_of(ctx), b->n, frames};
   if (prev) a.prev = *prev;
   if (head) { a.bq_coef = head->d_coef; a.bq_st = head->d_st; a.bq_wet = head->d_wet; } // Welsh, block-writing form: the BiQuad head fused (welsh_tp.h)
   if (b->kind == BANK_FM) { a.vpw = tp_vpw(b); launch_fm_tp(a, st, fused, done); }
@@ -1670,7 +1679,7 @@ static uint32_t fused_rows(const groove_bank* b, uint32_t frames) {
 }
 // The one argument block of the wave-uniform Welsh kernels: workgroups [wg_off, wg_off + n_wgs) of the bank's kind-sorted list.
 static UniformArgs uniform_args(const groove_bank* b, float* out, float* rows, uint32_t wg_off, size_t chs, uint32_t frames, uint32_t n_wgs) {
-  UniformArgs a{b->d_waves, b->d_state, out, rows, b->d_wg_list + wg_off, b->d_wg_cls + wg_off, b->d_wg_f32 + wg_off, chs, render_consts(b->ctx->sr), b->n_vwaves, b->n, frames, n_wgs};
+  UniformArgs a{b->d_waves, b->d_state, out, rows, b->d_wg_list + wg_off, b->d_wg_cls + wg_off, b->d_wg_f32 + wg_off, chs, render_consts_of(b->ctx), b->n_vwaves, b->n, frames, n_wgs};
   a.diag = b->ctx->d_diag;
 #ifdef GROOVE_HEARTBEAT
   a.heartbeat = b->ctx->hb;
@@ -1736,7 +1745,7 @@ static int launch_render(groove_bank* b, uint32_t frames, bool fused, size_t chs
   if (use_tp(b, frames)) {
     launch_tp(b, frames, fused, chs, out, rows, ctx->stream);
   } else if (b->kind == BANK_WELSH) {
-    const RenderConsts rc = render_consts(ctx->sr);
+    const RenderConsts rc = render_consts_of(ctx);
     if (b->n_vwaves == 0) { // interleaved bank: per-lane kernel over the physical lanes
       if (fused) hipLaunchKernelGGL(welsh_render_kernel<true>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, rows, rc);
       else hipLaunchKernelGGL(welsh_render_kernel<false>, grid, blk, 0, ctx->stream, b->d_params, b->d_state, b->n, frames, chs, out, rows, rc);
@@ -1938,7 +1947,7 @@ static int render_async_impl(groove_bank* b, uint32_t frames, groove_block* out,
       UniformArgs a = uniform_args(b, dst, rows, 0, chs, frames, fused_rows(b, frames));
       launch_small_uniform(b, a, st, false, frames);
     } else if (b->kind == BANK_WELSH) {
-      const RenderConsts rc = render_consts(ctx->sr);
+      const RenderConsts rc = render_consts_of(ctx);
       hipLaunchKernelGGL(welsh_render_kernel<false>, grid, blk, 0, st, b->d_params, b->d_state, b->n, frames, chs, dst, rows, rc);
     } else if (b->kind == BANK_FM) {
       hipLaunchKernelGGL(fm_render_kernel<false>, grid, blk, 0, st, b->d_params, b->d_state, b->n, frames, chs, dst, rows);
@@ -2029,7 +2038,7 @@ static int render_mix_pipelined(groove_bank* b, uint32_t frames, float* bus_dev,
     for (bool& f : ctx->fork_pending) f = true;
     ctx->need_fork = false;
   }
-  const RenderConsts rc = render_consts(ctx->sr);
+  const RenderConsts rc = render_consts_of(ctx);
   const dim3 blk(kThreads);
   // paced: the HOST waits for the reduction that frees this slot's rows (two blocks back: long done), so that the waits below are
   // dropped when they are made and the render streams carry no wait packet (docs/STREAMS.md item 13)
@@ -2255,7 +2264,7 @@ int groove_banks_render_mix_deferred(groove_ctx* ctx, groove_bank* const* banks,
   ctx->dpart_next ^= 1;
   if (ctx->deferred.rows) { m.prev.rows = ctx->deferred.rows; m.prev.bus = ctx->deferred.bus; m.prev.n_rows = ctx->deferred.n_rows; m.prev.frames = ctx->deferred.frames; m.prev.accumulate = ctx->deferred.accumulate; }
   deferred_taken(ctx);
-  m.rows = ctx->d_dpart[slot]; m.rc = render_consts(ctx->sr); m.frames = frames;
+  m.rows = ctx->d_dpart[slot]; m.rc = render_consts_of(ctx); m.frames = frames;
   static const InlineEvents no_events{};
   launch_tp_mixed(m, of_kind[2] ? of_kind[2]->inline_ev : no_events, grid, ctx->stream);
   for (uint32_t i = 0; i < n_banks; ++i) banks[i]->ctx_touched = true;

@@ -80,6 +80,9 @@ __device__ __forceinline__ void soa_store(uint32_t* __restrict__ buf, uint32_t n
 #ifndef GROOVE_WHOLE_WAVE_PATH
 #define GROOVE_WHOLE_WAVE_PATH 0 /* run_frames_segmented: a second copy of the frame for waves whose 64 lanes all sound (A/B builds) */
 #endif
+#ifndef GROOVE_LFO_LOOKAHEAD
+#define GROOVE_LFO_LOOKAHEAD 1 /* the smooth-f64 kinds' LFO look-ahead (below, "LFO look-ahead"); 0: every lane advances its LFO's recurrences (A/B builds) */
+#endif
 #ifndef GROOVE_COEF_LOOKAHEAD
 #define GROOVE_COEF_LOOKAHEAD 1 /* the retuned kinds' coefficient look-ahead (below, "coefficient look-ahead"); 0: every lane retunes for itself (round 5's code, for A/B builds) */
 #endif
@@ -264,7 +267,7 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
 // stored or summed).  Shadow lanes now contribute 2^32-1.  `on_zero(f, mine, wmin)` is called (wave-uniformly) if the minimum
 // is 0 all the same — it counts (diag.h) — and the segment is then one frame, which is what the checked form would do.
 // `setup(live, seg)` runs once per segment (wave-uniformly: every lane of the wave is in it) once the segment's length is known, and
-// `pre(k)` before frame k of the segment, outside the `live` test: the coefficient look-ahead of the retuned kinds (welsh_block).
+// `pre(k)` before frames k, k + 64, ... of the segment, outside the `live` test: the look-ahead tables' fill (welsh_block).
 template <bool FUSED, class FirstFn, class BeginFn, class SetupFn, class PreFn, class LiveFn, class EndFn, class ZeroFn>
 __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n, uint32_t v, bool active, size_t ch_stride,
                                                      float* __restrict__ out, float* __restrict__ rows, uint32_t prow, FirstFn&& first, BeginFn&& begin,
@@ -316,11 +319,15 @@ __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n
       }
     }
 #else
-    for (uint32_t k = 0; k < seg; ++k, ++f) {
-      pre(k);
-      float L = 0.0f, R = 0.0f;
-      if (live) live_frame(k, L, R);
-      put(f, L, R);
+    // in chunks of CoefTab::kFrames frames: `pre` (the look-ahead tables' fill: long, cold code) stays out of the frame loop proper
+    for (uint32_t k0 = 0; k0 < seg; k0 += 64u) {
+      pre(k0);
+      const uint32_t k1 = min(seg, k0 + 64u);
+      for (uint32_t k = k0; k < k1; ++k, ++f) {
+        float L = 0.0f, R = 0.0f;
+        if (live) live_frame(k, L, R);
+        put(f, L, R);
+      }
     }
 #endif
     end(seg, live);
@@ -362,67 +369,113 @@ __device__ __forceinline__ void welsh_diag_zero(const DiagWhere& dw, const Welsh
 // in one pass, into a table of the wave's own in LDS, and every frame then takes its six coefficients with broadcast reads.  Same
 // expressions on the same values as the per-lane path (welsh_frame_front / lp24_t_from_pct / lp24_coef*_from_t): the same bits.
 // Waves whose voices started apart, LFO-swept cutoffs and segments shorter than eight frames keep the per-lane path.
+//
+// LFO look-ahead (round 6, the smooth-f64 kinds: LFO on the pitch or the pulse width).  A voice's LFO runs while the voice sounds, so
+// voices struck together share its phase as well, and what it does to the oscillators' edges — 2^(l depth) or l depth — is one number
+// per wave and frame that every lane was advancing with ~13 f64 operations a frame (a rotation, a 4-term exponential series).  Same
+// table, one more double per entry: lane j evaluates it EXACTLY from the phase of frame k + j (the exact-f64 kind's expressions:
+// welsh_lfo_mod_exact), the frames read it, the phase moves once per segment and the recurrences are re-seeded there for whatever
+// segment has to run lane by lane later.  Not the recurrences' bits (they differ from the exact evaluation by their random walk of
+// ~1e-16 a frame, re-seeded every block): tests/test_gpu_library.py compares the two paths at 2e-6 and both with the oracle.
 struct CoefTab {
   static constexpr uint32_t kFrames = 64, kMinSegment = 8;
-  // One entry per frame: the six coefficients — f64 (48 bytes), or f32 padded to 32 bytes in the fp32-filter bodies (a power of two: the
-  // entry's address is then a scalar AND and one vector add instead of a 64-bit multiply-add per frame).  3 KiB per wave.
-  struct EntryF { Lp24CoefF c; float pad[2]; };
-  struct EntryD { Lp24CoefD c; };
+  // One entry per frame: the six coefficients (f64: 48 bytes; f32 in the fp32-filter bodies: 24) where the kind retunes, then `mod`
+  // (8 bytes) in the smooth-f64 kinds; an fp32 entry without `mod` is padded to 32 bytes (a power of two: its address is then a scalar
+  // AND and one vector add instead of a 64-bit multiply-add per frame).  3.5 KiB per wave at most.
+  static constexpr uint32_t kMaxEntry = 56;
   static __device__ __forceinline__ double* wave_base() {
-    __shared__ double t[kWaves][kFrames][sizeof(EntryD) / 8];
+    __shared__ double t[kWaves][kFrames][kMaxEntry / 8];
     return &t[threadIdx.x >> 6][0][0];
   }
-  // Frame i's entry, read through an LDS (address space 3) pointer built from a 32-bit byte address.  Word by word: a struct cannot be
-  // assigned across address spaces; the compiler merges the words into wide ds_read / ds_write.
+  // T at byte `off` of frame i's entry (entries `stride` bytes apart), read through an LDS (address space 3) pointer built from a 32-bit
+  // byte address.  Word by word: a struct cannot be assigned across address spaces; the compiler merges the words into wide ds_read /
+  // ds_write.
   typedef __attribute__((address_space(3))) uint32_t* LdsWords;
-  template <class T> static __device__ __forceinline__ T load(uint32_t i) {
+  template <class T> static __device__ __forceinline__ T load(uint32_t i, uint32_t stride, uint32_t off = 0) {
     typedef __attribute__((address_space(3))) char* LdsBytes;
     // (The address is wave-uniform; forcing it through SGPRs — two v_readfirstlane, scalar multiply and add, a move — was measured and
     // lost to this per-lane form, whose index arithmetic the compiler does with one v_mad_u64_u32: 0.3594 - 0.3676 against 0.3516 - 0.3538
     // ms per block in one job, tools/ab_bench.sh, round 6.)
-    const LdsWords w = (LdsWords)(uintptr_t)((uint32_t)(uintptr_t)(LdsBytes)wave_base() + i * (uint32_t)sizeof(T));
+    const LdsWords w = (LdsWords)(uintptr_t)((uint32_t)(uintptr_t)(LdsBytes)wave_base() + i * stride + off);
     WordsOf<T> t;
 #pragma unroll
     for (uint32_t k = 0; k < sizeof(T) / 4; ++k) t.w[k] = w[k];
     return __builtin_bit_cast(T, t);
   }
-  // ... and lane j's own entry (the fill: a per-lane address)
-  template <class T> static __device__ __forceinline__ void store_of_lane(uint32_t j, const T& x) {
+  // ... and into lane j's own entry (the fill: a per-lane address)
+  template <class T> static __device__ __forceinline__ void store_of_lane(uint32_t j, uint32_t stride, uint32_t off, const T& x) {
     typedef __attribute__((address_space(3))) char* LdsBytes;
-    const LdsWords w = (LdsWords)(uintptr_t)((uint32_t)(uintptr_t)(LdsBytes)wave_base() + j * (uint32_t)sizeof(T));
+    const LdsWords w = (LdsWords)(uintptr_t)((uint32_t)(uintptr_t)(LdsBytes)wave_base() + j * stride + off);
     const WordsOf<T> t = __builtin_bit_cast(WordsOf<T>, x);
 #pragma unroll
     for (uint32_t k = 0; k < sizeof(T) / 4; ++k) w[k] = t.w[k];
   }
 };
-// Do the live lanes of this wave share the filter envelope's stage?  Then its description, from the first of them, in SGPRs.
-// tab: `ok` as a 0 / 1 the compiler KNOWS to be in an SGPR (readfirstlane).
-struct FilEnvUniform { bool ok; float A, c1, c2, tf; uint32_t tab; };
+// The layout of a kind's entries.
+template <bool F32, bool COEF, bool LFO> struct TabLayout {
+  static constexpr uint32_t kCoef = COEF ? (F32 ? (uint32_t)sizeof(Lp24CoefF) : (uint32_t)sizeof(Lp24CoefD)) : 0u;
+  static constexpr uint32_t kModOff = kCoef;
+  static constexpr uint32_t kStride = LFO ? kCoef + 8u : (F32 ? 32u : (uint32_t)sizeof(Lp24CoefD));
+  static_assert(kStride <= CoefTab::kMaxEntry && kCoef % 8 == 0, "entry layout");
+};
+// Do the live lanes of this wave share the filter envelope's stage (-> tab)?  The LFO's phase (-> ltab)?  Then their description,
+// from the first live lane, in SGPRs.  tab / ltab: 0 / 1 the compiler KNOWS to be in an SGPR (readfirstlane).
+// cut: the coefficients follow the LFO (an LFO-swept cutoff in an F32 kind), not the filter envelope.
+struct WaveUniform { float A, c1, c2, tf; uint32_t lph_lo, lph_hi; uint32_t tab, ltab, cut; };
 __device__ __forceinline__ float lane_value(float x, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane)); }
 __device__ __forceinline__ bool same_bits(float a, float b) { return __builtin_bit_cast(uint32_t, a) == __builtin_bit_cast(uint32_t, b); }
-__device__ __forceinline__ FilEnvUniform fil_env_uniform(const WelshState& s, const WelshScratch& sc, bool live) {
-  FilEnvUniform u{false, 0.0f, 0.0f, 0.0f, 0.0f, 0u};
+template <bool COEF, bool LFO, int LFO_MODE, int CL>
+__device__ __forceinline__ WaveUniform wave_uniform(const WelshParams& p, const WelshState& s, const WelshScratch& sc, bool live, uint32_t look) {
+  WaveUniform u{0.0f, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u, 0u, 0u};
   const uint64_t mask = __ballot(live);
   if (mask == 0) return u;
   const int l0 = __builtin_ctzll(mask); // wave-uniform
-  u.A = lane_value(s.fil.A, l0); u.c1 = lane_value(sc.fc1, l0); u.c2 = lane_value(sc.fc2, l0); u.tf = lane_value(sc.tf, l0);
-  // bit patterns, so that a NaN (never produced; a torn shadow record could hold anything, but shadows are not live) cannot fake agreement
-  const bool same = same_bits(s.fil.A, u.A) && same_bits(sc.fc1, u.c1) && same_bits(sc.fc2, u.c2) && same_bits(sc.tf, u.tf);
-  u.ok = __ballot(live && !same) == 0;
-  u.tab = (uint32_t)__builtin_amdgcn_readfirstlane(u.ok ? 1 : 0);
+  if constexpr (LFO) {
+    // (a noise LFO has a state of its own per voice: class OSC_ANY of an F32 kind can be one)
+    if ((look & 2u) && osc_class_wave<CL>((p.flags >> WF_LFO_WAVE_SHIFT) & 15u) != (uint32_t)GROOVE_WAVE_NOISE) {
+      const uint32_t lo = (uint32_t)s.lfo.phase, hi = (uint32_t)(s.lfo.phase >> 32);
+      u.lph_lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, l0); u.lph_hi = (uint32_t)__builtin_amdgcn_readlane((int)hi, l0);
+      u.ltab = (uint32_t)__builtin_amdgcn_readfirstlane(__ballot(live && (lo != u.lph_lo || hi != u.lph_hi)) == 0 ? 1 : 0);
+    }
+  }
+  if constexpr (COEF) {
+    if constexpr (LFO && LFO_MODE == LFO_F32) { // an LFO-swept cutoff: the coefficients are the shared LFO's (welsh_frame_front: the envelope has precedence)
+      if (!(p.flags & WF_RETUNE_ENV) && (p.flags & WF_LFO_CUTOFF) && (look & 1u) && u.ltab != 0u) { u.tab = 1u; u.cut = 1u; }
+    }
+    if ((p.flags & WF_RETUNE_ENV) && (look & 1u)) {
+      u.A = lane_value(s.fil.A, l0); u.c1 = lane_value(sc.fc1, l0); u.c2 = lane_value(sc.fc2, l0); u.tf = lane_value(sc.tf, l0);
+      // bit patterns, so that a NaN (never produced; a torn shadow record could hold anything, but shadows are not live) cannot fake agreement
+      const bool same = same_bits(s.fil.A, u.A) && same_bits(sc.fc1, u.c1) && same_bits(sc.fc2, u.c2) && same_bits(sc.tf, u.tf);
+      u.tab = (uint32_t)__builtin_amdgcn_readfirstlane(__ballot(live && !same) == 0 ? 1 : 0);
+    }
+  }
   return u;
 }
-// Lane j: the coefficients of frame k0 + j of the segment, into the wave's table.  (All 64 lanes take part, live or not: the inputs
-// are wave-uniform.)
-template <bool F32>
-__device__ __forceinline__ void coef_tab_fill(const WelshParams& p, const RenderConsts& rc, const FilEnvUniform& u, uint32_t k0) {
+// Lane j: the entry of frame k0 + j of the segment, into the wave's table.  (All 64 lanes take part, live or not: the inputs are
+// wave-uniform.)
+template <bool F32, bool COEF, bool LFO, int LFO_MODE, int CL>
+__device__ __forceinline__ void wave_tab_fill(const WelshParams& p, const RenderConsts& rc, const WaveUniform& u, uint32_t k0) {
+  typedef TabLayout<F32, COEF, LFO> Lay;
   const uint32_t j = threadIdx.x & 63u;
-  const float n = u.tf + (float)(k0 + j); // the hoisted frames' counter sc.tf, which grows by 1.0f a frame (exact below 2^24)
-  const float pct = welsh_env_cutoff_pct(p, env_shape(n, u.A, u.c1, u.c2));
-  bool hi;
-  const float t = lp24_t_from_pct(pct, rc, hi);
-  if constexpr (F32) CoefTab::store_of_lane<CoefTab::EntryF>(j, CoefTab::EntryF{lp24_coeff_from_t(p.fc, t, hi), {0.0f, 0.0f}});
-  else CoefTab::store_of_lane<CoefTab::EntryD>(j, CoefTab::EntryD{lp24_coefd_from_t(p.fc, t, hi, (p.flags & WF_COEF_WIDE) != 0)});
+  float lfo = 0.0f;
+  if constexpr (LFO) {
+    if (u.ltab != 0u) { // frame k of the segment evaluates the LFO at the segment's start phase + (k + 1) increments
+      const uint64_t ph = (((uint64_t)u.lph_hi << 32) | u.lph_lo) + (uint64_t)(k0 + j + 1u) * p.lfo_inc;
+      if constexpr (LFO_MODE == LFO_F64_SMOOTH) CoefTab::store_of_lane(j, Lay::kStride, Lay::kModOff, welsh_lfo_mod_exact<CL>(p, ph));
+      else { lfo = welsh_lfo_value_f32<CL>(p, ph); CoefTab::store_of_lane(j, Lay::kStride, Lay::kModOff, lfo); }
+    }
+  }
+  if constexpr (COEF) {
+    if (u.tab != 0u) {
+      float pct;
+      if (LFO && LFO_MODE == LFO_F32 && u.cut != 0u) pct = welsh_lfo_cutoff_pct(p, lfo);
+      else pct = welsh_env_cutoff_pct(p, env_shape(u.tf + (float)(k0 + j), u.A, u.c1, u.c2)); // the hoisted frames' counter sc.tf grows by 1.0f a frame (exact below 2^24)
+      bool hi;
+      const float t = lp24_t_from_pct(pct, rc, hi);
+      if constexpr (F32) CoefTab::store_of_lane(j, Lay::kStride, 0, lp24_coeff_from_t(p.fc, t, hi));
+      else CoefTab::store_of_lane(j, Lay::kStride, 0, lp24_coefd_from_t(p.fc, t, hi, (p.flags & WF_COEF_WIDE) != 0));
+    }
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the wave's own reads below come after these writes
   __builtin_amdgcn_wave_barrier();
 }
@@ -442,27 +495,38 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
     // back two thirds of the gain (profiles/r05_f32_filter.log).
     welsh_scratch_f32_begin(p, s, rc, sc);
     if (!RETUNE) sc.coef_f = make_scalar(sc.coef_f);
-    FilEnvUniform fu{false, 0.0f, 0.0f, 0.0f, 0.0f, 0u}; // this segment's coefficient look-ahead (RETUNE kinds; fu.ok is wave-uniform)
+    constexpr bool COEF_LA = RETUNE && GROOVE_COEF_LOOKAHEAD;
+    constexpr bool LFO_LA = LFO_MODE != LFO_F64 && CL != LFO_UNUSED && GROOVE_LFO_LOOKAHEAD;
+    typedef TabLayout<true, COEF_LA, LFO_LA> Lay;
+    WaveUniform fu{0.0f, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u, 0u, 0u}; // this segment's look-aheads (fu.tab, fu.ltab are wave-uniform)
     run_frames_segmented<FUSED>(
         frames, n, v, active, ch_stride, out, rows, prow,
         [&](float& L, float& R) { welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL, false, REST, false, true>(p, s, rc, sc, L, R); },
         [&](bool& live) { const uint32_t k = welsh_segment_begin(p, s, live); welsh_segment_start_hoisted(s, sc); return k; },
         [&](bool live, uint32_t seg) {
-          fu.ok = false; fu.tab = 0u;
-          if constexpr (RETUNE && GROOVE_COEF_LOOKAHEAD) { if ((p.flags & WF_RETUNE_ENV) && seg >= CoefTab::kMinSegment) fu = fil_env_uniform(s, sc, live); }
+          fu.tab = 0u; fu.ltab = 0u;
+          if constexpr (COEF_LA || LFO_LA) { if (seg >= CoefTab::kMinSegment) fu = wave_uniform<COEF_LA, LFO_LA, LFO_MODE, CL>(p, s, sc, live, rc.look); }
         },
-        [&](uint32_t k) { if constexpr (RETUNE && GROOVE_COEF_LOOKAHEAD) { if (fu.tab != 0u && (k & (CoefTab::kFrames - 1)) == 0) coef_tab_fill<true>(p, rc, fu, k); } },
+        [&](uint32_t k) { if constexpr (COEF_LA || LFO_LA) { if ((fu.tab | fu.ltab) != 0u && (k & (CoefTab::kFrames - 1)) == 0) wave_tab_fill<true, COEF_LA, LFO_LA, LFO_MODE, CL>(p, rc, fu, k); } },
         [&](uint32_t k, float& L, float& R) {
-          uint32_t tab = 0u;
-          if constexpr (RETUNE && GROOVE_COEF_LOOKAHEAD) {
+          uint32_t tab = 0u, ltab = 0u;
+          double mod = 0.0;
+          if constexpr (COEF_LA) {
             tab = fu.tab;
-            if (tab != 0u) sc.coef_f = CoefTab::load<CoefTab::EntryF>(k & (CoefTab::kFrames - 1)).c;
+            if (tab != 0u) sc.coef_f = CoefTab::load<Lp24CoefF>(k & (CoefTab::kFrames - 1), Lay::kStride);
           }
-          welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true, true>(p, s, rc, sc, L, R, tab);
+          float tlfo = 0.0f;
+          if constexpr (LFO_LA) {
+            ltab = fu.ltab;
+            if constexpr (LFO_MODE == LFO_F64_SMOOTH) { if (ltab != 0u) mod = CoefTab::load<double>(k & (CoefTab::kFrames - 1), Lay::kStride, Lay::kModOff); }
+            else { if (ltab != 0u && ((p.flags & WF_LFO_AMP) || tab == 0u)) tlfo = CoefTab::load<float>(k & (CoefTab::kFrames - 1), Lay::kStride, Lay::kModOff); } // (a cutoff-only LFO is in the coefficients already)
+          }
+          welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true, true>(p, s, rc, sc, L, R, tab, ltab, mod, tlfo);
         },
         [&](uint32_t seg, bool live) {
           welsh_segment_end_hoisted<CL == LFO_UNUSED>(p, s, seg, live);
-          if constexpr (RETUNE && GROOVE_COEF_LOOKAHEAD) { if (fu.tab != 0u) { if (live) s.fil.value = env_last_value_of(s.fil); sc.prev_pct = __builtin_nanf(""); } }
+          if constexpr (COEF_LA) { if (fu.tab != 0u) { if (live) s.fil.value = env_last_value_of(s.fil); sc.prev_pct = __builtin_nanf(""); } }
+          if constexpr (LFO_LA) { if (fu.ltab != 0u && live) { s.lfo.phase += (uint64_t)seg * p.lfo_inc; if constexpr (LFO_MODE == LFO_F64_SMOOTH) welsh_lfo_reseed_smooth<CL>(p, s, sc); } }
         },
         [&](uint32_t f, uint32_t mine) { welsh_diag_zero(dw, s, active, f, mine); });
     welsh_scratch_f32_end(s, sc);
@@ -470,28 +534,38 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
   }
   if (UNIFORM && !RETUNE) sc.coef = make_scalar(sc.coef);
   if constexpr (UNIFORM) {
-    constexpr bool LOOKAHEAD = RETUNE && LFO_MODE != LFO_F64 && GROOVE_COEF_LOOKAHEAD; // (the exact-f64 kind keeps its own coefficient forms: resonance routing, lp24_coefd_from_fc)
-    FilEnvUniform fu{false, 0.0f, 0.0f, 0.0f, 0.0f, 0u};
+    constexpr bool COEF_LA = RETUNE && LFO_MODE != LFO_F64 && GROOVE_COEF_LOOKAHEAD; // (the exact-f64 kind keeps its own coefficient forms: resonance routing, lp24_coefd_from_fc)
+    constexpr bool LFO_LA = LFO_MODE != LFO_F64 && CL != LFO_UNUSED && GROOVE_LFO_LOOKAHEAD;
+    typedef TabLayout<false, COEF_LA, LFO_LA> Lay;
+    WaveUniform fu{0.0f, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u, 0u, 0u};
     run_frames_segmented<FUSED>(
         frames, n, v, active, ch_stride, out, rows, prow,
         [&](float& L, float& R) { welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL, false, REST>(p, s, rc, sc, L, R); },
         [&](bool& live) { const uint32_t k = welsh_segment_begin(p, s, live); welsh_segment_start_hoisted(s, sc); return k; },
         [&](bool live, uint32_t seg) {
-          fu.ok = false; fu.tab = 0u;
-          if constexpr (LOOKAHEAD) { if ((p.flags & WF_RETUNE_ENV) && seg >= CoefTab::kMinSegment) fu = fil_env_uniform(s, sc, live); }
+          fu.tab = 0u; fu.ltab = 0u;
+          if constexpr (COEF_LA || LFO_LA) { if (seg >= CoefTab::kMinSegment) fu = wave_uniform<COEF_LA, LFO_LA, LFO_MODE, CL>(p, s, sc, live, rc.look); }
         },
-        [&](uint32_t k) { if constexpr (LOOKAHEAD) { if (fu.tab != 0u && (k & (CoefTab::kFrames - 1)) == 0) coef_tab_fill<false>(p, rc, fu, k); } },
+        [&](uint32_t k) { if constexpr (COEF_LA || LFO_LA) { if ((fu.tab | fu.ltab) != 0u && (k & (CoefTab::kFrames - 1)) == 0) wave_tab_fill<false, COEF_LA, LFO_LA, LFO_MODE, CL>(p, rc, fu, k); } },
         [&](uint32_t k, float& L, float& R) {
-          uint32_t tab = 0u;
-          if constexpr (LOOKAHEAD) {
+          uint32_t tab = 0u, ltab = 0u;
+          double mod = 0.0;
+          if constexpr (COEF_LA) {
             tab = fu.tab;
-            if (tab != 0u) sc.coef = CoefTab::load<CoefTab::EntryD>(k & (CoefTab::kFrames - 1)).c;
+            if (tab != 0u) sc.coef = CoefTab::load<Lp24CoefD>(k & (CoefTab::kFrames - 1), Lay::kStride);
           }
-          welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true>(p, s, rc, sc, L, R, tab);
+          float tlfo = 0.0f;
+          if constexpr (LFO_LA) {
+            ltab = fu.ltab;
+            if constexpr (LFO_MODE == LFO_F64_SMOOTH) { if (ltab != 0u) mod = CoefTab::load<double>(k & (CoefTab::kFrames - 1), Lay::kStride, Lay::kModOff); }
+            else { if (ltab != 0u && ((p.flags & WF_LFO_AMP) || tab == 0u)) tlfo = CoefTab::load<float>(k & (CoefTab::kFrames - 1), Lay::kStride, Lay::kModOff); } // (a cutoff-only LFO is in the coefficients already)
+          }
+          welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true>(p, s, rc, sc, L, R, tab, ltab, mod, tlfo);
         },
         [&](uint32_t seg, bool live) {
           welsh_segment_end_hoisted<CL == LFO_UNUSED>(p, s, seg, live);
-          if constexpr (LOOKAHEAD) { if (fu.tab != 0u) { if (live) s.fil.value = env_last_value_of(s.fil); sc.prev_pct = __builtin_nanf(""); } }
+          if constexpr (COEF_LA) { if (fu.tab != 0u) { if (live) s.fil.value = env_last_value_of(s.fil); sc.prev_pct = __builtin_nanf(""); } }
+          if constexpr (LFO_LA) { if (fu.ltab != 0u && live) { s.lfo.phase += (uint64_t)seg * p.lfo_inc; if constexpr (LFO_MODE == LFO_F64_SMOOTH) welsh_lfo_reseed_smooth<CL>(p, s, sc); } }
         },
         [&](uint32_t f, uint32_t mine) { welsh_diag_zero(dw, s, active, f, mine); });
   } else {
@@ -592,7 +666,7 @@ __device__ __forceinline__ void welsh_uniform_body_impl(UniformArgsPtr a) {
   const bool active = (w0 < n_waves) && (lane < d.count);
   const uint32_t v = active ? d.vbase + lane : d.vbase; // idle lanes shadow the run's first voice
   WelshState s = soa_load<WelshState>(a->state, n, v);
-  RenderConsts rc{a->rc.pi_over_sr, a->rc.fc_max, a->rc.log2_x0, a->rc.x_lo, a->rc.x_hi};
+  RenderConsts rc{a->rc.pi_over_sr, a->rc.fc_max, a->rc.log2_x0, a->rc.x_lo, a->rc.x_hi}; rc.look = a->rc.look;
   // pinned in VGPRs for the block: as literals / SGPRs each costs a v_mov on every retuning frame (the instructions
   // that use them take one constant-bus operand): +2.5 % in the all-voices window of the million-voice project
   if constexpr (RETUNE) asm volatile("" : "+v"(rc.tan_k1), "+v"(rc.tan_k2), "+v"(rc.log2_x0), "+v"(rc.x_hi));

@@ -83,6 +83,14 @@ class Context:
         _lib.check(self.L.groove_set_time_parallel_pair_min_voices(self.h, n), self.h)
 
     @property
+    def look_ahead(self):
+        return self.L.groove_look_ahead(self.h)
+
+    @look_ahead.setter
+    def look_ahead(self, bits):
+        _lib.check(self.L.groove_set_look_ahead(self.h, bits), self.h)
+
+    @property
     def pipeline_min_waves(self):
         return self.L.groove_pipeline_min_waves(self.h)
 

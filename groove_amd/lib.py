@@ -38,6 +38,8 @@ SYMBOLS = {
     "groove_time_parallel_pair_min_voices": (_u32, [_vp]),
     "groove_set_pipeline_min_waves": (_i, [_vp, _u32]),
     "groove_pipeline_min_waves": (_u32, [_vp]),
+    "groove_set_look_ahead": (_i, [_vp, _u32]),
+    "groove_look_ahead": (_u32, [_vp]),
     "groove_set_fx_allpass_stream": (_i, [_vp, _i]),
     "groove_fx_allpass_stream": (_i, [_vp]),
     "groove_set_split_max_waves": (_i, [_vp, _u32]),

@@ -98,6 +98,13 @@ uint32_t groove_time_parallel_pair_min_voices(groove_ctx* ctx);
  * million-voice path on a small bank).  GROOVE_PIPELINE_MIN_WAVES in the environment sets it at groove_init. */
 int groove_set_pipeline_min_waves(groove_ctx* ctx, uint32_t waves);
 uint32_t groove_pipeline_min_waves(groove_ctx* ctx);
+/* Which look-aheads the wave-uniform Welsh kernels may use (csrc/kernels.h): bit 0 — a wave whose live voices share the filter
+ * envelope's stage computes 64 frames' filter coefficients in one pass, lane = frame (bit-identical to the per-lane retune); bit 1 —
+ * a wave whose live voices share the LFO's phase evaluates what the LFO does to the oscillators (pitch / pulse-width routing) the same
+ * way, exactly, where each lane would advance recurrences (within 1e-6 of them).  Default 3; GROOVE_LOOK_AHEAD in the environment
+ * sets it at groove_init.  Tests render the same bank with and without. */
+int groove_set_look_ahead(groove_ctx* ctx, uint32_t bits);
+uint32_t groove_look_ahead(groove_ctx* ctx);
 /* Tuning, for a render-ahead walk of blocks through an effect chain that ENDS in a reverb (config #3): on = the reverb's two
  * all-passes — the chain's last kernel, which nothing on the ctx stream reads behind — are launched on a side stream of the
  * library, so that the NEXT block's fused run follows this block's run directly and the all-passes overlap it (0.0489 -> 0.044 ms

@@ -13,7 +13,7 @@ namespace groove { int groove_emul_f32_filter = 0; } // 0: the product's f64 rec
 using namespace groove;
 
 struct EmulBank {
-  int kind; uint32_t n; double sr; int generic_lfo = 0; int segmented = 1; int time_parallel = 0; int role_split = 0; int f32_kind = 0;
+  int kind; uint32_t n; double sr; int generic_lfo = 0; int segmented = 1; int time_parallel = 0; int role_split = 0; int f32_kind = 0; int lfo_look_ahead = 0;
   uint32_t min_seg = 0xFFFFFFFFu; // the smallest value welsh_segment_begin has returned for any voice of this bank (must stay >= 1)
   std::vector<WelshParams> wp; std::vector<WelshState> ws; std::vector<WelshCold> wc;
   std::vector<FmParams> fp; std::vector<FmState> fs; std::vector<double> ratio;
@@ -45,6 +45,12 @@ static void welsh_emul_segment_frame2(const WelshParams& p, WelshState& s, const
   if (mode == LFO_F32) welsh_frame<false, RETUNE, LFO_F32, OSC_ANY, OSC_ANY, OSC_ANY, true, false, true>(p, s, rc, sc, L, R);
   else if (mode == LFO_F64) welsh_frame<false, RETUNE, LFO_F64, OSC_ANY, OSC_ANY, OSC_ANY, true, false, true>(p, s, rc, sc, L, R);
   else welsh_frame<false, RETUNE, LFO_F64_SMOOTH, OSC_ANY, OSC_ANY, OSC_ANY, true, false, true>(p, s, rc, sc, L, R);
+}
+// ... and a frame of a segment whose LFO comes from the wave's look-ahead table (kernels.h "LFO look-ahead"; a one-lane wave always
+// agrees with itself): `mod` evaluated exactly at this frame's phase, handed in
+template <bool RETUNE, bool F32FILT>
+static void welsh_emul_ltab_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc, WelshScratch& sc, uint64_t phase, float& L, float& R) {
+  welsh_frame<false, RETUNE, LFO_F64_SMOOTH, OSC_ANY, OSC_ANY, OSC_ANY, true, false, true, F32FILT>(p, s, rc, sc, L, R, 0u, 1u, welsh_lfo_mod_exact<OSC_ANY>(p, phase));
 }
 static void welsh_emul_segment_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc, WelshScratch& sc, bool retune, int mode,
                                      float& L, float& R) {
@@ -279,6 +285,7 @@ void emul_welsh_classify(const groove_welsh_params* p, uint32_t sr, uint32_t out
 }
 double emul_filter_f32_error(const groove_welsh_params* p, uint32_t sr) { WelshCold c; return welsh_filter_f32_error(derive_welsh(*p, (double)sr, c), (double)sr); }
 void emul_set_segmented(void* h, int on) { ((EmulBank*)h)->segmented = on; }
+void emul_set_lfo_look_ahead(void* h, int on) { ((EmulBank*)h)->lfo_look_ahead = on; }
 void emul_set_time_parallel(void* h, int on) { ((EmulBank*)h)->time_parallel = on; }
 // role_split != 0: Welsh voices of the four class-specialised base kinds (no exact-f64 LFO) render role by role, as the
 // role-split kernel does (welsh_split.h); must give the segmented form's bits
@@ -349,6 +356,20 @@ void emul_bank_render(void* h, uint32_t frames, float* out) {
           welsh_segment_start_hoisted(b->ws[v], sc);
         }
         L = R = 0.0f;
+        const bool ltab = b->lfo_look_ahead && mode == LFO_F64_SMOOTH && seg_len >= 8; // (kernels.h CoefTab::kMinSegment)
+        if (seg_live && ltab) {
+          const uint64_t ph = b->ws[v].lfo.phase + (uint64_t)(seg_len - seg_left + 1) * b->wp[v].lfo_inc; // the phase stands for the segment
+          if (f32) { if (retunes) welsh_emul_ltab_frame<true, true>(b->wp[v], b->ws[v], rc, sc, ph, L, R); else welsh_emul_ltab_frame<false, true>(b->wp[v], b->ws[v], rc, sc, ph, L, R); }
+          else { if (retunes) welsh_emul_ltab_frame<true, false>(b->wp[v], b->ws[v], rc, sc, ph, L, R); else welsh_emul_ltab_frame<false, false>(b->wp[v], b->ws[v], rc, sc, ph, L, R); }
+          if (--seg_left == 0) {
+            welsh_segment_end_hoisted<false>(b->wp[v], b->ws[v], seg_len, seg_live);
+            b->ws[v].lfo.phase += (uint64_t)seg_len * b->wp[v].lfo_inc;
+            welsh_lfo_reseed_smooth<OSC_ANY>(b->wp[v], b->ws[v], sc);
+          }
+          out[(size_t)f * n + v] = L;
+          out[((size_t)frames + f) * n + v] = R;
+          continue;
+        }
         if (seg_live && f32) { if (retunes) welsh_emul_f32_frame<false, true>(b->wp[v], b->ws[v], rc, sc, mode, L, R); else welsh_emul_f32_frame<false, false>(b->wp[v], b->ws[v], rc, sc, mode, L, R); }
         else if (seg_live) welsh_emul_segment_frame(b->wp[v], b->ws[v], rc, sc, retunes, mode, L, R);
         if (--seg_left == 0) welsh_segment_end_hoisted<false>(b->wp[v], b->ws[v], seg_len, seg_live);

@@ -37,6 +37,7 @@ def lib():
         L.emul_set_f32_kind.restype = u32; L.emul_set_f32_kind.argtypes = [vp, C.c_int]
         L.emul_filter_f32_error.restype = C.c_double; L.emul_filter_f32_error.argtypes = [C.POINTER(T.WelshParams), u32]
         L.emul_set_segmented.argtypes = [vp, C.c_int]
+        L.emul_set_lfo_look_ahead.argtypes = [vp, C.c_int]
         L.emul_set_time_parallel.argtypes = [vp, C.c_int]
         L.emul_set_role_split.argtypes = [vp, C.c_int]
         L.emul_bank_note_events.argtypes = [vp, C.POINTER(T.NoteEvent), u32]
@@ -80,6 +81,11 @@ class Bank:
     def set_segmented(self, on):
         """True (default): boundary-free segments as in the uniform kernels; False: every frame checked (per-lane kernel)."""
         lib().emul_set_segmented(self.h, 1 if on else 0)
+
+    def set_lfo_look_ahead(self, on):
+        """True: the smooth-f64 kinds' frames take what the LFO does to the oscillators from an exact evaluation at the frame's phase
+        (kernels.h "LFO look-ahead": what a wave whose voices share the LFO's phase does on the device) instead of advancing recurrences."""
+        lib().emul_set_lfo_look_ahead(self.h, 1 if on else 0)
 
     def set_time_parallel(self, on):
         """True: Welsh voices through the time-parallel form (welsh_tp.h: 64 lanes x 4 frames, affine-map scan)."""

@@ -22,10 +22,13 @@ def _render(bank_o, bank_e, on, off, blocks, off_block, frames=256):
     return np.concatenate(o, axis=1), np.concatenate(e, axis=1).astype(np.float64)
 
 
-def test_welsh_arithmetic_all_patches(oracle):
+@pytest.mark.parametrize("lfo_look_ahead", [False, True])
+def test_welsh_arithmetic_all_patches(oracle, lfo_look_ahead):
     n = 32
     params = P.welsh_voices(n)
-    o, e = _render(oracle.Bank.welsh(params), E.Bank.welsh(params), P.note_on_all(n), P.note_off_all(n), 172, 86)
+    be = E.Bank.welsh(params)
+    be.set_lfo_look_ahead(lfo_look_ahead)
+    o, e = _render(oracle.Bank.welsh(params), be, P.note_on_all(n), P.note_off_all(n), 172, 86)
     err = e - o
     per_voice = np.sqrt(np.mean(err ** 2, axis=(0, 1)))
     assert per_voice.max() <= 1e-5, per_voice
@@ -440,7 +443,7 @@ def _library_bank(keys_of=(43, 66)):
     return (T.WelshParams * n)(*pats), T.note_events_np(lanes, keys, True), T.note_events_np(lanes, keys, False)
 
 
-@pytest.mark.parametrize("form", ["per-kind (fp32 filter kind on)", "four roles", "time-parallel"])
+@pytest.mark.parametrize("form", ["per-kind (fp32 filter kind on)", "per-kind, LFO look-ahead", "four roles", "time-parallel"])
 def test_library_table_through_the_device_arithmetic(oracle, form):
     """The 106 slots of the library-proportioned table — square / sawtooth LFOs on the pitch and the pulse width (the smooth kinds'
     recurrences, re-seeded exactly on the frame of an LFO edge: dsp_core.h welsh_frame_front), filters with ripples up to 10.7 under
@@ -451,6 +454,7 @@ def test_library_table_through_the_device_arithmetic(oracle, form):
     be = E.Bank.welsh(params)
     if form.startswith("per-kind"):
         assert be.set_f32_kind(True) > 40
+        be.set_lfo_look_ahead(form.endswith("look-ahead"))   # (what a wave struck together does on the device: kernels.h "LFO look-ahead")
     elif form == "four roles":
         be.set_role_split(4)
     else:

@@ -110,10 +110,13 @@ def test_random_note_event_sequences_in_every_kernel_form(gpu_ctx, oracle):
             want = np.concatenate(want, axis=1)
             assert np.sqrt(np.mean(want ** 2)) > 1e-2
             outs = {}
-            for form in ("tp", "any", "split", "per-kind"):
+            # ("any, lanes' LFO": the all-kinds kernel without the LFO look-ahead — kernels.h: a wave whose voices share the LFO's phase
+            # evaluates a pitch / pulse-width LFO exactly where the role-split kernel's lanes advance recurrences — for the bit comparison)
+            for form in ("tp", "any", "any, lanes' LFO", "split", "per-kind"):
                 gpu_ctx.time_parallel_max_voices = old[0] if form == "tp" else 0
                 gpu_ctx.split_max_waves = (1 << 20) if form == "split" else 0
                 gpu_ctx.pipeline_min_waves = 1 if form == "per-kind" else old[2]
+                gpu_ctx.look_ahead = 1 if form.endswith("lanes' LFO") else 3
                 s = E.WelshSynth(gpu_ctx, params)
                 blk = gpu_ctx.block(n, 256)
                 got = []
@@ -128,10 +131,12 @@ def test_random_note_event_sequences_in_every_kernel_form(gpu_ctx, oracle):
                 assert len(set(int(v) % 32 for v in over)) <= 1 and rms.max() <= 2e-4, (seed, form, int(np.argmax(rms)), float(rms.max()), over)
                 outs[form] = got
                 s.destroy(); blk.destroy()
-            assert np.array_equal(outs["split"], outs["any"]), seed
+            assert np.array_equal(outs["split"], outs["any, lanes' LFO"]), seed
+            assert np.abs(outs["any"] - outs["any, lanes' LFO"]).max() <= 2e-6 * max(1.0, np.abs(outs["any"]).max()), seed
             assert np.abs(outs["tp"] - outs["any"]).max() <= 2e-6 * max(1.0, np.abs(outs["any"]).max()), seed
     finally:
         gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves, gpu_ctx.pipeline_min_waves = old
+        gpu_ctx.look_ahead = 3
     assert gpu_ctx.debug_info()["zero_segments"] == 0
 
 

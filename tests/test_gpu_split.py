@@ -2,7 +2,12 @@
 gains, pipelined over the block's frames through LDS) computes every quantity with the serial kernels' statements in their
 order: bus rows, voice blocks and the state record must be the serial kernels' BIT FOR BIT, for every patch of the
 synthetic table (every waveform class, LFO routing, sync, both filter modes), through note-on, note-off, release, the idle
-tail, ragged blocks, partly filled waves, and in the fused, block-writing and asynchronous forms."""
+tail, ragged blocks, partly filled waves, and in the fused, block-writing and asynchronous forms.
+
+(The serial kernels are run here WITHOUT their LFO look-ahead — groove_set_look_ahead(1): a serial wave whose voices share the LFO's phase
+evaluates a pitch / pulse-width LFO exactly from the phase, lane = frame, where the role-split kernel's lanes advance the recurrences;
+the two agree to 2e-6 — tests/test_gpu_random_inputs.py, tests/test_gpu_library.py — not to the bit.  The coefficient look-ahead stays on:
+it is the lanes' own arithmetic.)"""
 import numpy as np
 import pytest
 
@@ -14,13 +19,14 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture()
 def forms(gpu_ctx):
     """(set_form): switch the session ctx between the serial all-kinds kernel and the role-split one; restored afterwards."""
-    old_tp, old_split, old_pipe = gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves, gpu_ctx.pipeline_min_waves
+    old_tp, old_split, old_pipe, old_look = gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves, gpu_ctx.pipeline_min_waves, gpu_ctx.look_ahead
 
     def set_form(split):
         gpu_ctx.time_parallel_max_voices = 0
         gpu_ctx.split_max_waves = 4096 if split else 0
+        gpu_ctx.look_ahead = 1
     yield set_form
-    gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves, gpu_ctx.pipeline_min_waves = old_tp, old_split, old_pipe
+    gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves, gpu_ctx.pipeline_min_waves, gpu_ctx.look_ahead = old_tp, old_split, old_pipe, old_look
 
 
 SIZES = [256, 256, 100, 256, 9, 255, 256, 8, 256, 64, 256, 256, 17, 256]
@@ -138,6 +144,7 @@ def test_every_role_count_equals_the_serial_kernels_bit_for_bit(oracle, roles):
     finally:
         os.environ.pop("GROOVE_SPLIT_ROLES")
     try:
+        ctx.look_ahead = 1   # (the module's docstring)
         for n in (3072, 200):
             params, idx = P.welsh_voices_grouped(n, 0)
             on, off = P.grouped_note_events(idx, True), P.grouped_note_events(idx, False)
