@@ -870,23 +870,28 @@ GROOVE_HD float osc_value_classed(uint32_t w, uint64_t phase, uint64_t duty64, f
 // `tab` (a wave-uniform 0 / 1 in an SGPR; HOIST frames of the uniform kernels only): this segment's filter coefficients come from the
 // wave's look-ahead table (kernels.h "coefficient look-ahead"), so the frame neither evaluates the filter envelope nor derives a cutoff
 // percent from it.  (An integer, not a bool: as a bool the flag lived in a lane mask and its negation went through two vector instructions.)
+// AMPTAB (with `tab`): the table's entries carry the AMPLITUDE envelope's value of the frame too (`tab_amp`; the caller sets `tab` only
+// where the live lanes agree on BOTH envelopes' stages): the same env_shape on the same counter, from the lane that filled the entry.
 template <bool FIRST, bool RETUNE, int LFO_MODE = LFO_F64, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool SEGMENT = false, bool REST = false,
-          bool HOIST = false>
+          bool HOIST = false, bool AMPTAB = false>
 GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScratch& sc, float& sum, float& a, float& pct, bool& retune, float& lfo, uint32_t tab = 0u,
-                                 uint32_t ltab = 0u, double tab_mod = 0.0, float tab_lfo = 0.0f) {
+                                 uint32_t ltab = 0u, double tab_mod = 0.0, float tab_lfo = 0.0f, float tab_amp = 0.0f) {
   static_assert(!HOIST || (SEGMENT && !FIRST), "hoisted counters belong to a segment");
   if (SEGMENT && HOIST) {
     // env_shape with the segment's constants (welsh_segment_start_hoisted): two operations per envelope and frame
-    // (Round 6 also tried the AMPLITUDE envelope's value in the table — three instructions a frame less, one more word per entry:
-    // 0.362 - 0.373 against 0.354 - 0.357 ms per block in one job, tools/ab_bench.sh.  Lost; the envelope stays in the lane.)
-    s.amp.value = env_shape(sc.ta, s.amp.A, sc.ac1, sc.ac2);
-    sc.ta += 1.0f;
+    // (The amplitude envelope's value from the table was first tried with a flag and a branch of its own, before the frame loop ran in
+    // chunks: 0.362 - 0.373 against 0.354 - 0.357 ms per block in one job.  Lost in that form; AMPTAB rides on `tab`.)
+    if (!AMPTAB) { s.amp.value = env_shape(sc.ta, s.amp.A, sc.ac1, sc.ac2); sc.ta += 1.0f; }
     if (welsh_tab_off(tab)) {
+      if (AMPTAB) { s.amp.value = env_shape(sc.ta, s.amp.A, sc.ac1, sc.ac2); sc.ta += 1.0f; }
       s.fil.value = env_shape(sc.tf, s.fil.A, sc.fc1, sc.fc2); sc.tf += 1.0f;
 #if defined(__HIP_DEVICE_COMPILE__)
       // keeps `tab` a scalar BRANCH: if-converted, a table frame still evaluated the envelope and the percent and selected them away
       asm volatile("" : "+v"(s.fil.value));
+      if (AMPTAB) asm volatile("" : "+v"(s.amp.value));
 #endif
+    } else if (AMPTAB) {
+      s.amp.value = tab_amp;
     }
   } else if (SEGMENT) {
     env_advance(s.amp);
@@ -1181,14 +1186,14 @@ GROOVE_HD void welsh_frame_back(const WelshParams& p, Lp24StateD& filt, const Lp
 // after the segment (welsh_segment_end) — and an unused LFO's phase moves there too: two conversions, two integer
 // adds and a 64-bit add less on every frame.
 template <bool FIRST, bool RETUNE, int LFO_MODE = LFO_F64, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool SEGMENT = false, bool REST = false,
-          bool HOIST = false, bool F32FILT = false>
+          bool HOIST = false, bool F32FILT = false, bool AMPTAB = false>
 GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc,
-                           WelshScratch& sc, float& L, float& R, uint32_t tab = 0u, uint32_t ltab = 0u, double tab_mod = 0.0, float tab_lfo = 0.0f) {
+                           WelshScratch& sc, float& L, float& R, uint32_t tab = 0u, uint32_t ltab = 0u, double tab_mod = 0.0, float tab_lfo = 0.0f, float tab_amp = 0.0f) {
   static_assert(!(F32FILT && LFO_MODE == LFO_F64), "the exact-f64 kinds (resonance routing) keep the f64 filter");
   float sum, a, pct, lfo;
   bool retune;
   // (tab: the caller has put this frame's coefficients into sc.coef / sc.coef_f already — kernels.h "coefficient look-ahead")
-  if (!welsh_frame_front<FIRST, RETUNE, LFO_MODE, C1, C2, CL, SEGMENT, REST, HOIST>(p, s, sc, sum, a, pct, retune, lfo, tab, ltab, tab_mod, tab_lfo)) { L = 0.0f; R = 0.0f; return; }
+  if (!welsh_frame_front<FIRST, RETUNE, LFO_MODE, C1, C2, CL, SEGMENT, REST, HOIST, AMPTAB>(p, s, sc, sum, a, pct, retune, lfo, tab, ltab, tab_mod, tab_lfo, tab_amp)) { L = 0.0f; R = 0.0f; return; }
   if constexpr (F32FILT) { // sc.coef_f / sc.filt_f were set by welsh_scratch_f32_begin; the caller hands the state back with welsh_scratch_f32_end
     if (RETUNE && welsh_tab_off(tab)) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -80,6 +80,13 @@ __device__ __forceinline__ void soa_store(uint32_t* __restrict__ buf, uint32_t n
 #ifndef GROOVE_WHOLE_WAVE_PATH
 #define GROOVE_WHOLE_WAVE_PATH 0 /* run_frames_segmented: a second copy of the frame for waves whose 64 lanes all sound (A/B builds) */
 #endif
+#ifndef GROOVE_AMP_IN_TABLE
+#define GROOVE_AMP_IN_TABLE 0 /* 1: the retuned kinds' table entries carry the amplitude envelope's value of the frame too (TabLayout::kAmp, welsh_frame's AMPTAB: the
+                                 table flag then also asks for a shared amplitude stage).  Three vector instructions a table frame less — and nothing on the clock, twice:
+                                 with a flag and a branch of its own before the frame loop ran in chunks (0.362 - 0.373 against 0.354 - 0.357 ms per block), and riding
+                                 on the coefficient flag after (0.3464 - 0.3512 against 0.3483 - 0.3502; library 0.3469 - 0.3565 against 0.3494 - 0.3533; one job each,
+                                 tools/ab_bench.sh).  The frame is not short of issue slots at that point; left in the source, off. */
+#endif
 #ifndef GROOVE_LFO_LOOKAHEAD
 #define GROOVE_LFO_LOOKAHEAD 1 /* the smooth-f64 kinds' LFO look-ahead (below, "LFO look-ahead"); 0: every lane advances its LFO's recurrences (A/B builds) */
 #endif
@@ -382,7 +389,7 @@ struct CoefTab {
   // One entry per frame: the six coefficients (f64: 48 bytes; f32 in the fp32-filter bodies: 24) where the kind retunes, then `mod`
   // (8 bytes) in the smooth-f64 kinds; an fp32 entry without `mod` is padded to 32 bytes (a power of two: its address is then a scalar
   // AND and one vector add instead of a 64-bit multiply-add per frame).  3.5 KiB per wave at most.
-  static constexpr uint32_t kMaxEntry = 56;
+  static constexpr uint32_t kMaxEntry = 56; // (64 would take the per-kind kernels' LDS over a fifth of the CU's: four workgroups per CU instead of five)
   static __device__ __forceinline__ double* wave_base() {
     __shared__ double t[kWaves][kFrames][kMaxEntry / 8];
     return &t[threadIdx.x >> 6][0][0];
@@ -411,22 +418,28 @@ struct CoefTab {
     for (uint32_t k = 0; k < sizeof(T) / 4; ++k) w[k] = t.w[k];
   }
 };
-// The layout of a kind's entries.
-template <bool F32, bool COEF, bool LFO> struct TabLayout {
+// The layout of a kind's entries: [coefficients][LFO: `mod` (f64, smooth kinds) or the fp32 value][amplitude envelope's value (fp32)].
+// The amplitude value rides along where the entry stays within kMaxEntry (not the smooth-f64 kinds' f64-filter bodies: five workgroups'
+// tables and bus tiles fill a CU's 160 KiB of LDS to within 10 KiB).
+template <bool F32, bool COEF, bool LFO, bool SMOOTH> struct TabLayout {
   static constexpr uint32_t kCoef = COEF ? (F32 ? (uint32_t)sizeof(Lp24CoefF) : (uint32_t)sizeof(Lp24CoefD)) : 0u;
   static constexpr uint32_t kModOff = kCoef;
-  static constexpr uint32_t kStride = LFO ? kCoef + 8u : (F32 ? 32u : (uint32_t)sizeof(Lp24CoefD));
-  static_assert(kStride <= CoefTab::kMaxEntry && kCoef % 8 == 0, "entry layout");
+  static constexpr uint32_t kLfo = LFO ? (SMOOTH ? 8u : 4u) : 0u;
+  static constexpr uint32_t kAmpOff = kCoef + kLfo;
+  static constexpr bool kAmp = COEF && GROOVE_AMP_IN_TABLE && kAmpOff + 4u <= CoefTab::kMaxEntry;
+  static constexpr uint32_t kRaw = (kAmpOff + (kAmp ? 4u : 0u) + 7u) & ~7u;
+  static constexpr uint32_t kStride = F32 && COEF && kRaw <= 32u ? 32u : kRaw; // (a power of two where it costs nothing)
+  static_assert(kStride <= CoefTab::kMaxEntry && kCoef % 8 == 0, "entry layout"); // (stride 0: a kind without a table)
 };
 // Do the live lanes of this wave share the filter envelope's stage (-> tab)?  The LFO's phase (-> ltab)?  Then their description,
 // from the first live lane, in SGPRs.  tab / ltab: 0 / 1 the compiler KNOWS to be in an SGPR (readfirstlane).
 // cut: the coefficients follow the LFO (an LFO-swept cutoff in an F32 kind), not the filter envelope.
-struct WaveUniform { float A, c1, c2, tf; uint32_t lph_lo, lph_hi; uint32_t tab, ltab, cut; };
+struct WaveUniform { float A, c1, c2, tf; float aA, a1, a2, ta; uint32_t lph_lo, lph_hi; uint32_t tab, ltab, cut; };
 __device__ __forceinline__ float lane_value(float x, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane)); }
 __device__ __forceinline__ bool same_bits(float a, float b) { return __builtin_bit_cast(uint32_t, a) == __builtin_bit_cast(uint32_t, b); }
-template <bool COEF, bool LFO, int LFO_MODE, int CL>
+template <bool COEF, bool LFO, int LFO_MODE, int CL, bool AMP>
 __device__ __forceinline__ WaveUniform wave_uniform(const WelshParams& p, const WelshState& s, const WelshScratch& sc, bool live, uint32_t look) {
-  WaveUniform u{0.0f, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u, 0u, 0u};
+  WaveUniform u{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u, 0u, 0u};
   const uint64_t mask = __ballot(live);
   if (mask == 0) return u;
   const int l0 = __builtin_ctzll(mask); // wave-uniform
@@ -448,6 +461,13 @@ __device__ __forceinline__ WaveUniform wave_uniform(const WelshParams& p, const 
       const bool same = same_bits(s.fil.A, u.A) && same_bits(sc.fc1, u.c1) && same_bits(sc.fc2, u.c2) && same_bits(sc.tf, u.tf);
       u.tab = (uint32_t)__builtin_amdgcn_readfirstlane(__ballot(live && !same) == 0 ? 1 : 0);
     }
+    if constexpr (AMP) { // the entries carry the amplitude envelope's value: its stage must be shared as well
+      if (u.tab != 0u) {
+        u.aA = lane_value(s.amp.A, l0); u.a1 = lane_value(sc.ac1, l0); u.a2 = lane_value(sc.ac2, l0); u.ta = lane_value(sc.ta, l0);
+        const bool same = same_bits(s.amp.A, u.aA) && same_bits(sc.ac1, u.a1) && same_bits(sc.ac2, u.a2) && same_bits(sc.ta, u.ta);
+        u.tab = (uint32_t)__builtin_amdgcn_readfirstlane(__ballot(live && !same) == 0 ? 1 : 0);
+      }
+    }
   }
   return u;
 }
@@ -455,7 +475,7 @@ __device__ __forceinline__ WaveUniform wave_uniform(const WelshParams& p, const 
 // wave-uniform.)
 template <bool F32, bool COEF, bool LFO, int LFO_MODE, int CL>
 __device__ __forceinline__ void wave_tab_fill(const WelshParams& p, const RenderConsts& rc, const WaveUniform& u, uint32_t k0) {
-  typedef TabLayout<F32, COEF, LFO> Lay;
+  typedef TabLayout<F32, COEF, LFO, LFO_MODE == LFO_F64_SMOOTH> Lay;
   const uint32_t j = threadIdx.x & 63u;
   float lfo = 0.0f;
   if constexpr (LFO) {
@@ -474,6 +494,7 @@ __device__ __forceinline__ void wave_tab_fill(const WelshParams& p, const Render
       const float t = lp24_t_from_pct(pct, rc, hi);
       if constexpr (F32) CoefTab::store_of_lane(j, Lay::kStride, 0, lp24_coeff_from_t(p.fc, t, hi));
       else CoefTab::store_of_lane(j, Lay::kStride, 0, lp24_coefd_from_t(p.fc, t, hi, (p.flags & WF_COEF_WIDE) != 0));
+      if constexpr (Lay::kAmp) CoefTab::store_of_lane(j, Lay::kStride, Lay::kAmpOff, env_shape(u.ta + (float)(k0 + j), u.aA, u.a1, u.a2));
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the wave's own reads below come after these writes
@@ -497,23 +518,27 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
     if (!RETUNE) sc.coef_f = make_scalar(sc.coef_f);
     constexpr bool COEF_LA = RETUNE && GROOVE_COEF_LOOKAHEAD;
     constexpr bool LFO_LA = LFO_MODE != LFO_F64 && CL != LFO_UNUSED && GROOVE_LFO_LOOKAHEAD;
-    typedef TabLayout<true, COEF_LA, LFO_LA> Lay;
-    WaveUniform fu{0.0f, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u, 0u, 0u}; // this segment's look-aheads (fu.tab, fu.ltab are wave-uniform)
+    typedef TabLayout<true, COEF_LA, LFO_LA, LFO_MODE == LFO_F64_SMOOTH> Lay;
+    WaveUniform fu{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u, 0u, 0u}; // this segment's look-aheads (fu.tab, fu.ltab are wave-uniform)
     run_frames_segmented<FUSED>(
         frames, n, v, active, ch_stride, out, rows, prow,
         [&](float& L, float& R) { welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL, false, REST, false, true>(p, s, rc, sc, L, R); },
         [&](bool& live) { const uint32_t k = welsh_segment_begin(p, s, live); welsh_segment_start_hoisted(s, sc); return k; },
         [&](bool live, uint32_t seg) {
           fu.tab = 0u; fu.ltab = 0u;
-          if constexpr (COEF_LA || LFO_LA) { if (seg >= CoefTab::kMinSegment) fu = wave_uniform<COEF_LA, LFO_LA, LFO_MODE, CL>(p, s, sc, live, rc.look); }
+          if constexpr (COEF_LA || LFO_LA) { if (seg >= CoefTab::kMinSegment) fu = wave_uniform<COEF_LA, LFO_LA, LFO_MODE, CL, Lay::kAmp>(p, s, sc, live, rc.look); }
         },
         [&](uint32_t k) { if constexpr (COEF_LA || LFO_LA) { if ((fu.tab | fu.ltab) != 0u && (k & (CoefTab::kFrames - 1)) == 0) wave_tab_fill<true, COEF_LA, LFO_LA, LFO_MODE, CL>(p, rc, fu, k); } },
         [&](uint32_t k, float& L, float& R) {
           uint32_t tab = 0u, ltab = 0u;
           double mod = 0.0;
+          float tamp = 0.0f;
           if constexpr (COEF_LA) {
             tab = fu.tab;
-            if (tab != 0u) sc.coef_f = CoefTab::load<Lp24CoefF>(k & (CoefTab::kFrames - 1), Lay::kStride);
+            if (tab != 0u) {
+              sc.coef_f = CoefTab::load<Lp24CoefF>(k & (CoefTab::kFrames - 1), Lay::kStride);
+              if constexpr (Lay::kAmp) tamp = CoefTab::load<float>(k & (CoefTab::kFrames - 1), Lay::kStride, Lay::kAmpOff);
+            }
           }
           float tlfo = 0.0f;
           if constexpr (LFO_LA) {
@@ -521,7 +546,7 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
             if constexpr (LFO_MODE == LFO_F64_SMOOTH) { if (ltab != 0u) mod = CoefTab::load<double>(k & (CoefTab::kFrames - 1), Lay::kStride, Lay::kModOff); }
             else { if (ltab != 0u && ((p.flags & WF_LFO_AMP) || tab == 0u)) tlfo = CoefTab::load<float>(k & (CoefTab::kFrames - 1), Lay::kStride, Lay::kModOff); } // (a cutoff-only LFO is in the coefficients already)
           }
-          welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true, true>(p, s, rc, sc, L, R, tab, ltab, mod, tlfo);
+          welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true, true, Lay::kAmp>(p, s, rc, sc, L, R, tab, ltab, mod, tlfo, tamp);
         },
         [&](uint32_t seg, bool live) {
           welsh_segment_end_hoisted<CL == LFO_UNUSED>(p, s, seg, live);
@@ -536,23 +561,27 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
   if constexpr (UNIFORM) {
     constexpr bool COEF_LA = RETUNE && LFO_MODE != LFO_F64 && GROOVE_COEF_LOOKAHEAD; // (the exact-f64 kind keeps its own coefficient forms: resonance routing, lp24_coefd_from_fc)
     constexpr bool LFO_LA = LFO_MODE != LFO_F64 && CL != LFO_UNUSED && GROOVE_LFO_LOOKAHEAD;
-    typedef TabLayout<false, COEF_LA, LFO_LA> Lay;
-    WaveUniform fu{0.0f, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u, 0u, 0u};
+    typedef TabLayout<false, COEF_LA, LFO_LA, LFO_MODE == LFO_F64_SMOOTH> Lay;
+    WaveUniform fu{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u, 0u, 0u};
     run_frames_segmented<FUSED>(
         frames, n, v, active, ch_stride, out, rows, prow,
         [&](float& L, float& R) { welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL, false, REST>(p, s, rc, sc, L, R); },
         [&](bool& live) { const uint32_t k = welsh_segment_begin(p, s, live); welsh_segment_start_hoisted(s, sc); return k; },
         [&](bool live, uint32_t seg) {
           fu.tab = 0u; fu.ltab = 0u;
-          if constexpr (COEF_LA || LFO_LA) { if (seg >= CoefTab::kMinSegment) fu = wave_uniform<COEF_LA, LFO_LA, LFO_MODE, CL>(p, s, sc, live, rc.look); }
+          if constexpr (COEF_LA || LFO_LA) { if (seg >= CoefTab::kMinSegment) fu = wave_uniform<COEF_LA, LFO_LA, LFO_MODE, CL, Lay::kAmp>(p, s, sc, live, rc.look); }
         },
         [&](uint32_t k) { if constexpr (COEF_LA || LFO_LA) { if ((fu.tab | fu.ltab) != 0u && (k & (CoefTab::kFrames - 1)) == 0) wave_tab_fill<false, COEF_LA, LFO_LA, LFO_MODE, CL>(p, rc, fu, k); } },
         [&](uint32_t k, float& L, float& R) {
           uint32_t tab = 0u, ltab = 0u;
           double mod = 0.0;
+          float tamp = 0.0f;
           if constexpr (COEF_LA) {
             tab = fu.tab;
-            if (tab != 0u) sc.coef = CoefTab::load<Lp24CoefD>(k & (CoefTab::kFrames - 1), Lay::kStride);
+            if (tab != 0u) {
+              sc.coef = CoefTab::load<Lp24CoefD>(k & (CoefTab::kFrames - 1), Lay::kStride);
+              if constexpr (Lay::kAmp) tamp = CoefTab::load<float>(k & (CoefTab::kFrames - 1), Lay::kStride, Lay::kAmpOff);
+            }
           }
           float tlfo = 0.0f;
           if constexpr (LFO_LA) {
@@ -560,7 +589,7 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
             if constexpr (LFO_MODE == LFO_F64_SMOOTH) { if (ltab != 0u) mod = CoefTab::load<double>(k & (CoefTab::kFrames - 1), Lay::kStride, Lay::kModOff); }
             else { if (ltab != 0u && ((p.flags & WF_LFO_AMP) || tab == 0u)) tlfo = CoefTab::load<float>(k & (CoefTab::kFrames - 1), Lay::kStride, Lay::kModOff); } // (a cutoff-only LFO is in the coefficients already)
           }
-          welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true>(p, s, rc, sc, L, R, tab, ltab, mod, tlfo);
+          welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true, false, Lay::kAmp>(p, s, rc, sc, L, R, tab, ltab, mod, tlfo, tamp);
         },
         [&](uint32_t seg, bool live) {
           welsh_segment_end_hoisted<CL == LFO_UNUSED>(p, s, seg, live);
