@@ -749,6 +749,13 @@ GROOVE_HD bool welsh_tab_off(uint32_t tab) {
 #endif
   return tab == 0u;
 }
+// ... or as what the caller KNOWS it to be: TABS (welsh_frame's template word: bit 0 `tab` is on, bit 1 `ltab` is on) — the frames of a
+// chunk whose flags are all up run in a loop of their own without the tests (kernels.h run_frames_segmented, `fast_frame`).
+template <int TABS, int BIT>
+GROOVE_HD bool welsh_tab_is_off(uint32_t tab) {
+  if constexpr ((TABS & BIT) != 0) return false;
+  else return welsh_tab_off(tab);
+}
 // The cutoff percent an envelope-retuned filter takes from its envelope's value (DSP_SPEC section 6: start + (1 - start) end env).
 GROOVE_HD float welsh_env_cutoff_pct(const WelshParams& p, float fil_value) {
   return fmaf((1.0f - p.cutoff_start) * p.cutoff_end, fil_value, p.cutoff_start);
@@ -873,7 +880,7 @@ GROOVE_HD float osc_value_classed(uint32_t w, uint64_t phase, uint64_t duty64, f
 // AMPTAB (with `tab`): the table's entries carry the AMPLITUDE envelope's value of the frame too (`tab_amp`; the caller sets `tab` only
 // where the live lanes agree on BOTH envelopes' stages): the same env_shape on the same counter, from the lane that filled the entry.
 template <bool FIRST, bool RETUNE, int LFO_MODE = LFO_F64, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool SEGMENT = false, bool REST = false,
-          bool HOIST = false, bool AMPTAB = false>
+          bool HOIST = false, bool AMPTAB = false, int TABS = 0>
 GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScratch& sc, float& sum, float& a, float& pct, bool& retune, float& lfo, uint32_t tab = 0u,
                                  uint32_t ltab = 0u, double tab_mod = 0.0, float tab_lfo = 0.0f, float tab_amp = 0.0f) {
   static_assert(!HOIST || (SEGMENT && !FIRST), "hoisted counters belong to a segment");
@@ -882,7 +889,7 @@ GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScrat
     // (The amplitude envelope's value from the table was first tried with a flag and a branch of its own, before the frame loop ran in
     // chunks: 0.362 - 0.373 against 0.354 - 0.357 ms per block in one job.  Lost in that form; AMPTAB rides on `tab`.)
     if (!AMPTAB) { s.amp.value = env_shape(sc.ta, s.amp.A, sc.ac1, sc.ac2); sc.ta += 1.0f; }
-    if (welsh_tab_off(tab)) {
+    if (welsh_tab_is_off<TABS, 1>(tab)) {
       if (AMPTAB) { s.amp.value = env_shape(sc.ta, s.amp.A, sc.ac1, sc.ac2); sc.ta += 1.0f; }
       s.fil.value = env_shape(sc.tf, s.fil.A, sc.fc1, sc.fc2); sc.tf += 1.0f;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -935,7 +942,7 @@ GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScrat
   uint64_t d1 = p.o1_duty64, d2 = p.o2_duty64;
   lfo = 0.0f;
   double mod = 0.0;
-  if (!LTAB || welsh_tab_off(ltab)) {
+  if (!LTAB || welsh_tab_is_off<TABS, 2>(ltab)) {
     if (!first && !(HOIST && NO_LFO)) s.lfo.phase += p.lfo_inc;
     if (wl == GROOVE_WAVE_NOISE) nzl = noise_tick(s.lfo);
     if (r_edge) {
@@ -1018,7 +1025,7 @@ GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScrat
   // filter cutoff
   retune = false;
   pct = 0.0f;
-  if (RETUNE && welsh_tab_off(tab)) {
+  if (RETUNE && welsh_tab_is_off<TABS, 1>(tab)) {
     // (an unused LFO cannot drive the cutoff: in a retuned kind the envelope must)
     if (CL == LFO_UNUSED || (p.flags & WF_RETUNE_ENV)) {
       pct = welsh_env_cutoff_pct(p, s.fil.value);
@@ -1186,16 +1193,16 @@ GROOVE_HD void welsh_frame_back(const WelshParams& p, Lp24StateD& filt, const Lp
 // after the segment (welsh_segment_end) — and an unused LFO's phase moves there too: two conversions, two integer
 // adds and a 64-bit add less on every frame.
 template <bool FIRST, bool RETUNE, int LFO_MODE = LFO_F64, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool SEGMENT = false, bool REST = false,
-          bool HOIST = false, bool F32FILT = false, bool AMPTAB = false>
+          bool HOIST = false, bool F32FILT = false, bool AMPTAB = false, int TABS = 0>
 GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderConsts& rc,
                            WelshScratch& sc, float& L, float& R, uint32_t tab = 0u, uint32_t ltab = 0u, double tab_mod = 0.0, float tab_lfo = 0.0f, float tab_amp = 0.0f) {
   static_assert(!(F32FILT && LFO_MODE == LFO_F64), "the exact-f64 kinds (resonance routing) keep the f64 filter");
   float sum, a, pct, lfo;
   bool retune;
   // (tab: the caller has put this frame's coefficients into sc.coef / sc.coef_f already — kernels.h "coefficient look-ahead")
-  if (!welsh_frame_front<FIRST, RETUNE, LFO_MODE, C1, C2, CL, SEGMENT, REST, HOIST, AMPTAB>(p, s, sc, sum, a, pct, retune, lfo, tab, ltab, tab_mod, tab_lfo, tab_amp)) { L = 0.0f; R = 0.0f; return; }
+  if (!welsh_frame_front<FIRST, RETUNE, LFO_MODE, C1, C2, CL, SEGMENT, REST, HOIST, AMPTAB, TABS>(p, s, sc, sum, a, pct, retune, lfo, tab, ltab, tab_mod, tab_lfo, tab_amp)) { L = 0.0f; R = 0.0f; return; }
   if constexpr (F32FILT) { // sc.coef_f / sc.filt_f were set by welsh_scratch_f32_begin; the caller hands the state back with welsh_scratch_f32_end
-    if (RETUNE && welsh_tab_off(tab)) {
+    if (RETUNE && welsh_tab_is_off<TABS, 1>(tab)) {
 #if defined(__HIP_DEVICE_COMPILE__)
       if (HOIST) asm volatile("" : "+v"(pct)); // (the comparison below stays inside this branch)
 #endif
@@ -1204,7 +1211,7 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
     const float m = lp24_step_f32<SEGMENT && !RETUNE>(sc.filt_f, sc.coef_f, sum) * a; // uniform static kinds: coefficients in SGPRs
     L = m * p.gl; R = m * p.gr;
   } else {
-    if (welsh_tab_off(tab)) {
+    if (welsh_tab_is_off<TABS, 1>(tab)) {
 #if defined(__HIP_DEVICE_COMPILE__)
       if (HOIST && RETUNE) asm volatile("" : "+v"(pct));
 #endif

@@ -80,6 +80,9 @@ __device__ __forceinline__ void soa_store(uint32_t* __restrict__ buf, uint32_t n
 #ifndef GROOVE_WHOLE_WAVE_PATH
 #define GROOVE_WHOLE_WAVE_PATH 0 /* run_frames_segmented: a second copy of the frame for waves whose 64 lanes all sound (A/B builds) */
 #endif
+#ifndef GROOVE_FAST_TABLE_LOOP
+#define GROOVE_FAST_TABLE_LOOP 1 /* segments whose look-aheads are all up run a frame loop of their own, compiled without the flag tests (run_frames_segmented `fast`); 0: one loop (A/B builds) */
+#endif
 #ifndef GROOVE_AMP_IN_TABLE
 #define GROOVE_AMP_IN_TABLE 0 /* 1: the retuned kinds' table entries carry the amplitude envelope's value of the frame too (TabLayout::kAmp, welsh_frame's AMPTAB: the
                                  table flag then also asks for a shared amplitude stage).  Three vector instructions a table frame less — and nothing on the clock, twice:
@@ -275,10 +278,15 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
 // is 0 all the same — it counts (diag.h) — and the segment is then one frame, which is what the checked form would do.
 // `setup(live, seg)` runs once per segment (wave-uniformly: every lane of the wave is in it) once the segment's length is known, and
 // `pre(k)` before frames k, k + 64, ... of the segment, outside the `live` test: the look-ahead tables' fill (welsh_block).
-template <bool FUSED, class FirstFn, class BeginFn, class SetupFn, class PreFn, class LiveFn, class EndFn, class ZeroFn>
+// `fast()` (wave-uniform, asked once per segment after `setup`): every look-ahead this kind has is up for the segment — its frames then
+// run `fast_frame`, the frame compiled with the table flags as constants (dsp_core.h welsh_frame's TABS), in a loop of their own: no
+// flag tests, no taken branches round the code they guard.  (Why it matters: the instruction cache.  SQC_ICACHE_BUSY_CYCLES / SQ_CYCLES
+// of the million-voice window was 0.85 with the flags tested in the frame — tools/diag_pmc.sh —: forty wavefronts per cache fetch a
+// stream in which every tenth instruction is a branch, half of them taken.)
+template <bool FUSED, class FirstFn, class BeginFn, class SetupFn, class PreFn, class LiveFn, class FastFn, class FastFrameFn, class EndFn, class ZeroFn>
 __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n, uint32_t v, bool active, size_t ch_stride,
                                                      float* __restrict__ out, float* __restrict__ rows, uint32_t prow, FirstFn&& first, BeginFn&& begin,
-                                                     SetupFn&& setup, PreFn&& pre, LiveFn&& live_frame, EndFn&& end, ZeroFn&& on_zero) {
+                                                     SetupFn&& setup, PreFn&& pre, LiveFn&& live_frame, FastFn&& fast, FastFrameFn&& fast_frame, EndFn&& end, ZeroFn&& on_zero) {
   if (frames == 0) return;
   constexpr uint32_t C = FusedAcc::kChunk;
   static_assert(C > 1, "frame 0 never completes a chunk");
@@ -327,13 +335,22 @@ __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n
     }
 #else
     // in chunks of CoefTab::kFrames frames: `pre` (the look-ahead tables' fill: long, cold code) stays out of the frame loop proper
+    const bool all_tables = fast();
     for (uint32_t k0 = 0; k0 < seg; k0 += 64u) {
       pre(k0);
       const uint32_t k1 = min(seg, k0 + 64u);
-      for (uint32_t k = k0; k < k1; ++k, ++f) {
-        float L = 0.0f, R = 0.0f;
-        if (live) live_frame(k, L, R);
-        put(f, L, R);
+      if (all_tables) {
+        for (uint32_t k = k0; k < k1; ++k, ++f) {
+          float L = 0.0f, R = 0.0f;
+          if (live) fast_frame(k, L, R);
+          put(f, L, R);
+        }
+      } else {
+        for (uint32_t k = k0; k < k1; ++k, ++f) {
+          float L = 0.0f, R = 0.0f;
+          if (live) live_frame(k, L, R);
+          put(f, L, R);
+        }
       }
     }
 #endif
@@ -548,6 +565,25 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
           }
           welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true, true, Lay::kAmp>(p, s, rc, sc, L, R, tab, ltab, mod, tlfo, tamp);
         },
+        [&]() { // fast(): every look-ahead of this kind is up.  (The F32 kinds' fp32-filter bodies only: in the others the second loop costs
+                // registers — 2 - 20 scratch accesses per frame in one loop or the other, and 0.3438 -> 0.3607 ms per block with it everywhere.)
+          if constexpr (!(COEF_LA || LFO_LA) || !GROOVE_FAST_TABLE_LOOP || LFO_MODE != LFO_F32) return false;
+          else return __builtin_amdgcn_readfirstlane((int)((!COEF_LA || fu.tab != 0u) && (!LFO_LA || fu.ltab != 0u))) != 0;
+        },
+        [&](uint32_t k, float& L, float& R) {
+          constexpr int TABS = (COEF_LA ? 1 : 0) | (LFO_LA ? 2 : 0);
+          double mod = 0.0;
+          float tlfo = 0.0f, tamp = 0.0f;
+          if constexpr (COEF_LA) {
+            sc.coef_f = CoefTab::load<Lp24CoefF>(k & (CoefTab::kFrames - 1), Lay::kStride);
+            if constexpr (Lay::kAmp) tamp = CoefTab::load<float>(k & (CoefTab::kFrames - 1), Lay::kStride, Lay::kAmpOff);
+          }
+          if constexpr (LFO_LA) {
+            if constexpr (LFO_MODE == LFO_F64_SMOOTH) mod = CoefTab::load<double>(k & (CoefTab::kFrames - 1), Lay::kStride, Lay::kModOff);
+            else { if (!COEF_LA || (p.flags & WF_LFO_AMP)) tlfo = CoefTab::load<float>(k & (CoefTab::kFrames - 1), Lay::kStride, Lay::kModOff); }
+          }
+          welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true, true, Lay::kAmp, TABS>(p, s, rc, sc, L, R, 1u, 1u, mod, tlfo, tamp);
+        },
         [&](uint32_t seg, bool live) {
           welsh_segment_end_hoisted<CL == LFO_UNUSED>(p, s, seg, live);
           if constexpr (COEF_LA) { if (fu.tab != 0u) { if (live) s.fil.value = env_last_value_of(s.fil); sc.prev_pct = __builtin_nanf(""); } }
@@ -590,6 +626,24 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
             else { if (ltab != 0u && ((p.flags & WF_LFO_AMP) || tab == 0u)) tlfo = CoefTab::load<float>(k & (CoefTab::kFrames - 1), Lay::kStride, Lay::kModOff); } // (a cutoff-only LFO is in the coefficients already)
           }
           welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true, false, Lay::kAmp>(p, s, rc, sc, L, R, tab, ltab, mod, tlfo, tamp);
+        },
+        [&]() { // (the f64-filter bodies keep one loop: see the fp32-filter copy above)
+          if constexpr (true) return false;
+          else return __builtin_amdgcn_readfirstlane((int)((!COEF_LA || fu.tab != 0u) && (!LFO_LA || fu.ltab != 0u))) != 0;
+        },
+        [&](uint32_t k, float& L, float& R) {
+          constexpr int TABS = (COEF_LA ? 1 : 0) | (LFO_LA ? 2 : 0);
+          double mod = 0.0;
+          float tlfo = 0.0f, tamp = 0.0f;
+          if constexpr (COEF_LA) {
+            sc.coef = CoefTab::load<Lp24CoefD>(k & (CoefTab::kFrames - 1), Lay::kStride);
+            if constexpr (Lay::kAmp) tamp = CoefTab::load<float>(k & (CoefTab::kFrames - 1), Lay::kStride, Lay::kAmpOff);
+          }
+          if constexpr (LFO_LA) {
+            if constexpr (LFO_MODE == LFO_F64_SMOOTH) mod = CoefTab::load<double>(k & (CoefTab::kFrames - 1), Lay::kStride, Lay::kModOff);
+            else { if (!COEF_LA || (p.flags & WF_LFO_AMP)) tlfo = CoefTab::load<float>(k & (CoefTab::kFrames - 1), Lay::kStride, Lay::kModOff); }
+          }
+          welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true, false, Lay::kAmp, TABS>(p, s, rc, sc, L, R, 1u, 1u, mod, tlfo, tamp);
         },
         [&](uint32_t seg, bool live) {
           welsh_segment_end_hoisted<CL == LFO_UNUSED>(p, s, seg, live);
