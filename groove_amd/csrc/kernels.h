@@ -81,7 +81,10 @@ __device__ __forceinline__ void soa_store(uint32_t* __restrict__ buf, uint32_t n
 #define GROOVE_WHOLE_WAVE_PATH 0 /* run_frames_segmented: a second copy of the frame for waves whose 64 lanes all sound (A/B builds) */
 #endif
 #ifndef GROOVE_FAST_TABLE_LOOP
-#define GROOVE_FAST_TABLE_LOOP 1 /* segments whose look-aheads are all up run a frame loop of their own, compiled without the flag tests (run_frames_segmented `fast`); 0: one loop (A/B builds) */
+#define GROOVE_FAST_TABLE_LOOP 1 /* segments whose look-aheads are all up run a frame loop of their own, compiled without the flag tests (run_frames_segmented `fast`):
+                                    1 in the F32 kinds' fp32-filter bodies; 2 also in the smooth-f64 kinds' fp32-filter bodies with a sine / triangle LFO (no scratch access in
+                                    either loop, and nothing on the clock: 0.3367 - 0.3419 against 0.3344 - 0.3383 ms per block); 3 also in the F32 kinds' f64-filter bodies (the
+                                    library-proportioned bank 0.348 -> 0.387: their other loop spills); 0: one loop everywhere.  One job each, tools/ab_bench.sh. */
 #endif
 #ifndef GROOVE_AMP_IN_TABLE
 #define GROOVE_AMP_IN_TABLE 0 /* 1: the retuned kinds' table entries carry the amplitude envelope's value of the frame too (TabLayout::kAmp, welsh_frame's AMPTAB: the
@@ -567,7 +570,7 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
         },
         [&]() { // fast(): every look-ahead of this kind is up.  (The F32 kinds' fp32-filter bodies only: in the others the second loop costs
                 // registers — 2 - 20 scratch accesses per frame in one loop or the other, and 0.3438 -> 0.3607 ms per block with it everywhere.)
-          if constexpr (!(COEF_LA || LFO_LA) || !GROOVE_FAST_TABLE_LOOP || LFO_MODE != LFO_F32) return false;
+          if constexpr (!(COEF_LA || LFO_LA) || !GROOVE_FAST_TABLE_LOOP || !(LFO_MODE == LFO_F32 || (GROOVE_FAST_TABLE_LOOP >= 2 && CL != OSC_ANY))) return false;
           else return __builtin_amdgcn_readfirstlane((int)((!COEF_LA || fu.tab != 0u) && (!LFO_LA || fu.ltab != 0u))) != 0;
         },
         [&](uint32_t k, float& L, float& R) {
@@ -628,7 +631,7 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
           welsh_frame<false, RETUNE, LFO_MODE, C1, C2, CL, true, REST, true, false, Lay::kAmp>(p, s, rc, sc, L, R, tab, ltab, mod, tlfo, tamp);
         },
         [&]() { // (the f64-filter bodies keep one loop: see the fp32-filter copy above)
-          if constexpr (true) return false;
+          if constexpr (!(COEF_LA || LFO_LA) || GROOVE_FAST_TABLE_LOOP < 3 || LFO_MODE != LFO_F32) return false;
           else return __builtin_amdgcn_readfirstlane((int)((!COEF_LA || fu.tab != 0u) && (!LFO_LA || fu.ltab != 0u))) != 0;
         },
         [&](uint32_t k, float& L, float& R) {
