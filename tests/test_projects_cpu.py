@@ -229,7 +229,7 @@ def test_bench_line_reads_the_profile_of_its_own_window():
     ms = win["valu_per_step"] / 0.6 / bench.VALU_ISSUE_PER_S * 1e3        # a step at 0.6 of the spec issue rate of THIS profile's instruction count
     r = bench.roofline_block("welsh-1m", 1_000_000, ms, True, True, window=(20, 5))
     assert r["bound"] == "valu-issue" and r["traffic_same_window"] is True
-    assert 0.9 < r["frac"] < 2.0 and 0.05 < r["hbm_physical_frac"] < 0.25           # effective (can exceed 1) vs physical
+    assert 0.9 < r["frac"] < 2.6 and 0.05 < r["hbm_physical_frac"] < 0.35           # effective (can exceed 1: the fewer instructions a step needs, the higher) vs physical
     assert 0.55 < r["valu"]["achieved_frac"] < 0.65 and 0.7 < r["valu"]["cost_weighted_frac"]["low"] <= r["valu"]["cost_weighted_frac"]["high"] < 1.3
     lat = bench.roofline_block("sampler-16384", 16384, 0.0166, True, True)
     assert lat["bound"].startswith("latency") and lat["hbm_physical_frac"] < 0.25

@@ -17,37 +17,39 @@ schedule of this instruction stream can finish: bench.py reports step time again
 import os
 import re
 
-# (class, asm, accumulator type, [(constraint, type, value)], count per 100 in round 4, ... in round 5, ... in round 6)
+# (class, asm, accumulator type, [(constraint, type, value)], count per 100 in round 4, ... in round 5, ... in round 6 before the LFO look-ahead (MIX_ROUND=60), ... at the end of round 6)
 # Round 5 (profiles/r05_welsh-1m-window_summary.json: 20 (19 since the last build) of the 32 patches run the filter in fp32, docs/DSP_SPEC.md section 11):
 # 3.69e8 -> 3.37e8 wave-instructions per step, of which f64 20.8 -> 12.4 %, conversions 9.3 -> 6.3 %, fp32 add / mul / fma 44.6 -> 54.6 %,
 # everything else 16.4 -> 16.9 %, transcendental 2.1 -> 2.3 %, 64-bit integer 4.3 -> 4.7 %, 32-bit integer 2.6 -> 2.8 % (the fp32 step in
 # three-operand assembly and the polynomial envelopes took instructions out; the shares of what stayed grew).
 _MIX_BOTH = [
-    ("f64_add", "v_add_f64 %0, %1, %0", "double", [("v", "double", "1.0001")], 6, 3, 3),
-    ("f64_mul", "v_mul_f64 %0, %1, %0", "double", [("v", "double", "1.0001")], 4, 3, 4),
-    ("f64_fma", "v_fma_f64 %0, %1, %2, %0", "double", [("v", "double", "1.0001"), ("v", "double", "0.5")], 11, 6, 8),
-    ("cvt_f64_f32", "v_cvt_f64_f32 %0, %1", "double", [("v", "float", "1.5f")], 3, 2, 3),
-    ("cvt_f32_f64", "v_cvt_f32_f64 %0, %1", "float", [("v", "double", "1.5")], 3, 2, 2),
-    ("cvt_f32_u32", "v_cvt_f32_u32 %0, %1", "float", [("v", "unsigned", "3u")], 3, 2, 2),
-    ("trans_exp", "v_exp_f32 %0, %1", "float", [("v", "float", "0.5f")], 1, 1, 0),
-    ("trans_rcp", "v_rcp_f32 %0, %1", "float", [("v", "float", "1.5f")], 1, 1, 1),
-    ("int64", "v_lshl_add_u64 %0, %0, 0, %1", "unsigned long long", [("v", "unsigned long long", "3ull")], 4, 5, 7),
-    ("int32", "v_add_u32 %0, %1, %0", "unsigned", [("v", "unsigned", "3u")], 3, 3, 4),
-    ("f32_add", "v_add_f32 %0, %1, %0", "float", [("v", "float", "1.0001f")], 10, 12, 10),
-    ("f32_mul", "v_mul_f32 %0, %1, %0", "float", [("v", "float", "1.0001f")], 14, 15, 11),
-    ("f32_fma", "v_fma_f32 %0, %1, %2, %0", "float", [("v", "float", "1.0001f"), ("v", "float", "0.5f")], 12, 18, 15),
-    ("f32_add_s", "v_add_f32 %0, %1, %0", "float", [("s", "float", "1.0001f")], 2, 2, 2),
-    ("f32_mul_s", "v_mul_f32 %0, %1, %0", "float", [("s", "float", "1.0001f")], 4, 4, 3),
-    ("f32_fma_s", "v_fma_f32 %0, %1, %2, %0", "float", [("s", "float", "1.0001f"), ("v", "float", "0.5f")], 3, 4, 4),
-    ("mov", "v_mov_b32 %0, %1", "float", [("v", "float", "1.5f")], 8, 8, 8),
-    ("cndmask", "v_cndmask_b32 %0, %1, %0, vcc", "unsigned", [("v", "unsigned", "3u")], 4, 4, 6),
-    ("cmp", "v_cmp_lt_u32 vcc, %0, %1", "unsigned", [("v", "unsigned", "3u")], 4, 5, 7),
+    ("f64_add", "v_add_f64 %0, %1, %0", "double", [("v", "double", "1.0001")], 6, 3, 3, 2),
+    ("f64_mul", "v_mul_f64 %0, %1, %0", "double", [("v", "double", "1.0001")], 4, 3, 4, 3),
+    ("f64_fma", "v_fma_f64 %0, %1, %2, %0", "double", [("v", "double", "1.0001"), ("v", "double", "0.5")], 11, 6, 8, 6),
+    ("cvt_f64_f32", "v_cvt_f64_f32 %0, %1", "double", [("v", "float", "1.5f")], 3, 2, 3, 3),
+    ("cvt_f32_f64", "v_cvt_f32_f64 %0, %1", "float", [("v", "double", "1.5")], 3, 2, 2, 2),
+    ("cvt_f32_u32", "v_cvt_f32_u32 %0, %1", "float", [("v", "unsigned", "3u")], 3, 2, 2, 3),
+    ("trans_exp", "v_exp_f32 %0, %1", "float", [("v", "float", "0.5f")], 1, 1, 0, 0),
+    ("trans_rcp", "v_rcp_f32 %0, %1", "float", [("v", "float", "1.5f")], 1, 1, 1, 0),
+    ("int64", "v_lshl_add_u64 %0, %0, 0, %1", "unsigned long long", [("v", "unsigned long long", "3ull")], 4, 5, 7, 8),
+    ("int32", "v_add_u32 %0, %1, %0", "unsigned", [("v", "unsigned", "3u")], 3, 3, 4, 6),
+    ("f32_add", "v_add_f32 %0, %1, %0", "float", [("v", "float", "1.0001f")], 10, 12, 10, 10),
+    ("f32_mul", "v_mul_f32 %0, %1, %0", "float", [("v", "float", "1.0001f")], 14, 15, 11, 12),
+    ("f32_fma", "v_fma_f32 %0, %1, %2, %0", "float", [("v", "float", "1.0001f"), ("v", "float", "0.5f")], 12, 18, 15, 15),
+    ("f32_add_s", "v_add_f32 %0, %1, %0", "float", [("s", "float", "1.0001f")], 2, 2, 2, 3),
+    ("f32_mul_s", "v_mul_f32 %0, %1, %0", "float", [("s", "float", "1.0001f")], 4, 4, 3, 3),
+    ("f32_fma_s", "v_fma_f32 %0, %1, %2, %0", "float", [("s", "float", "1.0001f"), ("v", "float", "0.5f")], 3, 4, 4, 3),
+    ("mov", "v_mov_b32 %0, %1", "float", [("v", "float", "1.5f")], 8, 8, 8, 8),
+    ("cndmask", "v_cndmask_b32 %0, %1, %0, vcc", "unsigned", [("v", "unsigned", "3u")], 4, 4, 6, 6),
+    ("cmp", "v_cmp_lt_u32 vcc, %0, %1", "unsigned", [("v", "unsigned", "3u")], 4, 5, 7, 7),
 ]
 # Round 6 (profiles/r06_welsh-1m-window_summary.json: the coefficient look-ahead took the retune out of most frames — 3.39e8 -> 2.55e8
 # wave-instructions per step): transcendental 2.3 -> 0.4 %, f64 12.4 -> 15.0 %, conversions 6.3 -> 7.1 %, 64-bit integer 4.7 -> 7.3 %,
 # 32-bit integer 2.8 -> 3.8 %, fp32 add / mul / fma 54.6 -> 45.3 %, everything else 16.9 -> 21.1 % (the shares of what stayed grew).
-ROUND = int(os.environ.get("MIX_ROUND", "6"))   # MIX_ROUND=4 / 5 regenerate the earlier rounds' kernels (profiles/r04_mix_bound.json, r05_)
-MIX = [m[:4] + (m[4] if ROUND == 4 else m[5] if ROUND == 5 else m[6],) for m in _MIX_BOTH]
+# End of round 6 (the same file, retaken: the LFO look-ahead and the table frames' own loop — 2.34e8 -> 2.05e8 wave-instructions per step): f64 16.3 -> 11.2 %,
+# conversions 7.8 -> 8.1 %, transcendental 0.4 -> 0.1 %, 64-bit integer 8.0 -> 7.6 %, 32-bit integer 4.1 -> 6.0 %, fp32 add / mul / fma 44.7 -> 45.5 %, everything else 18.7 -> 21.5 %.
+ROUND = int(os.environ.get("MIX_ROUND", "6"))   # MIX_ROUND=4 / 5 / 60 regenerate the earlier kernels (profiles/r04_mix_bound.json, r05_, round 6 before the LFO look-ahead)
+MIX = [m[:4] + (m[4] if ROUND == 4 else m[5] if ROUND == 5 else m[6] if ROUND == 60 else m[7],) for m in _MIX_BOTH]
 # MIX_NO_SGPR=1: the same mix with every SGPR operand of an fp32 instruction replaced by a VGPR (what the bound would be if the kernels
 # kept their wave-uniform constants in vector registers; written to mix_bound_nosgpr.hip)
 NO_SGPR = os.environ.get("MIX_NO_SGPR", "0") == "1"
