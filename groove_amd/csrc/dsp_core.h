@@ -880,7 +880,7 @@ GROOVE_HD float osc_value_classed(uint32_t w, uint64_t phase, uint64_t duty64, f
 // AMPTAB (with `tab`): the table's entries carry the AMPLITUDE envelope's value of the frame too (`tab_amp`; the caller sets `tab` only
 // where the live lanes agree on BOTH envelopes' stages): the same env_shape on the same counter, from the lane that filled the entry.
 template <bool FIRST, bool RETUNE, int LFO_MODE = LFO_F64, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool SEGMENT = false, bool REST = false,
-          bool HOIST = false, bool AMPTAB = false, int TABS = 0>
+          bool HOIST = false, bool AMPTAB = false, int TABS = 0, bool NO_PCT = false>
 GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScratch& sc, float& sum, float& a, float& pct, bool& retune, float& lfo, uint32_t tab = 0u,
                                  uint32_t ltab = 0u, double tab_mod = 0.0, float tab_lfo = 0.0f, float tab_amp = 0.0f) {
   static_assert(!HOIST || (SEGMENT && !FIRST), "hoisted counters belong to a segment");
@@ -889,7 +889,10 @@ GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScrat
     // (The amplitude envelope's value from the table was first tried with a flag and a branch of its own, before the frame loop ran in
     // chunks: 0.362 - 0.373 against 0.354 - 0.357 ms per block in one job.  Lost in that form; AMPTAB rides on `tab`.)
     if (!AMPTAB) { s.amp.value = env_shape(sc.ta, s.amp.A, sc.ac1, sc.ac2); sc.ta += 1.0f; }
-    if (welsh_tab_is_off<TABS, 1>(tab)) {
+    // NO_PCT (welsh_frame's retuned HOIST frames): the filter envelope, the cutoff percent and the coefficients are one block behind ONE
+    // test of `tab` there, not three tests here and there (each test three scalar instructions and, on a table frame, a taken branch)
+    if (NO_PCT) {
+    } else if (welsh_tab_is_off<TABS, 1>(tab)) {
       if (AMPTAB) { s.amp.value = env_shape(sc.ta, s.amp.A, sc.ac1, sc.ac2); sc.ta += 1.0f; }
       s.fil.value = env_shape(sc.tf, s.fil.A, sc.fc1, sc.fc2); sc.tf += 1.0f;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1025,7 +1028,7 @@ GROOVE_HD bool welsh_frame_front(const WelshParams& p, WelshState& s, WelshScrat
   // filter cutoff
   retune = false;
   pct = 0.0f;
-  if (RETUNE && welsh_tab_is_off<TABS, 1>(tab)) {
+  if (RETUNE && !NO_PCT && welsh_tab_is_off<TABS, 1>(tab)) {
     // (an unused LFO cannot drive the cutoff: in a retuned kind the envelope must)
     if (CL == LFO_UNUSED || (p.flags & WF_RETUNE_ENV)) {
       pct = welsh_env_cutoff_pct(p, s.fil.value);
@@ -1200,7 +1203,28 @@ GROOVE_HD void welsh_frame(const WelshParams& p, WelshState& s, const RenderCons
   float sum, a, pct, lfo;
   bool retune;
   // (tab: the caller has put this frame's coefficients into sc.coef / sc.coef_f already — kernels.h "coefficient look-ahead")
-  if (!welsh_frame_front<FIRST, RETUNE, LFO_MODE, C1, C2, CL, SEGMENT, REST, HOIST, AMPTAB, TABS>(p, s, sc, sum, a, pct, retune, lfo, tab, ltab, tab_mod, tab_lfo, tab_amp)) { L = 0.0f; R = 0.0f; return; }
+  constexpr bool LATE = HOIST && RETUNE && LFO_MODE != LFO_F64 && !AMPTAB; // filter envelope -> percent -> coefficients in one block, below
+  if (!welsh_frame_front<FIRST, RETUNE, LFO_MODE, C1, C2, CL, SEGMENT, REST, HOIST, AMPTAB, TABS, LATE>(p, s, sc, sum, a, pct, retune, lfo, tab, ltab, tab_mod, tab_lfo, tab_amp)) { L = 0.0f; R = 0.0f; return; }
+  if constexpr (LATE) {
+    if (welsh_tab_is_off<TABS, 1>(tab)) {
+      // welsh_frame_front's statements, in its order: the filter envelope's value of the frame, then the percent from it — or from the LFO
+      s.fil.value = env_shape(sc.tf, s.fil.A, sc.fc1, sc.fc2); sc.tf += 1.0f;
+      if (CL == LFO_UNUSED || (p.flags & WF_RETUNE_ENV)) { pct = welsh_env_cutoff_pct(p, s.fil.value); retune = true; }
+      else if (LFO_MODE == LFO_F32 && (p.flags & WF_LFO_CUTOFF)) { pct = welsh_lfo_cutoff_pct(p, lfo); retune = true; }
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" : "+v"(pct)); // keeps `tab` a scalar BRANCH: if-converted, a table frame still evaluated all this and selected it away
+#endif
+      if constexpr (F32FILT) { if (retune && pct != sc.prev_pct) { sc.coef_f = lp24_coeff_from_pct(p.fc, pct, rc); sc.prev_pct = pct; } }
+      else welsh_frame_coef<RETUNE, LFO_MODE, CL>(p, rc, sc, pct, retune, lfo);
+    }
+    if constexpr (F32FILT) {
+      const float m = lp24_step_f32<false>(sc.filt_f, sc.coef_f, sum) * a;
+      L = m * p.gl; R = m * p.gr;
+    } else {
+      welsh_frame_back<false>(p, s.filt, sc.coef, sum, a, L, R);
+    }
+    return;
+  }
   if constexpr (F32FILT) { // sc.coef_f / sc.filt_f were set by welsh_scratch_f32_begin; the caller hands the state back with welsh_scratch_f32_end
     if (RETUNE && welsh_tab_is_off<TABS, 1>(tab)) {
 #if defined(__HIP_DEVICE_COMPILE__)
