@@ -1027,7 +1027,7 @@ def config_entry(ctx, workload, repeats, parity_voices=64):
             "algorithmic_bytes_per_voice_frame": roof["algorithmic_bytes_per_voice_frame"],
             "traffic": roof.get("traffic"), "traffic_source": roof.get("traffic_source"), "valu": roof.get("valu"),
             "parity_vs_oracle": par,
-            "library_counters_after": {k: v for k, v in ctx.debug_info().items() if k in ("host_waits", "host_waits_blocked", "host_wait_ms", "zero_segments")}}
+            "library_counters_after": {k: v for k, v in ctx.debug_info().items() if k in ("host_waits", "host_waits_blocked", "host_wait_ms", "zero_segments", "fast_table_misses")}}
 
 
 def form_entry(ctx, label, K, W, fused, grouped, note):
@@ -1291,6 +1291,8 @@ def measure(args, world, rank, local_rank):
         line["library"] = library_identity(line["streams"])
         if line["zero_segments"]:
             line["tainted"] = "the Welsh kernels counted zero-frame segments (csrc/diag.h; DESIGN.md section 7): this must not happen"
+        if line["streams"].get("fast_table_misses"):
+            line["tainted"] = "waves in a FAST body found a look-ahead table down (csrc/diag.h fast_table_misses): this must not happen"
     if dist is not None and not args.no_sections and not args.materialise and not args.interleaved:
         # ONE run of the driver's command carries all three N-GPU measurements (section_plan): the line's own measurement is one of
         # them, the other scaling mode of the same workload and config #5 follow with the same ranks and the same communicator

@@ -5,7 +5,8 @@
 //                       frames-to-next-boundary over a wave's ACTIVE lanes came back 0 (kernels.h run_frames_segmented,
 //                       welsh_split.h).  welsh_segment_begin promises >= 1 for any consistent envelope record, so the
 //                       count must stay 0 for the life of a context: groove_debug_info reports it, the GPU tests and
-//                       bench.py assert it.  Cost: one scalar compare + branch per segment.
+//                       bench.py assert it.  Cost: one scalar compare + branch per segment.  `fast_table_misses`: the same kind of
+//                       assertion for the FAST copies of the block bodies (kernels.h): must stay 0, reported and asserted alike.
 //
 // Diagnostic builds (make EXTRA=-D...; never shipped, never set by bench.py or the tests' product library):
 //   GROOVE_DIAG_SHADOW_IN_MIN   round 3's behaviour: the shadow lanes of padding waves take part in the wave minimum.
@@ -16,6 +17,7 @@
 //   GROOVE_TP_PROBE, GROOVE_SPLIT_PROBE   cycle probes of the time-parallel and role-split kernels (welsh_tp.h,
 //                               welsh_split.h; tools/tp_probe.py, tools/split_probe.py).
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 namespace groove {
@@ -30,6 +32,8 @@ struct DiagCounters {
   uint32_t shadow_zero_lanes; // GROOVE_DIAG_SHADOW_IN_MIN: lanes whose own frames-to-boundary was 0
   uint32_t shadow_zero_waves; // GROOVE_DIAG_SHADOW_IN_MIN: wave minima that came back 0 because of them
   uint32_t records;           // DiagRecord slots claimed (the first kDiagRecords are kept)
+  uint32_t fast_table_misses; // product: a wave that took the FAST copy of its body (kernels.h welsh_wave_tables_up) found a look-ahead table down at a segment start (must stay 0)
+  uint32_t fast_waves;        // waves that took the FAST copy of their body, counted only while bit 2 of the look-ahead word is set (groove_set_look_ahead(7): the tests ask whether the path they mean to test ran)
   DiagRecord rec[kDiagRecords];
 };
 
@@ -37,6 +41,13 @@ struct DiagCounters {
 // The guard's counter: called by ONE lane of a wave whose minimum was 0.
 __device__ __forceinline__ void diag_count_zero_segment(uint32_t* diag) {
   if (diag) atomicAdd(diag + 0, 1u);
+}
+__device__ __forceinline__ void diag_count_fast_wave(uint32_t* diag) {
+  if (diag) atomicAdd(diag + offsetof(DiagCounters, fast_waves) / 4, 1u);
+}
+// ... and the FAST bodies' assertion: called by one lane of a wave whose tables were promised for the block and are not up.
+__device__ __forceinline__ void diag_count_fast_table_miss(uint32_t* diag) {
+  if (diag) atomicAdd(diag + offsetof(DiagCounters, fast_table_misses) / 4, 1u);
 }
 #endif
 

@@ -1225,7 +1225,7 @@ static int init_impl(int device_ordinal, const uint8_t* comm_id, int rank, int w
   if (const char* e = std::getenv("GROOVE_FX_SEQ_ALLPASS")) ctx->seq_allpass = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_SAFE_STREAMS")) ctx->safe_streams = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_MIX_KERNEL")) ctx->mix_kernel = e[0] != '0';
-  if (const char* e = std::getenv("GROOVE_LOOK_AHEAD")) ctx->look_ahead = (uint32_t)std::strtoul(e, nullptr, 10) & 3u;
+  if (const char* e = std::getenv("GROOVE_LOOK_AHEAD")) ctx->look_ahead = (uint32_t)std::strtoul(e, nullptr, 10) & 7u;
   if (const char* e = std::getenv("GROOVE_SYNC_TIMEOUT_MS")) ctx->sync_timeout_ms = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_FM_TP_VPW4_MIN_VOICES")) ctx->fm_tp_vpw4_min_voices = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_BIND_EVENTS")) ctx->bind_events = std::atoi(e) != 0;
@@ -1332,7 +1332,7 @@ int groove_debug_info(groove_ctx* ctx, char* out, size_t cap) {
   DiagCounters dc{};
   GHIP(ctx, ctx_memcpy(ctx, &dc, ctx->d_diag, sizeof(dc), hipMemcpyDeviceToHost));
   std::string diag = "\"host_waits\": " + std::to_string(ctx->host_waits) + ", \"host_waits_blocked\": " + std::to_string(ctx->host_waits_blocked) + ", \"host_wait_ms\": " + std::to_string((double)ctx->host_wait_ns * 1e-6) +
-                     ", \"zero_segments\": " + std::to_string(dc.zero_segments) + ", \"source_hash\": \"" GROOVE_SOURCE_HASH "\", \"mix_kernel\": " + (ctx->mix_kernel ? "true" : "false");
+                     ", \"zero_segments\": " + std::to_string(dc.zero_segments) + ", \"fast_table_misses\": " + std::to_string(dc.fast_table_misses) + ", \"fast_waves\": " + std::to_string(dc.fast_waves) + ", \"source_hash\": \"" GROOVE_SOURCE_HASH "\", \"mix_kernel\": " + (ctx->mix_kernel ? "true" : "false");
 #ifdef GROOVE_DIAG_SHADOW_IN_MIN
   diag += ", \"diag_build\": \"GROOVE_DIAG_SHADOW_IN_MIN\", \"shadow_zero_lanes\": " + std::to_string(dc.shadow_zero_lanes) + ", \"shadow_zero_waves\": " + std::to_string(dc.shadow_zero_waves) + ", \"records\": [";
   for (uint32_t i = 0; i < std::min(dc.records, kDiagRecords); ++i) {
@@ -1370,7 +1370,7 @@ int groove_set_time_parallel_pair_min_voices(groove_ctx* ctx, uint32_t min_voice
 uint32_t groove_time_parallel_pair_min_voices(groove_ctx* ctx) { return ctx ? ctx->tp_vpw2_min_voices : 0; }
 int groove_set_look_ahead(groove_ctx* ctx, uint32_t bits) {
   if (!ctx) return fail(nullptr, "groove_set_look_ahead: ctx is NULL");
-  ctx->look_ahead = bits & 3u;
+  ctx->look_ahead = bits & 7u;
   return 0;
 }
 uint32_t groove_look_ahead(groove_ctx* ctx) { return ctx ? ctx->look_ahead : 0; }

@@ -286,7 +286,7 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
 // flag tests, no taken branches round the code they guard.  (Why it matters: the instruction cache.  SQC_ICACHE_BUSY_CYCLES / SQ_CYCLES
 // of the million-voice window was 0.85 with the flags tested in the frame — tools/diag_pmc.sh —: forty wavefronts per cache fetch a
 // stream in which every tenth instruction is a branch, half of them taken.)
-template <bool FUSED, class FirstFn, class BeginFn, class SetupFn, class PreFn, class LiveFn, class FastFn, class FastFrameFn, class EndFn, class ZeroFn>
+template <bool FUSED, bool FASTONLY = false, class FirstFn, class BeginFn, class SetupFn, class PreFn, class LiveFn, class FastFn, class FastFrameFn, class EndFn, class ZeroFn>
 __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n, uint32_t v, bool active, size_t ch_stride,
                                                      float* __restrict__ out, float* __restrict__ rows, uint32_t prow, FirstFn&& first, BeginFn&& begin,
                                                      SetupFn&& setup, PreFn&& pre, LiveFn&& live_frame, FastFn&& fast, FastFrameFn&& fast_frame, EndFn&& end, ZeroFn&& on_zero) {
@@ -338,17 +338,17 @@ __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n
     }
 #else
     // in chunks of CoefTab::kFrames frames: `pre` (the look-ahead tables' fill: long, cold code) stays out of the frame loop proper
-    const bool all_tables = fast();
+    const bool all_tables = FASTONLY ? true : fast();
     for (uint32_t k0 = 0; k0 < seg; k0 += 64u) {
       pre(k0);
       const uint32_t k1 = min(seg, k0 + 64u);
-      if (all_tables) {
+      if (FASTONLY || all_tables) {
         for (uint32_t k = k0; k < k1; ++k, ++f) {
           float L = 0.0f, R = 0.0f;
           if (live) fast_frame(k, L, R);
           put(f, L, R);
         }
-      } else {
+      } else if constexpr (!FASTONLY) {
         for (uint32_t k = k0; k < k1; ++k, ++f) {
           float L = 0.0f, R = 0.0f;
           if (live) live_frame(k, L, R);
@@ -521,7 +521,7 @@ __device__ __forceinline__ void wave_tab_fill(const WelshParams& p, const Render
   __builtin_amdgcn_wave_barrier();
 }
 
-template <bool FUSED, bool RETUNE, int LFO_MODE = LFO_F64, bool UNIFORM = false, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool REST = false, bool F32OK = false>
+template <bool FUSED, bool RETUNE, int LFO_MODE = LFO_F64, bool UNIFORM = false, int C1 = OSC_ANY, int C2 = OSC_ANY, int CL = OSC_ANY, bool REST = false, bool F32OK = false, bool FASTONLY = false>
 __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s, const RenderConsts& rc,
                                             uint32_t frames, uint32_t n, uint32_t v, bool active,
                                             size_t ch_stride, float* __restrict__ out, float* __restrict__ rows, uint32_t prow, const DiagWhere& dw = DiagWhere{nullptr, 0, 0, 0}) {
@@ -540,13 +540,16 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
     constexpr bool LFO_LA = LFO_MODE != LFO_F64 && CL != LFO_UNUSED && GROOVE_LFO_LOOKAHEAD;
     typedef TabLayout<true, COEF_LA, LFO_LA, LFO_MODE == LFO_F64_SMOOTH> Lay;
     WaveUniform fu{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u, 0u, 0u}; // this segment's look-aheads (fu.tab, fu.ltab are wave-uniform)
-    run_frames_segmented<FUSED>(
+    run_frames_segmented<FUSED, FASTONLY && (COEF_LA || LFO_LA)>(
         frames, n, v, active, ch_stride, out, rows, prow,
         [&](float& L, float& R) { welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL, false, REST, false, true>(p, s, rc, sc, L, R); },
         [&](bool& live) { const uint32_t k = welsh_segment_begin(p, s, live); welsh_segment_start_hoisted(s, sc); return k; },
         [&](bool live, uint32_t seg) {
           fu.tab = 0u; fu.ltab = 0u;
-          if constexpr (COEF_LA || LFO_LA) { if (seg >= CoefTab::kMinSegment) fu = wave_uniform<COEF_LA, LFO_LA, LFO_MODE, CL, Lay::kAmp>(p, s, sc, live, rc.look); }
+          if constexpr (COEF_LA || LFO_LA) { if (FASTONLY || seg >= CoefTab::kMinSegment) fu = wave_uniform<COEF_LA, LFO_LA, LFO_MODE, CL, Lay::kAmp>(p, s, sc, live, rc.look); }
+          if constexpr (FASTONLY && (COEF_LA || LFO_LA)) { // the promise this copy was chosen on (welsh_wave_tables_up): counted if it does not hold
+            if (!((!COEF_LA || fu.tab != 0u) && (!LFO_LA || fu.ltab != 0u)) && __ballot(live) != 0 && (threadIdx.x & 63u) == 0) diag_count_fast_table_miss(dw.diag);
+          }
         },
         [&](uint32_t k) { if constexpr (COEF_LA || LFO_LA) { if ((fu.tab | fu.ltab) != 0u && (k & (CoefTab::kFrames - 1)) == 0) wave_tab_fill<true, COEF_LA, LFO_LA, LFO_MODE, CL>(p, rc, fu, k); } },
         [&](uint32_t k, float& L, float& R) {
@@ -602,13 +605,16 @@ __device__ __forceinline__ void welsh_block(const WelshParams& p, WelshState& s,
     constexpr bool LFO_LA = LFO_MODE != LFO_F64 && CL != LFO_UNUSED && GROOVE_LFO_LOOKAHEAD;
     typedef TabLayout<false, COEF_LA, LFO_LA, LFO_MODE == LFO_F64_SMOOTH> Lay;
     WaveUniform fu{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u, 0u, 0u};
-    run_frames_segmented<FUSED>(
+    run_frames_segmented<FUSED, FASTONLY && (COEF_LA || LFO_LA)>(
         frames, n, v, active, ch_stride, out, rows, prow,
         [&](float& L, float& R) { welsh_frame<true, RETUNE, LFO_MODE, C1, C2, CL, false, REST>(p, s, rc, sc, L, R); },
         [&](bool& live) { const uint32_t k = welsh_segment_begin(p, s, live); welsh_segment_start_hoisted(s, sc); return k; },
         [&](bool live, uint32_t seg) {
           fu.tab = 0u; fu.ltab = 0u;
-          if constexpr (COEF_LA || LFO_LA) { if (seg >= CoefTab::kMinSegment) fu = wave_uniform<COEF_LA, LFO_LA, LFO_MODE, CL, Lay::kAmp>(p, s, sc, live, rc.look); }
+          if constexpr (COEF_LA || LFO_LA) { if (FASTONLY || seg >= CoefTab::kMinSegment) fu = wave_uniform<COEF_LA, LFO_LA, LFO_MODE, CL, Lay::kAmp>(p, s, sc, live, rc.look); }
+          if constexpr (FASTONLY && (COEF_LA || LFO_LA)) { // the promise this copy was chosen on (welsh_wave_tables_up): counted if it does not hold
+            if (!((!COEF_LA || fu.tab != 0u) && (!LFO_LA || fu.ltab != 0u)) && __ballot(live) != 0 && (threadIdx.x & 63u) == 0) diag_count_fast_table_miss(dw.diag);
+          }
         },
         [&](uint32_t k) { if constexpr (COEF_LA || LFO_LA) { if ((fu.tab | fu.ltab) != 0u && (k & (CoefTab::kFrames - 1)) == 0) wave_tab_fill<false, COEF_LA, LFO_LA, LFO_MODE, CL>(p, rc, fu, k); } },
         [&](uint32_t k, float& L, float& R) {
@@ -741,7 +747,7 @@ __device__ __forceinline__ UniformArgsPtr uniform_args_scalar(UniformArgsPtr a) 
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bits >> 32));
   return (UniformArgsPtr)(((uint64_t)hi << 32) | lo);
 }
-template <bool FUSED, int LFO_MODE, bool RETUNE, int C1, int C2, int CL, bool REST = false, bool F32OK = false>
+template <bool FUSED, int LFO_MODE, bool RETUNE, int C1, int C2, int CL, bool REST = false, bool F32OK = false, bool FAST = false>
 __device__ __forceinline__ void welsh_uniform_body_impl(UniformArgsPtr a) {
   const uint32_t wg = a->wg_list[GROOVE_WG_SLOT(a->n_wgs)]; // scalar load: the workgroup of virtual waves this block renders
   const uint32_t n_waves = a->n_waves, n = a->n;
@@ -756,7 +762,7 @@ __device__ __forceinline__ void welsh_uniform_body_impl(UniformArgsPtr a) {
   // pinned in VGPRs for the block: as literals / SGPRs each costs a v_mov on every retuning frame (the instructions
   // that use them take one constant-bus operand): +2.5 % in the all-voices window of the million-voice project
   if constexpr (RETUNE) asm volatile("" : "+v"(rc.tan_k1), "+v"(rc.tan_k2), "+v"(rc.log2_x0), "+v"(rc.x_hi));
-  welsh_block<FUSED, RETUNE, LFO_MODE, true, C1, C2, CL, REST, F32OK>(d.p, s, rc, a->frames, n, v, active, a->ch_stride, a->out, a->rows, wg, DiagWhere{a->diag, wg, w, d.count});
+  welsh_block<FUSED, RETUNE, LFO_MODE, true, C1, C2, CL, REST, F32OK, FAST>(d.p, s, rc, a->frames, n, v, active, a->ch_stride, a->out, a->rows, wg, DiagWhere{a->diag, wg, w, d.count});
   if (active) soa_store(a->state, n, v, s);
 }
 // Internal linkage + no `tail` marker on the kernels' calls: the compiler's inter-procedural register allocation then
@@ -767,10 +773,39 @@ __device__ __forceinline__ void welsh_uniform_body_impl(UniformArgsPtr a) {
 // million-voice block of HBM traffic that served nothing (round 2's PMC passes).
 #define GROOVE_NO_TAIL_CALLS __attribute__((disable_tail_calls))
 #define GROOVE_BODY_LINKAGE static
-template <bool FUSED, int LFO_MODE, bool RETUNE, int C1, int C2, int CL, bool F32OK = false>
+template <bool FUSED, int LFO_MODE, bool RETUNE, int C1, int C2, int CL, bool F32OK = false, bool FAST = false>
 GROOVE_BODY_LINKAGE __device__ __attribute__((noinline)) void welsh_uniform_body(UniformArgsPtr a) {
   // the class bodies only ever see waves of their own classes (dsp_core.h, REST)
-  welsh_uniform_body_impl<FUSED, LFO_MODE, RETUNE, C1, C2, CL, true, F32OK>(uniform_args_scalar(a));
+  welsh_uniform_body_impl<FUSED, LFO_MODE, RETUNE, C1, C2, CL, true, F32OK, FAST>(uniform_args_scalar(a));
+}
+// Will this wave's look-ahead tables be up for the whole block?  Note events land between blocks, so lanes whose filter envelope record,
+// LFO phase and first-tick flag agree bit for bit when a block starts evolve identically through it: every segment of the block will find
+// them in agreement (wave_uniform), whatever its length.  Such a wave takes the FAST copy of its body: the table frames' loop alone in
+// the function, no per-lane path beside it.  (Lanes that are idle when the block starts stay idle; a lane that goes idle on the way
+// drops out of the comparison.)
+__device__ __forceinline__ bool welsh_wave_tables_up(const UniformArgs& a) {
+  const uint32_t wg = a.wg_list[GROOVE_WG_SLOT(a.n_wgs)];
+  const uint32_t w0 = wg * kWaves + (threadIdx.x >> 6);
+  const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(w0, a.n_waves - 1));
+  const uint32_t vbase = a.waves[w].vbase, count = a.waves[w].count, flags = a.waves[w].p.flags;
+  if ((a.rc.look & 3u) != 3u) return false;
+  if (((flags >> WF_LFO_WAVE_SHIFT) & 15u) == (uint32_t)GROOVE_WAVE_NOISE) return false;
+  const bool active = (w0 < a.n_waves) && ((threadIdx.x & 63u) < count);
+  const uint32_t v = active ? vbase + (threadIdx.x & 63u) : vbase;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.state, 0, (int)(sizeof(WelshState) / 4 * a.n * 4u), 0x00020000);
+  auto word = [&](uint32_t k) { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(v * 4u), (int)(k * a.n * 4u), 0); };
+  constexpr uint32_t kAmp = offsetof(WelshState, amp) / 4, kFil = offsetof(WelshState, fil) / 4, kLfo = offsetof(WelshState, lfo) / 4, kFlags = offsetof(WelshState, vflags) / 4;
+  const bool live = active && word(kAmp + offsetof(EnvState, state) / 4) != ENV_IDLE;
+  const uint64_t mask = __ballot(live);
+  if (mask == 0) return true; // (nothing sounds: no frame runs)
+  const int l0 = __builtin_ctzll(mask);
+  bool same = true;
+#pragma unroll
+  for (uint32_t k = 0; k < sizeof(EnvState) / 4 + 3; ++k) {
+    const uint32_t x = word(k < sizeof(EnvState) / 4 ? kFil + k : k == sizeof(EnvState) / 4 ? kLfo : k == sizeof(EnvState) / 4 + 1 ? kLfo + 1 : kFlags);
+    same = same && x == (uint32_t)__builtin_amdgcn_readlane((int)x, l0);
+  }
+  return __ballot(live && !same) == 0;
 }
 // A workgroup whose voices are all silent with both envelopes idle (unused polyphony, voices past
 // their release) contributes zeros and changes nothing but idle-plateau counters: it writes its zero
@@ -800,9 +835,10 @@ __device__ __forceinline__ bool welsh_idle_workgroup(const UniformArgs& a) {
   return true;
 }
 // One scalar switch on the workgroup's class combination, to the block body compiled for it.
-template <bool FUSED, int LFO_MODE, bool RETUNE, bool F32OK = false>
+template <bool FUSED, int LFO_MODE, bool RETUNE, bool F32OK = false, bool FAST = false>
 __device__ __forceinline__ void welsh_dispatch_class(uint32_t cls, UniformArgsPtr ka) {
-#define GROOVE_CLS_CASE(CL, C1, C2) case wg_class_combo(CL, C1, C2): welsh_uniform_body<FUSED, LFO_MODE, RETUNE, C1, C2, CL, F32OK>(ka); break;
+  // (a FAST copy exists where the kind has a table at all: not for the static F32 kind's LFO-less bodies)
+#define GROOVE_CLS_CASE(CL, C1, C2) case wg_class_combo(CL, C1, C2): welsh_uniform_body<FUSED, LFO_MODE, RETUNE, C1, C2, CL, F32OK, (FAST && (RETUNE || CL != LFO_UNUSED))>(ka); break;
 #define GROOVE_CLS_ROW(CL, C1) GROOVE_CLS_CASE(CL, C1, 0) GROOVE_CLS_CASE(CL, C1, 1) GROOVE_CLS_CASE(CL, C1, 2) GROOVE_CLS_CASE(CL, C1, 3) GROOVE_CLS_CASE(CL, C1, 4)
 #define GROOVE_CLS_PLANE(CL) GROOVE_CLS_ROW(CL, 0) GROOVE_CLS_ROW(CL, 1) GROOVE_CLS_ROW(CL, 2) GROOVE_CLS_ROW(CL, 3) GROOVE_CLS_ROW(CL, 4)
   switch (cls) {
@@ -883,6 +919,15 @@ __global__ __launch_bounds__(kThreads, GROOVE_WAVES_ANY) GROOVE_NO_TAIL_CALLS vo
 // benchmark table (profiles/r05_welsh-1m-window_summary.json), 462 / 546 / 266 for the library-proportioned one — and the slowest stream is
 // the step; thirds of everything are balanced whatever the patches are, and every stream has one launch per block (a launch cannot
 // take less than one wavefront's walk of the block, ~180 us: two launches on a stream are two such floors).
+// FAST copies (end of round 6).  Every body with a look-ahead table exists twice in this kernel: the copy above, whose segments ask at
+// their start whether the tables are up and run the per-lane frame when they are not, and a FAST copy that holds the table frames' loop
+// and nothing else (welsh_block's FASTONLY) — chosen per WAVE when the block starts, by welsh_wave_tables_up: note events land between
+// blocks, so a wave whose live voices agree on the filter envelope's record, the LFO's phase and the first-tick flag when a block starts
+// will find them in agreement at every segment of the block.  With one hot loop per function the compiler keeps it in registers in every
+// body (the same loop beside the per-lane loop cost 2 - 20 scratch accesses a frame in the f64-filter and smooth-f64 bodies:
+// GROOVE_FAST_TABLE_LOOP): 57 - 110 instructions a frame where the shared loop's table path ran 130 - 170.  In one job, headline
+// 0.3301 - 0.3331 -> 0.3118 - 0.3172 ms per block, the library-proportioned bank 0.3376 -> 0.3293, the whole timeline 0.2751 -> 0.2628.  The
+// promise is a counted assertion (diag.h fast_table_misses, required to be 0 like zero_segments).
 #ifndef GROOVE_WAVES_MIX
 #define GROOVE_WAVES_MIX 5
 #endif
@@ -895,9 +940,15 @@ __global__ __launch_bounds__(kThreads, GROOVE_WAVES_MIX) GROOVE_NO_TAIL_CALLS vo
   const uint32_t cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[GROOVE_WG_SLOT(a.n_wgs)]);
   bool f32 = false;
   if constexpr (FUSED) f32 = __builtin_amdgcn_readfirstlane((int)a.wg_f32[GROOVE_WG_SLOT(a.n_wgs)]) != 0;
+  bool fastw = false;
+  if constexpr (FUSED) {
+    fastw = __builtin_amdgcn_readfirstlane((int)welsh_wave_tables_up(a)) != 0;
+    if (fastw && (a.rc.look & 4u) && (threadIdx.x & 63u) == 0) diag_count_fast_wave(a.diag); // (tests only: groove_set_look_ahead(7))
+  }
 #define GROOVE_MIX_CASE(MODE, RETUNE)                                                          \
   if constexpr (FUSED) {                                                                       \
-    if (f32) welsh_dispatch_class<FUSED, MODE, RETUNE, true>(cls, ka);                         \
+    if (fastw) { if (f32) welsh_dispatch_class<FUSED, MODE, RETUNE, true, true>(cls, ka); else welsh_dispatch_class<FUSED, MODE, RETUNE, false, true>(cls, ka); } \
+    else if (f32) welsh_dispatch_class<FUSED, MODE, RETUNE, true>(cls, ka);                         \
     else welsh_dispatch_class<FUSED, MODE, RETUNE, false>(cls, ka);                            \
   } else {                                                                                     \
     welsh_dispatch_class<FUSED, MODE, RETUNE, false>(cls, ka);                                 \

@@ -102,7 +102,8 @@ uint32_t groove_pipeline_min_waves(groove_ctx* ctx);
  * envelope's stage computes 64 frames' filter coefficients in one pass, lane = frame (bit-identical to the per-lane retune); bit 1 —
  * a wave whose live voices share the LFO's phase evaluates what the LFO does to the oscillators (pitch / pulse-width routing) the same
  * way, exactly, where each lane would advance recurrences (within 1e-6 of them).  Default 3; GROOVE_LOOK_AHEAD in the environment
- * sets it at groove_init.  Tests render the same bank with and without. */
+ * sets it at groove_init.  Tests render the same bank with and without.  Bit 2 (tests): count the waves that take the FAST copy of
+ * their block body (groove_debug_info: fast_waves). */
 int groove_set_look_ahead(groove_ctx* ctx, uint32_t bits);
 uint32_t groove_look_ahead(groove_ctx* ctx);
 /* Tuning, for a render-ahead walk of blocks through an effect chain that ENDS in a reverb (config #3): on = the reverb's two

@@ -27,9 +27,12 @@ def gpu_ctx():
     # the segment guard of the Welsh kernels is a COUNTED assertion (csrc/diag.h): no kernel of the whole session may have
     # seen a wave whose active lanes reported zero frames to their next envelope boundary
     ctx.synchronize()
-    zeros = ctx.debug_info()["zero_segments"]
+    info = ctx.debug_info()
+    zeros, misses = info["zero_segments"], info["fast_table_misses"]
     ctx.close()
     assert zeros == 0, f"{zeros} zero-frame segments counted during the GPU session (DESIGN.md section 7)"
+    # ... and so is the promise the FAST copies of the block bodies are chosen on (kernels.h welsh_wave_tables_up)
+    assert misses == 0, f"{misses} waves in a FAST body found a look-ahead table down during the GPU session"
 
 
 @pytest.fixture()

@@ -231,3 +231,72 @@ def test_coefficient_look_ahead_is_the_per_lane_retune_bit_for_bit(gpu_ctx, orac
                 assert np.array_equal(a.view(np.uint32), b_.view(np.uint32)), f"patch {j}: the even voices differ between the table and the per-lane retune"
     finally:
         gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves, gpu_ctx.pipeline_min_waves, gpu_ctx.look_ahead = old
+
+
+def test_fast_bodies_are_the_shared_bodies_sample_for_sample(gpu_ctx, oracle):
+    """kernels.h "FAST copies": in the fused mix kernel a wave whose live voices agree, when a block starts, on the filter envelope's
+    record, the LFO's phase and the first-tick flag takes a copy of its body that holds the table frames' loop and nothing else.  Each of
+    the 32 benchmark patches on 192 voices (three waves: one full, one of 61 voices struck a block later — uniform from then on —, one of 3),
+    fused onto a bus three ways: look-ahead word 7 (FAST copies, counted), 1 (no LFO table: no wave is promised its tables, every wave
+    takes the shared body) and 0.  The F32 kinds' buses must agree to the BIT (their tables hold the lanes' own arithmetic), the
+    smooth-f64 kinds' to 2e-6 of full scale per voice (exact LFO evaluation against the recurrences); every bus matches the oracle; the
+    FAST copies ran (fast_waves) and kept their promise (fast_table_misses)."""
+    from groove_amd import entities as E
+    old = gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves, gpu_ctx.pipeline_min_waves, gpu_ctx.look_ahead
+    gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves, gpu_ctx.pipeline_min_waves = 0, 0, 1
+    try:
+        n, frames, blocks = 192, 256, 10
+        lanes = np.arange(n, dtype=np.uint32)
+        keys = (40 + (lanes * 7) % 41).astype(np.uint8)
+        keys[keys % 12 == 9] += 1
+        a_set = np.r_[0:64, 128:131].astype(np.uint32)          # wave 0 (64 voices) and wave 2 (3 voices): struck in block 0
+        b_set = np.arange(64, 125, dtype=np.uint32)             # wave 1: 61 voices, struck in block 2
+        fast0 = gpu_ctx.debug_info()["fast_waves"]
+        for j in range(P.N_PATCHES):
+            patch = P.welsh_patch(j)
+            params = (T.WelshParams * n)(*[patch] * n)
+            ob = oracle.Bank.welsh(params)
+            want = []
+            buses = {}
+            for look in (7, 1, 0):
+                gpu_ctx.look_ahead = look
+                synth = E.WelshSynth(gpu_ctx, params)
+                assert "mix_kernel" in synth.kernel_form(frames, True), synth.kernel_form(frames, True)
+                bus = gpu_ctx.bus(blocks * frames)
+                for b in range(blocks):
+                    evs = []
+                    if b == 0:
+                        evs.append(T.note_events_np(a_set, keys[a_set], True))
+                    if b == 2:
+                        evs.append(T.note_events_np(b_set, keys[b_set], True))
+                    if b == 7:
+                        evs.append(T.note_events_np(a_set, keys[a_set], False))
+                    for ev in evs:
+                        synth.handle_midi_events(ev)
+                        if look == 7:
+                            ob.note_events(ev)
+                    synth.render_mix(bus, frames, at_frame=b * frames)
+                    if look == 7:
+                        want.append(ob.render_bus(frames))
+                buses[look] = bus.download().astype(np.float64)
+                synth.destroy(); bus.destroy()
+            want = np.concatenate(want, axis=0)
+            for look, got in buses.items():
+                # (a bank of ONE patch: its voices' errors are the same error at other pitches and do not average out on the bus as a mixed
+                # bank's do — the per-voice bar, 1e-5, is the one that applies; measured: 1.4e-6 at worst, patch 0)
+                assert np.sqrt(np.mean(((got - want) / n) ** 2)) <= 5e-6, (j, look)
+            smooth = bool(patch_is_smooth(patch))
+            if smooth:
+                assert np.abs(buses[7] - buses[1]).max() <= 2e-6 * n, (j, float(np.abs(buses[7] - buses[1]).max()))
+            else:
+                assert np.array_equal(buses[7], buses[1]), f"patch {j}: the FAST copy's bus differs from the shared body's"
+            assert np.array_equal(buses[1], buses[0]), f"patch {j}: the coefficient look-ahead's bus differs from the per-lane retune's"
+        info = gpu_ctx.debug_info()
+        assert info["fast_waves"] - fast0 >= P.N_PATCHES * 3 * (blocks - 3) and info["fast_table_misses"] == 0, info
+    finally:
+        gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves, gpu_ctx.pipeline_min_waves, gpu_ctx.look_ahead = old
+
+
+def patch_is_smooth(patch):
+    """The patch routes its LFO to the pitch or the pulse width (the smooth-f64 or exact-f64 kinds: groove_lfo_routing 2, 3, 5, 6, 7)."""
+    return int(patch.lfo_routing) in (T.LFO_PITCH, T.LFO_PULSE_WIDTH, T.LFO_PITCH_OSC2, T.LFO_PW_OSC1, T.LFO_PW_OSC2)
