@@ -204,7 +204,7 @@ struct groove_ctx {
   // the ROLE-SPLIT kernel (welsh_split.h: three wavefronts per 64 voices, pipelined over the block's frames) for banks of up
   // to this many virtual waves; 0 = never.  groove_set_split_max_waves.
   uint32_t split_max_waves = 1024;      // 65,536 voices = one workgroup (twelve wavefronts) per CU; measured (round 3, blocks 5-24): 20,000 voices 0.120 -> 0.090 ms per block, 32,768 0.119 -> 0.090, 65,536 0.123 -> 0.095; 80,000 (a second round of workgroups) 0.135 -> 0.153: not above
-  uint32_t split2_max_waves = 2048;      // banks above split_max_waves and up to this many virtual waves (131,072 voices): the TWO-role form, front + tangent | back — two workgroups of eight wavefronts per CU, so one round still; measured (blocks 5-24): 100,000 voices 0.1385 -> 0.134 ms per block, 125,000 0.145 -> 0.137 (three roles there: 0.164 / 0.165; two roles at 65,536: 0.106 against three roles' 0.095)
+  uint32_t split2_max_waves = 1024;      // (= split_max_waves: off by default since the end of round 6 — with the FAST copies of its bodies the all-kinds kernel walks a block of 80,000 - 125,000 voices in 0.091 - 0.095 ms where this form takes 0.119 - 0.125, in one job, tools/ab_env.sh; GROOVE_SPLIT2_MAX_WAVES=2048 brings it back.)  Banks above split_max_waves and up to this many virtual waves (131,072 voices until then): the TWO-role form, front + tangent | back — two workgroups of eight wavefronts per CU, so one round still; measured (blocks 5-24): 100,000 voices 0.1385 -> 0.134 ms per block, 125,000 0.145 -> 0.137 (three roles there: 0.164 / 0.165; two roles at 65,536: 0.106 against three roles' 0.095)
   int split_roles = 4;                   // roles of the form used up to split_max_waves: four (ctl | osc | tangent + quotients | back), measured against three
                                          // (front | tangent | back) in one job: 32,768 voices 0.0830 against 0.0888 ms per block, 65,536 0.0846-0.0855 against
                                          // 0.0903, config #5 0.1003-0.1008 against 0.0999-0.1001.  GROOVE_SPLIT_ROLES=3 / 2: A/B
@@ -1231,6 +1231,8 @@ static int init_impl(int device_ordinal, const uint8_t* comm_id, int rank, int w
   if (const char* e = std::getenv("GROOVE_BIND_EVENTS")) ctx->bind_events = std::atoi(e) != 0;
   if (const char* e = std::getenv("GROOVE_FX_CHUNKED_ALLPASS")) ctx->chunked_allpass = e[0] == '1';
   if (const char* e = std::getenv("GROOVE_TP_MAX_VOICES")) ctx->tp_max_voices = (uint32_t)std::strtoul(e, nullptr, 10);
+  if (const char* e = std::getenv("GROOVE_SPLIT_MAX_WAVES")) ctx->split_max_waves = (uint32_t)std::strtoul(e, nullptr, 10);   // (A/B runs: tools/ab_env.sh)
+  if (const char* e = std::getenv("GROOVE_SPLIT2_MAX_WAVES")) ctx->split2_max_waves = (uint32_t)std::strtoul(e, nullptr, 10);
   if (const char* e = std::getenv("GROOVE_SPLIT_ROLES")) { const int r = std::atoi(e); ctx->split_roles = r == 2 || r == 4 ? r : 3; }
   if (const char* e = std::getenv("GROOVE_F32_FILTER")) ctx->f32_filter = e[0] != '0'; // (A/B and the bit-identity tests between kernel forms)
   if (const char* e = std::getenv("GROOVE_PIPELINE_MIN_WAVES")) ctx->pipeline_min_waves = (uint32_t)std::strtoul(e, nullptr, 10); // tests force the pipeline on small banks

@@ -902,13 +902,28 @@ __global__ __launch_bounds__(kThreads, GROOVE_WAVES_ANY) GROOVE_NO_TAIL_CALLS vo
   if constexpr (FUSED) { tp_reduce_prev(a.prev, threadIdx.x, blockIdx.x, gridDim.x); if (welsh_idle_workgroup(a)) return; }
   const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wg_base[GROOVE_WG_SLOT(a.n_wgs)]);
   const uint32_t cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wg_cls[GROOVE_WG_SLOT(a.n_wgs)]);
+  // (FUSED: the FAST copies of the bodies, as in the mix kernel below — here, where a bank does not fill the chip and a block is one
+  // wavefront's walk of its frames, a shorter frame is a shorter block)
+  bool fastw = false;
+  if constexpr (FUSED) {
+    fastw = __builtin_amdgcn_readfirstlane((int)welsh_wave_tables_up(a)) != 0;
+    if (fastw && (a.rc.look & 4u) && (threadIdx.x & 63u) == 0) diag_count_fast_wave(a.diag);
+  }
+#define GROOVE_ANY_CASE(MODE, RETUNE)                                                          \
+  if constexpr (FUSED) {                                                                       \
+    if (fastw) welsh_dispatch_class<FUSED, MODE, RETUNE, false, true>(cls, ka);                \
+    else welsh_dispatch_class<FUSED, MODE, RETUNE>(cls, ka);                                   \
+  } else {                                                                                     \
+    welsh_dispatch_class<FUSED, MODE, RETUNE>(cls, ka);                                        \
+  }
   switch (base) {
-    case wg_base_kind_of(LFO_F32, false): welsh_dispatch_class<FUSED, LFO_F32, false>(cls, ka); break;
-    case wg_base_kind_of(LFO_F32, true): welsh_dispatch_class<FUSED, LFO_F32, true>(cls, ka); break;
-    case wg_base_kind_of(LFO_F64_SMOOTH, false): welsh_dispatch_class<FUSED, LFO_F64_SMOOTH, false>(cls, ka); break;
-    default: welsh_dispatch_class<FUSED, LFO_F64_SMOOTH, true>(cls, ka); break;
+    case wg_base_kind_of(LFO_F32, false): GROOVE_ANY_CASE(LFO_F32, false) break;
+    case wg_base_kind_of(LFO_F32, true): GROOVE_ANY_CASE(LFO_F32, true) break;
+    case wg_base_kind_of(LFO_F64_SMOOTH, false): GROOVE_ANY_CASE(LFO_F64_SMOOTH, false) break;
+    default: GROOVE_ANY_CASE(LFO_F64_SMOOTH, true) break;
     // (the exact-f64 base kinds 4 and 5 are never in this launch: groove_hip.hip launch_small_uniform)
   }
+#undef GROOVE_ANY_CASE
 }
 #endif // GROOVE_WELSH_ANY_TU
 // The four class-specialised base kinds in ONE kernel at the per-kind kernels' own register budget (all four are budgeted for five
