@@ -77,9 +77,9 @@ __device__ __forceinline__ void soa_store(uint32_t* __restrict__ buf, uint32_t n
                               0.172 at 125,000); the two exact-f64 base kinds, whose bodies need 133 VGPRs, no longer run in this kernel (the
                               host gives their workgroups to the per-kind kernels) */
 #endif
-#ifndef GROOVE_WHOLE_WAVE_PATH
-#define GROOVE_WHOLE_WAVE_PATH 0 /* run_frames_segmented: a second copy of the frame for waves whose 64 lanes all sound (A/B builds) */
-#endif
+/* (A second copy of the frame loop for waves whose 64 lanes all sound — no exec-mask region round the frame, no two moves of zero in front of
+   it — was measured twice in round 6 and lost twice: in the shared bodies 0.523 against 0.350 ms per block (the doubled loops spilled), inside
+   the FAST copies 0.3240 - 0.3258 against 0.3138 - 0.3174.  Not in the source any more.) */
 #ifndef GROOVE_FAST_TABLE_LOOP
 #define GROOVE_FAST_TABLE_LOOP 1 /* segments whose look-aheads are all up run a frame loop of their own, compiled without the flag tests (run_frames_segmented `fast`):
                                     1 in the F32 kinds' fp32-filter bodies; 2 also in the smooth-f64 kinds' fp32-filter bodies with a sine / triangle LFO (no scratch access in
@@ -88,10 +88,10 @@ __device__ __forceinline__ void soa_store(uint32_t* __restrict__ buf, uint32_t n
 #endif
 #ifndef GROOVE_AMP_IN_TABLE
 #define GROOVE_AMP_IN_TABLE 0 /* 1: the retuned kinds' table entries carry the amplitude envelope's value of the frame too (TabLayout::kAmp, welsh_frame's AMPTAB: the
-                                 table flag then also asks for a shared amplitude stage).  Three vector instructions a table frame less — and nothing on the clock, twice:
+                                 table flag then also asks for a shared amplitude stage).  Three vector instructions a table frame less — and nothing on the clock, three times:
                                  with a flag and a branch of its own before the frame loop ran in chunks (0.362 - 0.373 against 0.354 - 0.357 ms per block), and riding
-                                 on the coefficient flag after (0.3464 - 0.3512 against 0.3483 - 0.3502; library 0.3469 - 0.3565 against 0.3494 - 0.3533; one job each,
-                                 tools/ab_bench.sh).  The frame is not short of issue slots at that point; left in the source, off. */
+                                 on the coefficient flag after (0.3464 - 0.3512 against 0.3483 - 0.3502; library 0.3469 - 0.3565 against 0.3494 - 0.3533), and with the FAST copies, whose promise then
+                                 covers the amplitude envelope's record too (0.3175 - 0.3339 against 0.3098 - 0.3138); one job each, tools/ab_bench.sh.  The frame is not short of issue slots at that point; left in the source, off. */
 #endif
 #ifndef GROOVE_LFO_LOOKAHEAD
 #define GROOVE_LFO_LOOKAHEAD 1 /* the smooth-f64 kinds' LFO look-ahead (below, "LFO look-ahead"); 0: every lane advances its LFO's recurrences (A/B builds) */
@@ -320,23 +320,6 @@ __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n
     if (wmin == 0) on_zero(f, mine);
     const uint32_t seg = max(1u, min(wmin, frames - f));
     setup(live, seg);
-#if GROOVE_WHOLE_WAVE_PATH
-    // A wave all of whose 64 lanes sound (nearly every wave of a big bank) needs neither the exec-mask region around the frame nor
-    // the two moves of zero in front of it: a copy of the frame for that case, chosen by a scalar test per segment.
-    const bool whole = __builtin_amdgcn_readfirstlane((int)(__ballot(live) == ~0ull)) != 0;
-    for (uint32_t k = 0; k < seg; ++k, ++f) {
-      pre(k);
-      if (whole) {
-        float L, R;
-        live_frame(k, L, R);
-        put(f, L, R);
-      } else {
-        float L = 0.0f, R = 0.0f;
-        if (live) live_frame(k, L, R);
-        put(f, L, R);
-      }
-    }
-#else
     // in chunks of CoefTab::kFrames frames: `pre` (the look-ahead tables' fill: long, cold code) stays out of the frame loop proper
     const bool all_tables = FASTONLY ? true : fast();
     for (uint32_t k0 = 0; k0 < seg; k0 += 64u) {
@@ -356,7 +339,6 @@ __device__ __forceinline__ void run_frames_segmented(uint32_t frames, uint32_t n
         }
       }
     }
-#endif
     end(seg, live);
   }
   if (frames & (C - 1)) acc.flush(rows, frames, frames & ~(C - 1), frames & (C - 1));
@@ -395,7 +377,8 @@ __device__ __forceinline__ void welsh_diag_zero(const DiagWhere& dw, const Welsh
 // envelope's stage (counter, start level, shape constants), lane j computes the coefficients of frame k + j of the segment, 64 frames
 // in one pass, into a table of the wave's own in LDS, and every frame then takes its six coefficients with broadcast reads.  Same
 // expressions on the same values as the per-lane path (welsh_frame_front / lp24_t_from_pct / lp24_coef*_from_t): the same bits.
-// Waves whose voices started apart, LFO-swept cutoffs and segments shorter than eight frames keep the per-lane path.
+// Waves whose voices started apart and segments shorter than eight frames keep the per-lane path.  (LFO-swept cutoffs did too until the
+// LFO look-ahead below.)
 //
 // LFO look-ahead (round 6, the smooth-f64 kinds: LFO on the pitch or the pulse width).  A voice's LFO runs while the voice sounds, so
 // voices struck together share its phase as well, and what it does to the oscillators' edges — 2^(l depth) or l depth — is one number

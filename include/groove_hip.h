@@ -118,11 +118,12 @@ uint32_t groove_look_ahead(groove_ctx* ctx);
 int groove_set_fx_allpass_stream(groove_ctx* ctx, int on);
 int groove_fx_allpass_stream(groove_ctx* ctx);
 /* Tuning: Welsh banks of up to this many (virtual) wavefronts that are too big for the time-parallel form render ROLE-SPLIT:
- * three wavefronts per 64 voices — front (envelopes, LFO, oscillators), cutoff tangent, filter + gains — pipelined over the
- * block's frames through LDS, so that a bank which cannot fill the chip with voices fills it with the parts of a voice's
- * frame (csrc/welsh_split.h).  Same results bit for bit as the serial kernels.  Default 1,024 (65,536 voices: one workgroup per CU;
- * banks of up to twice that take a two-role form of the same kernel, two workgroups per CU);
- * 0 = never.  No reference counterpart. */
+ * four wavefronts per 64 voices — envelopes + LFO, oscillators, cutoff tangent + coefficient quotients, filter + gains — pipelined
+ * over the block's frames through LDS, so that a bank which cannot fill the chip with voices fills it with the parts of a voice's
+ * frame (csrc/welsh_split.h).  Same results bit for bit as the serial kernels run without their LFO look-ahead (groove_set_look_ahead),
+ * within 2e-6 of them with.  Default 1,024 (65,536 voices: one workgroup per CU; a two-role form of the same kernel for banks of up
+ * to twice that is off by default since the serial kernels' FAST bodies outrun it: GROOVE_SPLIT2_MAX_WAVES=2048 in the environment
+ * brings it back); 0 = never.  No reference counterpart. */
 int groove_set_split_max_waves(groove_ctx* ctx, uint32_t waves);
 uint32_t groove_split_max_waves(groove_ctx* ctx);
 /* HIP events on the ctx stream, for measurement (bench.py): create / record / elapsed. */
