@@ -557,7 +557,7 @@ def under_profiler():
 class timed_kernel_form:
     """Make a SMALL sample project run the Welsh kernel form the full-size workload's timed region runs.  The library picks the
     form by bank size: time-parallel with one voice per wavefront (up to 3,072 voices) or two (up to
-    16,384), role-split (up to 65,536 / 131,072), all kinds in one serial launch (up to ~450,000), one launch per base kind with
+    16,384), role-split (up to 65,536), all kinds in one serial launch (up to ~243,000), one launch per base kind with
     pipelined blocks above — and a sample of a few dozen voices would always take the first.  The tuning knobs of the C ABI
     force the timed bank's form for the duration.  (A Welsh limit of ONE voice, not zero: zero would switch the FM and sampler
     banks of a mixed project to their serial kernels too.)"""

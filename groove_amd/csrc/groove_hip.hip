@@ -208,7 +208,7 @@ struct groove_ctx {
   int split_roles = 4;                   // roles of the form used up to split_max_waves: four (ctl | osc | tangent + quotients | back), measured against three
                                          // (front | tangent | back) in one job: 32,768 voices 0.0830 against 0.0888 ms per block, 65,536 0.0846-0.0855 against
                                          // 0.0903, config #5 0.1003-0.1008 against 0.0999-0.1001.  GROOVE_SPLIT_ROLES=3 / 2: A/B
-  uint32_t pipeline_min_waves = 7000;   // banks at least this long (~450,000 voices) run one kernel per base kind and pipeline their fused blocks; smaller ones take the all-kinds kernel (round 2, blocks 5-44 of the timeline: 300,000 voices 0.275 -> 0.250 ms per block, 500,000 0.357 -> 0.342; 600,000 0.372 against 0.400.  Round 5: the per-kind kernels alone carry the fp32 filter kind and the crossover moved down from ~550,000 — the driver's window, in-job, per-kind against all-kinds: 500,000 voices 0.271 against 0.281, 420,000 0.246 against 0.244, 350,000 0.223 against 0.225: profiles/r05_pipeline_threshold_ab.log)
+  uint32_t pipeline_min_waves = 3800;   // banks at least this long (~243,000 voices; 7,000 = ~450,000 until the end of round 6: with the FAST copies of the bodies in both kernels the crossover moved down — in one job, tools/ab_env.sh, mix kernel against all-kinds kernel: 200,000 voices 0.114 against 0.110 ms per block, 250,000 0.120 against 0.121 - 0.123, 300,000 0.125 against 0.158, 400,000 0.139 against 0.188, 500,000 0.164 against 0.212) run the mix kernel (one launch per base kind before round 6) and pipeline their fused blocks; smaller ones take the all-kinds kernel (round 2, blocks 5-44 of the timeline: 300,000 voices 0.275 -> 0.250 ms per block, 500,000 0.357 -> 0.342; 600,000 0.372 against 0.400.  Round 5: the per-kind kernels alone carry the fp32 filter kind and the crossover moved down from ~550,000 — the driver's window, in-job, per-kind against all-kinds: 500,000 voices 0.271 against 0.281, 420,000 0.246 against 0.244, 350,000 0.223 against 0.225: profiles/r05_pipeline_threshold_ab.log)
   // How many of the bank streams exist and are handed out.  Three: with the ctx stream and the four
   // kind streams that is eight streams; a ninth lands on a hardware queue that already carries one of the others, and a
   // project with a bank on it ran three times slower (mixed-131072: 0.12 -> 0.39 ms per block whenever a bank had the

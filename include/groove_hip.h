@@ -92,7 +92,7 @@ uint32_t groove_time_parallel_max_voices(groove_ctx* ctx);
  * No reference counterpart. */
 int groove_set_time_parallel_pair_min_voices(groove_ctx* ctx, uint32_t min_voices);
 uint32_t groove_time_parallel_pair_min_voices(groove_ctx* ctx);
-/* Tuning: Welsh banks of at least this many (virtual) wavefronts — 64 voices each; default 7,000 = ~450,000 voices — run
+/* Tuning: Welsh banks of at least this many (virtual) wavefronts — 64 voices each; default 3,800 = ~243,000 voices — run
  * one kernel per base kind and pipeline consecutive fused blocks; smaller ones take one launch for all kinds.  1 forces
  * the per-kind pipelined form for every size (tests and bench.py's parity sample use it to run the kernels of the
  * million-voice path on a small bank).  GROOVE_PIPELINE_MIN_WAVES in the environment sets it at groove_init. */
