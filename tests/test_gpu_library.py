@@ -233,8 +233,9 @@ def test_coefficient_look_ahead_is_the_per_lane_retune_bit_for_bit(gpu_ctx, orac
         gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves, gpu_ctx.pipeline_min_waves, gpu_ctx.look_ahead = old
 
 
-def test_fast_bodies_are_the_shared_bodies_sample_for_sample(gpu_ctx, oracle):
-    """kernels.h "FAST copies": in the fused mix kernel a wave whose live voices agree, when a block starts, on the filter envelope's
+@pytest.mark.parametrize("kernel", ["mix", "all-kinds"])
+def test_fast_bodies_are_the_shared_bodies_sample_for_sample(gpu_ctx, oracle, kernel):
+    """kernels.h "FAST copies": in the fused mix kernel and the fused all-kinds kernel a wave whose live voices agree, when a block starts, on the filter envelope's
     record, the LFO's phase and the first-tick flag takes a copy of its body that holds the table frames' loop and nothing else.  Each of
     the 32 benchmark patches on 192 voices (three waves: one full, one of 61 voices struck a block later — uniform from then on —, one of 3),
     fused onto a bus three ways: look-ahead word 7 (FAST copies, counted), 1 (no LFO table: no wave is promised its tables, every wave
@@ -243,7 +244,7 @@ def test_fast_bodies_are_the_shared_bodies_sample_for_sample(gpu_ctx, oracle):
     FAST copies ran (fast_waves) and kept their promise (fast_table_misses)."""
     from groove_amd import entities as E
     old = gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves, gpu_ctx.pipeline_min_waves, gpu_ctx.look_ahead
-    gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves, gpu_ctx.pipeline_min_waves = 0, 0, 1
+    gpu_ctx.time_parallel_max_voices, gpu_ctx.split_max_waves, gpu_ctx.pipeline_min_waves = 0, 0, (1 if kernel == "mix" else 1 << 20)
     try:
         n, frames, blocks = 192, 256, 10
         lanes = np.arange(n, dtype=np.uint32)
@@ -261,7 +262,7 @@ def test_fast_bodies_are_the_shared_bodies_sample_for_sample(gpu_ctx, oracle):
             for look in (7, 1, 0):
                 gpu_ctx.look_ahead = look
                 synth = E.WelshSynth(gpu_ctx, params)
-                assert "mix_kernel" in synth.kernel_form(frames, True), synth.kernel_form(frames, True)
+                assert ("mix_kernel" if kernel == "mix" else "any_kernel") in synth.kernel_form(frames, True), synth.kernel_form(frames, True)
                 bus = gpu_ctx.bus(blocks * frames)
                 for b in range(blocks):
                     evs = []
